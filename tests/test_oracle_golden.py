@@ -1,0 +1,361 @@
+"""Pin the oracle (oracle/*.py) against golden vectors produced by the reference itself
+(tools/gen_golden.py, run in the build container).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import diffusion_ref as D
+from oracle import schedule as S
+from oracle import unet_ref as U
+from oracle.closed_form import fill_state_dict, fill_value, synth
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 2e-6          # same ATen CPU kernels, different op grouping
+
+
+def close(a, b, tol=TOL, rel=0.0):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.abs(a - b).max() if a.size else 0.0
+    bound = tol + rel * np.abs(b).max() if b.size else tol
+    assert err <= bound, f"max|d|={err:.3e} > {bound:.3e}"
+
+
+def probe_close(t, g, prefix, tol=TOL, rel=1e-5):
+    f = t.detach().double().flatten()
+    close(f[:64].numpy(), g[prefix + "/head"], tol, rel)
+    close(f[::997].numpy(), g[prefix + "/strided"], tol, rel)
+    s, ss = float(g[prefix + "/sum"]), float(g[prefix + "/sumsq"])
+    assert abs(f.sum().item() - s) <= 1e-4 * max(1.0, abs(s)) + 1e-3 * np.sqrt(ss)
+    assert abs((f * f).sum().item() - ss) <= 1e-4 * max(ss, 1e-12)
+
+
+# ------------------------------------------------------------------ G1: schedules (f64 tables bit-exact, int sets exact)
+@pytest.mark.parametrize("rs", ["", "ddim100", "ddim250", "250", "100", "ddim50", "10,10,10"])
+def test_schedule_tables(golden, rs):
+    g = golden("g1_schedules.npz")
+    tab, tmap, T0 = S.make_schedule(1000, "linear", rs)
+    tag = rs or "full"
+    assert T0 == 1000
+    np.testing.assert_array_equal(np.array(tmap, dtype=np.int64), g[f"{tag}/timestep_map"])
+    for n in S.TABLE_NAMES + ("fixed_large_variance",):
+        np.testing.assert_array_equal(tab[n], g[f"{tag}/{n}"], err_msg=n)     # float64, bit exact
+
+
+def test_cosine_and_space_timesteps(golden):
+    g = golden("g1_schedules.npz")
+    np.testing.assert_array_equal(S.make_schedule(500, "cosine", "")[0]["betas"], g["cosine500/betas"])
+    for key in [k for k in g.files if k.startswith("space/") and k != "space/errors"]:
+        _, T, spec = key.split("/")
+        got = S.space_timesteps(int(T), spec if spec.startswith("ddim") or "," not in spec else [int(s) for s in spec.split(",")])
+        np.testing.assert_array_equal(np.array(sorted(got), dtype=np.int64), g[key], err_msg=key)
+    errs = []
+    for T, spec in [(1000, "ddim7"), (10, "20"), (1000, "ddim999")]:
+        try:
+            S.space_timesteps(T, spec)
+            errs.append(0)
+        except ValueError:
+            errs.append(1)
+    np.testing.assert_array_equal(np.array(errs), g["space/errors"])
+    assert S.space_timesteps(1000, "ddim250") != S.space_timesteps(1000, "250")
+
+
+# ------------------------------------------------------------------ G2
+def test_timestep_embedding_and_wrapped_t(golden):
+    g = golden("g2_temb.npz")
+    t = torch.from_numpy(g["t"])
+    close(U.timestep_embedding(t, 128).numpy(), g["temb128"], 1e-6)
+    close(U.timestep_embedding(t, 33).numpy(), g["temb33"], 1e-6)
+    sch = D.Schedule(1000, "linear", "ddim100", True)
+    out = sch.model_t(torch.from_numpy(g["wrapped_in"]))
+    np.testing.assert_array_equal(out.numpy(), g["wrapped_out"])
+    assert out.dtype == torch.float32
+    sch2 = D.Schedule(1000, "linear", "250", False)
+    out2 = sch2.model_t(torch.tensor([0, 248, 249]))
+    np.testing.assert_array_equal(out2.numpy(), g["wrapped_norescale_out"])
+    assert out2.dtype == torch.int64
+
+
+# ------------------------------------------------------------------ G3: blocks fwd + grads
+def _block_sd(tag, spec):
+    sd = {k: fill_value(f"{tag}.{k}", s) for k, s in spec}
+    return {k: v.requires_grad_(True) for k, v in sd.items()}
+
+
+def _strip(spec, prefix):
+    return [(k[len(prefix) + 1:], s) for k, s in spec]
+
+
+CASES_RES = [("res_same", 128, 128, True), ("res_skip", 128, 256, True), ("res_cat", 384, 128, True), ("res_nossn", 64, 96, False)]
+
+
+@pytest.mark.parametrize("tag,ci,co,ssn", CASES_RES)
+def test_resblock(golden, tag, ci, co, ssn):
+    g = golden("g3_blocks.npz")
+    meta = json.load(open(os.path.join(GOLDEN, "g3_blocks.json")))[tag]
+    spec = _strip(U._layer_spec("b", ("res", ci, co), 512, ssn), "b")
+    sd = _block_sd(tag, spec)
+    x = synth(tag + ".x", meta["x_shape"]).requires_grad_(True)
+    e = synth(tag + ".emb", (meta["x_shape"][0], 512)).requires_grad_(True)
+    y = U.resblock({"b." + k: v for k, v in sd.items()}, "b", x, e, ssn)
+    (y * synth(tag + ".gy", meta["y_shape"])).sum().backward()
+    close(y.detach().numpy(), g[tag + "/y"], 1e-5)
+    close(x.grad.numpy(), g[tag + "/gx"], 1e-5, 1e-5)
+    close(e.grad.numpy(), g[tag + "/gemb"], 1e-5, 1e-5)
+    for k, v in sd.items():
+        probe_close(v.grad, g, f"{tag}/g.{k}", 1e-5)
+
+
+@pytest.mark.parametrize("ch,T", [(96, 256), (128, 64), (64, 256), (64, 16)])
+def test_attention_block(golden, ch, T):
+    g = golden("g3_blocks.npz")
+    tag = f"attn_{ch}_{T}"
+    meta = json.load(open(os.path.join(GOLDEN, "g3_blocks.json")))[tag]
+    spec = _strip(U._layer_spec("b", ("attn", ch * 4, 4), 512, True), "b")
+    sd = _block_sd(tag, spec)
+    x = synth(tag + ".x", meta["x_shape"]).requires_grad_(True)
+    y = U.attnblock({"b." + k: v for k, v in sd.items()}, "b", x, 4)
+    (y * synth(tag + ".gy", meta["y_shape"])).sum().backward()
+    close(y.detach().numpy(), g[tag + "/y"], 1e-5)
+    close(x.grad.numpy(), g[tag + "/gx"], 1e-5, 1e-5)
+    for k, v in sd.items():
+        probe_close(v.grad, g, f"{tag}/g.{k}", 1e-5)
+
+
+def test_qkv_attention(golden):
+    g = golden("g3_blocks.npz")
+    qkv = synth("qkv.x", (8, 96, 64), -2, 2).requires_grad_(True)
+    # oracle takes [B, 3C, T] + heads; the golden tensor is already [B*H, 3ch, T] => heads=1
+    y = U.qkv_attention(qkv, 1)
+    (y * synth("qkv.gy", tuple(y.shape))).sum().backward()
+    close(y.detach().numpy(), g["qkv/y"], 1e-6)
+    close(qkv.grad.numpy(), g["qkv/gx"], 1e-6)
+
+
+@pytest.mark.parametrize("tag,kind,xs", [("down", "down", (2, 128, 8, 8)), ("up", "up", (2, 128, 4, 4))])
+def test_resample(golden, tag, kind, xs):
+    g = golden("g3_blocks.npz")
+    spec = _strip(U._layer_spec("b", (kind, 128), 512, True), "b")
+    sd = _block_sd(tag, spec)
+    x = synth(tag + ".x", xs).requires_grad_(True)
+    y = U.run_layer({"b." + k: v for k, v in sd.items()}, "b", (kind, 128), x, None)
+    (y * synth(tag + ".gy", tuple(y.shape))).sum().backward()
+    close(y.detach().numpy(), g[tag + "/y"], 1e-5)
+    close(x.grad.numpy(), g[tag + "/gx"], 1e-5)
+    for k, v in sd.items():
+        probe_close(v.grad, g, f"{tag}/g.{k}", 1e-5)
+
+
+def test_head(golden):
+    import torch.nn.functional as F
+    g = golden("g3_blocks.npz")
+    sd = _block_sd("head", [("0.weight", (128,)), ("0.bias", (128,)), ("2.weight", (4, 128, 3, 3)), ("2.bias", (4,))])
+    x = synth("head.x", (2, 128, 8, 8)).requires_grad_(True)
+    y = F.conv2d(U.silu(U.gn32(x, sd["0.weight"], sd["0.bias"])), sd["2.weight"], sd["2.bias"], padding=1)
+    (y * synth("head.gy", tuple(y.shape))).sum().backward()
+    close(y.detach().numpy(), g["head/y"], 1e-5)
+    close(x.grad.numpy(), g["head/gx"], 1e-5)
+
+
+# ------------------------------------------------------------------ G4: encoder + causal layer
+@pytest.mark.parametrize("tag,C,S_,nv", [("enc32", 1, 32, 2), ("enc64", 4, 64, 4), ("enc96", 4, 96, 4)])
+def test_encoder(golden, tag, C, S_, nv):
+    g = golden("g4_encoder.npz")
+    cfg = U.default_cfg(image_size=64 if S_ == 96 else S_, in_channels=C, n_vars=nv, rep_cond=True,
+                        encoder_dims=U.encoder_dims(S_, nv))
+    spec = [(k, s) for k, s in U.param_spec(cfg) if k.startswith("rep_emb.")]
+    sd = fill_state_dict(spec)
+    L = U.n_encoder_layers(sd)
+    x = synth(tag + ".x", (4, C, S_, S_), 0.0, 1.0)
+    mu, var = U.encode(sd, x, L, training=False)
+    close(mu.numpy(), g[tag + "/eval_mu"], 1e-5)
+    close(var.numpy(), g[tag + "/eval_var"], 1e-5)
+    for v in sd.values():
+        if v.dtype == torch.float32:
+            v.requires_grad_(True)
+    xg = x.clone().requires_grad_(True)
+    new = {}
+    mu, var = U.encode(sd, xg, L, training=True, new_stats=new)
+    close(mu.detach().numpy(), g[tag + "/train_mu"], 2e-5)
+    close(var.detach().numpy(), g[tag + "/train_var"], 2e-5)
+    ((mu * synth(tag + ".gmu", (4, 512))).sum() + (var * synth(tag + ".gvar", (4, 512))).sum()).backward()
+    close(xg.grad.numpy(), g[tag + "/train_gx"], 1e-5, 1e-4)
+    for k, v in new.items():
+        close(v.detach().numpy(), g[f"{tag}/after.{k[len('rep_emb.'):]}"], 1e-6)
+    for k, v in sd.items():
+        kk = f"{tag}/g.{k[len('rep_emb.'):]}/head"
+        if k.endswith(".0.bias"):
+            continue        # conv bias ahead of batch-stat BN: gradient is exactly 0 in theory, rounding noise in fp32
+        if kk in g.files:
+            probe_close(v.grad, g, kk[:-5], 2e-5, 1e-4)
+
+
+def test_causal_layer(golden):
+    g = golden("g4_encoder.npz")
+    for nv, graphs in [(2, ["morpho"]), (4, ["circuit", "pendulum"])]:
+        cfg = U.default_cfg(n_vars=nv, rep_cond=True, causal_modeling=True)
+        spec = [(k, s) for k, s in U.param_spec(cfg) if k.startswith("causal_mask.")]
+        sd = fill_state_dict(spec)
+        u = synth(f"causal{nv}.u", (3, 512)).requires_grad_(True)
+        for gname in graphs:
+            A = torch.tensor(U.ADJ[gname], dtype=torch.float32)
+            z_pre = U.causal_masking(u, A, nv)
+            z_post = U.nonlinearity_add_back_noise(sd, u, z_pre, nv)
+            close(z_pre.detach().numpy(), g[f"causal/{gname}/z_pre"], 1e-6)
+            close(z_post.detach().numpy(), g[f"causal/{gname}/z_post"], 1e-5)
+        (z_post * synth(f"causal{nv}.gz", (3, 512))).sum().backward()
+        close(u.grad.numpy(), g[f"causal/{graphs[-1]}/gu"], 1e-5)
+    m, v = synth("rep.m", (3, 512)), synth("rep.v", (3, 512), 0.01, 1.0)
+    close(U.reparameterize(m, v, torch.from_numpy(g["reparam/eps"])).numpy(), g["reparam/z"], 1e-6)
+
+
+# ------------------------------------------------------------------ G5
+def test_representation_loss(golden):
+    g = golden("g5_rep_loss.npz")
+    for nv in (2, 4):
+        N = 5
+        mu, var = synth(f"rl{nv}.mu", (N, 512)), synth(f"rl{nv}.var", (N, 512), 0.05, 2.0)
+        zp, c = synth(f"rl{nv}.zp", (N, 512)), synth(f"rl{nv}.c", (N, nv), 0.0, 1.0)
+        mask = torch.tensor([1.0, 0.0, 1.0, 1.0, 0.0])
+        close(D.representation_loss(mu, var, zp, True, None, c).numpy(), g[f"nv{nv}/causal"], 1e-3, 1e-6)
+        close(D.representation_loss(mu, var, zp, False, None, c).numpy(), g[f"nv{nv}/plain"], 1e-3, 1e-6)
+        close(D.representation_loss(mu, var, zp, True, mask, c).numpy(), g[f"nv{nv}/causal_masked"], 1e-3, 1e-6)
+
+
+# ------------------------------------------------------------------ G6: full UNet forward (M32 / P64 / C64)
+MODEL_CFG = {
+    "M32": dict(image_size=32, in_channels=1, n_vars=2, class_cond=True),
+    "P64": dict(image_size=64, in_channels=4, n_vars=4),
+    "C64": dict(image_size=64, in_channels=3, n_vars=4),
+    "T28": dict(image_size=28, in_channels=1, n_vars=2, class_cond=True, num_channels=32, num_res_blocks=1),
+}
+
+
+def model_cfg(tag, **over):
+    return U.default_cfg(rep_cond=True, causal_modeling=True, **MODEL_CFG[tag], **over)
+
+
+def model_inputs(tag, cfg, N):
+    C, S_, nv = cfg["in_channels"], cfg["image_size"], cfg["n_vars"]
+    x = synth(tag + ".x", (N, C, S_, S_))
+    x0 = synth(tag + ".x0", (N, C, S_, S_), 0.0, 1.0)
+    c = synth(tag + ".c", (N, nv), 0.0, 1.0)
+    z = synth(tag + ".z", (N, 512))
+    y = torch.tensor([(3 * i + 1) % 10 for i in range(N)], dtype=torch.int64) if cfg["class_cond"] else None
+    return x, x0, c, z, y
+
+
+@pytest.mark.parametrize("tag", ["M32", "P64", "C64"])
+def test_unet_forward(golden, tag):
+    g = golden("g6_unet.npz")
+    cfg = model_cfg(tag)
+    spec = U.param_spec(cfg)
+    assert [k for k, _ in spec] == list(g[f"{tag}/keys"])                       # state-dict layout == reference
+    assert [str(tuple(s)) for _, s in spec] == list(g[f"{tag}/shapes"])
+    sd = fill_state_dict(spec)
+    n_params = sum(int(np.prod(s)) for k, s in spec if "running" not in k and "num_batches" not in k)
+    assert n_params == int(g[f"{tag}/n_params"])
+    x, x0, c, z, y = model_inputs(tag, cfg, 2)
+    t = torch.tensor([37.0, 990.0])
+    with torch.no_grad():
+        e, *_ = U.unet_forward(sd, cfg, x, t, y=y, z=z)
+        close(e.numpy(), g[f"{tag}/eps_z"], 2e-5)
+        e2, mu, var, zp, _ = U.unet_forward(sd, cfg, x, t, y=y, x_start=x0, eps_z=torch.from_numpy(g[f"{tag}/eps_draw"]))
+        close(mu.numpy(), g[f"{tag}/mu"], 1e-5)
+        close(var.numpy(), g[f"{tag}/var"], 1e-5)
+        close(zp.numpy(), g[f"{tag}/z_post"], 1e-5)
+        close(e2.numpy(), g[f"{tag}/eps_enc"], 2e-5)
+
+
+# ------------------------------------------------------------------ G7: training_losses + AdamW/EMA trajectory
+@pytest.mark.parametrize("variant,masking", [("plain", False), ("masked", True)])
+def test_training_trajectory(golden, variant, masking):
+    g = golden("g7_train.npz")
+    cfg = model_cfg("T28", masking=masking)
+    spec = U.param_spec(cfg)
+    sd = fill_state_dict(spec)
+    pkeys = [k for k, _ in spec if "running" not in k and "num_batches" not in k]
+    params = [sd[k].requires_grad_(True) for k in pkeys]
+    ema = [p.detach().clone() for p in params]
+    m = [torch.zeros_like(p) for p in params]
+    v = [torch.zeros_like(p) for p in params]
+    sch = D.Schedule(1000, "linear", "", True)
+    sel = list(g[f"{variant}/sel_names"])
+    N = 4
+    for step in range(3):
+        x0 = synth(f"T28.{step}.x0", (N, 1, 28, 28), 0.0, 1.0)
+        c = synth(f"T28.{step}.c", (N, 2), 0.0, 1.0)
+        y = torch.tensor([(step + 2 * i) % 10 for i in range(N)], dtype=torch.int64)
+        t = torch.from_numpy(g[f"{variant}/step{step}/t"])
+        noise = synth(f"T28.{step}.noise", (N, 1, 28, 28), -1.7, 1.7)
+        eps_z = torch.from_numpy(g[f"{variant}/step{step}/eps_draw"])
+        mask = torch.from_numpy(g[f"{variant}/step{step}/cfg_mask"]) if masking else None
+        new = {}
+
+        def model_full(x_t, tm, xs):
+            return U.unet_forward(sd, cfg, x_t, tm, y=y, c=c, x_start=xs, eps_z=eps_z, cfg_mask=mask, training=True, new_stats=new)
+
+        for p in params:
+            p.grad = None
+        terms = D.training_losses(sch, model_full, x0, t, noise, c=c, rep_cond=True, causal_modeling=True,
+                                  kl_weight=[0.0, 0.25, 0.5][step])
+        terms["loss"].mean().backward()
+        for k in ("loss", "mse", "kld_rep"):
+            close(terms[k].detach().numpy(), g[f"{variant}/step{step}/{k}"], 1e-4, 1e-5)
+        sq = sum((p.grad.double() ** 2).sum().item() for p in params)
+        assert abs(sq - float(g[f"{variant}/step{step}/grad_sqsum"])) <= 1e-3 * sq
+        if step == 0:
+            for k in sel:
+                probe_close(sd[k].grad, g, f"{variant}/grad0/{k}", 1e-5, 1e-3)
+        with torch.no_grad():
+            D.adamw_ema_step(params, [p.grad for p in params], m, v, ema, step + 1)
+            for k, val in new.items():
+                sd[k] = val
+        if step in (0, 2):
+            for k in sel:
+                i = pkeys.index(k)
+                probe_close(params[i], g, f"{variant}/after{step + 1}/{k}", 1e-5, 1e-4)
+                probe_close(ema[i], g, f"{variant}/ema{step + 1}/{k}", 1e-6, 1e-5)
+            close(sd["rep_emb.encoder.1.1.running_var"].numpy(), g[f"{variant}/after{step + 1}/bn_running_var"], 1e-6)
+    close(np.array([D.kl_weight_at(s) for s in (0, 1, 2, 25000, 49999, 50000, 60000)]), g["kl_weight_sched"], 0.0)
+
+
+# ------------------------------------------------------------------ G8: counterfactual pattern, single steps, DDIM-100 loop
+def test_ddim_p64(golden):
+    g = golden("g8_ddim.npz")
+    cfg = model_cfg("P64")
+    sd = fill_state_dict(U.param_spec(cfg))
+    N = 2
+    x, x0, c, z, _ = model_inputs("P64", cfg, N)
+    sch = D.Schedule(1000, "linear", "ddim100", True)
+    with torch.no_grad():
+        A = torch.tensor(U.ADJ["pendulum"], dtype=torch.float32)
+        mu, _ = U.encode(sd, x0, U.n_encoder_layers(sd))
+        z_post = U.nonlinearity_add_back_noise(sd, mu, U.causal_masking(mu, A, 4), 4)
+        z_post[:, :128] = 0.2
+        zz = U.reparameterize(z_post, torch.full_like(mu, 0.001), torch.from_numpy(g["cf/eps_draw"]))
+        close(zz.numpy(), g["cf/z"], 1e-5)
+        t99 = torch.full((N,), 99, dtype=torch.int64)
+        x_t = D.q_sample(sch, x0, t99, synth("P64.qnoise", (N, 4, 64, 64), -1.7, 1.7))
+        close(x_t.numpy(), g["cf/x_t"], 1e-6)
+        model_fn = lambda xx, tm: U.unet_forward(sd, cfg, xx, tm, z=zz)[0]
+        for tv in (99, 0):
+            tt = torch.full((N,), tv, dtype=torch.int64)
+            eps = model_fn(x_t, sch.model_t(tt))
+            o = D.ddim_step(sch, eps, x_t, tt)
+            close(o["sample"].numpy(), g[f"ddim_step{tv}/sample"], 3e-5)
+            # pred_xstart = sqrt(1/abar) x - sqrt(1/abar-1) eps amplifies eps rounding by up to ~150 at t'=99
+            amp = float(sch.tab["sqrt_recipm1_alphas_cumprod"][tv])
+            close(o["pred_xstart"].numpy(), g[f"ddim_step{tv}/pred_xstart"], 3e-5 + 3e-6 * amp)
+            o = D.ddim_step(sch, eps, x_t, tt, torch.from_numpy(g[f"ddim_eta_step{tv}/noise"]), eta=0.7)
+            close(o["sample"].numpy(), g[f"ddim_eta_step{tv}/sample"], 3e-5)
+            o = D.p_sample_step(sch, eps, x_t, tt, torch.from_numpy(g[f"p_step{tv}/noise"]))
+            close(o["sample"].numpy(), g[f"p_step{tv}/sample"], 3e-5)
+            close(o["pred_xstart"].numpy(), g[f"p_step{tv}/pred_xstart"], 3e-5 + 3e-6 * amp)
+        trace = []
+        D.sample_loop(sch, model_fn, x_t, ddim=True, trace=trace)
+        for k in (1, 2, 10, 50, 100):
+            close(trace[k - 1].numpy(), g[f"loop/sample_after{k}"], 1e-4)

@@ -1,0 +1,403 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (build container only).
+
+This is the only file in the repo that imports /root/reference.  It never
+travels as a dependency: tests read the committed .npz files.  Weights and
+inputs are closed-form (oracle/closed_form.py: hash of key name + flat index),
+so fixtures hold expected OUTPUTS plus the small amount of metadata needed to
+regenerate the inputs.
+
+    python tools/gen_golden.py [--only G1,G6] [--out tests/golden]
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch as th
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, "/root/reference")
+
+from improved_diffusion import gaussian_diffusion as gd            # noqa: E402  (reference)
+from improved_diffusion import nn as rnn                           # noqa: E402
+from improved_diffusion import respace as rrespace                 # noqa: E402
+from improved_diffusion import script_util as rsu                  # noqa: E402
+from improved_diffusion import unet as runet                       # noqa: E402
+
+from oracle.closed_form import fill_value, synth                   # noqa: E402
+from oracle.unet_ref import ADJ, encoder_dims                      # noqa: E402
+
+th.set_grad_enabled(True)
+
+
+def probe(t):
+    """Compact fingerprint of a big tensor: head, strided sample, sum, sum of squares."""
+    f = t.detach().double().flatten()
+    return dict(head=f[:64].float().numpy(), strided=f[::997].float().numpy(),
+                sum=np.float64(f.sum().item()), sumsq=np.float64((f * f).sum().item()))
+
+
+def flat_probe(prefix, t, out):
+    for k, v in probe(t).items():
+        out[f"{prefix}/{k}"] = v
+
+
+def load_closed_form(module, prefix=""):
+    sd = module.state_dict()
+    for k in sd:
+        sd[k] = fill_value(prefix + k, sd[k].shape)
+    module.load_state_dict(sd)
+    return module
+
+
+def build_model(name):
+    """Reference model + diffusion for the BASELINE shapes (M32 / P64 / C64 / tiny)."""
+    base = rsu.model_and_diffusion_defaults()
+    cfgs = {
+        "M32": dict(image_size=32, in_channels=1, n_vars=2, class_cond=True),
+        "P64": dict(image_size=64, in_channels=4, n_vars=4),
+        "C64": dict(image_size=64, in_channels=3, n_vars=4),
+        "T28": dict(image_size=28, in_channels=1, n_vars=2, class_cond=True, num_channels=32, num_res_blocks=1),
+    }
+    over = dict(rep_cond=True, causal_modeling=True)
+    over.update(cfgs[name])
+    return over, base
+
+
+def make(name, respacing="", masking=False):
+    over, base = build_model(name)
+    base.update(over)
+    base["timestep_respacing"] = respacing
+    base["masking"] = masking
+    model, diff = rsu.create_model_and_diffusion(**base)
+    # Q1: the committed encoder depth only works at 96/128 px; use the class's own hidden_dims kwarg.
+    dims = encoder_dims(base["image_size"], base["n_vars"])
+    model.rep_emb = rnn.GaussianConvEncoder(base["in_channels"], 512, hidden_dims=dims, num_vars=base["n_vars"])
+    load_closed_form(model)
+    return model, diff, base
+
+
+# --------------------------------------------------------------------------- G1
+def g1_schedules(out_dir):
+    out = {}
+    for rs in ["", "ddim100", "ddim250", "250", "100", "ddim50", "10,10,10"]:
+        d = rsu.create_gaussian_diffusion(steps=1000, timestep_respacing=rs, rescale_timesteps=True)
+        tag = rs or "full"
+        for n in ["betas", "alphas_cumprod", "alphas_cumprod_prev", "alphas_cumprod_next", "sqrt_alphas_cumprod",
+                  "sqrt_one_minus_alphas_cumprod", "log_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod",
+                  "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+                  "posterior_mean_coef1", "posterior_mean_coef2"]:
+            out[f"{tag}/{n}"] = getattr(d, n)
+        out[f"{tag}/timestep_map"] = np.array(d.timestep_map, dtype=np.int64)
+        out[f"{tag}/fixed_large_variance"] = np.append(d.posterior_variance[1], d.betas[1:])
+    d = rsu.create_gaussian_diffusion(steps=500, noise_schedule="cosine", timestep_respacing="")
+    out["cosine500/betas"] = d.betas
+    cases = [(300, [10, 15, 20]), (1000, "ddim25"), (1000, "1000"), (1000, "7"), (1000, "333,1"), (50, "ddim10"),
+             (1000, "1,1")]
+    for T, spec in cases:
+        key = f"space/{T}/{spec if isinstance(spec, str) else ','.join(map(str, spec))}"
+        out[key] = np.array(sorted(rrespace.space_timesteps(T, spec)), dtype=np.int64)
+    errs = []
+    for T, spec in [(1000, "ddim7"), (10, "20"), (1000, "ddim999")]:
+        try:
+            rrespace.space_timesteps(T, spec)
+            errs.append(0)
+        except ValueError:
+            errs.append(1)
+    out["space/errors"] = np.array(errs)
+    np.savez_compressed(os.path.join(out_dir, "g1_schedules.npz"), **out)
+
+
+# --------------------------------------------------------------------------- G2
+def g2_temb(out_dir):
+    out = {}
+    t = th.tensor([0.0, 1.0, 10.0, 249.0, 990.0, 999.0, 123.5])
+    out["temb128"] = rnn.timestep_embedding(t, 128).numpy()
+    out["temb33"] = rnn.timestep_embedding(t, 33).numpy()
+    out["t"] = t.numpy()
+    d = rsu.create_gaussian_diffusion(steps=1000, timestep_respacing="ddim100", rescale_timesteps=True)
+    seen = {}
+    wm = d._wrap_model(lambda x, ts, **kw: seen.setdefault("ts", ts))
+    ts = th.tensor([0, 1, 50, 99], dtype=th.int64)
+    wm(None, ts)
+    out["wrapped_in"] = ts.numpy()
+    out["wrapped_out"] = seen["ts"].numpy()
+    d2 = rsu.create_gaussian_diffusion(steps=1000, timestep_respacing="250", rescale_timesteps=False)
+    seen.clear()
+    d2._wrap_model(lambda x, ts, **kw: seen.setdefault("ts", ts))(None, th.tensor([0, 248, 249]))
+    out["wrapped_norescale_out"] = seen["ts"].numpy()
+    np.savez_compressed(os.path.join(out_dir, "g2_temb.npz"), **out)
+
+
+# --------------------------------------------------------------------------- G3
+def g3_blocks(out_dir):
+    out, meta = {}, {}
+
+    def run_block(tag, mod, x_shape, emb=True, extra=None):
+        load_closed_form(mod, tag + ".")
+        x = synth(tag + ".x", x_shape).requires_grad_(True)
+        args = [x]
+        if emb:
+            e = synth(tag + ".emb", (x_shape[0], 512)).requires_grad_(True)
+            args.append(e)
+        y = mod(*args)
+        gy = synth(tag + ".gy", tuple(y.shape))
+        (y * gy).sum().backward()
+        out[f"{tag}/y"] = y.detach().numpy()
+        out[f"{tag}/gx"] = x.grad.numpy()
+        if emb:
+            out[f"{tag}/gemb"] = e.grad.numpy()
+        for k, p in mod.named_parameters():
+            flat_probe(f"{tag}/g.{k}", p.grad, out)
+        meta[tag] = dict(x_shape=list(x_shape), y_shape=list(y.shape), emb=emb, **(extra or {}))
+
+    run_block("res_same", runet.ResBlock(128, 512, 0.0, use_scale_shift_norm=True), (2, 128, 4, 4))
+    run_block("res_skip", runet.ResBlock(128, 512, 0.0, out_channels=256, use_scale_shift_norm=True), (2, 128, 4, 4))
+    run_block("res_cat", runet.ResBlock(384, 512, 0.0, out_channels=128, use_scale_shift_norm=True), (2, 384, 4, 4))
+    run_block("res_nossn", runet.ResBlock(64, 512, 0.0, out_channels=96, use_scale_shift_norm=False), (2, 64, 6, 6))
+    for ch, T, heads in [(96, 256, 4), (128, 64, 4), (64, 256, 4), (64, 16, 4)]:
+        s = int(T ** 0.5)
+        run_block(f"attn_{ch}_{T}", runet.AttentionBlock(ch * heads, num_heads=heads), (1, ch * heads, s, s), emb=False,
+                  extra=dict(heads=heads))
+    run_block("down", runet.Downsample(128, True), (2, 128, 8, 8), emb=False)
+    run_block("up", runet.Upsample(128, True), (2, 128, 4, 4), emb=False)
+    # bare QKVAttention (unet.py:239-253) on a [B*H, 3*ch, T] tensor
+    qkv = synth("qkv.x", (8, 3 * 32, 64), -2, 2).requires_grad_(True)
+    y = runet.QKVAttention()(qkv)
+    gy = synth("qkv.gy", tuple(y.shape))
+    (y * gy).sum().backward()
+    out["qkv/y"], out["qkv/gx"] = y.detach().numpy(), qkv.grad.numpy()
+    # output head = GN32 -> SiLU -> conv3x3 (unet.py:495-499)
+    head = th.nn.Sequential(rnn.normalization(128), rnn.SiLU(), rnn.conv_nd(2, 128, 4, 3, padding=1))
+    run_block("head", head, (2, 128, 8, 8), emb=False)
+    np.savez_compressed(os.path.join(out_dir, "g3_blocks.npz"), **out)
+    with open(os.path.join(out_dir, "g3_blocks.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
+# --------------------------------------------------------------------------- G4
+def g4_encoder(out_dir):
+    out = {}
+    for tag, C, S, nv in [("enc32", 1, 32, 2), ("enc64", 4, 64, 4), ("enc96", 4, 96, 4)]:
+        dims = encoder_dims(S, nv)
+        enc = rnn.GaussianConvEncoder(C, 512, hidden_dims=dims, num_vars=nv)
+        load_closed_form(enc, "rep_emb.")
+        x = synth(tag + ".x", (4, C, S, S), 0.0, 1.0)
+        enc.eval()
+        mu, var = enc.encode(x)
+        out[f"{tag}/eval_mu"], out[f"{tag}/eval_var"] = mu.detach().numpy(), var.detach().numpy()
+        enc.train()
+        xg = x.clone().requires_grad_(True)
+        mu, var = enc.encode(xg)
+        out[f"{tag}/train_mu"], out[f"{tag}/train_var"] = mu.detach().numpy(), var.detach().numpy()
+        gmu, gvar = synth(tag + ".gmu", (4, 512)), synth(tag + ".gvar", (4, 512))
+        ((mu * gmu).sum() + (var * gvar).sum()).backward()
+        out[f"{tag}/train_gx"] = xg.grad.numpy()
+        for k, p in enc.named_parameters():
+            if p.grad is not None:
+                flat_probe(f"{tag}/g.{k}", p.grad, out)
+        for k, v in enc.state_dict().items():
+            if "running" in k:
+                out[f"{tag}/after.{k}"] = v.numpy()
+    for nv, graphs in [(2, ["morpho"]), (4, ["circuit", "pendulum"])]:
+        cm = rnn.CausalModeling(latent_dim=512, num_var=nv, learn=False)
+        load_closed_form(cm, "causal_mask.")
+        u = synth(f"causal{nv}.u", (3, 512)).requires_grad_(True)
+        for g in graphs:
+            A = th.tensor(ADJ[g], dtype=th.float32)
+            z_pre = cm.causal_masking(u, A)
+            z_post = cm.nonlinearity_add_back_noise(u, z_pre)
+            out[f"causal/{g}/z_pre"], out[f"causal/{g}/z_post"] = z_pre.detach().numpy(), z_post.detach().numpy()
+        gz = synth(f"causal{nv}.gz", (3, 512))
+        (z_post * gz).sum().backward()
+        out[f"causal/{graphs[-1]}/gu"] = u.grad.numpy()
+    th.manual_seed(7)
+    m, v = synth("rep.m", (3, 512)), synth("rep.v", (3, 512), 0.01, 1.0)
+    z = rnn.reparameterize(m, v)
+    th.manual_seed(7)
+    out["reparam/eps"] = th.randn(m.size()).numpy()
+    out["reparam/z"] = z.numpy()
+    np.savez_compressed(os.path.join(out_dir, "g4_encoder.npz"), **out)
+
+
+# --------------------------------------------------------------------------- G5
+def g5_rep_loss(out_dir):
+    out = {}
+    d = rsu.create_gaussian_diffusion(steps=1000)
+    for nv in (2, 4):
+        N = 5
+        mu, var = synth(f"rl{nv}.mu", (N, 512)), synth(f"rl{nv}.var", (N, 512), 0.05, 2.0)
+        zp, c = synth(f"rl{nv}.zp", (N, 512)), synth(f"rl{nv}.c", (N, nv), 0.0, 1.0)
+        mask = th.tensor([1.0, 0.0, 1.0, 1.0, 0.0])
+        out[f"nv{nv}/causal"] = d.representation_loss(mu, var, zp, True, None, c).numpy()
+        out[f"nv{nv}/plain"] = d.representation_loss(mu, var, zp, False, None, c).numpy()
+        out[f"nv{nv}/causal_masked"] = d.representation_loss(mu, var, zp, True, mask, c).numpy()
+    np.savez_compressed(os.path.join(out_dir, "g5_rep_loss.npz"), **out)
+
+
+# --------------------------------------------------------------------------- G6
+def model_inputs(tag, base, N):
+    C, S, nv = base["in_channels"], base["image_size"], base["n_vars"]
+    x = synth(tag + ".x", (N, C, S, S))
+    x0 = synth(tag + ".x0", (N, C, S, S), 0.0, 1.0)
+    c = synth(tag + ".c", (N, nv), 0.0, 1.0)
+    z = synth(tag + ".z", (N, 512))
+    y = th.tensor([(3 * i + 1) % 10 for i in range(N)], dtype=th.int64) if base["class_cond"] else None
+    return x, x0, c, z, y
+
+
+def g6_unet(out_dir):
+    out = {}
+    N = 2
+    for tag in ["M32", "P64", "C64"]:
+        model, diff, base = make(tag)
+        model.eval()
+        x, x0, c, z, y = model_inputs(tag, base, N)
+        t = th.tensor([37.0, 990.0])
+        kw = dict(y=y) if y is not None else {}
+        with th.no_grad():
+            e, *_ = model(x, t, z=z, **kw)                     # sampling path (z given)
+            out[f"{tag}/eps_z"] = e.numpy()
+            th.manual_seed(11)
+            e2, mu, var, zp, mask = model(x, t, x_start=x0, **kw)      # encoder path, eval-mode BN
+            th.manual_seed(11)
+            out[f"{tag}/eps_draw"] = th.randn(N, 512).numpy()
+            out[f"{tag}/eps_enc"], out[f"{tag}/mu"], out[f"{tag}/var"], out[f"{tag}/z_post"] = (
+                e2.numpy(), mu.numpy(), var.numpy(), zp.numpy())
+        out[f"{tag}/keys"] = np.array(list(model.state_dict().keys()))
+        out[f"{tag}/shapes"] = np.array([str(tuple(v.shape)) for v in model.state_dict().values()])
+        out[f"{tag}/n_params"] = np.int64(sum(p.numel() for p in model.parameters()))
+    np.savez_compressed(os.path.join(out_dir, "g6_unet.npz"), **out)
+
+
+# --------------------------------------------------------------------------- G7
+def kl_weight_at(step, total=50000):
+    # restated from reference train_util.py:176-187 (train_util itself cannot be imported: blobfile/mpi4py absent)
+    if step >= total:
+        return 1.0
+    if step <= 0:
+        return 0.0
+    return step / (total - 1)
+
+
+def g7_train(out_dir):
+    from torch.optim import AdamW
+    import copy
+    out = {}
+    for variant, masking in [("plain", False), ("masked", True)]:
+        model, diff, base = make("T28", masking=masking)
+        model.train()
+        N = 4
+        params = list(model.parameters())
+        ema = copy.deepcopy(params)
+        opt = AdamW(params, lr=1e-4, weight_decay=0.0)
+        names = [k for k, _ in model.named_parameters()]
+        sel = [0, 3, len(names) // 2, len(names) - 1, names.index("rep_emb.encoder.0.0.weight"),
+               names.index("causal_mask.nonlinearities.1.net.2.weight"), names.index("input_blocks.1.0.in_layers.2.weight"),
+               names.index("out.2.weight")]
+        out[f"{variant}/sel_names"] = np.array([names[i] for i in sel])
+        diff.kl_weight = 0.0
+        for step in range(3):
+            # NB kl_weight would be ~2e-5*step at these steps; use a visible weight so the KL path is exercised.
+            diff.kl_weight = [0.0, 0.25, 0.5][step]
+            x0 = synth(f"T28.{step}.x0", (N, 1, 28, 28), 0.0, 1.0)
+            c = synth(f"T28.{step}.c", (N, 2), 0.0, 1.0)
+            y = th.tensor([(step + 2 * i) % 10 for i in range(N)], dtype=th.int64)
+            t = th.tensor([(137 * (step + 1) + 251 * i) % 1000 for i in range(N)], dtype=th.int64)
+            noise = synth(f"T28.{step}.noise", (N, 1, 28, 28), -1.7, 1.7)
+            for p in params:
+                p.grad = None
+            th.manual_seed(100 + step)
+            terms = diff.training_losses(model, x0, t, model_kwargs=dict(c=c, y=y), noise=noise, rep_cond=True,
+                                         causal_modeling=True)
+            th.manual_seed(100 + step)
+            out[f"{variant}/step{step}/eps_draw"] = th.randn(N, 512).numpy()
+            if masking:
+                out[f"{variant}/step{step}/cfg_mask"] = th.bernoulli(th.zeros(N) + 0.5).numpy()
+            weights = th.ones(N)
+            (terms["loss"] * weights).mean().backward()
+            for k in ("loss", "mse", "kld_rep"):
+                out[f"{variant}/step{step}/{k}"] = terms[k].detach().numpy()
+            out[f"{variant}/step{step}/t"] = t.numpy()
+            out[f"{variant}/step{step}/grad_sqsum"] = np.float64(sum((p.grad.double() ** 2).sum().item() for p in params))
+            if step == 0:
+                for i in sel:
+                    flat_probe(f"{variant}/grad0/{names[i]}", params[i].grad, out)
+            opt.step()
+            rnn.update_ema(ema, params, rate=0.9999)
+            if step in (0, 2):
+                for i in sel:
+                    flat_probe(f"{variant}/after{step + 1}/{names[i]}", params[i], out)
+                    flat_probe(f"{variant}/ema{step + 1}/{names[i]}", ema[i], out)
+                out[f"{variant}/after{step + 1}/param_sum"] = np.float64(sum(p.double().sum().item() for p in params))
+                bn = model.state_dict()["rep_emb.encoder.1.1.running_var"]
+                out[f"{variant}/after{step + 1}/bn_running_var"] = bn.numpy().copy()
+    out["kl_weight_sched"] = np.array([kl_weight_at(s) for s in (0, 1, 2, 25000, 49999, 50000, 60000)])
+    np.savez_compressed(os.path.join(out_dir, "g7_train.npz"), **out)
+
+
+# --------------------------------------------------------------------------- G8
+def g8_ddim(out_dir):
+    out = {}
+    N = 2
+    model, diff, base = make("P64", respacing="ddim100")
+    model.eval()
+    x, x0, c, z, _ = model_inputs("P64", base, N)
+    A = th.tensor(ADJ["pendulum"], dtype=th.float32)
+    with th.no_grad():
+        # counterfactual pattern of image_causaldae_test.py:535-594 (pendulum branch), T'=100
+        mu, var = model.rep_emb.encode(x0)
+        var = th.ones_like(mu) * 0.001
+        z_pre = model.causal_mask.causal_masking(mu, A)
+        z_post = model.causal_mask.nonlinearity_add_back_noise(mu, z_pre)
+        z_post[:, :128] = 0.2
+        th.manual_seed(5)
+        zz = rnn.reparameterize(z_post, var)
+        th.manual_seed(5)
+        out["cf/eps_draw"] = th.randn(N, 512).numpy()
+        out["cf/z"] = zz.numpy()
+        noise = synth("P64.qnoise", (N, 4, 64, 64), -1.7, 1.7)
+        t = th.full((N,), 99, dtype=th.int64)
+        x_t = diff.q_sample(x0, t, noise=noise)
+        out["cf/x_t"] = x_t.numpy()
+        # single DDIM step + single ancestral step at t = 99 and t = 0
+        for tv in (99, 0):
+            tt = th.full((N,), tv, dtype=th.int64)
+            o = diff.ddim_sample(model, x_t, tt, model_kwargs=dict(z=zz))
+            out[f"ddim_step{tv}/sample"], out[f"ddim_step{tv}/pred_xstart"] = o["sample"].numpy(), o["pred_xstart"].numpy()
+            th.manual_seed(21)
+            o = diff.ddim_sample(model, x_t, tt, model_kwargs=dict(z=zz), eta=0.7)
+            th.manual_seed(21)
+            out[f"ddim_eta_step{tv}/noise"] = th.randn(N, 4, 64, 64).numpy()
+            out[f"ddim_eta_step{tv}/sample"] = o["sample"].numpy()
+            th.manual_seed(22)
+            o = diff.p_sample(model, x_t, tt, model_kwargs=dict(z=zz))
+            th.manual_seed(22)
+            out[f"p_step{tv}/noise"] = th.randn(N, 4, 64, 64).numpy()
+            out[f"p_step{tv}/sample"], out[f"p_step{tv}/pred_xstart"] = o["sample"].numpy(), o["pred_xstart"].numpy()
+        # full DDIM-100 loop, eta = 0 (the drawn noise is multiplied by sigma = 0)
+        k = 0
+        for o in diff.ddim_sample_loop_progressive(model, (N, 4, 64, 64), noise=x_t, model_kwargs=dict(z=zz)):
+            k += 1
+            if k in (1, 2, 10, 50, 100):
+                out[f"loop/sample_after{k}"] = o["sample"].numpy()
+    np.savez_compressed(os.path.join(out_dir, "g8_ddim.npz"), **out)
+
+
+ALL = dict(G1=g1_schedules, G2=g2_temb, G3=g3_blocks, G4=g4_encoder, G5=g5_rep_loss, G6=g6_unet, G7=g7_train, G8=g8_ddim)
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    th.set_num_threads(os.cpu_count())
+    for name, fn in ALL.items():
+        if a.only and name not in a.only.split(","):
+            continue
+        print("generating", name, flush=True)
+        fn(a.out)
