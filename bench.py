@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the CausalDiffAE diffusion hot path on MI355X.
+
+A "step" = one DDIM denoise step (UNet forward + fused DDIM update) over one batch of synthetic 64x64
+images: BASELINE.json config "Pendulum 64x64, 4 causal vars, DDIM-100 counterfactual sampling", per-GPU
+batch 128 (the per-GPU share of config 5).  The sampling batch is sharded over ranks with no collective in
+the loop (weak scaling).  Prints ONE JSON line (rank 0).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
+GFLOP_PER_IMAGE_STEP_P64 = 60.63       # SURVEY §8d (torch FlopCounter on the reference forward)
+
+
+def randomize(model, seed):
+    """Random (non-zero) weights of the architecture: zero-filled operands would flatter the clocks."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if p.dim() > 1:
+                fan_in = p[0].numel()
+                p.copy_(torch.randn(p.shape, generator=g) * (1.0 / fan_in) ** 0.5)
+            elif name.endswith("weight"):
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+            else:
+                p.copy_(0.05 * torch.randn(p.shape, generator=g))
+        for name, b in model.named_buffers():
+            if name.endswith("running_var"):
+                b.copy_(1.0 + 0.1 * torch.rand(b.shape, generator=g))
+
+
+def cpu_baseline(steps=3, batch=16):
+    """The oracle (torch-CPU restatement of the reference forward + DDIM step) timed on this host's cores."""
+    from oracle import diffusion_ref as D
+    from oracle import unet_ref as U
+    from oracle.closed_form import fill_state_dict, synth
+    torch.set_num_threads(os.cpu_count())
+    cfg = U.default_cfg(image_size=64, in_channels=4, n_vars=4, rep_cond=True, causal_modeling=True)
+    sd = fill_state_dict(U.param_spec(cfg))
+    sch = D.Schedule(1000, "linear", "ddim100", True)
+    x = synth("bench.cpu.x", (batch, 4, 64, 64))
+    z = synth("bench.cpu.z", (batch, 512))
+    fn = lambda xx, tm: U.unet_forward(sd, cfg, xx, tm, z=z)[0]
+    with torch.no_grad():
+        D.sample_loop(sch, fn, x, ddim=True, n_steps=1)
+        t0 = time.perf_counter()
+        D.sample_loop(sch, fn, x, ddim=True, n_steps=steps)
+        dt = time.perf_counter() - t0
+    return {"value": batch * steps / dt, "unit": "image-steps/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"oracle (torch-CPU restatement), P64 DDIM step, batch {batch}, {steps} steps after 1 warm-up, "
+                      f"{os.cpu_count()} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=128, help="images per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (the product path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method="env://")
+
+    import causaldiffae_amd  # noqa: F401
+    from causaldiffae_amd import _lib
+    from causaldiffae_amd.gaussian_diffusion import _GraphStep
+    from improved_diffusion import script_util as su
+    from improved_diffusion.nn import reparameterize
+    from improved_diffusion.unet import ADJACENCY
+
+    cfg = {**su.model_and_diffusion_defaults(), "image_size": 64, "in_channels": 4, "n_vars": 4, "rep_cond": True,
+           "causal_modeling": True, "timestep_respacing": "ddim100"}
+    model, diff = su.create_model_and_diffusion(**cfg)
+    randomize(model, 1234)
+    model.to(dev).eval()
+    N = args.batch
+    g = torch.Generator().manual_seed(100 + rank)          # each rank samples its own shard of the global batch
+    x0 = torch.rand(N, 4, 64, 64, generator=g).to(dev)
+    with torch.no_grad():
+        # counterfactual pattern of scripts/image_causaldae_test.py:535-594 (pendulum branch)
+        A = torch.tensor(ADJACENCY["pendulum"], dtype=torch.float32)
+        mu, var = model.rep_emb.encode(x0)
+        z_post = model.causal_mask.nonlinearity_add_back_noise(mu, model.causal_mask.causal_masking(mu, A))
+        z_post[:, :128] = 0.2
+        z = reparameterize(z_post, torch.full_like(mu, 0.001), eps=torch.randn(N, 512, generator=g).to(dev))
+        t_last = torch.full((N,), diff.num_timesteps - 1, dtype=torch.int64, device=dev)
+        x_t = diff.q_sample(x0, t_last, noise=torch.randn(N, 4, 64, 64, generator=g).to(dev))
+        kw = dict(z=z)
+
+        T = diff.num_timesteps
+        steps_tab = diff._step_table(dev, N)
+        if args.no_graph:
+            img = x_t.clone()
+
+            def do_step(k):
+                nonlocal img
+                img = diff.ddim_sample(model, img, steps_tab[k % T], model_kwargs=kw)["sample"]
+        else:
+            runner = _GraphStep(diff, model, x_t.clone(), kw, True, None)
+
+            def do_step(k):
+                runner.step(k % T)
+
+        def sync():
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+                torch.cuda.synchronize()
+
+        for k in range(max(1, args.warmup)):
+            do_step(k)
+        sync()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            do_step(args.warmup + k)
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = tt.item()
+
+        # roofline of the dominant kernel family (igemm on the fp32 matrix cores): HIP events on the launch
+        # stream around every launch during two eager steps, outside the timed region
+        roof = None
+        if rank == 0:
+            img2 = x_t.clone()
+            diff.ddim_sample(model, img2, steps_tab[0], model_kwargs=kw)
+            torch.cuda.synchronize()
+            _lib.prof_enable(True)
+            for k in range(2):
+                img2 = diff.ddim_sample(model, img2, steps_tab[k], model_kwargs=kw)["sample"]
+            prof = _lib.prof_read()
+            _lib.prof_enable(False)
+            ig = prof["igemm"]
+            ach = ig["work"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
+            roof = {"bound": "mfma", "kernel": "igemm_kernel (v_mfma_f32_32x32x2_f32)", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "launches_per_step": ig["launches"] // 2, "avg_launch_us": 1e3 * ig["ms"] / max(1, ig["launches"]),
+                    "flops_per_launch_avg": ig["work"] / max(1, ig["launches"]),
+                    "family_ms_per_step": {k: v["ms"] / 2 for k, v in prof.items()}}
+
+    if rank != 0:
+        return
+    value = world * N * args.steps / dt
+    out = {
+        "metric": "DDIM denoise image-steps/sec, 64x64 UNet (P64)", "value": value, "unit": "image-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "Pendulum 64x64 C=4, 4 causal vars, DDIM-100 counterfactual sampling (encode -> intervene -> "
+                               "q_sample -> ddim steps), UNet 93.45M params", "batch_per_gpu": N, "global_batch": N * world,
+                   "parallelism": f"batch-sharded x{world}, no collectives", "hip_graph": not args.no_graph},
+        "samples_per_sec_ddim100": value / 100.0,
+        "model_tflops": value * GFLOP_PER_IMAGE_STEP_P64 / 1e3,
+        "roofline": roof,
+    }
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline()
+        out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,142 @@
+"""ctypes binding of libcdae.so (include/cdae.h).  The HIP library is mandatory: importing this module
+without it raises, and calling any op on a non-GPU tensor raises — there is no CPU fallback."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcdae.so")
+
+P = ctypes.c_void_p
+I = ctypes.c_int
+L = ctypes.c_long
+LL = ctypes.c_longlong
+F = ctypes.c_float
+D = ctypes.c_double
+SZ = ctypes.c_size_t
+
+# name -> argtypes (return type is int unless listed in _RESTYPES); mirrors include/cdae.h one to one
+SIGNATURES = {
+    "cdae_version": [],
+    "cdae_last_error": [],
+    "cdae_conv3x3_fwd": [P, L, L, L, L, P, P, P, P, L, I, I, I, I, I, I, I, I, P, SZ, P],
+    "cdae_conv3x3_dgrad": [P, L, P, P, L, I, I, I, I, I, I, I, I, P, SZ, P],
+    "cdae_conv3x3_wgrad": [P, L, L, L, L, P, L, P, P, I, I, I, I, I, I, I, I, P, SZ, P],
+    "cdae_linear_fwd": [P, L, P, L, P, P, P, L, I, I, I, F, I, P, SZ, P],
+    "cdae_linear_dgrad": [P, L, P, L, P, L, I, I, I, I, P, SZ, P],
+    "cdae_linear_wgrad": [P, L, P, L, P, L, P, I, I, I, I, P, SZ, P],
+    "cdae_colsum": [P, L, P, L, I, I, P],
+    "cdae_qkv_attention_fwd": [P, P, P, I, I, I, I, P],
+    "cdae_qkv_attention_bwd": [P, P, P, P, P, I, I, I, I, P],
+    "cdae_gn_workspace_floats": [I, I],
+    "cdae_gn_stats": [P, I, I, I, I, I, F, P, P, P, P],
+    "cdae_gn_apply": [P, P, I, I, I, I, I, I, P, P, P, P, P, I, I, P],
+    "cdae_gn_bwd": [P, P, P, I, I, I, I, I, I, I, P, P, P, P, P, I, I, P, P, I, P, I, I, P, P],
+    "cdae_bn_workspace_floats": [I],
+    "cdae_bn_lrelu_fwd": [P, P, L, I, P, P, P, P, I, F, F, F, P, P, P, P, P, P],
+    "cdae_bn_lrelu_bwd": [P, P, P, L, I, P, P, P, P, F, P, P, I, P, P],
+    "cdae_softmax_rows": [P, L, I, P],
+    "cdae_softmax_rows_bwd": [P, P, L, I, P],
+    "cdae_silu_fwd": [P, P, L, P],
+    "cdae_silu_bwd": [P, P, P, L, P],
+    "cdae_timestep_embed_fwd": [P, P, P, I, I, P],
+    "cdae_model_timesteps": [P, P, F, I, P, P, I, P],
+    "cdae_embedding_add": [P, P, P, I, I, P],
+    "cdae_embedding_bwd": [P, P, P, I, I, P],
+    "cdae_axpby": [F, P, F, P, P, L, P],
+    "cdae_mul_rows": [P, P, I, I, P],
+    "cdae_copy2d": [P, P, L, I, L, L, I, P],
+    "cdae_nchw_to_nhwc": [P, P, I, I, I, P],
+    "cdae_nhwc_to_nchw": [P, P, I, I, I, P],
+    "cdae_sumpool2": [P, P, I, I, I, I, P],
+    "cdae_q_sample": [P, P, P, P, I, P, I, L, P],
+    "cdae_ddim_update": [P, P, P, P, I, F, P, I, P, P, I, L, P],
+    "cdae_ddpm_update": [P, P, P, P, I, P, I, P, P, I, L, P],
+    "cdae_softplus_fwd": [P, P, L, F, P],
+    "cdae_softplus_bwd": [P, P, P, L, P],
+    "cdae_reparam": [P, P, F, P, P, L, P],
+    "cdae_causal_mask": [P, P, P, I, I, I, I, P],
+    "cdae_adamw_ema": [P, P, P, P, P, L, D, D, D, D, D, I, D, D, P],
+    "cdae_sqsum": [P, L, P, P],
+    "cdae_mse_rows": [P, P, P, I, L, P],
+    "cdae_mse_rows_bwd": [P, P, P, P, I, L, P],
+    "cdae_prof_enable": [I],
+    "cdae_prof_read": [P, P, P],
+}
+_RESTYPES = {"cdae_last_error": ctypes.c_char_p, "cdae_gn_workspace_floats": SZ, "cdae_bn_workspace_floats": SZ}
+
+TAB_ROWS = 10
+PROF_FAMILIES = ("igemm", "groupnorm", "softmax", "elementwise", "optimizer")
+
+
+class CdaeError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
+            "or causaldiffae_amd/csrc/build.sh).  causaldiffae_amd has no CPU / eager fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
+        fn.argtypes = args
+        fn.restype = _RESTYPES.get(name, ctypes.c_int)
+    return lib
+
+
+lib = _load()
+
+
+def check(rc):
+    if rc != 0:
+        raise CdaeError(lib.cdae_last_error().decode())
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Refuses host tensors: the product path is GPU only."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise CdaeError("causaldiffae_amd ops need tensors on an MI355X device (got a CPU tensor); "
+                        "there is no CPU fallback — the CPU oracle lives in oracle/ for tests only")
+    return t.data_ptr()
+
+
+_ws = {}
+
+
+def workspace(device, name, nbytes):
+    """Persistent per-device scratch buffers (split-K slabs, norm partials); grown on demand, never shrunk."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), name)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        _ws[key] = buf
+    return buf
+
+
+SPLITK_BYTES = 256 << 20
+
+
+def splitk_ws(device):
+    return workspace(device, "splitk", SPLITK_BYTES)
+
+
+def prof_enable(on):
+    check(lib.cdae_prof_enable(1 if on else 0))
+
+
+def prof_read():
+    n = len(PROF_FAMILIES)
+    ms = (ctypes.c_double * n)()
+    work = (ctypes.c_double * n)()
+    cnt = (ctypes.c_longlong * n)()
+    check(lib.cdae_prof_read(ms, work, cnt))
+    return {PROF_FAMILIES[i]: dict(ms=ms[i], work=work[i], launches=cnt[i]) for i in range(n)}

@@ -1,0 +1,228 @@
+// api.hip — op-level C-ABI over the igemm kernel family: conv3x3 / linear / QKV attention (fwd, dgrad, wgrad).
+// See include/cdae.h for the contract of every entry point.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+#include "cdae_internal.h"
+#include "../../include/cdae.h"
+
+namespace {
+
+GemmParams base_params() {
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.batch = 1; p.batch_inner = 1; p.alpha = 1.f; p.ksplit = 1; p.stride = 1;
+    return p;
+}
+
+inline bool aligned16(const void* p) { return (((size_t)p) & 15) == 0; }
+
+void set_splitk(GemmParams& p, float* ws, size_t bytes) {
+    p.splitk_ws = ws; p.splitk_ws_bytes = bytes; p.ksplit_auto = ws != nullptr;
+}
+
+__global__ void colsum_kernel(const float* __restrict__ x, long ldx, float* __restrict__ out, long rows, int cols, long rows_per_block) {
+    __shared__ float sh[256];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const long r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float s = 0.f;
+    if (c < cols)
+        for (long r = r0 + rl; r < r1; r += 4) s += x[r * ldx + c];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0 && c < cols) atomicAdd(&out[c], (sh[threadIdx.x] + sh[threadIdx.x + 64]) + (sh[threadIdx.x + 128] + sh[threadIdx.x + 192]));
+}
+
+}  // namespace
+
+extern "C" {
+
+int cdae_colsum(const float* x, long ldx, float* out, long rows, int cols, int accumulate, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * cols, st) != hipSuccess) return cdae_fail("colsum memset failed");
+    long chunks = (rows + 511) / 512;
+    if (chunks > 1024) chunks = 1024;
+    if (chunks < 1) chunks = 1;
+    long rpb = (rows + chunks - 1) / chunks;
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, (unsigned)chunks), dim3(256), 0, st, x, ldx, out, rows, cols, rpb);
+    return hipGetLastError() == hipSuccess ? 0 : cdae_fail("colsum launch failed");
+}
+
+int cdae_conv3x3_fwd(const float* x, long sn, long sy, long sx, long sc, const float* w, const float* bias, const float* res,
+                     float* out, long ldo, int out_nchw, int N, int H, int W, int Cin, int Cout, int stride, int up,
+                     float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    if (stride != 1 && stride != 2) return cdae_fail("conv3x3: stride must be 1 or 2");
+    if (up && stride != 1) return cdae_fail("conv3x3: fused upsample needs stride 1");
+    const int Ho = up ? 2 * H : (H - 1) / stride + 1, Wo = up ? 2 * W : (W - 1) / stride + 1;
+    GemmParams p = base_params();
+    p.A = x; p.B = w; p.C = out; p.bias = bias; p.res = res;
+    p.M = N * Ho * Wo; p.N = Cout; p.K = 9 * Cin;
+    p.ldb = 9L * Cin; p.ldc = ldo;
+    p.out_mode = out_nchw ? OUT_NCHW : OUT_ROWMAJOR; p.out_hw = Ho * Wo;
+    const bool vec = sc == 1 && Cin % 32 == 0 && sx % 4 == 0 && sy % 4 == 0 && sn % 4 == 0 && aligned16(x);
+    p.amode = vec ? A_CONV_VEC : A_CONV_GEN;
+    p.bmode = B_PLAIN_KC;
+    p.b_scalar = !(p.K % 4 == 0 && aligned16(w));
+    p.conv_M = p.M; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.up = up;
+    p.sn = sn; p.sy = sy; p.sx = sx; p.sc = sc;
+    set_splitk(p, out_nchw ? nullptr : splitk_ws, splitk_ws_bytes);
+    if (out_nchw && res) return cdae_fail("conv3x3: residual with NCHW output unsupported");
+    return cdae_gemm_dispatch(p, stream);
+}
+
+int cdae_conv3x3_dgrad(const float* dy, long lddy, const float* w, float* dx, long lddx, int N, int H, int W, int Cin, int Cout,
+                       int stride, int up, int accumulate, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    const int Ho = up ? 2 * H : (H - 1) / stride + 1, Wo = up ? 2 * W : (W - 1) / stride + 1;   // dy grid
+    GemmParams p = base_params();
+    p.A = dy; p.B = w; p.C = dx;
+    p.N = Cin; p.K = 9 * Cout; p.ldc = lddx; p.accumulate = accumulate;
+    // gathered tensor = dy
+    p.H = Ho; p.W = Wo; p.Cin = Cout;
+    p.sn = (long)Ho * Wo * lddy; p.sy = (long)Wo * lddy; p.sx = lddy; p.sc = 1;
+    if (stride == 1) {          // rows enumerate the dy-sized grid (the upsampled grid when up=1)
+        p.Ho = Ho; p.Wo = Wo; p.stride = 1; p.tconv = 0; p.wflip = 1;
+    } else {                    // rows enumerate dx pixels, transposed stride-2 gather
+        p.Ho = H; p.Wo = W; p.tconv = 1; p.wflip = 0;
+    }
+    p.M = N * p.Ho * p.Wo; p.conv_M = p.M;
+    const bool vec = Cout % 32 == 0 && lddy % 4 == 0 && aligned16(dy);
+    p.amode = vec ? A_CONV_VEC : A_CONV_GEN;
+    p.bmode = B_WDGRAD_MC; p.wCout = Cout; p.wCin = Cin;
+    p.b_scalar = !(Cin % 4 == 0 && aligned16(w));
+    set_splitk(p, accumulate ? nullptr : splitk_ws, splitk_ws_bytes);
+    return cdae_gemm_dispatch(p, stream);
+}
+
+int cdae_conv3x3_wgrad(const float* x, long sn, long sy, long sx, long sc, const float* dy, long lddy, float* dw, float* dbias,
+                       int N, int H, int W, int Cin, int Cout, int stride, int up, int accumulate,
+                       float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    const int Ho = up ? 2 * H : (H - 1) / stride + 1, Wo = up ? 2 * W : (W - 1) / stride + 1;
+    GemmParams p = base_params();
+    p.A = dy; p.B = x; p.C = dw;
+    p.M = Cout; p.N = 9 * Cin; p.K = N * Ho * Wo;
+    p.lda = lddy; p.ldc = 9L * Cin; p.accumulate = accumulate;
+    p.amode = A_PLAIN_MC; p.a_scalar = !(lddy % 4 == 0 && aligned16(dy));
+    p.bmode = B_CONV_MC;
+    p.b_scalar = !(sc == 1 && Cin % 64 == 0 && sx % 4 == 0 && sy % 4 == 0 && sn % 4 == 0 && aligned16(x));
+    p.conv_M = p.K; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.up = up;
+    p.sn = sn; p.sy = sy; p.sx = sx; p.sc = sc;
+    set_splitk(p, splitk_ws, splitk_ws_bytes);
+    int rc = cdae_gemm_dispatch(p, stream);
+    if (rc == 0 && dbias) rc = cdae_colsum(dy, lddy, dbias, (long)N * Ho * Wo, Cout, accumulate, stream);
+    return rc;
+}
+
+int cdae_linear_fwd(const float* x, long ldx, const float* w, long ldw, const float* bias, const float* res, float* y, long ldy,
+                    int M, int N, int K, float alpha, int act, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    GemmParams p = base_params();
+    p.A = x; p.B = w; p.C = y; p.bias = bias; p.res = res;
+    p.M = M; p.N = N; p.K = K; p.lda = ldx; p.ldb = ldw; p.ldc = ldy; p.alpha = alpha; p.act = act;
+    p.amode = A_PLAIN_KC; p.bmode = B_PLAIN_KC;
+    p.a_scalar = !(K % 4 == 0 && ldx % 4 == 0 && aligned16(x));
+    p.b_scalar = !(K % 4 == 0 && ldw % 4 == 0 && aligned16(w));
+    set_splitk(p, splitk_ws, splitk_ws_bytes);
+    return cdae_gemm_dispatch(p, stream);
+}
+
+int cdae_linear_dgrad(const float* dy, long lddy, const float* w, long ldw, float* dx, long lddx, int M, int N, int K, int accumulate,
+                      float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    GemmParams p = base_params();
+    p.A = dy; p.B = w; p.C = dx;
+    p.M = M; p.N = K; p.K = N; p.lda = lddy; p.ldb = ldw; p.ldc = lddx; p.accumulate = accumulate;
+    p.amode = A_PLAIN_KC; p.bmode = B_PLAIN_MC;
+    p.a_scalar = !(N % 4 == 0 && lddy % 4 == 0 && aligned16(dy));
+    p.b_scalar = !(ldw % 4 == 0 && aligned16(w));
+    set_splitk(p, accumulate ? nullptr : splitk_ws, splitk_ws_bytes);
+    return cdae_gemm_dispatch(p, stream);
+}
+
+int cdae_linear_wgrad(const float* x, long ldx, const float* dy, long lddy, float* dw, long lddw, float* dbias, int M, int N, int K,
+                      int accumulate, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    GemmParams p = base_params();
+    p.A = dy; p.B = x; p.C = dw;
+    p.M = N; p.N = K; p.K = M; p.lda = lddy; p.ldb = ldx; p.ldc = lddw; p.accumulate = accumulate;
+    p.amode = A_PLAIN_MC; p.bmode = B_PLAIN_MC;
+    p.a_scalar = !(lddy % 4 == 0 && aligned16(dy));
+    p.b_scalar = !(ldx % 4 == 0 && aligned16(x));
+    set_splitk(p, splitk_ws, splitk_ws_bytes);
+    int rc = cdae_gemm_dispatch(p, stream);
+    if (rc == 0 && dbias) rc = cdae_colsum(dy, lddy, dbias, M, N, accumulate, stream);
+    return rc;
+}
+
+int cdae_qkv_attention_fwd(const float* qkv, float* out, float* probs, int B, int T, int heads, int ch, void* stream) {
+    const long C = (long)heads * ch, C3 = 3 * C;
+    if (ch % 4) return cdae_fail("attention: head dim must be a multiple of 4");
+    GemmParams p = base_params();
+    // S = (q k^T) / sqrt(ch)   [the reference scales q and k by ch^-1/4 each, unet.py:248-251]
+    p.A = qkv; p.B = qkv + ch; p.C = probs;
+    p.M = T; p.N = T; p.K = ch; p.lda = C3; p.ldb = C3; p.ldc = T;
+    p.batch = B * heads; p.batch_inner = heads;
+    p.a_bs0 = T * C3; p.a_bs1 = 3L * ch; p.b_bs0 = T * C3; p.b_bs1 = 3L * ch;
+    p.c_bs0 = (long)heads * T * T; p.c_bs1 = (long)T * T;
+    p.alpha = 1.f / sqrtf((float)ch);
+    p.amode = A_PLAIN_KC; p.bmode = B_PLAIN_KC;
+    p.a_scalar = p.b_scalar = !aligned16(qkv);
+    int rc = cdae_gemm_dispatch(p, stream);
+    if (rc) return rc;
+    rc = cdae_softmax_rows(probs, (long)B * heads * T, T, stream);
+    if (rc) return rc;
+    // O = P V
+    GemmParams q = base_params();
+    q.A = probs; q.B = qkv + 2 * ch; q.C = out;
+    q.M = T; q.N = ch; q.K = T; q.lda = T; q.ldb = C3; q.ldc = C;
+    q.batch = B * heads; q.batch_inner = heads;
+    q.a_bs0 = (long)heads * T * T; q.a_bs1 = (long)T * T; q.b_bs0 = T * C3; q.b_bs1 = 3L * ch;
+    q.c_bs0 = T * C; q.c_bs1 = ch;
+    q.amode = A_PLAIN_KC; q.bmode = B_PLAIN_MC;
+    q.a_scalar = !(T % 4 == 0 && aligned16(probs)); q.b_scalar = !aligned16(qkv);
+    return cdae_gemm_dispatch(q, stream);
+}
+
+int cdae_qkv_attention_bwd(const float* qkv, const float* probs, const float* dout, float* dqkv, float* dprobs,
+                           int B, int T, int heads, int ch, void* stream) {
+    const long C = (long)heads * ch, C3 = 3 * C;
+    const float alpha = 1.f / sqrtf((float)ch);
+    const bool t4 = T % 4 == 0;
+    int rc;
+    {   // dV[s][c] = sum_t P[t][s] dO[t][c]
+        GemmParams p = base_params();
+        p.A = probs; p.B = dout; p.C = dqkv + 2 * ch;
+        p.M = T; p.N = ch; p.K = T; p.lda = T; p.ldb = C; p.ldc = C3;
+        p.batch = B * heads; p.batch_inner = heads;
+        p.a_bs0 = (long)heads * T * T; p.a_bs1 = (long)T * T; p.b_bs0 = T * C; p.b_bs1 = ch; p.c_bs0 = T * C3; p.c_bs1 = 3L * ch;
+        p.amode = A_PLAIN_MC; p.bmode = B_PLAIN_MC; p.a_scalar = !(t4 && aligned16(probs)); p.b_scalar = !aligned16(dout);
+        if ((rc = cdae_gemm_dispatch(p, stream))) return rc;
+    }
+    {   // dP[t][s] = sum_c dO[t][c] V[s][c]
+        GemmParams p = base_params();
+        p.A = dout; p.B = qkv + 2 * ch; p.C = dprobs;
+        p.M = T; p.N = T; p.K = ch; p.lda = C; p.ldb = C3; p.ldc = T;
+        p.batch = B * heads; p.batch_inner = heads;
+        p.a_bs0 = T * C; p.a_bs1 = ch; p.b_bs0 = T * C3; p.b_bs1 = 3L * ch; p.c_bs0 = (long)heads * T * T; p.c_bs1 = (long)T * T;
+        p.amode = A_PLAIN_KC; p.bmode = B_PLAIN_KC; p.a_scalar = !aligned16(dout); p.b_scalar = !aligned16(qkv);
+        if ((rc = cdae_gemm_dispatch(p, stream))) return rc;
+    }
+    if ((rc = cdae_softmax_rows_bwd(probs, dprobs, (long)B * heads * T, T, stream))) return rc;
+    {   // dQ[t][c] = alpha sum_s dS[t][s] K[s][c]
+        GemmParams p = base_params();
+        p.A = dprobs; p.B = qkv + ch; p.C = dqkv;
+        p.M = T; p.N = ch; p.K = T; p.lda = T; p.ldb = C3; p.ldc = C3; p.alpha = alpha;
+        p.batch = B * heads; p.batch_inner = heads;
+        p.a_bs0 = (long)heads * T * T; p.a_bs1 = (long)T * T; p.b_bs0 = T * C3; p.b_bs1 = 3L * ch; p.c_bs0 = T * C3; p.c_bs1 = 3L * ch;
+        p.amode = A_PLAIN_KC; p.bmode = B_PLAIN_MC; p.a_scalar = !(t4 && aligned16(dprobs)); p.b_scalar = !aligned16(qkv);
+        if ((rc = cdae_gemm_dispatch(p, stream))) return rc;
+    }
+    {   // dK[s][c] = alpha sum_t dS[t][s] Q[t][c]
+        GemmParams p = base_params();
+        p.A = dprobs; p.B = qkv; p.C = dqkv + ch;
+        p.M = T; p.N = ch; p.K = T; p.lda = T; p.ldb = C3; p.ldc = C3; p.alpha = alpha;
+        p.batch = B * heads; p.batch_inner = heads;
+        p.a_bs0 = (long)heads * T * T; p.a_bs1 = (long)T * T; p.b_bs0 = T * C3; p.b_bs1 = 3L * ch; p.c_bs0 = T * C3; p.c_bs1 = 3L * ch;
+        p.amode = A_PLAIN_MC; p.bmode = B_PLAIN_MC; p.a_scalar = !(t4 && aligned16(dprobs)); p.b_scalar = !aligned16(qkv);
+        if ((rc = cdae_gemm_dispatch(p, stream))) return rc;
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Build libcdae.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
+set -euo pipefail
+cd "$(dirname "$0")"
+OUT=../libcdae.so
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -I../../include"
+mkdir -p build
+$HIPCC $FLAGS -c igemm.hip -o build/igemm.o &
+$HIPCC $FLAGS -c api.hip -o build/api.o &
+$HIPCC $FLAGS -c norm.hip -o build/norm.o &
+$HIPCC $FLAGS -ffp-contract=off -c elementwise.hip -o build/elementwise.o &
+$HIPCC $FLAGS -c prof.hip -o build/prof.o &
+wait
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT build/igemm.o build/api.o build/norm.o build/elementwise.o build/prof.o
+echo "built $(realpath $OUT)"

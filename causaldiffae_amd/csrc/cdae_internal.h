@@ -1,0 +1,43 @@
+// Internal declarations shared by the HIP translation units of libcdae.so (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+enum { A_PLAIN_KC = 0, A_CONV_VEC = 1, A_CONV_GEN = 2, A_PLAIN_MC = 3 };
+enum { B_PLAIN_KC = 0, B_PLAIN_MC = 1, B_CONV_MC = 2, B_WDGRAD_MC = 3 };
+enum { OUT_ROWMAJOR = 0, OUT_NCHW = 1 };
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_LRELU = 2 };
+
+struct GemmParams {
+    const float* A; const float* B; float* C;
+    const float* bias; const float* res;
+    int M, N, K;
+    long lda, ldb, ldc;
+    int batch, batch_inner;
+    long a_bs0, a_bs1, b_bs0, b_bs1, c_bs0, c_bs1;
+    float alpha;
+    int act, out_mode, out_hw, accumulate;
+    int amode, bmode;
+    int a_scalar, b_scalar;   // operand not 16-byte vectorisable (odd K / pitch / alignment): element-wise loads
+    // conv gather geometry (A_CONV_* rows / B_CONV_MC reduction pixels)
+    int conv_M;            // number of pixels enumerated by the gather (N*Ho*Wo)
+    int H, W, Cin;         // gathered tensor: spatial dims (before the fused 2x upsample) and channels
+    int Ho, Wo;            // pixel grid the gather rows enumerate
+    int stride, up, tconv;
+    long sn, sy, sx, sc;   // element strides of the gathered tensor
+    // OHWI weight access for B_WDGRAD_MC
+    int wCout, wCin, wflip;
+    // split-K
+    int ksplit, ksplit_auto, ksplit_force, force_tile;
+    float* splitk_ws; size_t splitk_ws_bytes;
+};
+
+int cdae_gemm_dispatch(GemmParams p, void* stream);
+
+// error reporting: sets the thread-local message returned by cdae_last_error(), returns -1
+int cdae_fail(const char* msg);
+
+// lightweight per-family profiling (HIP events on the launch stream), see prof.hip
+enum { PROF_IGEMM = 0, PROF_GN = 1, PROF_SOFTMAX = 2, PROF_ELEMWISE = 3, PROF_OPT = 4, PROF_NFAM = 5 };
+void cdae_prof_begin(int family, double work, hipStream_t st);
+void cdae_prof_end(int family, hipStream_t st);

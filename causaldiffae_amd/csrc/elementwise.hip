@@ -1,0 +1,313 @@
+// elementwise.hip — HBM-bound pointwise kernels of the diffusion hot path (gfx950).
+// Built with -ffp-contract=off: the sampler updates must round exactly like the reference's
+// separate ATen ops (a*x - b*eps is two roundings + a subtraction, not an FMA), because
+// sqrt(1/abar-1) ~ 150 at the first DDIM steps amplifies any difference.
+//
+// Reference lines: q_sample gaussian_diffusion.py:201-222; p_mean_variance :336-341,355-360;
+// ddim_sample :533-558; p_sample :409-414; timestep_embedding nn.py:551-569; reparameterize
+// nn.py:460-467; softplus nn.py:108; causal_masking nn.py:290-295; update_ema nn.py:503-513.
+#include <hip/hip_runtime.h>
+#include "cdae_internal.h"
+#include "../../include/cdae.h"
+
+namespace {
+
+#define GRID_STRIDE(idx, total) \
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < (total); idx += (long)gridDim.x * blockDim.x)
+
+int grid_for(long total, int cap = 4096) {
+    long b = (total + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+__global__ void silu_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
+    GRID_STRIDE(i, n) { float v = x[i]; y[i] = v / (1.f + expf(-v)); }
+}
+__global__ void silu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, long n) {
+    GRID_STRIDE(i, n) { float v = x[i], s = 1.f / (1.f + expf(-v)); dx[i] = dy[i] * s * (1.f + v * (1.f - s)); }
+}
+
+// out[n][k] = cos(t[n]*f[k]), out[n][half+k] = sin(t[n]*f[k]); odd dim gets a trailing zero
+__global__ void temb_kernel(const float* __restrict__ t, const float* __restrict__ freqs, float* __restrict__ out, int N, int dim) {
+    const int half = dim / 2;
+    GRID_STRIDE(i, (long)N * dim) {
+        int n = (int)(i / dim), k = (int)(i - (long)n * dim);
+        float v = 0.f;
+        if (k < half) v = cosf(t[n] * freqs[k]);
+        else if (k < 2 * half) v = sinf(t[n] * freqs[k - half]);
+        out[i] = v;
+    }
+}
+
+// spaced step index -> what the network sees: float(map[t]) * scale, or the integer map itself (as float storage)
+__global__ void model_t_kernel(const long long* __restrict__ t, const long long* __restrict__ map, float scale, int rescale,
+                               float* __restrict__ out_f, long long* __restrict__ out_i, int N) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    long long m = map[t[i]];
+    if (out_i) out_i[i] = m;
+    out_f[i] = rescale ? (float)m * scale : (float)m;
+}
+
+__global__ void embedding_add_kernel(float* __restrict__ emb, const float* __restrict__ table, const long long* __restrict__ idx, int N, int D) {
+    GRID_STRIDE(i, (long)N * D) { int n = (int)(i / D), d = (int)(i - (long)n * D); emb[i] += table[idx[n] * D + d]; }
+}
+__global__ void embedding_bwd_kernel(const float* __restrict__ demb, float* __restrict__ dtable, const long long* __restrict__ idx, int N, int D) {
+    GRID_STRIDE(i, (long)N * D) { int n = (int)(i / D), d = (int)(i - (long)n * D); atomicAdd(&dtable[idx[n] * D + d], demb[i]); }
+}
+
+__global__ void axpby_kernel(float a, const float* __restrict__ x, float b, const float* __restrict__ y, float* __restrict__ out, long n) {
+    GRID_STRIDE(i, n) {
+        float r = a * x[i];
+        if (y) r = r + b * y[i];
+        out[i] = r;
+    }
+}
+
+__global__ void mul_rows_kernel(float* __restrict__ x, const float* __restrict__ m, int N, int D) {
+    GRID_STRIDE(i, (long)N * D) { x[i] *= m[i / D]; }
+}
+
+// dst[row*ldd + off + c] = src[row*lds + c]  (channel concat / slice of NHWC tensors)
+__global__ void copy2d_kernel(const float* __restrict__ src, float* __restrict__ dst, long rows, int cols, long lds, long ldd, int accumulate) {
+    if ((cols & 3) == 0 && (lds & 3) == 0 && (ldd & 3) == 0 && (((size_t)src | (size_t)dst) & 15) == 0) {
+        const int c4n = cols >> 2;
+        GRID_STRIDE(i, rows * c4n) {
+            long r = i / c4n; int c = (int)(i - r * c4n) * 4;
+            float4 v = *reinterpret_cast<const float4*>(src + r * lds + c);
+            float4* d = reinterpret_cast<float4*>(dst + r * ldd + c);
+            if (accumulate) { float4 o = *d; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            *d = v;
+        }
+    } else {
+        GRID_STRIDE(i, rows * cols) {
+            long r = i / cols; int c = (int)(i - r * cols);
+            float v = src[r * lds + c];
+            if (accumulate) v += dst[r * ldd + c];
+            dst[r * ldd + c] = v;
+        }
+    }
+}
+
+// NCHW <-> NHWC (small channel counts at the model boundary)
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, int HW) {
+    GRID_STRIDE(i, (long)N * C * HW) {
+        int c = (int)(i % C); long r = i / C; int p = (int)(r % HW); int n = (int)(r / HW);
+        dst[i] = src[((long)n * C + c) * HW + p];
+    }
+}
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, int HW) {
+    GRID_STRIDE(i, (long)N * C * HW) {
+        int p = (int)(i % HW); long r = i / HW; int c = (int)(r % C); int n = (int)(r / C);
+        dst[i] = src[((long)n * HW + p) * C + c];
+    }
+}
+
+// 2x2 sum pool of an NHWC tensor [N,2H,2W,C] -> [N,H,W,C]  (dgrad of the fused nearest-2x upsample)
+__global__ void sumpool2_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int H, int W, int C) {
+    GRID_STRIDE(i, (long)N * H * W * C) {
+        int c = (int)(i % C); long r = i / C; int x = (int)(r % W); r /= W; int y = (int)(r % H); int n = (int)(r / H);
+        const float* s = src + (((long)n * 2 * H + 2 * y) * 2 * W + 2 * x) * C + c;
+        dst[i] = (s[0] + s[C]) + (s[(long)2 * W * C] + s[(long)2 * W * C + C]);
+    }
+}
+
+// ---- sampler math.  tab = fp32 copies of the f64 tables (rounded exactly like `.float()`), [NTAB][T]
+__global__ void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise, const long long* __restrict__ t,
+                                const float* __restrict__ tab, int T, float* __restrict__ out, long per_sample, long total) {
+    GRID_STRIDE(i, total) {
+        long long tt = t[i / per_sample];
+        float a = tab[CDAE_TAB_SQRT_AC * T + tt], b = tab[CDAE_TAB_SQRT_1MAC * T + tt];
+        out[i] = a * x0[i] + b * noise[i];
+    }
+}
+
+__global__ void ddim_update_kernel(const float* __restrict__ x, const float* __restrict__ eps, const long long* __restrict__ t,
+                                   const float* __restrict__ tab, int T, float eta, const float* __restrict__ noise, int clip,
+                                   float* __restrict__ sample, float* __restrict__ pred_xstart, long per_sample, long total) {
+    GRID_STRIDE(i, total) {
+        long long tt = t[i / per_sample];
+        float c1 = tab[CDAE_TAB_SQRT_RECIP_AC * T + tt], c2 = tab[CDAE_TAB_SQRT_RECIPM1_AC * T + tt];
+        float ab = tab[CDAE_TAB_AC * T + tt], abp = tab[CDAE_TAB_AC_PREV * T + tt];
+        float xv = x[i];
+        float x0 = c1 * xv - c2 * eps[i];
+        if (clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+        float e2 = (c1 * xv - x0) / c2;
+        float sigma = eta * sqrtf((1.f - abp) / (1.f - ab)) * sqrtf(1.f - ab / abp);
+        float mean = x0 * sqrtf(abp) + sqrtf(1.f - abp - sigma * sigma) * e2;
+        float nz = tt != 0 ? 1.f : 0.f;
+        float nv = noise ? noise[i] : 0.f;
+        sample[i] = mean + nz * sigma * nv;
+        if (pred_xstart) pred_xstart[i] = x0;
+    }
+}
+
+__global__ void ddpm_update_kernel(const float* __restrict__ x, const float* __restrict__ eps, const long long* __restrict__ t,
+                                   const float* __restrict__ tab, int T, const float* __restrict__ noise, int clip,
+                                   float* __restrict__ sample, float* __restrict__ pred_xstart, long per_sample, long total) {
+    GRID_STRIDE(i, total) {
+        long long tt = t[i / per_sample];
+        float c1 = tab[CDAE_TAB_SQRT_RECIP_AC * T + tt], c2 = tab[CDAE_TAB_SQRT_RECIPM1_AC * T + tt];
+        float k1 = tab[CDAE_TAB_POST_COEF1 * T + tt], k2 = tab[CDAE_TAB_POST_COEF2 * T + tt];
+        float lv = tab[CDAE_TAB_MODEL_LOGVAR * T + tt];
+        float xv = x[i];
+        float x0 = c1 * xv - c2 * eps[i];
+        if (clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+        float mean = k1 * x0 + k2 * xv;
+        float nz = tt != 0 ? 1.f : 0.f;
+        sample[i] = mean + nz * expf(0.5f * lv) * noise[i];
+        if (pred_xstart) pred_xstart[i] = x0;
+    }
+}
+
+// ---- causal encoder glue
+// mu/var head: var = softplus(v) + 1e-8 (threshold 20 like F.softplus)
+__global__ void softplus_eps_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float add) {
+    GRID_STRIDE(i, n) { float v = x[i]; y[i] = (v > 20.f ? v : log1pf(expf(v))) + add; }
+}
+__global__ void softplus_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, long n) {
+    GRID_STRIDE(i, n) { float v = x[i]; dx[i] = dy[i] * (v > 20.f ? 1.f : 1.f / (1.f + expf(-v))); }
+}
+// z = m + sqrt(v*vscale) * eps
+__global__ void reparam_kernel(const float* __restrict__ m, const float* __restrict__ v, float vscale, const float* __restrict__ eps,
+                               float* __restrict__ z, long n) {
+    GRID_STRIDE(i, n) { z[i] = m[i] + sqrtf(v[i] * vscale) * eps[i]; }
+}
+// z_pre[n][i][:] = sum_j A[j][i] * u[n][j][:]   (A^T u);  transpose=1 gives A u (the backward)
+__global__ void causal_mask_kernel(const float* __restrict__ u, const float* __restrict__ A, float* __restrict__ out, int N, int nv, int d, int transpose) {
+    GRID_STRIDE(idx, (long)N * nv * d) {
+        int k = (int)(idx % d); long r = idx / d; int i = (int)(r % nv); int n = (int)(r / nv);
+        float s = 0.f;
+        for (int j = 0; j < nv; ++j) {
+            float a = transpose ? A[i * nv + j] : A[j * nv + i];
+            s += a * u[((long)n * nv + j) * d + k];
+        }
+        out[idx] = s;
+    }
+}
+
+// ---- optimizer: AdamW (decoupled decay, bias correction) + EMA over one flat fp32 buffer (train_util.py:292-297, nn.py:503-513)
+__global__ void adamw_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                 float* __restrict__ ema, long n, float lr, float b1, float b2, float eps, float wd,
+                                 float bc1, float sqrt_bc2, float ema_rate, float grad_scale) {
+    GRID_STRIDE(i, n) {
+        float gi = g[i] * grad_scale;
+        float pi = p[i] * (1.f - lr * wd);
+        float mi = m[i] * b1 + (1.f - b1) * gi;
+        float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+        float denom = sqrtf(vi) / sqrt_bc2 + eps;
+        pi = pi - (lr / bc1) * (mi / denom);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+        if (ema) ema[i] = ema[i] * ema_rate + (1.f - ema_rate) * pi;
+    }
+}
+
+__global__ void sqsum_kernel(const float* __restrict__ x, long n, double* __restrict__ out) {
+    double s = 0.0;
+    GRID_STRIDE(i, n) { double v = x[i]; s += v * v; }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    __shared__ double sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+// per-sample mean of (a-b)^2 over `per` elements: one block per sample
+__global__ void mse_rows_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long per) {
+    const long n = blockIdx.x;
+    float s = 0.f;
+    for (long i = threadIdx.x; i < per; i += blockDim.x) { float d = a[n * per + i] - b[n * per + i]; s += d * d; }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    __shared__ float sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[n] = ((sh[0] + sh[1]) + (sh[2] + sh[3])) / (float)per;
+}
+// d/d b of mean((a-b)^2) * gout[n]:  -2 (a-b) gout[n] / per
+__global__ void mse_rows_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ gout,
+                                    float* __restrict__ db, long per, long total) {
+    GRID_STRIDE(i, total) { db[i] = -2.f * (a[i] - b[i]) * gout[i / per] / (float)per; }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+#define LAUNCH1D(kernel, total, ...) do { \
+    cdae_prof_begin(PROF_ELEMWISE, 0.0, ST); \
+    hipLaunchKernelGGL(kernel, dim3(grid_for(total)), dim3(256), 0, ST, __VA_ARGS__); \
+    cdae_prof_end(PROF_ELEMWISE, ST); \
+    if (hipGetLastError() != hipSuccess) return cdae_fail(#kernel " launch failed"); \
+    return 0; } while (0)
+
+extern "C" {
+
+int cdae_silu_fwd(const float* x, float* y, long n, void* stream) { LAUNCH1D(silu_kernel, n, x, y, n); }
+int cdae_silu_bwd(const float* x, const float* dy, float* dx, long n, void* stream) { LAUNCH1D(silu_bwd_kernel, n, x, dy, dx, n); }
+int cdae_timestep_embed_fwd(const float* t, const float* freqs, float* out, int N, int dim, void* stream) {
+    LAUNCH1D(temb_kernel, (long)N * dim, t, freqs, out, N, dim);
+}
+int cdae_model_timesteps(const long long* t, const long long* map, float scale, int rescale, float* out_f, long long* out_i, int N, void* stream) {
+    LAUNCH1D(model_t_kernel, N, t, map, scale, rescale, out_f, out_i, N);
+}
+int cdae_embedding_add(float* emb, const float* table, const long long* idx, int N, int D, void* stream) {
+    LAUNCH1D(embedding_add_kernel, (long)N * D, emb, table, idx, N, D);
+}
+int cdae_embedding_bwd(const float* demb, float* dtable, const long long* idx, int N, int D, void* stream) {
+    LAUNCH1D(embedding_bwd_kernel, (long)N * D, demb, dtable, idx, N, D);
+}
+int cdae_axpby(float a, const float* x, float b, const float* y, float* out, long n, void* stream) { LAUNCH1D(axpby_kernel, n, a, x, b, y, out, n); }
+int cdae_mul_rows(float* x, const float* m, int N, int D, void* stream) { LAUNCH1D(mul_rows_kernel, (long)N * D, x, m, N, D); }
+int cdae_copy2d(const float* src, float* dst, long rows, int cols, long lds, long ldd, int accumulate, void* stream) {
+    LAUNCH1D(copy2d_kernel, rows * cols / 4 + 1, src, dst, rows, cols, lds, ldd, accumulate);
+}
+int cdae_nchw_to_nhwc(const float* src, float* dst, int N, int C, int HW, void* stream) { LAUNCH1D(nchw_to_nhwc_kernel, (long)N * C * HW, src, dst, N, C, HW); }
+int cdae_nhwc_to_nchw(const float* src, float* dst, int N, int C, int HW, void* stream) { LAUNCH1D(nhwc_to_nchw_kernel, (long)N * C * HW, src, dst, N, C, HW); }
+int cdae_sumpool2(const float* src, float* dst, int N, int H, int W, int C, void* stream) { LAUNCH1D(sumpool2_kernel, (long)N * H * W * C, src, dst, N, H, W, C); }
+
+int cdae_q_sample(const float* x0, const float* noise, const long long* t, const float* tab, int T, float* out, int N, long per_sample, void* stream) {
+    LAUNCH1D(q_sample_kernel, N * per_sample, x0, noise, t, tab, T, out, per_sample, N * per_sample);
+}
+int cdae_ddim_update(const float* x, const float* eps, const long long* t, const float* tab, int T, float eta, const float* noise, int clip,
+                     float* sample, float* pred_xstart, int N, long per_sample, void* stream) {
+    LAUNCH1D(ddim_update_kernel, N * per_sample, x, eps, t, tab, T, eta, noise, clip, sample, pred_xstart, per_sample, N * per_sample);
+}
+int cdae_ddpm_update(const float* x, const float* eps, const long long* t, const float* tab, int T, const float* noise, int clip,
+                     float* sample, float* pred_xstart, int N, long per_sample, void* stream) {
+    if (!noise) return cdae_fail("ddpm_update needs a noise tensor");
+    LAUNCH1D(ddpm_update_kernel, N * per_sample, x, eps, t, tab, T, noise, clip, sample, pred_xstart, per_sample, N * per_sample);
+}
+
+int cdae_softplus_fwd(const float* x, float* y, long n, float add, void* stream) { LAUNCH1D(softplus_eps_kernel, n, x, y, n, add); }
+int cdae_softplus_bwd(const float* x, const float* dy, float* dx, long n, void* stream) { LAUNCH1D(softplus_bwd_kernel, n, x, dy, dx, n); }
+int cdae_reparam(const float* m, const float* v, float vscale, const float* eps, float* z, long n, void* stream) {
+    LAUNCH1D(reparam_kernel, n, m, v, vscale, eps, z, n);
+}
+int cdae_causal_mask(const float* u, const float* A, float* out, int N, int nv, int d, int transpose, void* stream) {
+    LAUNCH1D(causal_mask_kernel, (long)N * nv * d, u, A, out, N, nv, d, transpose);
+}
+
+int cdae_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, long n, double lr, double beta1, double beta2, double eps,
+                   double weight_decay, int step, double ema_rate, double grad_scale, void* stream) {
+    const float bc1 = (float)(1.0 - pow(beta1, (double)step));
+    const float sqrt_bc2 = (float)sqrt(1.0 - pow(beta2, (double)step));
+    cdae_prof_begin(PROF_OPT, (double)n * 32.0, ST);
+    hipLaunchKernelGGL(adamw_ema_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, ST, p, g, m, v, ema, n, (float)lr, (float)beta1, (float)beta2, (float)eps,
+                       (float)weight_decay, bc1, sqrt_bc2, (float)ema_rate, (float)grad_scale);
+    cdae_prof_end(PROF_OPT, ST);
+    if (hipGetLastError() != hipSuccess) return cdae_fail("adamw_ema launch failed");
+    return 0;
+}
+int cdae_sqsum(const float* x, long n, double* out, void* stream) {
+    if (hipMemsetAsync(out, 0, sizeof(double), ST) != hipSuccess) return cdae_fail("memset failed");
+    LAUNCH1D(sqsum_kernel, n, x, n, out);
+}
+int cdae_mse_rows(const float* a, const float* b, float* out, int N, long per, void* stream) {
+    hipLaunchKernelGGL(mse_rows_kernel, dim3(N), dim3(256), 0, ST, a, b, out, per);
+    if (hipGetLastError() != hipSuccess) return cdae_fail("mse_rows launch failed");
+    return 0;
+}
+int cdae_mse_rows_bwd(const float* a, const float* b, const float* gout, float* db, int N, long per, void* stream) {
+    LAUNCH1D(mse_rows_bwd_kernel, N * per, a, b, gout, db, per, N * per);
+}
+
+}  // extern "C"

@@ -1,0 +1,464 @@
+// igemm.hip — fp32 implicit-GEMM on CDNA4 matrix cores (v_mfma_f32_32x32x2_f32), gfx950 only.
+//
+// One kernel family does every dense contraction of the CausalDiffAE hot path:
+//   C[i][j] = alpha * sum_k A(i,k) * B(j,k)  (+ bias[j]) (+ res[i][j]) (-> SiLU)
+// with pluggable operand loaders:
+//   A_PLAIN_KC   A[i][k], k contiguous                       linear / conv1x1 / QK^T / dgrad
+//   A_CONV_VEC   im2col gather of an NHWC tensor, k=(tap,cin)  conv3x3 fwd (stride 1|2, fused nearest-2x
+//                upsample, "transposed" stride-2 gather for the Downsample dgrad); needs Cin % 32 == 0
+//   A_CONV_GEN   same gather, any Cin / any element strides    stem (NCHW input), encoder convs
+//   A_PLAIN_MC   A[i][k] stored k-major (i contiguous)         wgrad (dY^T), attention backward
+//   B_PLAIN_KC   B[j][k], k contiguous                         weights [Cout][9*Cin] (OHWI), K rows of K^T
+//   B_PLAIN_MC   B[j][k] stored k-major (j contiguous)         V in P@V, W in linear dgrad, X in wgrad
+//   B_CONV_MC    k = output pixel, j=(tap,cin): shifted NHWC rows   conv3x3 wgrad
+//   B_WDGRAD_MC  k=(tap,cout), j=cin of OHWI weights, tap flipped   conv3x3 dgrad
+//
+// Numerics: v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered fp32 fmaf chain (no reduced
+// precision), so results stay within fp32 rounding of the reference's ATen path.
+//
+// Tile: BM x BN x 32, 256 threads = 4 waves (2x2), each wave (BM/2)x(BN/2) as 32x32 MFMA tiles.
+// LDS: K-contiguous operands as [rows][32+4] (conflict-free ds_read_b128: one read feeds 4 MFMAs),
+// k-major operands as [32][rows+4] (ds_read_b32, lanes along rows).  Register-staged double
+// buffering: tile t+1's global loads are issued before the MFMAs of tile t and written to the
+// other LDS buffer afterwards (one barrier per K-step).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "cdae_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDK = BK + 4;     // row pitch (floats) of a K-contiguous LDS tile
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// ---- conv gather geometry for one GEMM row (an output pixel, or for wgrad a reduction pixel)
+struct PixRow {
+    long base;     // element offset of image n
+    int iy0, ix0;  // top-left input coordinate of the 3x3 window (already * stride - pad)
+    int ok;        // row < M
+};
+
+__device__ __forceinline__ PixRow make_pixrow(const GemmParams& p, int m) {
+    PixRow r;
+    r.ok = m < p.conv_M;
+    int mm = r.ok ? m : 0;
+    int hw = p.Ho * p.Wo;
+    int n = mm / hw, rem = mm - n * hw;
+    int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    r.base = (long)n * p.sn;
+    if (p.tconv) { r.iy0 = oy + 1; r.ix0 = ox + 1; }            // transposed stride-2 gather: src = (o + 1 - k) / 2
+    else { r.iy0 = oy * p.stride - 1; r.ix0 = ox * p.stride - 1; }
+    return r;
+}
+
+// offset (elements) of input pixel for window tap (ky,kx); returns false when the tap reads padding
+__device__ __forceinline__ bool tap_offset(const GemmParams& p, const PixRow& r, int ky, int kx, long& off) {
+    int iy, ix;
+    if (p.tconv) {
+        int ty = r.iy0 - ky, tx = r.ix0 - kx;
+        if ((ty | tx) < 0 || (ty & 1) || (tx & 1)) return false;
+        iy = ty >> 1; ix = tx >> 1;
+        if (iy >= p.H || ix >= p.W) return false;
+    } else {
+        iy = r.iy0 + ky; ix = r.ix0 + kx;
+        int Hin = p.up ? 2 * p.H : p.H, Win = p.up ? 2 * p.W : p.W;
+        if (iy < 0 || ix < 0 || iy >= Hin || ix >= Win) return false;
+        if (p.up) { iy >>= 1; ix >>= 1; }
+    }
+    off = r.base + (long)iy * p.sy + (long)ix * p.sx;
+    return true;
+}
+
+template <int BM, int BN, int AMODE, int BMODE>
+__global__ __launch_bounds__(256) void igemm_kernel(const GemmParams p) {
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr bool A_MC = (AMODE == A_PLAIN_MC);
+    constexpr bool B_MC = (BMODE != B_PLAIN_KC);
+    constexpr int LDAM = BM + 4, LDBM = BN + 4;
+    constexpr int A_TILE = A_MC ? BK * LDAM : BM * LDK;
+    constexpr int B_TILE = B_MC ? BK * LDBM : BN * LDK;
+    constexpr int A_V4 = BM * BK / 4 / 256;     // float4 loads per thread per tile
+    constexpr int B_V4 = BN * BK / 4 / 256;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + 2 * A_TILE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // block -> tile (m fastest), batch on z, split-K on the upper part of z
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int bz = blockIdx.z % p.batch, ks = blockIdx.z / p.batch;
+    const int bo = bz / p.batch_inner, bi = bz - bo * p.batch_inner;
+    const float* __restrict__ Ag = p.A + bo * p.a_bs0 + bi * p.a_bs1;
+    const float* __restrict__ Bg = p.B + bo * p.b_bs0 + bi * p.b_bs1;
+
+    const int nk_total = (p.K + BK - 1) / BK;
+    const int nk_per = (nk_total + p.ksplit - 1) / p.ksplit;
+    const int kt_begin = ks * nk_per;
+    const int kt_end = min(nk_total, kt_begin + nk_per);
+
+    // ---------------------------------------------------------------- per-thread loader state
+    PixRow arow[A_V4];
+    if constexpr (AMODE == A_CONV_VEC || AMODE == A_CONV_GEN) {
+#pragma unroll
+        for (int q = 0; q < A_V4; ++q) arow[q] = make_pixrow(p, m0 + (tid >> 3) + 32 * q);
+    }
+
+    float4 areg[A_V4], breg[B_V4];
+
+    auto load_A = [&](int kt) {
+        const int k0 = kt * BK;
+        if constexpr (AMODE == A_PLAIN_KC) {
+#pragma unroll
+            for (int q = 0; q < A_V4; ++q) {
+                int m = m0 + (tid >> 3) + 32 * q, k = k0 + (tid & 7) * 4;
+                if (!p.a_scalar) areg[q] = (m < p.M && k < p.K) ? ld4(Ag + (long)m * p.lda + k) : make_float4(0, 0, 0, 0);
+                else {
+                    float v[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (m < p.M)
+                        for (int e = 0; e < 4; ++e) if (k + e < p.K) v[e] = Ag[(long)m * p.lda + k + e];
+                    areg[q] = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        } else if constexpr (AMODE == A_CONV_VEC) {
+            int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;
+            int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+            for (int q = 0; q < A_V4; ++q) {
+                long off;
+                bool ok = arow[q].ok && tap_offset(p, arow[q], ky, kx, off);
+                areg[q] = ok ? ld4(Ag + off + c0 + (tid & 7) * 4) : make_float4(0, 0, 0, 0);
+            }
+        } else if constexpr (AMODE == A_CONV_GEN) {
+#pragma unroll
+            for (int q = 0; q < A_V4; ++q) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int k = k0 + (tid & 7) * 4 + e;
+                    v[e] = 0.f;
+                    if (arow[q].ok && k < p.K) {
+                        int tap = k / p.Cin, c = k - tap * p.Cin;
+                        int ky = tap / 3, kx = tap - ky * 3;
+                        long off;
+                        if (tap_offset(p, arow[q], ky, kx, off)) v[e] = Ag[off + (long)c * p.sc];
+                    }
+                }
+                areg[q] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        } else {   // A_PLAIN_MC: element (i,k) at Ag + k*lda + i
+#pragma unroll
+            for (int q = 0; q < A_V4; ++q) {
+                int idx = tid + 256 * q;
+                int kk = idx / (BM / 4), i4 = idx - kk * (BM / 4);
+                int k = k0 + kk, i = m0 + i4 * 4;
+                const float* src = Ag + (long)k * p.lda + i;
+                if (!p.a_scalar && k < p.K && i + 3 < p.M) areg[q] = ld4(src);
+                else {
+                    float v[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (k < p.K)
+                        for (int e = 0; e < 4; ++e) if (i + e < p.M) v[e] = src[e];
+                    areg[q] = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    };
+
+    auto load_B = [&](int kt) {
+        const int k0 = kt * BK;
+        if constexpr (BMODE == B_PLAIN_KC) {
+#pragma unroll
+            for (int q = 0; q < B_V4; ++q) {
+                int n = n0 + (tid >> 3) + 32 * q, k = k0 + (tid & 7) * 4;
+                if (!p.b_scalar) breg[q] = (n < p.N && k < p.K) ? ld4(Bg + (long)n * p.ldb + k) : make_float4(0, 0, 0, 0);
+                else {
+                    float v[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (n < p.N)
+                        for (int e = 0; e < 4; ++e) if (k + e < p.K) v[e] = Bg[(long)n * p.ldb + k + e];
+                    breg[q] = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < B_V4; ++q) {
+                int idx = tid + 256 * q;
+                int kk = idx / (BN / 4), j4 = idx - kk * (BN / 4);
+                int k = k0 + kk, j = n0 + j4 * 4;
+                const float* src = nullptr;
+                bool kok = k < p.K;
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (BMODE == B_CONV_MC) {
+                    // k = pixel of the dY grid, j = tap*Cin + cin
+                    PixRow r = make_pixrow(p, k);
+                    if (p.b_scalar) {
+                        for (int e = 0; e < 4; ++e) {
+                            int jj = j + e;
+                            if (r.ok && jj < p.N) {
+                                int tap = jj / p.Cin, c = jj - tap * p.Cin;
+                                int ky = tap / 3, kx = tap - ky * 3;
+                                long off;
+                                if (tap_offset(p, r, ky, kx, off)) v[e] = Bg[off + (long)c * p.sc];
+                            }
+                        }
+                        breg[q] = make_float4(v[0], v[1], v[2], v[3]);
+                        continue;
+                    }
+                    int tap = n0 / p.Cin;                 // whole block inside one tap (Cin % BN == 0)
+                    int ky = tap / 3, kx = tap - ky * 3;
+                    long off = 0;
+                    kok = r.ok && tap_offset(p, r, ky, kx, off);
+                    src = Bg + off + (j - tap * p.Cin);
+                } else if constexpr (BMODE == B_PLAIN_MC) {
+                    src = Bg + (long)k * p.ldb + j;
+                } else {   // B_WDGRAD_MC: k = tap*Cout + co (tap of the dY gather), j = cin; OHWI weights, tap flipped
+                    int kk2 = kok ? k : 0;
+                    int tap = kk2 / p.wCout, co = kk2 - tap * p.wCout;
+                    int ft = p.wflip ? 8 - tap : tap;
+                    src = Bg + ((long)co * 9 + ft) * p.wCin + j;
+                }
+                if (kok && !p.b_scalar && j + 3 < p.N) breg[q] = ld4(src);
+                else {
+                    if (kok)
+                        for (int e = 0; e < 4; ++e) if (j + e < p.N) v[e] = src[e];
+                    breg[q] = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    };
+
+    auto store_tiles = [&](int buf) {
+        float* a = As + buf * A_TILE;
+        float* b = Bs + buf * B_TILE;
+        if constexpr (!A_MC) {
+#pragma unroll
+            for (int q = 0; q < A_V4; ++q)
+                *reinterpret_cast<float4*>(a + ((tid >> 3) + 32 * q) * LDK + (tid & 7) * 4) = areg[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < A_V4; ++q) {
+                int idx = tid + 256 * q;
+                int kk = idx / (BM / 4), i4 = idx - kk * (BM / 4);
+                *reinterpret_cast<float4*>(a + kk * LDAM + i4 * 4) = areg[q];
+            }
+        }
+        if constexpr (!B_MC) {
+#pragma unroll
+            for (int q = 0; q < B_V4; ++q)
+                *reinterpret_cast<float4*>(b + ((tid >> 3) + 32 * q) * LDK + (tid & 7) * 4) = breg[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < B_V4; ++q) {
+                int idx = tid + 256 * q;
+                int kk = idx / (BN / 4), j4 = idx - kk * (BN / 4);
+                *reinterpret_cast<float4*>(b + kk * LDBM + j4 * 4) = breg[q];
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (kt_begin < kt_end) {
+        load_A(kt_begin);
+        load_B(kt_begin);
+        store_tiles(0);
+    }
+    __syncthreads();
+
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const bool more = kt + 1 < kt_end;
+        if (more) { load_A(kt + 1); load_B(kt + 1); }
+
+        const float* a = As + cur * A_TILE;
+        const float* b = Bs + cur * B_TILE;
+#pragma unroll
+        for (int kg = 0; kg < BK / 8; ++kg) {
+            float af[TM][4], bf[TN][4];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if constexpr (!A_MC) {
+                    float4 v = *reinterpret_cast<const float4*>(a + (wm * WM + i * 32 + l31) * LDK + kg * 8 + 4 * hh);
+                    af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) af[i][e] = a[(kg * 8 + 4 * hh + e) * LDAM + wm * WM + i * 32 + l31];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (!B_MC) {
+                    float4 v = *reinterpret_cast<const float4*>(b + (wn * WN + j * 32 + l31) * LDK + kg * 8 + 4 * hh);
+                    bf[j][0] = v.x; bf[j][1] = v.y; bf[j][2] = v.z; bf[j][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bf[j][e] = b[(kg * 8 + 4 * hh + e) * LDBM + wn * WN + j * 32 + l31];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+        }
+
+        if (more) store_tiles(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    // C layout of v_mfma_f32_32x32x2: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float* __restrict__ Cg;
+    const float* __restrict__ Rg = nullptr;
+    if (p.ksplit > 1) {
+        Cg = p.splitk_ws + ((long)ks * p.batch + bz) * (long)p.M * p.N;      // dense [M][N] slab
+    } else {
+        Cg = p.C + bo * p.c_bs0 + bi * p.c_bs1;
+        if (p.res) Rg = p.res + bo * p.c_bs0 + bi * p.c_bs1;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * WN + j * 32 + l31;
+            if (col >= p.N) continue;
+            const float bv = (p.ksplit == 1 && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (row >= p.M) continue;
+                if (p.ksplit > 1) { Cg[(long)row * p.N + col] = acc[i][j][r]; continue; }
+                long addr;
+                if (p.out_mode == OUT_NCHW) {
+                    int img = row / p.out_hw, pix = row - img * p.out_hw;
+                    addr = ((long)img * p.N + col) * p.out_hw + pix;
+                } else addr = (long)row * p.ldc + col;
+                float v = acc[i][j][r] * p.alpha + bv;
+                if (Rg) v += Rg[addr];
+                if (p.act == ACT_SILU) v = v / (1.f + expf(-v));
+                else if (p.act == ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
+                if (p.accumulate) v += Cg[addr];
+                Cg[addr] = v;
+            }
+        }
+}
+
+// split-K finish: C = alpha * sum_s slab[s] + bias (+res) (-> act), deterministic order
+__global__ void splitk_reduce_kernel(const GemmParams p) {
+    long total = (long)p.batch * p.M * p.N;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        long bz = idx / ((long)p.M * p.N), rem = idx - bz * (long)p.M * p.N;
+        int row = rem / p.N, col = rem - (long)row * p.N;
+        float s = 0.f;
+        for (int k = 0; k < p.ksplit; ++k) s += p.splitk_ws[((long)k * p.batch + bz) * (long)p.M * p.N + rem];
+        int bo = bz / p.batch_inner, bi = bz - bo * p.batch_inner;
+        float* Cg = p.C + bo * p.c_bs0 + bi * p.c_bs1;
+        long addr;
+        if (p.out_mode == OUT_NCHW) {
+            int img = row / p.out_hw, pix = row - img * p.out_hw;
+            addr = ((long)img * p.N + col) * p.out_hw + pix;
+        } else addr = (long)row * p.ldc + col;
+        float v = s * p.alpha + (p.bias ? p.bias[col] : 0.f);
+        if (p.res) v += (p.res + bo * p.c_bs0 + bi * p.c_bs1)[addr];
+        if (p.act == ACT_SILU) v = v / (1.f + expf(-v));
+        else if (p.act == ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
+        if (p.accumulate) v += Cg[addr];
+        Cg[addr] = v;
+    }
+}
+
+template <int BM, int BN, int AMODE, int BMODE>
+int launch(const GemmParams& p, hipStream_t st) {
+    constexpr bool A_MC = (AMODE == A_PLAIN_MC);
+    constexpr bool B_MC = (BMODE != B_PLAIN_KC);
+    constexpr int A_TILE = A_MC ? BK * (BM + 4) : BM * LDK;
+    constexpr int B_TILE = B_MC ? BK * (BN + 4) : BN * LDK;
+    constexpr size_t smem = 2 * (A_TILE + B_TILE) * sizeof(float);
+    static bool attr_done = false;      // per-instantiation; value is idempotent so a race is benign
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, AMODE, BMODE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
+        attr_done = true;
+    }
+    dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, p.batch * p.ksplit);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, AMODE, BMODE>), grid, dim3(256), smem, st, p);
+    return hipGetLastError() == hipSuccess ? 0 : cdae_fail("igemm launch failed");
+}
+
+template <int AMODE, int BMODE>
+int launch_tiles(const GemmParams& p, int big, hipStream_t st) {
+    return big ? launch<128, 128, AMODE, BMODE>(p, st) : launch<64, 64, AMODE, BMODE>(p, st);
+}
+
+}  // namespace
+
+// Heuristics: 128x128 tiles when they fill the chip (>= ~1 block per CU), else 64x64; split-K when even
+// 64x64 tiles leave CUs idle and K is deep (low-resolution levels at small batch, wgrad).
+int cdae_gemm_dispatch(GemmParams p, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (p.M <= 0 || p.N <= 0 || p.batch <= 0) return 0;
+    if (p.batch_inner <= 0) p.batch_inner = 1;
+    const long tiles_big = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.batch;
+    const long tiles_small = (long)((p.M + 63) / 64) * ((p.N + 63) / 64) * p.batch;
+    int big = tiles_big >= 192;
+    if (p.force_tile == 64) big = 0;
+    if (p.force_tile == 128) big = 1;
+    if (p.bmode == B_CONV_MC && !p.b_scalar) {           // a vectorised wgrad block must sit inside one tap
+        if (p.Cin % 128 != 0) big = 0;
+        if (p.Cin % 64 != 0) return cdae_fail("B_CONV_MC needs Cin % 64 == 0");
+    }
+    const long tiles = big ? tiles_big : tiles_small;
+    const int nk = (p.K + BK - 1) / BK;
+    int ks = 1;
+    if (p.ksplit_auto && p.splitk_ws && tiles < 256 && nk >= 8) {
+        ks = (int)((512 + tiles - 1) / tiles);
+        if (ks > nk / 4) ks = nk / 4;
+        if (ks > 64) ks = 64;
+        size_t need = (size_t)ks * p.batch * p.M * p.N * sizeof(float);
+        while (ks > 1 && need > p.splitk_ws_bytes) { --ks; need = (size_t)ks * p.batch * p.M * p.N * sizeof(float); }
+        if (ks < 1) ks = 1;
+    }
+    if (p.ksplit_force > 0) ks = p.ksplit_force;
+    if (ks > 1 && (!p.splitk_ws || (size_t)ks * p.batch * p.M * p.N * sizeof(float) > p.splitk_ws_bytes))
+        return cdae_fail("split-K workspace too small");
+    p.ksplit = ks;
+
+    cdae_prof_begin(PROF_IGEMM, 2.0 * p.M * p.N * (double)p.K * p.batch, st);
+    int rc = -1;
+#define CASE(AM, BM_) if (p.amode == AM && p.bmode == BM_) rc = launch_tiles<AM, BM_>(p, big, st)
+    CASE(A_PLAIN_KC, B_PLAIN_KC);
+    else CASE(A_CONV_VEC, B_PLAIN_KC);
+    else CASE(A_CONV_GEN, B_PLAIN_KC);
+    else CASE(A_PLAIN_KC, B_PLAIN_MC);
+    else CASE(A_PLAIN_MC, B_PLAIN_MC);
+    else CASE(A_PLAIN_MC, B_CONV_MC);
+    else CASE(A_CONV_VEC, B_WDGRAD_MC);
+    else CASE(A_CONV_GEN, B_WDGRAD_MC);
+    else rc = cdae_fail("unsupported igemm operand mode combination");
+#undef CASE
+    if (rc == 0 && ks > 1) {
+        long total = (long)p.batch * p.M * p.N;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+        if (hipGetLastError() != hipSuccess) rc = cdae_fail("splitk reduce launch failed");
+    }
+    cdae_prof_end(PROF_IGEMM, st);
+    return rc;
+}

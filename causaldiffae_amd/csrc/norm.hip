@@ -1,0 +1,579 @@
+// norm.hip — GroupNorm32 (+scale-shift, +SiLU), BatchNorm(+LeakyReLU) and row softmax for NHWC fp32
+// activations on gfx950.  All HBM-bound: float4 loads, per-thread register accumulation with a fixed
+// channel per thread (coalesced rows), LDS only for the final cross-thread combine, wave shuffles for
+// the softmax row reductions.  Statistics are accumulated relative to a pivot sample of the same
+// group/channel so that E[x^2]-E[x]^2 never cancels catastrophically; partials are combined in f64.
+//
+// Reference semantics: GroupNorm32 nn.py:435-437,541-548 (32 groups, eps 1e-5, fp32 statistics),
+// ResBlock scale-shift unet.py:190-194, SiLU nn.py:430-432, BatchNorm2d+LeakyReLU nn.py:46-53,
+// softmax over keys unet.py:252.
+#include <hip/hip_runtime.h>
+#include "cdae_internal.h"
+#include "../../include/cdae.h"
+
+namespace {
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.f + expf(-v)); }
+
+// ------------------------------------------------------------------ GroupNorm statistics
+// grid (nchunk, N), 256 threads.  partial[((n*nchunk + chunk)*G + g)*2 + {0,1}] = (sum, sumsq) of (x - pivot_g)
+template <int VEC>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, int HW, int C, int ldx, int cpg, int G,
+                                                          int pix_per_block, float* __restrict__ partial) {
+    __shared__ float sS[256], sQ[256];
+    const int n = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    const int E = C / VEC;
+    const int rows = 256 / E;                  // host guarantees E <= 256
+    const int tid = threadIdx.x;
+    const int r = tid / E, e = tid - r * E;
+    const bool active = r < rows;
+    const float* xn = x + (long)n * HW * ldx;
+    float S = 0.f, Q = 0.f;
+    if (active) {
+        const int g = (e * VEC) / cpg;
+        const float pivot = xn[g * cpg];
+        const int p0 = chunk * pix_per_block, p1 = min(HW, p0 + pix_per_block);
+        for (int p = p0 + r; p < p1; p += rows) {
+            if (VEC == 4) {
+                float4 v = *reinterpret_cast<const float4*>(xn + (long)p * ldx + e * 4);
+                float a = v.x - pivot, b = v.y - pivot, c = v.z - pivot, d = v.w - pivot;
+                S += (a + b) + (c + d);
+                Q += (a * a + b * b) + (c * c + d * d);
+            } else {
+                float a = xn[(long)p * ldx + e] - pivot;
+                S += a; Q += a * a;
+            }
+        }
+    }
+    sS[tid] = S; sQ[tid] = Q;
+    __syncthreads();
+    if (tid < G) {
+        const int e0 = tid * cpg / VEC, e1 = (tid + 1) * cpg / VEC;
+        float s = 0.f, q = 0.f;
+        for (int rr = 0; rr < rows; ++rr)
+            for (int ee = e0; ee < e1; ++ee) { s += sS[rr * E + ee]; q += sQ[rr * E + ee]; }
+        float* out = partial + (((long)n * nchunk + chunk) * G + tid) * 2;
+        out[0] = s; out[1] = q;
+    }
+}
+
+// grid N, G threads: stats[n*G+g] = mean, stats[N*G + n*G+g] = rstd
+__global__ void gn_finalize_kernel(const float* __restrict__ x, int HW, int ldx, int cpg, int G, int nchunk, float eps,
+                                   const float* __restrict__ partial, float* __restrict__ mean, float* __restrict__ rstd) {
+    const int n = blockIdx.x, g = threadIdx.x;
+    if (g >= G) return;
+    double s = 0.0, q = 0.0;
+    for (int c = 0; c < nchunk; ++c) {
+        const float* pp = partial + (((long)n * nchunk + c) * G + g) * 2;
+        s += pp[0]; q += pp[1];
+    }
+    const double cnt = (double)HW * cpg;
+    const double pivot = x[(long)n * HW * ldx + g * cpg];
+    const double m = s / cnt;
+    double var = q / cnt - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[n * G + g] = (float)(pivot + m);
+    rstd[n * G + g] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// y = silu?( gn(x) * gamma + beta  [ * (1 + scale) + shift ] )
+template <int VEC>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, float* __restrict__ y, long total_vec,
+                                                        int HW, int C, int ldx, int ldy, int cpg, int G,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float* __restrict__ ss, int ld_ss, int do_silu) {
+    const int E = C / VEC;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total_vec; idx += (long)gridDim.x * blockDim.x) {
+        const long pix = idx / E;
+        const int e = (int)(idx - pix * E);
+        const int n = (int)(pix / HW);
+        const int c = e * VEC;
+        const int g = c / cpg;
+        const float mu = mean[n * G + g], rs = rstd[n * G + g];
+        float v[VEC], o[VEC];
+        if (VEC == 4) {
+            float4 t = *reinterpret_cast<const float4*>(x + pix * ldx + c);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else v[0] = x[pix * ldx + c];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float h = (v[i] - mu) * rs * gamma[c + i] + beta[c + i];
+            if (ss) h = h * (1.f + ss[(long)n * ld_ss + c + i]) + ss[(long)n * ld_ss + C + c + i];
+            o[i] = do_silu ? silu_f(h) : h;
+        }
+        if (VEC == 4) *reinterpret_cast<float4*>(y + pix * ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
+        else y[pix * ldy + c] = o[0];
+    }
+}
+
+// ------------------------------------------------------------------ GroupNorm backward
+// With xh = (x-mean)*rstd, a = 1+scale (or 1), u = xh*gamma+beta, h = u*a+shift, out = silu?(h):
+//   dh = dy * silu'(h);  du = dh*a;  dxh = du*gamma
+//   dx = rstd * (dxh - mean_g(dxh) - xh * mean_g(dxh*xh))
+//   dgamma[c] += sum du*xh, dbeta[c] += sum du, dscale[n][c] = sum_p dh*u, dshift[n][c] = sum_p dh
+// Pass 1 (this kernel): per (n, chunk) partial sums  [G][2] (sum dxh, sum dxh*xh) and per-channel
+// partials [C][4] (du*xh, du, dh*u, dh).  grid (nchunk, N).
+template <int VEC>
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              int HW, int C, int ldx, int lddy, int cpg, int G, int pix_per_block,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ ss, int ld_ss, int do_silu,
+                                                              float* __restrict__ gpart /*[N][nchunk][G][2]*/,
+                                                              float* __restrict__ cpart /*[N][nchunk][C][4]*/) {
+    __shared__ float sA[256], sB[256];
+    __shared__ float sC[256 * 4 * 4];          // per thread VEC x 4 channel sums (only when rows > 1)
+    const int n = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    const int E = C / VEC, rows = 256 / E, tid = threadIdx.x;
+    const int r = tid / E, e = tid - r * E;
+    const bool active = r < rows;
+    float A = 0.f, B = 0.f;
+    float ch[VEC][4];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { ch[i][0] = ch[i][1] = ch[i][2] = ch[i][3] = 0.f; }
+    if (active) {
+        const int c = e * VEC, g = c / cpg;
+        const float mu = mean[n * G + g], rs = rstd[n * G + g];
+        float gm[VEC], bt[VEC], a[VEC], sh[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            gm[i] = gamma[c + i]; bt[i] = beta[c + i];
+            a[i] = ss ? 1.f + ss[(long)n * ld_ss + c + i] : 1.f;
+            sh[i] = ss ? ss[(long)n * ld_ss + C + c + i] : 0.f;
+        }
+        const int p0 = chunk * pix_per_block, p1 = min(HW, p0 + pix_per_block);
+        for (int p = p0 + r; p < p1; p += rows) {
+            const long pix = (long)n * HW + p;
+            float xv[VEC], dv[VEC];
+            if (VEC == 4) {
+                float4 t = *reinterpret_cast<const float4*>(x + pix * ldx + c);
+                float4 d = *reinterpret_cast<const float4*>(dy + pix * lddy + c);
+                xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+                dv[0] = d.x; dv[1] = d.y; dv[2] = d.z; dv[3] = d.w;
+            } else { xv[0] = x[pix * ldx + c]; dv[0] = dy[pix * lddy + c]; }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                float xh = (xv[i] - mu) * rs;
+                float u = xh * gm[i] + bt[i];
+                float h = u * a[i] + sh[i];
+                float dh = dv[i];
+                if (do_silu) { float s = 1.f / (1.f + expf(-h)); dh *= s * (1.f + h * (1.f - s)); }
+                float du = dh * a[i];
+                float dxh = du * gm[i];
+                A += dxh; B += dxh * xh;
+                ch[i][0] += du * xh; ch[i][1] += du; ch[i][2] += dh * u; ch[i][3] += dh;
+            }
+        }
+    }
+    sA[tid] = A; sB[tid] = B;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sC[(tid * VEC + i) * 4 + k] = ch[i][k];
+    __syncthreads();
+    if (tid < G) {
+        const int e0 = tid * cpg / VEC, e1 = (tid + 1) * cpg / VEC;
+        float s = 0.f, q = 0.f;
+        for (int rr = 0; rr < rows; ++rr)
+            for (int ee = e0; ee < e1; ++ee) { s += sA[rr * E + ee]; q += sB[rr * E + ee]; }
+        float* out = gpart + (((long)n * nchunk + chunk) * G + tid) * 2;
+        out[0] = s; out[1] = q;
+    }
+    // channel partials: thread (rr=0, e) folds the rows
+    if (r == 0) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float s = 0.f;
+                for (int rr = 0; rr < rows; ++rr) s += sC[((rr * E + e) * VEC + i) * 4 + k];
+                cpart[(((long)n * nchunk + chunk) * C + e * VEC + i) * 4 + k] = s;
+            }
+    }
+}
+
+// Pass 2a: fold chunk partials.  grid N, 256 threads: gsum[n][G][2] (means), and per-(n,c) / per-c outputs.
+__global__ void gn_bwd_fold_kernel(int N, int HW, int C, int cpg, int G, int nchunk,
+                                   const float* __restrict__ gpart, const float* __restrict__ cpart,
+                                   float* __restrict__ gsum /*[N][G][2]*/, float* __restrict__ dss, int ld_dss,
+                                   float* __restrict__ nc_part /*[N][C][2]*/) {
+    const int n = blockIdx.x;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        double s = 0, q = 0;
+        for (int c = 0; c < nchunk; ++c) {
+            const float* pp = gpart + (((long)n * nchunk + c) * G + g) * 2;
+            s += pp[0]; q += pp[1];
+        }
+        const double cnt = (double)HW * cpg;
+        gsum[(n * G + g) * 2 + 0] = (float)(s / cnt);
+        gsum[(n * G + g) * 2 + 1] = (float)(q / cnt);
+    }
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double v[4] = {0, 0, 0, 0};
+        for (int k = 0; k < nchunk; ++k) {
+            const float* pp = cpart + (((long)n * nchunk + k) * C + c) * 4;
+            v[0] += pp[0]; v[1] += pp[1]; v[2] += pp[2]; v[3] += pp[3];
+        }
+        nc_part[((long)n * C + c) * 2 + 0] = (float)v[0];
+        nc_part[((long)n * C + c) * 2 + 1] = (float)v[1];
+        if (dss) { dss[(long)n * ld_dss + c] = (float)v[2]; dss[(long)n * ld_dss + C + c] = (float)v[3]; }
+    }
+}
+
+// Pass 2b: dgamma[c] (+)= sum_n, dbeta[c] (+)= sum_n
+__global__ void gn_bwd_param_kernel(int N, int C, const float* __restrict__ nc_part, float* __restrict__ dgamma,
+                                    float* __restrict__ dbeta, int accumulate) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0, b = 0;
+    for (int n = 0; n < N; ++n) { a += nc_part[((long)n * C + c) * 2]; b += nc_part[((long)n * C + c) * 2 + 1]; }
+    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)a;
+    dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)b;
+}
+
+// Pass 3: dx
+template <int VEC>
+__global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                                         long total_vec, int HW, int C, int ldx, int lddy, int lddx, int cpg, int G,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ ss, int ld_ss, int do_silu,
+                                                         const float* __restrict__ gsum, int accumulate) {
+    const int E = C / VEC;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total_vec; idx += (long)gridDim.x * blockDim.x) {
+        const long pix = idx / E;
+        const int e = (int)(idx - pix * E), n = (int)(pix / HW), c = e * VEC, g = c / cpg;
+        const float mu = mean[n * G + g], rs = rstd[n * G + g];
+        const float m1 = gsum[(n * G + g) * 2], m2 = gsum[(n * G + g) * 2 + 1];
+        float xv[VEC], dv[VEC], o[VEC];
+        if (VEC == 4) {
+            float4 t = *reinterpret_cast<const float4*>(x + pix * ldx + c);
+            float4 d = *reinterpret_cast<const float4*>(dy + pix * lddy + c);
+            xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+            dv[0] = d.x; dv[1] = d.y; dv[2] = d.z; dv[3] = d.w;
+        } else { xv[0] = x[pix * ldx + c]; dv[0] = dy[pix * lddy + c]; }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float gm = gamma[c + i];
+            float a = ss ? 1.f + ss[(long)n * ld_ss + c + i] : 1.f;
+            float sh = ss ? ss[(long)n * ld_ss + C + c + i] : 0.f;
+            float xh = (xv[i] - mu) * rs;
+            float h = (xh * gm + beta[c + i]) * a + sh;
+            float dh = dv[i];
+            if (do_silu) { float s = 1.f / (1.f + expf(-h)); dh *= s * (1.f + h * (1.f - s)); }
+            float dxh = dh * a * gm;
+            o[i] = rs * (dxh - m1 - xh * m2);
+        }
+        if (accumulate) {
+            if (VEC == 4) {
+                float4 t = *reinterpret_cast<const float4*>(dx + pix * lddx + c);
+                o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
+            } else o[0] += dx[pix * lddx + c];
+        }
+        if (VEC == 4) *reinterpret_cast<float4*>(dx + pix * lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
+        else dx[pix * lddx + c] = o[0];
+    }
+}
+
+// ------------------------------------------------------------------ BatchNorm (encoder; C <= 256 channels, rows = N*H*W)
+// partial[(chunk*C + c)*2] = (sum, sumsq) of x - x[0][c]
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, long rows_total, int C, int rows_per_block,
+                                                          float* __restrict__ partial) {
+    __shared__ float sS[256], sQ[256];
+    const int tid = threadIdx.x, rows = 256 / C, r = tid / C, c = tid - r * C;
+    float S = 0.f, Q = 0.f;
+    if (r < rows) {
+        const float pivot = x[c];
+        const long p0 = (long)blockIdx.x * rows_per_block, p1 = min(rows_total, p0 + rows_per_block);
+        for (long p = p0 + r; p < p1; p += rows) { float a = x[p * C + c] - pivot; S += a; Q += a * a; }
+    }
+    sS[tid] = S; sQ[tid] = Q;
+    __syncthreads();
+    if (tid < C) {
+        float s = 0.f, q = 0.f;
+        for (int rr = 0; rr < rows; ++rr) { s += sS[rr * C + tid]; q += sQ[rr * C + tid]; }
+        partial[((long)blockIdx.x * C + tid) * 2] = s;
+        partial[((long)blockIdx.x * C + tid) * 2 + 1] = q;
+    }
+}
+
+// training: batch mean / biased var -> (scale, shift) for the apply pass, save mean & rstd, update running stats
+// (momentum 0.1, unbiased variance) like nn.BatchNorm2d.  eval: scale/shift from the running stats.
+__global__ void bn_finalize_kernel(const float* __restrict__ x, long rows_total, int C, int nchunk, const float* __restrict__ partial,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, int training, float eps, float momentum,
+                                   float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_rstd) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float m, v;
+    if (training) {
+        double s = 0, q = 0;
+        for (int k = 0; k < nchunk; ++k) { s += partial[((long)k * C + c) * 2]; q += partial[((long)k * C + c) * 2 + 1]; }
+        double cnt = (double)rows_total, mm = s / cnt, var = q / cnt - mm * mm;
+        if (var < 0) var = 0;
+        m = (float)(x[c] + mm); v = (float)var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * cnt / (cnt - 1.0));
+    } else { m = running_mean[c]; v = running_var[c]; }
+    float rs = 1.f / sqrtf(v + eps);
+    float a = gamma[c] * rs;
+    scale[c] = a; shift[c] = beta[c] - m * a;
+    if (save_mean) { save_mean[c] = m; save_rstd[c] = rs; }
+}
+
+__global__ void affine_lrelu_kernel(const float* __restrict__ x, float* __restrict__ y, long total, int C,
+                                    const float* __restrict__ scale, const float* __restrict__ shift, float slope) {
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int c = (int)(idx % C);
+        float h = x[idx] * scale[c] + shift[c];
+        y[idx] = h > 0.f ? h : h * slope;
+    }
+}
+
+// BN+LeakyReLU backward (training-mode statistics): xh=(x-mean)*rstd, h = xh*gamma+beta, y = lrelu(h)
+// pass 1: per-channel partial sums of dh and dh*xh; pass 2 (finalize): dgamma, dbeta, means; pass 3: dx
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy, long rows_total, int C,
+                                                              int rows_per_block, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
+                                                              float* __restrict__ partial) {
+    __shared__ float sS[256], sQ[256];
+    const int tid = threadIdx.x, rows = 256 / C, r = tid / C, c = tid - r * C;
+    float S = 0.f, Q = 0.f;
+    if (r < rows) {
+        const float mu = mean[c], rs = rstd[c], gm = gamma[c], bt = beta[c];
+        const long p0 = (long)blockIdx.x * rows_per_block, p1 = min(rows_total, p0 + rows_per_block);
+        for (long p = p0 + r; p < p1; p += rows) {
+            float xh = (x[p * C + c] - mu) * rs;
+            float h = xh * gm + bt;
+            float dh = dy[p * C + c] * (h > 0.f ? 1.f : slope);
+            S += dh; Q += dh * xh;
+        }
+    }
+    sS[tid] = S; sQ[tid] = Q;
+    __syncthreads();
+    if (tid < C) {
+        float s = 0.f, q = 0.f;
+        for (int rr = 0; rr < rows; ++rr) { s += sS[rr * C + tid]; q += sQ[rr * C + tid]; }
+        partial[((long)blockIdx.x * C + tid) * 2] = s;
+        partial[((long)blockIdx.x * C + tid) * 2 + 1] = q;
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(long rows_total, int C, int nchunk, const float* __restrict__ partial,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, float* __restrict__ sums /*[C][2]*/) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0, q = 0;
+    for (int k = 0; k < nchunk; ++k) { s += partial[((long)k * C + c) * 2]; q += partial[((long)k * C + c) * 2 + 1]; }
+    dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
+    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)q;
+    sums[c * 2] = (float)(s / (double)rows_total);
+    sums[c * 2 + 1] = (float)(q / (double)rows_total);
+}
+
+__global__ void bn_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, long total, int C,
+                                 const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, float slope, const float* __restrict__ sums) {
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int c = (int)(idx % C);
+        float rs = rstd[c], gm = gamma[c];
+        float xh = (x[idx] - mean[c]) * rs;
+        float h = xh * gm + beta[c];
+        float dh = dy[idx] * (h > 0.f ? 1.f : slope);
+        dx[idx] = gm * rs * (dh - sums[c * 2] - xh * sums[c * 2 + 1]);
+    }
+}
+
+// ------------------------------------------------------------------ row softmax (in place), one wave per row
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s, long rows, int T) {
+    const int lane = threadIdx.x & 63;
+    const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* p = s + row * T;
+    float v[16];                                  // T <= 1024; statically indexed (stays in registers)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < T ? p[c] : -INFINITY;
+        mx = fmaxf(mx, v[i]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < T ? expf(v[i] - mx) : 0.f;
+        sum += v[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = lane + 64 * i;
+        if (c < T) p[c] = v[i] * inv;
+    }
+}
+
+// dS = P * (dP - rowsum(dP * P)), in place on dP
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __restrict__ P, float* __restrict__ dP, long rows, int T) {
+    const int lane = threadIdx.x & 63;
+    const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* p = P + row * T;
+    float* d = dP + row * T;
+    float dot = 0.f;
+    for (int c = lane; c < T; c += 64) dot += p[c] * d[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+    for (int c = lane; c < T; c += 64) d[c] = p[c] * (d[c] - dot);
+}
+
+int grid_for(long total, int per_block = 256, int cap = 4096) {
+    long b = (total + per_block - 1) / per_block;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+int gn_chunks(int HW, int N, int E) {
+    int rows = 256 / E;
+    int nchunk = HW / (rows * 8);              // >= 8 pixels per thread
+    if (nchunk < 1) nchunk = 1;
+    while (nchunk > 1 && (long)nchunk * N > 2048) nchunk >>= 1;
+    if (nchunk > CDAE_GN_MAX_CHUNKS) nchunk = CDAE_GN_MAX_CHUNKS;
+    return nchunk;
+}
+
+}  // namespace
+
+#define CHECK_LAUNCH(msg) do { if (hipGetLastError() != hipSuccess) return cdae_fail(msg); } while (0)
+
+extern "C" {
+
+// workspace floats needed by cdae_gn_stats / cdae_gn_bwd
+size_t cdae_gn_workspace_floats(int N, int C) {
+    return (size_t)N * CDAE_GN_MAX_CHUNKS * ((size_t)32 * 2 + (size_t)C * 4) + (size_t)N * 32 * 2 + (size_t)N * C * 2;
+}
+
+int cdae_gn_stats(const float* x, int N, int HW, int C, int ldx, int groups, float eps, float* mean, float* rstd,
+                  float* ws, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (C % groups) return cdae_fail("gn: C % groups != 0");
+    const int cpg = C / groups;
+    const int VEC = (cpg % 4 == 0 && ldx % 4 == 0) ? 4 : 1;
+    const int E = C / VEC;
+    if (E > 256 || groups > 256) return cdae_fail("gn: unsupported channel count for this vector width");
+    const int nchunk = gn_chunks(HW, N, E);
+    const int ppb = (HW + nchunk - 1) / nchunk;
+    cdae_prof_begin(PROF_GN, (double)N * HW * C * 4.0, st);
+    if (VEC == 4) hipLaunchKernelGGL(gn_partial_kernel<4>, dim3(nchunk, N), dim3(256), 0, st, x, HW, C, ldx, cpg, groups, ppb, ws);
+    else hipLaunchKernelGGL(gn_partial_kernel<1>, dim3(nchunk, N), dim3(256), 0, st, x, HW, C, ldx, cpg, groups, ppb, ws);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(groups < 64 ? 64 : groups), 0, st, x, HW, ldx, cpg, groups, nchunk, eps, ws, mean, rstd);
+    cdae_prof_end(PROF_GN, st);
+    CHECK_LAUNCH("gn_stats launch failed");
+    return 0;
+}
+
+int cdae_gn_apply(const float* x, float* y, int N, int HW, int C, int ldx, int ldy, int groups, const float* mean, const float* rstd,
+                  const float* gamma, const float* beta, const float* scale_shift, int ld_ss, int silu, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int cpg = C / groups;
+    const int VEC = (cpg % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0) ? 4 : 1;
+    const long total = (long)N * HW * (C / VEC);
+    cdae_prof_begin(PROF_GN, (double)N * HW * C * 8.0, st);
+    if (VEC == 4) hipLaunchKernelGGL(gn_apply_kernel<4>, dim3(grid_for(total)), dim3(256), 0, st, x, y, total, HW, C, ldx, ldy, cpg, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu);
+    else hipLaunchKernelGGL(gn_apply_kernel<1>, dim3(grid_for(total)), dim3(256), 0, st, x, y, total, HW, C, ldx, ldy, cpg, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu);
+    cdae_prof_end(PROF_GN, st);
+    CHECK_LAUNCH("gn_apply launch failed");
+    return 0;
+}
+
+int cdae_gn_bwd(const float* x, const float* dy, float* dx, int N, int HW, int C, int ldx, int lddy, int lddx, int groups,
+                const float* mean, const float* rstd, const float* gamma, const float* beta, const float* scale_shift, int ld_ss, int silu,
+                float* dgamma, float* dbeta, int accumulate_params, float* d_scale_shift, int ld_dss, int accumulate_dx,
+                float* ws, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int cpg = C / groups;
+    const int VEC = (cpg % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0) ? 4 : 1;
+    const int E = C / VEC;
+    if (E > 256) return cdae_fail("gn_bwd: unsupported channel count");
+    const int nchunk = gn_chunks(HW, N, E);
+    const int ppb = (HW + nchunk - 1) / nchunk;
+    float* gpart = ws;
+    float* cpart = gpart + (size_t)N * nchunk * groups * 2;
+    float* gsum = cpart + (size_t)N * nchunk * C * 4;
+    float* ncp = gsum + (size_t)N * groups * 2;
+    const long total = (long)N * HW * E;
+    cdae_prof_begin(PROF_GN, (double)N * HW * C * 20.0, st);
+    if (VEC == 4) hipLaunchKernelGGL(gn_bwd_partial_kernel<4>, dim3(nchunk, N), dim3(256), 0, st, x, dy, HW, C, ldx, lddy, cpg, groups, ppb, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gpart, cpart);
+    else hipLaunchKernelGGL(gn_bwd_partial_kernel<1>, dim3(nchunk, N), dim3(256), 0, st, x, dy, HW, C, ldx, lddy, cpg, groups, ppb, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gpart, cpart);
+    hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3(N), dim3(256), 0, st, N, HW, C, cpg, groups, nchunk, gpart, cpart, gsum, d_scale_shift, ld_dss, ncp);
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, st, N, C, ncp, dgamma, dbeta, accumulate_params);
+    if (VEC == 4) hipLaunchKernelGGL(gn_bwd_dx_kernel<4>, dim3(grid_for(total)), dim3(256), 0, st, x, dy, dx, total, HW, C, ldx, lddy, lddx, cpg, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gsum, accumulate_dx);
+    else hipLaunchKernelGGL(gn_bwd_dx_kernel<1>, dim3(grid_for(total)), dim3(256), 0, st, x, dy, dx, total, HW, C, ldx, lddy, lddx, cpg, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gsum, accumulate_dx);
+    cdae_prof_end(PROF_GN, st);
+    CHECK_LAUNCH("gn_bwd launch failed");
+    return 0;
+}
+
+size_t cdae_bn_workspace_floats(int C) { return (size_t)CDAE_BN_MAX_CHUNKS * C * 2 + (size_t)C * 2; }
+
+int cdae_bn_lrelu_fwd(const float* x, float* y, long rows, int C, const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, int training, float eps, float momentum, float slope, float* scale, float* shift,
+                      float* save_mean, float* save_rstd, float* ws, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (C > 256) return cdae_fail("bn: C > 256 unsupported");
+    int nchunk = 1;
+    if (training) {
+        nchunk = (int)((rows + 1023) / 1024);
+        if (nchunk > CDAE_BN_MAX_CHUNKS) nchunk = CDAE_BN_MAX_CHUNKS;
+        if (nchunk < 1) nchunk = 1;
+        int rpb = (int)((rows + nchunk - 1) / nchunk);
+        hipLaunchKernelGGL(bn_partial_kernel, dim3(nchunk), dim3(256), 0, st, x, rows, C, rpb, ws);
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, st, x, rows, C, nchunk, ws, gamma, beta, running_mean, running_var,
+                       training, eps, momentum, scale, shift, save_mean, save_rstd);
+    const long total = rows * C;
+    hipLaunchKernelGGL(affine_lrelu_kernel, dim3(grid_for(total)), dim3(256), 0, st, x, y, total, C, scale, shift, slope);
+    CHECK_LAUNCH("bn_lrelu_fwd launch failed");
+    return 0;
+}
+
+int cdae_bn_lrelu_bwd(const float* x, const float* dy, float* dx, long rows, int C, const float* gamma, const float* beta,
+                      const float* save_mean, const float* save_rstd, float slope, float* dgamma, float* dbeta, int accumulate,
+                      float* ws, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (C > 256) return cdae_fail("bn: C > 256 unsupported");
+    int nchunk = (int)((rows + 1023) / 1024);
+    if (nchunk > CDAE_BN_MAX_CHUNKS) nchunk = CDAE_BN_MAX_CHUNKS;
+    if (nchunk < 1) nchunk = 1;
+    int rpb = (int)((rows + nchunk - 1) / nchunk);
+    float* sums = ws + (size_t)CDAE_BN_MAX_CHUNKS * C * 2;
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nchunk), dim3(256), 0, st, x, dy, rows, C, rpb, save_mean, save_rstd, gamma, beta, slope, ws);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, rows, C, nchunk, ws, dgamma, dbeta, accumulate, sums);
+    const long total = rows * C;
+    hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(grid_for(total)), dim3(256), 0, st, x, dy, dx, total, C, save_mean, save_rstd, gamma, beta, slope, sums);
+    CHECK_LAUNCH("bn_lrelu_bwd launch failed");
+    return 0;
+}
+
+int cdae_softmax_rows(float* s, long rows, int T, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (T > 1024) return cdae_fail("softmax: T > 1024 unsupported");
+    cdae_prof_begin(PROF_SOFTMAX, (double)rows * T * 8.0, st);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, s, rows, T);
+    cdae_prof_end(PROF_SOFTMAX, st);
+    CHECK_LAUNCH("softmax launch failed");
+    return 0;
+}
+
+int cdae_softmax_rows_bwd(const float* P, float* dP, long rows, int T, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, P, dP, rows, T);
+    CHECK_LAUNCH("softmax_bwd launch failed");
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,74 @@
+// prof.hip — error string + opt-in per-kernel-family timing with HIP events on the launch stream.
+// Used by bench.py to measure the dominant kernel's average launch duration live (roofline.achieved);
+// disabled by default so the timed region and graph capture never see an event record.
+#include <hip/hip_runtime.h>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "cdae_internal.h"
+#include "../../include/cdae.h"
+
+namespace {
+thread_local std::string g_err;
+struct Rec { int fam; double work; hipEvent_t a, b; };
+std::mutex g_mu;
+bool g_on = false;
+std::vector<Rec> g_recs;
+std::vector<hipEvent_t> g_pool;
+thread_local hipEvent_t t_start = nullptr;
+thread_local double t_work = 0;
+
+hipEvent_t get_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e; hipEventCreate(&e); return e;
+}
+}  // namespace
+
+int cdae_fail(const char* msg) { g_err = msg ? msg : "unknown"; return -1; }
+
+void cdae_prof_begin(int fam, double work, hipStream_t st) {
+    if (!g_on) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    t_start = get_event();
+    t_work = work;
+    hipEventRecord(t_start, st);
+}
+
+void cdae_prof_end(int fam, hipStream_t st) {
+    if (!g_on || !t_start) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    hipEvent_t e = get_event();
+    hipEventRecord(e, st);
+    g_recs.push_back({fam, t_work, t_start, e});
+    t_start = nullptr;
+}
+
+extern "C" {
+
+const char* cdae_last_error(void) { return g_err.c_str(); }
+
+int cdae_version(void) { return CDAE_VERSION; }
+
+int cdae_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_on = on != 0;
+    return 0;
+}
+
+// Synchronises the device, folds all recorded launches into per-family totals and clears the log.
+// ms/work/launches are arrays of CDAE_PROF_FAMILIES entries.
+int cdae_prof_read(double* ms, double* work, long long* launches) {
+    if (hipDeviceSynchronize() != hipSuccess) return cdae_fail("hipDeviceSynchronize failed");
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (int i = 0; i < PROF_NFAM; ++i) { ms[i] = 0; work[i] = 0; launches[i] = 0; }
+    for (auto& r : g_recs) {
+        float t = 0.f;
+        hipEventElapsedTime(&t, r.a, r.b);
+        ms[r.fam] += t; work[r.fam] += r.work; launches[r.fam] += 1;
+        g_pool.push_back(r.a); g_pool.push_back(r.b);
+    }
+    g_recs.clear();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,49 @@
+"""Distributed bootstrap (reference improved_diffusion/dist_util.py, which used mpi4py + gloo): one process per
+GPU, torchrun-style env rendezvous, backend "nccl" (= RCCL over xGMI on ROCm) on GPUs and gloo on CPU."""
+import io
+import os
+
+import torch as th
+import torch.distributed as dist
+
+GPUS_PER_NODE = 8
+
+
+def setup_dist(backend=None):
+    """Initialise the default process group from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (single process if unset)."""
+    if dist.is_initialized():
+        return
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29512")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend is None:
+        backend = "nccl" if th.cuda.is_available() else "gloo"
+    if th.cuda.is_available():
+        th.cuda.set_device(int(os.environ.get("LOCAL_RANK", int(os.environ["RANK"]) % max(1, th.cuda.device_count()))))
+    dist.init_process_group(backend=backend, init_method="env://")
+
+
+def dev():
+    if th.cuda.is_available():
+        return th.device(f"cuda:{th.cuda.current_device()}")
+    return th.device("cpu")
+
+
+def load_state_dict(path, **kwargs):
+    """Rank 0 reads the file, every rank receives the bytes (the reference MPI-broadcasts them, dist_util.py:54-64)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return th.load(path, **kwargs)
+    obj = [open(path, "rb").read() if dist.get_rank() == 0 else None]
+    dist.broadcast_object_list(obj, src=0)
+    return th.load(io.BytesIO(obj[0]), **kwargs)
+
+
+def sync_params(params):
+    """Broadcast tensors from rank 0 (a no-op in the reference, dist_util.py:67-74: fixed)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    for p in params:
+        with th.no_grad():
+            dist.broadcast(p, 0)

@@ -1,0 +1,295 @@
+"""Building blocks with the reference's names, constructor signatures and state-dict keys
+(reference improved_diffusion/nn.py), computing through the HIP kernels in ops.py.
+
+Parameters are created and initialised on the host (torch is plumbing for memory + init RNG); every
+forward runs on the GPU through libcdae.so and raises on CPU tensors.
+"""
+import math
+
+import torch as th
+import torch.nn as nn
+
+from . import ops
+
+REP_EPS = 1e-8
+
+
+# ----------------------------------------------------------------------------- primitive layers
+class SiLU(nn.Module):
+    """x * sigmoid(x)  (reference nn.py:430-432)."""
+
+    def forward(self, x):
+        return ops.silu(x)
+
+
+class LeakyReLU(nn.Module):
+    def __init__(self, negative_slope=0.01):
+        super().__init__()
+        self.negative_slope = negative_slope
+
+    def forward(self, x):       # only reached when someone runs the Sequential by hand
+        raise NotImplementedError("LeakyReLU is fused into the preceding BatchNorm / Linear kernel")
+
+
+class Identity(nn.Identity):
+    pass
+
+
+class Dropout(nn.Module):
+    def __init__(self, p=0.0):
+        super().__init__()
+        self.p = p
+
+    def forward(self, x):
+        if self.p > 0.0 and self.training:
+            raise NotImplementedError("dropout > 0 is not on the CausalDiffAE hot path (every config uses 0.0)")
+        return x
+
+
+class Linear(nn.Module):
+    """nn.Linear replacement: y = x W^T + b on the MFMA GEMM kernel."""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(th.empty(out_features, in_features))
+        self.bias = nn.Parameter(th.empty(out_features)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if bias:
+            bound = 1 / math.sqrt(in_features)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x, act=ops.ACT_NONE, res=None):
+        return ops.linear(x, self.weight, self.bias, res=res, act=act)
+
+
+class Embedding(nn.Module):
+    def __init__(self, num, dim):
+        super().__init__()
+        self.weight = nn.Parameter(th.randn(num, dim))
+
+
+class ConvNd(nn.Module):
+    """3x3 (pad 1, stride 1|2) or 1x1 convolution.  The weight keeps the reference's logical shape
+    ([Cout,Cin,k,k] / [Cout,Cin,1] for dims=1) so state dicts interchange; 3x3 weights are stored OHWI."""
+
+    def __init__(self, dims, in_channels, out_channels, kernel_size, stride=1, padding=0):
+        super().__init__()
+        if dims not in (1, 2):
+            raise ValueError(f"unsupported dimensions: {dims}")
+        if not ((kernel_size == 3 and padding == 1 and dims == 2) or (kernel_size == 1 and padding == 0)):
+            raise ValueError("only 3x3/pad 1 (2-D) and 1x1 convolutions exist on the CausalDiffAE hot path")
+        self.dims, self.in_channels, self.out_channels = dims, in_channels, out_channels
+        self.kernel_size, self.stride = kernel_size, stride
+        shape = (out_channels, in_channels) + (kernel_size,) * dims
+        w = th.empty(shape)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        if kernel_size == 3:
+            w = w.contiguous(memory_format=th.channels_last)
+        self.weight = nn.Parameter(w)
+        bound = 1 / math.sqrt(in_channels * kernel_size ** dims)
+        self.bias = nn.Parameter(th.empty(out_channels).uniform_(-bound, bound))
+
+    def forward(self, x, res=None, up=False, out_nchw=False):
+        if self.kernel_size == 3:
+            return ops.conv3x3(x, self.weight, self.bias, res=res, stride=self.stride, up=up, out_nchw=out_nchw)
+        if x.dim() == 3:       # [B, C, T] (AttentionBlock convention)
+            y = ops.conv1x1(x.unsqueeze(-1), self.weight, self.bias, None if res is None else res.unsqueeze(-1))
+            return y.squeeze(-1)
+        return ops.conv1x1(x, self.weight, self.bias, res)
+
+
+def conv_nd(dims, *args, **kwargs):
+    """Create a 1D or 2D convolution module (reference nn.py:470-480)."""
+    return ConvNd(dims, *args, **kwargs)
+
+
+def linear(*args, **kwargs):
+    return Linear(*args, **kwargs)
+
+
+def avg_pool_nd(*args, **kwargs):
+    raise NotImplementedError("avg-pool downsampling (conv_resample=False) is not used by CausalDiffAE")
+
+
+class GroupNorm32(nn.Module):
+    """GroupNorm with fp32 statistics (reference nn.py:435-437)."""
+
+    def __init__(self, num_groups, num_channels, eps=1e-5):
+        super().__init__()
+        self.num_groups, self.num_channels, self.eps = num_groups, num_channels, eps
+        self.weight = nn.Parameter(th.ones(num_channels))
+        self.bias = nn.Parameter(th.zeros(num_channels))
+
+    def forward(self, x, scale_shift=None, silu=False):
+        return ops.group_norm(x, self.weight, self.bias, scale_shift, silu, self.num_groups, self.eps)
+
+
+def normalization(channels):
+    return GroupNorm32(32, channels)
+
+
+class BatchNorm2d(nn.Module):
+    def __init__(self, num_features, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.weight = nn.Parameter(th.ones(num_features))
+        self.bias = nn.Parameter(th.zeros(num_features))
+        self.register_buffer("running_mean", th.zeros(num_features))
+        self.register_buffer("running_var", th.ones(num_features))
+        self.register_buffer("num_batches_tracked", th.tensor(0, dtype=th.long))
+
+    def forward(self, x, slope=0.01):
+        """BatchNorm fused with the LeakyReLU that always follows it in the encoder."""
+        if self.training:
+            self.num_batches_tracked += 1
+        return ops.bn_lrelu(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
+                            self.eps, self.momentum, slope)
+
+
+# ----------------------------------------------------------------------------- helpers kept from the reference API
+def zero_module(module):
+    for p in module.parameters():
+        p.detach().zero_()
+    return module
+
+
+def scale_module(module, scale):
+    for p in module.parameters():
+        p.detach().mul_(scale)
+    return module
+
+
+def mean_flat(tensor):
+    return tensor.mean(dim=list(range(1, len(tensor.shape))))
+
+
+def update_ema(target_params, source_params, rate=0.99):
+    for targ, src in zip(target_params, source_params):
+        targ.detach().mul_(rate).add_(src, alpha=1 - rate)
+
+
+_FREQ_CACHE = {}
+
+
+def _freqs(dim, max_period, device):
+    key = (dim, max_period, str(device))
+    f = _FREQ_CACHE.get(key)
+    if f is None:
+        half = dim // 2
+        # computed on the host exactly like the reference (nn.py:562-564) and uploaded once
+        f = th.exp(-math.log(max_period) * th.arange(start=0, end=half, dtype=th.float32) / half).to(device)
+        _FREQ_CACHE[key] = f
+    return f
+
+
+def timestep_embedding(timesteps, dim, max_period=10000):
+    """Sinusoidal timestep embeddings [N x dim] (reference nn.py:551-569)."""
+    return ops.timestep_embedding(timesteps, _freqs(dim, max_period, timesteps.device), dim)
+
+
+def checkpoint(func, inputs, params, flag):
+    """Activation recomputation (reference nn.py:572-618) via torch.utils.checkpoint."""
+    if flag:
+        from torch.utils.checkpoint import checkpoint as _ckpt
+        return _ckpt(func, *inputs, use_reentrant=False)
+    return func(*inputs)
+
+
+def kl_normal(qm, qv, pm, pv):
+    """Element-wise KL(N(qm,qv) || N(pm,pv)) summed over the last dim (reference nn.py:440-457)."""
+    element_wise = 0.5 * (th.log(pv) - th.log(qv) + qv / pv + (qm - pm).pow(2) / pv - 1)
+    return element_wise.sum(-1)
+
+
+_RNG_OVERRIDE = {}
+
+
+class rng_override:
+    """Context manager that injects the normal / Bernoulli draws of UNetModel.forward (tests, parity):
+    with rng_override(eps_z=..., cfg_mask=...): model(...)"""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        _RNG_OVERRIDE.update(self.kw)
+
+    def __exit__(self, *a):
+        for k in self.kw:
+            _RNG_OVERRIDE.pop(k, None)
+
+
+def reparameterize(m, v, eps=None):
+    """z = m + sqrt(v) * eps (reference nn.py:460-467).  eps is drawn on the device unless injected."""
+    if eps is None:
+        eps = _RNG_OVERRIDE.get("eps_z")
+    if eps is None:
+        eps = th.randn(m.size(), device=m.device)
+    return m + (v ** 0.5) * eps.to(m.device)
+
+
+# ----------------------------------------------------------------------------- causal semantic encoder
+class GaussianConvEncoder(nn.Module):
+    """[conv3x3 s2 -> BatchNorm2d -> LeakyReLU] x L -> flatten -> (fc_mu, softplus(fc_var)+1e-8)
+    (reference nn.py:15-110).  Constructor signature and parameter names follow the reference."""
+
+    def __init__(self, in_channels, latent_dim, hidden_dims=None, beta=4, gamma=1000., max_capacity=25,
+                 Capacity_max_iter=1e5, loss_type='B', num_vars=4, **kwargs):
+        super().__init__()
+        self.latent_dim, self.in_channels, self.num_vars = latent_dim, in_channels, num_vars
+        if hidden_dims is None:
+            hidden_dims = [16, 32, 32, 64, 64, 128] if num_vars == 4 else [16, 32, 64, 128]
+        self.hidden_dims = list(hidden_dims)
+        mods = []
+        c = in_channels
+        for h in hidden_dims:
+            mods.append(nn.Sequential(ConvNd(2, c, h, 3, stride=2, padding=1), BatchNorm2d(h), LeakyReLU()))
+            c = h
+        self.encoder = nn.Sequential(*mods)
+        self.fc_mu = Linear(hidden_dims[-1] * 4, latent_dim)
+        self.fc_var = Linear(hidden_dims[-1] * 4, latent_dim)
+
+    def encode(self, input):
+        h = input
+        for blk in self.encoder:
+            h = blk[1](blk[0](h))                       # conv -> fused BN+LeakyReLU
+        flat = ops.to_nchw(h).reshape(h.shape[0], -1)   # th.flatten on the NCHW order the fc weights expect
+        mu = self.fc_mu(flat)
+        var = ops.softplus_eps(self.fc_var(flat), REP_EPS)
+        return [mu, var]
+
+
+class MLP(nn.Module):
+    """Linear(d -> latent) LeakyReLU Linear(latent -> d)  (reference nn.py:225-240)."""
+
+    def __init__(self, latent_dim, num_var):
+        super().__init__()
+        self.latent_dim, self.num_var = latent_dim, num_var
+        self.net = nn.Sequential(Linear(latent_dim // num_var, latent_dim), LeakyReLU(), Linear(latent_dim, latent_dim // num_var))
+
+    def forward(self, x, res=None):
+        return self.net[2](self.net[0](x, act=ops.ACT_LRELU), res=res)
+
+
+class CausalModeling(nn.Module):
+    """Mask by the adjacency A, per-variable MLP, add back the exogenous noise (reference nn.py:244-312)."""
+
+    def __init__(self, latent_dim, num_var=None, learn=False, **kwargs):
+        super().__init__()
+        self.latent_dim, self.num_var = latent_dim, num_var
+        if learn:
+            self.A = nn.Parameter(th.zeros(num_var, num_var))
+        else:
+            self.A = th.tensor([[0, 1], [0, 0]])
+        self.nonlinearities = nn.ModuleDict({str(i): MLP(latent_dim=latent_dim, num_var=num_var) for i in range(num_var)})
+
+    def causal_masking(self, u, A):
+        return ops.causal_mask(u, A.to(u.device).float(), self.num_var)            # A^T u on [N, nv, d]
+
+    def nonlinearity_add_back_noise(self, u, z_pre):
+        N = u.shape[0]
+        d = self.latent_dim // self.num_var
+        u3 = u.reshape(N, self.num_var, d)
+        outs = [self.nonlinearities[str(i)](z_pre[:, i, :], res=u3[:, i, :].contiguous()) for i in range(self.num_var)]
+        return th.cat(outs, dim=1)

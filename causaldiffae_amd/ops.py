@@ -1,0 +1,495 @@
+"""Tensor-level wrappers over the C-ABI (include/cdae.h) with autograd.
+
+Layout contract of this package: activations are torch tensors of LOGICAL shape [N, C, H, W] whose
+storage is NHWC ("channels_last" strides), so they stay drop-in compatible with code written against
+the reference's NCHW API while every kernel sees coalesced channel-contiguous rows.  3x3 conv weights
+keep the reference's logical [Cout, Cin, 3, 3] shape (state-dict compatible) with channels_last
+storage = OHWI.  Nothing here computes on the host; a CPU tensor raises (see _lib.ptr).
+"""
+import torch
+from torch.autograd import Function
+
+from ._lib import check, lib, ptr, splitk_ws, stream, workspace, SPLITK_BYTES
+
+ACT_NONE, ACT_SILU, ACT_LRELU = 0, 1, 2
+
+
+# ----------------------------------------------------------------------------- layout helpers
+def new_act(N, C, H, W, device):
+    """Fresh activation: logical [N,C,H,W], NHWC storage."""
+    return torch.empty((N, H, W, C), dtype=torch.float32, device=device).permute(0, 3, 1, 2)
+
+
+def is_nhwc(x):
+    return x.dim() == 4 and x.permute(0, 2, 3, 1).is_contiguous()
+
+
+def to_nhwc(x):
+    """Return x as a logical-NCHW tensor with NHWC storage (no copy if it already is)."""
+    if is_nhwc(x):
+        return x
+    x = x.contiguous()
+    N, C, H, W = x.shape
+    out = new_act(N, C, H, W, x.device)
+    check(lib.cdae_nchw_to_nhwc(ptr(x), ptr(out), N, C, H * W, stream()))
+    return out
+
+
+def to_nchw(x):
+    """Return a plain NCHW-contiguous copy of a NHWC-stored activation."""
+    if x.is_contiguous():
+        return x
+    x = to_nhwc(x)
+    N, C, H, W = x.shape
+    out = torch.empty((N, C, H, W), dtype=torch.float32, device=x.device)
+    check(lib.cdae_nhwc_to_nchw(ptr(x), ptr(out), N, C, H * W, stream()))
+    return out
+
+
+def ohwi(w):
+    """Physical OHWI view check of a logical [Cout,Cin,3,3] weight (copy only if someone re-laid it out)."""
+    if w.permute(0, 2, 3, 1).is_contiguous():
+        return w
+    return w.contiguous(memory_format=torch.channels_last)
+
+
+def _f32c(t):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _sk(dev):
+    return ptr(splitk_ws(dev)), SPLITK_BYTES
+
+
+# ----------------------------------------------------------------------------- conv3x3
+class _Conv3x3(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, res, stride, up, out_nchw):
+        N, Cin, H, W = x.shape
+        Cout = w.shape[0]
+        w = ohwi(w)
+        Ho = 2 * H if up else (H - 1) // stride + 1
+        Wo = 2 * W if up else (W - 1) // stride + 1
+        if Cin >= 32 and not is_nhwc(x):
+            x = to_nhwc(x)
+        dev = x.device
+        out = torch.empty((N, Cout, Ho, Wo), dtype=torch.float32, device=dev) if out_nchw else new_act(N, Cout, Ho, Wo, dev)
+        if res is not None:
+            res = to_nhwc(res)
+        ws, wsb = _sk(dev)
+        check(lib.cdae_conv3x3_fwd(ptr(x), x.stride(0), x.stride(2), x.stride(3), x.stride(1), ptr(w), ptr(b), ptr(res),
+                                   ptr(out), Cout, 1 if out_nchw else 0, N, H, W, Cin, Cout, stride, 1 if up else 0,
+                                   ws, wsb, stream()))
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, up, out_nchw, b is not None, res is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, up, out_nchw, has_b, has_res = ctx.cfg
+        N, Cin, H, W = x.shape
+        Cout = w.shape[0]
+        dev = x.device
+        dy = to_nhwc(dy)                       # NHWC rows, pitch Cout
+        Ho, Wo = dy.shape[2], dy.shape[3]
+        ws, wsb = _sk(dev)
+        dx = dw = db = dres = None
+        if ctx.needs_input_grad[0]:
+            if up:
+                dxu = new_act(N, Cin, Ho, Wo, dev)
+                check(lib.cdae_conv3x3_dgrad(ptr(dy), Cout, ptr(w), ptr(dxu), Cin, N, H, W, Cin, Cout, 1, 1, 0, ws, wsb, stream()))
+                dx = new_act(N, Cin, H, W, dev)
+                check(lib.cdae_sumpool2(ptr(dxu), ptr(dx), N, H, W, Cin, stream()))
+            else:
+                dx = new_act(N, Cin, H, W, dev)
+                check(lib.cdae_conv3x3_dgrad(ptr(dy), Cout, ptr(w), ptr(dx), Cin, N, H, W, Cin, Cout, stride, 0, 0, ws, wsb, stream()))
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)           # same OHWI storage as the parameter
+            db = torch.empty(Cout, dtype=torch.float32, device=dev) if has_b else None
+            check(lib.cdae_conv3x3_wgrad(ptr(x), x.stride(0), x.stride(2), x.stride(3), x.stride(1), ptr(dy), Cout, ptr(dw), ptr(db),
+                                         N, H, W, Cin, Cout, stride, 1 if up else 0, 0, ws, wsb, stream()))
+        if has_res and ctx.needs_input_grad[3]:
+            dres = dy
+        return dx, dw, db, dres, None, None, None
+
+
+def conv3x3(x, w, b=None, res=None, stride=1, up=False, out_nchw=False):
+    return _Conv3x3.apply(x, w, b, res, stride, up, out_nchw)
+
+
+# ----------------------------------------------------------------------------- linear / conv1x1 on rows
+class _Linear(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, res, act, alpha):
+        # x [M,K] (row pitch = stride(0)), w [N,K]
+        M, K = x.shape
+        Nf = w.shape[0]
+        assert x.stride(1) == 1 and w.is_contiguous()
+        y = torch.empty((M, Nf), dtype=torch.float32, device=x.device)
+        pre = torch.empty_like(y) if (act != ACT_NONE and torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)) else None
+        ws, wsb = _sk(x.device)
+        if pre is not None:      # keep the pre-activation for the backward
+            check(lib.cdae_linear_fwd(ptr(x), x.stride(0), ptr(w), K, ptr(b), ptr(res), ptr(pre), Nf, M, Nf, K, alpha, ACT_NONE, ws, wsb, stream()))
+            if act == ACT_SILU:
+                check(lib.cdae_silu_fwd(ptr(pre), ptr(y), M * Nf, stream()))
+            else:
+                y = torch.where(pre > 0, pre, 0.01 * pre)
+        else:
+            check(lib.cdae_linear_fwd(ptr(x), x.stride(0), ptr(w), K, ptr(b), ptr(res), ptr(y), Nf, M, Nf, K, alpha, act, ws, wsb, stream()))
+        ctx.save_for_backward(x, w, pre)
+        ctx.cfg = (act, alpha, b is not None, res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, pre = ctx.saved_tensors
+        act, alpha, has_b, has_res = ctx.cfg
+        M, K = x.shape
+        Nf = w.shape[0]
+        dy = _f32c(dy)
+        dev = x.device
+        if act == ACT_SILU:
+            g = torch.empty_like(dy)
+            check(lib.cdae_silu_bwd(ptr(pre), ptr(dy), ptr(g), M * Nf, stream()))
+            dy = g
+        elif act == ACT_LRELU:
+            dy = torch.where(pre > 0, dy, 0.01 * dy)
+        ws, wsb = _sk(dev)
+        dx = dw = db = dres = None
+        dya = dy if alpha == 1.0 else dy * alpha
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, K), dtype=torch.float32, device=dev)
+            check(lib.cdae_linear_dgrad(ptr(dya), Nf, ptr(w), K, ptr(dx), K, M, Nf, K, 0, ws, wsb, stream()))
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            check(lib.cdae_linear_wgrad(ptr(x), x.stride(0), ptr(dya), Nf, ptr(dw), K, None, M, Nf, K, 0, ws, wsb, stream()))
+        if has_b and ctx.needs_input_grad[2]:
+            db = torch.empty(Nf, dtype=torch.float32, device=dev)
+            check(lib.cdae_colsum(ptr(dy), Nf, ptr(db), M, Nf, 0, stream()))
+        if has_res and ctx.needs_input_grad[3]:
+            dres = dy
+        return dx, dw, db, dres, None, None
+
+
+def linear(x, w, b=None, res=None, act=ACT_NONE, alpha=1.0):
+    """y = act(alpha * x @ w^T + b + res); x [..., K] -> [..., N]."""
+    shp = x.shape
+    x2 = x.reshape(-1, shp[-1])
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    w2 = w.reshape(w.shape[0], -1)
+    r2 = None if res is None else res.reshape(-1, w.shape[0])
+    y = _Linear.apply(x2, w2, b, r2, act, float(alpha))
+    return y.reshape(*shp[:-1], w.shape[0])
+
+
+def conv1x1(x, w, b=None, res=None):
+    """1x1 conv on an NHWC-stored activation == GEMM over its [N*H*W, C] rows."""
+    x = to_nhwc(x)
+    N, C, H, W = x.shape
+    rows = x.permute(0, 2, 3, 1).reshape(N * H * W, C)
+    r = None if res is None else to_nhwc(res).permute(0, 2, 3, 1).reshape(N * H * W, -1)
+    y = linear(rows, w, b, r)
+    return y.reshape(N, H, W, -1).permute(0, 3, 1, 2)
+
+
+# ----------------------------------------------------------------------------- GroupNorm32 (+scale-shift) (+SiLU)
+class _GroupNorm(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, ss, silu, groups, eps):
+        x = to_nhwc(x)
+        N, C, H, W = x.shape
+        dev = x.device
+        stats = torch.empty((2, N, groups), dtype=torch.float32, device=dev)
+        ws = workspace(dev, "gn", 4 * lib.cdae_gn_workspace_floats(N, C))
+        y = new_act(N, C, H, W, dev)
+        st = stream()
+        check(lib.cdae_gn_stats(ptr(x), N, H * W, C, C, groups, eps, ptr(stats[0]), ptr(stats[1]), ptr(ws), st))
+        if ss is not None:
+            assert ss.shape == (N, 2 * C) and ss.is_contiguous()
+        check(lib.cdae_gn_apply(ptr(x), ptr(y), N, H * W, C, C, C, groups, ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta),
+                                ptr(ss), 2 * C, 1 if silu else 0, st))
+        ctx.save_for_backward(x, gamma, beta, ss, stats)
+        ctx.cfg = (silu, groups)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, ss, stats = ctx.saved_tensors
+        silu, groups = ctx.cfg
+        N, C, H, W = x.shape
+        dev = x.device
+        dy = to_nhwc(dy)
+        dx = new_act(N, C, H, W, dev)
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(beta)
+        dss = torch.empty_like(ss) if ss is not None else None
+        ws = workspace(dev, "gn", 4 * lib.cdae_gn_workspace_floats(N, C))
+        check(lib.cdae_gn_bwd(ptr(x), ptr(dy), ptr(dx), N, H * W, C, C, C, C, groups, ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta),
+                              ptr(ss), 2 * C, 1 if silu else 0, ptr(dgamma), ptr(dbeta), 0, ptr(dss), 2 * C, 0, ptr(ws), stream()))
+        return dx, dgamma, dbeta, dss, None, None, None
+
+
+def group_norm(x, gamma, beta, scale_shift=None, silu=False, groups=32, eps=1e-5):
+    """GroupNorm over a logical [N,C,H,W] (or [N,C,T]) activation, optionally fused with the ResBlock
+    scale-shift (emb_out [N,2C]) and SiLU."""
+    if x.dim() == 3:
+        y = _GroupNorm.apply(x.unsqueeze(-1), gamma, beta, scale_shift, silu, groups, eps)
+        return y.squeeze(-1)
+    return _GroupNorm.apply(x, gamma, beta, scale_shift, silu, groups, eps)
+
+
+# ----------------------------------------------------------------------------- QKV attention
+class _Attention(Function):
+    @staticmethod
+    def forward(ctx, qkv, heads):
+        # qkv: rows [B, T, 3C] contiguous, per-head channel order q|k|v
+        B, T, C3 = qkv.shape
+        C = C3 // 3
+        ch = C // heads
+        dev = qkv.device
+        out = torch.empty((B, T, C), dtype=torch.float32, device=dev)
+        probs = torch.empty((B * heads, T, T), dtype=torch.float32, device=dev)
+        check(lib.cdae_qkv_attention_fwd(ptr(qkv), ptr(out), ptr(probs), B, T, heads, ch, stream()))
+        ctx.save_for_backward(qkv, probs)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, probs = ctx.saved_tensors
+        B, T, C3 = qkv.shape
+        heads = ctx.heads
+        ch = C3 // 3 // heads
+        dout = _f32c(dout)
+        dqkv = torch.empty_like(qkv)
+        dprobs = torch.empty_like(probs)
+        check(lib.cdae_qkv_attention_bwd(ptr(qkv), ptr(probs), ptr(dout), ptr(dqkv), ptr(dprobs), B, T, heads, ch, stream()))
+        return dqkv, None
+
+
+def qkv_attention(qkv_rows, heads):
+    return _Attention.apply(qkv_rows.contiguous(), heads)
+
+
+# ----------------------------------------------------------------------------- small pointwise ops
+class _SiLU(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32c(x)
+        y = torch.empty_like(x)
+        check(lib.cdae_silu_fwd(ptr(x), ptr(y), x.numel(), stream()))
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _f32c(dy)
+        dx = torch.empty_like(x)
+        check(lib.cdae_silu_bwd(ptr(x), ptr(dy), ptr(dx), x.numel(), stream()))
+        return dx
+
+
+def silu(x):
+    return _SiLU.apply(x)
+
+
+class _Cat(Function):
+    """Channel concat of two NHWC activations (th.cat(dim=1), unet.py:628) as two strided row copies."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = to_nhwc(a), to_nhwc(b)
+        N, Ca, H, W = a.shape
+        Cb = b.shape[1]
+        out = new_act(N, Ca + Cb, H, W, a.device)
+        st = stream()
+        rows = N * H * W
+        check(lib.cdae_copy2d(ptr(a), ptr(out), rows, Ca, Ca, Ca + Cb, 0, st))
+        check(lib.cdae_copy2d(ptr(b), out.data_ptr() + 4 * Ca, rows, Cb, Cb, Ca + Cb, 0, st))
+        ctx.split = (Ca, Cb)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        Ca, Cb = ctx.split
+        dy = to_nhwc(dy)
+        N, _, H, W = dy.shape
+        da, db = new_act(N, Ca, H, W, dy.device), new_act(N, Cb, H, W, dy.device)
+        st = stream()
+        rows = N * H * W
+        check(lib.cdae_copy2d(ptr(dy), ptr(da), rows, Ca, Ca + Cb, Ca, 0, st))
+        check(lib.cdae_copy2d(dy.data_ptr() + 4 * Ca, ptr(db), rows, Cb, Ca + Cb, Cb, 0, st))
+        return da, db
+
+
+def cat_channels(a, b):
+    return _Cat.apply(a, b)
+
+
+class _EmbeddingAdd(Function):
+    @staticmethod
+    def forward(ctx, emb, table, idx):
+        out = emb.clone()
+        idx = idx.to(torch.int64).contiguous()
+        check(lib.cdae_embedding_add(ptr(out), ptr(table), ptr(idx), out.shape[0], out.shape[1], stream()))
+        ctx.save_for_backward(idx)
+        ctx.tshape = table.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        dout = _f32c(dout)
+        dtab = torch.zeros(ctx.tshape, dtype=torch.float32, device=dout.device)
+        check(lib.cdae_embedding_bwd(ptr(dout), ptr(dtab), ptr(idx), dout.shape[0], dout.shape[1], stream()))
+        return dout, dtab, None
+
+
+def embedding_add(emb, table, idx):
+    return _EmbeddingAdd.apply(emb, table, idx)
+
+
+class _Add(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _f32c(a), _f32c(b)
+        out = torch.empty_like(a)
+        check(lib.cdae_axpby(1.0, ptr(a), 1.0, ptr(b), ptr(out), a.numel(), stream()))
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        return d, d
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+def timestep_embedding(t, freqs, dim):
+    """[cos(t f) | sin(t f)] (nn.py:551-569); t float32 [N]; no gradient flows to t."""
+    t = t.float().contiguous()
+    out = torch.empty((t.shape[0], dim), dtype=torch.float32, device=t.device)
+    check(lib.cdae_timestep_embed_fwd(ptr(t), ptr(freqs), ptr(out), t.shape[0], dim, stream()))
+    return out
+
+
+class _Softplus(Function):
+    @staticmethod
+    def forward(ctx, x, add_):
+        x = _f32c(x)
+        y = torch.empty_like(x)
+        check(lib.cdae_softplus_fwd(ptr(x), ptr(y), x.numel(), add_, stream()))
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _f32c(dy)
+        dx = torch.empty_like(x)
+        check(lib.cdae_softplus_bwd(ptr(x), ptr(dy), ptr(dx), x.numel(), stream()))
+        return dx, None
+
+
+def softplus_eps(x, add_=1e-8):
+    return _Softplus.apply(x, add_)
+
+
+class _CausalMask(Function):
+    @staticmethod
+    def forward(ctx, u, A, nv):
+        u = _f32c(u)
+        A = _f32c(A)
+        N = u.shape[0]
+        d = u.shape[1] // nv
+        out = torch.empty((N, nv, d), dtype=torch.float32, device=u.device)
+        check(lib.cdae_causal_mask(ptr(u), ptr(A), ptr(out), N, nv, d, 0, stream()))
+        ctx.save_for_backward(A)
+        ctx.nv = nv
+        return out
+
+    @staticmethod
+    def backward(ctx, dz):
+        (A,) = ctx.saved_tensors
+        dz = _f32c(dz)
+        N, nv, d = dz.shape
+        du = torch.empty((N, nv * d), dtype=torch.float32, device=dz.device)
+        check(lib.cdae_causal_mask(ptr(dz), ptr(A), ptr(du), N, nv, d, 1, stream()))
+        return du, None, None
+
+
+def causal_mask(u, A, nv):
+    return _CausalMask.apply(u, A, nv)
+
+
+class _BnLrelu(Function):
+    """BatchNorm2d (+running-stat update when training) + LeakyReLU on an NHWC activation."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rmean, rvar, training, eps, momentum, slope):
+        x = to_nhwc(x)
+        N, C, H, W = x.shape
+        dev = x.device
+        y = new_act(N, C, H, W, dev)
+        aux = torch.empty((4, C), dtype=torch.float32, device=dev)      # scale, shift, save_mean, save_rstd
+        ws = workspace(dev, "bn", 4 * lib.cdae_bn_workspace_floats(C))
+        check(lib.cdae_bn_lrelu_fwd(ptr(x), ptr(y), N * H * W, C, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), 1 if training else 0,
+                                    eps, momentum, slope, ptr(aux[0]), ptr(aux[1]), ptr(aux[2]), ptr(aux[3]), ptr(ws), stream()))
+        ctx.save_for_backward(x, gamma, beta, aux)
+        ctx.cfg = (training, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, aux = ctx.saved_tensors
+        training, slope = ctx.cfg
+        if not training:
+            raise NotImplementedError("BN backward is implemented for training-mode statistics only")
+        dy = to_nhwc(dy)
+        N, C, H, W = x.shape
+        dev = x.device
+        dx = new_act(N, C, H, W, dev)
+        dg, db = torch.empty_like(gamma), torch.empty_like(beta)
+        ws = workspace(dev, "bn", 4 * lib.cdae_bn_workspace_floats(C))
+        check(lib.cdae_bn_lrelu_bwd(ptr(x), ptr(dy), ptr(dx), N * H * W, C, ptr(gamma), ptr(beta), ptr(aux[2]), ptr(aux[3]), slope,
+                                    ptr(dg), ptr(db), 0, ptr(ws), stream()))
+        return dx, dg, db, None, None, None, None, None, None
+
+
+def bn_lrelu(x, gamma, beta, rmean, rvar, training, eps=1e-5, momentum=0.1, slope=0.01):
+    return _BnLrelu.apply(x, gamma, beta, rmean, rvar, training, eps, momentum, slope)
+
+
+class _MseRows(Function):
+    """mean_flat((target - pred)^2) (gaussian_diffusion.py:847); gradient flows to `pred` only."""
+
+    @staticmethod
+    def forward(ctx, target, pred):
+        target, pred = _f32c(target), _f32c(pred)
+        N = pred.shape[0]
+        per = pred.numel() // N
+        out = torch.empty(N, dtype=torch.float32, device=pred.device)
+        check(lib.cdae_mse_rows(ptr(target), ptr(pred), ptr(out), N, per, stream()))
+        ctx.save_for_backward(target, pred)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        target, pred = ctx.saved_tensors
+        g = _f32c(g)
+        N = pred.shape[0]
+        d = torch.empty_like(pred)
+        check(lib.cdae_mse_rows_bwd(ptr(target), ptr(pred), ptr(g), ptr(d), N, pred.numel() // N, stream()))
+        return None, d
+
+
+def mse_rows(target, pred):
+    return _MseRows.apply(target, pred)

@@ -1,0 +1,298 @@
+"""Training runtime: TrainLoop with the reference's constructor / semantics (improved_diffusion/train_util.py:
+microbatching, KL-weight warm-up, lr anneal, EMA, checkpoint names) on an MI355X-native data path:
+
+  * all parameters live in ONE flat fp32 buffer (the nn.Parameters are views), gradients in a second one:
+    AdamW + EMA is a single fused kernel over the flat buffer (reference: ~384 tensors x several ATen ops);
+  * data parallel = one process per GPU; gradients are all-reduced in contiguous buckets of the flat
+    gradient buffer over RCCL/xGMI, each bucket launched asynchronously from a post-accumulate hook as soon as
+    its last gradient is ready, i.e. overlapped with the rest of backward (DDP-style, train_util.py:111-118);
+  * rank 0 broadcasts parameters, EMA and BN buffers at start (the reference's sync_params is a no-op, Q6).
+"""
+import copy
+import os
+
+import numpy as np
+import torch as th
+import torch.distributed as dist
+
+from . import dist_util, logger
+from ._lib import check, lib, ptr, stream
+from .resample import LossAwareSampler, UniformSampler
+
+
+class FlatParams:
+    """Re-homes a module's parameters (and their .grad) as views of two flat fp32 buffers, in registration order."""
+
+    def __init__(self, model):
+        self.params = [p for p in model.parameters()]
+        self.names = [n for n, _ in model.named_parameters()]
+        dev = self.params[0].device
+        self.offsets, off = [], 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += p.numel()
+        self.numel = off
+        self.flat = th.empty(off, dtype=th.float32, device=dev)
+        self.grad = th.zeros(off, dtype=th.float32, device=dev)
+        for p, o in zip(self.params, self.offsets):
+            view = self.flat.as_strided(p.shape, p.stride(), o)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.grad.as_strided(p.shape, p.stride(), o)
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, o in zip(self.params, self.offsets):          # re-attach if someone set .grad = None
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad.as_strided(p.shape, p.stride(), o)
+
+
+class GradBuckets:
+    """Contiguous buckets over the flat gradient buffer, reduced asynchronously as they become ready.
+
+    Buckets are built from the END of the parameter list (gradients arrive roughly in reverse registration
+    order during backward).  xGMI is point-to-point: ring all-reduce time is per-link bound, so a few large
+    buckets (default 64 MiB) amortise latency while still overlapping with the remaining backward."""
+
+    def __init__(self, flat, bucket_bytes=64 << 20, group=None):
+        self.flat, self.group = flat, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.buckets, self.bucket_of = [], {}
+        hi, acc, members = flat.numel, 0, []
+        for i in range(len(flat.params) - 1, -1, -1):
+            members.append(i)
+            acc += flat.params[i].numel() * 4
+            if acc >= bucket_bytes or i == 0:
+                lo = flat.offsets[i]
+                self.buckets.append(dict(lo=lo, hi=hi, members=list(members), pending=0, work=None))
+                for m in members:
+                    self.bucket_of[m] = len(self.buckets) - 1
+                hi, acc, members = lo, 0, []
+        self.enabled = True
+        self._hooks = []
+        if self.world > 1:
+            for i, p in enumerate(flat.params):
+                if p.requires_grad:
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+        self.reset()
+
+    def reset(self):
+        for b in self.buckets:
+            b["pending"] = sum(1 for m in b["members"] if self.flat.params[m].requires_grad)
+            b["work"] = None
+
+    def _make_hook(self, i):
+        def hook(_p):
+            if not self.enabled:
+                return
+            b = self.buckets[self.bucket_of[i]]
+            b["pending"] -= 1
+            if b["pending"] == 0:
+                b["work"] = dist.all_reduce(self.flat.grad[b["lo"]:b["hi"]], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return hook
+
+    def finish(self):
+        """Wait for in-flight buckets, reduce any bucket whose hook never fired (unused params), average."""
+        if self.world == 1:
+            return
+        for b in self.buckets:
+            if b["work"] is None:
+                b["work"] = dist.all_reduce(self.flat.grad[b["lo"]:b["hi"]], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        for b in self.buckets:
+            b["work"].wait()
+        self.flat.grad.mul_(1.0 / self.world)
+        self.reset()
+
+
+class FusedAdamWEMA:
+    """torch.optim.AdamW semantics + update_ema (reference train_util.py:292-297, nn.py:503-513) as ONE kernel over
+    the flat parameter buffer per EMA rate."""
+
+    def __init__(self, model, lr=1e-4, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, ema_rates=(0.9999,)):
+        self.model = model
+        self.flat = FlatParams(model)
+        self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
+        self.ema_rates = list(ema_rates)
+        self.m = th.zeros_like(self.flat.flat)
+        self.v = th.zeros_like(self.flat.flat)
+        self.ema = [self.flat.flat.clone() for _ in self.ema_rates]
+        self.t = 0
+        self._sq = th.zeros(1, dtype=th.float64, device=self.flat.flat.device)
+
+    def zero_grad(self):
+        self.flat.zero_grad()
+
+    def grad_sqsum(self):
+        check(lib.cdae_sqsum(ptr(self.flat.grad), self.flat.numel, ptr(self._sq), stream()))
+        return float(self._sq.item())
+
+    def step(self, lr=None):
+        self.t += 1
+        f = self.flat
+        first = self.ema[0] if self.ema else None
+        check(lib.cdae_adamw_ema(ptr(f.flat), ptr(f.grad), ptr(self.m), ptr(self.v), ptr(first), f.numel,
+                                 self.lr if lr is None else lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                                 self.t, self.ema_rates[0] if self.ema else 0.0, 1.0, stream()))
+        for rate, e in zip(self.ema_rates[1:], self.ema[1:]):
+            e.mul_(rate).add_(f.flat, alpha=1 - rate)
+
+    def ema_state_dict(self, i):
+        """EMA weights under the model's parameter names / shapes (buffers copied from the live model)."""
+        sd = self.model.state_dict()
+        f = self.flat
+        for n, p, o in zip(f.names, f.params, f.offsets):
+            sd[n] = self.ema[i].as_strided(p.shape, p.stride(), o)
+        return sd
+
+    def broadcast_from_rank0(self):
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.broadcast(self.flat.flat, 0)
+            for e in self.ema:
+                dist.broadcast(e, 0)
+            for b in self.model.buffers():
+                dist.broadcast(b, 0)
+
+
+def linear_kl_weight(step, total_steps=50000, initial=0.0, final=1.0):
+    """KL warm-up (reference train_util.py:176-187): linear over total_steps with t = step/(total_steps-1)."""
+    if step >= total_steps:
+        return final
+    if step <= 0:
+        return initial
+    if total_steps <= 1:
+        return final
+    t = step / (total_steps - 1)
+    return (1.0 - t) * initial + t * final
+
+
+class TrainLoop:
+    def __init__(self, *, model, diffusion, data, batch_size, microbatch, lr, ema_rate, log_interval, save_interval,
+                 resume_checkpoint, use_fp16=False, fp16_scale_growth=1e-3, schedule_sampler=None, weight_decay=0.0,
+                 lr_anneal_steps=0, rep_cond=False, n_vars=None, causal_modeling=False, flow_based=False, in_channels=3,
+                 masking=False, bucket_mb=64):
+        if use_fp16:
+            raise NotImplementedError("reduced-precision training (bf16 torso) comes after fp32 parity; see DESIGN.md")
+        self.model, self.diffusion, self.data = model, diffusion, data
+        self.batch_size = batch_size
+        self.microbatch = microbatch if microbatch > 0 else batch_size
+        self.lr = lr
+        self.ema_rate = [ema_rate] if isinstance(ema_rate, float) else [float(x) for x in ema_rate.split(",")]
+        self.log_interval, self.save_interval, self.resume_checkpoint = log_interval, save_interval, resume_checkpoint
+        self.schedule_sampler = schedule_sampler or UniformSampler(diffusion)
+        self.weight_decay, self.lr_anneal_steps = weight_decay, lr_anneal_steps
+        self.rep_cond, self.n_vars, self.causal_modeling = rep_cond, n_vars, causal_modeling
+        self.flow_based, self.in_channels, self.masking = flow_based, in_channels, masking
+        self.step, self.resume_step = 0, 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.global_batch = self.batch_size * self.world
+
+        if resume_checkpoint:
+            self.resume_step = parse_resume_step_from_filename(resume_checkpoint)
+            self.model.load_state_dict(dist_util.load_state_dict(resume_checkpoint, map_location="cpu"))
+        self.opt = FusedAdamWEMA(model, lr=lr, weight_decay=weight_decay, ema_rates=self.ema_rate)
+        if resume_checkpoint:
+            ema_path = os.path.join(os.path.dirname(resume_checkpoint), "ema_checkpoint.pt")
+            if os.path.exists(ema_path):
+                sd = dist_util.load_state_dict(ema_path, map_location="cpu")
+                f = self.opt.flat
+                for n, p, o in zip(f.names, f.params, f.offsets):
+                    self.opt.ema[0].as_strided(p.shape, p.stride(), o).copy_(sd[n])
+        self.opt.broadcast_from_rank0()
+        self.buckets = GradBuckets(self.opt.flat, bucket_bytes=bucket_mb << 20)
+        self.model_params = self.opt.flat.params
+        self.master_params = self.model_params
+        self.use_ddp = self.world > 1
+        self.ddp_model = self.model
+        self.last_losses = None
+
+    # ------------------------------------------------------------------ loop
+    def run_loop(self):
+        while not self.lr_anneal_steps or self.step + self.resume_step < self.lr_anneal_steps:
+            batch, cond = next(self.data)
+            self.run_step(batch, cond)
+            if self.step % self.log_interval == 0:
+                logger.dumpkvs()
+            if self.step % self.save_interval == 0:
+                self.save()
+                if os.environ.get("DIFFUSION_TRAINING_TEST", "") and self.step > 0:
+                    return
+            self.step += 1
+            self.diffusion.kl_weight = linear_kl_weight(self.step, 50000, 0.0, 1.0)     # applied AFTER the step (train_util.py:210-214)
+        if (self.step - 1) % self.save_interval != 0:
+            self.save()
+
+    def run_step(self, batch, cond):
+        self.forward_backward(batch, cond)
+        self.optimize_normal()
+        self.log_step()
+
+    def forward_backward(self, batch, cond):
+        dev = dist_util.dev()
+        self.opt.zero_grad()
+        n = batch.shape[0]
+        for i in range(0, n, self.microbatch):
+            micro = batch[i:i + self.microbatch].to(dev, non_blocking=True)
+            micro_cond = {k: v[i:i + self.microbatch].to(dev, non_blocking=True) for k, v in cond.items()}
+            last = (i + self.microbatch) >= n
+            t, weights = self.schedule_sampler.sample(micro.shape[0], dev)
+            self.buckets.enabled = last                      # no_sync semantics: reduce only with the last microbatch
+            losses = self.diffusion.training_losses(self.model, micro, t, model_kwargs=micro_cond, rep_cond=self.rep_cond,
+                                                    causal_modeling=self.causal_modeling)
+            if isinstance(self.schedule_sampler, LossAwareSampler):
+                self.schedule_sampler.update_with_local_losses(t, losses["loss"].detach())
+            loss = (losses["loss"] * weights).mean()
+            self.last_losses = {k: v.detach() for k, v in losses.items()}
+            # microbatches contribute mean losses of their own slice; scale like the reference (no extra scaling)
+            loss.backward()
+        self.buckets.finish()
+
+    def optimize_normal(self):
+        self._anneal_lr()
+        self.opt.step(self._lr)
+
+    def _anneal_lr(self):
+        self._lr = self.lr
+        if self.lr_anneal_steps:
+            self._lr = self.lr * (1 - (self.step + self.resume_step) / self.lr_anneal_steps)
+
+    def log_step(self):
+        logger.logkv("step", self.step + self.resume_step)
+        logger.logkv("samples", (self.step + self.resume_step + 1) * self.global_batch)
+        if self.step % self.log_interval == 0 and self.last_losses is not None:      # one host sync per log interval
+            for k, v in self.last_losses.items():
+                logger.logkv_mean(k, v.float().mean().item())
+            logger.logkv_mean("grad_norm", float(np.sqrt(self.opt.grad_sqsum())))
+
+    # ------------------------------------------------------------------ checkpoints (names of train_util.py:319-345)
+    def save(self):
+        if self.rank == 0:             # the reference writes on rank 1 only (so never in single-process runs): fixed, SURVEY Q6
+            d = get_blob_logdir()
+            if d:
+                os.makedirs(d, exist_ok=True)
+                sd = {k: v.detach().cpu().contiguous() for k, v in self.model.state_dict().items()}
+                th.save(sd, os.path.join(d, f"model{(self.step + self.resume_step):06d}.pt"))
+                for i, _rate in enumerate(self.ema_rate):
+                    esd = {k: v.detach().cpu().contiguous() for k, v in self.opt.ema_state_dict(i).items()}
+                    th.save(esd, os.path.join(d, "ema_checkpoint.pt"))
+        if dist.is_initialized():
+            dist.barrier()
+
+
+def parse_resume_step_from_filename(filename):
+    """path/to/modelNNNNNN.pt -> NNNNNN (0 if it does not parse), reference train_util.py:366-378."""
+    parts = filename.split("model")
+    if len(parts) < 2:
+        return 0
+    try:
+        return int(parts[-1].split(".")[0])
+    except ValueError:
+        return 0
+
+
+def get_blob_logdir():
+    return os.environ.get("DIFFUSION_BLOB_LOGDIR", logger.get_dir())
+
+
+def find_resume_checkpoint():
+    return None

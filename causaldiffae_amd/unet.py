@@ -1,0 +1,302 @@
+"""UNetModel noise predictor with the reference's constructor, forward signature and state-dict layout
+(reference improved_diffusion/unet.py), executed by the HIP kernels behind ops.py.
+
+Fusion map (what one launch replaces in the reference's eager ATen stream):
+  GroupNorm32 + (1+scale)*.+shift + SiLU      -> gn_stats + gn_apply            (unet.py:186,190-194)
+  conv3x3 + bias + residual add               -> one igemm launch               (unet.py:186,194,198)
+  F.interpolate(nearest 2x) + conv3x3         -> upsample folded into the gather (unet.py:76-78)
+  qkv 1x1 / proj_out 1x1 (+ residual)         -> GEMM over NHWC rows            (unet.py:226,230-231)
+  QKVAttention                                -> 2 batched MFMA GEMMs + wave-shuffle softmax (unet.py:239-253)
+"""
+from abc import abstractmethod
+
+import torch as th
+import torch.nn as nn
+
+from . import ops
+from .nn import (
+    CausalModeling,
+    ConvNd,
+    Dropout,
+    Embedding,
+    GaussianConvEncoder,
+    Identity,
+    Linear,
+    SiLU,
+    _RNG_OVERRIDE,
+    checkpoint,
+    conv_nd,
+    linear,
+    normalization,
+    reparameterize,
+    timestep_embedding,
+    zero_module,
+)
+
+# Adjacency matrices (unet.py:571-578; pendulum is the commented-out alternative the test script passes itself)
+ADJACENCY = {
+    "morphomnist": [[0, 1], [0, 0]],
+    "circuit": [[0, 1, 1, 1], [0, 0, 0, 1], [0, 0, 0, 1], [0, 0, 0, 0]],
+    "pendulum": [[0, 0, 1, 1], [0, 0, 1, 1], [0, 0, 0, 0], [0, 0, 0, 0]],
+}
+
+
+def encoder_hidden_dims(image_size, n_vars):
+    """Encoder depth that ends on a 2x2 map (fc in-features = dims[-1]*4, reference nn.py:57).  The reference
+    hard-codes the 6-conv list (unet.py:377), which only runs at 96/128 px."""
+    if image_size in (28, 32):
+        return [16, 32, 64, 128]
+    if image_size == 64:
+        return [16, 32, 32, 64, 128]
+    return [16, 32, 32, 64, 64, 128]
+
+
+class TimestepBlock(nn.Module):
+    @abstractmethod
+    def forward(self, x, emb):
+        """Apply the module to `x` given `emb` timestep embeddings."""
+
+
+class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
+    def forward(self, x, emb):
+        for layer in self:
+            x = layer(x, emb) if isinstance(layer, TimestepBlock) else layer(x)
+        return x
+
+
+class Upsample(nn.Module):
+    def __init__(self, channels, use_conv, dims=2):
+        super().__init__()
+        if not use_conv or dims != 2:
+            raise NotImplementedError("CausalDiffAE always upsamples with conv_resample=True in 2-D")
+        self.channels, self.use_conv, self.dims = channels, use_conv, dims
+        self.conv = conv_nd(dims, channels, channels, 3, padding=1)
+
+    def forward(self, x):
+        assert x.shape[1] == self.channels
+        return self.conv(x, up=True)           # nearest-2x folded into the conv's input gather
+
+
+class Downsample(nn.Module):
+    def __init__(self, channels, use_conv, dims=2):
+        super().__init__()
+        if not use_conv or dims != 2:
+            raise NotImplementedError("CausalDiffAE always downsamples with conv_resample=True in 2-D")
+        self.channels, self.use_conv, self.dims = channels, use_conv, dims
+        self.op = conv_nd(dims, channels, channels, 3, stride=2, padding=1)
+
+    def forward(self, x):
+        assert x.shape[1] == self.channels
+        return self.op(x)
+
+
+class ResBlock(TimestepBlock):
+    def __init__(self, channels, emb_channels, dropout, out_channels=None, use_conv=False,
+                 use_scale_shift_norm=False, dims=2, use_checkpoint=False):
+        super().__init__()
+        self.channels, self.emb_channels, self.dropout = channels, emb_channels, dropout
+        self.out_channels = out_channels or channels
+        self.use_conv, self.use_checkpoint, self.use_scale_shift_norm = use_conv, use_checkpoint, use_scale_shift_norm
+        self.in_layers = nn.Sequential(normalization(channels), SiLU(), conv_nd(dims, channels, self.out_channels, 3, padding=1))
+        self.emb_layers = nn.Sequential(
+            SiLU(), linear(emb_channels, 2 * self.out_channels if use_scale_shift_norm else self.out_channels))
+        self.out_layers = nn.Sequential(
+            normalization(self.out_channels), SiLU(), Dropout(p=dropout),
+            zero_module(conv_nd(dims, self.out_channels, self.out_channels, 3, padding=1)))
+        if self.out_channels == channels:
+            self.skip_connection = Identity()
+        elif use_conv:
+            self.skip_connection = conv_nd(dims, channels, self.out_channels, 3, padding=1)
+        else:
+            self.skip_connection = conv_nd(dims, channels, self.out_channels, 1)
+
+    def forward(self, x, emb):
+        return checkpoint(self._forward, (x, emb), self.parameters(), self.use_checkpoint)
+
+    def _forward(self, x, emb):
+        x = ops.to_nhwc(x)
+        h = self.in_layers[0](x, silu=True)                        # GN + SiLU
+        h = self.in_layers[2](h)                                   # conv3x3 + bias
+        emb_out = self.emb_layers[1](ops.silu(emb))                # [N, (2)Cout]
+        if self.use_scale_shift_norm:
+            h = self.out_layers[0](h, scale_shift=emb_out, silu=True)
+        else:
+            h = self.out_layers[0](h + emb_out[:, :, None, None], silu=True)
+        h = self.out_layers[2](h)
+        skip = x if isinstance(self.skip_connection, Identity) else self.skip_connection(x)
+        return self.out_layers[3](h, res=skip)                     # conv3x3 + bias + residual
+
+
+class QKVAttention(nn.Module):
+    """[N*H, 3*ch, T] -> [N*H, ch, T] like the reference module (unet.py:239-253); the fused block below
+    uses the row-major form directly."""
+
+    def forward(self, qkv):
+        BH, C3, T = qkv.shape
+        rows = qkv.permute(0, 2, 1).contiguous()                   # [BH, T, 3ch], heads=1 per batch entry
+        out = ops.qkv_attention(rows, 1)
+        return out.permute(0, 2, 1)
+
+
+class AttentionBlock(nn.Module):
+    def __init__(self, channels, num_heads=1, use_checkpoint=False):
+        super().__init__()
+        self.channels, self.num_heads, self.use_checkpoint = channels, num_heads, use_checkpoint
+        self.norm = normalization(channels)
+        self.qkv = conv_nd(1, channels, channels * 3, 1)
+        self.attention = QKVAttention()
+        self.proj_out = zero_module(conv_nd(1, channels, channels, 1))
+
+    def forward(self, x):
+        return checkpoint(self._forward, (x,), self.parameters(), self.use_checkpoint)
+
+    def _forward(self, x):
+        x = ops.to_nhwc(x)
+        N, C, H, W = x.shape
+        T = H * W
+        h = self.norm(x)                                                            # GN, no activation
+        rows = h.permute(0, 2, 3, 1).reshape(N * T, C)
+        qkv = ops.linear(rows, self.qkv.weight, self.qkv.bias)                      # [N*T, 3C]; channel = head*3ch + {q,k,v}*ch + d
+        a = ops.qkv_attention(qkv.reshape(N, T, 3 * C), self.num_heads)            # [N, T, C]
+        xr = x.permute(0, 2, 3, 1).reshape(N * T, C)
+        out = ops.linear(a.reshape(N * T, C), self.proj_out.weight, self.proj_out.bias, res=xr)
+        return out.reshape(N, H, W, C).permute(0, 3, 1, 2)
+
+
+class UNetModel(nn.Module):
+    """The full UNet with timestep / label / context / representation conditioning (reference unet.py:279-632)."""
+
+    def __init__(self, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions, dropout=0,
+                 channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, num_classes=None, c_dim=None, rep_dim=None,
+                 causal_modeling=False, flow_based=False, use_checkpoint=False, num_heads=1, num_heads_upsample=-1,
+                 use_scale_shift_norm=False, masking=False, n_vars=4, image_size=None, encoder_hidden=None):
+        super().__init__()
+        if num_heads_upsample == -1:
+            num_heads_upsample = num_heads
+        if flow_based:
+            raise NotImplementedError("flow_based=True (MultivariateCausalFlow) is outside the BASELINE configs (SURVEY §8f.3)")
+        self.in_channels, self.model_channels, self.out_channels = in_channels, model_channels, out_channels
+        self.num_res_blocks, self.attention_resolutions = num_res_blocks, attention_resolutions
+        self.dropout, self.channel_mult, self.conv_resample = dropout, channel_mult, conv_resample
+        self.num_classes, self.c_dim, self.rep_dim = num_classes, c_dim, rep_dim
+        self.use_checkpoint, self.num_heads, self.num_heads_upsample = use_checkpoint, num_heads, num_heads_upsample
+        self.causal_modeling, self.flow_based, self.masking = causal_modeling, flow_based, masking
+        self.drop_prob = 0.5
+        self.n_vars = n_vars
+        self.adjacency = None            # optional override of the graph hard-coded in the reference forward (Q2)
+
+        time_embed_dim = model_channels * 4
+        self.time_embed = nn.Sequential(linear(model_channels, time_embed_dim), SiLU(), linear(time_embed_dim, time_embed_dim))
+        if num_classes is not None:
+            self.label_emb = Embedding(num_classes, time_embed_dim)
+        if c_dim is not None:
+            self.c_emb = nn.Sequential(linear(c_dim, 256), SiLU(), linear(256, time_embed_dim))
+        if rep_dim is not None:
+            hidden = encoder_hidden or (encoder_hidden_dims(image_size, n_vars) if image_size else None)
+            self.rep_emb = GaussianConvEncoder(in_channels=in_channels, latent_dim=rep_dim, hidden_dims=hidden, num_vars=4)
+            self.up_emb = Linear(rep_dim, time_embed_dim)
+        if causal_modeling:
+            self.causal_mask = CausalModeling(latent_dim=rep_dim, num_var=n_vars, learn=False)
+
+        self.input_blocks = nn.ModuleList([TimestepEmbedSequential(conv_nd(dims, in_channels, model_channels, 3, padding=1))])
+        input_block_chans = [model_channels]
+        ch, ds = model_channels, 1
+        for level, mult in enumerate(channel_mult):
+            for _ in range(num_res_blocks):
+                layers = [ResBlock(ch, time_embed_dim, dropout, out_channels=mult * model_channels, dims=dims,
+                                   use_checkpoint=use_checkpoint, use_scale_shift_norm=use_scale_shift_norm)]
+                ch = mult * model_channels
+                if ds in attention_resolutions:
+                    layers.append(AttentionBlock(ch, use_checkpoint=use_checkpoint, num_heads=num_heads))
+                self.input_blocks.append(TimestepEmbedSequential(*layers))
+                input_block_chans.append(ch)
+            if level != len(channel_mult) - 1:
+                self.input_blocks.append(TimestepEmbedSequential(Downsample(ch, conv_resample, dims=dims)))
+                input_block_chans.append(ch)
+                ds *= 2
+
+        self.middle_block = TimestepEmbedSequential(
+            ResBlock(ch, time_embed_dim, dropout, dims=dims, use_checkpoint=use_checkpoint, use_scale_shift_norm=use_scale_shift_norm),
+            AttentionBlock(ch, use_checkpoint=use_checkpoint, num_heads=num_heads),
+            ResBlock(ch, time_embed_dim, dropout, dims=dims, use_checkpoint=use_checkpoint, use_scale_shift_norm=use_scale_shift_norm),
+        )
+
+        self.output_blocks = nn.ModuleList([])
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for i in range(num_res_blocks + 1):
+                layers = [ResBlock(ch + input_block_chans.pop(), time_embed_dim, dropout, out_channels=model_channels * mult,
+                                   dims=dims, use_checkpoint=use_checkpoint, use_scale_shift_norm=use_scale_shift_norm)]
+                ch = model_channels * mult
+                if ds in attention_resolutions:
+                    layers.append(AttentionBlock(ch, use_checkpoint=use_checkpoint, num_heads=num_heads_upsample))
+                if level and i == num_res_blocks:
+                    layers.append(Upsample(ch, conv_resample, dims=dims))
+                    ds //= 2
+                self.output_blocks.append(TimestepEmbedSequential(*layers))
+
+        self.out = nn.Sequential(normalization(ch), SiLU(), zero_module(conv_nd(dims, model_channels, out_channels, 3, padding=1)))
+
+    # ------------------------------------------------------------------ precision
+    def convert_to_fp16(self):
+        raise NotImplementedError("reduced-precision torso (bf16 MFMA) is scheduled after fp32 parity; see DESIGN.md")
+
+    def convert_to_fp32(self):
+        return None
+
+    @property
+    def inner_dtype(self):
+        return next(self.input_blocks.parameters()).dtype
+
+    # ------------------------------------------------------------------ conditioning
+    def default_adjacency(self, device):
+        """Graph used when the encoder path runs inside forward (reference unet.py:571-578): n_vars==2 ->
+        MorphoMNIST, else CausalCircuit; `self.adjacency` overrides it (the reference ignores its A argument)."""
+        A = self.adjacency
+        if A is None:
+            A = ADJACENCY["morphomnist"] if self.n_vars == 2 else ADJACENCY["circuit"]
+        return th.as_tensor(A, dtype=th.float32).to(device)
+
+    def embed(self, timesteps, y=None, c=None, x_start=None, z=None):
+        """Everything ahead of the conv torso: returns (emb, mu, var, z_post, mask)."""
+        emb = self.time_embed[2](self.time_embed[0](timestep_embedding(timesteps, self.model_channels), act=ops.ACT_SILU))
+        if self.num_classes is not None:
+            assert y.shape == (timesteps.shape[0],)
+            emb = ops.embedding_add(emb, self.label_emb.weight, y)
+        if self.c_dim is not None:
+            emb = self.c_emb[2](self.c_emb[0](c.float(), act=ops.ACT_SILU), res=emb)
+        mu = var = z_post = mask = None
+        if self.rep_dim is not None:
+            if z is None:
+                mu, var = self.rep_emb.encode(x_start)
+                if self.causal_modeling:
+                    A = self.default_adjacency(mu.device)
+                    z_pre = self.causal_mask.causal_masking(mu, A)
+                    z_post = self.causal_mask.nonlinearity_add_back_noise(mu, z_pre)
+                    z = reparameterize(z_post, var * 0.001)
+                else:
+                    z = reparameterize(mu, var * 0.001)
+                if self.masking:
+                    mask = _RNG_OVERRIDE.get("cfg_mask")
+                    if mask is None:
+                        mask = th.bernoulli(th.full((z.shape[0],), 1 - self.drop_prob, device=z.device))
+                    mask = mask.to(z.device).float()
+                    z = z * mask[:, None]
+                    z_post = z_post * mask[:, None]
+            emb = self.up_emb(z.float(), res=emb)
+        return emb, mu, var, z_post, mask
+
+    def forward(self, x, timesteps, y=None, c=None, x_start=None, z=None, A=None, mask=None):
+        """x [N,C,H,W], timesteps [N] -> (eps [N,Cout,H,W] NCHW-contiguous, mu, var, z_post, mask)."""
+        assert (y is not None) == (self.num_classes is not None), \
+            "must specify y if and only if the model is class-conditional"
+        emb, mu, var, z_post, mask = self.embed(timesteps, y=y, c=c, x_start=x_start, z=z)
+        hs = []
+        h = x.float()
+        for module in self.input_blocks:
+            h = module(h, emb)
+            hs.append(h)
+        h = self.middle_block(h, emb)
+        for module in self.output_blocks:
+            h = module(ops.cat_channels(h, hs.pop()), emb)
+        h = self.out[0](h, silu=True)
+        return self.out[2](h, out_nchw=True), mu, var, z_post, mask

@@ -1,0 +1,152 @@
+/* cdae.h — C-ABI of libcdae.so: the MI355X (gfx950) kernels behind the CausalDiffAE diffusion hot path.
+ *
+ * The reference (Akomand/CausalDiffAE) has no FFI / plugin interface: its hot path is pure Python on
+ * ATen.  These entry points are what a binding for that path calls instead of the ATen
+ * ops; each one cites the reference lines it replaces.  Conventions:
+ *   - raw device pointers, fp32, activations NHWC ("channels_last") unless stated, weights of a 3x3
+ *     conv in OHWI order ([Cout][ky][kx][Cin] = the channels_last storage of the reference's
+ *     [Cout,Cin,3,3] parameter), linear / 1x1 weights [out][in];
+ *   - no allocation, no host sync; every kernel is enqueued on `stream` (a hipStream_t; 0 = null stream);
+ *     workspaces are caller-provided, sizes from the cdae_*_workspace_* queries;
+ *   - return 0 on success, -1 on error (message via cdae_last_error(), thread-local);
+ *   - re-entrant; the only global state is the opt-in profiler (cdae_prof_*).
+ */
+#ifndef CDAE_H
+#define CDAE_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CDAE_VERSION 1
+#define CDAE_GN_MAX_CHUNKS 64
+#define CDAE_BN_MAX_CHUNKS 256
+#define CDAE_PROF_FAMILIES 5      /* 0 igemm (MFMA), 1 groupnorm, 2 softmax, 3 elementwise, 4 optimizer */
+
+/* rows of the fp32 coefficient table passed to the sampler kernels: tab[row * T + t]
+ * (float32 roundings of the float64 tables of gaussian_diffusion.py:137-179, i.e. what
+ * _extract_into_tensor's `.float()` yields, gaussian_diffusion.py:948) */
+enum {
+    CDAE_TAB_SQRT_AC = 0,          /* sqrt_alphas_cumprod */
+    CDAE_TAB_SQRT_1MAC = 1,        /* sqrt_one_minus_alphas_cumprod */
+    CDAE_TAB_SQRT_RECIP_AC = 2,    /* sqrt_recip_alphas_cumprod */
+    CDAE_TAB_SQRT_RECIPM1_AC = 3,  /* sqrt_recipm1_alphas_cumprod */
+    CDAE_TAB_AC = 4,               /* alphas_cumprod */
+    CDAE_TAB_AC_PREV = 5,          /* alphas_cumprod_prev */
+    CDAE_TAB_POST_COEF1 = 6,       /* posterior_mean_coef1 */
+    CDAE_TAB_POST_COEF2 = 7,       /* posterior_mean_coef2 */
+    CDAE_TAB_MODEL_LOGVAR = 8,     /* model log-variance (FIXED_LARGE / FIXED_SMALL), gaussian_diffusion.py:305-318 */
+    CDAE_TAB_MODEL_VAR = 9,
+    CDAE_TAB_ROWS = 10
+};
+
+int cdae_version(void);
+const char* cdae_last_error(void);
+
+/* ---- dense contractions on the matrix cores (igemm.hip) -------------------------------------------------- */
+
+/* conv3x3, pad 1 — replaces nn.Conv2d in ResBlock.in_layers[2]/out_layers[3] (unet.py:143-162), the stem and
+ * output head (unet.py:392,498), Downsample.op (stride 2, unet.py:99) and Upsample (F.interpolate nearest 2x
+ * fused into the gather, unet.py:76-78), encoder convs (nn.py:49-50).
+ *   x   : [N,H,W,Cin] with element strides (sn,sy,sx,sc); sc==1 && Cin%32==0 takes the vector path
+ *   w   : OHWI [Cout][3][3][Cin];  bias [Cout] or NULL;  res: optional residual, same layout as out
+ *   out : [N,Ho,Wo,Cout] row pitch ldo (out_nchw=0) or NCHW contiguous (out_nchw=1)
+ *   Ho = up ? 2H : (H-1)/stride+1 (same for W).  splitk_ws may be NULL (disables split-K). */
+int cdae_conv3x3_fwd(const float* x, long sn, long sy, long sx, long sc, const float* w, const float* bias, const float* res,
+                     float* out, long ldo, int out_nchw, int N, int H, int W, int Cin, int Cout, int stride, int up,
+                     float* splitk_ws, size_t splitk_ws_bytes, void* stream);
+/* dgrad: dx[N,H,W,Cin] (pitch lddx) from dy[N,Ho,Wo,Cout] (pitch lddy).  For up=1 dx is the gradient w.r.t.
+ * the UPSAMPLED input [N,2H,2W,Cin]; follow with cdae_sumpool2. accumulate: dx += . */
+int cdae_conv3x3_dgrad(const float* dy, long lddy, const float* w, float* dx, long lddx, int N, int H, int W, int Cin, int Cout,
+                       int stride, int up, int accumulate, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
+/* wgrad: dw (OHWI) (+)= dy^T * im2col(x);  dbias (+)= column sums of dy (may be NULL). */
+int cdae_conv3x3_wgrad(const float* x, long sn, long sy, long sx, long sc, const float* dy, long lddy, float* dw, float* dbias,
+                       int N, int H, int W, int Cin, int Cout, int stride, int up, int accumulate,
+                       float* splitk_ws, size_t splitk_ws_bytes, void* stream);
+
+/* y[M][N] = act(alpha * x[M][K] @ w[N][K]^T + bias + res) — replaces nn.Linear (unet.py:354-379, emb_layers
+ * :148-154, nn.py:57-58,233-237) and the 1x1 convs (skip_connection unet.py:171, qkv/proj_out unet.py:216-218)
+ * on NHWC rows.  act: 0 none, 1 SiLU, 2 LeakyReLU(0.01). */
+int cdae_linear_fwd(const float* x, long ldx, const float* w, long ldw, const float* bias, const float* res, float* y, long ldy,
+                    int M, int N, int K, float alpha, int act, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
+/* dx[M][K] (+)= dy[M][N] @ w[N][K] */
+int cdae_linear_dgrad(const float* dy, long lddy, const float* w, long ldw, float* dx, long lddx, int M, int N, int K, int accumulate,
+                      float* splitk_ws, size_t splitk_ws_bytes, void* stream);
+/* dw[N][K] (+)= dy[M][N]^T @ x[M][K];  dbias[N] (+)= column sums of dy (may be NULL) */
+int cdae_linear_wgrad(const float* x, long ldx, const float* dy, long lddy, float* dw, long lddw, float* dbias, int M, int N, int K,
+                      int accumulate, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
+int cdae_colsum(const float* x, long ldx, float* out, long rows, int cols, int accumulate, void* stream);
+
+/* QKVAttention (unet.py:239-253) on the NHWC output of the qkv 1x1 conv: qkv[B][T][heads*3*ch] with the
+ * reference's per-head channel order q|k|v.  out[B][T][heads*ch].  probs: workspace [B*heads][T][T] floats
+ * (kept for the backward).  Two batched MFMA GEMMs + a wave-shuffle softmax. */
+int cdae_qkv_attention_fwd(const float* qkv, float* out, float* probs, int B, int T, int heads, int ch, void* stream);
+/* dqkv from dout; dprobs: scratch [B*heads][T][T] */
+int cdae_qkv_attention_bwd(const float* qkv, const float* probs, const float* dout, float* dqkv, float* dprobs,
+                           int B, int T, int heads, int ch, void* stream);
+
+/* ---- normalisation / softmax (norm.hip) ------------------------------------------------------------------- */
+size_t cdae_gn_workspace_floats(int N, int C);
+/* GroupNorm32 statistics (nn.py:435-437): mean/rstd [N*groups] over (HW x C/groups), fp32 in, f64 combine */
+int cdae_gn_stats(const float* x, int N, int HW, int C, int ldx, int groups, float eps, float* mean, float* rstd, float* ws, void* stream);
+/* y = silu?( ((x-mean)*rstd*gamma+beta) [* (1+scale[n][c]) + shift[n][c]] ), scale_shift = emb_out [N][2C] (unet.py:190-194) */
+int cdae_gn_apply(const float* x, float* y, int N, int HW, int C, int ldx, int ldy, int groups, const float* mean, const float* rstd,
+                  const float* gamma, const float* beta, const float* scale_shift, int ld_ss, int silu, void* stream);
+int cdae_gn_bwd(const float* x, const float* dy, float* dx, int N, int HW, int C, int ldx, int lddy, int lddx, int groups,
+                const float* mean, const float* rstd, const float* gamma, const float* beta, const float* scale_shift, int ld_ss, int silu,
+                float* dgamma, float* dbeta, int accumulate_params, float* d_scale_shift, int ld_dss, int accumulate_dx,
+                float* ws, void* stream);
+size_t cdae_bn_workspace_floats(int C);
+/* BatchNorm2d (batch stats if training, running stats otherwise) + LeakyReLU on NHWC rows (nn.py:46-53) */
+int cdae_bn_lrelu_fwd(const float* x, float* y, long rows, int C, const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, int training, float eps, float momentum, float slope, float* scale, float* shift,
+                      float* save_mean, float* save_rstd, float* ws, void* stream);
+int cdae_bn_lrelu_bwd(const float* x, const float* dy, float* dx, long rows, int C, const float* gamma, const float* beta,
+                      const float* save_mean, const float* save_rstd, float slope, float* dgamma, float* dbeta, int accumulate,
+                      float* ws, void* stream);
+int cdae_softmax_rows(float* s, long rows, int T, void* stream);
+int cdae_softmax_rows_bwd(const float* P, float* dP, long rows, int T, void* stream);
+
+/* ---- pointwise (elementwise.hip) -------------------------------------------------------------------------- */
+int cdae_silu_fwd(const float* x, float* y, long n, void* stream);
+int cdae_silu_bwd(const float* x, const float* dy, float* dx, long n, void* stream);
+/* timestep_embedding (nn.py:551-569); freqs[dim/2] is the host-computed exp(-ln(P) k/half) table */
+int cdae_timestep_embed_fwd(const float* t, const float* freqs, float* out, int N, int dim, void* stream);
+/* _WrappedModel (respace.py:119-124): out_i = map[t] (int64, exact), out_f = rescale ? float(map[t])*scale : float(map[t]) */
+int cdae_model_timesteps(const long long* t, const long long* map, float scale, int rescale, float* out_f, long long* out_i, int N, void* stream);
+int cdae_embedding_add(float* emb, const float* table, const long long* idx, int N, int D, void* stream);     /* unet.py:550 */
+int cdae_embedding_bwd(const float* demb, float* dtable, const long long* idx, int N, int D, void* stream);
+int cdae_axpby(float a, const float* x, float b, const float* y, float* out, long n, void* stream);          /* y may be NULL */
+int cdae_mul_rows(float* x, const float* m, int N, int D, void* stream);                                       /* unet.py:608-611 */
+int cdae_copy2d(const float* src, float* dst, long rows, int cols, long lds, long ldd, int accumulate, void* stream);  /* th.cat unet.py:628 */
+int cdae_nchw_to_nhwc(const float* src, float* dst, int N, int C, int HW, void* stream);
+int cdae_nhwc_to_nchw(const float* src, float* dst, int N, int C, int HW, void* stream);
+int cdae_sumpool2(const float* src, float* dst, int N, int H, int W, int C, void* stream);
+/* q_sample (gaussian_diffusion.py:201-222) */
+int cdae_q_sample(const float* x0, const float* noise, const long long* t, const float* tab, int T, float* out, int N, long per_sample, void* stream);
+/* one fused DDIM update (p_mean_variance eps branch + ddim_sample, gaussian_diffusion.py:336-338,533-558); noise may be NULL iff eta==0 */
+int cdae_ddim_update(const float* x, const float* eps, const long long* t, const float* tab, int T, float eta, const float* noise, int clip,
+                     float* sample, float* pred_xstart, int N, long per_sample, void* stream);
+/* one fused ancestral update (p_sample, gaussian_diffusion.py:383-414) */
+int cdae_ddpm_update(const float* x, const float* eps, const long long* t, const float* tab, int T, const float* noise, int clip,
+                     float* sample, float* pred_xstart, int N, long per_sample, void* stream);
+int cdae_softplus_fwd(const float* x, float* y, long n, float add, void* stream);                             /* nn.py:108 */
+int cdae_softplus_bwd(const float* x, const float* dy, float* dx, long n, void* stream);
+int cdae_reparam(const float* m, const float* v, float vscale, const float* eps, float* z, long n, void* stream);   /* nn.py:460-467 */
+int cdae_causal_mask(const float* u, const float* A, float* out, int N, int nv, int d, int transpose, void* stream); /* nn.py:290-295 */
+/* AdamW + EMA over flat fp32 buffers (train_util.py:292-297, nn.py:503-513); ema may be NULL */
+int cdae_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, long n, double lr, double beta1, double beta2, double eps,
+                   double weight_decay, int step, double ema_rate, double grad_scale, void* stream);
+int cdae_sqsum(const float* x, long n, double* out, void* stream);                                            /* grad-norm, train_util.py:299-303 */
+int cdae_mse_rows(const float* a, const float* b, float* out, int N, long per, void* stream);               /* mean_flat((a-b)^2), gaussian_diffusion.py:847 */
+int cdae_mse_rows_bwd(const float* a, const float* b, const float* gout, float* db, int N, long per, void* stream);
+
+/* ---- opt-in profiler (prof.hip): HIP events on the launch stream around every launch of a kernel family */
+int cdae_prof_enable(int on);
+int cdae_prof_read(double* ms, double* work, long long* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

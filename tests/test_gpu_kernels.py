@@ -1,0 +1,233 @@
+"""GPU parity of each HIP kernel (through the C-ABI wrappers in causaldiffae_amd.ops) against a plain
+torch-CPU fp32 restatement of the same op / the oracle.  Tolerances are stated per test; the bar for the
+whole path is fp32 within 1e-4 (BASELINE north_star)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def rnd(*shape, seed=0, lo=-1.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.rand(*shape, generator=g) * (hi - lo) + lo
+
+
+def err(a, b):
+    return (a.detach().cpu().double() - b.detach().cpu().double()).abs().max().item()
+
+
+def chlast_param(w):
+    return w.contiguous(memory_format=torch.channels_last).to(DEV)
+
+
+# ------------------------------------------------------------------ GEMM / linear
+@pytest.mark.parametrize("M,N,K", [(16, 512, 128), (2, 1024, 512), (300, 200, 68), (1024, 1152, 384), (4096, 128, 256),
+                                   (65, 33, 4), (8192, 256, 512)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_linear(M, N, K, act):
+    from causaldiffae_amd import ops
+    x, w, b, r = rnd(M, K), rnd(N, K, seed=1) / K ** 0.5, rnd(N, seed=2), rnd(M, N, seed=3)
+    y = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), res=r.to(DEV), act=act)
+    ref = F.linear(x.double(), w.double(), b.double()) + r.double()
+    ref = [ref, ref * torch.sigmoid(ref), F.leaky_relu(ref, 0.01)][act]
+    assert err(y, ref) < 2e-5
+
+
+def test_linear_backward():
+    from causaldiffae_amd import ops
+    M, N, K = 260, 384, 512
+    x, w, b = rnd(M, K), rnd(N, K, seed=1) / K ** 0.5, rnd(N, seed=2)
+    gy = rnd(M, N, seed=5)
+    xd, wd, bd = [t.to(DEV).requires_grad_(True) for t in (x, w, b)]
+    y = ops.linear(xd, wd, bd, act=1)
+    (y * gy.to(DEV)).sum().backward()
+    xc, wc, bc = [t.double().requires_grad_(True) for t in (x, w, b)]
+    yc = F.silu(F.linear(xc, wc, bc))
+    (yc * gy.double()).sum().backward()
+    assert err(y, yc) < 2e-5
+    assert err(xd.grad, xc.grad) < 5e-5
+    assert err(wd.grad, wc.grad) < 2e-4          # sums over M=260 rows
+    assert err(bd.grad, bc.grad) < 2e-4
+
+
+# ------------------------------------------------------------------ conv3x3 forward
+CONVS = [
+    # N, Cin, Cout, H, stride, up, nchw_in, out_nchw
+    (2, 128, 128, 16, 1, False, False, False),
+    (2, 128, 256, 8, 1, False, False, False),
+    (3, 384, 128, 8, 1, False, False, False),      # Cout < tile, Cin = 3*128
+    (2, 256, 256, 16, 2, False, False, False),     # Downsample
+    (2, 128, 128, 8, 1, True, False, False),       # Upsample fused
+    (2, 4, 128, 16, 1, False, True, False),        # stem, NCHW input, generic gather
+    (2, 1, 128, 12, 1, False, True, False),
+    (2, 3, 128, 9, 1, False, True, False),         # odd size
+    (2, 128, 4, 16, 1, False, False, True),        # output head -> NCHW
+    (4, 4, 16, 32, 2, False, True, False),         # encoder conv (stride 2, tiny channels)
+    (4, 16, 32, 16, 2, False, False, False),
+    (4, 32, 64, 8, 2, False, False, False),
+    (1, 1024, 512, 8, 1, False, False, False),     # deep K -> split-K
+    (2, 640, 384, 16, 1, False, False, False),
+]
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,stride,up,nchw_in,out_nchw", CONVS)
+def test_conv3x3_forward(N, Cin, Cout, H, stride, up, nchw_in, out_nchw):
+    from causaldiffae_amd import ops
+    x, w, b = rnd(N, Cin, H, H), rnd(Cout, Cin, 3, 3, seed=1) / (9 * Cin) ** 0.5, rnd(Cout, seed=2)
+    xin = x.to(DEV) if nchw_in else ops.to_nhwc(x.to(DEV))
+    xr = F.interpolate(x.double(), scale_factor=2, mode="nearest") if up else x.double()
+    ref = F.conv2d(xr, w.double(), b.double(), stride=stride, padding=1)
+    res = None
+    if not out_nchw:
+        r = rnd(*ref.shape, seed=7)
+        res = ops.to_nhwc(r.to(DEV))
+        ref = ref + r.double()
+    y = ops.conv3x3(xin, chlast_param(w), b.to(DEV), res=res, stride=stride, up=up, out_nchw=out_nchw)
+    assert tuple(y.shape) == tuple(ref.shape)
+    if out_nchw:
+        assert y.is_contiguous()
+    assert err(y, ref) < 3e-5
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,stride,up,nchw_in", [
+    (2, 128, 128, 8, 1, False, False), (2, 128, 256, 8, 1, False, False), (2, 256, 128, 8, 2, False, False),
+    (2, 128, 128, 4, 1, True, False), (2, 4, 128, 8, 1, False, True), (2, 128, 4, 8, 1, False, False),
+    (3, 16, 32, 8, 2, False, False), (2, 1, 16, 14, 2, False, True), (2, 384, 256, 8, 1, False, False)])
+def test_conv3x3_backward(N, Cin, Cout, H, stride, up, nchw_in):
+    from causaldiffae_amd import ops
+    x, w, b = rnd(N, Cin, H, H), rnd(Cout, Cin, 3, 3, seed=1) / (9 * Cin) ** 0.5, rnd(Cout, seed=2)
+    xd = (x.to(DEV) if nchw_in else ops.to_nhwc(x.to(DEV))).requires_grad_(True)
+    wd = chlast_param(w).requires_grad_(True)
+    bd = b.to(DEV).requires_grad_(True)
+    y = ops.conv3x3(xd, wd, bd, stride=stride, up=up)
+    xc, wc, bc = [t.double().requires_grad_(True) for t in (x, w, b)]
+    xr = F.interpolate(xc, scale_factor=2, mode="nearest") if up else xc
+    yc = F.conv2d(xr, wc, bc, stride=stride, padding=1)
+    gy = rnd(*yc.shape, seed=9)
+    (y * gy.to(DEV)).sum().backward()
+    (yc * gy.double()).sum().backward()
+    assert err(y, yc) < 3e-5
+    assert err(xd.grad, xc.grad) < 1e-4
+    scale = max(1.0, wc.grad.abs().max().item())
+    assert err(wd.grad, wc.grad) < 1e-4 * scale
+    assert err(bd.grad, bc.grad) < 1e-4 * max(1.0, bc.grad.abs().max().item())
+    assert wd.grad.permute(0, 2, 3, 1).is_contiguous() or Cin == 1
+
+
+# ------------------------------------------------------------------ GroupNorm
+@pytest.mark.parametrize("N,C,H", [(2, 128, 16), (2, 384, 8), (3, 640, 4), (2, 896, 8), (2, 1024, 8), (2, 128, 64), (2, 32, 7), (2, 96, 6)])
+@pytest.mark.parametrize("ssn,silu", [(False, True), (True, True), (False, False)])
+def test_group_norm(N, C, H, ssn, silu):
+    from causaldiffae_amd import ops
+    x = rnd(N, C, H, H, lo=-2, hi=3)
+    x = x + torch.linspace(-3, 3, C)[None, :, None, None]        # per-channel offsets: mean^2 >> var inside groups
+    g, b = rnd(C, seed=1) + 1.5, rnd(C, seed=2)
+    ss = rnd(N, 2 * C, seed=3) if ssn else None
+    xd, gd, bd = [t.to(DEV).requires_grad_(True) for t in (x, g, b)]
+    ssd = ss.to(DEV).requires_grad_(True) if ssn else None
+    y = ops.group_norm(ops.to_nhwc(xd), gd, bd, ssd, silu)
+    xc, gc, bc = [t.double().requires_grad_(True) for t in (x, g, b)]
+    ssc = ss.double().requires_grad_(True) if ssn else None
+    h = F.group_norm(xc, 32, gc, bc, 1e-5)
+    if ssn:
+        h = h * (1 + ssc[:, :C, None, None]) + ssc[:, C:, None, None]
+    yc = F.silu(h) if silu else h
+    gy = rnd(N, C, H, H, seed=4)
+    (y * gy.to(DEV)).sum().backward()
+    (yc * gy.double()).sum().backward()
+    assert err(y, yc) < 2e-5
+    assert err(xd.grad, xc.grad) < 1e-4
+    assert err(gd.grad, gc.grad) < 1e-4 * max(1.0, gc.grad.abs().max().item())
+    assert err(bd.grad, bc.grad) < 1e-4 * max(1.0, bc.grad.abs().max().item())
+    if ssn:
+        assert err(ssd.grad, ssc.grad) < 1e-4 * max(1.0, ssc.grad.abs().max().item())
+
+
+# ------------------------------------------------------------------ attention
+@pytest.mark.parametrize("B,T,heads,ch", [(2, 256, 4, 96), (2, 64, 4, 128), (3, 256, 4, 64), (2, 16, 4, 64), (1, 49, 4, 8)])
+def test_qkv_attention(B, T, heads, ch):
+    from causaldiffae_amd import ops
+    from oracle.unet_ref import qkv_attention
+    C = heads * ch
+    qkv = rnd(B, 3 * C, T, lo=-2, hi=2)                  # reference layout [B, 3C, T]
+    rows = qkv.permute(0, 2, 1).contiguous().to(DEV).requires_grad_(True)
+    out = ops.qkv_attention(rows, heads)                # [B, T, C]
+    qc = qkv.double().requires_grad_(True)
+    ref = qkv_attention(qc, heads)                      # [B, C, T]
+    gy = rnd(B, C, T, seed=3)
+    (out * gy.permute(0, 2, 1).to(DEV)).sum().backward()
+    (ref * gy.double()).sum().backward()
+    assert err(out.permute(0, 2, 1), ref) < 2e-5
+    assert err(rows.grad.permute(0, 2, 1), qc.grad) < 1e-4
+
+
+# ------------------------------------------------------------------ encoder BN + LeakyReLU
+@pytest.mark.parametrize("training", [True, False])
+def test_bn_lrelu(training):
+    from causaldiffae_amd import ops
+    N, C, H = 4, 32, 8
+    x = rnd(N, C, H, H, lo=-1, hi=2)
+    g, b = rnd(C, seed=1) + 1.5, rnd(C, seed=2)
+    rm, rv = rnd(C, seed=3) * 0.1, rnd(C, seed=4) * 0.2 + 1.0
+    bn = torch.nn.BatchNorm2d(C).double()
+    bn.weight.data, bn.bias.data = g.double(), b.double()
+    bn.running_mean.data, bn.running_var.data = rm.double().clone(), rv.double().clone()
+    bn.train(training)
+    xc = x.double().requires_grad_(True)
+    yc = F.leaky_relu(bn(xc), 0.01)
+    xd, gd, bd = [t.to(DEV).requires_grad_(True) for t in (x, g, b)]
+    rmd, rvd = rm.to(DEV), rv.to(DEV)
+    y = ops.bn_lrelu(ops.to_nhwc(xd), gd, bd, rmd, rvd, training)
+    assert err(y, yc) < 2e-5
+    if training:
+        assert err(rmd, bn.running_mean) < 1e-6 and err(rvd, bn.running_var) < 1e-6
+        gy = rnd(N, C, H, H, seed=6)
+        (y * gy.to(DEV)).sum().backward()
+        (yc * gy.double()).sum().backward()
+        assert err(xd.grad, xc.grad) < 1e-4
+        assert err(gd.grad, bn.weight.grad) < 1e-4 and err(bd.grad, bn.bias.grad) < 1e-4
+
+
+# ------------------------------------------------------------------ sampler kernels vs oracle
+def test_sampler_kernels():
+    from causaldiffae_amd import script_util as su
+    from oracle import diffusion_ref as D
+    for rs in ("ddim100", ""):
+        d = su.create_gaussian_diffusion(steps=1000, timestep_respacing=rs, rescale_timesteps=True)
+        sch = D.Schedule(1000, "linear", rs, True)
+        N = 6
+        t = torch.tensor([0, 1, 5, d.num_timesteps // 2, d.num_timesteps - 2, d.num_timesteps - 1], dtype=torch.int64)
+        x0, noise, x, eps = rnd(N, 4, 8, 8), rnd(N, 4, 8, 8, seed=1, lo=-2, hi=2), rnd(N, 4, 8, 8, seed=2, lo=-2, hi=2), rnd(N, 4, 8, 8, seed=3, lo=-2, hi=2)
+        td = t.to(DEV)
+        assert err(d.q_sample(x0.to(DEV), td, noise.to(DEV)), D.q_sample(sch, x0, t, noise)) == 0.0        # same fp32 ops, same order
+        for eta in (0.0, 0.7):
+            o = d._fused_update(True, x.to(DEV), eps.to(DEV), td, True, eta, noise.to(DEV) if eta else None)
+            r = D.ddim_step(sch, eps, x, t, noise, eta)
+            assert err(o["pred_xstart"], r["pred_xstart"]) == 0.0
+            assert err(o["sample"], r["sample"]) < 2e-6
+        o = d._fused_update(False, x.to(DEV), eps.to(DEV), td, True, 0.0, noise.to(DEV))
+        r = D.p_sample_step(sch, eps, x, t, noise)
+        assert err(o["sample"], r["sample"]) < 2e-6 and err(o["pred_xstart"], r["pred_xstart"]) == 0.0
+        # timestep map: int64 indices bit exact, float rescale identical
+        wm = d._wrap_model(lambda *a, **k: None)
+        idx, seen = wm.map_timesteps(td)
+        np.testing.assert_array_equal(idx.cpu().numpy(), np.array(d.timestep_map)[t.numpy()])
+        np.testing.assert_array_equal(seen.cpu().numpy(), sch.model_t(t).numpy())
+
+
+def test_timestep_embedding_and_small_ops():
+    from causaldiffae_amd import nn as pnn, ops
+    from oracle import unet_ref as U
+    t = torch.tensor([0.0, 1.0, 10.0, 249.0, 990.0, 999.0, 123.5])
+    assert err(pnn.timestep_embedding(t.to(DEV), 128), U.timestep_embedding(t, 128)) < 5e-6
+    assert err(pnn.timestep_embedding(t.to(DEV), 33), U.timestep_embedding(t, 33)) < 5e-6
+    x = rnd(5, 512, lo=-30, hi=30)
+    assert err(ops.softplus_eps(x.to(DEV)), F.softplus(x) + 1e-8) < 1e-6
+    assert err(ops.silu(x.to(DEV)), F.silu(x)) < 2e-6
+    a, b = ops.to_nhwc(rnd(2, 128, 4, 4).to(DEV)), ops.to_nhwc(rnd(2, 384, 4, 4, seed=1).to(DEV))
+    assert err(ops.cat_channels(a, b), torch.cat([a.cpu(), b.cpu()], 1)) == 0.0
+    assert err(ops.to_nchw(a), a.cpu()) == 0.0

@@ -1,0 +1,264 @@
+"""GPU parity of the product path (improved_diffusion API -> HIP kernels) against the committed golden
+vectors produced by the reference (tests/golden, tools/gen_golden.py) and against the CPU oracle on the
+same seeded inputs.  Bar: fp32 within 1e-4 (BASELINE north_star); integer timestep indices bit exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.closed_form import fill_value, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def err(a, b):
+    a = a.detach().cpu().double() if torch.is_tensor(a) else torch.as_tensor(np.asarray(a)).double()
+    b = b.detach().cpu().double() if torch.is_tensor(b) else torch.as_tensor(np.asarray(b)).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return (a - b).abs().max().item()
+
+
+def load_closed_form(module, prefix=""):
+    sd = module.state_dict()
+    module.load_state_dict({k: fill_value(prefix + k, v.shape) for k, v in sd.items()})
+    return module.to(DEV)
+
+
+def probe_err(t, g, prefix):
+    f = t.detach().cpu().double().flatten()
+    e = max(err(f[:64], g[prefix + "/head"]), err(f[::997], g[prefix + "/strided"]))
+    scale = max(1.0, float(np.abs(g[prefix + "/head"]).max()), float(np.abs(g[prefix + "/strided"]).max()))
+    return e / scale
+
+
+MODEL_CFG = {
+    "M32": dict(image_size=32, in_channels=1, n_vars=2, class_cond=True),
+    "P64": dict(image_size=64, in_channels=4, n_vars=4),
+    "C64": dict(image_size=64, in_channels=3, n_vars=4),
+    "T28": dict(image_size=28, in_channels=1, n_vars=2, class_cond=True, num_channels=32, num_res_blocks=1),
+}
+
+
+def make(tag, respacing="", masking=False):
+    from improved_diffusion import script_util as su
+    cfg = {**su.model_and_diffusion_defaults(), "rep_cond": True, "causal_modeling": True, **MODEL_CFG[tag],
+           "timestep_respacing": respacing, "masking": masking}
+    model, diff = su.create_model_and_diffusion(**cfg)
+    return load_closed_form(model), diff, cfg
+
+
+def model_inputs(tag, cfg, N):
+    C, S, nv = cfg["in_channels"], cfg["image_size"], cfg["n_vars"]
+    x = synth(tag + ".x", (N, C, S, S))
+    x0 = synth(tag + ".x0", (N, C, S, S), 0.0, 1.0)
+    c = synth(tag + ".c", (N, nv), 0.0, 1.0)
+    z = synth(tag + ".z", (N, 512))
+    y = torch.tensor([(3 * i + 1) % 10 for i in range(N)], dtype=torch.int64) if cfg["class_cond"] else None
+    return x, x0, c, z, y
+
+
+# ------------------------------------------------------------------ G3: blocks (forward + all gradients)
+@pytest.mark.parametrize("tag,ci,co,ssn", [("res_same", 128, 128, True), ("res_skip", 128, 256, True), ("res_cat", 384, 128, True),
+                                           ("res_nossn", 64, 96, False)])
+def test_resblock_golden(golden, tag, ci, co, ssn):
+    from improved_diffusion.unet import ResBlock
+    g = golden("g3_blocks.npz")
+    meta = json.load(open(os.path.join(GOLDEN, "g3_blocks.json")))[tag]
+    blk = load_closed_form(ResBlock(ci, 512, 0.0, out_channels=co, use_scale_shift_norm=ssn), tag + ".")
+    x = synth(tag + ".x", meta["x_shape"]).to(DEV).requires_grad_(True)
+    e = synth(tag + ".emb", (meta["x_shape"][0], 512)).to(DEV).requires_grad_(True)
+    y = blk(x, e)
+    (y * synth(tag + ".gy", meta["y_shape"]).to(DEV)).sum().backward()
+    assert err(y, g[tag + "/y"]) < 1e-4
+    assert err(x.grad, g[tag + "/gx"]) < 1e-4
+    assert err(e.grad, g[tag + "/gemb"]) < 1e-4
+    for k, p in blk.named_parameters():
+        assert probe_err(p.grad, g, f"{tag}/g.{k}") < 2e-4, k
+
+
+@pytest.mark.parametrize("ch,T", [(96, 256), (128, 64), (64, 256), (64, 16)])
+def test_attention_block_golden(golden, ch, T):
+    from improved_diffusion.unet import AttentionBlock
+    g = golden("g3_blocks.npz")
+    tag = f"attn_{ch}_{T}"
+    meta = json.load(open(os.path.join(GOLDEN, "g3_blocks.json")))[tag]
+    blk = load_closed_form(AttentionBlock(ch * 4, num_heads=4), tag + ".")
+    x = synth(tag + ".x", meta["x_shape"]).to(DEV).requires_grad_(True)
+    y = blk(x)
+    (y * synth(tag + ".gy", meta["y_shape"]).to(DEV)).sum().backward()
+    assert err(y, g[tag + "/y"]) < 1e-4
+    assert err(x.grad, g[tag + "/gx"]) < 1e-4
+    for k, p in blk.named_parameters():
+        assert probe_err(p.grad, g, f"{tag}/g.{k}") < 2e-4, k
+
+
+def test_qkv_module_and_resample_golden(golden):
+    from improved_diffusion.unet import Downsample, QKVAttention, Upsample
+    g = golden("g3_blocks.npz")
+    qkv = synth("qkv.x", (8, 96, 64), -2, 2).to(DEV).requires_grad_(True)
+    y = QKVAttention()(qkv)
+    (y * synth("qkv.gy", tuple(y.shape)).to(DEV)).sum().backward()
+    assert err(y, g["qkv/y"]) < 2e-5 and err(qkv.grad, g["qkv/gx"]) < 1e-4
+    for tag, mod, xs in [("down", Downsample(128, True), (2, 128, 8, 8)), ("up", Upsample(128, True), (2, 128, 4, 4))]:
+        mod = load_closed_form(mod, tag + ".")
+        x = synth(tag + ".x", xs).to(DEV).requires_grad_(True)
+        y = mod(x)
+        (y * synth(tag + ".gy", tuple(y.shape)).to(DEV)).sum().backward()
+        assert err(y, g[tag + "/y"]) < 1e-4 and err(x.grad, g[tag + "/gx"]) < 1e-4
+        for k, p in mod.named_parameters():
+            assert probe_err(p.grad, g, f"{tag}/g.{k}") < 2e-4, k
+
+
+# ------------------------------------------------------------------ G4: causal encoder
+@pytest.mark.parametrize("tag,C,S,nv", [("enc32", 1, 32, 2), ("enc64", 4, 64, 4), ("enc96", 4, 96, 4)])
+def test_encoder_golden(golden, tag, C, S, nv):
+    from improved_diffusion.nn import GaussianConvEncoder
+    from improved_diffusion.unet import encoder_hidden_dims
+    g = golden("g4_encoder.npz")
+    enc = load_closed_form(GaussianConvEncoder(C, 512, hidden_dims=encoder_hidden_dims(S, nv), num_vars=nv), "rep_emb.")
+    x = synth(tag + ".x", (4, C, S, S), 0.0, 1.0).to(DEV)
+    enc.eval()
+    with torch.no_grad():
+        mu, var = enc.encode(x)
+    assert err(mu, g[tag + "/eval_mu"]) < 1e-4 and err(var, g[tag + "/eval_var"]) < 1e-4
+    enc.train()
+    xg = x.clone().requires_grad_(True)
+    mu, var = enc.encode(xg)
+    assert err(mu, g[tag + "/train_mu"]) < 1e-4 and err(var, g[tag + "/train_var"]) < 1e-4
+    ((mu * synth(tag + ".gmu", (4, 512)).to(DEV)).sum() + (var * synth(tag + ".gvar", (4, 512)).to(DEV)).sum()).backward()
+    assert err(xg.grad, g[tag + "/train_gx"]) < 1e-4 * max(1.0, float(np.abs(g[tag + "/train_gx"]).max()))
+    for k, v in enc.state_dict().items():
+        if "running" in k:
+            assert err(v, g[f"{tag}/after.{k}"]) < 1e-5, k
+    for k, p in enc.named_parameters():
+        if k.endswith(".0.bias"):
+            continue            # exactly-zero gradient (bias ahead of batch-stat BN)
+        assert probe_err(p.grad, g, f"{tag}/g.{k}") < 3e-4, k
+
+
+def test_causal_layer_golden(golden):
+    from improved_diffusion.nn import CausalModeling
+    from improved_diffusion.unet import ADJACENCY
+    g = golden("g4_encoder.npz")
+    for nv, graphs in [(2, [("morpho", "morphomnist")]), (4, [("circuit", "circuit"), ("pendulum", "pendulum")])]:
+        cm = load_closed_form(CausalModeling(latent_dim=512, num_var=nv, learn=False), "causal_mask.")
+        u = synth(f"causal{nv}.u", (3, 512)).to(DEV).requires_grad_(True)
+        for gname, key in graphs:
+            A = torch.tensor(ADJACENCY[key], dtype=torch.float32)
+            z_pre = cm.causal_masking(u, A)
+            z_post = cm.nonlinearity_add_back_noise(u, z_pre)
+            assert err(z_pre, g[f"causal/{gname}/z_pre"]) < 1e-6
+            assert err(z_post, g[f"causal/{gname}/z_post"]) < 2e-5
+        (z_post * synth(f"causal{nv}.gz", (3, 512)).to(DEV)).sum().backward()
+        assert err(u.grad, g[f"causal/{graphs[-1][0]}/gu"]) < 5e-5
+
+
+# ------------------------------------------------------------------ G6: full UNet forward at BASELINE shapes
+@pytest.mark.parametrize("tag", ["M32", "P64", "C64"])
+def test_unet_forward_golden(golden, tag):
+    from improved_diffusion.nn import rng_override
+    g = golden("g6_unet.npz")
+    model, diff, cfg = make(tag)
+    model.eval()
+    x, x0, c, z, y = model_inputs(tag, cfg, 2)
+    kw = dict(y=y.to(DEV)) if y is not None else {}
+    t = torch.tensor([37.0, 990.0], device=DEV)
+    with torch.no_grad():
+        e, *_ = model(x.to(DEV), t, z=z.to(DEV), **kw)
+        assert e.is_contiguous() and tuple(e.shape) == tuple(x.shape)
+        assert err(e, g[f"{tag}/eps_z"]) < 1e-4
+        with rng_override(eps_z=torch.from_numpy(g[f"{tag}/eps_draw"]).to(DEV)):
+            e2, mu, var, zp, _ = model(x.to(DEV), t, x_start=x0.to(DEV), **kw)
+        assert err(mu, g[f"{tag}/mu"]) < 1e-4 and err(var, g[f"{tag}/var"]) < 1e-4 and err(zp, g[f"{tag}/z_post"]) < 1e-4
+        assert err(e2, g[f"{tag}/eps_enc"]) < 1e-4
+
+
+# ------------------------------------------------------------------ G8: counterfactual pattern, single steps, DDIM-100
+def test_ddim_p64_golden(golden):
+    from improved_diffusion.nn import reparameterize
+    from improved_diffusion.unet import ADJACENCY
+    g = golden("g8_ddim.npz")
+    model, diff, cfg = make("P64", respacing="ddim100")
+    model.eval()
+    N = 2
+    x, x0, c, z, _ = model_inputs("P64", cfg, N)
+    with torch.no_grad():
+        A = torch.tensor(ADJACENCY["pendulum"], dtype=torch.float32)
+        mu, var = model.rep_emb.encode(x0.to(DEV))
+        var = torch.ones_like(mu) * 0.001
+        z_pre = model.causal_mask.causal_masking(mu, A)
+        z_post = model.causal_mask.nonlinearity_add_back_noise(mu, z_pre)
+        z_post[:, :128] = 0.2
+        zz = reparameterize(z_post, var, eps=torch.from_numpy(g["cf/eps_draw"]).to(DEV))
+        assert err(zz, g["cf/z"]) < 2e-5
+        t99 = torch.full((N,), 99, dtype=torch.int64, device=DEV)
+        x_t = diff.q_sample(x0.to(DEV), t99, noise=synth("P64.qnoise", (N, 4, 64, 64), -1.7, 1.7).to(DEV))
+        assert err(x_t, g["cf/x_t"]) < 1e-6
+        for tv in (99, 0):
+            tt = torch.full((N,), tv, dtype=torch.int64, device=DEV)
+            amp = float(diff.sqrt_recipm1_alphas_cumprod[tv])
+            o = diff.ddim_sample(model, x_t, tt, model_kwargs=dict(z=zz))
+            assert err(o["sample"], g[f"ddim_step{tv}/sample"]) < 1e-4
+            assert err(o["pred_xstart"], g[f"ddim_step{tv}/pred_xstart"]) < 1e-4 + 1e-5 * amp
+            o = diff.ddim_sample(model, x_t, tt, model_kwargs=dict(z=zz), eta=0.7,
+                                 noise=torch.from_numpy(g[f"ddim_eta_step{tv}/noise"]).to(DEV))
+            assert err(o["sample"], g[f"ddim_eta_step{tv}/sample"]) < 1e-4
+            o = diff.p_sample(model, x_t, tt, model_kwargs=dict(z=zz), noise=torch.from_numpy(g[f"p_step{tv}/noise"]).to(DEV))
+            assert err(o["sample"], g[f"p_step{tv}/sample"]) < 1e-4
+        # DDIM-100 loop, eager and graph-replayed: both within 1e-4 of the reference's final sample
+        k = 0
+        for o in diff.ddim_sample_loop_progressive(model, (N, 4, 64, 64), noise=x_t, model_kwargs=dict(z=zz)):
+            k += 1
+            if k in (1, 2, 10, 50, 100):
+                assert err(o["sample"], g[f"loop/sample_after{k}"]) < 1e-4, k
+        final = diff.ddim_sample_loop(model, (N, 4, 64, 64), noise=x_t, model_kwargs=dict(z=zz), use_graph=True)
+        assert err(final, g["loop/sample_after100"]) < 1e-4
+        assert err(final, o["sample"]) == 0.0          # graph replay == eager, bit for bit
+
+
+# ------------------------------------------------------------------ G7: training_losses + AdamW/EMA trajectory
+@pytest.mark.parametrize("variant,masking", [("plain", False), ("masked", True)])
+def test_training_trajectory_golden(golden, variant, masking):
+    from improved_diffusion.nn import rng_override
+    from improved_diffusion.train_util import FusedAdamWEMA
+    g = golden("g7_train.npz")
+    model, diff, cfg = make("T28", masking=masking)
+    model.train()
+    opt = FusedAdamWEMA(model, lr=1e-4, weight_decay=0.0, ema_rates=[0.9999])
+    names = [k for k, _ in model.named_parameters()]
+    sel = list(g[f"{variant}/sel_names"])
+    N = 4
+    for step in range(3):
+        diff.kl_weight = [0.0, 0.25, 0.5][step]
+        x0 = synth(f"T28.{step}.x0", (N, 1, 28, 28), 0.0, 1.0).to(DEV)
+        c = synth(f"T28.{step}.c", (N, 2), 0.0, 1.0).to(DEV)
+        y = torch.tensor([(step + 2 * i) % 10 for i in range(N)], dtype=torch.int64, device=DEV)
+        t = torch.from_numpy(g[f"{variant}/step{step}/t"]).to(DEV)
+        noise = synth(f"T28.{step}.noise", (N, 1, 28, 28), -1.7, 1.7).to(DEV)
+        inj = dict(eps_z=torch.from_numpy(g[f"{variant}/step{step}/eps_draw"]).to(DEV))
+        if masking:
+            inj["cfg_mask"] = torch.from_numpy(g[f"{variant}/step{step}/cfg_mask"]).to(DEV)
+        opt.zero_grad()
+        with rng_override(**inj):
+            terms = diff.training_losses(model, x0, t, model_kwargs=dict(c=c, y=y), noise=noise, rep_cond=True, causal_modeling=True)
+        terms["loss"].mean().backward()
+        for k in ("loss", "mse", "kld_rep"):
+            ref = g[f"{variant}/step{step}/{k}"]
+            assert err(terms[k], ref) < 1e-4 * max(1.0, float(np.abs(ref).max())), (step, k)
+        sq = opt.grad_sqsum()
+        assert abs(sq - float(g[f"{variant}/step{step}/grad_sqsum"])) <= 2e-3 * sq
+        if step == 0:
+            for k in sel:
+                assert probe_err(dict(model.named_parameters())[k].grad, g, f"{variant}/grad0/{k}") < 1e-3, k
+        opt.step()
+        if step in (0, 2):
+            params = dict(model.named_parameters())
+            ema = opt.ema_state_dict(0)
+            for k in sel:
+                assert probe_err(params[k], g, f"{variant}/after{step + 1}/{k}") < 1e-5, k       # 1e-5
+                assert probe_err(ema[k], g, f"{variant}/ema{step + 1}/{k}") < 1e-5, k
+            assert err(model.state_dict()["rep_emb.encoder.1.1.running_var"], g[f"{variant}/after{step + 1}/bn_running_var"]) < 1e-5
