@@ -41,12 +41,26 @@ def randomize(model, seed):
                 b.copy_(1.0 + 0.1 * torch.rand(b.shape, generator=g))
 
 
-def cpu_baseline(steps=3, batch=16):
+def host_cores():
+    """CPUs this process may actually use: min(affinity, cgroup quota) — the GPU box exposes 256 logical CPUs
+    under a 16-CPU quota, and oversubscribing torch's thread pool there is 10x slower."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(steps=8, batch=16):
     """The oracle (torch-CPU restatement of the reference forward + DDIM step) timed on this host's cores."""
     from oracle import diffusion_ref as D
     from oracle import unet_ref as U
     from oracle.closed_form import fill_state_dict, synth
-    torch.set_num_threads(os.cpu_count())
+    cores = host_cores()
+    torch.set_num_threads(cores)
     cfg = U.default_cfg(image_size=64, in_channels=4, n_vars=4, rep_cond=True, causal_modeling=True)
     sd = fill_state_dict(U.param_spec(cfg))
     sch = D.Schedule(1000, "linear", "ddim100", True)
@@ -58,9 +72,9 @@ def cpu_baseline(steps=3, batch=16):
         t0 = time.perf_counter()
         D.sample_loop(sch, fn, x, ddim=True, n_steps=steps)
         dt = time.perf_counter() - t0
-    return {"value": batch * steps / dt, "unit": "image-steps/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": batch * steps / dt, "unit": "image-steps/s", "cores": cores, "kind": "port",
             "sample": f"oracle (torch-CPU restatement), P64 DDIM step, batch {batch}, {steps} steps after 1 warm-up, "
-                      f"{os.cpu_count()} threads"}
+                      f"{cores} threads (= cgroup CPU quota; host shows {os.cpu_count()} logical CPUs)"}
 
 
 def main():

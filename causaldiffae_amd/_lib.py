@@ -35,7 +35,7 @@ SIGNATURES = {
     "cdae_gn_bwd": [P, P, P, I, I, I, I, I, I, I, P, P, P, P, P, I, I, P, P, I, P, I, I, P, P],
     "cdae_bn_workspace_floats": [I],
     "cdae_bn_lrelu_fwd": [P, P, L, I, P, P, P, P, I, F, F, F, P, P, P, P, P, P],
-    "cdae_bn_lrelu_bwd": [P, P, P, L, I, P, P, P, P, F, P, P, I, P, P],
+    "cdae_bn_lrelu_bwd": [P, P, P, L, I, P, P, P, P, P, F, P, P, I, P, P],
     "cdae_softmax_rows": [P, L, I, P],
     "cdae_softmax_rows_bwd": [P, P, L, I, P],
     "cdae_silu_fwd": [P, P, L, P],

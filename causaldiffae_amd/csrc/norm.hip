@@ -335,17 +335,18 @@ __global__ void affine_lrelu_kernel(const float* __restrict__ x, float* __restri
 // pass 1: per-channel partial sums of dh and dh*xh; pass 2 (finalize): dgamma, dbeta, means; pass 3: dx
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy, long rows_total, int C,
                                                               int rows_per_block, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                              const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift, float slope,
                                                               float* __restrict__ partial) {
     __shared__ float sS[256], sQ[256];
     const int tid = threadIdx.x, rows = 256 / C, r = tid / C, c = tid - r * C;
     float S = 0.f, Q = 0.f;
     if (r < rows) {
-        const float mu = mean[c], rs = rstd[c], gm = gamma[c], bt = beta[c];
+        const float mu = mean[c], rs = rstd[c], sc = scale[c], sf = shift[c];
         const long p0 = (long)blockIdx.x * rows_per_block, p1 = min(rows_total, p0 + rows_per_block);
         for (long p = p0 + r; p < p1; p += rows) {
-            float xh = (x[p * C + c] - mu) * rs;
-            float h = xh * gm + bt;
+            float xv = x[p * C + c];
+            float xh = (xv - mu) * rs;
+            float h = xv * sc + sf;            // exactly the forward's pre-activation: same side of the LeakyReLU kink
             float dh = dy[p * C + c] * (h > 0.f ? 1.f : slope);
             S += dh; Q += dh * xh;
         }
@@ -374,12 +375,13 @@ __global__ void bn_bwd_finalize_kernel(long rows_total, int C, int nchunk, const
 
 __global__ void bn_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, long total, int C,
                                  const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                 const float* __restrict__ beta, float slope, const float* __restrict__ sums) {
+                                 const float* __restrict__ scale, const float* __restrict__ shift, float slope, const float* __restrict__ sums) {
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         int c = (int)(idx % C);
         float rs = rstd[c], gm = gamma[c];
-        float xh = (x[idx] - mean[c]) * rs;
-        float h = xh * gm + beta[c];
+        float xv = x[idx];
+        float xh = (xv - mean[c]) * rs;
+        float h = xv * scale[c] + shift[c];
         float dh = dy[idx] * (h > 0.f ? 1.f : slope);
         dx[idx] = gm * rs * (dh - sums[c * 2] - xh * sums[c * 2 + 1]);
     }
@@ -541,9 +543,9 @@ int cdae_bn_lrelu_fwd(const float* x, float* y, long rows, int C, const float* g
     return 0;
 }
 
-int cdae_bn_lrelu_bwd(const float* x, const float* dy, float* dx, long rows, int C, const float* gamma, const float* beta,
-                      const float* save_mean, const float* save_rstd, float slope, float* dgamma, float* dbeta, int accumulate,
-                      float* ws, void* stream) {
+int cdae_bn_lrelu_bwd(const float* x, const float* dy, float* dx, long rows, int C, const float* gamma, const float* scale,
+                      const float* shift, const float* save_mean, const float* save_rstd, float slope, float* dgamma, float* dbeta,
+                      int accumulate, float* ws, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (C > 256) return cdae_fail("bn: C > 256 unsupported");
     int nchunk = (int)((rows + 1023) / 1024);
@@ -551,10 +553,10 @@ int cdae_bn_lrelu_bwd(const float* x, const float* dy, float* dx, long rows, int
     if (nchunk < 1) nchunk = 1;
     int rpb = (int)((rows + nchunk - 1) / nchunk);
     float* sums = ws + (size_t)CDAE_BN_MAX_CHUNKS * C * 2;
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nchunk), dim3(256), 0, st, x, dy, rows, C, rpb, save_mean, save_rstd, gamma, beta, slope, ws);
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nchunk), dim3(256), 0, st, x, dy, rows, C, rpb, save_mean, save_rstd, scale, shift, slope, ws);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, rows, C, nchunk, ws, dgamma, dbeta, accumulate, sums);
     const long total = rows * C;
-    hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(grid_for(total)), dim3(256), 0, st, x, dy, dx, total, C, save_mean, save_rstd, gamma, beta, slope, sums);
+    hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(grid_for(total)), dim3(256), 0, st, x, dy, dx, total, C, save_mean, save_rstd, gamma, scale, shift, slope, sums);
     CHECK_LAUNCH("bn_lrelu_bwd launch failed");
     return 0;
 }

@@ -24,26 +24,41 @@ def is_nhwc(x):
     return x.dim() == 4 and x.permute(0, 2, 3, 1).is_contiguous()
 
 
+class _Relayout(Function):
+    """NCHW <-> NHWC storage change of a logical [N,C,H,W] tensor.  Values are unchanged, so the gradient passes
+    through as is (whatever its storage order)."""
+
+    @staticmethod
+    def forward(ctx, x, to_cl):
+        x = x.contiguous() if to_cl else x
+        N, C, H, W = x.shape
+        if to_cl:
+            out = new_act(N, C, H, W, x.device)
+            check(lib.cdae_nchw_to_nhwc(ptr(x), ptr(out), N, C, H * W, stream()))
+        else:
+            out = torch.empty((N, C, H, W), dtype=torch.float32, device=x.device)
+            check(lib.cdae_nhwc_to_nchw(ptr(x), ptr(out), N, C, H * W, stream()))
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, None
+
+
 def to_nhwc(x):
     """Return x as a logical-NCHW tensor with NHWC storage (no copy if it already is)."""
     if is_nhwc(x):
         return x
-    x = x.contiguous()
-    N, C, H, W = x.shape
-    out = new_act(N, C, H, W, x.device)
-    check(lib.cdae_nchw_to_nhwc(ptr(x), ptr(out), N, C, H * W, stream()))
-    return out
+    if x.dtype != torch.float32:
+        x = x.float()
+    return _Relayout.apply(x, True)
 
 
 def to_nchw(x):
-    """Return a plain NCHW-contiguous copy of a NHWC-stored activation."""
+    """Return a plain NCHW-contiguous version of a NHWC-stored activation."""
     if x.is_contiguous():
         return x
-    x = to_nhwc(x)
-    N, C, H, W = x.shape
-    out = torch.empty((N, C, H, W), dtype=torch.float32, device=x.device)
-    check(lib.cdae_nhwc_to_nchw(ptr(x), ptr(out), N, C, H * W, stream()))
-    return out
+    return _Relayout.apply(to_nhwc(x), False)
 
 
 def ohwi(w):
@@ -131,7 +146,7 @@ class _Linear(Function):
         Nf = w.shape[0]
         assert x.stride(1) == 1 and w.is_contiguous()
         y = torch.empty((M, Nf), dtype=torch.float32, device=x.device)
-        pre = torch.empty_like(y) if (act != ACT_NONE and torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)) else None
+        pre = torch.empty_like(y) if (act != ACT_NONE and any(ctx.needs_input_grad[:4])) else None   # grad mode is off inside forward
         ws, wsb = _sk(x.device)
         if pre is not None:      # keep the pre-activation for the backward
             check(lib.cdae_linear_fwd(ptr(x), x.stride(0), ptr(w), K, ptr(b), ptr(res), ptr(pre), Nf, M, Nf, K, alpha, ACT_NONE, ws, wsb, stream()))
@@ -459,7 +474,7 @@ class _BnLrelu(Function):
         dx = new_act(N, C, H, W, dev)
         dg, db = torch.empty_like(gamma), torch.empty_like(beta)
         ws = workspace(dev, "bn", 4 * lib.cdae_bn_workspace_floats(C))
-        check(lib.cdae_bn_lrelu_bwd(ptr(x), ptr(dy), ptr(dx), N * H * W, C, ptr(gamma), ptr(beta), ptr(aux[2]), ptr(aux[3]), slope,
+        check(lib.cdae_bn_lrelu_bwd(ptr(x), ptr(dy), ptr(dx), N * H * W, C, ptr(gamma), ptr(aux[0]), ptr(aux[1]), ptr(aux[2]), ptr(aux[3]), slope,
                                     ptr(dg), ptr(db), 0, ptr(ws), stream()))
         return dx, dg, db, None, None, None, None, None, None
 

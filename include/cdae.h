@@ -102,9 +102,10 @@ size_t cdae_bn_workspace_floats(int C);
 int cdae_bn_lrelu_fwd(const float* x, float* y, long rows, int C, const float* gamma, const float* beta, float* running_mean,
                       float* running_var, int training, float eps, float momentum, float slope, float* scale, float* shift,
                       float* save_mean, float* save_rstd, float* ws, void* stream);
-int cdae_bn_lrelu_bwd(const float* x, const float* dy, float* dx, long rows, int C, const float* gamma, const float* beta,
-                      const float* save_mean, const float* save_rstd, float slope, float* dgamma, float* dbeta, int accumulate,
-                      float* ws, void* stream);
+/* scale/shift are the forward's folded affine (y = lrelu(x*scale+shift)): the backward evaluates the kink on exactly that value */
+int cdae_bn_lrelu_bwd(const float* x, const float* dy, float* dx, long rows, int C, const float* gamma, const float* scale,
+                      const float* shift, const float* save_mean, const float* save_rstd, float slope, float* dgamma, float* dbeta,
+                      int accumulate, float* ws, void* stream);
 int cdae_softmax_rows(float* s, long rows, int T, void* stream);
 int cdae_softmax_rows_bwd(const float* P, float* dP, long rows, int T, void* stream);
 

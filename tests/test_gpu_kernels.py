@@ -127,9 +127,10 @@ def test_group_norm(N, C, H, ssn, silu):
     x = x + torch.linspace(-3, 3, C)[None, :, None, None]        # per-channel offsets: mean^2 >> var inside groups
     g, b = rnd(C, seed=1) + 1.5, rnd(C, seed=2)
     ss = rnd(N, 2 * C, seed=3) if ssn else None
-    xd, gd, bd = [t.to(DEV).requires_grad_(True) for t in (x, g, b)]
+    gd, bd = [t.to(DEV).requires_grad_(True) for t in (g, b)]
+    xd = ops.to_nhwc(x.to(DEV)).requires_grad_(True)
     ssd = ss.to(DEV).requires_grad_(True) if ssn else None
-    y = ops.group_norm(ops.to_nhwc(xd), gd, bd, ssd, silu)
+    y = ops.group_norm(xd, gd, bd, ssd, silu)
     xc, gc, bc = [t.double().requires_grad_(True) for t in (x, g, b)]
     ssc = ss.double().requires_grad_(True) if ssn else None
     h = F.group_norm(xc, 32, gc, bc, 1e-5)
@@ -179,9 +180,10 @@ def test_bn_lrelu(training):
     bn.train(training)
     xc = x.double().requires_grad_(True)
     yc = F.leaky_relu(bn(xc), 0.01)
-    xd, gd, bd = [t.to(DEV).requires_grad_(True) for t in (x, g, b)]
+    gd, bd = [t.to(DEV).requires_grad_(True) for t in (g, b)]
+    xd = ops.to_nhwc(x.to(DEV)).requires_grad_(True)
     rmd, rvd = rm.to(DEV), rv.to(DEV)
-    y = ops.bn_lrelu(ops.to_nhwc(xd), gd, bd, rmd, rvd, training)
+    y = ops.bn_lrelu(xd, gd, bd, rmd, rvd, training)
     assert err(y, yc) < 2e-5
     if training:
         assert err(rmd, bn.running_mean) < 1e-6 and err(rvd, bn.running_var) < 1e-6

@@ -130,14 +130,67 @@ def test_encoder_golden(golden, tag, C, S, nv):
     mu, var = enc.encode(xg)
     assert err(mu, g[tag + "/train_mu"]) < 1e-4 and err(var, g[tag + "/train_var"]) < 1e-4
     ((mu * synth(tag + ".gmu", (4, 512)).to(DEV)).sum() + (var * synth(tag + ".gvar", (4, 512)).to(DEV)).sum()).backward()
-    assert err(xg.grad, g[tag + "/train_gx"]) < 1e-4 * max(1.0, float(np.abs(g[tag + "/train_gx"]).max()))
+    # enc64's golden input puts one layer-0 pre-activation at 9e-8 (n=0,c=8,y=23,x=1): the LeakyReLU branch there is
+    # decided by fp32 rounding, so that one pixel's 0.99*dy shows up in gx (3x3x4 patch) and the layer-0 parameter
+    # gradients.  Everything else must match; test_encoder_backward_vs_oracle covers layer 0 on a kink-free input.
+    kink = tag == "enc64"
+    d = (xg.grad.cpu().double() - torch.from_numpy(g[tag + "/train_gx"]).double()).abs()
+    tol = 1e-4 * max(1.0, float(np.abs(g[tag + "/train_gx"]).max()))
+    assert int((d > tol).sum()) <= (36 if kink else 0)
     for k, v in enc.state_dict().items():
         if "running" in k:
             assert err(v, g[f"{tag}/after.{k}"]) < 1e-5, k
     for k, p in enc.named_parameters():
-        if k.endswith(".0.bias"):
-            continue            # exactly-zero gradient (bias ahead of batch-stat BN)
+        if k.endswith(".0.bias") or (kink and k.startswith("encoder.0.")):
+            continue            # exactly-zero gradient (bias ahead of batch-stat BN) / the kink pixel
         assert probe_err(p.grad, g, f"{tag}/g.{k}") < 3e-4, k
+
+
+def test_encoder_backward_vs_oracle():
+    """Encoder train-mode forward/backward vs the CPU oracle on an input with no LeakyReLU pre-activation near 0."""
+    import torch.nn.functional as F
+    from improved_diffusion.nn import GaussianConvEncoder
+    from oracle import unet_ref as U
+    from oracle.closed_form import fill_state_dict
+    dims = [16, 32, 32, 64, 128]
+    cfg = U.default_cfg(image_size=64, in_channels=4, n_vars=4, rep_cond=True, encoder_dims=dims)
+    sd = fill_state_dict([(k, s) for k, s in U.param_spec(cfg) if k.startswith("rep_emb.")])
+    for v in sd.values():
+        if v.dtype == torch.float32:
+            v.requires_grad_(True)
+    for attempt in range(8):
+        x = synth(f"enc64.nokink{attempt}", (4, 4, 64, 64), 0.0, 1.0)
+        # smallest |pre-activation| over all layers in the oracle
+        h, mins = x, []
+        with torch.no_grad():
+            for i in range(len(dims)):
+                p = f"rep_emb.encoder.{i}"
+                h = F.conv2d(h, sd[p + ".0.weight"], sd[p + ".0.bias"], stride=2, padding=1)
+                m, v = h.mean(dim=(0, 2, 3)), h.var(dim=(0, 2, 3), unbiased=False)
+                h = (h - m[None, :, None, None]) / torch.sqrt(v[None, :, None, None] + 1e-5) * sd[p + ".1.weight"][None, :, None, None] \
+                    + sd[p + ".1.bias"][None, :, None, None]
+                mins.append(h.abs().min().item())
+                h = F.leaky_relu(h, 0.01)
+        if min(mins) > 2e-5:
+            break
+    else:
+        pytest.skip("no kink-free input found")
+    enc = load_closed_form(GaussianConvEncoder(4, 512, hidden_dims=dims, num_vars=4), "rep_emb.")
+    enc.train()
+    xg = x.to(DEV).requires_grad_(True)
+    mu, var = enc.encode(xg)
+    gmu, gvar = synth("nokink.gmu", (4, 512)), synth("nokink.gvar", (4, 512))
+    ((mu * gmu.to(DEV)).sum() + (var * gvar.to(DEV)).sum()).backward()
+    xc = x.clone().requires_grad_(True)
+    m2, v2 = U.encode(sd, xc, len(dims), training=True)
+    ((m2 * gmu).sum() + (v2 * gvar).sum()).backward()
+    assert err(mu, m2) < 1e-4 and err(var, v2) < 1e-4
+    assert err(xg.grad, xc.grad) < 1e-4 * max(1.0, xc.grad.abs().max().item())
+    for k, p in enc.named_parameters():
+        ref = sd["rep_emb." + k].grad
+        if k.endswith(".0.bias"):
+            continue
+        assert err(p.grad, ref) < 1e-4 * max(1.0, ref.abs().max().item()), k
 
 
 def test_causal_layer_golden(golden):
