@@ -72,7 +72,21 @@ __device__ __forceinline__ bool tap_offset(const GemmParams& p, const PixRow& r,
     return true;
 }
 
-template <int BM, int BN, int AMODE, int BMODE>
+// Branch-free guarded loads.  A conditional `ok ? load : 0` makes hipcc branch around every load and wait
+// vmcnt(0) before the next one (all tile loads of a K-step serialised), and a value select after the load drags
+// the vmcnt wait in front of the MFMAs.  Selecting the ADDRESS instead (a zero-filled device constant when !ok)
+// keeps the loads unconditional, back-to-back and un-waited until the LDS store after the MFMAs.
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // non-const: stays in the global address space (a constant-space pointer turns the select into flat loads)
+
+__device__ __forceinline__ float4 ld4_if(const float* /*unused*/, const float* p, bool ok) {
+    return ld4(ok ? p : g_zero16);
+}
+__device__ __forceinline__ float ld1_if(const float* /*unused*/, const float* p, bool ok) {
+    return *(ok ? p : g_zero16);
+}
+
+// SCALAR = element-wise operand loads (odd K / pitch / alignment, tiny channel counts); only built for 64x64 tiles.
+template <int BM, int BN, int AMODE, int BMODE, bool SCALAR>
 __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams p) {
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr bool A_MC = (AMODE == A_PLAIN_MC);
@@ -92,8 +106,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams p) {
     const int l31 = lane & 31, hh = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
 
-    // block -> tile (m fastest), batch on z, split-K on the upper part of z
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // block -> tile: XCD-aware remap of the m-tile index (blocks b and b+8 share an XCD/L2: give each XCD a
+    // contiguous run of m-tiles so neighbouring image rows / halo pixels hit the same L2), batch on z, split-K
+    // on the upper part of z
+    int mt;
+    {
+        const int nmt = gridDim.x, b = blockIdx.x;
+        const int q = nmt >> 3, r = nmt & 7, x = b & 7;
+        mt = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    }
+    const int m0 = mt * BM, n0 = blockIdx.y * BN;
     const int bz = blockIdx.z % p.batch, ks = blockIdx.z / p.batch;
     const int bo = bz / p.batch_inner, bi = bz - bo * p.batch_inner;
     const float* __restrict__ Ag = p.A + bo * p.a_bs0 + bi * p.a_bs1;
@@ -106,9 +128,33 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams p) {
 
     // ---------------------------------------------------------------- per-thread loader state
     PixRow arow[A_V4];
+    long atap_off[A_V4];          // A_CONV_VEC: element offset of the current tap's pixel, refreshed when the tap changes
+    bool atap_ok[A_V4];
+    int a_cur_tap = -1;
     if constexpr (AMODE == A_CONV_VEC || AMODE == A_CONV_GEN) {
 #pragma unroll
-        for (int q = 0; q < A_V4; ++q) arow[q] = make_pixrow(p, m0 + (tid >> 3) + 32 * q);
+        for (int q = 0; q < A_V4; ++q) { arow[q] = make_pixrow(p, m0 + (tid >> 3) + 32 * q); atap_off[q] = 0; atap_ok[q] = false; }
+    }
+    // K-contiguous plain operands: row pointers are loop invariant
+    const float* arowp[A_V4];
+    bool arow_ok[A_V4];
+    if constexpr (AMODE == A_PLAIN_KC) {
+#pragma unroll
+        for (int q = 0; q < A_V4; ++q) {
+            int m = m0 + (tid >> 3) + 32 * q;
+            arow_ok[q] = m < p.M;
+            arowp[q] = Ag + (long)(arow_ok[q] ? m : 0) * p.lda + (tid & 7) * 4;
+        }
+    }
+    const float* browp[B_V4];
+    bool brow_ok[B_V4];
+    if constexpr (BMODE == B_PLAIN_KC) {
+#pragma unroll
+        for (int q = 0; q < B_V4; ++q) {
+            int n = n0 + (tid >> 3) + 32 * q;
+            brow_ok[q] = n < p.N;
+            browp[q] = Bg + (long)(brow_ok[q] ? n : 0) * p.ldb + (tid & 7) * 4;
+        }
     }
 
     float4 areg[A_V4], breg[B_V4];
@@ -116,55 +162,66 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams p) {
     auto load_A = [&](int kt) {
         const int k0 = kt * BK;
         if constexpr (AMODE == A_PLAIN_KC) {
+            const int k = k0 + (tid & 7) * 4;
 #pragma unroll
             for (int q = 0; q < A_V4; ++q) {
-                int m = m0 + (tid >> 3) + 32 * q, k = k0 + (tid & 7) * 4;
-                if (!p.a_scalar) areg[q] = (m < p.M && k < p.K) ? ld4(Ag + (long)m * p.lda + k) : make_float4(0, 0, 0, 0);
+                if constexpr (!SCALAR) areg[q] = ld4_if(Ag, arowp[q] + k0, arow_ok[q] && k < p.K);
                 else {
-                    float v[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (m < p.M)
-                        for (int e = 0; e < 4; ++e) if (k + e < p.K) v[e] = Ag[(long)m * p.lda + k + e];
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = ld1_if(Ag, arowp[q] + k0 + e, arow_ok[q] && k + e < p.K);
                     areg[q] = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
         } else if constexpr (AMODE == A_CONV_VEC) {
-            int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;
-            int ky = tap / 3, kx = tap - ky * 3;
+            const int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;
+            if (tap != a_cur_tap) {                 // block-uniform: refresh the per-row pixel offsets once per tap
+                a_cur_tap = tap;
+                const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
-            for (int q = 0; q < A_V4; ++q) {
-                long off;
-                bool ok = arow[q].ok && tap_offset(p, arow[q], ky, kx, off);
-                areg[q] = ok ? ld4(Ag + off + c0 + (tid & 7) * 4) : make_float4(0, 0, 0, 0);
+                for (int q = 0; q < A_V4; ++q) {
+                    long off = 0;
+                    atap_ok[q] = arow[q].ok && tap_offset(p, arow[q], ky, kx, off);
+                    atap_off[q] = off + (tid & 7) * 4;
+                }
             }
+#pragma unroll
+            for (int q = 0; q < A_V4; ++q) areg[q] = ld4_if(Ag, Ag + atap_off[q] + c0, atap_ok[q]);
         } else if constexpr (AMODE == A_CONV_GEN) {
 #pragma unroll
             for (int q = 0; q < A_V4; ++q) {
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    int k = k0 + (tid & 7) * 4 + e;
-                    v[e] = 0.f;
-                    if (arow[q].ok && k < p.K) {
-                        int tap = k / p.Cin, c = k - tap * p.Cin;
-                        int ky = tap / 3, kx = tap - ky * 3;
-                        long off;
-                        if (tap_offset(p, arow[q], ky, kx, off)) v[e] = Ag[off + (long)c * p.sc];
-                    }
+                    const int k = k0 + (tid & 7) * 4 + e;
+                    const int kk = k < p.K ? k : 0;
+                    const int tap = kk / p.Cin, c = kk - tap * p.Cin;
+                    const int ky = tap / 3, kx = tap - ky * 3;
+                    long off = 0;
+                    const bool ok = arow[q].ok && k < p.K && tap_offset(p, arow[q], ky, kx, off);
+                    v[e] = ld1_if(Ag, Ag + off + (long)c * p.sc, ok);
                 }
                 areg[q] = make_float4(v[0], v[1], v[2], v[3]);
             }
         } else {   // A_PLAIN_MC: element (i,k) at Ag + k*lda + i
 #pragma unroll
             for (int q = 0; q < A_V4; ++q) {
-                int idx = tid + 256 * q;
-                int kk = idx / (BM / 4), i4 = idx - kk * (BM / 4);
-                int k = k0 + kk, i = m0 + i4 * 4;
-                const float* src = Ag + (long)k * p.lda + i;
-                if (!p.a_scalar && k < p.K && i + 3 < p.M) areg[q] = ld4(src);
-                else {
-                    float v[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (k < p.K)
-                        for (int e = 0; e < 4; ++e) if (i + e < p.M) v[e] = src[e];
+                const int idx = tid + 256 * q;
+                const int kk = idx / (BM / 4), i4 = idx - kk * (BM / 4);
+                const int k = k0 + kk, i = m0 + i4 * 4;
+                const float* src = Ag + (long)(k < p.K ? k : 0) * p.lda + i;
+                if constexpr (!SCALAR) {
+                    if (p.M % 4 == 0) areg[q] = ld4_if(Ag, src, k < p.K && i < p.M);
+                    else {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = ld1_if(Ag, src + e, k < p.K && i + e < p.M);
+                        areg[q] = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                } else {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = ld1_if(Ag, src + e, k < p.K && i + e < p.M);
                     areg[q] = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
@@ -174,60 +231,69 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams p) {
     auto load_B = [&](int kt) {
         const int k0 = kt * BK;
         if constexpr (BMODE == B_PLAIN_KC) {
+            const int k = k0 + (tid & 7) * 4;
 #pragma unroll
             for (int q = 0; q < B_V4; ++q) {
-                int n = n0 + (tid >> 3) + 32 * q, k = k0 + (tid & 7) * 4;
-                if (!p.b_scalar) breg[q] = (n < p.N && k < p.K) ? ld4(Bg + (long)n * p.ldb + k) : make_float4(0, 0, 0, 0);
+                if constexpr (!SCALAR) breg[q] = ld4_if(Bg, browp[q] + k0, brow_ok[q] && k < p.K);
                 else {
-                    float v[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (n < p.N)
-                        for (int e = 0; e < 4; ++e) if (k + e < p.K) v[e] = Bg[(long)n * p.ldb + k + e];
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = ld1_if(Bg, browp[q] + k0 + e, brow_ok[q] && k + e < p.K);
                     breg[q] = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
         } else {
 #pragma unroll
             for (int q = 0; q < B_V4; ++q) {
-                int idx = tid + 256 * q;
-                int kk = idx / (BN / 4), j4 = idx - kk * (BN / 4);
-                int k = k0 + kk, j = n0 + j4 * 4;
-                const float* src = nullptr;
-                bool kok = k < p.K;
-                float v[4] = {0.f, 0.f, 0.f, 0.f};
-                if constexpr (BMODE == B_CONV_MC) {
-                    // k = pixel of the dY grid, j = tap*Cin + cin
-                    PixRow r = make_pixrow(p, k);
-                    if (p.b_scalar) {
-                        for (int e = 0; e < 4; ++e) {
-                            int jj = j + e;
-                            if (r.ok && jj < p.N) {
-                                int tap = jj / p.Cin, c = jj - tap * p.Cin;
-                                int ky = tap / 3, kx = tap - ky * 3;
-                                long off;
-                                if (tap_offset(p, r, ky, kx, off)) v[e] = Bg[off + (long)c * p.sc];
-                            }
-                        }
-                        breg[q] = make_float4(v[0], v[1], v[2], v[3]);
-                        continue;
+                const int idx = tid + 256 * q;
+                const int kk = idx / (BN / 4), j4 = idx - kk * (BN / 4);
+                const int k = k0 + kk, j = n0 + j4 * 4;
+                if constexpr (BMODE == B_CONV_MC && SCALAR) {
+                    // k = pixel of the dY grid, j = tap*Cin + cin decoded per element
+                    const PixRow r = make_pixrow(p, k);
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int jj = j + e < p.N ? j + e : 0;
+                        const int tap = jj / p.Cin, c = jj - tap * p.Cin;
+                        const int ky = tap / 3, kx = tap - ky * 3;
+                        long off = 0;
+                        const bool ok = r.ok && j + e < p.N && tap_offset(p, r, ky, kx, off);
+                        v[e] = ld1_if(Bg, Bg + off + (long)c * p.sc, ok);
                     }
-                    int tap = n0 / p.Cin;                 // whole block inside one tap (Cin % BN == 0)
-                    int ky = tap / 3, kx = tap - ky * 3;
-                    long off = 0;
-                    kok = r.ok && tap_offset(p, r, ky, kx, off);
-                    src = Bg + off + (j - tap * p.Cin);
-                } else if constexpr (BMODE == B_PLAIN_MC) {
-                    src = Bg + (long)k * p.ldb + j;
-                } else {   // B_WDGRAD_MC: k = tap*Cout + co (tap of the dY gather), j = cin; OHWI weights, tap flipped
-                    int kk2 = kok ? k : 0;
-                    int tap = kk2 / p.wCout, co = kk2 - tap * p.wCout;
-                    int ft = p.wflip ? 8 - tap : tap;
-                    src = Bg + ((long)co * 9 + ft) * p.wCin + j;
-                }
-                if (kok && !p.b_scalar && j + 3 < p.N) breg[q] = ld4(src);
-                else {
-                    if (kok)
-                        for (int e = 0; e < 4; ++e) if (j + e < p.N) v[e] = src[e];
                     breg[q] = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    const float* src;
+                    bool kok = k < p.K;
+                    if constexpr (BMODE == B_CONV_MC) {
+                        const PixRow r = make_pixrow(p, k);
+                        const int tap = n0 / p.Cin;                 // whole block inside one tap (Cin % BN == 0)
+                        const int ky = tap / 3, kx = tap - ky * 3;
+                        long off = 0;
+                        kok = r.ok && tap_offset(p, r, ky, kx, off);
+                        src = Bg + off + (j - tap * p.Cin);
+                    } else if constexpr (BMODE == B_PLAIN_MC) {
+                        src = Bg + (long)(kok ? k : 0) * p.ldb + j;
+                    } else {   // B_WDGRAD_MC: k = tap*Cout + co (tap of the dY gather), j = cin; OHWI weights, tap flipped
+                        const int kk2 = kok ? k : 0;
+                        const int tap = kk2 / p.wCout, co = kk2 - tap * p.wCout;
+                        const int ft = p.wflip ? 8 - tap : tap;
+                        src = Bg + ((long)co * 9 + ft) * p.wCin + j;
+                    }
+                    if constexpr (!SCALAR) {
+                        if (p.N % 4 == 0) breg[q] = ld4_if(Bg, src, kok && j < p.N);
+                        else {
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = ld1_if(Bg, src + e, kok && j + e < p.N);
+                            breg[q] = make_float4(v[0], v[1], v[2], v[3]);
+                        }
+                    } else {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = ld1_if(Bg, src + e, kok && j + e < p.N);
+                        breg[q] = make_float4(v[0], v[1], v[2], v[3]);
+                    }
                 }
             }
         }
@@ -382,7 +448,7 @@ __global__ void splitk_reduce_kernel(const GemmParams p) {
     }
 }
 
-template <int BM, int BN, int AMODE, int BMODE>
+template <int BM, int BN, int AMODE, int BMODE, bool SCALAR>
 int launch(const GemmParams& p, hipStream_t st) {
     constexpr bool A_MC = (AMODE == A_PLAIN_MC);
     constexpr bool B_MC = (BMODE != B_PLAIN_KC);
@@ -391,19 +457,21 @@ int launch(const GemmParams& p, hipStream_t st) {
     constexpr size_t smem = 2 * (A_TILE + B_TILE) * sizeof(float);
     static bool attr_done = false;      // per-instantiation; value is idempotent so a race is benign
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, AMODE, BMODE>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, AMODE, BMODE, SCALAR>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
         attr_done = true;
     }
     dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, p.batch * p.ksplit);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, AMODE, BMODE>), grid, dim3(256), smem, st, p);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, AMODE, BMODE, SCALAR>), grid, dim3(256), smem, st, p);
     return hipGetLastError() == hipSuccess ? 0 : cdae_fail("igemm launch failed");
 }
 
 template <int AMODE, int BMODE>
-int launch_tiles(const GemmParams& p, int big, hipStream_t st) {
-    return big ? launch<128, 128, AMODE, BMODE>(p, st) : launch<64, 64, AMODE, BMODE>(p, st);
+int launch_tiles(const GemmParams& p, int big, bool scalar, hipStream_t st) {
+    if (scalar) return launch<64, 64, AMODE, BMODE, true>(p, st);
+    if constexpr (AMODE == A_CONV_GEN) return cdae_fail("A_CONV_GEN is a scalar-only loader");
+    else return big ? launch<128, 128, AMODE, BMODE, false>(p, st) : launch<64, 64, AMODE, BMODE, false>(p, st);
 }
 
 }  // namespace
@@ -419,7 +487,9 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
     int big = tiles_big >= 192;
     if (p.force_tile == 64) big = 0;
     if (p.force_tile == 128) big = 1;
-    if (p.bmode == B_CONV_MC && !p.b_scalar) {           // a vectorised wgrad block must sit inside one tap
+    const bool scalar = p.a_scalar || p.b_scalar || p.amode == A_CONV_GEN;
+    if (scalar) big = 0;
+    if (p.bmode == B_CONV_MC && !scalar) {           // a vectorised wgrad block must sit inside one tap
         if (p.Cin % 128 != 0) big = 0;
         if (p.Cin % 64 != 0) return cdae_fail("B_CONV_MC needs Cin % 64 == 0");
     }
@@ -441,7 +511,7 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
 
     cdae_prof_begin(PROF_IGEMM, 2.0 * p.M * p.N * (double)p.K * p.batch, st);
     int rc = -1;
-#define CASE(AM, BM_) if (p.amode == AM && p.bmode == BM_) rc = launch_tiles<AM, BM_>(p, big, st)
+#define CASE(AM, BM_) if (p.amode == AM && p.bmode == BM_) rc = launch_tiles<AM, BM_>(p, big, scalar, st)
     CASE(A_PLAIN_KC, B_PLAIN_KC);
     else CASE(A_CONV_VEC, B_PLAIN_KC);
     else CASE(A_CONV_GEN, B_PLAIN_KC);
