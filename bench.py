@@ -77,6 +77,56 @@ def cpu_baseline(steps=8, batch=16):
                       f"{cores} threads (= cgroup CPU quota; host shows {os.cpu_count()} logical CPUs)"}
 
 
+def train_bench(dev, world, rank, steps, warmup, batch):
+    """Training leg of the metric: CausalCircuit 64x64 C=3 (BASELINE config 4), per-GPU batch `batch`, one optimizer
+    step = forward + backward + bucketed gradient all-reduce (RCCL, overlapped with backward) + fused AdamW/EMA."""
+    import numpy as np
+    from improved_diffusion import script_util as su
+    from improved_diffusion.image_datasets import load_data
+    from improved_diffusion.train_util import TrainLoop
+    cfg = {**su.model_and_diffusion_defaults(), "image_size": 64, "in_channels": 3, "n_vars": 4, "rep_cond": True,
+           "causal_modeling": True}
+    model, diff = su.create_model_and_diffusion(**cfg)
+    randomize(model, 4321)
+    model.to(dev).train()
+    np.random.seed(1000 + rank)
+    data = load_data(data_dir="synthetic", batch_size=batch, image_size=64, in_channels=3, n_vars=4, seed=rank)
+    loop = TrainLoop(model=model, diffusion=diff, data=data, batch_size=batch, microbatch=-1, lr=1e-4, ema_rate="0.9999",
+                     log_interval=10 ** 9, save_interval=10 ** 9, resume_checkpoint="", rep_cond=True, n_vars=4,
+                     causal_modeling=True, in_channels=3)
+    diff.kl_weight = 0.1
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(max(1, warmup)):
+        b, c = next(data)
+        loop.forward_backward(b, c)
+        loop.optimize_normal()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        b, c = next(data)
+        loop.forward_backward(b, c)
+        loop.optimize_normal()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    loss = float(loop.last_losses["loss"].mean().item())
+    return {"value": steps / dt, "unit": "train-steps/s", "ms_per_step": 1e3 * dt / steps, "batch_per_gpu": batch,
+            "global_batch": batch * world, "images_per_sec": batch * world * steps / dt,
+            "model_tflops": batch * world * steps / dt * 181.86 / 1e3, "dtype": "f32", "last_loss": loss,
+            "workload": "CausalCircuit 64x64 C=3 CausalDiffAE training step (fwd+bwd+all-reduce+AdamW/EMA), 93.4M params"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -85,18 +135,23 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--train-batch", type=int, default=32)
+    ap.add_argument("--train-steps", type=int, default=5)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the product path has no CPU fallback)"
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", init_method="env://")
+        # "nccl" is RCCL on ROCm; CDAE_DIST_BACKEND=gloo exists only to exercise the N>1 code path on a 1-GPU box
+        dist.init_process_group(os.environ.get("CDAE_DIST_BACKEND", "nccl"), init_method="env://")
 
     import causaldiffae_amd  # noqa: F401
     from causaldiffae_amd import _lib
@@ -126,6 +181,7 @@ def main():
 
         T = diff.num_timesteps
         steps_tab = diff._step_table(dev, N)
+        runner = None
         if args.no_graph:
             img = x_t.clone()
 
@@ -177,6 +233,14 @@ def main():
                     "flops_per_launch_avg": ig["work"] / max(1, ig["launches"]),
                     "family_ms_per_step": {k: v["ms"] / 2 for k, v in prof.items()}}
 
+    train = None
+    if not args.no_train:
+        del runner, model
+        torch.cuda.empty_cache()
+        try:
+            train = train_bench(dev, world, rank, args.train_steps, 2, args.train_batch)
+        except Exception as e:                      # never lose the headline line to the secondary leg
+            train = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank != 0:
         return
     value = world * N * args.steps / dt
@@ -190,6 +254,7 @@ def main():
         "samples_per_sec_ddim100": value / 100.0,
         "model_tflops": value * GFLOP_PER_IMAGE_STEP_P64 / 1e3,
         "roofline": roof,
+        "train": train,
     }
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline()

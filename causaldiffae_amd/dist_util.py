@@ -47,3 +47,24 @@ def sync_params(params):
     for p in params:
         with th.no_grad():
             dist.broadcast(p, 0)
+
+
+def shard_range(n, rank=None, world=None):
+    """[lo, hi) slice of a global batch of n independent items owned by `rank` (sampling shards the image batch
+    over ranks with no collective in the loop; remainders go to the lowest ranks)."""
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else 1
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def gather_samples(sample):
+    """all_gather of finished samples (the reference does this after the loop, image_causaldae_test.py:438-439)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [sample]
+    out = [th.zeros_like(sample) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, sample.contiguous())
+    return out
