@@ -24,11 +24,14 @@ struct GemmParams {
     int H, W, Cin;         // gathered tensor: spatial dims (before the fused 2x upsample) and channels
     int Ho, Wo;            // pixel grid the gather rows enumerate
     int stride, up, tconv;
+    // dispatcher-computed gather constants: magic division by Ho*Wo and Wo, mode folding (igemm.hip make_pixrow/tap_offset)
+    int hw, hw_shift, wo_shift; unsigned hw_magic, wo_magic;
+    int g_mul, g_add, g_sign, g_pm, g_sh;
     long sn, sy, sx, sc;   // element strides of the gathered tensor
     // OHWI weight access for B_WDGRAD_MC
     int wCout, wCin, wflip;
     // split-K
-    int ksplit, ksplit_auto, ksplit_force, force_tile;
+    int ksplit, ksplit_auto, ksplit_force, force_tile, waves8;
     float* splitk_ws; size_t splitk_ws_bytes;
 };
 

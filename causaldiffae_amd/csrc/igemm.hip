@@ -18,11 +18,13 @@
 //
 // Tile: BM x BN x 32, 256 threads = 4 waves (2x2), each wave (BM/2)x(BN/2) as 32x32 MFMA tiles.
 // LDS: K-contiguous operands as [rows][32+4] (conflict-free ds_read_b128: one read feeds 4 MFMAs),
-// k-major operands as [32][rows+4] (ds_read_b32, lanes along rows).  Register-staged double
+// k-major operands as [32][rows+4] with interleaved MFMA row slots (ds_read_b64 along rows).  Register-staged double
 // buffering: tile t+1's global loads are issued before the MFMAs of tile t and written to the
 // other LDS buffer afterwards (one barrier per K-step).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <type_traits>
 #include "cdae_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -41,35 +43,34 @@ struct PixRow {
     int ok;        // row < M
 };
 
+// exact floor(n / d) for n < 2^31 with a host-computed (magic, shift): (mulhi(n, magic) + n) >> shift
+__device__ __forceinline__ int fdiv(int n, unsigned magic, int shift) {
+    return (int)((__umulhi((unsigned)n, magic) + (unsigned)n) >> shift);
+}
+
+// Everything below is straight-line (no branches, no early returns): any control flow in the gather geometry ends
+// up between the tile loads and makes hipcc serialise them with vmcnt waits.  The mode switches (stride / fused
+// upsample / transposed stride-2 gather) are folded into host-computed constants g_*.
 __device__ __forceinline__ PixRow make_pixrow(const GemmParams& p, int m) {
     PixRow r;
     r.ok = m < p.conv_M;
-    int mm = r.ok ? m : 0;
-    int hw = p.Ho * p.Wo;
-    int n = mm / hw, rem = mm - n * hw;
-    int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    const int mm = r.ok ? m : 0;
+    const int n = fdiv(mm, p.hw_magic, p.hw_shift);
+    const int rem = mm - n * p.hw;
+    const int oy = fdiv(rem, p.wo_magic, p.wo_shift), ox = rem - oy * p.Wo;
     r.base = (long)n * p.sn;
-    if (p.tconv) { r.iy0 = oy + 1; r.ix0 = ox + 1; }            // transposed stride-2 gather: src = (o + 1 - k) / 2
-    else { r.iy0 = oy * p.stride - 1; r.ix0 = ox * p.stride - 1; }
+    r.iy0 = oy * p.g_mul + p.g_add;         // conv: o*stride - 1;  transposed gather: o + 1
+    r.ix0 = ox * p.g_mul + p.g_add;
     return r;
 }
 
-// offset (elements) of input pixel for window tap (ky,kx); returns false when the tap reads padding
+// offset (elements) of the input pixel under window tap (ky,kx); false when the tap reads padding
 __device__ __forceinline__ bool tap_offset(const GemmParams& p, const PixRow& r, int ky, int kx, long& off) {
-    int iy, ix;
-    if (p.tconv) {
-        int ty = r.iy0 - ky, tx = r.ix0 - kx;
-        if ((ty | tx) < 0 || (ty & 1) || (tx & 1)) return false;
-        iy = ty >> 1; ix = tx >> 1;
-        if (iy >= p.H || ix >= p.W) return false;
-    } else {
-        iy = r.iy0 + ky; ix = r.ix0 + kx;
-        int Hin = p.up ? 2 * p.H : p.H, Win = p.up ? 2 * p.W : p.W;
-        if (iy < 0 || ix < 0 || iy >= Hin || ix >= Win) return false;
-        if (p.up) { iy >>= 1; ix >>= 1; }
-    }
-    off = r.base + (long)iy * p.sy + (long)ix * p.sx;
-    return true;
+    const int ty = r.iy0 + p.g_sign * ky, tx = r.ix0 + p.g_sign * kx;      // transposed gather walks the taps backwards
+    const bool ok = ((ty | tx) >= 0) & (((ty | tx) & p.g_pm) == 0) & (ty < (p.H << p.g_sh)) & (tx < (p.W << p.g_sh));
+    const int iy = ty >> p.g_sh, ix = tx >> p.g_sh;                       // >>1: fused upsample source / stride-2 transpose
+    off = ok ? r.base + (long)iy * p.sy + (long)ix * p.sx : 0;
+    return ok;
 }
 
 // Branch-free guarded loads.  A conditional `ok ? load : 0` makes hipcc branch around every load and wait
@@ -86,16 +87,23 @@ __device__ __forceinline__ float ld1_if(const float* /*unused*/, const float* p,
 }
 
 // SCALAR = element-wise operand loads (odd K / pitch / alignment, tiny channel counts); only built for 64x64 tiles.
-template <int BM, int BN, int AMODE, int BMODE, bool SCALAR>
-__global__ __launch_bounds__(256) void igemm_kernel(const GemmParams p) {
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+template <int BM, int BN, int AMODE, int BMODE, bool SCALAR, int WAVES_N = 2>
+__global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p) {
+    // 2 x WAVES_N waves; WAVES_N = 4 (512 threads, 64x32 per wave at 128x128) doubles the waves per SIMD that can
+    // cover each other's barrier / LDS waits at the same LDS footprint
+    constexpr int THREADS = 128 * WAVES_N, RPP = THREADS / 8;     // RPP = tile rows covered per loader pass
+    constexpr int WM = BM / 2, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
     constexpr bool A_MC = (AMODE == A_PLAIN_MC);
     constexpr bool B_MC = (BMODE != B_PLAIN_KC);
+    // K-contiguous operands: LDS [rows][32+4], one ds_read_b128 per lane feeds 4 MFMAs.  k-major operands keep their
+    // global order in LDS, [32][rows+4] (coalesced float4 stores, no bank conflicts); the wave's MFMA row slots are
+    // INTERLEAVED over its tiles (slot s of tile t <-> row T*s+t) so one ds_read_b64/b128 along the rows serves all
+    // tiles of a k.  (A register-transposed variant measured 8-way ds_write conflicts and MFMA busy 0.39.)
     constexpr int LDAM = BM + 4, LDBM = BN + 4;
     constexpr int A_TILE = A_MC ? BK * LDAM : BM * LDK;
     constexpr int B_TILE = B_MC ? BK * LDBM : BN * LDK;
-    constexpr int A_V4 = BM * BK / 4 / 256;     // float4 loads per thread per tile
-    constexpr int B_V4 = BN * BK / 4 / 256;
+    constexpr int A_V4 = BM * BK / 4 / THREADS;     // float4 loads per thread per tile
+    constexpr int B_V4 = BN * BK / 4 / THREADS;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
@@ -104,19 +112,23 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-    // block -> tile: XCD-aware remap of the m-tile index (blocks b and b+8 share an XCD/L2: give each XCD a
-    // contiguous run of m-tiles so neighbouring image rows / halo pixels hit the same L2), batch on z, split-K
-    // on the upper part of z
-    int mt;
+    // block -> tile.  1-D grid; blocks b and b+8 share an XCD (and its L2), so first give each XCD a CONTIGUOUS run
+    // of virtual ids, then decode n-tile fastest, m-tile, K-split, batch: the n-tiles of one m-tile (same A rows),
+    // neighbouring m-tiles (shared 3x3 halo rows) and — for wgrad — all (tap, cin-block) tiles of one pixel chunk
+    // run on the same XCD at about the same time and hit in its L2 instead of re-fetching from HBM/MALL.
+    const int nmt = (p.M + BM - 1) / BM, nnt = (p.N + BN - 1) / BN;
+    int mt, nt, ks, bz;
     {
-        const int nmt = gridDim.x, b = blockIdx.x;
-        const int q = nmt >> 3, r = nmt & 7, x = b & 7;
-        mt = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+        const unsigned G = gridDim.x, b = blockIdx.x;
+        const unsigned q = G >> 3, r = G & 7, x = b & 7;
+        unsigned v = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+        nt = v % nnt; v /= nnt;
+        mt = v % nmt; v /= nmt;
+        ks = v % p.ksplit; bz = v / p.ksplit;
     }
-    const int m0 = mt * BM, n0 = blockIdx.y * BN;
-    const int bz = blockIdx.z % p.batch, ks = blockIdx.z / p.batch;
+    const int m0 = mt * BM, n0 = nt * BN;
     const int bo = bz / p.batch_inner, bi = bz - bo * p.batch_inner;
     const float* __restrict__ Ag = p.A + bo * p.a_bs0 + bi * p.a_bs1;
     const float* __restrict__ Bg = p.B + bo * p.b_bs0 + bi * p.b_bs1;
@@ -133,7 +145,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams p) {
     int a_cur_tap = -1;
     if constexpr (AMODE == A_CONV_VEC || AMODE == A_CONV_GEN) {
 #pragma unroll
-        for (int q = 0; q < A_V4; ++q) { arow[q] = make_pixrow(p, m0 + (tid >> 3) + 32 * q); atap_off[q] = 0; atap_ok[q] = false; }
+        for (int q = 0; q < A_V4; ++q) { arow[q] = make_pixrow(p, m0 + (tid >> 3) + RPP * q); atap_off[q] = 0; atap_ok[q] = false; }
     }
     // K-contiguous plain operands: row pointers are loop invariant
     const float* arowp[A_V4];
@@ -141,7 +153,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams p) {
     if constexpr (AMODE == A_PLAIN_KC) {
 #pragma unroll
         for (int q = 0; q < A_V4; ++q) {
-            int m = m0 + (tid >> 3) + 32 * q;
+            int m = m0 + (tid >> 3) + RPP * q;
             arow_ok[q] = m < p.M;
             arowp[q] = Ag + (long)(arow_ok[q] ? m : 0) * p.lda + (tid & 7) * 4;
         }
@@ -151,7 +163,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams p) {
     if constexpr (BMODE == B_PLAIN_KC) {
 #pragma unroll
         for (int q = 0; q < B_V4; ++q) {
-            int n = n0 + (tid >> 3) + 32 * q;
+            int n = n0 + (tid >> 3) + RPP * q;
             brow_ok[q] = n < p.N;
             browp[q] = Bg + (long)(brow_ok[q] ? n : 0) * p.ldb + (tid & 7) * 4;
         }
@@ -206,19 +218,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams p) {
         } else {   // A_PLAIN_MC: element (i,k) at Ag + k*lda + i
 #pragma unroll
             for (int q = 0; q < A_V4; ++q) {
-                const int idx = tid + 256 * q;
+                const int idx = tid + THREADS * q;
                 const int kk = idx / (BM / 4), i4 = idx - kk * (BM / 4);
                 const int k = k0 + kk, i = m0 + i4 * 4;
                 const float* src = Ag + (long)(k < p.K ? k : 0) * p.lda + i;
-                if constexpr (!SCALAR) {
-                    if (p.M % 4 == 0) areg[q] = ld4_if(Ag, src, k < p.K && i < p.M);
-                    else {
-                        float v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = ld1_if(Ag, src + e, k < p.K && i + e < p.M);
-                        areg[q] = make_float4(v[0], v[1], v[2], v[3]);
-                    }
-                } else {
+                if constexpr (!SCALAR) areg[q] = ld4_if(Ag, src, k < p.K && i < p.M);      // host guarantees M % 4 == 0
+                else {
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = ld1_if(Ag, src + e, k < p.K && i + e < p.M);
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams p) {
         } else {
 #pragma unroll
             for (int q = 0; q < B_V4; ++q) {
-                const int idx = tid + 256 * q;
+                const int idx = tid + THREADS * q;
                 const int kk = idx / (BN / 4), j4 = idx - kk * (BN / 4);
                 const int k = k0 + kk, j = n0 + j4 * 4;
                 if constexpr (BMODE == B_CONV_MC && SCALAR) {
@@ -280,15 +285,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams p) {
                         const int ft = p.wflip ? 8 - tap : tap;
                         src = Bg + ((long)co * 9 + ft) * p.wCin + j;
                     }
-                    if constexpr (!SCALAR) {
-                        if (p.N % 4 == 0) breg[q] = ld4_if(Bg, src, kok && j < p.N);
-                        else {
-                            float v[4];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = ld1_if(Bg, src + e, kok && j + e < p.N);
-                            breg[q] = make_float4(v[0], v[1], v[2], v[3]);
-                        }
-                    } else {
+                    if constexpr (!SCALAR) breg[q] = ld4_if(Bg, src, kok && j < p.N);      // host guarantees N % 4 == 0
+                    else {
                         float v[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = ld1_if(Bg, src + e, kok && j + e < p.N);
@@ -305,24 +303,24 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams p) {
         if constexpr (!A_MC) {
 #pragma unroll
             for (int q = 0; q < A_V4; ++q)
-                *reinterpret_cast<float4*>(a + ((tid >> 3) + 32 * q) * LDK + (tid & 7) * 4) = areg[q];
+                *reinterpret_cast<float4*>(a + ((tid >> 3) + RPP * q) * LDK + (tid & 7) * 4) = areg[q];
         } else {
 #pragma unroll
             for (int q = 0; q < A_V4; ++q) {
-                int idx = tid + 256 * q;
-                int kk = idx / (BM / 4), i4 = idx - kk * (BM / 4);
+                const int idx = tid + THREADS * q;
+                const int kk = idx / (BM / 4), i4 = idx - kk * (BM / 4);
                 *reinterpret_cast<float4*>(a + kk * LDAM + i4 * 4) = areg[q];
             }
         }
         if constexpr (!B_MC) {
 #pragma unroll
             for (int q = 0; q < B_V4; ++q)
-                *reinterpret_cast<float4*>(b + ((tid >> 3) + 32 * q) * LDK + (tid & 7) * 4) = breg[q];
+                *reinterpret_cast<float4*>(b + ((tid >> 3) + RPP * q) * LDK + (tid & 7) * 4) = breg[q];
         } else {
 #pragma unroll
             for (int q = 0; q < B_V4; ++q) {
-                int idx = tid + 256 * q;
-                int kk = idx / (BN / 4), j4 = idx - kk * (BN / 4);
+                const int idx = tid + THREADS * q;
+                const int kk = idx / (BN / 4), j4 = idx - kk * (BN / 4);
                 *reinterpret_cast<float4*>(b + kk * LDBM + j4 * 4) = breg[q];
             }
         }
@@ -353,24 +351,40 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams p) {
 #pragma unroll
         for (int kg = 0; kg < BK / 8; ++kg) {
             float af[TM][4], bf[TN][4];
+            if constexpr (!A_MC) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                if constexpr (!A_MC) {
+                for (int i = 0; i < TM; ++i) {
                     float4 v = *reinterpret_cast<const float4*>(a + (wm * WM + i * 32 + l31) * LDK + kg * 8 + 4 * hh);
                     af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
-                } else {
+                }
+            } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) af[i][e] = a[(kg * 8 + 4 * hh + e) * LDAM + wm * WM + i * 32 + l31];
+                for (int e = 0; e < 4; ++e) {
+                    const float* src = a + (kg * 8 + 4 * hh + e) * LDAM + wm * WM + TM * l31;      // rows TM*slot + t
+                    if constexpr (TM == 2) { float2 v = *reinterpret_cast<const float2*>(src); af[0][e] = v.x; af[1][e] = v.y; }
+                    else if constexpr (TM == 4) { float4 v = *reinterpret_cast<const float4*>(src); af[0][e] = v.x; af[1][e] = v.y; af[2][e] = v.z; af[3][e] = v.w; }
+                    else {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) af[i][e] = src[i];
+                    }
                 }
             }
+            if constexpr (!B_MC) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                if constexpr (!B_MC) {
+                for (int j = 0; j < TN; ++j) {
                     float4 v = *reinterpret_cast<const float4*>(b + (wn * WN + j * 32 + l31) * LDK + kg * 8 + 4 * hh);
                     bf[j][0] = v.x; bf[j][1] = v.y; bf[j][2] = v.z; bf[j][3] = v.w;
-                } else {
+                }
+            } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) bf[j][e] = b[(kg * 8 + 4 * hh + e) * LDBM + wn * WN + j * 32 + l31];
+                for (int e = 0; e < 4; ++e) {
+                    const float* src = b + (kg * 8 + 4 * hh + e) * LDBM + wn * WN + TN * l31;
+                    if constexpr (TN == 2) { float2 v = *reinterpret_cast<const float2*>(src); bf[0][e] = v.x; bf[1][e] = v.y; }
+                    else if constexpr (TN == 4) { float4 v = *reinterpret_cast<const float4*>(src); bf[0][e] = v.x; bf[1][e] = v.y; bf[2][e] = v.z; bf[3][e] = v.w; }
+                    else {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) bf[j][e] = src[j];
+                    }
                 }
             }
 #pragma unroll
@@ -401,12 +415,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams p) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * WN + j * 32 + l31;
+            const int col = n0 + wn * WN + (B_MC ? TN * l31 + j : j * 32 + l31);      // k-major B: interleaved column slots
             if (col >= p.N) continue;
             const float bv = (p.ksplit == 1 && p.bias) ? p.bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const int slot = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const int row = m0 + wm * WM + (A_MC ? TM * slot + i : i * 32 + slot);              // k-major A: interleaved row slots
                 if (row >= p.M) continue;
                 if (p.ksplit > 1) { Cg[(long)row * p.N + col] = acc[i][j][r]; continue; }
                 long addr;
@@ -448,7 +463,7 @@ __global__ void splitk_reduce_kernel(const GemmParams p) {
     }
 }
 
-template <int BM, int BN, int AMODE, int BMODE, bool SCALAR>
+template <int BM, int BN, int AMODE, int BMODE, bool SCALAR, int WAVES_N = 2>
 int launch(const GemmParams& p, hipStream_t st) {
     constexpr bool A_MC = (AMODE == A_PLAIN_MC);
     constexpr bool B_MC = (BMODE != B_PLAIN_KC);
@@ -457,13 +472,13 @@ int launch(const GemmParams& p, hipStream_t st) {
     constexpr size_t smem = 2 * (A_TILE + B_TILE) * sizeof(float);
     static bool attr_done = false;      // per-instantiation; value is idempotent so a race is benign
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, AMODE, BMODE, SCALAR>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, AMODE, BMODE, SCALAR, WAVES_N>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
         attr_done = true;
     }
-    dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, p.batch * p.ksplit);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, AMODE, BMODE, SCALAR>), grid, dim3(256), smem, st, p);
+    dim3 grid((unsigned)((long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.batch * p.ksplit));
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, AMODE, BMODE, SCALAR, WAVES_N>), grid, dim3(128 * WAVES_N), smem, st, p);
     return hipGetLastError() == hipSuccess ? 0 : cdae_fail("igemm launch failed");
 }
 
@@ -471,7 +486,10 @@ template <int AMODE, int BMODE>
 int launch_tiles(const GemmParams& p, int big, bool scalar, hipStream_t st) {
     if (scalar) return launch<64, 64, AMODE, BMODE, true>(p, st);
     if constexpr (AMODE == A_CONV_GEN) return cdae_fail("A_CONV_GEN is a scalar-only loader");
-    else return big ? launch<128, 128, AMODE, BMODE, false>(p, st) : launch<64, 64, AMODE, BMODE, false>(p, st);
+    else {
+        if (big && p.waves8) return launch<128, 128, AMODE, BMODE, false, 4>(p, st);
+        return big ? launch<128, 128, AMODE, BMODE, false>(p, st) : launch<64, 64, AMODE, BMODE, false>(p, st);
+    }
 }
 
 }  // namespace
@@ -484,9 +502,29 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
     if (p.batch_inner <= 0) p.batch_inner = 1;
     const long tiles_big = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.batch;
     const long tiles_small = (long)((p.M + 63) / 64) * ((p.N + 63) / 64) * p.batch;
-    int big = tiles_big >= 192;
+    const int nk0 = (p.K + BK - 1) / BK;
+    // 128x128 tiles when they fill the chip, counting the K-splits a deep reduction allows (wgrad: K = all pixels)
+    const long can_split = (p.ksplit_auto && p.splitk_ws) ? (nk0 / 8 > 64 ? 64 : (nk0 / 8 < 1 ? 1 : nk0 / 8)) : 1;
+    int big = tiles_big * can_split >= 192 && p.M >= 96 && p.N >= 96;
+    // conv gather constants (see make_pixrow / tap_offset)
+    if (p.Ho > 0 && p.Wo > 0) {
+        auto magic = [](unsigned d, unsigned& m, int& sh) {
+            sh = 0;
+            while ((1u << sh) < d) ++sh;
+            m = (unsigned)(((unsigned long long)((1ull << sh) - d) << 32) / d) + 1u;
+        };
+        p.hw = p.Ho * p.Wo;
+        magic((unsigned)p.hw, p.hw_magic, p.hw_shift);
+        magic((unsigned)p.Wo, p.wo_magic, p.wo_shift);
+        if (p.tconv) { p.g_mul = 1; p.g_add = 1; p.g_sign = -1; p.g_pm = 1; p.g_sh = 1; }
+        else { p.g_mul = p.stride; p.g_add = -1; p.g_sign = 1; p.g_pm = 0; p.g_sh = p.up ? 1 : 0; }
+    }
     if (p.force_tile == 64) big = 0;
     if (p.force_tile == 128) big = 1;
+    static const int cfg_waves8 = getenv("CDAE_IGEMM_WAVES8") ? atoi(getenv("CDAE_IGEMM_WAVES8")) : 1;   // 8-wave 128x128 tiles by default
+    p.waves8 = cfg_waves8;
+    if (p.amode == A_PLAIN_MC && p.M % 4) p.a_scalar = 1;          // vector k-major loaders read 4 rows / columns at once
+    if (p.bmode != B_PLAIN_KC && p.N % 4) p.b_scalar = 1;
     const bool scalar = p.a_scalar || p.b_scalar || p.amode == A_CONV_GEN;
     if (scalar) big = 0;
     if (p.bmode == B_CONV_MC && !scalar) {           // a vectorised wgrad block must sit inside one tap
