@@ -227,8 +227,14 @@ def main():
             _lib.prof_enable(False)
             ig = prof["igemm"]
             ach = ig["work"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
+            traffic, traffic_src = None, None
+            pmc_file = os.path.join(ROOT, "profiles", "r01_igemm_pmc_summary.json")
+            if os.path.exists(pmc_file) and N == 128:        # PMC counters cannot be read in-process: separate rocprofv3 --pmc passes
+                pm = json.load(open(pmc_file))
+                traffic, traffic_src = pm["hbm_traffic_bytes_per_launch"], "profiles/r01_igemm_pmc_summary.json (rocprofv3 --pmc, same workload)"
             roof = {"bound": "mfma", "kernel": "igemm_kernel (v_mfma_f32_32x32x2_f32)", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+                    "traffic_source": traffic_src,
                     "launches_per_step": ig["launches"] // 2, "avg_launch_us": 1e3 * ig["ms"] / max(1, ig["launches"]),
                     "flops_per_launch_avg": ig["work"] / max(1, ig["launches"]),
                     "family_ms_per_step": {k: v["ms"] / 2 for k, v in prof.items()}}

@@ -171,8 +171,12 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
 
     float4 areg[A_V4], breg[B_V4];
 
+    // K-step -> first k of the step: tap major, channel minor (the per-row tap geometry is refreshed once per tap;
+    // a channel-chunk-major order was measured 5 % slower because it recomputes it every step).
+    auto kstart = [&](int kt) -> int { return kt * BK; };
+
     auto load_A = [&](int kt) {
-        const int k0 = kt * BK;
+        const int k0 = kstart(kt);
         if constexpr (AMODE == A_PLAIN_KC) {
             const int k = k0 + (tid & 7) * 4;
 #pragma unroll
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
     };
 
     auto load_B = [&](int kt) {
-        const int k0 = kt * BK;
+        const int k0 = kstart(kt);
         if constexpr (BMODE == B_PLAIN_KC) {
             const int k = k0 + (tid & 7) * 4;
 #pragma unroll
