@@ -20,6 +20,8 @@ SZ = ctypes.c_size_t
 SIGNATURES = {
     "cdae_version": [],
     "cdae_last_error": [],
+    "cdae_set_default_precision": [I],
+    "cdae_get_default_precision": [],
     "cdae_conv3x3_fwd": [P, L, L, L, L, P, P, P, P, L, I, I, I, I, I, I, I, I, P, SZ, P],
     "cdae_conv3x3_dgrad": [P, L, P, P, L, I, I, I, I, I, I, I, I, P, SZ, P],
     "cdae_conv3x3_wgrad": [P, L, L, L, L, P, L, P, P, I, I, I, I, I, I, I, I, P, SZ, P],
@@ -127,6 +129,18 @@ SPLITK_BYTES = 256 << 20
 
 def splitk_ws(device):
     return workspace(device, "splitk", SPLITK_BYTES)
+
+
+PRECISIONS = {"fp32": 0, "f16x3": 1}
+
+
+def set_precision(name):
+    """'fp32' (v_mfma_f32_32x32x2_f32, exact fp32 chain) or 'f16x3' (split-precision f16 MFMA, ~2^-22, default)."""
+    check(lib.cdae_set_default_precision(PRECISIONS[name]))
+
+
+def get_precision():
+    return {v: k for k, v in PRECISIONS.items()}[lib.cdae_get_default_precision()]
 
 
 def prof_enable(on):

@@ -11,7 +11,7 @@ namespace {
 GemmParams base_params() {
     GemmParams p;
     memset(&p, 0, sizeof(p));
-    p.batch = 1; p.batch_inner = 1; p.alpha = 1.f; p.ksplit = 1; p.stride = 1;
+    p.batch = 1; p.batch_inner = 1; p.alpha = 1.f; p.ksplit = 1; p.stride = 1; p.prec = -1;
     return p;
 }
 

@@ -26,8 +26,11 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "cdae_internal.h"
+#include "../../include/cdae.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -87,8 +90,16 @@ __device__ __forceinline__ float ld1_if(const float* /*unused*/, const float* p,
 }
 
 // SCALAR = element-wise operand loads (odd K / pitch / alignment, tiny channel counts); only built for 64x64 tiles.
-template <int BM, int BN, int AMODE, int BMODE, bool SCALAR, int WAVES_N = 2>
+//
+// PREC = 1: "f16x3" split precision for K-contiguous operand pairs.  Each fp32 operand value x is split on its way
+// into LDS into two f16 planes, x ~ hi + lo (hi = f16(x), lo = f16(x - hi): 22 significand bits), and every product
+// is evaluated as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation (the dropped lo*lo term
+// is 2^-22 relative).  3 MFMAs at 16x the fp32-MFMA rate = 5.3x less matrix-pipe time than v_mfma_f32_32x32x2_f32 at
+// ~fp32 accuracy; the two accumulators (hi*hi | cross terms) are summed in the epilogue.  Range: |x| < 65504 (the
+// reference network is fp16-safe by construction: it ships a use_fp16 mode, unet.py:501-507).
+template <int BM, int BN, int AMODE, int BMODE, bool SCALAR, int WAVES_N = 2, int PREC = 0>
 __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p) {
+    static_assert(PREC == 0 || (AMODE != A_PLAIN_MC && BMODE == B_PLAIN_KC), "split precision needs K-contiguous operands");
     // 2 x WAVES_N waves; WAVES_N = 4 (512 threads, 64x32 per wave at 128x128) doubles the waves per SIMD that can
     // cover each other's barrier / LDS waits at the same LDS footprint
     constexpr int THREADS = 128 * WAVES_N, RPP = THREADS / 8;     // RPP = tile rows covered per loader pass
@@ -100,8 +111,9 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
     // INTERLEAVED over its tiles (slot s of tile t <-> row T*s+t) so one ds_read_b64/b128 along the rows serves all
     // tiles of a k.  (A register-transposed variant measured 8-way ds_write conflicts and MFMA busy 0.39.)
     constexpr int LDAM = BM + 4, LDBM = BN + 4;
-    constexpr int A_TILE = A_MC ? BK * LDAM : BM * LDK;
-    constexpr int B_TILE = B_MC ? BK * LDBM : BN * LDK;
+    // PREC 1: two f16 planes of [rows][32 halfs] (64 B rows, 16-B chunks XOR-swizzled by (row>>2)&3: conflict-free b128)
+    constexpr int A_TILE = PREC ? BM * 32 : (A_MC ? BK * LDAM : BM * LDK);       // in floats
+    constexpr int B_TILE = PREC ? BN * 32 : (B_MC ? BK * LDBM : BN * LDK);
     constexpr int A_V4 = BM * BK / 4 / THREADS;     // float4 loads per thread per tile
     constexpr int B_V4 = BN * BK / 4 / THREADS;
 
@@ -301,9 +313,27 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
         }
     };
 
+    // split one float4 (4 consecutive k of `row`) into hi/lo f16 and store both planes (plane stride = ROWS*64 B)
+    auto store_split = [&](char* tile, int plane_bytes, int row, int c4, const float4& v) {
+        half4 hi, lo;
+        hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
+        lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);
+        lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);
+        const int off = row * 64 + 16 * ((c4 >> 1) ^ ((row >> 2) & 3)) + 8 * (c4 & 1);
+        *reinterpret_cast<half4*>(tile + off) = hi;
+        *reinterpret_cast<half4*>(tile + plane_bytes + off) = lo;
+    };
+
     auto store_tiles = [&](int buf) {
         float* a = As + buf * A_TILE;
         float* b = Bs + buf * B_TILE;
+        if constexpr (PREC == 1) {
+#pragma unroll
+            for (int q = 0; q < A_V4; ++q) store_split(reinterpret_cast<char*>(a), BM * 64, (tid >> 3) + RPP * q, tid & 7, areg[q]);
+#pragma unroll
+            for (int q = 0; q < B_V4; ++q) store_split(reinterpret_cast<char*>(b), BN * 64, (tid >> 3) + RPP * q, tid & 7, breg[q]);
+            return;
+        }
         if constexpr (!A_MC) {
 #pragma unroll
             for (int q = 0; q < A_V4; ++q)
@@ -331,12 +361,16 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
     };
 
     f32x16 acc[TM][TN];
+    f32x16 acc_lo[PREC ? TM : 1][PREC ? TN : 1];      // cross terms hi*lo + lo*hi (PREC 1)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] = 0.f;
+                if constexpr (PREC == 1) acc_lo[i][j][r] = 0.f;
+            }
 
     if (kt_begin < kt_end) {
         load_A(kt_begin);
@@ -352,6 +386,36 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
 
         const float* a = As + cur * A_TILE;
         const float* b = Bs + cur * B_TILE;
+        if constexpr (PREC == 1) {
+            const char* ac = reinterpret_cast<const char*>(a);
+            const char* bc = reinterpret_cast<const char*>(b);
+#pragma unroll
+            for (int sk = 0; sk < 2; ++sk) {                 // two 16-deep MFMA steps per 32-k tile; lane half hh holds k = 8hh..8hh+7
+                half8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int row = wm * WM + i * 32 + l31;
+                    const int off = row * 64 + 16 * ((2 * sk + hh) ^ ((row >> 2) & 3));
+                    ah[i] = *reinterpret_cast<const half8*>(ac + off);
+                    al[i] = *reinterpret_cast<const half8*>(ac + BM * 64 + off);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int row = wn * WN + j * 32 + l31;
+                    const int off = row * 64 + 16 * ((2 * sk + hh) ^ ((row >> 2) & 3));
+                    bh[j] = *reinterpret_cast<const half8*>(bc + off);
+                    bl[j] = *reinterpret_cast<const half8*>(bc + BN * 64 + off);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc_lo[i][j], 0, 0, 0);
+                        acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc_lo[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        } else
 #pragma unroll
         for (int kg = 0; kg < BK / 8; ++kg) {
             float af[TM][4], bf[TN][4];
@@ -406,7 +470,15 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
     }
 
     // ---------------------------------------------------------------- epilogue
-    // C layout of v_mfma_f32_32x32x2: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if constexpr (PREC == 1) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += acc_lo[i][j][r];
+    }
+    // C layout of v_mfma_f32_32x32xK (dtype independent): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float* __restrict__ Cg;
     const float* __restrict__ Rg = nullptr;
     if (p.ksplit > 1) {
@@ -467,22 +539,22 @@ __global__ void splitk_reduce_kernel(const GemmParams p) {
     }
 }
 
-template <int BM, int BN, int AMODE, int BMODE, bool SCALAR, int WAVES_N = 2>
+template <int BM, int BN, int AMODE, int BMODE, bool SCALAR, int WAVES_N = 2, int PREC = 0>
 int launch(const GemmParams& p, hipStream_t st) {
     constexpr bool A_MC = (AMODE == A_PLAIN_MC);
     constexpr bool B_MC = (BMODE != B_PLAIN_KC);
-    constexpr int A_TILE = A_MC ? BK * (BM + 4) : BM * LDK;
-    constexpr int B_TILE = B_MC ? BK * (BN + 4) : BN * LDK;
+    constexpr int A_TILE = PREC ? BM * 32 : (A_MC ? BK * (BM + 4) : BM * LDK);
+    constexpr int B_TILE = PREC ? BN * 32 : (B_MC ? BK * (BN + 4) : BN * LDK);
     constexpr size_t smem = 2 * (A_TILE + B_TILE) * sizeof(float);
     static bool attr_done = false;      // per-instantiation; value is idempotent so a race is benign
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, AMODE, BMODE, SCALAR, WAVES_N>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, AMODE, BMODE, SCALAR, WAVES_N, PREC>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
         attr_done = true;
     }
     dim3 grid((unsigned)((long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.batch * p.ksplit));
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, AMODE, BMODE, SCALAR, WAVES_N>), grid, dim3(128 * WAVES_N), smem, st, p);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, AMODE, BMODE, SCALAR, WAVES_N, PREC>), grid, dim3(128 * WAVES_N), smem, st, p);
     return hipGetLastError() == hipSuccess ? 0 : cdae_fail("igemm launch failed");
 }
 
@@ -491,12 +563,28 @@ int launch_tiles(const GemmParams& p, int big, bool scalar, hipStream_t st) {
     if (scalar) return launch<64, 64, AMODE, BMODE, true>(p, st);
     if constexpr (AMODE == A_CONV_GEN) return cdae_fail("A_CONV_GEN is a scalar-only loader");
     else {
+        if constexpr (AMODE != A_PLAIN_MC && BMODE == B_PLAIN_KC) {
+            if (p.prec == 1) return big ? launch<128, 128, AMODE, BMODE, false, 4, 1>(p, st) : launch<64, 64, AMODE, BMODE, false, 2, 1>(p, st);
+        }
         if (big && p.waves8) return launch<128, 128, AMODE, BMODE, false, 4>(p, st);
         return big ? launch<128, 128, AMODE, BMODE, false>(p, st) : launch<64, 64, AMODE, BMODE, false>(p, st);
     }
 }
 
 }  // namespace
+
+namespace {
+int g_default_prec = -1;      // -1: not yet initialised (env CDAE_IGEMM_PREC, else f16x3)
+}
+extern "C" int cdae_get_default_precision(void) {
+    if (g_default_prec < 0) g_default_prec = getenv("CDAE_IGEMM_PREC") ? atoi(getenv("CDAE_IGEMM_PREC")) : CDAE_PREC_F16X3;
+    return g_default_prec;
+}
+extern "C" int cdae_set_default_precision(int prec) {
+    if (prec != CDAE_PREC_FP32 && prec != CDAE_PREC_F16X3) return cdae_fail("unknown precision mode");
+    g_default_prec = prec;
+    return 0;
+}
 
 // Heuristics: 128x128 tiles when they fill the chip (>= ~1 block per CU), else 64x64; split-K when even
 // 64x64 tiles leave CUs idle and K is deep (low-resolution levels at small batch, wgrad).
@@ -527,6 +615,7 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
     if (p.force_tile == 128) big = 1;
     static const int cfg_waves8 = getenv("CDAE_IGEMM_WAVES8") ? atoi(getenv("CDAE_IGEMM_WAVES8")) : 1;   // 8-wave 128x128 tiles by default
     p.waves8 = cfg_waves8;
+    if (p.prec < 0) p.prec = cdae_get_default_precision();
     if (p.amode == A_PLAIN_MC && p.M % 4) p.a_scalar = 1;          // vector k-major loaders read 4 rows / columns at once
     if (p.bmode != B_PLAIN_KC && p.N % 4) p.b_scalar = 1;
     const bool scalar = p.a_scalar || p.b_scalar || p.amode == A_CONV_GEN;

@@ -44,6 +44,18 @@ enum {
 int cdae_version(void);
 const char* cdae_last_error(void);
 
+/* Arithmetic of the dense contractions whose operands are both K-contiguous (conv3x3 / linear / 1x1 forward, QK^T).
+ * Inputs, outputs and accumulation are fp32 in both modes.
+ *   CDAE_PREC_FP32  : v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fmaf chain.
+ *   CDAE_PREC_F16X3 : every fp32 operand is split into two f16 planes (hi + lo, 22 significand bits) and each product is
+ *                     hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 (3 MFMAs at 16x the fp32 rate; the dropped lo*lo
+ *                     term is 2^-22 relative).  Requires |operand| < 65504 (true for this network: the reference ships
+ *                     an fp16 mode).  Default; also selectable with env CDAE_IGEMM_PREC=0|1 before the first call. */
+#define CDAE_PREC_FP32 0
+#define CDAE_PREC_F16X3 1
+int cdae_set_default_precision(int prec);
+int cdae_get_default_precision(void);
+
 /* ---- dense contractions on the matrix cores (igemm.hip) -------------------------------------------------- */
 
 /* conv3x3, pad 1 — replaces nn.Conv2d in ResBlock.in_layers[2]/out_layers[3] (unet.py:143-162), the stem and

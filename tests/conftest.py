@@ -26,3 +26,13 @@ def golden():
         return cache[name]
 
     return load
+
+
+@pytest.fixture(params=["f16x3", "fp32"])
+def precision(request):
+    """Run a GPU test under both arithmetic modes of the K-contiguous contractions (include/cdae.h)."""
+    import causaldiffae_amd
+    old = causaldiffae_amd.get_precision()
+    causaldiffae_amd.set_precision(request.param)
+    yield request.param
+    causaldiffae_amd.set_precision(old)

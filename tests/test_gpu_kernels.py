@@ -28,7 +28,7 @@ def chlast_param(w):
 @pytest.mark.parametrize("M,N,K", [(16, 512, 128), (2, 1024, 512), (300, 200, 68), (1024, 1152, 384), (4096, 128, 256),
                                    (65, 33, 4), (8192, 256, 512)])
 @pytest.mark.parametrize("act", [0, 1, 2])
-def test_linear(M, N, K, act):
+def test_linear(M, N, K, act, precision):
     from causaldiffae_amd import ops
     x, w, b, r = rnd(M, K), rnd(N, K, seed=1) / K ** 0.5, rnd(N, seed=2), rnd(M, N, seed=3)
     y = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), res=r.to(DEV), act=act)
@@ -75,7 +75,7 @@ CONVS = [
 
 
 @pytest.mark.parametrize("N,Cin,Cout,H,stride,up,nchw_in,out_nchw", CONVS)
-def test_conv3x3_forward(N, Cin, Cout, H, stride, up, nchw_in, out_nchw):
+def test_conv3x3_forward(N, Cin, Cout, H, stride, up, nchw_in, out_nchw, precision):
     from causaldiffae_amd import ops
     x, w, b = rnd(N, Cin, H, H), rnd(Cout, Cin, 3, 3, seed=1) / (9 * Cin) ** 0.5, rnd(Cout, seed=2)
     xin = x.to(DEV) if nchw_in else ops.to_nhwc(x.to(DEV))
@@ -150,7 +150,7 @@ def test_group_norm(N, C, H, ssn, silu):
 
 # ------------------------------------------------------------------ attention
 @pytest.mark.parametrize("B,T,heads,ch", [(2, 256, 4, 96), (2, 64, 4, 128), (3, 256, 4, 64), (2, 16, 4, 64), (1, 49, 4, 8)])
-def test_qkv_attention(B, T, heads, ch):
+def test_qkv_attention(B, T, heads, ch, precision):
     from causaldiffae_amd import ops
     from oracle.unet_ref import qkv_attention
     C = heads * ch

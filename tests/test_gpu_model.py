@@ -64,7 +64,7 @@ def model_inputs(tag, cfg, N):
 # ------------------------------------------------------------------ G3: blocks (forward + all gradients)
 @pytest.mark.parametrize("tag,ci,co,ssn", [("res_same", 128, 128, True), ("res_skip", 128, 256, True), ("res_cat", 384, 128, True),
                                            ("res_nossn", 64, 96, False)])
-def test_resblock_golden(golden, tag, ci, co, ssn):
+def test_resblock_golden(golden, tag, ci, co, ssn, precision):
     from improved_diffusion.unet import ResBlock
     g = golden("g3_blocks.npz")
     meta = json.load(open(os.path.join(GOLDEN, "g3_blocks.json")))[tag]
@@ -212,7 +212,7 @@ def test_causal_layer_golden(golden):
 
 # ------------------------------------------------------------------ G6: full UNet forward at BASELINE shapes
 @pytest.mark.parametrize("tag", ["M32", "P64", "C64"])
-def test_unet_forward_golden(golden, tag):
+def test_unet_forward_golden(golden, tag, precision):
     from improved_diffusion.nn import rng_override
     g = golden("g6_unet.npz")
     model, diff, cfg = make(tag)
@@ -231,7 +231,7 @@ def test_unet_forward_golden(golden, tag):
 
 
 # ------------------------------------------------------------------ G8: counterfactual pattern, single steps, DDIM-100
-def test_ddim_p64_golden(golden):
+def test_ddim_p64_golden(golden, precision):
     from improved_diffusion.nn import reparameterize
     from improved_diffusion.unet import ADJACENCY
     g = golden("g8_ddim.npz")
@@ -275,7 +275,7 @@ def test_ddim_p64_golden(golden):
 
 # ------------------------------------------------------------------ G7: training_losses + AdamW/EMA trajectory
 @pytest.mark.parametrize("variant,masking", [("plain", False), ("masked", True)])
-def test_training_trajectory_golden(golden, variant, masking):
+def test_training_trajectory_golden(golden, variant, masking, precision):
     from improved_diffusion.nn import rng_override
     from improved_diffusion.train_util import FusedAdamWEMA
     g = golden("g7_train.npz")
