@@ -33,16 +33,23 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
         const int g = (e * VEC) / cpg;
         const float pivot = xn[g * cpg];
         const int p0 = chunk * pix_per_block, p1 = min(HW, p0 + pix_per_block);
-        for (int p = p0 + r; p < p1; p += rows) {
-            if (VEC == 4) {
-                float4 v = *reinterpret_cast<const float4*>(xn + (long)p * ldx + e * 4);
+        int p = p0 + r;
+        if (VEC == 4) {
+            auto acc4 = [&](const float4& v) {
                 float a = v.x - pivot, b = v.y - pivot, c = v.z - pivot, d = v.w - pivot;
                 S += (a + b) + (c + d);
                 Q += (a * a + b * b) + (c * c + d * d);
-            } else {
-                float a = xn[(long)p * ldx + e] - pivot;
-                S += a; Q += a * a;
+            };
+            for (; p + 3 * rows < p1; p += 4 * rows) {        // four independent 16-byte loads in flight
+                float4 v0 = *reinterpret_cast<const float4*>(xn + (long)p * ldx + e * 4);
+                float4 v1 = *reinterpret_cast<const float4*>(xn + (long)(p + rows) * ldx + e * 4);
+                float4 v2 = *reinterpret_cast<const float4*>(xn + (long)(p + 2 * rows) * ldx + e * 4);
+                float4 v3 = *reinterpret_cast<const float4*>(xn + (long)(p + 3 * rows) * ldx + e * 4);
+                acc4(v0); acc4(v1); acc4(v2); acc4(v3);
             }
+            for (; p < p1; p += rows) acc4(*reinterpret_cast<const float4*>(xn + (long)p * ldx + e * 4));
+        } else {
+            for (; p < p1; p += rows) { float a = xn[(long)p * ldx + e] - pivot; S += a; Q += a * a; }
         }
     }
     sS[tid] = S; sQ[tid] = Q;
@@ -77,33 +84,53 @@ __global__ void gn_finalize_kernel(const float* __restrict__ x, int HW, int ldx,
 }
 
 // y = silu?( gn(x) * gamma + beta  [ * (1 + scale) + shift ] )
+// grid (nchunk, N), 256 threads: a thread owns one channel vector for the whole chunk, so the normalisation folds into a
+// per-thread affine (y = x*A + B, the form ATen's CPU kernel uses too) computed once; the pixel loop is pure
+// load / fma / SiLU / store with four independent 16-byte loads in flight and no index arithmetic.
 template <int VEC>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, float* __restrict__ y, long total_vec,
-                                                        int HW, int C, int ldx, int ldy, int cpg, int G,
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, float* __restrict__ y, int HW, int C, int ldx, int ldy,
+                                                        int cpg, int G, int pix_per_block,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ ss, int ld_ss, int do_silu) {
-    const int E = C / VEC;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total_vec; idx += (long)gridDim.x * blockDim.x) {
-        const long pix = idx / E;
-        const int e = (int)(idx - pix * E);
-        const int n = (int)(pix / HW);
-        const int c = e * VEC;
-        const int g = c / cpg;
-        const float mu = mean[n * G + g], rs = rstd[n * G + g];
-        float v[VEC], o[VEC];
-        if (VEC == 4) {
-            float4 t = *reinterpret_cast<const float4*>(x + pix * ldx + c);
-            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-        } else v[0] = x[pix * ldx + c];
+    const int n = blockIdx.y, E = C / VEC, rows = 256 / E, tid = threadIdx.x;
+    const int r = tid / E, e = tid - r * E;
+    if (r >= rows) return;
+    const int c = e * VEC, g = c / cpg;
+    const float mu = mean[n * G + g], rs = rstd[n * G + g];
+    float A[VEC], B[VEC];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            float h = (v[i] - mu) * rs * gamma[c + i] + beta[c + i];
-            if (ss) h = h * (1.f + ss[(long)n * ld_ss + c + i]) + ss[(long)n * ld_ss + C + c + i];
-            o[i] = do_silu ? silu_f(h) : h;
+    for (int i = 0; i < VEC; ++i) {
+        A[i] = rs * gamma[c + i];
+        B[i] = fmaf(-mu, A[i], beta[c + i]);
+        if (ss) {
+            const float sc = 1.f + ss[(long)n * ld_ss + c + i], sh = ss[(long)n * ld_ss + C + c + i];
+            A[i] *= sc;
+            B[i] = fmaf(B[i], sc, sh);
         }
-        if (VEC == 4) *reinterpret_cast<float4*>(y + pix * ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
-        else y[pix * ldy + c] = o[0];
+    }
+    const float* xp = x + (long)n * HW * ldx + c;
+    float* yp = y + (long)n * HW * ldy + c;
+    const int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
+    auto apply = [&](float v, int i) { float h = fmaf(v, A[i], B[i]); return do_silu ? silu_f(h) : h; };
+    int p = p0 + r;
+    if constexpr (VEC == 4) {
+        for (; p + 3 * rows < p1; p += 4 * rows) {
+            float4 v0 = *reinterpret_cast<const float4*>(xp + (long)p * ldx);
+            float4 v1 = *reinterpret_cast<const float4*>(xp + (long)(p + rows) * ldx);
+            float4 v2 = *reinterpret_cast<const float4*>(xp + (long)(p + 2 * rows) * ldx);
+            float4 v3 = *reinterpret_cast<const float4*>(xp + (long)(p + 3 * rows) * ldx);
+            *reinterpret_cast<float4*>(yp + (long)p * ldy) = make_float4(apply(v0.x, 0), apply(v0.y, 1), apply(v0.z, 2), apply(v0.w, 3));
+            *reinterpret_cast<float4*>(yp + (long)(p + rows) * ldy) = make_float4(apply(v1.x, 0), apply(v1.y, 1), apply(v1.z, 2), apply(v1.w, 3));
+            *reinterpret_cast<float4*>(yp + (long)(p + 2 * rows) * ldy) = make_float4(apply(v2.x, 0), apply(v2.y, 1), apply(v2.z, 2), apply(v2.w, 3));
+            *reinterpret_cast<float4*>(yp + (long)(p + 3 * rows) * ldy) = make_float4(apply(v3.x, 0), apply(v3.y, 1), apply(v3.z, 2), apply(v3.w, 3));
+        }
+        for (; p < p1; p += rows) {
+            float4 v = *reinterpret_cast<const float4*>(xp + (long)p * ldx);
+            *reinterpret_cast<float4*>(yp + (long)p * ldy) = make_float4(apply(v.x, 0), apply(v.y, 1), apply(v.z, 2), apply(v.w, 3));
+        }
+    } else {
+        for (; p < p1; p += rows) yp[(long)p * ldy] = apply(xp[(long)p * ldx], 0);
     }
 }
 
@@ -483,10 +510,16 @@ int cdae_gn_apply(const float* x, float* y, int N, int HW, int C, int ldx, int l
     hipStream_t st = (hipStream_t)stream;
     const int cpg = C / groups;
     const int VEC = (cpg % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0) ? 4 : 1;
-    const long total = (long)N * HW * (C / VEC);
+    const int E = C / VEC;
+    if (E > 256) return cdae_fail("gn_apply: unsupported channel count for this vector width");
+    const int rows = 256 / E;
+    int nchunk = HW / (rows * 16);             // >= 16 pixels per thread
+    if (nchunk < 1) nchunk = 1;
+    while (nchunk > 1 && (long)nchunk * N > 4096) nchunk >>= 1;
+    const int ppb = (HW + nchunk - 1) / nchunk;
     cdae_prof_begin(PROF_GN, (double)N * HW * C * 8.0, st);
-    if (VEC == 4) hipLaunchKernelGGL(gn_apply_kernel<4>, dim3(grid_for(total)), dim3(256), 0, st, x, y, total, HW, C, ldx, ldy, cpg, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu);
-    else hipLaunchKernelGGL(gn_apply_kernel<1>, dim3(grid_for(total)), dim3(256), 0, st, x, y, total, HW, C, ldx, ldy, cpg, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu);
+    if (VEC == 4) hipLaunchKernelGGL(gn_apply_kernel<4>, dim3(nchunk, N), dim3(256), 0, st, x, y, HW, C, ldx, ldy, cpg, groups, ppb, mean, rstd, gamma, beta, scale_shift, ld_ss, silu);
+    else hipLaunchKernelGGL(gn_apply_kernel<1>, dim3(nchunk, N), dim3(256), 0, st, x, y, HW, C, ldx, ldy, cpg, groups, ppb, mean, rstd, gamma, beta, scale_shift, ld_ss, silu);
     cdae_prof_end(PROF_GN, st);
     CHECK_LAUNCH("gn_apply launch failed");
     return 0;
