@@ -21,6 +21,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
+F16_MFMA_PEAK_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (spec)
 GFLOP_PER_IMAGE_STEP_P64 = 60.63       # SURVEY §8d (torch FlopCounter on the reference forward)
 
 
@@ -136,6 +137,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--precision", choices=["f16x3", "fp32"], default=None, help="arithmetic of the K-contiguous contractions")
     ap.add_argument("--train-batch", type=int, default=32)
     ap.add_argument("--train-steps", type=int, default=5)
     args = ap.parse_args()
@@ -160,6 +162,8 @@ def main():
     from improved_diffusion.nn import reparameterize
     from improved_diffusion.unet import ADJACENCY
 
+    if args.precision:
+        causaldiffae_amd.set_precision(args.precision)
     cfg = {**su.model_and_diffusion_defaults(), "image_size": 64, "in_channels": 4, "n_vars": 4, "rep_cond": True,
            "causal_modeling": True, "timestep_respacing": "ddim100"}
     model, diff = su.create_model_and_diffusion(**cfg)
@@ -227,14 +231,21 @@ def main():
             _lib.prof_enable(False)
             ig = prof["igemm"]
             ach = ig["work"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
+            prec = causaldiffae_amd.get_precision()
+            # f16x3: every algorithmic multiply-add is 3 f16 MFMA multiply-adds, so the matrix-core roof for ALGORITHMIC
+            # flops is the dense f16 peak / 3; fp32: the fp32 MFMA peak
+            peak = F16_MFMA_PEAK_TFLOPS / 3.0 if prec == "f16x3" else FP32_MFMA_PEAK_TFLOPS
+            kern = ("igemm_kernel<...,PREC=1> (v_mfma_f32_32x32x16_f16, f16x3 split precision, fp32 accumulate)" if prec == "f16x3"
+                    else "igemm_kernel (v_mfma_f32_32x32x2_f32)")
             traffic, traffic_src = None, None
-            pmc_file = os.path.join(ROOT, "profiles", "r01_igemm_pmc_summary.json")
+            pmc_file = os.path.join(ROOT, "profiles", f"r01_igemm_pmc_summary_{prec}.json")
             if os.path.exists(pmc_file) and N == 128:        # PMC counters cannot be read in-process: separate rocprofv3 --pmc passes
                 pm = json.load(open(pmc_file))
-                traffic, traffic_src = pm["hbm_traffic_bytes_per_launch"], "profiles/r01_igemm_pmc_summary.json (rocprofv3 --pmc, same workload)"
-            roof = {"bound": "mfma", "kernel": "igemm_kernel (v_mfma_f32_32x32x2_f32)", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
-                    "traffic_source": traffic_src,
+                traffic, traffic_src = pm["hbm_traffic_bytes_per_launch"], f"profiles/{os.path.basename(pmc_file)} (rocprofv3 --pmc, same workload)"
+            roof = {"bound": "mfma", "kernel": kern, "achieved": ach, "peak": peak, "unit": "TFLOP/s (algorithmic 2MNK)",
+                    "frac": ach / peak, "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
+                    "precision_mode": prec, "executed_mfma_tflops": ach * (3.0 if prec == "f16x3" else 1.0),
+                    "vs_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
                     "launches_per_step": ig["launches"] // 2, "avg_launch_us": 1e3 * ig["ms"] / max(1, ig["launches"]),
                     "flops_per_launch_avg": ig["work"] / max(1, ig["launches"]),
                     "family_ms_per_step": {k: v["ms"] / 2 for k, v in prof.items()}}
@@ -253,7 +264,9 @@ def main():
     out = {
         "metric": "DDIM denoise image-steps/sec, 64x64 UNet (P64)", "value": value, "unit": "image-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if causaldiffae_amd.get_precision() == "fp32" else "f32 (in/out/accumulate; products as f16x3 split, 2^-22)",
+        "data": "synthetic",
         "config": {"workload": "Pendulum 64x64 C=4, 4 causal vars, DDIM-100 counterfactual sampling (encode -> intervene -> "
                                "q_sample -> ddim steps), UNet 93.45M params", "batch_per_gpu": N, "global_batch": N * world,
                    "parallelism": f"batch-sharded x{world}, no collectives", "hip_graph": not args.no_graph},
