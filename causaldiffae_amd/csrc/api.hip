@@ -75,7 +75,7 @@ int cdae_conv3x3_dgrad(const float* dy, long lddy, const float* w, float* dx, lo
     const int Ho = up ? 2 * H : (H - 1) / stride + 1, Wo = up ? 2 * W : (W - 1) / stride + 1;   // dy grid
     GemmParams p = base_params();
     p.A = dy; p.B = w; p.C = dx;
-    p.N = Cin; p.K = 9 * Cout; p.ldc = lddx; p.accumulate = accumulate;
+    p.N = Cin; p.K = 9 * Cout; p.ldc = lddx; p.accumulate = accumulate; p.grad_operand = 1;
     // gathered tensor = dy
     p.H = Ho; p.W = Wo; p.Cin = Cout;
     p.sn = (long)Ho * Wo * lddy; p.sy = (long)Wo * lddy; p.sx = lddy; p.sc = 1;
@@ -100,7 +100,7 @@ int cdae_conv3x3_wgrad(const float* x, long sn, long sy, long sx, long sc, const
     GemmParams p = base_params();
     p.A = dy; p.B = x; p.C = dw;
     p.M = Cout; p.N = 9 * Cin; p.K = N * Ho * Wo;
-    p.lda = lddy; p.ldc = 9L * Cin; p.accumulate = accumulate;
+    p.lda = lddy; p.ldc = 9L * Cin; p.accumulate = accumulate; p.grad_operand = 1;
     p.amode = A_PLAIN_MC; p.a_scalar = !(lddy % 4 == 0 && aligned16(dy));
     p.bmode = B_CONV_MC;
     p.b_scalar = !(sc == 1 && Cin % 64 == 0 && sx % 4 == 0 && sy % 4 == 0 && sn % 4 == 0 && aligned16(x));
@@ -128,7 +128,7 @@ int cdae_linear_dgrad(const float* dy, long lddy, const float* w, long ldw, floa
                       float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
     GemmParams p = base_params();
     p.A = dy; p.B = w; p.C = dx;
-    p.M = M; p.N = K; p.K = N; p.lda = lddy; p.ldb = ldw; p.ldc = lddx; p.accumulate = accumulate;
+    p.M = M; p.N = K; p.K = N; p.lda = lddy; p.ldb = ldw; p.ldc = lddx; p.accumulate = accumulate; p.grad_operand = 1;
     p.amode = A_PLAIN_KC; p.bmode = B_PLAIN_MC;
     p.a_scalar = !(N % 4 == 0 && lddy % 4 == 0 && aligned16(dy));
     p.b_scalar = !(ldw % 4 == 0 && aligned16(w));
@@ -140,7 +140,7 @@ int cdae_linear_wgrad(const float* x, long ldx, const float* dy, long lddy, floa
                       int accumulate, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
     GemmParams p = base_params();
     p.A = dy; p.B = x; p.C = dw;
-    p.M = N; p.N = K; p.K = M; p.lda = lddy; p.ldb = ldx; p.ldc = lddw; p.accumulate = accumulate;
+    p.M = N; p.N = K; p.K = M; p.lda = lddy; p.ldb = ldx; p.ldc = lddw; p.accumulate = accumulate; p.grad_operand = 1;
     p.amode = A_PLAIN_MC; p.bmode = B_PLAIN_MC;
     p.a_scalar = !(lddy % 4 == 0 && aligned16(dy));
     p.b_scalar = !(ldx % 4 == 0 && aligned16(x));
@@ -191,7 +191,7 @@ int cdae_qkv_attention_bwd(const float* qkv, const float* probs, const float* do
         p.M = T; p.N = ch; p.K = T; p.lda = T; p.ldb = C; p.ldc = C3;
         p.batch = B * heads; p.batch_inner = heads;
         p.a_bs0 = (long)heads * T * T; p.a_bs1 = (long)T * T; p.b_bs0 = T * C; p.b_bs1 = ch; p.c_bs0 = T * C3; p.c_bs1 = 3L * ch;
-        p.amode = A_PLAIN_MC; p.bmode = B_PLAIN_MC; p.a_scalar = !(t4 && aligned16(probs)); p.b_scalar = !aligned16(dout);
+        p.amode = A_PLAIN_MC; p.bmode = B_PLAIN_MC; p.a_scalar = !(t4 && aligned16(probs)); p.b_scalar = !aligned16(dout); p.grad_operand = 1;
         if ((rc = cdae_gemm_dispatch(p, stream))) return rc;
     }
     {   // dP[t][s] = sum_c dO[t][c] V[s][c]
@@ -200,7 +200,7 @@ int cdae_qkv_attention_bwd(const float* qkv, const float* probs, const float* do
         p.M = T; p.N = T; p.K = ch; p.lda = C; p.ldb = C3; p.ldc = T;
         p.batch = B * heads; p.batch_inner = heads;
         p.a_bs0 = T * C; p.a_bs1 = ch; p.b_bs0 = T * C3; p.b_bs1 = 3L * ch; p.c_bs0 = (long)heads * T * T; p.c_bs1 = (long)T * T;
-        p.amode = A_PLAIN_KC; p.bmode = B_PLAIN_KC; p.a_scalar = !aligned16(dout); p.b_scalar = !aligned16(qkv);
+        p.amode = A_PLAIN_KC; p.bmode = B_PLAIN_KC; p.a_scalar = !aligned16(dout); p.b_scalar = !aligned16(qkv); p.grad_operand = 1;
         if ((rc = cdae_gemm_dispatch(p, stream))) return rc;
     }
     if ((rc = cdae_softmax_rows_bwd(probs, dprobs, (long)B * heads * T, T, stream))) return rc;
@@ -210,7 +210,7 @@ int cdae_qkv_attention_bwd(const float* qkv, const float* probs, const float* do
         p.M = T; p.N = ch; p.K = T; p.lda = T; p.ldb = C3; p.ldc = C3; p.alpha = alpha;
         p.batch = B * heads; p.batch_inner = heads;
         p.a_bs0 = (long)heads * T * T; p.a_bs1 = (long)T * T; p.b_bs0 = T * C3; p.b_bs1 = 3L * ch; p.c_bs0 = T * C3; p.c_bs1 = 3L * ch;
-        p.amode = A_PLAIN_KC; p.bmode = B_PLAIN_MC; p.a_scalar = !(t4 && aligned16(dprobs)); p.b_scalar = !aligned16(qkv);
+        p.amode = A_PLAIN_KC; p.bmode = B_PLAIN_MC; p.a_scalar = !(t4 && aligned16(dprobs)); p.b_scalar = !aligned16(qkv); p.grad_operand = 1;
         if ((rc = cdae_gemm_dispatch(p, stream))) return rc;
     }
     {   // dK[s][c] = alpha sum_t dS[t][s] Q[t][c]
@@ -219,7 +219,7 @@ int cdae_qkv_attention_bwd(const float* qkv, const float* probs, const float* do
         p.M = T; p.N = ch; p.K = T; p.lda = T; p.ldb = C3; p.ldc = C3; p.alpha = alpha;
         p.batch = B * heads; p.batch_inner = heads;
         p.a_bs0 = (long)heads * T * T; p.a_bs1 = (long)T * T; p.b_bs0 = T * C3; p.b_bs1 = 3L * ch; p.c_bs0 = T * C3; p.c_bs1 = 3L * ch;
-        p.amode = A_PLAIN_MC; p.bmode = B_PLAIN_MC; p.a_scalar = !(t4 && aligned16(dprobs)); p.b_scalar = !aligned16(qkv);
+        p.amode = A_PLAIN_MC; p.bmode = B_PLAIN_MC; p.a_scalar = !(t4 && aligned16(dprobs)); p.b_scalar = !aligned16(qkv); p.grad_operand = 1;
         if ((rc = cdae_gemm_dispatch(p, stream))) return rc;
     }
     return 0;

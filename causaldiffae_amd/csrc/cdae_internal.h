@@ -32,6 +32,7 @@ struct GemmParams {
     int wCout, wCin, wflip;
     // split-K
     int ksplit, ksplit_auto, ksplit_force, force_tile, waves8;
+    int grad_operand;       // one operand is a gradient tensor (range unsafe for f16): split mode uses bf16 planes
     int prec;               // -1: library default (env CDAE_IGEMM_PREC), 0: fp32 MFMA, 1: f16x3 split precision (K-contiguous operand pairs only)
     float* splitk_ws; size_t splitk_ws_bytes;
 };

@@ -31,6 +31,11 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -97,9 +102,15 @@ __device__ __forceinline__ float ld1_if(const float* /*unused*/, const float* p,
 // is 2^-22 relative).  3 MFMAs at 16x the fp32-MFMA rate = 5.3x less matrix-pipe time than v_mfma_f32_32x32x2_f32 at
 // ~fp32 accuracy; the two accumulators (hi*hi | cross terms) are summed in the epilogue.  Range: |x| < 65504 (the
 // reference network is fp16-safe by construction: it ships a use_fp16 mode, unet.py:501-507).
+// PREC = 2: the same with bf16 planes ("bf16x3", 16 significand bits, full fp32 range) — used for every GEMM that
+// has a GRADIENT operand (dgrad / wgrad / attention backward): gradients underflow f16, and 2^-16 is far below what
+// the optimizer can see.
+// K-contiguous operands: planes of [rows][32 x 16-bit] (64-B rows, 16-B chunks XOR-swizzled by (row>>2)&3), fragments
+// by one ds_read_b128.  k-major operands: planes of [32 k][rows+32] (coalesced 8-B stores), fragments by two
+// ds_read_b64_tr_b16 (hardware transpose read; the +32 pad makes both conflict-free).
 template <int BM, int BN, int AMODE, int BMODE, bool SCALAR, int WAVES_N = 2, int PREC = 0>
 __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p) {
-    static_assert(PREC == 0 || (AMODE != A_PLAIN_MC && BMODE == B_PLAIN_KC), "split precision needs K-contiguous operands");
+    static_assert(PREC == 0 || !SCALAR, "split precision is only built for vectorised loaders");
     // 2 x WAVES_N waves; WAVES_N = 4 (512 threads, 64x32 per wave at 128x128) doubles the waves per SIMD that can
     // cover each other's barrier / LDS waits at the same LDS footprint
     constexpr int THREADS = 128 * WAVES_N, RPP = THREADS / 8;     // RPP = tile rows covered per loader pass
@@ -112,8 +123,11 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
     // tiles of a k.  (A register-transposed variant measured 8-way ds_write conflicts and MFMA busy 0.39.)
     constexpr int LDAM = BM + 4, LDBM = BN + 4;
     // PREC 1: two f16 planes of [rows][32 halfs] (64 B rows, 16-B chunks XOR-swizzled by (row>>2)&3: conflict-free b128)
-    constexpr int A_TILE = PREC ? BM * 32 : (A_MC ? BK * LDAM : BM * LDK);       // in floats
-    constexpr int B_TILE = PREC ? BN * 32 : (B_MC ? BK * LDBM : BN * LDK);
+    constexpr int PAM = BM + 32, PBM = BN + 32;                                  // k-major 16-bit plane pitch (elements)
+    constexpr int A_PLANE = A_MC ? BK * PAM * 2 : BM * 64;                       // bytes per 16-bit plane
+    constexpr int B_PLANE = B_MC ? BK * PBM * 2 : BN * 64;
+    constexpr int A_TILE = PREC ? A_PLANE / 2 : (A_MC ? BK * LDAM : BM * LDK);   // in floats (two planes)
+    constexpr int B_TILE = PREC ? B_PLANE / 2 : (B_MC ? BK * LDBM : BN * LDK);
     constexpr int A_V4 = BM * BK / 4 / THREADS;     // float4 loads per thread per tile
     constexpr int B_V4 = BN * BK / 4 / THREADS;
 
@@ -313,25 +327,50 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
         }
     };
 
-    // split one float4 (4 consecutive k of `row`) into hi/lo f16 and store both planes (plane stride = ROWS*64 B)
-    auto store_split = [&](char* tile, int plane_bytes, int row, int c4, const float4& v) {
-        half4 hi, lo;
-        hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
-        lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);
-        lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);
-        const int off = row * 64 + 16 * ((c4 >> 1) ^ ((row >> 2) & 3)) + 8 * (c4 & 1);
-        *reinterpret_cast<half4*>(tile + off) = hi;
-        *reinterpret_cast<half4*>(tile + plane_bytes + off) = lo;
+    // split a float4 into hi/lo 16-bit planes (f16 for PREC 1, bf16 for PREC 2) and store 8 B into each plane
+    auto store_split = [&](char* tile, int plane_bytes, int off, const float4& v) {
+        if constexpr (PREC == 2) {
+            bf4 hi, lo;
+            hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
+            lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
+            lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
+            *reinterpret_cast<bf4*>(tile + off) = hi;
+            *reinterpret_cast<bf4*>(tile + plane_bytes + off) = lo;
+        } else {
+            half4 hi, lo;
+            hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
+            lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);
+            lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);
+            *reinterpret_cast<half4*>(tile + off) = hi;
+            *reinterpret_cast<half4*>(tile + plane_bytes + off) = lo;
+        }
     };
+    auto kc_off = [&](int row, int c4) { return row * 64 + 16 * ((c4 >> 1) ^ ((row >> 2) & 3)) + 8 * (c4 & 1); };
 
     auto store_tiles = [&](int buf) {
         float* a = As + buf * A_TILE;
         float* b = Bs + buf * B_TILE;
-        if constexpr (PREC == 1) {
+        if constexpr (PREC != 0) {
+            char* ac = reinterpret_cast<char*>(a);
+            char* bc = reinterpret_cast<char*>(b);
 #pragma unroll
-            for (int q = 0; q < A_V4; ++q) store_split(reinterpret_cast<char*>(a), BM * 64, (tid >> 3) + RPP * q, tid & 7, areg[q]);
+            for (int q = 0; q < A_V4; ++q) {
+                if constexpr (!A_MC) store_split(ac, A_PLANE, kc_off((tid >> 3) + RPP * q, tid & 7), areg[q]);
+                else {
+                    const int idx = tid + THREADS * q;
+                    const int kk = idx / (BM / 4), i4 = idx - kk * (BM / 4);
+                    store_split(ac, A_PLANE, (kk * PAM + i4 * 4) * 2, areg[q]);
+                }
+            }
 #pragma unroll
-            for (int q = 0; q < B_V4; ++q) store_split(reinterpret_cast<char*>(b), BN * 64, (tid >> 3) + RPP * q, tid & 7, breg[q]);
+            for (int q = 0; q < B_V4; ++q) {
+                if constexpr (!B_MC) store_split(bc, B_PLANE, kc_off((tid >> 3) + RPP * q, tid & 7), breg[q]);
+                else {
+                    const int idx = tid + THREADS * q;
+                    const int kk = idx / (BN / 4), j4 = idx - kk * (BN / 4);
+                    store_split(bc, B_PLANE, (kk * PBM + j4 * 4) * 2, breg[q]);
+                }
+            }
             return;
         }
         if constexpr (!A_MC) {
@@ -361,7 +400,7 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
     };
 
     f32x16 acc[TM][TN];
-    f32x16 acc_lo[PREC ? TM : 1][PREC ? TN : 1];      // cross terms hi*lo + lo*hi (PREC 1)
+    f32x16 acc_lo[PREC ? TM : 1][PREC ? TN : 1];      // cross terms hi*lo + lo*hi (split precision)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -369,7 +408,7 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 acc[i][j][r] = 0.f;
-                if constexpr (PREC == 1) acc_lo[i][j][r] = 0.f;
+                if constexpr (PREC != 0) acc_lo[i][j][r] = 0.f;
             }
 
     if (kt_begin < kt_end) {
@@ -386,33 +425,52 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
 
         const float* a = As + cur * A_TILE;
         const float* b = Bs + cur * B_TILE;
-        if constexpr (PREC == 1) {
+        if constexpr (PREC != 0) {
             const char* ac = reinterpret_cast<const char*>(a);
             const char* bc = reinterpret_cast<const char*>(b);
+            // one 16-bit MFMA operand (8 consecutive k of this lane's row) from a plane
+            auto frag = [&](const char* plane, int row0, int sk, auto mc_tag, int pitch) -> u16x8 {
+                if constexpr (!decltype(mc_tag)::value) {
+                    const int row = row0 + l31;
+                    return *reinterpret_cast<const u16x8*>(plane + row * 64 + 16 * ((2 * sk + hh) ^ ((row >> 2) & 3)));
+                } else {
+                    // k-major plane [k][pitch]: ds_read_b64_tr_b16 — lane 4q+p of a 16-lane group addresses row k0+q,
+                    // columns c0+4p..+3 and receives column (lane&15) of the 4 rows: 4 consecutive k of its own row slot
+                    const int q4 = (lane & 15) >> 2, p4 = lane & 3;
+                    const int c0 = row0 + 16 * ((lane >> 4) & 1), k0 = 16 * sk + 8 * hh;
+                    const char* src = plane + ((k0 + q4) * pitch + c0 + 4 * p4) * 2;
+                    fp16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(src));
+                    fp16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(src + 4 * pitch * 2));
+                    u16x4 a4 = __builtin_bit_cast(u16x4, lo4), b4 = __builtin_bit_cast(u16x4, hi4);
+                    u16x8 r;
+                    r[0] = a4[0]; r[1] = a4[1]; r[2] = a4[2]; r[3] = a4[3]; r[4] = b4[0]; r[5] = b4[1]; r[6] = b4[2]; r[7] = b4[3];
+                    return r;
+                }
+            };
+            auto mma = [&](const u16x8& x, const u16x8& y, const f32x16& c) -> f32x16 {
+                if constexpr (PREC == 2) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, x), __builtin_bit_cast(bf8, y), c, 0, 0, 0);
+                else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, x), __builtin_bit_cast(half8, y), c, 0, 0, 0);
+            };
 #pragma unroll
             for (int sk = 0; sk < 2; ++sk) {                 // two 16-deep MFMA steps per 32-k tile; lane half hh holds k = 8hh..8hh+7
-                half8 ah[TM], al[TM], bh[TN], bl[TN];
+                u16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    const int row = wm * WM + i * 32 + l31;
-                    const int off = row * 64 + 16 * ((2 * sk + hh) ^ ((row >> 2) & 3));
-                    ah[i] = *reinterpret_cast<const half8*>(ac + off);
-                    al[i] = *reinterpret_cast<const half8*>(ac + BM * 64 + off);
+                    ah[i] = frag(ac, wm * WM + i * 32, sk, std::integral_constant<bool, A_MC>{}, PAM);
+                    al[i] = frag(ac + A_PLANE, wm * WM + i * 32, sk, std::integral_constant<bool, A_MC>{}, PAM);
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    const int row = wn * WN + j * 32 + l31;
-                    const int off = row * 64 + 16 * ((2 * sk + hh) ^ ((row >> 2) & 3));
-                    bh[j] = *reinterpret_cast<const half8*>(bc + off);
-                    bl[j] = *reinterpret_cast<const half8*>(bc + BN * 64 + off);
+                    bh[j] = frag(bc, wn * WN + j * 32, sk, std::integral_constant<bool, B_MC>{}, PBM);
+                    bl[j] = frag(bc + B_PLANE, wn * WN + j * 32, sk, std::integral_constant<bool, B_MC>{}, PBM);
                 }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc_lo[i][j], 0, 0, 0);
-                        acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc_lo[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc_lo[i][j] = mma(al[i], bh[j], acc_lo[i][j]);
+                        acc_lo[i][j] = mma(ah[i], bl[j], acc_lo[i][j]);
+                        acc[i][j] = mma(ah[i], bh[j], acc[i][j]);
                     }
             }
         } else
@@ -470,7 +528,7 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
     }
 
     // ---------------------------------------------------------------- epilogue
-    if constexpr (PREC == 1) {
+    if constexpr (PREC != 0) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -491,13 +549,13 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * WN + (B_MC ? TN * l31 + j : j * 32 + l31);      // k-major B: interleaved column slots
+            const int col = n0 + wn * WN + ((B_MC && PREC == 0) ? TN * l31 + j : j * 32 + l31);      // fp32 k-major B: interleaved column slots
             if (col >= p.N) continue;
             const float bv = (p.ksplit == 1 && p.bias) ? p.bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int slot = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                const int row = m0 + wm * WM + (A_MC ? TM * slot + i : i * 32 + slot);              // k-major A: interleaved row slots
+                const int row = m0 + wm * WM + ((A_MC && PREC == 0) ? TM * slot + i : i * 32 + slot);              // fp32 k-major A: interleaved row slots
                 if (row >= p.M) continue;
                 if (p.ksplit > 1) { Cg[(long)row * p.N + col] = acc[i][j][r]; continue; }
                 long addr;
@@ -543,8 +601,8 @@ template <int BM, int BN, int AMODE, int BMODE, bool SCALAR, int WAVES_N = 2, in
 int launch(const GemmParams& p, hipStream_t st) {
     constexpr bool A_MC = (AMODE == A_PLAIN_MC);
     constexpr bool B_MC = (BMODE != B_PLAIN_KC);
-    constexpr int A_TILE = PREC ? BM * 32 : (A_MC ? BK * (BM + 4) : BM * LDK);
-    constexpr int B_TILE = PREC ? BN * 32 : (B_MC ? BK * (BN + 4) : BN * LDK);
+    constexpr int A_TILE = PREC ? (A_MC ? BK * (BM + 32) : BM * 32) : (A_MC ? BK * (BM + 4) : BM * LDK);
+    constexpr int B_TILE = PREC ? (B_MC ? BK * (BN + 32) : BN * 32) : (B_MC ? BK * (BN + 4) : BN * LDK);
     constexpr size_t smem = 2 * (A_TILE + B_TILE) * sizeof(float);
     static bool attr_done = false;      // per-instantiation; value is idempotent so a race is benign
     if (!attr_done) {
@@ -563,9 +621,8 @@ int launch_tiles(const GemmParams& p, int big, bool scalar, hipStream_t st) {
     if (scalar) return launch<64, 64, AMODE, BMODE, true>(p, st);
     if constexpr (AMODE == A_CONV_GEN) return cdae_fail("A_CONV_GEN is a scalar-only loader");
     else {
-        if constexpr (AMODE != A_PLAIN_MC && BMODE == B_PLAIN_KC) {
-            if (p.prec == 1) return big ? launch<128, 128, AMODE, BMODE, false, 4, 1>(p, st) : launch<64, 64, AMODE, BMODE, false, 2, 1>(p, st);
-        }
+        if (p.prec == 1) return big ? launch<128, 128, AMODE, BMODE, false, 4, 1>(p, st) : launch<64, 64, AMODE, BMODE, false, 2, 1>(p, st);
+        if (p.prec == 2) return big ? launch<128, 128, AMODE, BMODE, false, 4, 2>(p, st) : launch<64, 64, AMODE, BMODE, false, 2, 2>(p, st);
         if (big && p.waves8) return launch<128, 128, AMODE, BMODE, false, 4>(p, st);
         return big ? launch<128, 128, AMODE, BMODE, false>(p, st) : launch<64, 64, AMODE, BMODE, false>(p, st);
     }
@@ -615,7 +672,9 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
     if (p.force_tile == 128) big = 1;
     static const int cfg_waves8 = getenv("CDAE_IGEMM_WAVES8") ? atoi(getenv("CDAE_IGEMM_WAVES8")) : 1;   // 8-wave 128x128 tiles by default
     p.waves8 = cfg_waves8;
-    if (p.prec < 0) p.prec = cdae_get_default_precision();
+    // precision: fp32 mode -> fp32 MFMA everywhere; split mode -> f16x3 for activation x weight GEMMs, bf16x3 when an
+    // operand is a gradient (api.hip marks those with grad_operand)
+    if (p.prec < 0) p.prec = cdae_get_default_precision() == CDAE_PREC_FP32 ? 0 : (p.grad_operand ? 2 : 1);
     if (p.amode == A_PLAIN_MC && p.M % 4) p.a_scalar = 1;          // vector k-major loaders read 4 rows / columns at once
     if (p.bmode != B_PLAIN_KC && p.N % 4) p.b_scalar = 1;
     const bool scalar = p.a_scalar || p.b_scalar || p.amode == A_CONV_GEN;
