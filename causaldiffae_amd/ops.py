@@ -80,12 +80,28 @@ def _sk(dev):
     return ptr(splitk_ws(dev)), SPLITK_BYTES
 
 
+def _sink(t):
+    """(grad view, ready callback) of a parameter whose gradient lives in a flat buffer (train_util.FlatParams).
+    Backward kernels then ACCUMULATE straight into that view (no temporary, no autograd add kernel) and the
+    Function returns None for the parameter."""
+    if t is None:
+        return None, None
+    return getattr(t, "_grad_view", None), getattr(t, "_grad_ready", None)
+
+
+def _done(*cbs):
+    for cb in cbs:
+        if cb is not None:
+            cb()
+
+
 # ----------------------------------------------------------------------------- conv3x3
 class _Conv3x3(Function):
     @staticmethod
     def forward(ctx, x, w, b, res, stride, up, out_nchw):
         N, Cin, H, W = x.shape
         Cout = w.shape[0]
+        w_in = w
         w = ohwi(w)
         Ho = 2 * H if up else (H - 1) // stride + 1
         Wo = 2 * W if up else (W - 1) // stride + 1
@@ -101,6 +117,7 @@ class _Conv3x3(Function):
                                    ws, wsb, stream()))
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, up, out_nchw, b is not None, res is not None)
+        ctx.sinks = (_sink(w_in), _sink(b))
         return out
 
     @staticmethod
@@ -124,10 +141,18 @@ class _Conv3x3(Function):
                 dx = new_act(N, Cin, H, W, dev)
                 check(lib.cdae_conv3x3_dgrad(ptr(dy), Cout, ptr(w), ptr(dx), Cin, N, H, W, Cin, Cout, stride, 0, 0, ws, wsb, stream()))
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)           # same OHWI storage as the parameter
-            db = torch.empty(Cout, dtype=torch.float32, device=dev) if has_b else None
+            (gw, rw), (gb, rb) = ctx.sinks
+            direct = gw is not None and w.stride() == gw.stride() and (not has_b or gb is not None)
+            if direct:
+                dw, db = gw, gb
+            else:
+                dw = torch.empty_like(w)           # same OHWI storage as the parameter
+                db = torch.empty(Cout, dtype=torch.float32, device=dev) if has_b else None
             check(lib.cdae_conv3x3_wgrad(ptr(x), x.stride(0), x.stride(2), x.stride(3), x.stride(1), ptr(dy), Cout, ptr(dw), ptr(db),
-                                         N, H, W, Cin, Cout, stride, 1 if up else 0, 0, ws, wsb, stream()))
+                                         N, H, W, Cin, Cout, stride, 1 if up else 0, 1 if direct else 0, ws, wsb, stream()))
+            if direct:
+                dw = db = None
+                _done(rw, rb)
         if has_res and ctx.needs_input_grad[3]:
             dres = dy
         return dx, dw, db, dres, None, None, None
@@ -158,6 +183,7 @@ class _Linear(Function):
             check(lib.cdae_linear_fwd(ptr(x), x.stride(0), ptr(w), K, ptr(b), ptr(res), ptr(y), Nf, M, Nf, K, alpha, act, ws, wsb, stream()))
         ctx.save_for_backward(x, w, pre)
         ctx.cfg = (act, alpha, b is not None, res is not None)
+        ctx.sinks = (_sink(w), _sink(b))
         return y
 
     @staticmethod
@@ -180,12 +206,21 @@ class _Linear(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=dev)
             check(lib.cdae_linear_dgrad(ptr(dya), Nf, ptr(w), K, ptr(dx), K, M, Nf, K, 0, ws, wsb, stream()))
+        (gw, rw), (gb, rb) = ctx.sinks
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
-            check(lib.cdae_linear_wgrad(ptr(x), x.stride(0), ptr(dya), Nf, ptr(dw), K, None, M, Nf, K, 0, ws, wsb, stream()))
+            direct = gw is not None and gw.is_contiguous()
+            dw = gw if direct else torch.empty_like(w)
+            check(lib.cdae_linear_wgrad(ptr(x), x.stride(0), ptr(dya), Nf, ptr(dw), K, None, M, Nf, K, 1 if direct else 0, ws, wsb, stream()))
+            if direct:
+                dw = None
+                _done(rw)
         if has_b and ctx.needs_input_grad[2]:
-            db = torch.empty(Nf, dtype=torch.float32, device=dev)
-            check(lib.cdae_colsum(ptr(dy), Nf, ptr(db), M, Nf, 0, stream()))
+            direct = gb is not None
+            db = gb if direct else torch.empty(Nf, dtype=torch.float32, device=dev)
+            check(lib.cdae_colsum(ptr(dy), Nf, ptr(db), M, Nf, 1 if direct else 0, stream()))
+            if direct:
+                db = None
+                _done(rb)
         if has_res and ctx.needs_input_grad[3]:
             dres = dy
         return dx, dw, db, dres, None, None
@@ -197,7 +232,13 @@ def linear(x, w, b=None, res=None, act=ACT_NONE, alpha=1.0):
     x2 = x.reshape(-1, shp[-1])
     if x2.stride(1) != 1:
         x2 = x2.contiguous()
-    w2 = w.reshape(w.shape[0], -1)
+    if w.dim() == 2:
+        w2 = w
+    else:                       # 1x1 conv weight [Cout,Cin,1(,1)]: same memory as [Cout,Cin]; carry the flat-grad sink over
+        w2 = w.reshape(w.shape[0], -1)
+        gv = getattr(w, "_grad_view", None)
+        if gv is not None:
+            w2._grad_view, w2._grad_ready = gv.reshape(w.shape[0], -1), getattr(w, "_grad_ready", None)
     r2 = None if res is None else res.reshape(-1, w.shape[0])
     y = _Linear.apply(x2, w2, b, r2, act, float(alpha))
     return y.reshape(*shp[:-1], w.shape[0])
@@ -231,6 +272,7 @@ class _GroupNorm(Function):
                                 ptr(ss), 2 * C, 1 if silu else 0, st))
         ctx.save_for_backward(x, gamma, beta, ss, stats)
         ctx.cfg = (silu, groups)
+        ctx.sinks = (_sink(gamma), _sink(beta))
         return y
 
     @staticmethod
@@ -241,12 +283,17 @@ class _GroupNorm(Function):
         dev = x.device
         dy = to_nhwc(dy)
         dx = new_act(N, C, H, W, dev)
-        dgamma = torch.empty_like(gamma)
-        dbeta = torch.empty_like(beta)
+        (gg, rg), (gb, rb) = ctx.sinks
+        direct = gg is not None and gb is not None
+        dgamma = gg if direct else torch.empty_like(gamma)
+        dbeta = gb if direct else torch.empty_like(beta)
         dss = torch.empty_like(ss) if ss is not None else None
         ws = workspace(dev, "gn", 4 * lib.cdae_gn_workspace_floats(N, C))
         check(lib.cdae_gn_bwd(ptr(x), ptr(dy), ptr(dx), N, H * W, C, C, C, C, groups, ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta),
-                              ptr(ss), 2 * C, 1 if silu else 0, ptr(dgamma), ptr(dbeta), 0, ptr(dss), 2 * C, 0, ptr(ws), stream()))
+                              ptr(ss), 2 * C, 1 if silu else 0, ptr(dgamma), ptr(dbeta), 1 if direct else 0, ptr(dss), 2 * C, 0, ptr(ws), stream()))
+        if direct:
+            dgamma = dbeta = None
+            _done(rg, rb)
         return dx, dgamma, dbeta, dss, None, None, None
 
 
@@ -356,14 +403,19 @@ class _EmbeddingAdd(Function):
         check(lib.cdae_embedding_add(ptr(out), ptr(table), ptr(idx), out.shape[0], out.shape[1], stream()))
         ctx.save_for_backward(idx)
         ctx.tshape = table.shape
+        ctx.sink = _sink(table)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         (idx,) = ctx.saved_tensors
         dout = _f32c(dout)
-        dtab = torch.zeros(ctx.tshape, dtype=torch.float32, device=dout.device)
+        gt, rt = ctx.sink
+        dtab = gt if gt is not None else torch.zeros(ctx.tshape, dtype=torch.float32, device=dout.device)
         check(lib.cdae_embedding_bwd(ptr(dout), ptr(dtab), ptr(idx), dout.shape[0], dout.shape[1], stream()))
+        if gt is not None:
+            dtab = None
+            _done(rt)
         return dout, dtab, None
 
 
@@ -460,6 +512,7 @@ class _BnLrelu(Function):
                                     eps, momentum, slope, ptr(aux[0]), ptr(aux[1]), ptr(aux[2]), ptr(aux[3]), ptr(ws), stream()))
         ctx.save_for_backward(x, gamma, beta, aux)
         ctx.cfg = (training, slope)
+        ctx.sinks = (_sink(gamma), _sink(beta))
         return y
 
     @staticmethod
@@ -472,10 +525,16 @@ class _BnLrelu(Function):
         N, C, H, W = x.shape
         dev = x.device
         dx = new_act(N, C, H, W, dev)
-        dg, db = torch.empty_like(gamma), torch.empty_like(beta)
+        (gg, rg), (gb, rb) = ctx.sinks
+        direct = gg is not None and gb is not None
+        dg = gg if direct else torch.empty_like(gamma)
+        db = gb if direct else torch.empty_like(beta)
         ws = workspace(dev, "bn", 4 * lib.cdae_bn_workspace_floats(C))
         check(lib.cdae_bn_lrelu_bwd(ptr(x), ptr(dy), ptr(dx), N * H * W, C, ptr(gamma), ptr(aux[0]), ptr(aux[1]), ptr(aux[2]), ptr(aux[3]), slope,
-                                    ptr(dg), ptr(db), 0, ptr(ws), stream()))
+                                    ptr(dg), ptr(db), 1 if direct else 0, ptr(ws), stream()))
+        if direct:
+            dg = db = None
+            _done(rg, rb)
         return dx, dg, db, None, None, None, None, None, None
 
 

@@ -39,12 +39,16 @@ class FlatParams:
             view.copy_(p.data)
             p.data = view
             p.grad = self.grad.as_strided(p.shape, p.stride(), o)
+            # backward kernels accumulate straight into this view (ops._sink): no temporaries, no autograd add kernels
+            p._grad_view = p.grad
+            p._grad_ready = None
 
     def zero_grad(self):
         self.grad.zero_()
         for p, o in zip(self.params, self.offsets):          # re-attach if someone set .grad = None
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
                 p.grad = self.grad.as_strided(p.shape, p.stride(), o)
+                p._grad_view = p.grad
 
 
 class GradBuckets:
@@ -73,7 +77,9 @@ class GradBuckets:
         if self.world > 1:
             for i, p in enumerate(flat.params):
                 if p.requires_grad:
-                    self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+                    hook = self._make_hook(i)
+                    self._hooks.append(p.register_post_accumulate_grad_hook(hook))    # gradients that arrive through autograd
+                    p._grad_ready = (lambda h=hook, q=p: h(q))                         # gradients written in place by ops._sink
         self.reset()
 
     def reset(self):
