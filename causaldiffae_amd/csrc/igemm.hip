@@ -100,7 +100,8 @@ __device__ __forceinline__ float ld1_if(const float* /*unused*/, const float* p,
 // into LDS into two f16 planes, x ~ hi + lo (hi = f16(x), lo = f16(x - hi): 22 significand bits), and every product
 // is evaluated as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation (the dropped lo*lo term
 // is 2^-22 relative).  3 MFMAs at 16x the fp32-MFMA rate = 5.3x less matrix-pipe time than v_mfma_f32_32x32x2_f32 at
-// ~fp32 accuracy; the two accumulators (hi*hi | cross terms) are summed in the epilogue.  Range: |x| < 65504 (the
+// ~fp32 accuracy, all into one fp32 accumulator (a two-stage register prefetch was tried: +30 VGPRs, one wave per
+// SIMD less, 17 % slower).  Range: |x| < 65504 (the
 // reference network is fp16-safe by construction: it ships a use_fp16 mode, unet.py:501-507).
 // PREC = 2: the same with bf16 planes ("bf16x3", 16 significand bits, full fp32 range) — used for every GEMM that
 // has a GRADIENT operand (dgrad / wgrad / attention backward): gradients underflow f16, and 2^-16 is far below what
@@ -400,7 +401,6 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
     };
 
     f32x16 acc[TM][TN];
-    f32x16 acc_lo[PREC ? TM : 1][PREC ? TN : 1];      // cross terms hi*lo + lo*hi (split precision)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -408,7 +408,6 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 acc[i][j][r] = 0.f;
-                if constexpr (PREC != 0) acc_lo[i][j][r] = 0.f;
             }
 
     if (kt_begin < kt_end) {
@@ -468,8 +467,8 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        acc_lo[i][j] = mma(al[i], bh[j], acc_lo[i][j]);
-                        acc_lo[i][j] = mma(ah[i], bl[j], acc_lo[i][j]);
+                        acc[i][j] = mma(al[i], bh[j], acc[i][j]);        // cross terms first, then hi*hi, one fp32 accumulator
+                        acc[i][j] = mma(ah[i], bl[j], acc[i][j]);
                         acc[i][j] = mma(ah[i], bh[j], acc[i][j]);
                     }
             }
@@ -528,14 +527,6 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
     }
 
     // ---------------------------------------------------------------- epilogue
-    if constexpr (PREC != 0) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] += acc_lo[i][j][r];
-    }
     // C layout of v_mfma_f32_32x32xK (dtype independent): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float* __restrict__ Cg;
     const float* __restrict__ Rg = nullptr;
