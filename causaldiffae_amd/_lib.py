@@ -131,11 +131,12 @@ def splitk_ws(device):
     return workspace(device, "splitk", SPLITK_BYTES)
 
 
-PRECISIONS = {"fp32": 0, "f16x3": 1}
+PRECISIONS = {"fp32": 0, "f16x3": 1, "mixed16": 2}
 
 
 def set_precision(name):
-    """'fp32' (v_mfma_f32_32x32x2_f32, exact fp32 chain) or 'f16x3' (split-precision f16 MFMA, ~2^-22, default)."""
+    """'fp32' (v_mfma_f32_32x32x2_f32, exact fp32 chain), 'f16x3' (split-precision f16 MFMA, ~2^-22, default) or
+    'mixed16' (single f16 / bf16 plane: the reduced-precision torso, outside the 1e-4 parity bar)."""
     check(lib.cdae_set_default_precision(PRECISIONS[name]))
 
 

@@ -103,7 +103,9 @@ __device__ __forceinline__ float ld1_if(const float* /*unused*/, const float* p,
 // ~fp32 accuracy, all into one fp32 accumulator (a two-stage register prefetch was tried: +30 VGPRs, one wave per
 // SIMD less, 17 % slower).  Range: |x| < 65504 (the
 // reference network is fp16-safe by construction: it ships a use_fp16 mode, unet.py:501-507).
-// PREC = 2: the same with bf16 planes ("bf16x3", 16 significand bits, full fp32 range) — used for every GEMM that
+// PREC = 3 / 4: ONE f16 / bf16 plane and one MFMA per product — the reduced-precision torso ("mixed16" mode, the
+// counterpart of the reference's use_fp16 torso / BASELINE's bf16 training config; not used for the fp32-parity path).
+// PREC = 2: the same as PREC 1 with bf16 planes ("bf16x3", 16 significand bits, full fp32 range) — used for every GEMM that
 // has a GRADIENT operand (dgrad / wgrad / attention backward): gradients underflow f16, and 2^-16 is far below what
 // the optimizer can see.
 // K-contiguous operands: planes of [rows][32 x 16-bit] (64-B rows, 16-B chunks XOR-swizzled by (row>>2)&3), fragments
@@ -112,6 +114,8 @@ __device__ __forceinline__ float ld1_if(const float* /*unused*/, const float* p,
 template <int BM, int BN, int AMODE, int BMODE, bool SCALAR, int WAVES_N = 2, int PREC = 0>
 __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p) {
     static_assert(PREC == 0 || !SCALAR, "split precision is only built for vectorised loaders");
+    constexpr int NPL = (PREC == 1 || PREC == 2) ? 2 : 1;       // 16-bit planes per operand
+    constexpr bool BF = (PREC == 2 || PREC == 4);               // bf16 (else f16) planes
     // 2 x WAVES_N waves; WAVES_N = 4 (512 threads, 64x32 per wave at 128x128) doubles the waves per SIMD that can
     // cover each other's barrier / LDS waits at the same LDS footprint
     constexpr int THREADS = 128 * WAVES_N, RPP = THREADS / 8;     // RPP = tile rows covered per loader pass
@@ -127,8 +131,8 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
     constexpr int PAM = BM + 32, PBM = BN + 32;                                  // k-major 16-bit plane pitch (elements)
     constexpr int A_PLANE = A_MC ? BK * PAM * 2 : BM * 64;                       // bytes per 16-bit plane
     constexpr int B_PLANE = B_MC ? BK * PBM * 2 : BN * 64;
-    constexpr int A_TILE = PREC ? A_PLANE / 2 : (A_MC ? BK * LDAM : BM * LDK);   // in floats (two planes)
-    constexpr int B_TILE = PREC ? B_PLANE / 2 : (B_MC ? BK * LDBM : BN * LDK);
+    constexpr int A_TILE = PREC ? NPL * A_PLANE / 4 : (A_MC ? BK * LDAM : BM * LDK);   // in floats
+    constexpr int B_TILE = PREC ? NPL * B_PLANE / 4 : (B_MC ? BK * LDBM : BN * LDK);
     constexpr int A_V4 = BM * BK / 4 / THREADS;     // float4 loads per thread per tile
     constexpr int B_V4 = BN * BK / 4 / THREADS;
 
@@ -330,20 +334,24 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
 
     // split a float4 into hi/lo 16-bit planes (f16 for PREC 1, bf16 for PREC 2) and store 8 B into each plane
     auto store_split = [&](char* tile, int plane_bytes, int off, const float4& v) {
-        if constexpr (PREC == 2) {
+        if constexpr (BF) {
             bf4 hi, lo;
             hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
-            lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
-            lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
             *reinterpret_cast<bf4*>(tile + off) = hi;
-            *reinterpret_cast<bf4*>(tile + plane_bytes + off) = lo;
+            if constexpr (NPL == 2) {
+                lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
+                lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
+                *reinterpret_cast<bf4*>(tile + plane_bytes + off) = lo;
+            }
         } else {
             half4 hi, lo;
             hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
-            lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);
-            lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);
             *reinterpret_cast<half4*>(tile + off) = hi;
-            *reinterpret_cast<half4*>(tile + plane_bytes + off) = lo;
+            if constexpr (NPL == 2) {
+                lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);
+                lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);
+                *reinterpret_cast<half4*>(tile + plane_bytes + off) = lo;
+            }
         }
     };
     auto kc_off = [&](int row, int c4) { return row * 64 + 16 * ((c4 >> 1) ^ ((row >> 2) & 3)) + 8 * (c4 & 1); };
@@ -447,7 +455,7 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
                 }
             };
             auto mma = [&](const u16x8& x, const u16x8& y, const f32x16& c) -> f32x16 {
-                if constexpr (PREC == 2) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, x), __builtin_bit_cast(bf8, y), c, 0, 0, 0);
+                if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, x), __builtin_bit_cast(bf8, y), c, 0, 0, 0);
                 else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, x), __builtin_bit_cast(half8, y), c, 0, 0, 0);
             };
 #pragma unroll
@@ -456,19 +464,21 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     ah[i] = frag(ac, wm * WM + i * 32, sk, std::integral_constant<bool, A_MC>{}, PAM);
-                    al[i] = frag(ac + A_PLANE, wm * WM + i * 32, sk, std::integral_constant<bool, A_MC>{}, PAM);
+                    if constexpr (NPL == 2) al[i] = frag(ac + A_PLANE, wm * WM + i * 32, sk, std::integral_constant<bool, A_MC>{}, PAM);
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     bh[j] = frag(bc, wn * WN + j * 32, sk, std::integral_constant<bool, B_MC>{}, PBM);
-                    bl[j] = frag(bc + B_PLANE, wn * WN + j * 32, sk, std::integral_constant<bool, B_MC>{}, PBM);
+                    if constexpr (NPL == 2) bl[j] = frag(bc + B_PLANE, wn * WN + j * 32, sk, std::integral_constant<bool, B_MC>{}, PBM);
                 }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        acc[i][j] = mma(al[i], bh[j], acc[i][j]);        // cross terms first, then hi*hi, one fp32 accumulator
-                        acc[i][j] = mma(ah[i], bl[j], acc[i][j]);
+                        if constexpr (NPL == 2) {
+                            acc[i][j] = mma(al[i], bh[j], acc[i][j]);        // cross terms first, then hi*hi, one fp32 accumulator
+                            acc[i][j] = mma(ah[i], bl[j], acc[i][j]);
+                        }
                         acc[i][j] = mma(ah[i], bh[j], acc[i][j]);
                     }
             }
@@ -592,8 +602,9 @@ template <int BM, int BN, int AMODE, int BMODE, bool SCALAR, int WAVES_N = 2, in
 int launch(const GemmParams& p, hipStream_t st) {
     constexpr bool A_MC = (AMODE == A_PLAIN_MC);
     constexpr bool B_MC = (BMODE != B_PLAIN_KC);
-    constexpr int A_TILE = PREC ? (A_MC ? BK * (BM + 32) : BM * 32) : (A_MC ? BK * (BM + 4) : BM * LDK);
-    constexpr int B_TILE = PREC ? (B_MC ? BK * (BN + 32) : BN * 32) : (B_MC ? BK * (BN + 4) : BN * LDK);
+    constexpr int NPL = (PREC == 1 || PREC == 2) ? 2 : 1;
+    constexpr int A_TILE = PREC ? NPL * (A_MC ? BK * (BM + 32) : BM * 32) / 2 : (A_MC ? BK * (BM + 4) : BM * LDK);
+    constexpr int B_TILE = PREC ? NPL * (B_MC ? BK * (BN + 32) : BN * 32) / 2 : (B_MC ? BK * (BN + 4) : BN * LDK);
     constexpr size_t smem = 2 * (A_TILE + B_TILE) * sizeof(float);
     static bool attr_done = false;      // per-instantiation; value is idempotent so a race is benign
     if (!attr_done) {
@@ -614,6 +625,8 @@ int launch_tiles(const GemmParams& p, int big, bool scalar, hipStream_t st) {
     else {
         if (p.prec == 1) return big ? launch<128, 128, AMODE, BMODE, false, 4, 1>(p, st) : launch<64, 64, AMODE, BMODE, false, 2, 1>(p, st);
         if (p.prec == 2) return big ? launch<128, 128, AMODE, BMODE, false, 4, 2>(p, st) : launch<64, 64, AMODE, BMODE, false, 2, 2>(p, st);
+        if (p.prec == 3) return big ? launch<128, 128, AMODE, BMODE, false, 4, 3>(p, st) : launch<64, 64, AMODE, BMODE, false, 2, 3>(p, st);
+        if (p.prec == 4) return big ? launch<128, 128, AMODE, BMODE, false, 4, 4>(p, st) : launch<64, 64, AMODE, BMODE, false, 2, 4>(p, st);
         if (big && p.waves8) return launch<128, 128, AMODE, BMODE, false, 4>(p, st);
         return big ? launch<128, 128, AMODE, BMODE, false>(p, st) : launch<64, 64, AMODE, BMODE, false>(p, st);
     }
@@ -629,7 +642,7 @@ extern "C" int cdae_get_default_precision(void) {
     return g_default_prec;
 }
 extern "C" int cdae_set_default_precision(int prec) {
-    if (prec != CDAE_PREC_FP32 && prec != CDAE_PREC_F16X3) return cdae_fail("unknown precision mode");
+    if (prec != CDAE_PREC_FP32 && prec != CDAE_PREC_F16X3 && prec != CDAE_PREC_MIXED16) return cdae_fail("unknown precision mode");
     g_default_prec = prec;
     return 0;
 }
@@ -665,7 +678,10 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
     p.waves8 = cfg_waves8;
     // precision: fp32 mode -> fp32 MFMA everywhere; split mode -> f16x3 for activation x weight GEMMs, bf16x3 when an
     // operand is a gradient (api.hip marks those with grad_operand)
-    if (p.prec < 0) p.prec = cdae_get_default_precision() == CDAE_PREC_FP32 ? 0 : (p.grad_operand ? 2 : 1);
+    if (p.prec < 0) {
+        const int mode = cdae_get_default_precision();
+        p.prec = mode == CDAE_PREC_FP32 ? 0 : mode == CDAE_PREC_MIXED16 ? (p.grad_operand ? 4 : 3) : (p.grad_operand ? 2 : 1);
+    }
     if (p.amode == A_PLAIN_MC && p.M % 4) p.a_scalar = 1;          // vector k-major loaders read 4 rows / columns at once
     if (p.bmode != B_PLAIN_KC && p.N % 4) p.b_scalar = 1;
     const bool scalar = p.a_scalar || p.b_scalar || p.amode == A_CONV_GEN;

@@ -176,8 +176,8 @@ class TrainLoop:
                  resume_checkpoint, use_fp16=False, fp16_scale_growth=1e-3, schedule_sampler=None, weight_decay=0.0,
                  lr_anneal_steps=0, rep_cond=False, n_vars=None, causal_modeling=False, flow_based=False, in_channels=3,
                  masking=False, bucket_mb=64):
-        if use_fp16:
-            raise NotImplementedError("reduced-precision training (bf16 torso) comes after fp32 parity; see DESIGN.md")
+        if use_fp16:       # reduced-precision torso; fp32 master weights are the only weights, bf16 gradients need no loss scaling
+            model.convert_to_fp16()
         self.model, self.diffusion, self.data = model, diffusion, data
         self.batch_size = batch_size
         self.microbatch = microbatch if microbatch > 0 else batch_size

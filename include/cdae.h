@@ -50,9 +50,14 @@ const char* cdae_last_error(void);
  *   CDAE_PREC_F16X3 : every fp32 operand is split into two f16 planes (hi + lo, 22 significand bits) and each product is
  *                     hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 (3 MFMAs at 16x the fp32 rate; the dropped lo*lo
  *                     term is 2^-22 relative).  Requires |operand| < 65504 (true for this network: the reference ships
- *                     an fp16 mode).  Default; also selectable with env CDAE_IGEMM_PREC=0|1 before the first call. */
+ *                     an fp16 mode).  Default; also selectable with env CDAE_IGEMM_PREC=0|1|2 before the first call.
+ *   CDAE_PREC_MIXED16 : reduced-precision torso — one f16 plane per operand (one bf16 plane when an operand is a
+ *                     gradient), fp32 accumulation; GroupNorm / softmax / embeddings / optimizer stay fp32.  The
+ *                     counterpart of the reference's use_fp16 torso (unet.py:501-507) and of BASELINE's bf16 training
+ *                     config; NOT within the 1e-4 parity bar (loss agreement ~1e-2). */
 #define CDAE_PREC_FP32 0
 #define CDAE_PREC_F16X3 1
+#define CDAE_PREC_MIXED16 2
 int cdae_set_default_precision(int prec);
 int cdae_get_default_precision(void);
 

@@ -315,3 +315,42 @@ def test_training_trajectory_golden(golden, variant, masking, precision):
                 assert probe_err(params[k], g, f"{variant}/after{step + 1}/{k}") < 1e-5, k       # 1e-5
                 assert probe_err(ema[k], g, f"{variant}/ema{step + 1}/{k}") < 1e-5, k
             assert err(model.state_dict()["rep_emb.encoder.1.1.running_var"], g[f"{variant}/after{step + 1}/bn_running_var"]) < 1e-5
+
+
+# ------------------------------------------------------------------ reduced-precision torso (BASELINE config 2 class)
+def test_mixed16_training_tracks_fp32():
+    """`mixed16` (single f16 / bf16 plane, fp32 accumulate) vs the default split-precision path on the same seeded
+    M32-shaped training steps: per-step losses agree within 2e-2 relative (SURVEY §8d parity gate for the bf16 config)."""
+    import causaldiffae_amd
+    from improved_diffusion.nn import rng_override
+    from improved_diffusion.train_util import FusedAdamWEMA
+
+    def run(mode):
+        causaldiffae_amd.set_precision(mode)
+        try:
+            model, diff, cfg = make("M32")
+            model.train()
+            opt = FusedAdamWEMA(model, lr=1e-4, ema_rates=[0.9999])
+            diff.kl_weight = 0.1
+            out = []
+            N = 8
+            for step in range(4):
+                x0 = synth(f"mx.{step}.x0", (N, 1, 32, 32), 0.0, 1.0).to(DEV)
+                c = synth(f"mx.{step}.c", (N, 2), 0.0, 1.0).to(DEV)
+                y = torch.tensor([(step + i) % 10 for i in range(N)], dtype=torch.int64, device=DEV)
+                t = torch.tensor([(97 * (step + 1) + 131 * i) % 1000 for i in range(N)], dtype=torch.int64, device=DEV)
+                noise = synth(f"mx.{step}.noise", (N, 1, 32, 32), -1.7, 1.7).to(DEV)
+                opt.zero_grad()
+                with rng_override(eps_z=synth(f"mx.{step}.eps", (N, 512), -1.7, 1.7).to(DEV)):
+                    terms = diff.training_losses(model, x0, t, model_kwargs=dict(c=c, y=y), noise=noise, rep_cond=True, causal_modeling=True)
+                terms["loss"].mean().backward()
+                opt.step()
+                out.append((terms["loss"].mean().item(), terms["mse"].mean().item()))
+            return out
+        finally:
+            causaldiffae_amd.set_precision("f16x3")
+
+    ref, low = run("f16x3"), run("mixed16")
+    for (l0, m0), (l1, m1) in zip(ref, low):
+        assert abs(l1 - l0) <= 2e-2 * abs(l0) and abs(m1 - m0) <= 2e-2 * abs(m0), (ref, low)
+    assert ref != low          # the reduced-precision path really ran
