@@ -107,6 +107,11 @@ int cdae_conv3x3_wgrad(const float* x, long sn, long sy, long sx, long sc, const
     p.conv_M = p.K; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.up = up;
     p.sn = sn; p.sy = sy; p.sx = sx; p.sc = sc;
     set_splitk(p, splitk_ws, splitk_ws_bytes);
+    if (dbias) {      // fused: the n-tile-0 blocks add dY's column sums while they stage it
+        if (!accumulate && hipMemsetAsync(dbias, 0, sizeof(float) * Cout, (hipStream_t)stream) != hipSuccess) return cdae_fail("dbias memset failed");
+        p.colsum_out = dbias;
+        return cdae_gemm_dispatch(p, stream);
+    }
     int rc = cdae_gemm_dispatch(p, stream);
     if (rc == 0 && dbias) rc = cdae_colsum(dy, lddy, dbias, (long)N * Ho * Wo, Cout, accumulate, stream);
     return rc;
@@ -145,9 +150,11 @@ int cdae_linear_wgrad(const float* x, long ldx, const float* dy, long lddy, floa
     p.a_scalar = !(lddy % 4 == 0 && aligned16(dy));
     p.b_scalar = !(ldx % 4 == 0 && aligned16(x));
     set_splitk(p, splitk_ws, splitk_ws_bytes);
-    int rc = cdae_gemm_dispatch(p, stream);
-    if (rc == 0 && dbias) rc = cdae_colsum(dy, lddy, dbias, M, N, accumulate, stream);
-    return rc;
+    if (dbias) {      // fused column sums of dy (see cdae_conv3x3_wgrad)
+        if (!accumulate && hipMemsetAsync(dbias, 0, sizeof(float) * N, (hipStream_t)stream) != hipSuccess) return cdae_fail("dbias memset failed");
+        p.colsum_out = dbias;
+    }
+    return cdae_gemm_dispatch(p, stream);
 }
 
 int cdae_qkv_attention_fwd(const float* qkv, float* out, float* probs, int B, int T, int heads, int ch, void* stream) {

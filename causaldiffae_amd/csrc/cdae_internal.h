@@ -11,6 +11,7 @@ enum { ACT_NONE = 0, ACT_SILU = 1, ACT_LRELU = 2 };
 struct GemmParams {
     const float* A; const float* B; float* C;
     const float* bias; const float* res;
+    float* colsum_out;     // A_PLAIN_MC only: += column sums of A over k (conv / linear bias gradient), [M] floats
     int M, N, K;
     long lda, ldb, ldc;
     int batch, batch_inner;

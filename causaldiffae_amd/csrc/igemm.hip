@@ -356,9 +356,20 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
     };
     auto kc_off = [&](int row, int c4) { return row * 64 + 16 * ((c4 >> 1) ^ ((row >> 2) & 3)) + 8 * (c4 & 1); };
 
+    // wgrad: the A operand is dY^T, so its column sums over the pixels (= the bias gradient, the reference gets it from
+    // autograd's conv backward) fall out of the tiles that pass through anyway: the n-tile-0 blocks add up what they stage
+    float4 colsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool do_colsum = A_MC && p.colsum_out != nullptr && nt == 0;
+
     auto store_tiles = [&](int buf) {
         float* a = As + buf * A_TILE;
         float* b = Bs + buf * B_TILE;
+        if constexpr (A_MC) {
+            if (do_colsum) {
+#pragma unroll
+                for (int q = 0; q < A_V4; ++q) { colsum.x += areg[q].x; colsum.y += areg[q].y; colsum.z += areg[q].z; colsum.w += areg[q].w; }
+            }
+        }
         if constexpr (PREC != 0) {
             char* ac = reinterpret_cast<char*>(a);
             char* bc = reinterpret_cast<char*>(b);
@@ -534,6 +545,25 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
         if (more) store_tiles(cur ^ 1);
         __syncthreads();
         cur ^= 1;
+    }
+
+    if constexpr (A_MC) {
+        if (do_colsum) {          // block-uniform
+            // threads with equal tid % (BM/4) hold partial sums of the same 4 columns (rows of the GEMM): fold through LDS
+            float4* red = reinterpret_cast<float4*>(smem);          // the tile buffers are dead after the last barrier
+            red[tid] = colsum;
+            __syncthreads();
+            if (tid < BM / 4) {
+                float4 s4 = red[tid];
+                for (int t = tid + BM / 4; t < THREADS; t += BM / 4) { float4 v = red[t]; s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w; }
+                const int i = m0 + tid * 4;
+                if (i < p.M) atomicAdd(p.colsum_out + i, s4.x);
+                if (i + 1 < p.M) atomicAdd(p.colsum_out + i + 1, s4.y);
+                if (i + 2 < p.M) atomicAdd(p.colsum_out + i + 2, s4.z);
+                if (i + 3 < p.M) atomicAdd(p.colsum_out + i + 3, s4.w);
+            }
+            __syncthreads();
+        }
     }
 
     // ---------------------------------------------------------------- epilogue

@@ -207,14 +207,18 @@ class _Linear(Function):
             dx = torch.empty((M, K), dtype=torch.float32, device=dev)
             check(lib.cdae_linear_dgrad(ptr(dya), Nf, ptr(w), K, ptr(dx), K, M, Nf, K, 0, ws, wsb, stream()))
         (gw, rw), (gb, rb) = ctx.sinks
+        want_b = has_b and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            direct = gw is not None and gw.is_contiguous()
+            direct = gw is not None and gw.is_contiguous() and (not want_b or gb is not None)
             dw = gw if direct else torch.empty_like(w)
-            check(lib.cdae_linear_wgrad(ptr(x), x.stride(0), ptr(dya), Nf, ptr(dw), K, None, M, Nf, K, 1 if direct else 0, ws, wsb, stream()))
+            if want_b:              # bias gradient = column sums of dy, fused into the wgrad kernel (alpha is 1 for layers with a bias)
+                db = gb if direct else torch.empty(Nf, dtype=torch.float32, device=dev)
+            check(lib.cdae_linear_wgrad(ptr(x), x.stride(0), ptr(dya), Nf, ptr(dw), K, ptr(db) if want_b else None, M, Nf, K,
+                                        1 if direct else 0, ws, wsb, stream()))
             if direct:
-                dw = None
-                _done(rw)
-        if has_b and ctx.needs_input_grad[2]:
+                dw = db = None
+                _done(rw, rb if want_b else None)
+        elif want_b:
             direct = gb is not None
             db = gb if direct else torch.empty(Nf, dtype=torch.float32, device=dev)
             check(lib.cdae_colsum(ptr(dy), Nf, ptr(db), M, Nf, 1 if direct else 0, stream()))
