@@ -1,0 +1,67 @@
+"""Counterfactual generation: encode -> causal layer -> do-intervention on one variable's latent slice -> q_sample to the
+last (spaced) step -> DDIM / ancestral decode.  This is the call pattern of the reference's evaluation script
+(scripts/image_causaldae_test.py:405-436 MorphoMNIST, :535-594 pendulum, :773-815 circuit; traversal :481-531), factored
+into functions; the image batch is sharded over ranks with no collective inside the loop and gathered at the end."""
+import torch as th
+
+from . import dist_util
+from .nn import reparameterize
+from .unet import ADJACENCY
+
+
+def encode_with_intervention(model, batch, A, var_index=None, value=None, var=0.001, eps=None, intervene_on="z_post"):
+    """-> z [N, rep_dim] conditioning the decoder.
+
+    mu = encoder mean of `batch`; z_pre = A^T mu; z_post = MLP(z_pre) + mu; then the slice of variable `var_index`
+    (rep_dim / n_vars wide) is overwritten with `value` — on z_post (pendulum / circuit branches of the script) or on
+    mu before the causal layer (`intervene_on="mu"`, the MorphoMNIST branch) — and z = z_post + sqrt(var) * eps."""
+    mu, _ = model.rep_emb.encode(batch)
+    nv = model.n_vars
+    d = mu.shape[1] // nv
+    A = th.as_tensor(A, dtype=th.float32)
+    if var_index is not None and intervene_on == "mu":
+        mu = mu.clone()
+        mu[:, var_index * d:(var_index + 1) * d] = value
+    z_pre = model.causal_mask.causal_masking(mu, A)
+    z_post = model.causal_mask.nonlinearity_add_back_noise(mu, z_pre)
+    if var_index is not None and intervene_on == "z_post":
+        z_post[:, var_index * d:(var_index + 1) * d] = value
+    return reparameterize(z_post, th.full_like(z_post, var), eps=eps)
+
+
+def counterfactual_sample(model, diffusion, batch, A="circuit", var_index=None, value=None, *, use_ddim=True, eta=0.0, w=None,
+                          clip_denoised=True, extra_kwargs=None, q_noise=None, z_eps=None, intervene_on="z_post",
+                          use_graph=True, shard=False, gather=False):
+    """Counterfactual images for `batch` [N,C,S,S] (values in the training range) under do(var_index := value).
+
+    Returns the decoded samples (this rank's shard unless gather=True).  `shard=True` splits the batch over the ranks of
+    the default process group (`dist_util.shard_range`); no collective runs inside the sampling loop."""
+    if isinstance(A, str):
+        A = ADJACENCY[A]
+    if shard:
+        lo, hi = dist_util.shard_range(batch.shape[0])
+        batch = batch[lo:hi]
+        q_noise = None if q_noise is None else q_noise[lo:hi]
+        z_eps = None if z_eps is None else z_eps[lo:hi]
+    dev = next(model.parameters()).device
+    batch = batch.to(dev)
+    with th.no_grad():
+        z = encode_with_intervention(model, batch, A, var_index, value, eps=z_eps, intervene_on=intervene_on)
+        t_last = th.full((batch.shape[0],), diffusion.num_timesteps - 1, dtype=th.int64, device=dev)
+        noise = th.randn_like(batch) if q_noise is None else q_noise.to(dev)
+        x_t = diffusion.q_sample(batch, t_last, noise=noise)          # the script starts from a noised input, not pure noise
+        kw = dict(extra_kwargs or {})
+        kw["z"] = z
+        if use_ddim:
+            sample = diffusion.ddim_sample_loop(model, tuple(batch.shape), noise=x_t, clip_denoised=clip_denoised, model_kwargs=kw,
+                                                eta=eta, w=w, use_graph=use_graph and eta == 0.0)
+        else:
+            sample = diffusion.p_sample_loop(model, tuple(batch.shape), noise=x_t, clip_denoised=clip_denoised, model_kwargs=kw)
+    if gather:
+        return th.cat(dist_util.gather_samples(sample), dim=0)
+    return sample
+
+
+def latent_traversal(model, diffusion, batch, A, var_index, values, **kw):
+    """One counterfactual batch per intervention value (reference traversal loop, image_causaldae_test.py:481-531)."""
+    return [counterfactual_sample(model, diffusion, batch, A, var_index, float(v), **kw) for v in values]

@@ -354,3 +354,61 @@ def test_mixed16_training_tracks_fp32():
     for (l0, m0), (l1, m1) in zip(ref, low):
         assert abs(l1 - l0) <= 2e-2 * abs(l0) and abs(m1 - m0) <= 2e-2 * abs(m0), (ref, low)
     assert ref != low          # the reduced-precision path really ran
+
+
+# ------------------------------------------------------------------ counterfactual driver == the script's explicit sequence
+def test_counterfactual_driver_golden(golden):
+    from improved_diffusion.counterfactual import counterfactual_sample, latent_traversal
+    g = golden("g8_ddim.npz")
+    model, diff, cfg = make("P64", respacing="ddim100")
+    model.eval()
+    N = 2
+    x, x0, c, z, _ = model_inputs("P64", cfg, N)
+    out = counterfactual_sample(model, diff, x0, "pendulum", 0, 0.2, z_eps=torch.from_numpy(g["cf/eps_draw"]).to(DEV),
+                                q_noise=synth("P64.qnoise", (N, 4, 64, 64), -1.7, 1.7))
+    assert err(out, g["loop/sample_after100"]) < 1e-4
+    trav = latent_traversal(model, diff, x0, "pendulum", 1, [0.0, 0.5], z_eps=torch.zeros(N, 512, device=DEV),
+                            q_noise=synth("P64.qnoise", (N, 4, 64, 64), -1.7, 1.7), use_graph=False)
+    assert len(trav) == 2 and err(trav[0], trav[1]) > 1e-3          # the intervention value changes the decode
+
+
+# ------------------------------------------------------------------ TrainLoop semantics + checkpoint format
+def test_trainloop_checkpoints(tmp_path, monkeypatch):
+    from improved_diffusion import logger, script_util as su
+    from improved_diffusion.image_datasets import load_data
+    from improved_diffusion.train_util import TrainLoop, linear_kl_weight, parse_resume_step_from_filename
+    monkeypatch.setenv("DIFFUSION_TRAINING_TEST", "1")
+    logger.configure(dir=str(tmp_path))
+    cfg = {**su.model_and_diffusion_defaults(), "rep_cond": True, "causal_modeling": True, **MODEL_CFG["T28"]}
+    np.random.seed(0)
+
+    def build():
+        model, diff = su.create_model_and_diffusion(**cfg)
+        return load_closed_form(model), diff
+
+    model, diff = build()
+    data = load_data(data_dir="synthetic", batch_size=4, image_size=28, class_cond=True, in_channels=1, n_vars=2)
+    loop = TrainLoop(model=model, diffusion=diff, data=data, batch_size=4, microbatch=2, lr=1e-4, ema_rate="0.9999", log_interval=1,
+                     save_interval=2, resume_checkpoint="", rep_cond=True, n_vars=2, causal_modeling=True, in_channels=1)
+    loop.run_loop()                       # DIFFUSION_TRAINING_TEST: returns after the first save with step > 0
+    assert loop.step == 2
+    assert diff.kl_weight == linear_kl_weight(2)          # applied after each step (reference train_util.py:210-214)
+    ck = tmp_path / "model000002.pt"
+    assert ck.exists() and (tmp_path / "model000000.pt").exists() and (tmp_path / "ema_checkpoint.pt").exists()
+    sd = torch.load(ck)
+    assert list(sd.keys()) == list(model.state_dict().keys())
+    assert all(v.is_contiguous() for v in sd.values())                        # plain reference-layout tensors on disk
+    for k, v in model.state_dict().items():
+        assert err(v, sd[k]) == 0.0, k
+    ema = torch.load(tmp_path / "ema_checkpoint.pt")
+    k0 = "input_blocks.1.0.in_layers.2.weight"
+    assert 0 < err(ema[k0], sd[k0]) < 1e-3                                     # EMA lags the weights
+    # resume: step parsed from the file name, weights + EMA restored
+    assert parse_resume_step_from_filename(str(ck)) == 2
+    model2, diff2 = build()
+    loop2 = TrainLoop(model=model2, diffusion=diff2, data=data, batch_size=4, microbatch=-1, lr=1e-4, ema_rate="0.9999", log_interval=10,
+                      save_interval=100, resume_checkpoint=str(ck), rep_cond=True, n_vars=2, causal_modeling=True, in_channels=1)
+    assert loop2.resume_step == 2
+    for k, v in model2.state_dict().items():
+        assert err(v, sd[k]) == 0.0, k
+    assert err(loop2.opt.ema_state_dict(0)[k0], ema[k0]) == 0.0
