@@ -52,6 +52,7 @@ SIGNATURES = {
     "cdae_nchw_to_nhwc": [P, P, I, I, I, P],
     "cdae_nhwc_to_nchw": [P, P, I, I, I, P],
     "cdae_sumpool2": [P, P, I, I, I, I, P],
+    "cdae_gather_u8": [P, P, P, I, L, F, F, P],
     "cdae_q_sample": [P, P, P, P, I, P, I, L, P],
     "cdae_ddim_update": [P, P, P, P, I, F, P, I, P, P, I, L, P],
     "cdae_ddpm_update": [P, P, P, P, I, P, I, P, P, I, L, P],

@@ -103,6 +103,19 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __rest
     }
 }
 
+// Batch assembly from an HBM-resident u8 image pool (HWC per image): out[b] = pool[idx[b]] / div + shift, NHWC fp32
+// (a true IEEE division: ToTensor's x/255 and the image-folder x/127.5-1 are reproduced bit for bit).
+// per4 = bytes per image / 4.  One thread expands 4 bytes to one float4; both sides are fully coalesced.
+__global__ void gather_u8_kernel(const unsigned* __restrict__ pool, const long long* __restrict__ idx, float4* __restrict__ out,
+                                 long per4, long total4, float div, float shift) {
+    GRID_STRIDE(i, total4) {
+        long b = i / per4, r = i - b * per4;
+        unsigned w = pool[idx[b] * per4 + r];
+        out[i] = make_float4((float)(w & 255u) / div + shift, (float)((w >> 8) & 255u) / div + shift,
+                             (float)((w >> 16) & 255u) / div + shift, (float)(w >> 24) / div + shift);
+    }
+}
+
 // 2x2 sum pool of an NHWC tensor [N,2H,2W,C] -> [N,H,W,C]  (dgrad of the fused nearest-2x upsample)
 __global__ void sumpool2_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int H, int W, int C) {
     GRID_STRIDE(i, (long)N * H * W * C) {
@@ -259,6 +272,10 @@ int cdae_axpby(float a, const float* x, float b, const float* y, float* out, lon
 int cdae_mul_rows(float* x, const float* m, int N, int D, void* stream) { LAUNCH1D(mul_rows_kernel, (long)N * D, x, m, N, D); }
 int cdae_copy2d(const float* src, float* dst, long rows, int cols, long lds, long ldd, int accumulate, void* stream) {
     LAUNCH1D(copy2d_kernel, rows * cols / 4 + 1, src, dst, rows, cols, lds, ldd, accumulate);
+}
+int cdae_gather_u8(const unsigned char* pool, const long long* idx, float* out, int B, long per_sample, float div, float shift, void* stream) {
+    if (per_sample % 4 != 0) return cdae_fail("cdae_gather_u8: bytes per image must be a multiple of 4");
+    LAUNCH1D(gather_u8_kernel, (long)B * (per_sample / 4), (const unsigned*)pool, idx, (float4*)out, per_sample / 4, (long)B * (per_sample / 4), div, shift);
 }
 int cdae_nchw_to_nhwc(const float* src, float* dst, int N, int C, int HW, void* stream) { LAUNCH1D(nchw_to_nhwc_kernel, (long)N * C * HW, src, dst, N, C, HW); }
 int cdae_nhwc_to_nchw(const float* src, float* dst, int N, int C, int HW, void* stream) { LAUNCH1D(nhwc_to_nchw_kernel, (long)N * C * HW, src, dst, N, C, HW); }

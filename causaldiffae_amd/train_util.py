@@ -248,7 +248,7 @@ class TrainLoop:
             if isinstance(self.schedule_sampler, LossAwareSampler):
                 self.schedule_sampler.update_with_local_losses(t, losses["loss"].detach())
             loss = (losses["loss"] * weights).mean()
-            self.last_losses = {k: v.detach() for k, v in losses.items()}
+            self.last_losses, self.last_t, self.last_w = {k: v.detach() for k, v in losses.items()}, t, weights
             # microbatches contribute mean losses of their own slice; scale like the reference (no extra scaling)
             loss.backward()
         self.buckets.finish()
@@ -266,8 +266,7 @@ class TrainLoop:
         logger.logkv("step", self.step + self.resume_step)
         logger.logkv("samples", (self.step + self.resume_step + 1) * self.global_batch)
         if self.step % self.log_interval == 0 and self.last_losses is not None:      # one host sync per log interval
-            for k, v in self.last_losses.items():
-                logger.logkv_mean(k, v.float().mean().item())
+            log_loss_dict(self.diffusion, self.last_t, {k: v * self.last_w for k, v in self.last_losses.items()})
             logger.logkv_mean("grad_norm", float(np.sqrt(self.opt.grad_sqsum())))
 
     # ------------------------------------------------------------------ checkpoints (names of train_util.py:319-345)
@@ -302,3 +301,16 @@ def get_blob_logdir():
 
 def find_resume_checkpoint():
     return None
+
+
+def log_loss_dict(diffusion, ts, losses):
+    """Mean of every loss term plus its mean per timestep quartile (`<key>_q0..3`), the keys of train_util.py:401-407.
+    Called once per log interval here (the reference calls it — and syncs the device — on every microbatch)."""
+    ts = ts.detach().cpu().numpy().reshape(-1)
+    for key, values in losses.items():
+        v = values.detach().float().cpu().numpy()
+        logger.logkv_mean(key, float(v.mean()))
+        if v.ndim == 0 or v.shape[0] != ts.shape[0]:      # scalar term (masked kld_rep): no per-sample split
+            continue
+        for sub_t, sub_loss in zip(ts, v.reshape(ts.shape[0], -1).mean(axis=1)):
+            logger.logkv_mean(f"{key}_q{int(4 * sub_t / diffusion.num_timesteps)}", float(sub_loss))

@@ -140,6 +140,9 @@ int cdae_mul_rows(float* x, const float* m, int N, int D, void* stream);        
 int cdae_copy2d(const float* src, float* dst, long rows, int cols, long lds, long ldd, int accumulate, void* stream);  /* th.cat unet.py:628 */
 int cdae_nchw_to_nhwc(const float* src, float* dst, int N, int C, int HW, void* stream);
 int cdae_nhwc_to_nchw(const float* src, float* dst, int N, int C, int HW, void* stream);
+/* batch assembly from an HBM-resident u8 HWC image pool: out[b,:] = pool[idx[b],:] / div + shift (NHWC fp32, IEEE division).  Replaces the
+   reference's host DataLoader + ToTensor/`/255` per item (image_datasets.py:266-297, 352-372, 451-467); per_sample % 4 == 0 */
+int cdae_gather_u8(const unsigned char* pool, const long long* idx, float* out, int B, long per_sample, float div, float shift, void* stream);
 int cdae_sumpool2(const float* src, float* dst, int N, int H, int W, int C, void* stream);
 /* q_sample (gaussian_diffusion.py:201-222) */
 int cdae_q_sample(const float* x0, const float* noise, const long long* t, const float* tab, int T, float* out, int N, long per_sample, void* stream);

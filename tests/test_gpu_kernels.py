@@ -233,3 +233,25 @@ def test_timestep_embedding_and_small_ops():
     a, b = ops.to_nhwc(rnd(2, 128, 4, 4).to(DEV)), ops.to_nhwc(rnd(2, 384, 4, 4, seed=1).to(DEV))
     assert err(ops.cat_channels(a, b), torch.cat([a.cpu(), b.cpu()], 1)) == 0.0
     assert err(ops.to_nchw(a), a.cpu()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,div,shift", [((37, 28, 28, 1), 255.0, 0.0), ((19, 96, 96, 4), 255.0, 0.0), ((11, 64, 64, 3), 127.5, -1.0)])
+def test_device_feed_matches_host_feed(shape, div, shift):
+    """HBM-resident pool + cdae_gather_u8 == the host feed (u8/div+shift, bit-exact), incl. labels and the epoch order."""
+    from causaldiffae_amd import image_datasets as ds
+    rng = np.random.RandomState(7)
+    imgs = rng.randint(0, 256, size=shape).astype(np.uint8)
+    imgs[0] = np.arange(np.prod(shape[1:]), dtype=np.int64).reshape(shape[1:]) % 256        # every byte value
+    pool = ds.Pool(imgs, {"c": rng.rand(shape[0], 4).astype(np.float32), "y": rng.randint(0, 10, size=shape[0]).astype(np.int64)},
+                   div=div, shift=shift)
+    host, devf = ds.Feed(pool, 8, shuffle=True, seed=3), ds.Feed(pool, 8, shuffle=True, seed=3, device="cuda:0")
+    for _ in range(5):
+        xh, ch = next(host)
+        xd, cd = next(devf)
+        assert xd.is_cuda and xd.shape == xh.shape
+        assert torch.equal(xd.cpu(), xh)
+        for k in ch:
+            assert torch.equal(cd[k].cpu(), ch[k])
+    from causaldiffae_amd import ops
+    assert ops.is_nhwc(xd) or shape[3] == 1

@@ -412,3 +412,35 @@ def test_trainloop_checkpoints(tmp_path, monkeypatch):
     for k, v in model2.state_dict().items():
         assert err(v, sd[k]) == 0.0, k
     assert err(loop2.opt.ema_state_dict(0)[k0], ema[k0]) == 0.0
+
+
+@pytest.mark.gpu
+def test_image_train_script_on_morphomnist_files(tmp_path):
+    """scripts/image_train.py end to end: MorphoMNIST-format files -> HBM-resident pool -> TrainLoop -> reference-named
+    checkpoints + progress.csv with the reference's keys."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__)))
+    from test_datasets_cpu import _make_morpho
+    root = str(tmp_path / "morphomnist")
+    _make_morpho(root, n_train=40, n_test=8)
+    logdir = str(tmp_path / "logs")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(repo, "scripts", "image_train.py"), "--data_dir", root, "--image_size", "28", "--in_channels", "1",
+           "--n_vars", "2", "--class_cond", "True", "--rep_cond", "True", "--causal_modeling", "True", "--num_channels", "32",
+           "--num_res_blocks", "1", "--batch_size", "8", "--microbatch", "4", "--log_interval", "2", "--save_interval", "3",
+           "--lr_anneal_steps", "5", "--log_dir", logdir]
+    env = dict(os.environ, MASTER_PORT="29533")
+    env.pop("RANK", None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    files = sorted(os.listdir(logdir))
+    assert "model000003.pt" in files and "ema_checkpoint.pt" in files and "progress.csv" in files and "log.txt" in files, files
+    rows = open(os.path.join(logdir, "progress.csv")).read().splitlines()
+    head = rows[0].split(",")
+    for k in ("step", "samples", "loss", "mse", "kld_rep", "grad_norm"):
+        assert k in head, head
+    assert any(k.startswith("loss_q") for k in head)
+    assert len(rows) >= 3
+    loss = [float(r.split(",")[head.index("loss")]) for r in rows[1:] if r.split(",")[head.index("loss")]]
+    assert all(np.isfinite(loss))
