@@ -62,6 +62,9 @@ SIGNATURES = {
     "cdae_causal_mask": [P, P, P, I, I, I, I, P],
     "cdae_adamw_ema": [P, P, P, P, P, L, D, D, D, D, D, I, D, D, P],
     "cdae_sqsum": [P, L, P, P],
+    "cdae_p_mean_variance": [P, P, P, P, I, I, I, I, P, P, P, P, P, P, I, L, P],
+    "cdae_vb_terms": [P, P, P, P, P, I, I, I, I, P, P, I, L, P],
+    "cdae_vb_terms_bwd": [P, P, P, P, P, I, I, I, I, I, P, P, I, L, P],
     "cdae_mse_rows": [P, P, P, I, L, P],
     "cdae_mse_rows_bwd": [P, P, P, P, I, L, P],
     "cdae_prof_enable": [I],
@@ -69,7 +72,7 @@ SIGNATURES = {
 }
 _RESTYPES = {"cdae_last_error": ctypes.c_char_p, "cdae_gn_workspace_floats": SZ, "cdae_bn_workspace_floats": SZ}
 
-TAB_ROWS = 10
+TAB_ROWS = 12
 PROF_FAMILIES = ("igemm", "groupnorm", "softmax", "elementwise", "optimizer")
 
 

@@ -143,8 +143,8 @@ __global__ void ddim_update_kernel(const float* __restrict__ x, const float* __r
         float c1 = tab[CDAE_TAB_SQRT_RECIP_AC * T + tt], c2 = tab[CDAE_TAB_SQRT_RECIPM1_AC * T + tt];
         float ab = tab[CDAE_TAB_AC * T + tt], abp = tab[CDAE_TAB_AC_PREV * T + tt];
         float xv = x[i];
-        float x0 = c1 * xv - c2 * eps[i];
-        if (clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+        float x0 = (clip & 2) ? eps[i] : c1 * xv - c2 * eps[i];       // bit 1: `eps` already holds the processed pred_xstart
+        if (clip & 1) x0 = fminf(fmaxf(x0, -1.f), 1.f);
         float e2 = (c1 * xv - x0) / c2;
         float sigma = eta * sqrtf((1.f - abp) / (1.f - ab)) * sqrtf(1.f - ab / abp);
         float mean = x0 * sqrtf(abp) + sqrtf(1.f - abp - sigma * sigma) * e2;
@@ -225,6 +225,124 @@ __global__ void sqsum_kernel(const float* __restrict__ x, long n, double* __rest
     if (threadIdx.x == 0) atomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
+
+// ---- learned-variance / variational-bound branches (gaussian_diffusion.py:289-303, 682-715; losses.py) -------------------
+// mean_type: 0 = model predicts eps, 1 = model predicts x0.  var_type: 0 = fixed (table rows 8/9), 1 = LEARNED (output is the
+// log-variance), 2 = LEARNED_RANGE (output in [-1,1] interpolates log beta_t .. clipped posterior log-variance).
+struct PmvCoef { float c1, c2, k1, k2, lv_fixed, v_fixed, min_log, max_log; };
+__device__ inline PmvCoef pmv_coef(const float* __restrict__ tab, int T, long long tt) {
+    PmvCoef c;
+    c.c1 = tab[CDAE_TAB_SQRT_RECIP_AC * T + tt]; c.c2 = tab[CDAE_TAB_SQRT_RECIPM1_AC * T + tt];
+    c.k1 = tab[CDAE_TAB_POST_COEF1 * T + tt];    c.k2 = tab[CDAE_TAB_POST_COEF2 * T + tt];
+    c.lv_fixed = tab[CDAE_TAB_MODEL_LOGVAR * T + tt]; c.v_fixed = tab[CDAE_TAB_MODEL_VAR * T + tt];
+    c.min_log = tab[CDAE_TAB_POST_LOGVAR_CLIPPED * T + tt]; c.max_log = tab[CDAE_TAB_LOG_BETAS * T + tt];
+    return c;
+}
+// returns: x0 (processed), mean, lv; `inside` = 1 when the clamp passed the value through (gradient gate)
+__device__ inline void pmv_elem(float xv, float mo, float mv, const PmvCoef& c, int mean_type, int var_type, int clip,
+                                float& x0, float& mean, float& lv, float& inside) {
+    if (var_type == 1) lv = mv;
+    else if (var_type == 2) { float frac = (mv + 1.f) / 2.f; lv = frac * c.max_log + (1.f - frac) * c.min_log; }
+    else lv = c.lv_fixed;
+    x0 = mean_type == 1 ? mo : c.c1 * xv - c.c2 * mo;
+    inside = 1.f;
+    if (clip) { inside = (x0 >= -1.f && x0 <= 1.f) ? 1.f : 0.f; x0 = fminf(fmaxf(x0, -1.f), 1.f); }
+    mean = c.k1 * x0 + c.k2 * xv;
+}
+
+// p_mean_variance (+ optional ancestral sample).  out2: model output, per sample `ostride` floats: [mean part | var part].
+__global__ void pmv_kernel(const float* __restrict__ x, const float* __restrict__ out2, long ostride, const long long* __restrict__ t,
+                           const float* __restrict__ tab, int T, int mean_type, int var_type, int clip, const float* __restrict__ noise,
+                           float* __restrict__ mean_o, float* __restrict__ var_o, float* __restrict__ lv_o, float* __restrict__ x0_o,
+                           float* __restrict__ sample_o, long per, long total) {
+    GRID_STRIDE(i, total) {
+        long n = i / per, e = i - n * per;
+        long long tt = t[n];
+        PmvCoef c = pmv_coef(tab, T, tt);
+        float mo = out2[n * ostride + e], mv = var_type ? out2[n * ostride + per + e] : 0.f;
+        float x0, mean, lv, inside;
+        pmv_elem(x[i], mo, mv, c, mean_type, var_type, clip, x0, mean, lv, inside);
+        if (mean_o) mean_o[i] = mean;
+        if (var_o) var_o[i] = var_type ? expf(lv) : c.v_fixed;
+        if (lv_o) lv_o[i] = lv;
+        if (x0_o) x0_o[i] = x0;
+        if (sample_o) sample_o[i] = mean + (tt != 0 ? 1.f : 0.f) * expf(0.5f * lv) * noise[i];
+    }
+}
+
+#define CDF_K 0.7978845608028654f          /* sqrt(2/pi) */
+__device__ inline float approx_cdf(float v) { return 0.5f * (1.f + tanhf(CDF_K * (v + 0.044715f * (v * v * v)))); }
+// d/dv of approx_cdf
+__device__ inline float approx_pdf(float v) {
+    float th = tanhf(CDF_K * (v + 0.044715f * (v * v * v)));
+    return 0.5f * (1.f - th * th) * CDF_K * (1.f + 3.f * 0.044715f * v * v);
+}
+
+// one element of the bound: KL(q(x_{t-1}|x_t,x_0) || p) for t > 0, -log p(x_0 | x_1) (discretised Gaussian) at t == 0, in nats;
+// optionally its derivatives with respect to the model mean and log-variance.
+__device__ inline float vb_elem(float x0v, float xv, float mean, float lv, const PmvCoef& c, bool first, bool want_grad, float& dmean, float& dlv) {
+    if (!first) {
+        float m1 = c.k1 * x0v + c.k2 * xv, lv1 = c.min_log;
+        float d = m1 - mean, e1 = expf(lv1 - lv), e2 = expf(-lv);
+        if (want_grad) { dmean = -d * e2; dlv = 0.5f * (1.f - e1 - d * d * e2); }
+        return 0.5f * (-1.f + lv - lv1 + e1 + d * d * e2);
+    }
+    float cen = x0v - mean, inv = expf(-(0.5f * lv));
+    float pin = inv * (cen + 1.f / 255.f), nin = inv * (cen - 1.f / 255.f);
+    float cp = approx_cdf(pin), cm = approx_cdf(nin);
+    float lp, dp = 0.f, dn = 0.f;             // d lp / d pin, d lp / d nin
+    if (x0v < -0.999f)      { lp = logf(fmaxf(cp, 1e-12f));        if (want_grad && cp >= 1e-12f) dp = approx_pdf(pin) / cp; }
+    else if (x0v > 0.999f)  { float q = 1.f - cm; lp = logf(fmaxf(q, 1e-12f)); if (want_grad && q >= 1e-12f) dn = -approx_pdf(nin) / q; }
+    else { float dl = cp - cm; lp = logf(fmaxf(dl, 1e-12f)); if (want_grad && dl >= 1e-12f) { dp = approx_pdf(pin) / dl; dn = -approx_pdf(nin) / dl; } }
+    if (want_grad) {                         // nll = -lp; d pin/d mean = d nin/d mean = -inv; d pin/d lv = -pin/2, d nin/d lv = -nin/2
+        dmean = (dp + dn) * inv;
+        dlv = 0.5f * (dp * pin + dn * nin);
+    }
+    return -lp;
+}
+
+// vb[n] = mean over the sample of vb_elem / ln 2 (bits per dim).  One block per sample; also writes pred_xstart if asked.
+__global__ void vb_terms_kernel(const float* __restrict__ x0, const float* __restrict__ x, const float* __restrict__ out2, long ostride,
+                                const long long* __restrict__ t, const float* __restrict__ tab, int T, int mean_type, int var_type, int clip,
+                                float* __restrict__ vb, float* __restrict__ x0_o, long per) {
+    const long n = blockIdx.x;
+    long long tt = t[n];
+    PmvCoef c = pmv_coef(tab, T, tt);
+    float s = 0.f;
+    for (long e = threadIdx.x; e < per; e += blockDim.x) {
+        float mo = out2[n * ostride + e], mv = var_type ? out2[n * ostride + per + e] : 0.f;
+        float p0, mean, lv, inside, dm, dl;
+        pmv_elem(x[n * per + e], mo, mv, c, mean_type, var_type, clip, p0, mean, lv, inside);
+        s += vb_elem(x0[n * per + e], x[n * per + e], mean, lv, c, tt == 0, false, dm, dl);
+        if (x0_o) x0_o[n * per + e] = p0;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    __shared__ float sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) vb[n] = (((sh[0] + sh[1]) + (sh[2] + sh[3])) / (float)per) / 0.6931471805599453f;
+}
+
+// d vb / d model output (both halves; the mean half is zero-filled when the mean is frozen, gaussian_diffusion.py:822-825)
+__global__ void vb_terms_bwd_kernel(const float* __restrict__ x0, const float* __restrict__ x, const float* __restrict__ out2, long ostride,
+                                    const long long* __restrict__ t, const float* __restrict__ tab, int T, int mean_type, int var_type, int clip,
+                                    int freeze_mean, const float* __restrict__ gout, float* __restrict__ dout2, long per, long total) {
+    GRID_STRIDE(i, total) {
+        long n = i / per, e = i - n * per;
+        long long tt = t[n];
+        PmvCoef c = pmv_coef(tab, T, tt);
+        float mo = out2[n * ostride + e], mv = var_type ? out2[n * ostride + per + e] : 0.f;
+        float p0, mean, lv, inside, dm, dl;
+        pmv_elem(x[i], mo, mv, c, mean_type, var_type, clip, p0, mean, lv, inside);
+        vb_elem(x0[i], x[i], mean, lv, c, tt == 0, true, dm, dl);
+        float g = gout[n] / ((float)per * 0.6931471805599453f);
+        float dmo = 0.f;
+        if (!freeze_mean) dmo = g * dm * c.k1 * inside * (mean_type == 1 ? 1.f : -c.c2);
+        dout2[n * ostride + e] = dmo;
+        if (var_type) dout2[n * ostride + per + e] = g * dl * (var_type == 2 ? 0.5f * (c.max_log - c.min_log) : 1.f);
+    }
+}
+
 // per-sample mean of (a-b)^2 over `per` elements: one block per sample
 __global__ void mse_rows_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long per) {
     const long n = blockIdx.x;
@@ -292,6 +410,34 @@ int cdae_ddpm_update(const float* x, const float* eps, const long long* t, const
                      float* sample, float* pred_xstart, int N, long per_sample, void* stream) {
     if (!noise) return cdae_fail("ddpm_update needs a noise tensor");
     LAUNCH1D(ddpm_update_kernel, N * per_sample, x, eps, t, tab, T, noise, clip, sample, pred_xstart, per_sample, N * per_sample);
+}
+
+int cdae_p_mean_variance(const float* x, const float* model_out, const long long* t, const float* tab, int T, int mean_type, int var_type,
+                         int clip, const float* noise, float* mean, float* variance, float* log_variance, float* pred_xstart, float* sample,
+                         int N, long per_sample, void* stream) {
+    if (mean_type < 0 || mean_type > 1 || var_type < 0 || var_type > 2) return cdae_fail("p_mean_variance: bad mean/var type");
+    if (sample && !noise) return cdae_fail("p_mean_variance: sample requested without noise");
+    long ostride = var_type ? 2 * per_sample : per_sample;
+    LAUNCH1D(pmv_kernel, N * per_sample, x, model_out, ostride, t, tab, T, mean_type, var_type, clip, noise, mean, variance, log_variance,
+             pred_xstart, sample, per_sample, N * per_sample);
+}
+int cdae_vb_terms(const float* x_start, const float* x_t, const float* model_out, const long long* t, const float* tab, int T, int mean_type,
+                  int var_type, int clip, float* vb, float* pred_xstart, int N, long per_sample, void* stream) {
+    if (mean_type < 0 || mean_type > 1 || var_type < 0 || var_type > 2) return cdae_fail("vb_terms: bad mean/var type");
+    long ostride = var_type ? 2 * per_sample : per_sample;
+    cdae_prof_begin(PROF_ELEMWISE, 0.0, ST);
+    hipLaunchKernelGGL(vb_terms_kernel, dim3(N), dim3(256), 0, ST, x_start, x_t, model_out, ostride, t, tab, T, mean_type, var_type, clip, vb,
+                       pred_xstart, per_sample);
+    cdae_prof_end(PROF_ELEMWISE, ST);
+    if (hipGetLastError() != hipSuccess) return cdae_fail("vb_terms launch failed");
+    return 0;
+}
+int cdae_vb_terms_bwd(const float* x_start, const float* x_t, const float* model_out, const long long* t, const float* tab, int T, int mean_type,
+                      int var_type, int clip, int freeze_mean, const float* gout, float* dmodel_out, int N, long per_sample, void* stream) {
+    if (mean_type < 0 || mean_type > 1 || var_type < 0 || var_type > 2) return cdae_fail("vb_terms_bwd: bad mean/var type");
+    long ostride = var_type ? 2 * per_sample : per_sample;
+    LAUNCH1D(vb_terms_bwd_kernel, N * per_sample, x_start, x_t, model_out, ostride, t, tab, T, mean_type, var_type, clip, freeze_mean, gout,
+             dmodel_out, per_sample, N * per_sample);
 }
 
 int cdae_softplus_fwd(const float* x, float* y, long n, float add, void* stream) { LAUNCH1D(softplus_eps_kernel, n, x, y, n, add); }

@@ -61,7 +61,7 @@ class LossType(enum.Enum):
 
 _TAB_ORDER = ("sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod",
               "sqrt_recipm1_alphas_cumprod", "alphas_cumprod", "alphas_cumprod_prev", "posterior_mean_coef1",
-              "posterior_mean_coef2", "_model_log_variance", "_model_variance")
+              "posterior_mean_coef2", "_model_log_variance", "_model_variance", "posterior_log_variance_clipped", "_log_betas")
 assert len(_TAB_ORDER) == TAB_ROWS
 
 
@@ -94,9 +94,15 @@ class GaussianDiffusion:
         if model_var_type == ModelVarType.FIXED_SMALL:
             self._model_variance = self.posterior_variance
             self._model_log_variance = self.posterior_log_variance_clipped
-        else:   # FIXED_LARGE (reference gaussian_diffusion.py:305-311); learned variances are outside the hot path
+        else:   # FIXED_LARGE (reference gaussian_diffusion.py:305-311); rows unused when the variance is learned
             self._model_variance = np.append(self.posterior_variance[1], betas[1:])
             self._model_log_variance = np.log(self._model_variance)
+        self._log_betas = np.log(betas)
+        if model_mean_type == ModelMeanType.PREVIOUS_X:
+            raise NotImplementedError("ModelMeanType.PREVIOUS_X cannot be built by create_gaussian_diffusion (script_util.py:309-317)")
+        self._mean_code = 1 if model_mean_type == ModelMeanType.START_X else 0
+        self._var_code = {ModelVarType.LEARNED: 1, ModelVarType.LEARNED_RANGE: 2}.get(model_var_type, 0)
+        self._hot = self._mean_code == 0 and self._var_code == 0        # eps-prediction, fixed variance: the fused hot path
         self.causal_modeling = causal_modeling
         self.kl_weight = 0.0
         self._dev = {}
@@ -177,26 +183,38 @@ class GaussianDiffusion:
         check(lib.cdae_axpby(float(w), ptr(eps), float(1 - w), ptr(eps_u), ptr(out), eps.numel(), stream()))
         return out
 
-    def _check_eps_path(self):
-        if self.model_mean_type != ModelMeanType.EPSILON or self.model_var_type not in (ModelVarType.FIXED_LARGE, ModelVarType.FIXED_SMALL):
-            raise NotImplementedError("only the epsilon-prediction / fixed-variance branch is on the CausalDiffAE hot path "
-                                      "(learn_sigma / predict_xstart: SURVEY §8f.3)")
+    def _pmv_launch(self, x, model_out, t, clip, noise=None, want=("mean", "variance", "log_variance", "pred_xstart")):
+        """cdae_p_mean_variance over a raw model output [N, C or 2C, ...]; returns the requested tensors (+ "sample" with noise)."""
+        x, model_out = x.float().contiguous(), model_out.float().contiguous()
+        N = x.shape[0]
+        per = x.numel() // N
+        assert model_out.shape == (N, x.shape[1] * (2 if self._var_code else 1), *x.shape[2:])
+        bufs = {k: th.empty_like(x) for k in want}
+        if noise is not None:
+            noise = noise.float().contiguous()
+            bufs["sample"] = th.empty_like(x)
+        check(lib.cdae_p_mean_variance(ptr(x), ptr(model_out), ptr(t.to(th.int64).contiguous()), ptr(self._tab(x.device)), self.num_timesteps,
+                                       self._mean_code, self._var_code, 1 if clip else 0, ptr(noise), ptr(bufs.get("mean")),
+                                       ptr(bufs.get("variance")), ptr(bufs.get("log_variance")), ptr(bufs.get("pred_xstart")),
+                                       ptr(bufs.get("sample")), N, per, stream()))
+        return bufs
 
     def p_mean_variance(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None, w=None):
-        """Reference gaussian_diffusion.py:248-353 (epsilon / fixed-variance branch); API-completeness path, the
-        sampler loops below use the fused update kernels instead."""
-        self._check_eps_path()
+        """Reference gaussian_diffusion.py:248-353 for every parameterisation the factory builds (eps | x0 mean; fixed small/large |
+        LEARNED | LEARNED_RANGE variance): the network, then ONE kernel for the four outputs.  The sampler loops of the
+        eps / fixed-variance configuration use the fused update kernels instead."""
         B = x.shape[0]
         assert t.shape == (B,)
-        eps = self._model_eps(model, x, t, model_kwargs, w)
-        pred = self._predict_xstart_from_eps(x, t, eps)
-        if denoised_fn is not None:
-            pred = denoised_fn(pred)
+        model_out = self._model_eps(model, x, t, model_kwargs, w)
+        if denoised_fn is None:
+            return self._pmv_launch(x, model_out, t, clip_denoised)
+        out = self._pmv_launch(x, model_out, t, False, want=("variance", "log_variance", "pred_xstart"))
+        pred = denoised_fn(out["pred_xstart"])
         if clip_denoised:
             pred = pred.clamp(-1, 1)
-        mean, _, _ = self.q_posterior_mean_variance(x_start=pred, x_t=x, t=t)
-        return {"mean": mean, "variance": self._extract(self._model_variance, t, x.shape),
-                "log_variance": self._extract(self._model_log_variance, t, x.shape), "pred_xstart": pred}
+        out["pred_xstart"] = pred
+        out["mean"], _, _ = self.q_posterior_mean_variance(x_start=pred, x_t=x, t=t)
+        return out
 
     def _predict_xstart_from_eps(self, x_t, t, eps):
         return (self._extract(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t
@@ -206,24 +224,24 @@ class GaussianDiffusion:
         return (self._extract(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t - pred_xstart) \
             / self._extract(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape)
 
-    def _fused_update(self, ddim, x, eps, t, clip, eta, noise, sample_out=None, pred_out=None):
+    def _fused_update(self, ddim, x, eps, t, clip, eta, noise, sample_out=None, pred_out=None, eps_is_xstart=False):
         x, eps = x.float().contiguous(), eps.float().contiguous()
         N = x.shape[0]
+        clip = (1 if clip else 0) | (2 if eps_is_xstart else 0)
         sample = th.empty_like(x) if sample_out is None else sample_out
         pred = th.empty_like(x) if pred_out is None else pred_out
         tab = self._tab(x.device)
         t = t.to(th.int64).contiguous()
         if ddim:
             check(lib.cdae_ddim_update(ptr(x), ptr(eps), ptr(t), ptr(tab), self.num_timesteps, float(eta), ptr(noise),
-                                       1 if clip else 0, ptr(sample), ptr(pred), N, x.numel() // N, stream()))
+                                       clip, ptr(sample), ptr(pred), N, x.numel() // N, stream()))
         else:
-            check(lib.cdae_ddpm_update(ptr(x), ptr(eps), ptr(t), ptr(tab), self.num_timesteps, ptr(noise), 1 if clip else 0,
+            check(lib.cdae_ddpm_update(ptr(x), ptr(eps), ptr(t), ptr(tab), self.num_timesteps, ptr(noise), clip & 1,
                                        ptr(sample), ptr(pred), N, x.numel() // N, stream()))
         return {"sample": sample, "pred_xstart": pred}
 
     def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None, noise=None):
         """x_{t-1} ~ p(.|x_t) (reference :383-414).  `noise` may be injected (tests); default: drawn on the device."""
-        self._check_eps_path()
         if denoised_fn is not None:
             out = self.p_mean_variance(model, x, t, clip_denoised, denoised_fn, model_kwargs)
             nz = th.randn_like(x) if noise is None else noise
@@ -231,22 +249,31 @@ class GaussianDiffusion:
             return {"sample": out["mean"] + mask * th.exp(0.5 * out["log_variance"]) * nz, "pred_xstart": out["pred_xstart"]}
         eps = self._model_eps(model, x, t, model_kwargs)
         nz = th.randn_like(x) if noise is None else noise.float().contiguous()
+        if not self._hot:           # learned variance / x0-prediction: generic kernel with the ancestral draw fused in
+            out = self._pmv_launch(x, eps, t, clip_denoised, noise=nz, want=("pred_xstart",))
+            return {"sample": out["sample"], "pred_xstart": out["pred_xstart"]}
         return self._fused_update(False, x, eps, t, clip_denoised, 0.0, nz)
 
     def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None, eta=0.0, w=None, noise=None):
         """One DDIM step (reference :506-558) = network + ONE fused update kernel.  At eta == 0 the reference still
         draws randn_like(x) and multiplies it by sigma = 0; the draw is skipped here."""
-        self._check_eps_path()
-        if denoised_fn is not None:
-            raise NotImplementedError("denoised_fn is not used by any CausalDiffAE script")
-        eps = self._model_eps(model, x, t, model_kwargs, w)
         nz = None
         if eta != 0.0:
             nz = th.randn_like(x) if noise is None else noise.float().contiguous()
+        if denoised_fn is not None or not self._hot:
+            pred = self.p_mean_variance(model, x, t, clip_denoised, denoised_fn, model_kwargs, w)["pred_xstart"]
+            return self._fused_update(True, x, pred, t, False, eta, nz, eps_is_xstart=True)
+        eps = self._model_eps(model, x, t, model_kwargs, w)
         return self._fused_update(True, x, eps, t, clip_denoised, eta, nz)
 
-    def ddim_reverse_sample(self, *a, **k):
-        raise NotImplementedError("ddim_reverse_sample is only reachable from image_nll.py (SURVEY §2: out of scope)")
+    def ddim_reverse_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None, eta=0.0):
+        """x_{t+1} from the deterministic reverse ODE (reference :560-596); evaluation-only utility, plain device ops."""
+        assert eta == 0.0, "Reverse ODE only for deterministic path"
+        out = self.p_mean_variance(model, x, t, clip_denoised, denoised_fn, model_kwargs)
+        eps = (self._extract(self.sqrt_recip_alphas_cumprod, t, x.shape) * x - out["pred_xstart"]) \
+            / self._extract(self.sqrt_recipm1_alphas_cumprod, t, x.shape)
+        ab_next = self._extract(self.alphas_cumprod_next, t, x.shape)
+        return {"sample": out["pred_xstart"] * th.sqrt(ab_next) + th.sqrt(1 - ab_next) * eps, "pred_xstart": out["pred_xstart"]}
 
     # ------------------------------------------------------------------ loops
     def _loop(self, ddim, model, shape, noise, clip_denoised, denoised_fn, model_kwargs, device, progress, eta, w,
@@ -262,7 +289,7 @@ class GaussianDiffusion:
             from tqdm.auto import tqdm
             order = tqdm(order)
         runner = None
-        if use_graph and denoised_fn is None and step_noise is None and (ddim and eta == 0.0):
+        if use_graph and self._hot and denoised_fn is None and step_noise is None and (ddim and eta == 0.0):
             runner = _GraphStep(self, model, img, model_kwargs, clip_denoised, w)
         for k in order:
             t = steps[k]
@@ -329,32 +356,81 @@ class GaussianDiffusion:
         return kld
 
     def training_losses(self, model, x_start, t, model_kwargs=None, noise=None, rep_cond=False, causal_modeling=False):
-        """MSE(eps) [+ kl_weight * representation KL] (reference gaussian_diffusion.py:768-859, MSE branch)."""
-        if self.loss_type not in (LossType.MSE, LossType.RESCALED_MSE):
-            raise NotImplementedError("VLB losses are outside the CausalDiffAE hot path (SURVEY §8f.3)")
-        self._check_eps_path()
+        """Reference gaussian_diffusion.py:768-859.  MSE / RESCALED_MSE: mse(target, mean half) [+ kl_weight * representation KL];
+        with a learned variance the bound on [mean.detach() | variance half] is added instead (x T/1000 when rescaled) and, as in
+        the reference (:849-850), the representation KL is then reported but not added.  KL / RESCALED_KL: the bound alone.
+        Q8: the reference's frozen-output lambda returns one tensor where p_mean_variance unpacks five, so its own learn_sigma
+        training crashes; the bound here receives the raw output directly (upstream improved-diffusion's semantics)."""
         if model_kwargs is None:
             model_kwargs = {}
         if noise is None:
             noise = th.randn_like(x_start)
         x_t = self.q_sample(x_start, t, noise=noise)
         terms = {}
+        if self.loss_type in (LossType.KL, LossType.RESCALED_KL):
+            terms["loss"] = self._vb_terms_bpd(model=model, x_start=x_start, x_t=x_t, t=t, clip_denoised=False,
+                                               model_kwargs=model_kwargs)["output"]
+            if self.loss_type == LossType.RESCALED_KL:
+                terms["loss"] = terms["loss"] * self.num_timesteps
+            return terms
+        if self.loss_type not in (LossType.MSE, LossType.RESCALED_MSE):
+            raise NotImplementedError(self.loss_type)
         if rep_cond:
             model_kwargs["x_start"] = x_start
             model_output, mu, var, z_post, mask = model(x_t, self._scale_timesteps(t), **model_kwargs)
             terms["kld_rep"] = self.representation_loss(mu, var, z_post, causal_modeling, mask, model_kwargs["c"])
         else:
             model_output = model(x_t, self._scale_timesteps(t), **model_kwargs)[0]
-        assert model_output.shape == noise.shape == x_start.shape
-        terms["mse"] = ops.mse_rows(noise, model_output)
-        terms["loss"] = terms["mse"] + self.kl_weight * terms["kld_rep"] if rep_cond else terms["mse"]
+        if self._var_code:
+            B, C = x_t.shape[:2]
+            assert model_output.shape == (B, C * 2, *x_t.shape[2:])
+            vb, _ = ops.vb_terms(model_output, x_start, x_t, t, self._tab(x_t.device), self.num_timesteps, self._mean_code,
+                                 self._var_code, False, True)
+            terms["vb"] = vb * (self.num_timesteps / 1000.0) if self.loss_type == LossType.RESCALED_MSE else vb
+            model_output = model_output[:, :C]
+        target = x_start if self._mean_code else noise
+        assert model_output.shape == target.shape == x_start.shape
+        terms["mse"] = ops.mse_rows(target, model_output)
+        if "vb" in terms:
+            terms["loss"] = terms["mse"] + terms["vb"]
+        else:
+            terms["loss"] = terms["mse"] + self.kl_weight * terms["kld_rep"] if rep_cond else terms["mse"]
         return terms
 
-    def _vb_terms_bpd(self, *a, **k):
-        raise NotImplementedError("VLB terms: SURVEY §2 out of scope (image_nll.py / learn_sigma only)")
+    def _vb_terms_bpd(self, model, x_start, x_t, t, clip_denoised=True, model_kwargs=None):
+        """One term of the bound per sample in bits/dim: KL(q(x_{t-1}|x_t,x_0) || p) for t > 0, the discretised-Gaussian decoder
+        NLL at t == 0 (reference :682-715): the network, then one kernel (differentiable with respect to the raw output)."""
+        model_out = model(x_t, self._scale_timesteps(t), **(model_kwargs or {}))
+        if isinstance(model_out, (tuple, list)):
+            model_out = model_out[0]
+        vb, pred = ops.vb_terms(model_out, x_start, x_t, t, self._tab(x_t.device), self.num_timesteps, self._mean_code, self._var_code,
+                                bool(clip_denoised), False)
+        return {"output": vb, "pred_xstart": pred}
 
-    def calc_bpd_loop(self, *a, **k):
-        raise NotImplementedError("bpd evaluation: SURVEY §2 out of scope (image_nll.py only)")
+    def _prior_bpd(self, x_start):
+        """KL(q(x_T | x_0) || N(0, I)) in bits/dim (reference :862-880); once per evaluation, plain device ops."""
+        from .losses import normal_kl
+        t = th.full((x_start.shape[0],), self.num_timesteps - 1, dtype=th.int64, device=x_start.device)
+        qt_mean, _, qt_log_variance = self.q_mean_variance(x_start, t)
+        return mean_flat(normal_kl(qt_mean, qt_log_variance, 0.0, 0.0)) / np.log(2.0)
+
+    def calc_bpd_loop(self, model, x_start, clip_denoised=True, model_kwargs=None, noise=None):
+        """The whole bound, term by term from t = T-1 down to 0 (reference :882-931).  `noise` [T, N, ...] replays the per-step
+        q_sample draws (tests); default: drawn on the device."""
+        vb, xstart_mse, mse = [], [], []
+        steps = self._step_table(x_start.device, x_start.shape[0])
+        for k in range(self.num_timesteps):
+            t_batch = steps[k]
+            nz = th.randn_like(x_start) if noise is None else noise[k]
+            x_t = self.q_sample(x_start=x_start, t=t_batch, noise=nz)
+            with th.no_grad():
+                out = self._vb_terms_bpd(model, x_start=x_start, x_t=x_t, t=t_batch, clip_denoised=clip_denoised, model_kwargs=model_kwargs)
+            vb.append(out["output"])
+            xstart_mse.append(ops.mse_rows(x_start, out["pred_xstart"]))
+            mse.append(ops.mse_rows(nz, self._predict_eps_from_xstart(x_t, t_batch, out["pred_xstart"])))
+        vb, xstart_mse, mse = th.stack(vb, dim=1), th.stack(xstart_mse, dim=1), th.stack(mse, dim=1)
+        prior_bpd = self._prior_bpd(x_start)
+        return {"total_bpd": vb.sum(dim=1) + prior_bpd, "prior_bpd": prior_bpd, "vb": vb, "xstart_mse": xstart_mse, "mse": mse}
 
 
 class _GraphStep:

@@ -571,3 +571,38 @@ class _MseRows(Function):
 
 def mse_rows(target, pred):
     return _MseRows.apply(target, pred)
+
+
+class _VbTerms(Function):
+    """One variational-bound term per sample in bits/dim (gaussian_diffusion.py:682-715) with its gradient with respect to the
+    raw model output [N, C or 2C, H, W]; `freeze_mean` zeroes the mean half's gradient (the hybrid loss, :822-825)."""
+
+    @staticmethod
+    def forward(ctx, model_out, x_start, x_t, t, tab, T, mean_type, var_type, clip, freeze_mean):
+        model_out, x_start, x_t = _f32c(model_out), _f32c(x_start), _f32c(x_t)
+        t = t.to(torch.int64).contiguous()
+        N = x_t.shape[0]
+        per = x_t.numel() // N
+        assert model_out.numel() == N * per * (2 if var_type else 1), "model output does not match the variance parameterisation"
+        vb = torch.empty(N, dtype=torch.float32, device=x_t.device)
+        pred = torch.empty_like(x_t)
+        check(lib.cdae_vb_terms(ptr(x_start), ptr(x_t), ptr(model_out), ptr(t), ptr(tab), T, mean_type, var_type, 1 if clip else 0,
+                                ptr(vb), ptr(pred), N, per, stream()))
+        ctx.save_for_backward(model_out, x_start, x_t, t, tab)
+        ctx.cfg = (T, mean_type, var_type, clip, freeze_mean)
+        ctx.mark_non_differentiable(pred)
+        return vb, pred
+
+    @staticmethod
+    def backward(ctx, g, _gpred):
+        model_out, x_start, x_t, t, tab = ctx.saved_tensors
+        T, mean_type, var_type, clip, freeze_mean = ctx.cfg
+        N = x_t.shape[0]
+        d = torch.empty_like(model_out)
+        check(lib.cdae_vb_terms_bwd(ptr(x_start), ptr(x_t), ptr(model_out), ptr(t), ptr(tab), T, mean_type, var_type, 1 if clip else 0,
+                                    1 if freeze_mean else 0, ptr(_f32c(g)), ptr(d), N, x_t.numel() // N, stream()))
+        return d, None, None, None, None, None, None, None, None, None
+
+
+def vb_terms(model_out, x_start, x_t, t, tab, T, mean_type, var_type, clip, freeze_mean):
+    return _VbTerms.apply(model_out, x_start, x_t, t, tab, T, mean_type, var_type, clip, freeze_mean)

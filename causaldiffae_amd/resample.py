@@ -1,4 +1,5 @@
-"""Timestep samplers (reference improved_diffusion/resample.py).  Only the uniform sampler is on the hot path."""
+"""Timestep samplers (reference improved_diffusion/resample.py).  The uniform sampler is the one on the hot path; the
+loss-second-moment importance sampler (resample.py:71-154) is host-side bookkeeping over a [T, history] table."""
 from abc import ABC, abstractmethod
 
 import numpy as np
@@ -9,7 +10,7 @@ def create_named_schedule_sampler(name, diffusion):
     if name == "uniform":
         return UniformSampler(diffusion)
     if name == "loss-second-moment":
-        raise NotImplementedError("loss-second-moment resampling is out of scope (reference resample.py:134 uses removed np.int)")
+        return LossSecondMomentResampler(diffusion)
     raise NotImplementedError(f"unknown schedule sampler: {name}")
 
 
@@ -38,7 +39,48 @@ class UniformSampler(ScheduleSampler):
 
 
 class LossAwareSampler(ScheduleSampler):
-    """Kept as a type so `isinstance(sampler, LossAwareSampler)` in callers keeps working."""
-
     def update_with_local_losses(self, local_ts, local_losses):
-        raise NotImplementedError
+        """Every rank contributes its (timesteps, losses); all ranks then apply the same update in rank order so the
+        reweighting stays identical everywhere (resample.py:72-103, done with one object all-gather instead of three padded
+        tensor all-gathers)."""
+        import torch.distributed as dist
+        mine = (local_ts.detach().cpu().tolist(), local_losses.detach().cpu().tolist())
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            parts = [None] * dist.get_world_size()
+            dist.all_gather_object(parts, mine)
+        else:
+            parts = [mine]
+        self.update_with_all_losses([t for p in parts for t in p[0]], [l for p in parts for l in p[1]])
+
+    @abstractmethod
+    def update_with_all_losses(self, ts, losses):
+        """Deterministic update from the gathered (timestep, loss) pairs; called with identical arguments on every rank."""
+
+
+class LossSecondMomentResampler(LossAwareSampler):
+    """p(t) proportional to sqrt(E[loss_t^2]) over the last `history_per_term` losses seen at t, mixed with a uniform floor;
+    uniform until every timestep has a full history (resample.py:127-154).  The history is a ring per timestep — the
+    second moment does not depend on the order the reference keeps by shifting.  (The reference's constructor uses
+    `np.int`, removed in numpy >= 1.24, so it cannot be instantiated in this image: parity is by definition.)"""
+
+    def __init__(self, diffusion, history_per_term=10, uniform_prob=0.001):
+        self.diffusion, self.history_per_term, self.uniform_prob = diffusion, history_per_term, uniform_prob
+        self._loss_history = np.zeros([diffusion.num_timesteps, history_per_term], dtype=np.float64)
+        self._loss_counts = np.zeros([diffusion.num_timesteps], dtype=np.int64)       # total losses ever seen per step
+
+    def weights(self):
+        if not self._warmed_up():
+            return np.ones([self.diffusion.num_timesteps], dtype=np.float64)
+        w = np.sqrt(np.mean(self._loss_history ** 2, axis=-1))
+        w /= np.sum(w)
+        w *= 1 - self.uniform_prob
+        w += self.uniform_prob / len(w)
+        return w
+
+    def update_with_all_losses(self, ts, losses):
+        for t, loss in zip(ts, losses):
+            self._loss_history[t, self._loss_counts[t] % self.history_per_term] = loss
+            self._loss_counts[t] += 1
+
+    def _warmed_up(self):
+        return bool((self._loss_counts >= self.history_per_term).all())

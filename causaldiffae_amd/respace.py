@@ -64,6 +64,9 @@ class SpacedDiffusion(GaussianDiffusion):
     def training_losses(self, model, *args, **kwargs):
         return super().training_losses(self._wrap_model(model), *args, **kwargs)
 
+    def _vb_terms_bpd(self, model, *args, **kwargs):           # reached through p_mean_variance in the reference (respace.py:90-93)
+        return super()._vb_terms_bpd(self._wrap_model(model), *args, **kwargs)
+
     def _wrap_model(self, model):
         if isinstance(model, _WrappedModel):
             return model

@@ -38,7 +38,9 @@ enum {
     CDAE_TAB_POST_COEF2 = 7,       /* posterior_mean_coef2 */
     CDAE_TAB_MODEL_LOGVAR = 8,     /* model log-variance (FIXED_LARGE / FIXED_SMALL), gaussian_diffusion.py:305-318 */
     CDAE_TAB_MODEL_VAR = 9,
-    CDAE_TAB_ROWS = 10
+    CDAE_TAB_POST_LOGVAR_CLIPPED = 10, /* posterior_log_variance_clipped (LEARNED_RANGE lower end; true log-variance of the bound) */
+    CDAE_TAB_LOG_BETAS = 11,           /* log(betas) (LEARNED_RANGE upper end) */
+    CDAE_TAB_ROWS = 12
 };
 
 int cdae_version(void);
@@ -146,12 +148,27 @@ int cdae_gather_u8(const unsigned char* pool, const long long* idx, float* out, 
 int cdae_sumpool2(const float* src, float* dst, int N, int H, int W, int C, void* stream);
 /* q_sample (gaussian_diffusion.py:201-222) */
 int cdae_q_sample(const float* x0, const float* noise, const long long* t, const float* tab, int T, float* out, int N, long per_sample, void* stream);
-/* one fused DDIM update (p_mean_variance eps branch + ddim_sample, gaussian_diffusion.py:336-338,533-558); noise may be NULL iff eta==0 */
+/* one fused DDIM update (p_mean_variance eps branch + ddim_sample, gaussian_diffusion.py:336-338,533-558); noise may be NULL iff eta==0.
+   clip: bit 0 = clamp pred_xstart to [-1,1]; bit 1 = `eps` already holds the processed pred_xstart (learned-variance / x0-prediction callers) */
 int cdae_ddim_update(const float* x, const float* eps, const long long* t, const float* tab, int T, float eta, const float* noise, int clip,
                      float* sample, float* pred_xstart, int N, long per_sample, void* stream);
 /* one fused ancestral update (p_sample, gaussian_diffusion.py:383-414) */
 int cdae_ddpm_update(const float* x, const float* eps, const long long* t, const float* tab, int T, const float* noise, int clip,
                      float* sample, float* pred_xstart, int N, long per_sample, void* stream);
+/* p_mean_variance for every (mean, variance) parameterisation the factory can build (gaussian_diffusion.py:248-353):
+   mean_type 0 = eps-prediction, 1 = x0-prediction; var_type 0 = fixed (table), 1 = LEARNED, 2 = LEARNED_RANGE.  model_out is NCHW
+   [N, C or 2C, H, W] (per sample: mean part then variance part).  Any output may be NULL; `sample` (needs `noise`) is the fused
+   ancestral draw mean + (t != 0) exp(lv / 2) noise (gaussian_diffusion.py:383-414). */
+int cdae_p_mean_variance(const float* x, const float* model_out, const long long* t, const float* tab, int T, int mean_type, int var_type,
+                         int clip, const float* noise, float* mean, float* variance, float* log_variance, float* pred_xstart, float* sample,
+                         int N, long per_sample, void* stream);
+/* one term of the variational bound per sample, in bits/dim (_vb_terms_bpd, gaussian_diffusion.py:682-715; normal_kl and
+   discretized_gaussian_log_likelihood, losses.py:12-77), and its gradient with respect to model_out (freeze_mean: the mean half
+   gets zeros, gaussian_diffusion.py:822-825). */
+int cdae_vb_terms(const float* x_start, const float* x_t, const float* model_out, const long long* t, const float* tab, int T, int mean_type,
+                  int var_type, int clip, float* vb, float* pred_xstart, int N, long per_sample, void* stream);
+int cdae_vb_terms_bwd(const float* x_start, const float* x_t, const float* model_out, const long long* t, const float* tab, int T, int mean_type,
+                      int var_type, int clip, int freeze_mean, const float* gout, float* dmodel_out, int N, long per_sample, void* stream);
 int cdae_softplus_fwd(const float* x, float* y, long n, float add, void* stream);                             /* nn.py:108 */
 int cdae_softplus_bwd(const float* x, const float* dy, float* dx, long n, void* stream);
 int cdae_reparam(const float* m, const float* v, float vscale, const float* eps, float* z, long n, void* stream);   /* nn.py:460-467 */

@@ -14,6 +14,10 @@ Reference lines restated:
   prior / representation_loss          gaussian_diffusion.py:718-766, nn.py:440-457
   training_losses (MSE branch)         gaussian_diffusion.py:768-859
   TrainLoop optimizer step             train_util.py:176-187,210-214,292-311; nn.py:503-513
+  learned-sigma p_mean_variance        gaussian_diffusion.py:289-303
+  _vb_terms_bpd / _prior_bpd / calc_bpd_loop   gaussian_diffusion.py:682-715, 862-931
+  normal_kl / discretized Gaussian LL  losses.py:12-77
+  hybrid + bound-only training losses  gaussian_diffusion.py:792-837 (frozen-mean lambda fixed to a 5-tuple, see DESIGN Q8)
 """
 import numpy as np
 import torch
@@ -129,6 +133,111 @@ def training_losses(sch, model_full, x0, t, noise, c=None, rep_cond=False, causa
     terms["mse"] = ((noise - eps) ** 2).mean(dim=list(range(1, x0.dim())))
     terms["loss"] = terms["mse"] + kl_weight * terms["kld_rep"] if rep_cond else terms["mse"]
     return terms
+
+
+# --------------------------------------------------------------------------- learned sigma / variational bound
+def normal_kl(mean1, logvar1, mean2, logvar2):
+    """losses.py:12-39."""
+    logvar1, logvar2 = [v if isinstance(v, torch.Tensor) else torch.tensor(float(v)) for v in (logvar1, logvar2)]
+    return 0.5 * (-1.0 + logvar2 - logvar1 + torch.exp(logvar1 - logvar2) + ((mean1 - mean2) ** 2) * torch.exp(-logvar2))
+
+
+def approx_standard_normal_cdf(x):
+    """losses.py:42-47."""
+    return 0.5 * (1.0 + torch.tanh(np.sqrt(2.0 / np.pi) * (x + 0.044715 * torch.pow(x, 3))))
+
+
+def discretized_gaussian_log_likelihood(x, means, log_scales):
+    """losses.py:50-77."""
+    cen = x - means
+    inv = torch.exp(-log_scales)
+    cdf_plus = approx_standard_normal_cdf(inv * (cen + 1.0 / 255.0))
+    cdf_min = approx_standard_normal_cdf(inv * (cen - 1.0 / 255.0))
+    log_cdf_plus = torch.log(cdf_plus.clamp(min=1e-12))
+    log_one_minus = torch.log((1.0 - cdf_min).clamp(min=1e-12))
+    delta = cdf_plus - cdf_min
+    return torch.where(x < -0.999, log_cdf_plus, torch.where(x > 0.999, log_one_minus, torch.log(delta.clamp(min=1e-12))))
+
+
+def p_mean_variance_general(sch, model_out, x, t, mean_type="eps", var_type="fixed_large", clip=True):
+    """gaussian_diffusion.py:289-353.  mean_type: "eps" | "xstart"; var_type: "fixed_large" | "fixed_small" | "learned" |
+    "learned_range".  model_out is [N, C or 2C, ...]."""
+    nd = x.dim()
+    C = x.shape[1]
+    if var_type in ("learned", "learned_range"):
+        model_out, vals = torch.split(model_out, C, dim=1)
+        if var_type == "learned":
+            logvar = vals
+        else:
+            min_log = sch.ext("posterior_log_variance_clipped", t, nd)
+            max_log = torch.from_numpy(np.log(sch.tab["betas"]))[t].float().reshape(-1, *([1] * (nd - 1)))
+            frac = (vals + 1) / 2
+            logvar = frac * max_log + (1 - frac) * min_log
+        var = torch.exp(logvar)
+    elif var_type == "fixed_large":
+        var, logvar = sch.ext("fixed_large_variance", t, nd).expand_as(x), sch.ext("fixed_large_log_variance", t, nd).expand_as(x)
+    else:
+        var, logvar = sch.ext("posterior_variance", t, nd).expand_as(x), sch.ext("posterior_log_variance_clipped", t, nd).expand_as(x)
+    if mean_type == "xstart":
+        x0 = model_out
+    else:
+        x0 = sch.ext("sqrt_recip_alphas_cumprod", t, nd) * x - sch.ext("sqrt_recipm1_alphas_cumprod", t, nd) * model_out
+    if clip:
+        x0 = x0.clamp(-1, 1)
+    mean = sch.ext("posterior_mean_coef1", t, nd) * x0 + sch.ext("posterior_mean_coef2", t, nd) * x
+    return dict(mean=mean, variance=var, log_variance=logvar, pred_xstart=x0)
+
+
+def vb_terms_bpd(sch, model_out, x0, x_t, t, mean_type="eps", var_type="fixed_large", clip=True):
+    """gaussian_diffusion.py:682-715."""
+    nd = x0.dim()
+    true_mean = sch.ext("posterior_mean_coef1", t, nd) * x0 + sch.ext("posterior_mean_coef2", t, nd) * x_t
+    true_lv = sch.ext("posterior_log_variance_clipped", t, nd)
+    out = p_mean_variance_general(sch, model_out, x_t, t, mean_type, var_type, clip)
+    dims = list(range(1, nd))
+    kl = normal_kl(true_mean, true_lv, out["mean"], out["log_variance"]).mean(dim=dims) / np.log(2.0)
+    nll = (-discretized_gaussian_log_likelihood(x0, out["mean"], 0.5 * out["log_variance"])).mean(dim=dims) / np.log(2.0)
+    return dict(output=torch.where(t == 0, nll, kl), pred_xstart=out["pred_xstart"])
+
+
+def prior_bpd(sch, x0):
+    """gaussian_diffusion.py:862-880."""
+    t = torch.full((x0.shape[0],), sch.T - 1, dtype=torch.int64)
+    mean = sch.ext("sqrt_alphas_cumprod", t, x0.dim()) * x0
+    lv = sch.ext("log_one_minus_alphas_cumprod", t, x0.dim())
+    return normal_kl(mean, lv, 0.0, 0.0).mean(dim=list(range(1, x0.dim()))) / np.log(2.0)
+
+
+def calc_bpd_loop(sch, model_fn, x0, noises, mean_type="eps", var_type="fixed_large", clip=True):
+    """gaussian_diffusion.py:882-931; model_fn(x, t_model) -> raw model output; noises[k] is the draw of loop iteration k."""
+    nd = x0.dim()
+    dims = list(range(1, nd))
+    vb, xs_mse, mse = [], [], []
+    for k, i in enumerate(list(range(sch.T))[::-1]):
+        t = torch.full((x0.shape[0],), i, dtype=torch.int64)
+        x_t = q_sample(sch, x0, t, noises[k])
+        with torch.no_grad():
+            out = vb_terms_bpd(sch, model_fn(x_t, sch.model_t(t)), x0, x_t, t, mean_type, var_type, clip)
+        vb.append(out["output"])
+        xs_mse.append(((out["pred_xstart"] - x0) ** 2).mean(dim=dims))
+        eps = (sch.ext("sqrt_recip_alphas_cumprod", t, nd) * x_t - out["pred_xstart"]) / sch.ext("sqrt_recipm1_alphas_cumprod", t, nd)
+        mse.append(((eps - noises[k]) ** 2).mean(dim=dims))
+    vb, xs_mse, mse = torch.stack(vb, 1), torch.stack(xs_mse, 1), torch.stack(mse, 1)
+    pb = prior_bpd(sch, x0)
+    return dict(total_bpd=vb.sum(1) + pb, prior_bpd=pb, vb=vb, xstart_mse=xs_mse, mse=mse)
+
+
+def hybrid_losses(sch, model_out, x0, x_t, t, noise, var_type="learned_range", rescaled=True):
+    """gaussian_diffusion.py:813-850 for learned variances: mse on the eps half + the bound on [eps.detach() | var half]
+    (x T/1000 for RESCALED_MSE)."""
+    C = x0.shape[1]
+    eps_out, var_out = torch.split(model_out, C, dim=1)
+    frozen = torch.cat([eps_out.detach(), var_out], dim=1)
+    vb = vb_terms_bpd(sch, frozen, x0, x_t, t, "eps", var_type, clip=False)["output"]
+    if rescaled:
+        vb = vb * (sch.T / 1000.0)
+    mse = ((noise - eps_out) ** 2).mean(dim=list(range(1, x0.dim())))
+    return dict(mse=mse, vb=vb, loss=mse + vb)
 
 
 def kl_weight_at(step, total=50000):

@@ -43,10 +43,10 @@ MODEL_CFG = {
 }
 
 
-def make(tag, respacing="", masking=False):
+def make(tag, respacing="", masking=False, **extra):
     from improved_diffusion import script_util as su
     cfg = {**su.model_and_diffusion_defaults(), "rep_cond": True, "causal_modeling": True, **MODEL_CFG[tag],
-           "timestep_respacing": respacing, "masking": masking}
+           "timestep_respacing": respacing, "masking": masking, **extra}
     model, diff = su.create_model_and_diffusion(**cfg)
     return load_closed_form(model), diff, cfg
 
@@ -444,3 +444,120 @@ def test_image_train_script_on_morphomnist_files(tmp_path):
     assert len(rows) >= 3
     loss = [float(r.split(",")[head.index("loss")]) for r in rows[1:] if r.split(",")[head.index("loss")]]
     assert all(np.isfinite(loss))
+
+
+# ------------------------------------------------------------------ G9: learned sigma / variational bound
+G9_VARIANTS = {"range": dict(learn_sigma=True), "fixed": dict(), "xstart": dict(learn_sigma=True, predict_xstart=True),
+               "small": dict(sigma_small=True)}
+
+
+def g9_inputs():
+    N = 4
+    x0 = torch.round(synth("G9.x0", (N, 1, 28, 28), 0.0, 255.0)) / 127.5 - 1.0
+    noise = synth("G9.noise", (N, 1, 28, 28), -1.7, 1.7)
+    c = synth("G9.c", (N, 2), 0.0, 1.0)
+    y = torch.tensor([1, 3, 5, 7], dtype=torch.int64)
+    z = synth("G9.z", (N, 512), -1.0, 1.0)
+    return N, x0.to(DEV), noise.to(DEV), c.to(DEV), y.to(DEV), z.to(DEV)
+
+
+def rel_err(a, ref):
+    ref = np.asarray(ref)
+    return err(a, ref) / max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", list(G9_VARIANTS))
+def test_learned_sigma_and_bound_golden(golden, tag, precision):
+    """p_mean_variance / _vb_terms_bpd / p_sample / ddim_sample / _prior_bpd for every (mean, variance) parameterisation the
+    factory builds, against the reference's outputs (gaussian_diffusion.py:248-353, 383-414, 506-558, 682-715, 862-880)."""
+    g = golden("g9_vlb.npz")
+    N, x0, noise, c, y, z = g9_inputs()
+    t = torch.from_numpy(g["t"]).to(DEV)
+    model, diff, cfg = make("T28", **G9_VARIANTS[tag])
+    model.eval()
+    kw = dict(c=c, y=y, z=z)
+    x_t = diff.q_sample(x0, t, noise=noise)
+    with torch.no_grad():
+        raw = model(x_t, diff._scale_timesteps(t), **kw)[0]
+        raw_err = err(raw, g[f"{tag}/vb_grad/raw"])
+        assert raw_err < 1e-4
+        # end to end through the network: x0 = (x_t - sqrt(1-abar) eps)/sqrt(abar) amplifies the network's rounding by up to
+        # sqrt(1/abar_999 - 1) = 157, so the bound here is 1e-4 + 200 x the raw-output error; the kernels themselves are
+        # checked at 1e-5 below on the reference's own raw output.
+        loose = 1e-4 + 200 * raw_err
+        pm = diff.p_mean_variance(model, x_t, t, clip_denoised=True, model_kwargs=kw)
+        for k in ("mean", "variance", "log_variance", "pred_xstart"):
+            assert rel_err(pm[k], g[f"{tag}/pmv_clip1/{k}"]) < loose, k
+        fixed = lambda *a, **k: (torch.from_numpy(g[f"{tag}/vb_grad/raw"]).to(DEV), None, None, None, None)     # noqa: E731
+        for clip in (True, False):
+            pm = diff.p_mean_variance(fixed, x_t, t, clip_denoised=clip, model_kwargs=kw)
+            for k in ("mean", "variance", "log_variance", "pred_xstart"):
+                assert rel_err(pm[k], g[f"{tag}/pmv_clip{int(clip)}/{k}"]) < 1e-5, (clip, k)
+            vb = diff._vb_terms_bpd(fixed, x0, x_t, t, clip_denoised=clip, model_kwargs=kw)
+            assert rel_err(vb["output"], g[f"{tag}/vb_clip{int(clip)}/output"]) < 1e-5, clip
+            assert rel_err(vb["pred_xstart"], g[f"{tag}/vb_clip{int(clip)}/pred_xstart"]) < 1e-5, clip
+        ps = diff.p_sample(fixed, x_t, t, model_kwargs=kw, noise=torch.from_numpy(g[f"{tag}/p_sample/noise"]).to(DEV))
+        assert rel_err(ps["sample"], g[f"{tag}/p_sample/sample"]) < 1e-5
+        dd = diff.ddim_sample(fixed, x_t, t, model_kwargs=kw, eta=0.0)
+        assert rel_err(dd["sample"], g[f"{tag}/ddim/sample"]) < 1e-5 and rel_err(dd["pred_xstart"], g[f"{tag}/ddim/pred_xstart"]) < 1e-5
+        assert rel_err(diff._prior_bpd(x0), g[f"{tag}/prior_bpd"]) < 1e-5
+    # kernel-only check on the reference's own raw output, incl. the gradient with respect to it
+    raw = torch.from_numpy(g[f"{tag}/vb_grad/raw"]).to(DEV).requires_grad_(True)
+    out = diff._vb_terms_bpd(lambda *a, **k: (raw, None, None, None, None), x0, x_t, t, clip_denoised=False)["output"]
+    assert rel_err(out, g[f"{tag}/vb_clip0/output"]) < 1e-5
+    (out * torch.arange(1, N + 1, dtype=torch.float32, device=DEV)).sum().backward()
+    ref = g[f"{tag}/vb_grad/draw"]
+    assert err(raw.grad, ref) < 1e-4 * float(np.abs(ref).max()) + 1e-9
+
+
+@pytest.mark.gpu
+def test_hybrid_loss_golden(golden, precision):
+    """learn_sigma training: mse + bound on [eps.detach() | var half] x T/1000 (gaussian_diffusion.py:813-850; DESIGN Q8)."""
+    from improved_diffusion.nn import rng_override
+    g = golden("g9_vlb.npz")
+    N, x0, noise, c, y, z = g9_inputs()
+    t = torch.from_numpy(g["t"]).to(DEV)
+    model, diff, cfg = make("T28", learn_sigma=True)
+    model.train()
+    with rng_override(eps_z=torch.from_numpy(g["hybrid/eps_draw"]).to(DEV)):
+        terms = diff.training_losses(model, x0, t, model_kwargs=dict(c=c, y=y), noise=noise, rep_cond=True, causal_modeling=True)
+    assert set(terms) == {"kld_rep", "vb", "mse", "loss"}
+    terms["loss"].mean().backward()
+    for k in ("mse", "vb", "loss", "kld_rep"):
+        assert rel_err(terms[k], g[f"hybrid/{k}"]) < 1e-4, k
+    params = dict(model.named_parameters())
+    sq = sum((p.grad.double() ** 2).sum().item() for p in params.values() if p.grad is not None)
+    assert abs(sq - float(g["hybrid/grad_sqsum"])) <= 2e-3 * sq
+    for k in ("out.2.weight", "out.2.bias", "input_blocks.1.0.in_layers.2.weight", "time_embed.0.weight"):
+        assert probe_err(params[k].grad, g, f"hybrid/grad/{k}") < 1e-3, k
+
+
+@pytest.mark.gpu
+def test_bound_only_loss_golden(golden, precision):
+    """use_kl=True -> RESCALED_KL: loss = T * bound term, gradient through mean (gaussian_diffusion.py:792-802)."""
+    g = golden("g9_vlb.npz")
+    N, x0, noise, c, y, z = g9_inputs()
+    t = torch.from_numpy(g["t"]).to(DEV)
+    model, diff, cfg = make("T28", use_kl=True)
+    model.train()
+    terms = diff.training_losses(model, x0, t, model_kwargs=dict(c=c, y=y, z=z), noise=noise)
+    assert set(terms) == {"loss"}
+    terms["loss"].mean().backward()
+    assert rel_err(terms["loss"], g["kl/loss"]) < 1e-4
+    params = dict(model.named_parameters())
+    sq = sum((p.grad.double() ** 2).sum().item() for p in params.values() if p.grad is not None)
+    assert abs(sq - float(g["kl/grad_sqsum"])) <= 2e-3 * sq
+    for k in ("out.2.weight", "out.2.bias", "input_blocks.1.0.in_layers.2.weight"):
+        assert probe_err(params[k].grad, g, f"kl/grad/{k}") < 1e-3, k
+
+
+@pytest.mark.gpu
+def test_calc_bpd_loop_golden(golden):
+    g = golden("g9_vlb.npz")
+    N, x0, noise, c, y, z = g9_inputs()
+    model, diff, cfg = make("T28", respacing="8", learn_sigma=True)
+    model.eval()
+    out = diff.calc_bpd_loop(model, x0, clip_denoised=True, model_kwargs=dict(c=c, y=y, z=z), noise=torch.from_numpy(g["bpd/noise"]).to(DEV))
+    for k in ("total_bpd", "prior_bpd", "vb", "xstart_mse", "mse"):
+        assert rel_err(out[k], g[f"bpd/{k}"]) < 1e-4, k

@@ -121,3 +121,32 @@ def test_uniform_sampler_matches_numpy_stream():
     ref = np.random.choice(1000, size=(16,), p=np.ones(1000) / 1000)
     np.testing.assert_array_equal(t.numpy(), ref)
     assert t.dtype == torch.int64 and w.dtype == torch.float32 and torch.all(w == 1)
+
+
+def test_loss_second_moment_resampler():
+    """resample.py:127-154 by definition: uniform until warmed up, then sqrt(second moment) mixed with a 0.1 % uniform floor."""
+    from causaldiffae_amd.resample import LossAwareSampler, LossSecondMomentResampler, create_named_schedule_sampler
+
+    class Diff:
+        num_timesteps = 4
+
+    s = create_named_schedule_sampler("loss-second-moment", Diff)
+    assert isinstance(s, LossSecondMomentResampler) and isinstance(s, LossAwareSampler)
+    assert np.array_equal(s.weights(), np.ones(4))
+    hist = {t: [] for t in range(4)}
+    rng = np.random.RandomState(0)
+    for k in range(13):                       # 13 > history: the oldest three values per step must drop out
+        ts = torch.arange(4)
+        ls = torch.from_numpy(rng.rand(4).astype(np.float32) * (1 + ts.numpy()))
+        if k == 5:
+            assert np.array_equal(s.weights(), np.ones(4))          # not warmed up yet
+        s.update_with_local_losses(ts, ls)
+        for t, l in zip(ts.tolist(), ls.tolist()):
+            hist[t] = (hist[t] + [l])[-10:]
+    want = np.sqrt(np.array([np.mean(np.square(hist[t])) for t in range(4)]))
+    want = want / want.sum() * (1 - 0.001) + 0.001 / 4
+    assert np.allclose(s.weights(), want, rtol=1e-10, atol=0)      # ring vs shifted history: summation order only
+    np.random.seed(3)
+    idx, w = s.sample(64, "cpu")
+    p = want / want.sum()
+    assert idx.dtype == torch.int64 and np.allclose(w.numpy(), 1 / (4 * p[idx.numpy()]), rtol=1e-6)

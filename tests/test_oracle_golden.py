@@ -359,3 +359,104 @@ def test_ddim_p64(golden):
         D.sample_loop(sch, model_fn, x_t, ddim=True, trace=trace)
         for k in (1, 2, 10, 50, 100):
             close(trace[k - 1].numpy(), g[f"loop/sample_after{k}"], 1e-4)
+
+
+# ------------------------------------------------------------------ G9: learned sigma / variational bound
+G9_VARIANTS = {"range": ("eps", "learned_range", True), "fixed": ("eps", "fixed_large", False),
+               "xstart": ("xstart", "learned_range", True), "small": ("eps", "fixed_small", False)}
+
+
+def g9_inputs():
+    N = 4
+    x0 = torch.round(synth("G9.x0", (N, 1, 28, 28), 0.0, 255.0)) / 127.5 - 1.0
+    noise = synth("G9.noise", (N, 1, 28, 28), -1.7, 1.7)
+    c = synth("G9.c", (N, 2), 0.0, 1.0)
+    y = torch.tensor([1, 3, 5, 7], dtype=torch.int64)
+    z = synth("G9.z", (N, 512), -1.0, 1.0)
+    return N, x0, noise, c, y, z
+
+
+def test_losses_py(golden):
+    g = golden("g9_vlb.npz")
+    sh = (3, 2, 8, 8)
+    m1, lv1 = synth("G9.m1", sh, -1.0, 1.0), synth("G9.lv1", sh, -6.0, 0.5)
+    m2, lv2 = synth("G9.m2", sh, -1.0, 1.0), synth("G9.lv2", sh, -6.0, 0.5)
+    close(D.normal_kl(m1, lv1, m2, lv2).numpy(), g["losses/normal_kl"], 0.0, 1e-6)
+    close(D.normal_kl(m1, lv1, 0.0, 0.0).numpy(), g["losses/normal_kl_scalar"], 0.0, 1e-6)
+    xq = torch.from_numpy(g["losses/xq"])
+    close(D.discretized_gaussian_log_likelihood(xq, m2, synth("G9.ls", sh, -4.0, 0.0)).numpy(), g["losses/dgll"], 1e-6, 1e-6)
+    close(D.approx_standard_normal_cdf(synth("G9.cdf", (64,), -5.0, 5.0)).numpy(), g["losses/cdf"], 1e-7)
+
+
+@pytest.mark.parametrize("tag", list(G9_VARIANTS))
+def test_learned_sigma_and_bound(golden, tag):
+    g = golden("g9_vlb.npz")
+    mean_type, var_type, learn = G9_VARIANTS[tag]
+    N, x0, noise, c, y, z = g9_inputs()
+    t = torch.from_numpy(g["t"])
+    sch = D.Schedule(1000, "linear", "", True)
+    x_t = D.q_sample(sch, x0, t, noise)
+    # the oracle network reproduces the reference's raw output (2 channels when sigma is learned)
+    cfg = model_cfg("T28", learn_sigma=learn)
+    sd = fill_state_dict(U.param_spec(cfg))
+    with torch.no_grad():
+        raw = U.unet_forward(sd, cfg, x_t, sch.model_t(t), y=y, c=c, z=z)[0]
+    close(raw.numpy(), g[f"{tag}/vb_grad/raw"], 2e-5)
+    raw = torch.from_numpy(g[f"{tag}/vb_grad/raw"])
+    for clip in (True, False):
+        pm = D.p_mean_variance_general(sch, raw, x_t, t, mean_type, var_type, clip)
+        for k in ("mean", "variance", "log_variance", "pred_xstart"):
+            close(pm[k].expand_as(x_t).numpy(), g[f"{tag}/pmv_clip{int(clip)}/{k}"], 1e-5, 1e-6)
+        vb = D.vb_terms_bpd(sch, raw, x0, x_t, t, mean_type, var_type, clip)
+        close(vb["output"].numpy(), g[f"{tag}/vb_clip{int(clip)}/output"], 1e-5, 1e-5)
+        close(vb["pred_xstart"].numpy(), g[f"{tag}/vb_clip{int(clip)}/pred_xstart"], 1e-5, 1e-6)
+    pm = D.p_mean_variance_general(sch, raw, x_t, t, mean_type, var_type, True)
+    nz = (t != 0).float().reshape(-1, 1, 1, 1)
+    close((pm["mean"] + nz * torch.exp(0.5 * pm["log_variance"]) * torch.from_numpy(g[f"{tag}/p_sample/noise"])).numpy(),
+          g[f"{tag}/p_sample/sample"], 1e-5)
+    close(D.prior_bpd(sch, x0).numpy(), g[f"{tag}/prior_bpd"], 1e-7, 1e-5)
+    # gradient of the bound with respect to the raw output
+    r = raw.clone().requires_grad_(True)
+    out = D.vb_terms_bpd(sch, r, x0, x_t, t, mean_type, var_type, False)["output"]
+    (out * torch.arange(1, N + 1, dtype=torch.float32)).sum().backward()
+    close(r.grad.numpy(), g[f"{tag}/vb_grad/draw"], 1e-7, 1e-4)
+
+
+def test_hybrid_loss_terms(golden):
+    g = golden("g9_vlb.npz")
+    N, x0, noise, c, y, z = g9_inputs()
+    t = torch.from_numpy(g["t"])
+    sch = D.Schedule(1000, "linear", "", True)
+    cfg = model_cfg("T28", learn_sigma=True)
+    spec = U.param_spec(cfg)
+    sd = fill_state_dict(spec)
+    pkeys = [k for k, _ in spec if "running" not in k and "num_batches" not in k]
+    for k in pkeys:
+        sd[k].requires_grad_(True)
+    x_t = D.q_sample(sch, x0, t, noise)
+    out, mu, var, zp, mask = U.unet_forward(sd, cfg, x_t, sch.model_t(t), y=y, c=c, x_start=x0,
+                                            eps_z=torch.from_numpy(g["hybrid/eps_draw"]), training=True, new_stats={})
+    terms = D.hybrid_losses(sch, out, x0, x_t, t, noise)
+    terms["loss"].mean().backward()
+    for k in ("mse", "vb", "loss"):
+        close(terms[k].detach().numpy(), g[f"hybrid/{k}"], 1e-5, 1e-5)
+    close(D.representation_loss(mu, var, zp, True, mask, c).detach().numpy(), g["hybrid/kld_rep"], 1e-4, 1e-5)
+    sq = sum((sd[k].grad.double() ** 2).sum().item() for k in pkeys if sd[k].grad is not None)
+    assert abs(sq - float(g["hybrid/grad_sqsum"])) <= 1e-3 * sq
+    for k in ("out.2.weight", "out.2.bias", "input_blocks.1.0.in_layers.2.weight", "time_embed.0.weight"):
+        probe_close(sd[k].grad, g, f"hybrid/grad/{k}", 1e-6, 1e-3)
+
+
+def test_calc_bpd_loop(golden):
+    g = golden("g9_vlb.npz")
+    N, x0, noise, c, y, z = g9_inputs()
+    sch = D.Schedule(1000, "linear", "8", True)
+    cfg = model_cfg("T28", learn_sigma=True)
+    sd = fill_state_dict(U.param_spec(cfg))
+
+    def model_fn(x, tm):
+        return U.unet_forward(sd, cfg, x, tm, y=y, c=c, z=z)[0]
+
+    out = D.calc_bpd_loop(sch, model_fn, x0, torch.from_numpy(g["bpd/noise"]), "eps", "learned_range", True)
+    for k in ("total_bpd", "prior_bpd", "vb", "xstart_mse", "mse"):
+        close(out[k].numpy(), g[f"bpd/{k}"], 1e-5, 1e-4)

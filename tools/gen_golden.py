@@ -67,11 +67,12 @@ def build_model(name):
     return over, base
 
 
-def make(name, respacing="", masking=False):
+def make(name, respacing="", masking=False, **extra):
     over, base = build_model(name)
     base.update(over)
     base["timestep_respacing"] = respacing
     base["masking"] = masking
+    base.update(extra)
     model, diff = rsu.create_model_and_diffusion(**base)
     # Q1: the committed encoder depth only works at 96/128 px; use the class's own hidden_dims kwarg.
     dims = encoder_dims(base["image_size"], base["n_vars"])
@@ -387,7 +388,115 @@ def g8_ddim(out_dir):
     np.savez_compressed(os.path.join(out_dir, "g8_ddim.npz"), **out)
 
 
-ALL = dict(G1=g1_schedules, G2=g2_temb, G3=g3_blocks, G4=g4_encoder, G5=g5_rep_loss, G6=g6_unet, G7=g7_train, G8=g8_ddim)
+# --------------------------------------------------------------------------- G9
+def g9_vlb(out_dir):
+    """Learned-sigma / variational-bound branches (gaussian_diffusion.py:289-303,682-715,792-837,862-931; losses.py)."""
+    from improved_diffusion import losses as rloss
+    out = {}
+    # (a) losses.py on closed-form inputs
+    sh = (3, 2, 8, 8)
+    m1, lv1 = synth("G9.m1", sh, -1.0, 1.0), synth("G9.lv1", sh, -6.0, 0.5)
+    m2, lv2 = synth("G9.m2", sh, -1.0, 1.0), synth("G9.lv2", sh, -6.0, 0.5)
+    out["losses/normal_kl"] = rloss.normal_kl(m1, lv1, m2, lv2).numpy()
+    out["losses/normal_kl_scalar"] = rloss.normal_kl(m1, lv1, 0.0, 0.0).numpy()
+    xq = (th.round(synth("G9.xq", sh, 0.0, 255.0)) / 127.5 - 1.0)
+    xq.view(-1)[:7] = th.tensor([-1.0, 1.0, -1.0, 1.0, 0.9992, -0.9992, 0.0])
+    ls = synth("G9.ls", sh, -4.0, 0.0)
+    out["losses/xq"] = xq.numpy()
+    out["losses/dgll"] = rloss.discretized_gaussian_log_likelihood(xq, means=m2, log_scales=ls).numpy()
+    out["losses/cdf"] = rloss.approx_standard_normal_cdf(synth("G9.cdf", (64,), -5.0, 5.0)).numpy()
+
+    N = 4
+    t = th.tensor([0, 5, 500, 999], dtype=th.int64)
+    x0 = th.round(synth("G9.x0", (N, 1, 28, 28), 0.0, 255.0)) / 127.5 - 1.0
+    noise = synth("G9.noise", (N, 1, 28, 28), -1.7, 1.7)
+    c = synth("G9.c", (N, 2), 0.0, 1.0)
+    y = th.tensor([1, 3, 5, 7], dtype=th.int64)
+    z = synth("G9.z", (N, 512), -1.0, 1.0)
+    out["t"] = t.numpy()
+    for tag, extra in [("range", dict(learn_sigma=True)), ("fixed", dict()), ("xstart", dict(learn_sigma=True, predict_xstart=True)),
+                       ("small", dict(sigma_small=True))]:
+        model, diff, base = make("T28", **extra)
+        model.eval()
+        kw = dict(c=c, y=y, z=z)
+        x_t = diff.q_sample(x0, t, noise=noise)
+        with th.no_grad():
+            for clip in (True, False):
+                pm = diff.p_mean_variance(model, x_t, t, clip_denoised=clip, model_kwargs=kw)
+                for k, v in pm.items():
+                    out[f"{tag}/pmv_clip{int(clip)}/{k}"] = v.numpy()
+                vb = diff._vb_terms_bpd(model, x0, x_t, t, clip_denoised=clip, model_kwargs=kw)
+                out[f"{tag}/vb_clip{int(clip)}/output"] = vb["output"].numpy()
+                out[f"{tag}/vb_clip{int(clip)}/pred_xstart"] = vb["pred_xstart"].numpy()
+            th.manual_seed(77)
+            ps = diff.p_sample(model, x_t, t, model_kwargs=kw)
+            th.manual_seed(77)
+            out[f"{tag}/p_sample/noise"] = th.randn_like(x_t).numpy()
+            out[f"{tag}/p_sample/sample"] = ps["sample"].numpy()
+            dd = diff.ddim_sample(model, x_t, t, model_kwargs=kw, eta=0.0)
+            out[f"{tag}/ddim/sample"] = dd["sample"].numpy()
+            out[f"{tag}/ddim/pred_xstart"] = dd["pred_xstart"].numpy()
+            out[f"{tag}/prior_bpd"] = diff._prior_bpd(x0).numpy()
+        # vb gradient with respect to the raw model output (both halves), per-sample weights 1..N
+        with th.no_grad():
+            raw = model(x_t, diff._scale_timesteps(t), **kw)[0]
+        raw = raw.clone().requires_grad_(True)
+        vb = diff._vb_terms_bpd(lambda *a, r=raw, **k: (r, None, None, None, None), x0, x_t, t, clip_denoised=False)["output"]
+        (vb * th.arange(1, N + 1, dtype=th.float32)).sum().backward()
+        out[f"{tag}/vb_grad/raw"] = raw.detach().numpy()
+        out[f"{tag}/vb_grad/draw"] = raw.grad.numpy()
+
+    # (c) hybrid loss as upstream improved-diffusion intends it.  The committed training_losses crashes for learn_sigma=True: its
+    # frozen-output lambda returns one tensor where p_mean_variance unpacks five (gaussian_diffusion.py:286,826) - so the terms are
+    # composed here from the reference's own pieces with a five-tuple lambda.
+    model, diff, base = make("T28", learn_sigma=True)
+    model.train()
+    params = list(model.parameters())
+    names = [k for k, _ in model.named_parameters()]
+    x_t = diff.q_sample(x0, t, noise=noise)
+    kw = dict(c=c, y=y, x_start=x0)
+    th.manual_seed(5)
+    model_output, mu, var, z_post, mask = model(x_t, diff._scale_timesteps(t), **kw)
+    th.manual_seed(5)
+    out["hybrid/eps_draw"] = th.randn(N, 512).numpy()
+    kld = diff.representation_loss(mu, var, z_post, True, mask, c)
+    eps_out, var_out = th.split(model_output, 1, dim=1)
+    frozen = th.cat([eps_out.detach(), var_out], dim=1)
+    vb = diff._vb_terms_bpd(model=lambda *a, r=frozen, **k: (r, None, None, None, None), x_start=x0, x_t=x_t, t=t, clip_denoised=False)["output"]
+    vb = vb * (diff.num_timesteps / 1000.0)
+    mse = rnn.mean_flat((noise - eps_out) ** 2)
+    loss = mse + vb                      # reference :849-850: with "vb" present the representation KL is NOT added
+    loss.mean().backward()
+    for k, v in (("mse", mse), ("vb", vb), ("loss", loss), ("kld_rep", kld)):
+        out[f"hybrid/{k}"] = v.detach().numpy()
+    out["hybrid/grad_sqsum"] = np.float64(sum((p.grad.double() ** 2).sum().item() for p in params if p.grad is not None))
+    for nme in ("out.2.weight", "out.2.bias", "input_blocks.1.0.in_layers.2.weight", "time_embed.0.weight"):
+        flat_probe(f"hybrid/grad/{nme}", params[names.index(nme)].grad, out)
+
+    # (d) pure-bound training loss (use_kl=True -> RESCALED_KL, fixed variance): the reference's own training_losses runs
+    model, diff, base = make("T28", use_kl=True)
+    model.train()
+    params = list(model.parameters())
+    terms = diff.training_losses(model, x0, t, model_kwargs=dict(c=c, y=y, z=z), noise=noise)
+    terms["loss"].mean().backward()
+    out["kl/loss"] = terms["loss"].detach().numpy()
+    out["kl/grad_sqsum"] = np.float64(sum((p.grad.double() ** 2).sum().item() for p in params if p.grad is not None))
+    for nme in ("out.2.weight", "out.2.bias", "input_blocks.1.0.in_layers.2.weight"):
+        flat_probe(f"kl/grad/{nme}", params[names.index(nme)].grad, out)
+
+    # (e) calc_bpd_loop on an 8-step respaced chain (learned range), noise replayed from the seed
+    model, diff, base = make("T28", respacing="8", learn_sigma=True)
+    model.eval()
+    th.manual_seed(9)
+    bpd = diff.calc_bpd_loop(model, x0, clip_denoised=True, model_kwargs=dict(c=c, y=y, z=z))
+    th.manual_seed(9)
+    out["bpd/noise"] = th.stack([th.randn_like(x0) for _ in range(8)]).numpy()
+    for k, v in bpd.items():
+        out[f"bpd/{k}"] = v.numpy()
+    np.savez_compressed(os.path.join(out_dir, "g9_vlb.npz"), **out)
+
+
+ALL = dict(G1=g1_schedules, G2=g2_temb, G3=g3_blocks, G4=g4_encoder, G5=g5_rep_loss, G6=g6_unet, G7=g7_train, G8=g8_ddim, G9=g9_vlb)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
