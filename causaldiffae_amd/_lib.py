@@ -40,6 +40,8 @@ SIGNATURES = {
     "cdae_bn_lrelu_bwd": [P, P, P, L, I, P, P, P, P, P, F, P, P, I, P, P],
     "cdae_softmax_rows": [P, L, I, P],
     "cdae_softmax_rows_bwd": [P, P, L, I, P],
+    "cdae_act_fwd": [P, P, L, I, P],
+    "cdae_act_bwd": [P, P, P, L, I, P],
     "cdae_silu_fwd": [P, P, L, P],
     "cdae_silu_bwd": [P, P, P, L, P],
     "cdae_timestep_embed_fwd": [P, P, P, I, I, P],

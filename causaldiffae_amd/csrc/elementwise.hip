@@ -27,6 +27,28 @@ __global__ void silu_bwd_kernel(const float* __restrict__ x, const float* __rest
     GRID_STRIDE(i, n) { float v = x[i], s = 1.f / (1.f + expf(-v)); dx[i] = dy[i] * s * (1.f + v * (1.f - s)); }
 }
 
+// generic pointwise activations on a stored pre-activation (codes = the GEMM epilogue's: 1 SiLU, 2 LeakyReLU(0.01), 3 ReLU, 4 sigmoid)
+__device__ inline float act_apply(float v, int kind) {
+    if (kind == 1) return v / (1.f + expf(-v));
+    if (kind == 2) return v > 0.f ? v : 0.01f * v;
+    if (kind == 3) return fmaxf(v, 0.f);
+    if (kind == 4) return 1.f / (1.f + expf(-v));
+    return v;
+}
+__global__ void act_kernel(const float* __restrict__ x, float* __restrict__ y, long n, int kind) {
+    GRID_STRIDE(i, n) { y[i] = act_apply(x[i], kind); }
+}
+__global__ void act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, long n, int kind) {
+    GRID_STRIDE(i, n) {
+        float v = x[i], g = dy[i], d = 1.f;
+        if (kind == 1) { float s = 1.f / (1.f + expf(-v)); d = s * (1.f + v * (1.f - s)); }
+        else if (kind == 2) d = v > 0.f ? 1.f : 0.01f;
+        else if (kind == 3) d = v > 0.f ? 1.f : 0.f;
+        else if (kind == 4) { float s = 1.f / (1.f + expf(-v)); d = s * (1.f - s); }
+        dx[i] = g * d;
+    }
+}
+
 // out[n][k] = cos(t[n]*f[k]), out[n][half+k] = sin(t[n]*f[k]); odd dim gets a trailing zero
 __global__ void temb_kernel(const float* __restrict__ t, const float* __restrict__ freqs, float* __restrict__ out, int N, int dim) {
     const int half = dim / 2;
@@ -372,6 +394,8 @@ __global__ void mse_rows_bwd_kernel(const float* __restrict__ a, const float* __
 
 extern "C" {
 
+int cdae_act_fwd(const float* x, float* y, long n, int kind, void* stream) { LAUNCH1D(act_kernel, n, x, y, n, kind); }
+int cdae_act_bwd(const float* x, const float* dy, float* dx, long n, int kind, void* stream) { LAUNCH1D(act_bwd_kernel, n, x, dy, dx, n, kind); }
 int cdae_silu_fwd(const float* x, float* y, long n, void* stream) { LAUNCH1D(silu_kernel, n, x, y, n); }
 int cdae_silu_bwd(const float* x, const float* dy, float* dx, long n, void* stream) { LAUNCH1D(silu_bwd_kernel, n, x, dy, dx, n); }
 int cdae_timestep_embed_fwd(const float* t, const float* freqs, float* out, int N, int dim, void* stream) {

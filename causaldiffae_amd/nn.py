@@ -35,6 +35,16 @@ class Identity(nn.Identity):
     pass
 
 
+class ReLU(nn.Module):
+    def forward(self, x):       # only reached when someone runs the Sequential by hand
+        raise NotImplementedError("ReLU is applied by the preceding Linear (act=ops.ACT_RELU)")
+
+
+class Sigmoid(nn.Module):
+    def forward(self, x):
+        raise NotImplementedError("Sigmoid is applied by the preceding Linear (act=ops.ACT_SIGMOID)")
+
+
 class Dropout(nn.Module):
     def __init__(self, p=0.0):
         super().__init__()
@@ -227,6 +237,63 @@ def reparameterize(m, v, eps=None):
     if eps is None:
         eps = th.randn(m.size(), device=m.device)
     return m + (v ** 0.5) * eps.to(m.device)
+
+
+# ----------------------------------------------------------------------------- causal normalising flow (flow_based=True)
+class MultivariateCausalFlow(nn.Module):
+    """Affine autoregressive flow over `dim` latent blocks of width `k` (reference nn.py:342-426).  Block i is transformed
+    as z_i = exp(s_i) e_i + t_i with (s_i, t_i) = conditioner(z * column i of C repeated k times); the conditioners are two
+    3-layer MLPs (ReLU, ReLU, sigmoid) shared by all blocks, run on the GEMM kernels.  Parameter names match the reference
+    (`s_cond.{0,2,4}`, `t_cond.{0,2,4}`).  The reference reshapes to (-1, 2, 256) whatever dim/k say; here dim/k are used.
+
+    Reference behaviours kept on purpose: `flow` conditions block i on the blocks already produced (later blocks, block i
+    itself included, are still zero), while `reverse` conditions on the FULL z — so `reverse` is not the inverse of `flow`
+    whenever C has a non-zero diagonal, as it does for the caller's C = I - A (unet.py:581)."""
+
+    def __init__(self, dim, k, nh=100):
+        super().__init__()
+        self.dim, self.k = dim, k
+        self.s_cond = nn.Sequential(Linear(dim * k, nh), ReLU(), Linear(nh, nh), ReLU(), Linear(nh, k), Sigmoid())
+        self.t_cond = nn.Sequential(Linear(dim * k, nh), ReLU(), Linear(nh, nh), ReLU(), Linear(nh, k), Sigmoid())
+
+    @staticmethod
+    def _run(net, x):
+        return net[4](net[2](net[0](x, act=ops.ACT_RELU), act=ops.ACT_RELU), act=ops.ACT_SIGMOID)
+
+    def _column_mask(self, C, i, device):
+        col = th.as_tensor(C, dtype=th.float32)[:, i].to(device)
+        if not bool((col == 1).any()):                 # "no parents" branch of the reference
+            col = th.zeros_like(col)
+        return col.repeat_interleave(self.k)           # == C[:, i].repeat(k, 1).T.reshape(dim * k)
+
+    def flow(self, e, C):
+        """e [N, dim*k] -> [z [N, dim*k], log_det [N]] with log_det = sum of all slopes."""
+        N = e.shape[0]
+        e3 = e.reshape(N, self.dim, self.k)
+        blocks = []
+        log_det = th.zeros(N, device=e.device)
+        for i in range(self.dim):
+            done = blocks + [th.zeros(N, self.k, device=e.device)] * (self.dim - len(blocks))
+            inp = th.cat(done, dim=1) * self._column_mask(C, i, e.device)
+            s, t = self._run(self.s_cond, inp), self._run(self.t_cond, inp)
+            blocks.append(th.exp(s) * e3[:, i, :] + t)
+            log_det = log_det + s.sum(dim=1)
+        return [th.cat(blocks, dim=1), log_det]
+
+    def reverse(self, z, C):
+        """z [N, dim*k] -> [log_det [N] (minus the slopes), log N(e; 1, I)] — see the class note on what this inverts."""
+        N = z.shape[0]
+        z3 = z.reshape(N, self.dim, self.k)
+        log_det = th.zeros(N, device=z.device)
+        es = []
+        for i in range(self.dim):
+            inp = z.reshape(N, -1) * self._column_mask(C, i, z.device)
+            s, t = self._run(self.s_cond, inp), self._run(self.t_cond, inp)
+            es.append(th.exp(-s) * (z3[:, i, :] - t))
+            log_det = log_det - s.sum(dim=1)
+        e = th.cat(es, dim=1)
+        log_prob = -0.5 * ((e - 1.0) ** 2).sum(dim=1) - 0.5 * e.shape[1] * math.log(2 * math.pi)     # MultivariateNormal(ones, I)
+        return [log_det, log_prob]
 
 
 # ----------------------------------------------------------------------------- causal semantic encoder

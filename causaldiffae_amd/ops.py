@@ -11,7 +11,7 @@ from torch.autograd import Function
 
 from ._lib import check, lib, ptr, splitk_ws, stream, workspace, SPLITK_BYTES
 
-ACT_NONE, ACT_SILU, ACT_LRELU = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_LRELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3, 4
 
 
 # ----------------------------------------------------------------------------- layout helpers
@@ -175,10 +175,10 @@ class _Linear(Function):
         ws, wsb = _sk(x.device)
         if pre is not None:      # keep the pre-activation for the backward
             check(lib.cdae_linear_fwd(ptr(x), x.stride(0), ptr(w), K, ptr(b), ptr(res), ptr(pre), Nf, M, Nf, K, alpha, ACT_NONE, ws, wsb, stream()))
-            if act == ACT_SILU:
-                check(lib.cdae_silu_fwd(ptr(pre), ptr(y), M * Nf, stream()))
-            else:
-                y = torch.where(pre > 0, pre, 0.01 * pre)
+            check(lib.cdae_act_fwd(ptr(pre), ptr(y), M * Nf, act, stream()))
+        elif act in (ACT_RELU, ACT_SIGMOID):      # not in the GEMM epilogue (cold path): activate in place
+            check(lib.cdae_linear_fwd(ptr(x), x.stride(0), ptr(w), K, ptr(b), ptr(res), ptr(y), Nf, M, Nf, K, alpha, ACT_NONE, ws, wsb, stream()))
+            check(lib.cdae_act_fwd(ptr(y), ptr(y), M * Nf, act, stream()))
         else:
             check(lib.cdae_linear_fwd(ptr(x), x.stride(0), ptr(w), K, ptr(b), ptr(res), ptr(y), Nf, M, Nf, K, alpha, act, ws, wsb, stream()))
         ctx.save_for_backward(x, w, pre)
@@ -194,12 +194,10 @@ class _Linear(Function):
         Nf = w.shape[0]
         dy = _f32c(dy)
         dev = x.device
-        if act == ACT_SILU:
+        if act != ACT_NONE:
             g = torch.empty_like(dy)
-            check(lib.cdae_silu_bwd(ptr(pre), ptr(dy), ptr(g), M * Nf, stream()))
+            check(lib.cdae_act_bwd(ptr(pre), ptr(dy), ptr(g), M * Nf, act, stream()))
             dy = g
-        elif act == ACT_LRELU:
-            dy = torch.where(pre > 0, dy, 0.01 * dy)
         ws, wsb = _sk(dev)
         dx = dw = db = dres = None
         dya = dy if alpha == 1.0 else dy * alpha

@@ -22,6 +22,7 @@ from .nn import (
     GaussianConvEncoder,
     Identity,
     Linear,
+    MultivariateCausalFlow,
     SiLU,
     _RNG_OVERRIDE,
     checkpoint,
@@ -173,8 +174,6 @@ class UNetModel(nn.Module):
         super().__init__()
         if num_heads_upsample == -1:
             num_heads_upsample = num_heads
-        if flow_based:
-            raise NotImplementedError("flow_based=True (MultivariateCausalFlow) is outside the BASELINE configs (SURVEY §8f.3)")
         self.in_channels, self.model_channels, self.out_channels = in_channels, model_channels, out_channels
         self.num_res_blocks, self.attention_resolutions = num_res_blocks, attention_resolutions
         self.dropout, self.channel_mult, self.conv_resample = dropout, channel_mult, conv_resample
@@ -197,6 +196,8 @@ class UNetModel(nn.Module):
             self.up_emb = Linear(rep_dim, time_embed_dim)
         if causal_modeling:
             self.causal_mask = CausalModeling(latent_dim=rep_dim, num_var=n_vars, learn=False)
+        if flow_based:        # the reference builds MultivariateCausalFlow(dim=2, k=256) whatever n_vars is (unet.py:385-386)
+            self.causal_flow = MultivariateCausalFlow(dim=2, k=256)
 
         self.input_blocks = nn.ModuleList([TimestepEmbedSequential(conv_nd(dims, in_channels, model_channels, 3, padding=1))])
         input_block_chans = [model_channels]
@@ -276,8 +277,14 @@ class UNetModel(nn.Module):
                 mu, var = self.rep_emb.encode(x_start)
                 if self.causal_modeling:
                     A = self.default_adjacency(mu.device)
-                    z_pre = self.causal_mask.causal_masking(mu, A)
-                    z_post = self.causal_mask.nonlinearity_add_back_noise(mu, z_pre)
+                    if self.flow_based:       # unet.py:580-587: flow in place of the masked MLPs; `mask` becomes a scalar
+                        Cm = th.eye(A.shape[0], device=mu.device) - A
+                        z_post, _ = self.causal_flow.flow(mu, Cm)
+                        log_det, _ = self.causal_flow.reverse(z_post, Cm)
+                        mask = -th.mean(log_det)
+                    else:
+                        z_pre = self.causal_mask.causal_masking(mu, A)
+                        z_post = self.causal_mask.nonlinearity_add_back_noise(mu, z_pre)
                     z = reparameterize(z_post, var * 0.001)
                 else:
                     z = reparameterize(mu, var * 0.001)

@@ -129,6 +129,10 @@ int cdae_softmax_rows(float* s, long rows, int T, void* stream);
 int cdae_softmax_rows_bwd(const float* P, float* dP, long rows, int T, void* stream);
 
 /* ---- pointwise (elementwise.hip) -------------------------------------------------------------------------- */
+/* pointwise activation of a stored pre-activation and its gradient; kind: 1 SiLU, 2 LeakyReLU(0.01) (nn.py:232), 3 ReLU, 4 sigmoid
+   (the conditioner nets of MultivariateCausalFlow, nn.py:350-366).  In place (y == x, dx == dy) is allowed. */
+int cdae_act_fwd(const float* x, float* y, long n, int kind, void* stream);
+int cdae_act_bwd(const float* x, const float* dy, float* dx, long n, int kind, void* stream);
 int cdae_silu_fwd(const float* x, float* y, long n, void* stream);
 int cdae_silu_bwd(const float* x, const float* dy, float* dx, long n, void* stream);
 /* timestep_embedding (nn.py:551-569); freqs[dim/2] is the host-computed exp(-ln(P) k/half) table */

@@ -39,7 +39,7 @@ def default_cfg(**over):
                num_heads_upsample=-1, attention_resolutions="16,8", learn_sigma=False,
                class_cond=False, context_cond=False, rep_cond=False, n_vars=4,
                causal_modeling=False, masking=False, use_scale_shift_norm=True,
-               encoder_dims=None)
+               encoder_dims=None, flow_based=False)
     cfg.update(over)
     return cfg
 
@@ -152,6 +152,10 @@ def param_spec(cfg):
             p = f"causal_mask.nonlinearities.{i}.net"
             spec += [(f"{p}.0.weight", (REP_DIM, d)), (f"{p}.0.bias", (REP_DIM,)),
                      (f"{p}.2.weight", (d, REP_DIM)), (f"{p}.2.bias", (d,))]
+    if cfg["flow_based"]:           # MultivariateCausalFlow(dim=2, k=256), nh=100 (unet.py:385-386, nn.py:343-366)
+        for net in ("s_cond", "t_cond"):
+            for li, (o, i) in zip((0, 2, 4), ((100, 512), (100, 100), (256, 100))):
+                spec += [(f"causal_flow.{net}.{li}.weight", (o, i)), (f"causal_flow.{net}.{li}.bias", (o,))]
     for bi, layers in enumerate(a["input"]):
         for li, layer in enumerate(layers):
             spec += _layer_spec(f"input_blocks.{bi}.{li}", layer, emb, ssn)
@@ -290,6 +294,48 @@ def nonlinearity_add_back_noise(sd, u, z_pre, n_vars):
     return torch.stack(outs, dim=1).reshape(u.shape[0], -1)
 
 
+def _flow_cond(sd, net, x):
+    p = f"causal_flow.{net}"
+    h = F.relu(F.linear(x, sd[p + ".0.weight"], sd[p + ".0.bias"]))
+    h = F.relu(F.linear(h, sd[p + ".2.weight"], sd[p + ".2.bias"]))
+    return torch.sigmoid(F.linear(h, sd[p + ".4.weight"], sd[p + ".4.bias"]))
+
+
+def _flow_mask(C, i, k):
+    col = C[:, i]
+    return col.repeat(k, 1).T.reshape(-1) if bool((col == 1).any()) else torch.zeros(C.shape[0] * k)
+
+
+def causal_flow(sd, e, C, dim=2, k=256):
+    """nn.py:368-393: z_i = exp(s_i) e_i + t_i, conditioners see the blocks filled so far times column i of C."""
+    N = e.shape[0]
+    e3 = e.reshape(N, dim, k)
+    z = torch.zeros(N, dim, k)
+    log_det = torch.zeros(N)
+    for i in range(dim):
+        inp = z.reshape(N, dim * k) * _flow_mask(C, i, k)
+        s, t = _flow_cond(sd, "s_cond", inp), _flow_cond(sd, "t_cond", inp)
+        z = torch.cat([z[:, :i], (torch.exp(s) * e3[:, i] + t)[:, None], z[:, i + 1:]], dim=1)
+        log_det = log_det + s.sum(dim=1)
+    return z.reshape(N, dim * k), log_det
+
+
+def causal_flow_reverse(sd, z, C, dim=2, k=256):
+    """nn.py:395-426: conditioners see the FULL z (so this is not the inverse of `causal_flow` when diag(C) != 0)."""
+    N = z.shape[0]
+    z3 = z.reshape(N, dim, k)
+    log_det = torch.zeros(N)
+    es = []
+    for i in range(dim):
+        inp = z.reshape(N, dim * k) * _flow_mask(C, i, k)
+        s, t = _flow_cond(sd, "s_cond", inp), _flow_cond(sd, "t_cond", inp)
+        es.append(torch.exp(-s) * (z3[:, i] - t))
+        log_det = log_det - s.sum(dim=1)
+    e = torch.cat(es, dim=1)
+    log_prob = -0.5 * ((e - 1.0) ** 2).sum(dim=1) - 0.5 * dim * k * math.log(2 * math.pi)
+    return log_det, log_prob
+
+
 def reparameterize(m, v, eps):
     """nn.py:460-467 with the normal draw `eps` injected."""
     return m + (v ** 0.5) * eps
@@ -323,8 +369,13 @@ def unet_forward(sd, cfg, x, t, y=None, c=None, x_start=None, z=None, A=None,
                 nv = cfg["n_vars"]
                 if A is None:
                     A = torch.tensor(ADJ["morpho"] if nv == 2 else ADJ["circuit"], dtype=torch.float32)
-                z_pre = causal_masking(mu, A, nv)
-                z_post = nonlinearity_add_back_noise(sd, mu, z_pre, nv)
+                if cfg["flow_based"]:                                   # unet.py:580-587
+                    Cm = torch.eye(A.shape[0]) - A
+                    z_post, _ = causal_flow(sd, mu, Cm)
+                    mask = -torch.mean(causal_flow_reverse(sd, z_post, Cm)[0])
+                else:
+                    z_pre = causal_masking(mu, A, nv)
+                    z_post = nonlinearity_add_back_noise(sd, mu, z_pre, nv)
                 z = reparameterize(z_post, var * 0.001, eps_z)         # unet.py:592
             else:
                 z = reparameterize(mu, var * 0.001, eps_z)

@@ -561,3 +561,41 @@ def test_calc_bpd_loop_golden(golden):
     out = diff.calc_bpd_loop(model, x0, clip_denoised=True, model_kwargs=dict(c=c, y=y, z=z), noise=torch.from_numpy(g["bpd/noise"]).to(DEV))
     for k in ("total_bpd", "prior_bpd", "vb", "xstart_mse", "mse"):
         assert rel_err(out[k], g[f"bpd/{k}"]) < 1e-4, k
+
+
+# ------------------------------------------------------------------ G10: flow_based=True
+@pytest.mark.gpu
+def test_causal_flow_golden(golden, precision):
+    """MultivariateCausalFlow.flow / reverse and training_losses through it (nn.py:342-426, unet.py:580-587)."""
+    from improved_diffusion.nn import rng_override
+    g = golden("g10_flow.npz")
+    model, diff, cfg = make("T28", flow_based=True)
+    assert list(model.state_dict().keys()) == list(g["keys"])
+    assert [str(tuple(v.shape)) for v in model.state_dict().values()] == list(g["shapes"])
+    model.train()
+    N = 4
+    mu = synth("G10.mu", (N, 512), -1.0, 1.0).to(DEV)
+    C = torch.eye(2) - torch.tensor([[0, 1], [0, 0]], dtype=torch.float32)
+    with torch.no_grad():
+        z_post, log_det = model.causal_flow.flow(mu, C)
+        rev_log_det, log_prob = model.causal_flow.reverse(z_post, C)
+    assert err(z_post, g["flow/z_post"]) < 1e-4
+    assert err(log_det, g["flow/log_det"]) < 1e-3 and err(rev_log_det, g["flow/rev_log_det"]) < 1e-3     # sums of 512 slopes ~ 256
+    assert rel_err(log_prob, g["flow/log_prob"]) < 1e-5
+    x0 = synth("G10.x0", (N, 1, 28, 28), 0.0, 1.0).to(DEV)
+    c = synth("G10.c", (N, 2), 0.0, 1.0).to(DEV)
+    y = torch.tensor([0, 2, 4, 6], dtype=torch.int64, device=DEV)
+    t = torch.tensor([3, 250, 600, 998], dtype=torch.int64, device=DEV)
+    noise = synth("G10.noise", (N, 1, 28, 28), -1.7, 1.7).to(DEV)
+    diff.kl_weight = 0.5
+    with rng_override(eps_z=torch.from_numpy(g["eps_draw"]).to(DEV)):
+        terms = diff.training_losses(model, x0, t, model_kwargs=dict(c=c, y=y), noise=noise, rep_cond=True, causal_modeling=True)
+    terms["loss"].mean().backward()
+    assert terms["kld_rep"].dim() == 0                       # the scalar `mask` turns the KL into a batch sum
+    for k in ("loss", "mse", "kld_rep"):
+        assert rel_err(terms[k], g[f"train/{k}"]) < 1e-4, k
+    params = dict(model.named_parameters())
+    sq = sum((p.grad.double() ** 2).sum().item() for p in params.values() if p.grad is not None)
+    assert abs(sq - float(g["train/grad_sqsum"])) <= 2e-3 * sq
+    for k in ("causal_flow.s_cond.0.weight", "causal_flow.s_cond.4.bias", "causal_flow.t_cond.2.weight", "rep_emb.fc_mu.weight", "out.2.weight"):
+        assert probe_err(params[k].grad, g, f"train/grad/{k}") < 2e-3, k

@@ -460,3 +460,51 @@ def test_calc_bpd_loop(golden):
     out = D.calc_bpd_loop(sch, model_fn, x0, torch.from_numpy(g["bpd/noise"]), "eps", "learned_range", True)
     for k in ("total_bpd", "prior_bpd", "vb", "xstart_mse", "mse"):
         close(out[k].numpy(), g[f"bpd/{k}"], 1e-5, 1e-4)
+
+
+# ------------------------------------------------------------------ G10: flow_based=True (MultivariateCausalFlow)
+def test_causal_flow(golden):
+    g = golden("g10_flow.npz")
+    cfg = model_cfg("T28", flow_based=True)
+    spec = U.param_spec(cfg)
+    assert [k for k, _ in spec] == list(g["keys"]) and [str(tuple(s)) for _, s in spec] == list(g["shapes"])
+    sd = fill_state_dict(spec)
+    mu = synth("G10.mu", (4, 512), -1.0, 1.0)
+    C = torch.eye(2) - torch.tensor(U.ADJ["morpho"], dtype=torch.float32)
+    with torch.no_grad():
+        z, ld = U.causal_flow(sd, mu, C)
+        rld, lp = U.causal_flow_reverse(sd, z, C)
+    close(z.numpy(), g["flow/z_post"], 1e-5)
+    close(ld.numpy(), g["flow/log_det"], 1e-4)
+    close(rld.numpy(), g["flow/rev_log_det"], 1e-4)
+    close(lp.numpy(), g["flow/log_prob"], 1e-3, 1e-6)
+
+
+def test_flow_training_losses(golden):
+    g = golden("g10_flow.npz")
+    cfg = model_cfg("T28", flow_based=True)
+    spec = U.param_spec(cfg)
+    sd = fill_state_dict(spec)
+    pkeys = [k for k, _ in spec if "running" not in k and "num_batches" not in k]
+    for k in pkeys:
+        sd[k].requires_grad_(True)
+    N = 4
+    x0 = synth("G10.x0", (N, 1, 28, 28), 0.0, 1.0)
+    c = synth("G10.c", (N, 2), 0.0, 1.0)
+    y = torch.tensor([0, 2, 4, 6], dtype=torch.int64)
+    t = torch.tensor([3, 250, 600, 998], dtype=torch.int64)
+    noise = synth("G10.noise", (N, 1, 28, 28), -1.7, 1.7)
+    sch = D.Schedule(1000, "linear", "", True)
+    eps_z = torch.from_numpy(g["eps_draw"])
+
+    def model_full(x_t, tm, xs):
+        return U.unet_forward(sd, cfg, x_t, tm, y=y, c=c, x_start=xs, eps_z=eps_z, training=True, new_stats={})
+
+    terms = D.training_losses(sch, model_full, x0, t, noise, c=c, rep_cond=True, causal_modeling=True, kl_weight=0.5)
+    terms["loss"].mean().backward()
+    for k in ("loss", "mse", "kld_rep"):
+        close(terms[k].detach().numpy(), g[f"train/{k}"], 1e-4, 1e-5)
+    sq = sum((sd[k].grad.double() ** 2).sum().item() for k in pkeys if sd[k].grad is not None)
+    assert abs(sq - float(g["train/grad_sqsum"])) <= 1e-3 * sq
+    for k in ("causal_flow.s_cond.0.weight", "causal_flow.s_cond.4.bias", "causal_flow.t_cond.2.weight", "rep_emb.fc_mu.weight", "out.2.weight"):
+        probe_close(sd[k].grad, g, f"train/grad/{k}", 1e-5, 2e-3)

@@ -496,7 +496,46 @@ def g9_vlb(out_dir):
     np.savez_compressed(os.path.join(out_dir, "g9_vlb.npz"), **out)
 
 
-ALL = dict(G1=g1_schedules, G2=g2_temb, G3=g3_blocks, G4=g4_encoder, G5=g5_rep_loss, G6=g6_unet, G7=g7_train, G8=g8_ddim, G9=g9_vlb)
+# --------------------------------------------------------------------------- G10
+def g10_flow(out_dir):
+    """flow_based=True: MultivariateCausalFlow in place of the masked MLP layer (nn.py:342-426, unet.py:580-587)."""
+    out = {}
+    N = 4
+    model, diff, base = make("T28", flow_based=True)
+    out["keys"] = np.array(list(model.state_dict().keys()))
+    out["shapes"] = np.array([str(tuple(v.shape)) for v in model.state_dict().values()])
+    model.train()
+    x0 = synth("G10.x0", (N, 1, 28, 28), 0.0, 1.0)
+    c = synth("G10.c", (N, 2), 0.0, 1.0)
+    y = th.tensor([0, 2, 4, 6], dtype=th.int64)
+    t = th.tensor([3, 250, 600, 998], dtype=th.int64)
+    noise = synth("G10.noise", (N, 1, 28, 28), -1.7, 1.7)
+    # the flow alone
+    mu = synth("G10.mu", (N, 512), -1.0, 1.0)
+    C = th.eye(2) - th.tensor([[0, 1], [0, 0]], dtype=th.float32)
+    with th.no_grad():
+        z_post, log_det = model.causal_flow.flow(mu, C)
+        rev_log_det, log_prob = model.causal_flow.reverse(z_post, C)
+    out["flow/z_post"], out["flow/log_det"] = z_post.numpy(), log_det.numpy()
+    out["flow/rev_log_det"], out["flow/log_prob"] = rev_log_det.numpy(), log_prob.numpy()
+    # training_losses through the flow
+    diff.kl_weight = 0.5
+    params = list(model.parameters())
+    names = [k for k, _ in model.named_parameters()]
+    th.manual_seed(11)
+    terms = diff.training_losses(model, x0, t, model_kwargs=dict(c=c, y=y), noise=noise, rep_cond=True, causal_modeling=True)
+    th.manual_seed(11)
+    out["eps_draw"] = th.randn(N, 512).numpy()
+    terms["loss"].mean().backward()
+    for k in ("loss", "mse", "kld_rep"):
+        out[f"train/{k}"] = terms[k].detach().numpy()
+    out["train/grad_sqsum"] = np.float64(sum((p.grad.double() ** 2).sum().item() for p in params if p.grad is not None))
+    for nme in ("causal_flow.s_cond.0.weight", "causal_flow.s_cond.4.bias", "causal_flow.t_cond.2.weight", "rep_emb.fc_mu.weight", "out.2.weight"):
+        flat_probe(f"train/grad/{nme}", params[names.index(nme)].grad, out)
+    np.savez_compressed(os.path.join(out_dir, "g10_flow.npz"), **out)
+
+
+ALL = dict(G1=g1_schedules, G2=g2_temb, G3=g3_blocks, G4=g4_encoder, G5=g5_rep_loss, G6=g6_unet, G7=g7_train, G8=g8_ddim, G9=g9_vlb, G10=g10_flow)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
