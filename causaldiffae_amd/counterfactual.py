@@ -1,7 +1,10 @@
 """Counterfactual generation: encode -> causal layer -> do-intervention on one variable's latent slice -> q_sample to the
 last (spaced) step -> DDIM / ancestral decode.  This is the call pattern of the reference's evaluation script
 (scripts/image_causaldae_test.py:405-436 MorphoMNIST, :535-594 pendulum, :773-815 circuit; traversal :481-531), factored
-into functions; the image batch is sharded over ranks with no collective inside the loop and gathered at the end."""
+into functions; the image batch is sharded over ranks with no collective inside the loop and gathered at the end.
+The two sibling scripts use the same kernels with other conditioning: image_diffae_test.py (representation without the
+causal layer: the edit goes into mu) is handled by `counterfactual_sample` on a `causal_modeling=False` model, and
+image_conditional_test.py (label vector `c` through c_emb) by `label_conditional_sample`."""
 import torch as th
 
 from . import dist_util
@@ -18,6 +21,11 @@ def encode_with_intervention(model, batch, A, var_index=None, value=None, var=0.
     mu, _ = model.rep_emb.encode(batch)
     nv = model.n_vars
     d = mu.shape[1] // nv
+    if not getattr(model, "causal_modeling", True):      # DiffAE (image_diffae_test.py:270-300): no causal layer, edit mu itself
+        if var_index is not None:
+            mu = mu.clone()
+            mu[:, var_index * d:(var_index + 1) * d] = value
+        return reparameterize(mu, th.full_like(mu, var), eps=eps)
     A = th.as_tensor(A, dtype=th.float32)
     if var_index is not None and intervene_on == "mu":
         mu = mu.clone()
@@ -65,3 +73,35 @@ def counterfactual_sample(model, diffusion, batch, A="circuit", var_index=None, 
 def latent_traversal(model, diffusion, batch, A, var_index, values, **kw):
     """One counterfactual batch per intervention value (reference traversal loop, image_causaldae_test.py:481-531)."""
     return [counterfactual_sample(model, diffusion, batch, A, var_index, float(v), **kw) for v in values]
+
+
+
+def label_conditional_sample(model, diffusion, batch, cond, var_index=None, value=None, *, from_input=True, use_ddim=True, eta=0.0,
+                             clip_denoised=True, q_noise=None, use_graph=True, shard=False, gather=False):
+    """Label-conditional generation (scripts/image_conditional_test.py:112-150, 224-240): the model is conditioned on the
+    label vector cond["c"] (and cond["y"] if class-conditional); do(var_index := value) overwrites one label column.
+    from_input=True starts the reverse chain from q_sample(batch, T-1) like the script's pendulum branch; False from noise."""
+    cond = {k: v.clone() for k, v in cond.items()}
+    if shard:
+        lo, hi = dist_util.shard_range(batch.shape[0])
+        batch = batch[lo:hi]
+        cond = {k: v[lo:hi] for k, v in cond.items()}
+        q_noise = None if q_noise is None else q_noise[lo:hi]
+    dev = next(model.parameters()).device
+    batch = batch.to(dev)
+    cond = {k: v.to(dev) for k, v in cond.items()}
+    if var_index is not None:
+        cond["c"][:, var_index] = value
+    with th.no_grad():
+        start = None
+        if from_input:
+            t_last = th.full((batch.shape[0],), diffusion.num_timesteps - 1, dtype=th.int64, device=dev)
+            start = diffusion.q_sample(batch, t_last, noise=th.randn_like(batch) if q_noise is None else q_noise.to(dev))
+        if use_ddim:
+            sample = diffusion.ddim_sample_loop(model, tuple(batch.shape), noise=start, clip_denoised=clip_denoised, model_kwargs=cond,
+                                                eta=eta, use_graph=use_graph and eta == 0.0)
+        else:
+            sample = diffusion.p_sample_loop(model, tuple(batch.shape), noise=start, clip_denoised=clip_denoised, model_kwargs=cond)
+    if gather:
+        return th.cat(dist_util.gather_samples(sample), dim=0)
+    return sample

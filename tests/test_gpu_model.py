@@ -599,3 +599,60 @@ def test_causal_flow_golden(golden, precision):
     assert abs(sq - float(g["train/grad_sqsum"])) <= 2e-3 * sq
     for k in ("causal_flow.s_cond.0.weight", "causal_flow.s_cond.4.bias", "causal_flow.t_cond.2.weight", "rep_emb.fc_mu.weight", "out.2.weight"):
         assert probe_err(params[k].grad, g, f"train/grad/{k}") < 2e-3, k
+
+
+# ------------------------------------------------------------------ G11: label-conditional and DiffAE families
+def g11_inputs():
+    N = 3
+    return (N, synth("G11.x0", (N, 1, 28, 28), 0.0, 1.0), synth("G11.c", (N, 2), 0.0, 1.0), synth("G11.c4", (N, 4), 0.0, 1.0),
+            torch.tensor([2, 4, 9], dtype=torch.int64), synth("G11.noise", (N, 1, 28, 28), -1.7, 1.7),
+            torch.tensor([10, 400, 990], dtype=torch.int64))
+
+
+@pytest.mark.gpu
+def test_label_conditional_family_golden(golden, precision):
+    """context_cond model: training_losses and the image_conditional_test.py sampling pattern (do(c_0 := -0.2), DDIM-5)."""
+    from improved_diffusion.counterfactual import label_conditional_sample
+    g = golden("g11_variants.npz")
+    N, x0, c, c4, y, noise, tt = g11_inputs()
+    model, diff, cfg = make("T28", rep_cond=False, causal_modeling=False, context_cond=True)
+    assert list(model.state_dict().keys()) == list(g["cond/keys"])
+    model.train()
+    terms = diff.training_losses(model, x0.to(DEV), tt.to(DEV), model_kwargs=dict(c=c4.to(DEV), y=y.to(DEV)), noise=noise.to(DEV))
+    terms["loss"].mean().backward()
+    assert rel_err(terms["loss"], g["cond/train/loss"]) < 1e-4 and rel_err(terms["mse"], g["cond/train/mse"]) < 1e-4
+    params = dict(model.named_parameters())
+    for k in ("c_emb.0.weight", "c_emb.2.bias", "out.2.weight"):
+        assert probe_err(params[k].grad, g, f"cond/train/grad/{k}") < 1e-3, k
+    model, diff, cfg = make("T28", respacing="ddim5", rep_cond=False, causal_modeling=False, context_cond=True)
+    model.eval()
+    for use_graph in (False, True):
+        out = label_conditional_sample(model, diff, x0, dict(c=c4, y=y), 0, -0.2, q_noise=noise, use_graph=use_graph)
+        assert err(out, g["cond/sample"]) < 1e-4, use_graph
+
+
+@pytest.mark.gpu
+def test_diffae_family_golden(golden, precision):
+    """rep_cond without the causal layer: training_losses and the image_diffae_test.py pattern (mu[:, 256:] := 0.4, DDIM-5)."""
+    from improved_diffusion.counterfactual import counterfactual_sample
+    from improved_diffusion.nn import rng_override
+    g = golden("g11_variants.npz")
+    N, x0, c, c4, y, noise, tt = g11_inputs()
+    model, diff, cfg = make("T28", causal_modeling=False)
+    assert list(model.state_dict().keys()) == list(g["diffae/keys"])
+    model.train()
+    diff.kl_weight = 0.3
+    with rng_override(eps_z=torch.from_numpy(g["diffae/eps_draw"]).to(DEV)):
+        terms = diff.training_losses(model, x0.to(DEV), tt.to(DEV), model_kwargs=dict(c=c.to(DEV), y=y.to(DEV)), noise=noise.to(DEV),
+                                     rep_cond=True, causal_modeling=False)
+    terms["loss"].mean().backward()
+    for k in ("loss", "mse", "kld_rep"):
+        assert rel_err(terms[k], g[f"diffae/train/{k}"]) < 1e-4, k
+    params = dict(model.named_parameters())
+    for k in ("rep_emb.fc_var.weight", "up_emb.weight", "out.2.weight"):
+        assert probe_err(params[k].grad, g, f"diffae/train/grad/{k}") < 1e-3, k
+    model, diff, cfg = make("T28", respacing="ddim5", causal_modeling=False)
+    model.eval()
+    out = counterfactual_sample(model, diff, x0, None, 1, 0.4, extra_kwargs=dict(c=c.to(DEV), y=y.to(DEV)), q_noise=noise,
+                                z_eps=torch.from_numpy(g["diffae/z_eps"]).to(DEV))
+    assert err(out, g["diffae/sample"]) < 1e-4

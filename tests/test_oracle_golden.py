@@ -508,3 +508,65 @@ def test_flow_training_losses(golden):
     assert abs(sq - float(g["train/grad_sqsum"])) <= 1e-3 * sq
     for k in ("causal_flow.s_cond.0.weight", "causal_flow.s_cond.4.bias", "causal_flow.t_cond.2.weight", "rep_emb.fc_mu.weight", "out.2.weight"):
         probe_close(sd[k].grad, g, f"train/grad/{k}", 1e-5, 2e-3)
+
+
+# ------------------------------------------------------------------ G11: label-conditional and DiffAE model families
+def g11_inputs():
+    N = 3
+    return (N, synth("G11.x0", (N, 1, 28, 28), 0.0, 1.0), synth("G11.c", (N, 2), 0.0, 1.0), synth("G11.c4", (N, 4), 0.0, 1.0),
+            torch.tensor([2, 4, 9], dtype=torch.int64), synth("G11.noise", (N, 1, 28, 28), -1.7, 1.7),
+            torch.tensor([10, 400, 990], dtype=torch.int64))
+
+
+def test_label_conditional_family(golden):
+    g = golden("g11_variants.npz")
+    N, x0, c, c4, y, noise, tt = g11_inputs()
+    cfg = U.default_cfg(**MODEL_CFG["T28"], context_cond=True)
+    spec = U.param_spec(cfg)
+    assert [k for k, _ in spec] == list(g["cond/keys"])
+    sd = fill_state_dict(spec)
+    for k, _ in spec:
+        sd[k].requires_grad_(True)
+    sch = D.Schedule(1000, "linear", "", True)
+    terms = D.training_losses(sch, lambda x_t, tm, xs: U.unet_forward(sd, cfg, x_t, tm, y=y, c=c4), x0, tt, noise)
+    terms["loss"].mean().backward()
+    close(terms["loss"].detach().numpy(), g["cond/train/loss"], 1e-5, 1e-5)
+    for k in ("c_emb.0.weight", "c_emb.2.bias", "out.2.weight"):
+        probe_close(sd[k].grad, g, f"cond/train/grad/{k}", 1e-6, 1e-3)
+    sch5 = D.Schedule(1000, "linear", "ddim5", True)
+    cc = c4.clone()
+    cc[:, 0] = -0.2
+    x_t = D.q_sample(sch5, x0, torch.full((N,), sch5.T - 1, dtype=torch.int64), noise)
+    with torch.no_grad():
+        out = D.sample_loop(sch5, lambda x, tm: U.unet_forward(sd, cfg, x, tm, y=y, c=cc)[0], x_t, ddim=True)
+    close(out.numpy(), g["cond/sample"], 5e-5)
+
+
+def test_diffae_family(golden):
+    g = golden("g11_variants.npz")
+    N, x0, c, c4, y, noise, tt = g11_inputs()
+    cfg = U.default_cfg(**MODEL_CFG["T28"], rep_cond=True)
+    spec = U.param_spec(cfg)
+    assert [k for k, _ in spec] == list(g["diffae/keys"])
+    sd = fill_state_dict(spec)
+    pkeys = [k for k, _ in spec if "running" not in k and "num_batches" not in k]
+    for k in pkeys:
+        sd[k].requires_grad_(True)
+    sch = D.Schedule(1000, "linear", "", True)
+    eps_z = torch.from_numpy(g["diffae/eps_draw"])
+    terms = D.training_losses(sch, lambda x_t, tm, xs: U.unet_forward(sd, cfg, x_t, tm, y=y, x_start=xs, eps_z=eps_z, training=True, new_stats={}),
+                              x0, tt, noise, c=c, rep_cond=True, causal_modeling=False, kl_weight=0.3)
+    terms["loss"].mean().backward()
+    for k in ("loss", "mse", "kld_rep"):
+        close(terms[k].detach().numpy(), g[f"diffae/train/{k}"], 1e-4, 1e-5)
+    for k in ("rep_emb.fc_var.weight", "up_emb.weight", "out.2.weight"):
+        probe_close(sd[k].grad, g, f"diffae/train/grad/{k}", 1e-6, 1e-3)
+    with torch.no_grad():
+        mu, var = U.encode(sd, x0, U.n_encoder_layers(sd), False, None)
+        mu[:, 256:512] = 0.4
+        z = U.reparameterize(mu, torch.full_like(mu, 0.001), torch.from_numpy(g["diffae/z_eps"]))
+        close(z.numpy(), g["diffae/z"], 1e-5)
+        sch5 = D.Schedule(1000, "linear", "ddim5", True)
+        x_t = D.q_sample(sch5, x0, torch.full((N,), sch5.T - 1, dtype=torch.int64), noise)
+        out = D.sample_loop(sch5, lambda x, tm: U.unet_forward(sd, cfg, x, tm, y=y, z=z)[0], x_t, ddim=True)
+    close(out.numpy(), g["diffae/sample"], 5e-5)

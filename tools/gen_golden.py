@@ -75,8 +75,9 @@ def make(name, respacing="", masking=False, **extra):
     base.update(extra)
     model, diff = rsu.create_model_and_diffusion(**base)
     # Q1: the committed encoder depth only works at 96/128 px; use the class's own hidden_dims kwarg.
-    dims = encoder_dims(base["image_size"], base["n_vars"])
-    model.rep_emb = rnn.GaussianConvEncoder(base["in_channels"], 512, hidden_dims=dims, num_vars=base["n_vars"])
+    if base["rep_cond"]:
+        dims = encoder_dims(base["image_size"], base["n_vars"])
+        model.rep_emb = rnn.GaussianConvEncoder(base["in_channels"], 512, hidden_dims=dims, num_vars=base["n_vars"])
     load_closed_form(model)
     return model, diff, base
 
@@ -535,7 +536,75 @@ def g10_flow(out_dir):
     np.savez_compressed(os.path.join(out_dir, "g10_flow.npz"), **out)
 
 
-ALL = dict(G1=g1_schedules, G2=g2_temb, G3=g3_blocks, G4=g4_encoder, G5=g5_rep_loss, G6=g6_unet, G7=g7_train, G8=g8_ddim, G9=g9_vlb, G10=g10_flow)
+# --------------------------------------------------------------------------- G11
+def g11_variants(out_dir):
+    """The two sibling model families of the evaluation scripts: label-conditional (context_cond, image_conditional_test.py:112-150)
+    and DiffAE without the causal layer (image_diffae_test.py:262-322)."""
+    out = {}
+    N = 3
+    x0 = synth("G11.x0", (N, 1, 28, 28), 0.0, 1.0)
+    c = synth("G11.c", (N, 2), 0.0, 1.0)
+    y = th.tensor([2, 4, 9], dtype=th.int64)
+    noise = synth("G11.noise", (N, 1, 28, 28), -1.7, 1.7)
+    tt = th.tensor([10, 400, 990], dtype=th.int64)
+    # (a) label-conditional; the label vector is CONTEXT_DIM = 4 wide whatever n_vars says (script_util.py:10)
+    c4 = synth("G11.c4", (N, 4), 0.0, 1.0)
+    for phase in ("train", "sample"):
+        model, diff, base = make("T28", respacing="" if phase == "train" else "ddim5", rep_cond=False, causal_modeling=False, context_cond=True)
+        if phase == "train":
+            out["cond/keys"] = np.array(list(model.state_dict().keys()))
+            model.train()
+            terms = diff.training_losses(model, x0, tt, model_kwargs=dict(c=c4, y=y), noise=noise)
+            terms["loss"].mean().backward()
+            out["cond/train/loss"], out["cond/train/mse"] = terms["loss"].detach().numpy(), terms["mse"].detach().numpy()
+            params = dict(model.named_parameters())
+            for nme in ("c_emb.0.weight", "c_emb.2.bias", "out.2.weight"):
+                flat_probe(f"cond/train/grad/{nme}", params[nme].grad, out)
+        else:
+            model.eval()
+            t_last = th.full((N,), diff.num_timesteps - 1, dtype=th.int64)
+            x_t = diff.q_sample(x0, t_last, noise=noise)
+            cc = c4.clone()
+            cc[:, 0] = -0.2
+            with th.no_grad():
+                out["cond/sample"] = diff.ddim_sample_loop(model, (N, 1, 28, 28), noise=x_t, clip_denoised=True,
+                                                           model_kwargs=dict(c=cc, y=y)).numpy()
+    # (b) DiffAE: representation conditioning without the causal layer
+    for phase in ("train", "sample"):
+        model, diff, base = make("T28", respacing="" if phase == "train" else "ddim5", causal_modeling=False)
+        if phase == "train":
+            out["diffae/keys"] = np.array(list(model.state_dict().keys()))
+            model.train()
+            diff.kl_weight = 0.3
+            th.manual_seed(21)
+            terms = diff.training_losses(model, x0, tt, model_kwargs=dict(c=c, y=y), noise=noise, rep_cond=True, causal_modeling=False)
+            th.manual_seed(21)
+            out["diffae/eps_draw"] = th.randn(N, 512).numpy()
+            terms["loss"].mean().backward()
+            for k in ("loss", "mse", "kld_rep"):
+                out[f"diffae/train/{k}"] = terms[k].detach().numpy()
+            params = dict(model.named_parameters())
+            for nme in ("rep_emb.fc_var.weight", "up_emb.weight", "out.2.weight"):
+                flat_probe(f"diffae/train/grad/{nme}", params[nme].grad, out)
+        else:
+            model.eval()
+            with th.no_grad():
+                mu, var = model.rep_emb.encode(x0)
+                var = th.ones(mu.shape) * 0.001
+                mu[:, 256:512] = th.ones((N, 256)) * 0.4
+                th.manual_seed(22)
+                z = rnn.reparameterize(mu, var)
+                th.manual_seed(22)
+                out["diffae/z_eps"] = th.randn(N, 512).numpy()
+                out["diffae/z"] = z.numpy()
+                t_last = th.full((N,), diff.num_timesteps - 1, dtype=th.int64)
+                x_t = diff.q_sample(x0, t_last, noise=noise)
+                out["diffae/sample"] = diff.ddim_sample_loop(model, (N, 1, 28, 28), noise=x_t, clip_denoised=True,
+                                                             model_kwargs=dict(c=c, y=y, z=z)).numpy()
+    np.savez_compressed(os.path.join(out_dir, "g11_variants.npz"), **out)
+
+
+ALL = dict(G1=g1_schedules, G2=g2_temb, G3=g3_blocks, G4=g4_encoder, G5=g5_rep_loss, G6=g6_unet, G7=g7_train, G8=g8_ddim, G9=g9_vlb, G10=g10_flow, G11=g11_variants)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
