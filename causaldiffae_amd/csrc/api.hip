@@ -70,6 +70,45 @@ int cdae_conv3x3_fwd(const float* x, long sn, long sy, long sx, long sc, const f
     return cdae_gemm_dispatch(p, stream);
 }
 
+int cdae_conv3x3_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, long sn, long sy, long sx, const unsigned short* w_hi,
+                        const unsigned short* w_lo, const float* bias, const float* res, float* out, long ldo, int out_nchw, int N, int H, int W,
+                        int Cin, int Cout, int stride, int up, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    if (stride != 1 && stride != 2) return cdae_fail("conv3x3: stride must be 1 or 2");
+    if (up && stride != 1) return cdae_fail("conv3x3: fused upsample needs stride 1");
+    const int Ho = up ? 2 * H : (H - 1) / stride + 1, Wo = up ? 2 * W : (W - 1) / stride + 1;
+    if ((long)N * H * W * sx >= (1L << 31)) return cdae_fail("conv3x3_fwd_ps: activation larger than 2^31 elements");
+    if (sx % 8 || sy % 8 || sn % 8 || !aligned16(x_hi) || !aligned16(x_lo) || !aligned16(w_hi) || !aligned16(w_lo))
+        return cdae_fail("conv3x3_fwd_ps: planes must be 16-byte aligned with pixel pitch % 8 == 0");
+    GemmParams p = base_params();
+    p.presplit = 1;
+    p.A = reinterpret_cast<const float*>(x_hi); p.A_lo = x_lo; p.B = reinterpret_cast<const float*>(w_hi); p.B_lo = w_lo;
+    p.C = out; p.bias = bias; p.res = res;
+    p.M = N * Ho * Wo; p.N = Cout; p.K = 9 * Cin;
+    p.ldb = 9L * Cin; p.ldc = ldo;
+    p.out_mode = out_nchw ? OUT_NCHW : OUT_ROWMAJOR; p.out_hw = Ho * Wo;
+    p.amode = A_CONV_VEC; p.bmode = B_PLAIN_KC;
+    p.conv_M = p.M; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.up = up;
+    p.sn = sn; p.sy = sy; p.sx = sx; p.sc = 1;
+    set_splitk(p, out_nchw ? nullptr : splitk_ws, splitk_ws_bytes);
+    if (out_nchw && res) return cdae_fail("conv3x3: residual with NCHW output unsupported");
+    return cdae_gemm_dispatch(p, stream);
+}
+
+int cdae_linear_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, long ldx, const unsigned short* w_hi, const unsigned short* w_lo,
+                       long ldw, const float* bias, const float* res, float* y, long ldy, int M, int N, int K, float alpha, int act,
+                       float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    if ((long)M * ldx >= (1L << 31)) return cdae_fail("linear_fwd_ps: activation larger than 2^31 elements");
+    if (!aligned16(x_hi) || !aligned16(x_lo) || !aligned16(w_hi) || !aligned16(w_lo)) return cdae_fail("linear_fwd_ps: planes must be 16-byte aligned");
+    GemmParams p = base_params();
+    p.presplit = 1;
+    p.A = reinterpret_cast<const float*>(x_hi); p.A_lo = x_lo; p.B = reinterpret_cast<const float*>(w_hi); p.B_lo = w_lo;
+    p.C = y; p.bias = bias; p.res = res;
+    p.M = M; p.N = N; p.K = K; p.lda = ldx; p.ldb = ldw; p.ldc = ldy; p.alpha = alpha; p.act = act;
+    p.amode = A_PLAIN_KC; p.bmode = B_PLAIN_KC;
+    set_splitk(p, splitk_ws, splitk_ws_bytes);
+    return cdae_gemm_dispatch(p, stream);
+}
+
 int cdae_conv3x3_dgrad(const float* dy, long lddy, const float* w, float* dx, long lddx, int N, int H, int W, int Cin, int Cout,
                        int stride, int up, int accumulate, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
     const int Ho = up ? 2 * H : (H - 1) / stride + 1, Wo = up ? 2 * W : (W - 1) / stride + 1;   // dy grid

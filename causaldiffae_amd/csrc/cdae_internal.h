@@ -36,6 +36,10 @@ struct GemmParams {
     int grad_operand;       // one operand is a gradient tensor (range unsafe for f16): split mode uses bf16 planes
     int prec;               // -1: library default (env CDAE_IGEMM_PREC), 0: fp32 MFMA, 1: f16x3 split precision (K-contiguous operand pairs only)
     float* splitk_ws; size_t splitk_ws_bytes;
+    // pre-split operands (ps_kernel): A / B point at the hi f16 planes, A_lo / B_lo at the lo planes (same strides, in elements)
+    int presplit;
+    int dbg;                // dev ablations of ps_kernel (env CDAE_PS_DBG): 1 A rows -> one hot line, 2 B rows -> hot, 4 no loads after the first
+    const unsigned short* A_lo; const unsigned short* B_lo;
 };
 
 int cdae_gemm_dispatch(GemmParams p, void* stream);

@@ -27,6 +27,19 @@ __global__ void silu_bwd_kernel(const float* __restrict__ x, const float* __rest
     GRID_STRIDE(i, n) { float v = x[i], s = 1.f / (1.f + expf(-v)); dx[i] = dy[i] * s * (1.f + v * (1.f - s)); }
 }
 
+// fp32 -> two f16 planes (hi = f16(x), lo = f16(x - hi)): the operand format of the pre-split GEMM kernel (weights, once per version)
+typedef _Float16 ew_half4 __attribute__((ext_vector_type(4)));
+__global__ void split_f16_kernel(const float4* __restrict__ src, ew_half4* __restrict__ hi, ew_half4* __restrict__ lo, long n4) {
+    GRID_STRIDE(i, n4) {
+        const float4 v = src[i];
+        ew_half4 h, l;
+        h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+        l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]);
+        l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);
+        hi[i] = h; lo[i] = l;
+    }
+}
+
 // generic pointwise activations on a stored pre-activation (codes = the GEMM epilogue's: 1 SiLU, 2 LeakyReLU(0.01), 3 ReLU, 4 sigmoid)
 __device__ inline float act_apply(float v, int kind) {
     if (kind == 1) return v / (1.f + expf(-v));
@@ -394,6 +407,10 @@ __global__ void mse_rows_bwd_kernel(const float* __restrict__ a, const float* __
 
 extern "C" {
 
+int cdae_split_f16(const float* src, unsigned short* hi, unsigned short* lo, long n, void* stream) {
+    if (n % 4 || (((size_t)src | (size_t)hi | (size_t)lo) & 7)) return cdae_fail("split_f16: n % 4 == 0 and 8-byte aligned planes required");
+    LAUNCH1D(split_f16_kernel, n / 4, (const float4*)src, (ew_half4*)hi, (ew_half4*)lo, n / 4);
+}
 int cdae_act_fwd(const float* x, float* y, long n, int kind, void* stream) { LAUNCH1D(act_kernel, n, x, y, n, kind); }
 int cdae_act_bwd(const float* x, const float* dy, float* dx, long n, int kind, void* stream) { LAUNCH1D(act_bwd_kernel, n, x, dy, dx, n, kind); }
 int cdae_silu_fwd(const float* x, float* y, long n, void* stream) { LAUNCH1D(silu_kernel, n, x, y, n); }

@@ -604,6 +604,231 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// ps_kernel: the same f16x3 product on operands that are ALREADY split into f16 planes in HBM (activations by the
+// producing GroupNorm kernel, weights once per weight version).  The main loop then has no conversion VALU and no
+// register staging: every 16-byte piece of a tile goes global -> LDS by LDS-DMA (global_load_lds_dwordx4), the planes
+// keep the [rows][64 B] image of the in-kernel-split path (16-B chunks XOR-swizzled by (row>>2)&3 — applied on the
+// per-lane SOURCE address, the LDS destination of a DMA is lane-linear), and the fragment reads / MFMAs are unchanged.
+// One barrier per 32-deep step: wait own DMAs -> barrier -> issue the next stage's DMAs -> 12 MFMAs per wave.
+// The conv gather's per-row tap offsets (9 per output pixel, -1 = padding) are computed once into an LDS table.
+__device__ __attribute__((aligned(16))) unsigned g_zero_ps[4] = {0u, 0u, 0u, 0u};
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NPL, int STAGES>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void ps_kernel(const GemmParams p) {
+    constexpr int THREADS = 64 * WAVES_M * WAVES_N, RPP = THREADS / 4;  // RPP = tile rows covered by one DMA pass of the block
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
+    static_assert(STAGES == 2 || STAGES == 3, "2 stages: one __syncthreads per step; 3 stages: DMAs stay in flight across a raw barrier");
+    constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;                // bytes per 16-bit plane
+    constexpr int STAGE = NPL * (A_PLANE + B_PLANE);
+    constexpr int A_P = BM / RPP, B_P = BN / RPP;                      // 16-byte pieces per thread per plane
+    static_assert(A_P >= 1 && B_P >= 1, "tile smaller than one DMA pass");
+    typedef const unsigned short* hp;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const lds = reinterpret_cast<char*>(smem);
+    int* const taptab = reinterpret_cast<int*>(lds + STAGES * STAGE);  // [taps][BM] element offsets, -1 = zero row
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    const int nmt = (p.M + BM - 1) / BM, nnt = (p.N + BN - 1) / BN;
+    int mt, nt, ks;
+    {
+        const unsigned G = gridDim.x, b = blockIdx.x;
+        const unsigned q = G >> 3, r = G & 7, x = b & 7;
+        unsigned v = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+        nt = v % nnt; v /= nnt;
+        mt = v % nmt; ks = v / nmt;
+    }
+    const int m0 = mt * BM, n0 = nt * BN;
+    const hp a_hi = reinterpret_cast<hp>(p.A), a_lo = p.A_lo;
+    const hp b_hi = reinterpret_cast<hp>(p.B), b_lo = p.B_lo;
+    // padding rows read a zero page.  The select is done on the element OFFSET (zero page expressed relative to each plane):
+    // selecting between two pointers makes hipcc branch around two different load forms.
+    const hp zero = reinterpret_cast<hp>(g_zero_ps);
+    const long za_hi = zero - a_hi, za_lo = NPL == 2 ? zero - a_lo : 0, zb_hi = zero - b_hi, zb_lo = NPL == 2 ? zero - b_lo : 0;
+
+    const int taps = p.amode == A_CONV_VEC ? 9 : 1;
+    const int cpt = (taps == 9 ? p.Cin : p.K) / BK;                    // 32-deep steps per tap
+    const int nk_total = taps * cpt;
+    const int nk_per = (nk_total + p.ksplit - 1) / p.ksplit;
+    const int kt_begin = ks * nk_per;
+    const int kt_end = min(nk_total, kt_begin + nk_per);
+
+    for (int idx = tid; idx < taps * BM; idx += THREADS) {
+        const int tap = idx / BM, row = idx - tap * BM, m = m0 + row;
+        int off = -1;
+        if (taps == 1) { if (m < p.M) off = m * (int)p.lda; }
+        else {
+            const PixRow r = make_pixrow(p, m);
+            long o;
+            const bool ok = tap_offset(p, r, tap / 3, tap - 3 * (tap / 3), o);
+            if (ok && r.ok) off = (int)o;
+        }
+        if ((p.dbg & 1) && off >= 0) off = (row & 15) * 64;
+        taptab[idx] = off;
+    }
+
+    // B rows are loop invariant: per piece a running pointer (or the zero page for rows >= N)
+    long boff[B_P];                // element offset of this thread's piece in the weight planes
+    bool bok[B_P];
+#pragma unroll
+    for (int q = 0; q < B_P; ++q) {
+        const int row = (tid >> 2) + RPP * q, c = (tid & 3) ^ ((row >> 2) & 3);
+        bok[q] = n0 + row < p.N;
+        boff[q] = (long)(bok[q] ? n0 + row : 0) * p.ldb + (long)kt_begin * BK + c * 8;
+    }
+    int acol[A_P];                 // this thread's 16-byte chunk inside the 32-deep k slice, in elements
+#pragma unroll
+    for (int q = 0; q < A_P; ++q) { const int row = (tid >> 2) + RPP * q; acol[q] = 8 * ((tid & 3) ^ ((row >> 2) & 3)); }
+
+    auto dma = [&](hp src, char* dst_wave_base) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst_wave_base, 16, 0, 0);
+    };
+    // issue the DMAs of one 32-deep step (tap, channel offset kc) into `stage`; B pointers advance by one step
+    auto issue = [&](int stage, int tap, int kc) {
+        char* const sa = lds + stage * STAGE;
+        char* const sb = sa + NPL * A_PLANE;
+#pragma unroll
+        for (int q = 0; q < A_P; ++q) {
+            const int off = taptab[tap * BM + (tid >> 2) + RPP * q];
+            const long e = (long)off + kc + acol[q];
+            const bool ok = off >= 0;
+            char* const dst = sa + (q * THREADS + wave * 64) * 16;
+            dma(a_hi + (ok ? e : za_hi), dst);
+            if constexpr (NPL == 2) dma(a_lo + (ok ? e : za_lo), dst + A_PLANE);
+        }
+#pragma unroll
+        for (int q = 0; q < B_P; ++q) {
+            char* const dst = sb + (q * THREADS + wave * 64) * 16;
+            dma(b_hi + (bok[q] ? boff[q] : zb_hi), dst);
+            if constexpr (NPL == 2) dma(b_lo + (bok[q] ? boff[q] : zb_lo), dst + B_PLANE);
+            boff[q] += (p.dbg & 2) ? 0 : BK;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int tap = kt_begin / cpt, chunk = kt_begin - tap * cpt;            // position of the NEXT step to issue
+    auto advance = [&]() { ++chunk; const bool wrap = chunk == cpt; chunk = wrap ? 0 : chunk; tap += wrap ? 1 : 0; };
+
+    __syncthreads();                                                   // tap table visible
+    constexpr int G = NPL * (A_P + B_P);                               // DMAs per wave per step
+    const bool nodma = (p.dbg & 4) != 0;
+    auto issue_next = [&](int stage) { issue(stage, (p.dbg & 1) ? 0 : tap, (p.dbg & 1) ? 0 : chunk * BK); advance(); };
+    if (kt_begin < kt_end) issue_next(0);
+    if constexpr (STAGES == 3) { if (kt_begin + 1 < kt_end) issue_next(1); }
+
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        if constexpr (STAGES == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's DMAs of stage `cur` have landed
+            __syncthreads();                                           // ... everyone's have, and stage cur^1 is no longer read
+            if (kt + 1 < kt_end && !nodma) issue_next(cur ^ 1);
+        } else {
+            // stage kt landed when at most the G DMAs of stage kt+1 are still outstanding; the barrier also tells that every
+            // wave is done reading stage kt-1 == (kt+2) % 3, which the next DMAs overwrite.  No vmcnt(0) in the loop.
+            if (kt + 1 < kt_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(p.dbg & 8)) __builtin_amdgcn_s_barrier();
+            if (kt + 2 < kt_end && !nodma) issue_next(cur == 0 ? 2 : cur - 1);
+        }
+
+        const char* ac = lds + cur * STAGE;
+        const char* bc = ac + NPL * A_PLANE;
+        auto frag = [&](const char* plane, int row0, int sk) -> u16x8 {
+            const int row = (p.dbg & 16) ? 0 : row0 + l31;             // dbg 16: every lane reads the same 16 bytes (LDS broadcast, no bandwidth)
+            return *reinterpret_cast<const u16x8*>(plane + row * 64 + 16 * ((2 * sk + hh) ^ ((row >> 2) & 3)));
+        };
+        auto mma = [&](const u16x8& x, const u16x8& y, const f32x16& c) -> f32x16 {
+            return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, x), __builtin_bit_cast(half8, y), c, 0, 0, 0);
+        };
+#pragma unroll
+        for (int sk = 0; sk < 2; ++sk) {
+            u16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = frag(ac, wm * WM + i * 32, sk);
+                if constexpr (NPL == 2) al[i] = frag(ac + A_PLANE, wm * WM + i * 32, sk);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[j] = frag(bc, wn * WN + j * 32, sk);
+                if constexpr (NPL == 2) bl[j] = frag(bc + B_PLANE, wn * WN + j * 32, sk);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (NPL == 2) {
+                        acc[i][j] = mma(al[i], bh[j], acc[i][j]);        // same order as the in-kernel-split path: bit-identical sums
+                        acc[i][j] = mma(ah[i], bl[j], acc[i][j]);
+                    }
+                    acc[i][j] = mma(ah[i], bh[j], acc[i][j]);
+                }
+        }
+        cur = cur + 1 == STAGES ? 0 : cur + 1;
+    }
+
+    // ---------------------------------------------------------------- epilogue (as igemm_kernel's, K-contiguous case)
+    float* __restrict__ Cg;
+    const float* __restrict__ Rg = nullptr;
+    if (p.ksplit > 1) Cg = p.splitk_ws + (long)ks * (long)p.M * p.N;
+    else { Cg = p.C; Rg = p.res; }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * WN + j * 32 + l31;
+            if (col >= p.N) continue;
+            const float bv = (p.ksplit == 1 && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (row >= p.M) continue;
+                if (p.ksplit > 1) { Cg[(long)row * p.N + col] = acc[i][j][r]; continue; }
+                long addr;
+                if (p.out_mode == OUT_NCHW) {
+                    int img = row / p.out_hw, pix = row - img * p.out_hw;
+                    addr = ((long)img * p.N + col) * p.out_hw + pix;
+                } else addr = (long)row * p.ldc + col;
+                float v = acc[i][j][r] * p.alpha + bv;
+                if (Rg) v += Rg[addr];
+                if (p.act == ACT_SILU) v = v / (1.f + expf(-v));
+                else if (p.act == ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
+                if (p.accumulate) v += Cg[addr];
+                Cg[addr] = v;
+            }
+        }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NPL, int STAGES>
+int launch_ps(const GemmParams& p, hipStream_t st) {
+    const int taps = p.amode == A_CONV_VEC ? 9 : 1;
+    constexpr size_t tiles = (size_t)STAGES * NPL * (BM + BN) * 64;
+    const size_t smem = tiles + (size_t)taps * BM * sizeof(int);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ps_kernel<BM, BN, WAVES_M, WAVES_N, NPL, STAGES>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(tiles + 9 * BM * sizeof(int))) != hipSuccess)
+            return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
+        attr_done = true;
+    }
+    dim3 grid((unsigned)((long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.ksplit));
+    hipLaunchKernelGGL((ps_kernel<BM, BN, WAVES_M, WAVES_N, NPL, STAGES>), grid, dim3(64 * WAVES_M * WAVES_N), smem, st, p);
+    return hipGetLastError() == hipSuccess ? 0 : cdae_fail("ps_kernel launch failed");
+}
+
 // split-K finish: C = alpha * sum_s slab[s] + bias (+res) (-> act), deterministic order
 __global__ void splitk_reduce_kernel(const GemmParams p) {
     long total = (long)p.batch * p.M * p.N;
@@ -712,6 +937,15 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
         const int mode = cdae_get_default_precision();
         p.prec = mode == CDAE_PREC_FP32 ? 0 : mode == CDAE_PREC_MIXED16 ? (p.grad_operand ? 4 : 3) : (p.grad_operand ? 2 : 1);
     }
+    if (p.presplit) {
+        static const int cfg_dbg = getenv("CDAE_PS_DBG") ? atoi(getenv("CDAE_PS_DBG")) : 0;
+        p.dbg = cfg_dbg;
+        if (!((p.amode == A_CONV_VEC || p.amode == A_PLAIN_KC) && p.bmode == B_PLAIN_KC) || p.batch != 1)
+            return cdae_fail("pre-split operands: only K-contiguous conv / plain GEMMs without batch");
+        const int kin = p.amode == A_CONV_VEC ? p.Cin : p.K;
+        if (kin % BK || p.K % BK || p.ldb % 8 || (p.amode == A_PLAIN_KC && p.lda % 8) || (p.prec != 1 && p.prec != 3))
+            return cdae_fail("pre-split operands: need K (Cin) % 32 == 0, 16-byte aligned rows and an f16 precision mode");
+    }
     if (p.amode == A_PLAIN_MC && p.M % 4) p.a_scalar = 1;          // vector k-major loaders read 4 rows / columns at once
     if (p.bmode != B_PLAIN_KC && p.N % 4) p.b_scalar = 1;
     const bool scalar = p.a_scalar || p.b_scalar || p.amode == A_CONV_GEN;
@@ -739,7 +973,14 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
     cdae_prof_begin(PROF_IGEMM, 2.0 * p.M * p.N * (double)p.K * p.batch, st);
     int rc = -1;
 #define CASE(AM, BM_) if (p.amode == AM && p.bmode == BM_) rc = launch_tiles<AM, BM_>(p, big, scalar, st)
-    CASE(A_PLAIN_KC, B_PLAIN_KC);
+    if (p.presplit) {
+        static const int cfg_tile = getenv("CDAE_PS_TILE") ? atoi(getenv("CDAE_PS_TILE")) : 128;   // 256: measured 6 % slower end to end (1 block per CU)
+        const long tiles_256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
+        const bool huge = cfg_tile == 256 && big && tiles_256 * ks >= 200;            // 256x128 tiles, 1 block / CU, 3-stage DMA ring
+        if (p.prec == 1) rc = huge ? launch_ps<256, 128, 4, 2, 2, 3>(p, st) : big ? launch_ps<128, 128, 2, 4, 2, 2>(p, st) : launch_ps<64, 64, 2, 2, 2, 2>(p, st);
+        else rc = huge ? launch_ps<256, 128, 4, 2, 1, 3>(p, st) : big ? launch_ps<128, 128, 2, 4, 1, 2>(p, st) : launch_ps<64, 64, 2, 2, 1, 2>(p, st);
+    }
+    else CASE(A_PLAIN_KC, B_PLAIN_KC);
     else CASE(A_CONV_VEC, B_PLAIN_KC);
     else CASE(A_CONV_GEN, B_PLAIN_KC);
     else CASE(A_PLAIN_KC, B_PLAIN_MC);

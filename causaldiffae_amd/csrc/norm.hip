@@ -87,12 +87,16 @@ __global__ void gn_finalize_kernel(const float* __restrict__ x, int HW, int ldx,
 // grid (nchunk, N), 256 threads: a thread owns one channel vector for the whole chunk, so the normalisation folds into a
 // per-thread affine (y = x*A + B, the form ATen's CPU kernel uses too) computed once; the pixel loop is pure
 // load / fma / SiLU / store with four independent 16-byte loads in flight and no index arithmetic.
-template <int VEC>
+// SPLIT: the result is written as two f16 planes (hi = f16(v), lo = f16(v - hi), pitch ldy elements each) — the operand format
+// of the pre-split conv / GEMM kernel (igemm.hip ps_kernel), so the consumer's main loop has no conversion work.
+typedef _Float16 gn_half4 __attribute__((ext_vector_type(4)));
+template <int VEC, bool SPLIT = false>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, float* __restrict__ y, int HW, int C, int ldx, int ldy,
                                                         int cpg, int G, int pix_per_block,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        const float* __restrict__ ss, int ld_ss, int do_silu) {
+                                                        const float* __restrict__ ss, int ld_ss, int do_silu,
+                                                        unsigned short* __restrict__ y_hi = nullptr, unsigned short* __restrict__ y_lo = nullptr) {
     const int n = blockIdx.y, E = C / VEC, rows = 256 / E, tid = threadIdx.x;
     const int r = tid / E, e = tid - r * E;
     if (r >= rows) return;
@@ -115,20 +119,26 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     auto apply = [&](float v, int i) { float h = fmaf(v, A[i], B[i]); return do_silu ? silu_f(h) : h; };
     int p = p0 + r;
     if constexpr (VEC == 4) {
+        const long hbase = (long)n * HW * ldy + c;
+        auto put = [&](int pp, const float4& v) {
+            const float r0 = apply(v.x, 0), r1 = apply(v.y, 1), r2 = apply(v.z, 2), r3 = apply(v.w, 3);
+            if constexpr (SPLIT) {
+                gn_half4 hi, lo;
+                hi[0] = (_Float16)r0; hi[1] = (_Float16)r1; hi[2] = (_Float16)r2; hi[3] = (_Float16)r3;
+                lo[0] = (_Float16)(r0 - (float)hi[0]); lo[1] = (_Float16)(r1 - (float)hi[1]);
+                lo[2] = (_Float16)(r2 - (float)hi[2]); lo[3] = (_Float16)(r3 - (float)hi[3]);
+                *reinterpret_cast<gn_half4*>(y_hi + hbase + (long)pp * ldy) = hi;
+                *reinterpret_cast<gn_half4*>(y_lo + hbase + (long)pp * ldy) = lo;
+            } else *reinterpret_cast<float4*>(yp + (long)pp * ldy) = make_float4(r0, r1, r2, r3);
+        };
         for (; p + 3 * rows < p1; p += 4 * rows) {
             float4 v0 = *reinterpret_cast<const float4*>(xp + (long)p * ldx);
             float4 v1 = *reinterpret_cast<const float4*>(xp + (long)(p + rows) * ldx);
             float4 v2 = *reinterpret_cast<const float4*>(xp + (long)(p + 2 * rows) * ldx);
             float4 v3 = *reinterpret_cast<const float4*>(xp + (long)(p + 3 * rows) * ldx);
-            *reinterpret_cast<float4*>(yp + (long)p * ldy) = make_float4(apply(v0.x, 0), apply(v0.y, 1), apply(v0.z, 2), apply(v0.w, 3));
-            *reinterpret_cast<float4*>(yp + (long)(p + rows) * ldy) = make_float4(apply(v1.x, 0), apply(v1.y, 1), apply(v1.z, 2), apply(v1.w, 3));
-            *reinterpret_cast<float4*>(yp + (long)(p + 2 * rows) * ldy) = make_float4(apply(v2.x, 0), apply(v2.y, 1), apply(v2.z, 2), apply(v2.w, 3));
-            *reinterpret_cast<float4*>(yp + (long)(p + 3 * rows) * ldy) = make_float4(apply(v3.x, 0), apply(v3.y, 1), apply(v3.z, 2), apply(v3.w, 3));
+            put(p, v0); put(p + rows, v1); put(p + 2 * rows, v2); put(p + 3 * rows, v3);
         }
-        for (; p < p1; p += rows) {
-            float4 v = *reinterpret_cast<const float4*>(xp + (long)p * ldx);
-            *reinterpret_cast<float4*>(yp + (long)p * ldy) = make_float4(apply(v.x, 0), apply(v.y, 1), apply(v.z, 2), apply(v.w, 3));
-        }
+        for (; p < p1; p += rows) put(p, *reinterpret_cast<const float4*>(xp + (long)p * ldx));
     } else {
         for (; p < p1; p += rows) yp[(long)p * ldy] = apply(xp[(long)p * ldx], 0);
     }
@@ -550,6 +560,25 @@ int cdae_gn_bwd(const float* x, const float* dy, float* dx, int N, int HW, int C
     else hipLaunchKernelGGL(gn_bwd_dx_kernel<1>, dim3(grid_for(total)), dim3(256), 0, st, x, dy, dx, total, HW, C, ldx, lddy, lddx, cpg, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gsum, accumulate_dx);
     cdae_prof_end(PROF_GN, st);
     CHECK_LAUNCH("gn_bwd launch failed");
+    return 0;
+}
+
+int cdae_gn_apply_split(const float* x, unsigned short* y_hi, unsigned short* y_lo, int N, int HW, int C, int ldx, int ldy, int groups,
+                        const float* mean, const float* rstd, const float* gamma, const float* beta, const float* scale_shift, int ld_ss,
+                        int silu, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int cpg = C / groups;
+    if (!(cpg % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0) || C / 4 > 256) return cdae_fail("gn_apply_split: needs channels-per-group % 4 == 0, C <= 1024");
+    const int E = C / 4, rows = 256 / E;
+    int nchunk = HW / (rows * 16);
+    if (nchunk < 1) nchunk = 1;
+    while (nchunk > 1 && (long)nchunk * N > 4096) nchunk >>= 1;
+    const int ppb = (HW + nchunk - 1) / nchunk;
+    cdae_prof_begin(PROF_GN, (double)N * HW * C * 8.0, st);
+    hipLaunchKernelGGL((gn_apply_kernel<4, true>), dim3(nchunk, N), dim3(256), 0, st, x, (float*)nullptr, HW, C, ldx, ldy, cpg, groups, ppb, mean, rstd,
+                       gamma, beta, scale_shift, ld_ss, silu, y_hi, y_lo);
+    cdae_prof_end(PROF_GN, st);
+    CHECK_LAUNCH("gn_apply_split launch failed");
     return 0;
 }
 

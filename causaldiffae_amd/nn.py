@@ -101,6 +101,9 @@ class ConvNd(nn.Module):
         self.bias = nn.Parameter(th.empty(out_channels).uniform_(-bound, bound))
 
     def forward(self, x, res=None, up=False, out_nchw=False):
+        if isinstance(x, ops.SplitAct):
+            assert self.kernel_size == 3
+            return ops.conv3x3_ps(x, self.weight, self.bias, res=res, stride=self.stride, up=up, out_nchw=out_nchw)
         if self.kernel_size == 3:
             return ops.conv3x3(x, self.weight, self.bias, res=res, stride=self.stride, up=up, out_nchw=out_nchw)
         if x.dim() == 3:       # [B, C, T] (AttentionBlock convention)
@@ -131,7 +134,11 @@ class GroupNorm32(nn.Module):
         self.weight = nn.Parameter(th.ones(num_channels))
         self.bias = nn.Parameter(th.zeros(num_channels))
 
-    def forward(self, x, scale_shift=None, silu=False):
+    def forward(self, x, scale_shift=None, silu=False, split=False):
+        """split=True: the caller feeds the result straight into a conv3x3 / 1x1 GEMM; in no-grad f16 modes it is then written
+        as pre-split f16 planes (ops.SplitAct) for the LDS-DMA kernel."""
+        if split and x.dim() == 4 and ops.presplit_ok() and ops.can_split(self.num_channels, self.num_groups):
+            return ops.group_norm_split(x, self.weight, self.bias, scale_shift, silu, self.num_groups, self.eps)
         return ops.group_norm(x, self.weight, self.bias, scale_shift, silu, self.num_groups, self.eps)
 
 

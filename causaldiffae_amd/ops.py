@@ -6,6 +6,9 @@ the reference's NCHW API while every kernel sees coalesced channel-contiguous ro
 keep the reference's logical [Cout, Cin, 3, 3] shape (state-dict compatible) with channels_last
 storage = OHWI.  Nothing here computes on the host; a CPU tensor raises (see _lib.ptr).
 """
+import os
+import weakref
+
 import torch
 from torch.autograd import Function
 
@@ -604,3 +607,96 @@ class _VbTerms(Function):
 
 def vb_terms(model_out, x_start, x_t, t, tab, T, mean_type, var_type, clip, freeze_mean):
     return _VbTerms.apply(model_out, x_start, x_t, t, tab, T, mean_type, var_type, clip, freeze_mean)
+
+# ----------------------------------------------------------------------------- pre-split operand path (inference)
+class SplitAct:
+    """An activation stored as two f16 planes, x = hi + lo (2^-22 relative): what the pre-split GEMM kernel consumes.
+    hi / lo are dense [N, H, W, C] half tensors; `shape` is the logical [N, C, H, W]."""
+    __slots__ = ("hi", "lo", "shape")
+
+    def __init__(self, hi, lo, shape):
+        self.hi, self.lo, self.shape = hi, lo, tuple(shape)
+
+
+_WSPLIT = {}
+_PRESPLIT_ON = os.environ.get("CDAE_PRESPLIT", "1") != "0"      # dev switch: 0 = in-kernel split everywhere
+_WEIGHT_EPOCH = [0]
+
+
+def bump_weight_epoch():
+    """Called by whoever rewrites parameter storage behind autograd's back (the fused optimizer kernel)."""
+    _WEIGHT_EPOCH[0] += 1
+
+
+def split_weight(w):
+    """(hi, lo) f16 planes of a weight in its PHYSICAL element order (OHWI for channels_last 3x3 weights, [N][K] for linear /
+    1x1 weights).  Cached per tensor object (weak reference) and validated against (storage pointer, autograd version,
+    weight epoch), so a new tensor that happens to reuse a freed address never sees stale planes."""
+    assert w.is_contiguous() or (w.dim() == 4 and w.permute(0, 2, 3, 1).is_contiguous()), "split_weight needs a dense weight"
+    tag = (w.data_ptr(), w._version, _WEIGHT_EPOCH[0])
+    hit = _WSPLIT.get(id(w))
+    if hit is not None and hit[0]() is w and hit[1] == tag:
+        return hit[2], hit[3]
+    n = w.numel()
+    planes = torch.empty((2, n), dtype=torch.float16, device=w.device)
+    check(lib.cdae_split_f16(ptr(w), ptr(planes[0]), ptr(planes[1]), n, stream()))
+    if len(_WSPLIT) > 4096:
+        for k in [k for k, v in _WSPLIT.items() if v[0]() is None]:
+            del _WSPLIT[k]
+    _WSPLIT[id(w)] = (weakref.ref(w), tag, planes[0], planes[1])
+    return planes[0], planes[1]
+
+
+def presplit_ok():
+    """The pre-split path applies to no-grad forwards in the f16 precision modes."""
+    from ._lib import get_precision
+    return _PRESPLIT_ON and not torch.is_grad_enabled() and get_precision() in ("f16x3", "mixed16")
+
+
+def group_norm_split(x, gamma, beta, scale_shift=None, silu=False, groups=32, eps=1e-5):
+    """GroupNorm (+ scale-shift, + SiLU) whose result is written directly as f16 hi/lo planes (no autograd)."""
+    x = to_nhwc(x)
+    N, C, H, W = x.shape
+    dev = x.device
+    stats = torch.empty((2, N, groups), dtype=torch.float32, device=dev)
+    ws = workspace(dev, "gn", 4 * lib.cdae_gn_workspace_floats(N, C))
+    planes = torch.empty((2, N, H, W, C), dtype=torch.float16, device=dev)
+    st = stream()
+    check(lib.cdae_gn_stats(ptr(x), N, H * W, C, C, groups, eps, ptr(stats[0]), ptr(stats[1]), ptr(ws), st))
+    check(lib.cdae_gn_apply_split(ptr(x), ptr(planes[0]), ptr(planes[1]), N, H * W, C, C, C, groups, ptr(stats[0]), ptr(stats[1]),
+                                  ptr(gamma), ptr(beta), ptr(scale_shift), 2 * C, 1 if silu else 0, st))
+    return SplitAct(planes[0], planes[1], (N, C, H, W))
+
+
+def can_split(C, groups=32):
+    return C % 32 == 0 and (C // groups) % 4 == 0 and C <= 1024
+
+
+def conv3x3_ps(xs, w, b=None, res=None, stride=1, up=False, out_nchw=False):
+    """conv3x3 of a SplitAct with pre-split OHWI weights (no autograd); result fp32 like ops.conv3x3."""
+    N, Cin, H, W = xs.shape
+    Cout = w.shape[0]
+    w_hi, w_lo = split_weight(ohwi(w))                 # channels_last storage == OHWI (ohwi() returns w itself then: cached)
+    Ho = 2 * H if up else (H - 1) // stride + 1
+    Wo = 2 * W if up else (W - 1) // stride + 1
+    dev = xs.hi.device
+    out = torch.empty((N, Cout, Ho, Wo), dtype=torch.float32, device=dev) if out_nchw else new_act(N, Cout, Ho, Wo, dev)
+    if res is not None:
+        res = to_nhwc(res)
+    ws, wsb = _sk(dev)
+    check(lib.cdae_conv3x3_fwd_ps(ptr(xs.hi), ptr(xs.lo), H * W * Cin, W * Cin, Cin, ptr(w_hi), ptr(w_lo), ptr(b), ptr(res), ptr(out), Cout,
+                                  1 if out_nchw else 0, N, H, W, Cin, Cout, stride, 1 if up else 0, ws, wsb, stream()))
+    return out
+
+
+def linear_ps(xs, w, b=None, res=None, act=ACT_NONE):
+    """y = act(rows(xs) @ w^T + b + res) for a SplitAct seen as [N*H*W, C] rows (no autograd)."""
+    N, C, H, W = xs.shape
+    M, Nf = N * H * W, w.shape[0]
+    assert w.numel() == Nf * C and w.is_contiguous()
+    w_hi, w_lo = split_weight(w)
+    y = torch.empty((M, Nf), dtype=torch.float32, device=xs.hi.device)
+    ws, wsb = _sk(xs.hi.device)
+    check(lib.cdae_linear_fwd_ps(ptr(xs.hi), ptr(xs.lo), C, ptr(w_hi), ptr(w_lo), C, ptr(b), ptr(res), ptr(y), Nf, M, Nf, C, 1.0, act,
+                                 ws, wsb, stream()))
+    return y

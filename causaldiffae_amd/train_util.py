@@ -15,7 +15,7 @@ import numpy as np
 import torch as th
 import torch.distributed as dist
 
-from . import dist_util, logger
+from . import dist_util, logger, ops
 from ._lib import check, lib, ptr, stream
 from .resample import LossAwareSampler, UniformSampler
 
@@ -141,6 +141,7 @@ class FusedAdamWEMA:
                                  self.t, self.ema_rates[0] if self.ema else 0.0, 1.0, stream()))
         for rate, e in zip(self.ema_rates[1:], self.ema[1:]):
             e.mul_(rate).add_(f.flat, alpha=1 - rate)
+        ops.bump_weight_epoch()          # parameter storage was rewritten by a raw kernel: cached pre-split weight planes are stale
 
     def ema_state_dict(self, i):
         """EMA weights under the model's parameter names / shapes (buffers copied from the live model)."""
@@ -157,6 +158,7 @@ class FusedAdamWEMA:
                 dist.broadcast(e, 0)
             for b in self.model.buffers():
                 dist.broadcast(b, 0)
+        ops.bump_weight_epoch()
 
 
 def linear_kl_weight(step, total_steps=50000, initial=0.0, final=1.0):

@@ -116,13 +116,13 @@ class ResBlock(TimestepBlock):
 
     def _forward(self, x, emb):
         x = ops.to_nhwc(x)
-        h = self.in_layers[0](x, silu=True)                        # GN + SiLU
+        h = self.in_layers[0](x, silu=True, split=True)            # GN + SiLU (pre-split f16 planes on the inference path)
         h = self.in_layers[2](h)                                   # conv3x3 + bias
         emb_out = self.emb_layers[1](ops.silu(emb))                # [N, (2)Cout]
         if self.use_scale_shift_norm:
-            h = self.out_layers[0](h, scale_shift=emb_out, silu=True)
+            h = self.out_layers[0](h, scale_shift=emb_out, silu=True, split=True)
         else:
-            h = self.out_layers[0](h + emb_out[:, :, None, None], silu=True)
+            h = self.out_layers[0](h + emb_out[:, :, None, None], silu=True, split=True)
         h = self.out_layers[2](h)
         skip = x if isinstance(self.skip_connection, Identity) else self.skip_connection(x)
         return self.out_layers[3](h, res=skip)                     # conv3x3 + bias + residual
@@ -155,9 +155,12 @@ class AttentionBlock(nn.Module):
         x = ops.to_nhwc(x)
         N, C, H, W = x.shape
         T = H * W
-        h = self.norm(x)                                                            # GN, no activation
-        rows = h.permute(0, 2, 3, 1).reshape(N * T, C)
-        qkv = ops.linear(rows, self.qkv.weight, self.qkv.bias)                      # [N*T, 3C]; channel = head*3ch + {q,k,v}*ch + d
+        h = self.norm(x, split=True)                                                # GN, no activation
+        if isinstance(h, ops.SplitAct):
+            qkv = ops.linear_ps(h, self.qkv.weight, self.qkv.bias)
+        else:
+            rows = h.permute(0, 2, 3, 1).reshape(N * T, C)
+            qkv = ops.linear(rows, self.qkv.weight, self.qkv.bias)                  # [N*T, 3C]; channel = head*3ch + {q,k,v}*ch + d
         a = ops.qkv_attention(qkv.reshape(N, T, 3 * C), self.num_heads)            # [N, T, C]
         xr = x.permute(0, 2, 3, 1).reshape(N * T, C)
         out = ops.linear(a.reshape(N * T, C), self.proj_out.weight, self.proj_out.bias, res=xr)
@@ -311,5 +314,5 @@ class UNetModel(nn.Module):
         h = self.middle_block(h, emb)
         for module in self.output_blocks:
             h = module(ops.cat_channels(h, hs.pop()), emb)
-        h = self.out[0](h, silu=True)
+        h = self.out[0](h, silu=True, split=True)
         return self.out[2](h, out_nchw=True), mu, var, z_post, mask

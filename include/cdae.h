@@ -77,6 +77,20 @@ int cdae_conv3x3_fwd(const float* x, long sn, long sy, long sx, long sc, const f
                      float* splitk_ws, size_t splitk_ws_bytes, void* stream);
 /* dgrad: dx[N,H,W,Cin] (pitch lddx) from dy[N,Ho,Wo,Cout] (pitch lddy).  For up=1 dx is the gradient w.r.t.
  * the UPSAMPLED input [N,2H,2W,Cin]; follow with cdae_sumpool2. accumulate: dx += . */
+/* Pre-split operand path (inference): the same f16x3 products on operands already stored as two f16 planes (hi = f16(x),
+   lo = f16(x - hi)) — activations by cdae_gn_apply_split, weights by cdae_split_f16 once per weight version.  Tiles go
+   global -> LDS by LDS-DMA with no conversion work in the main loop; results are bit-identical to cdae_conv3x3_fwd /
+   cdae_linear_fwd in f16x3 mode.  Strides in elements of a plane; Cin (K) % 32 == 0, pixel pitch % 8 == 0. */
+int cdae_conv3x3_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, long sn, long sy, long sx, const unsigned short* w_hi,
+                        const unsigned short* w_lo, const float* bias, const float* res, float* out, long ldo, int out_nchw, int N, int H, int W,
+                        int Cin, int Cout, int stride, int up, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
+int cdae_linear_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, long ldx, const unsigned short* w_hi, const unsigned short* w_lo,
+                       long ldw, const float* bias, const float* res, float* y, long ldy, int M, int N, int K, float alpha, int act,
+                       float* splitk_ws, size_t splitk_ws_bytes, void* stream);
+int cdae_split_f16(const float* src, unsigned short* hi, unsigned short* lo, long n, void* stream);
+int cdae_gn_apply_split(const float* x, unsigned short* y_hi, unsigned short* y_lo, int N, int HW, int C, int ldx, int ldy, int groups,
+                        const float* mean, const float* rstd, const float* gamma, const float* beta, const float* scale_shift, int ld_ss,
+                        int silu, void* stream);
 int cdae_conv3x3_dgrad(const float* dy, long lddy, const float* w, float* dx, long lddx, int N, int H, int W, int Cin, int Cout,
                        int stride, int up, int accumulate, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
 /* wgrad: dw (OHWI) (+)= dy^T * im2col(x);  dbias (+)= column sums of dy (may be NULL). */

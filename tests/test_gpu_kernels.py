@@ -255,3 +255,100 @@ def test_device_feed_matches_host_feed(shape, div, shift):
             assert torch.equal(cd[k].cpu(), ch[k])
     from causaldiffae_amd import ops
     assert ops.is_nhwc(xd) or shape[3] == 1
+
+
+# ------------------------------------------------------------------ pre-split operand path (LDS-DMA kernel)
+def _split_nhwc(x):
+    """fp32 logical [N,C,H,W] (NHWC storage) -> ops.SplitAct through cdae_split_f16."""
+    from causaldiffae_amd import ops
+    from causaldiffae_amd._lib import check, lib, ptr, stream
+    x = ops.to_nhwc(x)
+    N, C, H, W = x.shape
+    planes = torch.empty((2, N, H, W, C), dtype=torch.float16, device=x.device)
+    check(lib.cdae_split_f16(ptr(x), ptr(planes[0]), ptr(planes[1]), x.numel(), stream()))
+    return ops.SplitAct(planes[0], planes[1], (N, C, H, W))
+
+
+@pytest.mark.gpu
+def test_split_f16_planes():
+    x = (torch.randn(4, 64, 8, 8, device="cuda:0") * 3).contiguous(memory_format=torch.channels_last)
+    s = _split_nhwc(x)
+    xr = x.permute(0, 2, 3, 1)
+    hi = xr.half()
+    assert torch.equal(s.hi, hi) and torch.equal(s.lo, (xr - hi.float()).half())
+    rec = s.hi.float() + s.lo.float()
+    assert (rec - xr).abs().max().item() <= 2.0 ** -21 * xr.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,Cin,Cout,S,stride,up,res,nchw", [
+    (2, 128, 128, 16, 1, False, False, False),      # 64x64 tiles
+    (8, 128, 256, 32, 1, False, True, False),       # 128x128 tiles, residual epilogue
+    (3, 256, 384, 16, 2, False, False, False),      # stride 2, ragged M
+    (2, 512, 256, 8, 1, True, False, False),        # fused nearest-2x upsample
+    (2, 1024, 512, 8, 1, False, True, False),       # deep K -> split-K slabs
+    (2, 128, 4, 32, 1, False, False, True),         # output head: Cout 4, NCHW result
+    (1, 160, 96, 8, 1, False, False, False),        # Cin = 5 x 32, Cout not a tile multiple
+])
+def test_conv3x3_presplit_is_bit_identical(N, Cin, Cout, S, stride, up, res, nchw):
+    """The LDS-DMA kernel on pre-split planes runs the same products in the same order as the in-kernel split:
+    identical bits, every geometry (and the same split-K choice)."""
+    from causaldiffae_amd import ops
+    from causaldiffae_amd._lib import get_precision, set_precision
+    prev = get_precision()
+    set_precision("f16x3")
+    try:
+        g = torch.Generator(device="cuda:0").manual_seed(5)
+        x = ops.to_nhwc(torch.randn(N, Cin, S, S, device="cuda:0", generator=g))
+        w = (torch.randn(Cout, Cin, 3, 3, device="cuda:0", generator=g) / (9 * Cin) ** 0.5).contiguous(memory_format=torch.channels_last)
+        b = torch.randn(Cout, device="cuda:0", generator=g)
+        So = 2 * S if up else (S - 1) // stride + 1
+        r = ops.to_nhwc(torch.randn(N, Cout, So, So, device="cuda:0", generator=g)) if res else None
+        with torch.no_grad():
+            ref = ops.conv3x3(x, w, b, res=r, stride=stride, up=up, out_nchw=nchw)
+            got = ops.conv3x3_ps(_split_nhwc(x), w, b, res=r, stride=stride, up=up, out_nchw=nchw)
+        assert got.shape == ref.shape and got.stride() == ref.stride()
+        assert torch.equal(got, ref)
+        wf = w.float()
+        exact = F.conv2d(F.interpolate(x.contiguous(), scale_factor=2, mode="nearest") if up else x.contiguous(), wf, b, stride=stride, padding=1)
+        if res:
+            exact = exact + r
+        assert (got - exact).abs().max().item() < 2e-5 * max(1.0, exact.abs().max().item())
+    finally:
+        set_precision(prev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C,S,Nf", [(2, 384, 16, 1152), (1, 512, 8, 1536), (4, 128, 8, 96)])
+def test_linear_presplit_is_bit_identical(N, C, S, Nf):
+    from causaldiffae_amd import ops
+    from causaldiffae_amd._lib import get_precision, set_precision
+    prev = get_precision()
+    set_precision("f16x3")
+    try:
+        g = torch.Generator(device="cuda:0").manual_seed(6)
+        x = ops.to_nhwc(torch.randn(N, C, S, S, device="cuda:0", generator=g))
+        w = torch.randn(Nf, C, 1, device="cuda:0", generator=g) / C ** 0.5
+        b = torch.randn(Nf, device="cuda:0", generator=g)
+        rows = x.permute(0, 2, 3, 1).reshape(N * S * S, C)
+        with torch.no_grad():
+            ref = ops.linear(rows, w, b)
+            got = ops.linear_ps(_split_nhwc(x), w, b)
+        assert torch.equal(got, ref)
+    finally:
+        set_precision(prev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,S,ss,silu", [(128, 16, False, True), (384, 8, True, True), (512, 8, False, False)])
+def test_group_norm_split_matches_fp32_output(C, S, ss, silu):
+    from causaldiffae_amd import ops
+    g = torch.Generator(device="cuda:0").manual_seed(7)
+    x = ops.to_nhwc(torch.randn(3, C, S, S, device="cuda:0", generator=g) * 2 + 0.5)
+    gamma, beta = torch.randn(C, device="cuda:0", generator=g), torch.randn(C, device="cuda:0", generator=g)
+    sc = torch.randn(3, 2 * C, device="cuda:0", generator=g) * 0.3 if ss else None
+    with torch.no_grad():
+        y = ops.group_norm(x, gamma, beta, sc, silu).permute(0, 2, 3, 1)
+        s = ops.group_norm_split(x, gamma, beta, sc, silu)
+    hi = y.half()
+    assert torch.equal(s.hi, hi) and torch.equal(s.lo, (y - hi.float()).half())

@@ -1,0 +1,35 @@
+"""Dev tool: time the pre-split conv kernel on representative layer shapes (env CDAE_PS_DBG selects an ablation)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from causaldiffae_amd import ops
+from causaldiffae_amd._lib import check, lib, ptr, stream
+DEV = "cuda:0"
+B = 128
+
+
+def split(x):
+    x = ops.to_nhwc(x)
+    N, C, H, W = x.shape
+    planes = torch.empty((2, N, H, W, C), dtype=torch.float16, device=x.device)
+    check(lib.cdae_split_f16(ptr(x), ptr(planes[0]), ptr(planes[1]), x.numel(), stream()))
+    return ops.SplitAct(planes[0], planes[1], (N, C, H, W))
+
+
+for (ci, co, r) in [(128, 128, 64), (256, 256, 32), (384, 384, 16), (512, 512, 8), (1024, 512, 8)]:
+    x = torch.randn(B, ci, r, r, device=DEV)
+    xs = split(x)
+    w = (torch.randn(co, ci, 3, 3, device=DEV) / (9 * ci) ** .5).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        for _ in range(3):
+            ops.conv3x3_ps(xs, w, None)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            ops.conv3x3_ps(xs, w, None)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 100
+        fl = 2.0 * B * r * r * co * ci * 9
+        print(f"dbg={os.environ.get('CDAE_PS_DBG','0')} conv {ci}->{co} @{r}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF")
