@@ -71,9 +71,11 @@ int cdae_conv3x3_fwd(const float* x, long sn, long sy, long sx, long sc, const f
 }
 
 int cdae_conv3x3_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, long sn, long sy, long sx, const unsigned short* w_hi,
-                        const unsigned short* w_lo, const float* bias, const float* res, float* out, long ldo, int out_nchw, int N, int H, int W,
+                        const unsigned short* w_lo, const float* bias, const float* res, float* out, long ldo, int out_nchw,
+                        unsigned short* out_hi, unsigned short* out_lo, int N, int H, int W,
                         int Cin, int Cout, int stride, int up, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
     if (stride != 1 && stride != 2) return cdae_fail("conv3x3: stride must be 1 or 2");
+    if (out_hi && (out_nchw || !out_lo)) return cdae_fail("conv3x3_fwd_ps: plane output needs both planes and a row-major result");
     if (up && stride != 1) return cdae_fail("conv3x3: fused upsample needs stride 1");
     const int Ho = up ? 2 * H : (H - 1) / stride + 1, Wo = up ? 2 * W : (W - 1) / stride + 1;
     if ((long)N * H * W * sx >= (1L << 31)) return cdae_fail("conv3x3_fwd_ps: activation larger than 2^31 elements");
@@ -82,7 +84,7 @@ int cdae_conv3x3_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, 
     GemmParams p = base_params();
     p.presplit = 1;
     p.A = reinterpret_cast<const float*>(x_hi); p.A_lo = x_lo; p.B = reinterpret_cast<const float*>(w_hi); p.B_lo = w_lo;
-    p.C = out; p.bias = bias; p.res = res;
+    p.C = out; p.bias = bias; p.res = res; p.C_hi = out_hi; p.C_lo = out_lo;
     p.M = N * Ho * Wo; p.N = Cout; p.K = 9 * Cin;
     p.ldb = 9L * Cin; p.ldc = ldo;
     p.out_mode = out_nchw ? OUT_NCHW : OUT_ROWMAJOR; p.out_hw = Ho * Wo;
@@ -92,6 +94,36 @@ int cdae_conv3x3_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, 
     set_splitk(p, out_nchw ? nullptr : splitk_ws, splitk_ws_bytes);
     if (out_nchw && res) return cdae_fail("conv3x3: residual with NCHW output unsupported");
     return cdae_gemm_dispatch(p, stream);
+}
+
+// nearest-2x upsample + conv3x3 as four 2x2 convolutions of the LOW-resolution input, one per output parity (ph_y, ph_x):
+// rows 2y+ph_y-1 .. 2y+ph_y+1 of the upsampled image are input rows {y-1+ph_y, y+ph_y} with the 3 kernel rows folded 1+2 or
+// 2+1, likewise for columns — 16 instead of 36 multiply-adds per (pixel, channel pair).  w4 = [4 phases][Cout][2][2][Cin]
+// folded weights (hi / lo planes); the result lands in out[N, 2H, 2W, Cout] rows of pitch ldo.
+int cdae_upconv3x3_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, long sn, long sy, long sx, const unsigned short* w4_hi,
+                          const unsigned short* w4_lo, const float* bias, float* out, long ldo, int N, int H, int W, int Cin, int Cout,
+                          float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    if ((long)N * H * W * sx >= (1L << 31)) return cdae_fail("upconv3x3_fwd_ps: activation larger than 2^31 elements");
+    if (sx % 8 || sy % 8 || sn % 8 || !aligned16(x_hi) || !aligned16(x_lo) || !aligned16(w4_hi) || !aligned16(w4_lo))
+        return cdae_fail("upconv3x3_fwd_ps: planes must be 16-byte aligned with pixel pitch % 8 == 0");
+    for (int ph = 0; ph < 4; ++ph) {
+        GemmParams p = base_params();
+        p.presplit = 1; p.ps_taps = 4; p.ph_y = ph >> 1; p.ph_x = ph & 1;
+        const long woff = (long)ph * Cout * 4 * Cin;
+        p.A = reinterpret_cast<const float*>(x_hi); p.A_lo = x_lo;
+        p.B = reinterpret_cast<const float*>(w4_hi + woff); p.B_lo = w4_lo + woff;
+        p.C = out; p.bias = bias;
+        p.M = N * H * W; p.N = Cout; p.K = 4 * Cin;
+        p.ldb = 4L * Cin; p.ldc = ldo;
+        p.out_mode = OUT_UP2;
+        p.amode = A_CONV_VEC; p.bmode = B_PLAIN_KC;
+        p.conv_M = p.M; p.H = H; p.W = W; p.Cin = Cin; p.Ho = H; p.Wo = W; p.stride = 1; p.up = 0;
+        p.sn = sn; p.sy = sy; p.sx = sx; p.sc = 1;
+        set_splitk(p, splitk_ws, splitk_ws_bytes);
+        const int rc = cdae_gemm_dispatch(p, stream);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 int cdae_linear_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, long ldx, const unsigned short* w_hi, const unsigned short* w_lo,
@@ -157,9 +189,11 @@ int cdae_conv3x3_wgrad(const float* x, long sn, long sy, long sx, long sc, const
 }
 
 int cdae_linear_fwd(const float* x, long ldx, const float* w, long ldw, const float* bias, const float* res, float* y, long ldy,
-                    int M, int N, int K, float alpha, int act, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+                    unsigned short* y_hi, unsigned short* y_lo, int M, int N, int K, float alpha, int act, float* splitk_ws,
+                    size_t splitk_ws_bytes, void* stream) {
     GemmParams p = base_params();
-    p.A = x; p.B = w; p.C = y; p.bias = bias; p.res = res;
+    p.A = x; p.B = w; p.C = y; p.bias = bias; p.res = res; p.C_hi = y_hi; p.C_lo = y_lo;
+    if (y_hi && !y_lo) return cdae_fail("linear_fwd: plane output needs both planes");
     p.M = M; p.N = N; p.K = K; p.lda = ldx; p.ldb = ldw; p.ldc = ldy; p.alpha = alpha; p.act = act;
     p.amode = A_PLAIN_KC; p.bmode = B_PLAIN_KC;
     p.a_scalar = !(K % 4 == 0 && ldx % 4 == 0 && aligned16(x));

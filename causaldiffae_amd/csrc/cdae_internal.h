@@ -5,7 +5,7 @@
 
 enum { A_PLAIN_KC = 0, A_CONV_VEC = 1, A_CONV_GEN = 2, A_PLAIN_MC = 3 };
 enum { B_PLAIN_KC = 0, B_PLAIN_MC = 1, B_CONV_MC = 2, B_WDGRAD_MC = 3 };
-enum { OUT_ROWMAJOR = 0, OUT_NCHW = 1 };
+enum { OUT_ROWMAJOR = 0, OUT_NCHW = 1, OUT_UP2 = 2 };
 enum { ACT_NONE = 0, ACT_SILU = 1, ACT_LRELU = 2 };
 
 struct GemmParams {
@@ -38,6 +38,12 @@ struct GemmParams {
     float* splitk_ws; size_t splitk_ws_bytes;
     // pre-split operands (ps_kernel): A / B point at the hi f16 planes, A_lo / B_lo at the lo planes (same strides, in elements)
     int presplit;
+    // optional second output: the result also as f16 hi/lo planes with row pitch ldc (row-major outputs only), so a following
+    // conv can take the pre-split path without a conversion pass
+    unsigned short* C_hi; unsigned short* C_lo;
+    // ps_kernel sub-pixel phase of a nearest-2x-upsample + conv3x3 (ps_taps == 4): 2x2 taps at offset (ph_y, ph_x), and
+    // out_mode OUT_UP2 scatters GEMM row (n, y, x) to output pixel (n, 2y + ph_y, 2x + ph_x)
+    int ps_taps, ph_y, ph_x;
     int dbg;                // dev ablations of ps_kernel (env CDAE_PS_DBG): 1 A rows -> one hot line, 2 B rows -> hot, 4 no loads after the first
     const unsigned short* A_lo; const unsigned short* B_lo;
 };

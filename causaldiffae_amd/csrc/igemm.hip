@@ -94,6 +94,14 @@ __device__ __forceinline__ float ld1_if(const float* /*unused*/, const float* p,
     return *(ok ? p : g_zero16);
 }
 
+// second output of an epilogue: v as f16 hi/lo planes
+__device__ __forceinline__ void store_planes(const GemmParams& p, long addr, float v) {
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    p.C_hi[addr] = __builtin_bit_cast(unsigned short, h);
+    p.C_lo[addr] = __builtin_bit_cast(unsigned short, l);
+}
+
 // SCALAR = element-wise operand loads (odd K / pitch / alignment, tiny channel counts); only built for 64x64 tiles.
 //
 // PREC = 1: "f16x3" split precision for K-contiguous operand pairs.  Each fp32 operand value x is split on its way
@@ -600,6 +608,7 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
                 else if (p.act == ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
                 if (p.accumulate) v += Cg[addr];
                 Cg[addr] = v;
+                if (p.C_hi) store_planes(p, addr, v);
             }
         }
 }
@@ -651,8 +660,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void ps_kernel(const GemmPa
     const hp zero = reinterpret_cast<hp>(g_zero_ps);
     const long za_hi = zero - a_hi, za_lo = NPL == 2 ? zero - a_lo : 0, zb_hi = zero - b_hi, zb_lo = NPL == 2 ? zero - b_lo : 0;
 
-    const int taps = p.amode == A_CONV_VEC ? 9 : 1;
-    const int cpt = (taps == 9 ? p.Cin : p.K) / BK;                    // 32-deep steps per tap
+    const int taps = p.amode == A_CONV_VEC ? (p.ps_taps == 4 ? 4 : 9) : 1;
+    const int cpt = (taps == 1 ? p.K : p.Cin) / BK;                    // 32-deep steps per tap
     const int nk_total = taps * cpt;
     const int nk_per = (nk_total + p.ksplit - 1) / p.ksplit;
     const int kt_begin = ks * nk_per;
@@ -665,7 +674,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void ps_kernel(const GemmPa
         else {
             const PixRow r = make_pixrow(p, m);
             long o;
-            const bool ok = tap_offset(p, r, tap / 3, tap - 3 * (tap / 3), o);
+            // 9 taps: the 3x3 window; 4 taps: the 2x2 window of one sub-pixel phase, shifted by (ph_y, ph_x)
+            const int ky = taps == 9 ? tap / 3 : (tap >> 1) + p.ph_y, kx = taps == 9 ? tap - 3 * (tap / 3) : (tap & 1) + p.ph_x;
+            const bool ok = tap_offset(p, r, ky, kx, o);
             if (ok && r.ok) off = (int)o;
         }
         if ((p.dbg & 1) && off >= 0) off = (row & 15) * 64;
@@ -801,6 +812,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void ps_kernel(const GemmPa
                 if (p.out_mode == OUT_NCHW) {
                     int img = row / p.out_hw, pix = row - img * p.out_hw;
                     addr = ((long)img * p.N + col) * p.out_hw + pix;
+                } else if (p.out_mode == OUT_UP2) {
+                    const int x = row - fdiv(row, p.wo_magic, p.wo_shift) * p.Wo;          // (n, y, x) -> (n, 2y + ph_y, 2x + ph_x)
+                    addr = (4L * row - 2 * x + p.ph_y * 2 * p.Wo + p.ph_x) * p.ldc + col;
                 } else addr = (long)row * p.ldc + col;
                 float v = acc[i][j][r] * p.alpha + bv;
                 if (Rg) v += Rg[addr];
@@ -808,13 +822,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void ps_kernel(const GemmPa
                 else if (p.act == ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
                 if (p.accumulate) v += Cg[addr];
                 Cg[addr] = v;
+                if (p.C_hi) store_planes(p, addr, v);
             }
         }
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int NPL, int STAGES>
 int launch_ps(const GemmParams& p, hipStream_t st) {
-    const int taps = p.amode == A_CONV_VEC ? 9 : 1;
+    const int taps = p.amode == A_CONV_VEC ? (p.ps_taps == 4 ? 4 : 9) : 1;
     constexpr size_t tiles = (size_t)STAGES * NPL * (BM + BN) * 64;
     const size_t smem = tiles + (size_t)taps * BM * sizeof(int);
     static bool attr_done = false;
@@ -843,6 +858,9 @@ __global__ void splitk_reduce_kernel(const GemmParams p) {
         if (p.out_mode == OUT_NCHW) {
             int img = row / p.out_hw, pix = row - img * p.out_hw;
             addr = ((long)img * p.N + col) * p.out_hw + pix;
+        } else if (p.out_mode == OUT_UP2) {
+            const int x = row - fdiv(row, p.wo_magic, p.wo_shift) * p.Wo;
+            addr = (4L * row - 2 * x + p.ph_y * 2 * p.Wo + p.ph_x) * p.ldc + col;
         } else addr = (long)row * p.ldc + col;
         float v = s * p.alpha + (p.bias ? p.bias[col] : 0.f);
         if (p.res) v += (p.res + bo * p.c_bs0 + bi * p.c_bs1)[addr];
@@ -850,6 +868,7 @@ __global__ void splitk_reduce_kernel(const GemmParams p) {
         else if (p.act == ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
         if (p.accumulate) v += Cg[addr];
         Cg[addr] = v;
+        if (p.C_hi) store_planes(p, addr, v);
     }
 }
 

@@ -100,10 +100,10 @@ class ConvNd(nn.Module):
         bound = 1 / math.sqrt(in_channels * kernel_size ** dims)
         self.bias = nn.Parameter(th.empty(out_channels).uniform_(-bound, bound))
 
-    def forward(self, x, res=None, up=False, out_nchw=False):
+    def forward(self, x, res=None, up=False, out_nchw=False, emit_split=False):
         if isinstance(x, ops.SplitAct):
             assert self.kernel_size == 3
-            return ops.conv3x3_ps(x, self.weight, self.bias, res=res, stride=self.stride, up=up, out_nchw=out_nchw)
+            return ops.conv3x3_ps(x, self.weight, self.bias, res=res, stride=self.stride, up=up, out_nchw=out_nchw, emit_split=emit_split)
         if self.kernel_size == 3:
             return ops.conv3x3(x, self.weight, self.bias, res=res, stride=self.stride, up=up, out_nchw=out_nchw)
         if x.dim() == 3:       # [B, C, T] (AttentionBlock convention)

@@ -177,13 +177,13 @@ class _Linear(Function):
         pre = torch.empty_like(y) if (act != ACT_NONE and any(ctx.needs_input_grad[:4])) else None   # grad mode is off inside forward
         ws, wsb = _sk(x.device)
         if pre is not None:      # keep the pre-activation for the backward
-            check(lib.cdae_linear_fwd(ptr(x), x.stride(0), ptr(w), K, ptr(b), ptr(res), ptr(pre), Nf, M, Nf, K, alpha, ACT_NONE, ws, wsb, stream()))
+            check(lib.cdae_linear_fwd(ptr(x), x.stride(0), ptr(w), K, ptr(b), ptr(res), ptr(pre), Nf, None, None, M, Nf, K, alpha, ACT_NONE, ws, wsb, stream()))
             check(lib.cdae_act_fwd(ptr(pre), ptr(y), M * Nf, act, stream()))
         elif act in (ACT_RELU, ACT_SIGMOID):      # not in the GEMM epilogue (cold path): activate in place
-            check(lib.cdae_linear_fwd(ptr(x), x.stride(0), ptr(w), K, ptr(b), ptr(res), ptr(y), Nf, M, Nf, K, alpha, ACT_NONE, ws, wsb, stream()))
+            check(lib.cdae_linear_fwd(ptr(x), x.stride(0), ptr(w), K, ptr(b), ptr(res), ptr(y), Nf, None, None, M, Nf, K, alpha, ACT_NONE, ws, wsb, stream()))
             check(lib.cdae_act_fwd(ptr(y), ptr(y), M * Nf, act, stream()))
         else:
-            check(lib.cdae_linear_fwd(ptr(x), x.stride(0), ptr(w), K, ptr(b), ptr(res), ptr(y), Nf, M, Nf, K, alpha, act, ws, wsb, stream()))
+            check(lib.cdae_linear_fwd(ptr(x), x.stride(0), ptr(w), K, ptr(b), ptr(res), ptr(y), Nf, None, None, M, Nf, K, alpha, act, ws, wsb, stream()))
         ctx.save_for_backward(x, w, pre)
         ctx.cfg = (act, alpha, b is not None, res is not None)
         ctx.sinks = (_sink(w), _sink(b))
@@ -672,8 +672,51 @@ def can_split(C, groups=32):
     return C % 32 == 0 and (C // groups) % 4 == 0 and C <= 1024
 
 
-def conv3x3_ps(xs, w, b=None, res=None, stride=1, up=False, out_nchw=False):
-    """conv3x3 of a SplitAct with pre-split OHWI weights (no autograd); result fp32 like ops.conv3x3."""
+_W4 = {}
+
+
+def fold_upconv_weight(w):
+    """[4 phases][Cout][2][2][Cin] weights of the sub-pixel form of nearest-2x-upsample + conv3x3 (cdae_upconv3x3_fwd_ps): for
+    output parity p the three kernel rows fold as {0 | 1+2} (p = 0) or {0+1 | 2} (p = 1), same for columns.  Cached like
+    split_weight; returns the (hi, lo) planes."""
+    tag = (w.data_ptr(), w._version, _WEIGHT_EPOCH[0])
+    hit = _W4.get(id(w))
+    if hit is not None and hit[0]() is w and hit[1] == tag:
+        return hit[2], hit[3]
+    k = w.detach().permute(0, 2, 3, 1).float()                      # [Cout, 3, 3, Cin]
+    rows = ((k[:, 0:1], k[:, 1:2] + k[:, 2:3]), (k[:, 0:1] + k[:, 1:2], k[:, 2:3]))
+    phases = []
+    for py in (0, 1):
+        r = torch.cat(rows[py], dim=1)                               # [Cout, 2, 3, Cin]
+        cols = ((r[:, :, 0:1], r[:, :, 1:2] + r[:, :, 2:3]), (r[:, :, 0:1] + r[:, :, 1:2], r[:, :, 2:3]))
+        for px in (0, 1):
+            phases.append(torch.cat(cols[px], dim=2))                # [Cout, 2, 2, Cin]
+    w4 = torch.stack(phases, dim=0).contiguous()
+    n = w4.numel()
+    planes = torch.empty((2, n), dtype=torch.float16, device=w.device)
+    check(lib.cdae_split_f16(ptr(w4), ptr(planes[0]), ptr(planes[1]), n, stream()))
+    _W4[id(w)] = (weakref.ref(w), tag, planes[0], planes[1])
+    return planes[0], planes[1]
+
+
+def upconv3x3_ps(xs, w, b=None):
+    """nearest-2x upsample + conv3x3 of a SplitAct as four 2x2 sub-pixel convolutions (2.25x fewer multiply-adds)."""
+    N, Cin, H, W = xs.shape
+    Cout = w.shape[0]
+    w_hi, w_lo = fold_upconv_weight(w)
+    dev = xs.hi.device
+    out = new_act(N, Cout, 2 * H, 2 * W, dev)
+    ws, wsb = _sk(dev)
+    check(lib.cdae_upconv3x3_fwd_ps(ptr(xs.hi), ptr(xs.lo), H * W * Cin, W * Cin, Cin, ptr(w_hi), ptr(w_lo), ptr(b), ptr(out), Cout,
+                                    N, H, W, Cin, Cout, ws, wsb, stream()))
+    return out
+
+
+def conv3x3_ps(xs, w, b=None, res=None, stride=1, up=False, out_nchw=False, emit_split=False):
+    """conv3x3 of a SplitAct with pre-split OHWI weights (no autograd); result fp32 like ops.conv3x3.  emit_split: the result
+    also leaves the kernel as f16 planes, attached as `out._split` for a following conv."""
+    if up and not res and not out_nchw and not emit_split:
+        return upconv3x3_ps(xs, w, b)
     N, Cin, H, W = xs.shape
     Cout = w.shape[0]
     w_hi, w_lo = split_weight(ohwi(w))                 # channels_last storage == OHWI (ohwi() returns w itself then: cached)
@@ -684,9 +727,28 @@ def conv3x3_ps(xs, w, b=None, res=None, stride=1, up=False, out_nchw=False):
     if res is not None:
         res = to_nhwc(res)
     ws, wsb = _sk(dev)
+    planes = torch.empty((2, N, Ho, Wo, Cout), dtype=torch.float16, device=dev) if emit_split else None
     check(lib.cdae_conv3x3_fwd_ps(ptr(xs.hi), ptr(xs.lo), H * W * Cin, W * Cin, Cin, ptr(w_hi), ptr(w_lo), ptr(b), ptr(res), ptr(out), Cout,
-                                  1 if out_nchw else 0, N, H, W, Cin, Cout, stride, 1 if up else 0, ws, wsb, stream()))
+                                  1 if out_nchw else 0, ptr(planes[0]) if emit_split else None, ptr(planes[1]) if emit_split else None,
+                                  N, H, W, Cin, Cout, stride, 1 if up else 0, ws, wsb, stream()))
+    if emit_split:
+        out._split = SplitAct(planes[0], planes[1], (N, Cout, Ho, Wo))
     return out
+
+
+def linear_emit(rows, w, b, res, shape):
+    """y = rows @ w^T + b + res (no autograd) whose result also leaves the kernel as f16 planes: returns (y, SplitAct) for the
+    logical [N, C, H, W] `shape` the rows belong to."""
+    M, K = rows.shape
+    Nf = w.shape[0]
+    N, C, H, W = shape
+    assert rows.stride(1) == 1 and w.numel() == Nf * K and w.is_contiguous() and Nf == C
+    y = torch.empty((M, Nf), dtype=torch.float32, device=rows.device)
+    planes = torch.empty((2, N, H, W, C), dtype=torch.float16, device=rows.device)
+    ws, wsb = _sk(rows.device)
+    check(lib.cdae_linear_fwd(ptr(rows), rows.stride(0), ptr(w), K, ptr(b), ptr(res), ptr(y), Nf, ptr(planes[0]), ptr(planes[1]),
+                              M, Nf, K, 1.0, ACT_NONE, ws, wsb, stream()))
+    return y, SplitAct(planes[0], planes[1], shape)
 
 
 def linear_ps(xs, w, b=None, res=None, act=ACT_NONE):

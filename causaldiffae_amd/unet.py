@@ -75,6 +75,9 @@ class Upsample(nn.Module):
 
     def forward(self, x):
         assert x.shape[1] == self.channels
+        xs = getattr(x, "_split", None)        # pre-split planes left by the producing kernel (inference): sub-pixel form
+        if xs is not None and ops.presplit_ok():
+            return self.conv(xs, up=True)
         return self.conv(x, up=True)           # nearest-2x folded into the conv's input gather
 
 
@@ -88,6 +91,9 @@ class Downsample(nn.Module):
 
     def forward(self, x):
         assert x.shape[1] == self.channels
+        xs = getattr(x, "_split", None)
+        if xs is not None and ops.presplit_ok():
+            return self.op(xs)
         return self.op(x)
 
 
@@ -98,6 +104,7 @@ class ResBlock(TimestepBlock):
         self.channels, self.emb_channels, self.dropout = channels, emb_channels, dropout
         self.out_channels = out_channels or channels
         self.use_conv, self.use_checkpoint, self.use_scale_shift_norm = use_conv, use_checkpoint, use_scale_shift_norm
+        self.emit_split = False        # set by UNetModel when a Down/Upsample conv reads this block's output
         self.in_layers = nn.Sequential(normalization(channels), SiLU(), conv_nd(dims, channels, self.out_channels, 3, padding=1))
         self.emb_layers = nn.Sequential(
             SiLU(), linear(emb_channels, 2 * self.out_channels if use_scale_shift_norm else self.out_channels))
@@ -125,6 +132,8 @@ class ResBlock(TimestepBlock):
             h = self.out_layers[0](h + emb_out[:, :, None, None], silu=True, split=True)
         h = self.out_layers[2](h)
         skip = x if isinstance(self.skip_connection, Identity) else self.skip_connection(x)
+        if isinstance(h, ops.SplitAct):                            # emit_split: a Down/Upsample conv consumes this block's output
+            return self.out_layers[3](h, res=skip, emit_split=self.emit_split)
         return self.out_layers[3](h, res=skip)                     # conv3x3 + bias + residual
 
 
@@ -143,6 +152,7 @@ class AttentionBlock(nn.Module):
     def __init__(self, channels, num_heads=1, use_checkpoint=False):
         super().__init__()
         self.channels, self.num_heads, self.use_checkpoint = channels, num_heads, use_checkpoint
+        self.emit_split = False
         self.norm = normalization(channels)
         self.qkv = conv_nd(1, channels, channels * 3, 1)
         self.attention = QKVAttention()
@@ -163,6 +173,11 @@ class AttentionBlock(nn.Module):
             qkv = ops.linear(rows, self.qkv.weight, self.qkv.bias)                  # [N*T, 3C]; channel = head*3ch + {q,k,v}*ch + d
         a = ops.qkv_attention(qkv.reshape(N, T, 3 * C), self.num_heads)            # [N, T, C]
         xr = x.permute(0, 2, 3, 1).reshape(N * T, C)
+        if self.emit_split and ops.presplit_ok():
+            out, planes = ops.linear_emit(a.reshape(N * T, C), self.proj_out.weight, self.proj_out.bias, xr, (N, C, H, W))
+            out = out.reshape(N, H, W, C).permute(0, 3, 1, 2)
+            out._split = planes
+            return out
         out = ops.linear(a.reshape(N * T, C), self.proj_out.weight, self.proj_out.bias, res=xr)
         return out.reshape(N, H, W, C).permute(0, 3, 1, 2)
 
@@ -239,6 +254,13 @@ class UNetModel(nn.Module):
                 self.output_blocks.append(TimestepEmbedSequential(*layers))
 
         self.out = nn.Sequential(normalization(ch), SiLU(), zero_module(conv_nd(dims, model_channels, out_channels, 3, padding=1)))
+        # producers whose output feeds a resampling conv also emit it as pre-split planes on the inference path
+        for i, blk in enumerate(self.input_blocks):
+            if isinstance(blk[0], Downsample) and isinstance(self.input_blocks[i - 1][-1], (ResBlock, AttentionBlock)):
+                self.input_blocks[i - 1][-1].emit_split = True
+        for blk in self.output_blocks:
+            if isinstance(blk[-1], Upsample) and isinstance(blk[-2], (ResBlock, AttentionBlock)):
+                blk[-2].emit_split = True
 
     # ------------------------------------------------------------------ precision
     def convert_to_fp16(self):

@@ -82,8 +82,14 @@ int cdae_conv3x3_fwd(const float* x, long sn, long sy, long sx, long sc, const f
    global -> LDS by LDS-DMA with no conversion work in the main loop; results are bit-identical to cdae_conv3x3_fwd /
    cdae_linear_fwd in f16x3 mode.  Strides in elements of a plane; Cin (K) % 32 == 0, pixel pitch % 8 == 0. */
 int cdae_conv3x3_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, long sn, long sy, long sx, const unsigned short* w_hi,
-                        const unsigned short* w_lo, const float* bias, const float* res, float* out, long ldo, int out_nchw, int N, int H, int W,
+                        const unsigned short* w_lo, const float* bias, const float* res, float* out, long ldo, int out_nchw,
+                        unsigned short* out_hi, unsigned short* out_lo, int N, int H, int W,
                         int Cin, int Cout, int stride, int up, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
+/* nearest-2x upsample + conv3x3 (unet.py:67-76) as four 2x2 sub-pixel convolutions of the low-resolution input: 2.25x fewer
+   multiply-adds than convolving the upsampled image.  w4 = [4][Cout][2][2][Cin] folded weights as hi / lo planes. */
+int cdae_upconv3x3_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, long sn, long sy, long sx, const unsigned short* w4_hi,
+                          const unsigned short* w4_lo, const float* bias, float* out, long ldo, int N, int H, int W, int Cin, int Cout,
+                          float* splitk_ws, size_t splitk_ws_bytes, void* stream);
 int cdae_linear_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, long ldx, const unsigned short* w_hi, const unsigned short* w_lo,
                        long ldw, const float* bias, const float* res, float* y, long ldy, int M, int N, int K, float alpha, int act,
                        float* splitk_ws, size_t splitk_ws_bytes, void* stream);
@@ -102,6 +108,7 @@ int cdae_conv3x3_wgrad(const float* x, long sn, long sy, long sx, long sc, const
  * :148-154, nn.py:57-58,233-237) and the 1x1 convs (skip_connection unet.py:171, qkv/proj_out unet.py:216-218)
  * on NHWC rows.  act: 0 none, 1 SiLU, 2 LeakyReLU(0.01). */
 int cdae_linear_fwd(const float* x, long ldx, const float* w, long ldw, const float* bias, const float* res, float* y, long ldy,
+                    unsigned short* y_hi, unsigned short* y_lo /* optional: the result also as f16 hi/lo planes, pitch ldy */,
                     int M, int N, int K, float alpha, int act, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
 /* dx[M][K] (+)= dy[M][N] @ w[N][K] */
 int cdae_linear_dgrad(const float* dy, long lddy, const float* w, long ldw, float* dx, long lddx, int M, int N, int K, int accumulate,
