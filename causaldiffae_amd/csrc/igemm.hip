@@ -623,9 +623,14 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
 // The conv gather's per-row tap offsets (9 per output pixel, -1 = padding) are computed once into an LDS table.
 __device__ __attribute__((aligned(16))) unsigned g_zero_ps[4] = {0u, 0u, 0u, 0u};
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NPL, int STAGES>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void ps_kernel(const GemmParams p) {
-    constexpr int THREADS = 64 * WAVES_M * WAVES_N, RPP = THREADS / 4;  // RPP = tile rows covered by one DMA pass of the block
+// LOADERS > 0: that many extra waves do nothing but issue the DMAs (an LDS-DMA costs its issuing wave 60-180 cycles, four per
+// step in a wave that also has 12 MFMAs to issue); the compute waves then only read fragments and issue MFMAs.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NPL, int STAGES, int LOADERS = 0>
+__global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + LOADERS)) void ps_kernel(const GemmParams p) {
+    constexpr int NCOMP = WAVES_M * WAVES_N, THREADS = 64 * (NCOMP + LOADERS);
+    constexpr int LT = LOADERS ? 64 * LOADERS : THREADS;               // threads that issue DMAs
+    constexpr int RPP = LT / 4;                                        // tile rows covered by one DMA pass
+    static_assert(LOADERS == 0 || STAGES == 2, "loader waves are built for the 2-stage loop");
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
     static_assert(STAGES == 2 || STAGES == 3, "2 stages: one __syncthreads per step; 3 stages: DMAs stay in flight across a raw barrier");
     constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;                // bytes per 16-bit plane
@@ -642,6 +647,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void ps_kernel(const GemmPa
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const bool is_loader = LOADERS > 0 && wave >= NCOMP;               // wave-uniform role
+    const bool loads_here = LOADERS == 0 || is_loader;
+    const int ltid = LOADERS ? tid - 64 * NCOMP : tid, lwave = LOADERS ? wave - NCOMP : wave;   // index among the DMA-issuing threads
 
     const int nmt = (p.M + BM - 1) / BM, nnt = (p.N + BN - 1) / BN;
     int mt, nt, ks;
@@ -688,13 +696,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void ps_kernel(const GemmPa
     bool bok[B_P];
 #pragma unroll
     for (int q = 0; q < B_P; ++q) {
-        const int row = (tid >> 2) + RPP * q, c = (tid & 3) ^ ((row >> 2) & 3);
+        const int row = ((ltid >> 2) + RPP * q) & (BN - 1), c = (ltid & 3) ^ ((row >> 2) & 3);      // (& mask: compute waves of a loader build carry a dummy index)
         bok[q] = n0 + row < p.N;
         boff[q] = (long)(bok[q] ? n0 + row : 0) * p.ldb + (long)kt_begin * BK + c * 8;
     }
     int acol[A_P];                 // this thread's 16-byte chunk inside the 32-deep k slice, in elements
+    int arow[A_P];
 #pragma unroll
-    for (int q = 0; q < A_P; ++q) { const int row = (tid >> 2) + RPP * q; acol[q] = 8 * ((tid & 3) ^ ((row >> 2) & 3)); }
+    for (int q = 0; q < A_P; ++q) { arow[q] = ((ltid >> 2) + RPP * q) & (BM - 1); acol[q] = 8 * ((ltid & 3) ^ ((arow[q] >> 2) & 3)); }
 
     auto dma = [&](hp src, char* dst_wave_base) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -706,16 +715,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void ps_kernel(const GemmPa
         char* const sb = sa + NPL * A_PLANE;
 #pragma unroll
         for (int q = 0; q < A_P; ++q) {
-            const int off = taptab[tap * BM + (tid >> 2) + RPP * q];
+            const int off = taptab[tap * BM + arow[q]];
             const long e = (long)off + kc + acol[q];
             const bool ok = off >= 0;
-            char* const dst = sa + (q * THREADS + wave * 64) * 16;
+            char* const dst = sa + (q * LT + lwave * 64) * 16;
             dma(a_hi + (ok ? e : za_hi), dst);
             if constexpr (NPL == 2) dma(a_lo + (ok ? e : za_lo), dst + A_PLANE);
         }
 #pragma unroll
         for (int q = 0; q < B_P; ++q) {
-            char* const dst = sb + (q * THREADS + wave * 64) * 16;
+            char* const dst = sb + (q * LT + lwave * 64) * 16;
             dma(b_hi + (bok[q] ? boff[q] : zb_hi), dst);
             if constexpr (NPL == 2) dma(b_lo + (bok[q] ? boff[q] : zb_lo), dst + B_PLANE);
             boff[q] += (p.dbg & 2) ? 0 : BK;
@@ -737,7 +746,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void ps_kernel(const GemmPa
     constexpr int G = NPL * (A_P + B_P);                               // DMAs per wave per step
     const bool nodma = (p.dbg & 4) != 0;
     auto issue_next = [&](int stage) { issue(stage, (p.dbg & 1) ? 0 : tap, (p.dbg & 1) ? 0 : chunk * BK); advance(); };
-    if (kt_begin < kt_end) issue_next(0);
+    if (loads_here && kt_begin < kt_end) issue_next(0);
     if constexpr (STAGES == 3) { if (kt_begin + 1 < kt_end) issue_next(1); }
 
     int cur = 0;
@@ -745,7 +754,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void ps_kernel(const GemmPa
         if constexpr (STAGES == 2) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's DMAs of stage `cur` have landed
             __syncthreads();                                           // ... everyone's have, and stage cur^1 is no longer read
-            if (kt + 1 < kt_end && !nodma) issue_next(cur ^ 1);
+            if (loads_here && kt + 1 < kt_end && !nodma) issue_next(cur ^ 1);
+            if (is_loader) { cur ^= 1; continue; }                     // loader waves: back to the barrier
         } else {
             // stage kt landed when at most the G DMAs of stage kt+1 are still outstanding; the barrier also tells that every
             // wave is done reading stage kt-1 == (kt+2) % 3, which the next DMAs overwrite.  No vmcnt(0) in the loop.
@@ -792,6 +802,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void ps_kernel(const GemmPa
     }
 
     // ---------------------------------------------------------------- epilogue (as igemm_kernel's, K-contiguous case)
+    if (is_loader) return;
     float* __restrict__ Cg;
     const float* __restrict__ Rg = nullptr;
     if (p.ksplit > 1) Cg = p.splitk_ws + (long)ks * (long)p.M * p.N;
@@ -827,21 +838,261 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void ps_kernel(const GemmPa
         }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NPL, int STAGES>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NPL, int STAGES, int LOADERS = 0>
 int launch_ps(const GemmParams& p, hipStream_t st) {
     const int taps = p.amode == A_CONV_VEC ? (p.ps_taps == 4 ? 4 : 9) : 1;
     constexpr size_t tiles = (size_t)STAGES * NPL * (BM + BN) * 64;
     const size_t smem = tiles + (size_t)taps * BM * sizeof(int);
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ps_kernel<BM, BN, WAVES_M, WAVES_N, NPL, STAGES>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ps_kernel<BM, BN, WAVES_M, WAVES_N, NPL, STAGES, LOADERS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(tiles + 9 * BM * sizeof(int))) != hipSuccess)
             return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
         attr_done = true;
     }
     dim3 grid((unsigned)((long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.ksplit));
-    hipLaunchKernelGGL((ps_kernel<BM, BN, WAVES_M, WAVES_N, NPL, STAGES>), grid, dim3(64 * WAVES_M * WAVES_N), smem, st, p);
+    hipLaunchKernelGGL((ps_kernel<BM, BN, WAVES_M, WAVES_N, NPL, STAGES, LOADERS>), grid, dim3(64 * (WAVES_M * WAVES_N + LOADERS)), smem, st, p);
     return hipGetLastError() == hipSuccess ? 0 : cdae_fail("ps_kernel launch failed");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pswin_kernel: stride-1 conv3x3 on pre-split planes with the activation WINDOW resident in LDS.  The 9 taps of a tile of
+// 128 consecutive output pixels read the same input pixels shifted by (ky-1)*W + (kx-1), so per 32-channel chunk the block
+// loads one window of 128 + 2W + 2 pixel rows ONCE (instead of nine 128-row tiles) and every tap reads its A fragments from
+// the window at a row offset; pixels that fall outside the image (or into the neighbouring image of the batch) are masked
+// to zero in the fragment registers by a per-lane 9-bit tap mask.  Per step (chunk, tap) only the 128 x 32 weight tile is
+// staged (double-buffered).  A-operand traffic drops 4.5x (W = 64) .. 7.9x (W = 8), bytes per step from 32 KB to ~20 KB.
+// K order is (chunk, tap, channel) — the sums differ from ps_kernel's (tap, channel) order by fp32 rounding only.
+// BST = 3 weight stages (rows up to 32 pixels: the window is small enough for two blocks per CU): the DMAs of step s+2 are in
+// flight while step s computes, and the loop waits with a counted vmcnt instead of draining.
+template <int BN, int NPL, int BST, int MAXWIN>
+__global__ __launch_bounds__(512, 4) void pswin_kernel(const GemmParams p) {     // 4 waves per SIMD (2 blocks per CU): at most 128 VGPRs
+    constexpr int BM = 128, WAVES_N = 4, THREADS = 512;
+    constexpr int WM = 64, WN = BN / WAVES_N, TM = 2, TN = WN / 32;
+    static_assert(MAXWIN % 16 == 0 && (BST == 2 || BST == 3), "window rows come in 16-row DMA blocks");
+    constexpr int A_PLANE = MAXWIN * 64, B_PLANE = BN * 64;
+    constexpr int A_SLOTS = 5;                                          // 2 planes x 17 row blocks over 8 waves
+    typedef const unsigned short* hp;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const lds = reinterpret_cast<char*>(smem);
+    char* const awin = lds;                                             // [NPL][MAXWIN][64 B]
+    char* const bst = lds + NPL * A_PLANE;                              // [BST stages][NPL][BN][64 B]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    const int nmt = (p.M + BM - 1) / BM, nnt = (p.N + BN - 1) / BN;
+    int mt, nt, ks;
+    {
+        const unsigned G = gridDim.x, b = blockIdx.x;
+        const unsigned q = G >> 3, r = G & 7, x = b & 7;
+        unsigned v = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+        nt = v % nnt; v /= nnt;
+        mt = v % nmt; ks = v / nmt;
+    }
+    const int m0 = mt * BM, n0 = nt * BN;
+    const hp a_hi = reinterpret_cast<hp>(p.A), a_lo = p.A_lo;
+    const hp b_hi = reinterpret_cast<hp>(p.B), b_lo = p.B_lo;
+    const hp zero = reinterpret_cast<hp>(g_zero_ps);
+    const long za_hi = zero - a_hi, za_lo = NPL == 2 ? zero - a_lo : 0, zb_hi = zero - b_hi, zb_lo = NPL == 2 ? zero - b_lo : 0;
+
+    const int W = p.W, win = BM + 2 * W + 2, NB = (win + 15) >> 4;      // window rows, 16-row DMA blocks per plane
+    const int nchunk = p.Cin / BK;
+    const int c_per = (nchunk + p.ksplit - 1) / p.ksplit;
+    const int c_begin = ks * c_per, c_end = min(nchunk, c_begin + c_per);
+
+    // ---- A window DMA slots of this wave: piece pc = wave + 8q covers plane pc / NB, rows 16 (pc % NB) .. +15
+    int aoff[A_SLOTS];             // element offset of this lane's 16 bytes at chunk 0, or -1 (outside the tensor)
+#pragma unroll
+    for (int q = 0; q < A_SLOTS; ++q) {
+        const int pc = wave + 8 * q, pl = pc >= NB ? 1 : 0, rb = pc - pl * NB;
+        const int j = rb * 16 + (lane >> 2);                             // window row
+        const int pix = m0 - W - 1 + j;                                  // flattened input pixel (n, y, x)
+        const int c = (lane & 3) ^ ((j >> 2) & 3);
+        aoff[q] = (pix >= 0 && pix < p.M && j < win) ? pix * (int)p.sx + c * 8 : -1;
+    }
+    // ---- B tile pieces: wave w stages rows 16w..16w+15 (hi and lo) — BN = 128: 8 row blocks, one per wave
+    long boff;
+    bool bok;
+    {
+        const int row = wave * 16 + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
+        bok = row < BN && n0 + row < p.N;
+        boff = (long)(bok ? n0 + row : 0) * p.ldb + c * 8;
+    }
+    auto dma = [&](hp src, char* dst_wave_base) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst_wave_base, 16, 0, 0);
+    };
+    auto issue_A = [&](int chunk) {
+#pragma unroll
+        for (int q = 0; q < A_SLOTS; ++q) {
+            const int pc = wave + 8 * q;
+            if (pc < NPL * NB) {                                         // wave-uniform
+                const int pl = pc >= NB ? 1 : 0, rb = pc - pl * NB;
+                const bool ok = aoff[q] >= 0;
+                const long e = (long)aoff[q] + chunk * BK;
+                char* const dst = awin + pl * A_PLANE + rb * 1024;
+                if (pl == 0) dma(a_hi + (ok ? e : za_hi), dst);
+                else dma(a_lo + (ok ? e : za_lo), dst);
+            }
+        }
+    };
+    auto issue_B = [&](int stage, int chunk, int tap) {
+        if (wave * 16 < BN) {
+            char* const dst = bst + stage * (NPL * B_PLANE) + wave * 1024;
+            const long e = boff + (long)tap * p.Cin + chunk * BK;
+            dma(b_hi + (bok ? e : zb_hi), dst);
+            if constexpr (NPL == 2) dma(b_lo + (bok ? e : zb_lo), dst + B_PLANE);
+        }
+    };
+
+    // ---- per-lane tap masks of the wave's two 32-row sub-tiles: bit (3 ky + kx) set when tap (ky, kx) reads a real pixel
+    int tapmask[TM], jrow[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm * WM + i * 32 + l31, m = m0 + r;
+        jrow[i] = r;                                                     // window row of tap (0, 0); tap (ky, kx) adds ky*W + kx
+        const PixRow pr = make_pixrow(p, m);                            // iy0 = y - 1, ix0 = x - 1 (stride 1)
+        int mk = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ty = pr.iy0 + t / 3, tx = pr.ix0 + t % 3;
+            mk |= (pr.ok && ty >= 0 && ty < p.H && tx >= 0 && tx < W) ? (1 << t) : 0;
+        }
+        tapmask[i] = mk;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto mma = [&](const u16x8& x, const u16x8& y, const f32x16& c) -> f32x16 {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, x), __builtin_bit_cast(half8, y), c, 0, 0, 0);
+    };
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+    if (c_begin < c_end) {
+        issue_A(c_begin); issue_B(0, c_begin, 0);
+        if constexpr (BST == 3) issue_B(1, c_begin, 1);
+    }
+    int stage = 0;
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {           // not unrolled: nine copies keep every tap's addresses and masks live (197 VGPRs)
+            if constexpr (BST == 2) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                const int ntap = tap == 8 ? 0 : tap + 1, nchk = tap == 8 ? chunk + 1 : chunk;     // stage the next step's weight tile
+                if (nchk < c_end) issue_B(stage ^ 1, nchk, ntap);
+            } else {
+                // weights of this step landed when only the next step's NPL pieces may still be in flight; at tap 0 the window
+                // (issued last) must be complete too, and on the very last step nothing younger exists: drain.
+                const bool last = chunk + 1 == c_end && tap == 8;
+                if (tap == 0 || last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPL) : "memory");
+                __builtin_amdgcn_s_barrier();
+                const int t2 = tap + 2, ntap = t2 >= 9 ? t2 - 9 : t2, nchk = t2 >= 9 ? chunk + 1 : chunk;
+                if (nchk < c_end) issue_B(stage >= 1 ? stage - 1 : 2, nchk, ntap);                // (stage + 2) % 3
+            }
+            const int ky = tap / 3, kx = tap - 3 * ky, shift = ky * W + kx;
+            const char* bc = bst + stage * (NPL * B_PLANE);
+            unsigned amask[TM];
+            int abase[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                amask[i] = (tapmask[i] >> tap) & 1 ? 0xffffffffu : 0u;
+                const int j = jrow[i] + shift;
+                abase[i] = j * 64 + 16 * (hh ^ ((j >> 2) & 3));           // sk = 0 chunk; sk = 1 flips chunk bit 1 (+-32 bytes)
+            }
+#pragma unroll
+            for (int sk = 0; sk < 2; ++sk) {
+                u16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int a = abase[i] ^ (sk * 32);
+                    u32x4 h4 = *reinterpret_cast<const u32x4*>(awin + a);
+                    h4 &= amask[i];
+                    ah[i] = __builtin_bit_cast(u16x8, h4);
+                    if constexpr (NPL == 2) {
+                        u32x4 l4 = *reinterpret_cast<const u32x4*>(awin + A_PLANE + a);
+                        l4 &= amask[i];
+                        al[i] = __builtin_bit_cast(u16x8, l4);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int row = wn * WN + j * 32 + l31;
+                    const int b = row * 64 + 16 * ((2 * sk + hh) ^ ((row >> 2) & 3));
+                    bh[j] = *reinterpret_cast<const u16x8*>(bc + b);
+                    if constexpr (NPL == 2) bl[j] = *reinterpret_cast<const u16x8*>(bc + B_PLANE + b);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (NPL == 2) {
+                            acc[i][j] = mma(al[i], bh[j], acc[i][j]);
+                            acc[i][j] = mma(ah[i], bl[j], acc[i][j]);
+                        }
+                        acc[i][j] = mma(ah[i], bh[j], acc[i][j]);
+                    }
+            }
+            stage = stage + 1 == BST ? 0 : stage + 1;
+        }
+        if (chunk + 1 < c_end) {
+            __builtin_amdgcn_s_barrier();                                // every wave is done with this chunk's window
+            issue_A(chunk + 1);                                          // lands before the vmcnt(0) + barrier of the next step
+        }
+    }
+
+    // ---------------------------------------------------------------- epilogue (row-major result)
+    float* __restrict__ Cg;
+    const float* __restrict__ Rg = nullptr;
+    if (p.ksplit > 1) Cg = p.splitk_ws + (long)ks * (long)p.M * p.N;
+    else { Cg = p.C; Rg = p.res; }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * WN + j * 32 + l31;
+            if (col >= p.N) continue;
+            const float bv = (p.ksplit == 1 && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (row >= p.M) continue;
+                if (p.ksplit > 1) { Cg[(long)row * p.N + col] = acc[i][j][r]; continue; }
+                const long addr = (long)row * p.ldc + col;
+                float v = acc[i][j][r] * p.alpha + bv;
+                if (Rg) v += Rg[addr];
+                if (p.act == ACT_SILU) v = v / (1.f + expf(-v));
+                else if (p.act == ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
+                if (p.accumulate) v += Cg[addr];
+                Cg[addr] = v;
+                if (p.C_hi) store_planes(p, addr, v);
+            }
+        }
+}
+
+template <int BN, int NPL, int BST, int MAXWIN>
+int launch_pswin(const GemmParams& p, hipStream_t st) {
+    constexpr size_t smem = (size_t)NPL * MAXWIN * 64 + (size_t)BST * NPL * BN * 64;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pswin_kernel<BN, NPL, BST, MAXWIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
+        attr_done = true;
+    }
+    dim3 grid((unsigned)((long)((p.M + 127) / 128) * ((p.N + BN - 1) / BN) * p.ksplit));
+    hipLaunchKernelGGL((pswin_kernel<BN, NPL, BST, MAXWIN>), grid, dim3(512), smem, st, p);
+    return hipGetLastError() == hipSuccess ? 0 : cdae_fail("pswin_kernel launch failed");
 }
 
 // split-K finish: C = alpha * sum_s slab[s] + bias (+res) (-> act), deterministic order
@@ -996,7 +1247,24 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
         static const int cfg_tile = getenv("CDAE_PS_TILE") ? atoi(getenv("CDAE_PS_TILE")) : 128;   // 256: measured 6 % slower end to end (1 block per CU)
         const long tiles_256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
         const bool huge = cfg_tile == 256 && big && tiles_256 * ks >= 200;            // 256x128 tiles, 1 block / CU, 3-stage DMA ring
-        if (p.prec == 1) rc = huge ? launch_ps<256, 128, 4, 2, 2, 3>(p, st) : big ? launch_ps<128, 128, 2, 4, 2, 2>(p, st) : launch_ps<64, 64, 2, 2, 2, 2>(p, st);
+        static const int cfg_win = getenv("CDAE_PS_WIN") ? atoi(getenv("CDAE_PS_WIN")) : 1;
+        // window-resident form: stride-1 3x3 convs on a dense NHWC tensor, rows up to 64 pixels, row-major result
+        const bool win_ok = cfg_win && p.amode == A_CONV_VEC && p.ps_taps != 4 && p.stride == 1 && !p.up && p.W <= 64 && big &&
+                            p.sy == (long)p.W * p.sx && p.sn == (long)p.H * p.W * p.sx && p.out_mode == OUT_ROWMAJOR;
+        if (win_ok) {
+            const int nchunk = p.Cin / BK;
+            if (p.ksplit > nchunk) p.ksplit = nchunk;              // K is split by whole channel chunks here
+            ks = p.ksplit;
+            const bool deep = p.W <= 32 && cfg_win == 3;           // CDAE_PS_WIN=3: 3-stage weight ring where it fits (measured: no gain over 2 stages)
+            if (p.prec == 1) rc = deep ? launch_pswin<128, 2, 3, 208>(p, st) : launch_pswin<128, 2, 2, 272>(p, st);
+            else rc = deep ? launch_pswin<128, 1, 3, 208>(p, st) : launch_pswin<128, 1, 2, 272>(p, st);
+        }
+        static const int cfg_loaders = getenv("CDAE_PS_LOADERS") ? atoi(getenv("CDAE_PS_LOADERS")) : 0;
+        if (win_ok) {}
+        else
+        if (p.prec == 1 && big && !huge && cfg_loaders == 4) rc = launch_ps<128, 128, 2, 4, 2, 2, 4>(p, st);
+        else if (p.prec == 1 && big && !huge && cfg_loaders == 2) rc = launch_ps<128, 128, 2, 4, 2, 2, 2>(p, st);
+        else if (p.prec == 1) rc = huge ? launch_ps<256, 128, 4, 2, 2, 3>(p, st) : big ? launch_ps<128, 128, 2, 4, 2, 2>(p, st) : launch_ps<64, 64, 2, 2, 2, 2>(p, st);
         else rc = huge ? launch_ps<256, 128, 4, 2, 1, 3>(p, st) : big ? launch_ps<128, 128, 2, 4, 1, 2>(p, st) : launch_ps<64, 64, 2, 2, 1, 2>(p, st);
     }
     else CASE(A_PLAIN_KC, B_PLAIN_KC);
