@@ -235,8 +235,8 @@ def main():
             # f16x3: every algorithmic multiply-add is 3 f16 MFMA multiply-adds, so the matrix-core roof for ALGORITHMIC
             # flops is the dense f16 peak / 3; fp32: the fp32 MFMA peak
             peak = F16_MFMA_PEAK_TFLOPS / 3.0 if prec == "f16x3" else FP32_MFMA_PEAK_TFLOPS
-            kern = ("igemm_kernel<...,PREC=1> (v_mfma_f32_32x32x16_f16, f16x3 split precision, fp32 accumulate)" if prec == "f16x3"
-                    else "igemm_kernel (v_mfma_f32_32x32x2_f32)")
+            kern = ("pswin_kernel / ps_kernel / igemm_kernel<PREC=1> (v_mfma_f32_32x32x16_f16 on pre-split f16 hi/lo planes staged by "
+                    "LDS-DMA, f16x3 split precision, fp32 accumulate)" if prec == "f16x3" else "igemm_kernel (v_mfma_f32_32x32x2_f32)")
             traffic, traffic_src = None, None
             pmc_file = os.path.join(ROOT, "profiles", f"r01_igemm_pmc_summary_{prec}.json")
             if os.path.exists(pmc_file) and N == 128:        # PMC counters cannot be read in-process: separate rocprofv3 --pmc passes
@@ -245,6 +245,12 @@ def main():
             roof = {"bound": "mfma", "kernel": kern, "achieved": ach, "peak": peak, "unit": "TFLOP/s (algorithmic 2MNK)",
                     "frac": ach / peak, "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
                     "precision_mode": prec, "executed_mfma_tflops": ach * (3.0 if prec == "f16x3" else 1.0),
+                    # 2MNK as EXECUTED: the three upsample convs run in their folded sub-pixel form (2.25x fewer multiply-adds than
+                    # the reference's formulation), so this is below the reference-algorithm rate `model_tflops` implies
+                    "flops_convention": "executed 2MNK per launch (sub-pixel up-convs at folded size)",
+                    # a register-resident v_mfma_f32_32x32x16_f16 loop sustains 1640 TFLOP/s on this part (tools/hiptests/mfma_peak.hip,
+                    # profiles/r01_mfma_sustained.txt): 547 TFLOP/s in f16x3 terms
+                    "frac_of_sustained_mfma": (ach / (1640.0 / 3.0)) if prec == "f16x3" else None,
                     "vs_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
                     "launches_per_step": ig["launches"] // 2, "avg_launch_us": 1e3 * ig["ms"] / max(1, ig["launches"]),
                     "flops_per_launch_avg": ig["work"] / max(1, ig["launches"]),
