@@ -202,6 +202,19 @@ int cdae_linear_fwd(const float* x, long ldx, const float* w, long ldw, const fl
     return cdae_gemm_dispatch(p, stream);
 }
 
+// y = [x1 | x2] @ w^T + bias: the K range split over two row-major sources (a channel concatenation read in place)
+int cdae_linear_fwd_cat(const float* x1, long ld1, int K1, const float* x2, long ld2, const float* w, long ldw, const float* bias, float* y,
+                        long ldy, int M, int N, int K, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    if (K1 % 32 || K % 4 || ld1 % 4 || ld2 % 4 || ldw % 4 || !aligned16(x1) || !aligned16(x2) || !aligned16(w))
+        return cdae_fail("linear_fwd_cat: K1 % 32 == 0 and 16-byte aligned rows required");
+    GemmParams p = base_params();
+    p.A = x1; p.A2 = x2; p.lda2 = ld2; p.K1 = K1; p.B = w; p.C = y; p.bias = bias;
+    p.M = M; p.N = N; p.K = K; p.lda = ld1; p.ldb = ldw; p.ldc = ldy;
+    p.amode = A_PLAIN_KC; p.bmode = B_PLAIN_KC;
+    set_splitk(p, splitk_ws, splitk_ws_bytes);
+    return cdae_gemm_dispatch(p, stream);
+}
+
 int cdae_linear_dgrad(const float* dy, long lddy, const float* w, long ldw, float* dx, long lddx, int M, int N, int K, int accumulate,
                       float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
     GemmParams p = base_params();

@@ -37,6 +37,9 @@ struct GemmParams {
     int prec;               // -1: library default (env CDAE_IGEMM_PREC), 0: fp32 MFMA, 1: f16x3 split precision (K-contiguous operand pairs only)
     float* splitk_ws; size_t splitk_ws_bytes;
     // pre-split operands (ps_kernel): A / B point at the hi f16 planes, A_lo / B_lo at the lo planes (same strides, in elements)
+    // A_PLAIN_KC with the K range split over two row-major sources: columns [0, K1) from A (pitch lda), [K1, K) from A2 (pitch
+    // lda2) — a channel concatenation consumed in place.  A2 == nullptr: one source.  K1 % 32 == 0.
+    const float* A2; long lda2; int K1;
     int presplit;
     // optional second output: the result also as f16 hi/lo planes with row pitch ldc (row-major outputs only), so a following
     // conv can take the pre-split path without a conversion pass

@@ -188,13 +188,16 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
     }
     // K-contiguous plain operands: row pointers are loop invariant
     const float* arowp[A_V4];
+    long adelta[A_V4];            // two-source A: what to add to arowp[q] + k0 once k0 reaches the second source (else unused)
     bool arow_ok[A_V4];
     if constexpr (AMODE == A_PLAIN_KC) {
 #pragma unroll
         for (int q = 0; q < A_V4; ++q) {
             int m = m0 + (tid >> 3) + RPP * q;
             arow_ok[q] = m < p.M;
-            arowp[q] = Ag + (long)(arow_ok[q] ? m : 0) * p.lda + (tid & 7) * 4;
+            const long mm = arow_ok[q] ? m : 0;
+            arowp[q] = Ag + mm * p.lda + (tid & 7) * 4;
+            adelta[q] = p.A2 ? (p.A2 + mm * p.lda2 + (tid & 7) * 4 - p.K1) - arowp[q] : 0;
         }
     }
     const float* browp[B_V4];
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
             const int k = k0 + (tid & 7) * 4;
 #pragma unroll
             for (int q = 0; q < A_V4; ++q) {
-                if constexpr (!SCALAR) areg[q] = ld4_if(Ag, arowp[q] + k0, arow_ok[q] && k < p.K);
+                if constexpr (!SCALAR) areg[q] = ld4_if(Ag, arowp[q] + k0 + ((p.A2 && k0 >= p.K1) ? adelta[q] : 0L), arow_ok[q] && k < p.K);
                 else {
                     float v[4];
 #pragma unroll
@@ -1207,6 +1210,7 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
         const int mode = cdae_get_default_precision();
         p.prec = mode == CDAE_PREC_FP32 ? 0 : mode == CDAE_PREC_MIXED16 ? (p.grad_operand ? 4 : 3) : (p.grad_operand ? 2 : 1);
     }
+    if (p.A2 && (p.amode != A_PLAIN_KC || p.a_scalar || p.K1 % BK || p.batch != 1)) return cdae_fail("two-source A: vectorised A_PLAIN_KC only, K1 % 32 == 0");
     if (p.presplit) {
         static const int cfg_dbg = getenv("CDAE_PS_DBG") ? atoi(getenv("CDAE_PS_DBG")) : 0;
         p.dbg = cfg_dbg;

@@ -17,9 +17,17 @@ __device__ __forceinline__ float silu_f(float v) { return v / (1.f + expf(-v)); 
 
 // ------------------------------------------------------------------ GroupNorm statistics
 // grid (nchunk, N), 256 threads.  partial[((n*nchunk + chunk)*G + g)*2 + {0,1}] = (sum, sumsq) of (x - pivot_g)
+// Two-source form (x2 != nullptr): channels [0, C1) come from x (pitch ldx), channels [C1, C) from x2 (pitch ld2) — the UNet's
+// skip concatenation th.cat([h, hs.pop()], dim=1) (unet.py:629) read in place instead of being copied into one tensor.
+__device__ __forceinline__ const float* gn_src(const float* x, int ldx, const float* x2, int ld2, int C1, long npix0, int c, int& ld) {
+    if (x2 && c >= C1) { ld = ld2; return x2 + npix0 * ld2 + (c - C1); }
+    ld = ldx;
+    return x + npix0 * ldx + c;
+}
 template <int VEC>
 __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, int HW, int C, int ldx, int cpg, int G,
-                                                          int pix_per_block, float* __restrict__ partial) {
+                                                          int pix_per_block, float* __restrict__ partial,
+                                                          const float* __restrict__ x2 = nullptr, int ld2 = 0, int C1 = 0) {
     __shared__ float sS[256], sQ[256];
     const int n = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
     const int E = C / VEC;
@@ -27,11 +35,12 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
     const int tid = threadIdx.x;
     const int r = tid / E, e = tid - r * E;
     const bool active = r < rows;
-    const float* xn = x + (long)n * HW * ldx;
     float S = 0.f, Q = 0.f;
     if (active) {
         const int g = (e * VEC) / cpg;
-        const float pivot = xn[g * cpg];
+        int ld, ldp;
+        const float* xe = gn_src(x, ldx, x2, ld2, C1, (long)n * HW, e * VEC, ld);         // this thread's channel vector at pixel 0
+        const float pivot = *gn_src(x, ldx, x2, ld2, C1, (long)n * HW, g * cpg, ldp);
         const int p0 = chunk * pix_per_block, p1 = min(HW, p0 + pix_per_block);
         int p = p0 + r;
         if (VEC == 4) {
@@ -41,15 +50,15 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
                 Q += (a * a + b * b) + (c * c + d * d);
             };
             for (; p + 3 * rows < p1; p += 4 * rows) {        // four independent 16-byte loads in flight
-                float4 v0 = *reinterpret_cast<const float4*>(xn + (long)p * ldx + e * 4);
-                float4 v1 = *reinterpret_cast<const float4*>(xn + (long)(p + rows) * ldx + e * 4);
-                float4 v2 = *reinterpret_cast<const float4*>(xn + (long)(p + 2 * rows) * ldx + e * 4);
-                float4 v3 = *reinterpret_cast<const float4*>(xn + (long)(p + 3 * rows) * ldx + e * 4);
+                float4 v0 = *reinterpret_cast<const float4*>(xe + (long)p * ld);
+                float4 v1 = *reinterpret_cast<const float4*>(xe + (long)(p + rows) * ld);
+                float4 v2 = *reinterpret_cast<const float4*>(xe + (long)(p + 2 * rows) * ld);
+                float4 v3 = *reinterpret_cast<const float4*>(xe + (long)(p + 3 * rows) * ld);
                 acc4(v0); acc4(v1); acc4(v2); acc4(v3);
             }
-            for (; p < p1; p += rows) acc4(*reinterpret_cast<const float4*>(xn + (long)p * ldx + e * 4));
+            for (; p < p1; p += rows) acc4(*reinterpret_cast<const float4*>(xe + (long)p * ld));
         } else {
-            for (; p < p1; p += rows) { float a = xn[(long)p * ldx + e] - pivot; S += a; Q += a * a; }
+            for (; p < p1; p += rows) { float a = xe[(long)p * ld] - pivot; S += a; Q += a * a; }
         }
     }
     sS[tid] = S; sQ[tid] = Q;
@@ -66,7 +75,8 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
 
 // grid N, G threads: stats[n*G+g] = mean, stats[N*G + n*G+g] = rstd
 __global__ void gn_finalize_kernel(const float* __restrict__ x, int HW, int ldx, int cpg, int G, int nchunk, float eps,
-                                   const float* __restrict__ partial, float* __restrict__ mean, float* __restrict__ rstd) {
+                                   const float* __restrict__ partial, float* __restrict__ mean, float* __restrict__ rstd,
+                                   const float* __restrict__ x2 = nullptr, int ld2 = 0, int C1 = 0) {
     const int n = blockIdx.x, g = threadIdx.x;
     if (g >= G) return;
     double s = 0.0, q = 0.0;
@@ -75,7 +85,8 @@ __global__ void gn_finalize_kernel(const float* __restrict__ x, int HW, int ldx,
         s += pp[0]; q += pp[1];
     }
     const double cnt = (double)HW * cpg;
-    const double pivot = x[(long)n * HW * ldx + g * cpg];
+    int ldp;
+    const double pivot = *gn_src(x, ldx, x2, ld2, C1, (long)n * HW, g * cpg, ldp);
     const double m = s / cnt;
     double var = q / cnt - m * m;
     if (var < 0.0) var = 0.0;
@@ -96,7 +107,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ ss, int ld_ss, int do_silu,
-                                                        unsigned short* __restrict__ y_hi = nullptr, unsigned short* __restrict__ y_lo = nullptr) {
+                                                        unsigned short* __restrict__ y_hi = nullptr, unsigned short* __restrict__ y_lo = nullptr,
+                                                        const float* __restrict__ x2 = nullptr, int ld2 = 0, int C1 = 0) {
     const int n = blockIdx.y, E = C / VEC, rows = 256 / E, tid = threadIdx.x;
     const int r = tid / E, e = tid - r * E;
     if (r >= rows) return;
@@ -113,7 +125,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
             B[i] = fmaf(B[i], sc, sh);
         }
     }
-    const float* xp = x + (long)n * HW * ldx + c;
+    int ldxe;
+    const float* xp = gn_src(x, ldx, x2, ld2, C1, (long)n * HW, c, ldxe);
+    ldx = ldxe;
     float* yp = y + (long)n * HW * ldy + c;
     const int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
     auto apply = [&](float v, int i) { float h = fmaf(v, A[i], B[i]); return do_silu ? silu_f(h) : h; };
@@ -566,8 +580,31 @@ int cdae_gn_bwd(const float* x, const float* dy, float* dx, int N, int HW, int C
 int cdae_gn_apply_split(const float* x, unsigned short* y_hi, unsigned short* y_lo, int N, int HW, int C, int ldx, int ldy, int groups,
                         const float* mean, const float* rstd, const float* gamma, const float* beta, const float* scale_shift, int ld_ss,
                         int silu, void* stream) {
+    return cdae_gn_apply_split2(x, ldx, nullptr, 0, C, y_hi, y_lo, N, HW, C, ldy, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, stream);
+}
+
+int cdae_gn_stats2(const float* x1, int ld1, const float* x2, int ld2, int C1, int N, int HW, int C, int groups, float eps, float* mean,
+                   float* rstd, float* ws, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int cpg = C / groups;
+    if (!(cpg % 4 == 0 && ld1 % 4 == 0 && ld2 % 4 == 0 && C1 % 4 == 0) || C / 4 > 256) return cdae_fail("gn_stats2: needs 4-channel vectors, C <= 1024");
+    const int E = C / 4;
+    const int nchunk = gn_chunks(HW, N, E);
+    const int ppb = (HW + nchunk - 1) / nchunk;
+    cdae_prof_begin(PROF_GN, (double)N * HW * C * 4.0, st);
+    hipLaunchKernelGGL(gn_partial_kernel<4>, dim3(nchunk, N), dim3(256), 0, st, x1, HW, C, ld1, cpg, groups, ppb, ws, x2, ld2, C1);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(groups < 64 ? 64 : groups), 0, st, x1, HW, ld1, cpg, groups, nchunk, eps, ws, mean, rstd, x2, ld2, C1);
+    cdae_prof_end(PROF_GN, st);
+    CHECK_LAUNCH("gn_stats2 launch failed");
+    return 0;
+}
+
+int cdae_gn_apply_split2(const float* x, int ldx, const float* x2, int ld2, int C1, unsigned short* y_hi, unsigned short* y_lo, int N, int HW,
+                         int C, int ldy, int groups, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                         const float* scale_shift, int ld_ss, int silu, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int cpg = C / groups;
+    if (x2 && (ld2 % 4 || C1 % 4)) return cdae_fail("gn_apply_split2: second source needs 4-channel alignment");
     if (!(cpg % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0) || C / 4 > 256) return cdae_fail("gn_apply_split: needs channels-per-group % 4 == 0, C <= 1024");
     const int E = C / 4, rows = 256 / E;
     int nchunk = HW / (rows * 16);
@@ -576,7 +613,7 @@ int cdae_gn_apply_split(const float* x, unsigned short* y_hi, unsigned short* y_
     const int ppb = (HW + nchunk - 1) / nchunk;
     cdae_prof_begin(PROF_GN, (double)N * HW * C * 8.0, st);
     hipLaunchKernelGGL((gn_apply_kernel<4, true>), dim3(nchunk, N), dim3(256), 0, st, x, (float*)nullptr, HW, C, ldx, ldy, cpg, groups, ppb, mean, rstd,
-                       gamma, beta, scale_shift, ld_ss, silu, y_hi, y_lo);
+                       gamma, beta, scale_shift, ld_ss, silu, y_hi, y_lo, x2, ld2, C1);
     cdae_prof_end(PROF_GN, st);
     CHECK_LAUNCH("gn_apply_split launch failed");
     return 0;

@@ -104,6 +104,10 @@ class ConvNd(nn.Module):
         if isinstance(x, ops.SplitAct):
             assert self.kernel_size == 3
             return ops.conv3x3_ps(x, self.weight, self.bias, res=res, stride=self.stride, up=up, out_nchw=out_nchw, emit_split=emit_split)
+        if isinstance(x, ops.CatAct):
+            if self.kernel_size == 1 and res is None:
+                return ops.conv1x1_cat(x, self.weight, self.bias)
+            x = ops.materialize(x)
         if self.kernel_size == 3:
             return ops.conv3x3(x, self.weight, self.bias, res=res, stride=self.stride, up=up, out_nchw=out_nchw)
         if x.dim() == 3:       # [B, C, T] (AttentionBlock convention)
@@ -137,9 +141,9 @@ class GroupNorm32(nn.Module):
     def forward(self, x, scale_shift=None, silu=False, split=False):
         """split=True: the caller feeds the result straight into a conv3x3 / 1x1 GEMM; in no-grad f16 modes it is then written
         as pre-split f16 planes (ops.SplitAct) for the LDS-DMA kernel."""
-        if split and x.dim() == 4 and ops.presplit_ok() and ops.can_split(self.num_channels, self.num_groups):
+        if split and len(x.shape) == 4 and ops.presplit_ok() and ops.can_split(self.num_channels, self.num_groups):
             return ops.group_norm_split(x, self.weight, self.bias, scale_shift, silu, self.num_groups, self.eps)
-        return ops.group_norm(x, self.weight, self.bias, scale_shift, silu, self.num_groups, self.eps)
+        return ops.group_norm(ops.materialize(x), self.weight, self.bias, scale_shift, silu, self.num_groups, self.eps)
 
 
 def normalization(channels):

@@ -396,8 +396,43 @@ class _Cat(Function):
         return da, db
 
 
+class CatAct:
+    """th.cat([a, b], dim=1) of two NHWC-stored activations that is never materialised (no-grad f16 modes): GroupNorm reads the
+    two sources in place and the 1x1 skip convolution runs as two accumulating GEMMs."""
+    __slots__ = ("a", "b", "shape")
+
+    def __init__(self, a, b):
+        self.a, self.b = a, b
+        self.shape = (a.shape[0], a.shape[1] + b.shape[1], a.shape[2], a.shape[3])
+
+
 def cat_channels(a, b):
+    if presplit_ok() and a.dim() == 4 and a.shape[1] % 4 == 0 and b.shape[1] % 4 == 0:
+        return CatAct(to_nhwc(a), to_nhwc(b))
     return _Cat.apply(a, b)
+
+
+def materialize(x):
+    """A real tensor for consumers that do not understand CatAct."""
+    return _Cat.apply(x.a, x.b) if isinstance(x, CatAct) else x
+
+
+def conv1x1_cat(x, w, b=None):
+    """1x1 conv of a CatAct: y = a @ W[:, :C1]^T + b, then y += b_rows @ W[:, C1:]^T (no autograd)."""
+    N, C, H, W = x.shape
+    C1, M, Nf = x.a.shape[1], N * H * W, w.shape[0]
+    assert w.numel() == Nf * C and w.is_contiguous()
+    ra = x.a.permute(0, 2, 3, 1).reshape(M, C1)
+    rb = x.b.permute(0, 2, 3, 1).reshape(M, C - C1)
+    y = torch.empty((M, Nf), dtype=torch.float32, device=ra.device)
+    ws, wsb = _sk(ra.device)
+    if C1 % 32 == 0:                  # one GEMM whose K range walks the two sources
+        check(lib.cdae_linear_fwd_cat(ptr(ra), C1, C1, ptr(rb), C - C1, ptr(w), C, ptr(b), ptr(y), Nf, M, Nf, C, ws, wsb, stream()))
+    else:                             # two accumulating GEMMs
+        wp = w.data_ptr()
+        check(lib.cdae_linear_fwd(ptr(ra), C1, wp, C, ptr(b), None, ptr(y), Nf, None, None, M, Nf, C1, 1.0, ACT_NONE, ws, wsb, stream()))
+        check(lib.cdae_linear_fwd(ptr(rb), C - C1, wp + 4 * C1, C, None, ptr(y), ptr(y), Nf, None, None, M, Nf, C - C1, 1.0, ACT_NONE, ws, wsb, stream()))
+    return y.reshape(N, H, W, Nf).permute(0, 3, 1, 2)
 
 
 class _EmbeddingAdd(Function):
@@ -654,17 +689,23 @@ def presplit_ok():
 
 
 def group_norm_split(x, gamma, beta, scale_shift=None, silu=False, groups=32, eps=1e-5):
-    """GroupNorm (+ scale-shift, + SiLU) whose result is written directly as f16 hi/lo planes (no autograd)."""
-    x = to_nhwc(x)
+    """GroupNorm (+ scale-shift, + SiLU) whose result is written directly as f16 hi/lo planes (no autograd).  x may be a CatAct:
+    both kernels then read the two sources in place."""
+    if isinstance(x, CatAct):
+        x1, x2 = x.a, x.b
+        C1, ld2 = x1.shape[1], x2.shape[1]
+    else:
+        x1, x2 = to_nhwc(x), None
+        C1, ld2 = x1.shape[1], 0
     N, C, H, W = x.shape
-    dev = x.device
+    dev = x1.device
     stats = torch.empty((2, N, groups), dtype=torch.float32, device=dev)
     ws = workspace(dev, "gn", 4 * lib.cdae_gn_workspace_floats(N, C))
     planes = torch.empty((2, N, H, W, C), dtype=torch.float16, device=dev)
     st = stream()
-    check(lib.cdae_gn_stats(ptr(x), N, H * W, C, C, groups, eps, ptr(stats[0]), ptr(stats[1]), ptr(ws), st))
-    check(lib.cdae_gn_apply_split(ptr(x), ptr(planes[0]), ptr(planes[1]), N, H * W, C, C, C, groups, ptr(stats[0]), ptr(stats[1]),
-                                  ptr(gamma), ptr(beta), ptr(scale_shift), 2 * C, 1 if silu else 0, st))
+    check(lib.cdae_gn_stats2(ptr(x1), C1, ptr(x2), ld2, C1, N, H * W, C, groups, eps, ptr(stats[0]), ptr(stats[1]), ptr(ws), st))
+    check(lib.cdae_gn_apply_split2(ptr(x1), C1, ptr(x2), ld2, C1, ptr(planes[0]), ptr(planes[1]), N, H * W, C, C, groups, ptr(stats[0]),
+                                   ptr(stats[1]), ptr(gamma), ptr(beta), ptr(scale_shift), 2 * C, 1 if silu else 0, st))
     return SplitAct(planes[0], planes[1], (N, C, H, W))
 
 

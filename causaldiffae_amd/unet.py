@@ -122,7 +122,8 @@ class ResBlock(TimestepBlock):
         return checkpoint(self._forward, (x, emb), self.parameters(), self.use_checkpoint)
 
     def _forward(self, x, emb):
-        x = ops.to_nhwc(x)
+        if not isinstance(x, ops.CatAct):                          # CatAct: the skip concatenation, read in place by GN and the 1x1 skip
+            x = ops.to_nhwc(x)
         h = self.in_layers[0](x, silu=True, split=True)            # GN + SiLU (pre-split f16 planes on the inference path)
         h = self.in_layers[2](h)                                   # conv3x3 + bias
         emb_out = self.emb_layers[1](ops.silu(emb))                # [N, (2)Cout]
@@ -131,7 +132,7 @@ class ResBlock(TimestepBlock):
         else:
             h = self.out_layers[0](h + emb_out[:, :, None, None], silu=True, split=True)
         h = self.out_layers[2](h)
-        skip = x if isinstance(self.skip_connection, Identity) else self.skip_connection(x)
+        skip = ops.materialize(x) if isinstance(self.skip_connection, Identity) else self.skip_connection(x)
         if isinstance(h, ops.SplitAct):                            # emit_split: a Down/Upsample conv consumes this block's output
             return self.out_layers[3](h, res=skip, emit_split=self.emit_split)
         return self.out_layers[3](h, res=skip)                     # conv3x3 + bias + residual

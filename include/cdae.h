@@ -94,6 +94,17 @@ int cdae_linear_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, l
                        long ldw, const float* bias, const float* res, float* y, long ldy, int M, int N, int K, float alpha, int act,
                        float* splitk_ws, size_t splitk_ws_bytes, void* stream);
 int cdae_split_f16(const float* src, unsigned short* hi, unsigned short* lo, long n, void* stream);
+/* y = [x1 | x2] @ w^T + bias with the K range split over two row-major sources (the 1x1 skip conv of a ResBlock fed by the
+   skip concatenation, unet.py:629,198); K1 % 32 == 0 */
+int cdae_linear_fwd_cat(const float* x1, long ld1, int K1, const float* x2, long ld2, const float* w, long ldw, const float* bias, float* y,
+                        long ldy, int M, int N, int K, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
+/* two-source forms: channels [0, C1) are read from x1 (pixel pitch ld1), channels [C1, C) from x2 (pitch ld2) — the skip
+   concatenation th.cat([h, hs.pop()], dim=1) (unet.py:629) consumed in place instead of being copied; x2 == NULL: one source */
+int cdae_gn_stats2(const float* x1, int ld1, const float* x2, int ld2, int C1, int N, int HW, int C, int groups, float eps, float* mean,
+                   float* rstd, float* ws, void* stream);
+int cdae_gn_apply_split2(const float* x, int ldx, const float* x2, int ld2, int C1, unsigned short* y_hi, unsigned short* y_lo, int N, int HW,
+                         int C, int ldy, int groups, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                         const float* scale_shift, int ld_ss, int silu, void* stream);
 int cdae_gn_apply_split(const float* x, unsigned short* y_hi, unsigned short* y_lo, int N, int HW, int C, int ldx, int ldy, int groups,
                         const float* mean, const float* rstd, const float* gamma, const float* beta, const float* scale_shift, int ld_ss,
                         int silu, void* stream);

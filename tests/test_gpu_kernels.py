@@ -416,3 +416,28 @@ def test_epilogue_plane_outputs():
     assert torch.equal(y2, ref)
     hi = ref.half()
     assert torch.equal(planes.hi.reshape(-1, 384), hi) and torch.equal(planes.lo.reshape(-1, 384), (ref - hi.float()).half())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C1,C2,S,ss", [(512, 384, 8, True), (256, 128, 16, False), (128, 128, 32, True)])
+def test_virtual_concat_consumers(C1, C2, S, ss):
+    """GroupNorm and the 1x1 skip conv reading th.cat([a, b], 1) in place (ops.CatAct) == the same ops on the materialised tensor
+    (groups may straddle the seam: 896 channels / 32 groups = 28 per group)."""
+    from causaldiffae_amd import ops
+    g = torch.Generator(device="cuda:0").manual_seed(11)
+    a = ops.to_nhwc(torch.randn(3, C1, S, S, device="cuda:0", generator=g) * 1.5 + 0.3)
+    b = ops.to_nhwc(torch.randn(3, C2, S, S, device="cuda:0", generator=g) * 0.7 - 0.2)
+    C = C1 + C2
+    gamma, beta = torch.randn(C, device="cuda:0", generator=g), torch.randn(C, device="cuda:0", generator=g)
+    sc = torch.randn(3, 2 * C, device="cuda:0", generator=g) * 0.3 if ss else None
+    w = torch.randn(256, C, 1, 1, device="cuda:0", generator=g) / C ** 0.5
+    bias = torch.randn(256, device="cuda:0", generator=g)
+    with torch.no_grad():
+        full = torch.cat([a, b], dim=1)
+        ref = ops.group_norm_split(full, gamma, beta, sc, True)
+        got = ops.group_norm_split(ops.CatAct(a, b), gamma, beta, sc, True)
+        assert torch.equal(got.hi, ref.hi) and torch.equal(got.lo, ref.lo)
+        yref = ops.conv1x1(full, w, bias)
+        ygot = ops.conv1x1_cat(ops.CatAct(a, b), w, bias)
+    assert ygot.shape == yref.shape
+    assert (ygot - yref).abs().max().item() < 2e-6 * max(1.0, yref.abs().max().item())       # K summed in two parts
