@@ -868,13 +868,14 @@ int launch_ps(const GemmParams& p, hipStream_t st) {
 // K order is (chunk, tap, channel) — the sums differ from ps_kernel's (tap, channel) order by fp32 rounding only.
 // BST = 3 weight stages (rows up to 32 pixels: the window is small enough for two blocks per CU): the DMAs of step s+2 are in
 // flight while step s computes, and the loop waits with a counted vmcnt instead of draining.
-template <int BN, int NPL, int BST, int MAXWIN>
-__global__ __launch_bounds__(512, 4) void pswin_kernel(const GemmParams p) {     // 4 waves per SIMD (2 blocks per CU): at most 128 VGPRs
-    constexpr int BM = 128, WAVES_N = 4, THREADS = 512;
+template <int BN, int NPL, int BST, int MAXWIN, int WAVES_N = 4>
+__global__ __launch_bounds__(128 * WAVES_N, WAVES_N) void pswin_kernel(const GemmParams p) {     // two blocks per CU: 8 waves x <= 128 VGPRs or 4 waves x <= 256
+    constexpr int BM = 128, NW = 2 * WAVES_N, THREADS = 64 * NW;
     constexpr int WM = 64, WN = BN / WAVES_N, TM = 2, TN = WN / 32;
     static_assert(MAXWIN % 16 == 0 && (BST == 2 || BST == 3), "window rows come in 16-row DMA blocks");
     constexpr int A_PLANE = MAXWIN * 64, B_PLANE = BN * 64;
-    constexpr int A_SLOTS = 5;                                          // 2 planes x 17 row blocks over 8 waves
+    constexpr int A_SLOTS = (2 * 17 + NW - 1) / NW;                     // 2 planes x 17 row blocks over the block's waves
+    constexpr int B_RB = (BN / 16) / NW;                                // 16-row weight blocks per wave
     typedef const unsigned short* hp;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -911,19 +912,20 @@ __global__ __launch_bounds__(512, 4) void pswin_kernel(const GemmParams p) {    
     int aoff[A_SLOTS];             // element offset of this lane's 16 bytes at chunk 0, or -1 (outside the tensor)
 #pragma unroll
     for (int q = 0; q < A_SLOTS; ++q) {
-        const int pc = wave + 8 * q, pl = pc >= NB ? 1 : 0, rb = pc - pl * NB;
+        const int pc = wave + NW * q, pl = pc >= NB ? 1 : 0, rb = pc - pl * NB;
         const int j = rb * 16 + (lane >> 2);                             // window row
         const int pix = m0 - W - 1 + j;                                  // flattened input pixel (n, y, x)
         const int c = (lane & 3) ^ ((j >> 2) & 3);
         aoff[q] = (pix >= 0 && pix < p.M && j < win) ? pix * (int)p.sx + c * 8 : -1;
     }
-    // ---- B tile pieces: wave w stages rows 16w..16w+15 (hi and lo) — BN = 128: 8 row blocks, one per wave
-    long boff;
-    bool bok;
-    {
-        const int row = wave * 16 + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
-        bok = row < BN && n0 + row < p.N;
-        boff = (long)(bok ? n0 + row : 0) * p.ldb + c * 8;
+    // ---- B tile pieces: wave w stages the 16-row blocks w, w + NW, ... (hi and lo)
+    long boff[B_RB];
+    bool bok[B_RB];
+#pragma unroll
+    for (int q = 0; q < B_RB; ++q) {
+        const int row = (wave + NW * q) * 16 + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
+        bok[q] = n0 + row < p.N;
+        boff[q] = (long)(bok[q] ? n0 + row : 0) * p.ldb + c * 8;
     }
     auto dma = [&](hp src, char* dst_wave_base) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -932,7 +934,7 @@ __global__ __launch_bounds__(512, 4) void pswin_kernel(const GemmParams p) {    
     auto issue_A = [&](int chunk) {
 #pragma unroll
         for (int q = 0; q < A_SLOTS; ++q) {
-            const int pc = wave + 8 * q;
+            const int pc = wave + NW * q;
             if (pc < NPL * NB) {                                         // wave-uniform
                 const int pl = pc >= NB ? 1 : 0, rb = pc - pl * NB;
                 const bool ok = aoff[q] >= 0;
@@ -944,11 +946,12 @@ __global__ __launch_bounds__(512, 4) void pswin_kernel(const GemmParams p) {    
         }
     };
     auto issue_B = [&](int stage, int chunk, int tap) {
-        if (wave * 16 < BN) {
-            char* const dst = bst + stage * (NPL * B_PLANE) + wave * 1024;
-            const long e = boff + (long)tap * p.Cin + chunk * BK;
-            dma(b_hi + (bok ? e : zb_hi), dst);
-            if constexpr (NPL == 2) dma(b_lo + (bok ? e : zb_lo), dst + B_PLANE);
+#pragma unroll
+        for (int q = 0; q < B_RB; ++q) {
+            char* const dst = bst + stage * (NPL * B_PLANE) + (wave + NW * q) * 1024;
+            const long e = boff[q] + (long)tap * p.Cin + chunk * BK;
+            dma(b_hi + (bok[q] ? e : zb_hi), dst);
+            if constexpr (NPL == 2) dma(b_lo + (bok[q] ? e : zb_lo), dst + B_PLANE);
         }
     };
 
@@ -985,6 +988,17 @@ __global__ __launch_bounds__(512, 4) void pswin_kernel(const GemmParams p) {    
         issue_A(c_begin); issue_B(0, c_begin, 0);
         if constexpr (BST == 3) issue_B(1, c_begin, 1);
     }
+    // diagnostic build only (CDAE_PS_DBG & 32): s_memtime stamps around the three segments of a step, summed per wave and
+    // written to the split-K workspace by lane 0 of every wave of the first 64 blocks.  The stamps' lgkmcnt(0) serialises what the
+    // real kernel overlaps: read the SHARES, never the run time of this mode.
+    const bool stamps = (p.dbg & 32) != 0;
+    unsigned long long t_wait = 0, t_issue = 0, t_comp = 0, t_prev = 0;
+    auto stamp = [&]() -> unsigned long long {
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        return t;
+    };
+    if (stamps) t_prev = stamp();
     int stage = 0;
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
 #pragma unroll 1
@@ -992,14 +1006,16 @@ __global__ __launch_bounds__(512, 4) void pswin_kernel(const GemmParams p) {    
             if constexpr (BST == 2) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
+                if (stamps) { const unsigned long long t = stamp(); t_wait += t - t_prev; t_prev = t; }
                 const int ntap = tap == 8 ? 0 : tap + 1, nchk = tap == 8 ? chunk + 1 : chunk;     // stage the next step's weight tile
                 if (nchk < c_end) issue_B(stage ^ 1, nchk, ntap);
+                if (stamps) { const unsigned long long t = stamp(); t_issue += t - t_prev; t_prev = t; }
             } else {
                 // weights of this step landed when only the next step's NPL pieces may still be in flight; at tap 0 the window
                 // (issued last) must be complete too, and on the very last step nothing younger exists: drain.
                 const bool last = chunk + 1 == c_end && tap == 8;
                 if (tap == 0 || last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPL) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPL * B_RB) : "memory");
                 __builtin_amdgcn_s_barrier();
                 const int t2 = tap + 2, ntap = t2 >= 9 ? t2 - 9 : t2, nchk = t2 >= 9 ? chunk + 1 : chunk;
                 if (nchk < c_end) issue_B(stage >= 1 ? stage - 1 : 2, nchk, ntap);                // (stage + 2) % 3
@@ -1048,6 +1064,7 @@ __global__ __launch_bounds__(512, 4) void pswin_kernel(const GemmParams p) {    
                     }
             }
             stage = stage + 1 == BST ? 0 : stage + 1;
+            if (stamps) { const unsigned long long t = stamp(); t_comp += t - t_prev; t_prev = t; }
         }
         if (chunk + 1 < c_end) {
             __builtin_amdgcn_s_barrier();                                // every wave is done with this chunk's window
@@ -1055,6 +1072,10 @@ __global__ __launch_bounds__(512, 4) void pswin_kernel(const GemmParams p) {    
         }
     }
 
+    if (stamps && blockIdx.x < 64 && lane == 0 && p.splitk_ws && p.ksplit == 1) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(p.splitk_ws) + (blockIdx.x * NW + wave) * 4;
+        o[0] = t_wait; o[1] = t_issue; o[2] = t_comp; o[3] = stamp() - t_prev;
+    }
     // ---------------------------------------------------------------- epilogue (row-major result)
     float* __restrict__ Cg;
     const float* __restrict__ Rg = nullptr;
@@ -1084,17 +1105,19 @@ __global__ __launch_bounds__(512, 4) void pswin_kernel(const GemmParams p) {    
         }
 }
 
-template <int BN, int NPL, int BST, int MAXWIN>
+template <int BN, int NPL, int BST, int MAXWIN, int WAVES_N = 4>
 int launch_pswin(const GemmParams& p, hipStream_t st) {
     constexpr size_t smem = (size_t)NPL * MAXWIN * 64 + (size_t)BST * NPL * BN * 64;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pswin_kernel<BN, NPL, BST, MAXWIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
         attr_done = true;
     }
     dim3 grid((unsigned)((long)((p.M + 127) / 128) * ((p.N + BN - 1) / BN) * p.ksplit));
-    hipLaunchKernelGGL((pswin_kernel<BN, NPL, BST, MAXWIN>), grid, dim3(512), smem, st, p);
+    static const size_t pad = getenv("CDAE_PS_PAD_LDS") ? (size_t)atoi(getenv("CDAE_PS_PAD_LDS")) : 0;       // dev: force fewer blocks per CU
+    if (pad) hipFuncSetAttribute(reinterpret_cast<const void*>(&pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem + pad));
+    hipLaunchKernelGGL((pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N>), grid, dim3(128 * WAVES_N), smem + pad, st, p);
     return hipGetLastError() == hipSuccess ? 0 : cdae_fail("pswin_kernel launch failed");
 }
 
@@ -1260,7 +1283,8 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
             if (p.ksplit > nchunk) p.ksplit = nchunk;              // K is split by whole channel chunks here
             ks = p.ksplit;
             const bool deep = p.W <= 32 && cfg_win == 3;           // CDAE_PS_WIN=3: 3-stage weight ring where it fits (measured: no gain over 2 stages)
-            if (p.prec == 1) rc = deep ? launch_pswin<128, 2, 3, 208>(p, st) : launch_pswin<128, 2, 2, 272>(p, st);
+            if (p.prec == 1 && cfg_win == 4) rc = launch_pswin<128, 2, 2, 272, 2>(p, st);       // CDAE_PS_WIN=4: 4 waves of 64x64 per block
+            else if (p.prec == 1) rc = deep ? launch_pswin<128, 2, 3, 208>(p, st) : launch_pswin<128, 2, 2, 272>(p, st);
             else rc = deep ? launch_pswin<128, 1, 3, 208>(p, st) : launch_pswin<128, 1, 2, 272>(p, st);
         }
         static const int cfg_loaders = getenv("CDAE_PS_LOADERS") ? atoi(getenv("CDAE_PS_LOADERS")) : 0;

@@ -16,6 +16,7 @@ def split(x):
     return ops.SplitAct(planes[0], planes[1], (N, C, H, W))
 
 
+STAMPS = (int(os.environ.get("CDAE_PS_DBG", "0")) & 32) != 0
 for (ci, co, r) in [(128, 128, 64), (256, 256, 32), (384, 384, 16), (512, 512, 8), (1024, 512, 8)]:
     x = torch.randn(B, ci, r, r, device=DEV)
     xs = split(x)
@@ -33,3 +34,11 @@ for (ci, co, r) in [(128, 128, 64), (256, 256, 32), (384, 384, 16), (512, 512, 8
         us = e0.elapsed_time(e1) * 100
         fl = 2.0 * B * r * r * co * ci * 9
         print(f"dbg={os.environ.get('CDAE_PS_DBG','0')} conv {ci}->{co} @{r}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF")
+        if STAMPS:
+            from causaldiffae_amd._lib import splitk_ws
+            w64 = splitk_ws(torch.device(DEV)).view(torch.int64)[:64 * 8 * 4].reshape(64 * 8, 4).double().cpu()
+            tot = w64.sum(1, keepdim=True)
+            sh = (w64 / tot).mean(0)
+            steps = 9 * ci // 32
+            print(f"    per step (cycles @100MHz-ish memtime units): wait+barrier {w64[:,0].mean()/steps:8.1f}  issue {w64[:,1].mean()/steps:8.1f}  "
+                  f"compute {w64[:,2].mean()/steps:8.1f}   shares wait {sh[0]:.2f} issue {sh[1]:.2f} compute {sh[2]:.2f} tail {sh[3]:.2f}")
