@@ -72,7 +72,7 @@ int cdae_conv3x3_fwd(const float* x, long sn, long sy, long sx, long sc, const f
 
 int cdae_conv3x3_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, long sn, long sy, long sx, const unsigned short* w_hi,
                         const unsigned short* w_lo, const float* bias, const float* res, float* out, long ldo, int out_nchw,
-                        unsigned short* out_hi, unsigned short* out_lo, int N, int H, int W,
+                        unsigned short* out_hi, unsigned short* out_lo, float* gn_part, int N, int H, int W,
                         int Cin, int Cout, int stride, int up, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
     if (stride != 1 && stride != 2) return cdae_fail("conv3x3: stride must be 1 or 2");
     if (out_hi && (out_nchw || !out_lo)) return cdae_fail("conv3x3_fwd_ps: plane output needs both planes and a row-major result");
@@ -84,14 +84,14 @@ int cdae_conv3x3_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, 
     GemmParams p = base_params();
     p.presplit = 1;
     p.A = reinterpret_cast<const float*>(x_hi); p.A_lo = x_lo; p.B = reinterpret_cast<const float*>(w_hi); p.B_lo = w_lo;
-    p.C = out; p.bias = bias; p.res = res; p.C_hi = out_hi; p.C_lo = out_lo;
+    p.C = out; p.bias = bias; p.res = res; p.C_hi = out_hi; p.C_lo = out_lo; p.gn_part = gn_part;
     p.M = N * Ho * Wo; p.N = Cout; p.K = 9 * Cin;
     p.ldb = 9L * Cin; p.ldc = ldo;
     p.out_mode = out_nchw ? OUT_NCHW : OUT_ROWMAJOR; p.out_hw = Ho * Wo;
     p.amode = A_CONV_VEC; p.bmode = B_PLAIN_KC;
     p.conv_M = p.M; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.up = up;
     p.sn = sn; p.sy = sy; p.sx = sx; p.sc = 1;
-    set_splitk(p, out_nchw ? nullptr : splitk_ws, splitk_ws_bytes);
+    set_splitk(p, (out_nchw || gn_part) ? nullptr : splitk_ws, splitk_ws_bytes);      // epilogue statistics need the final values: no split-K
     if (out_nchw && res) return cdae_fail("conv3x3: residual with NCHW output unsupported");
     return cdae_gemm_dispatch(p, stream);
 }
@@ -101,8 +101,8 @@ int cdae_conv3x3_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, 
 // 2+1, likewise for columns — 16 instead of 36 multiply-adds per (pixel, channel pair).  w4 = [4 phases][Cout][2][2][Cin]
 // folded weights (hi / lo planes); the result lands in out[N, 2H, 2W, Cout] rows of pitch ldo.
 int cdae_upconv3x3_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, long sn, long sy, long sx, const unsigned short* w4_hi,
-                          const unsigned short* w4_lo, const float* bias, float* out, long ldo, int N, int H, int W, int Cin, int Cout,
-                          float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+                          const unsigned short* w4_lo, const float* bias, float* out, long ldo, float* gn_part, int N, int H, int W, int Cin,
+                          int Cout, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
     if ((long)N * H * W * sx >= (1L << 31)) return cdae_fail("upconv3x3_fwd_ps: activation larger than 2^31 elements");
     if (sx % 8 || sy % 8 || sn % 8 || !aligned16(x_hi) || !aligned16(x_lo) || !aligned16(w4_hi) || !aligned16(w4_lo))
         return cdae_fail("upconv3x3_fwd_ps: planes must be 16-byte aligned with pixel pitch % 8 == 0");
@@ -116,10 +116,11 @@ int cdae_upconv3x3_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo
         p.M = N * H * W; p.N = Cout; p.K = 4 * Cin;
         p.ldb = 4L * Cin; p.ldc = ldo;
         p.out_mode = OUT_UP2;
+        if (gn_part) p.gn_part = gn_part + (long)ph * ((p.M + 31) / 32) * Cout * 2;
         p.amode = A_CONV_VEC; p.bmode = B_PLAIN_KC;
         p.conv_M = p.M; p.H = H; p.W = W; p.Cin = Cin; p.Ho = H; p.Wo = W; p.stride = 1; p.up = 0;
         p.sn = sn; p.sy = sy; p.sx = sx; p.sc = 1;
-        set_splitk(p, splitk_ws, splitk_ws_bytes);
+        set_splitk(p, gn_part ? nullptr : splitk_ws, splitk_ws_bytes);
         const int rc = cdae_gemm_dispatch(p, stream);
         if (rc) return rc;
     }

@@ -47,6 +47,9 @@ struct GemmParams {
     // ps_kernel sub-pixel phase of a nearest-2x-upsample + conv3x3 (ps_taps == 4): 2x2 taps at offset (ph_y, ph_x), and
     // out_mode OUT_UP2 scatters GEMM row (n, y, x) to output pixel (n, 2y + ph_y, 2x + ph_x)
     int ps_taps, ph_y, ph_x;
+    // ps_kernel / pswin_kernel epilogues: per (32-row chunk, column) partial (sum, sum of squares) of the FINAL output values,
+    // [ceil(M/32)][N][2] floats — the GroupNorm statistics of the next layer without another pass over the tensor
+    float* gn_part;
     int dbg;                // dev ablations of ps_kernel (env CDAE_PS_DBG): 1 A rows -> one hot line, 2 B rows -> hot, 4 no loads after the first
     const unsigned short* A_lo; const unsigned short* B_lo;
 };

@@ -817,6 +817,7 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + LOADERS)) void ps_kernel(
             const int col = n0 + wn * WN + j * 32 + l31;
             if (col >= p.N) continue;
             const float bv = (p.ksplit == 1 && p.bias) ? p.bias[col] : 0.f;
+            float gs = 0.f, gq = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -837,6 +838,14 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + LOADERS)) void ps_kernel(
                 if (p.accumulate) v += Cg[addr];
                 Cg[addr] = v;
                 if (p.C_hi) store_planes(p, addr, v);
+                gs += v; gq += v * v;
+            }
+            if (p.gn_part && p.ksplit == 1) {           // this wave owns the whole 32 x 32 sub-tile: one deterministic write per (chunk, column)
+                gs += __shfl_xor(gs, 32); gq += __shfl_xor(gq, 32);
+                if (hh == 0) {
+                    float* o = p.gn_part + ((long)((m0 + wm * WM + i * 32) >> 5) * p.N + col) * 2;
+                    o[0] = gs; o[1] = gq;
+                }
             }
         }
 }
@@ -1088,6 +1097,7 @@ __global__ __launch_bounds__(128 * WAVES_N, WAVES_N) void pswin_kernel(const Gem
             const int col = n0 + wn * WN + j * 32 + l31;
             if (col >= p.N) continue;
             const float bv = (p.ksplit == 1 && p.bias) ? p.bias[col] : 0.f;
+            float gs = 0.f, gq = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -1101,6 +1111,14 @@ __global__ __launch_bounds__(128 * WAVES_N, WAVES_N) void pswin_kernel(const Gem
                 if (p.accumulate) v += Cg[addr];
                 Cg[addr] = v;
                 if (p.C_hi) store_planes(p, addr, v);
+                gs += v; gq += v * v;
+            }
+            if (p.gn_part && p.ksplit == 1) {
+                gs += __shfl_xor(gs, 32); gq += __shfl_xor(gq, 32);
+                if (hh == 0) {
+                    float* o = p.gn_part + ((long)((m0 + wm * WM + i * 32) >> 5) * p.N + col) * 2;
+                    o[0] = gs; o[1] = gq;
+                }
             }
         }
 }
@@ -1266,6 +1284,8 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
     if (ks > 1 && (!p.splitk_ws || (size_t)ks * p.batch * p.M * p.N * sizeof(float) > p.splitk_ws_bytes))
         return cdae_fail("split-K workspace too small");
     p.ksplit = ks;
+    if (p.gn_part && (ks > 1 || !p.presplit || (p.out_mode != OUT_ROWMAJOR && p.out_mode != OUT_UP2) || p.accumulate))
+        return cdae_fail("GroupNorm partial sums from the epilogue need a pre-split, unsplit-K, row-major, non-accumulating launch");
 
     cdae_prof_begin(PROF_IGEMM, 2.0 * p.M * p.N * (double)p.K * p.batch, st);
     int rc = -1;

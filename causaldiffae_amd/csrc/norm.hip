@@ -94,6 +94,46 @@ __global__ void gn_finalize_kernel(const float* __restrict__ x, int HW, int ldx,
     rstd[n * G + g] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// GroupNorm statistics from per-(32-row chunk, channel) partial (sum, sumsq) left behind by the producing conv's epilogue
+// (igemm.hip ps_kernel / pswin_kernel), for one or two sources (a channel concatenation).  Two small kernels, fixed summation
+// order (deterministic): (1) grid (N, C/32): 8 chunk-lanes x 32 channels per block fold the image's HW/32 chunks per channel in
+// f64 -> chan[n][c] = (sum, sumsq); (2) grid N: thread g folds the channels of group g.
+// nseg: a tensor written by the four sub-pixel phases of an up-conv carries four segments of partials, each [N][HW/4/32][C][2].
+__global__ __launch_bounds__(256) void gn_parts_channel_kernel(const float* __restrict__ part1, int C1, int nseg1, const float* __restrict__ part2,
+                                                                int C2, int nseg2, int N, int HW, double* __restrict__ chan) {
+    __shared__ double sS[8][32], sQ[8][32];
+    const int n = blockIdx.y, C = C1 + C2;
+    const int cl = threadIdx.x >> 5, c = blockIdx.x * 32 + (threadIdx.x & 31);
+    double s = 0.0, q = 0.0;
+    if (c < C) {
+        const bool second = c >= C1;
+        const int Cs = second ? C2 : C1, nseg = second ? nseg2 : nseg1, nch = (HW / nseg) >> 5;
+        const float2* base = reinterpret_cast<const float2*>(second ? part2 : part1) + (second ? c - C1 : c);
+        for (int sg = 0; sg < nseg; ++sg) {
+            const float2* src = base + ((long)sg * N + n) * nch * Cs;
+            for (int k = cl; k < nch; k += 8) { const float2 v = src[(long)k * Cs]; s += v.x; q += v.y; }
+        }
+    }
+    sS[cl][threadIdx.x & 31] = s; sQ[cl][threadIdx.x & 31] = q;
+    __syncthreads();
+    if (cl == 0 && c < C) {
+        for (int k = 1; k < 8; ++k) { s += sS[k][threadIdx.x]; q += sQ[k][threadIdx.x]; }
+        chan[((long)n * C + c) * 2] = s; chan[((long)n * C + c) * 2 + 1] = q;
+    }
+}
+__global__ void gn_parts_group_kernel(const double* __restrict__ chan, int C, int HW, int cpg, int G, float eps,
+                                      float* __restrict__ mean, float* __restrict__ rstd) {
+    const int n = blockIdx.x, g = threadIdx.x;
+    if (g >= G) return;
+    double s = 0.0, q = 0.0;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s += chan[((long)n * C + c) * 2]; q += chan[((long)n * C + c) * 2 + 1]; }
+    const double cnt = (double)HW * cpg, m = s / cnt;
+    double var = q / cnt - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[n * G + g] = (float)m;
+    rstd[n * G + g] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
 // y = silu?( gn(x) * gamma + beta  [ * (1 + scale) + shift ] )
 // grid (nchunk, N), 256 threads: a thread owns one channel vector for the whole chunk, so the normalisation folds into a
 // per-thread affine (y = x*A + B, the form ATen's CPU kernel uses too) computed once; the pixel loop is pure
@@ -581,6 +621,22 @@ int cdae_gn_apply_split(const float* x, unsigned short* y_hi, unsigned short* y_
                         const float* mean, const float* rstd, const float* gamma, const float* beta, const float* scale_shift, int ld_ss,
                         int silu, void* stream) {
     return cdae_gn_apply_split2(x, ldx, nullptr, 0, C, y_hi, y_lo, N, HW, C, ldy, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, stream);
+}
+
+int cdae_gn_stats_from_parts(const float* part1, int C1, int nseg1, const float* part2, int C2, int nseg2, int N, int HW, int groups, float eps,
+                             float* mean, float* rstd, float* ws /* >= N * C * 4 floats */, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int C = C1 + C2;
+    if (nseg1 < 1 || HW % (32 * nseg1) || (part2 && (nseg2 < 1 || HW % (32 * nseg2)))) return cdae_fail("gn_stats_from_parts: HW must be a multiple of 32 per segment");
+    if (HW % 32 || C % groups || groups > 256 || (part2 == nullptr) != (C2 == 0) || (((size_t)ws) & 7))
+        return cdae_fail("gn_stats_from_parts: HW % 32 == 0, groups <= 256 and an 8-byte aligned workspace required");
+    double* chan = reinterpret_cast<double*>(ws);
+    cdae_prof_begin(PROF_GN, (double)N * (HW / 32) * C * 8.0, st);
+    hipLaunchKernelGGL(gn_parts_channel_kernel, dim3((C + 31) / 32, N), dim3(256), 0, st, part1, C1, nseg1, part2, C2, part2 ? nseg2 : 1, N, HW, chan);
+    hipLaunchKernelGGL(gn_parts_group_kernel, dim3(N), dim3(groups < 64 ? 64 : groups), 0, st, chan, C, HW, C / groups, groups, eps, mean, rstd);
+    cdae_prof_end(PROF_GN, st);
+    CHECK_LAUNCH("gn_stats_from_parts launch failed");
+    return 0;
 }
 
 int cdae_gn_stats2(const float* x1, int ld1, const float* x2, int ld2, int C1, int N, int HW, int C, int groups, float eps, float* mean,

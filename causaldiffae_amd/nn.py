@@ -100,10 +100,11 @@ class ConvNd(nn.Module):
         bound = 1 / math.sqrt(in_channels * kernel_size ** dims)
         self.bias = nn.Parameter(th.empty(out_channels).uniform_(-bound, bound))
 
-    def forward(self, x, res=None, up=False, out_nchw=False, emit_split=False):
+    def forward(self, x, res=None, up=False, out_nchw=False, emit_split=False, gn_stats=False):
         if isinstance(x, ops.SplitAct):
             assert self.kernel_size == 3
-            return ops.conv3x3_ps(x, self.weight, self.bias, res=res, stride=self.stride, up=up, out_nchw=out_nchw, emit_split=emit_split)
+            return ops.conv3x3_ps(x, self.weight, self.bias, res=res, stride=self.stride, up=up, out_nchw=out_nchw, emit_split=emit_split,
+                                  gn_stats=gn_stats)
         if isinstance(x, ops.CatAct):
             if self.kernel_size == 1 and res is None:
                 return ops.conv1x1_cat(x, self.weight, self.bias)

@@ -703,7 +703,14 @@ def group_norm_split(x, gamma, beta, scale_shift=None, silu=False, groups=32, ep
     ws = workspace(dev, "gn", 4 * lib.cdae_gn_workspace_floats(N, C))
     planes = torch.empty((2, N, H, W, C), dtype=torch.float16, device=dev)
     st = stream()
-    check(lib.cdae_gn_stats2(ptr(x1), C1, ptr(x2), ld2, C1, N, H * W, C, groups, eps, ptr(stats[0]), ptr(stats[1]), ptr(ws), st))
+    p1, p2 = getattr(x1, "_gnparts", None), getattr(x2, "_gnparts", None) if x2 is not None else None
+    if p1 is not None and (x2 is None or p2 is not None) and (H * W) % 32 == 0:
+        # the producing conv(s) left per-chunk partial sums behind: no statistics pass over the tensor
+        check(lib.cdae_gn_stats_from_parts(ptr(p1), C1, getattr(x1, "_gnseg", 1), ptr(p2), 0 if x2 is None else C - C1,
+                                           1 if x2 is None else getattr(x2, "_gnseg", 1), N, H * W, groups, eps,
+                                           ptr(stats[0]), ptr(stats[1]), ptr(workspace(dev, "gnparts", 16 * N * C)), st))
+    else:
+        check(lib.cdae_gn_stats2(ptr(x1), C1, ptr(x2), ld2, C1, N, H * W, C, groups, eps, ptr(stats[0]), ptr(stats[1]), ptr(ws), st))
     check(lib.cdae_gn_apply_split2(ptr(x1), C1, ptr(x2), ld2, C1, ptr(planes[0]), ptr(planes[1]), N, H * W, C, C, groups, ptr(stats[0]),
                                    ptr(stats[1]), ptr(gamma), ptr(beta), ptr(scale_shift), 2 * C, 1 if silu else 0, st))
     return SplitAct(planes[0], planes[1], (N, C, H, W))
@@ -740,7 +747,7 @@ def fold_upconv_weight(w):
     return planes[0], planes[1]
 
 
-def upconv3x3_ps(xs, w, b=None):
+def upconv3x3_ps(xs, w, b=None, gn_stats=False):
     """nearest-2x upsample + conv3x3 of a SplitAct as four 2x2 sub-pixel convolutions (2.25x fewer multiply-adds)."""
     N, Cin, H, W = xs.shape
     Cout = w.shape[0]
@@ -748,16 +755,22 @@ def upconv3x3_ps(xs, w, b=None):
     dev = xs.hi.device
     out = new_act(N, Cout, 2 * H, 2 * W, dev)
     ws, wsb = _sk(dev)
+    M = N * H * W
+    gn_stats = gn_stats and (H * W) % 32 == 0 and ((M + 127) // 128) * ((Cout + 127) // 128) >= 256
+    parts = torch.empty((4, M // 32, Cout, 2), dtype=torch.float32, device=dev) if gn_stats else None
     check(lib.cdae_upconv3x3_fwd_ps(ptr(xs.hi), ptr(xs.lo), H * W * Cin, W * Cin, Cin, ptr(w_hi), ptr(w_lo), ptr(b), ptr(out), Cout,
-                                    N, H, W, Cin, Cout, ws, wsb, stream()))
+                                    ptr(parts), N, H, W, Cin, Cout, ws, wsb, stream()))
+    if gn_stats:
+        out._gnparts, out._gnseg = parts, 4
     return out
 
 
-def conv3x3_ps(xs, w, b=None, res=None, stride=1, up=False, out_nchw=False, emit_split=False):
+def conv3x3_ps(xs, w, b=None, res=None, stride=1, up=False, out_nchw=False, emit_split=False, gn_stats=False):
     """conv3x3 of a SplitAct with pre-split OHWI weights (no autograd); result fp32 like ops.conv3x3.  emit_split: the result
-    also leaves the kernel as f16 planes, attached as `out._split` for a following conv."""
+    also leaves the kernel as f16 planes, attached as `out._split` for a following conv.  gn_stats: the epilogue also leaves
+    per-(32-pixel chunk, channel) partial sums (`out._gnparts`) from which the next GroupNorm takes its statistics."""
     if up and not res and not out_nchw and not emit_split:
-        return upconv3x3_ps(xs, w, b)
+        return upconv3x3_ps(xs, w, b, gn_stats)
     N, Cin, H, W = xs.shape
     Cout = w.shape[0]
     w_hi, w_lo = split_weight(ohwi(w))                 # channels_last storage == OHWI (ohwi() returns w itself then: cached)
@@ -769,11 +782,18 @@ def conv3x3_ps(xs, w, b=None, res=None, stride=1, up=False, out_nchw=False, emit
         res = to_nhwc(res)
     ws, wsb = _sk(dev)
     planes = torch.empty((2, N, Ho, Wo, Cout), dtype=torch.float16, device=dev) if emit_split else None
+    M = N * Ho * Wo
+    # statistics need the final values in the epilogue, i.e. no split-K: only where the unsplit grid fills the chip anyway
+    # (the dispatcher's own rule: >= 256 tiles of 128 x 128), and where a 32-pixel chunk never straddles two images
+    gn_stats = gn_stats and not out_nchw and (Ho * Wo) % 32 == 0 and ((M + 127) // 128) * ((Cout + 127) // 128) >= 256
+    parts = torch.empty(((M + 31) // 32, Cout, 2), dtype=torch.float32, device=dev) if gn_stats else None
     check(lib.cdae_conv3x3_fwd_ps(ptr(xs.hi), ptr(xs.lo), H * W * Cin, W * Cin, Cin, ptr(w_hi), ptr(w_lo), ptr(b), ptr(res), ptr(out), Cout,
                                   1 if out_nchw else 0, ptr(planes[0]) if emit_split else None, ptr(planes[1]) if emit_split else None,
-                                  N, H, W, Cin, Cout, stride, 1 if up else 0, ws, wsb, stream()))
+                                  ptr(parts), N, H, W, Cin, Cout, stride, 1 if up else 0, ws, wsb, stream()))
     if emit_split:
         out._split = SplitAct(planes[0], planes[1], (N, Cout, Ho, Wo))
+    if gn_stats:
+        out._gnparts = parts
     return out
 
 

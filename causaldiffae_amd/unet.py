@@ -77,7 +77,7 @@ class Upsample(nn.Module):
         assert x.shape[1] == self.channels
         xs = getattr(x, "_split", None)        # pre-split planes left by the producing kernel (inference): sub-pixel form
         if xs is not None and ops.presplit_ok():
-            return self.conv(xs, up=True)
+            return self.conv(xs, up=True, gn_stats=True)
         return self.conv(x, up=True)           # nearest-2x folded into the conv's input gather
 
 
@@ -93,7 +93,7 @@ class Downsample(nn.Module):
         assert x.shape[1] == self.channels
         xs = getattr(x, "_split", None)
         if xs is not None and ops.presplit_ok():
-            return self.op(xs)
+            return self.op(xs, gn_stats=True)
         return self.op(x)
 
 
@@ -125,7 +125,8 @@ class ResBlock(TimestepBlock):
         if not isinstance(x, ops.CatAct):                          # CatAct: the skip concatenation, read in place by GN and the 1x1 skip
             x = ops.to_nhwc(x)
         h = self.in_layers[0](x, silu=True, split=True)            # GN + SiLU (pre-split f16 planes on the inference path)
-        h = self.in_layers[2](h)                                   # conv3x3 + bias
+        fast = isinstance(h, ops.SplitAct)
+        h = self.in_layers[2](h, gn_stats=True) if fast else self.in_layers[2](h)     # conv3x3 + bias (+ GroupNorm partial sums)
         emb_out = self.emb_layers[1](ops.silu(emb))                # [N, (2)Cout]
         if self.use_scale_shift_norm:
             h = self.out_layers[0](h, scale_shift=emb_out, silu=True, split=True)
@@ -134,7 +135,7 @@ class ResBlock(TimestepBlock):
         h = self.out_layers[2](h)
         skip = ops.materialize(x) if isinstance(self.skip_connection, Identity) else self.skip_connection(x)
         if isinstance(h, ops.SplitAct):                            # emit_split: a Down/Upsample conv consumes this block's output
-            return self.out_layers[3](h, res=skip, emit_split=self.emit_split)
+            return self.out_layers[3](h, res=skip, emit_split=self.emit_split, gn_stats=True)
         return self.out_layers[3](h, res=skip)                     # conv3x3 + bias + residual
 
 

@@ -83,13 +83,22 @@ int cdae_conv3x3_fwd(const float* x, long sn, long sy, long sx, long sc, const f
    cdae_linear_fwd in f16x3 mode.  Strides in elements of a plane; Cin (K) % 32 == 0, pixel pitch % 8 == 0. */
 int cdae_conv3x3_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, long sn, long sy, long sx, const unsigned short* w_hi,
                         const unsigned short* w_lo, const float* bias, const float* res, float* out, long ldo, int out_nchw,
-                        unsigned short* out_hi, unsigned short* out_lo, int N, int H, int W,
+                        unsigned short* out_hi, unsigned short* out_lo,
+                        float* gn_part /* optional [ceil(M/32)][Cout][2]: per (32-pixel chunk, channel) sum and sum of squares of the
+                                          result, consumed by cdae_gn_stats_from_parts; disables split-K */,
+                        int N, int H, int W,
                         int Cin, int Cout, int stride, int up, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
+/* GroupNorm mean / rstd of a tensor (or of the channel concatenation of two) from the partial sums its producing conv(s) left
+   behind — replaces the statistics pass of cdae_gn_stats(2).  HW % 32 == 0. */
+int cdae_gn_stats_from_parts(const float* part1, int C1, int nseg1 /* 1, or 4 for a sub-pixel up-conv result */, const float* part2, int C2,
+                             int nseg2, int N, int HW, int groups, float eps, float* mean, float* rstd,
+                             float* ws /* N * (C1 + C2) * 4 floats, 8-byte aligned */, void* stream);
 /* nearest-2x upsample + conv3x3 (unet.py:67-76) as four 2x2 sub-pixel convolutions of the low-resolution input: 2.25x fewer
    multiply-adds than convolving the upsampled image.  w4 = [4][Cout][2][2][Cin] folded weights as hi / lo planes. */
 int cdae_upconv3x3_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, long sn, long sy, long sx, const unsigned short* w4_hi,
-                          const unsigned short* w4_lo, const float* bias, float* out, long ldo, int N, int H, int W, int Cin, int Cout,
-                          float* splitk_ws, size_t splitk_ws_bytes, void* stream);
+                          const unsigned short* w4_lo, const float* bias, float* out, long ldo,
+                          float* gn_part /* optional [4][N*H*W/32][Cout][2] partial sums, one segment per phase */,
+                          int N, int H, int W, int Cin, int Cout, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
 int cdae_linear_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, long ldx, const unsigned short* w_hi, const unsigned short* w_lo,
                        long ldw, const float* bias, const float* res, float* y, long ldy, int M, int N, int K, float alpha, int act,
                        float* splitk_ws, size_t splitk_ws_bytes, void* stream);

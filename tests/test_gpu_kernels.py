@@ -441,3 +441,58 @@ def test_virtual_concat_consumers(C1, C2, S, ss):
         ygot = ops.conv1x1_cat(ops.CatAct(a, b), w, bias)
     assert ygot.shape == yref.shape
     assert (ygot - yref).abs().max().item() < 2e-6 * max(1.0, yref.abs().max().item())       # K summed in two parts
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,Cin,Cout,S,stride,cat", [(32, 128, 128, 32, 1, False), (48, 256, 384, 16, 1, True), (64, 128, 256, 32, 2, False)])
+def test_groupnorm_statistics_from_conv_epilogue(N, Cin, Cout, S, stride, cat):
+    """GroupNorm fed by the partial sums a conv epilogue leaves behind == GroupNorm with its own statistics pass (also for the
+    channel concatenation of two such tensors, with groups straddling the seam)."""
+    from causaldiffae_amd import ops
+    g = torch.Generator(device="cuda:0").manual_seed(12)
+    x = ops.to_nhwc(torch.randn(N, Cin, S, S, device="cuda:0", generator=g))
+    w = (torch.randn(Cout, Cin, 3, 3, device="cuda:0", generator=g) / (9 * Cin) ** 0.5).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(Cout, device="cuda:0", generator=g)
+    with torch.no_grad():
+        y = ops.conv3x3_ps(_split_nhwc(x), w, b, stride=stride, gn_stats=True)
+        assert hasattr(y, "_gnparts")
+        plain = ops.conv3x3_ps(_split_nhwc(x), w, b, stride=stride)
+        assert torch.equal(y, plain)
+        So = y.shape[2]
+        parts = y._gnparts.double()
+        yr = y.permute(0, 2, 3, 1).reshape(-1, 32, Cout).double()
+        assert (parts[:, :, 0] - yr.sum(1)).abs().max().item() < 1e-4 and (parts[:, :, 1] - (yr * yr).sum(1)).abs().max().item() < 1e-3
+        if cat:
+            w2 = (torch.randn(128, Cin, 3, 3, device="cuda:0", generator=g) / (9 * Cin) ** 0.5).contiguous(memory_format=torch.channels_last)
+            y2 = ops.conv3x3_ps(_split_nhwc(x), w2, None, gn_stats=True)
+            src, C = ops.CatAct(y, y2), Cout + 128
+            ref_in = ops.CatAct(y.detach().clone(), y2.detach().clone())        # clones carry no partial sums: statistics pass
+        else:
+            src, C = y, Cout
+            ref_in = y.detach().clone()
+        gamma, beta = torch.randn(C, device="cuda:0", generator=g), torch.randn(C, device="cuda:0", generator=g)
+        got = ops.group_norm_split(src, gamma, beta, None, True)
+        ref = ops.group_norm_split(ref_in, gamma, beta, None, True)
+    d = ((got.hi.float() + got.lo.float()) - (ref.hi.float() + ref.lo.float())).abs().max().item()
+    assert d < 2e-5, d
+
+
+@pytest.mark.gpu
+def test_groupnorm_statistics_from_upconv_phases():
+    """A sub-pixel up-conv leaves four segments of partial sums (one per output parity); the next GroupNorm folds them."""
+    from causaldiffae_amd import ops
+    g = torch.Generator(device="cuda:0").manual_seed(13)
+    x = ops.to_nhwc(torch.randn(64, 256, 16, 16, device="cuda:0", generator=g))
+    w = (torch.randn(256, 256, 3, 3, device="cuda:0", generator=g) / 48.0).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(256, device="cuda:0", generator=g)
+    skip = ops.to_nhwc(torch.randn(64, 128, 32, 32, device="cuda:0", generator=g))
+    gamma, beta = torch.randn(384, device="cuda:0", generator=g), torch.randn(384, device="cuda:0", generator=g)
+    with torch.no_grad():
+        y = ops.upconv3x3_ps(_split_nhwc(x), w, b, gn_stats=True)
+        assert y._gnseg == 4 and torch.equal(y, ops.upconv3x3_ps(_split_nhwc(x), w, b))
+        wk = (torch.randn(128, 128, 3, 3, device="cuda:0", generator=g) / 34.0).contiguous(memory_format=torch.channels_last)
+        s2 = ops.conv3x3_ps(_split_nhwc(skip), wk, None, gn_stats=True)
+        got = ops.group_norm_split(ops.CatAct(y, s2), gamma, beta, None, True)
+        ref = ops.group_norm_split(ops.CatAct(y.detach().clone(), s2.detach().clone()), gamma, beta, None, True)
+    d = ((got.hi.float() + got.lo.float()) - (ref.hi.float() + ref.lo.float())).abs().max().item()
+    assert d < 2e-5, d
