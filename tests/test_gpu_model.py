@@ -656,3 +656,25 @@ def test_diffae_family_golden(golden, precision):
     out = counterfactual_sample(model, diff, x0, None, 1, 0.4, extra_kwargs=dict(c=c.to(DEV), y=y.to(DEV)), q_noise=noise,
                                 z_eps=torch.from_numpy(g["diffae/z_eps"]).to(DEV))
     assert err(out, g["diffae/sample"]) < 1e-4
+
+
+@pytest.mark.gpu
+def test_mixed16_inference_on_presplit_path():
+    """The reduced-precision torso (convert_to_fp16 -> single f16 plane, one MFMA per product) through the pre-split / window
+    kernels: tracks the default f16x3 result to f16 accuracy."""
+    from causaldiffae_amd._lib import get_precision, set_precision
+    model, diff, cfg = make("P64")
+    model.eval()
+    x, x0, c, z, y = model_inputs("P64", cfg, 2)
+    t = torch.tensor([37.0, 990.0], device=DEV)
+    prev = get_precision()
+    try:
+        with torch.no_grad():
+            set_precision("f16x3")
+            ref = model(x.to(DEV), t, z=z.to(DEV))[0]
+            set_precision("mixed16")
+            got = model(x.to(DEV), t, z=z.to(DEV))[0]
+    finally:
+        set_precision(prev)
+    rel = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert 0 < rel < 2e-2, rel
