@@ -144,6 +144,8 @@ class GroupNorm32(nn.Module):
         as pre-split f16 planes (ops.SplitAct) for the LDS-DMA kernel."""
         if split and len(x.shape) == 4 and ops.presplit_ok() and ops.can_split(self.num_channels, self.num_groups):
             return ops.group_norm_split(x, self.weight, self.bias, scale_shift, silu, self.num_groups, self.eps)
+        if scale_shift is not None and not scale_shift.is_contiguous():          # a column slice of the batched emb_layers GEMM
+            scale_shift = scale_shift.contiguous()
         return ops.group_norm(ops.materialize(x), self.weight, self.bias, scale_shift, silu, self.num_groups, self.eps)
 
 

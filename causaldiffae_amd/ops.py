@@ -699,6 +699,10 @@ def group_norm_split(x, gamma, beta, scale_shift=None, silu=False, groups=32, ep
         C1, ld2 = x1.shape[1], 0
     N, C, H, W = x.shape
     dev = x1.device
+    ld_ss = 2 * C
+    if scale_shift is not None:        # [N, 2C] rows; may be a column slice of the batched emb_layers GEMM (row pitch > 2C)
+        assert scale_shift.shape == (N, 2 * C) and scale_shift.stride(1) == 1 and scale_shift.dtype == torch.float32
+        ld_ss = scale_shift.stride(0)
     stats = torch.empty((2, N, groups), dtype=torch.float32, device=dev)
     ws = workspace(dev, "gn", 4 * lib.cdae_gn_workspace_floats(N, C))
     planes = torch.empty((2, N, H, W, C), dtype=torch.float16, device=dev)
@@ -712,7 +716,7 @@ def group_norm_split(x, gamma, beta, scale_shift=None, silu=False, groups=32, ep
     else:
         check(lib.cdae_gn_stats2(ptr(x1), C1, ptr(x2), ld2, C1, N, H * W, C, groups, eps, ptr(stats[0]), ptr(stats[1]), ptr(ws), st))
     check(lib.cdae_gn_apply_split2(ptr(x1), C1, ptr(x2), ld2, C1, ptr(planes[0]), ptr(planes[1]), N, H * W, C, C, groups, ptr(stats[0]),
-                                   ptr(stats[1]), ptr(gamma), ptr(beta), ptr(scale_shift), 2 * C, 1 if silu else 0, st))
+                                   ptr(stats[1]), ptr(gamma), ptr(beta), ptr(scale_shift), ld_ss, 1 if silu else 0, st))
     return SplitAct(planes[0], planes[1], (N, C, H, W))
 
 

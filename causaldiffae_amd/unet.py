@@ -65,6 +65,15 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
         return x
 
 
+class EmbAll:
+    """The timestep embedding together with every ResBlock's `emb_layers` projection of it, computed by ONE GEMM per forward
+    (inference path): `slices[id(block)]` is that block's [N, (2)Cout] column slice of the batched result."""
+    __slots__ = ("emb", "slices")
+
+    def __init__(self, emb, slices):
+        self.emb, self.slices = emb, slices
+
+
 class Upsample(nn.Module):
     def __init__(self, channels, use_conv, dims=2):
         super().__init__()
@@ -127,7 +136,10 @@ class ResBlock(TimestepBlock):
         h = self.in_layers[0](x, silu=True, split=True)            # GN + SiLU (pre-split f16 planes on the inference path)
         fast = isinstance(h, ops.SplitAct)
         h = self.in_layers[2](h, gn_stats=True) if fast else self.in_layers[2](h)     # conv3x3 + bias (+ GroupNorm partial sums)
-        emb_out = self.emb_layers[1](ops.silu(emb))                # [N, (2)Cout]
+        if isinstance(emb, EmbAll):
+            emb_out = emb.slices[id(self)]                         # column slice of the batched emb_layers GEMM
+        else:
+            emb_out = self.emb_layers[1](ops.silu(emb))            # [N, (2)Cout]
         if self.use_scale_shift_norm:
             h = self.out_layers[0](h, scale_shift=emb_out, silu=True, split=True)
         else:
@@ -325,11 +337,32 @@ class UNetModel(nn.Module):
             emb = self.up_emb(z.float(), res=emb)
         return emb, mu, var, z_post, mask
 
+    def _emb_all(self, emb):
+        """All 22 `emb_layers` projections (unet.py:186: Linear(SiLU(emb)) per ResBlock) as one GEMM over the concatenated
+        weights; the concatenation is cached per weight version."""
+        blocks = [m for m in self.modules() if isinstance(m, ResBlock)]
+        tag = (ops._WEIGHT_EPOCH[0],) + tuple(b.emb_layers[1].weight._version for b in blocks) + tuple(b.emb_layers[1].weight.data_ptr() for b in blocks)
+        cache = getattr(self, "_emb_cat", None)
+        if cache is None or cache[0] != tag:
+            w = th.cat([b.emb_layers[1].weight.detach() for b in blocks], dim=0).contiguous()
+            bias = th.cat([b.emb_layers[1].bias.detach() for b in blocks], dim=0).contiguous()
+            offs, o = [], 0
+            for b in blocks:
+                offs.append((id(b), o, b.emb_layers[1].weight.shape[0]))
+                o += b.emb_layers[1].weight.shape[0]
+            cache = (tag, w, bias, offs)
+            self._emb_cat = cache
+        _, w, bias, offs = cache
+        e_all = ops.linear(ops.silu(emb), w, bias)
+        return EmbAll(emb, {bid: e_all[:, o:o + n] for bid, o, n in offs})
+
     def forward(self, x, timesteps, y=None, c=None, x_start=None, z=None, A=None, mask=None):
         """x [N,C,H,W], timesteps [N] -> (eps [N,Cout,H,W] NCHW-contiguous, mu, var, z_post, mask)."""
         assert (y is not None) == (self.num_classes is not None), \
             "must specify y if and only if the model is class-conditional"
         emb, mu, var, z_post, mask = self.embed(timesteps, y=y, c=c, x_start=x_start, z=z)
+        if ops.presplit_ok():
+            emb = self._emb_all(emb)
         hs = []
         h = x.float()
         for module in self.input_blocks:
