@@ -1026,8 +1026,10 @@ __global__ __launch_bounds__(128 * WAVES_N, WAVES_N) void pswin_kernel(const Gem
                 if (tap == 0 || last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPL * B_RB) : "memory");
                 __builtin_amdgcn_s_barrier();
-                const int t2 = tap + 2, ntap = t2 >= 9 ? t2 - 9 : t2, nchk = t2 >= 9 ? chunk + 1 : chunk;
-                if (nchk < c_end) issue_B(stage >= 1 ? stage - 1 : 2, nchk, ntap);                // (stage + 2) % 3
+                if (!(p.dbg & 64)) {
+                    const int t2 = tap + 2, ntap = t2 >= 9 ? t2 - 9 : t2, nchk = t2 >= 9 ? chunk + 1 : chunk;
+                    if (nchk < c_end) issue_B(stage >= 1 ? stage - 1 : 2, nchk, ntap);            // (stage + 2) % 3
+                }
             }
             const int ky = tap / 3, kx = tap - 3 * ky, shift = ky * W + kx;
             const char* bc = bst + stage * (NPL * B_PLANE);
@@ -1071,6 +1073,12 @@ __global__ __launch_bounds__(128 * WAVES_N, WAVES_N) void pswin_kernel(const Gem
                         }
                         acc[i][j] = mma(ah[i], bh[j], acc[i][j]);
                     }
+            }
+            if constexpr (BST == 3) {
+                if (p.dbg & 64) {     // late issue: the step's own MFMAs are queued before this wave joins the block's DMA burst
+                    const int t2 = tap + 2, ntap = t2 >= 9 ? t2 - 9 : t2, nchk = t2 >= 9 ? chunk + 1 : chunk;
+                    if (nchk < c_end) issue_B(stage >= 1 ? stage - 1 : 2, nchk, ntap);
+                }
             }
             stage = stage + 1 == BST ? 0 : stage + 1;
             if (stamps) { const unsigned long long t = stamp(); t_comp += t - t_prev; t_prev = t; }
