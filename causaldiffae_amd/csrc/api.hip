@@ -96,6 +96,31 @@ int cdae_conv3x3_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, 
     return cdae_gemm_dispatch(p, stream);
 }
 
+// GroupNorm (+scale-shift, +SiLU) -> conv3x3 (stride 1) in ONE kernel: x1 / x2 are the fp32 INPUT of the norm (two sources = the
+// skip concatenation), coef its per-(image, channel) affine from cdae_gn_coef; weights as pre-split planes.
+int cdae_conv3x3_fwd_gn(const float* x1, long ld1, int C1, const float* x2, long ld2, const float* coef, int silu, const unsigned short* w_hi,
+                        const unsigned short* w_lo, const float* bias, const float* res, float* out, long ldo, unsigned short* out_hi,
+                        unsigned short* out_lo, float* gn_part, int N, int H, int W, int Cin, int Cout, float* splitk_ws, size_t splitk_ws_bytes,
+                        void* stream) {
+    if ((long)N * H * W >= (1L << 31) / 4) return cdae_fail("conv3x3_fwd_gn: too many pixels");
+    if (ld1 % 4 || (x2 && (ld2 % 4 || C1 % 32)) || Cin % 32 || !aligned16(x1) || !aligned16(x2) || !aligned16(coef) || !aligned16(w_hi) || !aligned16(w_lo))
+        return cdae_fail("conv3x3_fwd_gn: 16-byte aligned rows, Cin % 32 == 0 (and C1 % 32 == 0 with two sources) required");
+    if (out_hi && !out_lo) return cdae_fail("conv3x3_fwd_gn: plane output needs both planes");
+    GemmParams p = base_params();
+    p.presplit = 1;
+    p.A = x1; p.lda = ld1; p.A2 = x2; p.lda2 = ld2; p.K1 = x2 ? C1 : Cin; p.gn_coef = coef; p.gn_silu = silu;
+    p.B = reinterpret_cast<const float*>(w_hi); p.B_lo = w_lo;
+    p.C = out; p.bias = bias; p.res = res; p.C_hi = out_hi; p.C_lo = out_lo; p.gn_part = gn_part;
+    p.M = N * H * W; p.N = Cout; p.K = 9 * Cin;
+    p.ldb = 9L * Cin; p.ldc = ldo;
+    p.out_mode = OUT_ROWMAJOR; p.out_hw = H * W;
+    p.amode = A_CONV_VEC; p.bmode = B_PLAIN_KC;
+    p.conv_M = p.M; p.H = H; p.W = W; p.Cin = Cin; p.Ho = H; p.Wo = W; p.stride = 1; p.up = 0;
+    p.sx = Cin; p.sy = (long)W * Cin; p.sn = (long)H * W * Cin; p.sc = 1;      // logical geometry of the (virtual) normalised tensor
+    set_splitk(p, gn_part ? nullptr : splitk_ws, splitk_ws_bytes);
+    return cdae_gemm_dispatch(p, stream);
+}
+
 // nearest-2x upsample + conv3x3 as four 2x2 convolutions of the LOW-resolution input, one per output parity (ph_y, ph_x):
 // rows 2y+ph_y-1 .. 2y+ph_y+1 of the upsampled image are input rows {y-1+ph_y, y+ph_y} with the 3 kernel rows folded 1+2 or
 // 2+1, likewise for columns — 16 instead of 36 multiply-adds per (pixel, channel pair).  w4 = [4 phases][Cout][2][2][Cin]

@@ -50,6 +50,10 @@ struct GemmParams {
     // ps_kernel / pswin_kernel epilogues: per (32-row chunk, column) partial (sum, sum of squares) of the FINAL output values,
     // [ceil(M/32)][N][2] floats — the GroupNorm statistics of the next layer without another pass over the tensor
     float* gn_part;
+    // pswin_kernel with GNA: the A operand is the fp32 INPUT of a GroupNorm (+scale-shift, +SiLU) — A / A2 as for the two-source
+    // GEMM (K1 = channels of the first source) — and gn_coef [N][Cin][2] holds that norm folded to y = silu?(x * a + b) per
+    // (image, channel); the kernel normalises, activates and splits each window chunk on its way into LDS
+    const float* gn_coef; int gn_silu;
     int dbg;                // dev ablations of ps_kernel (env CDAE_PS_DBG): 1 A rows -> one hot line, 2 B rows -> hot, 4 no loads after the first
     const unsigned short* A_lo; const unsigned short* B_lo;
 };

@@ -877,9 +877,15 @@ int launch_ps(const GemmParams& p, hipStream_t st) {
 // K order is (chunk, tap, channel) — the sums differ from ps_kernel's (tap, channel) order by fp32 rounding only.
 // BST = 3 weight stages (rows up to 32 pixels: the window is small enough for two blocks per CU): the DMAs of step s+2 are in
 // flight while step s computes, and the loop waits with a counted vmcnt instead of draining.
-template <int BN, int NPL, int BST, int MAXWIN, int WAVES_N = 4>
+// GNA: the window is not copied from pre-split planes but PRODUCED in the kernel from the GroupNorm's fp32 input: every thread
+// keeps the next chunk's float4s in registers (loaded one chunk ahead), folds y = silu?(x * a + b) with the per-(image, channel)
+// coefficients (a 1-KB LDS-DMA per chunk), splits to f16 hi/lo and writes the same swizzled window image.  This is the
+// reference's ResBlock prologue (GroupNorm -> SiLU -> conv3x3, unet.py:187-197) without the normalised tensor ever existing in HBM.
+template <int BN, int NPL, int BST, int MAXWIN, int WAVES_N = 4, bool GNA = false>
 __global__ __launch_bounds__(128 * WAVES_N, WAVES_N) void pswin_kernel(const GemmParams p) {     // two blocks per CU: 8 waves x <= 128 VGPRs or 4 waves x <= 256
     constexpr int BM = 128, NW = 2 * WAVES_N, THREADS = 64 * NW;
+    static_assert(!GNA || BST == 2, "the fused-GroupNorm window is built for the 2-stage weight ring");
+    constexpr int G_SLOTS = (MAXWIN * 8 + THREADS - 1) / THREADS;        // float4s of a window chunk per thread
     constexpr int WM = 64, WN = BN / WAVES_N, TM = 2, TN = WN / 32;
     static_assert(MAXWIN % 16 == 0 && (BST == 2 || BST == 3), "window rows come in 16-row DMA blocks");
     constexpr int A_PLANE = MAXWIN * 64, B_PLANE = BN * 64;
@@ -891,6 +897,7 @@ __global__ __launch_bounds__(128 * WAVES_N, WAVES_N) void pswin_kernel(const Gem
     char* const lds = reinterpret_cast<char*>(smem);
     char* const awin = lds;                                             // [NPL][MAXWIN][64 B]
     char* const bst = lds + NPL * A_PLANE;                              // [BST stages][NPL][BN][64 B]
+    char* const coefb = bst + BST * NPL * B_PLANE;                      // GNA: [2][4 images][32 channels][a, b] floats
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -916,6 +923,61 @@ __global__ __launch_bounds__(128 * WAVES_N, WAVES_N) void pswin_kernel(const Gem
     const int nchunk = p.Cin / BK;
     const int c_per = (nchunk + p.ksplit - 1) / p.ksplit;
     const int c_begin = ks * c_per, c_end = min(nchunk, c_begin + c_per);
+
+    // ---- GNA: this thread's float4 slots of a window chunk (item = tid + THREADS q: window row item / 8, channels 4 (item % 8) .. +3)
+    int gpix[G_SLOTS], gimg[G_SLOTS];          // flattened pixel (or -1) and image index relative to the window's first image
+    float4 xv[G_SLOTS];
+    const int pix_first = max(m0 - W - 1, 0), img_first = fdiv(pix_first, p.hw_magic, p.hw_shift), img_last = fdiv(p.M - 1, p.hw_magic, p.hw_shift);
+    if constexpr (GNA) {
+#pragma unroll
+        for (int q = 0; q < G_SLOTS; ++q) {
+            const int item = tid + THREADS * q, j = item >> 3, pix = m0 - W - 1 + j;
+            const bool ok = j < win && pix >= 0 && pix < p.M;
+            gpix[q] = ok ? pix : -1;
+            gimg[q] = ok ? min(fdiv(pix, p.hw_magic, p.hw_shift) - img_first, 3) : 0;
+        }
+    }
+    const float* const gzero = reinterpret_cast<const float*>(g_zero_ps);
+    auto gna_load = [&](int chunk) {           // issue the global loads of one chunk of the window into registers
+        const int c0 = chunk * BK + (tid & 7) * 4;
+        const bool second = p.A2 && c0 >= p.K1;
+        const float* src = second ? p.A2 : p.A;
+        const long pitch = second ? p.lda2 : p.lda;
+        const int cc = second ? c0 - p.K1 : c0;
+#pragma unroll
+        for (int q = 0; q < G_SLOTS; ++q)
+            xv[q] = ld4(gpix[q] >= 0 ? src + (long)gpix[q] * pitch + cc : gzero);
+    };
+    auto gna_coef_dma = [&](int chunk, int buf) {      // wave 0: (a, b) of 4 images x 32 channels -> 1 KB of LDS
+        if (wave == 0) {
+            const int img = min(img_first + (lane >> 4), img_last);
+            const float* src = p.gn_coef + ((long)img * p.Cin + chunk * BK) * 2 + (lane & 15) * 4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(coefb + buf * 1024), 16, 0, 0);
+        }
+    };
+    auto gna_stage = [&](int buf) {            // registers -> normalise (+SiLU) -> f16 hi/lo -> swizzled window image
+#pragma unroll
+        for (int q = 0; q < G_SLOTS; ++q) {
+            const int item = tid + THREADS * q, j = item >> 3, f4 = item & 7;
+            if (j < MAXWIN) {
+                const float4* cf = reinterpret_cast<const float4*>(coefb + buf * 1024 + gimg[q] * 256 + f4 * 32);
+                const float4 c01 = cf[0], c23 = cf[1];              // a0 b0 a1 b1 | a2 b2 a3 b3
+                float y0 = fmaf(xv[q].x, c01.x, c01.y), y1 = fmaf(xv[q].y, c01.z, c01.w);
+                float y2 = fmaf(xv[q].z, c23.x, c23.y), y3 = fmaf(xv[q].w, c23.z, c23.w);
+                if (p.gn_silu) { y0 = y0 / (1.f + expf(-y0)); y1 = y1 / (1.f + expf(-y1)); y2 = y2 / (1.f + expf(-y2)); y3 = y3 / (1.f + expf(-y3)); }
+                half4 hi, lo;
+                hi[0] = (_Float16)y0; hi[1] = (_Float16)y1; hi[2] = (_Float16)y2; hi[3] = (_Float16)y3;
+                const int off = j * 64 + 16 * ((f4 >> 1) ^ ((j >> 2) & 3)) + 8 * (f4 & 1);
+                *reinterpret_cast<half4*>(awin + off) = hi;
+                if constexpr (NPL == 2) {
+                    lo[0] = (_Float16)(y0 - (float)hi[0]); lo[1] = (_Float16)(y1 - (float)hi[1]);
+                    lo[2] = (_Float16)(y2 - (float)hi[2]); lo[3] = (_Float16)(y3 - (float)hi[3]);
+                    *reinterpret_cast<half4*>(awin + A_PLANE + off) = lo;
+                }
+            }
+        }
+    };
 
     // ---- A window DMA slots of this wave: piece pc = wave + 8q covers plane pc / NB, rows 16 (pc % NB) .. +15
     int aoff[A_SLOTS];             // element offset of this lane's 16 bytes at chunk 0, or -1 (outside the tensor)
@@ -994,8 +1056,16 @@ __global__ __launch_bounds__(128 * WAVES_N, WAVES_N) void pswin_kernel(const Gem
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
     if (c_begin < c_end) {
-        issue_A(c_begin); issue_B(0, c_begin, 0);
-        if constexpr (BST == 3) issue_B(1, c_begin, 1);
+        if constexpr (GNA) {
+            gna_load(c_begin); gna_coef_dma(c_begin, 0); issue_B(0, c_begin, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                             // coefficients visible
+            gna_stage(0);
+            if (c_begin + 1 < c_end) { gna_load(c_begin + 1); gna_coef_dma(c_begin + 1, 1); }
+        } else {
+            issue_A(c_begin); issue_B(0, c_begin, 0);
+            if constexpr (BST == 3) issue_B(1, c_begin, 1);
+        }
     }
     // diagnostic build only (CDAE_PS_DBG & 32): s_memtime stamps around the three segments of a step, summed per wave and
     // written to the split-K workspace by lane 0 of every wave of the first 64 blocks.  The stamps' lgkmcnt(0) serialises what the
@@ -1013,8 +1083,14 @@ __global__ __launch_bounds__(128 * WAVES_N, WAVES_N) void pswin_kernel(const Gem
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {           // not unrolled: nine copies keep every tap's addresses and masks live (197 VGPRs)
             if constexpr (BST == 2) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
+                // GNA, tap 0: the weight DMAs are older than the next chunk's register prefetch (<= G_SLOTS loads + one coefficient
+                // DMA issued after them), so a counted wait retires the weights and leaves the prefetch in flight
+                if (GNA && tap == 0 && chunk + 1 < c_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GNA ? G_SLOTS : 0) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if constexpr (GNA) {         // raw barrier: __syncthreads() would drain the register prefetch with its own vmcnt(0)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                } else __syncthreads();
                 if (stamps) { const unsigned long long t = stamp(); t_wait += t - t_prev; t_prev = t; }
                 const int ntap = tap == 8 ? 0 : tap + 1, nchk = tap == 8 ? chunk + 1 : chunk;     // stage the next step's weight tile
                 if (nchk < c_end) issue_B(stage ^ 1, nchk, ntap);
@@ -1084,8 +1160,14 @@ __global__ __launch_bounds__(128 * WAVES_N, WAVES_N) void pswin_kernel(const Gem
             if (stamps) { const unsigned long long t = stamp(); t_comp += t - t_prev; t_prev = t; }
         }
         if (chunk + 1 < c_end) {
-            __builtin_amdgcn_s_barrier();                                // every wave is done with this chunk's window
-            issue_A(chunk + 1);                                          // lands before the vmcnt(0) + barrier of the next step
+            if constexpr (GNA) {
+                __syncthreads();                                         // every wave is done with this chunk's window
+                gna_stage((chunk + 1 - c_begin) & 1);                    // its registers and coefficients landed steps ago
+                if (chunk + 2 < c_end) { gna_load(chunk + 2); gna_coef_dma(chunk + 2, (chunk + 2 - c_begin) & 1); }
+            } else {
+                __builtin_amdgcn_s_barrier();                            // every wave is done with this chunk's window
+                issue_A(chunk + 1);                                      // lands before the vmcnt(0) + barrier of the next step
+            }
         }
     }
 
@@ -1131,19 +1213,19 @@ __global__ __launch_bounds__(128 * WAVES_N, WAVES_N) void pswin_kernel(const Gem
         }
 }
 
-template <int BN, int NPL, int BST, int MAXWIN, int WAVES_N = 4>
+template <int BN, int NPL, int BST, int MAXWIN, int WAVES_N = 4, bool GNA = false>
 int launch_pswin(const GemmParams& p, hipStream_t st) {
-    constexpr size_t smem = (size_t)NPL * MAXWIN * 64 + (size_t)BST * NPL * BN * 64;
+    constexpr size_t smem = (size_t)NPL * MAXWIN * 64 + (size_t)BST * NPL * BN * 64 + (GNA ? 2048 : 0);
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N, GNA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
         attr_done = true;
     }
     dim3 grid((unsigned)((long)((p.M + 127) / 128) * ((p.N + BN - 1) / BN) * p.ksplit));
     static const size_t pad = getenv("CDAE_PS_PAD_LDS") ? (size_t)atoi(getenv("CDAE_PS_PAD_LDS")) : 0;       // dev: force fewer blocks per CU
-    if (pad) hipFuncSetAttribute(reinterpret_cast<const void*>(&pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem + pad));
-    hipLaunchKernelGGL((pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N>), grid, dim3(128 * WAVES_N), smem + pad, st, p);
+    if (pad) hipFuncSetAttribute(reinterpret_cast<const void*>(&pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N, GNA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem + pad));
+    hipLaunchKernelGGL((pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N, GNA>), grid, dim3(128 * WAVES_N), smem + pad, st, p);
     return hipGetLastError() == hipSuccess ? 0 : cdae_fail("pswin_kernel launch failed");
 }
 
@@ -1259,7 +1341,7 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
         const int mode = cdae_get_default_precision();
         p.prec = mode == CDAE_PREC_FP32 ? 0 : mode == CDAE_PREC_MIXED16 ? (p.grad_operand ? 4 : 3) : (p.grad_operand ? 2 : 1);
     }
-    if (p.A2 && (p.amode != A_PLAIN_KC || p.a_scalar || p.K1 % BK || p.batch != 1)) return cdae_fail("two-source A: vectorised A_PLAIN_KC only, K1 % 32 == 0");
+    if (p.A2 && !p.gn_coef && (p.amode != A_PLAIN_KC || p.a_scalar || p.K1 % BK || p.batch != 1)) return cdae_fail("two-source A: vectorised A_PLAIN_KC only, K1 % 32 == 0");
     if (p.presplit) {
         static const int cfg_dbg = getenv("CDAE_PS_DBG") ? atoi(getenv("CDAE_PS_DBG")) : 0;
         p.dbg = cfg_dbg;
@@ -1306,6 +1388,13 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
         // window-resident form: stride-1 3x3 convs on a dense NHWC tensor, rows up to 64 pixels, row-major result
         const bool win_ok = cfg_win && p.amode == A_CONV_VEC && p.ps_taps != 4 && p.stride == 1 && !p.up && p.W <= 64 && big &&
                             p.sy == (long)p.W * p.sx && p.sn == (long)p.H * p.W * p.sx && p.out_mode == OUT_ROWMAJOR;
+        if (p.gn_coef && (!win_ok || (p.A2 && p.K1 % BK))) return cdae_fail("fused GroupNorm prologue: only on the window-resident conv path");
+        if (win_ok && p.gn_coef) {
+            const int nchunk = p.Cin / BK;
+            if (p.ksplit > nchunk) p.ksplit = nchunk;
+            ks = p.ksplit;
+            rc = p.prec == 1 ? launch_pswin<128, 2, 2, 272, 4, true>(p, st) : launch_pswin<128, 1, 2, 272, 4, true>(p, st);
+        } else
         if (win_ok) {
             const int nchunk = p.Cin / BK;
             if (p.ksplit > nchunk) p.ksplit = nchunk;              // K is split by whole channel chunks here

@@ -623,6 +623,39 @@ int cdae_gn_apply_split(const float* x, unsigned short* y_hi, unsigned short* y_
     return cdae_gn_apply_split2(x, ldx, nullptr, 0, C, y_hi, y_lo, N, HW, C, ldy, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, stream);
 }
 
+// GroupNorm (+scale-shift) folded to one affine per (image, channel): coef[n][c] = (a, b) with y = x * a + b — the same arithmetic,
+// in the same order, as gn_apply_kernel's per-thread fold, so a consumer that applies it reproduces that kernel bit for bit.
+__global__ void gn_coef_kernel(const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                               const float* __restrict__ beta, const float* __restrict__ ss, int ld_ss, int C, int cpg, int G,
+                               float* __restrict__ coef, long total) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / C), c = (int)(i - (long)n * C), g = c / cpg;
+        const float mu = mean[n * G + g], rs = rstd[n * G + g];
+        float a = rs * gamma[c];
+        float b = fmaf(-mu, a, beta[c]);
+        if (ss) {
+            const float sc = 1.f + ss[(long)n * ld_ss + c], sh = ss[(long)n * ld_ss + C + c];
+            a *= sc;
+            b = fmaf(b, sc, sh);
+        }
+        coef[i * 2] = a; coef[i * 2 + 1] = b;
+    }
+}
+
+int cdae_gn_coef(const float* mean, const float* rstd, const float* gamma, const float* beta, const float* scale_shift, int ld_ss, float* coef,
+                 int N, int C, int groups, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (C % groups || (((size_t)coef) & 15)) return cdae_fail("gn_coef: C % groups == 0 and a 16-byte aligned coefficient buffer required");
+    const long total = (long)N * C;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    cdae_prof_begin(PROF_GN, (double)total * 16.0, st);
+    hipLaunchKernelGGL(gn_coef_kernel, dim3(blocks), dim3(256), 0, st, mean, rstd, gamma, beta, scale_shift, ld_ss, C, C / groups, groups, coef, total);
+    cdae_prof_end(PROF_GN, st);
+    CHECK_LAUNCH("gn_coef launch failed");
+    return 0;
+}
+
 int cdae_gn_stats_from_parts(const float* part1, int C1, int nseg1, const float* part2, int C2, int nseg2, int N, int HW, int groups, float eps,
                              float* mean, float* rstd, float* ws /* >= N * C * 4 floats */, void* stream) {
     hipStream_t st = (hipStream_t)stream;

@@ -101,6 +101,10 @@ class ConvNd(nn.Module):
         self.bias = nn.Parameter(th.empty(out_channels).uniform_(-bound, bound))
 
     def forward(self, x, res=None, up=False, out_nchw=False, emit_split=False, gn_stats=False):
+        if isinstance(x, ops.LazyGN):          # GroupNorm output not written yet: fuse it into the conv where the kernel exists
+            if self.kernel_size == 3 and ops.gn_conv_ok(x, self.out_channels, self.stride, up, out_nchw):
+                return ops.conv3x3_gn(x, self.weight, self.bias, res=res, emit_split=emit_split, gn_stats=gn_stats)
+            x = x.planes()
         if isinstance(x, ops.SplitAct):
             assert self.kernel_size == 3
             return ops.conv3x3_ps(x, self.weight, self.bias, res=res, stride=self.stride, up=up, out_nchw=out_nchw, emit_split=emit_split,
@@ -143,7 +147,7 @@ class GroupNorm32(nn.Module):
         """split=True: the caller feeds the result straight into a conv3x3 / 1x1 GEMM; in no-grad f16 modes it is then written
         as pre-split f16 planes (ops.SplitAct) for the LDS-DMA kernel."""
         if split and len(x.shape) == 4 and ops.presplit_ok() and ops.can_split(self.num_channels, self.num_groups):
-            return ops.group_norm_split(x, self.weight, self.bias, scale_shift, silu, self.num_groups, self.eps)
+            return ops.group_norm_lazy(x, self.weight, self.bias, scale_shift, silu, self.num_groups, self.eps)
         if scale_shift is not None and not scale_shift.is_contiguous():          # a column slice of the batched emb_layers GEMM
             scale_shift = scale_shift.contiguous()
         return ops.group_norm(ops.materialize(x), self.weight, self.bias, scale_shift, silu, self.num_groups, self.eps)

@@ -655,6 +655,10 @@ class SplitAct:
 
 _WSPLIT = {}
 _PRESPLIT_ON = os.environ.get("CDAE_PRESPLIT", "1") != "0"      # dev switch: 0 = in-kernel split everywhere
+# GroupNorm applied inside the conv's window staging (ops.conv3x3_gn): correct (bit-identical, tested) but measured 5 % SLOWER end to
+# end than writing planes once — every n-tile block and every halo row re-normalises the same pixels (2-8x the work of the standalone
+# pass, in VALU the kernel cannot spare).  Opt-in.
+_GNCONV_ON = os.environ.get("CDAE_GNCONV", "0") == "1"
 _WEIGHT_EPOCH = [0]
 
 
@@ -688,9 +692,29 @@ def presplit_ok():
     return _PRESPLIT_ON and not torch.is_grad_enabled() and get_precision() in ("f16x3", "mixed16")
 
 
-def group_norm_split(x, gamma, beta, scale_shift=None, silu=False, groups=32, eps=1e-5):
-    """GroupNorm (+ scale-shift, + SiLU) whose result is written directly as f16 hi/lo planes (no autograd).  x may be a CatAct:
-    both kernels then read the two sources in place."""
+class LazyGN:
+    """A GroupNorm (+scale-shift, +SiLU) whose statistics are known but whose output has not been written: the consumer decides.
+    A stride-1 conv3x3 on the window-resident path applies it while staging its activation window (`conv3x3_gn`, the tensor never
+    exists in HBM); anything else calls `.planes()` and gets the usual pre-split f16 planes."""
+    __slots__ = ("x1", "x2", "shape", "stats", "gamma", "beta", "ss", "ld_ss", "silu", "groups")
+
+    def __init__(self, x1, x2, shape, stats, gamma, beta, ss, ld_ss, silu, groups):
+        self.x1, self.x2, self.shape, self.stats = x1, x2, tuple(shape), stats
+        self.gamma, self.beta, self.ss, self.ld_ss, self.silu, self.groups = gamma, beta, ss, ld_ss, silu, groups
+
+    def planes(self):
+        N, C, H, W = self.shape
+        C1 = self.x1.shape[1]
+        planes = torch.empty((2, N, H, W, C), dtype=torch.float16, device=self.x1.device)
+        check(lib.cdae_gn_apply_split2(ptr(self.x1), C1, ptr(self.x2), 0 if self.x2 is None else C - C1, C1, ptr(planes[0]), ptr(planes[1]),
+                                       N, H * W, C, C, self.groups, ptr(self.stats[0]), ptr(self.stats[1]), ptr(self.gamma), ptr(self.beta),
+                                       ptr(self.ss), self.ld_ss, 1 if self.silu else 0, stream()))
+        return SplitAct(planes[0], planes[1], self.shape)
+
+
+def group_norm_lazy(x, gamma, beta, scale_shift=None, silu=False, groups=32, eps=1e-5):
+    """Statistics of a GroupNorm over x (a tensor or a CatAct), taken from the producing convs' partial sums where they exist;
+    returns a LazyGN (no autograd)."""
     if isinstance(x, CatAct):
         x1, x2 = x.a, x.b
         C1, ld2 = x1.shape[1], x2.shape[1]
@@ -704,8 +728,6 @@ def group_norm_split(x, gamma, beta, scale_shift=None, silu=False, groups=32, ep
         assert scale_shift.shape == (N, 2 * C) and scale_shift.stride(1) == 1 and scale_shift.dtype == torch.float32
         ld_ss = scale_shift.stride(0)
     stats = torch.empty((2, N, groups), dtype=torch.float32, device=dev)
-    ws = workspace(dev, "gn", 4 * lib.cdae_gn_workspace_floats(N, C))
-    planes = torch.empty((2, N, H, W, C), dtype=torch.float16, device=dev)
     st = stream()
     p1, p2 = getattr(x1, "_gnparts", None), getattr(x2, "_gnparts", None) if x2 is not None else None
     if p1 is not None and (x2 is None or p2 is not None) and (H * W) % 32 == 0:
@@ -714,10 +736,51 @@ def group_norm_split(x, gamma, beta, scale_shift=None, silu=False, groups=32, ep
                                            1 if x2 is None else getattr(x2, "_gnseg", 1), N, H * W, groups, eps,
                                            ptr(stats[0]), ptr(stats[1]), ptr(workspace(dev, "gnparts", 16 * N * C)), st))
     else:
+        ws = workspace(dev, "gn", 4 * lib.cdae_gn_workspace_floats(N, C))
         check(lib.cdae_gn_stats2(ptr(x1), C1, ptr(x2), ld2, C1, N, H * W, C, groups, eps, ptr(stats[0]), ptr(stats[1]), ptr(ws), st))
-    check(lib.cdae_gn_apply_split2(ptr(x1), C1, ptr(x2), ld2, C1, ptr(planes[0]), ptr(planes[1]), N, H * W, C, C, groups, ptr(stats[0]),
-                                   ptr(stats[1]), ptr(gamma), ptr(beta), ptr(scale_shift), ld_ss, 1 if silu else 0, st))
-    return SplitAct(planes[0], planes[1], (N, C, H, W))
+    return LazyGN(x1, x2, (N, C, H, W), stats, gamma, beta, scale_shift, ld_ss, silu, groups)
+
+
+def group_norm_split(x, gamma, beta, scale_shift=None, silu=False, groups=32, eps=1e-5):
+    """GroupNorm (+ scale-shift, + SiLU) whose result is written directly as f16 hi/lo planes (no autograd).  x may be a CatAct:
+    both kernels then read the two sources in place."""
+    return group_norm_lazy(x, gamma, beta, scale_shift, silu, groups, eps).planes()
+
+
+def gn_conv_ok(lz, Cout, stride, up, out_nchw):
+    """Can this LazyGN be applied inside the window-resident conv kernel?  (the dispatcher's own conditions)"""
+    N, C, H, W = lz.shape
+    M = N * H * W
+    return (_GNCONV_ON and stride == 1 and not up and not out_nchw and W <= 64 and C % 32 == 0 and Cout >= 96 and M >= 96
+            and (lz.x2 is None or lz.x1.shape[1] % 32 == 0) and ((M + 127) // 128) * ((Cout + 127) // 128) >= 192)
+
+
+def conv3x3_gn(lz, w, b=None, res=None, emit_split=False, gn_stats=False):
+    """conv3x3(stride 1) of a LazyGN: GroupNorm -> (scale-shift) -> SiLU -> conv in one kernel (no autograd)."""
+    N, Cin, H, W = lz.shape
+    Cout = w.shape[0]
+    w_hi, w_lo = split_weight(ohwi(w))
+    dev = lz.x1.device
+    coef = torch.empty((N, Cin, 2), dtype=torch.float32, device=dev)
+    st = stream()
+    check(lib.cdae_gn_coef(ptr(lz.stats[0]), ptr(lz.stats[1]), ptr(lz.gamma), ptr(lz.beta), ptr(lz.ss), lz.ld_ss, ptr(coef), N, Cin, lz.groups, st))
+    out = new_act(N, Cout, H, W, dev)
+    if res is not None:
+        res = to_nhwc(res)
+    M = N * H * W
+    planes = torch.empty((2, N, H, W, Cout), dtype=torch.float16, device=dev) if emit_split else None
+    gn_stats = gn_stats and (H * W) % 32 == 0 and ((M + 127) // 128) * ((Cout + 127) // 128) >= 256
+    parts = torch.empty(((M + 31) // 32, Cout, 2), dtype=torch.float32, device=dev) if gn_stats else None
+    C1 = lz.x1.shape[1]
+    ws, wsb = _sk(dev)
+    check(lib.cdae_conv3x3_fwd_gn(ptr(lz.x1), C1, C1, ptr(lz.x2), 0 if lz.x2 is None else Cin - C1, ptr(coef), 1 if lz.silu else 0,
+                                  ptr(w_hi), ptr(w_lo), ptr(b), ptr(res), ptr(out), Cout, ptr(planes[0]) if emit_split else None,
+                                  ptr(planes[1]) if emit_split else None, ptr(parts), N, H, W, Cin, Cout, ws, wsb, st))
+    if emit_split:
+        out._split = SplitAct(planes[0], planes[1], (N, Cout, H, W))
+    if gn_stats:
+        out._gnparts = parts
+    return out
 
 
 def can_split(C, groups=32):

@@ -134,7 +134,7 @@ class ResBlock(TimestepBlock):
         if not isinstance(x, ops.CatAct):                          # CatAct: the skip concatenation, read in place by GN and the 1x1 skip
             x = ops.to_nhwc(x)
         h = self.in_layers[0](x, silu=True, split=True)            # GN + SiLU (pre-split f16 planes on the inference path)
-        fast = isinstance(h, ops.SplitAct)
+        fast = isinstance(h, (ops.SplitAct, ops.LazyGN))
         h = self.in_layers[2](h, gn_stats=True) if fast else self.in_layers[2](h)     # conv3x3 + bias (+ GroupNorm partial sums)
         if isinstance(emb, EmbAll):
             emb_out = emb.slices[id(self)]                         # column slice of the batched emb_layers GEMM
@@ -146,7 +146,7 @@ class ResBlock(TimestepBlock):
             h = self.out_layers[0](h + emb_out[:, :, None, None], silu=True, split=True)
         h = self.out_layers[2](h)
         skip = ops.materialize(x) if isinstance(self.skip_connection, Identity) else self.skip_connection(x)
-        if isinstance(h, ops.SplitAct):                            # emit_split: a Down/Upsample conv consumes this block's output
+        if isinstance(h, (ops.SplitAct, ops.LazyGN)):              # emit_split: a Down/Upsample conv consumes this block's output
             return self.out_layers[3](h, res=skip, emit_split=self.emit_split, gn_stats=True)
         return self.out_layers[3](h, res=skip)                     # conv3x3 + bias + residual
 
@@ -180,6 +180,8 @@ class AttentionBlock(nn.Module):
         N, C, H, W = x.shape
         T = H * W
         h = self.norm(x, split=True)                                                # GN, no activation
+        if isinstance(h, ops.LazyGN):
+            h = h.planes()
         if isinstance(h, ops.SplitAct):
             qkv = ops.linear_ps(h, self.qkv.weight, self.qkv.bias)
         else:

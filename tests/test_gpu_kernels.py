@@ -496,3 +496,34 @@ def test_groupnorm_statistics_from_upconv_phases():
         ref = ops.group_norm_split(ops.CatAct(y.detach().clone(), s2.detach().clone()), gamma, beta, None, True)
     d = ((got.hi.float() + got.lo.float()) - (ref.hi.float() + ref.lo.float())).abs().max().item()
     assert d < 2e-5, d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C1,C2,Cout,S,ss,res", [
+    (32, 128, 0, 128, 32, True, False),      # single source, scale-shift, 4 chunks
+    (8, 128, 0, 256, 64, False, True),       # W = 64 (window 258 rows), residual epilogue
+    (48, 256, 128, 256, 16, True, False),    # skip concatenation as two sources, groups of 12 straddle nothing (C1 % 32 == 0)
+    (200, 512, 384, 512, 8, True, True),     # 8x8 images: the window spans up to four images, 28-channel groups straddle the seam
+])
+def test_fused_groupnorm_conv_is_bit_identical(N, C1, C2, Cout, S, ss, res):
+    """GroupNorm -> (scale-shift) -> SiLU -> conv3x3 in ONE kernel (normalisation applied while staging the activation window)
+    == GroupNorm writing f16 planes + the window conv on those planes, bit for bit."""
+    from causaldiffae_amd import ops
+    g = torch.Generator(device="cuda:0").manual_seed(14)
+    a = ops.to_nhwc(torch.randn(N, C1, S, S, device="cuda:0", generator=g) * 1.3 + 0.2)
+    x = ops.CatAct(a, ops.to_nhwc(torch.randn(N, C2, S, S, device="cuda:0", generator=g) * 0.8 - 0.1)) if C2 else a
+    C = C1 + C2
+    gamma, beta = torch.randn(C, device="cuda:0", generator=g), torch.randn(C, device="cuda:0", generator=g)
+    sc = torch.randn(N, 2 * C, device="cuda:0", generator=g) * 0.3 if ss else None
+    w = (torch.randn(Cout, C, 3, 3, device="cuda:0", generator=g) / (9 * C) ** 0.5).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(Cout, device="cuda:0", generator=g)
+    r = ops.to_nhwc(torch.randn(N, Cout, S, S, device="cuda:0", generator=g)) if res else None
+    with torch.no_grad():
+        lz = ops.group_norm_lazy(x, gamma, beta, sc, True)
+        ref = ops.conv3x3_ps(lz.planes(), w, b, res=r, gn_stats=True, emit_split=True)
+        got = ops.conv3x3_gn(lz, w, b, res=r, gn_stats=True, emit_split=True)
+    assert torch.equal(got, ref)
+    assert torch.equal(got._split.hi, ref._split.hi) and torch.equal(got._split.lo, ref._split.lo)
+    assert hasattr(got, "_gnparts") == hasattr(ref, "_gnparts")
+    if hasattr(ref, "_gnparts"):
+        assert torch.equal(got._gnparts, ref._gnparts)
