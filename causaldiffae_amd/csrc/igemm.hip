@@ -1139,6 +1139,7 @@ __global__ __launch_bounds__(128 * WAVES_N, WAVES_N) void pswin_kernel(const Gem
                     bh[j] = *reinterpret_cast<const u16x8*>(bc + b);
                     if constexpr (NPL == 2) bl[j] = *reinterpret_cast<const u16x8*>(bc + B_PLANE + b);
                 }
+X
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1149,6 +1150,7 @@ __global__ __launch_bounds__(128 * WAVES_N, WAVES_N) void pswin_kernel(const Gem
                         }
                         acc[i][j] = mma(ah[i], bh[j], acc[i][j]);
                     }
+                if (p.dbg & 128) __builtin_amdgcn_s_setprio(0);
             }
             if constexpr (BST == 3) {
                 if (p.dbg & 64) {     // late issue: the step's own MFMAs are queued before this wave joins the block's DMA burst
