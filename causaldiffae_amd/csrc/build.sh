@@ -6,11 +6,12 @@ OUT=../libcdae.so
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -I../../include"
 mkdir -p build
-$HIPCC $FLAGS -c igemm.hip -o build/igemm.o &
-$HIPCC $FLAGS -c api.hip -o build/api.o &
-$HIPCC $FLAGS -c norm.hip -o build/norm.o &
-$HIPCC $FLAGS -ffp-contract=off -c elementwise.hip -o build/elementwise.o &
-$HIPCC $FLAGS -c prof.hip -o build/prof.o &
-wait
+pids=()
+$HIPCC $FLAGS -c igemm.hip -o build/igemm.o & pids+=($!)
+$HIPCC $FLAGS -c api.hip -o build/api.o & pids+=($!)
+$HIPCC $FLAGS -c norm.hip -o build/norm.o & pids+=($!)
+$HIPCC $FLAGS -ffp-contract=off -c elementwise.hip -o build/elementwise.o & pids+=($!)
+$HIPCC $FLAGS -c prof.hip -o build/prof.o & pids+=($!)
+for pid in "${pids[@]}"; do wait "$pid" || { echo "build.sh: a compile step failed" >&2; exit 1; }; done     # a bare `wait` would hide failures
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT build/igemm.o build/api.o build/norm.o build/elementwise.o build/prof.o
 echo "built $(realpath $OUT)"

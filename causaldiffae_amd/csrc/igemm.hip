@@ -1139,7 +1139,7 @@ __global__ __launch_bounds__(128 * WAVES_N, WAVES_N) void pswin_kernel(const Gem
                     bh[j] = *reinterpret_cast<const u16x8*>(bc + b);
                     if constexpr (NPL == 2) bl[j] = *reinterpret_cast<const u16x8*>(bc + B_PLANE + b);
                 }
-X
+                if (!(p.dbg & 128)) __builtin_amdgcn_s_setprio(1);     // MFMA bursts win issue arbitration over other waves' staging work (+1-2 %)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1150,7 +1150,7 @@ X
                         }
                         acc[i][j] = mma(ah[i], bh[j], acc[i][j]);
                     }
-                if (p.dbg & 128) __builtin_amdgcn_s_setprio(0);
+                if (!(p.dbg & 128)) __builtin_amdgcn_s_setprio(0);
             }
             if constexpr (BST == 3) {
                 if (p.dbg & 64) {     // late issue: the step's own MFMAs are queued before this wave joins the block's DMA burst
