@@ -881,15 +881,19 @@ int launch_ps(const GemmParams& p, hipStream_t st) {
 // keeps the next chunk's float4s in registers (loaded one chunk ahead), folds y = silu?(x * a + b) with the per-(image, channel)
 // coefficients (a 1-KB LDS-DMA per chunk), splits to f16 hi/lo and writes the same swizzled window image.  This is the
 // reference's ResBlock prologue (GroupNorm -> SiLU -> conv3x3, unet.py:187-197) without the normalised tensor ever existing in HBM.
-template <int BN, int NPL, int BST, int MAXWIN, int WAVES_N = 4, bool GNA = false>
-__global__ __launch_bounds__(128 * WAVES_N, WAVES_N) void pswin_kernel(const GemmParams p) {     // two blocks per CU: 8 waves x <= 128 VGPRs or 4 waves x <= 256
-    constexpr int BM = 128, NW = 2 * WAVES_N, THREADS = 64 * NW;
-    static_assert(!GNA || BST == 2, "the fused-GroupNorm window is built for the 2-stage weight ring");
+// BM = 256 (4 x 2 waves of 64 x 64): twice the MFMAs per step and per staged weight byte.  Its window is TIGHT — exactly BM + 2W
+// rows (384 at W = 64, so that window + two weight stages are 80 KB and two blocks still share a CU): the two corner rows of the
+// loose window are only ever read by masked taps when tiles start on an image-row boundary (BM % W == 0), so their reads clamp.
+template <int BN, int NPL, int BST, int MAXWIN, int WAVES_N = 4, bool GNA = false, int BM = 128>
+__global__ __launch_bounds__(BM / 64 * WAVES_N * 64, BM / 64 * WAVES_N / 2) void pswin_kernel(const GemmParams p) {     // two blocks per CU
+    constexpr int WAVES_M = BM / 64, NW = WAVES_M * WAVES_N, THREADS = 64 * NW;
+    constexpr bool TIGHT = BM == 256;
+    static_assert(!GNA || (BST == 2 && BM == 128), "the fused-GroupNorm window is built for the 2-stage weight ring and 128-row tiles");
     constexpr int G_SLOTS = (MAXWIN * 8 + THREADS - 1) / THREADS;        // float4s of a window chunk per thread
     constexpr int WM = 64, WN = BN / WAVES_N, TM = 2, TN = WN / 32;
     static_assert(MAXWIN % 16 == 0 && (BST == 2 || BST == 3), "window rows come in 16-row DMA blocks");
     constexpr int A_PLANE = MAXWIN * 64, B_PLANE = BN * 64;
-    constexpr int A_SLOTS = (2 * 17 + NW - 1) / NW;                     // 2 planes x 17 row blocks over the block's waves
+    constexpr int A_SLOTS = (2 * (MAXWIN / 16) + NW - 1) / NW;          // 2 planes x 16-row blocks over the block's waves
     constexpr int B_RB = (BN / 16) / NW;                                // 16-row weight blocks per wave
     typedef const unsigned short* hp;
 
@@ -919,7 +923,8 @@ __global__ __launch_bounds__(128 * WAVES_N, WAVES_N) void pswin_kernel(const Gem
     const hp zero = reinterpret_cast<hp>(g_zero_ps);
     const long za_hi = zero - a_hi, za_lo = NPL == 2 ? zero - a_lo : 0, zb_hi = zero - b_hi, zb_lo = NPL == 2 ? zero - b_lo : 0;
 
-    const int W = p.W, win = BM + 2 * W + 2, NB = (win + 15) >> 4;      // window rows, 16-row DMA blocks per plane
+    const int W = p.W, win = BM + 2 * W + (TIGHT ? 0 : 2), NB = (win + 15) >> 4;      // window rows, 16-row DMA blocks per plane
+    const int pix0 = m0 - W - (TIGHT ? 0 : 1);                          // flattened input pixel of window row 0
     const int nchunk = p.Cin / BK;
     const int c_per = (nchunk + p.ksplit - 1) / p.ksplit;
     const int c_begin = ks * c_per, c_end = min(nchunk, c_begin + c_per);
@@ -927,11 +932,11 @@ __global__ __launch_bounds__(128 * WAVES_N, WAVES_N) void pswin_kernel(const Gem
     // ---- GNA: this thread's float4 slots of a window chunk (item = tid + THREADS q: window row item / 8, channels 4 (item % 8) .. +3)
     int gpix[G_SLOTS], gimg[G_SLOTS];          // flattened pixel (or -1) and image index relative to the window's first image
     float4 xv[G_SLOTS];
-    const int pix_first = max(m0 - W - 1, 0), img_first = fdiv(pix_first, p.hw_magic, p.hw_shift), img_last = fdiv(p.M - 1, p.hw_magic, p.hw_shift);
+    const int pix_first = max(pix0, 0), img_first = fdiv(pix_first, p.hw_magic, p.hw_shift), img_last = fdiv(p.M - 1, p.hw_magic, p.hw_shift);
     if constexpr (GNA) {
 #pragma unroll
         for (int q = 0; q < G_SLOTS; ++q) {
-            const int item = tid + THREADS * q, j = item >> 3, pix = m0 - W - 1 + j;
+            const int item = tid + THREADS * q, j = item >> 3, pix = pix0 + j;
             const bool ok = j < win && pix >= 0 && pix < p.M;
             gpix[q] = ok ? pix : -1;
             gimg[q] = ok ? min(fdiv(pix, p.hw_magic, p.hw_shift) - img_first, 3) : 0;
@@ -985,7 +990,7 @@ __global__ __launch_bounds__(128 * WAVES_N, WAVES_N) void pswin_kernel(const Gem
     for (int q = 0; q < A_SLOTS; ++q) {
         const int pc = wave + NW * q, pl = pc >= NB ? 1 : 0, rb = pc - pl * NB;
         const int j = rb * 16 + (lane >> 2);                             // window row
-        const int pix = m0 - W - 1 + j;                                  // flattened input pixel (n, y, x)
+        const int pix = pix0 + j;                                        // flattened input pixel (n, y, x)
         const int c = (lane & 3) ^ ((j >> 2) & 3);
         aoff[q] = (pix >= 0 && pix < p.M && j < win) ? pix * (int)p.sx + c * 8 : -1;
     }
@@ -1107,14 +1112,15 @@ __global__ __launch_bounds__(128 * WAVES_N, WAVES_N) void pswin_kernel(const Gem
                     if (nchk < c_end) issue_B(stage >= 1 ? stage - 1 : 2, nchk, ntap);            // (stage + 2) % 3
                 }
             }
-            const int ky = tap / 3, kx = tap - 3 * ky, shift = ky * W + kx;
+            const int ky = tap / 3, kx = tap - 3 * ky, shift = ky * W + kx - (TIGHT ? 1 : 0);
             const char* bc = bst + stage * (NPL * B_PLANE);
             unsigned amask[TM];
             int abase[TM];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 amask[i] = (tapmask[i] >> tap) & 1 ? 0xffffffffu : 0u;
-                const int j = jrow[i] + shift;
+                int j = jrow[i] + shift;
+                if constexpr (TIGHT) j = min(max(j, 0), win - 1);            // the clamped reads belong to masked taps
                 abase[i] = j * 64 + 16 * (hh ^ ((j >> 2) & 3));           // sk = 0 chunk; sk = 1 flips chunk bit 1 (+-32 bytes)
             }
 #pragma unroll
@@ -1215,19 +1221,19 @@ __global__ __launch_bounds__(128 * WAVES_N, WAVES_N) void pswin_kernel(const Gem
         }
 }
 
-template <int BN, int NPL, int BST, int MAXWIN, int WAVES_N = 4, bool GNA = false>
+template <int BN, int NPL, int BST, int MAXWIN, int WAVES_N = 4, bool GNA = false, int BM = 128>
 int launch_pswin(const GemmParams& p, hipStream_t st) {
     constexpr size_t smem = (size_t)NPL * MAXWIN * 64 + (size_t)BST * NPL * BN * 64 + (GNA ? 2048 : 0);
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N, GNA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N, GNA, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
         attr_done = true;
     }
-    dim3 grid((unsigned)((long)((p.M + 127) / 128) * ((p.N + BN - 1) / BN) * p.ksplit));
+    dim3 grid((unsigned)((long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.ksplit));
     static const size_t pad = getenv("CDAE_PS_PAD_LDS") ? (size_t)atoi(getenv("CDAE_PS_PAD_LDS")) : 0;       // dev: force fewer blocks per CU
-    if (pad) hipFuncSetAttribute(reinterpret_cast<const void*>(&pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N, GNA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem + pad));
-    hipLaunchKernelGGL((pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N, GNA>), grid, dim3(128 * WAVES_N), smem + pad, st, p);
+    if (pad) hipFuncSetAttribute(reinterpret_cast<const void*>(&pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N, GNA, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem + pad));
+    hipLaunchKernelGGL((pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N, GNA, BM>), grid, dim3(BM / 64 * WAVES_N * 64), smem + pad, st, p);
     return hipGetLastError() == hipSuccess ? 0 : cdae_fail("pswin_kernel launch failed");
 }
 
@@ -1402,6 +1408,11 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
             if (p.ksplit > nchunk) p.ksplit = nchunk;              // K is split by whole channel chunks here
             ks = p.ksplit;
             const bool deep = p.W <= 32 && cfg_win == 3;           // CDAE_PS_WIN=3: 3-stage weight ring where it fits (measured: no gain over 2 stages)
+            static const int cfg_bm = getenv("CDAE_PS_WIN_BM") ? atoi(getenv("CDAE_PS_WIN_BM")) : 256;
+            // 256-row tiles: rows must divide the tile (tight window) and the larger grid must still fill two blocks per CU
+            const bool tall = cfg_bm == 256 && p.prec == 1 && 256 % p.W == 0 && (long)((p.M + 255) / 256) * ((p.N + 127) / 128) * ks >= 512;
+            if (tall) rc = launch_pswin<128, 2, 2, 384, 2, false, 256>(p, st);
+            else
             if (p.prec == 1 && cfg_win == 4) rc = launch_pswin<128, 2, 2, 272, 2>(p, st);       // CDAE_PS_WIN=4: 4 waves of 64x64 per block
             else if (p.prec == 1) rc = deep ? launch_pswin<128, 2, 3, 208>(p, st) : launch_pswin<128, 2, 2, 272>(p, st);
             else rc = deep ? launch_pswin<128, 1, 3, 208>(p, st) : launch_pswin<128, 1, 2, 272>(p, st);

@@ -292,6 +292,8 @@ def test_split_f16_planes():
     (2, 128, 128, 64, 1, False, False, False),      # window kernel at W = 64 (window 258 rows)
     (5, 64, 128, 8, 1, False, True, False),         # window kernel: 8x8 images, tiles span two images, ragged last tile
     (3, 96, 192, 16, 1, False, False, False),       # window kernel: Cin = 3 chunks, two n-tiles (one ragged)
+    (64, 64, 128, 64, 1, False, True, False),       # 256-row tiles, tight 384-row window at W = 64 (>= 512 tiles), residual
+    (260, 64, 256, 32, 1, False, False, False),     # 256-row tiles at W = 32, two n-tiles, ragged last tile (M % 256 != 0)
 ])
 def test_conv3x3_presplit_is_bit_identical(N, Cin, Cout, S, stride, up, res, nchw):
     """The LDS-DMA kernel on pre-split planes runs the same products in the same order as the in-kernel split:
