@@ -284,31 +284,51 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
     }
 }
 
-// Pass 2a: fold chunk partials.  grid N, 256 threads: gsum[n][G][2] (means), and per-(n,c) / per-c outputs.
-__global__ void gn_bwd_fold_kernel(int N, int HW, int C, int cpg, int G, int nchunk,
-                                   const float* __restrict__ gpart, const float* __restrict__ cpart,
-                                   float* __restrict__ gsum /*[N][G][2]*/, float* __restrict__ dss, int ld_dss,
-                                   float* __restrict__ nc_part /*[N][C][2]*/) {
-    const int n = blockIdx.x;
-    for (int g = threadIdx.x; g < G; g += blockDim.x) {
-        double s = 0, q = 0;
-        for (int c = 0; c < nchunk; ++c) {
-            const float* pp = gpart + (((long)n * nchunk + c) * G + g) * 2;
-            s += pp[0]; q += pp[1];
+// Pass 2a: fold chunk partials.  grid (C/64 + 1, N), 256 threads = 4 chunk-lanes x 64 columns; fixed summation order.
+// Blocks x < C/64 fold 64 channels each ([N][C][2] for pass 2b, and d(scale, shift)); the last block folds the G group sums.
+__global__ __launch_bounds__(256) void gn_bwd_fold_kernel(int N, int HW, int C, int cpg, int G, int nchunk,
+                                                          const float* __restrict__ gpart, const float* __restrict__ cpart,
+                                                          float* __restrict__ gsum /*[N][G][2]*/, float* __restrict__ dss, int ld_dss,
+                                                          float* __restrict__ nc_part /*[N][C][2]*/) {
+    __shared__ double red[4][64][4];
+    const int n = blockIdx.y, cl = threadIdx.x >> 6, col = threadIdx.x & 63;
+    const int cblocks = (C + 63) / 64;
+    double v[4] = {0, 0, 0, 0};
+    if ((int)blockIdx.x < cblocks) {
+        const int c = blockIdx.x * 64 + col;
+        if (c < C)
+            for (int k = cl; k < nchunk; k += 4) {
+                const float4 pp = *reinterpret_cast<const float4*>(cpart + (((long)n * nchunk + k) * C + c) * 4);
+                v[0] += pp.x; v[1] += pp.y; v[2] += pp.z; v[3] += pp.w;
+            }
+        for (int i = 0; i < 4; ++i) red[cl][col][i] = v[i];
+        __syncthreads();
+        if (cl == 0 && c < C) {
+            for (int k = 1; k < 4; ++k)
+                for (int i = 0; i < 4; ++i) v[i] += red[k][col][i];
+            nc_part[((long)n * C + c) * 2 + 0] = (float)v[0];
+            nc_part[((long)n * C + c) * 2 + 1] = (float)v[1];
+            if (dss) { dss[(long)n * ld_dss + c] = (float)v[2]; dss[(long)n * ld_dss + C + c] = (float)v[3]; }
         }
-        const double cnt = (double)HW * cpg;
-        gsum[(n * G + g) * 2 + 0] = (float)(s / cnt);
-        gsum[(n * G + g) * 2 + 1] = (float)(q / cnt);
-    }
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        double v[4] = {0, 0, 0, 0};
-        for (int k = 0; k < nchunk; ++k) {
-            const float* pp = cpart + (((long)n * nchunk + k) * C + c) * 4;
-            v[0] += pp[0]; v[1] += pp[1]; v[2] += pp[2]; v[3] += pp[3];
+    } else {
+        for (int g0 = 0; g0 < G; g0 += 64) {            // G <= 256: at most four rounds
+            const int g = g0 + col;
+            v[0] = v[1] = 0;
+            if (g < G)
+                for (int k = cl; k < nchunk; k += 4) {
+                    const float* pp = gpart + (((long)n * nchunk + k) * G + g) * 2;
+                    v[0] += pp[0]; v[1] += pp[1];
+                }
+            __syncthreads();
+            red[cl][col][0] = v[0]; red[cl][col][1] = v[1];
+            __syncthreads();
+            if (cl == 0 && g < G) {
+                for (int k = 1; k < 4; ++k) { v[0] += red[k][col][0]; v[1] += red[k][col][1]; }
+                const double cnt = (double)HW * cpg;
+                gsum[(n * G + g) * 2 + 0] = (float)(v[0] / cnt);
+                gsum[(n * G + g) * 2 + 1] = (float)(v[1] / cnt);
+            }
         }
-        nc_part[((long)n * C + c) * 2 + 0] = (float)v[0];
-        nc_part[((long)n * C + c) * 2 + 1] = (float)v[1];
-        if (dss) { dss[(long)n * ld_dss + c] = (float)v[2]; dss[(long)n * ld_dss + C + c] = (float)v[3]; }
     }
 }
 
@@ -608,7 +628,7 @@ int cdae_gn_bwd(const float* x, const float* dy, float* dx, int N, int HW, int C
     cdae_prof_begin(PROF_GN, (double)N * HW * C * 20.0, st);
     if (VEC == 4) hipLaunchKernelGGL(gn_bwd_partial_kernel<4>, dim3(nchunk, N), dim3(256), 0, st, x, dy, HW, C, ldx, lddy, cpg, groups, ppb, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gpart, cpart);
     else hipLaunchKernelGGL(gn_bwd_partial_kernel<1>, dim3(nchunk, N), dim3(256), 0, st, x, dy, HW, C, ldx, lddy, cpg, groups, ppb, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gpart, cpart);
-    hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3(N), dim3(256), 0, st, N, HW, C, cpg, groups, nchunk, gpart, cpart, gsum, d_scale_shift, ld_dss, ncp);
+    hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3((C + 63) / 64 + 1, N), dim3(256), 0, st, N, HW, C, cpg, groups, nchunk, gpart, cpart, gsum, d_scale_shift, ld_dss, ncp);
     hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, st, N, C, ncp, dgamma, dbeta, accumulate_params);
     if (VEC == 4) hipLaunchKernelGGL(gn_bwd_dx_kernel<4>, dim3(grid_for(total)), dim3(256), 0, st, x, dy, dx, total, HW, C, ldx, lddy, lddx, cpg, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gsum, accumulate_dx);
     else hipLaunchKernelGGL(gn_bwd_dx_kernel<1>, dim3(grid_for(total)), dim3(256), 0, st, x, dy, dx, total, HW, C, ldx, lddy, lddx, cpg, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gsum, accumulate_dx);
