@@ -884,10 +884,9 @@ int launch_ps(const GemmParams& p, hipStream_t st) {
 // BM = 256 (4 x 2 waves of 64 x 64): twice the MFMAs per step and per staged weight byte.  Its window is TIGHT — exactly BM + 2W
 // rows (384 at W = 64, so that window + two weight stages are 80 KB and two blocks still share a CU): the two corner rows of the
 // loose window are only ever read by masked taps when tiles start on an image-row boundary (BM % W == 0), so their reads clamp.
-template <int BN, int NPL, int BST, int MAXWIN, int WAVES_N = 4, bool GNA = false, int BM = 128>
-__global__ __launch_bounds__(BM / 64 * WAVES_N * 64, BM / 64 * WAVES_N / 2) void pswin_kernel(const GemmParams p) {     // two blocks per CU
+template <int BN, int NPL, int BST, int MAXWIN, int WAVES_N = 4, bool GNA = false, int BM = 128, bool TIGHT = (BM == 256), int BLOCKS = 2>
+__global__ __launch_bounds__(BM / 64 * WAVES_N * 64, BM / 64 * WAVES_N * BLOCKS / 4) void pswin_kernel(const GemmParams p) {     // BLOCKS blocks per CU
     constexpr int WAVES_M = BM / 64, NW = WAVES_M * WAVES_N, THREADS = 64 * NW;
-    constexpr bool TIGHT = BM == 256;
     static_assert(!GNA || (BST == 2 && BM == 128), "the fused-GroupNorm window is built for the 2-stage weight ring and 128-row tiles");
     constexpr int G_SLOTS = (MAXWIN * 8 + THREADS - 1) / THREADS;        // float4s of a window chunk per thread
     constexpr int WM = 64, WN = BN / WAVES_N, TM = 2, TN = WN / 32;
@@ -1221,19 +1220,19 @@ __global__ __launch_bounds__(BM / 64 * WAVES_N * 64, BM / 64 * WAVES_N / 2) void
         }
 }
 
-template <int BN, int NPL, int BST, int MAXWIN, int WAVES_N = 4, bool GNA = false, int BM = 128>
+template <int BN, int NPL, int BST, int MAXWIN, int WAVES_N = 4, bool GNA = false, int BM = 128, bool TIGHT = (BM == 256), int BLOCKS = 2>
 int launch_pswin(const GemmParams& p, hipStream_t st) {
     constexpr size_t smem = (size_t)NPL * MAXWIN * 64 + (size_t)BST * NPL * BN * 64 + (GNA ? 2048 : 0);
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N, GNA, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N, GNA, BM, TIGHT, BLOCKS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
         attr_done = true;
     }
     dim3 grid((unsigned)((long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.ksplit));
     static const size_t pad = getenv("CDAE_PS_PAD_LDS") ? (size_t)atoi(getenv("CDAE_PS_PAD_LDS")) : 0;       // dev: force fewer blocks per CU
-    if (pad) hipFuncSetAttribute(reinterpret_cast<const void*>(&pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N, GNA, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem + pad));
-    hipLaunchKernelGGL((pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N, GNA, BM>), grid, dim3(BM / 64 * WAVES_N * 64), smem + pad, st, p);
+    if (pad) hipFuncSetAttribute(reinterpret_cast<const void*>(&pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N, GNA, BM, TIGHT, BLOCKS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem + pad));
+    hipLaunchKernelGGL((pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N, GNA, BM, TIGHT, BLOCKS>), grid, dim3(BM / 64 * WAVES_N * 64), smem + pad, st, p);
     return hipGetLastError() == hipSuccess ? 0 : cdae_fail("pswin_kernel launch failed");
 }
 
@@ -1411,7 +1410,11 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
             static const int cfg_bm = getenv("CDAE_PS_WIN_BM") ? atoi(getenv("CDAE_PS_WIN_BM")) : 256;
             // 256-row tiles: rows must divide the tile (tight window) and the larger grid must still fill two blocks per CU
             const bool tall = cfg_bm == 256 && p.prec == 1 && 256 % p.W == 0 && (long)((p.M + 255) / 256) * ((p.N + 127) / 128) * ks >= 512;
+            // rows of 16 or 8 pixels: the tight window is 160 rows, 52.5 KB with the two weight stages: THREE blocks (24 waves) per CU
+            static const int cfg_b3 = getenv("CDAE_PS_WIN_B3") ? atoi(getenv("CDAE_PS_WIN_B3")) : 0;     // measured: +2 % at 16x16, -8 % at 8x8 -> off
+            const bool small_rows = cfg_b3 && p.prec == 1 && p.W <= 16 && 128 % p.W == 0 && cfg_win == 1;
             if (tall) rc = launch_pswin<128, 2, 2, 384, 2, false, 256>(p, st);
+            else if (small_rows) rc = launch_pswin<128, 2, 2, 160, 4, false, 128, true, 3>(p, st);
             else
             if (p.prec == 1 && cfg_win == 4) rc = launch_pswin<128, 2, 2, 272, 2>(p, st);       // CDAE_PS_WIN=4: 4 waves of 64x64 per block
             else if (p.prec == 1) rc = deep ? launch_pswin<128, 2, 3, 208>(p, st) : launch_pswin<128, 2, 2, 272>(p, st);
