@@ -1369,7 +1369,8 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
     const long tiles = big ? tiles_big : tiles_small;
     const int nk = (p.K + BK - 1) / BK;
     int ks = 1;
-    if (p.ksplit_auto && p.splitk_ws && tiles < 256 && nk >= 8) {
+    static const int cfg_mintiles = getenv("CDAE_KS_MINTILES") ? atoi(getenv("CDAE_KS_MINTILES")) : 256;
+    if (p.ksplit_auto && p.splitk_ws && tiles < cfg_mintiles && nk >= 8) {
         ks = (int)((512 + tiles - 1) / tiles);
         if (ks > nk / 4) ks = nk / 4;
         if (ks > 64) ks = 64;
