@@ -128,3 +128,72 @@ def test_kl_weight_and_resume_name(golden):
     np.testing.assert_array_equal(got, g["kl_weight_sched"])
     assert parse_resume_step_from_filename("/x/y/model012345.pt") == 12345
     assert parse_resume_step_from_filename("/x/y/ema_checkpoint.pt") == 0
+
+
+def _worker_feed(rank, world, port, root, logdir, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from causaldiffae_amd import dist_util, logger
+    from causaldiffae_amd.image_datasets import load_data, read_morphomnist
+    from causaldiffae_amd.resample import LossSecondMomentResampler
+    dist_util.setup_dist(backend="gloo")
+    try:
+        # (1) load_data takes the [rank::world] stride of the files
+        feed = load_data(data_dir=root, batch_size=4, image_size=28, split="train")
+        x, cond = next(feed)
+        shard = read_morphomnist(root, "train", rank, world)
+        full = read_morphomnist(root, "train")
+        ok_shard = bool((shard.cond["c"] == full.cond["c"][rank::world]).all()) and x.shape == (4, 1, 28, 28)
+        seen = {tuple(row.tolist()) for row in cond["c"]}
+        mine = {tuple(row.tolist()) for row in torch.from_numpy(shard.cond["c"])}
+        # (2) logger: means are averaged over ranks weighted by their counts, delivered on rank 0
+        logger.configure(dir=logdir, format_strs=["csv"], comm=True)
+        logger.logkv_mean("loss", 1.0 + rank)            # rank 0: one sample of 1.0; rank 1: two samples of 2.0 and 4.0 (mean 3.0)
+        if rank == 1:
+            logger.logkv_mean("loss", 5.0 - rank)
+        kv = logger.dumpkvs()
+        logger.reset()
+        # (3) loss-aware sampler: both ranks end with the same history after exchanging their local losses
+        class D:
+            num_timesteps = 6
+        s = LossSecondMomentResampler(D, history_per_term=2)
+        for k in range(3):
+            ts = torch.tensor([(rank + 2 * k) % 6, (rank + 2 * k + 3) % 6])
+            s.update_with_local_losses(ts, torch.tensor([1.0 + rank + k, 2.0 * (1 + rank) + k]))
+        hist = torch.from_numpy(s._loss_history.copy())
+        hists = [torch.zeros_like(hist) for _ in range(world)]
+        dist.all_gather(hists, hist)
+        q.put((rank, ok_shard, seen <= mine, kv, bool(torch.equal(hists[0], hists[1])), int(s._loss_counts.sum())))
+    except Exception:
+        import traceback
+        q.put((rank, "error", traceback.format_exc(), None, None, None))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_data_feed_logger_and_sampler_world2(tmp_path):
+    """Rank-strided dataset shards, cross-rank averaged logging and the loss-aware sampler's exchange under gloo, world size 2."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_datasets_cpu import _make_morpho
+    root = str(tmp_path / "morphomnist")
+    _make_morpho(root, n_train=21, n_test=8)
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_feed, args=(r, world, port, root, str(tmp_path / "logs"), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for r in res:
+        assert r[1] != "error", r[2]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    res = sorted(res)
+    for rank, ok_shard, batch_in_shard, kv, same_hist, n_losses in res:
+        assert ok_shard and batch_in_shard and same_hist
+        assert n_losses == 12                               # 3 rounds x 2 ranks x 2 losses, applied identically on both ranks
+    assert abs(res[0][3]["loss"] - (1.0 * 1 + 3.0 * 2) / 3) < 1e-12          # weighted by sample counts, on rank 0
+    assert res[1][3] == {"dummy": 1}
