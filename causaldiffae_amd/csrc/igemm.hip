@@ -1083,9 +1083,12 @@ __global__ __launch_bounds__(BM / 64 * WAVES_N * 64, BM / 64 * WAVES_N * BLOCKS 
     };
     if (stamps) t_prev = stamp();
     int stage = 0;
+    // ntaps = 9: the 3x3 window; 4: the 2x2 window of one sub-pixel phase (ph_y, ph_x) of an upsample + conv — tap t reads window
+    // position (t / 2 + ph_y, t % 2 + ph_x) of the same 3x3 neighbourhood, so window, masks and row shifts are shared.
+    const int ntaps = p.ps_taps == 4 ? 4 : 9, lasttap = ntaps - 1;
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
 #pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {           // not unrolled: nine copies keep every tap's addresses and masks live (197 VGPRs)
+        for (int tap = 0; tap < ntaps; ++tap) {       // not unrolled: nine copies keep every tap's addresses and masks live (197 VGPRs)
             if constexpr (BST == 2) {
                 // GNA, tap 0: the weight DMAs are older than the next chunk's register prefetch (<= G_SLOTS loads + one coefficient
                 // DMA issued after them), so a counted wait retires the weights and leaves the prefetch in flight
@@ -1096,28 +1099,29 @@ __global__ __launch_bounds__(BM / 64 * WAVES_N * 64, BM / 64 * WAVES_N * BLOCKS 
                     __builtin_amdgcn_s_barrier();
                 } else __syncthreads();
                 if (stamps) { const unsigned long long t = stamp(); t_wait += t - t_prev; t_prev = t; }
-                const int ntap = tap == 8 ? 0 : tap + 1, nchk = tap == 8 ? chunk + 1 : chunk;     // stage the next step's weight tile
+                const int ntap = tap == lasttap ? 0 : tap + 1, nchk = tap == lasttap ? chunk + 1 : chunk;     // stage the next step's weight tile
                 if (nchk < c_end) issue_B(stage ^ 1, nchk, ntap);
                 if (stamps) { const unsigned long long t = stamp(); t_issue += t - t_prev; t_prev = t; }
             } else {
                 // weights of this step landed when only the next step's NPL pieces may still be in flight; at tap 0 the window
                 // (issued last) must be complete too, and on the very last step nothing younger exists: drain.
-                const bool last = chunk + 1 == c_end && tap == 8;
+                const bool last = chunk + 1 == c_end && tap == lasttap;
                 if (tap == 0 || last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPL * B_RB) : "memory");
                 __builtin_amdgcn_s_barrier();
                 if (!(p.dbg & 64)) {
-                    const int t2 = tap + 2, ntap = t2 >= 9 ? t2 - 9 : t2, nchk = t2 >= 9 ? chunk + 1 : chunk;
+                    const int t2 = tap + 2, ntap = t2 >= ntaps ? t2 - ntaps : t2, nchk = t2 >= ntaps ? chunk + 1 : chunk;
                     if (nchk < c_end) issue_B(stage >= 1 ? stage - 1 : 2, nchk, ntap);            // (stage + 2) % 3
                 }
             }
-            const int ky = tap / 3, kx = tap - 3 * ky, shift = ky * W + kx - (TIGHT ? 1 : 0);
+            const int ky = ntaps == 9 ? tap / 3 : (tap >> 1) + p.ph_y, kx = ntaps == 9 ? tap - 3 * ky : (tap & 1) + p.ph_x;
+            const int wtap = ky * 3 + kx, shift = ky * W + kx - (TIGHT ? 1 : 0);          // wtap: position in the 3x3 neighbourhood (mask bit)
             const char* bc = bst + stage * (NPL * B_PLANE);
             unsigned amask[TM];
             int abase[TM];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                amask[i] = (tapmask[i] >> tap) & 1 ? 0xffffffffu : 0u;
+                amask[i] = (tapmask[i] >> wtap) & 1 ? 0xffffffffu : 0u;
                 int j = jrow[i] + shift;
                 if constexpr (TIGHT) j = min(max(j, 0), win - 1);            // the clamped reads belong to masked taps
                 abase[i] = j * 64 + 16 * (hh ^ ((j >> 2) & 3));           // sk = 0 chunk; sk = 1 flips chunk bit 1 (+-32 bytes)
@@ -1159,7 +1163,7 @@ __global__ __launch_bounds__(BM / 64 * WAVES_N * 64, BM / 64 * WAVES_N * BLOCKS 
             }
             if constexpr (BST == 3) {
                 if (p.dbg & 64) {     // late issue: the step's own MFMAs are queued before this wave joins the block's DMA burst
-                    const int t2 = tap + 2, ntap = t2 >= 9 ? t2 - 9 : t2, nchk = t2 >= 9 ? chunk + 1 : chunk;
+                    const int t2 = tap + 2, ntap = t2 >= ntaps ? t2 - ntaps : t2, nchk = t2 >= ntaps ? chunk + 1 : chunk;
                     if (nchk < c_end) issue_B(stage >= 1 ? stage - 1 : 2, nchk, ntap);
                 }
             }
@@ -1200,7 +1204,11 @@ __global__ __launch_bounds__(BM / 64 * WAVES_N * 64, BM / 64 * WAVES_N * BLOCKS 
                 const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
                 if (row >= p.M) continue;
                 if (p.ksplit > 1) { Cg[(long)row * p.N + col] = acc[i][j][r]; continue; }
-                const long addr = (long)row * p.ldc + col;
+                long addr;
+                if (p.out_mode == OUT_UP2) {
+                    const int x = row - fdiv(row, p.wo_magic, p.wo_shift) * p.Wo;          // (n, y, x) -> (n, 2y + ph_y, 2x + ph_x)
+                    addr = (4L * row - 2 * x + p.ph_y * 2 * p.Wo + p.ph_x) * p.ldc + col;
+                } else addr = (long)row * p.ldc + col;
                 float v = acc[i][j][r] * p.alpha + bv;
                 if (Rg) v += Rg[addr];
                 if (p.act == ACT_SILU) v = v / (1.f + expf(-v));
@@ -1393,9 +1401,11 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
         const long tiles_256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
         const bool huge = cfg_tile == 256 && big && tiles_256 * ks >= 200;            // 256x128 tiles, 1 block / CU, 3-stage DMA ring
         static const int cfg_win = getenv("CDAE_PS_WIN") ? atoi(getenv("CDAE_PS_WIN")) : 1;
+        static const int cfg_subpix = getenv("CDAE_PS_WIN_SUBPIX") ? atoi(getenv("CDAE_PS_WIN_SUBPIX")) : 1;      // sub-pixel phases on the window kernel
         // window-resident form: stride-1 3x3 convs on a dense NHWC tensor, rows up to 64 pixels, row-major result
-        const bool win_ok = cfg_win && p.amode == A_CONV_VEC && p.ps_taps != 4 && p.stride == 1 && !p.up && p.W <= 64 && big &&
-                            p.sy == (long)p.W * p.sx && p.sn == (long)p.H * p.W * p.sx && p.out_mode == OUT_ROWMAJOR;
+        const bool win_ok = cfg_win && p.amode == A_CONV_VEC && p.stride == 1 && !p.up && p.W <= 64 && big &&
+                            p.sy == (long)p.W * p.sx && p.sn == (long)p.H * p.W * p.sx &&
+                            (p.ps_taps == 4 ? p.out_mode == OUT_UP2 && !p.gn_coef && cfg_subpix : p.out_mode == OUT_ROWMAJOR);
         if (p.gn_coef && (!win_ok || (p.A2 && p.K1 % BK))) return cdae_fail("fused GroupNorm prologue: only on the window-resident conv path");
         if (win_ok && p.gn_coef) {
             const int nchunk = p.Cin / BK;

@@ -366,7 +366,9 @@ def test_group_norm_split_matches_fp32_output(C, S, ss, silu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,Cin,Cout,S", [(2, 256, 256, 16), (3, 512, 512, 8), (1, 384, 384, 16), (2, 128, 96, 8)])
+@pytest.mark.parametrize("N,Cin,Cout,S", [(2, 256, 256, 16), (3, 512, 512, 8), (1, 384, 384, 16), (2, 128, 96, 8),
+                                         (64, 256, 256, 16),      # phases on the window kernel (128-row tiles)
+                                         (256, 64, 128, 32)])     # phases on the window kernel with 256-row tiles
 def test_upconv_subpixel_matches_upsample_conv(N, Cin, Cout, S):
     """nearest-2x + conv3x3 as four folded 2x2 convolutions of the low-resolution input == convolving the upsampled image
     (fp32 rounding of the folded weights only)."""
