@@ -41,6 +41,8 @@ SIGNATURES = {
     "cdae_linear_wgrad": [P, L, P, L, P, L, P, I, I, I, I, P, SZ, P],
     "cdae_colsum": [P, L, P, L, I, I, P],
     "cdae_qkv_attention_fwd": [P, P, P, I, I, I, I, P],
+    "cdae_qkv_attention_fused_supported": [I, I],
+    "cdae_qkv_attention_fwd_fused": [P, P, I, I, I, I, P],
     "cdae_qkv_attention_bwd": [P, P, P, P, P, I, I, I, I, P],
     "cdae_gn_workspace_floats": [I, I],
     "cdae_gn_stats": [P, I, I, I, I, I, F, P, P, P, P],

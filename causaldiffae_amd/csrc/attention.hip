@@ -1,0 +1,231 @@
+// Fused QKVAttention forward for inference (reference improved_diffusion/unet.py:239-253): softmax(q k^T / sqrt(ch)) v per
+// (batch, head) in ONE kernel — the [T, T] probabilities never leave the registers.  Split precision like the GEMMs: every
+// operand is split into f16 hi/lo on its way into LDS / registers and each product is hi*hi + hi*lo + lo*hi on
+// v_mfma_f32_32x32x16_f16 with fp32 accumulation; the softmax itself is fp32.
+//
+// qkv: rows [B][T][heads * 3ch], per head the channel order is q | k | v (the reference's reshape to [B*heads, 3ch, T]).
+// One block = one (batch, head) and 32 * WAVES queries; each wave owns 32 queries:
+//   phase 0  the wave's Q rows -> registers as MFMA B-fragments (hi / lo)
+//   phase 1  S^T = K Q^T per 32-key tile (K staged through LDS in passes of <= 128 keys): lane = query, registers = keys,
+//            so the softmax over keys is an in-lane reduction plus one cross-half shuffle
+//   phase 2  softmax in registers (exact: T <= 256 keys are all resident, no online rescaling)
+//   phase 3  O = P V: P is already laid out as the MFMA A operand (lane = query row); its register order fixes a permutation
+//            of the 16 keys of an MFMA step, and V (staged k-major, read with ds_read_b64_tr_b16) is fetched in that same order
+//   phase 4  O -> out[B][T][heads * ch]
+#include <hip/hip_runtime.h>
+
+#include "cdae.h"
+#include "cdae_internal.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x16 mma(const u16x8& a, const u16x8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+}
+// 8 fp32 -> f16 hi / lo fragments.  The empty asm makes each value opaque: when x is the result of a multiply, hipcc otherwise
+// converts it to f16 twice — v_cvt_pk_f16_f32 of the fp32 product for the fragment, but v_fma_mixlo_f16 of the UNROUNDED
+// product for the subtraction — and in the rare double-rounding cases where the two disagree the hi / lo pair is off by one f16
+// ulp (seen as ~1 query in 1000 with an error of 2^-12 of a probability; -ffp-contract=off does not stop that fold).
+__device__ __forceinline__ void split8(const float* v, u16x8& hi, u16x8& lo) {
+    half8 h, l;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float x = v[i];
+        asm volatile("" : "+v"(x));
+        h[i] = (_Float16)x;
+        l[i] = (_Float16)(x - (float)h[i]);
+    }
+    hi = __builtin_bit_cast(u16x8, h);
+    lo = __builtin_bit_cast(u16x8, l);
+}
+
+template <int CH, int NKT>
+__global__ __launch_bounds__(NKT >= 4 ? 256 : 64 * NKT) void attn_fused_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                                int heads, float alpha) {
+    constexpr int T = 32 * NKT, WAVES = NKT >= 4 ? 4 : NKT, THREADS = 64 * WAVES;
+    constexpr int PASS = T < 128 ? T : 128, NPASS = T / PASS, TPP = PASS / 32;       // keys per staging pass, passes, key tiles per pass
+    constexpr int KSTEPS = CH / 16, CT = CH / 32;                                      // 16-deep MFMA steps over ch; 32-wide output tiles
+    constexpr int KP = CH * 2 + 16;                                                    // K plane row pitch in bytes (conflict-free b128 reads)
+    constexpr int VP = (CH + 32) * 2;                                                  // V plane row pitch in bytes (k-major, transpose reads)
+    constexpr int PLANE = PASS * (KP > VP ? KP : VP);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const lds = reinterpret_cast<char*>(smem);                                   // [2 planes][PASS rows][pitch]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
+    const int q0 = (blockIdx.x * WAVES + wave) * 32;                                   // this wave's first query
+    const long C3 = (long)heads * 3 * CH, C = (long)heads * CH;
+    const float* const base = qkv + (long)b * T * C3 + (long)h * 3 * CH;               // q at +0, k at +CH, v at +2CH
+
+    // ---- phase 0: Q fragments (B operand of S^T = K Q^T: lane = query column, 8 consecutive ch per lane and step)
+    u16x8 qh[KSTEPS], ql[KSTEPS];
+    {
+        const float* qrow = base + (long)(q0 + l31) * C3;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            const float4 a = *reinterpret_cast<const float4*>(qrow + s * 16 + 8 * hh);
+            const float4 c = *reinterpret_cast<const float4*>(qrow + s * 16 + 8 * hh + 4);
+            const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+            split8(v, qh[s], ql[s]);
+        }
+    }
+
+    // ---- phase 1: S^T tiles.  acc[kt][r] = S[query = q0 + l31][key = 32 kt + (r & 3) + 8 (r >> 2) + 4 hh]
+    f32x16 acc[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[kt][r] = 0.f;
+
+    auto stage = [&](int key0, int which /*1 = K (KC layout), 2 = V (k-major)*/) {
+        const int pitch = which == 1 ? KP : VP;
+        for (int item = tid; item < PASS * (CH / 4); item += THREADS) {
+            const int row = item / (CH / 4), f4 = item - row * (CH / 4);
+            const float4 v = *reinterpret_cast<const float4*>(base + (long)(key0 + row) * C3 + which * CH + f4 * 4);
+            half4 hi, lo;
+            hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
+            lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);
+            lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);
+            *reinterpret_cast<half4*>(lds + row * pitch + f4 * 8) = hi;
+            *reinterpret_cast<half4*>(lds + PLANE + row * pitch + f4 * 8) = lo;
+        }
+    };
+
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        if (ps) __syncthreads();
+        stage(ps * PASS, 1);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < TPP; ++t) {
+            const int kt = ps * TPP + t;
+            const char* arow = lds + (t * 32 + l31) * KP + 16 * hh;                     // A operand: lane = key row, 8 ch at 8 hh
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                const u16x8 kh = *reinterpret_cast<const u16x8*>(arow + s * 32);
+                const u16x8 kl = *reinterpret_cast<const u16x8*>(arow + PLANE + s * 32);
+                acc[kt] = mma(kl, qh[s], acc[kt]);
+                acc[kt] = mma(kh, ql[s], acc[kt]);
+                acc[kt] = mma(kh, qh[s], acc[kt]);
+            }
+        }
+    }
+
+    // ---- phase 2: softmax over the keys of each query (lane): in-lane over tiles and registers, then across the two lane halves
+    float m = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[kt][r] *= alpha; m = fmaxf(m, acc[kt][r]); }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float e = expf(acc[kt][r] - m); acc[kt][r] = e; sum += e; }
+    sum += __shfl_xor(sum, 32);
+    // the probabilities are split as p * 2^10 (values in [0, 1024]: their f16 lo parts stay NORMAL numbers — unscaled, every lo of a
+    // p < 1/8 is an f16 subnormal) and the factor is taken out of O again at the end; powers of two, so nothing is rounded.
+    const float inv = 1024.f / sum;
+
+    // ---- phase 3: O = P V.  MFMA step sk of key tile kt consumes registers r = 8 sk .. 8 sk + 7 of acc[kt], i.e. the keys
+    //      32 kt + 16 sk + 4 hh + {0,1,2,3, 8,9,10,11}: V is read in exactly that order (two transpose reads 8 rows apart).
+    f32x16 o[CT];
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
+    const int q4 = (lane & 15) >> 2, p4 = lane & 3, chalf = 16 * ((lane >> 4) & 1);
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        __syncthreads();
+        stage(ps * PASS, 2);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < TPP; ++t) {
+            const int kt = ps * TPP + t;
+#pragma unroll
+            for (int sk = 0; sk < 2; ++sk) {
+                float pv[8];
+#pragma unroll
+                for (int jx = 0; jx < 8; ++jx) pv[jx] = acc[kt][8 * sk + jx] * inv;
+                u16x8 ph, pl;
+                split8(pv, ph, pl);
+                const int krow = t * 32 + 16 * sk + 4 * hh + q4;
+#pragma unroll
+                for (int j = 0; j < CT; ++j) {
+                    const char* src = lds + krow * VP + (j * 32 + chalf + 4 * p4) * 2;
+                    u16x8 vh, vl;
+                    {
+                        const fp16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(src));
+                        const fp16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(src + 8 * VP));
+                        const u16x4 a4 = __builtin_bit_cast(u16x4, a), c4 = __builtin_bit_cast(u16x4, c);
+                        vh[0] = a4[0]; vh[1] = a4[1]; vh[2] = a4[2]; vh[3] = a4[3]; vh[4] = c4[0]; vh[5] = c4[1]; vh[6] = c4[2]; vh[7] = c4[3];
+                    }
+                    {
+                        const fp16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(src + PLANE));
+                        const fp16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(src + PLANE + 8 * VP));
+                        const u16x4 a4 = __builtin_bit_cast(u16x4, a), c4 = __builtin_bit_cast(u16x4, c);
+                        vl[0] = a4[0]; vl[1] = a4[1]; vl[2] = a4[2]; vl[3] = a4[3]; vl[4] = c4[0]; vl[5] = c4[1]; vl[6] = c4[2]; vl[7] = c4[3];
+                    }
+                    o[j] = mma(pl, vh, o[j]);
+                    o[j] = mma(ph, vl, o[j]);
+                    o[j] = mma(ph, vh, o[j]);
+                }
+            }
+        }
+    }
+
+    // ---- phase 4: O[query row][ch col] -> out[b][q0 + row][h * CH + col]
+    float* const obase = out + ((long)b * T + q0) * C + (long)h * CH;
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            obase[(long)row * C + j * 32 + l31] = o[j][r] * (1.f / 1024.f);
+        }
+}
+
+template <int CH, int NKT>
+int launch_attn(const float* qkv, float* out, int B, int heads, hipStream_t st) {
+    constexpr int T = 32 * NKT, WAVES = NKT >= 4 ? 4 : NKT, PASS = T < 128 ? T : 128;
+    constexpr int KP = CH * 2 + 16, VP = (CH + 32) * 2;
+    constexpr size_t smem = 2 * (size_t)PASS * (KP > VP ? KP : VP);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fused_kernel<CH, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((attn_fused_kernel<CH, NKT>), dim3(T / (32 * WAVES), B * heads), dim3(64 * WAVES), smem, st, qkv, out, heads,
+                       1.f / sqrtf((float)CH));
+    return hipGetLastError() == hipSuccess ? 0 : cdae_fail("attn_fused launch failed");
+}
+
+}  // namespace
+
+extern "C" int cdae_qkv_attention_fused_supported(int T, int ch) {
+    return (T == 64 || T == 256) && (ch == 64 || ch == 96 || ch == 128);
+}
+
+extern "C" int cdae_qkv_attention_fwd_fused(const float* qkv, float* out, int B, int T, int heads, int ch, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if ((((size_t)qkv) & 15) || !cdae_qkv_attention_fused_supported(T, ch)) return cdae_fail("attention_fwd_fused: unsupported shape (T in {64, 256}, ch in {64, 96, 128})");
+    cdae_prof_begin(PROF_IGEMM, 4.0 * B * heads * (double)T * T * ch, st);
+    int rc;
+#define ATT(CHV, NK) rc = launch_attn<CHV, NK>(qkv, out, B, heads, st)
+    if (T == 256) { if (ch == 64) ATT(64, 8); else if (ch == 96) ATT(96, 8); else ATT(128, 8); }
+    else { if (ch == 64) ATT(64, 2); else if (ch == 96) ATT(96, 2); else ATT(128, 2); }
+#undef ATT
+    cdae_prof_end(PROF_IGEMM, st);
+    return rc;
+}

@@ -96,6 +96,7 @@ __device__ __forceinline__ float ld1_if(const float* /*unused*/, const float* p,
 
 // second output of an epilogue: v as f16 hi/lo planes
 __device__ __forceinline__ void store_planes(const GemmParams& p, long addr, float v) {
+    asm volatile("" : "+v"(v));        // opaque: no second, differently rounded f16 conversion folded into the producing fma (see attention.hip split8)
     const _Float16 h = (_Float16)v;
     const _Float16 l = (_Float16)(v - (float)h);
     p.C_hi[addr] = __builtin_bit_cast(unsigned short, h);
@@ -970,6 +971,7 @@ __global__ __launch_bounds__(BM / 64 * WAVES_N * 64, BM / 64 * WAVES_N * BLOCKS 
                 float y0 = fmaf(xv[q].x, c01.x, c01.y), y1 = fmaf(xv[q].y, c01.z, c01.w);
                 float y2 = fmaf(xv[q].z, c23.x, c23.y), y3 = fmaf(xv[q].w, c23.z, c23.w);
                 if (p.gn_silu) { y0 = y0 / (1.f + expf(-y0)); y1 = y1 / (1.f + expf(-y1)); y2 = y2 / (1.f + expf(-y2)); y3 = y3 / (1.f + expf(-y3)); }
+                asm volatile("" : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3));      // opaque before the split (attention.hip split8)
                 half4 hi, lo;
                 hi[0] = (_Float16)y0; hi[1] = (_Float16)y1; hi[2] = (_Float16)y2; hi[3] = (_Float16)y3;
                 const int off = j * 64 + 16 * ((f4 >> 1) ^ ((j >> 2) & 3)) + 8 * (f4 & 1);

@@ -175,8 +175,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     if constexpr (VEC == 4) {
         const long hbase = (long)n * HW * ldy + c;
         auto put = [&](int pp, const float4& v) {
-            const float r0 = apply(v.x, 0), r1 = apply(v.y, 1), r2 = apply(v.z, 2), r3 = apply(v.w, 3);
+            float r0 = apply(v.x, 0), r1 = apply(v.y, 1), r2 = apply(v.z, 2), r3 = apply(v.w, 3);
             if constexpr (SPLIT) {
+                asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));      // opaque before the split (attention.hip split8)
                 gn_half4 hi, lo;
                 hi[0] = (_Float16)r0; hi[1] = (_Float16)r1; hi[2] = (_Float16)r2; hi[3] = (_Float16)r3;
                 lo[0] = (_Float16)(r0 - (float)hi[0]); lo[1] = (_Float16)(r1 - (float)hi[1]);

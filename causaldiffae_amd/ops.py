@@ -340,8 +340,22 @@ class _Attention(Function):
         return dqkv, None
 
 
+_FUSED_ATTN_ON = os.environ.get("CDAE_FUSED_ATTN", "1") != "0"
+
+
 def qkv_attention(qkv_rows, heads):
-    return _Attention.apply(qkv_rows.contiguous(), heads)
+    """softmax(q k^T / sqrt(ch)) v per (batch, head) on rows [B, T, 3C] (per head: q | k | v).  No-grad forwards in the f16 modes
+    take the fused kernel (probabilities stay in registers) where the shape is built; everything else the three-kernel path,
+    which keeps the probabilities for the backward."""
+    qkv_rows = qkv_rows.contiguous()
+    B, T, C3 = qkv_rows.shape
+    ch = C3 // 3 // heads
+    if (_FUSED_ATTN_ON and not torch.is_grad_enabled() and qkv_rows.dtype == torch.float32
+            and lib.cdae_get_default_precision() == 1 and lib.cdae_qkv_attention_fused_supported(T, ch)):
+        out = torch.empty((B, T, C3 // 3), dtype=torch.float32, device=qkv_rows.device)
+        check(lib.cdae_qkv_attention_fwd_fused(ptr(qkv_rows), ptr(out), B, T, heads, ch, stream()))
+        return out
+    return _Attention.apply(qkv_rows, heads)
 
 
 # ----------------------------------------------------------------------------- small pointwise ops

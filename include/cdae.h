@@ -155,6 +155,11 @@ int cdae_qkv_attention_fwd(const float* qkv, float* out, float* probs, int B, in
 /* dqkv from dout; dprobs: scratch [B*heads][T][T] */
 int cdae_qkv_attention_bwd(const float* qkv, const float* probs, const float* dout, float* dqkv, float* dprobs,
                            int B, int T, int heads, int ch, void* stream);
+/* QKVAttention forward for inference as ONE kernel (unet.py:239-253): q k^T, fp32 softmax and the product with v per (batch, head)
+   with the [T, T] probabilities kept in registers (no `probs` output, so no backward).  T in {64, 256}, ch in {64, 96, 128}:
+   cdae_qkv_attention_fused_supported tells; other shapes use cdae_qkv_attention_fwd. */
+int cdae_qkv_attention_fused_supported(int T, int ch);
+int cdae_qkv_attention_fwd_fused(const float* qkv, float* out, int B, int T, int heads, int ch, void* stream);
 
 /* ---- normalisation / softmax (norm.hip) ------------------------------------------------------------------- */
 size_t cdae_gn_workspace_floats(int N, int C);

@@ -531,3 +531,40 @@ def test_fused_groupnorm_conv_is_bit_identical(N, C1, C2, Cout, S, ss, res):
     assert hasattr(got, "_gnparts") == hasattr(ref, "_gnparts")
     if hasattr(ref, "_gnparts"):
         assert torch.equal(got._gnparts, ref._gnparts)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,heads,ch", [(3, 256, 4, 96), (5, 64, 4, 128), (2, 256, 4, 64), (2, 64, 2, 96), (1, 256, 1, 128)])
+def test_fused_attention_matches_three_kernel_path(B, T, heads, ch):
+    """QKVAttention as one kernel (probabilities in registers) vs the GEMM / softmax / GEMM path and vs an fp64 restatement."""
+    from causaldiffae_amd import ops
+    from causaldiffae_amd._lib import check, lib, ptr, stream
+    g = torch.Generator(device="cuda:0").manual_seed(15)
+    qkv = torch.randn(B, T, 3 * heads * ch, device="cuda:0", generator=g) * 1.2
+    with torch.no_grad():
+        got = ops.qkv_attention(qkv, heads)
+        out = torch.empty_like(got)
+        probs = torch.empty((B * heads, T, T), dtype=torch.float32, device="cuda:0")
+        check(lib.cdae_qkv_attention_fwd(ptr(qkv), ptr(out), ptr(probs), B, T, heads, ch, stream()))
+    x = qkv.double().reshape(B, T, heads, 3, ch)
+    q, k, v = x[:, :, :, 0], x[:, :, :, 1], x[:, :, :, 2]
+    w = torch.softmax(torch.einsum("bthc,bshc->bhts", q, k) / ch ** 0.5, dim=-1)
+    exact = torch.einsum("bhts,bshc->bthc", w, v).reshape(B, T, heads * ch)
+    scale = exact.abs().max().item()
+    assert (got.double() - exact).abs().max().item() < 2e-5 * max(1.0, scale)
+    assert (got - out).abs().max().item() < 2e-5 * max(1.0, scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,heads,ch,seed", [(16, 256, 4, 96, 6), (16, 256, 4, 128, 7), (64, 64, 4, 128, 8), (16, 256, 4, 64, 9)])
+def test_fused_attention_rows_sum_to_one(B, T, heads, ch, seed):
+    """Size-independent property: with V == 1 every output is the sum of one query's probabilities, so it must be 1 to fp32
+    rounding for EVERY query.  A single inconsistent hi / lo pair in the in-register split of P shows up as 2^-16 here (this
+    caught a double-rounding fold in the f16 conversion that hit about one query in a thousand)."""
+    from causaldiffae_amd import ops
+    g = torch.Generator(device="cuda:0").manual_seed(seed)
+    qkv = torch.randn(B, T, 3 * heads * ch, device="cuda:0", generator=g) * 1.2
+    qkv.view(B, T, heads, 3, ch)[:, :, :, 2] = 1.0
+    with torch.no_grad():
+        o = ops.qkv_attention(qkv, heads)
+    assert (o - 1.0).abs().max().item() < 2e-6
