@@ -33,6 +33,12 @@ SIGNATURES = {
     "cdae_upconv3x3_fwd_ps": [P, P, L, L, L, P, P, P, P, L, P, I, I, I, I, I, P, SZ, P],
     "cdae_linear_fwd_ps": [P, P, L, P, P, L, P, P, P, L, I, I, I, F, I, P, SZ, P],
     "cdae_split_f16": [P, P, P, L, P],
+    "cdae_split_bf16": [P, P, P, L, P],
+    "cdae_wdgrad_planes": [P, P, P, I, I, P],
+    "cdae_conv3x3_dgrad_ps": [P, P, P, P, P, L, I, I, I, I, I, P, SZ, P],
+    "cdae_conv3x3_wgrad_win_supported": [I, I, I, I, I],
+    "cdae_conv3x3_wgrad_win": [P, P, P, P, P, P, I, I, I, I, I, I, P, SZ, P],
+    "cdae_gn_apply_split_train": [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, I, I, P],
     "cdae_gn_apply_split": [P, P, P, I, I, I, I, I, I, P, P, P, P, P, I, I, P],
     "cdae_gn_stats2": [P, I, P, I, I, I, I, I, I, F, P, P, P, P],
     "cdae_linear_fwd_cat": [P, L, I, P, L, P, L, P, P, L, I, I, I, P, SZ, P],

@@ -214,6 +214,27 @@ int cdae_conv3x3_wgrad(const float* x, long sn, long sy, long sx, long sc, const
     return rc;
 }
 
+// dgrad of a stride-1 conv3x3 on the pre-split kernels: dx = conv3x3(dy, wt), dy as bf16 hi/lo planes (cdae_split_bf16, dense NHWC,
+// pixel pitch Cout) and wt = the flipped / transposed weight planes of cdae_wdgrad_planes ([Cin][9][Cout])
+int cdae_conv3x3_dgrad_ps(const unsigned short* dy_hi, const unsigned short* dy_lo, const unsigned short* wt_hi, const unsigned short* wt_lo,
+                          float* dx, long lddx, int N, int H, int W, int Cin, int Cout, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    if ((long)N * H * W * Cout >= (1L << 31)) return cdae_fail("conv3x3_dgrad_ps: gradient larger than 2^31 elements");
+    if (Cout % 32 || !aligned16(dy_hi) || !aligned16(dy_lo) || !aligned16(wt_hi) || !aligned16(wt_lo))
+        return cdae_fail("conv3x3_dgrad_ps: Cout % 32 == 0 and 16-byte aligned planes required");
+    GemmParams p = base_params();
+    p.presplit = 1; p.prec = 2; p.grad_operand = 1;
+    p.A = reinterpret_cast<const float*>(dy_hi); p.A_lo = dy_lo; p.B = reinterpret_cast<const float*>(wt_hi); p.B_lo = wt_lo;
+    p.C = dx;
+    p.M = N * H * W; p.N = Cin; p.K = 9 * Cout;
+    p.ldb = 9L * Cout; p.ldc = lddx;
+    p.out_mode = OUT_ROWMAJOR; p.out_hw = H * W;
+    p.amode = A_CONV_VEC; p.bmode = B_PLAIN_KC;
+    p.conv_M = p.M; p.H = H; p.W = W; p.Cin = Cout; p.Ho = H; p.Wo = W; p.stride = 1; p.up = 0;
+    p.sx = Cout; p.sy = (long)W * Cout; p.sn = (long)H * W * Cout; p.sc = 1;
+    set_splitk(p, splitk_ws, splitk_ws_bytes);
+    return cdae_gemm_dispatch(p, stream);
+}
+
 int cdae_linear_fwd(const float* x, long ldx, const float* w, long ldw, const float* bias, const float* res, float* y, long ldy,
                     unsigned short* y_hi, unsigned short* y_lo, int M, int N, int K, float alpha, int act, float* splitk_ws,
                     size_t splitk_ws_bytes, void* stream) {

@@ -40,6 +40,41 @@ __global__ void split_f16_kernel(const float4* __restrict__ src, ew_half4* __res
     }
 }
 
+// fp32 -> two bf16 planes (hi = bf16(x), lo = bf16(x - hi)): gradients on the pre-split path (full fp32 range, 16 significand bits)
+typedef __bf16 ew_bf4 __attribute__((ext_vector_type(4)));
+__global__ void split_bf16_kernel(const float4* __restrict__ src, ew_bf4* __restrict__ hi, ew_bf4* __restrict__ lo, long n4) {
+    GRID_STRIDE(i, n4) {
+        const float4 v = src[i];
+        ew_bf4 h, l;
+        h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+        l[0] = (__bf16)(v.x - (float)h[0]); l[1] = (__bf16)(v.y - (float)h[1]);
+        l[2] = (__bf16)(v.z - (float)h[2]); l[3] = (__bf16)(v.w - (float)h[3]);
+        hi[i] = h; lo[i] = l;
+    }
+}
+
+// conv3x3 weight (OHWI [Cout][9][Cin]) -> the weight of the dgrad convolution, [Cin][9][Cout] with the taps flipped, as bf16 hi/lo
+// planes: dx = conv3x3(dy, this).  One 32x32 (co, ci) tile of one tap per block, transposed through LDS.
+__global__ __launch_bounds__(256) void wdgrad_planes_kernel(const float* __restrict__ w, __bf16* __restrict__ hi, __bf16* __restrict__ lo, int Cout, int Cin) {
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z, ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        tile[r][tx] = (co < Cout && ci < Cin) ? w[((long)co * 9 + tap) * Cin + ci] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + tx;
+        if (ci < Cin && co < Cout) {
+            const float v = tile[tx][r];
+            const __bf16 h = (__bf16)v;
+            const long o = ((long)ci * 9 + (8 - tap)) * Cout + co;
+            hi[o] = h; lo[o] = (__bf16)(v - (float)h);
+        }
+    }
+}
+
 // generic pointwise activations on a stored pre-activation (codes = the GEMM epilogue's: 1 SiLU, 2 LeakyReLU(0.01), 3 ReLU, 4 sigmoid)
 __device__ inline float act_apply(float v, int kind) {
     if (kind == 1) return v / (1.f + expf(-v));
@@ -410,6 +445,15 @@ extern "C" {
 int cdae_split_f16(const float* src, unsigned short* hi, unsigned short* lo, long n, void* stream) {
     if (n % 4 || (((size_t)src | (size_t)hi | (size_t)lo) & 7)) return cdae_fail("split_f16: n % 4 == 0 and 8-byte aligned planes required");
     LAUNCH1D(split_f16_kernel, n / 4, (const float4*)src, (ew_half4*)hi, (ew_half4*)lo, n / 4);
+}
+int cdae_split_bf16(const float* src, unsigned short* hi, unsigned short* lo, long n, void* stream) {
+    if (n % 4 || (((size_t)src & 15) | (((size_t)hi | (size_t)lo) & 7))) return cdae_fail("split_bf16: n % 4 == 0, 16-byte aligned source and 8-byte aligned planes required");
+    LAUNCH1D(split_bf16_kernel, n / 4, (const float4*)src, (ew_bf4*)hi, (ew_bf4*)lo, n / 4);
+}
+int cdae_wdgrad_planes(const float* w, unsigned short* hi, unsigned short* lo, int Cout, int Cin, void* stream) {
+    if (Cout <= 0 || Cin <= 0) return cdae_fail("wdgrad_planes: empty weight");
+    hipLaunchKernelGGL(wdgrad_planes_kernel, dim3((Cin + 31) / 32, (Cout + 31) / 32, 9), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)hi, (__bf16*)lo, Cout, Cin);
+    return hipGetLastError() == hipSuccess ? 0 : cdae_fail("wdgrad_planes launch failed");
 }
 int cdae_act_fwd(const float* x, float* y, long n, int kind, void* stream) { LAUNCH1D(act_kernel, n, x, y, n, kind); }
 int cdae_act_bwd(const float* x, const float* dy, float* dx, long n, int kind, void* stream) { LAUNCH1D(act_bwd_kernel, n, x, dy, dx, n, kind); }

@@ -629,7 +629,8 @@ __device__ __attribute__((aligned(16))) unsigned g_zero_ps[4] = {0u, 0u, 0u, 0u}
 
 // LOADERS > 0: that many extra waves do nothing but issue the DMAs (an LDS-DMA costs its issuing wave 60-180 cycles, four per
 // step in a wave that also has 12 MFMAs to issue); the compute waves then only read fragments and issue MFMAs.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NPL, int STAGES, int LOADERS = 0>
+// BF: the planes hold bf16 (gradient operands: full fp32 range, 16 significand bits over the two planes) instead of f16.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NPL, int STAGES, int LOADERS = 0, bool BF = false>
 __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + LOADERS)) void ps_kernel(const GemmParams p) {
     constexpr int NCOMP = WAVES_M * WAVES_N, THREADS = 64 * (NCOMP + LOADERS);
     constexpr int LT = LOADERS ? 64 * LOADERS : THREADS;               // threads that issue DMAs
@@ -776,7 +777,8 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + LOADERS)) void ps_kernel(
             return *reinterpret_cast<const u16x8*>(plane + row * 64 + 16 * ((2 * sk + hh) ^ ((row >> 2) & 3)));
         };
         auto mma = [&](const u16x8& x, const u16x8& y, const f32x16& c) -> f32x16 {
-            return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, x), __builtin_bit_cast(half8, y), c, 0, 0, 0);
+            if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, x), __builtin_bit_cast(bf8, y), c, 0, 0, 0);
+            else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, x), __builtin_bit_cast(half8, y), c, 0, 0, 0);
         };
 #pragma unroll
         for (int sk = 0; sk < 2; ++sk) {
@@ -851,20 +853,20 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + LOADERS)) void ps_kernel(
         }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NPL, int STAGES, int LOADERS = 0>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NPL, int STAGES, int LOADERS = 0, bool BF = false>
 int launch_ps(const GemmParams& p, hipStream_t st) {
     const int taps = p.amode == A_CONV_VEC ? (p.ps_taps == 4 ? 4 : 9) : 1;
     constexpr size_t tiles = (size_t)STAGES * NPL * (BM + BN) * 64;
     const size_t smem = tiles + (size_t)taps * BM * sizeof(int);
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ps_kernel<BM, BN, WAVES_M, WAVES_N, NPL, STAGES, LOADERS>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ps_kernel<BM, BN, WAVES_M, WAVES_N, NPL, STAGES, LOADERS, BF>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(tiles + 9 * BM * sizeof(int))) != hipSuccess)
             return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
         attr_done = true;
     }
     dim3 grid((unsigned)((long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.ksplit));
-    hipLaunchKernelGGL((ps_kernel<BM, BN, WAVES_M, WAVES_N, NPL, STAGES, LOADERS>), grid, dim3(64 * (WAVES_M * WAVES_N + LOADERS)), smem, st, p);
+    hipLaunchKernelGGL((ps_kernel<BM, BN, WAVES_M, WAVES_N, NPL, STAGES, LOADERS, BF>), grid, dim3(64 * (WAVES_M * WAVES_N + LOADERS)), smem, st, p);
     return hipGetLastError() == hipSuccess ? 0 : cdae_fail("ps_kernel launch failed");
 }
 
@@ -885,7 +887,7 @@ int launch_ps(const GemmParams& p, hipStream_t st) {
 // BM = 256 (4 x 2 waves of 64 x 64): twice the MFMAs per step and per staged weight byte.  Its window is TIGHT — exactly BM + 2W
 // rows (384 at W = 64, so that window + two weight stages are 80 KB and two blocks still share a CU): the two corner rows of the
 // loose window are only ever read by masked taps when tiles start on an image-row boundary (BM % W == 0), so their reads clamp.
-template <int BN, int NPL, int BST, int MAXWIN, int WAVES_N = 4, bool GNA = false, int BM = 128, bool TIGHT = (BM == 256), int BLOCKS = 2>
+template <int BN, int NPL, int BST, int MAXWIN, int WAVES_N = 4, bool GNA = false, int BM = 128, bool TIGHT = (BM == 256), int BLOCKS = 2, bool BF = false>
 __global__ __launch_bounds__(BM / 64 * WAVES_N * 64, BM / 64 * WAVES_N * BLOCKS / 4) void pswin_kernel(const GemmParams p) {     // BLOCKS blocks per CU
     constexpr int WAVES_M = BM / 64, NW = WAVES_M * WAVES_N, THREADS = 64 * NW;
     static_assert(!GNA || (BST == 2 && BM == 128), "the fused-GroupNorm window is built for the 2-stage weight ring and 128-row tiles");
@@ -1057,7 +1059,8 @@ __global__ __launch_bounds__(BM / 64 * WAVES_N * 64, BM / 64 * WAVES_N * BLOCKS 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     auto mma = [&](const u16x8& x, const u16x8& y, const f32x16& c) -> f32x16 {
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, x), __builtin_bit_cast(half8, y), c, 0, 0, 0);
+        if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, x), __builtin_bit_cast(bf8, y), c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, x), __builtin_bit_cast(half8, y), c, 0, 0, 0);
     };
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -1230,19 +1233,19 @@ __global__ __launch_bounds__(BM / 64 * WAVES_N * 64, BM / 64 * WAVES_N * BLOCKS 
         }
 }
 
-template <int BN, int NPL, int BST, int MAXWIN, int WAVES_N = 4, bool GNA = false, int BM = 128, bool TIGHT = (BM == 256), int BLOCKS = 2>
+template <int BN, int NPL, int BST, int MAXWIN, int WAVES_N = 4, bool GNA = false, int BM = 128, bool TIGHT = (BM == 256), int BLOCKS = 2, bool BF = false>
 int launch_pswin(const GemmParams& p, hipStream_t st) {
     constexpr size_t smem = (size_t)NPL * MAXWIN * 64 + (size_t)BST * NPL * BN * 64 + (GNA ? 2048 : 0);
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N, GNA, BM, TIGHT, BLOCKS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N, GNA, BM, TIGHT, BLOCKS, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
         attr_done = true;
     }
     dim3 grid((unsigned)((long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.ksplit));
     static const size_t pad = getenv("CDAE_PS_PAD_LDS") ? (size_t)atoi(getenv("CDAE_PS_PAD_LDS")) : 0;       // dev: force fewer blocks per CU
-    if (pad) hipFuncSetAttribute(reinterpret_cast<const void*>(&pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N, GNA, BM, TIGHT, BLOCKS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem + pad));
-    hipLaunchKernelGGL((pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N, GNA, BM, TIGHT, BLOCKS>), grid, dim3(BM / 64 * WAVES_N * 64), smem + pad, st, p);
+    if (pad) hipFuncSetAttribute(reinterpret_cast<const void*>(&pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N, GNA, BM, TIGHT, BLOCKS, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem + pad));
+    hipLaunchKernelGGL((pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N, GNA, BM, TIGHT, BLOCKS, BF>), grid, dim3(BM / 64 * WAVES_N * 64), smem + pad, st, p);
     return hipGetLastError() == hipSuccess ? 0 : cdae_fail("pswin_kernel launch failed");
 }
 
@@ -1365,8 +1368,9 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
         if (!((p.amode == A_CONV_VEC || p.amode == A_PLAIN_KC) && p.bmode == B_PLAIN_KC) || p.batch != 1)
             return cdae_fail("pre-split operands: only K-contiguous conv / plain GEMMs without batch");
         const int kin = p.amode == A_CONV_VEC ? p.Cin : p.K;
-        if (kin % BK || p.K % BK || p.ldb % 8 || (p.amode == A_PLAIN_KC && p.lda % 8) || (p.prec != 1 && p.prec != 3))
-            return cdae_fail("pre-split operands: need K (Cin) % 32 == 0, 16-byte aligned rows and an f16 precision mode");
+        if (kin % BK || p.K % BK || p.ldb % 8 || (p.amode == A_PLAIN_KC && p.lda % 8) || (p.prec != 1 && p.prec != 2 && p.prec != 3))
+            return cdae_fail("pre-split operands: need K (Cin) % 32 == 0, 16-byte aligned rows and a 16-bit split precision mode");
+        if (p.prec == 2 && (p.gn_coef || p.ps_taps == 4)) return cdae_fail("pre-split bf16 planes: plain conv3x3 / GEMM only");
     }
     if (p.amode == A_PLAIN_MC && p.M % 4) p.a_scalar = 1;          // vector k-major loaders read 4 rows / columns at once
     if (p.bmode != B_PLAIN_KC && p.N % 4) p.b_scalar = 1;
@@ -1422,11 +1426,13 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
             const bool deep = p.W <= 32 && cfg_win == 3;           // CDAE_PS_WIN=3: 3-stage weight ring where it fits (measured: no gain over 2 stages)
             static const int cfg_bm = getenv("CDAE_PS_WIN_BM") ? atoi(getenv("CDAE_PS_WIN_BM")) : 256;
             // 256-row tiles: rows must divide the tile (tight window) and the larger grid must still fill two blocks per CU
-            const bool tall = cfg_bm == 256 && p.prec == 1 && 256 % p.W == 0 && (long)((p.M + 255) / 256) * ((p.N + 127) / 128) * ks >= 512;
+            const bool tall2 = cfg_bm == 256 && 256 % p.W == 0 && (long)((p.M + 255) / 256) * ((p.N + 127) / 128) * ks >= 512;
+            const bool tall = tall2 && p.prec == 1;
             // rows of 16 or 8 pixels: the tight window is 160 rows, 52.5 KB with the two weight stages: THREE blocks (24 waves) per CU
             static const int cfg_b3 = getenv("CDAE_PS_WIN_B3") ? atoi(getenv("CDAE_PS_WIN_B3")) : 0;     // measured: +2 % at 16x16, -8 % at 8x8 -> off
             const bool small_rows = cfg_b3 && p.prec == 1 && p.W <= 16 && 128 % p.W == 0 && cfg_win == 1;
-            if (tall) rc = launch_pswin<128, 2, 2, 384, 2, false, 256>(p, st);
+            if (p.prec == 2) rc = tall2 ? launch_pswin<128, 2, 2, 384, 2, false, 256, true, 2, true>(p, st) : launch_pswin<128, 2, 2, 272, 4, false, 128, false, 2, true>(p, st);
+            else if (tall) rc = launch_pswin<128, 2, 2, 384, 2, false, 256>(p, st);
             else if (small_rows) rc = launch_pswin<128, 2, 2, 160, 4, false, 128, true, 3>(p, st);
             else
             if (p.prec == 1 && cfg_win == 4) rc = launch_pswin<128, 2, 2, 272, 2>(p, st);       // CDAE_PS_WIN=4: 4 waves of 64x64 per block
@@ -1435,6 +1441,7 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
         }
         static const int cfg_loaders = getenv("CDAE_PS_LOADERS") ? atoi(getenv("CDAE_PS_LOADERS")) : 0;
         if (win_ok) {}
+        else if (p.prec == 2) rc = big ? launch_ps<128, 128, 2, 4, 2, 2, 0, true>(p, st) : launch_ps<64, 64, 2, 2, 2, 2, 0, true>(p, st);
         else
         if (p.prec == 1 && big && !huge && cfg_loaders == 4) rc = launch_ps<128, 128, 2, 4, 2, 2, 4>(p, st);
         else if (p.prec == 1 && big && !huge && cfg_loaders == 2) rc = launch_ps<128, 128, 2, 4, 2, 2, 2>(p, st);

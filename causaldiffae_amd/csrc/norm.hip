@@ -141,6 +141,7 @@ __global__ void gn_parts_group_kernel(const double* __restrict__ chan, int C, in
 // SPLIT: the result is written as two f16 planes (hi = f16(v), lo = f16(v - hi), pitch ldy elements each) — the operand format
 // of the pre-split conv / GEMM kernel (igemm.hip ps_kernel), so the consumer's main loop has no conversion work.
 typedef _Float16 gn_half4 __attribute__((ext_vector_type(4)));
+typedef __bf16 gn_bf4 __attribute__((ext_vector_type(4)));
 template <int VEC, bool SPLIT = false>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, float* __restrict__ y, int HW, int C, int ldx, int ldy,
                                                         int cpg, int G, int pix_per_block,
@@ -148,7 +149,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ ss, int ld_ss, int do_silu,
                                                         unsigned short* __restrict__ y_hi = nullptr, unsigned short* __restrict__ y_lo = nullptr,
-                                                        const float* __restrict__ x2 = nullptr, int ld2 = 0, int C1 = 0) {
+                                                        const float* __restrict__ x2 = nullptr, int ld2 = 0, int C1 = 0,
+                                                        unsigned short* __restrict__ yb_hi = nullptr, unsigned short* __restrict__ yb_lo = nullptr) {
     const int n = blockIdx.y, E = C / VEC, rows = 256 / E, tid = threadIdx.x;
     const int r = tid / E, e = tid - r * E;
     if (r >= rows) return;
@@ -184,6 +186,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                 lo[2] = (_Float16)(r2 - (float)hi[2]); lo[3] = (_Float16)(r3 - (float)hi[3]);
                 *reinterpret_cast<gn_half4*>(y_hi + hbase + (long)pp * ldy) = hi;
                 *reinterpret_cast<gn_half4*>(y_lo + hbase + (long)pp * ldy) = lo;
+                if (yb_hi) {       // training: the same values also as bf16 hi/lo planes, the wgrad kernel's operand format (wgrad.hip)
+                    gn_bf4 bh, bl;
+                    bh[0] = (__bf16)r0; bh[1] = (__bf16)r1; bh[2] = (__bf16)r2; bh[3] = (__bf16)r3;
+                    bl[0] = (__bf16)(r0 - (float)bh[0]); bl[1] = (__bf16)(r1 - (float)bh[1]);
+                    bl[2] = (__bf16)(r2 - (float)bh[2]); bl[3] = (__bf16)(r3 - (float)bh[3]);
+                    *reinterpret_cast<gn_bf4*>(yb_hi + hbase + (long)pp * ldy) = bh;
+                    *reinterpret_cast<gn_bf4*>(yb_lo + hbase + (long)pp * ldy) = bl;
+                }
             } else *reinterpret_cast<float4*>(yp + (long)pp * ldy) = make_float4(r0, r1, r2, r3);
         };
         for (; p + 3 * rows < p1; p += 4 * rows) {
@@ -709,9 +719,26 @@ int cdae_gn_stats2(const float* x1, int ld1, const float* x2, int ld2, int C1, i
     return 0;
 }
 
+static int gn_apply_split_impl(const float* x, int ldx, const float* x2, int ld2, int C1, unsigned short* y_hi, unsigned short* y_lo,
+                               unsigned short* yb_hi, unsigned short* yb_lo, int N, int HW, int C, int ldy, int groups, const float* mean,
+                               const float* rstd, const float* gamma, const float* beta, const float* scale_shift, int ld_ss, int silu, void* stream);
+
 int cdae_gn_apply_split2(const float* x, int ldx, const float* x2, int ld2, int C1, unsigned short* y_hi, unsigned short* y_lo, int N, int HW,
                          int C, int ldy, int groups, const float* mean, const float* rstd, const float* gamma, const float* beta,
                          const float* scale_shift, int ld_ss, int silu, void* stream) {
+    return gn_apply_split_impl(x, ldx, x2, ld2, C1, y_hi, y_lo, nullptr, nullptr, N, HW, C, ldy, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, stream);
+}
+
+int cdae_gn_apply_split_train(const float* x, unsigned short* y_hi, unsigned short* y_lo, unsigned short* yb_hi, unsigned short* yb_lo, int N,
+                              int HW, int C, int ldx, int ldy, int groups, const float* mean, const float* rstd, const float* gamma,
+                              const float* beta, const float* scale_shift, int ld_ss, int silu, void* stream) {
+    if (!yb_hi || !yb_lo) return cdae_fail("gn_apply_split_train: both bf16 planes required");
+    return gn_apply_split_impl(x, ldx, nullptr, 0, C, y_hi, y_lo, yb_hi, yb_lo, N, HW, C, ldy, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, stream);
+}
+
+static int gn_apply_split_impl(const float* x, int ldx, const float* x2, int ld2, int C1, unsigned short* y_hi, unsigned short* y_lo,
+                               unsigned short* yb_hi, unsigned short* yb_lo, int N, int HW, int C, int ldy, int groups, const float* mean,
+                               const float* rstd, const float* gamma, const float* beta, const float* scale_shift, int ld_ss, int silu, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int cpg = C / groups;
     if (x2 && (ld2 % 4 || C1 % 4)) return cdae_fail("gn_apply_split2: second source needs 4-channel alignment");
@@ -723,7 +750,7 @@ int cdae_gn_apply_split2(const float* x, int ldx, const float* x2, int ld2, int 
     const int ppb = (HW + nchunk - 1) / nchunk;
     cdae_prof_begin(PROF_GN, (double)N * HW * C * 8.0, st);
     hipLaunchKernelGGL((gn_apply_kernel<4, true>), dim3(nchunk, N), dim3(256), 0, st, x, (float*)nullptr, HW, C, ldx, ldy, cpg, groups, ppb, mean, rstd,
-                       gamma, beta, scale_shift, ld_ss, silu, y_hi, y_lo, x2, ld2, C1);
+                       gamma, beta, scale_shift, ld_ss, silu, y_hi, y_lo, x2, ld2, C1, yb_hi, yb_lo);
     cdae_prof_end(PROF_GN, st);
     CHECK_LAUNCH("gn_apply_split launch failed");
     return 0;

@@ -1,0 +1,291 @@
+// wgrad.hip — weight gradient of a stride-1 conv3x3 with the activation WINDOW resident in LDS (gfx950 only).
+//
+//   dW[co][ky][kx][ci] = sum over pixels (n, y, x) of dy[n, y, x, co] * a[n, y + ky - 1, x + kx - 1, ci]      (zero padding)
+//
+// the backward the reference gets from autograd through F.conv2d (nn.py:470-480; ResBlock convs unet.py:187-197).  As a GEMM the
+// reduction runs over PIXELS, so both operands are "k-major" in memory ([pixel][channel] rows): they go global -> LDS by LDS-DMA
+// exactly as they lie, and the MFMA fragments come out of LDS through the hardware transpose read (ds_read_b64_tr_b16).  Both
+// operands are bf16 hi/lo planes (x = hi + lo, 16 significand bits, full fp32 range — gradients underflow f16): dy from
+// cdae_split_bf16, a from the GroupNorm that produced the conv input (cdae_gn_apply_split_train).  Each product is
+// hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+//
+// Tiling: a block owns 64 output x 64 input channels, ALL 9 taps, and a contiguous range of 64-pixel K steps; 4 waves of
+// 32 x 32 x 9 taps (144 accumulator registers).  The 9 taps of a step read the same activation pixels shifted by
+// (ky-1)*W + (kx-1), so the activations live in a RING of pixel rows in LDS: every pixel row is fetched once per block (not 9
+// times) and a step only loads the 64 new rows.  The images of the batch are laid out in a virtual pixel stream with G >= W+1
+// zero rows between them (served from a zero line), which makes the vertical padding and the image boundaries ordinary rows;
+// the horizontal padding (x-1 at x == 0, x+1 at x == W-1) is a mask on the dy fragments (element 0 / element 7 of a lane's 8
+// pixels, because steps start on multiples of 64 and W divides 64).
+// Ring rows come in 16-row DMA blocks; a tap's 16 rows may start anywhere, so slot 0 is mirrored behind the last slot and reads
+// never wrap inside a fragment.  Split-K over the pixel range: each block writes its partial [Cout][9*Cin] slab, reduced in a
+// fixed order by wg_reduce_kernel (deterministic), or stores directly when one block covers all pixels.
+// The bias gradient (column sums of dy) rides along as two extra MFMAs per 16-pixel step against a ones operand in the blocks of
+// the first input-channel tile.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "cdae_internal.h"
+#include "../../include/cdae.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct WgParams {
+    const unsigned short* a_hi; const unsigned short* a_lo;     // [N*HW][Cin] bf16 planes
+    const unsigned short* d_hi; const unsigned short* d_lo;     // [N*HW][Cout] bf16 planes
+    float* out;              // ksplit == 1: dW (OHWI [Cout][9*Cin]); else slabs [ksplit][Cout][9*Cin]
+    float* colsum;           // += column sums of dy, or nullptr
+    int N, HW, W, Cin, Cout;
+    int steps, steps_per, ksplit, accumulate;
+    int period, period_shift; unsigned period_magic;            // HW + G rows per image in the virtual stream
+    int U0, RB;              // rows before image 0 (16 * halo blocks); ring size in 16-row blocks
+};
+
+__device__ __attribute__((aligned(16))) unsigned g_zero_wg[4] = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ int fdiv(int n, unsigned magic, int shift) {
+    return (int)((__umulhi((unsigned)n, magic) + (unsigned)n) >> shift);
+}
+
+// LDS image: activations [plane 2][channel half 2][(RB + 1) * 16 rows][64 B], dy [stage 2][plane 2][channel half 2][64 rows][64 B]
+__global__ __launch_bounds__(256, 1) void wgwin_kernel(const WgParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const lds = reinterpret_cast<char*>(smem);
+    const int RROWS = (p.RB + 1) * 16;                 // ring rows incl. the mirror of slot 0
+    const int A_SUB = RROWS * 64;                      // bytes per (plane, half) sub-plane
+    char* const dyb = lds + 4 * A_SUB;                 // dy stages
+    constexpr int D_SUB = 64 * 64, D_STAGE = 4 * D_SUB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hh = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;           // wave tile: output channels 32 wm.., input channels 32 wn..
+    const int nci = p.Cin >> 6, nco = p.Cout >> 6;
+    int b = blockIdx.x;
+    const int cit = b % nci; b /= nci;
+    const int cot = b % nco; b /= nco;
+    const int ks = b;
+    const int ci0 = cit * 64, co0 = cot * 64;
+    const int s_begin = ks * p.steps_per, s_end = min(p.steps, s_begin + p.steps_per);
+
+    // ---- DMA roles: wave w stages sub-plane (P = w >> 1, half = w & 1) of both operands
+    const int dP = wave >> 1, dH = wave & 1;
+    const unsigned short* const a_src = (dP ? p.a_lo : p.a_hi) + ci0 + dH * 32 + (lane & 3) * 8;
+    const unsigned short* const d_src = (dP ? p.d_lo : p.d_hi) + co0 + dH * 32 + (lane & 3) * 8;
+    char* const a_dst = lds + (dP * 2 + dH) * A_SUB;
+    auto dma = [&](const void* src, char* dst_wave_base) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst_wave_base, 16, 0, 0);
+    };
+    // one 16-row block of the virtual stream (rows u = 16 blk .. +15) into ring slot `slot`
+    auto issue_a = [&](int blk, int slot) {
+        const int v = blk * 16 + (lane >> 2) - p.U0;
+        const int vv = v < 0 ? 0 : v;
+        const int img = fdiv(vv, p.period_magic, p.period_shift);
+        const int q = vv - img * p.period;
+        const bool ok = v >= 0 && q < p.HW && img < p.N;
+        const void* src = ok ? (const void*)(a_src + ((long)img * p.HW + q) * p.Cin) : (const void*)g_zero_wg;
+        dma(src, a_dst + slot * 1024);
+        if (slot == 0) dma(src, a_dst + p.RB * 1024);
+    };
+    auto issue_d = [&](int pix0, int stage) {
+        char* const dst = dyb + stage * D_STAGE + (dP * 2 + dH) * D_SUB;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+            dma(d_src + (long)(pix0 + blk * 16 + (lane >> 2)) * p.Cout, dst + blk * 1024);
+    };
+
+    // ---- fragment addressing (ds_read_b64_tr_b16: lane 4q+p of a 16-lane group addresses row k+q, 4 columns at 4p, and receives
+    //      column (lane & 15) of those 4 rows; two reads 4 rows apart give the lane its 8 consecutive k)
+    const int q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const int lane_off = (8 * hh + q4) * 64 + 32 * ((lane >> 4) & 1) + 8 * p4;
+    auto trread = [&](const char* src) -> u32x2 {
+        const fp16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(src));
+        return __builtin_bit_cast(u32x2, v);
+    };
+    auto frag = [&](const char* src) -> u32x4 {        // rows k .. k+3 and k+4 .. k+7
+        const u32x2 a = trread(src), c = trread(src + 256);
+        u32x4 r; r[0] = a[0]; r[1] = a[1]; r[2] = c[0]; r[3] = c[1];
+        return r;
+    };
+    auto mma = [&](const u32x4& x, const u32x4& y, const f32x16& c) -> f32x16 {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, x), __builtin_bit_cast(bf8, y), c, 0, 0, 0);
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    f32x16 accb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+    const bool do_colsum = p.colsum != nullptr && cit == 0 && wn == 0;
+    u32x4 ones; ones[0] = ones[1] = ones[2] = ones[3] = 0x3F803F80u;       // bf16 1.0 pairs
+
+    // horizontal padding masks of this lane's 8 pixels in 16-pixel step sk: x0 = (16 sk + 8 hh) mod W
+    unsigned mL[4], mR[4];
+#pragma unroll
+    for (int sk = 0; sk < 4; ++sk) {
+        const int x0 = (16 * sk + 8 * hh) & (p.W - 1);
+        mL[sk] = x0 == 0 ? 0xFFFF0000u : 0xFFFFFFFFu;          // tap kx = 0 reads x - 1: the pixel at x == 0 (element 0) contributes nothing
+        mR[sk] = x0 == p.W - 8 ? 0x0000FFFFu : 0xFFFFFFFFu;    // tap kx = 2 reads x + 1: the pixel at x == W - 1 (element 7)
+    }
+
+    if (s_begin < s_end) {
+        const int hb = p.U0 >> 4;                      // halo blocks each side of a step's 4 blocks
+        // position of step s in the virtual stream
+        int img = (s_begin * 64) / p.HW, q = s_begin * 64 - img * p.HW;
+        int B0 = (img * p.period + q + p.U0) >> 4;     // first block of the step's own 64 rows
+        int slot0 = 0;                                 // ring slot of block B0 - hb (the window's first block)
+        int next_blk = B0 - hb, next_slot = 0;         // next block to load and its slot
+        auto load_upto = [&](int blk_end) {            // uniform loop
+            for (; next_blk < blk_end; ++next_blk) {
+                issue_a(next_blk, next_slot);
+                next_slot = next_slot + 1 == p.RB ? 0 : next_slot + 1;
+            }
+        };
+        load_upto(B0 + 4 + hb);
+        issue_d(s_begin * 64, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        for (int s = s_begin; s < s_end; ++s) {
+            const int st = (s - s_begin) & 1;
+            // ---- prefetch step s + 1
+            int img_n = img, q_n = q + 64;
+            if (q_n == p.HW) { q_n = 0; ++img_n; }
+            const int B0n = (img_n * p.period + q_n + p.U0) >> 4;
+            if (s + 1 < s_end) {
+                load_upto(B0n + 4 + hb);
+                issue_d((s + 1) * 64, st ^ 1);
+            }
+            // ---- compute step s: window rows start at ring row slot0 * 16 (block B0 - hb); the step's own rows at + 16 hb
+            const char* const dy_hi = dyb + st * D_STAGE + wm * D_SUB + lane_off;
+            const char* const dy_lo = dy_hi + 2 * D_SUB;
+            const char* const a_hi = lds + wn * A_SUB + lane_off;
+            const int row_own = slot0 * 16 + p.U0;     // ring row (before wrap) of the step's first own pixel
+            const int ring = p.RB * 16;
+#pragma unroll
+            for (int sk = 0; sk < 4; ++sk) {
+                u32x4 dh[3], dl[3];
+                dh[1] = frag(dy_hi + sk * 1024);
+                dl[1] = frag(dy_lo + sk * 1024);
+                dh[0] = dh[1]; dh[0][0] &= mL[sk]; dl[0] = dl[1]; dl[0][0] &= mL[sk];
+                dh[2] = dh[1]; dh[2][3] &= mR[sk]; dl[2] = dl[1]; dl[2][3] &= mR[sk];
+                if (do_colsum) { accb = mma(dh[1], ones, accb); accb = mma(dl[1], ones, accb); }
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int ky = t / 3, kx = t - 3 * ky;
+                    int rt = row_own + (ky - 1) * p.W + (kx - 1) + 16 * sk;
+                    rt = rt < 0 ? rt + ring : rt;
+                    rt = rt >= ring ? rt - ring : rt;
+                    const char* src = a_hi + rt * 64;
+                    const u32x4 ah = frag(src), al = frag(src + 2 * A_SUB);
+                    acc[t] = mma(dl[kx], ah, acc[t]);
+                    acc[t] = mma(dh[kx], al, acc[t]);
+                    acc[t] = mma(dh[kx], ah, acc[t]);
+                }
+            }
+            // ---- advance
+            const int adv = B0n - B0;
+            slot0 += adv; slot0 = slot0 >= p.RB ? slot0 - p.RB : slot0;
+            B0 = B0n; img = img_n; q = q_n;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: D[row = co][col = ci] of tap t -> out[(co0 + 32 wm + row) * 9 Cin + t * Cin + ci0 + 32 wn + col]
+    const long ldo = 9L * p.Cin;
+    float* const ob = p.out + (p.ksplit > 1 ? (long)ks * p.Cout * ldo : 0L) + (long)(co0 + wm * 32) * ldo + ci0 + wn * 32 + l31;
+    const bool accum = p.ksplit == 1 && p.accumulate;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            float* o = ob + (long)row * ldo + t * p.Cin;
+            *o = accum ? *o + acc[t][r] : acc[t][r];
+        }
+    if (do_colsum && l31 == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) atomicAdd(p.colsum + co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh, accb[r]);
+    }
+}
+
+// dW (+)= sum over the K-split slabs, in slab order
+__global__ void wg_reduce_kernel(const float4* __restrict__ ws, float4* __restrict__ out, long n4, int ksplit, int accumulate) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 s = ws[i];
+        for (int k = 1; k < ksplit; ++k) {
+            const float4 v = ws[(long)k * n4 + i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        if (accumulate) { const float4 o = out[i]; s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
+        out[i] = s;
+    }
+}
+
+}  // namespace
+
+extern "C" int cdae_conv3x3_wgrad_win_supported(int N, int H, int W, int Cin, int Cout) {
+    return N > 0 && W >= 8 && W <= 64 && (W & (W - 1)) == 0 && (H * W) % 64 == 0 && Cin % 64 == 0 && Cout % 64 == 0 &&
+           (long)N * H * W * (Cin > Cout ? Cin : Cout) < (1L << 31);
+}
+
+extern "C" int cdae_conv3x3_wgrad_win(const unsigned short* a_hi, const unsigned short* a_lo, const unsigned short* dy_hi, const unsigned short* dy_lo,
+                                      float* dw, float* dbias, int N, int H, int W, int Cin, int Cout, int accumulate, float* splitk_ws,
+                                      size_t splitk_ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!cdae_conv3x3_wgrad_win_supported(N, H, W, Cin, Cout))
+        return cdae_fail("conv3x3_wgrad_win: needs W a power of two in [8, 64], H*W % 64 == 0, Cin % 64 == 0, Cout % 64 == 0");
+    if ((((size_t)a_hi | (size_t)a_lo | (size_t)dy_hi | (size_t)dy_lo | (size_t)dw) & 15)) return cdae_fail("conv3x3_wgrad_win: 16-byte aligned operands required");
+    WgParams p;
+    p.a_hi = a_hi; p.a_lo = a_lo; p.d_hi = dy_hi; p.d_lo = dy_lo;
+    p.N = N; p.HW = H * W; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    p.steps = N * p.HW / 64;
+    const int hb = W / 16 + 1;                         // 16 hb >= W + 1
+    const int G = 16 * hb;                             // zero rows between images
+    p.U0 = 16 * hb; p.period = p.HW + G;
+    p.RB = 8 + G / 16 + 2 * hb + 1;                    // live window (4 + 2 hb) + the largest prefetch (4 + G/16) + 1 spare
+    {
+        int sh = 0;
+        while ((1u << sh) < (unsigned)p.period) ++sh;
+        p.period_magic = (unsigned)(((unsigned long long)((1ull << sh) - (unsigned)p.period) << 32) / (unsigned)p.period) + 1u;
+        p.period_shift = sh;
+    }
+    const long tiles = (long)(Cin / 64) * (Cout / 64);
+    const size_t slab = (size_t)Cout * 9 * Cin * sizeof(float);
+    int ks = (int)((512 + tiles - 1) / tiles);
+    if (ks > p.steps) ks = p.steps;
+    while (ks > 1 && (!splitk_ws || (size_t)ks * slab > splitk_ws_bytes)) --ks;
+    p.steps_per = (p.steps + ks - 1) / ks;
+    ks = (p.steps + p.steps_per - 1) / p.steps_per;    // no empty blocks
+    p.ksplit = ks; p.accumulate = accumulate;
+    p.out = ks > 1 ? splitk_ws : dw;
+    p.colsum = dbias;
+    if (dbias && !accumulate && hipMemsetAsync(dbias, 0, sizeof(float) * Cout, st) != hipSuccess) return cdae_fail("dbias memset failed");
+    const size_t smem = (size_t)4 * (p.RB + 1) * 16 * 64 + 2 * 4 * 64 * 64;
+    static size_t attr_bytes = 0;
+    if (smem > attr_bytes) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgwin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
+        attr_bytes = smem;
+    }
+    cdae_prof_begin(PROF_IGEMM, 2.0 * Cout * 9.0 * Cin * (double)N * p.HW, st);
+    hipLaunchKernelGGL(wgwin_kernel, dim3((unsigned)(tiles * ks)), dim3(256), smem, st, p);
+    int rc = hipGetLastError() == hipSuccess ? 0 : cdae_fail("wgwin_kernel launch failed");
+    if (rc == 0 && ks > 1) {
+        const long n4 = (long)Cout * 9 * Cin / 4;
+        int blocks = (int)((n4 + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(wg_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)splitk_ws, (float4*)dw, n4, ks, accumulate);
+        if (hipGetLastError() != hipSuccess) rc = cdae_fail("wg_reduce launch failed");
+    }
+    cdae_prof_end(PROF_IGEMM, st);
+    return rc;
+}

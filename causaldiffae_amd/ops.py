@@ -878,6 +878,124 @@ def conv3x3_ps(xs, w, b=None, res=None, stride=1, up=False, out_nchw=False, emit
     return out
 
 
+# ----------------------------------------------------------------------------- training on the pre-split kernels
+_TRAIN_PS_ON = os.environ.get("CDAE_TRAIN_PRESPLIT", "1") != "0"      # dev switch: 0 = separate GroupNorm / conv3x3 Functions (in-kernel split)
+_WDGRAD = {}
+
+
+def train_presplit_ok(x, Cout, groups=32):
+    """GroupNorm -> (SiLU) -> conv3x3 as ONE autograd node on the pre-split kernels: grad mode, f16x3 precision, and a shape the
+    window wgrad kernel takes (channel counts % 64, rows of 8..64 pixels)."""
+    from ._lib import get_precision
+    N, C, H, W = x if isinstance(x, tuple) else x.shape
+    return (_TRAIN_PS_ON and torch.is_grad_enabled() and get_precision() == "f16x3" and C % groups == 0 and (C // groups) % 4 == 0
+            and lib.cdae_conv3x3_wgrad_win_supported(N, H, W, C, Cout) == 1)
+
+
+def dgrad_weight(w):
+    """bf16 hi/lo planes of the dgrad weight of an OHWI conv3x3 weight ([Cin][9][Cout], taps flipped); cached like split_weight."""
+    tag = (w.data_ptr(), w._version, _WEIGHT_EPOCH[0])
+    hit = _WDGRAD.get(id(w))
+    if hit is not None and hit[0]() is w and hit[1] == tag:
+        return hit[2], hit[3]
+    Cout, Cin = w.shape[0], w.shape[1]
+    planes = torch.empty((2, w.numel()), dtype=torch.bfloat16, device=w.device)
+    check(lib.cdae_wdgrad_planes(ptr(w), ptr(planes[0]), ptr(planes[1]), Cout, Cin, stream()))
+    if len(_WDGRAD) > 4096:
+        for k in [k for k, v in _WDGRAD.items() if v[0]() is None]:
+            del _WDGRAD[k]
+    _WDGRAD[id(w)] = (weakref.ref(w), tag, planes[0], planes[1])
+    return planes[0], planes[1]
+
+
+class _GNConvPS(Function):
+    """out = conv3x3(silu?(GroupNorm(x) * (1 + scale) + shift), w) + b (+ res), stride 1 — the ResBlock's in_layers / out_layers
+    (reference unet.py:187-197 with nn.py:435-437) as one node.  The normalised activation exists only as f16 hi/lo planes: the
+    window kernel consumes them in the forward, wgrad reads them back, and dgrad runs on the same kernel with bf16 planes of dy."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, ss, w, b, res, silu, groups, eps):
+        x = to_nhwc(x)
+        N, C, H, W = x.shape
+        Cout = w.shape[0]
+        w_in, w = w, ohwi(w)
+        dev = x.device
+        st = stream()
+        stats = torch.empty((2, N, groups), dtype=torch.float32, device=dev)
+        gws = workspace(dev, "gn", 4 * lib.cdae_gn_workspace_floats(N, C))
+        check(lib.cdae_gn_stats(ptr(x), N, H * W, C, C, groups, eps, ptr(stats[0]), ptr(stats[1]), ptr(gws), st))
+        if ss is not None:
+            assert ss.shape == (N, 2 * C) and ss.is_contiguous()
+        planes = torch.empty((2, N, H, W, C), dtype=torch.float16, device=dev)            # forward operand (dropped after the conv)
+        bplanes = torch.empty((2, N, H, W, C), dtype=torch.bfloat16, device=dev)          # kept for wgrad
+        check(lib.cdae_gn_apply_split_train(ptr(x), ptr(planes[0]), ptr(planes[1]), ptr(bplanes[0]), ptr(bplanes[1]), N, H * W, C, C, C, groups,
+                                            ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta), ptr(ss), 2 * C, 1 if silu else 0, st))
+        w_hi, w_lo = split_weight(w)
+        out = new_act(N, Cout, H, W, dev)
+        if res is not None:
+            res = to_nhwc(res)
+        ws, wsb = _sk(dev)
+        check(lib.cdae_conv3x3_fwd_ps(ptr(planes[0]), ptr(planes[1]), H * W * C, W * C, C, ptr(w_hi), ptr(w_lo), ptr(b), ptr(res), ptr(out), Cout,
+                                      0, None, None, None, N, H, W, C, Cout, 1, 0, ws, wsb, st))
+        ctx.save_for_backward(x, gamma, beta, ss, stats, bplanes, w)
+        ctx.cfg = (silu, groups, b is not None, res is not None)
+        ctx.sinks = (_sink(gamma), _sink(beta), _sink(w_in), _sink(b))
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, ss, stats, planes, w = ctx.saved_tensors
+        silu, groups, has_b, has_res = ctx.cfg
+        N, C, H, W = x.shape
+        Cout = w.shape[0]
+        dev = x.device
+        st = stream()
+        dy = to_nhwc(dy)
+        ws, wsb = _sk(dev)
+        (gg, rg), (gbt, rbt), (gw, rw), (gb, rb) = ctx.sinks
+        dx = dgamma = dbeta = dss = dw = db = dres = None
+        dplanes = torch.empty((2, N, H, W, Cout), dtype=torch.bfloat16, device=dev)          # dy once as bf16 planes: dgrad and wgrad
+        check(lib.cdae_split_bf16(ptr(dy), ptr(dplanes[0]), ptr(dplanes[1]), dy.numel(), st))
+        # --- wgrad: saved activation planes x gradient planes, window kernel
+        if ctx.needs_input_grad[4]:
+            direct = gw is not None and w.stride() == gw.stride() and (not has_b or gb is not None)
+            if direct:
+                dw, db = gw, gb
+            else:
+                dw = torch.empty_like(w)
+                db = torch.empty(Cout, dtype=torch.float32, device=dev) if has_b else None
+            check(lib.cdae_conv3x3_wgrad_win(ptr(planes[0]), ptr(planes[1]), ptr(dplanes[0]), ptr(dplanes[1]), ptr(dw), ptr(db), N, H, W, C, Cout,
+                                             1 if direct else 0, ws, wsb, st))
+            if direct:
+                dw = db = None
+                _done(rw, rb)
+        # --- dgrad on the window kernel, then through the GroupNorm
+        if any(ctx.needs_input_grad[:4]):
+            wt_hi, wt_lo = dgrad_weight(w)
+            dyn = new_act(N, C, H, W, dev)
+            check(lib.cdae_conv3x3_dgrad_ps(ptr(dplanes[0]), ptr(dplanes[1]), ptr(wt_hi), ptr(wt_lo), ptr(dyn), C, N, H, W, C, Cout, ws, wsb, st))
+            dx = new_act(N, C, H, W, dev)
+            direct = gg is not None and gbt is not None
+            dgamma = gg if direct else torch.empty_like(gamma)
+            dbeta = gbt if direct else torch.empty_like(beta)
+            dss = torch.empty_like(ss) if ss is not None else None
+            gws = workspace(dev, "gn", 4 * lib.cdae_gn_workspace_floats(N, C))
+            check(lib.cdae_gn_bwd(ptr(x), ptr(dyn), ptr(dx), N, H * W, C, C, C, C, groups, ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta),
+                                  ptr(ss), 2 * C, 1 if silu else 0, ptr(dgamma), ptr(dbeta), 1 if direct else 0, ptr(dss), 2 * C, 0, ptr(gws), st))
+            if direct:
+                dgamma = dbeta = None
+                _done(rg, rbt)
+        if has_res and ctx.needs_input_grad[6]:
+            dres = dy
+        return dx, dgamma, dbeta, dss, dw, db, dres, None, None, None
+
+
+def gn_conv3x3(x, gamma, beta, scale_shift, w, b=None, res=None, silu=True, groups=32, eps=1e-5):
+    if scale_shift is not None and not scale_shift.is_contiguous():
+        scale_shift = scale_shift.contiguous()
+    return _GNConvPS.apply(x, gamma, beta, scale_shift, w, b, res, silu, groups, eps)
+
+
 def linear_emit(rows, w, b, res, shape):
     """y = rows @ w^T + b + res (no autograd) whose result also leaves the kernel as f16 planes: returns (y, SplitAct) for the
     logical [N, C, H, W] `shape` the rows belong to."""

@@ -130,9 +130,28 @@ class ResBlock(TimestepBlock):
     def forward(self, x, emb):
         return checkpoint(self._forward, (x, emb), self.parameters(), self.use_checkpoint)
 
+    def _train_fused(self, x):
+        """Grad-mode fast path: both GroupNorm -> SiLU -> conv3x3 chains as fused nodes on the pre-split kernels."""
+        n1, c1, n2, c2 = self.in_layers[0], self.in_layers[2], self.out_layers[0], self.out_layers[3]
+        return ((self.dropout == 0 or not self.training) and not isinstance(x, ops.CatAct) and x.dim() == 4
+                and ops.train_presplit_ok(x, c1.out_channels, n1.num_groups)
+                and ops.train_presplit_ok((x.shape[0], c1.out_channels, x.shape[2], x.shape[3]), c2.out_channels, n2.num_groups))
+
+    def _forward_train(self, x, emb):
+        n1, c1, n2, c2 = self.in_layers[0], self.in_layers[2], self.out_layers[0], self.out_layers[3]
+        x = ops.to_nhwc(x)
+        h = ops.gn_conv3x3(x, n1.weight, n1.bias, None, c1.weight, c1.bias, None, True, n1.num_groups, n1.eps)
+        emb_out = emb.slices[id(self)] if isinstance(emb, EmbAll) else self.emb_layers[1](ops.silu(emb))
+        skip = x if isinstance(self.skip_connection, Identity) else self.skip_connection(x)
+        if self.use_scale_shift_norm:
+            return ops.gn_conv3x3(h, n2.weight, n2.bias, emb_out, c2.weight, c2.bias, skip, True, n2.num_groups, n2.eps)
+        return ops.gn_conv3x3(h + emb_out[:, :, None, None], n2.weight, n2.bias, None, c2.weight, c2.bias, skip, True, n2.num_groups, n2.eps)
+
     def _forward(self, x, emb):
         if not isinstance(x, ops.CatAct):                          # CatAct: the skip concatenation, read in place by GN and the 1x1 skip
             x = ops.to_nhwc(x)
+        if self._train_fused(x):
+            return self._forward_train(x, emb)
         h = self.in_layers[0](x, silu=True, split=True)            # GN + SiLU (pre-split f16 planes on the inference path)
         fast = isinstance(h, (ops.SplitAct, ops.LazyGN))
         h = self.in_layers[2](h, gn_stats=True) if fast else self.in_layers[2](h)     # conv3x3 + bias (+ GroupNorm partial sums)

@@ -129,6 +129,29 @@ int cdae_gn_apply_split(const float* x, unsigned short* y_hi, unsigned short* y_
                         int silu, void* stream);
 int cdae_conv3x3_dgrad(const float* dy, long lddy, const float* w, float* dx, long lddx, int N, int H, int W, int Cin, int Cout,
                        int stride, int up, int accumulate, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
+/* Training on the pre-split kernels (stride-1 3x3 convs; same reference lines as cdae_conv3x3_fwd — the backward the reference
+   gets from autograd through F.conv2d, nn.py:470-480 / unet.py:187-197).  The GroupNorm in front of the conv writes its result
+   as f16 planes (forward operand, 2^-22) AND as bf16 planes (kept for the backward); the gradient is split into bf16 planes
+   (full fp32 range, 2^-16) once and feeds both dgrad and wgrad.
+   cdae_gn_apply_split_train: cdae_gn_apply_split plus the bf16 plane pair yb_hi / yb_lo (same pitch ldy).
+   cdae_split_bf16: hi = bf16(x), lo = bf16(x - hi).
+   cdae_wdgrad_planes: w OHWI [Cout][9][Cin] -> bf16 planes of the dgrad weight [Cin][9][Cout], taps flipped.
+   cdae_conv3x3_dgrad_ps: dx[N,H,W,Cin] (row pitch lddx) = conv3x3(dy planes [N,H,W,Cout], wt planes) on the window kernel.
+   cdae_conv3x3_wgrad_win: dw (OHWI) (+)= dy^T * im2col(a), a / dy as dense NHWC bf16 planes; dbias (+)= column sums of dy (may be
+   NULL).  The activation window stays in an LDS ring (each pixel row fetched once per block, not once per tap), fragments by
+   transpose reads, split-K over pixel ranges with a fixed-order reduction (wgrad.hip).  _supported: W a power of two in [8, 64],
+   H*W % 64 == 0, Cin % 64 == 0, Cout % 64 == 0. */
+int cdae_gn_apply_split_train(const float* x, unsigned short* y_hi, unsigned short* y_lo, unsigned short* yb_hi, unsigned short* yb_lo, int N,
+                              int HW, int C, int ldx, int ldy, int groups, const float* mean, const float* rstd, const float* gamma,
+                              const float* beta, const float* scale_shift, int ld_ss, int silu, void* stream);
+int cdae_split_bf16(const float* src, unsigned short* hi, unsigned short* lo, long n, void* stream);
+int cdae_wdgrad_planes(const float* w, unsigned short* hi, unsigned short* lo, int Cout, int Cin, void* stream);
+int cdae_conv3x3_dgrad_ps(const unsigned short* dy_hi, const unsigned short* dy_lo, const unsigned short* wt_hi, const unsigned short* wt_lo,
+                          float* dx, long lddx, int N, int H, int W, int Cin, int Cout, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
+int cdae_conv3x3_wgrad_win_supported(int N, int H, int W, int Cin, int Cout);
+int cdae_conv3x3_wgrad_win(const unsigned short* a_hi, const unsigned short* a_lo, const unsigned short* dy_hi, const unsigned short* dy_lo,
+                           float* dw, float* dbias, int N, int H, int W, int Cin, int Cout, int accumulate, float* splitk_ws,
+                           size_t splitk_ws_bytes, void* stream);
 /* wgrad: dw (OHWI) (+)= dy^T * im2col(x);  dbias (+)= column sums of dy (may be NULL). */
 int cdae_conv3x3_wgrad(const float* x, long sn, long sy, long sx, long sc, const float* dy, long lddy, float* dw, float* dbias,
                        int N, int H, int W, int Cin, int Cout, int stride, int up, int accumulate,
