@@ -53,6 +53,32 @@ __global__ void split_bf16_kernel(const float4* __restrict__ src, ew_bf4* __rest
     }
 }
 
+// nearest-2x upsample of an NHWC activation written straight as operand planes of the training convs: f16 hi/lo (forward conv) and
+// bf16 hi/lo (kept for wgrad), [N][2H][2W][C] dense.  One thread = 4 channels of one input pixel = 4 output pixels.
+__global__ void upsample2_split_kernel(const float4* __restrict__ x, ew_half4* __restrict__ fh, ew_half4* __restrict__ fl, ew_bf4* __restrict__ bh,
+                                       ew_bf4* __restrict__ bl, int H, int W, int C4, long total) {
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C4);
+        long pix = i / C4;
+        const int xx = (int)(pix % W); pix /= W;
+        const int yy = (int)(pix % H);
+        const long n = pix / H;
+        const float4 v = x[i];
+        ew_half4 h, l; ew_bf4 b, m;
+        h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+        l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]);
+        l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);
+        b[0] = (__bf16)v.x; b[1] = (__bf16)v.y; b[2] = (__bf16)v.z; b[3] = (__bf16)v.w;
+        m[0] = (__bf16)(v.x - (float)b[0]); m[1] = (__bf16)(v.y - (float)b[1]);
+        m[2] = (__bf16)(v.z - (float)b[2]); m[3] = (__bf16)(v.w - (float)b[3]);
+        const long o = ((n * 2 * H + 2 * yy) * 2 * W + 2 * xx) * C4 + c, row = 2L * W * C4;
+        fh[o] = h; fh[o + C4] = h; fh[o + row] = h; fh[o + row + C4] = h;
+        fl[o] = l; fl[o + C4] = l; fl[o + row] = l; fl[o + row + C4] = l;
+        bh[o] = b; bh[o + C4] = b; bh[o + row] = b; bh[o + row + C4] = b;
+        bl[o] = m; bl[o + C4] = m; bl[o + row] = m; bl[o + row + C4] = m;
+    }
+}
+
 // conv3x3 weight (OHWI [Cout][9][Cin]) -> the weight of the dgrad convolution, [Cin][9][Cout] with the taps flipped, as bf16 hi/lo
 // planes: dx = conv3x3(dy, this).  One 32x32 (co, ci) tile of one tap per block, transposed through LDS.
 __global__ __launch_bounds__(256) void wdgrad_planes_kernel(const float* __restrict__ w, __bf16* __restrict__ hi, __bf16* __restrict__ lo, int Cout, int Cin) {
@@ -449,6 +475,13 @@ int cdae_split_f16(const float* src, unsigned short* hi, unsigned short* lo, lon
 int cdae_split_bf16(const float* src, unsigned short* hi, unsigned short* lo, long n, void* stream) {
     if (n % 4 || (((size_t)src & 15) | (((size_t)hi | (size_t)lo) & 7))) return cdae_fail("split_bf16: n % 4 == 0, 16-byte aligned source and 8-byte aligned planes required");
     LAUNCH1D(split_bf16_kernel, n / 4, (const float4*)src, (ew_bf4*)hi, (ew_bf4*)lo, n / 4);
+}
+int cdae_upsample2_split(const float* x, unsigned short* f_hi, unsigned short* f_lo, unsigned short* b_hi, unsigned short* b_lo, int N, int H,
+                         int W, int C, void* stream) {
+    if (C % 4 || (((size_t)x) & 15) || (((size_t)f_hi | (size_t)f_lo | (size_t)b_hi | (size_t)b_lo) & 7))
+        return cdae_fail("upsample2_split: C % 4 == 0, 16-byte aligned input and 8-byte aligned planes required");
+    const long total = (long)N * H * W * (C / 4);
+    LAUNCH1D(upsample2_split_kernel, total, (const float4*)x, (ew_half4*)f_hi, (ew_half4*)f_lo, (ew_bf4*)b_hi, (ew_bf4*)b_lo, H, W, C / 4, total);
 }
 int cdae_wdgrad_planes(const float* w, unsigned short* hi, unsigned short* lo, int Cout, int Cin, void* stream) {
     if (Cout <= 0 || Cin <= 0) return cdae_fail("wdgrad_planes: empty weight");

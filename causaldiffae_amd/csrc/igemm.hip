@@ -1384,7 +1384,8 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
     const int nk = (p.K + BK - 1) / BK;
     int ks = 1;
     static const int cfg_mintiles = getenv("CDAE_KS_MINTILES") ? atoi(getenv("CDAE_KS_MINTILES")) : 256;
-    if (p.ksplit_auto && p.splitk_ws && tiles < cfg_mintiles && nk >= 8) {
+    static const int cfg_minnk = getenv("CDAE_KS_MINNK") ? atoi(getenv("CDAE_KS_MINNK")) : 8;
+    if (p.ksplit_auto && p.splitk_ws && tiles < cfg_mintiles && nk >= cfg_minnk) {
         ks = (int)((512 + tiles - 1) / tiles);
         if (ks > nk / 4) ks = nk / 4;
         if (ks > 64) ks = 64;

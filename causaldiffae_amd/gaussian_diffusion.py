@@ -65,6 +65,9 @@ _TAB_ORDER = ("sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "sqrt_reci
 assert len(_TAB_ORDER) == TAB_ROWS
 
 
+_PRIOR_SCALE = {}
+
+
 class GaussianDiffusion:
     """Training and sampling utilities (reference gaussian_diffusion.py:104-182 for the constructor contract)."""
 
@@ -335,7 +338,10 @@ class GaussianDiffusion:
     def prior(self, scale, label, dim):
         """Prior mean of variable j is (label_j - scale_j0) / scale_j1 broadcast over its latent slice, unit
         variance (reference :718-725, vectorised: the reference loops N x nv with a device sync per element)."""
-        sc = th.as_tensor(np.asarray(scale), dtype=th.float32, device=label.device)
+        key = (str(label.device), np.asarray(scale, dtype=np.float32).tobytes())      # uploaded once (no H2D copy inside a captured step)
+        sc = _PRIOR_SCALE.get(key)
+        if sc is None:
+            sc = _PRIOR_SCALE[key] = th.as_tensor(np.asarray(scale), dtype=th.float32, device=label.device)
         mean = ((label.float() - sc[:, 0]) / (sc[:, 1] - 0))[:, :, None].expand(-1, -1, dim)
         return mean, th.ones_like(mean)
 

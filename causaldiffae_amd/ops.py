@@ -990,6 +990,76 @@ class _GNConvPS(Function):
         return dx, dgamma, dbeta, dss, dw, db, dres, None, None, None
 
 
+class _UpConvPS(Function):
+    """out = conv3x3(nearest_2x(x), w) + b — the Upsample block (reference unet.py:86-104) on the pre-split training kernels: the
+    upsampled activation is written once as operand planes, dgrad comes back at the upsampled size and is sum-pooled 2x2."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = to_nhwc(x)
+        N, C, H, W = x.shape
+        Cout = w.shape[0]
+        w_in, w = w, ohwi(w)
+        dev = x.device
+        st = stream()
+        planes = torch.empty((2, N, 2 * H, 2 * W, C), dtype=torch.float16, device=dev)
+        bplanes = torch.empty((2, N, 2 * H, 2 * W, C), dtype=torch.bfloat16, device=dev)
+        check(lib.cdae_upsample2_split(ptr(x), ptr(planes[0]), ptr(planes[1]), ptr(bplanes[0]), ptr(bplanes[1]), N, H, W, C, st))
+        w_hi, w_lo = split_weight(w)
+        out = new_act(N, Cout, 2 * H, 2 * W, dev)
+        ws, wsb = _sk(dev)
+        check(lib.cdae_conv3x3_fwd_ps(ptr(planes[0]), ptr(planes[1]), 4 * H * W * C, 2 * W * C, C, ptr(w_hi), ptr(w_lo), ptr(b), None, ptr(out), Cout,
+                                      0, None, None, None, N, 2 * H, 2 * W, C, Cout, 1, 0, ws, wsb, st))
+        ctx.save_for_backward(bplanes, w)
+        ctx.cfg = (b is not None, (N, C, H, W))
+        ctx.sinks = (_sink(w_in), _sink(b))
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        bplanes, w = ctx.saved_tensors
+        has_b, (N, C, H, W) = ctx.cfg
+        Cout = w.shape[0]
+        dev = w.device
+        st = stream()
+        dy = to_nhwc(dy)
+        ws, wsb = _sk(dev)
+        (gw, rw), (gb, rb) = ctx.sinks
+        dx = dw = db = None
+        dplanes = torch.empty((2, N, 2 * H, 2 * W, Cout), dtype=torch.bfloat16, device=dev)
+        check(lib.cdae_split_bf16(ptr(dy), ptr(dplanes[0]), ptr(dplanes[1]), dy.numel(), st))
+        if ctx.needs_input_grad[1]:
+            direct = gw is not None and w.stride() == gw.stride() and (not has_b or gb is not None)
+            if direct:
+                dw, db = gw, gb
+            else:
+                dw = torch.empty_like(w)
+                db = torch.empty(Cout, dtype=torch.float32, device=dev) if has_b else None
+            check(lib.cdae_conv3x3_wgrad_win(ptr(bplanes[0]), ptr(bplanes[1]), ptr(dplanes[0]), ptr(dplanes[1]), ptr(dw), ptr(db), N, 2 * H, 2 * W, C,
+                                             Cout, 1 if direct else 0, ws, wsb, st))
+            if direct:
+                dw = db = None
+                _done(rw, rb)
+        if ctx.needs_input_grad[0]:
+            wt_hi, wt_lo = dgrad_weight(w)
+            dxu = new_act(N, C, 2 * H, 2 * W, dev)
+            check(lib.cdae_conv3x3_dgrad_ps(ptr(dplanes[0]), ptr(dplanes[1]), ptr(wt_hi), ptr(wt_lo), ptr(dxu), C, N, 2 * H, 2 * W, C, Cout, ws, wsb, st))
+            dx = new_act(N, C, H, W, dev)
+            check(lib.cdae_sumpool2(ptr(dxu), ptr(dx), N, H, W, C, st))
+        return dx, dw, db
+
+
+def upconv3x3_train_ok(x, Cout):
+    from ._lib import get_precision
+    N, C, H, W = x.shape
+    return (_TRAIN_PS_ON and torch.is_grad_enabled() and get_precision() == "f16x3" and x.dim() == 4
+            and lib.cdae_conv3x3_wgrad_win_supported(N, 2 * H, 2 * W, C, Cout) == 1)
+
+
+def upconv3x3_train(x, w, b=None):
+    return _UpConvPS.apply(x, w, b)
+
+
 def gn_conv3x3(x, gamma, beta, scale_shift, w, b=None, res=None, silu=True, groups=32, eps=1e-5):
     if scale_shift is not None and not scale_shift.is_contiguous():
         scale_shift = scale_shift.contiguous()

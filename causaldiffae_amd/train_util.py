@@ -97,6 +97,13 @@ class GradBuckets:
                 b["work"] = dist.all_reduce(self.flat.grad[b["lo"]:b["hi"]], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         return hook
 
+    def reduce_all(self):
+        """All buckets at once, after a backward that ran with the hooks disabled (hipGraph replay)."""
+        if self.world == 1:
+            return
+        self.reset()
+        self.finish()
+
     def finish(self):
         """Wait for in-flight buckets, reduce any bucket whose hook never fired (unused params), average."""
         if self.world == 1:
@@ -177,7 +184,7 @@ class TrainLoop:
     def __init__(self, *, model, diffusion, data, batch_size, microbatch, lr, ema_rate, log_interval, save_interval,
                  resume_checkpoint, use_fp16=False, fp16_scale_growth=1e-3, schedule_sampler=None, weight_decay=0.0,
                  lr_anneal_steps=0, rep_cond=False, n_vars=None, causal_modeling=False, flow_based=False, in_channels=3,
-                 masking=False, bucket_mb=64):
+                 masking=False, bucket_mb=64, use_graph=None):
         if use_fp16:       # reduced-precision torso; fp32 master weights are the only weights, bf16 gradients need no loss scaling
             model.convert_to_fp16()
         self.model, self.diffusion, self.data = model, diffusion, data
@@ -213,6 +220,8 @@ class TrainLoop:
         self.use_ddp = self.world > 1
         self.ddp_model = self.model
         self.last_losses = None
+        self.use_graph = os.environ.get("CDAE_TRAIN_GRAPH", "0") == "1" if use_graph is None else bool(use_graph)
+        self._graphs, self._graph_failed, self._eager_steps = {}, False, 0
 
     # ------------------------------------------------------------------ loop
     def run_loop(self):
@@ -235,7 +244,69 @@ class TrainLoop:
         self.optimize_normal()
         self.log_step()
 
+    # ------------------------------------------------------------------ hipGraph replay of forward + backward
+    def _graph_wanted(self, batch):
+        """A training step is ~1600 kernel launches, many of them a few microseconds long: launched one by one the host, not the
+        GPU, sets the step time.  With static shapes (one microbatch, uniform timestep sampling) the whole forward + backward is
+        captured once into a hipGraph and replayed; inputs, timesteps, loss weights and the KL weight live in static buffers.
+        The gradient all-reduce (world > 1) and the optimizer kernel stay outside the graph.
+        OPT-IN (use_graph=True / CDAE_TRAIN_GRAPH=1): gradients match the eager step to its own run-to-run noise (6e-6), but on
+        ROCm 7.2 replaying the 1600-node graph measured 48.9 ms against 42.0 ms for eager launches on the same MI355X box — the
+        eager launch queue already overlaps with execution, graph nodes do not."""
+        return (self.use_graph and not self._graph_failed and th.cuda.is_available() and isinstance(self.schedule_sampler, UniformSampler)
+                and self.microbatch >= batch.shape[0] and self._eager_steps >= 2)
+
+    def _graph_capture(self, batch, cond):
+        dev = dist_util.dev()
+        st = dict(batch=batch.to(dev).clone(), cond={k: v.to(dev).clone() for k, v in cond.items()},
+                  t=th.zeros(batch.shape[0], dtype=th.int64, device=dev), w=th.ones(batch.shape[0], dtype=th.float32, device=dev),
+                  klw=th.zeros((), dtype=th.float32, device=dev))
+        kl_saved = self.diffusion.kl_weight
+        self.diffusion.kl_weight = st["klw"]
+        self.buckets.enabled = False
+        ops.bump_weight_epoch()              # the captured step must contain the weight-plane kernels, not reuse cached planes
+        graph = th.cuda.CUDAGraph()
+        try:
+            with th.cuda.graph(graph):
+                self.opt.zero_grad()
+                losses = self.diffusion.training_losses(self.model, st["batch"], st["t"], model_kwargs=dict(st["cond"]),
+                                                        rep_cond=self.rep_cond, causal_modeling=self.causal_modeling)
+                loss = (losses["loss"] * st["w"]).mean()
+                loss.backward()
+            st["losses"] = {k: v.detach() for k, v in losses.items()}
+            st["graph"] = graph
+        finally:
+            self.diffusion.kl_weight = kl_saved
+            ops.bump_weight_epoch()          # planes cached during capture belong to the graph's private pool
+        return st
+
+    def _graph_step(self, batch, cond):
+        key = (tuple(batch.shape), tuple(sorted((k, tuple(v.shape)) for k, v in cond.items())))
+        st = self._graphs.get(key)
+        if st is None:
+            try:
+                st = self._graphs[key] = self._graph_capture(batch, cond)
+            except Exception as e:          # capture is an optimisation: anything it cannot record runs eagerly, loudly
+                self._graph_failed = True
+                logger.log(f"hipGraph capture of the training step failed ({type(e).__name__}: {e}); running eagerly")
+                return False
+        dev = dist_util.dev()
+        st["batch"].copy_(batch, non_blocking=True)
+        for k, v in cond.items():
+            st["cond"][k].copy_(v, non_blocking=True)
+        t, weights = self.schedule_sampler.sample(batch.shape[0], dev)
+        st["t"].copy_(t)
+        st["w"].copy_(weights)
+        st["klw"].fill_(float(self.diffusion.kl_weight))
+        st["graph"].replay()
+        self.last_losses, self.last_t, self.last_w = st["losses"], st["t"], st["w"]
+        self.buckets.reduce_all()
+        return True
+
     def forward_backward(self, batch, cond):
+        if self._graph_wanted(batch) and self._graph_step(batch, cond):
+            return
+        self._eager_steps += 1
         dev = dist_util.dev()
         self.opt.zero_grad()
         n = batch.shape[0]

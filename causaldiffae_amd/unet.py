@@ -58,6 +58,9 @@ class TimestepBlock(nn.Module):
         """Apply the module to `x` given `emb` timestep embeddings."""
 
 
+_ADJ_CACHE = {}
+
+
 class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
     def forward(self, x, emb):
         for layer in self:
@@ -87,6 +90,8 @@ class Upsample(nn.Module):
         xs = getattr(x, "_split", None)        # pre-split planes left by the producing kernel (inference): sub-pixel form
         if xs is not None and ops.presplit_ok():
             return self.conv(xs, up=True, gn_stats=True)
+        if ops.upconv3x3_train_ok(x, self.channels):
+            return ops.upconv3x3_train(x, self.conv.weight, self.conv.bias)
         return self.conv(x, up=True)           # nearest-2x folded into the conv's input gather
 
 
@@ -321,7 +326,13 @@ class UNetModel(nn.Module):
         A = self.adjacency
         if A is None:
             A = ADJACENCY["morphomnist"] if self.n_vars == 2 else ADJACENCY["circuit"]
-        return th.as_tensor(A, dtype=th.float32).to(device)
+        if isinstance(A, th.Tensor):
+            return A.to(device=device, dtype=th.float32)
+        key = (str(device), tuple(map(tuple, A)))          # uploaded once: no host-to-device copy inside a (graph-captured) step
+        hit = _ADJ_CACHE.get(key)
+        if hit is None:
+            hit = _ADJ_CACHE[key] = th.as_tensor(A, dtype=th.float32).to(device)
+        return hit
 
     def embed(self, timesteps, y=None, c=None, x_start=None, z=None):
         """Everything ahead of the conv torso: returns (emb, mu, var, z_post, mask)."""

@@ -144,6 +144,10 @@ int cdae_conv3x3_dgrad(const float* dy, long lddy, const float* w, float* dx, lo
 int cdae_gn_apply_split_train(const float* x, unsigned short* y_hi, unsigned short* y_lo, unsigned short* yb_hi, unsigned short* yb_lo, int N,
                               int HW, int C, int ldx, int ldy, int groups, const float* mean, const float* rstd, const float* gamma,
                               const float* beta, const float* scale_shift, int ld_ss, int silu, void* stream);
+/* nearest-2x upsample (Upsample, unet.py:86-104: F.interpolate(scale_factor=2, mode="nearest") before the conv) of x[N,H,W,C] written
+   as the f16 (f_*) and bf16 (b_*) operand planes [N,2H,2W,C] of the training convs */
+int cdae_upsample2_split(const float* x, unsigned short* f_hi, unsigned short* f_lo, unsigned short* b_hi, unsigned short* b_lo, int N, int H,
+                         int W, int C, void* stream);
 int cdae_split_bf16(const float* src, unsigned short* hi, unsigned short* lo, long n, void* stream);
 int cdae_wdgrad_planes(const float* w, unsigned short* hi, unsigned short* lo, int Cout, int Cin, void* stream);
 int cdae_conv3x3_dgrad_ps(const unsigned short* dy_hi, const unsigned short* dy_lo, const unsigned short* wt_hi, const unsigned short* wt_lo,

@@ -568,3 +568,137 @@ def test_fused_attention_rows_sum_to_one(B, T, heads, ch, seed):
     with torch.no_grad():
         o = ops.qkv_attention(qkv, heads)
     assert (o - 1.0).abs().max().item() < 2e-6
+
+
+# ----------------------------------------------------------------------------- training on the pre-split kernels
+def _wgrad_ref(a, dy):
+    """fp64 weight / bias gradient of a stride-1 conv3x3 (NCHW a [N,Cin,H,W], dy [N,Cout,H,W]) in OHWI order."""
+    N, Cin, H, W = a.shape
+    Cout = dy.shape[1]
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, device=a.device, requires_grad=True)
+    out = torch.nn.functional.conv2d(a.double(), w, None, padding=1)
+    out.backward(dy.double())
+    return w.grad.permute(0, 2, 3, 1).contiguous(), dy.double().sum(dim=(0, 2, 3))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,H,W,Cin,Cout,accumulate", [
+    (3, 8, 8, 64, 64, 0),          # one 64-pixel step per image: every step crosses an image boundary; one block per tile (no split-K)
+    (5, 8, 8, 128, 64, 1),         # odd image count, accumulate into an existing gradient
+    (2, 16, 16, 64, 128, 0),       # 4 steps per image
+    (3, 32, 32, 128, 128, 0),      # split-K over pixel ranges that start inside an image
+    (2, 64, 64, 64, 64, 1),        # one image row per step, widest ring
+    (4, 16, 8, 64, 64, 0),         # non-square image (H != W)
+])
+def test_wgrad_window_kernel_matches_fp64(N, H, W, Cin, Cout, accumulate):
+    """cdae_conv3x3_wgrad_win (LDS-ring window, transpose-read fragments, bf16 hi/lo planes) against autograd in fp64; operands are
+    exactly representable as hi + lo so the comparison sees only the fp32 accumulation."""
+    from causaldiffae_amd._lib import check, lib, ptr, stream, splitk_ws, SPLITK_BYTES
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(11)
+    a = torch.randn(N, H, W, Cin, device=dev, generator=g)
+    dy = torch.randn(N, H, W, Cout, device=dev, generator=g) * 1e-3
+    ap = torch.empty((2, N, H, W, Cin), dtype=torch.bfloat16, device=dev)
+    dp = torch.empty((2, N, H, W, Cout), dtype=torch.bfloat16, device=dev)
+    check(lib.cdae_split_bf16(ptr(a), ptr(ap[0]), ptr(ap[1]), a.numel(), stream()))
+    check(lib.cdae_split_bf16(ptr(dy), ptr(dp[0]), ptr(dp[1]), dy.numel(), stream()))
+    a_q = (ap[0].float() + ap[1].float()).permute(0, 3, 1, 2)           # what the kernel sees
+    dy_q = (dp[0].float() + dp[1].float()).permute(0, 3, 1, 2)
+    assert (a_q.permute(0, 2, 3, 1) - a).abs().max().item() < 2e-4 * a.abs().max().item()      # bf16 hi + lo: 2^-16
+    dw0 = torch.randn(Cout, 3, 3, Cin, device=dev, generator=g) * 1e-2
+    db0 = torch.randn(Cout, device=dev, generator=g) * 1e-2
+    dw, db = dw0.clone(), db0.clone()
+    assert lib.cdae_conv3x3_wgrad_win_supported(N, H, W, Cin, Cout) == 1
+    check(lib.cdae_conv3x3_wgrad_win(ptr(ap[0]), ptr(ap[1]), ptr(dp[0]), ptr(dp[1]), ptr(dw), ptr(db), N, H, W, Cin, Cout, accumulate,
+                                     ptr(splitk_ws(torch.device(dev))), SPLITK_BYTES, stream()))
+    ref_w, ref_b = _wgrad_ref(a_q, dy_q)
+    if accumulate:
+        ref_w, ref_b = ref_w + dw0.double(), ref_b + db0.double()
+    # hi*hi + hi*lo + lo*hi drops lo*lo (2^-16 relative to a product) and accumulates in fp32
+    assert (dw.double() - ref_w).abs().max().item() < 3e-5 * ref_w.abs().max().item()
+    assert (db.double() - ref_b).abs().max().item() < 3e-5 * ref_b.abs().max().item()
+
+
+@pytest.mark.gpu
+def test_wgrad_window_kernel_rejects_unsupported_shapes():
+    from causaldiffae_amd._lib import lib
+    assert lib.cdae_conv3x3_wgrad_win_supported(2, 8, 8, 96, 64) == 0          # Cin % 64
+    assert lib.cdae_conv3x3_wgrad_win_supported(2, 12, 12, 64, 64) == 0        # rows not a power of two
+    assert lib.cdae_conv3x3_wgrad_win_supported(2, 4, 4, 64, 64) == 0          # fewer than 64 pixels per image
+    assert lib.cdae_conv3x3_wgrad_win_supported(2, 128, 128, 64, 64) == 0      # rows wider than the ring
+
+
+def _gnconv_case(N, C, Cout, H, ss_on, res_on, mode):
+    from causaldiffae_amd import ops
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(5)
+    cl = torch.channels_last
+    x = torch.randn(N, C, H, H, device=dev, generator=g).contiguous(memory_format=cl)
+    gamma = 1 + 0.1 * torch.randn(C, device=dev, generator=g)
+    beta = 0.1 * torch.randn(C, device=dev, generator=g)
+    ss = 0.2 * torch.randn(N, 2 * C, device=dev, generator=g) if ss_on else None
+    w = (torch.randn(Cout, C, 3, 3, device=dev, generator=g) / (3 * C ** 0.5)).contiguous(memory_format=cl)
+    b = 0.1 * torch.randn(Cout, device=dev, generator=g)
+    res = torch.randn(N, Cout, H, H, device=dev, generator=g).contiguous(memory_format=cl) if res_on else None
+    dy = torch.randn(N, Cout, H, H, device=dev, generator=g).contiguous(memory_format=cl) * 1e-3
+    dt = torch.float64 if mode == "f64" else torch.float32
+    leaves = [None if t is None else t.detach().to(dt).requires_grad_() for t in (x, gamma, beta, ss, w, b, res)]
+    x, gamma, beta, ss, w, b, res = leaves
+    if mode == "f64":
+        h = torch.nn.functional.group_norm(x, 32, gamma, beta, 1e-5)
+        if ss_on:
+            h = h * (1 + ss[:, :C, None, None]) + ss[:, C:, None, None]
+        out = torch.nn.functional.conv2d(torch.nn.functional.silu(h), w, b, padding=1)
+        out = out + res if res_on else out
+    elif mode == "fused":
+        out = ops.gn_conv3x3(x, gamma, beta, ss, w, b, res, True, 32, 1e-5)
+    else:
+        out = ops.conv3x3(ops.group_norm(x, gamma, beta, ss, True, 32, 1e-5), w, b, res)
+    out.backward(dy.to(dt))
+    return [out.detach()] + [t.grad for t in leaves if t is not None]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C,Cout,H,ss_on,res_on", [(4, 128, 128, 64, True, True), (8, 256, 256, 32, False, False), (8, 384, 384, 16, True, True),
+                                                     (16, 512, 512, 8, True, False), (2, 128, 256, 32, True, True)])
+def test_fused_gn_conv_training_node(N, C, Cout, H, ss_on, res_on):
+    """ops.gn_conv3x3 (GroupNorm -> SiLU -> conv3x3 as one autograd node on the pre-split kernels: f16-plane forward, bf16-plane
+    dgrad on the window kernel, LDS-ring wgrad) against torch autograd in fp64, and no worse than the separate-node path."""
+    from causaldiffae_amd import ops
+    with torch.enable_grad():
+        assert ops.train_presplit_ok((N, C, H, H), Cout)
+        fused, old, ref = (_gnconv_case(N, C, Cout, H, ss_on, res_on, m) for m in ("fused", "old", "f64"))
+    for f, o, r in zip(fused, old, ref):
+        sc = r.abs().max().item() + 1e-30
+        ef, eo = (f.double() - r).abs().max().item() / sc, (o.double() - r).abs().max().item() / sc
+        assert ef < 2e-5, (ef, eo)                     # forward 2^-22 products, backward bf16x3 (2^-16 per product, averaged down)
+        assert ef < 3 * eo + 5e-6, (ef, eo)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C,H", [(4, 256, 32), (8, 512, 8), (2, 384, 16)])
+def test_upsample_conv_training_node(N, C, H):
+    """ops.upconv3x3_train (nearest-2x written once as operand planes, conv / dgrad / wgrad on the window kernels, 2x2 sum-pool of
+    the input gradient) against interpolate + conv2d autograd in fp64."""
+    from causaldiffae_amd import ops
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(7)
+    cl = torch.channels_last
+    x0 = torch.randn(N, C, H, H, device=dev, generator=g).contiguous(memory_format=cl)
+    w0 = (torch.randn(C, C, 3, 3, device=dev, generator=g) / (3 * C ** 0.5)).contiguous(memory_format=cl)
+    b0 = 0.1 * torch.randn(C, device=dev, generator=g)
+    dy = torch.randn(N, C, 2 * H, 2 * H, device=dev, generator=g).contiguous(memory_format=cl) * 1e-3
+    res = []
+    with torch.enable_grad():
+        for mode in ("f64", "fused"):
+            dt = torch.float64 if mode == "f64" else torch.float32
+            x, w, b = [t.detach().to(dt).requires_grad_() for t in (x0, w0, b0)]
+            if mode == "f64":
+                out = torch.nn.functional.conv2d(torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest"), w, b, padding=1)
+            else:
+                assert ops.upconv3x3_train_ok(x, C)
+                out = ops.upconv3x3_train(x, w, b)
+            out.backward(dy.to(dt))
+            res.append([out.detach(), x.grad, w.grad, b.grad])
+    for r, f in zip(*res):
+        assert (f.double() - r).abs().max().item() < 2e-5 * r.abs().max().item()

@@ -678,3 +678,45 @@ def test_mixed16_inference_on_presplit_path():
         set_precision(prev)
     rel = (got - ref).abs().max().item() / ref.abs().max().item()
     assert 0 < rel < 2e-2, rel
+
+
+@pytest.mark.gpu
+def test_train_step_graph_replay_matches_eager():
+    """TrainLoop(use_graph=True): forward + backward replayed from a hipGraph (static input / timestep / weight / KL-weight buffers)
+    gives the same losses and gradients as eager launches from the same RNG state, to the eager path's own run-to-run noise."""
+    import numpy as np
+    from improved_diffusion import script_util as su
+    from improved_diffusion.image_datasets import load_data
+    from improved_diffusion.train_util import TrainLoop
+    dev = torch.device("cuda:0")
+
+    def run(use_graph):
+        cfg = {**su.model_and_diffusion_defaults(), "image_size": 32, "in_channels": 3, "n_vars": 4, "rep_cond": True, "causal_modeling": True,
+               "num_channels": 64}
+        model, diff = su.create_model_and_diffusion(**cfg)
+        g = torch.Generator().manual_seed(4321)
+        with torch.no_grad():
+            for p in model.parameters():
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+        model.to(dev).train()
+        data = load_data(data_dir="synthetic", batch_size=4, image_size=32, in_channels=3, n_vars=4, seed=0)
+        loop = TrainLoop(model=model, diffusion=diff, data=data, batch_size=4, microbatch=-1, lr=1e-4, ema_rate="0.9999", log_interval=10 ** 9,
+                         save_interval=10 ** 9, resume_checkpoint="", rep_cond=True, n_vars=4, causal_modeling=True, in_channels=3,
+                         use_graph=use_graph)
+        out = []
+        for i in range(5):
+            diff.kl_weight = 0.05 * (i + 1)                  # changes every step, like run_loop's warm-up
+            np.random.seed(100 + i)
+            torch.manual_seed(200 + i)
+            b, c = next(data)
+            loop.forward_backward(b, c)
+            out.append((loop.last_losses["loss"].clone(), loop.opt.flat.grad.clone()))
+            loop.optimize_normal()
+        return out, loop
+
+    eager, _ = run(False)
+    graph, loop = run(True)
+    assert len(loop._graphs) == 1 and not loop._graph_failed
+    for (le, ge), (lg, gg) in zip(eager, graph):
+        assert torch.allclose(le, lg, rtol=1e-5, atol=1e-6)
+        assert (ge - gg).abs().max().item() < 1e-4 * ge.abs().max().item()
