@@ -91,7 +91,9 @@ def train_bench(dev, world, rank, steps, warmup, batch):
     randomize(model, 4321)
     model.to(dev).train()
     np.random.seed(1000 + rank)
-    data = load_data(data_dir="synthetic", batch_size=batch, image_size=64, in_channels=3, n_vars=4, seed=rank)
+    # HBM-resident synthetic pool + gather kernel: the feed the training script uses (`--host_feed` off), no host work per step
+    data = load_data(data_dir="synthetic", batch_size=batch, image_size=64, in_channels=3, n_vars=4, seed=rank,
+                     device=None if os.environ.get("CDAE_BENCH_HOST_FEED") == "1" else dev)
     loop = TrainLoop(model=model, diffusion=diff, data=data, batch_size=batch, microbatch=-1, lr=1e-4, ema_rate="0.9999",
                      log_interval=10 ** 9, save_interval=10 ** 9, resume_checkpoint="", rep_cond=True, n_vars=4,
                      causal_modeling=True, in_channels=3)

@@ -23,6 +23,7 @@
 // the first input-channel tile.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "cdae_internal.h"
 #include "../../include/cdae.h"
 
@@ -52,7 +53,10 @@ __device__ __forceinline__ int fdiv(int n, unsigned magic, int shift) {
 }
 
 // LDS image: activations [plane 2][channel half 2][(RB + 1) * 16 rows][64 B], dy [stage 2][plane 2][channel half 2][64 rows][64 B]
-__global__ __launch_bounds__(256, 1) void wgwin_kernel(const WgParams p) {
+// NWAVES = 8: the block splits every 64-pixel step over two groups of 4 waves (pixels 0..31 / 32..63 of the step), i.e. two waves
+// per SIMD that cover each other's LDS latency; the second group's accumulators are added to the first's through LDS at the end.
+template <int NWAVES>
+__global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void wgwin_kernel(const WgParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* const lds = reinterpret_cast<char*>(smem);
     const int RROWS = (p.RB + 1) * 16;                 // ring rows incl. the mirror of slot 0
@@ -62,7 +66,9 @@ __global__ __launch_bounds__(256, 1) void wgwin_kernel(const WgParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hh = lane >> 5, l31 = lane & 31;
-    const int wm = wave >> 1, wn = wave & 1;           // wave tile: output channels 32 wm.., input channels 32 wn..
+    const int wm = (wave >> 1) & 1, wn = wave & 1;     // wave tile: output channels 32 wm.., input channels 32 wn..
+    const int kg = wave >> 2;                          // K group (NWAVES = 8): 16-pixel sub-steps 2 kg, 2 kg + 1 of every step
+    constexpr int SKN = NWAVES == 8 ? 2 : 4;
     const int nci = p.Cin >> 6, nco = p.Cout >> 6;
     int b = blockIdx.x;
     const int cit = b % nci; b /= nci;
@@ -72,7 +78,8 @@ __global__ __launch_bounds__(256, 1) void wgwin_kernel(const WgParams p) {
     const int s_begin = ks * p.steps_per, s_end = min(p.steps, s_begin + p.steps_per);
 
     // ---- DMA roles: wave w stages sub-plane (P = w >> 1, half = w & 1) of both operands
-    const int dP = wave >> 1, dH = wave & 1;
+    const int dP = (wave >> 1) & 1, dH = wave & 1;
+    const bool dma_a = NWAVES == 4 || kg == 0, dma_d = NWAVES == 4 || kg == 1;      // 8 waves: group 0 stages activations, group 1 dy
     const unsigned short* const a_src = (dP ? p.a_lo : p.a_hi) + ci0 + dH * 32 + (lane & 3) * 8;
     const unsigned short* const d_src = (dP ? p.d_lo : p.d_hi) + co0 + dH * 32 + (lane & 3) * 8;
     char* const a_dst = lds + (dP * 2 + dH) * A_SUB;
@@ -127,12 +134,13 @@ __global__ __launch_bounds__(256, 1) void wgwin_kernel(const WgParams p) {
     u32x4 ones; ones[0] = ones[1] = ones[2] = ones[3] = 0x3F803F80u;       // bf16 1.0 pairs
 
     // horizontal padding masks of this lane's 8 pixels in 16-pixel step sk: x0 = (16 sk + 8 hh) mod W
-    unsigned mL[4], mR[4];
+    unsigned mL[SKN], mR[SKN];
 #pragma unroll
-    for (int sk = 0; sk < 4; ++sk) {
+    for (int ski = 0; ski < SKN; ++ski) {
+        const int sk = NWAVES == 8 ? 2 * kg + ski : ski;
         const int x0 = (16 * sk + 8 * hh) & (p.W - 1);
-        mL[sk] = x0 == 0 ? 0xFFFF0000u : 0xFFFFFFFFu;          // tap kx = 0 reads x - 1: the pixel at x == 0 (element 0) contributes nothing
-        mR[sk] = x0 == p.W - 8 ? 0x0000FFFFu : 0xFFFFFFFFu;    // tap kx = 2 reads x + 1: the pixel at x == W - 1 (element 7)
+        mL[ski] = x0 == 0 ? 0xFFFF0000u : 0xFFFFFFFFu;          // tap kx = 0 reads x - 1: the pixel at x == 0 (element 0) contributes nothing
+        mR[ski] = x0 == p.W - 8 ? 0x0000FFFFu : 0xFFFFFFFFu;    // tap kx = 2 reads x + 1: the pixel at x == W - 1 (element 7)
     }
 
     if (s_begin < s_end) {
@@ -144,12 +152,12 @@ __global__ __launch_bounds__(256, 1) void wgwin_kernel(const WgParams p) {
         int next_blk = B0 - hb, next_slot = 0;         // next block to load and its slot
         auto load_upto = [&](int blk_end) {            // uniform loop
             for (; next_blk < blk_end; ++next_blk) {
-                issue_a(next_blk, next_slot);
+                if (dma_a) issue_a(next_blk, next_slot);
                 next_slot = next_slot + 1 == p.RB ? 0 : next_slot + 1;
             }
         };
         load_upto(B0 + 4 + hb);
-        issue_d(s_begin * 64, 0);
+        if (dma_d) issue_d(s_begin * 64, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(256, 1) void wgwin_kernel(const WgParams p) {
             const int B0n = (img_n * p.period + q_n + p.U0) >> 4;
             if (s + 1 < s_end) {
                 load_upto(B0n + 4 + hb);
-                issue_d((s + 1) * 64, st ^ 1);
+                if (dma_d) issue_d((s + 1) * 64, st ^ 1);
             }
             // ---- compute step s: window rows start at ring row slot0 * 16 (block B0 - hb); the step's own rows at + 16 hb
             const char* const dy_hi = dyb + st * D_STAGE + wm * D_SUB + lane_off;
@@ -170,12 +178,13 @@ __global__ __launch_bounds__(256, 1) void wgwin_kernel(const WgParams p) {
             const int row_own = slot0 * 16 + p.U0;     // ring row (before wrap) of the step's first own pixel
             const int ring = p.RB * 16;
 #pragma unroll
-            for (int sk = 0; sk < 4; ++sk) {
+            for (int ski = 0; ski < SKN; ++ski) {
+                const int sk = NWAVES == 8 ? 2 * kg + ski : ski;
                 u32x4 dh[3], dl[3];
                 dh[1] = frag(dy_hi + sk * 1024);
                 dl[1] = frag(dy_lo + sk * 1024);
-                dh[0] = dh[1]; dh[0][0] &= mL[sk]; dl[0] = dl[1]; dl[0][0] &= mL[sk];
-                dh[2] = dh[1]; dh[2][3] &= mR[sk]; dl[2] = dl[1]; dl[2][3] &= mR[sk];
+                dh[0] = dh[1]; dh[0][0] &= mL[ski]; dl[0] = dl[1]; dl[0][0] &= mL[ski];
+                dh[2] = dh[1]; dh[2][3] &= mR[ski]; dl[2] = dl[1]; dl[2][3] &= mR[ski];
                 if (do_colsum) { accb = mma(dh[1], ones, accb); accb = mma(dl[1], ones, accb); }
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
@@ -197,6 +206,37 @@ __global__ __launch_bounds__(256, 1) void wgwin_kernel(const WgParams p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
+    }
+
+    if constexpr (NWAVES == 8) {
+        // fold the second K group into the first through LDS (the ring is dead now), three taps at a time: [wave & 3][3 + 1][16][64] floats
+        float* const xch = reinterpret_cast<float*>(lds) + (wave & 3) * (4 * 16 * 64) + lane;
+#pragma unroll
+        for (int round = 0; round < 3; ++round) {
+            __syncthreads();
+            if (kg == 1) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xch[(t * 16 + r) * 64] = acc[3 * round + t][r];
+                if (round == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xch[(3 * 16 + r) * 64] = accb[r];
+                }
+            }
+            __syncthreads();
+            if (kg == 0) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[3 * round + t][r] += xch[(t * 16 + r) * 64];
+                if (round == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) accb[r] += xch[(3 * 16 + r) * 64];
+                }
+            }
+        }
+        if (kg == 1) return;
     }
 
     // ---- epilogue: D[row = co][col = ci] of tap t -> out[(co0 + 32 wm + row) * 9 Cin + t * Cin + ci0 + 32 wn + col]
@@ -270,14 +310,17 @@ extern "C" int cdae_conv3x3_wgrad_win(const unsigned short* a_hi, const unsigned
     p.colsum = dbias;
     if (dbias && !accumulate && hipMemsetAsync(dbias, 0, sizeof(float) * Cout, st) != hipSuccess) return cdae_fail("dbias memset failed");
     const size_t smem = (size_t)4 * (p.RB + 1) * 16 * 64 + 2 * 4 * 64 * 64;
+    static const int cfg_waves = getenv("CDAE_WG_WAVES") ? atoi(getenv("CDAE_WG_WAVES")) : 8;
     static size_t attr_bytes = 0;
     if (smem > attr_bytes) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgwin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgwin_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&wgwin_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
         attr_bytes = smem;
     }
     cdae_prof_begin(PROF_IGEMM, 2.0 * Cout * 9.0 * Cin * (double)N * p.HW, st);
-    hipLaunchKernelGGL(wgwin_kernel, dim3((unsigned)(tiles * ks)), dim3(256), smem, st, p);
+    if (cfg_waves == 8) hipLaunchKernelGGL(wgwin_kernel<8>, dim3((unsigned)(tiles * ks)), dim3(512), smem, st, p);
+    else hipLaunchKernelGGL(wgwin_kernel<4>, dim3((unsigned)(tiles * ks)), dim3(256), smem, st, p);
     int rc = hipGetLastError() == hipSuccess ? 0 : cdae_fail("wgwin_kernel launch failed");
     if (rc == 0 && ks > 1) {
         const long n4 = (long)Cout * 9 * Cin / 4;

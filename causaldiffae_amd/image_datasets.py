@@ -279,6 +279,17 @@ def load_data(*, data_dir, batch_size, image_size, class_cond=False, split="trai
     [rank::world] stride.  data_dir "" / "synthetic" -> seeded synthetic tensors of the requested shape (benchmarks).
     `device`: None -> host tensors (reference behaviour); a cuda device -> HBM-resident pool + gather kernel."""
     if data_dir in ("", "synthetic", None):
+        if device is not None and th.device(device).type == "cuda":
+            # the same HBM-resident feed real datasets use (u8 pool + one gather launch per batch), over seeded synthetic images
+            rng = np.random.RandomState(seed)
+            n = max(4 * batch_size, 1024)
+            cond = {"c": rng.rand(n, n_vars).astype(np.float32)}
+            if class_cond:
+                cond["y"] = rng.randint(0, 10, size=(n,)).astype(np.int64)
+            pool = Pool(rng.randint(0, 256, size=(n, image_size, image_size, in_channels), dtype=np.uint8), cond, div=127.5, shift=-1.0,
+                        name="synthetic")
+            yield from Feed(pool, batch_size, shuffle=True, device=device, seed=seed)
+            return
         yield from _synthetic(batch_size, image_size, class_cond, in_channels, n_vars, seed)
         return
     rank, world = _rank_world()
