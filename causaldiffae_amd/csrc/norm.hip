@@ -73,6 +73,35 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
     }
 }
 
+// G == 32 (GroupNorm32, every norm of the model): grid N, 256 threads = 8 chunk lanes x 32 groups; the serial per-thread walk over
+// up to 128 chunks below costs ~10 us of pure latency per launch, 56 launches per network pass
+__global__ __launch_bounds__(256) void gn_finalize32_kernel(const float* __restrict__ x, int HW, int ldx, int cpg, int nchunk, float eps,
+                                                            const float* __restrict__ partial, float* __restrict__ mean, float* __restrict__ rstd,
+                                                            const float* __restrict__ x2, int ld2, int C1) {
+    __shared__ double sS[8][32], sQ[8][32];
+    const int n = blockIdx.x, g = threadIdx.x & 31, cl = threadIdx.x >> 5;
+    double s = 0.0, q = 0.0;
+    for (int c = cl; c < nchunk; c += 8) {
+        const float2 v = *reinterpret_cast<const float2*>(partial + (((long)n * nchunk + c) * 32 + g) * 2);
+        s += v.x; q += v.y;
+    }
+    sS[cl][g] = s; sQ[cl][g] = q;
+    __syncthreads();
+    if (cl == 0) {
+        s = 0.0; q = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s += sS[k][g]; q += sQ[k][g]; }
+        const double cnt = (double)HW * cpg;
+        int ldp;
+        const double pivot = *gn_src(x, ldx, x2, ld2, C1, (long)n * HW, g * cpg, ldp);
+        const double m = s / cnt;
+        double var = q / cnt - m * m;
+        if (var < 0.0) var = 0.0;
+        mean[n * 32 + g] = (float)(pivot + m);
+        rstd[n * 32 + g] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
 // grid N, G threads: stats[n*G+g] = mean, stats[N*G + n*G+g] = rstd
 __global__ void gn_finalize_kernel(const float* __restrict__ x, int HW, int ldx, int cpg, int G, int nchunk, float eps,
                                    const float* __restrict__ partial, float* __restrict__ mean, float* __restrict__ rstd,
@@ -343,7 +372,25 @@ __global__ __launch_bounds__(256) void gn_bwd_fold_kernel(int N, int HW, int C, 
     }
 }
 
-// Pass 2b: dgamma[c] (+)= sum_n, dbeta[c] (+)= sum_n
+// Pass 2b: dgamma[c] (+)= sum_n, dbeta[c] (+)= sum_n.  grid C/32, 256 threads = 8 image lanes x 32 channels (fixed fold order)
+__global__ __launch_bounds__(256) void gn_bwd_param8_kernel(int N, int C, const float* __restrict__ nc_part, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int accumulate) {
+    __shared__ double sA[8][32], sB[8][32];
+    const int cc = threadIdx.x & 31, nl = threadIdx.x >> 5, c = blockIdx.x * 32 + cc;
+    double a = 0, b = 0;
+    if (c < C)
+        for (int n = nl; n < N; n += 8) { const float2 v = *reinterpret_cast<const float2*>(nc_part + ((long)n * C + c) * 2); a += v.x; b += v.y; }
+    sA[nl][cc] = a; sB[nl][cc] = b;
+    __syncthreads();
+    if (nl == 0 && c < C) {
+        a = 0; b = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { a += sA[k][cc]; b += sB[k][cc]; }
+        dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)a;
+        dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)b;
+    }
+}
+
 __global__ void gn_bwd_param_kernel(int N, int C, const float* __restrict__ nc_part, float* __restrict__ dgamma,
                                     float* __restrict__ dbeta, int accumulate) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -594,7 +641,8 @@ int cdae_gn_stats(const float* x, int N, int HW, int C, int ldx, int groups, flo
     cdae_prof_begin(PROF_GN, (double)N * HW * C * 4.0, st);
     if (VEC == 4) hipLaunchKernelGGL(gn_partial_kernel<4>, dim3(nchunk, N), dim3(256), 0, st, x, HW, C, ldx, cpg, groups, ppb, ws);
     else hipLaunchKernelGGL(gn_partial_kernel<1>, dim3(nchunk, N), dim3(256), 0, st, x, HW, C, ldx, cpg, groups, ppb, ws);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(groups < 64 ? 64 : groups), 0, st, x, HW, ldx, cpg, groups, nchunk, eps, ws, mean, rstd);
+    if (groups == 32) hipLaunchKernelGGL(gn_finalize32_kernel, dim3(N), dim3(256), 0, st, x, HW, ldx, cpg, nchunk, eps, ws, mean, rstd, (const float*)nullptr, 0, 0);
+    else hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(groups < 64 ? 64 : groups), 0, st, x, HW, ldx, cpg, groups, nchunk, eps, ws, mean, rstd);
     cdae_prof_end(PROF_GN, st);
     CHECK_LAUNCH("gn_stats launch failed");
     return 0;
@@ -640,7 +688,8 @@ int cdae_gn_bwd(const float* x, const float* dy, float* dx, int N, int HW, int C
     if (VEC == 4) hipLaunchKernelGGL(gn_bwd_partial_kernel<4>, dim3(nchunk, N), dim3(256), 0, st, x, dy, HW, C, ldx, lddy, cpg, groups, ppb, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gpart, cpart);
     else hipLaunchKernelGGL(gn_bwd_partial_kernel<1>, dim3(nchunk, N), dim3(256), 0, st, x, dy, HW, C, ldx, lddy, cpg, groups, ppb, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gpart, cpart);
     hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3((C + 63) / 64 + 1, N), dim3(256), 0, st, N, HW, C, cpg, groups, nchunk, gpart, cpart, gsum, d_scale_shift, ld_dss, ncp);
-    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, st, N, C, ncp, dgamma, dbeta, accumulate_params);
+    if (N >= 8) hipLaunchKernelGGL(gn_bwd_param8_kernel, dim3((C + 31) / 32), dim3(256), 0, st, N, C, ncp, dgamma, dbeta, accumulate_params);
+    else hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, st, N, C, ncp, dgamma, dbeta, accumulate_params);
     if (VEC == 4) hipLaunchKernelGGL(gn_bwd_dx_kernel<4>, dim3(grid_for(total)), dim3(256), 0, st, x, dy, dx, total, HW, C, ldx, lddy, lddx, cpg, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gsum, accumulate_dx);
     else hipLaunchKernelGGL(gn_bwd_dx_kernel<1>, dim3(grid_for(total)), dim3(256), 0, st, x, dy, dx, total, HW, C, ldx, lddy, lddx, cpg, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gsum, accumulate_dx);
     cdae_prof_end(PROF_GN, st);
@@ -713,7 +762,8 @@ int cdae_gn_stats2(const float* x1, int ld1, const float* x2, int ld2, int C1, i
     const int ppb = (HW + nchunk - 1) / nchunk;
     cdae_prof_begin(PROF_GN, (double)N * HW * C * 4.0, st);
     hipLaunchKernelGGL(gn_partial_kernel<4>, dim3(nchunk, N), dim3(256), 0, st, x1, HW, C, ld1, cpg, groups, ppb, ws, x2, ld2, C1);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(groups < 64 ? 64 : groups), 0, st, x1, HW, ld1, cpg, groups, nchunk, eps, ws, mean, rstd, x2, ld2, C1);
+    if (groups == 32) hipLaunchKernelGGL(gn_finalize32_kernel, dim3(N), dim3(256), 0, st, x1, HW, ld1, cpg, nchunk, eps, ws, mean, rstd, x2, ld2, C1);
+    else hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(groups < 64 ? 64 : groups), 0, st, x1, HW, ld1, cpg, groups, nchunk, eps, ws, mean, rstd, x2, ld2, C1);
     cdae_prof_end(PROF_GN, st);
     CHECK_LAUNCH("gn_stats2 launch failed");
     return 0;
