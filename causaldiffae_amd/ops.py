@@ -914,7 +914,7 @@ class _GNConvPS(Function):
     window kernel consumes them in the forward, wgrad reads them back, and dgrad runs on the same kernel with bf16 planes of dy."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, ss, w, b, res, silu, groups, eps):
+    def forward(ctx, x, gamma, beta, ss, w, b, res, silu, groups, eps, ss_sink=None):
         x = to_nhwc(x)
         N, C, H, W = x.shape
         Cout = w.shape[0]
@@ -924,12 +924,14 @@ class _GNConvPS(Function):
         stats = torch.empty((2, N, groups), dtype=torch.float32, device=dev)
         gws = workspace(dev, "gn", 4 * lib.cdae_gn_workspace_floats(N, C))
         check(lib.cdae_gn_stats(ptr(x), N, H * W, C, C, groups, eps, ptr(stats[0]), ptr(stats[1]), ptr(gws), st))
-        if ss is not None:
-            assert ss.shape == (N, 2 * C) and ss.is_contiguous()
+        ld_ss = 2 * C
+        if ss is not None:         # [N, 2C] rows; may be a column slice of the batched emb_layers GEMM (row pitch > 2C)
+            assert ss.shape == (N, 2 * C) and ss.stride(1) == 1 and ss.dtype == torch.float32
+            ld_ss = ss.stride(0)
         planes = torch.empty((2, N, H, W, C), dtype=torch.float16, device=dev)            # forward operand (dropped after the conv)
         bplanes = torch.empty((2, N, H, W, C), dtype=torch.bfloat16, device=dev)          # kept for wgrad
         check(lib.cdae_gn_apply_split_train(ptr(x), ptr(planes[0]), ptr(planes[1]), ptr(bplanes[0]), ptr(bplanes[1]), N, H * W, C, C, C, groups,
-                                            ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta), ptr(ss), 2 * C, 1 if silu else 0, st))
+                                            ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta), ptr(ss), ld_ss, 1 if silu else 0, st))
         w_hi, w_lo = split_weight(w)
         out = new_act(N, Cout, H, W, dev)
         if res is not None:
@@ -940,6 +942,7 @@ class _GNConvPS(Function):
         ctx.save_for_backward(x, gamma, beta, ss, stats, bplanes, w)
         ctx.cfg = (silu, groups, b is not None, res is not None)
         ctx.sinks = (_sink(gamma), _sink(beta), _sink(w_in), _sink(b))
+        ctx.ss_sink = ss_sink if ss is not None else None      # where d(scale_shift) goes when the batched embedding GEMM collects it
         return out
 
     @staticmethod
@@ -978,16 +981,20 @@ class _GNConvPS(Function):
             direct = gg is not None and gbt is not None
             dgamma = gg if direct else torch.empty_like(gamma)
             dbeta = gbt if direct else torch.empty_like(beta)
-            dss = torch.empty_like(ss) if ss is not None else None
+            sink = ctx.ss_sink
+            dss = None if ss is None else (sink if sink is not None else torch.empty((N, 2 * C), dtype=torch.float32, device=dev))
             gws = workspace(dev, "gn", 4 * lib.cdae_gn_workspace_floats(N, C))
             check(lib.cdae_gn_bwd(ptr(x), ptr(dyn), ptr(dx), N, H * W, C, C, C, C, groups, ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta),
-                                  ptr(ss), 2 * C, 1 if silu else 0, ptr(dgamma), ptr(dbeta), 1 if direct else 0, ptr(dss), 2 * C, 0, ptr(gws), st))
+                                  ptr(ss), 2 * C if ss is None else ss.stride(0), 1 if silu else 0, ptr(dgamma), ptr(dbeta), 1 if direct else 0,
+                                  ptr(dss), 2 * C if dss is None else dss.stride(0), 0, ptr(gws), st))
+            if sink is not None:
+                dss = None             # written in place into the batched embedding GEMM's gradient buffer
             if direct:
                 dgamma = dbeta = None
                 _done(rg, rbt)
         if has_res and ctx.needs_input_grad[6]:
             dres = dy
-        return dx, dgamma, dbeta, dss, dw, db, dres, None, None, None
+        return dx, dgamma, dbeta, dss, dw, db, dres, None, None, None, None
 
 
 class _UpConvPS(Function):
@@ -1061,9 +1068,83 @@ def upconv3x3_train(x, w, b=None):
 
 
 def gn_conv3x3(x, gamma, beta, scale_shift, w, b=None, res=None, silu=True, groups=32, eps=1e-5):
-    if scale_shift is not None and not scale_shift.is_contiguous():
-        scale_shift = scale_shift.contiguous()
-    return _GNConvPS.apply(x, gamma, beta, scale_shift, w, b, res, silu, groups, eps)
+    sink = getattr(scale_shift, "_dss_sink", None) if scale_shift is not None else None
+    if scale_shift is not None and scale_shift.stride(-1) != 1:
+        scale_shift, sink = scale_shift.contiguous(), None
+    return _GNConvPS.apply(x, gamma, beta, scale_shift, w, b, res, silu, groups, eps, sink)
+
+
+class _EmbAllTrain(Function):
+    """Every ResBlock's `emb_layers` projection (reference unet.py:148-154: Linear(SiLU(emb)), 22 of them) as ONE GEMM in training.
+    The weights / biases are adjacent rows of the flat parameter buffer (train_util.FlatParams lays them out that way), so the
+    concatenated weight is a view, and the backward's single wgrad GEMM accumulates straight into the flat gradient buffer.  The
+    consumers (ops._GNConvPS) write their d(scale, shift) slices directly into `dall`, this node's gradient buffer; slices that
+    reach it through autograd instead (blocks on the separate-node path) arrive as `dout` and are added."""
+
+    @staticmethod
+    def forward(ctx, emb, flat):
+        N, K = emb.shape
+        W, b = flat["w"], flat["b"]
+        T = W.shape[0]
+        dev = emb.device
+        st = stream()
+        emb = _f32c(emb)
+        s = torch.empty_like(emb)
+        check(lib.cdae_silu_fwd(ptr(emb), ptr(s), emb.numel(), st))
+        out = torch.empty((N, T), dtype=torch.float32, device=dev)
+        ws, wsb = _sk(dev)
+        check(lib.cdae_linear_fwd(ptr(s), K, ptr(W), K, ptr(b), None, ptr(out), T, None, None, N, T, K, 1.0, ACT_NONE, ws, wsb, st))
+        dall = torch.zeros((N, T), dtype=torch.float32, device=dev)
+        flat["_dall"] = dall
+        ctx.save_for_backward(emb, s)
+        ctx.flat, ctx.dall = flat, dall
+        ctx.set_materialize_grads(False)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        emb, s = ctx.saved_tensors
+        flat, dall = ctx.flat, ctx.dall
+        if dout is not None:
+            dall.add_(dout)
+        N, K = emb.shape
+        W, gw, gb = flat["w"], flat["gw"], flat["gb"]
+        T = W.shape[0]
+        dev = emb.device
+        st = stream()
+        ws, wsb = _sk(dev)
+        demb = None
+        if ctx.needs_input_grad[0]:
+            ds = torch.empty((N, K), dtype=torch.float32, device=dev)
+            check(lib.cdae_linear_dgrad(ptr(dall), T, ptr(W), K, ptr(ds), K, N, T, K, 0, ws, wsb, st))
+            demb = torch.empty_like(ds)
+            check(lib.cdae_silu_bwd(ptr(emb), ptr(ds), ptr(demb), ds.numel(), st))
+        check(lib.cdae_linear_wgrad(ptr(s), K, ptr(dall), T, ptr(gw), K, ptr(gb), N, T, K, 1, ws, wsb, st))
+        for p in flat["params"]:
+            cb = getattr(p, "_grad_ready", None)
+            if cb is not None:
+                cb()
+        return demb, None
+
+
+_EMBALL_ON = os.environ.get("CDAE_TRAIN_EMBALL", "1") != "0"      # dev switch: 0 = one Linear per ResBlock
+
+
+def emb_all_train_ok(model):
+    flat = getattr(model, "_emb_flat", None)
+    return _EMBALL_ON and flat is not None and torch.is_grad_enabled() and all(p.requires_grad for p in flat["params"])
+
+
+def emb_all_train(emb, flat):
+    """Returns {id(block): [N, n_i] column slice}; each slice carries `_dss_sink`, the matching slice of the gradient buffer."""
+    out = _EmbAllTrain.apply(emb, flat)
+    dall = flat.pop("_dall")
+    slices = {}
+    for bid, o, n in flat["offs"]:
+        sl = out[:, o:o + n]
+        sl._dss_sink = dall[:, o:o + n]
+        slices[bid] = sl
+    return slices
 
 
 def linear_emit(rows, w, b, res, shape):

@@ -24,8 +24,19 @@ class FlatParams:
     """Re-homes a module's parameters (and their .grad) as views of two flat fp32 buffers, in registration order."""
 
     def __init__(self, model):
-        self.params = [p for p in model.parameters()]
-        self.names = [n for n, _ in model.named_parameters()]
+        named = list(model.named_parameters())
+        # the ResBlocks' emb_layers weights (then their biases) first and adjacent: their concatenation is then a VIEW of the flat
+        # buffer and the batched embedding GEMM (ops._EmbAllTrain) needs no copies, forward or backward.  Being first they are also
+        # the last bucket to be all-reduced, which matches when their gradient is produced (the very end of backward).
+        group = model.emb_param_groups() if hasattr(model, "emb_param_groups") else None
+        lead = []
+        if group is not None and group[1] and len({w.shape[1] for w in group[1]}) == 1 and all(w.is_contiguous() for w in group[1]):
+            lead = list(group[1]) + list(group[2])
+            ids = {id(p) for p in lead}
+            by_id = {id(p): n for n, p in named}
+            named = [(by_id[id(p)], p) for p in lead] + [(n, p) for n, p in named if id(p) not in ids]
+        self.params = [p for _, p in named]
+        self.names = [n for n, _ in named]
         dev = self.params[0].device
         self.offsets, off = [], 0
         for p in self.params:
@@ -42,6 +53,15 @@ class FlatParams:
             # backward kernels accumulate straight into this view (ops._sink): no temporaries, no autograd add kernels
             p._grad_view = p.grad
             p._grad_ready = None
+        if lead:
+            blocks, ws, bs = group
+            T, K = sum(w.shape[0] for w in ws), ws[0].shape[1]
+            offs, o = [], 0
+            for blk, w in zip(blocks, ws):
+                offs.append((id(blk), o, w.shape[0]))
+                o += w.shape[0]
+            model._emb_flat = dict(w=self.flat[:T * K].view(T, K), b=self.flat[T * K:T * K + T], gw=self.grad[:T * K].view(T, K),
+                                   gb=self.grad[T * K:T * K + T], params=lead, offs=offs)
 
     def zero_grad(self):
         self.grad.zero_()

@@ -369,6 +369,12 @@ class UNetModel(nn.Module):
             emb = self.up_emb(z.float(), res=emb)
         return emb, mu, var, z_post, mask
 
+    def emb_param_groups(self):
+        """(blocks, weights, biases) of the ResBlocks' `emb_layers` Linear in module order: train_util.FlatParams stores them
+        adjacently so that their concatenation is a view (ops._EmbAllTrain)."""
+        blocks = [m for m in self.modules() if isinstance(m, ResBlock)]
+        return blocks, [b.emb_layers[1].weight for b in blocks], [b.emb_layers[1].bias for b in blocks]
+
     def _emb_all(self, emb):
         """All 22 `emb_layers` projections (unet.py:186: Linear(SiLU(emb)) per ResBlock) as one GEMM over the concatenated
         weights; the concatenation is cached per weight version."""
@@ -395,6 +401,8 @@ class UNetModel(nn.Module):
         emb, mu, var, z_post, mask = self.embed(timesteps, y=y, c=c, x_start=x_start, z=z)
         if ops.presplit_ok():
             emb = self._emb_all(emb)
+        elif ops.emb_all_train_ok(self):
+            emb = EmbAll(emb, ops.emb_all_train(emb, self._emb_flat))      # one GEMM for the 22 emb_layers, fwd and bwd
         hs = []
         h = x.float()
         for module in self.input_blocks:

@@ -720,3 +720,47 @@ def test_train_step_graph_replay_matches_eager():
     for (le, ge), (lg, gg) in zip(eager, graph):
         assert torch.allclose(le, lg, rtol=1e-5, atol=1e-6)
         assert (ge - gg).abs().max().item() < 1e-4 * ge.abs().max().item()
+
+
+@pytest.mark.gpu
+def test_batched_emb_layers_training_matches_per_block_linears():
+    """TrainLoop lays the ResBlocks' emb_layers weights out adjacently in the flat buffer; ops._EmbAllTrain then computes all of them
+    (and their gradients) with one GEMM each way, the fused GN-conv nodes writing d(scale, shift) straight into its gradient buffer.
+    Same losses and gradients as one Linear per block."""
+    import numpy as np
+    from causaldiffae_amd import ops
+    from improved_diffusion import script_util as su
+    from improved_diffusion.image_datasets import load_data
+    from improved_diffusion.train_util import TrainLoop
+    dev = torch.device("cuda:0")
+
+    def run(batched):
+        saved = ops._EMBALL_ON
+        ops._EMBALL_ON = batched
+        try:
+            cfg = {**su.model_and_diffusion_defaults(), "image_size": 32, "in_channels": 3, "n_vars": 4, "rep_cond": True, "causal_modeling": True,
+                   "num_channels": 64}
+            model, diff = su.create_model_and_diffusion(**cfg)
+            g = torch.Generator().manual_seed(4321)
+            with torch.no_grad():
+                for p in model.parameters():
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+            model.to(dev).train()
+            data = load_data(data_dir="synthetic", batch_size=4, image_size=32, in_channels=3, n_vars=4, seed=0)
+            loop = TrainLoop(model=model, diffusion=diff, data=data, batch_size=4, microbatch=2, lr=1e-4, ema_rate="0.9999", log_interval=10 ** 9,
+                             save_interval=10 ** 9, resume_checkpoint="", rep_cond=True, n_vars=4, causal_modeling=True, in_channels=3)
+            assert hasattr(model, "_emb_flat") and model._emb_flat["w"].data_ptr() == loop.opt.flat.flat.data_ptr()
+            diff.kl_weight = 0.1
+            np.random.seed(100)
+            torch.manual_seed(200)
+            b, c = next(data)
+            loop.forward_backward(b, c)                       # two microbatches: gradients accumulate over both
+            return {n: p.grad.detach().clone() for n, p in model.named_parameters()}, loop.last_losses["loss"].clone()
+        finally:
+            ops._EMBALL_ON = saved
+
+    (g0, l0), (g1, l1) = run(False), run(True)
+    assert torch.allclose(l0, l1, rtol=1e-5, atol=1e-6)
+    for n in g0:
+        if "emb_layers" in n or "time_embed" in n or "in_layers.2" in n:
+            assert (g0[n] - g1[n]).abs().max().item() <= 1e-4 * g0[n].abs().max().item() + 1e-12, n
