@@ -101,6 +101,48 @@ __global__ __launch_bounds__(256) void wdgrad_planes_kernel(const float* __restr
     }
 }
 
+// All registered conv3x3 weights in ONE launch: f16 hi/lo planes in the weight's own OHWI order (forward operand) and bf16 hi/lo
+// planes of the dgrad weight ([Cin][9][Cout], taps flipped).  desc[i] = {weight offset in `flat` (elements), Cout, Cin, first tile};
+// a block = one 32 x 32 (co, ci) tile of one tap of one weight; output planes use the same element offsets, relative to the first
+// registered weight's offset `base`.
+struct WPrepDesc { long off; int Cout, Cin, tile0, pad; };
+__global__ __launch_bounds__(256) void wprep_all_kernel(const float* __restrict__ flat, const WPrepDesc* __restrict__ desc, int nw, long base,
+                                                        _Float16* __restrict__ fh, _Float16* __restrict__ fl, __bf16* __restrict__ bh,
+                                                        __bf16* __restrict__ bl) {
+    __shared__ float tile[32][33];
+    int lo = 0, hi = nw - 1;                       // last descriptor whose first tile <= blockIdx.x
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (desc[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+    const WPrepDesc d = desc[lo];
+    int t = blockIdx.x - d.tile0;
+    const int nci = (d.Cin + 31) >> 5, nco = (d.Cout + 31) >> 5;
+    const int cit = t % nci; t /= nci;
+    const int cot = t % nco; const int tap = t / nco;
+    const float* w = flat + d.off;
+    const long o0 = d.off - base;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, ci0 = cit * 32, co0 = cot * 32;
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        float v = 0.f;
+        if (co < d.Cout && ci < d.Cin) {
+            const long i = ((long)co * 9 + tap) * d.Cin + ci;
+            v = w[i];
+            const _Float16 h = (_Float16)v;
+            fh[o0 + i] = h; fl[o0 + i] = (_Float16)(v - (float)h);
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + tx;
+        if (ci < d.Cin && co < d.Cout) {
+            const float v = tile[tx][r];
+            const __bf16 h = (__bf16)v;
+            const long o = o0 + ((long)ci * 9 + (8 - tap)) * d.Cout + co;
+            bh[o] = h; bl[o] = (__bf16)(v - (float)h);
+        }
+    }
+}
+
 // generic pointwise activations on a stored pre-activation (codes = the GEMM epilogue's: 1 SiLU, 2 LeakyReLU(0.01), 3 ReLU, 4 sigmoid)
 __device__ inline float act_apply(float v, int kind) {
     if (kind == 1) return v / (1.f + expf(-v));
@@ -482,6 +524,13 @@ int cdae_upsample2_split(const float* x, unsigned short* f_hi, unsigned short* f
         return cdae_fail("upsample2_split: C % 4 == 0, 16-byte aligned input and 8-byte aligned planes required");
     const long total = (long)N * H * W * (C / 4);
     LAUNCH1D(upsample2_split_kernel, total, (const float4*)x, (ew_half4*)f_hi, (ew_half4*)f_lo, (ew_bf4*)b_hi, (ew_bf4*)b_lo, H, W, C / 4, total);
+}
+int cdae_wprep_all(const float* flat, const void* desc, int nw, int total_tiles, long base, unsigned short* f_hi, unsigned short* f_lo,
+                   unsigned short* b_hi, unsigned short* b_lo, void* stream) {
+    if (nw <= 0 || total_tiles <= 0) return 0;
+    hipLaunchKernelGGL(wprep_all_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, flat, (const WPrepDesc*)desc, nw, base, (_Float16*)f_hi,
+                       (_Float16*)f_lo, (__bf16*)b_hi, (__bf16*)b_lo);
+    return hipGetLastError() == hipSuccess ? 0 : cdae_fail("wprep_all launch failed");
 }
 int cdae_wdgrad_planes(const float* w, unsigned short* hi, unsigned short* lo, int Cout, int Cin, void* stream) {
     if (Cout <= 0 || Cin <= 0) return cdae_fail("wdgrad_planes: empty weight");

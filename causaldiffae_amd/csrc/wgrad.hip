@@ -300,7 +300,8 @@ extern "C" int cdae_conv3x3_wgrad_win(const unsigned short* a_hi, const unsigned
     }
     const long tiles = (long)(Cin / 64) * (Cout / 64);
     const size_t slab = (size_t)Cout * 9 * Cin * sizeof(float);
-    int ks = (int)((512 + tiles - 1) / tiles);
+    static const int cfg_blocks = getenv("CDAE_WG_BLOCKS") ? atoi(getenv("CDAE_WG_BLOCKS")) : 256;      // grid target: one block per CU (measured 256 / 512 / 768: 39.6 / 39.7-40.9 / 40.6-43.2 ms per training step)
+    int ks = (int)((cfg_blocks + tiles - 1) / tiles);
     if (ks > p.steps) ks = p.steps;
     while (ks > 1 && (!splitk_ws || (size_t)ks * slab > splitk_ws_bytes)) --ks;
     p.steps_per = (p.steps + ks - 1) / ks;

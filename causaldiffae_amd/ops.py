@@ -681,11 +681,66 @@ def bump_weight_epoch():
     _WEIGHT_EPOCH[0] += 1
 
 
+class ConvWeightBank:
+    """Operand planes of MANY conv3x3 weights that live in one flat fp32 buffer (train_util.FlatParams): f16 hi/lo in OHWI order for
+    the forward convs and bf16 hi/lo of the dgrad weights, all refreshed by ONE launch per weight version (cdae_wprep_all) instead of
+    two small launches per conv and step.  split_weight / dgrad_weight serve registered weights from here."""
+
+    def __init__(self, flat, weights):
+        import numpy as np
+        self.flat, self.weights = flat, list(weights)
+        dev = flat.device
+        offs = [(w.data_ptr() - flat.data_ptr()) // 4 for w in self.weights]
+        self.base = min(offs)
+        span = max(o + w.numel() for o, w in zip(offs, self.weights)) - self.base
+        self.f16 = torch.empty((2, span), dtype=torch.float16, device=dev)
+        self.b16 = torch.empty((2, span), dtype=torch.bfloat16, device=dev)
+        desc = np.zeros(len(self.weights), dtype=np.dtype([("off", "<i8"), ("cout", "<i4"), ("cin", "<i4"), ("tile0", "<i4"), ("pad", "<i4")]))
+        tiles, self.where = 0, {}
+        for i, (o, w) in enumerate(zip(offs, self.weights)):
+            Cout, Cin = w.shape[0], w.shape[1]
+            desc[i] = (o, Cout, Cin, tiles, 0)
+            tiles += 9 * ((Cout + 31) // 32) * ((Cin + 31) // 32)
+            self.where[id(w)] = (o - self.base, w.numel())
+        self.tiles = tiles
+        self.desc = torch.from_numpy(desc.view(np.uint8).copy()).to(dev)
+        self.epoch, self.versions = None, {}
+        for w in self.weights:
+            _BANK_OF[id(w)] = (weakref.ref(w), self)
+
+    def planes(self, w, bf16):
+        if self.epoch != _WEIGHT_EPOCH[0] or self.versions.get(id(w)) != w._version:
+            check(lib.cdae_wprep_all(ptr(self.flat), ptr(self.desc), len(self.weights), self.tiles, self.base, ptr(self.f16[0]), ptr(self.f16[1]),
+                                     ptr(self.b16[0]), ptr(self.b16[1]), stream()))
+            self.epoch, self.versions = _WEIGHT_EPOCH[0], {id(x): x._version for x in self.weights}
+        o, n = self.where[id(w)]
+        buf = self.b16 if bf16 else self.f16
+        return buf[0, o:o + n], buf[1, o:o + n]
+
+
+_BANK_OF = {}
+
+
+def register_conv_bank(flat, params):
+    """Called by train_util.FlatParams: every OHWI-stored 3x3 conv weight that is a view of `flat` gets its planes from one bank."""
+    ws = [p for p in params if p.dim() == 4 and tuple(p.shape[2:]) == (3, 3) and p.permute(0, 2, 3, 1).is_contiguous() and p.numel() % 8 == 0
+          and ((p.data_ptr() - flat.data_ptr()) // 4) % 8 == 0]
+    return ConvWeightBank(flat, ws) if ws and os.environ.get("CDAE_WEIGHT_BANK", "1") != "0" else None
+
+
+def _bank(w):
+    hit = _BANK_OF.get(id(w))
+    return hit[1] if hit is not None and hit[0]() is w else None
+
+
 def split_weight(w):
     """(hi, lo) f16 planes of a weight in its PHYSICAL element order (OHWI for channels_last 3x3 weights, [N][K] for linear /
     1x1 weights).  Cached per tensor object (weak reference) and validated against (storage pointer, autograd version,
     weight epoch), so a new tensor that happens to reuse a freed address never sees stale planes."""
     assert w.is_contiguous() or (w.dim() == 4 and w.permute(0, 2, 3, 1).is_contiguous()), "split_weight needs a dense weight"
+    bank = _bank(w)
+    if bank is not None:
+        return bank.planes(w, False)
     tag = (w.data_ptr(), w._version, _WEIGHT_EPOCH[0])
     hit = _WSPLIT.get(id(w))
     if hit is not None and hit[0]() is w and hit[1] == tag:
@@ -894,6 +949,9 @@ def train_presplit_ok(x, Cout, groups=32):
 
 def dgrad_weight(w):
     """bf16 hi/lo planes of the dgrad weight of an OHWI conv3x3 weight ([Cin][9][Cout], taps flipped); cached like split_weight."""
+    bank = _bank(w)
+    if bank is not None:
+        return bank.planes(w, True)
     tag = (w.data_ptr(), w._version, _WEIGHT_EPOCH[0])
     hit = _WDGRAD.get(id(w))
     if hit is not None and hit[0]() is w and hit[1] == tag:

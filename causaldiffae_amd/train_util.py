@@ -53,6 +53,7 @@ class FlatParams:
             # backward kernels accumulate straight into this view (ops._sink): no temporaries, no autograd add kernels
             p._grad_view = p.grad
             p._grad_ready = None
+        self.conv_bank = ops.register_conv_bank(self.flat, self.params) if dev.type == "cuda" else None
         if lead:
             blocks, ws, bs = group
             T, K = sum(w.shape[0] for w in ws), ws[0].shape[1]

@@ -150,6 +150,11 @@ int cdae_upsample2_split(const float* x, unsigned short* f_hi, unsigned short* f
                          int W, int C, void* stream);
 int cdae_split_bf16(const float* src, unsigned short* hi, unsigned short* lo, long n, void* stream);
 int cdae_wdgrad_planes(const float* w, unsigned short* hi, unsigned short* lo, int Cout, int Cin, void* stream);
+/* cdae_split_f16 + cdae_wdgrad_planes for MANY conv3x3 weights in one launch (once per optimizer step).  The weights live in one
+   fp32 buffer `flat`; desc = nw records {long offset (elements); int Cout, Cin, first_tile, pad} with first_tile the running sum of
+   9 * ceil(Cout/32) * ceil(Cin/32); every output plane is addressed by (weight offset - base). */
+int cdae_wprep_all(const float* flat, const void* desc, int nw, int total_tiles, long base, unsigned short* f_hi, unsigned short* f_lo,
+                   unsigned short* b_hi, unsigned short* b_lo, void* stream);
 int cdae_conv3x3_dgrad_ps(const unsigned short* dy_hi, const unsigned short* dy_lo, const unsigned short* wt_hi, const unsigned short* wt_lo,
                           float* dx, long lddx, int N, int H, int W, int Cin, int Cout, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
 int cdae_conv3x3_wgrad_win_supported(int N, int H, int W, int Cin, int Cout);
