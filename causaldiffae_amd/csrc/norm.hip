@@ -408,7 +408,12 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const float* __restrict_
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ ss, int ld_ss, int do_silu,
-                                                         const float* __restrict__ gsum, int accumulate) {
+                                                         const float* __restrict__ gsum, int accumulate,
+                                                         const float* __restrict__ dx_add = nullptr, int ld_add = 0,
+                                                         unsigned short* __restrict__ dxb_hi = nullptr, unsigned short* __restrict__ dxb_lo = nullptr) {
+    // dx_add: a second gradient of the same tensor (the ResBlock's residual path) added on the way out instead of by a separate
+    // add kernel.  dxb_hi / dxb_lo (VEC == 4, dense [pixels][C]): the result also — or, with dx == nullptr, only — as bf16 hi/lo
+    // planes, the operand format in which the preceding conv's dgrad / wgrad consume it.
     const int E = C / VEC;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total_vec; idx += (long)gridDim.x * blockDim.x) {
         const long pix = idx / E;
@@ -440,8 +445,25 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const float* __restrict_
                 o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
             } else o[0] += dx[pix * lddx + c];
         }
-        if (VEC == 4) *reinterpret_cast<float4*>(dx + pix * lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
-        else dx[pix * lddx + c] = o[0];
+        if (dx_add) {
+            if (VEC == 4) {
+                float4 t = *reinterpret_cast<const float4*>(dx_add + pix * ld_add + c);
+                o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
+            } else o[0] += dx_add[pix * ld_add + c];
+        }
+        if (dx) {
+            if (VEC == 4) *reinterpret_cast<float4*>(dx + pix * lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
+            else dx[pix * lddx + c] = o[0];
+        }
+        if constexpr (VEC == 4) {
+            if (dxb_hi) {
+                gn_bf4 bh, bl;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { bh[i] = (__bf16)o[i]; bl[i] = (__bf16)(o[i] - (float)bh[i]); }
+                *reinterpret_cast<gn_bf4*>(dxb_hi + pix * C + c) = bh;
+                *reinterpret_cast<gn_bf4*>(dxb_lo + pix * C + c) = bl;
+            }
+        }
     }
 }
 
@@ -672,9 +694,22 @@ int cdae_gn_bwd(const float* x, const float* dy, float* dx, int N, int HW, int C
                 const float* mean, const float* rstd, const float* gamma, const float* beta, const float* scale_shift, int ld_ss, int silu,
                 float* dgamma, float* dbeta, int accumulate_params, float* d_scale_shift, int ld_dss, int accumulate_dx,
                 float* ws, void* stream) {
+    return cdae_gn_bwd_ex(x, dy, dx, N, HW, C, ldx, lddy, lddx, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, dgamma, dbeta,
+                          accumulate_params, d_scale_shift, ld_dss, accumulate_dx, nullptr, 0, nullptr, nullptr, ws, stream);
+}
+
+int cdae_gn_bwd_ex(const float* x, const float* dy, float* dx, int N, int HW, int C, int ldx, int lddy, int lddx, int groups,
+                   const float* mean, const float* rstd, const float* gamma, const float* beta, const float* scale_shift, int ld_ss, int silu,
+                   float* dgamma, float* dbeta, int accumulate_params, float* d_scale_shift, int ld_dss, int accumulate_dx,
+                   const float* dx_add, int ld_add, unsigned short* dxb_hi, unsigned short* dxb_lo, float* ws, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    if (!dx && !dxb_hi) return cdae_fail("gn_bwd: no output for dx");
+    if ((dxb_hi != nullptr) != (dxb_lo != nullptr)) return cdae_fail("gn_bwd: both bf16 planes or none");
+    if (!dx && accumulate_dx) return cdae_fail("gn_bwd: accumulate_dx needs the fp32 dx");
+    if (dxb_hi && !((C / groups) % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && (!dx || lddx % 4 == 0) && (!dx_add || ld_add % 4 == 0)))
+        return cdae_fail("gn_bwd: plane output needs the 4-channel vector path");
     const int cpg = C / groups;
-    const int VEC = (cpg % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0) ? 4 : 1;
+    const int VEC = (cpg % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && (!dx || lddx % 4 == 0) && (!dx_add || ld_add % 4 == 0)) ? 4 : 1;
     const int E = C / VEC;
     if (E > 256) return cdae_fail("gn_bwd: unsupported channel count");
     const int nchunk = gn_chunks(HW, N, E);
@@ -690,8 +725,8 @@ int cdae_gn_bwd(const float* x, const float* dy, float* dx, int N, int HW, int C
     hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3((C + 63) / 64 + 1, N), dim3(256), 0, st, N, HW, C, cpg, groups, nchunk, gpart, cpart, gsum, d_scale_shift, ld_dss, ncp);
     if (N >= 8) hipLaunchKernelGGL(gn_bwd_param8_kernel, dim3((C + 31) / 32), dim3(256), 0, st, N, C, ncp, dgamma, dbeta, accumulate_params);
     else hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, st, N, C, ncp, dgamma, dbeta, accumulate_params);
-    if (VEC == 4) hipLaunchKernelGGL(gn_bwd_dx_kernel<4>, dim3(grid_for(total)), dim3(256), 0, st, x, dy, dx, total, HW, C, ldx, lddy, lddx, cpg, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gsum, accumulate_dx);
-    else hipLaunchKernelGGL(gn_bwd_dx_kernel<1>, dim3(grid_for(total)), dim3(256), 0, st, x, dy, dx, total, HW, C, ldx, lddy, lddx, cpg, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gsum, accumulate_dx);
+    if (VEC == 4) hipLaunchKernelGGL(gn_bwd_dx_kernel<4>, dim3(grid_for(total)), dim3(256), 0, st, x, dy, dx, total, HW, C, ldx, lddy, lddx, cpg, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gsum, accumulate_dx, dx_add, ld_add, dxb_hi, dxb_lo);
+    else hipLaunchKernelGGL(gn_bwd_dx_kernel<1>, dim3(grid_for(total)), dim3(256), 0, st, x, dy, dx, total, HW, C, ldx, lddy, lddx, cpg, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gsum, accumulate_dx, dx_add, ld_add);
     cdae_prof_end(PROF_GN, st);
     CHECK_LAUNCH("gn_bwd launch failed");
     return 0;

@@ -1132,6 +1132,173 @@ def gn_conv3x3(x, gamma, beta, scale_shift, w, b=None, res=None, silu=True, grou
     return _GNConvPS.apply(x, gamma, beta, scale_shift, w, b, res, silu, groups, eps, sink)
 
 
+def _rb_gn_planes(x, gamma, beta, ss, silu, groups, eps, st):
+    """GroupNorm statistics + (scale-shift, SiLU) written as f16 planes (forward conv operand) and bf16 planes (kept for wgrad)."""
+    N, C, H, W = x.shape
+    dev = x.device
+    stats = torch.empty((2, N, groups), dtype=torch.float32, device=dev)
+    gws = workspace(dev, "gn", 4 * lib.cdae_gn_workspace_floats(N, C))
+    check(lib.cdae_gn_stats(ptr(x), N, H * W, C, C, groups, eps, ptr(stats[0]), ptr(stats[1]), ptr(gws), st))
+    planes = torch.empty((2, N, H, W, C), dtype=torch.float16, device=dev)
+    bplanes = torch.empty((2, N, H, W, C), dtype=torch.bfloat16, device=dev)
+    check(lib.cdae_gn_apply_split_train(ptr(x), ptr(planes[0]), ptr(planes[1]), ptr(bplanes[0]), ptr(bplanes[1]), N, H * W, C, C, C, groups,
+                                        ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta), ptr(ss), 2 * C if ss is None else ss.stride(0),
+                                        1 if silu else 0, st))
+    return stats, planes, bplanes
+
+
+def _rb_conv(planes, w, b, res, shape, Cout, st):
+    N, C, H, W = shape
+    dev = planes.device
+    w_hi, w_lo = split_weight(w)
+    out = new_act(N, Cout, H, W, dev)
+    ws, wsb = _sk(dev)
+    check(lib.cdae_conv3x3_fwd_ps(ptr(planes[0]), ptr(planes[1]), H * W * C, W * C, C, ptr(w_hi), ptr(w_lo), ptr(b), ptr(res), ptr(out), Cout,
+                                  0, None, None, None, N, H, W, C, Cout, 1, 0, ws, wsb, st))
+    return out
+
+
+def _rb_conv_bwd(bplanes, dplanes, w, sinks, has_b, shape, Cout, need_w, st):
+    """wgrad (into the flat-gradient sinks when they exist) and dgrad of one stride-1 conv from its operand planes."""
+    N, C, H, W = shape
+    dev = w.device
+    ws, wsb = _sk(dev)
+    (gw, rw), (gb, rb) = sinks
+    dw = db = None
+    if need_w:
+        direct = gw is not None and w.stride() == gw.stride() and (not has_b or gb is not None)
+        if direct:
+            dw, db = gw, gb
+        else:
+            dw = torch.empty_like(w)
+            db = torch.empty(Cout, dtype=torch.float32, device=dev) if has_b else None
+        check(lib.cdae_conv3x3_wgrad_win(ptr(bplanes[0]), ptr(bplanes[1]), ptr(dplanes[0]), ptr(dplanes[1]), ptr(dw), ptr(db), N, H, W, C, Cout,
+                                         1 if direct else 0, ws, wsb, st))
+        if direct:
+            dw = db = None
+            _done(rw, rb)
+    wt_hi, wt_lo = dgrad_weight(w)
+    dyn = new_act(N, C, H, W, dev)
+    check(lib.cdae_conv3x3_dgrad_ps(ptr(dplanes[0]), ptr(dplanes[1]), ptr(wt_hi), ptr(wt_lo), ptr(dyn), C, N, H, W, C, Cout, ws, wsb, st))
+    return dyn, dw, db
+
+
+class _ResBlockPS(Function):
+    """The whole ResBlock (reference unet.py:156-199) as ONE autograd node on the pre-split kernels:
+        h = conv1(silu(GN1(x)));  out = conv2(silu(GN2(h) * (1 + scale) + shift)) + skip(x),   skip = identity or 1x1 conv.
+    Besides what _GNConvPS fuses, the backward needs no gradient-accumulation kernels: the residual gradient is added inside the
+    first GroupNorm's dx kernel (identity skip) or that kernel accumulates onto the 1x1 skip's dgrad, and the gradient between the
+    two halves leaves GN2's backward directly as the bf16 planes conv1's dgrad / wgrad consume (no fp32 copy, no split pass)."""
+
+    @staticmethod
+    def forward(ctx, x, ss, ss_sink, g1, b1, w1, c1b, g2, b2, w2, c2b, sw, sb, groups, eps):
+        x = to_nhwc(x)
+        N, C, H, W = x.shape
+        Cout = w1.shape[0]
+        st = stream()
+        dev = x.device
+        w1_in, w2_in, w1, w2 = w1, w2, ohwi(w1), ohwi(w2)
+        stats1, planes, bplanes1 = _rb_gn_planes(x, g1, b1, None, True, groups, eps, st)
+        h = _rb_conv(planes, w1, c1b, None, (N, C, H, W), Cout, st)
+        if ss is not None:
+            assert ss.shape == (N, 2 * Cout) and ss.stride(1) == 1 and ss.dtype == torch.float32
+        stats2, planes, bplanes2 = _rb_gn_planes(h, g2, b2, ss, True, groups, eps, st)
+        if sw is None:
+            skip = x
+        else:                               # 1x1 skip conv on the NHWC rows
+            skip = new_act(N, Cout, H, W, dev)
+            ws, wsb = _sk(dev)
+            check(lib.cdae_linear_fwd(ptr(x), C, ptr(sw), C, ptr(sb), None, ptr(skip), Cout, None, None, N * H * W, Cout, C, 1.0, ACT_NONE,
+                                      ws, wsb, st))
+        out = _rb_conv(planes, w2, c2b, skip, (N, Cout, H, W), Cout, st)
+        del planes
+        ctx.save_for_backward(x, h, ss, stats1, stats2, bplanes1, bplanes2, g1, b1, w1, g2, b2, w2, sw)
+        ctx.cfg = (groups, c1b is not None, c2b is not None, sb is not None)
+        ctx.sinks = (_sink(g1), _sink(b1), _sink(w1_in), _sink(c1b), _sink(g2), _sink(b2), _sink(w2_in), _sink(c2b), _sink(sw), _sink(sb))
+        ctx.ss_sink = ss_sink if ss is not None else None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, h, ss, stats1, stats2, bplanes1, bplanes2, g1, b1, w1, g2, b2, w2, sw = ctx.saved_tensors
+        groups, has_c1b, has_c2b, has_sb = ctx.cfg
+        sg1, sb1, sw1, sc1b, sg2, sb2, sw2, sc2b, ssw, ssb = ctx.sinks
+        N, C, H, W = x.shape
+        Cout = w1.shape[0]
+        dev = x.device
+        st = stream()
+        dout = to_nhwc(dout)
+        need = ctx.needs_input_grad
+        ws, wsb = _sk(dev)
+
+        def gn_bwd(xin, dyn, stats, gamma, beta, ssv, sinks, Cn, dx, acc_dx, dx_add, planes_out):
+            (gg, rg), (gb_, rb_) = sinks
+            direct = gg is not None and gb_ is not None
+            dgamma = gg if direct else torch.empty_like(gamma)
+            dbeta = gb_ if direct else torch.empty_like(beta)
+            sink = ctx.ss_sink if ssv is not None else None
+            dss = None if ssv is None else (sink if sink is not None else torch.empty((N, 2 * Cn), dtype=torch.float32, device=dev))
+            gws = workspace(dev, "gn", 4 * lib.cdae_gn_workspace_floats(N, Cn))
+            check(lib.cdae_gn_bwd_ex(ptr(xin), ptr(dyn), ptr(dx), N, H * W, Cn, Cn, Cn, Cn, groups, ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta),
+                                     ptr(ssv), 2 * Cn if ssv is None else ssv.stride(0), 1, ptr(dgamma), ptr(dbeta), 1 if direct else 0,
+                                     ptr(dss), 2 * Cn if dss is None else dss.stride(0), 1 if acc_dx else 0, ptr(dx_add), Cn,
+                                     ptr(planes_out[0]) if planes_out is not None else None, ptr(planes_out[1]) if planes_out is not None else None,
+                                     ptr(gws), st))
+            if direct:
+                dgamma = dbeta = None
+                _done(rg, rb_)
+            return dgamma, dbeta, (None if sink is not None else dss)
+
+        # ---- second half: conv2 and GN2
+        dplanes = torch.empty((2, N, H, W, Cout), dtype=torch.bfloat16, device=dev)
+        check(lib.cdae_split_bf16(ptr(dout), ptr(dplanes[0]), ptr(dplanes[1]), dout.numel(), st))
+        dyn2, dw2, dc2b = _rb_conv_bwd(bplanes2, dplanes, w2, (sw2, sc2b), has_c2b, (N, Cout, H, W), Cout, need[9], st)
+        # dh leaves GN2's backward as bf16 planes only (it is nothing but conv1's dy); `dplanes` is reused for it
+        dg2, db2, dss = gn_bwd(h, dyn2, stats2, g2, b2, ss, (sg2, sb2), Cout, None, False, None, dplanes)
+        del dyn2
+        # ---- first half: conv1, then GN1 with the residual gradient folded in
+        dyn1, dw1, dc1b = _rb_conv_bwd(bplanes1, dplanes, w1, (sw1, sc1b), has_c1b, (N, C, H, W), Cout, need[5], st)
+        del dplanes
+        dsw = dsb = None
+        if sw is None:
+            dx = new_act(N, C, H, W, dev)
+            dg1, db1, _ = gn_bwd(x, dyn1, stats1, g1, b1, None, (sg1, sb1), C, dx, False, dout, None)
+        else:
+            M = N * H * W
+            dx = new_act(N, C, H, W, dev)
+            check(lib.cdae_linear_dgrad(ptr(dout), Cout, ptr(sw), C, ptr(dx), C, M, Cout, C, 0, ws, wsb, st))
+            dg1, db1, _ = gn_bwd(x, dyn1, stats1, g1, b1, None, (sg1, sb1), C, dx, True, None, None)
+            (gsw, rsw), (gsb, rsb) = ssw, ssb
+            direct = gsw is not None and gsw.is_contiguous() and (not has_sb or gsb is not None)
+            dsw = gsw if direct else torch.empty_like(sw)
+            dsb = (gsb if direct else torch.empty(Cout, dtype=torch.float32, device=dev)) if has_sb else None
+            check(lib.cdae_linear_wgrad(ptr(x), C, ptr(dout), Cout, ptr(dsw), C, ptr(dsb), M, Cout, C, 1 if direct else 0, ws, wsb, st))
+            if direct:
+                dsw = dsb = None
+                _done(rsw, rsb if has_sb else None)
+        return dx, dss, None, dg1, db1, dw1, dc1b, dg2, db2, dw2, dc2b, dsw, dsb, None, None
+
+
+_RBNODE_ON = os.environ.get("CDAE_TRAIN_RBNODE", "1") != "0"      # dev switch: 0 = two fused GN-conv nodes per ResBlock
+
+
+def resblock_node_ok():
+    return _RBNODE_ON
+
+
+def resblock_train(x, ss, g1, b1, w1, c1b, g2, b2, w2, c2b, sw=None, sb=None, groups=32, eps=1e-5):
+    sink = getattr(ss, "_dss_sink", None) if ss is not None else None
+    if ss is not None and ss.stride(-1) != 1:
+        ss, sink = ss.contiguous(), None
+    if sw is not None and sw.dim() != 2:            # [Cout, Cin, 1, 1] conv weight: same memory as [Cout, Cin]; carry the flat-grad sink over
+        w2d = sw.reshape(sw.shape[0], -1)
+        gv = getattr(sw, "_grad_view", None)
+        if gv is not None:
+            w2d._grad_view, w2d._grad_ready = gv.reshape(sw.shape[0], -1), getattr(sw, "_grad_ready", None)
+        sw = w2d
+    return _ResBlockPS.apply(x, ss, sink, g1, b1, w1, c1b, g2, b2, w2, c2b, sw, sb, groups, eps)
+
+
 class _EmbAllTrain(Function):
     """Every ResBlock's `emb_layers` projection (reference unet.py:148-154: Linear(SiLU(emb)), 22 of them) as ONE GEMM in training.
     The weights / biases are adjacent rows of the flat parameter buffer (train_util.FlatParams lays them out that way), so the

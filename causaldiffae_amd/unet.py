@@ -145,8 +145,13 @@ class ResBlock(TimestepBlock):
     def _forward_train(self, x, emb):
         n1, c1, n2, c2 = self.in_layers[0], self.in_layers[2], self.out_layers[0], self.out_layers[3]
         x = ops.to_nhwc(x)
-        h = ops.gn_conv3x3(x, n1.weight, n1.bias, None, c1.weight, c1.bias, None, True, n1.num_groups, n1.eps)
         emb_out = emb.slices[id(self)] if isinstance(emb, EmbAll) else self.emb_layers[1](ops.silu(emb))
+        sk = self.skip_connection
+        if self.use_scale_shift_norm and ops.resblock_node_ok() and (isinstance(sk, Identity) or sk.kernel_size == 1):
+            one = isinstance(sk, Identity)           # the whole block as one autograd node
+            return ops.resblock_train(x, emb_out, n1.weight, n1.bias, c1.weight, c1.bias, n2.weight, n2.bias, c2.weight, c2.bias,
+                                      None if one else sk.weight, None if one else sk.bias, n1.num_groups, n1.eps)
+        h = ops.gn_conv3x3(x, n1.weight, n1.bias, None, c1.weight, c1.bias, None, True, n1.num_groups, n1.eps)
         skip = x if isinstance(self.skip_connection, Identity) else self.skip_connection(x)
         if self.use_scale_shift_norm:
             return ops.gn_conv3x3(h, n2.weight, n2.bias, emb_out, c2.weight, c2.bias, skip, True, n2.num_groups, n2.eps)

@@ -204,6 +204,13 @@ int cdae_gn_bwd(const float* x, const float* dy, float* dx, int N, int HW, int C
                 const float* mean, const float* rstd, const float* gamma, const float* beta, const float* scale_shift, int ld_ss, int silu,
                 float* dgamma, float* dbeta, int accumulate_params, float* d_scale_shift, int ld_dss, int accumulate_dx,
                 float* ws, void* stream);
+/* cdae_gn_bwd with two fusions for the ResBlock backward: dx_add (nullable, pitch ld_add) — another gradient of the same tensor, the
+   residual path, added on the way out instead of by a separate add; dxb_hi / dxb_lo (nullable, dense [N*HW][C]) — dx also written
+   as bf16 hi/lo planes, the operand of the preceding conv's dgrad / wgrad (dx may then be NULL: planes only). */
+int cdae_gn_bwd_ex(const float* x, const float* dy, float* dx, int N, int HW, int C, int ldx, int lddy, int lddx, int groups,
+                   const float* mean, const float* rstd, const float* gamma, const float* beta, const float* scale_shift, int ld_ss, int silu,
+                   float* dgamma, float* dbeta, int accumulate_params, float* d_scale_shift, int ld_dss, int accumulate_dx,
+                   const float* dx_add, int ld_add, unsigned short* dxb_hi, unsigned short* dxb_lo, float* ws, void* stream);
 size_t cdae_bn_workspace_floats(int C);
 /* BatchNorm2d (batch stats if training, running stats otherwise) + LeakyReLU on NHWC rows (nn.py:46-53) */
 int cdae_bn_lrelu_fwd(const float* x, float* y, long rows, int C, const float* gamma, const float* beta, float* running_mean,

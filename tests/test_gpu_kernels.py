@@ -702,3 +702,45 @@ def test_upsample_conv_training_node(N, C, H):
             res.append([out.detach(), x.grad, w.grad, b.grad])
     for r, f in zip(*res):
         assert (f.double() - r).abs().max().item() < 2e-5 * r.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C,Cout,H", [(4, 128, 128, 32), (2, 256, 128, 16), (8, 512, 512, 8), (2, 128, 256, 64)])
+def test_resblock_training_node(N, C, Cout, H):
+    """ops.resblock_train: the whole ResBlock (GN-SiLU-conv, GN-scale/shift-SiLU-conv, identity or 1x1 skip) as one autograd node —
+    residual gradient folded into GroupNorm's dx kernel, the inter-conv gradient passed as bf16 planes — against torch autograd in
+    fp64 for every input and parameter."""
+    import torch.nn.functional as F
+    from causaldiffae_amd import ops
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(9)
+    cl = torch.channels_last
+
+    def rnd(*shape, scale=1.0):
+        return torch.randn(*shape, device=dev, generator=g) * scale
+
+    x0 = rnd(N, C, H, H).contiguous(memory_format=cl)
+    ss0 = rnd(N, 2 * Cout, scale=0.2)
+    p0 = dict(g1=1 + rnd(C, scale=0.1), b1=rnd(C, scale=0.1), w1=(rnd(Cout, C, 3, 3) / (3 * C ** 0.5)).contiguous(memory_format=cl),
+              c1b=rnd(Cout, scale=0.1), g2=1 + rnd(Cout, scale=0.1), b2=rnd(Cout, scale=0.1),
+              w2=(rnd(Cout, Cout, 3, 3) / (3 * Cout ** 0.5)).contiguous(memory_format=cl), c2b=rnd(Cout, scale=0.1))
+    if C != Cout:
+        p0.update(sw=rnd(Cout, C, 1, 1) / C ** 0.5, sb=rnd(Cout, scale=0.1))
+    dy = rnd(N, Cout, H, H).contiguous(memory_format=cl) * 1e-3
+    res = []
+    with torch.enable_grad():
+        for mode in ("f64", "node"):
+            dt = torch.float64 if mode == "f64" else torch.float32
+            x, ss = x0.detach().to(dt).requires_grad_(), ss0.detach().to(dt).requires_grad_()
+            p = {k: v.detach().to(dt).requires_grad_() for k, v in p0.items()}
+            if mode == "f64":
+                h = F.conv2d(F.silu(F.group_norm(x, 32, p["g1"], p["b1"], 1e-5)), p["w1"], p["c1b"], padding=1)
+                h = F.group_norm(h, 32, p["g2"], p["b2"], 1e-5) * (1 + ss[:, :Cout, None, None]) + ss[:, Cout:, None, None]
+                out = F.conv2d(F.silu(h), p["w2"], p["c2b"], padding=1) + (x if C == Cout else F.conv2d(x, p["sw"], p["sb"]))
+            else:
+                out = ops.resblock_train(x, ss, p["g1"], p["b1"], p["w1"], p["c1b"], p["g2"], p["b2"], p["w2"], p["c2b"], p.get("sw"), p.get("sb"))
+            out.backward(dy.to(dt))
+            res.append([out.detach(), x.grad, ss.grad] + [p[k].grad for k in sorted(p)])
+    names = ["out", "dx", "dss"] + sorted(p0)
+    for n, r, f in zip(names, *res):
+        assert (f.double().reshape(r.shape) - r).abs().max().item() < 3e-5 * r.abs().max().item(), n
