@@ -107,11 +107,16 @@ class GradBuckets:
         for b in self.buckets:
             b["pending"] = sum(1 for m in b["members"] if self.flat.params[m].requires_grad)
             b["work"] = None
+        self.fired = [False] * len(self.flat.params)
 
     def _make_hook(self, i):
         def hook(_p):
-            if not self.enabled:
+            # a parameter whose gradient is written in place (ops._sink) reports through `_grad_ready`, and autograd's
+            # post-accumulate hook fires for it AS WELL although the Function returned None for it: count each parameter once,
+            # or a bucket is all-reduced while half of its gradients are still missing
+            if not self.enabled or self.fired[i]:
                 return
+            self.fired[i] = True
             b = self.buckets[self.bucket_of[i]]
             b["pending"] -= 1
             if b["pending"] == 0:

@@ -764,3 +764,23 @@ def test_batched_emb_layers_training_matches_per_block_linears():
     for n in g0:
         if "emb_layers" in n or "time_embed" in n or "in_layers.2" in n:
             assert (g0[n] - g1[n]).abs().max().item() <= 1e-4 * g0[n].abs().max().item() + 1e-12, n
+
+
+@pytest.mark.gpu
+def test_data_parallel_gradients_match_single_process(tmp_path):
+    """Two ranks (gloo, both on cuda:0, the same 4 images each) through TrainLoop's bucketed all-reduce against one process: the
+    averaged flat gradient must be the single-process gradient.  Guards the hook accounting — parameters whose gradient is written
+    in place report through `_grad_ready` AND through autograd's post-accumulate hook; counted twice, a bucket is reduced while
+    gradients are still missing (seen as all-zero time_embed gradients)."""
+    import os, socket, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {**os.environ, "DP2_OUT": str(tmp_path / "dp2.pt"), "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    worker = os.path.join(here, "dp2_worker.py")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), worker], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run([sys.executable, worker], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
