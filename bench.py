@@ -111,13 +111,13 @@ def train_bench(dev, world, rank, steps, warmup, batch):
         loop.forward_backward(b, c)
         loop.optimize_normal()
     sync()
-    t0 = time.perf_counter()
+    t0, c0 = time.perf_counter(), time.process_time()
     for _ in range(steps):
         b, c = next(data)
         loop.forward_backward(b, c)
         loop.optimize_normal()
     sync()
-    dt = time.perf_counter() - t0
+    dt, cpu = time.perf_counter() - t0, time.process_time() - c0
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -127,6 +127,7 @@ def train_bench(dev, world, rank, steps, warmup, batch):
     return {"value": steps / dt, "unit": "train-steps/s", "ms_per_step": 1e3 * dt / steps, "batch_per_gpu": batch,
             "global_batch": batch * world, "images_per_sec": batch * world * steps / dt,
             "model_tflops": batch * world * steps / dt * 181.86 / 1e3, "dtype": "f32", "last_loss": loss,
+            "host_cpu_ms_per_step": 1e3 * cpu / steps,
             "workload": "CausalCircuit 64x64 C=3 CausalDiffAE training step (fwd+bwd+all-reduce+AdamW/EMA), 93.4M params"}
 
 
