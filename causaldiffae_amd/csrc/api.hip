@@ -194,6 +194,10 @@ int cdae_conv3x3_wgrad(const float* x, long sn, long sy, long sx, long sc, const
                        int N, int H, int W, int Cin, int Cout, int stride, int up, int accumulate,
                        float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
     const int Ho = up ? 2 * H : (H - 1) / stride + 1, Wo = up ? 2 * W : (W - 1) / stride + 1;
+    // a handful of output channels over a dense NHWC input (the UNet's `out` conv): the sliding-window FMA kernel of wgrad.hip
+    if (Cout <= 8 && stride == 1 && !up && sc == 1 && Cin % 4 == 0 && Cin >= 32 && sx == Cin && sy == (long)W * Cin && sn == (long)H * W * Cin &&
+        splitk_ws && cdae_get_default_precision() != CDAE_PREC_MIXED16)
+        return cdae_conv3x3_wgrad_fewout(x, dy, lddy, dw, dbias, N, H, W, Cin, Cout, accumulate, splitk_ws, splitk_ws_bytes, stream);
     GemmParams p = base_params();
     p.A = dy; p.B = x; p.C = dw;
     p.M = Cout; p.N = 9 * Cin; p.K = N * Ho * Wo;

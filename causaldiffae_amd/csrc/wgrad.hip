@@ -270,7 +270,116 @@ __global__ void wg_reduce_kernel(const float4* __restrict__ ws, float4* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// wgrad of a stride-1 conv3x3 with a HANDFUL of output channels (the UNet's `out` conv, 128 -> 3 or 6 channels, reference
+// unet.py:474-478): as an implicit GEMM it is a 6 x 1152 output over 131072 pixels — the MFMA tile kernels run it at a few percent of
+// anything (0.49 ms per training step).  Here a thread owns one input channel and sweeps image rows with a sliding 3x3 register
+// window of the activation (three new loads per pixel), accumulating dW[co][tap][ci] for all co in registers: plain fp32 FMAs, like
+// the reference.  grid (row groups, Cin / 128); per-block partials [Cout][9][Cin] reduced in block order by wg_reduce_kernel.
+template <int CO>
+__global__ __launch_bounds__(128) void wgrad_fewout_kernel(const float* __restrict__ x, const float* __restrict__ dy, long lddy, float* __restrict__ part,
+                                                           float* __restrict__ colsum_part, int N, int H, int W, int Cin, int rows_per_block) {
+    const int ci = blockIdx.y * 128 + threadIdx.x;
+    const bool live = ci < Cin;
+    const int row0 = blockIdx.x * rows_per_block, row1 = min(N * H, row0 + rows_per_block);
+    float acc[CO][9];
+#pragma unroll
+    for (int c = 0; c < CO; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
+    float bs[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) bs[c] = 0.f;
+    for (int row = row0; row < row1; ++row) {
+        const int n = row / H, y = row - n * H;
+        const float* xr[3];
+        bool ok[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int yy = y + k - 1;
+            ok[k] = live && yy >= 0 && yy < H;
+            xr[k] = x + ((long)(n * H + (ok[k] ? yy : y)) * W) * Cin + (live ? ci : 0);
+        }
+        float v[3][3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { v[k][0] = 0.f; v[k][1] = 0.f; v[k][2] = ok[k] ? xr[k][0] : 0.f; }
+        const float* d = dy + (long)row * W * lddy;
+        for (int xx = 0; xx < W; ++xx) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                v[k][0] = v[k][1]; v[k][1] = v[k][2];
+                v[k][2] = (ok[k] && xx + 1 < W) ? xr[k][(long)(xx + 1) * Cin] : 0.f;
+            }
+#pragma unroll
+            for (int c = 0; c < CO; ++c) {
+                const float g = d[(long)xx * lddy + c];
+                bs[c] += g;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc[c][t] = fmaf(g, v[t / 3][t % 3], acc[c][t]);
+            }
+        }
+    }
+    if (live) {
+        float* o = part + (long)blockIdx.x * CO * 9 * Cin + ci;
+#pragma unroll
+        for (int c = 0; c < CO; ++c)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) o[(long)(c * 9 + t) * Cin] = acc[c][t];
+    }
+    if (colsum_part && blockIdx.y == 0 && threadIdx.x == 0) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) colsum_part[(long)blockIdx.x * 8 + c] = c < CO ? bs[c < CO ? c : 0] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void fewout_bias_kernel(const float* __restrict__ part, float* __restrict__ db, int nblk, int Cout, int accumulate) {
+    __shared__ float sm[256][8];
+    float s[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) s[c] = 0.f;
+    for (int b = threadIdx.x; b < nblk; b += 256) {
+        const float4 lo = *reinterpret_cast<const float4*>(part + (long)b * 8), hi = *reinterpret_cast<const float4*>(part + (long)b * 8 + 4);
+        s[0] += lo.x; s[1] += lo.y; s[2] += lo.z; s[3] += lo.w; s[4] += hi.x; s[5] += hi.y; s[6] += hi.z; s[7] += hi.w;
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) sm[threadIdx.x][c] = s[c];
+    __syncthreads();
+    if (threadIdx.x < Cout) {
+        float t = 0.f;
+        for (int k = 0; k < 256; ++k) t += sm[k][threadIdx.x];          // fixed order
+        db[threadIdx.x] = accumulate ? db[threadIdx.x] + t : t;
+    }
+}
+
 }  // namespace
+
+extern "C" int cdae_conv3x3_wgrad_fewout(const float* x, const float* dy, long lddy, float* dw, float* dbias, int N, int H, int W, int Cin, int Cout,
+                                         int accumulate, float* ws, size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (Cout < 1 || Cout > 8 || Cin % 4) return cdae_fail("conv3x3_wgrad_fewout: 1..8 output channels, Cin % 4 == 0");
+    int rpb = 2;
+    int nblk = (N * H + rpb - 1) / rpb;
+    const size_t per = (size_t)Cout * 9 * Cin * sizeof(float);
+    while (nblk > 1 && (size_t)nblk * per + (size_t)nblk * 8 * sizeof(float) > ws_bytes) { rpb *= 2; nblk = (N * H + rpb - 1) / rpb; }
+    if (!ws || (size_t)nblk * per + (size_t)nblk * 8 * sizeof(float) > ws_bytes) return cdae_fail("conv3x3_wgrad_fewout: workspace too small");
+    float* colpart = dbias ? ws + (size_t)nblk * Cout * 9 * Cin : nullptr;
+    dim3 grid(nblk, (Cin + 127) / 128);
+    cdae_prof_begin(PROF_IGEMM, 2.0 * Cout * 9.0 * Cin * (double)N * H * W, st);
+#define FEW(C) hipLaunchKernelGGL(wgrad_fewout_kernel<C>, grid, dim3(128), 0, st, x, dy, lddy, ws, colpart, N, H, W, Cin, rpb)
+    switch (Cout) { case 1: FEW(1); break; case 2: FEW(2); break; case 3: FEW(3); break; case 4: FEW(4); break;
+                    case 5: FEW(5); break; case 6: FEW(6); break; case 7: FEW(7); break; default: FEW(8); }
+#undef FEW
+    int rc = hipGetLastError() == hipSuccess ? 0 : cdae_fail("wgrad_fewout launch failed");
+    if (rc == 0) {
+        const long n4 = (long)Cout * 9 * Cin / 4;
+        int blocks = (int)((n4 + 255) / 256);
+        hipLaunchKernelGGL(wg_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)ws, (float4*)dw, n4, nblk, accumulate);
+        if (dbias) hipLaunchKernelGGL(fewout_bias_kernel, dim3(1), dim3(256), 0, st, colpart, dbias, nblk, Cout, accumulate);
+        if (hipGetLastError() != hipSuccess) rc = cdae_fail("wgrad_fewout reduce launch failed");
+    }
+    cdae_prof_end(PROF_IGEMM, st);
+    return rc;
+}
 
 extern "C" int cdae_conv3x3_wgrad_win_supported(int N, int H, int W, int Cin, int Cout) {
     return N > 0 && W >= 8 && W <= 64 && (W & (W - 1)) == 0 && (H * W) % 64 == 0 && Cin % 64 == 0 && Cout % 64 == 0 &&

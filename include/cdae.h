@@ -157,6 +157,11 @@ int cdae_wprep_all(const float* flat, const void* desc, int nw, int total_tiles,
                    unsigned short* b_hi, unsigned short* b_lo, void* stream);
 int cdae_conv3x3_dgrad_ps(const unsigned short* dy_hi, const unsigned short* dy_lo, const unsigned short* wt_hi, const unsigned short* wt_lo,
                           float* dx, long lddx, int N, int H, int W, int Cin, int Cout, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
+/* wgrad of a stride-1 conv3x3 with 1..8 output channels over a dense NHWC fp32 input (the `out` conv, unet.py:474-478): sliding-window
+   fp32 FMAs, one thread per input channel; cdae_conv3x3_wgrad routes such shapes here.  ws: >= ceil(N*H/2) * (Cout*9*Cin + 8) floats
+   (fewer row groups are used if it is smaller). */
+int cdae_conv3x3_wgrad_fewout(const float* x, const float* dy, long lddy, float* dw, float* dbias, int N, int H, int W, int Cin, int Cout,
+                              int accumulate, float* ws, size_t ws_bytes, void* stream);
 int cdae_conv3x3_wgrad_win_supported(int N, int H, int W, int Cin, int Cout);
 int cdae_conv3x3_wgrad_win(const unsigned short* a_hi, const unsigned short* a_lo, const unsigned short* dy_hi, const unsigned short* dy_lo,
                            float* dw, float* dbias, int N, int H, int W, int Cin, int Cout, int accumulate, float* splitk_ws,

@@ -744,3 +744,25 @@ def test_resblock_training_node(N, C, Cout, H):
     names = ["out", "dx", "dss"] + sorted(p0)
     for n, r, f in zip(names, *res):
         assert (f.double().reshape(r.shape) - r).abs().max().item() < 3e-5 * r.abs().max().item(), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,H,W,Cin,Cout,accumulate", [(4, 16, 16, 128, 6, 0), (3, 8, 12, 64, 3, 1), (2, 32, 32, 256, 8, 0), (5, 7, 9, 36, 1, 0)])
+def test_wgrad_few_output_channels(N, H, W, Cin, Cout, accumulate):
+    """cdae_conv3x3_wgrad_fewout (sliding-window fp32 FMAs, the `out` conv's wgrad) against autograd in fp64, incl. odd image sizes,
+    channel counts that are not a multiple of the block, and accumulation into an existing gradient."""
+    from causaldiffae_amd._lib import check, lib, ptr, stream, splitk_ws, SPLITK_BYTES
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(13)
+    a = torch.randn(N, H, W, Cin, device=dev, generator=g)
+    dy = torch.randn(N, H, W, Cout, device=dev, generator=g) * 1e-2
+    dw0 = torch.randn(Cout, 3, 3, Cin, device=dev, generator=g) * 1e-2
+    db0 = torch.randn(Cout, device=dev, generator=g) * 1e-2
+    dw, db = dw0.clone(), db0.clone()
+    check(lib.cdae_conv3x3_wgrad_fewout(ptr(a), ptr(dy), Cout, ptr(dw), ptr(db), N, H, W, Cin, Cout, accumulate, ptr(splitk_ws(torch.device(dev))),
+                                        SPLITK_BYTES, stream()))
+    ref_w, ref_b = _wgrad_ref(a.permute(0, 3, 1, 2), dy.permute(0, 3, 1, 2))
+    if accumulate:
+        ref_w, ref_b = ref_w + dw0.double(), ref_b + db0.double()
+    assert (dw.double() - ref_w).abs().max().item() < 2e-6 * ref_w.abs().max().item()
+    assert (db.double() - ref_b).abs().max().item() < 2e-6 * ref_b.abs().max().item()
