@@ -723,6 +723,8 @@ _BANK_OF = {}
 
 def register_conv_bank(flat, params):
     """Called by train_util.FlatParams: every OHWI-stored 3x3 conv weight that is a view of `flat` gets its planes from one bank."""
+    for k in [k for k, (ref, _) in _BANK_OF.items() if ref() is None]:       # banks of models that no longer exist (their planes are large)
+        del _BANK_OF[k]
     ws = [p for p in params if p.dim() == 4 and tuple(p.shape[2:]) == (3, 3) and p.permute(0, 2, 3, 1).is_contiguous() and p.numel() % 8 == 0
           and ((p.data_ptr() - flat.data_ptr()) // 4) % 8 == 0]
     return ConvWeightBank(flat, ws) if ws and os.environ.get("CDAE_WEIGHT_BANK", "1") != "0" else None
