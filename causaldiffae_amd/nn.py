@@ -345,6 +345,22 @@ class GaussianConvEncoder(nn.Module):
         return [mu, var]
 
 
+class GaussianConvEncoderClf(GaussianConvEncoder):
+    """The evaluation classifier / regressor of the reference's test scripts (reference nn.py:115-222, built by
+    scripts/image_causaldae_test.py:131-156 to score counterfactuals): the same strided conv encoder plus one Linear head on the
+    flattened features; forward(x) -> [N, 1].  Same parameter names (encoder.*, fc_mu, fc_var, fc), so its checkpoints load."""
+
+    def __init__(self, in_channels, latent_dim, hidden_dims=None, num_vars=4, **kwargs):
+        super().__init__(in_channels, latent_dim, hidden_dims=hidden_dims, num_vars=num_vars, **kwargs)
+        self.fc = Linear(self.hidden_dims[-1] * 4, 1)
+
+    def forward(self, x):
+        h = x
+        for blk in self.encoder:
+            h = blk[1](blk[0](h))
+        return self.fc(ops.to_nchw(h).reshape(h.shape[0], -1))
+
+
 class MLP(nn.Module):
     """Linear(d -> latent) LeakyReLU Linear(latent -> d)  (reference nn.py:225-240)."""
 

@@ -784,3 +784,33 @@ def test_data_parallel_gradients_match_single_process(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     r = subprocess.run([sys.executable, worker], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_encoder_classifier_matches_torch_modules():
+    """nn.GaussianConvEncoderClf (the evaluation classifier the reference's image_causaldae_test.py builds): same state-dict layout as
+    the reference module, forward == Linear(flatten(strided conv -> BatchNorm(eval) -> LeakyReLU stack)) built from plain torch modules."""
+    import torch.nn as tnn
+    from improved_diffusion.nn import GaussianConvEncoderClf
+    dev = "cuda:0"
+    clf = GaussianConvEncoderClf(in_channels=4, latent_dim=512, num_vars=4)
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for n, p in clf.state_dict().items():
+            if p.dtype.is_floating_point:
+                p.copy_(torch.rand(p.shape, generator=g) + 0.5 if "running_var" in n else torch.randn(p.shape, generator=g) * 0.2)
+    clf.to(dev).eval()
+    dims = [16, 32, 32, 64, 64, 128]
+    mods, c = [], 4
+    for h in dims:
+        mods.append(tnn.Sequential(tnn.Conv2d(c, h, 3, stride=2, padding=1), tnn.BatchNorm2d(h), tnn.LeakyReLU()))
+        c = h
+    ref = tnn.ModuleDict({"encoder": tnn.Sequential(*mods), "fc_mu": tnn.Linear(512, 512), "fc_var": tnn.Linear(512, 512), "fc": tnn.Linear(512, 1)})
+    ref.load_state_dict({k: v.detach().cpu().contiguous() for k, v in clf.state_dict().items()})       # same keys, same shapes
+    ref.double().eval()
+    x = torch.randn(6, 4, 128, 128, generator=g)
+    with torch.no_grad():
+        want = ref["fc"](torch.flatten(ref["encoder"](x.double()), 1))
+        got = clf(x.to(dev))
+    assert got.shape == (6, 1)
+    assert (got.cpu().double() - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())

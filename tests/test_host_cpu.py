@@ -150,3 +150,23 @@ def test_loss_second_moment_resampler():
     idx, w = s.sample(64, "cpu")
     p = want / want.sum()
     assert idx.dtype == torch.int64 and np.allclose(w.numpy(), 1 / (4 * p[idx.numpy()]), rtol=1e-6)
+
+
+def test_metrics_dci_and_mcc_on_known_representations():
+    """causaldiffae_amd.metrics (the `mt._compute_dci` / `mt.MCC` surface of the reference's evaluation script): a representation that
+    is a permutation of the factors is perfectly disentangled and complete; a fully mixed one is not."""
+    import numpy as np
+    from improved_diffusion import metrics as mt
+    rng = np.random.RandomState(0)
+    ys = rng.randint(0, 5, size=(3, 400)).astype(np.float64)             # [factors, points]
+    clean = ys[[2, 0, 1]] + 0.01 * rng.randn(3, 400)                      # each code = one factor
+    mixed = np.stack([ys.sum(0), ys.sum(0) + 0.01 * rng.randn(400), ys.sum(0) - 0.01 * rng.randn(400)])
+    s, imp, share = mt._compute_dci(clean[:, :300], ys[:, :300], clean[:, 300:], ys[:, 300:])
+    assert imp.shape == (3, 3) and abs(share.sum() - 1) < 1e-9
+    assert s["disentanglement"] > 0.95 and s["completeness"] > 0.95
+    s2, _, _ = mt._compute_dci(mixed[:, :300], ys[:, :300], mixed[:, 300:], ys[:, 300:])
+    assert s2["disentanglement"] < 0.5
+    assert set(s) == {"informativeness_train", "informativeness_test", "disentanglement", "completeness"}
+    z = rng.randn(500, 4)
+    assert mt.MCC(z, z[:, [3, 1, 0, 2]] * np.array([1.0, -2.0, 0.5, 3.0])) > 0.999
+    assert mt.MCC(z, rng.randn(500, 4)) < 0.3
