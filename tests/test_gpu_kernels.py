@@ -589,6 +589,8 @@ def _wgrad_ref(a, dy):
     (3, 32, 32, 128, 128, 0),      # split-K over pixel ranges that start inside an image
     (2, 64, 64, 64, 64, 1),        # one image row per step, widest ring
     (4, 16, 8, 64, 64, 0),         # non-square image (H != W)
+    (2, 16, 16, 640, 384, 0),      # skip-concatenation widths: 10 x 6 channel tiles
+    (1, 8, 8, 1024, 512, 1),       # widest layer of the network, a single image
 ])
 def test_wgrad_window_kernel_matches_fp64(N, H, W, Cin, Cout, accumulate):
     """cdae_conv3x3_wgrad_win (LDS-ring window, transpose-read fragments, bf16 hi/lo planes) against autograd in fp64; operands are
@@ -660,7 +662,8 @@ def _gnconv_case(N, C, Cout, H, ss_on, res_on, mode):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,C,Cout,H,ss_on,res_on", [(4, 128, 128, 64, True, True), (8, 256, 256, 32, False, False), (8, 384, 384, 16, True, True),
-                                                     (16, 512, 512, 8, True, False), (2, 128, 256, 32, True, True)])
+                                                     (16, 512, 512, 8, True, False), (2, 128, 256, 32, True, True), (3, 896, 384, 16, True, True),
+                                                     (1, 1024, 512, 8, False, True)])
 def test_fused_gn_conv_training_node(N, C, Cout, H, ss_on, res_on):
     """ops.gn_conv3x3 (GroupNorm -> SiLU -> conv3x3 as one autograd node on the pre-split kernels: f16-plane forward, bf16-plane
     dgrad on the window kernel, LDS-ring wgrad) against torch autograd in fp64, and no worse than the separate-node path."""
