@@ -70,7 +70,13 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void wgwin_kernel(const Wg
     const int kg = wave >> 2;                          // K group (NWAVES = 8): 16-pixel sub-steps 2 kg, 2 kg + 1 of every step
     constexpr int SKN = NWAVES == 8 ? 2 : 4;
     const int nci = p.Cin >> 6, nco = p.Cout >> 6;
-    int b = blockIdx.x;
+    // blocks b and b + 8 run on the same XCD (and share its L2): give every XCD a contiguous run of virtual ids, so that the channel
+    // tiles of one pixel range — which read the same dy / activation rows — meet in one L2
+    int b;
+    {
+        const unsigned G = gridDim.x, bb = blockIdx.x, q = G >> 3, r = G & 7, x = bb & 7;
+        b = (int)((x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bb >> 3));
+    }
     const int cit = b % nci; b /= nci;
     const int cot = b % nco; b /= nco;
     const int ks = b;
