@@ -14,6 +14,42 @@ def create_named_schedule_sampler(name, diffusion):
     raise NotImplementedError(f"unknown schedule sampler: {name}")
 
 
+class _PinnedRing:
+    """Host staging for the per-step timestep / weight uploads.  `from_numpy(x).to(cuda)` copies from pageable memory, which blocks
+    the host until the stream has drained — every training step then starts with an empty launch queue.  A small ring of pinned
+    buffers and `copy_(non_blocking=True)` keeps the upload asynchronous; a slot is reused only after its own copy has completed."""
+
+    def __init__(self, depth=8):
+        self.depth, self.slots, self.next = depth, {}, 0
+
+    def upload(self, arr, device):
+        key = (arr.dtype.str, arr.shape)
+        ring = self.slots.get(key)
+        if ring is None:
+            ring = self.slots[key] = [[th.empty(arr.shape, dtype=th.from_numpy(arr[:0]).dtype).pin_memory(), None] for _ in range(self.depth)]
+        self.next = (self.next + 1) % self.depth
+        buf, ev = ring[self.next]
+        if ev is not None:
+            ev.synchronize()
+        buf.numpy()[...] = arr
+        out = th.empty(arr.shape, dtype=buf.dtype, device=device)
+        out.copy_(buf, non_blocking=True)
+        ev = th.cuda.Event()
+        ev.record()
+        ring[self.next][1] = ev
+        return out
+
+
+_RING = _PinnedRing()
+
+
+def _upload(arr, device):
+    """numpy -> device tensor; asynchronous on CUDA devices (see _PinnedRing), plain conversion elsewhere."""
+    if th.device(device).type != "cuda":
+        return th.from_numpy(np.ascontiguousarray(arr)).to(device)
+    return _RING.upload(np.ascontiguousarray(arr), device)
+
+
 class ScheduleSampler(ABC):
     @abstractmethod
     def weights(self):
@@ -26,7 +62,7 @@ class ScheduleSampler(ABC):
         p = w / np.sum(w)
         idx = np.random.choice(len(p), size=(batch_size,), p=p)
         weights = 1 / (len(p) * p[idx])
-        return th.from_numpy(idx).long().to(device), th.from_numpy(weights).float().to(device)
+        return _upload(idx.astype(np.int64, copy=False), device), _upload(weights.astype(np.float32), device)
 
 
 class UniformSampler(ScheduleSampler):
