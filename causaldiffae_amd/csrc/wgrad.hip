@@ -192,17 +192,29 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void wgwin_kernel(const Wg
                 dh[0] = dh[1]; dh[0][0] &= mL[ski]; dl[0] = dl[1]; dl[0][0] &= mL[ski];
                 dh[2] = dh[1]; dh[2][3] &= mR[ski]; dl[2] = dl[1]; dl[2][3] &= mR[ski];
                 if (do_colsum) { accb = mma(dh[1], ones, accb); accb = mma(dl[1], ones, accb); }
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int ky = t / 3, kx = t - 3 * ky;
-                    int rt = row_own + (ky - 1) * p.W + (kx - 1) + 16 * sk;
+                // software pipeline over the taps: tap t + 1's fragments are requested BEFORE tap t's MFMAs are issued (left to itself
+                // hipcc reads each fragment right in front of its first use and waits for it: MFMA busy 0.44)
+                auto tap_src = [&](int t) -> const char* {
+                    int rt = row_own + (t / 3 - 1) * p.W + (t % 3 - 1) + 16 * sk;
                     rt = rt < 0 ? rt + ring : rt;
                     rt = rt >= ring ? rt - ring : rt;
-                    const char* src = a_hi + rt * 64;
-                    const u32x4 ah = frag(src), al = frag(src + 2 * A_SUB);
-                    acc[t] = mma(dl[kx], ah, acc[t]);
-                    acc[t] = mma(dh[kx], al, acc[t]);
-                    acc[t] = mma(dh[kx], ah, acc[t]);
+                    return a_hi + rt * 64;
+                };
+                u32x4 fh[3], fl[3];                        // fragment sets of taps t, t + 1, t + 2 (two taps = 6 MFMAs of lookahead)
+                fh[0] = frag(tap_src(0)); fl[0] = frag(tap_src(0) + 2 * A_SUB);
+                fh[1] = frag(tap_src(1)); fl[1] = frag(tap_src(1) + 2 * A_SUB);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int kx = t % 3;
+                    if (t + 2 < 9) {
+                        const char* src = tap_src(t + 2);
+                        fh[(t + 2) % 3] = frag(src); fl[(t + 2) % 3] = frag(src + 2 * A_SUB);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[t] = mma(dl[kx], fh[t % 3], acc[t]);
+                    acc[t] = mma(dh[kx], fl[t % 3], acc[t]);
+                    acc[t] = mma(dh[kx], fh[t % 3], acc[t]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             // ---- advance
