@@ -27,4 +27,4 @@ pr = cProfile.Profile()
 t0 = time.perf_counter(); c0 = time.process_time()
 pr.enable(); steps(10); pr.disable()
 print("wall ms/step", 100 * (time.perf_counter() - t0), "cpu ms/step", 100 * (time.process_time() - c0))
-pstats.Stats(pr).sort_stats("tottime").print_stats(22)
+st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(30)
