@@ -57,6 +57,8 @@ SIGNATURES = {
     "cdae_gn_stats": [P, I, I, I, I, I, F, P, P, P, P],
     "cdae_gn_apply": [P, P, I, I, I, I, I, I, P, P, P, P, P, I, I, P],
     "cdae_gn_bwd": [P, P, P, I, I, I, I, I, I, I, P, P, P, P, P, I, I, P, P, I, P, I, I, P, P],
+    "cdae_gn_apply_split_train2": [P, I, P, I, I, P, P, P, P, I, I, I, I, I, P, P, P, P, P, I, I, P],
+    "cdae_gn_bwd_cat": [P, I, P, I, I, P, I, P, I, P, I, I, I, I, I, P, P, P, P, P, I, I, P, P, I, P, I, I, P, P],
     "cdae_gn_bwd_ex": [P, P, P, I, I, I, I, I, I, I, P, P, P, P, P, I, I, P, P, I, P, I, I, P, I, P, P, P, P],
     "cdae_bn_workspace_floats": [I],
     "cdae_bn_lrelu_fwd": [P, P, L, I, P, P, P, P, I, F, F, F, P, P, P, P, P, P],

@@ -252,7 +252,8 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               const float* __restrict__ ss, int ld_ss, int do_silu,
                                                               float* __restrict__ gpart /*[N][nchunk][G][2]*/,
-                                                              float* __restrict__ cpart /*[N][nchunk][C][4]*/) {
+                                                              float* __restrict__ cpart /*[N][nchunk][C][4]*/,
+                                                              const float* __restrict__ x2 = nullptr, int ld2 = 0, int C1 = 0) {
     __shared__ float sA[256], sB[256];
     __shared__ float sC[256 * 4 * 4];          // per thread VEC x 4 channel sums (only when rows > 1)
     const int n = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
@@ -274,15 +275,17 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
             sh[i] = ss ? ss[(long)n * ld_ss + C + c + i] : 0.f;
         }
         const int p0 = chunk * pix_per_block, p1 = min(HW, p0 + pix_per_block);
+        int ldxe;                                   // this thread's channel vector lives in one of the two sources (skip concatenation)
+        const float* const xb = gn_src(x, ldx, x2, ld2, C1, (long)n * HW, c, ldxe);
         for (int p = p0 + r; p < p1; p += rows) {
             const long pix = (long)n * HW + p;
             float xv[VEC], dv[VEC];
             if (VEC == 4) {
-                float4 t = *reinterpret_cast<const float4*>(x + pix * ldx + c);
+                float4 t = *reinterpret_cast<const float4*>(xb + (long)p * ldxe);
                 float4 d = *reinterpret_cast<const float4*>(dy + pix * lddy + c);
                 xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
                 dv[0] = d.x; dv[1] = d.y; dv[2] = d.z; dv[3] = d.w;
-            } else { xv[0] = x[pix * ldx + c]; dv[0] = dy[pix * lddy + c]; }
+            } else { xv[0] = xb[(long)p * ldxe]; dv[0] = dy[pix * lddy + c]; }
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
                 float xh = (xv[i] - mu) * rs;
@@ -410,7 +413,11 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const float* __restrict_
                                                          const float* __restrict__ ss, int ld_ss, int do_silu,
                                                          const float* __restrict__ gsum, int accumulate,
                                                          const float* __restrict__ dx_add = nullptr, int ld_add = 0,
-                                                         unsigned short* __restrict__ dxb_hi = nullptr, unsigned short* __restrict__ dxb_lo = nullptr) {
+                                                         unsigned short* __restrict__ dxb_hi = nullptr, unsigned short* __restrict__ dxb_lo = nullptr,
+                                                         const float* __restrict__ x2 = nullptr, int ld2 = 0, int C1 = 0,
+                                                         float* __restrict__ dx2 = nullptr, int lddx2 = 0) {
+    // x2 / dx2: channels [C1, C) of the normalised tensor live in a second source (the skip concatenation read in place); their
+    // gradient goes to dx2 [pixels][C - C1]
     // dx_add: a second gradient of the same tensor (the ResBlock's residual path) added on the way out instead of by a separate
     // add kernel.  dxb_hi / dxb_lo (VEC == 4, dense [pixels][C]): the result also — or, with dx == nullptr, only — as bf16 hi/lo
     // planes, the operand format in which the preceding conv's dgrad / wgrad consume it.
@@ -421,12 +428,15 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const float* __restrict_
         const float mu = mean[n * G + g], rs = rstd[n * G + g];
         const float m1 = gsum[(n * G + g) * 2], m2 = gsum[(n * G + g) * 2 + 1];
         float xv[VEC], dv[VEC], o[VEC];
+        const bool second = x2 != nullptr && c >= C1;
+        const float* const xp = second ? x2 + pix * ld2 + (c - C1) : x + pix * ldx + c;
+        float* const dxp = dx == nullptr ? nullptr : (second ? dx2 + pix * lddx2 + (c - C1) : dx + pix * lddx + c);
         if (VEC == 4) {
-            float4 t = *reinterpret_cast<const float4*>(x + pix * ldx + c);
+            float4 t = *reinterpret_cast<const float4*>(xp);
             float4 d = *reinterpret_cast<const float4*>(dy + pix * lddy + c);
             xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
             dv[0] = d.x; dv[1] = d.y; dv[2] = d.z; dv[3] = d.w;
-        } else { xv[0] = x[pix * ldx + c]; dv[0] = dy[pix * lddy + c]; }
+        } else { xv[0] = *xp; dv[0] = dy[pix * lddy + c]; }
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             float gm = gamma[c + i];
@@ -441,9 +451,9 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const float* __restrict_
         }
         if (accumulate) {
             if (VEC == 4) {
-                float4 t = *reinterpret_cast<const float4*>(dx + pix * lddx + c);
+                float4 t = *reinterpret_cast<const float4*>(dxp);
                 o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
-            } else o[0] += dx[pix * lddx + c];
+            } else o[0] += *dxp;
         }
         if (dx_add) {
             if (VEC == 4) {
@@ -452,8 +462,8 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const float* __restrict_
             } else o[0] += dx_add[pix * ld_add + c];
         }
         if (dx) {
-            if (VEC == 4) *reinterpret_cast<float4*>(dx + pix * lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
-            else dx[pix * lddx + c] = o[0];
+            if (VEC == 4) *reinterpret_cast<float4*>(dxp) = make_float4(o[0], o[1], o[2], o[3]);
+            else *dxp = o[0];
         }
         if constexpr (VEC == 4) {
             if (dxb_hi) {
@@ -698,10 +708,35 @@ int cdae_gn_bwd(const float* x, const float* dy, float* dx, int N, int HW, int C
                           accumulate_params, d_scale_shift, ld_dss, accumulate_dx, nullptr, 0, nullptr, nullptr, ws, stream);
 }
 
+static int gn_bwd_impl(const float* x, const float* x2, int ld2, int C1, const float* dy, float* dx, float* dx2, int lddx2, int N, int HW, int C, int ldx,
+                       int lddy, int lddx, int groups, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                       const float* scale_shift, int ld_ss, int silu, float* dgamma, float* dbeta, int accumulate_params, float* d_scale_shift,
+                       int ld_dss, int accumulate_dx, const float* dx_add, int ld_add, unsigned short* dxb_hi, unsigned short* dxb_lo, float* ws,
+                       void* stream);
+
 int cdae_gn_bwd_ex(const float* x, const float* dy, float* dx, int N, int HW, int C, int ldx, int lddy, int lddx, int groups,
                    const float* mean, const float* rstd, const float* gamma, const float* beta, const float* scale_shift, int ld_ss, int silu,
                    float* dgamma, float* dbeta, int accumulate_params, float* d_scale_shift, int ld_dss, int accumulate_dx,
                    const float* dx_add, int ld_add, unsigned short* dxb_hi, unsigned short* dxb_lo, float* ws, void* stream) {
+    return gn_bwd_impl(x, nullptr, 0, C, dy, dx, nullptr, 0, N, HW, C, ldx, lddy, lddx, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, dgamma,
+                       dbeta, accumulate_params, d_scale_shift, ld_dss, accumulate_dx, dx_add, ld_add, dxb_hi, dxb_lo, ws, stream);
+}
+
+int cdae_gn_bwd_cat(const float* x1, int ld1, const float* x2, int ld2, int C1, const float* dy, int lddy, float* dx1, int lddx1, float* dx2, int lddx2,
+                    int N, int HW, int C, int groups, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                    const float* scale_shift, int ld_ss, int silu, float* dgamma, float* dbeta, int accumulate_params, float* d_scale_shift,
+                    int ld_dss, int accumulate_dx, float* ws, void* stream) {
+    if (!x2 || !dx1 || !dx2 || C1 <= 0 || C1 >= C || C1 % 4 || ld1 % 4 || ld2 % 4 || lddx1 % 4 || lddx2 % 4 || (C / groups) % 4)
+        return cdae_fail("gn_bwd_cat: two sources with 4-channel aligned widths and pitches required");
+    return gn_bwd_impl(x1, x2, ld2, C1, dy, dx1, dx2, lddx2, N, HW, C, ld1, lddy, lddx1, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, dgamma,
+                       dbeta, accumulate_params, d_scale_shift, ld_dss, accumulate_dx, nullptr, 0, nullptr, nullptr, ws, stream);
+}
+
+static int gn_bwd_impl(const float* x, const float* x2, int ld2, int C1, const float* dy, float* dx, float* dx2, int lddx2, int N, int HW, int C, int ldx,
+                       int lddy, int lddx, int groups, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                       const float* scale_shift, int ld_ss, int silu, float* dgamma, float* dbeta, int accumulate_params, float* d_scale_shift,
+                       int ld_dss, int accumulate_dx, const float* dx_add, int ld_add, unsigned short* dxb_hi, unsigned short* dxb_lo, float* ws,
+                       void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (!dx && !dxb_hi) return cdae_fail("gn_bwd: no output for dx");
     if ((dxb_hi != nullptr) != (dxb_lo != nullptr)) return cdae_fail("gn_bwd: both bf16 planes or none");
@@ -720,13 +755,13 @@ int cdae_gn_bwd_ex(const float* x, const float* dy, float* dx, int N, int HW, in
     float* ncp = gsum + (size_t)N * groups * 2;
     const long total = (long)N * HW * E;
     cdae_prof_begin(PROF_GN, (double)N * HW * C * 20.0, st);
-    if (VEC == 4) hipLaunchKernelGGL(gn_bwd_partial_kernel<4>, dim3(nchunk, N), dim3(256), 0, st, x, dy, HW, C, ldx, lddy, cpg, groups, ppb, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gpart, cpart);
-    else hipLaunchKernelGGL(gn_bwd_partial_kernel<1>, dim3(nchunk, N), dim3(256), 0, st, x, dy, HW, C, ldx, lddy, cpg, groups, ppb, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gpart, cpart);
+    if (VEC == 4) hipLaunchKernelGGL(gn_bwd_partial_kernel<4>, dim3(nchunk, N), dim3(256), 0, st, x, dy, HW, C, ldx, lddy, cpg, groups, ppb, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gpart, cpart, x2, ld2, C1);
+    else hipLaunchKernelGGL(gn_bwd_partial_kernel<1>, dim3(nchunk, N), dim3(256), 0, st, x, dy, HW, C, ldx, lddy, cpg, groups, ppb, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gpart, cpart, x2, ld2, C1);
     hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3((C + 63) / 64 + 1, N), dim3(256), 0, st, N, HW, C, cpg, groups, nchunk, gpart, cpart, gsum, d_scale_shift, ld_dss, ncp);
     if (N >= 8) hipLaunchKernelGGL(gn_bwd_param8_kernel, dim3((C + 31) / 32), dim3(256), 0, st, N, C, ncp, dgamma, dbeta, accumulate_params);
     else hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, st, N, C, ncp, dgamma, dbeta, accumulate_params);
-    if (VEC == 4) hipLaunchKernelGGL(gn_bwd_dx_kernel<4>, dim3(grid_for(total)), dim3(256), 0, st, x, dy, dx, total, HW, C, ldx, lddy, lddx, cpg, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gsum, accumulate_dx, dx_add, ld_add, dxb_hi, dxb_lo);
-    else hipLaunchKernelGGL(gn_bwd_dx_kernel<1>, dim3(grid_for(total)), dim3(256), 0, st, x, dy, dx, total, HW, C, ldx, lddy, lddx, cpg, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gsum, accumulate_dx, dx_add, ld_add);
+    if (VEC == 4) hipLaunchKernelGGL(gn_bwd_dx_kernel<4>, dim3(grid_for(total)), dim3(256), 0, st, x, dy, dx, total, HW, C, ldx, lddy, lddx, cpg, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gsum, accumulate_dx, dx_add, ld_add, dxb_hi, dxb_lo, x2, ld2, C1, dx2, lddx2);
+    else hipLaunchKernelGGL(gn_bwd_dx_kernel<1>, dim3(grid_for(total)), dim3(256), 0, st, x, dy, dx, total, HW, C, ldx, lddy, lddx, cpg, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gsum, accumulate_dx, dx_add, ld_add, nullptr, nullptr, x2, ld2, C1, dx2, lddx2);
     cdae_prof_end(PROF_GN, st);
     CHECK_LAUNCH("gn_bwd launch failed");
     return 0;
@@ -819,6 +854,13 @@ int cdae_gn_apply_split_train(const float* x, unsigned short* y_hi, unsigned sho
                               const float* beta, const float* scale_shift, int ld_ss, int silu, void* stream) {
     if (!yb_hi || !yb_lo) return cdae_fail("gn_apply_split_train: both bf16 planes required");
     return gn_apply_split_impl(x, ldx, nullptr, 0, C, y_hi, y_lo, yb_hi, yb_lo, N, HW, C, ldy, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, stream);
+}
+
+int cdae_gn_apply_split_train2(const float* x1, int ld1, const float* x2, int ld2, int C1, unsigned short* y_hi, unsigned short* y_lo,
+                               unsigned short* yb_hi, unsigned short* yb_lo, int N, int HW, int C, int ldy, int groups, const float* mean,
+                               const float* rstd, const float* gamma, const float* beta, const float* scale_shift, int ld_ss, int silu, void* stream) {
+    if (!yb_hi || !yb_lo) return cdae_fail("gn_apply_split_train2: both bf16 planes required");
+    return gn_apply_split_impl(x1, ld1, x2, ld2, C1, y_hi, y_lo, yb_hi, yb_lo, N, HW, C, ldy, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, stream);
 }
 
 static int gn_apply_split_impl(const float* x, int ldx, const float* x2, int ld2, int C1, unsigned short* y_hi, unsigned short* y_lo,

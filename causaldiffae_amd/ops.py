@@ -420,9 +420,15 @@ class CatAct:
         self.shape = (a.shape[0], a.shape[1] + b.shape[1], a.shape[2], a.shape[3])
 
 
+_TRAIN_CAT_ON = os.environ.get("CDAE_TRAIN_CAT", "1") != "0"      # dev switch: 0 = materialise the skip concatenation in training
+
+
 def cat_channels(a, b):
     if presplit_ok() and a.dim() == 4 and a.shape[1] % 4 == 0 and b.shape[1] % 4 == 0:
         return CatAct(to_nhwc(a), to_nhwc(b))
+    if (_TRAIN_CAT_ON and _TRAIN_PS_ON and _RBNODE_ON and torch.is_grad_enabled() and (a.requires_grad or b.requires_grad) and a.dim() == 4 and a.shape[1] % 32 == 0 and b.shape[1] % 32 == 0
+            and a.dtype == torch.float32 and b.dtype == torch.float32):
+        return CatAct(to_nhwc(a), to_nhwc(b))          # consumed in place by ops.resblock_train (the ResBlock materialises it otherwise)
     return _Cat.apply(a, b)
 
 
@@ -1134,18 +1140,26 @@ def gn_conv3x3(x, gamma, beta, scale_shift, w, b=None, res=None, silu=True, grou
     return _GNConvPS.apply(x, gamma, beta, scale_shift, w, b, res, silu, groups, eps, sink)
 
 
-def _rb_gn_planes(x, gamma, beta, ss, silu, groups, eps, st):
-    """GroupNorm statistics + (scale-shift, SiLU) written as f16 planes (forward conv operand) and bf16 planes (kept for wgrad)."""
-    N, C, H, W = x.shape
+def _rb_gn_planes(x, gamma, beta, ss, silu, groups, eps, st, x2=None):
+    """GroupNorm statistics + (scale-shift, SiLU) written as f16 planes (forward conv operand) and bf16 planes (kept for wgrad).
+    x2: the second source of a skip concatenation read in place (channels [C1, C))."""
+    N, C1, H, W = x.shape
+    C = C1 + (0 if x2 is None else x2.shape[1])
     dev = x.device
     stats = torch.empty((2, N, groups), dtype=torch.float32, device=dev)
     gws = workspace(dev, "gn", 4 * lib.cdae_gn_workspace_floats(N, C))
-    check(lib.cdae_gn_stats(ptr(x), N, H * W, C, C, groups, eps, ptr(stats[0]), ptr(stats[1]), ptr(gws), st))
     planes = torch.empty((2, N, H, W, C), dtype=torch.float16, device=dev)
     bplanes = torch.empty((2, N, H, W, C), dtype=torch.bfloat16, device=dev)
-    check(lib.cdae_gn_apply_split_train(ptr(x), ptr(planes[0]), ptr(planes[1]), ptr(bplanes[0]), ptr(bplanes[1]), N, H * W, C, C, C, groups,
-                                        ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta), ptr(ss), 2 * C if ss is None else ss.stride(0),
-                                        1 if silu else 0, st))
+    ld_ss = 2 * C if ss is None else ss.stride(0)
+    if x2 is None:
+        check(lib.cdae_gn_stats(ptr(x), N, H * W, C, C, groups, eps, ptr(stats[0]), ptr(stats[1]), ptr(gws), st))
+        check(lib.cdae_gn_apply_split_train(ptr(x), ptr(planes[0]), ptr(planes[1]), ptr(bplanes[0]), ptr(bplanes[1]), N, H * W, C, C, C, groups,
+                                            ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta), ptr(ss), ld_ss, 1 if silu else 0, st))
+    else:
+        C2 = C - C1
+        check(lib.cdae_gn_stats2(ptr(x), C1, ptr(x2), C2, C1, N, H * W, C, groups, eps, ptr(stats[0]), ptr(stats[1]), ptr(gws), st))
+        check(lib.cdae_gn_apply_split_train2(ptr(x), C1, ptr(x2), C2, C1, ptr(planes[0]), ptr(planes[1]), ptr(bplanes[0]), ptr(bplanes[1]), N, H * W, C,
+                                             C, groups, ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta), ptr(ss), ld_ss, 1 if silu else 0, st))
     return stats, planes, bplanes
 
 
@@ -1193,28 +1207,37 @@ class _ResBlockPS(Function):
     two halves leaves GN2's backward directly as the bf16 planes conv1's dgrad / wgrad consume (no fp32 copy, no split pass)."""
 
     @staticmethod
-    def forward(ctx, x, ss, ss_sink, g1, b1, w1, c1b, g2, b2, w2, c2b, sw, sb, groups, eps):
+    def forward(ctx, x, ss, ss_sink, g1, b1, w1, c1b, g2, b2, w2, c2b, sw, sb, groups, eps, x2=None):
+        # x2: the block input is the skip concatenation [x | x2] (reference unet.py:628), read in place by the first GroupNorm and the 1x1
+        # skip conv — the concatenated tensor and its four copies per step (forward and backward) do not exist
         x = to_nhwc(x)
-        N, C, H, W = x.shape
+        N, C1, H, W = x.shape
+        if x2 is not None:
+            x2 = to_nhwc(x2)
+        C = C1 + (0 if x2 is None else x2.shape[1])
         Cout = w1.shape[0]
         st = stream()
         dev = x.device
         w1_in, w2_in, w1, w2 = w1, w2, ohwi(w1), ohwi(w2)
-        stats1, planes, bplanes1 = _rb_gn_planes(x, g1, b1, None, True, groups, eps, st)
+        stats1, planes, bplanes1 = _rb_gn_planes(x, g1, b1, None, True, groups, eps, st, x2)
         h = _rb_conv(planes, w1, c1b, None, (N, C, H, W), Cout, st)
         if ss is not None:
             assert ss.shape == (N, 2 * Cout) and ss.stride(1) == 1 and ss.dtype == torch.float32
         stats2, planes, bplanes2 = _rb_gn_planes(h, g2, b2, ss, True, groups, eps, st)
         if sw is None:
+            assert x2 is None
             skip = x
         else:                               # 1x1 skip conv on the NHWC rows
             skip = new_act(N, Cout, H, W, dev)
             ws, wsb = _sk(dev)
-            check(lib.cdae_linear_fwd(ptr(x), C, ptr(sw), C, ptr(sb), None, ptr(skip), Cout, None, None, N * H * W, Cout, C, 1.0, ACT_NONE,
-                                      ws, wsb, st))
+            if x2 is None:
+                check(lib.cdae_linear_fwd(ptr(x), C, ptr(sw), C, ptr(sb), None, ptr(skip), Cout, None, None, N * H * W, Cout, C, 1.0, ACT_NONE,
+                                          ws, wsb, st))
+            else:
+                check(lib.cdae_linear_fwd_cat(ptr(x), C1, C1, ptr(x2), C - C1, ptr(sw), C, ptr(sb), ptr(skip), Cout, N * H * W, Cout, C, ws, wsb, st))
         out = _rb_conv(planes, w2, c2b, skip, (N, Cout, H, W), Cout, st)
         del planes
-        ctx.save_for_backward(x, h, ss, stats1, stats2, bplanes1, bplanes2, g1, b1, w1, g2, b2, w2, sw)
+        ctx.save_for_backward(x, h, ss, stats1, stats2, bplanes1, bplanes2, g1, b1, w1, g2, b2, w2, sw, x2)
         ctx.cfg = (groups, c1b is not None, c2b is not None, sb is not None)
         ctx.sinks = (_sink(g1), _sink(b1), _sink(w1_in), _sink(c1b), _sink(g2), _sink(b2), _sink(w2_in), _sink(c2b), _sink(sw), _sink(sb))
         ctx.ss_sink = ss_sink if ss is not None else None
@@ -1222,10 +1245,11 @@ class _ResBlockPS(Function):
 
     @staticmethod
     def backward(ctx, dout):
-        x, h, ss, stats1, stats2, bplanes1, bplanes2, g1, b1, w1, g2, b2, w2, sw = ctx.saved_tensors
+        x, h, ss, stats1, stats2, bplanes1, bplanes2, g1, b1, w1, g2, b2, w2, sw, x2 = ctx.saved_tensors
         groups, has_c1b, has_c2b, has_sb = ctx.cfg
         sg1, sb1, sw1, sc1b, sg2, sb2, sw2, sc2b, ssw, ssb = ctx.sinks
-        N, C, H, W = x.shape
+        N, C1, H, W = x.shape
+        C = C1 + (0 if x2 is None else x2.shape[1])
         Cout = w1.shape[0]
         dev = x.device
         st = stream()
@@ -1261,24 +1285,46 @@ class _ResBlockPS(Function):
         # ---- first half: conv1, then GN1 with the residual gradient folded in
         dyn1, dw1, dc1b = _rb_conv_bwd(bplanes1, dplanes, w1, (sw1, sc1b), has_c1b, (N, C, H, W), Cout, need[5], st)
         del dplanes
-        dsw = dsb = None
+        dsw = dsb = dx2 = None
         if sw is None:
             dx = new_act(N, C, H, W, dev)
             dg1, db1, _ = gn_bwd(x, dyn1, stats1, g1, b1, None, (sg1, sb1), C, dx, False, dout, None)
         else:
             M = N * H * W
-            dx = new_act(N, C, H, W, dev)
-            check(lib.cdae_linear_dgrad(ptr(dout), Cout, ptr(sw), C, ptr(dx), C, M, Cout, C, 0, ws, wsb, st))
-            dg1, db1, _ = gn_bwd(x, dyn1, stats1, g1, b1, None, (sg1, sb1), C, dx, True, None, None)
             (gsw, rsw), (gsb, rsb) = ssw, ssb
             direct = gsw is not None and gsw.is_contiguous() and (not has_sb or gsb is not None)
             dsw = gsw if direct else torch.empty_like(sw)
             dsb = (gsb if direct else torch.empty(Cout, dtype=torch.float32, device=dev)) if has_sb else None
-            check(lib.cdae_linear_wgrad(ptr(x), C, ptr(dout), Cout, ptr(dsw), C, ptr(dsb), M, Cout, C, 1 if direct else 0, ws, wsb, st))
+            acc = 1 if direct else 0
+            if x2 is None:
+                dx = new_act(N, C, H, W, dev)
+                check(lib.cdae_linear_dgrad(ptr(dout), Cout, ptr(sw), C, ptr(dx), C, M, Cout, C, 0, ws, wsb, st))
+                dg1, db1, _ = gn_bwd(x, dyn1, stats1, g1, b1, None, (sg1, sb1), C, dx, True, None, None)
+                check(lib.cdae_linear_wgrad(ptr(x), C, ptr(dout), Cout, ptr(dsw), C, ptr(dsb), M, Cout, C, acc, ws, wsb, st))
+            else:
+                # two sources: the skip conv's dgrad / wgrad column ranges go to / come from the two tensors, then the first GroupNorm's
+                # backward accumulates onto both
+                C2 = C - C1
+                dx, dx2 = new_act(N, C1, H, W, dev), new_act(N, C2, H, W, dev)
+                check(lib.cdae_linear_dgrad(ptr(dout), Cout, ptr(sw), C, ptr(dx), C1, M, Cout, C1, 0, ws, wsb, st))
+                check(lib.cdae_linear_dgrad(ptr(dout), Cout, sw.data_ptr() + 4 * C1, C, ptr(dx2), C2, M, Cout, C2, 0, ws, wsb, st))
+                (gg, rg), (gb_, rb_) = sg1, sb1
+                dirn = gg is not None and gb_ is not None
+                dg1 = gg if dirn else torch.empty_like(g1)
+                db1 = gb_ if dirn else torch.empty_like(b1)
+                gws = workspace(dev, "gn", 4 * lib.cdae_gn_workspace_floats(N, C))
+                check(lib.cdae_gn_bwd_cat(ptr(x), C1, ptr(x2), C2, C1, ptr(dyn1), C, ptr(dx), C1, ptr(dx2), C2, N, H * W, C, groups, ptr(stats1[0]),
+                                          ptr(stats1[1]), ptr(g1), ptr(b1), None, 2 * C, 1, ptr(dg1), ptr(db1), 1 if dirn else 0, None, 2 * C, 1,
+                                          ptr(gws), st))
+                if dirn:
+                    dg1 = db1 = None
+                    _done(rg, rb_)
+                check(lib.cdae_linear_wgrad(ptr(x), C1, ptr(dout), Cout, ptr(dsw), C, ptr(dsb), M, Cout, C1, acc, ws, wsb, st))
+                check(lib.cdae_linear_wgrad(ptr(x2), C2, ptr(dout), Cout, dsw.data_ptr() + 4 * C1, C, None, M, Cout, C2, acc, ws, wsb, st))
             if direct:
                 dsw = dsb = None
                 _done(rsw, rsb if has_sb else None)
-        return dx, dss, None, dg1, db1, dw1, dc1b, dg2, db2, dw2, dc2b, dsw, dsb, None, None
+        return dx, dss, None, dg1, db1, dw1, dc1b, dg2, db2, dw2, dc2b, dsw, dsb, None, None, dx2
 
 
 _RBNODE_ON = os.environ.get("CDAE_TRAIN_RBNODE", "1") != "0"      # dev switch: 0 = two fused GN-conv nodes per ResBlock
@@ -1289,6 +1335,10 @@ def resblock_node_ok():
 
 
 def resblock_train(x, ss, g1, b1, w1, c1b, g2, b2, w2, c2b, sw=None, sb=None, groups=32, eps=1e-5):
+    """x: a tensor, or a CatAct (the skip concatenation read in place; needs the 1x1 skip conv)."""
+    x2 = None
+    if isinstance(x, CatAct):
+        x, x2 = x.a, x.b
     sink = getattr(ss, "_dss_sink", None) if ss is not None else None
     if ss is not None and ss.stride(-1) != 1:
         ss, sink = ss.contiguous(), None
@@ -1298,7 +1348,7 @@ def resblock_train(x, ss, g1, b1, w1, c1b, g2, b2, w2, c2b, sw=None, sb=None, gr
         if gv is not None:
             w2d._grad_view, w2d._grad_ready = gv.reshape(sw.shape[0], -1), getattr(sw, "_grad_ready", None)
         sw = w2d
-    return _ResBlockPS.apply(x, ss, sink, g1, b1, w1, c1b, g2, b2, w2, c2b, sw, sb, groups, eps)
+    return _ResBlockPS.apply(x, ss, sink, g1, b1, w1, c1b, g2, b2, w2, c2b, sw, sb, groups, eps, x2)
 
 
 class _EmbAllTrain(Function):

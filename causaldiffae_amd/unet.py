@@ -138,13 +138,17 @@ class ResBlock(TimestepBlock):
     def _train_fused(self, x):
         """Grad-mode fast path: both GroupNorm -> SiLU -> conv3x3 chains as fused nodes on the pre-split kernels."""
         n1, c1, n2, c2 = self.in_layers[0], self.in_layers[2], self.out_layers[0], self.out_layers[3]
-        return ((self.dropout == 0 or not self.training) and not isinstance(x, ops.CatAct) and x.dim() == 4
+        if isinstance(x, ops.CatAct):      # the concatenation is read in place only by the whole-block node with a 1x1 skip conv
+            if not (self.use_scale_shift_norm and ops.resblock_node_ok() and isinstance(self.skip_connection, ConvNd) and self.skip_connection.kernel_size == 1):
+                return False
+        return ((self.dropout == 0 or not self.training) and len(x.shape) == 4
                 and ops.train_presplit_ok(x, c1.out_channels, n1.num_groups)
                 and ops.train_presplit_ok((x.shape[0], c1.out_channels, x.shape[2], x.shape[3]), c2.out_channels, n2.num_groups))
 
     def _forward_train(self, x, emb):
         n1, c1, n2, c2 = self.in_layers[0], self.in_layers[2], self.out_layers[0], self.out_layers[3]
-        x = ops.to_nhwc(x)
+        if not isinstance(x, ops.CatAct):
+            x = ops.to_nhwc(x)
         emb_out = emb.slices[id(self)] if isinstance(emb, EmbAll) else self.emb_layers[1](ops.silu(emb))
         sk = self.skip_connection
         if self.use_scale_shift_norm and ops.resblock_node_ok() and (isinstance(sk, Identity) or sk.kernel_size == 1):
@@ -158,10 +162,13 @@ class ResBlock(TimestepBlock):
         return ops.gn_conv3x3(h + emb_out[:, :, None, None], n2.weight, n2.bias, None, c2.weight, c2.bias, skip, True, n2.num_groups, n2.eps)
 
     def _forward(self, x, emb):
+        if th.is_grad_enabled():
+            if self._train_fused(x):
+                return self._forward_train(x, emb)
+            if isinstance(x, ops.CatAct):
+                x = ops.materialize(x)                              # grad mode off the fused path: a real (differentiable) concatenation
         if not isinstance(x, ops.CatAct):                          # CatAct: the skip concatenation, read in place by GN and the 1x1 skip
             x = ops.to_nhwc(x)
-        if self._train_fused(x):
-            return self._forward_train(x, emb)
         h = self.in_layers[0](x, silu=True, split=True)            # GN + SiLU (pre-split f16 planes on the inference path)
         fast = isinstance(h, (ops.SplitAct, ops.LazyGN))
         h = self.in_layers[2](h, gn_stats=True) if fast else self.in_layers[2](h)     # conv3x3 + bias (+ GroupNorm partial sums)

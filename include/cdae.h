@@ -141,6 +141,16 @@ int cdae_conv3x3_dgrad(const float* dy, long lddy, const float* w, float* dx, lo
    NULL).  The activation window stays in an LDS ring (each pixel row fetched once per block, not once per tap), fragments by
    transpose reads, split-K over pixel ranges with a fixed-order reduction (wgrad.hip).  _supported: W a power of two in [8, 64],
    H*W % 64 == 0, Cin % 64 == 0, Cout % 64 == 0. */
+/* two-source forms for the skip concatenation in training (channels [0, C1) from x1, [C1, C) from x2; no concatenated tensor exists):
+   cdae_gn_apply_split_train2 = cdae_gn_apply_split_train over the two sources; cdae_gn_bwd_cat = cdae_gn_bwd reading x from the two
+   sources and writing (or accumulating onto) dx1 [pixels][C1] and dx2 [pixels][C - C1]. */
+int cdae_gn_apply_split_train2(const float* x1, int ld1, const float* x2, int ld2, int C1, unsigned short* y_hi, unsigned short* y_lo,
+                               unsigned short* yb_hi, unsigned short* yb_lo, int N, int HW, int C, int ldy, int groups, const float* mean,
+                               const float* rstd, const float* gamma, const float* beta, const float* scale_shift, int ld_ss, int silu, void* stream);
+int cdae_gn_bwd_cat(const float* x1, int ld1, const float* x2, int ld2, int C1, const float* dy, int lddy, float* dx1, int lddx1, float* dx2, int lddx2,
+                    int N, int HW, int C, int groups, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                    const float* scale_shift, int ld_ss, int silu, float* dgamma, float* dbeta, int accumulate_params, float* d_scale_shift,
+                    int ld_dss, int accumulate_dx, float* ws, void* stream);
 int cdae_gn_apply_split_train(const float* x, unsigned short* y_hi, unsigned short* y_lo, unsigned short* yb_hi, unsigned short* yb_lo, int N,
                               int HW, int C, int ldx, int ldy, int groups, const float* mean, const float* rstd, const float* gamma,
                               const float* beta, const float* scale_shift, int ld_ss, int silu, void* stream);

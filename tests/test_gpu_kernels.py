@@ -769,3 +769,47 @@ def test_wgrad_few_output_channels(N, H, W, Cin, Cout, accumulate):
         ref_w, ref_b = ref_w + dw0.double(), ref_b + db0.double()
     assert (dw.double() - ref_w).abs().max().item() < 2e-6 * ref_w.abs().max().item()
     assert (db.double() - ref_b).abs().max().item() < 2e-6 * ref_b.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C1,C2,Cout,H", [(4, 128, 128, 128, 32), (2, 256, 128, 256, 16), (3, 512, 384, 512, 8), (2, 128, 256, 128, 64)])
+def test_resblock_training_node_two_sources(N, C1, C2, Cout, H):
+    """ops.resblock_train on a CatAct: the skip concatenation th.cat([h, hs.pop()], dim=1) (unet.py:628) read in place by the first
+    GroupNorm and the 1x1 skip conv, its gradient written to the two tensors separately — against autograd in fp64 on a real cat."""
+    import torch.nn.functional as F
+    from causaldiffae_amd import ops
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(17)
+    cl = torch.channels_last
+    C = C1 + C2
+
+    def rnd(*shape, scale=1.0):
+        return torch.randn(*shape, device=dev, generator=g) * scale
+
+    a0, b0 = rnd(N, C1, H, H).contiguous(memory_format=cl), rnd(N, C2, H, H).contiguous(memory_format=cl)
+    ss0 = rnd(N, 2 * Cout, scale=0.2)
+    p0 = dict(g1=1 + rnd(C, scale=0.1), b1=rnd(C, scale=0.1), w1=(rnd(Cout, C, 3, 3) / (3 * C ** 0.5)).contiguous(memory_format=cl),
+              c1b=rnd(Cout, scale=0.1), g2=1 + rnd(Cout, scale=0.1), b2=rnd(Cout, scale=0.1),
+              w2=(rnd(Cout, Cout, 3, 3) / (3 * Cout ** 0.5)).contiguous(memory_format=cl), c2b=rnd(Cout, scale=0.1),
+              sw=rnd(Cout, C, 1, 1) / C ** 0.5, sb=rnd(Cout, scale=0.1))
+    dy = rnd(N, Cout, H, H).contiguous(memory_format=cl) * 1e-3
+    res = []
+    with torch.enable_grad():
+        for mode in ("f64", "node"):
+            dt = torch.float64 if mode == "f64" else torch.float32
+            a, b, ss = (t.detach().to(dt).requires_grad_() for t in (a0, b0, ss0))
+            p = {k: v.detach().to(dt).requires_grad_() for k, v in p0.items()}
+            if mode == "f64":
+                x = torch.cat([a, b], dim=1)
+                h = F.conv2d(F.silu(F.group_norm(x, 32, p["g1"], p["b1"], 1e-5)), p["w1"], p["c1b"], padding=1)
+                h = F.group_norm(h, 32, p["g2"], p["b2"], 1e-5) * (1 + ss[:, :Cout, None, None]) + ss[:, Cout:, None, None]
+                out = F.conv2d(F.silu(h), p["w2"], p["c2b"], padding=1) + F.conv2d(x, p["sw"], p["sb"])
+            else:
+                x = ops.cat_channels(a, b)
+                assert isinstance(x, ops.CatAct)
+                out = ops.resblock_train(x, ss, p["g1"], p["b1"], p["w1"], p["c1b"], p["g2"], p["b2"], p["w2"], p["c2b"], p["sw"], p["sb"])
+            out.backward(dy.to(dt))
+            res.append([out.detach(), a.grad, b.grad, ss.grad] + [p[k].grad for k in sorted(p)])
+    names = ["out", "da", "db", "dss"] + sorted(p0)
+    for n, r, f in zip(names, *res):
+        assert (f.double().reshape(r.shape) - r).abs().max().item() < 3e-5 * r.abs().max().item(), n
