@@ -266,6 +266,26 @@ int cdae_linear_fwd_cat(const float* x1, long ld1, int K1, const float* x2, long
     return cdae_gemm_dispatch(p, stream);
 }
 
+// cdae_linear_fwd_cat that ALSO writes GroupNorm(+SiLU)([x1 | x2]) as f16 hi/lo planes [M][K] while the rows pass through its loader:
+// the ResBlock's 1x1 skip conv and the normalisation pass of its first GroupNorm in one sweep over the block input.  coef [N][K][2]
+// from cdae_gn_coef; HW = pixels per image (rows per coefficient set).  x2 may be NULL (one source).
+int cdae_linear_fwd_cat_gn(const float* x1, long ld1, int K1, const float* x2, long ld2, const float* w, long ldw, const float* bias, float* y,
+                           long ldy, const float* coef, int silu, unsigned short* s_hi, unsigned short* s_lo, int M, int N, int K, int HW,
+                           float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    if ((x2 && K1 % 32) || K % 32 || ld1 % 4 || (x2 && ld2 % 4) || ldw % 4 || !aligned16(x1) || !aligned16(x2) || !aligned16(w) || !aligned16(coef) ||
+        !aligned16(s_hi) || !aligned16(s_lo) || !s_hi || !s_lo || !coef || HW <= 0 || M % HW)
+        return cdae_fail("linear_fwd_cat_gn: K (and K1) % 32 == 0, 16-byte aligned rows / planes / coefficients, M a multiple of HW required");
+    GemmParams p = base_params();
+    p.A = x1; p.A2 = x2; p.lda2 = ld2; p.K1 = x2 ? K1 : K; p.B = w; p.C = y; p.bias = bias;
+    p.M = M; p.N = N; p.K = K; p.lda = ld1; p.ldb = ldw; p.ldc = ldy;
+    p.amode = A_PLAIN_KC; p.bmode = B_PLAIN_KC;
+    p.gn_coef = coef; p.gn_silu = silu; p.S_hi = s_hi; p.S_lo = s_lo;
+    p.Ho = HW; p.Wo = 1;                       // image index of a row: fdiv(m, hw_magic) with hw = Ho * Wo
+    p.force_tile = 128;
+    set_splitk(p, nullptr, 0);                 // every (row, k) piece must pass exactly one n-tile-0 block; the grids that use this are full
+    return cdae_gemm_dispatch(p, stream);
+}
+
 int cdae_linear_dgrad(const float* dy, long lddy, const float* w, long ldw, float* dx, long lddx, int M, int N, int K, int accumulate,
                       float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
     GemmParams p = base_params();

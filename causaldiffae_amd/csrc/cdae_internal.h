@@ -54,6 +54,7 @@ struct GemmParams {
     // GEMM (K1 = channels of the first source) — and gn_coef [N][Cin][2] holds that norm folded to y = silu?(x * a + b) per
     // (image, channel); the kernel normalises, activates and splits each window chunk on its way into LDS
     const float* gn_coef; int gn_silu;
+    unsigned short* S_hi; unsigned short* S_lo;       // igemm_kernel GNS: side output, the GroupNorm (gn_coef, gn_silu) of the A operand as f16 planes [M][K]
     int dbg;                // dev ablations of ps_kernel (env CDAE_PS_DBG): 1 A rows -> one hot line, 2 B rows -> hot, 4 no loads after the first
     const unsigned short* A_lo; const unsigned short* B_lo;
 };

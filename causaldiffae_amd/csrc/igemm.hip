@@ -120,9 +120,15 @@ __device__ __forceinline__ void store_planes(const GemmParams& p, long addr, flo
 // K-contiguous operands: planes of [rows][32 x 16-bit] (64-B rows, 16-B chunks XOR-swizzled by (row>>2)&3), fragments
 // by one ds_read_b128.  k-major operands: planes of [32 k][rows+32] (coalesced 8-B stores), fragments by two
 // ds_read_b64_tr_b16 (hardware transpose read; the +32 pad makes both conflict-free).
-template <int BM, int BN, int AMODE, int BMODE, bool SCALAR, int WAVES_N = 2, int PREC = 0>
+// GNS (one instantiation: the 1x1 skip conv of a ResBlock, K-contiguous fp32 A, f16x3): the A operand is the RAW block input, which the
+// block's first GroupNorm reads as well — so while an A tile sits in registers on its way into LDS, the n-tile-0 blocks also apply that
+// GroupNorm (+SiLU; folded per (image, channel) coefficients p.gn_coef, bit-identical to gn_apply_kernel) and write the result as
+// f16 hi/lo planes (p.S_hi / p.S_lo, dense [M][K]): the separate normalisation pass over the tensor disappears.  The GEMM is
+// HBM-bound, the extra VALU work is free.
+template <int BM, int BN, int AMODE, int BMODE, bool SCALAR, int WAVES_N = 2, int PREC = 0, bool GNS = false>
 __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p) {
     static_assert(PREC == 0 || !SCALAR, "split precision is only built for vectorised loaders");
+    static_assert(!GNS || (AMODE == A_PLAIN_KC && PREC == 1 && !SCALAR), "the GroupNorm side output rides on the K-contiguous f16x3 loader");
     constexpr int NPL = (PREC == 1 || PREC == 2) ? 2 : 1;       // 16-bit planes per operand
     constexpr bool BF = (PREC == 2 || PREC == 4);               // bf16 (else f16) planes
     // 2 x WAVES_N waves; WAVES_N = 4 (512 threads, 64x32 per wave at 128x128) doubles the waves per SIMD that can
@@ -373,9 +379,34 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
     float4 colsum = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool do_colsum = A_MC && p.colsum_out != nullptr && nt == 0;
 
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, int kt_of = 0) {
         float* a = As + buf * A_TILE;
         float* b = Bs + buf * B_TILE;
+        if constexpr (GNS) {
+            if (nt == 0) {                                    // block-uniform: one column block per row tile writes the planes
+                const int k = kstart(kt_of) + (tid & 7) * 4;
+#pragma unroll
+                for (int q = 0; q < A_V4; ++q) {
+                    const int m = m0 + (tid >> 3) + RPP * q;
+                    if (m < p.M && k < p.K) {
+                        const int img = fdiv(m, p.hw_magic, p.hw_shift);
+                        const float4* cf = reinterpret_cast<const float4*>(p.gn_coef + ((long)img * p.K + k) * 2);
+                        const float4 c01 = cf[0], c23 = cf[1];                // a0 b0 a1 b1 | a2 b2 a3 b3
+                        float y0 = fmaf(areg[q].x, c01.x, c01.y), y1 = fmaf(areg[q].y, c01.z, c01.w);
+                        float y2 = fmaf(areg[q].z, c23.x, c23.y), y3 = fmaf(areg[q].w, c23.z, c23.w);
+                        if (p.gn_silu) { y0 = y0 / (1.f + expf(-y0)); y1 = y1 / (1.f + expf(-y1)); y2 = y2 / (1.f + expf(-y2)); y3 = y3 / (1.f + expf(-y3)); }
+                        asm volatile("" : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3));      // opaque before the split (attention.hip split8)
+                        half4 hi, lo;
+                        hi[0] = (_Float16)y0; hi[1] = (_Float16)y1; hi[2] = (_Float16)y2; hi[3] = (_Float16)y3;
+                        lo[0] = (_Float16)(y0 - (float)hi[0]); lo[1] = (_Float16)(y1 - (float)hi[1]);
+                        lo[2] = (_Float16)(y2 - (float)hi[2]); lo[3] = (_Float16)(y3 - (float)hi[3]);
+                        const long o = (long)m * p.K + k;
+                        *reinterpret_cast<half4*>(p.S_hi + o) = hi;
+                        *reinterpret_cast<half4*>(p.S_lo + o) = lo;
+                    }
+                }
+            }
+        }
         if constexpr (A_MC) {
             if (do_colsum) {
 #pragma unroll
@@ -444,7 +475,7 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
     if (kt_begin < kt_end) {
         load_A(kt_begin);
         load_B(kt_begin);
-        store_tiles(0);
+        store_tiles(0, kt_begin);
     }
     __syncthreads();
 
@@ -554,7 +585,7 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
         }
 
-        if (more) store_tiles(cur ^ 1);
+        if (more) store_tiles(cur ^ 1, kt + 1);
         __syncthreads();
         cur ^= 1;
     }
@@ -1277,7 +1308,7 @@ __global__ void splitk_reduce_kernel(const GemmParams p) {
     }
 }
 
-template <int BM, int BN, int AMODE, int BMODE, bool SCALAR, int WAVES_N = 2, int PREC = 0>
+template <int BM, int BN, int AMODE, int BMODE, bool SCALAR, int WAVES_N = 2, int PREC = 0, bool GNS = false>
 int launch(const GemmParams& p, hipStream_t st) {
     constexpr bool A_MC = (AMODE == A_PLAIN_MC);
     constexpr bool B_MC = (BMODE != B_PLAIN_KC);
@@ -1287,13 +1318,13 @@ int launch(const GemmParams& p, hipStream_t st) {
     constexpr size_t smem = 2 * (A_TILE + B_TILE) * sizeof(float);
     static bool attr_done = false;      // per-instantiation; value is idempotent so a race is benign
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, AMODE, BMODE, SCALAR, WAVES_N, PREC>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, AMODE, BMODE, SCALAR, WAVES_N, PREC, GNS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
         attr_done = true;
     }
     dim3 grid((unsigned)((long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.batch * p.ksplit));
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, AMODE, BMODE, SCALAR, WAVES_N, PREC>), grid, dim3(128 * WAVES_N), smem, st, p);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, AMODE, BMODE, SCALAR, WAVES_N, PREC, GNS>), grid, dim3(128 * WAVES_N), smem, st, p);
     return hipGetLastError() == hipSuccess ? 0 : cdae_fail("igemm launch failed");
 }
 
@@ -1302,6 +1333,12 @@ int launch_tiles(const GemmParams& p, int big, bool scalar, hipStream_t st) {
     if (scalar) return launch<64, 64, AMODE, BMODE, true>(p, st);
     if constexpr (AMODE == A_CONV_GEN) return cdae_fail("A_CONV_GEN is a scalar-only loader");
     else {
+        if constexpr (AMODE == A_PLAIN_KC && BMODE == B_PLAIN_KC) {
+            if (p.S_hi) {
+                if (p.prec != 1 || !big) return cdae_fail("GroupNorm side output: f16x3 mode and a grid of 128x128 tiles required");
+                return launch<128, 128, AMODE, BMODE, false, 4, 1, true>(p, st);
+            }
+        }
         if (p.prec == 1) return big ? launch<128, 128, AMODE, BMODE, false, 4, 1>(p, st) : launch<64, 64, AMODE, BMODE, false, 2, 1>(p, st);
         if (p.prec == 2) return big ? launch<128, 128, AMODE, BMODE, false, 4, 2>(p, st) : launch<64, 64, AMODE, BMODE, false, 2, 2>(p, st);
         if (p.prec == 3) return big ? launch<128, 128, AMODE, BMODE, false, 4, 3>(p, st) : launch<64, 64, AMODE, BMODE, false, 2, 3>(p, st);

@@ -789,6 +789,35 @@ class LazyGN:
         return SplitAct(planes[0], planes[1], self.shape)
 
 
+_SKIPGN_ON = os.environ.get("CDAE_SKIP_GN", "1") != "0"      # dev switch: 0 = separate GroupNorm apply pass and 1x1 skip GEMM
+
+
+def skip_gn_ok(lz, w):
+    """The ResBlock's 1x1 skip conv can carry the block's first GroupNorm along (one sweep over the block input)?"""
+    from ._lib import get_precision
+    N, C, H, W = lz.shape
+    C1 = lz.x1.shape[1]
+    return (_SKIPGN_ON and get_precision() == "f16x3" and w.dim() >= 2 and w.numel() == w.shape[0] * C and C % 32 == 0 and C1 % 32 == 0
+            and w.shape[0] >= 96 and N * H * W >= 96 and lz.x1.stride(1) == 1)
+
+
+def skip_gn_fused(lz, w, b=None):
+    """(skip = conv1x1([x1 | x2], w) + b,  SplitAct of silu?(GroupNorm([x1 | x2]))) from ONE pass over the block input: the skip GEMM's
+    loader also normalises the rows it stages and writes them as the f16 planes the block's first conv3x3 consumes (no autograd)."""
+    N, C, H, W = lz.shape
+    C1, M, Nf = lz.x1.shape[1], N * H * W, w.shape[0]
+    dev = lz.x1.device
+    st = stream()
+    coef = torch.empty((N, C, 2), dtype=torch.float32, device=dev)
+    check(lib.cdae_gn_coef(ptr(lz.stats[0]), ptr(lz.stats[1]), ptr(lz.gamma), ptr(lz.beta), ptr(lz.ss), lz.ld_ss, ptr(coef), N, C, lz.groups, st))
+    planes = torch.empty((2, N, H, W, C), dtype=torch.float16, device=dev)
+    y = torch.empty((M, Nf), dtype=torch.float32, device=dev)
+    ws, wsb = _sk(dev)
+    check(lib.cdae_linear_fwd_cat_gn(ptr(lz.x1), C1, C1, ptr(lz.x2), 0 if lz.x2 is None else C - C1, ptr(w), C, ptr(b), ptr(y), Nf, ptr(coef),
+                                     1 if lz.silu else 0, ptr(planes[0]), ptr(planes[1]), M, Nf, C, H * W, ws, wsb, st))
+    return y.reshape(N, H, W, Nf).permute(0, 3, 1, 2), SplitAct(planes[0], planes[1], lz.shape)
+
+
 def group_norm_lazy(x, gamma, beta, scale_shift=None, silu=False, groups=32, eps=1e-5):
     """Statistics of a GroupNorm over x (a tensor or a CatAct), taken from the producing convs' partial sums where they exist;
     returns a LazyGN (no autograd)."""

@@ -170,6 +170,10 @@ class ResBlock(TimestepBlock):
         if not isinstance(x, ops.CatAct):                          # CatAct: the skip concatenation, read in place by GN and the 1x1 skip
             x = ops.to_nhwc(x)
         h = self.in_layers[0](x, silu=True, split=True)            # GN + SiLU (pre-split f16 planes on the inference path)
+        skip = None
+        sk = self.skip_connection
+        if isinstance(h, ops.LazyGN) and isinstance(sk, ConvNd) and sk.kernel_size == 1 and ops.skip_gn_ok(h, sk.weight):
+            skip, h = ops.skip_gn_fused(h, sk.weight, sk.bias)     # the 1x1 skip conv writes the normalised planes while it reads x
         fast = isinstance(h, (ops.SplitAct, ops.LazyGN))
         h = self.in_layers[2](h, gn_stats=True) if fast else self.in_layers[2](h)     # conv3x3 + bias (+ GroupNorm partial sums)
         if isinstance(emb, EmbAll):
@@ -181,7 +185,8 @@ class ResBlock(TimestepBlock):
         else:
             h = self.out_layers[0](h + emb_out[:, :, None, None], silu=True, split=True)
         h = self.out_layers[2](h)
-        skip = ops.materialize(x) if isinstance(self.skip_connection, Identity) else self.skip_connection(x)
+        if skip is None:
+            skip = ops.materialize(x) if isinstance(self.skip_connection, Identity) else self.skip_connection(x)
         if isinstance(h, (ops.SplitAct, ops.LazyGN)):              # emit_split: a Down/Upsample conv consumes this block's output
             return self.out_layers[3](h, res=skip, emit_split=self.emit_split, gn_stats=True)
         return self.out_layers[3](h, res=skip)                     # conv3x3 + bias + residual

@@ -117,6 +117,13 @@ int cdae_split_f16(const float* src, unsigned short* hi, unsigned short* lo, lon
    skip concatenation, unet.py:629,198); K1 % 32 == 0 */
 int cdae_linear_fwd_cat(const float* x1, long ld1, int K1, const float* x2, long ld2, const float* w, long ldw, const float* bias, float* y,
                         long ldy, int M, int N, int K, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
+/* cdae_linear_fwd_cat + the block's first GroupNorm in the same sweep: besides y, the n-tile-0 blocks write
+   silu?(x * a + b) (coef [N][K][2] from cdae_gn_coef: bit-identical to cdae_gn_apply_split2) as f16 hi/lo planes s_hi / s_lo [M][K],
+   i.e. the operand of the block's first conv3x3 — ResBlock skip_connection (unet.py:171,198) and in_layers[0:2] (unet.py:135-137,187)
+   over ONE read of the (concatenated) block input.  HW = pixels per image; x2 may be NULL.  f16x3 mode, M >= 96, N >= 96. */
+int cdae_linear_fwd_cat_gn(const float* x1, long ld1, int K1, const float* x2, long ld2, const float* w, long ldw, const float* bias, float* y,
+                           long ldy, const float* coef, int silu, unsigned short* s_hi, unsigned short* s_lo, int M, int N, int K, int HW,
+                           float* splitk_ws, size_t splitk_ws_bytes, void* stream);
 /* two-source forms: channels [0, C1) are read from x1 (pixel pitch ld1), channels [C1, C) from x2 (pitch ld2) — the skip
    concatenation th.cat([h, hs.pop()], dim=1) (unet.py:629) consumed in place instead of being copied; x2 == NULL: one source */
 int cdae_gn_stats2(const float* x1, int ld1, const float* x2, int ld2, int C1, int N, int HW, int C, int groups, float eps, float* mean,

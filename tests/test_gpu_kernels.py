@@ -813,3 +813,31 @@ def test_resblock_training_node_two_sources(N, C1, C2, Cout, H):
     names = ["out", "da", "db", "dss"] + sorted(p0)
     for n, r, f in zip(names, *res):
         assert (f.double().reshape(r.shape) - r).abs().max().item() < 3e-5 * r.abs().max().item(), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C1,C2,Cout,H", [(4, 128, 128, 128, 32), (2, 256, 128, 256, 16), (3, 512, 384, 512, 8), (2, 128, 0, 256, 32)])
+def test_skip_gemm_carries_groupnorm_planes(N, C1, C2, Cout, H):
+    """cdae_linear_fwd_cat_gn: the ResBlock's 1x1 skip conv whose loader also writes GroupNorm+SiLU of the (concatenated) block input as
+    f16 planes — the planes bit-identical to cdae_gn_apply_split2's, the GEMM result equal to cdae_linear_fwd_cat's."""
+    from causaldiffae_amd import ops
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(23)
+    cl = torch.channels_last
+    C = C1 + C2
+    a = torch.randn(N, C1, H, H, device=dev, generator=g).contiguous(memory_format=cl)
+    b = torch.randn(N, C2, H, H, device=dev, generator=g).contiguous(memory_format=cl) if C2 else None
+    gamma = 1 + 0.1 * torch.randn(C, device=dev, generator=g)
+    beta = 0.1 * torch.randn(C, device=dev, generator=g)
+    w = torch.randn(Cout, C, 1, 1, device=dev, generator=g) / C ** 0.5
+    bias = 0.1 * torch.randn(Cout, device=dev, generator=g)
+    with torch.no_grad():
+        x = ops.CatAct(a, b) if C2 else a
+        lz = ops.group_norm_lazy(x, gamma, beta, None, True, 32, 1e-5)
+        assert ops.skip_gn_ok(lz, w)
+        skip, planes = ops.skip_gn_fused(lz, w, bias)
+        ref_planes = lz.planes()
+        ref_skip = ops.conv1x1_cat(x, w.reshape(Cout, C), bias) if C2 else ops.conv1x1(a, w.reshape(Cout, C), bias)
+    assert torch.equal(planes.hi, ref_planes.hi) and torch.equal(planes.lo, ref_planes.lo)
+    # the GEMM itself: same products, but the separate launch may split K on these small grids (different fp32 summation order)
+    assert (skip - ref_skip).abs().max().item() < 2e-5 * ref_skip.abs().max().item()
