@@ -125,7 +125,7 @@ __device__ __forceinline__ void store_planes(const GemmParams& p, long addr, flo
 // GroupNorm (+SiLU; folded per (image, channel) coefficients p.gn_coef, bit-identical to gn_apply_kernel) and write the result as
 // f16 hi/lo planes (p.S_hi / p.S_lo, dense [M][K]): the separate normalisation pass over the tensor disappears.  The GEMM is
 // HBM-bound, the extra VALU work is free.
-template <int BM, int BN, int AMODE, int BMODE, bool SCALAR, int WAVES_N = 2, int PREC = 0, bool GNS = false>
+template <int BM, int BN, int AMODE, int BMODE, bool SCALAR, int WAVES_N = 2, int PREC = 0, bool GNS = false, bool DEEP = false>
 __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p) {
     static_assert(PREC == 0 || !SCALAR, "split precision is only built for vectorised loaders");
     static_assert(!GNS || (AMODE == A_PLAIN_KC && PREC == 1 && !SCALAR), "the GroupNorm side output rides on the K-contiguous f16x3 loader");
@@ -219,23 +219,24 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
     }
 
     float4 areg[A_V4], breg[B_V4];
+    float4 areg2[DEEP ? A_V4 : 1], breg2[DEEP ? B_V4 : 1];          // DEEP: second register set of the two-step load pipeline
 
     // K-step -> first k of the step: tap major, channel minor (the per-row tap geometry is refreshed once per tap;
     // a channel-chunk-major order was measured 5 % slower because it recomputes it every step).
     auto kstart = [&](int kt) -> int { return kt * BK; };
 
-    auto load_A = [&](int kt) {
+    auto load_A = [&](int kt, float4* ra) {
         const int k0 = kstart(kt);
         if constexpr (AMODE == A_PLAIN_KC) {
             const int k = k0 + (tid & 7) * 4;
 #pragma unroll
             for (int q = 0; q < A_V4; ++q) {
-                if constexpr (!SCALAR) areg[q] = ld4_if(Ag, arowp[q] + k0 + ((p.A2 && k0 >= p.K1) ? adelta[q] : 0L), arow_ok[q] && k < p.K);
+                if constexpr (!SCALAR) ra[q] = ld4_if(Ag, arowp[q] + k0 + ((p.A2 && k0 >= p.K1) ? adelta[q] : 0L), arow_ok[q] && k < p.K);
                 else {
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = ld1_if(Ag, arowp[q] + k0 + e, arow_ok[q] && k + e < p.K);
-                    areg[q] = make_float4(v[0], v[1], v[2], v[3]);
+                    ra[q] = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
         } else if constexpr (AMODE == A_CONV_VEC) {
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
                 }
             }
 #pragma unroll
-            for (int q = 0; q < A_V4; ++q) areg[q] = ld4_if(Ag, Ag + atap_off[q] + c0, atap_ok[q]);
+            for (int q = 0; q < A_V4; ++q) ra[q] = ld4_if(Ag, Ag + atap_off[q] + c0, atap_ok[q]);
         } else if constexpr (AMODE == A_CONV_GEN) {
 #pragma unroll
             for (int q = 0; q < A_V4; ++q) {
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
                     const bool ok = arow[q].ok && k < p.K && tap_offset(p, arow[q], ky, kx, off);
                     v[e] = ld1_if(Ag, Ag + off + (long)c * p.sc, ok);
                 }
-                areg[q] = make_float4(v[0], v[1], v[2], v[3]);
+                ra[q] = make_float4(v[0], v[1], v[2], v[3]);
             }
         } else {   // A_PLAIN_MC: element (i,k) at Ag + k*lda + i
 #pragma unroll
@@ -275,29 +276,29 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
                 const int kk = idx / (BM / 4), i4 = idx - kk * (BM / 4);
                 const int k = k0 + kk, i = m0 + i4 * 4;
                 const float* src = Ag + (long)(k < p.K ? k : 0) * p.lda + i;
-                if constexpr (!SCALAR) areg[q] = ld4_if(Ag, src, k < p.K && i < p.M);      // host guarantees M % 4 == 0
+                if constexpr (!SCALAR) ra[q] = ld4_if(Ag, src, k < p.K && i < p.M);      // host guarantees M % 4 == 0
                 else {
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = ld1_if(Ag, src + e, k < p.K && i + e < p.M);
-                    areg[q] = make_float4(v[0], v[1], v[2], v[3]);
+                    ra[q] = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
         }
     };
 
-    auto load_B = [&](int kt) {
+    auto load_B = [&](int kt, float4* rb) {
         const int k0 = kstart(kt);
         if constexpr (BMODE == B_PLAIN_KC) {
             const int k = k0 + (tid & 7) * 4;
 #pragma unroll
             for (int q = 0; q < B_V4; ++q) {
-                if constexpr (!SCALAR) breg[q] = ld4_if(Bg, browp[q] + k0, brow_ok[q] && k < p.K);
+                if constexpr (!SCALAR) rb[q] = ld4_if(Bg, browp[q] + k0, brow_ok[q] && k < p.K);
                 else {
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = ld1_if(Bg, browp[q] + k0 + e, brow_ok[q] && k + e < p.K);
-                    breg[q] = make_float4(v[0], v[1], v[2], v[3]);
+                    rb[q] = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
         } else {
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
                         const bool ok = r.ok && j + e < p.N && tap_offset(p, r, ky, kx, off);
                         v[e] = ld1_if(Bg, Bg + off + (long)c * p.sc, ok);
                     }
-                    breg[q] = make_float4(v[0], v[1], v[2], v[3]);
+                    rb[q] = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
                     const float* src;
                     bool kok = k < p.K;
@@ -338,12 +339,12 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
                         const int ft = p.wflip ? 8 - tap : tap;
                         src = Bg + ((long)co * 9 + ft) * p.wCin + j;
                     }
-                    if constexpr (!SCALAR) breg[q] = ld4_if(Bg, src, kok && j < p.N);      // host guarantees N % 4 == 0
+                    if constexpr (!SCALAR) rb[q] = ld4_if(Bg, src, kok && j < p.N);      // host guarantees N % 4 == 0
                     else {
                         float v[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = ld1_if(Bg, src + e, kok && j + e < p.N);
-                        breg[q] = make_float4(v[0], v[1], v[2], v[3]);
+                        rb[q] = make_float4(v[0], v[1], v[2], v[3]);
                     }
                 }
             }
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
     float4 colsum = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool do_colsum = A_MC && p.colsum_out != nullptr && nt == 0;
 
-    auto store_tiles = [&](int buf, int kt_of = 0) {
+    auto store_tiles = [&](int buf, int kt_of, const float4* ra, const float4* rb) {
         float* a = As + buf * A_TILE;
         float* b = Bs + buf * B_TILE;
         if constexpr (GNS) {
@@ -392,8 +393,8 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
                         const int img = fdiv(m, p.hw_magic, p.hw_shift);
                         const float4* cf = reinterpret_cast<const float4*>(p.gn_coef + ((long)img * p.K + k) * 2);
                         const float4 c01 = cf[0], c23 = cf[1];                // a0 b0 a1 b1 | a2 b2 a3 b3
-                        float y0 = fmaf(areg[q].x, c01.x, c01.y), y1 = fmaf(areg[q].y, c01.z, c01.w);
-                        float y2 = fmaf(areg[q].z, c23.x, c23.y), y3 = fmaf(areg[q].w, c23.z, c23.w);
+                        float y0 = fmaf(ra[q].x, c01.x, c01.y), y1 = fmaf(ra[q].y, c01.z, c01.w);
+                        float y2 = fmaf(ra[q].z, c23.x, c23.y), y3 = fmaf(ra[q].w, c23.z, c23.w);
                         if (p.gn_silu) { y0 = y0 / (1.f + expf(-y0)); y1 = y1 / (1.f + expf(-y1)); y2 = y2 / (1.f + expf(-y2)); y3 = y3 / (1.f + expf(-y3)); }
                         asm volatile("" : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3));      // opaque before the split (attention.hip split8)
                         half4 hi, lo;
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
         if constexpr (A_MC) {
             if (do_colsum) {
 #pragma unroll
-                for (int q = 0; q < A_V4; ++q) { colsum.x += areg[q].x; colsum.y += areg[q].y; colsum.z += areg[q].z; colsum.w += areg[q].w; }
+                for (int q = 0; q < A_V4; ++q) { colsum.x += ra[q].x; colsum.y += ra[q].y; colsum.z += ra[q].z; colsum.w += ra[q].w; }
             }
         }
         if constexpr (PREC != 0) {
@@ -418,20 +419,20 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
             char* bc = reinterpret_cast<char*>(b);
 #pragma unroll
             for (int q = 0; q < A_V4; ++q) {
-                if constexpr (!A_MC) store_split(ac, A_PLANE, kc_off((tid >> 3) + RPP * q, tid & 7), areg[q]);
+                if constexpr (!A_MC) store_split(ac, A_PLANE, kc_off((tid >> 3) + RPP * q, tid & 7), ra[q]);
                 else {
                     const int idx = tid + THREADS * q;
                     const int kk = idx / (BM / 4), i4 = idx - kk * (BM / 4);
-                    store_split(ac, A_PLANE, (kk * PAM + i4 * 4) * 2, areg[q]);
+                    store_split(ac, A_PLANE, (kk * PAM + i4 * 4) * 2, ra[q]);
                 }
             }
 #pragma unroll
             for (int q = 0; q < B_V4; ++q) {
-                if constexpr (!B_MC) store_split(bc, B_PLANE, kc_off((tid >> 3) + RPP * q, tid & 7), breg[q]);
+                if constexpr (!B_MC) store_split(bc, B_PLANE, kc_off((tid >> 3) + RPP * q, tid & 7), rb[q]);
                 else {
                     const int idx = tid + THREADS * q;
                     const int kk = idx / (BN / 4), j4 = idx - kk * (BN / 4);
-                    store_split(bc, B_PLANE, (kk * PBM + j4 * 4) * 2, breg[q]);
+                    store_split(bc, B_PLANE, (kk * PBM + j4 * 4) * 2, rb[q]);
                 }
             }
             return;
@@ -439,25 +440,25 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
         if constexpr (!A_MC) {
 #pragma unroll
             for (int q = 0; q < A_V4; ++q)
-                *reinterpret_cast<float4*>(a + ((tid >> 3) + RPP * q) * LDK + (tid & 7) * 4) = areg[q];
+                *reinterpret_cast<float4*>(a + ((tid >> 3) + RPP * q) * LDK + (tid & 7) * 4) = ra[q];
         } else {
 #pragma unroll
             for (int q = 0; q < A_V4; ++q) {
                 const int idx = tid + THREADS * q;
                 const int kk = idx / (BM / 4), i4 = idx - kk * (BM / 4);
-                *reinterpret_cast<float4*>(a + kk * LDAM + i4 * 4) = areg[q];
+                *reinterpret_cast<float4*>(a + kk * LDAM + i4 * 4) = ra[q];
             }
         }
         if constexpr (!B_MC) {
 #pragma unroll
             for (int q = 0; q < B_V4; ++q)
-                *reinterpret_cast<float4*>(b + ((tid >> 3) + RPP * q) * LDK + (tid & 7) * 4) = breg[q];
+                *reinterpret_cast<float4*>(b + ((tid >> 3) + RPP * q) * LDK + (tid & 7) * 4) = rb[q];
         } else {
 #pragma unroll
             for (int q = 0; q < B_V4; ++q) {
                 const int idx = tid + THREADS * q;
                 const int kk = idx / (BN / 4), j4 = idx - kk * (BN / 4);
-                *reinterpret_cast<float4*>(b + kk * LDBM + j4 * 4) = breg[q];
+                *reinterpret_cast<float4*>(b + kk * LDBM + j4 * 4) = rb[q];
             }
         }
     };
@@ -473,16 +474,20 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
             }
 
     if (kt_begin < kt_end) {
-        load_A(kt_begin);
-        load_B(kt_begin);
-        store_tiles(0, kt_begin);
+        load_A(kt_begin, areg);
+        load_B(kt_begin, breg);
+        store_tiles(0, kt_begin, areg, breg);
+        if constexpr (DEEP) { if (kt_begin + 1 < kt_end) { load_A(kt_begin + 1, areg); load_B(kt_begin + 1, breg); } }
     }
     __syncthreads();
 
     int cur = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
+    // one 32-deep K step.  DEEP: the global loads run TWO steps ahead of the MFMAs in two alternating register sets (the shallow, tall
+    // GEMMs of the 1x1 convs are latency-bound with one step in flight: each step waits a full HBM round trip for 32 KB per block)
+    auto kstep = [&](int kt, float4* ra_c, float4* rb_c, float4* ra_n, float4* rb_n) {
         const bool more = kt + 1 < kt_end;
-        if (more) { load_A(kt + 1); load_B(kt + 1); }
+        if constexpr (DEEP) { if (kt + 2 < kt_end) { load_A(kt + 2, ra_n); load_B(kt + 2, rb_n); } }
+        else if (more) { load_A(kt + 1, ra_c); load_B(kt + 1, rb_c); }
 
         const float* a = As + cur * A_TILE;
         const float* b = Bs + cur * B_TILE;
@@ -585,9 +590,17 @@ __global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
         }
 
-        if (more) store_tiles(cur ^ 1, kt + 1);
+        if (more) store_tiles(cur ^ 1, kt + 1, ra_c, rb_c);
         __syncthreads();
         cur ^= 1;
+    };
+    if constexpr (DEEP) {
+        for (int kt = kt_begin; kt < kt_end; kt += 2) {
+            kstep(kt, areg, breg, areg2, breg2);
+            if (kt + 1 < kt_end) kstep(kt + 1, areg2, breg2, areg, breg);
+        }
+    } else {
+        for (int kt = kt_begin; kt < kt_end; ++kt) kstep(kt, areg, breg, areg, breg);
     }
 
     if constexpr (A_MC) {
@@ -1308,7 +1321,7 @@ __global__ void splitk_reduce_kernel(const GemmParams p) {
     }
 }
 
-template <int BM, int BN, int AMODE, int BMODE, bool SCALAR, int WAVES_N = 2, int PREC = 0, bool GNS = false>
+template <int BM, int BN, int AMODE, int BMODE, bool SCALAR, int WAVES_N = 2, int PREC = 0, bool GNS = false, bool DEEP = false>
 int launch(const GemmParams& p, hipStream_t st) {
     constexpr bool A_MC = (AMODE == A_PLAIN_MC);
     constexpr bool B_MC = (BMODE != B_PLAIN_KC);
@@ -1318,13 +1331,13 @@ int launch(const GemmParams& p, hipStream_t st) {
     constexpr size_t smem = 2 * (A_TILE + B_TILE) * sizeof(float);
     static bool attr_done = false;      // per-instantiation; value is idempotent so a race is benign
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, AMODE, BMODE, SCALAR, WAVES_N, PREC, GNS>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, AMODE, BMODE, SCALAR, WAVES_N, PREC, GNS, DEEP>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
         attr_done = true;
     }
     dim3 grid((unsigned)((long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.batch * p.ksplit));
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, AMODE, BMODE, SCALAR, WAVES_N, PREC, GNS>), grid, dim3(128 * WAVES_N), smem, st, p);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, AMODE, BMODE, SCALAR, WAVES_N, PREC, GNS, DEEP>), grid, dim3(128 * WAVES_N), smem, st, p);
     return hipGetLastError() == hipSuccess ? 0 : cdae_fail("igemm launch failed");
 }
 
@@ -1334,10 +1347,12 @@ int launch_tiles(const GemmParams& p, int big, bool scalar, hipStream_t st) {
     if constexpr (AMODE == A_CONV_GEN) return cdae_fail("A_CONV_GEN is a scalar-only loader");
     else {
         if constexpr (AMODE == A_PLAIN_KC && BMODE == B_PLAIN_KC) {
+            static const int cfg_deep = getenv("CDAE_IGEMM_DEEP") ? atoi(getenv("CDAE_IGEMM_DEEP")) : 1;
             if (p.S_hi) {
                 if (p.prec != 1 || !big) return cdae_fail("GroupNorm side output: f16x3 mode and a grid of 128x128 tiles required");
-                return launch<128, 128, AMODE, BMODE, false, 4, 1, true>(p, st);
+                return (cfg_deep & 2) ? launch<128, 128, AMODE, BMODE, false, 4, 1, true, true>(p, st) : launch<128, 128, AMODE, BMODE, false, 4, 1, true>(p, st);
             }
+            if (p.prec == 1 && big && (cfg_deep & 1)) return launch<128, 128, AMODE, BMODE, false, 4, 1, false, true>(p, st);
         }
         if (p.prec == 1) return big ? launch<128, 128, AMODE, BMODE, false, 4, 1>(p, st) : launch<64, 64, AMODE, BMODE, false, 2, 1>(p, st);
         if (p.prec == 2) return big ? launch<128, 128, AMODE, BMODE, false, 4, 2>(p, st) : launch<64, 64, AMODE, BMODE, false, 2, 2>(p, st);
