@@ -126,7 +126,7 @@ __device__ __forceinline__ void store_planes(const GemmParams& p, long addr, flo
 // f16 hi/lo planes (p.S_hi / p.S_lo, dense [M][K]): the separate normalisation pass over the tensor disappears.  The GEMM is
 // HBM-bound, the extra VALU work is free.
 template <int BM, int BN, int AMODE, int BMODE, bool SCALAR, int WAVES_N = 2, int PREC = 0, bool GNS = false, bool DEEP = false>
-__global__ __launch_bounds__(128 * WAVES_N) void igemm_kernel(const GemmParams p) {
+__global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_kernel(const GemmParams p) {     // GNS + DEEP: keep four waves per SIMD (128 VGPRs)
     static_assert(PREC == 0 || !SCALAR, "split precision is only built for vectorised loaders");
     static_assert(!GNS || (AMODE == A_PLAIN_KC && PREC == 1 && !SCALAR), "the GroupNorm side output rides on the K-contiguous f16x3 loader");
     constexpr int NPL = (PREC == 1 || PREC == 2) ? 2 : 1;       // 16-bit planes per operand
@@ -1347,7 +1347,7 @@ int launch_tiles(const GemmParams& p, int big, bool scalar, hipStream_t st) {
     if constexpr (AMODE == A_CONV_GEN) return cdae_fail("A_CONV_GEN is a scalar-only loader");
     else {
         if constexpr (AMODE == A_PLAIN_KC && BMODE == B_PLAIN_KC) {
-            static const int cfg_deep = getenv("CDAE_IGEMM_DEEP") ? atoi(getenv("CDAE_IGEMM_DEEP")) : 5;       // bit 0 plain fwd GEMM, 1 the GroupNorm-carrying skip GEMM, 2 linear dgrad / wgrad
+            static const int cfg_deep = getenv("CDAE_IGEMM_DEEP") ? atoi(getenv("CDAE_IGEMM_DEEP")) : 7;       // bit 0 plain fwd GEMM, 1 the GroupNorm-carrying skip GEMM, 2 linear dgrad / wgrad
             if (p.S_hi) {
                 if (p.prec != 1 || !big) return cdae_fail("GroupNorm side output: f16x3 mode and a grid of 128x128 tiles required");
                 return (cfg_deep & 2) ? launch<128, 128, AMODE, BMODE, false, 4, 1, true, true>(p, st) : launch<128, 128, AMODE, BMODE, false, 4, 1, true>(p, st);
@@ -1355,7 +1355,7 @@ int launch_tiles(const GemmParams& p, int big, bool scalar, hipStream_t st) {
             if (p.prec == 1 && big && (cfg_deep & 1)) return launch<128, 128, AMODE, BMODE, false, 4, 1, false, true>(p, st);
         }
         if constexpr ((AMODE == A_PLAIN_KC || AMODE == A_PLAIN_MC) && BMODE == B_PLAIN_MC) {     // linear / 1x1 dgrad and wgrad: the same latency-bound shape
-            static const int cfg_deep2 = getenv("CDAE_IGEMM_DEEP") ? atoi(getenv("CDAE_IGEMM_DEEP")) : 5;
+            static const int cfg_deep2 = getenv("CDAE_IGEMM_DEEP") ? atoi(getenv("CDAE_IGEMM_DEEP")) : 7;
             if (p.prec == 2 && big && (cfg_deep2 & 4)) return launch<128, 128, AMODE, BMODE, false, 4, 2, false, true>(p, st);
         }
         if (p.prec == 1) return big ? launch<128, 128, AMODE, BMODE, false, 4, 1>(p, st) : launch<64, 64, AMODE, BMODE, false, 2, 1>(p, st);
