@@ -1300,7 +1300,14 @@ __global__ void splitk_reduce_kernel(const GemmParams p) {
         long bz = idx / ((long)p.M * p.N), rem = idx - bz * (long)p.M * p.N;
         int row = rem / p.N, col = rem - (long)row * p.N;
         float s = 0.f;
-        for (int k = 0; k < p.ksplit; ++k) s += p.splitk_ws[((long)k * p.batch + bz) * (long)p.M * p.N + rem];
+        const float* slab = p.splitk_ws + bz * (long)p.M * p.N + rem;
+        const long kstride = (long)p.batch * p.M * p.N;
+        int k = 0;
+        for (; k + 4 <= p.ksplit; k += 4) {          // four slab loads in flight (the dependent-add loop alone waits a round trip per slab); same order of additions
+            const float v0 = slab[k * kstride], v1 = slab[(k + 1) * kstride], v2 = slab[(k + 2) * kstride], v3 = slab[(k + 3) * kstride];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; k < p.ksplit; ++k) s += slab[k * kstride];
         int bo = bz / p.batch_inner, bi = bz - bo * p.batch_inner;
         float* Cg = p.C + bo * p.c_bs0 + bi * p.c_bs1;
         long addr;

@@ -279,7 +279,15 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void wgwin_kernel(const Wg
 __global__ void wg_reduce_kernel(const float4* __restrict__ ws, float4* __restrict__ out, long n4, int ksplit, int accumulate) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         float4 s = ws[i];
-        for (int k = 1; k < ksplit; ++k) {
+        int k = 1;
+        for (; k + 4 <= ksplit; k += 4) {            // four slab loads in flight; the additions keep their order
+            const float4 v0 = ws[(long)k * n4 + i], v1 = ws[(long)(k + 1) * n4 + i], v2 = ws[(long)(k + 2) * n4 + i], v3 = ws[(long)(k + 3) * n4 + i];
+            s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+            s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+            s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+            s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+        }
+        for (; k < ksplit; ++k) {
             const float4 v = ws[(long)k * n4 + i];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
