@@ -38,6 +38,8 @@ SIGNATURES = {
     "cdae_wdgrad_planes": [P, P, P, I, I, P],
     "cdae_wprep_all": [P, P, I, I, L, P, P, P, P, P],
     "cdae_conv3x3_dgrad_ps": [P, P, P, P, P, L, I, I, I, I, I, P, SZ, P],
+    "cdae_conv3x3_stem_supported": [I, I, I],
+    "cdae_conv3x3_stem": [P, L, L, L, L, P, P, P, L, I, I, I, I, I, P],
     "cdae_conv3x3_wgrad_fewout": [P, P, L, P, P, I, I, I, I, I, I, P, SZ, P],
     "cdae_conv3x3_wgrad_win_supported": [I, I, I, I, I],
     "cdae_conv3x3_wgrad_win": [P, P, P, P, P, P, I, I, I, I, I, I, P, SZ, P],

@@ -1,6 +1,7 @@
 // api.hip — op-level C-ABI over the igemm kernel family: conv3x3 / linear / QKV attention (fwd, dgrad, wgrad).
 // See include/cdae.h for the contract of every entry point.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <math.h>
 #include <string.h>
 #include "cdae_internal.h"
@@ -54,6 +55,11 @@ int cdae_conv3x3_fwd(const float* x, long sn, long sy, long sx, long sc, const f
     if (stride != 1 && stride != 2) return cdae_fail("conv3x3: stride must be 1 or 2");
     if (up && stride != 1) return cdae_fail("conv3x3: fused upsample needs stride 1");
     const int Ho = up ? 2 * H : (H - 1) / stride + 1, Wo = up ? 2 * W : (W - 1) / stride + 1;
+    // the network's input conv (1..4 channels): exact-fp32 streaming kernel of stem.hip instead of a 36-deep implicit GEMM
+    static const int cfg_stem = getenv("CDAE_STEM") ? atoi(getenv("CDAE_STEM")) : 1;      // dev switch: 0 = implicit GEMM for the input conv
+    if (cfg_stem && stride == 1 && !up && !out_nchw && !res && cdae_conv3x3_stem_supported(Cin, Cout, W) && ldo % 4 == 0 && aligned16(out) && aligned16(bias) &&
+        cdae_get_default_precision() != CDAE_PREC_MIXED16)
+        return cdae_conv3x3_stem(x, sn, sy, sx, sc, w, bias, out, ldo, N, H, W, Cin, Cout, stream);
     GemmParams p = base_params();
     p.A = x; p.B = w; p.C = out; p.bias = bias; p.res = res;
     p.M = N * Ho * Wo; p.N = Cout; p.K = 9 * Cin;

@@ -177,6 +177,11 @@ int cdae_conv3x3_dgrad_ps(const unsigned short* dy_hi, const unsigned short* dy_
 /* wgrad of a stride-1 conv3x3 with 1..8 output channels over a dense NHWC fp32 input (the `out` conv, unet.py:474-478): sliding-window
    fp32 FMAs, one thread per input channel; cdae_conv3x3_wgrad routes such shapes here.  ws: >= ceil(N*H/2) * (Cout*9*Cin + 8) floats
    (fewer row groups are used if it is smaller). */
+/* the UNet's input conv (unet.py:395-399; 1..4 input channels, stride 1, NHWC rows out): exact fp32 on the vector ALUs, one output image
+   row per block; cdae_conv3x3_fwd routes such shapes here.  x may have any element strides (the model input is NCHW). */
+int cdae_conv3x3_stem_supported(int Cin, int Cout, int W);
+int cdae_conv3x3_stem(const float* x, long sn, long sy, long sx, long sc, const float* w, const float* bias, float* out, long ldo,
+                      int N, int H, int W, int Cin, int Cout, void* stream);
 int cdae_conv3x3_wgrad_fewout(const float* x, const float* dy, long lddy, float* dw, float* dbias, int N, int H, int W, int Cin, int Cout,
                               int accumulate, float* ws, size_t ws_bytes, void* stream);
 int cdae_conv3x3_wgrad_win_supported(int N, int H, int W, int Cin, int Cout);

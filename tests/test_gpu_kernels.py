@@ -841,3 +841,27 @@ def test_skip_gemm_carries_groupnorm_planes(N, C1, C2, Cout, H):
     assert torch.equal(planes.hi, ref_planes.hi) and torch.equal(planes.lo, ref_planes.lo)
     # the GEMM itself: same products, but the separate launch may split K on these small grids (different fp32 summation order)
     assert (skip - ref_skip).abs().max().item() < 2e-5 * ref_skip.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,Cin,Cout,H,W,nchw", [(3, 4, 128, 16, 16, True), (2, 3, 128, 64, 64, True), (5, 1, 128, 28, 28, True), (2, 4, 64, 8, 12, False),
+                                                 (2, 2, 96, 9, 7, True)])
+def test_stem_conv_matches_fp64(N, Cin, Cout, H, W, nchw):
+    """cdae_conv3x3_stem (the UNet input conv, 1..4 channels, exact fp32 on the vector ALUs) through ops.conv3x3 — NCHW model inputs and
+    NHWC tensors, odd image sizes, channel-group counts that do not divide the block — against conv2d in fp64."""
+    import torch.nn.functional as F
+    from causaldiffae_amd import ops
+    from causaldiffae_amd._lib import lib
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(31)
+    x = torch.randn(N, Cin, H, W, device=dev, generator=g)
+    if not nchw:
+        x = x.contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, 3, 3, device=dev, generator=g) / (3 * Cin ** 0.5)).contiguous(memory_format=torch.channels_last)
+    b = 0.1 * torch.randn(Cout, device=dev, generator=g)
+    assert lib.cdae_conv3x3_stem_supported(Cin, Cout, W) == 1
+    with torch.no_grad():
+        got = ops.conv3x3(x, w, b)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    assert got.shape == ref.shape
+    assert (got.double() - ref).abs().max().item() < 2e-6 * ref.abs().max().item()
