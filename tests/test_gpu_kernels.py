@@ -591,6 +591,9 @@ def _wgrad_ref(a, dy):
     (4, 16, 8, 64, 64, 0),         # non-square image (H != W)
     (2, 16, 16, 640, 384, 0),      # skip-concatenation widths: 10 x 6 channel tiles
     (1, 8, 8, 1024, 512, 1),       # widest layer of the network, a single image
+    (12, 16, 16, 256, 256, 0),     # 3 steps per block against 4 steps per image: blocks start and end at every phase inside an image
+    (10, 32, 32, 256, 128, 0),     # 5 steps per block against 16 per image
+    (37, 8, 8, 64, 64, 0),         # one step per block, a prime number of images
 ])
 def test_wgrad_window_kernel_matches_fp64(N, H, W, Cin, Cout, accumulate):
     """cdae_conv3x3_wgrad_win (LDS-ring window, transpose-read fragments, bf16 hi/lo planes) against autograd in fp64; operands are
