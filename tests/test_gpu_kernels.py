@@ -666,7 +666,7 @@ def _gnconv_case(N, C, Cout, H, ss_on, res_on, mode):
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,C,Cout,H,ss_on,res_on", [(4, 128, 128, 64, True, True), (8, 256, 256, 32, False, False), (8, 384, 384, 16, True, True),
                                                      (16, 512, 512, 8, True, False), (2, 128, 256, 32, True, True), (3, 896, 384, 16, True, True),
-                                                     (1, 1024, 512, 8, False, True)])
+                                                     (1, 1024, 512, 8, False, True), (3, 128, 128, 8, True, True)])      # last: 192 rows, 1.5 row tiles
 def test_fused_gn_conv_training_node(N, C, Cout, H, ss_on, res_on):
     """ops.gn_conv3x3 (GroupNorm -> SiLU -> conv3x3 as one autograd node on the pre-split kernels: f16-plane forward, bf16-plane
     dgrad on the window kernel, LDS-ring wgrad) against torch autograd in fp64, and no worse than the separate-node path."""
