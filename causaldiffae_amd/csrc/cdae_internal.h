@@ -60,6 +60,9 @@ struct GemmParams {
 };
 
 int cdae_gemm_dispatch(GemmParams p, void* stream);
+// convwin.hip: second-generation window-resident conv3x3 on pre-split planes
+bool cdae_convwin_ok(const GemmParams& p);
+int cdae_convwin_launch(const GemmParams& p, void* stream);
 
 // error reporting: sets the thread-local message returned by cdae_last_error(), returns -1
 int cdae_fail(const char* msg);
@@ -68,3 +71,15 @@ int cdae_fail(const char* msg);
 enum { PROF_IGEMM = 0, PROF_GN = 1, PROF_SOFTMAX = 2, PROF_ELEMWISE = 3, PROF_OPT = 4, PROF_NFAM = 5 };
 void cdae_prof_begin(int family, double work, hipStream_t st);
 void cdae_prof_end(int family, hipStream_t st);
+
+// LDS-DMA (global_load_lds_dwordx4) issued through inline assembly: lane l's 16 bytes at `src` land at LDS byte address
+// lds_dst + 16 l (lds_dst wave-uniform).  Why not __builtin_amdgcn_global_load_lds: hipcc's waitcnt pass keeps the ADDRESS
+// registers of an in-flight LDS-DMA on its scoreboard and puts `s_waitcnt vmcnt(0)` in front of the next instruction that
+// redefines one of them — in a software-pipelined loop that is a full drain of the DMAs just issued, in the middle of the
+// MFMA stream (round-2 finding; visible in the ISA of every round-1 plane kernel).  Opaque asm leaves all waiting to the
+// kernel's own counted s_waitcnt.
+#ifdef __HIPCC__
+__device__ __forceinline__ void cdae_lds_dma16(const void* src, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_dst), "v"(src) : "memory", "m0");
+}
+#endif

@@ -1,0 +1,395 @@
+// convwin.hip — stride-1 conv3x3 (and the 2x2 sub-pixel phases of upsample+conv) on pre-split 16-bit planes, gfx950 only.
+// Second generation of the window-resident kernel (igemm.hip pswin_kernel); reference op: the two conv3x3 of a ResBlock,
+// /root/reference/improved_diffusion/unet.py:143-162,185-198 (plain fp32 ATen conv2d there).
+//
+// What changed against pswin_kernel and why (round-1 profile: MFMA busy 0.40, waves parked 0.44 of the time):
+//  * 4 waves per block, each owning a 128 x 64 tile of the 256 x 128 block tile, two blocks per CU (two waves per SIMD from
+//    DIFFERENT barrier domains): 96 MFMAs per wave per barrier instead of 24, 0.75x the LDS fragment bytes per MFMA.
+//  * v_mfma_f32_16x16x32_{f16,bf16}: the same flops per cycle as 32x32x16 at visibly lower power — a register-resident loop
+//    sustains 1980 vs 1650 TFLOP/s on this part (tools/hiptests/mfma_peak.hip), and K = 32 per instruction lets ONE MFMA
+//    span two (tap, 16-channel) units: lanes 0-31 supply unit 2s, lanes 32-63 unit 2s+1 — every lane reads its own 16 bytes
+//    of LDS anyway, so the two halves simply read different taps (row shifts) / different window halves.
+//  * the activation window is kept as two 16-channel halves; K order is (16-channel group, tap, channel).  A half is dead after
+//    the last tap of its group and is reloaded (LDS-DMA) four K-steps before the group after next needs it — the window load
+//    latency, which pswin_kernel exposed once per 32-channel chunk, is hidden behind MFMA work.
+//  * LDS rows are 32 bytes, unswizzled: the hardware's ds_read_b128 lane groups ({0-3,12-15,20-27}, ...) see 16 distinct rows
+//    with the pieces alternating exactly so that 2*row + piece covers all sixteen 16-byte bank groups for ANY row shift.
+//
+// Product per element (same as every split-precision kernel here): lo*hi + hi*lo + hi*hi, fp32 accumulate.
+// LDS map (80 KB, two blocks per CU): window [half 2][plane 2][384 rows][32 B] = 48 KB, weights [stage 2][plane 2][khalf 2]
+// [128 rows][32 B] = 32 KB.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "cdae_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ int fdiv_cw(int n, unsigned magic, int shift) {             // exact floor(n / d), see igemm.hip fdiv
+    return (int)((__umulhi((unsigned)n, magic) + (unsigned)n) >> shift);
+}
+
+__device__ __forceinline__ void store_planes_cw(const GemmParams& p, long addr, float v) {
+    asm volatile("" : "+v"(v));        // opaque: one rounding of hi (see attention.hip split8)
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    p.C_hi[addr] = __builtin_bit_cast(unsigned short, h);
+    p.C_lo[addr] = __builtin_bit_cast(unsigned short, l);
+}
+
+constexpr int CW_BM = 256, CW_BN = 128;
+constexpr int CW_A_PLANE = 12288, CW_A_HALF = 2 * CW_A_PLANE;               // 384 rows x 32 B
+constexpr int CW_B_BASE = 2 * CW_A_HALF, CW_B_KH = 4096, CW_B_PLANE = 2 * CW_B_KH, CW_B_STAGE = 2 * CW_B_PLANE;
+constexpr int CW_LDS = CW_B_BASE + 2 * CW_B_STAGE;                           // 81920
+constexpr int CW_WIN_DMAS = 6;                                               // window DMAs per wave per reload: 3 row blocks x 2 planes
+// Fragment reads of taps that fall on padding go to an LDS address beyond every allocation: the hardware returns zeros for
+// out-of-range DS reads (tools/hiptests/lds_oob.hip; tests/test_gpu_kernels.py::test_lds_out_of_range_reads_return_zero), which
+// replaces eight v_and per 16-row tile and K-step — the loop's vector-issue budget belongs to the MFMAs.
+constexpr unsigned CW_OOB = 0x0003C000u;       // + the largest read offset stays below 2^18 (0x100000 reads in-range data: the DS address wraps)
+
+// LDS traffic of the K loop goes through inline assembly: the kernel counts its own lgkmcnt (hipcc waits with lgkmcnt(0) whenever
+// anything is outstanding, which would expose the latency of the prefetches issued a few instructions earlier).
+template <int IMM>
+__device__ __forceinline__ u32x4 cw_lds_read(unsigned addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM));
+    return v;
+}
+// lane l's 16 bytes at (base + voff) -> LDS byte lds_dst + 16 l; base and lds_dst wave-uniform, voff a 32-bit byte offset
+// (sbase a kernel-argument pointer, soff a uniform byte offset: readfirstlane pins the sum to the scalar unit — hipcc is free to
+// compute uniform values on the vector ALU and would then hand the "s" operand a VGPR pair)
+#ifndef CW_VARIANT
+#define CW_VARIANT 0
+#endif
+__device__ __forceinline__ void cw_dma(const void* sbase, int soff, unsigned voff, unsigned lds_dst) {
+#if CW_VARIANT & 1
+    cdae_lds_dma16(reinterpret_cast<const char*>(sbase) + soff + voff, (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst));
+    return;
+#endif
+    const char* base = reinterpret_cast<const char*>(sbase) + __builtin_amdgcn_readfirstlane(soff);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane((int)lds_dst)), "v"(voff), "s"(base) : "memory");
+}
+
+template <bool BF>
+__global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, const int ntiles) {
+    typedef const unsigned short* hp;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, kg = lane >> 4, pc = kg & 1;
+    const bool selb = kg >= 2;                                       // this lane feeds K 16..31 of every MFMA: the step's SECOND unit
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int nmt = (p.M + CW_BM - 1) / CW_BM, nnt = (p.N + CW_BN - 1) / CW_BN;
+    const hp a_hi = reinterpret_cast<hp>(p.A), a_lo = p.A_lo;
+    const hp b_hi = reinterpret_cast<hp>(p.B), b_lo = p.B_lo;
+    const int W = p.W;                                                 // tight window of 256 + 2 W rows: row j <-> flattened pixel pix0 + j
+    const int nchunk = p.Cin >> 5;
+    const int c_per = (nchunk + p.ksplit - 1) / p.ksplit;
+
+    // ---- state of the tile being computed (a persistent block walks tiles blockIdx.x, + gridDim.x, ...)
+    int m0, n0, ks, g_begin, g_end, nsteps;
+    unsigned aoffb[3];             // window DMA: byte offset (group 0) of this lane's 16 bytes of rows 32 (wave + 4 q) + lane / 2
+    unsigned woffb;                // weight DMA: byte offset of row n0 + 32 wave + lane / 2 (tap 0, group 0)
+    int tapmask[8];                // per 16-row tile: bit (3 ky + kx) set when tap (ky, kx) of this lane's pixel reads a real pixel
+    auto setup = [&](int tile) {
+        int mt, nt;
+        {       // XCD-aware decode: consecutive tiles of one XCD share the activation window / the weight tile in that XCD's L2
+            const unsigned G = (unsigned)ntiles, b = (unsigned)tile;
+            const unsigned q = G >> 3, r = G & 7, x = b & 7;
+            unsigned v = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+            nt = v % nnt; v /= nnt;
+            mt = v % nmt; ks = v / nmt;
+        }
+        m0 = mt * CW_BM; n0 = nt * CW_BN;
+        const int c_begin = ks * c_per, c_end = min(nchunk, c_begin + c_per);
+        g_begin = 2 * c_begin; g_end = 2 * c_end;                     // 16-channel groups of this K split
+        nsteps = ((g_end - g_begin) * 9) >> 1;                        // K-steps of two (group, tap) units each
+        const int pix0 = m0 - W;
+        // rows outside the tensor (and weight rows beyond Cout) are CLAMPED, not zero-filled: whatever lands there is only ever
+        // addressed by padding taps (redirected out of range) or feeds output columns that are never stored
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int pix = min(max(pix0 + (wave + 4 * q) * 32 + (lane >> 1), 0), p.M - 1);
+            aoffb[q] = (unsigned)pix * (unsigned)p.sx * 2u + (lane & 1) * 16u;
+        }
+        const int wrow = min(n0 + wave * 32 + (lane >> 1), p.N - 1);
+        woffb = (unsigned)wrow * (unsigned)p.ldb * 2u + (lane & 1) * 16u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + wm * 128 + 16 * i + lr;
+            const bool ok = m < p.M;
+            const int mm = ok ? m : 0;
+            const int n = fdiv_cw(mm, p.hw_magic, p.hw_shift), rem = mm - n * p.hw;
+            const int y = fdiv_cw(rem, p.wo_magic, p.wo_shift), x = rem - y * p.Wo;
+            int mk = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int ty = y - 1 + t / 3, tx = x - 1 + t % 3;
+                mk |= (ok && ty >= 0 && ty < p.H && tx >= 0 && tx < W) ? (1 << t) : 0;
+            }
+            tapmask[i] = mk;
+        }
+    };
+
+    auto issue_window = [&](int g) {                                  // group g -> half g & 1
+        const unsigned dst = (g & 1) * CW_A_HALF + wave * 1024;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            cw_dma(a_hi, g * 32, aoffb[q], dst + q * 4096);
+            cw_dma(a_lo, g * 32, aoffb[q], dst + q * 4096 + CW_A_PLANE);
+        }
+    };
+    // weights of the step whose first unit is (g, t) -> stage
+    auto issue_weights = [&](int stage, int g, int t) {
+        int gb = g, tb = t + 1;
+        if (tb == 9) { tb = 0; ++gb; }
+        const unsigned dst = CW_B_BASE + stage * CW_B_STAGE + wave * 1024;
+        int ea, eb;
+        if (p.dbg & 512) { ea = (((g * 9 + t) * 2048 + wave * 512) & 0xffff) * 2; eb = ea + 128; }     // dev: contiguous fake source
+        else { ea = (t * p.Cin + g * 16) * 2; eb = (tb * p.Cin + gb * 16) * 2; }
+        const unsigned vo = (p.dbg & 512) ? lane * 16u : woffb;
+        cw_dma(b_hi, ea, vo, dst);
+        cw_dma(b_hi, eb, vo, dst + CW_B_KH);
+        cw_dma(b_lo, ea, vo, dst + CW_B_PLANE);
+        cw_dma(b_lo, eb, vo, dst + CW_B_PLANE + CW_B_KH);
+    };
+    auto issue_prologue = [&]() {
+        issue_window(g_begin);
+        issue_window(g_begin + 1);
+        issue_weights(0, g_begin, 0);
+        issue_weights(1, g_begin, 2);
+    };
+
+    const unsigned a_lane = (wm * 128 + lr) * 32 + pc * 16;            // byte offset of (tile 0 row, piece) in a window plane
+    const unsigned b_lane = CW_B_BASE + (selb ? CW_B_KH : 0) + (wn * 64 + lr) * 32 + pc * 16;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto mma = [&](const u32x4& x, const u32x4& y, const f32x4& c) -> f32x4 {
+        if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, x), __builtin_bit_cast(bf8, y), c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, x), __builtin_bit_cast(half8, y), c, 0, 0, 0);
+    };
+    // geometry of the step whose first unit is (g, t): this lane's mask bit and byte address of its tile-0 fragment (half + row shift)
+    auto geom = [&](int g, int t, int& wtap, unsigned& addr) {
+        int gb = g, tb = t + 1;
+        if (tb == 9) { tb = 0; ++gb; }
+        const int my_t = selb ? tb : t, my_g = selb ? gb : g;
+        const int ky = (my_t * 11) >> 5, kx = my_t - 3 * ky;              // tap / 3, tap % 3 for tap < 9
+        wtap = my_t;
+        addr = a_lane + (my_g & 1) * CW_A_HALF + (ky * W + kx - 1) * 32;
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    setup(tile);
+    issue_prologue();
+    while (true) {
+        // the tile's first window halves and weight stages (and the previous tile's stores).  The BUILTIN wait, not asm: hipcc's waitcnt
+        // pass must see that nothing it knows of (epilogue loads) is pending when the K loop starts, or it plants a vmcnt(0) on the
+        // first register redefinition inside the loop — a full drain of the DMAs the loop has just issued, every step
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        int ga = g_begin, ta = 0;              // first unit of the current step
+        int gi = g_begin, ti = 4;              // first unit of the next step whose weights are to be staged (step 2)
+        int g_old = g_begin;                   // oldest group whose window half is still live
+        bool reload_prev = false;
+        int wtap_c; unsigned a_c;
+        geom(ga, ta, wtap_c, a_c);
+        unsigned b_c = b_lane;                 // this step's weight stage
+        u32x4 bh[4], bl[4], ah[2], al[2];
+        // fragment address of padding taps -> out of range -> zeros
+#if CW_VARIANT & 2
+        extern __shared__ __attribute__((aligned(16))) char lds[];
+#define CW_READ_A(I, BUF, WTAP, ADDR) { const unsigned m_ = (unsigned)__builtin_amdgcn_sbfe(tapmask[I], WTAP, 1); \
+            const unsigned ad_ = m_ ? ADDR + (I) * 512 : a_lane; \
+            ah[BUF] = *reinterpret_cast<const u32x4*>(lds + ad_) & m_; al[BUF] = *reinterpret_cast<const u32x4*>(lds + ad_ + CW_A_PLANE) & m_; }
+#define CW_READ_B(J, ADDR) { bh[J] = *reinterpret_cast<const u32x4*>(lds + ADDR + (J) * 512); bl[J] = *reinterpret_cast<const u32x4*>(lds + ADDR + (J) * 512 + CW_B_PLANE); }
+#define CW_WAIT(...)
+#else
+#define CW_READ_A(I, BUF, WTAP, ADDR) { const unsigned m_ = (unsigned)__builtin_amdgcn_sbfe(tapmask[I], WTAP, 1); \
+            const unsigned ad_ = (ADDR & m_) | (CW_OOB & ~m_); \
+            ah[BUF] = cw_lds_read<(I) * 512>(ad_); al[BUF] = cw_lds_read<(I) * 512 + CW_A_PLANE>(ad_); }
+#define CW_READ_B(J, ADDR) { bh[J] = cw_lds_read<(J) * 512>(ADDR); bl[J] = cw_lds_read<(J) * 512 + CW_B_PLANE>(ADDR); }
+#define CW_WAIT(...) asm volatile(__VA_ARGS__)
+#endif
+        CW_READ_A(0, 0, wtap_c, a_c);
+        CW_READ_B(0, b_c); CW_READ_B(1, b_c); CW_READ_B(2, b_c); CW_READ_B(3, b_c);
+
+        for (int s = 0; s < nsteps; ++s) {
+            int gn = ga, tn = ta + 2;          // first unit of the next step
+            if (tn >= 9) { tn -= 9; ++gn; }
+            int wtap_n; unsigned a_n;
+            geom(gn, tn, wtap_n, a_n);
+            const unsigned b_n = b_lane + ((s + 1) & 1) * CW_B_STAGE;
+            // outstanding LDS reads here, oldest first: A(0) [2], B(0) [2], B(1) [2], B(2) [2], B(3) [2]
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int cur = i & 1;
+                if (i == 4) {
+                    // ---- mid-step: every wave holds this step's weight fragments in registers, so the stage is free for step s + 2;
+                    // the weights of step s + 1 (issued one step ago) must have landed; a window reload issued after them may stay in flight
+                    if (reload_prev) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CW_WIN_DMAS) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (!(p.dbg & 8)) __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    if (s + 2 < nsteps && !(p.dbg & 4)) issue_weights(s & 1, gi, ti);
+                    ti += 2;
+                    if (ti >= 9) { ti -= 9; ++gi; }
+                    reload_prev = false;
+                    if (ga > g_old) {              // every unit of g_old lies in finished steps: its half is free
+                        if (g_old + 2 < g_end && !(p.dbg & 20)) { issue_window(g_old + 2); reload_prev = true; }
+                        ++g_old;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // tile 0 needs A(0) and B(0) of the ten reads in flight; every other tile's A pair is the only thing outstanding
+                if (i == 0) CW_WAIT("s_waitcnt lgkmcnt(6)" : "+v"(ah[0]), "+v"(al[0]), "+v"(bh[0]), "+v"(bl[0]));
+                else CW_WAIT("s_waitcnt lgkmcnt(0)" : "+v"(ah[cur]), "+v"(al[cur]));
+                acc[i][0] = mma(al[cur], bh[0], acc[i][0]);
+                acc[i][0] = mma(ah[cur], bl[0], acc[i][0]);
+                acc[i][0] = mma(ah[cur], bh[0], acc[i][0]);
+                __builtin_amdgcn_sched_barrier(0);
+                // the next tile's fragment reads go out behind the first three MFMAs and have nine MFMAs to land
+                if (i == 0) { CW_READ_A(1, 1, wtap_c, a_c); }
+                else if (i == 1) { CW_READ_A(2, 0, wtap_c, a_c); }
+                else if (i == 2) { CW_READ_A(3, 1, wtap_c, a_c); }
+                else if (i == 3) { CW_READ_A(4, 0, wtap_c, a_c); }
+                else if (i == 4) { CW_READ_A(5, 1, wtap_c, a_c); }
+                else if (i == 5) { CW_READ_A(6, 0, wtap_c, a_c); }
+                else if (i == 6) { CW_READ_A(7, 1, wtap_c, a_c); }
+                else { CW_READ_A(0, 0, wtap_n, a_n); CW_READ_B(0, b_n); }      // next step: its first tile and the first dead weight fragments
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 1; j < 4; ++j) {
+                    // tile 0: B(j) is the oldest of the reads in flight [B(j) .. B(3), A(1)]
+                    if (i == 0) CW_WAIT("s_waitcnt lgkmcnt(%2)" : "+v"(bh[j]), "+v"(bl[j]) : "n"(8 - 2 * j));
+                    acc[i][j] = mma(al[cur], bh[j], acc[i][j]);
+                    acc[i][j] = mma(ah[cur], bl[j], acc[i][j]);
+                    acc[i][j] = mma(ah[cur], bh[j], acc[i][j]);
+                    if (i == 7) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (j == 1) { CW_READ_B(1, b_n); } else if (j == 2) { CW_READ_B(2, b_n); } else { CW_READ_B(3, b_n); }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            ta = tn; ga = gn; wtap_c = wtap_n; a_c = a_n; b_c = b_n;
+        }
+#undef CW_READ_A
+#undef CW_READ_B
+#undef CW_WAIT
+
+        // ---- tile done: stage the next tile's operands, then write this tile's result (the stores drain behind the next K loop)
+        const int em0 = m0, en0 = n0, eks = ks;
+        const int next = tile + gridDim.x;
+        const bool has_next = next < ntiles;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the look-ahead reads of the step that does not exist
+        __builtin_amdgcn_s_barrier();                                    // every wave is done reading the window and the weight stages
+        asm volatile("" ::: "memory");
+        if (has_next) { setup(next); issue_prologue(); }
+
+        // accumulator tile (i, j): this lane holds rows 4 kg + r (r = 0..3) of column 16 j + lr; the four column tiles of a row are
+        // stored back to back so that the 256 bytes a wave owns of each output row reach L2 together
+        if (!(p.dbg & 256)) {
+            float* __restrict__ Cg;
+            const float* __restrict__ Rg = nullptr;
+            if (p.ksplit > 1) Cg = p.splitk_ws + (long)eks * (long)p.M * p.N;
+            else { Cg = p.C; Rg = p.res; }
+            const int col0 = en0 + wn * 64 + lr;
+            float bv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = (col0 + 16 * j < p.N && p.ksplit == 1 && p.bias) ? p.bias[col0 + 16 * j] : 0.f;
+#pragma unroll
+            for (int i2 = 0; i2 < 4; ++i2) {
+                float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = em0 + wm * 128 + 32 * i2 + 16 * ii + 4 * kg + r;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int col = col0 + 16 * j;
+                            if (row < p.M && col < p.N) {
+                                const float a = acc[2 * i2 + ii][j][r];
+                                if (p.ksplit > 1) Cg[(long)row * p.N + col] = a;
+                                else {
+                                    const long addr = (long)row * p.ldc + col;
+                                    float v = a * p.alpha + bv[j];
+                                    if (Rg) v += Rg[addr];
+                                    if (p.accumulate) v += Cg[addr];
+                                    Cg[addr] = v;
+                                    if (p.C_hi) store_planes_cw(p, addr, v);
+                                    gs[j] += v; gq[j] += v * v;
+                                }
+                            }
+                        }
+                    }
+                }
+                if (p.gn_part && p.ksplit == 1) {                        // per (32-row chunk, column) partial sums of the final values
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float s_ = gs[j], q_ = gq[j];
+                        s_ += __shfl_xor(s_, 16); q_ += __shfl_xor(q_, 16);
+                        s_ += __shfl_xor(s_, 32); q_ += __shfl_xor(q_, 32);
+                        if (kg == 0 && col0 + 16 * j < p.N) {
+                            float* o = p.gn_part + ((long)((em0 + wm * 128 + 32 * i2) >> 5) * p.N + col0 + 16 * j) * 2;
+                            o[0] = s_; o[1] = q_;
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);       // keep the stores' address arithmetic from being hoisted in front of the first one (spills)
+            }
+        }
+        if (!has_next) break;
+        tile = next;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+template <bool BF>
+int launch_convwin(const GemmParams& p, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convwin_kernel<BF>), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS) != hipSuccess)
+            return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
+        attr_done = true;
+    }
+    const long ntiles = (long)((p.M + CW_BM - 1) / CW_BM) * ((p.N + CW_BN - 1) / CW_BN) * p.ksplit;
+    static const int cfg_persist = getenv("CDAE_CONVWIN_GRID") ? atoi(getenv("CDAE_CONVWIN_GRID")) : 512;      // two blocks per CU
+    dim3 grid((unsigned)(ntiles < cfg_persist ? ntiles : cfg_persist));
+    hipLaunchKernelGGL((convwin_kernel<BF>), grid, dim3(256), CW_LDS, st, p, (int)ntiles);
+    return hipGetLastError() == hipSuccess ? 0 : cdae_fail("convwin_kernel launch failed");
+}
+
+}  // namespace
+
+// Shapes this kernel takes (the dispatcher has already checked: stride 1, dense NHWC planes, row-major output).
+bool cdae_convwin_ok(const GemmParams& p) {
+    if (p.prec != 1 && p.prec != 2) return false;
+    if (p.gn_coef || p.A2 || p.ps_taps == 4 || p.out_mode != OUT_ROWMAJOR || p.act != ACT_NONE) return false;
+    if (p.W != 8 && p.W != 16 && p.W != 32 && p.W != 64) return false;            // tight window: tiles start on image-row boundaries
+    if (p.Cin % 32 || p.ldb % 8 || p.sx % 8) return false;
+    if ((long)p.M * p.sx * 2 >= (1L << 32) || (long)p.N * p.ldb * 2 >= (1L << 32)) return false;      // 32-bit byte offsets in the DMAs
+    return true;
+}
+
+int cdae_convwin_launch(const GemmParams& p, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    return p.prec == 2 ? launch_convwin<true>(p, st) : launch_convwin<false>(p, st);
+}

@@ -931,12 +931,12 @@ int launch_ps(const GemmParams& p, hipStream_t st) {
 // BM = 256 (4 x 2 waves of 64 x 64): twice the MFMAs per step and per staged weight byte.  Its window is TIGHT — exactly BM + 2W
 // rows (384 at W = 64, so that window + two weight stages are 80 KB and two blocks still share a CU): the two corner rows of the
 // loose window are only ever read by masked taps when tiles start on an image-row boundary (BM % W == 0), so their reads clamp.
-template <int BN, int NPL, int BST, int MAXWIN, int WAVES_N = 4, bool GNA = false, int BM = 128, bool TIGHT = (BM == 256), int BLOCKS = 2, bool BF = false>
-__global__ __launch_bounds__(BM / 64 * WAVES_N * 64, BM / 64 * WAVES_N * BLOCKS / 4) void pswin_kernel(const GemmParams p) {     // BLOCKS blocks per CU
-    constexpr int WAVES_M = BM / 64, NW = WAVES_M * WAVES_N, THREADS = 64 * NW;
+template <int BN, int NPL, int BST, int MAXWIN, int WAVES_N = 4, bool GNA = false, int BM = 128, bool TIGHT = (BM == 256), int BLOCKS = 2, bool BF = false, int WM_ = 64>
+__global__ __launch_bounds__(BM / WM_ * WAVES_N * 64, BM / WM_ * WAVES_N * BLOCKS / 4) void pswin_kernel(const GemmParams p) {     // BLOCKS blocks per CU; WM_ = rows of a wave tile
+    constexpr int WAVES_M = BM / WM_, NW = WAVES_M * WAVES_N, THREADS = 64 * NW;
     static_assert(!GNA || (BST == 2 && BM == 128), "the fused-GroupNorm window is built for the 2-stage weight ring and 128-row tiles");
     constexpr int G_SLOTS = (MAXWIN * 8 + THREADS - 1) / THREADS;        // float4s of a window chunk per thread
-    constexpr int WM = 64, WN = BN / WAVES_N, TM = 2, TN = WN / 32;
+    constexpr int WM = WM_, WN = BN / WAVES_N, TM = WM_ / 32, TN = WN / 32;
     static_assert(MAXWIN % 16 == 0 && (BST == 2 || BST == 3), "window rows come in 16-row DMA blocks");
     constexpr int A_PLANE = MAXWIN * 64, B_PLANE = BN * 64;
     constexpr int A_SLOTS = (2 * (MAXWIN / 16) + NW - 1) / NW;          // 2 planes x 16-row blocks over the block's waves
@@ -1277,19 +1277,19 @@ __global__ __launch_bounds__(BM / 64 * WAVES_N * 64, BM / 64 * WAVES_N * BLOCKS 
         }
 }
 
-template <int BN, int NPL, int BST, int MAXWIN, int WAVES_N = 4, bool GNA = false, int BM = 128, bool TIGHT = (BM == 256), int BLOCKS = 2, bool BF = false>
+template <int BN, int NPL, int BST, int MAXWIN, int WAVES_N = 4, bool GNA = false, int BM = 128, bool TIGHT = (BM == 256), int BLOCKS = 2, bool BF = false, int WM_ = 64>
 int launch_pswin(const GemmParams& p, hipStream_t st) {
     constexpr size_t smem = (size_t)NPL * MAXWIN * 64 + (size_t)BST * NPL * BN * 64 + (GNA ? 2048 : 0);
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N, GNA, BM, TIGHT, BLOCKS, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N, GNA, BM, TIGHT, BLOCKS, BF, WM_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
         attr_done = true;
     }
     dim3 grid((unsigned)((long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.ksplit));
     static const size_t pad = getenv("CDAE_PS_PAD_LDS") ? (size_t)atoi(getenv("CDAE_PS_PAD_LDS")) : 0;       // dev: force fewer blocks per CU
-    if (pad) hipFuncSetAttribute(reinterpret_cast<const void*>(&pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N, GNA, BM, TIGHT, BLOCKS, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem + pad));
-    hipLaunchKernelGGL((pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N, GNA, BM, TIGHT, BLOCKS, BF>), grid, dim3(BM / 64 * WAVES_N * 64), smem + pad, st, p);
+    if (pad) hipFuncSetAttribute(reinterpret_cast<const void*>(&pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N, GNA, BM, TIGHT, BLOCKS, BF, WM_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem + pad));
+    hipLaunchKernelGGL((pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N, GNA, BM, TIGHT, BLOCKS, BF, WM_>), grid, dim3(BM / WM_ * WAVES_N * 64), smem + pad, st, p);
     return hipGetLastError() == hipSuccess ? 0 : cdae_fail("pswin_kernel launch failed");
 }
 
@@ -1492,10 +1492,17 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
             // 256-row tiles: rows must divide the tile (tight window) and the larger grid must still fill two blocks per CU
             const bool tall2 = cfg_bm == 256 && 256 % p.W == 0 && (long)((p.M + 255) / 256) * ((p.N + 127) / 128) * ks >= 512;
             const bool tall = tall2 && p.prec == 1;
+            static const int cfg_wm = getenv("CDAE_PS_WIN_WM") ? atoi(getenv("CDAE_PS_WIN_WM")) : 64;
             // rows of 16 or 8 pixels: the tight window is 160 rows, 52.5 KB with the two weight stages: THREE blocks (24 waves) per CU
             static const int cfg_b3 = getenv("CDAE_PS_WIN_B3") ? atoi(getenv("CDAE_PS_WIN_B3")) : 0;     // measured: +2 % at 16x16, -8 % at 8x8 -> off
             const bool small_rows = cfg_b3 && p.prec == 1 && p.W <= 16 && 128 % p.W == 0 && cfg_win == 1;
+            // second-generation window kernel (convwin.hip): 4 waves of 128 x 64, 16x16x32 MFMA, staggered half-window reloads
+            static const int cfg_cw = getenv("CDAE_CONVWIN") ? atoi(getenv("CDAE_CONVWIN")) : 1;
+            static const int cfg_cw_min = getenv("CDAE_CONVWIN_MINTILES") ? atoi(getenv("CDAE_CONVWIN_MINTILES")) : 512;
+            if (cfg_cw && cdae_convwin_ok(p) && (long)((p.M + 255) / 256) * ((p.N + 127) / 128) * ks >= cfg_cw_min) rc = cdae_convwin_launch(p, st);
+            else
             if (p.prec == 2) rc = tall2 ? launch_pswin<128, 2, 2, 384, 2, false, 256, true, 2, true>(p, st) : launch_pswin<128, 2, 2, 272, 4, false, 128, false, 2, true>(p, st);
+            else if (tall && cfg_wm == 128) rc = launch_pswin<128, 2, 2, 384, 2, false, 256, true, 2, false, 128>(p, st);      // 4 waves of 128 x 64
             else if (tall) rc = launch_pswin<128, 2, 2, 384, 2, false, 256>(p, st);
             else if (small_rows) rc = launch_pswin<128, 2, 2, 160, 4, false, 128, true, 3>(p, st);
             else

@@ -28,6 +28,24 @@ __global__ void k(const half8* __restrict__ in, float* out, int iters) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// the same flops per iteration on v_mfma_f32_16x16x32_f16 (24 MFMAs of half the size): eight accumulators, three dependent MFMAs each
+__global__ void k16(const half8* __restrict__ in, float* out, int iters) {
+    half8 a0 = in[threadIdx.x], a1 = in[threadIdx.x + 64], b0 = in[threadIdx.x + 128], b1 = in[threadIdx.x + 192];
+    f32x4 c[8] = {};
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            c[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b0, c[q], 0, 0, 0);
+            c[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b1, c[q], 0, 0, 0);
+            c[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, c[q], 0, 0, 0);
+        }
+    }
+    float s = 0.f;
+    for (int q = 0; q < 8; ++q) for (int r = 0; r < 4; ++r) s += c[q][r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 int main() {
     half8* in; float* out;
     hipMalloc(&in, 256 * sizeof(half8)); hipMalloc(&out, 4096 * 1024 * sizeof(float));
@@ -48,5 +66,16 @@ int main() {
             const double fl = (double)blocks * iters * 12 * 2.0 * 32 * 32 * 16;
             printf("chain=%d waves/SIMD=%d: %.3f ms  %.0f TFLOP/s f16 MFMA (%.0f TF f16x3-equivalent)\n", chain, wps, ms, fl / ms / 1e9, fl / ms / 3e9);
         }
+    for (int wps = 1; wps <= 4; wps *= 2) {
+        const int blocks = 256 * 4 * wps, iters = 4000;
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(k16, dim3(blocks), dim3(64), 0, 0, in, out, iters);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+        }
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        const double fl = (double)blocks * iters * 24 * 2.0 * 16 * 16 * 32;
+        printf("16x16x32 chain=1 waves/SIMD=%d: %.3f ms  %.0f TFLOP/s f16 MFMA (%.0f TF f16x3-equivalent)\n", wps, ms, fl / ms / 1e9, fl / ms / 3e9);
+    }
     return 0;
 }

@@ -33,7 +33,11 @@ for (ci, co, r) in [(128, 128, 64), (256, 256, 32), (384, 384, 16), (512, 512, 8
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 100
         fl = 2.0 * B * r * r * co * ci * 9
-        print(f"dbg={os.environ.get('CDAE_PS_DBG','0')} conv {ci}->{co} @{r}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF")
+        y = ops.conv3x3_ps(xs, w, None)
+        exact = torch.nn.functional.conv2d(x[:4].double(), w.double(), padding=1)
+        err = (y[:4].double() - exact).abs().max().item()
+        err2 = (y[-2:].double() - torch.nn.functional.conv2d(x[-2:].double(), w.double(), padding=1)).abs().max().item()
+        print(f"dbg={os.environ.get('CDAE_PS_DBG','0')} cw={os.environ.get('CDAE_CONVWIN','1')} conv {ci}->{co} @{r}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF  err {max(err, err2):.2e}")
         if STAMPS:
             from causaldiffae_amd._lib import splitk_ws
             w64 = splitk_ws(torch.device(DEV)).view(torch.int64)[:64 * 8 * 4].reshape(64 * 8, 4).double().cpu()
