@@ -27,6 +27,9 @@ SIGNATURES = {
     "cdae_conv3x3_wgrad": [P, L, L, L, L, P, L, P, P, I, I, I, I, I, I, I, I, P, SZ, P],
     "cdae_linear_fwd": [P, L, P, L, P, P, P, L, P, P, I, I, I, F, I, P, SZ, P],
     "cdae_conv3x3_fwd_ps": [P, P, L, L, L, P, P, P, P, P, L, I, P, P, P, I, I, I, I, I, I, I, P, SZ, P],
+    "cdae_conv3x3_fwd_psk": [P, P, L, L, L, P, P, P, P, P, P, P, L, I, P, P, P, I, I, I, I, I, I, I, P, SZ, P],
+    "cdae_conv3x3_dgrad_psk": [P, P, P, P, P, P, P, L, I, I, I, I, I, P, SZ, P],
+    "cdae_conv_wpack": [P, P, P, P, I, I, I, P],
     "cdae_conv3x3_fwd_gn": [P, L, I, P, L, P, I, P, P, P, P, P, L, P, P, P, I, I, I, I, I, P, SZ, P],
     "cdae_gn_coef": [P, P, P, P, P, I, P, I, I, I, P],
     "cdae_gn_stats_from_parts": [P, I, I, P, I, I, I, I, I, F, P, P, P, P],
@@ -37,6 +40,7 @@ SIGNATURES = {
     "cdae_upsample2_split": [P, P, P, P, P, I, I, I, I, P],
     "cdae_wdgrad_planes": [P, P, P, I, I, P],
     "cdae_wprep_all": [P, P, I, I, L, P, P, P, P, P],
+    "cdae_wprep_all_k": [P, P, I, I, L, P, P, P, P, P, P, P, P, P],
     "cdae_conv3x3_dgrad_ps": [P, P, P, P, P, L, I, I, I, I, I, P, SZ, P],
     "cdae_conv3x3_stem_supported": [I, I, I],
     "cdae_conv3x3_stem": [P, L, L, L, L, P, P, P, L, I, I, I, I, I, P],

@@ -80,6 +80,16 @@ int cdae_conv3x3_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, 
                         const unsigned short* w_lo, const float* bias, const float* res, float* out, long ldo, int out_nchw,
                         unsigned short* out_hi, unsigned short* out_lo, float* gn_part, int N, int H, int W,
                         int Cin, int Cout, int stride, int up, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    return cdae_conv3x3_fwd_psk(x_hi, x_lo, sn, sy, sx, w_hi, w_lo, nullptr, nullptr, bias, res, out, ldo, out_nchw, out_hi, out_lo, gn_part, N, H, W, Cin,
+                                Cout, stride, up, splitk_ws, splitk_ws_bytes, stream);
+}
+
+// the same with the weights ALSO in K-group-major order (wk_hi / wk_lo from cdae_conv_wpack, may be null): the window kernel's layout
+int cdae_conv3x3_fwd_psk(const unsigned short* x_hi, const unsigned short* x_lo, long sn, long sy, long sx, const unsigned short* w_hi,
+                         const unsigned short* w_lo, const unsigned short* wk_hi, const unsigned short* wk_lo, const float* bias, const float* res,
+                         float* out, long ldo, int out_nchw, unsigned short* out_hi, unsigned short* out_lo, float* gn_part, int N, int H, int W,
+                         int Cin, int Cout, int stride, int up, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    if ((wk_hi != nullptr) != (wk_lo != nullptr) || !aligned16(wk_hi) || !aligned16(wk_lo)) return cdae_fail("conv3x3_fwd_psk: packed weights need both planes, 16-byte aligned");
     if (stride != 1 && stride != 2) return cdae_fail("conv3x3: stride must be 1 or 2");
     if (out_hi && (out_nchw || !out_lo)) return cdae_fail("conv3x3_fwd_ps: plane output needs both planes and a row-major result");
     if (up && stride != 1) return cdae_fail("conv3x3: fused upsample needs stride 1");
@@ -90,6 +100,7 @@ int cdae_conv3x3_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, 
     GemmParams p = base_params();
     p.presplit = 1;
     p.A = reinterpret_cast<const float*>(x_hi); p.A_lo = x_lo; p.B = reinterpret_cast<const float*>(w_hi); p.B_lo = w_lo;
+    p.Bk_hi = wk_hi; p.Bk_lo = wk_lo;
     p.C = out; p.bias = bias; p.res = res; p.C_hi = out_hi; p.C_lo = out_lo; p.gn_part = gn_part;
     p.M = N * Ho * Wo; p.N = Cout; p.K = 9 * Cin;
     p.ldb = 9L * Cin; p.ldc = ldo;
@@ -228,12 +239,20 @@ int cdae_conv3x3_wgrad(const float* x, long sn, long sy, long sx, long sc, const
 // pixel pitch Cout) and wt = the flipped / transposed weight planes of cdae_wdgrad_planes ([Cin][9][Cout])
 int cdae_conv3x3_dgrad_ps(const unsigned short* dy_hi, const unsigned short* dy_lo, const unsigned short* wt_hi, const unsigned short* wt_lo,
                           float* dx, long lddx, int N, int H, int W, int Cin, int Cout, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    return cdae_conv3x3_dgrad_psk(dy_hi, dy_lo, wt_hi, wt_lo, nullptr, nullptr, dx, lddx, N, H, W, Cin, Cout, splitk_ws, splitk_ws_bytes, stream);
+}
+
+int cdae_conv3x3_dgrad_psk(const unsigned short* dy_hi, const unsigned short* dy_lo, const unsigned short* wt_hi, const unsigned short* wt_lo,
+                           const unsigned short* wtk_hi, const unsigned short* wtk_lo, float* dx, long lddx, int N, int H, int W, int Cin, int Cout,
+                           float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    if ((wtk_hi != nullptr) != (wtk_lo != nullptr) || !aligned16(wtk_hi) || !aligned16(wtk_lo)) return cdae_fail("conv3x3_dgrad_psk: packed weights need both planes, 16-byte aligned");
     if ((long)N * H * W * Cout >= (1L << 31)) return cdae_fail("conv3x3_dgrad_ps: gradient larger than 2^31 elements");
     if (Cout % 32 || !aligned16(dy_hi) || !aligned16(dy_lo) || !aligned16(wt_hi) || !aligned16(wt_lo))
         return cdae_fail("conv3x3_dgrad_ps: Cout % 32 == 0 and 16-byte aligned planes required");
     GemmParams p = base_params();
     p.presplit = 1; p.prec = 2; p.grad_operand = 1;
     p.A = reinterpret_cast<const float*>(dy_hi); p.A_lo = dy_lo; p.B = reinterpret_cast<const float*>(wt_hi); p.B_lo = wt_lo;
+    p.Bk_hi = wtk_hi; p.Bk_lo = wtk_lo;
     p.C = dx;
     p.M = N * H * W; p.N = Cin; p.K = 9 * Cout;
     p.ldb = 9L * Cout; p.ldc = lddx;

@@ -57,6 +57,9 @@ struct GemmParams {
     unsigned short* S_hi; unsigned short* S_lo;       // igemm_kernel GNS: side output, the GroupNorm (gn_coef, gn_silu) of the A operand as f16 planes [M][K]
     int dbg;                // dev ablations of ps_kernel (env CDAE_PS_DBG): 1 A rows -> one hot line, 2 B rows -> hot, 4 no loads after the first
     const unsigned short* A_lo; const unsigned short* B_lo;
+    // conv3x3 weights additionally in K-GROUP-MAJOR order [K / 16][taps][rows][16] (cdae_conv_wpack), hi / lo planes: one (group, tap)
+    // unit of an n-tile is one contiguous run, which is how convwin_kernel's weight DMA wants it (nullptr: OHWI planes only)
+    const unsigned short* Bk_hi; const unsigned short* Bk_lo;
 };
 
 int cdae_gemm_dispatch(GemmParams p, void* stream);

@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
 
     const int nmt = (p.M + CW_BM - 1) / CW_BM, nnt = (p.N + CW_BN - 1) / CW_BN;
     const hp a_hi = reinterpret_cast<hp>(p.A), a_lo = p.A_lo;
-    const hp b_hi = reinterpret_cast<hp>(p.B), b_lo = p.B_lo;
+    const bool packed = p.Bk_hi != nullptr;                            // weights [K / 16][9][rows][16]: a (group, tap) unit is one contiguous run
+    const hp b_hi = packed ? p.Bk_hi : reinterpret_cast<hp>(p.B), b_lo = packed ? p.Bk_lo : p.B_lo;
     const int W = p.W;                                                 // tight window of 256 + 2 W rows: row j <-> flattened pixel pix0 + j
     const int nchunk = p.Cin >> 5;
     const int c_per = (nchunk + p.ksplit - 1) / p.ksplit;
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
             aoffb[q] = (unsigned)pix * (unsigned)p.sx * 2u + (lane & 1) * 16u;
         }
         const int wrow = min(n0 + wave * 32 + (lane >> 1), p.N - 1);
-        woffb = (unsigned)wrow * (unsigned)p.ldb * 2u + (lane & 1) * 16u;
+        woffb = packed ? (unsigned)wrow * 32u + (lane & 1) * 16u : (unsigned)wrow * (unsigned)p.ldb * 2u + (lane & 1) * 16u;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int m = m0 + wm * 128 + 16 * i + lr;
@@ -151,13 +152,12 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
         if (tb == 9) { tb = 0; ++gb; }
         const unsigned dst = CW_B_BASE + stage * CW_B_STAGE + wave * 1024;
         int ea, eb;
-        if (p.dbg & 512) { ea = (((g * 9 + t) * 2048 + wave * 512) & 0xffff) * 2; eb = ea + 128; }     // dev: contiguous fake source
+        if (packed) { ea = (g * 9 + t) * p.N * 32; eb = (gb * 9 + tb) * p.N * 32; }
         else { ea = (t * p.Cin + g * 16) * 2; eb = (tb * p.Cin + gb * 16) * 2; }
-        const unsigned vo = (p.dbg & 512) ? lane * 16u : woffb;
-        cw_dma(b_hi, ea, vo, dst);
-        cw_dma(b_hi, eb, vo, dst + CW_B_KH);
-        cw_dma(b_lo, ea, vo, dst + CW_B_PLANE);
-        cw_dma(b_lo, eb, vo, dst + CW_B_PLANE + CW_B_KH);
+        cw_dma(b_hi, ea, woffb, dst);
+        cw_dma(b_hi, eb, woffb, dst + CW_B_KH);
+        cw_dma(b_lo, ea, woffb, dst + CW_B_PLANE);
+        cw_dma(b_lo, eb, woffb, dst + CW_B_PLANE + CW_B_KH);
     };
     auto issue_prologue = [&]() {
         issue_window(g_begin);
@@ -302,7 +302,51 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
 
         // accumulator tile (i, j): this lane holds rows 4 kg + r (r = 0..3) of column 16 j + lr; the four column tiles of a row are
         // stored back to back so that the 256 bytes a wave owns of each output row reach L2 together
-        if (!(p.dbg & 256)) {
+        const bool interior = em0 + CW_BM <= p.M && en0 + CW_BN <= p.N;
+        if (p.dbg & 256) {}                                                // dev ablation: no epilogue
+        else if (interior && p.ksplit == 1 && !p.accumulate && !p.C_hi) {
+            // the common case, kept lean (the general path below spends ~20 instructions per element on bounds and mode tests):
+            // one row pointer per (tile, r), the four column tiles at immediate offsets
+            const long lane_off = (long)(em0 + wm * 128 + 4 * kg) * p.ldc + en0 + wn * 64 + lr;
+            float* __restrict__ cbase = p.C + lane_off;
+            const float* __restrict__ rbase = p.res ? p.res + lane_off : nullptr;
+            float bv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = p.bias ? p.bias[en0 + wn * 64 + lr + 16 * j] : 0.f;
+#pragma unroll
+            for (int i2 = 0; i2 < 4; ++i2) {
+                float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const long ro = (long)(32 * i2 + 16 * ii + r) * p.ldc;
+                        float v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = acc[2 * i2 + ii][j][r] * p.alpha + bv[j];
+                        if (rbase) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] += rbase[ro + 16 * j];
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { cbase[ro + 16 * j] = v[j]; gs[j] += v[j]; gq[j] += v[j] * v[j]; }
+                    }
+                }
+                if (p.gn_part) {                                         // per (32-row chunk, column) partial sums of the final values
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float s_ = gs[j], q_ = gq[j];
+                        s_ += __shfl_xor(s_, 16); q_ += __shfl_xor(q_, 16);
+                        s_ += __shfl_xor(s_, 32); q_ += __shfl_xor(q_, 32);
+                        if (kg == 0) {
+                            float* o = p.gn_part + ((long)((em0 + wm * 128 + 32 * i2) >> 5) * p.N + en0 + wn * 64 + lr + 16 * j) * 2;
+                            o[0] = s_; o[1] = q_;
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
             float* __restrict__ Cg;
             const float* __restrict__ Rg = nullptr;
             if (p.ksplit > 1) Cg = p.splitk_ws + (long)eks * (long)p.M * p.N;
@@ -377,7 +421,35 @@ int launch_convwin(const GemmParams& p, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : cdae_fail("convwin_kernel launch failed");
 }
 
+// [rows][taps][K] 16-bit planes (OHWI conv weights, or the [Cin][9][Cout] dgrad weights) -> [K / 16][taps][rows][16]
+__global__ void wpack_kernel(const uint4* __restrict__ s_hi, const uint4* __restrict__ s_lo, uint4* __restrict__ d_hi, uint4* __restrict__ d_lo,
+                             int rows, int taps, int K) {
+    const long total = (long)rows * taps * (K >> 3);                 // 16-byte pieces per plane
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int pc = (int)(i & 1);                                  // destination order: piece, row, tap, group
+        long r = i >> 1;
+        const int row = (int)(r % rows); r /= rows;
+        const int t = (int)(r % taps);
+        const int g = (int)(r / taps);
+        const long src = ((long)row * taps + t) * (K >> 3) + g * 2 + pc;
+        d_hi[i] = s_hi[src];
+        d_lo[i] = s_lo[src];
+    }
+}
+
 }  // namespace
+
+extern "C" int cdae_conv_wpack(const unsigned short* w_hi, const unsigned short* w_lo, unsigned short* k_hi, unsigned short* k_lo, int rows, int taps,
+                               int K, void* stream) {
+    if (K % 16 || rows <= 0 || taps <= 0 || (((size_t)w_hi | (size_t)w_lo | (size_t)k_hi | (size_t)k_lo) & 15))
+        return cdae_fail("conv_wpack: K % 16 == 0 and 16-byte aligned planes required");
+    const long total = (long)rows * taps * (K >> 3);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wpack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint4*>(w_hi), reinterpret_cast<const uint4*>(w_lo),
+                       reinterpret_cast<uint4*>(k_hi), reinterpret_cast<uint4*>(k_lo), rows, taps, K);
+    return hipGetLastError() == hipSuccess ? 0 : cdae_fail("wpack_kernel launch failed");
+}
 
 // Shapes this kernel takes (the dispatcher has already checked: stride 1, dense NHWC planes, row-major output).
 bool cdae_convwin_ok(const GemmParams& p) {

@@ -108,7 +108,9 @@ __global__ __launch_bounds__(256) void wdgrad_planes_kernel(const float* __restr
 struct WPrepDesc { long off; int Cout, Cin, tile0, pad; };
 __global__ __launch_bounds__(256) void wprep_all_kernel(const float* __restrict__ flat, const WPrepDesc* __restrict__ desc, int nw, long base,
                                                         _Float16* __restrict__ fh, _Float16* __restrict__ fl, __bf16* __restrict__ bh,
-                                                        __bf16* __restrict__ bl) {
+                                                        __bf16* __restrict__ bl, _Float16* __restrict__ kfh, _Float16* __restrict__ kfl,
+                                                        __bf16* __restrict__ kbh, __bf16* __restrict__ kbl) {
+    // kf* / kb* (optional): the same planes in K-group-major order [K / 16][9][rows][16] (cdae_conv_wpack's layout) at the same offsets
     __shared__ float tile[32][33];
     int lo = 0, hi = nw - 1;                       // last descriptor whose first tile <= blockIdx.x
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (desc[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
@@ -127,7 +129,12 @@ __global__ __launch_bounds__(256) void wprep_all_kernel(const float* __restrict_
             const long i = ((long)co * 9 + tap) * d.Cin + ci;
             v = w[i];
             const _Float16 h = (_Float16)v;
-            fh[o0 + i] = h; fl[o0 + i] = (_Float16)(v - (float)h);
+            const _Float16 l = (_Float16)(v - (float)h);
+            fh[o0 + i] = h; fl[o0 + i] = l;
+            if (kfh) {
+                const long k = o0 + (((long)(ci >> 4) * 9 + tap) * d.Cout + co) * 16 + (ci & 15);
+                kfh[k] = h; kfl[k] = l;
+            }
         }
         tile[r][tx] = v;
     }
@@ -138,7 +145,12 @@ __global__ __launch_bounds__(256) void wprep_all_kernel(const float* __restrict_
             const float v = tile[tx][r];
             const __bf16 h = (__bf16)v;
             const long o = o0 + ((long)ci * 9 + (8 - tap)) * d.Cout + co;
-            bh[o] = h; bl[o] = (__bf16)(v - (float)h);
+            const __bf16 l = (__bf16)(v - (float)h);
+            bh[o] = h; bl[o] = l;
+            if (kbh) {
+                const long k = o0 + (((long)(co >> 4) * 9 + (8 - tap)) * d.Cin + ci) * 16 + (co & 15);
+                kbh[k] = h; kbl[k] = l;
+            }
         }
     }
 }
@@ -528,8 +540,16 @@ int cdae_upsample2_split(const float* x, unsigned short* f_hi, unsigned short* f
 int cdae_wprep_all(const float* flat, const void* desc, int nw, int total_tiles, long base, unsigned short* f_hi, unsigned short* f_lo,
                    unsigned short* b_hi, unsigned short* b_lo, void* stream) {
     if (nw <= 0 || total_tiles <= 0) return 0;
+    return cdae_wprep_all_k(flat, desc, nw, total_tiles, base, f_hi, f_lo, b_hi, b_lo, nullptr, nullptr, nullptr, nullptr, stream);
+}
+// + the K-group-major copies for the second-generation window kernel (all four NULL, or all four given; Cin, Cout % 16 == 0 then)
+int cdae_wprep_all_k(const float* flat, const void* desc, int nw, int total_tiles, long base, unsigned short* f_hi, unsigned short* f_lo,
+                     unsigned short* b_hi, unsigned short* b_lo, unsigned short* kf_hi, unsigned short* kf_lo, unsigned short* kb_hi,
+                     unsigned short* kb_lo, void* stream) {
+    if (nw <= 0 || total_tiles <= 0) return 0;
+    if ((kf_hi || kf_lo || kb_hi || kb_lo) && !(kf_hi && kf_lo && kb_hi && kb_lo)) return cdae_fail("wprep_all_k: give all four packed planes or none");
     hipLaunchKernelGGL(wprep_all_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, flat, (const WPrepDesc*)desc, nw, base, (_Float16*)f_hi,
-                       (_Float16*)f_lo, (__bf16*)b_hi, (__bf16*)b_lo);
+                       (_Float16*)f_lo, (__bf16*)b_hi, (__bf16*)b_lo, (_Float16*)kf_hi, (_Float16*)kf_lo, (__bf16*)kb_hi, (__bf16*)kb_lo);
     return hipGetLastError() == hipSuccess ? 0 : cdae_fail("wprep_all launch failed");
 }
 int cdae_wdgrad_planes(const float* w, unsigned short* hi, unsigned short* lo, int Cout, int Cin, void* stream) {

@@ -701,6 +701,10 @@ class ConvWeightBank:
         span = max(o + w.numel() for o, w in zip(offs, self.weights)) - self.base
         self.f16 = torch.empty((2, span), dtype=torch.float16, device=dev)
         self.b16 = torch.empty((2, span), dtype=torch.bfloat16, device=dev)
+        # the same planes in K-group-major order for the second-generation window kernel (channel counts % 16 == 0 everywhere)
+        self.kpack = _KPACK_ON and all(w.shape[0] % 16 == 0 and w.shape[1] % 16 == 0 for w in self.weights)
+        self.kf16 = torch.empty((2, span), dtype=torch.float16, device=dev) if self.kpack else None
+        self.kb16 = torch.empty((2, span), dtype=torch.bfloat16, device=dev) if self.kpack else None
         desc = np.zeros(len(self.weights), dtype=np.dtype([("off", "<i8"), ("cout", "<i4"), ("cin", "<i4"), ("tile0", "<i4"), ("pad", "<i4")]))
         tiles, self.where = 0, {}
         for i, (o, w) in enumerate(zip(offs, self.weights)):
@@ -714,13 +718,27 @@ class ConvWeightBank:
         for w in self.weights:
             _BANK_OF[id(w)] = (weakref.ref(w), self)
 
-    def planes(self, w, bf16):
+    def _refresh(self, w):
         if self.epoch != _WEIGHT_EPOCH[0] or self.versions.get(id(w)) != w._version:
-            check(lib.cdae_wprep_all(ptr(self.flat), ptr(self.desc), len(self.weights), self.tiles, self.base, ptr(self.f16[0]), ptr(self.f16[1]),
-                                     ptr(self.b16[0]), ptr(self.b16[1]), stream()))
+            k = self.kpack
+            check(lib.cdae_wprep_all_k(ptr(self.flat), ptr(self.desc), len(self.weights), self.tiles, self.base, ptr(self.f16[0]), ptr(self.f16[1]),
+                                       ptr(self.b16[0]), ptr(self.b16[1]), ptr(self.kf16[0]) if k else None, ptr(self.kf16[1]) if k else None,
+                                       ptr(self.kb16[0]) if k else None, ptr(self.kb16[1]) if k else None, stream()))
             self.epoch, self.versions = _WEIGHT_EPOCH[0], {id(x): x._version for x in self.weights}
+
+    def planes(self, w, bf16):
+        self._refresh(w)
         o, n = self.where[id(w)]
         buf = self.b16 if bf16 else self.f16
+        return buf[0, o:o + n], buf[1, o:o + n]
+
+    def packed(self, w, bf16):
+        """K-group-major planes (cdae_conv_wpack's order) or (None, None)"""
+        if not self.kpack:
+            return None, None
+        self._refresh(w)
+        o, n = self.where[id(w)]
+        buf = self.kb16 if bf16 else self.kf16
         return buf[0, o:o + n], buf[1, o:o + n]
 
 
@@ -761,6 +779,40 @@ def split_weight(w):
             del _WSPLIT[k]
     _WSPLIT[id(w)] = (weakref.ref(w), tag, planes[0], planes[1])
     return planes[0], planes[1]
+
+
+_KPACK_ON = os.environ.get("CDAE_KPACK", "1") != "0"       # dev switch: 0 = OHWI weight planes only (first-generation window kernel)
+_WPACK = {}
+
+
+def packed_weight(w, bf16=False):
+    """(hi, lo) planes of a conv3x3 weight in K-group-major order [K / 16][9][rows][16] for the second-generation window kernel
+    (rows = Cout, K = Cin for the forward planes; the dgrad planes have rows = Cin, K = Cout), or (None, None).  Cached like split_weight."""
+    if not _KPACK_ON or w.shape[0] % 16 or w.shape[1] % 16:
+        return None, None
+    bank = _bank(w)
+    if bank is not None:
+        return bank.packed(w, bf16)
+    src = dgrad_weight(w) if bf16 else split_weight(w)
+    tag = (src[0].data_ptr(), w.data_ptr(), w._version, _WEIGHT_EPOCH[0])
+    hit = _WPACK.get((id(w), bf16))
+    if hit is not None and hit[0]() is w and hit[1] == tag:
+        return hit[2], hit[3]
+    Cout, Cin = w.shape[0], w.shape[1]
+    rows, K = (Cin, Cout) if bf16 else (Cout, Cin)
+    out = torch.empty((2, w.numel()), dtype=src[0].dtype, device=w.device)
+    check(lib.cdae_conv_wpack(ptr(src[0]), ptr(src[1]), ptr(out[0]), ptr(out[1]), rows, 9, K, stream()))
+    if len(_WPACK) > 4096:
+        for k in [k for k, v in _WPACK.items() if v[0]() is None]:
+            del _WPACK[k]
+    _WPACK[(id(w), bf16)] = (weakref.ref(w), tag, out[0], out[1])
+    return out[0], out[1]
+
+
+def _pk(w, bf16):
+    """packed-plane pointer pair for the _psk entry points"""
+    k_hi, k_lo = packed_weight(ohwi(w) if not bf16 else w, bf16)
+    return ptr(k_hi), ptr(k_lo)
 
 
 def presplit_ok():
@@ -960,7 +1012,7 @@ def conv3x3_ps(xs, w, b=None, res=None, stride=1, up=False, out_nchw=False, emit
     # (the dispatcher's own rule: >= 256 tiles of 128 x 128), and where a 32-pixel chunk never straddles two images
     gn_stats = gn_stats and not out_nchw and (Ho * Wo) % 32 == 0 and ((M + 127) // 128) * ((Cout + 127) // 128) >= 256
     parts = torch.empty(((M + 31) // 32, Cout, 2), dtype=torch.float32, device=dev) if gn_stats else None
-    check(lib.cdae_conv3x3_fwd_ps(ptr(xs.hi), ptr(xs.lo), H * W * Cin, W * Cin, Cin, ptr(w_hi), ptr(w_lo), ptr(b), ptr(res), ptr(out), Cout,
+    check(lib.cdae_conv3x3_fwd_psk(ptr(xs.hi), ptr(xs.lo), H * W * Cin, W * Cin, Cin, ptr(w_hi), ptr(w_lo), *_pk(w, False), ptr(b), ptr(res), ptr(out), Cout,
                                   1 if out_nchw else 0, ptr(planes[0]) if emit_split else None, ptr(planes[1]) if emit_split else None,
                                   ptr(parts), N, H, W, Cin, Cout, stride, 1 if up else 0, ws, wsb, stream()))
     if emit_split:
@@ -1032,7 +1084,7 @@ class _GNConvPS(Function):
         if res is not None:
             res = to_nhwc(res)
         ws, wsb = _sk(dev)
-        check(lib.cdae_conv3x3_fwd_ps(ptr(planes[0]), ptr(planes[1]), H * W * C, W * C, C, ptr(w_hi), ptr(w_lo), ptr(b), ptr(res), ptr(out), Cout,
+        check(lib.cdae_conv3x3_fwd_psk(ptr(planes[0]), ptr(planes[1]), H * W * C, W * C, C, ptr(w_hi), ptr(w_lo), *_pk(w, False), ptr(b), ptr(res), ptr(out), Cout,
                                       0, None, None, None, N, H, W, C, Cout, 1, 0, ws, wsb, st))
         ctx.save_for_backward(x, gamma, beta, ss, stats, bplanes, w)
         ctx.cfg = (silu, groups, b is not None, res is not None)
@@ -1071,7 +1123,7 @@ class _GNConvPS(Function):
         if any(ctx.needs_input_grad[:4]):
             wt_hi, wt_lo = dgrad_weight(w)
             dyn = new_act(N, C, H, W, dev)
-            check(lib.cdae_conv3x3_dgrad_ps(ptr(dplanes[0]), ptr(dplanes[1]), ptr(wt_hi), ptr(wt_lo), ptr(dyn), C, N, H, W, C, Cout, ws, wsb, st))
+            check(lib.cdae_conv3x3_dgrad_psk(ptr(dplanes[0]), ptr(dplanes[1]), ptr(wt_hi), ptr(wt_lo), *_pk(w, True), ptr(dyn), C, N, H, W, C, Cout, ws, wsb, st))
             dx = new_act(N, C, H, W, dev)
             direct = gg is not None and gbt is not None
             dgamma = gg if direct else torch.empty_like(gamma)
@@ -1110,7 +1162,7 @@ class _UpConvPS(Function):
         w_hi, w_lo = split_weight(w)
         out = new_act(N, Cout, 2 * H, 2 * W, dev)
         ws, wsb = _sk(dev)
-        check(lib.cdae_conv3x3_fwd_ps(ptr(planes[0]), ptr(planes[1]), 4 * H * W * C, 2 * W * C, C, ptr(w_hi), ptr(w_lo), ptr(b), None, ptr(out), Cout,
+        check(lib.cdae_conv3x3_fwd_psk(ptr(planes[0]), ptr(planes[1]), 4 * H * W * C, 2 * W * C, C, ptr(w_hi), ptr(w_lo), *_pk(w, False), ptr(b), None, ptr(out), Cout,
                                       0, None, None, None, N, 2 * H, 2 * W, C, Cout, 1, 0, ws, wsb, st))
         ctx.save_for_backward(bplanes, w)
         ctx.cfg = (b is not None, (N, C, H, W))
@@ -1145,7 +1197,7 @@ class _UpConvPS(Function):
         if ctx.needs_input_grad[0]:
             wt_hi, wt_lo = dgrad_weight(w)
             dxu = new_act(N, C, 2 * H, 2 * W, dev)
-            check(lib.cdae_conv3x3_dgrad_ps(ptr(dplanes[0]), ptr(dplanes[1]), ptr(wt_hi), ptr(wt_lo), ptr(dxu), C, N, 2 * H, 2 * W, C, Cout, ws, wsb, st))
+            check(lib.cdae_conv3x3_dgrad_psk(ptr(dplanes[0]), ptr(dplanes[1]), ptr(wt_hi), ptr(wt_lo), *_pk(w, True), ptr(dxu), C, N, 2 * H, 2 * W, C, Cout, ws, wsb, st))
             dx = new_act(N, C, H, W, dev)
             check(lib.cdae_sumpool2(ptr(dxu), ptr(dx), N, H, W, C, st))
         return dx, dw, db
@@ -1198,7 +1250,7 @@ def _rb_conv(planes, w, b, res, shape, Cout, st):
     w_hi, w_lo = split_weight(w)
     out = new_act(N, Cout, H, W, dev)
     ws, wsb = _sk(dev)
-    check(lib.cdae_conv3x3_fwd_ps(ptr(planes[0]), ptr(planes[1]), H * W * C, W * C, C, ptr(w_hi), ptr(w_lo), ptr(b), ptr(res), ptr(out), Cout,
+    check(lib.cdae_conv3x3_fwd_psk(ptr(planes[0]), ptr(planes[1]), H * W * C, W * C, C, ptr(w_hi), ptr(w_lo), *_pk(w, False), ptr(b), ptr(res), ptr(out), Cout,
                                   0, None, None, None, N, H, W, C, Cout, 1, 0, ws, wsb, st))
     return out
 
@@ -1224,7 +1276,7 @@ def _rb_conv_bwd(bplanes, dplanes, w, sinks, has_b, shape, Cout, need_w, st):
             _done(rw, rb)
     wt_hi, wt_lo = dgrad_weight(w)
     dyn = new_act(N, C, H, W, dev)
-    check(lib.cdae_conv3x3_dgrad_ps(ptr(dplanes[0]), ptr(dplanes[1]), ptr(wt_hi), ptr(wt_lo), ptr(dyn), C, N, H, W, C, Cout, ws, wsb, st))
+    check(lib.cdae_conv3x3_dgrad_psk(ptr(dplanes[0]), ptr(dplanes[1]), ptr(wt_hi), ptr(wt_lo), *_pk(w, True), ptr(dyn), C, N, H, W, C, Cout, ws, wsb, st))
     return dyn, dw, db
 
 

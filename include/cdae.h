@@ -88,6 +88,20 @@ int cdae_conv3x3_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, 
                                           result, consumed by cdae_gn_stats_from_parts; disables split-K */,
                         int N, int H, int W,
                         int Cin, int Cout, int stride, int up, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
+/* Second-generation window kernel (convwin.hip; stride-1 3x3 convs on rows of 8..64 pixels): it wants the weights ALSO in
+   K-group-major order [K / 16][taps][rows][16] (one (16-channel group, tap) unit of an n-tile = one contiguous run for its LDS-DMA).
+   cdae_conv_wpack: [rows][taps][K] planes -> that order (rows = Cout, K = Cin for the forward; rows = Cin, K = Cout for the dgrad
+   weights of cdae_wdgrad_planes).  cdae_conv3x3_fwd_psk / cdae_conv3x3_dgrad_psk = the _ps entry points with the packed planes
+   passed along (NULL: identical to _ps; the library falls back to the first-generation kernels). */
+int cdae_conv_wpack(const unsigned short* w_hi, const unsigned short* w_lo, unsigned short* k_hi, unsigned short* k_lo, int rows, int taps,
+                    int K, void* stream);
+int cdae_conv3x3_fwd_psk(const unsigned short* x_hi, const unsigned short* x_lo, long sn, long sy, long sx, const unsigned short* w_hi,
+                         const unsigned short* w_lo, const unsigned short* wk_hi, const unsigned short* wk_lo, const float* bias, const float* res,
+                         float* out, long ldo, int out_nchw, unsigned short* out_hi, unsigned short* out_lo, float* gn_part, int N, int H, int W,
+                         int Cin, int Cout, int stride, int up, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
+int cdae_conv3x3_dgrad_psk(const unsigned short* dy_hi, const unsigned short* dy_lo, const unsigned short* wt_hi, const unsigned short* wt_lo,
+                           const unsigned short* wtk_hi, const unsigned short* wtk_lo, float* dx, long lddx, int N, int H, int W, int Cin, int Cout,
+                           float* splitk_ws, size_t splitk_ws_bytes, void* stream);
 /* GroupNorm mean / rstd of a tensor (or of the channel concatenation of two) from the partial sums its producing conv(s) left
    behind — replaces the statistics pass of cdae_gn_stats(2).  HW % 32 == 0. */
 int cdae_gn_stats_from_parts(const float* part1, int C1, int nseg1 /* 1, or 4 for a sub-pixel up-conv result */, const float* part2, int C2,
@@ -172,6 +186,9 @@ int cdae_wdgrad_planes(const float* w, unsigned short* hi, unsigned short* lo, i
    9 * ceil(Cout/32) * ceil(Cin/32); every output plane is addressed by (weight offset - base). */
 int cdae_wprep_all(const float* flat, const void* desc, int nw, int total_tiles, long base, unsigned short* f_hi, unsigned short* f_lo,
                    unsigned short* b_hi, unsigned short* b_lo, void* stream);
+int cdae_wprep_all_k(const float* flat, const void* desc, int nw, int total_tiles, long base, unsigned short* f_hi, unsigned short* f_lo,
+                     unsigned short* b_hi, unsigned short* b_lo, unsigned short* kf_hi, unsigned short* kf_lo, unsigned short* kb_hi,
+                     unsigned short* kb_lo /* K-group-major copies (cdae_conv_wpack's order), all NULL or all given */, void* stream);
 int cdae_conv3x3_dgrad_ps(const unsigned short* dy_hi, const unsigned short* dy_lo, const unsigned short* wt_hi, const unsigned short* wt_lo,
                           float* dx, long lddx, int N, int H, int W, int Cin, int Cout, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
 /* wgrad of a stride-1 conv3x3 with 1..8 output channels over a dense NHWC fp32 input (the `out` conv, unet.py:474-478): sliding-window
