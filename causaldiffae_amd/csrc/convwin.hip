@@ -108,9 +108,9 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
             mt = v % nmt; ks = v / nmt;
         }
         m0 = mt * CW_BM; n0 = nt * CW_BN;
-        const int c_begin = ks * c_per, c_end = min(nchunk, c_begin + c_per);
+        const int c_begin = ks * c_per, c_end = max(min(nchunk, c_begin + c_per), c_begin);       // the last splits of an uneven division are empty
         g_begin = 2 * c_begin; g_end = 2 * c_end;                     // 16-channel groups of this K split
-        nsteps = ((g_end - g_begin) * 9) >> 1;                        // K-steps of two (group, tap) units each
+        nsteps = ((g_end - g_begin) * 9) >> 1;                        // K-steps of two (group, tap) units each (0: the slab is zeros)
         const int pix0 = m0 - W;
         // rows outside the tensor (and weight rows beyond Cout) are CLAMPED, not zero-filled: whatever lands there is only ever
         // addressed by padding taps (redirected out of range) or feeds output columns that are never stored
@@ -160,6 +160,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
         cw_dma(b_lo, eb, woffb, dst + CW_B_PLANE + CW_B_KH);
     };
     auto issue_prologue = [&]() {
+        if (nsteps == 0) return;
         issue_window(g_begin);
         issue_window(g_begin + 1);
         issue_weights(0, g_begin, 0);
@@ -223,8 +224,10 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
 #define CW_READ_B(J, ADDR) { bh[J] = cw_lds_read<(J) * 512>(ADDR); bl[J] = cw_lds_read<(J) * 512 + CW_B_PLANE>(ADDR); }
 #define CW_WAIT(...) asm volatile(__VA_ARGS__)
 #endif
-        CW_READ_A(0, 0, wtap_c, a_c);
-        CW_READ_B(0, b_c); CW_READ_B(1, b_c); CW_READ_B(2, b_c); CW_READ_B(3, b_c);
+        if (nsteps > 0) {
+            CW_READ_A(0, 0, wtap_c, a_c);
+            CW_READ_B(0, b_c); CW_READ_B(1, b_c); CW_READ_B(2, b_c); CW_READ_B(3, b_c);
+        }
 
         for (int s = 0; s < nsteps; ++s) {
             int gn = ga, tn = ta + 2;          // first unit of the next step

@@ -1498,8 +1498,19 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
             const bool small_rows = cfg_b3 && p.prec == 1 && p.W <= 16 && 128 % p.W == 0 && cfg_win == 1;
             // second-generation window kernel (convwin.hip): 4 waves of 128 x 64, 16x16x32 MFMA, staggered half-window reloads
             static const int cfg_cw = getenv("CDAE_CONVWIN") ? atoi(getenv("CDAE_CONVWIN")) : 1;
-            static const int cfg_cw_min = getenv("CDAE_CONVWIN_MINTILES") ? atoi(getenv("CDAE_CONVWIN_MINTILES")) : 512;
-            if (cfg_cw && cdae_convwin_ok(p) && (long)((p.M + 255) / 256) * ((p.N + 127) / 128) * ks >= cfg_cw_min) rc = cdae_convwin_launch(p, st);
+            static const int cfg_cw_min = getenv("CDAE_CONVWIN_MINTILES") ? atoi(getenv("CDAE_CONVWIN_MINTILES")) : 256;
+            static const int cfg_cw_ks = getenv("CDAE_CONVWIN_SPLITK") ? atoi(getenv("CDAE_CONVWIN_SPLITK")) : 1;
+            const long cw_tiles = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
+            bool cw = cfg_cw && cdae_convwin_ok(p);
+            if (cw && cw_tiles * ks < cfg_cw_min) {
+                // too few 256 x 128 tiles for two blocks per CU: split K by whole 32-channel chunks (the low-resolution levels)
+                int k2 = (int)((512 + cw_tiles - 1) / cw_tiles);
+                if (k2 > nchunk / 2) k2 = nchunk / 2;              // at least two chunks = 18 K-steps per split
+                while (k2 > 1 && (size_t)k2 * p.M * p.N * sizeof(float) > p.splitk_ws_bytes) --k2;
+                if (cfg_cw_ks && k2 > 1 && p.ksplit_auto && p.splitk_ws && !p.gn_part && cw_tiles * k2 >= cfg_cw_min) { p.ksplit = ks = k2; }
+                else cw = false;
+            }
+            if (cw) rc = cdae_convwin_launch(p, st);
             else
             if (p.prec == 2) rc = tall2 ? launch_pswin<128, 2, 2, 384, 2, false, 256, true, 2, true>(p, st) : launch_pswin<128, 2, 2, 272, 4, false, 128, false, 2, true>(p, st);
             else if (tall && cfg_wm == 128) rc = launch_pswin<128, 2, 2, 384, 2, false, 256, true, 2, false, 128>(p, st);      // 4 waves of 128 x 64

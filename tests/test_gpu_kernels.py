@@ -461,7 +461,8 @@ def test_groupnorm_statistics_from_conv_epilogue(N, Cin, Cout, S, stride, cat):
         y = ops.conv3x3_ps(_split_nhwc(x), w, b, stride=stride, gn_stats=True)
         assert hasattr(y, "_gnparts")
         plain = ops.conv3x3_ps(_split_nhwc(x), w, b, stride=stride)
-        assert torch.equal(y, plain)
+        # the statistics epilogue excludes split-K, so the two launches may partition K differently: fp32 rounding of the sum only
+        assert (y - plain).abs().max().item() < 4e-6 * max(1.0, plain.abs().max().item())
         So = y.shape[2]
         parts = y._gnparts.double()
         yr = y.permute(0, 2, 3, 1).reshape(-1, 32, Cout).double()
@@ -511,7 +512,7 @@ def test_groupnorm_statistics_from_upconv_phases():
 ])
 def test_fused_groupnorm_conv_is_bit_identical(N, C1, C2, Cout, S, ss, res):
     """GroupNorm -> (scale-shift) -> SiLU -> conv3x3 in ONE kernel (normalisation applied while staging the activation window)
-    == GroupNorm writing f16 planes + the window conv on those planes, bit for bit."""
+    == GroupNorm writing f16 planes + the window conv on those planes (fp32 summation order aside)."""
     from causaldiffae_amd import ops
     g = torch.Generator(device="cuda:0").manual_seed(14)
     a = ops.to_nhwc(torch.randn(N, C1, S, S, device="cuda:0", generator=g) * 1.3 + 0.2)
@@ -526,11 +527,13 @@ def test_fused_groupnorm_conv_is_bit_identical(N, C1, C2, Cout, S, ss, res):
         lz = ops.group_norm_lazy(x, gamma, beta, sc, True)
         ref = ops.conv3x3_ps(lz.planes(), w, b, res=r, gn_stats=True, emit_split=True)
         got = ops.conv3x3_gn(lz, w, b, res=r, gn_stats=True, emit_split=True)
-    assert torch.equal(got, ref)
-    assert torch.equal(got._split.hi, ref._split.hi) and torch.equal(got._split.lo, ref._split.lo)
+    # same products; the plane path may run on the second-generation window kernel, which sums K in (16-channel group, tap) order
+    scale = max(1.0, ref.abs().max().item())
+    assert (got - ref).abs().max().item() < 4e-6 * scale
+    assert (got._split.hi.float() + got._split.lo.float() - ref._split.hi.float() - ref._split.lo.float()).abs().max().item() < 4e-6 * scale
     assert hasattr(got, "_gnparts") == hasattr(ref, "_gnparts")
     if hasattr(ref, "_gnparts"):
-        assert torch.equal(got._gnparts, ref._gnparts)
+        assert (got._gnparts - ref._gnparts).abs().max().item() < 1e-3 * max(1.0, ref._gnparts.abs().max().item())
 
 
 @pytest.mark.gpu
