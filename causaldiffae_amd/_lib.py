@@ -20,6 +20,7 @@ SZ = ctypes.c_size_t
 SIGNATURES = {
     "cdae_version": [],
     "cdae_last_error": [],
+    "cdae_workspace_bytes": [I, P, I],
     "cdae_set_default_precision": [I],
     "cdae_get_default_precision": [],
     "cdae_conv3x3_fwd": [P, L, L, L, L, P, P, P, P, L, I, I, I, I, I, I, I, I, P, SZ, P],
@@ -104,7 +105,7 @@ SIGNATURES = {
     "cdae_prof_enable": [I],
     "cdae_prof_read": [P, P, P],
 }
-_RESTYPES = {"cdae_last_error": ctypes.c_char_p, "cdae_gn_workspace_floats": SZ, "cdae_bn_workspace_floats": SZ}
+_RESTYPES = {"cdae_last_error": ctypes.c_char_p, "cdae_gn_workspace_floats": SZ, "cdae_bn_workspace_floats": SZ, "cdae_workspace_bytes": SZ}
 
 TAB_ROWS = 12
 PROF_FAMILIES = ("igemm", "groupnorm", "softmax", "elementwise", "optimizer")
@@ -158,6 +159,7 @@ def ptr(t):
 
 
 _ws = {}
+_ws_retired = []
 
 
 def workspace(device, name, nbytes):
@@ -165,15 +167,27 @@ def workspace(device, name, nbytes):
     key = (device.index if device.index is not None else torch.cuda.current_device(), name)
     buf = _ws.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
+        if buf is not None:
+            _ws_retired.append(buf)       # a captured HIP graph may still hold this pointer: outgrown buffers are kept, never recycled
         buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
         _ws[key] = buf
     return buf
 
 
-SPLITK_BYTES = 256 << 20
+WS_SPLITK, WS_GROUPNORM, WS_GN_PARTS, WS_BATCHNORM = 0, 1, 2, 3
+
+
+def workspace_bytes(op, *dims):
+    """cdae_workspace_bytes(op, dims): the library states what scratch an op wants (include/cdae.h)"""
+    arr = (ctypes.c_long * len(dims))(*dims) if dims else None
+    return int(lib.cdae_workspace_bytes(op, arr, len(dims)))
+
+
+SPLITK_BYTES = workspace_bytes(WS_SPLITK)       # the covering size, asked of the library once at import
 
 
 def splitk_ws(device):
+    """ONE split-K workspace per device, sized by the library for every layer of the reference's UNets (no dims = the covering size)"""
     return workspace(device, "splitk", SPLITK_BYTES)
 
 

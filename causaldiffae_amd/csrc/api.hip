@@ -76,6 +76,34 @@ int cdae_conv3x3_fwd(const float* x, long sn, long sy, long sx, long sc, const f
     return cdae_gemm_dispatch(p, stream);
 }
 
+size_t cdae_workspace_bytes(int op, const long* dims, int ndims) {
+    switch (op) {
+    case CDAE_WS_SPLITK: {
+        const size_t cap = (size_t)256 << 20;
+        if (!dims || ndims < 3) return cap;
+        // the dispatcher wants up to ceil(512 / tiles) slabs of M x N floats (at most 64, at most K / 128): see cdae_gemm_dispatch
+        const long M = dims[0], N = dims[1], K = dims[2];
+        if (M <= 0 || N <= 0 || K <= 0) return 0;
+        const long tiles = ((M + 127) / 128) * ((N + 127) / 128);
+        long ks = tiles >= 256 ? 1 : (512 + tiles - 1) / tiles;
+        const long kmax = K / 128 > 0 ? K / 128 : 1;
+        if (ks > kmax) ks = kmax;
+        if (ks > 64) ks = 64;
+        // the window conv kernel counts 256 x 128 tiles and splits by 32-channel chunks of a 3x3 conv (K = 9 Cin), two chunks at least
+        const long tiles2 = ((M + 255) / 256) * ((N + 127) / 128);
+        long ks2 = tiles2 >= 256 ? 1 : (512 + tiles2 - 1) / tiles2;
+        if (ks2 > K / 576) ks2 = K / 576;
+        if (ks2 > ks) ks = ks2;
+        const size_t need = ks > 1 ? (size_t)ks * M * N * sizeof(float) : 0;
+        return need > cap ? cap : need;
+    }
+    case CDAE_WS_GROUPNORM: return dims && ndims >= 2 ? cdae_gn_workspace_floats((int)dims[0], (int)dims[1]) * sizeof(float) : 0;
+    case CDAE_WS_GN_PARTS: return dims && ndims >= 2 ? (size_t)16 * dims[0] * dims[1] : 0;
+    case CDAE_WS_BATCHNORM: return dims && ndims >= 1 ? cdae_bn_workspace_floats((int)dims[0]) * sizeof(float) : 0;
+    default: return 0;
+    }
+}
+
 int cdae_conv3x3_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, long sn, long sy, long sx, const unsigned short* w_hi,
                         const unsigned short* w_lo, const float* bias, const float* res, float* out, long ldo, int out_nchw,
                         unsigned short* out_hi, unsigned short* out_lo, float* gn_part, int N, int H, int W,

@@ -62,9 +62,21 @@ def shard_range(n, rank=None, world=None):
 
 
 def gather_samples(sample):
-    """all_gather of finished samples (the reference does this after the loop, image_causaldae_test.py:438-439)."""
+    """all_gather of finished samples (the reference does this after the loop, image_causaldae_test.py:438-439).  The ranks' shards
+    may differ by one row (shard_range gives the remainder to the lowest ranks): every rank pads to the longest shard, and the
+    gathered per-rank row counts trim the result, so the collective always sees equal shapes."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return [sample]
-    out = [th.zeros_like(sample) for _ in range(dist.get_world_size())]
-    dist.all_gather(out, sample.contiguous())
-    return out
+    world = dist.get_world_size()
+    sample = sample.contiguous()
+    counts = th.zeros(world, dtype=th.int64, device=sample.device)
+    counts[dist.get_rank()] = sample.shape[0]
+    dist.all_reduce(counts)
+    counts = counts.tolist()
+    longest = max(counts)
+    if sample.shape[0] < longest:
+        pad = th.zeros((longest - sample.shape[0],) + tuple(sample.shape[1:]), dtype=sample.dtype, device=sample.device)
+        sample = th.cat([sample, pad], dim=0)
+    out = [th.zeros_like(sample) for _ in range(world)]
+    dist.all_gather(out, sample)
+    return [o[:n] for o, n in zip(out, counts)]

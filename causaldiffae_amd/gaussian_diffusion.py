@@ -293,12 +293,16 @@ class GaussianDiffusion:
             order = tqdm(order)
         runner = None
         if use_graph and self._hot and denoised_fn is None and step_noise is None and (ddim and eta == 0.0):
-            runner = _GraphStep(self, model, img, model_kwargs, clip_denoised, w)
+            # the replay updates its image buffer in place: never the caller's `noise` (the reference leaves it untouched)
+            runner = _GraphStep(self, model, img.clone() if noise is not None and img.data_ptr() == noise.data_ptr() else img,
+                                model_kwargs, clip_denoised, w)
         for k in order:
             t = steps[k]
             with th.no_grad():
                 if runner is not None:
                     out = runner.step(k)
+                    if self.yield_copies:          # the progressive generators hand out fresh tensors like the reference does
+                        out = {k_: v.clone() for k_, v in out.items()}
                 elif ddim:
                     nz = None if step_noise is None else step_noise[k]
                     out = self.ddim_sample(model, img, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn,
@@ -321,6 +325,8 @@ class GaussianDiffusion:
             final = sample
         return final["sample"]
 
+    yield_copies = True        # graph replay: yield clones of the static buffers (ddim_sample_loop itself turns this off: it keeps only the last)
+
     def ddim_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, model_kwargs=None,
                                      device=None, progress=False, eta=0.0, w=None, step_noise=None, use_graph=False):
         yield from self._loop(True, model, shape, noise, clip_denoised, denoised_fn, model_kwargs, device, progress, eta, w,
@@ -329,9 +335,13 @@ class GaussianDiffusion:
     def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, model_kwargs=None, device=None,
                          progress=False, eta=0.0, w=None, step_noise=None, use_graph=False):
         final = None
-        for sample in self.ddim_sample_loop_progressive(model, shape, noise, clip_denoised, denoised_fn, model_kwargs, device,
-                                                        progress, eta, w, step_noise, use_graph):
-            final = sample
+        self.yield_copies = False
+        try:
+            for sample in self.ddim_sample_loop_progressive(model, shape, noise, clip_denoised, denoised_fn, model_kwargs, device,
+                                                            progress, eta, w, step_noise, use_graph):
+                final = sample
+        finally:
+            self.yield_copies = True
         return final["sample"].clone() if use_graph else final["sample"]
 
     # ------------------------------------------------------------------ losses

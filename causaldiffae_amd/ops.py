@@ -12,7 +12,7 @@ import weakref
 import torch
 from torch.autograd import Function
 
-from ._lib import check, lib, ptr, splitk_ws, stream, workspace, SPLITK_BYTES
+from ._lib import check, lib, ptr, splitk_ws, stream, workspace, workspace_bytes, SPLITK_BYTES, WS_GN_PARTS
 
 ACT_NONE, ACT_SILU, ACT_LRELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3, 4
 
@@ -892,7 +892,7 @@ def group_norm_lazy(x, gamma, beta, scale_shift=None, silu=False, groups=32, eps
         # the producing conv(s) left per-chunk partial sums behind: no statistics pass over the tensor
         check(lib.cdae_gn_stats_from_parts(ptr(p1), C1, getattr(x1, "_gnseg", 1), ptr(p2), 0 if x2 is None else C - C1,
                                            1 if x2 is None else getattr(x2, "_gnseg", 1), N, H * W, groups, eps,
-                                           ptr(stats[0]), ptr(stats[1]), ptr(workspace(dev, "gnparts", 16 * N * C)), st))
+                                           ptr(stats[0]), ptr(stats[1]), ptr(workspace(dev, "gnparts", workspace_bytes(WS_GN_PARTS, N, C))), st))
     else:
         ws = workspace(dev, "gn", 4 * lib.cdae_gn_workspace_floats(N, C))
         check(lib.cdae_gn_stats2(ptr(x1), C1, ptr(x2), ld2, C1, N, H * W, C, groups, eps, ptr(stats[0]), ptr(stats[1]), ptr(ws), st))

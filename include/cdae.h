@@ -46,6 +46,18 @@ enum {
 int cdae_version(void);
 const char* cdae_last_error(void);
 
+/* Scratch a caller must provide (the library never allocates).  op selects the family, dims its problem size:
+ *   CDAE_WS_SPLITK      dims = {M, N, K} of the contraction (conv3x3: M = N*Ho*Wo, N = Cout, K = 9*Cin; wgrad: M = Cout, N = 9*Cin,
+ *                       K = pixels): bytes of split-K slabs that let every dispatcher heuristic take its first choice.  A smaller
+ *                       (or NULL) workspace is legal — the dispatcher then splits less.  dims == NULL: the size that covers every
+ *                       layer of the reference's UNets up to batch 256 (256 MiB).
+ *   CDAE_WS_GROUPNORM   dims = {N, C}: partial sums of cdae_gn_* (bytes of cdae_gn_workspace_floats(N, C) floats)
+ *   CDAE_WS_GN_PARTS    dims = {N, C}: per-channel sums of cdae_gn_stats_from_parts (16 * N * C bytes)
+ *   CDAE_WS_BATCHNORM   dims = {C}:   partial sums of cdae_bn_* (bytes of cdae_bn_workspace_floats(C) floats)
+ * Returns 0 for an unknown op or missing dims. */
+enum { CDAE_WS_SPLITK = 0, CDAE_WS_GROUPNORM = 1, CDAE_WS_GN_PARTS = 2, CDAE_WS_BATCHNORM = 3 };
+size_t cdae_workspace_bytes(int op, const long* dims, int ndims);
+
 /* Arithmetic of the dense contractions whose operands are both K-contiguous (conv3x3 / linear / 1x1 forward, QK^T).
  * Inputs, outputs and accumulation are fp32 in both modes.
  *   CDAE_PREC_FP32  : v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fmaf chain.

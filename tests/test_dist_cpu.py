@@ -80,6 +80,10 @@ def _worker(rank, world, port, q):
         err = (flat.grad - want).abs().max().item()
         lo, hi = dist_util.shard_range(1024 + 3, rank, world)
         got = dist_util.gather_samples(torch.full((2, 3), float(rank)))
+        # uneven shards (n % world != 0: the low rank owns one row more) — every rank must still see all rows in rank order
+        l5, h5 = dist_util.shard_range(5, rank, world)
+        uneven = dist_util.gather_samples(torch.arange(l5, h5, dtype=torch.float32).reshape(-1, 1).repeat(1, 4))
+        assert [t.shape[0] for t in uneven] == [3, 2] and torch.equal(torch.cat(uneven)[:, 0], torch.arange(5.0))
         q.put((rank, err, err_mb, (lo, hi), [float(t[0, 0]) for t in got]))
     except Exception as e:          # surface the failure instead of a queue timeout
         import traceback
