@@ -55,13 +55,43 @@ def host_cores():
     return n
 
 
-def cpu_baseline(steps=8, batch=16):
-    """The oracle (torch-CPU restatement of the reference forward + DDIM step) timed on this host's cores."""
+def _cpu_train_step(U, D, sd, cfg, sch, x0, c, y, steps):
+    """Oracle training steps on the host: training_losses + backward + AdamW/EMA (reference train_util.py:232-297)."""
+    names = [k for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k and "num_batches" not in k]
+    params = [sd[k].clone().requires_grad_(True) for k in names]
+    live = dict(sd)
+    live.update(dict(zip(names, params)))
+    m, v = [torch.zeros_like(p) for p in params], [torch.zeros_like(p) for p in params]
+    ema = [p.detach().clone() for p in params]
+    N = x0.shape[0]
+    g = torch.Generator().manual_seed(7)
+    t0 = None
+    for step in range(steps + 1):
+        if step == 1:
+            t0 = time.perf_counter()
+        t = torch.randint(0, 1000, (N,), generator=g)
+        noise, eps_z = torch.randn(x0.shape, generator=g), torch.randn(N, 512, generator=g)
+        fn = lambda x_t, tm, xs: U.unet_forward(live, cfg, x_t, tm, y=y, x_start=xs, eps_z=eps_z, training=True, new_stats={})
+        terms = D.training_losses(sch, fn, x0, t, noise, c=c, rep_cond=True, causal_modeling=True, kl_weight=0.1)
+        terms["loss"].mean().backward()
+        with torch.no_grad():
+            D.adamw_ema_step([p.data for p in params], [p.grad for p in params], m, v, ema, step + 1)
+            for p in params:
+                p.grad = None
+    return steps / (time.perf_counter() - t0)
+
+
+def cpu_baseline(ddim_steps=6, batch=16):
+    """The oracle (torch-CPU restatement of the reference, pinned to the reference's own outputs by tests/test_oracle_golden.py)
+    timed on this host's cores: the headline P64 DDIM step, the C64 training step, and BASELINE config [0] (MorphoMNIST 32x32,
+    T = 1000, batch 16: sampling step and training step).  Bounded samples, a few tens of seconds in all."""
     from oracle import diffusion_ref as D
     from oracle import unet_ref as U
     from oracle.closed_form import fill_state_dict, synth
     cores = host_cores()
     torch.set_num_threads(cores)
+    note = f"{cores} threads (= cgroup CPU quota; host shows {os.cpu_count()} logical CPUs)"
+    # --- headline: P64 DDIM-100 step
     cfg = U.default_cfg(image_size=64, in_channels=4, n_vars=4, rep_cond=True, causal_modeling=True)
     sd = fill_state_dict(U.param_spec(cfg))
     sch = D.Schedule(1000, "linear", "ddim100", True)
@@ -71,11 +101,35 @@ def cpu_baseline(steps=8, batch=16):
     with torch.no_grad():
         D.sample_loop(sch, fn, x, ddim=True, n_steps=1)
         t0 = time.perf_counter()
-        D.sample_loop(sch, fn, x, ddim=True, n_steps=steps)
+        D.sample_loop(sch, fn, x, ddim=True, n_steps=ddim_steps)
         dt = time.perf_counter() - t0
-    return {"value": batch * steps / dt, "unit": "image-steps/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (torch-CPU restatement), P64 DDIM step, batch {batch}, {steps} steps after 1 warm-up, "
-                      f"{cores} threads (= cgroup CPU quota; host shows {os.cpu_count()} logical CPUs)"}
+    out = {"value": batch * ddim_steps / dt, "unit": "image-steps/s", "cores": cores, "kind": "port",
+           "sample": f"oracle (torch-CPU restatement), P64 DDIM step, batch {batch}, {ddim_steps} steps after 1 warm-up, {note}"}
+    # --- C64 training step (BASELINE config [3]'s model, batch 16 on the host)
+    cfg_c = U.default_cfg(image_size=64, in_channels=3, n_vars=4, rep_cond=True, causal_modeling=True)
+    sd_c = fill_state_dict(U.param_spec(cfg_c))
+    sps = _cpu_train_step(U, D, sd_c, cfg_c, D.Schedule(1000, "linear", "", True), synth("bench.cpu.x0c", (batch, 3, 64, 64), 0.0, 1.0),
+                          synth("bench.cpu.cc", (batch, 4), 0.0, 1.0), None, 1)
+    out["train"] = {"value": sps, "unit": "train-steps/s", "images_per_sec": sps * batch, "cores": cores, "kind": "port",
+                    "sample": f"oracle training_losses + backward + AdamW/EMA, C64 batch {batch}, 1 step after 1 warm-up, {note}"}
+    # --- BASELINE config [0]: MorphoMNIST 32x32, 2 causal vars, T = 1000, batch 16
+    cfg_m = U.default_cfg(image_size=32, in_channels=1, n_vars=2, rep_cond=True, causal_modeling=True, class_cond=True)
+    sd_m = fill_state_dict(U.param_spec(cfg_m))
+    sch_m = D.Schedule(1000, "linear", "", True)
+    xm, zm = synth("bench.cpu.xm", (16, 1, 32, 32)), synth("bench.cpu.zm", (16, 512))
+    ym = torch.arange(16) % 10
+    fm = lambda xx, tm: U.unet_forward(sd_m, cfg_m, xx, tm, y=ym, z=zm)[0]
+    with torch.no_grad():
+        D.sample_loop(sch_m, fm, xm, ddim=False, n_steps=1, noises=[torch.zeros_like(xm)] * 1000)
+        t0 = time.perf_counter()
+        D.sample_loop(sch_m, fm, xm, ddim=False, n_steps=10, noises=[torch.zeros_like(xm)] * 1000)
+        dtm = time.perf_counter() - t0
+    sps_m = _cpu_train_step(U, D, sd_m, cfg_m, sch_m, synth("bench.cpu.x0m", (16, 1, 32, 32), 0.0, 1.0), synth("bench.cpu.cm", (16, 2), 0.0, 1.0), ym, 2)
+    out["config0_m32"] = {"p_sample_image_steps_per_sec": 16 * 10 / dtm, "samples_per_sec_T1000": 16 * 10 / dtm / 1000.0,
+                          "train_steps_per_sec": sps_m, "cores": cores, "kind": "port",
+                          "sample": f"oracle, MorphoMNIST 32x32 C=1, 2 causal vars, class_cond, T=1000, batch 16: 10 p_sample steps and 2 training "
+                                    f"steps after 1 warm-up each, {note}"}
+    return out
 
 
 def train_bench(dev, world, rank, steps, warmup, batch):
@@ -126,8 +180,10 @@ def train_bench(dev, world, rank, steps, warmup, batch):
     loss = float(loop.last_losses["loss"].mean().item())
     return {"value": steps / dt, "unit": "train-steps/s", "ms_per_step": 1e3 * dt / steps, "batch_per_gpu": batch,
             "global_batch": batch * world, "images_per_sec": batch * world * steps / dt,
-            "model_tflops": batch * world * steps / dt * 181.86 / 1e3, "dtype": "f32", "last_loss": loss,
-            "host_cpu_ms_per_step": 1e3 * cpu / steps,
+            "model_tflops": batch * world * steps / dt * 181.86 / 1e3,
+            "dtype": "f32 in/out/accumulate/optimizer; forward products f16x3 (2^-22), bf16x3 (2^-16) products in dgrad/wgrad",
+            "steps": steps, "warmup": warmup, "last_loss": loss,
+            "host_cpu_ms_per_step": 1e3 * cpu / steps, "dist_backend": (torch.distributed.get_backend() if world > 1 else None),
             "workload": "CausalCircuit 64x64 C=3 CausalDiffAE training step (fwd+bwd+all-reduce+AdamW/EMA), 93.4M params"}
 
 
@@ -142,7 +198,8 @@ def main():
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--precision", choices=["f16x3", "fp32"], default=None, help="arithmetic of the K-contiguous contractions")
     ap.add_argument("--train-batch", type=int, default=32)
-    ap.add_argument("--train-steps", type=int, default=5)
+    ap.add_argument("--train-steps", type=int, default=20)
+    ap.add_argument("--no-fp32", action="store_true", help="skip the secondary IEEE-fp32-product leg")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -188,18 +245,6 @@ def main():
 
         T = diff.num_timesteps
         steps_tab = diff._step_table(dev, N)
-        runner = None
-        if args.no_graph:
-            img = x_t.clone()
-
-            def do_step(k):
-                nonlocal img
-                img = diff.ddim_sample(model, img, steps_tab[k % T], model_kwargs=kw)["sample"]
-        else:
-            runner = _GraphStep(diff, model, x_t.clone(), kw, True, None)
-
-            def do_step(k):
-                runner.step(k % T)
 
         def sync():
             torch.cuda.synchronize()
@@ -207,86 +252,129 @@ def main():
                 dist.barrier()
                 torch.cuda.synchronize()
 
-        for k in range(max(1, args.warmup)):
-            do_step(k)
-        sync()
-        t0 = time.perf_counter()
-        for k in range(args.steps):
-            do_step(args.warmup + k)
-        sync()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = tt.item()
+        def timed_ddim(steps, warmup):
+            """EXACTLY `steps` timed DDIM steps (graph replay unless --no-graph) after `warmup` untimed ones, max over ranks"""
+            if args.no_graph:
+                state = {"img": x_t.clone()}
 
-        # roofline of the dominant kernel family (igemm on the fp32 matrix cores): HIP events on the launch
-        # stream around every launch during two eager steps, outside the timed region
-        roof = None
-        if rank == 0:
+                def do_step(k):
+                    state["img"] = diff.ddim_sample(model, state["img"], steps_tab[k % T], model_kwargs=kw)["sample"]
+            else:
+                runner = _GraphStep(diff, model, x_t.clone(), kw, True, None)
+
+                def do_step(k):
+                    runner.step(k % T)
+            for k in range(max(1, warmup)):
+                do_step(k)
+            sync()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                do_step(warmup + k)
+            sync()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt = tt.item()
+            return dt
+
+        def roofline(prec, eager_steps=2):
+            """HIP events on the launch stream around every launch of the contraction families during eager steps, outside the timed
+            region.  The dominant kernel (the window conv, convwin_kernel) is reported by itself; `all_contractions` is the whole family."""
             img2 = x_t.clone()
             diff.ddim_sample(model, img2, steps_tab[0], model_kwargs=kw)
             torch.cuda.synchronize()
             _lib.prof_enable(True)
-            for k in range(2):
+            for k in range(eager_steps):
                 img2 = diff.ddim_sample(model, img2, steps_tab[k], model_kwargs=kw)["sample"]
             prof = _lib.prof_read()
             _lib.prof_enable(False)
-            ig = prof["igemm"]
-            ach = ig["work"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
-            prec = causaldiffae_amd.get_precision()
-            # f16x3: every algorithmic multiply-add is 3 f16 MFMA multiply-adds, so the matrix-core roof for ALGORITHMIC
-            # flops is the dense f16 peak / 3; fp32: the fp32 MFMA peak
+            # f16x3: every algorithmic multiply-add is 3 f16 MFMA multiply-adds, so the matrix-core roof for ALGORITHMIC flops is the
+            # dense f16 peak / 3; fp32: the fp32 MFMA peak
             peak = F16_MFMA_PEAK_TFLOPS / 3.0 if prec == "f16x3" else FP32_MFMA_PEAK_TFLOPS
-            kern = ("pswin_kernel / ps_kernel / igemm_kernel<PREC=1> (v_mfma_f32_32x32x16_f16 on pre-split f16 hi/lo planes staged by "
-                    "LDS-DMA, f16x3 split precision, fp32 accumulate)" if prec == "f16x3" else "igemm_kernel (v_mfma_f32_32x32x2_f32)")
-            traffic, traffic_src = None, None
-            pmc_file = os.path.join(ROOT, "profiles", f"r01_igemm_pmc_summary_{prec}.json")
-            if os.path.exists(pmc_file) and N == 128:        # PMC counters cannot be read in-process: separate rocprofv3 --pmc passes
+            cw, ig = prof["convwin"], prof["igemm"]
+            dom = cw if cw["launches"] > 0 and cw["ms"] >= 0.4 * (cw["ms"] + ig["ms"]) else ig
+            name = ("convwin_kernel<f16> (convwin.hip: stride-1 conv3x3 on pre-split f16 hi/lo planes, window resident in LDS, "
+                    "v_mfma_f32_16x16x32_f16 x3 per product, fp32 accumulate)" if dom is cw else
+                    ("igemm_kernel (v_mfma_f32_32x32x2_f32, IEEE fp32 products)" if prec == "fp32" else "pswin / ps / igemm_kernel family (f16x3)"))
+            ach = dom["work"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+            fam_ms, fam_work, fam_n = cw["ms"] + ig["ms"], cw["work"] + ig["work"], cw["launches"] + ig["launches"]
+            r = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s (algorithmic 2MNK)", "frac": ach / peak,
+                 "precision_mode": prec, "launches_per_step": dom["launches"] // eager_steps,
+                 "avg_launch_us": 1e3 * dom["ms"] / max(1, dom["launches"]), "flops_per_launch_avg": dom["work"] / max(1, dom["launches"]),
+                 "share_of_contraction_time": dom["ms"] / fam_ms if fam_ms > 0 else None,
+                 "executed_mfma_tflops": ach * (3.0 if prec == "f16x3" else 1.0),
+                 # 2MNK as EXECUTED: the three upsample convs run in their folded sub-pixel form (2.25x fewer multiply-adds than the
+                 # reference's formulation), so this is below the reference-algorithm rate `model_tflops` implies
+                 "flops_convention": "executed 2MNK per launch (sub-pixel up-convs at folded size)",
+                 # register-resident MFMA loops on random operands sustain 1650 (32x32x16) / 1980 (16x16x32) TFLOP/s on this part
+                 # (tools/hiptests/mfma_peak.hip, profiles/r02_mfma_sustained.txt): 660 TFLOP/s in f16x3 terms for the 16x16x32 kernel
+                 "frac_of_sustained_mfma": (ach / (1980.0 / 3.0)) if prec == "f16x3" else None,
+                 "all_contractions": {"achieved": fam_work / (fam_ms * 1e-3) / 1e12 if fam_ms > 0 else 0.0, "launches_per_step": fam_n // eager_steps,
+                                      "ms_per_step": fam_ms / eager_steps},
+                 "family_ms_per_step": {k: v["ms"] / eager_steps for k, v in prof.items()}}
+            r["all_contractions"]["frac"] = r["all_contractions"]["achieved"] / peak
+            # HBM traffic of the dominant kernel: PMC counters cannot be read in-process (separate rocprofv3 --pmc passes of this same
+            # command, folded by tools/pmc_summary.py and committed under profiles/)
+            traffic = traffic_src = None
+            pmc_file = os.path.join(ROOT, "profiles", f"r02_convwin_pmc_summary_{prec}.json" if dom is cw else f"r01_igemm_pmc_summary_{prec}.json")
+            if os.path.exists(pmc_file) and N == 128:
                 pm = json.load(open(pmc_file))
                 traffic, traffic_src = pm["hbm_traffic_bytes_per_launch"], f"profiles/{os.path.basename(pmc_file)} (rocprofv3 --pmc, same workload)"
-            roof = {"bound": "mfma", "kernel": kern, "achieved": ach, "peak": peak, "unit": "TFLOP/s (algorithmic 2MNK)",
-                    "frac": ach / peak, "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
-                    "precision_mode": prec, "executed_mfma_tflops": ach * (3.0 if prec == "f16x3" else 1.0),
-                    # 2MNK as EXECUTED: the three upsample convs run in their folded sub-pixel form (2.25x fewer multiply-adds than
-                    # the reference's formulation), so this is below the reference-algorithm rate `model_tflops` implies
-                    "flops_convention": "executed 2MNK per launch (sub-pixel up-convs at folded size)",
-                    # a register-resident v_mfma_f32_32x32x16_f16 loop sustains 1640 TFLOP/s on this part (tools/hiptests/mfma_peak.hip,
-                    # profiles/r01_mfma_sustained.txt): 547 TFLOP/s in f16x3 terms
-                    "frac_of_sustained_mfma": (ach / (1640.0 / 3.0)) if prec == "f16x3" else None,
-                    "vs_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
-                    "launches_per_step": ig["launches"] // 2, "avg_launch_us": 1e3 * ig["ms"] / max(1, ig["launches"]),
-                    "flops_per_launch_avg": ig["work"] / max(1, ig["launches"]),
-                    "family_ms_per_step": {k: v["ms"] / 2 for k, v in prof.items()}}
+            alg = dom["bytes"] / max(1, dom["launches"]) if dom["bytes"] > 0 else None
+            r.update({"traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
+                      "algorithmic_bytes_per_launch": alg, "traffic_ratio": (traffic / alg) if traffic and alg else None})
+            return r
+
+        prec0 = causaldiffae_amd.get_precision()
+        dt = timed_ddim(args.steps, args.warmup)
+        roof = roofline(prec0) if rank == 0 else None
+        # secondary leg (single GPU): the other product mode — IEEE fp32 products on v_mfma_f32_32x32x2_f32 against its own roof
+        other = None
+        if world == 1 and not args.no_fp32:
+            alt = "fp32" if prec0 == "f16x3" else "f16x3"
+            causaldiffae_amd.set_precision(alt)
+            try:
+                k2 = max(2, min(args.steps, 4))
+                dt2 = timed_ddim(k2, 1)
+                other = {"precision_mode": alt, "value": N * k2 / dt2, "unit": "image-steps/s", "ms_per_step": 1e3 * dt2 / k2, "steps": k2,
+                         "warmup": 1, "model_tflops": N * k2 / dt2 * GFLOP_PER_IMAGE_STEP_P64 / 1e3, "roofline": roofline(alt, 1)}
+            finally:
+                causaldiffae_amd.set_precision(prec0)
 
     train = None
     if not args.no_train:
-        del runner, model
+        del model
         torch.cuda.empty_cache()
         try:
-            train = train_bench(dev, world, rank, args.train_steps, 2, args.train_batch)
+            train = train_bench(dev, world, rank, args.train_steps, 3, args.train_batch)
         except Exception as e:                      # never lose the headline line to the secondary leg
             train = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank != 0:
         return
     value = world * N * args.steps / dt
+    dtype_of = {"fp32": "f32 (IEEE fp32 products, v_mfma_f32_32x32x2_f32)",
+                "f16x3": "f32 in/out/accumulate; products as f16x3 split (hi*hi + hi*lo + lo*hi on f16 MFMA, 2^-22 relative)"}
     out = {
         "metric": "DDIM denoise image-steps/sec, 64x64 UNet (P64)", "value": value, "unit": "image-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if causaldiffae_amd.get_precision() == "fp32" else "f32 (in/out/accumulate; products as f16x3 split, 2^-22)",
-        "data": "synthetic",
+        "dtype": dtype_of[prec0], "data": "synthetic",
         "config": {"workload": "Pendulum 64x64 C=4, 4 causal vars, DDIM-100 counterfactual sampling (encode -> intervene -> "
                                "q_sample -> ddim steps), UNet 93.45M params", "batch_per_gpu": N, "global_batch": N * world,
                    "parallelism": f"batch-sharded x{world}, no collectives", "hip_graph": not args.no_graph},
+        "dist_backend": (dist.get_backend() if world > 1 else None), "ranks_in_group": (dist.get_world_size() if world > 1 else 1),
         "samples_per_sec_ddim100": value / 100.0,
         "model_tflops": value * GFLOP_PER_IMAGE_STEP_P64 / 1e3,
         "roofline": roof,
+        "other_precision": other,
         "train": train,
     }
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline()
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        if train and "value" in train:
+            out["train_gpu_over_cpu_images_per_sec"] = train["images_per_sec"] / out["cpu_baseline"]["train"]["images_per_sec"]
     print(json.dumps(out))
 
 

@@ -103,12 +103,12 @@ SIGNATURES = {
     "cdae_mse_rows": [P, P, P, I, L, P],
     "cdae_mse_rows_bwd": [P, P, P, P, I, L, P],
     "cdae_prof_enable": [I],
-    "cdae_prof_read": [P, P, P],
+    "cdae_prof_read": [P, P, P, P],
 }
 _RESTYPES = {"cdae_last_error": ctypes.c_char_p, "cdae_gn_workspace_floats": SZ, "cdae_bn_workspace_floats": SZ, "cdae_workspace_bytes": SZ}
 
 TAB_ROWS = 12
-PROF_FAMILIES = ("igemm", "groupnorm", "softmax", "elementwise", "optimizer")
+PROF_FAMILIES = ("igemm", "groupnorm", "softmax", "elementwise", "optimizer", "convwin")
 
 
 class CdaeError(RuntimeError):
@@ -212,6 +212,7 @@ def prof_read():
     n = len(PROF_FAMILIES)
     ms = (ctypes.c_double * n)()
     work = (ctypes.c_double * n)()
+    nbytes = (ctypes.c_double * n)()
     cnt = (ctypes.c_longlong * n)()
-    check(lib.cdae_prof_read(ms, work, cnt))
-    return {PROF_FAMILIES[i]: dict(ms=ms[i], work=work[i], launches=cnt[i]) for i in range(n)}
+    check(lib.cdae_prof_read(ms, work, nbytes, cnt))
+    return {PROF_FAMILIES[i]: dict(ms=ms[i], work=work[i], bytes=nbytes[i], launches=cnt[i]) for i in range(n)}

@@ -71,9 +71,10 @@ int cdae_convwin_launch(const GemmParams& p, void* stream);
 int cdae_fail(const char* msg);
 
 // lightweight per-family profiling (HIP events on the launch stream), see prof.hip
-enum { PROF_IGEMM = 0, PROF_GN = 1, PROF_SOFTMAX = 2, PROF_ELEMWISE = 3, PROF_OPT = 4, PROF_NFAM = 5 };
+enum { PROF_IGEMM = 0, PROF_GN = 1, PROF_SOFTMAX = 2, PROF_ELEMWISE = 3, PROF_OPT = 4, PROF_CONVWIN = 5, PROF_NFAM = 6 };
 void cdae_prof_begin(int family, double work, hipStream_t st);
 void cdae_prof_end(int family, hipStream_t st);
+void cdae_prof_note(int family, double bytes);
 
 // LDS-DMA (global_load_lds_dwordx4) issued through inline assembly: lane l's 16 bytes at `src` land at LDS byte address
 // lds_dst + 16 l (lds_dst wave-uniform).  Why not __builtin_amdgcn_global_load_lds: hipcc's waitcnt pass keeps the ADDRESS

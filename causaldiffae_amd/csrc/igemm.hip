@@ -1510,7 +1510,11 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
                 if (cfg_cw_ks && k2 > 1 && p.ksplit_auto && p.splitk_ws && !p.gn_part && cw_tiles * k2 >= cfg_cw_min) { p.ksplit = ks = k2; }
                 else cw = false;
             }
-            if (cw) rc = cdae_convwin_launch(p, st);
+            if (cw) {
+                // algorithmic bytes: both activation planes, both weight planes, the fp32 result (+ the residual read)
+                cdae_prof_note(PROF_CONVWIN, 4.0 * p.M * p.Cin + 4.0 * p.K * p.N + 4.0 * p.M * p.N * (p.res ? 2 : 1));
+                rc = cdae_convwin_launch(p, st);
+            }
             else
             if (p.prec == 2) rc = tall2 ? launch_pswin<128, 2, 2, 384, 2, false, 256, true, 2, true>(p, st) : launch_pswin<128, 2, 2, 272, 4, false, 128, false, 2, true>(p, st);
             else if (tall && cfg_wm == 128) rc = launch_pswin<128, 2, 2, 384, 2, false, 256, true, 2, false, 128>(p, st);      // 4 waves of 128 x 64

@@ -10,13 +10,14 @@
 
 namespace {
 thread_local std::string g_err;
-struct Rec { int fam; double work; hipEvent_t a, b; };
+struct Rec { int fam; double work, bytes; hipEvent_t a, b; };
 std::mutex g_mu;
 bool g_on = false;
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
 thread_local hipEvent_t t_start = nullptr;
-thread_local double t_work = 0;
+thread_local double t_work = 0, t_bytes = 0;
+thread_local int t_fam = -1;
 
 hipEvent_t get_event() {
     if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
@@ -30,8 +31,14 @@ void cdae_prof_begin(int fam, double work, hipStream_t st) {
     if (!g_on) return;
     std::lock_guard<std::mutex> lk(g_mu);
     t_start = get_event();
-    t_work = work;
+    t_work = work; t_bytes = 0; t_fam = fam;
     hipEventRecord(t_start, st);
+}
+
+// the launch between begin and end belongs to `fam` instead (a sub-family reported on its own) and moves `bytes` algorithmic bytes
+void cdae_prof_note(int fam, double bytes) {
+    if (!g_on || !t_start) return;
+    t_fam = fam; t_bytes = bytes;
 }
 
 void cdae_prof_end(int fam, hipStream_t st) {
@@ -39,7 +46,7 @@ void cdae_prof_end(int fam, hipStream_t st) {
     std::lock_guard<std::mutex> lk(g_mu);
     hipEvent_t e = get_event();
     hipEventRecord(e, st);
-    g_recs.push_back({fam, t_work, t_start, e});
+    g_recs.push_back({t_fam >= 0 ? t_fam : fam, t_work, t_bytes, t_start, e});
     t_start = nullptr;
 }
 
@@ -56,15 +63,15 @@ int cdae_prof_enable(int on) {
 }
 
 // Synchronises the device, folds all recorded launches into per-family totals and clears the log.
-// ms/work/launches are arrays of CDAE_PROF_FAMILIES entries.
-int cdae_prof_read(double* ms, double* work, long long* launches) {
+// ms / work (flops) / bytes (algorithmic, where the dispatcher states them) / launches are arrays of CDAE_PROF_FAMILIES entries.
+int cdae_prof_read(double* ms, double* work, double* bytes, long long* launches) {
     if (hipDeviceSynchronize() != hipSuccess) return cdae_fail("hipDeviceSynchronize failed");
     std::lock_guard<std::mutex> lk(g_mu);
-    for (int i = 0; i < PROF_NFAM; ++i) { ms[i] = 0; work[i] = 0; launches[i] = 0; }
+    for (int i = 0; i < PROF_NFAM; ++i) { ms[i] = 0; work[i] = 0; bytes[i] = 0; launches[i] = 0; }
     for (auto& r : g_recs) {
         float t = 0.f;
         hipEventElapsedTime(&t, r.a, r.b);
-        ms[r.fam] += t; work[r.fam] += r.work; launches[r.fam] += 1;
+        ms[r.fam] += t; work[r.fam] += r.work; bytes[r.fam] += r.bytes; launches[r.fam] += 1;
         g_pool.push_back(r.a); g_pool.push_back(r.b);
     }
     g_recs.clear();

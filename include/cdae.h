@@ -22,7 +22,7 @@ extern "C" {
 #define CDAE_VERSION 1
 #define CDAE_GN_MAX_CHUNKS 64
 #define CDAE_BN_MAX_CHUNKS 256
-#define CDAE_PROF_FAMILIES 5      /* 0 igemm (MFMA), 1 groupnorm, 2 softmax, 3 elementwise, 4 optimizer */
+#define CDAE_PROF_FAMILIES 6      /* 0 igemm (every contraction but 5), 1 groupnorm, 2 softmax, 3 elementwise, 4 optimizer, 5 convwin (the window conv kernel) */
 
 /* rows of the fp32 coefficient table passed to the sampler kernels: tab[row * T + t]
  * (float32 roundings of the float64 tables of gaussian_diffusion.py:137-179, i.e. what
@@ -337,7 +337,8 @@ int cdae_mse_rows_bwd(const float* a, const float* b, const float* gout, float* 
 
 /* ---- opt-in profiler (prof.hip): HIP events on the launch stream around every launch of a kernel family */
 int cdae_prof_enable(int on);
-int cdae_prof_read(double* ms, double* work, long long* launches);
+/* per family since the last read: milliseconds, flops (2MNK as executed), algorithmic bytes (convwin: each operand and the result once), launches */
+int cdae_prof_read(double* ms, double* work, double* bytes, long long* launches);
 
 #ifdef __cplusplus
 }

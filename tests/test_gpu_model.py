@@ -28,11 +28,19 @@ def load_closed_form(module, prefix=""):
     return module.to(DEV)
 
 
-def probe_err(t, g, prefix):
+def probe_err(t, g, prefix, base=None):
+    """Largest deviation of the head / strided samples from the reference's, RELATIVE TO THE REFERENCE TENSOR'S OWN largest sampled
+    entry (no absolute floor: a gradient of magnitude 1e-3 is judged at 1e-3 * tol).  base: compare (t - base) with (golden - base),
+    i.e. the UPDATE a training step applied rather than the weights themselves."""
     f = t.detach().cpu().double().flatten()
-    e = max(err(f[:64], g[prefix + "/head"]), err(f[::997], g[prefix + "/strided"]))
-    scale = max(1.0, float(np.abs(g[prefix + "/head"]).max()), float(np.abs(g[prefix + "/strided"]).max()))
-    return e / scale
+    gh, gs = torch.from_numpy(g[prefix + "/head"]).double(), torch.from_numpy(g[prefix + "/strided"]).double()
+    fh, fs = f[:64], f[::997]
+    if base is not None:
+        b = base.detach().cpu().double().flatten()
+        fh, fs, gh, gs = fh - b[:64], fs - b[::997], gh - b[:64], gs - b[::997]
+    e = max(err(fh, gh), err(fs, gs))
+    scale = max(float(gh.abs().max()), float(gs.abs().max()))
+    return e / scale if scale > 0 else e
 
 
 MODEL_CFG = {
@@ -120,7 +128,7 @@ def test_encoder_golden(golden, tag, C, S, nv):
     from improved_diffusion.unet import encoder_hidden_dims
     g = golden("g4_encoder.npz")
     enc = load_closed_form(GaussianConvEncoder(C, 512, hidden_dims=encoder_hidden_dims(S, nv), num_vars=nv), "rep_emb.")
-    x = synth(tag + ".x", (4, C, S, S), 0.0, 1.0).to(DEV)
+    x = synth(str(g[tag + "/input_name"]), (4, C, S, S), 0.0, 1.0).to(DEV)      # chosen by the generator away from every LeakyReLU kink
     enc.eval()
     with torch.no_grad():
         mu, var = enc.encode(x)
@@ -130,19 +138,13 @@ def test_encoder_golden(golden, tag, C, S, nv):
     mu, var = enc.encode(xg)
     assert err(mu, g[tag + "/train_mu"]) < 1e-4 and err(var, g[tag + "/train_var"]) < 1e-4
     ((mu * synth(tag + ".gmu", (4, 512)).to(DEV)).sum() + (var * synth(tag + ".gvar", (4, 512)).to(DEV)).sum()).backward()
-    # enc64's golden input puts one layer-0 pre-activation at 9e-8 (n=0,c=8,y=23,x=1): the LeakyReLU branch there is
-    # decided by fp32 rounding, so that one pixel's 0.99*dy shows up in gx (3x3x4 patch) and the layer-0 parameter
-    # gradients.  Everything else must match; test_encoder_backward_vs_oracle covers layer 0 on a kink-free input.
-    kink = tag == "enc64"
-    d = (xg.grad.cpu().double() - torch.from_numpy(g[tag + "/train_gx"]).double()).abs()
-    tol = 1e-4 * max(1.0, float(np.abs(g[tag + "/train_gx"]).max()))
-    assert int((d > tol).sum()) <= (36 if kink else 0)
+    assert err(xg.grad, g[tag + "/train_gx"]) < 1e-4 * max(1.0, float(np.abs(g[tag + "/train_gx"]).max()))
     for k, v in enc.state_dict().items():
         if "running" in k:
             assert err(v, g[f"{tag}/after.{k}"]) < 1e-5, k
     for k, p in enc.named_parameters():
-        if k.endswith(".0.bias") or (kink and k.startswith("encoder.0.")):
-            continue            # exactly-zero gradient (bias ahead of batch-stat BN) / the kink pixel
+        if k.endswith(".0.bias"):
+            continue            # mathematically zero gradient (a conv bias ahead of a batch-statistics BatchNorm): rounding noise on both sides
         assert probe_err(p.grad, g, f"{tag}/g.{k}") < 3e-4, k
 
 
@@ -303,18 +305,179 @@ def test_training_trajectory_golden(golden, variant, masking, precision):
             ref = g[f"{variant}/step{step}/{k}"]
             assert err(terms[k], ref) < 1e-4 * max(1.0, float(np.abs(ref).max())), (step, k)
         sq = opt.grad_sqsum()
-        assert abs(sq - float(g[f"{variant}/step{step}/grad_sqsum"])) <= 2e-3 * sq
+        assert abs(sq - float(g[f"{variant}/step{step}/grad_sqsum"])) <= 5e-4 * sq
         if step == 0:
             for k in sel:
-                assert probe_err(dict(model.named_parameters())[k].grad, g, f"{variant}/grad0/{k}") < 1e-3, k
+                # relative to the gradient tensor's own scale (4.7e-4 .. 0.35 here), not to 1
+                assert probe_err(dict(model.named_parameters())[k].grad, g, f"{variant}/grad0/{k}") < 2e-4, k
         opt.step()
         if step in (0, 2):
             params = dict(model.named_parameters())
             ema = opt.ema_state_dict(0)
             for k in sel:
-                assert probe_err(params[k], g, f"{variant}/after{step + 1}/{k}") < 1e-5, k       # 1e-5
+                init = fill_value(k, params[k].shape)
+                # the UPDATE the optimizer applied (w_after - w_init, ~1e-4 per step) within 1e-2 of the reference's update, and the
+                # weights themselves within SURVEY 8a row T's 1e-5 of their own scale (the EMA moves by 1e-4 of an update per step:
+                # below fp32 resolution of the weights, so only the value is compared there)
+                assert probe_err(params[k], g, f"{variant}/after{step + 1}/{k}", base=init) < 1e-2, k
+                assert probe_err(params[k], g, f"{variant}/after{step + 1}/{k}") < 1e-5, k
                 assert probe_err(ema[k], g, f"{variant}/ema{step + 1}/{k}") < 1e-5, k
             assert err(model.state_dict()["rep_emb.encoder.1.1.running_var"], g[f"{variant}/after{step + 1}/bn_running_var"]) < 1e-5
+
+
+# ------------------------------------------------------------------ G12: one training step of the FULL benchmarked models
+def grad_probe_err(t, g, prefix):
+    """head / strided samples of a full-model gradient against the reference's, relative to that tensor's own largest entry"""
+    f = t.detach().cpu().double().flatten()
+    e = max(err(f[:16], g[prefix + "/head"]), err(f[::4999], g[prefix + "/strided"]))
+    return e / float(g[prefix + "/absmax"])
+
+
+def _full_train_step(g, tag, **extra):
+    from improved_diffusion.nn import rng_override
+    model, diff, cfg = make(tag, **extra)
+    model.train()
+    N = 2
+    x, x0, c, z, y = model_inputs(tag + ".train", cfg, N)
+    t = torch.tensor([37, 990], dtype=torch.int64, device=DEV)
+    noise = synth(tag + ".train.noise", tuple(x0.shape), -1.7, 1.7).to(DEV)
+    diff.kl_weight = 0.3
+    kw = dict(c=c.to(DEV))
+    if y is not None:
+        kw["y"] = y.to(DEV)
+    with rng_override(eps_z=torch.from_numpy(g[f"{tag}/eps_draw"]).to(DEV)):
+        terms = diff.training_losses(model, x0.to(DEV), t, model_kwargs=kw, noise=noise, rep_cond=True, causal_modeling=True)
+    terms["loss"].mean().backward()
+    return model, terms
+
+
+@pytest.mark.parametrize("tag", ["M32", "C64"])
+def test_full_model_training_step_golden(golden, tag, precision):
+    """training_losses + backward (reference gaussian_diffusion.py:768-859) on the 41 M / 93 M parameter models bench.py trains:
+    loss terms, the squared gradient norm and EVERY parameter's gradient (head + strided samples) against the reference's, each
+    gradient judged relative to its own largest entry.  The backward GEMMs form bf16x3 products (2^-16 per product)."""
+    g = golden("g12_full_train.npz")
+    model, terms = _full_train_step(g, tag)
+    for k in ("loss", "mse", "kld_rep"):
+        ref = g[f"{tag}/{k}"]
+        assert err(terms[k], ref) < 1e-4 * max(1.0, float(np.abs(ref).max())), k
+    params = dict(model.named_parameters())
+    names = [str(k) for k in g[f"{tag}/grad_names"]]
+    sq = sum(float((params[k].grad.double() ** 2).sum()) for k in names)
+    assert abs(sq - float(g[f"{tag}/grad_sqsum"])) <= 5e-4 * sq
+    worst = ("", 0.0)
+    for k in names:
+        if float(g[f"{tag}/g/{k}/absmax"]) == 0.0:
+            assert float(params[k].grad.abs().max()) == 0.0, k       # partners of zero-initialised layers
+            continue
+        if k.startswith("rep_emb.encoder.") and k.endswith(".0.bias"):
+            continue            # mathematically zero gradient: rounding noise on both sides
+        e = grad_probe_err(params[k].grad, g, f"{tag}/g/{k}")
+        if e > worst[1]:
+            worst = (k, e)
+    assert worst[1] < 2e-4, worst
+    for k, v in model.state_dict().items():
+        if "running_mean" in k or "running_var" in k:
+            assert err(v, g[f"{tag}/after/{k}"]) < 1e-5 * max(1.0, float(np.abs(g[f"{tag}/after/{k}"]).max())), k
+
+
+def test_use_checkpoint_gradients_golden(golden):
+    """use_checkpoint=True (reference nn.py:572-618: activations recomputed in the backward) gives the reference's gradients too."""
+    g = golden("g12_full_train.npz")
+    model, terms = _full_train_step(g, "M32", use_checkpoint=True)
+    assert err(terms["loss"], g["M32/loss"]) < 1e-4 * max(1.0, float(np.abs(g["M32/loss"]).max()))
+    params = dict(model.named_parameters())
+    for k in [str(k) for k in g["M32/grad_names"]]:
+        if float(g[f"M32/g/{k}/absmax"]) == 0.0 or (k.startswith("rep_emb.encoder.") and k.endswith(".0.bias")):
+            continue
+        assert grad_probe_err(params[k].grad, g, f"M32/g/{k}") < 2e-4, k
+
+
+# ------------------------------------------------------------------ G13: guidance w (reference gaussian_diffusion.py:277-285)
+def test_guided_ddim_step_golden(golden, precision):
+    g = golden("g13_guidance.npz")
+    model, diff, cfg = make("P64", respacing="ddim100")
+    model.eval()
+    N = 2
+    x, x0, c, z, _ = model_inputs("P64", cfg, N)
+    with torch.no_grad():
+        x_t = diff.q_sample(x0.to(DEV), torch.full((N,), 99, dtype=torch.int64, device=DEV), noise=synth("P64.qnoise", (N, 4, 64, 64), -1.7, 1.7).to(DEV))
+        for tv in (99, 40):
+            tt = torch.full((N,), tv, dtype=torch.int64, device=DEV)
+            amp = float(diff.sqrt_recipm1_alphas_cumprod[tv])      # pred_xstart = sqrt(1/ab) x - sqrt(1/ab - 1) eps: the eps error times `amp`
+            for w in (0.5, 2.0):
+                o = diff.ddim_sample(model, x_t, tt, model_kwargs=dict(z=z.to(DEV)), w=w)
+                assert err(o["sample"], g[f"t{tv}/w{w}/sample"]) < 1e-4, (tv, w)
+                assert err(o["pred_xstart"], g[f"t{tv}/w{w}/pred_xstart"]) < 1e-4 + 1e-5 * amp, (tv, w)
+                pm = diff.p_mean_variance(model, x_t, tt, model_kwargs=dict(z=z.to(DEV)), w=w)
+                assert err(pm["mean"], g[f"t{tv}/w{w}/mean"]) < 1e-4, (tv, w)
+        # the guided loop runs end to end (two forwards per step) and differs from the unguided one
+        a = diff.ddim_sample_loop(model, (N, 4, 64, 64), noise=x_t, model_kwargs=dict(z=z.to(DEV)), w=2.0)
+        b = diff.ddim_sample_loop(model, (N, 4, 64, 64), noise=x_t, model_kwargs=dict(z=z.to(DEV)))
+        assert torch.isfinite(a).all() and err(a, b) > 1e-3
+
+
+# ------------------------------------------------------------------ G14: p_sample_loop end to end (reference gaussian_diffusion.py:416-504)
+def test_p_sample_loop_golden(golden, precision):
+    g = golden("g14_p_sample_loop.npz")
+    model, diff, cfg = make("M32", respacing="20")
+    model.eval()
+    N = 2
+    x, x0, c, z, y = model_inputs("M32", cfg, N)
+    kw = dict(z=z.to(DEV), y=y.to(DEV))
+    x_T = synth("M32.xT", (N, 1, 32, 32), -1.7, 1.7).to(DEV)
+    noises = [torch.from_numpy(n).to(DEV) for n in g["step_noise"]]
+    assert diff.num_timesteps == 20
+    with torch.no_grad():
+        k = 0
+        for o in diff.p_sample_loop_progressive(model, (N, 1, 32, 32), noise=x_T, model_kwargs=kw, step_noise=noises):
+            k += 1
+            if k in (1, 10, 20):
+                assert err(o["sample"], g[f"sample_after{k}"]) < 1e-4, k
+        assert k == 20
+        final = diff.p_sample_loop(model, (N, 1, 32, 32), noise=x_T, model_kwargs=kw, step_noise=noises)
+    assert err(final, g["sample_after20"]) < 1e-4
+    assert err(x_T, synth("M32.xT", (N, 1, 32, 32), -1.7, 1.7)) == 0.0          # the caller's noise is left untouched
+
+
+# ------------------------------------------------------------------ G15: BASELINE config [1] — reduced-precision torso at batch 256
+def test_mixed16_m32_batch256_loss_curve_golden(golden):
+    """BASELINE 'MorphoMNIST 32x32 CausalDiffAE training, bf16, batch 256': three optimizer steps of the `mixed16` torso (single
+    f16 / bf16 plane per operand, fp32 accumulate) against the REFERENCE's fp32 losses on the same data (rel 2e-2)."""
+    import causaldiffae_amd
+    from improved_diffusion.nn import rng_override
+    from improved_diffusion.train_util import FusedAdamWEMA
+    g = golden("g15_m32_b256.npz")
+    N = 256
+    causaldiffae_amd.set_precision("mixed16")
+    try:
+        model, diff, cfg = make("M32")
+        model.train()
+        opt = FusedAdamWEMA(model, lr=1e-4, weight_decay=0.0, ema_rates=[0.9999])
+        diff.kl_weight = 0.1
+        for step in range(3):
+            x0 = synth(f"M32b.{step}.x0", (N, 1, 32, 32), 0.0, 1.0).to(DEV)
+            c = synth(f"M32b.{step}.c", (N, 2), 0.0, 1.0).to(DEV)
+            y = torch.tensor([(step + 3 * i) % 10 for i in range(N)], dtype=torch.int64, device=DEV)
+            t = torch.tensor([(137 * (step + 1) + 251 * i) % 1000 for i in range(N)], dtype=torch.int64, device=DEV)
+            noise = synth(f"M32b.{step}.noise", (N, 1, 32, 32), -1.7, 1.7).to(DEV)
+            torch.manual_seed(200 + step)
+            eps = torch.randn(N, 512)               # the draw the reference made (CPU generator, same torch build as the generator script)
+            chk = g[f"step{step}/eps_draw_check"]
+            assert abs(eps.double().sum().item() - chk[0]) < 1e-6 * max(1.0, abs(chk[0])) and np.allclose(eps.flatten()[:6].numpy(), chk[2:], atol=0), \
+                "torch's CPU randn stream differs from the one the fixture was generated with"
+            opt.zero_grad()
+            with rng_override(eps_z=eps.to(DEV)):
+                terms = diff.training_losses(model, x0, t, model_kwargs=dict(c=c, y=y), noise=noise, rep_cond=True, causal_modeling=True)
+            terms["loss"].mean().backward()
+            opt.step()
+            for k in ("loss", "mse", "kld_rep"):
+                ref = float(g[f"step{step}/{k}_mean"])
+                got = float(terms[k].double().mean())
+                assert abs(got - ref) <= 2e-2 * abs(ref), (step, k, got, ref)
+            assert err(terms["loss"], g[f"step{step}/loss"]) <= 5e-2 * float(np.abs(g[f"step{step}/loss"]).max()), step
+    finally:
+        causaldiffae_amd.set_precision("f16x3")
 
 
 # ------------------------------------------------------------------ reduced-precision torso (BASELINE config 2 class)

@@ -169,7 +169,7 @@ def test_encoder(golden, tag, C, S_, nv):
     spec = [(k, s) for k, s in U.param_spec(cfg) if k.startswith("rep_emb.")]
     sd = fill_state_dict(spec)
     L = U.n_encoder_layers(sd)
-    x = synth(tag + ".x", (4, C, S_, S_), 0.0, 1.0)
+    x = synth(str(g[tag + "/input_name"]), (4, C, S_, S_), 0.0, 1.0)       # the generator picks an input away from every LeakyReLU kink
     mu, var = U.encode(sd, x, L, training=False)
     close(mu.numpy(), g[tag + "/eval_mu"], 1e-5)
     close(var.numpy(), g[tag + "/eval_var"], 1e-5)
@@ -570,3 +570,95 @@ def test_diffae_family(golden):
         x_t = D.q_sample(sch5, x0, torch.full((N,), sch5.T - 1, dtype=torch.int64), noise)
         out = D.sample_loop(sch5, lambda x, tm: U.unet_forward(sd, cfg, x, tm, y=y, z=z)[0], x_t, ddim=True)
     close(out.numpy(), g["diffae/sample"], 5e-5)
+
+
+# ------------------------------------------------------------------ G12: one training step of the full 41 M / 93 M parameter models
+def _model_inputs(tag, cfg, N):
+    C, S_, nv = cfg["in_channels"], cfg["image_size"], cfg["n_vars"]
+    x0 = synth(tag + ".x0", (N, C, S_, S_), 0.0, 1.0)
+    c = synth(tag + ".c", (N, nv), 0.0, 1.0)
+    y = torch.tensor([(3 * i + 1) % 10 for i in range(N)], dtype=torch.int64) if cfg["class_cond"] else None
+    return x0, c, y
+
+
+def grad_probe_close(t, g, prefix, rel):
+    """head / strided samples of a gradient against the reference's, relative to that tensor's own largest entry"""
+    f = t.detach().double().flatten()
+    scale = float(g[prefix + "/absmax"])
+    for key, got in (("head", f[:16]), ("strided", f[::4999])):
+        d = np.abs(got.numpy() - g[prefix + "/" + key].astype(np.float64)).max()
+        assert d <= rel * scale + 1e-12, f"{prefix}/{key}: {d:.3e} vs scale {scale:.3e}"
+    ss = float(g[prefix + "/sumsq"])
+    assert abs((f * f).sum().item() - ss) <= 1e-3 * ss + 1e-20, prefix
+
+
+@pytest.mark.parametrize("tag", ["M32", "C64"])
+def test_full_model_training_step(golden, tag):
+    g = golden("g12_full_train.npz")
+    cfg = model_cfg(tag)
+    sd = fill_state_dict(U.param_spec(cfg))
+    names = [str(k) for k in g[f"{tag}/grad_names"]]
+    for k in names:
+        sd[k].requires_grad_(True)
+    x0, c, y = _model_inputs(tag + ".train", cfg, 2)
+    t = torch.tensor([37, 990], dtype=torch.int64)
+    noise = synth(tag + ".train.noise", tuple(x0.shape), -1.7, 1.7)
+    eps_z = torch.from_numpy(g[f"{tag}/eps_draw"])
+    new = {}
+    fn = lambda x_t, tm, xs: U.unet_forward(sd, cfg, x_t, tm, y=y, c=c, x_start=xs, eps_z=eps_z, training=True, new_stats=new)
+    terms = D.training_losses(D.Schedule(1000, "linear", "", True), fn, x0, t, noise, c=c, rep_cond=True, causal_modeling=True, kl_weight=0.3)
+    terms["loss"].mean().backward()
+    for k in ("loss", "mse", "kld_rep"):
+        close(terms[k].detach().numpy(), g[f"{tag}/{k}"], 1e-4, 1e-5)
+    sq = sum((sd[k].grad.double() ** 2).sum().item() for k in names)
+    assert abs(sq - float(g[f"{tag}/grad_sqsum"])) <= 1e-4 * sq
+    for k in names:
+        if float(g[f"{tag}/g/{k}/absmax"]) == 0.0:
+            assert float(sd[k].grad.abs().max()) == 0.0, k          # zero-initialised partners: exactly zero in the reference too
+            continue
+        if k.startswith("rep_emb.encoder.") and k.endswith(".0.bias"):
+            continue            # a conv bias ahead of a batch-statistics BatchNorm: mathematically zero gradient, rounding noise on both sides
+        grad_probe_close(sd[k].grad, g, f"{tag}/g/{k}", 2e-4)
+    for k, v in new.items():
+        close(v.numpy(), g[f"{tag}/after/{k}"], 1e-6, 1e-5)
+
+
+# ------------------------------------------------------------------ G13: guidance w (conditional and z = 0 forwards blended)
+def test_guided_ddim_step(golden):
+    g = golden("g13_guidance.npz")
+    cfg = model_cfg("P64")
+    sd = fill_state_dict(U.param_spec(cfg))
+    sch = D.Schedule(1000, "linear", "ddim100", True)
+    N = 2
+    x0 = synth("P64.x0", (N, 4, 64, 64), 0.0, 1.0)
+    z = synth("P64.z", (N, 512))
+    x_t = D.q_sample(sch, x0, torch.full((N,), 99, dtype=torch.int64), synth("P64.qnoise", (N, 4, 64, 64), -1.7, 1.7))
+    fn = lambda x, tm, zz: U.unet_forward(sd, cfg, x, tm, z=zz)[0]
+    with torch.no_grad():
+        for tv in (99, 40):
+            tt = torch.full((N,), tv, dtype=torch.int64)
+            for w in (0.5, 2.0):
+                eps = D.guided_eps(fn, x_t, sch.model_t(tt), z, w)
+                o = D.ddim_step(sch, eps, x_t, tt)
+                close(o["sample"].numpy(), g[f"t{tv}/w{w}/sample"], 2e-5)
+                close(o["pred_xstart"].numpy(), g[f"t{tv}/w{w}/pred_xstart"], 2e-5)
+                close(D.p_mean_variance(sch, eps, x_t, tt)["mean"].numpy(), g[f"t{tv}/w{w}/mean"], 2e-5)
+
+
+# ------------------------------------------------------------------ G14: the ancestral loop end to end (p_sample_loop, 20 respaced steps)
+def test_p_sample_loop_m32(golden):
+    g = golden("g14_p_sample_loop.npz")
+    cfg = model_cfg("M32")
+    sd = fill_state_dict(U.param_spec(cfg))
+    sch = D.Schedule(1000, "linear", "20", True)
+    N = 2
+    z = synth("M32.z", (N, 512))
+    y = torch.tensor([(3 * i + 1) % 10 for i in range(N)], dtype=torch.int64)
+    x_T = synth("M32.xT", (N, 1, 32, 32), -1.7, 1.7)
+    noises = [torch.from_numpy(n) for n in g["step_noise"]]
+    trace = []
+    with torch.no_grad():
+        final = D.sample_loop(sch, lambda x, tm: U.unet_forward(sd, cfg, x, tm, y=y, z=z)[0], x_T, ddim=False, noises=noises, trace=trace)
+    for k in (1, 10, 20):
+        close(trace[k - 1].numpy(), g[f"sample_after{k}"], 5e-5)
+    close(final.numpy(), g["sample_after20"], 5e-5)
