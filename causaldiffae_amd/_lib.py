@@ -21,6 +21,7 @@ SIGNATURES = {
     "cdae_version": [],
     "cdae_last_error": [],
     "cdae_workspace_bytes": [I, P, I],
+    "cdae_range_status": [P],
     "cdae_set_default_precision": [I],
     "cdae_get_default_precision": [],
     "cdae_conv3x3_fwd": [P, L, L, L, L, P, P, P, P, L, I, I, I, I, I, I, I, I, P, SZ, P],
@@ -202,6 +203,21 @@ def set_precision(name):
 
 def get_precision():
     return {v: k for k, v in PRECISIONS.items()}[lib.cdae_get_default_precision()]
+
+
+class CdaeRangeError(CdaeError):
+    pass
+
+
+def range_check(what="a contraction"):
+    """Synchronise, read and clear the library's range flag; raise if any contraction produced a non-finite value since the last
+    check (an operand beyond the f16 range of the split-precision planes, or a genuinely non-finite input)."""
+    torch.cuda.synchronize()
+    bad = ctypes.c_int(0)
+    check(lib.cdae_range_status(ctypes.byref(bad)))
+    if bad.value:
+        raise CdaeRangeError(f"{what}: non-finite result — an operand left the range of the f16 split-precision planes (|x| < 65520) "
+                             f"or was not finite; rerun with causaldiffae_amd.set_precision('fp32') (IEEE fp32 products, fp32 range)")
 
 
 def prof_enable(on):

@@ -48,7 +48,7 @@ __device__ __forceinline__ void split8(const float* v, u16x8& hi, u16x8& lo) {
 
 template <int CH, int NKT>
 __global__ __launch_bounds__(NKT >= 4 ? 256 : 64 * NKT) void attn_fused_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                                                int heads, float alpha) {
+                                                                                int heads, float alpha, int* __restrict__ range_flag) {
     constexpr int T = 32 * NKT, WAVES = NKT >= 4 ? 4 : NKT, THREADS = 64 * WAVES;
     constexpr int PASS = T < 128 ? T : 128, NPASS = T / PASS, TPP = PASS / 32;       // keys per staging pass, passes, key tiles per pass
     constexpr int KSTEPS = CH / 16, CT = CH / 32;                                      // 16-deep MFMA steps over ch; 32-wide output tiles
@@ -191,7 +191,9 @@ __global__ __launch_bounds__(NKT >= 4 ? 256 : 64 * NKT) void attn_fused_kernel(c
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-            obase[(long)row * C + j * 32 + l31] = o[j][r] * (1.f / 1024.f);
+            const float v = o[j][r] * (1.f / 1024.f);
+            obase[(long)row * C + j * 32 + l31] = v;
+            if (!__builtin_isfinite(v) && range_flag) *range_flag = 1;      // q / k / v beyond the f16 range of the in-kernel split (cdae_range_status)
         }
 }
 
@@ -207,7 +209,7 @@ int launch_attn(const float* qkv, float* out, int B, int heads, hipStream_t st) 
         attr_done = true;
     }
     hipLaunchKernelGGL((attn_fused_kernel<CH, NKT>), dim3(T / (32 * WAVES), B * heads), dim3(64 * WAVES), smem, st, qkv, out, heads,
-                       1.f / sqrtf((float)CH));
+                       1.f / sqrtf((float)CH), cdae_range_flag_ptr());
     return hipGetLastError() == hipSuccess ? 0 : cdae_fail("attn_fused launch failed");
 }
 

@@ -60,6 +60,10 @@ struct GemmParams {
     // conv3x3 weights additionally in K-GROUP-MAJOR order [K / 16][taps][rows][16] (cdae_conv_wpack), hi / lo planes: one (group, tap)
     // unit of an n-tile is one contiguous run, which is how convwin_kernel's weight DMA wants it (nullptr: OHWI planes only)
     const unsigned short* Bk_hi; const unsigned short* Bk_lo;
+    // range guard: every contraction epilogue raises *range_flag when a final value is not finite.  An operand beyond the f16 range
+    // (|x| >= 65520) becomes hi = inf, lo = -inf in the split and the products NaN, so this is where an overflow of the 16-bit
+    // planes surfaces; the host reads the flag with cdae_range_status() (pinned host memory, written straight from the kernels)
+    int* range_flag;
 };
 
 int cdae_gemm_dispatch(GemmParams p, void* stream);
@@ -75,6 +79,7 @@ enum { PROF_IGEMM = 0, PROF_GN = 1, PROF_SOFTMAX = 2, PROF_ELEMWISE = 3, PROF_OP
 void cdae_prof_begin(int family, double work, hipStream_t st);
 void cdae_prof_end(int family, hipStream_t st);
 void cdae_prof_note(int family, double bytes);
+int* cdae_range_flag_ptr();      // device-visible int[1], see GemmParams::range_flag
 
 // LDS-DMA (global_load_lds_dwordx4) issued through inline assembly: lane l's 16 bytes at `src` land at LDS byte address
 // lds_dst + 16 l (lds_dst wave-uniform).  Why not __builtin_amdgcn_global_load_lds: hipcc's waitcnt pass keeps the ADDRESS

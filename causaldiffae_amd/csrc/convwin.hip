@@ -333,6 +333,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                         }
 #pragma unroll
                         for (int j = 0; j < 4; ++j) { cbase[ro + 16 * j] = v[j]; gs[j] += v[j]; gq[j] += v[j] * v[j]; }
+                        if (!__builtin_isfinite(v[0] + v[1] + v[2] + v[3]) && p.range_flag) *p.range_flag = 1;      // f16 plane overflow surfaces as NaN / inf
                     }
                 }
                 if (p.gn_part) {                                         // per (32-row chunk, column) partial sums of the final values
@@ -378,6 +379,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                                     if (Rg) v += Rg[addr];
                                     if (p.accumulate) v += Cg[addr];
                                     Cg[addr] = v;
+                                    if (!__builtin_isfinite(v) && p.range_flag) *p.range_flag = 1;
                                     if (p.C_hi) store_planes_cw(p, addr, v);
                                     gs[j] += v; gq[j] += v * v;
                                 }

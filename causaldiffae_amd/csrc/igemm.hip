@@ -656,6 +656,7 @@ __global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_ke
                 else if (p.act == ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
                 if (p.accumulate) v += Cg[addr];
                 Cg[addr] = v;
+                if (!__builtin_isfinite(v) && p.range_flag) *p.range_flag = 1;
                 if (p.C_hi) store_planes(p, addr, v);
             }
         }
@@ -884,6 +885,7 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + LOADERS)) void ps_kernel(
                 else if (p.act == ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
                 if (p.accumulate) v += Cg[addr];
                 Cg[addr] = v;
+                if (!__builtin_isfinite(v) && p.range_flag) *p.range_flag = 1;
                 if (p.C_hi) store_planes(p, addr, v);
                 gs += v; gq += v * v;
             }
@@ -1264,6 +1266,7 @@ __global__ __launch_bounds__(BM / WM_ * WAVES_N * 64, BM / WM_ * WAVES_N * BLOCK
                 else if (p.act == ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
                 if (p.accumulate) v += Cg[addr];
                 Cg[addr] = v;
+                if (!__builtin_isfinite(v) && p.range_flag) *p.range_flag = 1;
                 if (p.C_hi) store_planes(p, addr, v);
                 gs += v; gq += v * v;
             }
@@ -1324,6 +1327,7 @@ __global__ void splitk_reduce_kernel(const GemmParams p) {
         else if (p.act == ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
         if (p.accumulate) v += Cg[addr];
         Cg[addr] = v;
+        if (!__builtin_isfinite(v) && p.range_flag) *p.range_flag = 1;
         if (p.C_hi) store_planes(p, addr, v);
     }
 }
@@ -1425,6 +1429,7 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
         p.prec = mode == CDAE_PREC_FP32 ? 0 : mode == CDAE_PREC_MIXED16 ? (p.grad_operand ? 4 : 3) : (p.grad_operand ? 2 : 1);
     }
     if (p.A2 && !p.gn_coef && (p.amode != A_PLAIN_KC || p.a_scalar || p.K1 % BK || p.batch != 1)) return cdae_fail("two-source A: vectorised A_PLAIN_KC only, K1 % 32 == 0");
+    p.range_flag = cdae_range_flag_ptr();
     if (p.presplit) {
         static const int cfg_dbg = getenv("CDAE_PS_DBG") ? atoi(getenv("CDAE_PS_DBG")) : 0;
         p.dbg = cfg_dbg;

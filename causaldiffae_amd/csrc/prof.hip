@@ -25,6 +25,19 @@ hipEvent_t get_event() {
 }
 }  // namespace
 
+int* cdae_range_flag_ptr() {
+    static int* host = nullptr;
+    static int* dev = nullptr;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!host) {
+        if (hipHostMalloc(reinterpret_cast<void**>(&host), 64, hipHostMallocMapped) != hipSuccess) { host = nullptr; return nullptr; }
+        host[0] = 0;
+        if (hipHostGetDevicePointer(reinterpret_cast<void**>(&dev), host, 0) != hipSuccess) dev = host;
+    }
+    return dev;
+}
+
 int cdae_fail(const char* msg) { g_err = msg ? msg : "unknown"; return -1; }
 
 void cdae_prof_begin(int fam, double work, hipStream_t st) {
@@ -55,6 +68,17 @@ extern "C" {
 const char* cdae_last_error(void) { return g_err.c_str(); }
 
 int cdae_version(void) { return CDAE_VERSION; }
+
+// *nonfinite = number-ish (0 / 1) of contraction results that were not finite since the last call, then cleared.  The caller
+// synchronises the streams it cares about first (the flag lives in pinned host memory the kernels write to directly).
+int cdae_range_status(int* nonfinite) {
+    int* f = cdae_range_flag_ptr();
+    if (!f || !nonfinite) return cdae_fail("range_status: no flag");
+    volatile int* v = f;
+    *nonfinite = *v;
+    *v = 0;
+    return 0;
+}
 
 int cdae_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_mu);

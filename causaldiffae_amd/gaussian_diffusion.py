@@ -313,6 +313,9 @@ class GaussianDiffusion:
                                         model_kwargs=model_kwargs, noise=nz)
                 yield out
                 img = out["sample"]
+        if self._hot:
+            from ._lib import range_check
+            range_check("sampling loop")        # never hand back a sample that went through an overflowed f16 plane (raises CdaeRangeError)
 
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, model_kwargs=None,
                                   device=None, progress=False, step_noise=None):

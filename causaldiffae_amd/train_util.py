@@ -367,6 +367,9 @@ class TrainLoop:
         if self.step % self.log_interval == 0 and self.last_losses is not None:      # one host sync per log interval
             log_loss_dict(self.diffusion, self.last_t, {k: v * self.last_w for k, v in self.last_losses.items()})
             logger.logkv_mean("grad_norm", float(np.sqrt(self.opt.grad_sqsum())))
+            if dist_util.dev().type == "cuda":
+                from ._lib import range_check
+                range_check("training step")     # an operand left the f16 range of the split-precision planes: stop instead of training on NaNs
 
     # ------------------------------------------------------------------ checkpoints (names of train_util.py:319-345)
     def save(self):

@@ -58,6 +58,13 @@ const char* cdae_last_error(void);
 enum { CDAE_WS_SPLITK = 0, CDAE_WS_GROUPNORM = 1, CDAE_WS_GN_PARTS = 2, CDAE_WS_BATCHNORM = 3 };
 size_t cdae_workspace_bytes(int op, const long* dims, int ndims);
 
+/* Range guard of the split-precision modes.  f16 planes hold |x| < 65520 only; a larger operand becomes inf in the split and
+ * NaN in the products.  Every contraction epilogue raises a flag when a FINAL value is not finite; cdae_range_status reports and
+ * clears it (synchronise the stream first).  The Python API raises CdaeRangeError instead of returning such tensors and points at
+ * the IEEE `fp32` mode, which has fp32's range.  Small magnitudes: below 2^-3 the lo plane is an f16 subnormal, i.e. the pair is
+ * fixed-point with an LSB of 2^-24 (absolute error <= 2^-25 per operand element) instead of 2^-22 relative. */
+int cdae_range_status(int* nonfinite);
+
 /* Arithmetic of the dense contractions whose operands are both K-contiguous (conv3x3 / linear / 1x1 forward, QK^T).
  * Inputs, outputs and accumulation are fp32 in both modes.
  *   CDAE_PREC_FP32  : v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fmaf chain.

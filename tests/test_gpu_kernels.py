@@ -871,3 +871,115 @@ def test_stem_conv_matches_fp64(N, Cin, Cout, H, W, nchw):
     ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
     assert got.shape == ref.shape
     assert (got.double() - ref).abs().max().item() < 2e-6 * ref.abs().max().item()
+
+
+# ------------------------------------------------------------------ dynamic range of the split-precision (f16x3) contractions
+def _rel(got, exact):
+    return (got.double().cpu() - exact.cpu()).abs().max().item() / exact.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("e", [-16, -12, -8, 0, 8, 12])
+def test_split_precision_dynamic_range(e):
+    """conv3x3 / linear on pre-split planes and the fused attention with one operand scaled by 2^e, against fp64.  In range the
+    error is that of the split (2^-22 relative); below 2^-3 the lo plane is an f16 subnormal, so the pair turns into fixed point
+    with an LSB of 2^-24: the documented bound is 4 * 2^-24 / max|operand| relative to the result (include/cdae.h)."""
+    from causaldiffae_amd import ops
+    from causaldiffae_amd._lib import get_precision, range_check, set_precision
+    prev = get_precision()
+    set_precision("f16x3")
+    try:
+        range_check("stale")
+    except Exception:
+        pass
+    try:
+        def bound_for(t):          # 2^-22-relative in range; fixed point with an LSB of 2^-24 once the operand's lo plane is subnormal
+            return max(6e-6, 4.0 * 2.0 ** -24 / t.abs().max().item())
+        g = torch.Generator(device="cuda:0").manual_seed(21)
+        sc = 2.0 ** e
+        # conv3x3 on planes: scaled activation, fan-in-scaled weights
+        x = ops.to_nhwc(torch.randn(4, 128, 16, 16, device="cuda:0", generator=g) * sc)
+        w = (torch.randn(128, 128, 3, 3, device="cuda:0", generator=g) / 1152 ** 0.5).contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            y = ops.conv3x3_ps(_split_nhwc(x), w, None)
+        exact = F.conv2d(x.double().contiguous(), w.double(), padding=1)
+        assert torch.isfinite(y).all() and _rel(y, exact) < bound_for(x), (e, _rel(y, exact))
+        # the same conv with the WEIGHTS scaled instead
+        w2 = (w * sc).contiguous(memory_format=torch.channels_last)
+        x1 = ops.to_nhwc(torch.randn(4, 128, 16, 16, device="cuda:0", generator=g))
+        with torch.no_grad():
+            y = ops.conv3x3_ps(_split_nhwc(x1), w2, None)
+        exact = F.conv2d(x1.double().contiguous(), w2.double(), padding=1)
+        assert torch.isfinite(y).all() and _rel(y, exact) < bound_for(w2), (e, _rel(y, exact))
+        # linear on planes
+        xl = ops.to_nhwc(torch.randn(2, 256, 8, 8, device="cuda:0", generator=g) * sc)
+        wl = torch.randn(384, 256, 1, device="cuda:0", generator=g) / 16.0
+        with torch.no_grad():
+            yl = ops.linear_ps(_split_nhwc(xl), wl, None)
+        exact = xl.permute(0, 2, 3, 1).reshape(-1, 256).double() @ wl[:, :, 0].double().t()
+        assert torch.isfinite(yl).all() and _rel(yl, exact) < bound_for(xl), (e, _rel(yl, exact))
+        # fused attention, values scaled (q / k unscaled: the softmax is scale sensitive by definition)
+        B, T, heads, ch = 2, 64, 2, 96
+        qkv = torch.randn(B, T, 3 * heads * ch, device="cuda:0", generator=g)
+        q5 = qkv.reshape(B, T, heads, 3, ch).clone()
+        q5[:, :, :, 2] *= sc
+        qkv = q5.reshape(B, T, 3 * heads * ch).contiguous()
+        with torch.no_grad():
+            a = ops.qkv_attention(qkv, heads)
+        xd = qkv.double().reshape(B, T, heads, 3, ch)
+        wgt = torch.softmax(torch.einsum("bthc,bshc->bhts", xd[:, :, :, 0], xd[:, :, :, 1]) / ch ** 0.5, dim=-1)
+        exact = torch.einsum("bhts,bshc->bthc", wgt, xd[:, :, :, 2]).reshape(B, T, heads * ch)
+        assert torch.isfinite(a).all() and _rel(a, exact) < max(bound_for(q5[:, :, :, 2]), 2e-5), (e, _rel(a, exact))
+        range_check("in-range operands")          # nothing above may have raised the flag
+    finally:
+        set_precision(prev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["conv_act", "conv_weight", "linear", "attention"])
+def test_split_precision_overflow_raises(which):
+    """Operands beyond the f16 range (2^16-scaled normal data: |x| up to ~3e5 > 65504) must not come back as inf / NaN tensors
+    unnoticed: the library's range flag is raised and the Python API turns it into CdaeRangeError; the `fp32` mode (IEEE fp32
+    products, fp32 range) computes the same call correctly."""
+    import causaldiffae_amd
+    from causaldiffae_amd import ops
+    from causaldiffae_amd._lib import CdaeRangeError, get_precision, range_check, set_precision
+    prev = get_precision()
+    g = torch.Generator(device="cuda:0").manual_seed(22)
+    sc = 2.0 ** 16
+
+    def run():
+        with torch.no_grad():
+            if which in ("conv_act", "conv_weight"):
+                x = ops.to_nhwc(torch.randn(2, 64, 16, 16, device="cuda:0", generator=g) * (sc if which == "conv_act" else 1.0))
+                w = (torch.randn(64, 64, 3, 3, device="cuda:0", generator=g) / 24.0 * (sc * 64 if which == "conv_weight" else 1.0)).contiguous(memory_format=torch.channels_last)
+                y = ops.conv3x3_ps(_split_nhwc(x), w, None) if get_precision() != "fp32" else ops.conv3x3(x, w, None)
+                return y, F.conv2d(x.double().contiguous(), w.double(), padding=1)
+            if which == "linear":
+                x = torch.randn(256, 128, device="cuda:0", generator=g) * sc
+                w = torch.randn(64, 128, device="cuda:0", generator=g) / 11.0
+                return ops.linear(x, w, None), x.double() @ w.double().t()
+            B, T, heads, ch = 1, 64, 1, 128
+            qkv = torch.randn(B, T, 3 * ch, device="cuda:0", generator=g)
+            qkv[:, :, 2 * ch:] *= sc
+            xd = qkv.double().reshape(B, T, heads, 3, ch)
+            wgt = torch.softmax(torch.einsum("bthc,bshc->bhts", xd[:, :, :, 0], xd[:, :, :, 1]) / ch ** 0.5, dim=-1)
+            return ops.qkv_attention(qkv, heads), torch.einsum("bhts,bshc->bthc", wgt, xd[:, :, :, 2]).reshape(B, T, heads * ch)
+
+    try:
+        set_precision("f16x3")
+        try:
+            range_check("stale")
+        except CdaeRangeError:
+            pass
+        g.manual_seed(22)
+        run()
+        with pytest.raises(CdaeRangeError):
+            range_check(which)
+        set_precision("fp32")
+        g.manual_seed(22)
+        y, exact = run()
+        causaldiffae_amd.range_check(which + " in fp32 mode")
+        assert torch.isfinite(y).all() and _rel(y, exact) < 1e-5
+    finally:
+        set_precision(prev)

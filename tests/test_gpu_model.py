@@ -473,7 +473,7 @@ def test_mixed16_m32_batch256_loss_curve_golden(golden):
             opt.step()
             for k in ("loss", "mse", "kld_rep"):
                 ref = float(g[f"step{step}/{k}_mean"])
-                got = float(terms[k].double().mean())
+                got = float(terms[k].detach().double().mean())
                 assert abs(got - ref) <= 2e-2 * abs(ref), (step, k, got, ref)
             assert err(terms["loss"], g[f"step{step}/loss"]) <= 5e-2 * float(np.abs(g[f"step{step}/loss"]).max()), step
     finally:
