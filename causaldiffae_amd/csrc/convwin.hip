@@ -192,15 +192,22 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
 
     int tile = blockIdx.x;
     if (tile >= ntiles) return;
+    // dev (CDAE_PS_DBG & 32): s_memtime around the waits, summed per wave, written to the split-K workspace by lane 0 of the first 64 blocks
+    const bool stamps = (p.dbg & 32) != 0;
+    unsigned long long t_top = 0, t_vm = 0, t_bar = 0, t_epi = 0;
+    auto now = [&]() -> unsigned long long { return stamps ? (unsigned long long)__builtin_readcyclecounter() : 0ull; };
+    const unsigned long long t_begin = now();
     setup(tile);
     issue_prologue();
     while (true) {
+        const unsigned long long t0_ = now();
         // the tile's first window halves and weight stages (and the previous tile's stores).  The BUILTIN wait, not asm: hipcc's waitcnt
         // pass must see that nothing it knows of (epilogue loads) is pending when the K loop starts, or it plants a vmcnt(0) on the
         // first register redefinition inside the loop — a full drain of the DMAs the loop has just issued, every step
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        t_top += now() - t0_;
         int ga = g_begin, ta = 0;              // first unit of the current step
         int gi = g_begin, ti = 4;              // first unit of the next step whose weights are to be staged (step 2)
         int g_old = g_begin;                   // oldest group whose window half is still live
@@ -235,6 +242,9 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
             int wtap_n; unsigned a_n;
             geom(gn, tn, wtap_n, a_n);
             const unsigned b_n = b_lane + ((s + 1) & 1) * CW_B_STAGE;
+            // the two waves of a SIMD belong to different blocks: alternating the issue priority by step parity lets one of them run
+            // its MFMA burst unbroken while the other is at its mid-step wait (measured +2..3 %; CDAE_PS_DBG & 64 turns it off)
+            if (!(p.dbg & 64)) { if (s & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
             // outstanding LDS reads here, oldest first: A(0) [2], B(0) [2], B(1) [2], B(2) [2], B(3) [2]
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -242,10 +252,13 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                 if (i == 4) {
                     // ---- mid-step: every wave holds this step's weight fragments in registers, so the stage is free for step s + 2;
                     // the weights of step s + 1 (issued one step ago) must have landed; a window reload issued after them may stay in flight
+                    const unsigned long long t1_ = now();
                     if (reload_prev) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CW_WIN_DMAS) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const unsigned long long t2_ = now();
                     if (!(p.dbg & 8)) __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
+                    if (stamps) { const unsigned long long t3_ = now(); t_vm += t2_ - t1_; t_bar += t3_ - t2_; }
                     if (s + 2 < nsteps && !(p.dbg & 4)) issue_weights(s & 1, gi, ti);
                     ti += 2;
                     if (ti >= 9) { ti -= 9; ++gi; }
@@ -294,6 +307,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
 #undef CW_READ_B
 #undef CW_WAIT
 
+        __builtin_amdgcn_s_setprio(0);
         // ---- tile done: stage the next tile's operands, then write this tile's result (the stores drain behind the next K loop)
         const int em0 = m0, en0 = n0, eks = ks;
         const int next = tile + gridDim.x;
@@ -302,6 +316,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
         __builtin_amdgcn_s_barrier();                                    // every wave is done reading the window and the weight stages
         asm volatile("" ::: "memory");
         if (has_next) { setup(next); issue_prologue(); }
+        const unsigned long long t4_ = now();
 
         // accumulator tile (i, j): this lane holds rows 4 kg + r (r = 0..3) of column 16 j + lr; the four column tiles of a row are
         // stored back to back so that the 256 bytes a wave owns of each output row reach L2 together
@@ -402,12 +417,17 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                 __builtin_amdgcn_sched_barrier(0);       // keep the stores' address arithmetic from being hoisted in front of the first one (spills)
             }
         }
+        t_epi += now() - t4_;
         if (!has_next) break;
         tile = next;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (stamps && blockIdx.x < 64 && lane == 0 && p.splitk_ws && p.ksplit == 1) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(p.splitk_ws) + (blockIdx.x * 4 + wave) * 8;
+        o[0] = t_top; o[1] = t_vm; o[2] = t_bar; o[3] = t_epi; o[4] = now() - t_begin;
     }
 }
 

@@ -1011,6 +1011,10 @@ def conv3x3_ps(xs, w, b=None, res=None, stride=1, up=False, out_nchw=False, emit
     # statistics need the final values in the epilogue, i.e. no split-K: only where the unsplit grid fills the chip anyway
     # (the dispatcher's own rule: >= 256 tiles of 128 x 128), and where a 32-pixel chunk never straddles two images
     gn_stats = gn_stats and not out_nchw and (Ho * Wo) % 32 == 0 and ((M + 127) // 128) * ((Cout + 127) // 128) >= 256
+    if gn_stats and stride == 1 and not up and ((M + 255) // 256) * ((Cout + 127) // 128) < 256:
+        # the window kernel's 256 x 128 tiles would not fill the chip here (the 8 x 8 level): it splits K instead, which rules out
+        # the epilogue statistics — the next GroupNorm runs its own (small) statistics pass
+        gn_stats = False
     parts = torch.empty(((M + 31) // 32, Cout, 2), dtype=torch.float32, device=dev) if gn_stats else None
     check(lib.cdae_conv3x3_fwd_psk(ptr(xs.hi), ptr(xs.lo), H * W * Cin, W * Cin, Cin, ptr(w_hi), ptr(w_lo), *_pk(w, False), ptr(b), ptr(res), ptr(out), Cout,
                                   1 if out_nchw else 0, ptr(planes[0]) if emit_split else None, ptr(planes[1]) if emit_split else None,

@@ -108,6 +108,17 @@ class GradBuckets:
             b["pending"] = sum(1 for m in b["members"] if self.flat.params[m].requires_grad)
             b["work"] = None
         self.fired = [False] * len(self.flat.params)
+        self.next_launch = 0          # collectives are issued in bucket-index order on EVERY rank, whatever order the hooks fire in
+
+    def _launch_ready(self):
+        """Launch every complete bucket whose predecessors have been launched.  A rank whose gradients arrive in a different order
+        (e.g. a parameter that falls back from the in-place sink to the autograd path) must still issue the same sequence of
+        collectives as its peers, or RCCL pairs up different buckets and deadlocks — the rule DDP follows."""
+        while self.next_launch < len(self.buckets) and self.buckets[self.next_launch]["pending"] == 0:
+            b = self.buckets[self.next_launch]
+            if b["work"] is None:
+                b["work"] = dist.all_reduce(self.flat.grad[b["lo"]:b["hi"]], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.next_launch += 1
 
     def _make_hook(self, i):
         def hook(_p):
@@ -120,7 +131,7 @@ class GradBuckets:
             b = self.buckets[self.bucket_of[i]]
             b["pending"] -= 1
             if b["pending"] == 0:
-                b["work"] = dist.all_reduce(self.flat.grad[b["lo"]:b["hi"]], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._launch_ready()
         return hook
 
     def reduce_all(self):
@@ -134,7 +145,7 @@ class GradBuckets:
         """Wait for in-flight buckets, reduce any bucket whose hook never fired (unused params), average."""
         if self.world == 1:
             return
-        for b in self.buckets:
+        for b in self.buckets:             # in index order, like the hooks
             if b["work"] is None:
                 b["work"] = dist.all_reduce(self.flat.grad[b["lo"]:b["hi"]], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         for b in self.buckets:

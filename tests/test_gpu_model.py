@@ -950,6 +950,44 @@ def test_data_parallel_gradients_match_single_process(tmp_path):
 
 
 @pytest.mark.gpu
+def test_data_parallel_nccl_two_gpus(tmp_path):
+    """The same check over RCCL (backend "nccl"), one GPU per rank, DIFFERENT images per rank: the bucketed, overlapped all-reduce of
+    TrainLoop against the mean of the per-shard gradients computed in one process (reference partitioning train_util.py:107-118,
+    255-259).  Needs two GPUs: skipped on a one-GPU box."""
+    import os, socket, subprocess, sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL all-reduce between two devices)")
+    here = os.path.dirname(os.path.abspath(__file__))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {**os.environ, "DP2_OUT": str(tmp_path / "dp2.pt"), "HSA_ENABLE_IPC_MODE_LEGACY": "0", "DP2_BACKEND": "nccl", "DP2_SPLIT": "1"}
+    worker = os.path.join(here, "dp2_worker.py")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), worker], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run([sys.executable, worker], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_data_parallel_split_shards_gloo(tmp_path):
+    """Different images per rank through the same bucketed all-reduce, on the one GPU every box has (gloo, both ranks on cuda:0)."""
+    import os, socket, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {**os.environ, "DP2_OUT": str(tmp_path / "dp2.pt"), "HSA_ENABLE_IPC_MODE_LEGACY": "0", "DP2_SPLIT": "1"}
+    worker = os.path.join(here, "dp2_worker.py")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), worker], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run([sys.executable, worker], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
 def test_encoder_classifier_matches_torch_modules():
     """nn.GaussianConvEncoderClf (the evaluation classifier the reference's image_causaldae_test.py builds): same state-dict layout as
     the reference module, forward == Linear(flatten(strided conv -> BatchNorm(eval) -> LeakyReLU stack)) built from plain torch modules."""

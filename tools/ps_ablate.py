@@ -38,7 +38,14 @@ for (ci, co, r) in [(128, 128, 64), (256, 256, 32), (384, 384, 16), (512, 512, 8
         err = (y[:4].double() - exact).abs().max().item()
         err2 = (y[-2:].double() - torch.nn.functional.conv2d(x[-2:].double(), w.double(), padding=1)).abs().max().item()
         print(f"dbg={os.environ.get('CDAE_PS_DBG','0')} cw={os.environ.get('CDAE_CONVWIN','1')} conv {ci}->{co} @{r}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF  err {max(err, err2):.2e}")
-        if STAMPS:
+        if STAMPS and os.environ.get("CDAE_CONVWIN", "1") != "0":
+            from causaldiffae_amd._lib import splitk_ws
+            w64 = splitk_ws(torch.device(DEV)).view(torch.int64)[:64 * 4 * 8].reshape(64 * 4, 8).double().cpu()
+            tot = w64[:, 4].mean()
+            print(f"    convwin stamps (cycles per wave, mean over 256 waves): total {tot:.0f}  tile-top wait {w64[:,0].mean():.0f} ({w64[:,0].mean()/tot:.3f})  "
+                  f"mid vmcnt wait {w64[:,1].mean():.0f} ({w64[:,1].mean()/tot:.3f})  mid barrier {w64[:,2].mean():.0f} ({w64[:,2].mean()/tot:.3f})  "
+                  f"epilogue issue {w64[:,3].mean():.0f} ({w64[:,3].mean()/tot:.3f})")
+        elif STAMPS:
             from causaldiffae_amd._lib import splitk_ws
             w64 = splitk_ws(torch.device(DEV)).view(torch.int64)[:64 * 8 * 4].reshape(64 * 8, 4).double().cpu()
             tot = w64.sum(1, keepdim=True)
