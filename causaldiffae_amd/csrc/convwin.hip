@@ -75,7 +75,9 @@ __device__ __forceinline__ void cw_dma(const void* sbase, int soff, unsigned vof
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane((int)lds_dst)), "v"(voff), "s"(base) : "memory");
 }
 
-template <bool BF>
+// NT = 9: the 3x3 window.  NT = 4: the 2x2 window of one sub-pixel phase (ph_y, ph_x) of nearest-2x-upsample + conv3x3 (tap t reads window
+// position (t / 2 + ph_y, t % 2 + ph_x) of the same 3x3 neighbourhood; weights [rows][4][K]; result scattered to (2y + ph_y, 2x + ph_x)).
+template <bool BF, int NT>
 __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, const int ntiles) {
     typedef const unsigned short* hp;
 
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
         m0 = mt * CW_BM; n0 = nt * CW_BN;
         const int c_begin = ks * c_per, c_end = max(min(nchunk, c_begin + c_per), c_begin);       // the last splits of an uneven division are empty
         g_begin = 2 * c_begin; g_end = 2 * c_end;                     // 16-channel groups of this K split
-        nsteps = ((g_end - g_begin) * 9) >> 1;                        // K-steps of two (group, tap) units each (0: the slab is zeros)
+        nsteps = ((g_end - g_begin) * NT) >> 1;                        // K-steps of two (group, tap) units each (0: the slab is zeros)
         const int pix0 = m0 - W;
         // rows outside the tensor (and weight rows beyond Cout) are CLAMPED, not zero-filled: whatever lands there is only ever
         // addressed by padding taps (redirected out of range) or feeds output columns that are never stored
@@ -149,10 +151,10 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
     // weights of the step whose first unit is (g, t) -> stage
     auto issue_weights = [&](int stage, int g, int t) {
         int gb = g, tb = t + 1;
-        if (tb == 9) { tb = 0; ++gb; }
+        if (tb == NT) { tb = 0; ++gb; }
         const unsigned dst = CW_B_BASE + stage * CW_B_STAGE + wave * 1024;
         int ea, eb;
-        if (packed) { ea = (g * 9 + t) * p.N * 32; eb = (gb * 9 + tb) * p.N * 32; }
+        if (packed) { ea = (g * NT + t) * p.N * 32; eb = (gb * NT + tb) * p.N * 32; }
         else { ea = (t * p.Cin + g * 16) * 2; eb = (tb * p.Cin + gb * 16) * 2; }
         cw_dma(b_hi, ea, woffb, dst);
         cw_dma(b_hi, eb, woffb, dst + CW_B_KH);
@@ -164,7 +166,8 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
         issue_window(g_begin);
         issue_window(g_begin + 1);
         issue_weights(0, g_begin, 0);
-        issue_weights(1, g_begin, 2);
+        if (NT == 9) issue_weights(1, g_begin, 2);
+        else issue_weights(1, g_begin, 2);
     };
 
     const unsigned a_lane = (wm * 128 + lr) * 32 + pc * 16;            // byte offset of (tile 0 row, piece) in a window plane
@@ -183,10 +186,11 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
     // geometry of the step whose first unit is (g, t): this lane's mask bit and byte address of its tile-0 fragment (half + row shift)
     auto geom = [&](int g, int t, int& wtap, unsigned& addr) {
         int gb = g, tb = t + 1;
-        if (tb == 9) { tb = 0; ++gb; }
+        if (tb == NT) { tb = 0; ++gb; }
         const int my_t = selb ? tb : t, my_g = selb ? gb : g;
-        const int ky = (my_t * 11) >> 5, kx = my_t - 3 * ky;              // tap / 3, tap % 3 for tap < 9
-        wtap = my_t;
+        const int ky = NT == 9 ? (my_t * 11) >> 5 : (my_t >> 1) + p.ph_y;  // tap / 3 for tap < 9
+        const int kx = NT == 9 ? my_t - 3 * ky : (my_t & 1) + p.ph_x;
+        wtap = 3 * ky + kx;
         addr = a_lane + (my_g & 1) * CW_A_HALF + (ky * W + kx - 1) * 32;
     };
 
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
         asm volatile("" ::: "memory");
         t_top += now() - t0_;
         int ga = g_begin, ta = 0;              // first unit of the current step
-        int gi = g_begin, ti = 4;              // first unit of the next step whose weights are to be staged (step 2)
+        int gi = g_begin + (NT == 4 ? 1 : 0), ti = NT == 4 ? 0 : 4;      // first unit of the next step whose weights are to be staged (step 2 = unit 4)
         int g_old = g_begin;                   // oldest group whose window half is still live
         bool reload_prev = false;
         int wtap_c; unsigned a_c;
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
 
         for (int s = 0; s < nsteps; ++s) {
             int gn = ga, tn = ta + 2;          // first unit of the next step
-            if (tn >= 9) { tn -= 9; ++gn; }
+            if (tn >= NT) { tn -= NT; ++gn; }
             int wtap_n; unsigned a_n;
             geom(gn, tn, wtap_n, a_n);
             const unsigned b_n = b_lane + ((s + 1) & 1) * CW_B_STAGE;
@@ -259,12 +263,19 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                     if (!(p.dbg & 8)) __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
                     if (stamps) { const unsigned long long t3_ = now(); t_vm += t2_ - t1_; t_bar += t3_ - t2_; }
+                    // NT = 4: a group lasts two steps only, so a reloaded half is read (look-ahead of the step after next) one step after
+                    // it was requested: the window goes out BEFORE the weights and the next mid-step wait drains everything
+                    bool reload = false;
+                    if (ga > g_old) {              // every unit of g_old lies in finished steps: its half is free
+                        reload = g_old + 2 < g_end && !(p.dbg & 20);
+                        if (NT == 4 && reload) issue_window(g_old + 2);
+                    }
                     if (s + 2 < nsteps && !(p.dbg & 4)) issue_weights(s & 1, gi, ti);
                     ti += 2;
-                    if (ti >= 9) { ti -= 9; ++gi; }
+                    if (ti >= NT) { ti -= NT; ++gi; }
                     reload_prev = false;
-                    if (ga > g_old) {              // every unit of g_old lies in finished steps: its half is free
-                        if (g_old + 2 < g_end && !(p.dbg & 20)) { issue_window(g_old + 2); reload_prev = true; }
+                    if (ga > g_old) {
+                        if (NT == 9 && reload) { issue_window(g_old + 2); reload_prev = true; }
                         ++g_old;
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -325,7 +336,9 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
         else if (interior && p.ksplit == 1 && !p.accumulate && !p.C_hi) {
             // the common case, kept lean (the general path below spends ~20 instructions per element on bounds and mode tests):
             // one row pointer per (tile, r), the four column tiles at immediate offsets
-            const long lane_off = (long)(em0 + wm * 128 + 4 * kg) * p.ldc + en0 + wn * 64 + lr;
+            const bool up2 = p.out_mode == OUT_UP2;       // sub-pixel phase: GEMM row (n, y, x) -> output pixel (n, 2y + ph_y, 2x + ph_x)
+            const int row0 = em0 + wm * 128 + 4 * kg;
+            const long lane_off = (up2 ? 0 : (long)row0 * p.ldc) + en0 + wn * 64 + lr;
             float* __restrict__ cbase = p.C + lane_off;
             const float* __restrict__ rbase = p.res ? p.res + lane_off : nullptr;
             float bv[4];
@@ -338,7 +351,11 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                 for (int ii = 0; ii < 2; ++ii) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const long ro = (long)(32 * i2 + 16 * ii + r) * p.ldc;
+                        long ro;
+                        if (up2) {
+                            const int row = row0 + 32 * i2 + 16 * ii + r, x = row & (p.Wo - 1);             // Wo is a power of two here
+                            ro = (4L * row - 2 * x + p.ph_y * 2 * p.Wo + p.ph_x) * p.ldc;
+                        } else ro = (long)(32 * i2 + 16 * ii + r) * p.ldc;
                         float v[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = acc[2 * i2 + ii][j][r] * p.alpha + bv[j];
@@ -389,7 +406,11 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                                 const float a = acc[2 * i2 + ii][j][r];
                                 if (p.ksplit > 1) Cg[(long)row * p.N + col] = a;
                                 else {
-                                    const long addr = (long)row * p.ldc + col;
+                                    long addr;
+                                    if (p.out_mode == OUT_UP2) {
+                                        const int x = row & (p.Wo - 1);
+                                        addr = (4L * row - 2 * x + p.ph_y * 2 * p.Wo + p.ph_x) * p.ldc + col;
+                                    } else addr = (long)row * p.ldc + col;
                                     float v = a * p.alpha + bv[j];
                                     if (Rg) v += Rg[addr];
                                     if (p.accumulate) v += Cg[addr];
@@ -431,18 +452,18 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
     }
 }
 
-template <bool BF>
+template <bool BF, int NT>
 int launch_convwin(const GemmParams& p, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convwin_kernel<BF>), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convwin_kernel<BF, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS) != hipSuccess)
             return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
         attr_done = true;
     }
     const long ntiles = (long)((p.M + CW_BM - 1) / CW_BM) * ((p.N + CW_BN - 1) / CW_BN) * p.ksplit;
     static const int cfg_persist = getenv("CDAE_CONVWIN_GRID") ? atoi(getenv("CDAE_CONVWIN_GRID")) : 512;      // two blocks per CU
     dim3 grid((unsigned)(ntiles < cfg_persist ? ntiles : cfg_persist));
-    hipLaunchKernelGGL((convwin_kernel<BF>), grid, dim3(256), CW_LDS, st, p, (int)ntiles);
+    hipLaunchKernelGGL((convwin_kernel<BF, NT>), grid, dim3(256), CW_LDS, st, p, (int)ntiles);
     return hipGetLastError() == hipSuccess ? 0 : cdae_fail("convwin_kernel launch failed");
 }
 
@@ -479,7 +500,8 @@ extern "C" int cdae_conv_wpack(const unsigned short* w_hi, const unsigned short*
 // Shapes this kernel takes (the dispatcher has already checked: stride 1, dense NHWC planes, row-major output).
 bool cdae_convwin_ok(const GemmParams& p) {
     if (p.prec != 1 && p.prec != 2) return false;
-    if (p.gn_coef || p.A2 || p.ps_taps == 4 || p.out_mode != OUT_ROWMAJOR || p.act != ACT_NONE) return false;
+    if (p.gn_coef || p.A2 || p.act != ACT_NONE) return false;
+    if (p.ps_taps == 4 ? (p.out_mode != OUT_UP2 || p.prec != 1 || p.Bk_hi) : p.out_mode != OUT_ROWMAJOR) return false;
     if (p.W != 8 && p.W != 16 && p.W != 32 && p.W != 64) return false;            // tight window: tiles start on image-row boundaries
     if (p.Cin % 32 || p.ldb % 8 || p.sx % 8) return false;
     if ((long)p.M * p.sx * 2 >= (1L << 32) || (long)p.N * p.ldb * 2 >= (1L << 32)) return false;      // 32-bit byte offsets in the DMAs
@@ -488,5 +510,6 @@ bool cdae_convwin_ok(const GemmParams& p) {
 
 int cdae_convwin_launch(const GemmParams& p, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    return p.prec == 2 ? launch_convwin<true>(p, st) : launch_convwin<false>(p, st);
+    if (p.ps_taps == 4) return launch_convwin<false, 4>(p, st);
+    return p.prec == 2 ? launch_convwin<true, 9>(p, st) : launch_convwin<false, 9>(p, st);
 }
