@@ -1,22 +1,25 @@
 #!/bin/bash
 # Round profile on the GPU box (run through gpurun from the repo root): kernel stats + three PMC passes of eager DDIM steps.
-#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/profile_round.sh r01 v4'
+#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/profile_round.sh r02 v1'
+# Every rocprofv3 call runs under `timeout` (a pass that aborts inside the profiler otherwise hangs until gpurun's own limit).
 set -u
-TAG=${1:-r01}; VER=${2:-v4}
+TAG=${1:-r02}; VER=${2:-v1}
 export TMPDIR=/tmp
 R=$PWD
 O=$R/gpurun_out/prof_$VER
 mkdir -p $O
 cd /tmp
-CMD="python3 $R/bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-train"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- $CMD > $O/trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o f -- $CMD > $O/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/write -o w -- $CMD > $O/write.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $O/sq -o s -- $CMD > $O/sq.log 2>&1
+CMD="python3 $R/bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-train --no-fp32"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- $CMD > $O/trace.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o f -- $CMD > $O/fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/write -o w -- $CMD > $O/write.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $O/sq -o s -- $CMD > $O/sq.log 2>&1
 cd $R
+python3 tools/pmc_summary.py --fetch $O/fetch --write $O/write --sq $O/sq --trace $O/trace --kernels 'convwin_kernel' \
+    --label "f16x3, eager P64 DDIM steps, batch 128" --out $O/${TAG}_convwin_pmc_summary_f16x3.json > $O/summary.log 2>&1
 python3 tools/pmc_summary.py --fetch $O/fetch --write $O/write --sq $O/sq --trace $O/trace --kernels 'ps_kernel|pswin_kernel|igemm_kernel' \
-    --label "f16x3, eager P64 DDIM steps, batch 128" --out $O/${TAG}_igemm_pmc_summary_f16x3.json > $O/summary.log 2>&1
+    --label "f16x3, eager P64 DDIM steps, batch 128: every contraction that is not the window conv kernel" --out $O/${TAG}_igemm_pmc_summary_f16x3.json >> $O/summary.log 2>&1
 cp $O/trace/*kernel_stats.csv $O/${TAG}_bench_ddim_p64_b128_kernel_stats_${VER}_f16x3.csv 2>/dev/null
-tail -30 $O/summary.log
-rm -rf $O/fetch/*kernel* 2>/dev/null
+tail -60 $O/summary.log
+rm -rf $O/fetch $O/write $O/sq $O/trace/*kernel_trace.csv
 du -sh $O
