@@ -984,3 +984,25 @@ def test_split_precision_overflow_raises(which):
         assert torch.isfinite(y).all() and _rel(y, exact) < 1e-5
     finally:
         set_precision(prev)
+
+
+@pytest.mark.gpu
+def test_lds_out_of_range_reads_return_zero(tmp_path):
+    """convwin.hip sends the fragment reads of padding taps to an LDS address beyond every allocation and relies on the hardware
+    returning zeros there (with two blocks resident per CU, whose allocations are neighbours).  The probe reads such addresses from
+    1024 blocks that filled their own 80 KB with a pattern: everything out of range must be zero, the in-range control must not."""
+    import os, subprocess
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "hiptests", "lds_oob.hip")
+    exe = str(tmp_path / "lds_oob")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", src, "-o", exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("offset")]
+    assert len(lines) == 8
+    for l in lines:
+        nonzero = int(l.split(":")[1].split("of")[0])
+        if "in range" in l:
+            assert nonzero == 4096, l
+        else:
+            assert nonzero == 0, l

@@ -1,5 +1,5 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/t_all.log 2>&1
-tail -6 gpurun_out/t_all.log
+( time timeout 1200 python bench.py ) > gpurun_out/bench_full.log 2>&1
+tail -4 gpurun_out/bench_full.log
