@@ -78,7 +78,7 @@ __device__ __forceinline__ void cw_dma(const void* sbase, int soff, unsigned vof
 // NT = 9: the 3x3 window.  NT = 4: the 2x2 window of one sub-pixel phase (ph_y, ph_x) of nearest-2x-upsample + conv3x3 (tap t reads window
 // position (t / 2 + ph_y, t % 2 + ph_x) of the same 3x3 neighbourhood; weights [rows][4][K]; result scattered to (2y + ph_y, 2x + ph_x)).
 template <bool BF, int NT>
-__global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, const int ntiles) {
+__global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, const int ntiles, const int dephase_arg) {
     typedef const unsigned short* hp;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -201,6 +201,14 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
     unsigned long long t_top = 0, t_vm = 0, t_bar = 0, t_epi = 0;
     auto now = [&]() -> unsigned long long { return stamps ? (unsigned long long)__builtin_readcyclecounter() : 0ull; };
     const unsigned long long t_begin = now();
+    // De-phasing (tiles >= 2 per block): all persistent blocks otherwise reach their stores together and the chip-wide burst
+    // (268 MB at ~5.3 TB/s for a 128-channel result at 64 x 64, batch 128) stalls every wave at once.  The second half of the grid
+    // therefore starts with only the LOWER 64 rows of each wave's 128 (row tiles 0..3) of its first tile and finishes with the UPPER
+    // 64: the same work, but its tile boundaries sit half a tile away from the first half's, so one block of a CU computes while
+    // the other one stores.  part: 0 = all eight row tiles, 1 = tiles 0..3, 2 = tiles 4..7.
+    const int first_tile = tile;
+    bool high_pending = dephase_arg && blockIdx.x >= (gridDim.x >> 1) && first_tile + (int)gridDim.x < ntiles;
+    int part = high_pending ? 1 : 0;
     setup(tile);
     issue_prologue();
     while (true) {
@@ -283,9 +291,12 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                 // tile 0 needs A(0) and B(0) of the ten reads in flight; every other tile's A pair is the only thing outstanding
                 if (i == 0) CW_WAIT("s_waitcnt lgkmcnt(6)" : "+v"(ah[0]), "+v"(al[0]), "+v"(bh[0]), "+v"(bl[0]));
                 else CW_WAIT("s_waitcnt lgkmcnt(0)" : "+v"(ah[cur]), "+v"(al[cur]));
-                acc[i][0] = mma(al[cur], bh[0], acc[i][0]);
-                acc[i][0] = mma(ah[cur], bl[0], acc[i][0]);
-                acc[i][0] = mma(ah[cur], bh[0], acc[i][0]);
+                const bool en = part == 0 || ((i < 4) == (part == 1));        // wave-uniform: a half item skips the other half's MFMAs
+                if (en) {
+                    acc[i][0] = mma(al[cur], bh[0], acc[i][0]);
+                    acc[i][0] = mma(ah[cur], bl[0], acc[i][0]);
+                    acc[i][0] = mma(ah[cur], bh[0], acc[i][0]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 // the next tile's fragment reads go out behind the first three MFMAs and have nine MFMAs to land
                 if (i == 0) { CW_READ_A(1, 1, wtap_c, a_c); }
@@ -301,9 +312,11 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                 for (int j = 1; j < 4; ++j) {
                     // tile 0: B(j) is the oldest of the reads in flight [B(j) .. B(3), A(1)]
                     if (i == 0) CW_WAIT("s_waitcnt lgkmcnt(%2)" : "+v"(bh[j]), "+v"(bl[j]) : "n"(8 - 2 * j));
-                    acc[i][j] = mma(al[cur], bh[j], acc[i][j]);
-                    acc[i][j] = mma(ah[cur], bl[j], acc[i][j]);
-                    acc[i][j] = mma(ah[cur], bh[j], acc[i][j]);
+                    if (en) {
+                        acc[i][j] = mma(al[cur], bh[j], acc[i][j]);
+                        acc[i][j] = mma(ah[cur], bl[j], acc[i][j]);
+                        acc[i][j] = mma(ah[cur], bh[j], acc[i][j]);
+                    }
                     if (i == 7) {
                         __builtin_amdgcn_sched_barrier(0);
                         if (j == 1) { CW_READ_B(1, b_n); } else if (j == 2) { CW_READ_B(2, b_n); } else { CW_READ_B(3, b_n); }
@@ -320,9 +333,11 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
 
         __builtin_amdgcn_s_setprio(0);
         // ---- tile done: stage the next tile's operands, then write this tile's result (the stores drain behind the next K loop)
-        const int em0 = m0, en0 = n0, eks = ks;
-        const int next = tile + gridDim.x;
-        const bool has_next = next < ntiles;
+        const int em0 = m0, en0 = n0, eks = ks, epart = part;
+        int next = tile + gridDim.x;
+        bool has_next = part != 2 && next < ntiles;
+        part = 0;
+        if (!has_next && epart != 2 && high_pending) { next = first_tile; part = 2; has_next = true; high_pending = false; }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the look-ahead reads of the step that does not exist
         __builtin_amdgcn_s_barrier();                                    // every wave is done reading the window and the weight stages
         asm volatile("" ::: "memory");
@@ -346,6 +361,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
             for (int j = 0; j < 4; ++j) bv[j] = p.bias ? p.bias[en0 + wn * 64 + lr + 16 * j] : 0.f;
 #pragma unroll
             for (int i2 = 0; i2 < 4; ++i2) {
+                if (epart != 0 && ((i2 < 2) != (epart == 1))) continue;      // a half item owns only its own row tiles
                 float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ii = 0; ii < 2; ++ii) {
@@ -393,6 +409,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
             for (int j = 0; j < 4; ++j) bv[j] = (col0 + 16 * j < p.N && p.ksplit == 1 && p.bias) ? p.bias[col0 + 16 * j] : 0.f;
 #pragma unroll
             for (int i2 = 0; i2 < 4; ++i2) {
+                if (epart != 0 && ((i2 < 2) != (epart == 1))) continue;
                 float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ii = 0; ii < 2; ++ii) {
@@ -463,7 +480,10 @@ int launch_convwin(const GemmParams& p, hipStream_t st) {
     const long ntiles = (long)((p.M + CW_BM - 1) / CW_BM) * ((p.N + CW_BN - 1) / CW_BN) * p.ksplit;
     static const int cfg_persist = getenv("CDAE_CONVWIN_GRID") ? atoi(getenv("CDAE_CONVWIN_GRID")) : 512;      // two blocks per CU
     dim3 grid((unsigned)(ntiles < cfg_persist ? ntiles : cfg_persist));
-    hipLaunchKernelGGL((convwin_kernel<BF, NT>), grid, dim3(256), CW_LDS, st, p, (int)ntiles);
+    // measured: 128->128 at 64 x 64 519 vs 478 us, DDIM step 27.3 vs 25.8 ms — the two half items cost ~1.4 tiles (same DMA and LDS
+    // traffic as a whole tile each), more than the overlapped store burst returns at four tiles per block: off by default
+    static const int cfg_dephase = getenv("CDAE_CONVWIN_DEPHASE") ? atoi(getenv("CDAE_CONVWIN_DEPHASE")) : 0;
+    hipLaunchKernelGGL((convwin_kernel<BF, NT>), grid, dim3(256), CW_LDS, st, p, (int)ntiles, (int)(cfg_dephase && ntiles >= 2 * (long)cfg_persist));
     return hipGetLastError() == hipSuccess ? 0 : cdae_fail("convwin_kernel launch failed");
 }
 

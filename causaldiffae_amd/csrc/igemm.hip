@@ -755,9 +755,10 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + LOADERS)) void ps_kernel(
 #pragma unroll
     for (int q = 0; q < A_P; ++q) { arow[q] = ((ltid >> 2) + RPP * q) & (BM - 1); acol[q] = 8 * ((ltid & 3) ^ ((arow[q] >> 2) & 3)); }
 
+    // LDS-DMA through inline asm (cdae_lds_dma16): with the builtin, hipcc drains the DMAs (vmcnt(0)) in front of the next LDS read that
+    // might alias their destination — i.e. right after they were issued, before the MFMAs they were meant to overlap
     auto dma = [&](hp src, char* dst_wave_base) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)dst_wave_base, 16, 0, 0);
+        cdae_lds_dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst_wave_base - lds)));
     };
     // issue the DMAs of one 32-deep step (tap, channel offset kc) into `stage`; B pointers advance by one step
     auto issue = [&](int stage, int tap, int kc) {
@@ -1052,9 +1053,10 @@ __global__ __launch_bounds__(BM / WM_ * WAVES_N * 64, BM / WM_ * WAVES_N * BLOCK
         bok[q] = n0 + row < p.N;
         boff[q] = (long)(bok[q] ? n0 + row : 0) * p.ldb + c * 8;
     }
+    // LDS-DMA through inline asm (cdae_lds_dma16): with the builtin, hipcc drains the DMAs (vmcnt(0)) in front of the next LDS read that
+    // might alias their destination — i.e. right after they were issued, before the MFMAs they were meant to overlap
     auto dma = [&](hp src, char* dst_wave_base) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)dst_wave_base, 16, 0, 0);
+        cdae_lds_dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst_wave_base - lds)));
     };
     auto issue_A = [&](int chunk) {
 #pragma unroll

@@ -89,9 +89,10 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void wgwin_kernel(const Wg
     const unsigned short* const a_src = (dP ? p.a_lo : p.a_hi) + ci0 + dH * 32 + (lane & 3) * 8;
     const unsigned short* const d_src = (dP ? p.d_lo : p.d_hi) + co0 + dH * 32 + (lane & 3) * 8;
     char* const a_dst = lds + (dP * 2 + dH) * A_SUB;
+    // LDS-DMA through inline asm (cdae_lds_dma16): with the builtin, hipcc drains the DMAs (vmcnt(0)) in front of the next LDS read that
+    // might alias their destination — i.e. right after they were issued, before the MFMAs they were meant to overlap
     auto dma = [&](const void* src, char* dst_wave_base) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)dst_wave_base, 16, 0, 0);
+        cdae_lds_dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst_wave_base - lds)));
     };
     // one 16-row block of the virtual stream (rows u = 16 blk .. +15) into ring slot `slot`
     auto issue_a = [&](int blk, int slot) {
