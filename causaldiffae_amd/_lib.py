@@ -220,6 +220,27 @@ def range_check(what="a contraction"):
                              f"or was not finite; rerun with causaldiffae_amd.set_precision('fp32') (IEEE fp32 products, fp32 range)")
 
 
+class precision_scope:
+    """with precision_scope("mixed16"): ... — the library's arithmetic mode for the duration of a block, restored on exit (a model
+    converted with convert_to_fp16() applies it around its own forward and TrainLoop around forward + backward, so a second model
+    or a sampler in the same process keeps the parity mode).  None = leave the mode alone."""
+
+    def __init__(self, name):
+        self.name, self.prev = name, None
+
+    def __enter__(self):
+        if self.name is not None:
+            self.prev = get_precision()
+            if self.prev != self.name:
+                set_precision(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        if self.name is not None and self.prev != self.name:
+            set_precision(self.prev)
+        return False
+
+
 def prof_enable(on):
     check(lib.cdae_prof_enable(1 if on else 0))
 

@@ -223,7 +223,7 @@ class TrainLoop:
                  lr_anneal_steps=0, rep_cond=False, n_vars=None, causal_modeling=False, flow_based=False, in_channels=3,
                  masking=False, bucket_mb=64, use_graph=None):
         if use_fp16:       # reduced-precision torso; fp32 master weights are the only weights, bf16 gradients need no loss scaling
-            model.convert_to_fp16()
+            model.convert_to_fp16()        # marks THIS model (the mode is scoped to its forward / backward, not process-wide)
         self.model, self.diffusion, self.data = model, diffusion, data
         self.batch_size = batch_size
         self.microbatch = microbatch if microbatch > 0 else batch_size
@@ -244,12 +244,7 @@ class TrainLoop:
             self.model.load_state_dict(dist_util.load_state_dict(resume_checkpoint, map_location="cpu"))
         self.opt = FusedAdamWEMA(model, lr=lr, weight_decay=weight_decay, ema_rates=self.ema_rate)
         if resume_checkpoint:
-            ema_path = os.path.join(os.path.dirname(resume_checkpoint), "ema_checkpoint.pt")
-            if os.path.exists(ema_path):
-                sd = dist_util.load_state_dict(ema_path, map_location="cpu")
-                f = self.opt.flat
-                for n, p, o in zip(f.names, f.params, f.offsets):
-                    self.opt.ema[0].as_strided(p.shape, p.stride(), o).copy_(sd[n])
+            self._load_resume_state(resume_checkpoint)
         self.opt.broadcast_from_rank0()
         self.buckets = GradBuckets(self.opt.flat, bucket_bytes=bucket_mb << 20)
         self.model_params = self.opt.flat.params
@@ -341,6 +336,11 @@ class TrainLoop:
         return True
 
     def forward_backward(self, batch, cond):
+        from ._lib import precision_scope
+        with precision_scope(getattr(self.model, "_cdae_precision", None)):      # the backward kernels run in the model's own mode too
+            self._forward_backward(batch, cond)
+
+    def _forward_backward(self, batch, cond):
         if self._graph_wanted(batch) and self._graph_step(batch, cond):
             return
         self._eager_steps += 1
@@ -382,6 +382,33 @@ class TrainLoop:
                 from ._lib import range_check
                 range_check("training step")     # an operand left the f16 range of the split-precision planes: stop instead of training on NaNs
 
+    def _load_resume_state(self, resume_checkpoint):
+        """EMA per rate and the Adam moments of the checkpoint's step.  `ema_<rate>_<step>.pt` / `opt<step>.pt` (upstream
+        improved-diffusion's names) when this trainer wrote them; else the reference's single `ema_checkpoint.pt`, which its loop
+        overwrites once per rate (train_util.py:319-345) and which therefore holds the LAST rate."""
+        d, step = os.path.dirname(resume_checkpoint), self.resume_step
+        f = self.opt.flat
+
+        def into(flat_buf, sd):
+            for n, p, o in zip(f.names, f.params, f.offsets):
+                flat_buf.as_strided(p.shape, p.stride(), o).copy_(sd[n])
+
+        found = set()
+        for i, rate in enumerate(self.ema_rate):
+            path = os.path.join(d, f"ema_{rate}_{step:06d}.pt")
+            if os.path.exists(path):
+                into(self.opt.ema[i], dist_util.load_state_dict(path, map_location="cpu"))
+                found.add(i)
+        legacy = os.path.join(d, "ema_checkpoint.pt")
+        if (len(self.ema_rate) - 1) not in found and os.path.exists(legacy):
+            into(self.opt.ema[-1], dist_util.load_state_dict(legacy, map_location="cpu"))
+        opt_path = os.path.join(d, f"opt{step:06d}.pt")
+        if os.path.exists(opt_path):
+            st = dist_util.load_state_dict(opt_path, map_location="cpu")
+            into(self.opt.m, st["exp_avg"])
+            into(self.opt.v, st["exp_avg_sq"])
+            self.opt.t = int(st["step"])
+
     # ------------------------------------------------------------------ checkpoints (names of train_util.py:319-345)
     def save(self):
         if self.rank == 0:             # the reference writes on rank 1 only (so never in single-process runs): fixed, SURVEY Q6
@@ -390,9 +417,16 @@ class TrainLoop:
                 os.makedirs(d, exist_ok=True)
                 sd = {k: v.detach().cpu().contiguous() for k, v in self.model.state_dict().items()}
                 th.save(sd, os.path.join(d, f"model{(self.step + self.resume_step):06d}.pt"))
-                for i, _rate in enumerate(self.ema_rate):
+                step = self.step + self.resume_step
+                for i, rate in enumerate(self.ema_rate):
                     esd = {k: v.detach().cpu().contiguous() for k, v in self.opt.ema_state_dict(i).items()}
-                    th.save(esd, os.path.join(d, "ema_checkpoint.pt"))
+                    th.save(esd, os.path.join(d, "ema_checkpoint.pt"))          # the reference's name (one file, the last rate wins)
+                    th.save(esd, os.path.join(d, f"ema_{rate}_{step:06d}.pt"))    # + one file per rate, so a resume restores every rate
+                f = self.opt.flat
+                names = set(f.names)
+                view = lambda buf: {n: buf.as_strided(p.shape, p.stride(), o).detach().cpu().contiguous() for n, p, o in zip(f.names, f.params, f.offsets)
+                                    if n in names}
+                th.save({"exp_avg": view(self.opt.m), "exp_avg_sq": view(self.opt.v), "step": self.opt.t}, os.path.join(d, f"opt{step:06d}.pt"))
         if dist.is_initialized():
             dist.barrier()
 

@@ -324,13 +324,11 @@ class UNetModel(nn.Module):
         """Reduced-precision torso (reference unet.py:501-507 casts the conv weights to half).  Here storage stays
         fp32 and the matrix-core contractions switch to single-plane f16 (bf16 where an operand is a gradient) with
         fp32 accumulation; GroupNorm, softmax, embeddings and the optimizer stay fp32 like the reference's GroupNorm32 /
-        softmax.  The mode is process-wide (the library's default precision)."""
-        from ._lib import set_precision
-        set_precision("mixed16")
+        softmax.  The mode belongs to this model: other models / samplers of the process keep the parity mode."""
+        self._cdae_precision = "mixed16"       # applied around THIS model's forward (and by TrainLoop around its backward), not process-wide
 
     def convert_to_fp32(self):
-        from ._lib import set_precision
-        set_precision("f16x3")
+        self._cdae_precision = None
 
     @property
     def inner_dtype(self):
@@ -411,7 +409,12 @@ class UNetModel(nn.Module):
         e_all = ops.linear(ops.silu(emb), w, bias)
         return EmbAll(emb, {bid: e_all[:, o:o + n] for bid, o, n in offs})
 
-    def forward(self, x, timesteps, y=None, c=None, x_start=None, z=None, A=None, mask=None):
+    def forward(self, *args, **kwargs):
+        from ._lib import precision_scope
+        with precision_scope(getattr(self, "_cdae_precision", None)):
+            return self._forward(*args, **kwargs)
+
+    def _forward(self, x, timesteps, y=None, c=None, x_start=None, z=None, A=None, mask=None):
         """x [N,C,H,W], timesteps [N] -> (eps [N,Cout,H,W] NCHW-contiguous, mu, var, z_post, mask)."""
         assert (y is not None) == (self.num_classes is not None), \
             "must specify y if and only if the model is class-conditional"

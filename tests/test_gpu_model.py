@@ -844,6 +844,62 @@ def test_mixed16_inference_on_presplit_path():
 
 
 @pytest.mark.gpu
+def test_convert_to_fp16_is_scoped_to_the_model():
+    """model.convert_to_fp16() (reference unet.py:501-507) marks THAT model: its forwards run the reduced-precision torso, the
+    process-wide mode — and with it every other model / sampler of the process — stays in the parity mode."""
+    from causaldiffae_amd._lib import get_precision
+    model, diff, cfg = make("T28")
+    other, _, _ = make("T28")
+    model.eval(); other.eval()
+    x, x0, c, z, y = model_inputs("T28", cfg, 2)
+    t = torch.tensor([37.0, 990.0], device=DEV)
+    kw = dict(z=z.to(DEV), y=y.to(DEV))
+    assert get_precision() == "f16x3"
+    with torch.no_grad():
+        ref = other(x.to(DEV), t, **kw)[0]
+        model.convert_to_fp16()
+        low = model(x.to(DEV), t, **kw)[0]
+        assert get_precision() == "f16x3"                        # restored after the forward
+        again = other(x.to(DEV), t, **kw)[0]
+        model.convert_to_fp32()
+        back = model(x.to(DEV), t, **kw)[0]
+    assert err(again, ref) == 0.0 and err(back, ref) == 0.0      # the untouched model and the re-converted one: parity mode, bit for bit
+    rel = err(low, ref) / ref.abs().max().item()
+    assert 0 < rel < 2e-2, rel                                   # the converted model really ran single-plane products
+
+
+@pytest.mark.gpu
+def test_resume_restores_every_ema_rate_and_adam_state(tmp_path, monkeypatch):
+    """A resumed TrainLoop continues exactly: both EMA rates and the Adam moments / step come back from the files save() wrote."""
+    from improved_diffusion import logger, script_util as su
+    from improved_diffusion.image_datasets import load_data
+    from improved_diffusion.train_util import TrainLoop
+    monkeypatch.setenv("DIFFUSION_TRAINING_TEST", "1")
+    logger.configure(dir=str(tmp_path))
+    cfg = {**su.model_and_diffusion_defaults(), "rep_cond": True, "causal_modeling": True, **MODEL_CFG["T28"]}
+    np.random.seed(0)
+
+    def build(resume=""):
+        model, diff = su.create_model_and_diffusion(**cfg)
+        load_closed_form(model)
+        data = load_data(data_dir="synthetic", batch_size=4, image_size=28, class_cond=True, in_channels=1, n_vars=2)
+        return TrainLoop(model=model, diffusion=diff, data=data, batch_size=4, microbatch=-1, lr=1e-4, ema_rate="0.99,0.9999", log_interval=10,
+                         save_interval=2, resume_checkpoint=resume, rep_cond=True, n_vars=2, causal_modeling=True, in_channels=1)
+
+    loop = build()
+    loop.run_loop()                                   # DIFFUSION_TRAINING_TEST: returns after the save at step 2
+    assert loop.step == 2 and loop.opt.t == 3         # steps 0, 1, 2 were optimised before the save at step 2
+    for name in ("model000002.pt", "ema_0.99_000002.pt", "ema_0.9999_000002.pt", "opt000002.pt", "ema_checkpoint.pt"):
+        assert (tmp_path / name).exists(), name
+    loop2 = build(str(tmp_path / "model000002.pt"))
+    assert loop2.resume_step == 2 and loop2.opt.t == loop.opt.t
+    assert err(loop2.opt.m, loop.opt.m) == 0.0 and err(loop2.opt.v, loop.opt.v) == 0.0
+    for i in range(2):
+        assert err(loop2.opt.ema[i], loop.opt.ema[i]) == 0.0, i
+    assert err(loop.opt.ema[0], loop.opt.ema[1]) > 0.0          # the two rates really differ
+
+
+@pytest.mark.gpu
 def test_train_step_graph_replay_matches_eager():
     """TrainLoop(use_graph=True): forward + backward replayed from a hipGraph (static input / timestep / weight / KL-weight buffers)
     gives the same losses and gradients as eager launches from the same RNG state, to the eager path's own run-to-run noise."""
