@@ -1006,3 +1006,31 @@ def test_lds_out_of_range_reads_return_zero(tmp_path):
             assert nonzero == 4096, l
         else:
             assert nonzero == 0, l
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,Cin,Cout,S,up", [(64, 128, 128, 64, False),      # 1024 tiles, four per persistent block
+                                             (128, 256, 256, 32, False),     # K = 2304, two n-tiles share a window
+                                             (128, 512, 512, 8, False),      # 8x8 level: split-K slabs + reduce
+                                             (96, 384, 384, 16, False),      # 16x16: a tile spans exactly one image
+                                             (256, 64, 128, 32, True)])      # sub-pixel phases (four 2x2-tap launches)
+def test_window_conv_is_race_free_and_deterministic(N, Cin, Cout, S, up):
+    """The second-generation window kernel keeps LDS-DMAs in flight across barriers with counted waits: a misplaced wait shows up as
+    rare wrong tiles that come and go with memory load.  Twenty launches of the same problem, with an unrelated memory-bound kernel
+    in between, must give bit-identical results, and the first must agree with an fp64 convolution."""
+    from causaldiffae_amd import ops
+    g = torch.Generator(device="cuda:0").manual_seed(31)
+    x = ops.to_nhwc(torch.randn(N, Cin, S, S, device="cuda:0", generator=g))
+    w = (torch.randn(Cout, Cin, 3, 3, device="cuda:0", generator=g) / (9 * Cin) ** 0.5).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(Cout, device="cuda:0", generator=g)
+    xs = _split_nhwc(x)
+    junk = torch.empty(64 << 20, dtype=torch.float32, device="cuda:0")
+    with torch.no_grad():
+        first = ops.conv3x3_ps(xs, w, b, up=up).clone()
+        for it in range(20):
+            junk.normal_() if it % 3 == 0 else junk.mul_(1.0001)          # perturb caches / HBM queues between launches
+            again = ops.conv3x3_ps(xs, w, b, up=up)
+            assert torch.equal(again, first), it
+        xin = F.interpolate(x[:2].contiguous(), scale_factor=2, mode="nearest") if up else x[:2].contiguous()
+        exact = F.conv2d(xin.double(), w.double(), b.double(), padding=1)
+    assert (first[:2].double() - exact).abs().max().item() < 2e-5 * max(1.0, exact.abs().max().item())
