@@ -1509,12 +1509,18 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
             static const int cfg_cw_ks = getenv("CDAE_CONVWIN_SPLITK") ? atoi(getenv("CDAE_CONVWIN_SPLITK")) : 1;
             const long cw_tiles = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
             bool cw = cfg_cw && cdae_convwin_ok(p);
-            if (cw && cw_tiles * ks < cfg_cw_min) {
-                // too few 256 x 128 tiles for two blocks per CU: split K by whole 32-channel chunks (the low-resolution levels)
-                int k2 = (int)((512 + cw_tiles - 1) / cw_tiles);
-                if (k2 > nchunk / 2) k2 = nchunk / 2;              // at least two chunks = 18 K-steps per split
-                while (k2 > 1 && (size_t)k2 * p.M * p.N * sizeof(float) > p.splitk_ws_bytes) --k2;
-                if (cfg_cw_ks && k2 > 1 && p.ksplit_auto && p.splitk_ws && !p.gn_part && cw_tiles * k2 >= cfg_cw_min) { p.ksplit = ks = k2; }
+            if (cw) {
+                // fewer 256 x 128 tiles than block slots (two per CU): split K by whole 32-channel chunks (the low-resolution levels, and
+                // everything below 64 x 64 at training batch sizes).  floor, not ceil: 96 tiles x 6 = 576 would need a second, nearly
+                // empty round of blocks; x 5 = 480 runs in one
+                int kbest = ks;
+                if (cw_tiles * ks < 512 && cfg_cw_ks && p.ksplit_auto && p.splitk_ws && !p.gn_part) {
+                    int k2 = (int)(512 / cw_tiles);
+                    if (k2 > nchunk / 2) k2 = nchunk / 2;          // at least two chunks = 18 K-steps per split
+                    while (k2 > 1 && (size_t)k2 * p.M * p.N * sizeof(float) > p.splitk_ws_bytes) --k2;
+                    if (k2 > 1) kbest = k2;
+                }
+                if (cw_tiles * kbest >= cfg_cw_min) p.ksplit = ks = kbest;
                 else cw = false;
             }
             if (cw) {

@@ -1,5 +1,15 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-timeout 1200 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "race_free or lds_out_of_range" > gpurun_out/t_race.log 2>&1
-tail -8 gpurun_out/t_race.log
+{
+cp causaldiffae_amd/libcdae.so /tmp/new.so
+for v in new old new old; do
+  cp /tmp/new.so causaldiffae_amd/libcdae.so; [ $v = old ] && cp causaldiffae_amd/libcdae_old.so causaldiffae_amd/libcdae.so
+  echo "== $v"
+  timeout 300 python tools/train_step.py 20 2>&1 | grep -v amdgpu | tail -1 | python -c "
+import sys,ast
+d=ast.literal_eval(sys.stdin.read()); print(d['ms_per_step'], d['value'])"
+done
+cp /tmp/new.so causaldiffae_amd/libcdae.so
+} > gpurun_out/exp1.log 2>&1
+tail -10 gpurun_out/exp1.log
