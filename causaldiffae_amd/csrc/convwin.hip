@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                             for (int j = 0; j < 4; ++j) v[j] += rbase[ro + 16 * j];
                         }
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) { cbase[ro + 16 * j] = v[j]; gs[j] += v[j]; gq[j] += v[j] * v[j]; }
+                        for (int j = 0; j < 4; ++j) { cbase[ro + 16 * j] = v[j]; gs[j] += v[j]; gq[j] += v[j] * v[j]; }      // (nontemporal stores: measured +-0)
                         if (!__builtin_isfinite(v[0] + v[1] + v[2] + v[3]) && p.range_flag) *p.range_flag = 1;      // f16 plane overflow surfaces as NaN / inf
                     }
                 }

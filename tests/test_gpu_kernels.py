@@ -1034,3 +1034,16 @@ def test_window_conv_is_race_free_and_deterministic(N, Cin, Cout, S, up):
         xin = F.interpolate(x[:2].contiguous(), scale_factor=2, mode="nearest") if up else x[:2].contiguous()
         exact = F.conv2d(xin.double(), w.double(), b.double(), padding=1)
     assert (first[:2].double() - exact).abs().max().item() < 2e-5 * max(1.0, exact.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_window_conv_odd_shapes():
+    """Partial last tiles in M and N, Cin of three chunks, one-image and odd-batch problems on the second-generation window kernel
+    (forced onto them by CDAE_CONVWIN_MINTILES=1; at production sizes the dispatcher routes e.g. batch 129 at the 8 x 8 level there)."""
+    import os, subprocess, sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "convwin_odd_worker.py")
+    r = subprocess.run([sys.executable, worker], env={**os.environ, "CDAE_CONVWIN_MINTILES": "1", "CDAE_CONVWIN_SPLITK": "0"}, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run([sys.executable, worker], env={**os.environ, "CDAE_CONVWIN_MINTILES": "1"}, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]          # the same with split-K allowed
