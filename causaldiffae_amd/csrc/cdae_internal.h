@@ -64,6 +64,9 @@ struct GemmParams {
     // (|x| >= 65520) becomes hi = inf, lo = -inf in the split and the products NaN, so this is where an overflow of the 16-bit
     // planes surfaces; the host reads the flag with cdae_range_status() (pinned host memory, written straight from the kernels)
     int* range_flag;
+    // igemm_kernel GNS: the (a, b) coefficients of the (at most two) images a 128-row tile touches are preloaded into LDS behind the
+    // tiles (16 bytes x K), set by the launcher when that fits; 0 = read them from global memory inside the loop
+    int gn_tab;
 };
 
 int cdae_gemm_dispatch(GemmParams p, void* stream);

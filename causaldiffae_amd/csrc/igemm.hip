@@ -184,6 +184,26 @@ __global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_ke
     const int kt_begin = ks * nk_per;
     const int kt_end = min(nk_total, kt_begin + nk_per);
 
+    // GNS: GroupNorm coefficients of this tile's images from LDS.  Read from global memory inside store_tiles they sit BEHIND the
+    // register prefetch of the next two K-steps in the (in-order) vmcnt queue, so waiting for them drained the prefetch every
+    // step — the "two steps ahead" pipeline of this HBM-bound kernel never ran ahead at all.
+    float* const ctab = smem + 2 * (A_TILE + B_TILE);
+    int gn_img0 = 0;
+    const bool gn_tab = GNS && p.gn_tab && nt == 0;
+    if constexpr (GNS) {
+        if (gn_tab) {
+            gn_img0 = fdiv(m0, p.hw_magic, p.hw_shift);
+            const int img_last = fdiv(p.M - 1, p.hw_magic, p.hw_shift);
+            const int per = p.K >> 1;                                  // float4s per image: K x (a, b)
+            for (int t = tid; t < 2 * per; t += THREADS) {
+                const int sel = t >= per ? 1 : 0;
+                const int img = min(gn_img0 + sel, img_last);
+                reinterpret_cast<float4*>(ctab)[t] = *reinterpret_cast<const float4*>(p.gn_coef + ((long)img * p.K) * 2 + (long)(t - sel * per) * 4);
+            }
+            __syncthreads();
+        }
+    }
+
     // ---------------------------------------------------------------- per-thread loader state
     PixRow arow[A_V4];
     long atap_off[A_V4];          // A_CONV_VEC: element offset of the current tap's pixel, refreshed when the tap changes
@@ -391,7 +411,8 @@ __global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_ke
                     const int m = m0 + (tid >> 3) + RPP * q;
                     if (m < p.M && k < p.K) {
                         const int img = fdiv(m, p.hw_magic, p.hw_shift);
-                        const float4* cf = reinterpret_cast<const float4*>(p.gn_coef + ((long)img * p.K + k) * 2);
+                        const float4* cf = gn_tab ? reinterpret_cast<const float4*>(ctab + ((img - gn_img0) * p.K + k) * 2)
+                                                  : reinterpret_cast<const float4*>(p.gn_coef + ((long)img * p.K + k) * 2);
                         const float4 c01 = cf[0], c23 = cf[1];                // a0 b0 a1 b1 | a2 b2 a3 b3
                         float y0 = fmaf(ra[q].x, c01.x, c01.y), y1 = fmaf(ra[q].y, c01.z, c01.w);
                         float y2 = fmaf(ra[q].z, c23.x, c23.y), y3 = fmaf(ra[q].w, c23.z, c23.w);
@@ -1341,16 +1362,26 @@ int launch(const GemmParams& p, hipStream_t st) {
     constexpr int NPL = (PREC == 1 || PREC == 2) ? 2 : 1;
     constexpr int A_TILE = PREC ? NPL * (A_MC ? BK * (BM + 32) : BM * 32) / 2 : (A_MC ? BK * (BM + 4) : BM * LDK);
     constexpr int B_TILE = PREC ? NPL * (B_MC ? BK * (BN + 32) : BN * 32) / 2 : (B_MC ? BK * (BN + 4) : BN * LDK);
-    constexpr size_t smem = 2 * (A_TILE + B_TILE) * sizeof(float);
+    constexpr size_t tiles = 2 * (A_TILE + B_TILE) * sizeof(float);
+    constexpr size_t tab_max = GNS ? 16 * 1024 : 0;          // coefficient table: 16 bytes x K, K <= 1024 (two blocks of 80 KB still share a CU)
     static bool attr_done = false;      // per-instantiation; value is idempotent so a race is benign
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, AMODE, BMODE, SCALAR, WAVES_N, PREC, GNS, DEEP>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(tiles + tab_max)) != hipSuccess)
             return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
         attr_done = true;
     }
+    GemmParams q = p;
+    size_t smem = tiles;
+    if constexpr (GNS) {
+        // a 128-row tile touches at most two images when an image has >= 64 rows... in general ceil(128 / hw) + 1: table only for hw >= 128 or hw == 64
+        static const int cfg_tab = getenv("CDAE_GNS_TAB") ? atoi(getenv("CDAE_GNS_TAB")) : 1;
+        const bool two = p.hw >= BM || (p.hw * 2 == BM);
+        q.gn_tab = cfg_tab && two && (size_t)16 * p.K <= tab_max && p.K % 4 == 0 && p.ksplit == 1 && p.batch == 1;
+        if (q.gn_tab) smem += (size_t)16 * p.K;
+    }
     dim3 grid((unsigned)((long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.batch * p.ksplit));
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, AMODE, BMODE, SCALAR, WAVES_N, PREC, GNS, DEEP>), grid, dim3(128 * WAVES_N), smem, st, p);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, AMODE, BMODE, SCALAR, WAVES_N, PREC, GNS, DEEP>), grid, dim3(128 * WAVES_N), smem, st, q);
     return hipGetLastError() == hipSuccess ? 0 : cdae_fail("igemm launch failed");
 }
 
