@@ -83,6 +83,7 @@ SIGNATURES = {
     "cdae_embedding_add": [P, P, P, I, I, P],
     "cdae_embedding_bwd": [P, P, P, I, I, P],
     "cdae_axpby": [F, P, F, P, P, L, P],
+    "cdae_mul_scale": [P, P, F, P, L, P],
     "cdae_mul_rows": [P, P, I, I, P],
     "cdae_copy2d": [P, P, L, I, L, L, I, P],
     "cdae_nchw_to_nhwc": [P, P, I, I, I, P],

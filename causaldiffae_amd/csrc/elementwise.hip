@@ -206,6 +206,11 @@ __global__ void embedding_bwd_kernel(const float* __restrict__ demb, float* __re
     GRID_STRIDE(i, (long)N * D) { int n = (int)(i / D), d = (int)(i - (long)n * D); atomicAdd(&dtable[idx[n] * D + d], demb[i]); }
 }
 
+// out = x * m * scale: nn.Dropout in training (reference unet.py:153 `nn.Dropout(p=dropout)`; m = the Bernoulli(1 - p) keep mask as 0 / 1
+// floats, scale = 1 / (1 - p)), and its backward with dy in place of x
+__global__ void mul_scale_kernel(const float* __restrict__ x, const float* __restrict__ m, float scale, float* __restrict__ out, long n) {
+    GRID_STRIDE(i, n) { out[i] = x[i] * m[i] * scale; }
+}
 __global__ void axpby_kernel(float a, const float* __restrict__ x, float b, const float* __restrict__ y, float* __restrict__ out, long n) {
     GRID_STRIDE(i, n) {
         float r = a * x[i];
@@ -574,6 +579,7 @@ int cdae_embedding_bwd(const float* demb, float* dtable, const long long* idx, i
     LAUNCH1D(embedding_bwd_kernel, (long)N * D, demb, dtable, idx, N, D);
 }
 int cdae_axpby(float a, const float* x, float b, const float* y, float* out, long n, void* stream) { LAUNCH1D(axpby_kernel, n, a, x, b, y, out, n); }
+int cdae_mul_scale(const float* x, const float* m, float scale, float* out, long n, void* stream) { LAUNCH1D(mul_scale_kernel, n, x, m, scale, out, n); }
 int cdae_mul_rows(float* x, const float* m, int N, int D, void* stream) { LAUNCH1D(mul_rows_kernel, (long)N * D, x, m, N, D); }
 int cdae_copy2d(const float* src, float* dst, long rows, int cols, long lds, long ldd, int accumulate, void* stream) {
     LAUNCH1D(copy2d_kernel, rows * cols / 4 + 1, src, dst, rows, cols, lds, ldd, accumulate);

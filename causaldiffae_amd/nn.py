@@ -45,15 +45,52 @@ class Sigmoid(nn.Module):
         raise NotImplementedError("Sigmoid is applied by the preceding Linear (act=ops.ACT_SIGMOID)")
 
 
+class _DropoutFn(th.autograd.Function):
+    """y = x * mask / (1 - p) on the elementwise kernel; backward dx = dy * mask / (1 - p)."""
+
+    @staticmethod
+    def forward(ctx, x, mask, scale):
+        x = x.contiguous() if not x.is_contiguous(memory_format=th.channels_last) else x
+        y = th.empty_like(x)
+        ops.check(ops.lib.cdae_mul_scale(ops.ptr(x), ops.ptr(mask), float(scale), ops.ptr(y), x.numel(), ops.stream()))
+        ctx.save_for_backward(mask)
+        ctx.scale = float(scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        dy = dy.contiguous(memory_format=th.channels_last) if mask.is_contiguous(memory_format=th.channels_last) and not mask.is_contiguous() else dy.contiguous()
+        dx = th.empty_like(dy)
+        ops.check(ops.lib.cdae_mul_scale(ops.ptr(dy), ops.ptr(mask), ctx.scale, ops.ptr(dx), dy.numel(), ops.stream()))
+        return dx, None, None
+
+
 class Dropout(nn.Module):
+    """nn.Dropout(p) of the ResBlock's out_layers (reference unet.py:153).  Identity in eval mode and for p = 0 (every CausalDiffAE
+    config); in training the keep mask ~ Bernoulli(1 - p) is drawn on the device (or injected: rng_override(dropout_mask=...), one
+    entry consumed per call) and applied by cdae_mul_scale.  The block then runs its unfused path (the fused ResBlock node has no
+    mask input), like the reference runs dropout as its own module."""
+
     def __init__(self, p=0.0):
         super().__init__()
         self.p = p
 
     def forward(self, x):
-        if self.p > 0.0 and self.training:
-            raise NotImplementedError("dropout > 0 is not on the CausalDiffAE hot path (every config uses 0.0)")
-        return x
+        if self.p <= 0.0 or not self.training:
+            return x
+        if not th.is_tensor(x):
+            raise TypeError("Dropout needs a plain tensor (the ResBlock asks its GroupNorm for one when dropout is active)")
+        inj = _RNG_OVERRIDE.get("dropout_mask")
+        if inj is not None:
+            mask = inj.pop(0) if isinstance(inj, list) else inj
+            mask = mask.to(x.device).float().expand_as(x)
+        else:
+            mask = th.bernoulli(th.full(x.shape, 1.0 - self.p, device=x.device))
+        # same memory order as x (NHWC storage of a logical NCHW tensor): the kernel multiplies storage element by storage element
+        mask = mask.contiguous(memory_format=th.channels_last) if (x.dim() == 4 and x.is_contiguous(memory_format=th.channels_last) and not x.is_contiguous()) \
+            else mask.contiguous()
+        return _DropoutFn.apply(x, mask, 1.0 / (1.0 - self.p))
 
 
 class Linear(nn.Module):

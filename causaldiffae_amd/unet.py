@@ -180,11 +180,12 @@ class ResBlock(TimestepBlock):
             emb_out = emb.slices[id(self)]                         # column slice of the batched emb_layers GEMM
         else:
             emb_out = self.emb_layers[1](ops.silu(emb))            # [N, (2)Cout]
+        split = not (self.dropout > 0 and self.training)           # an active dropout needs the normalised values as a plain tensor
         if self.use_scale_shift_norm:
-            h = self.out_layers[0](h, scale_shift=emb_out, silu=True, split=True)
+            h = self.out_layers[0](h, scale_shift=emb_out, silu=True, split=split)
         else:
-            h = self.out_layers[0](h + emb_out[:, :, None, None], silu=True, split=True)
-        h = self.out_layers[2](h)
+            h = self.out_layers[0](h + emb_out[:, :, None, None], silu=True, split=split)
+        h = self.out_layers[2](h)                                  # nn.Dropout: identity unless training with p > 0
         if skip is None:
             skip = ops.materialize(x) if isinstance(self.skip_connection, Identity) else self.skip_connection(x)
         if isinstance(h, (ops.SplitAct, ops.LazyGN)):              # emit_split: a Down/Upsample conv consumes this block's output

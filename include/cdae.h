@@ -300,6 +300,7 @@ int cdae_model_timesteps(const long long* t, const long long* map, float scale, 
 int cdae_embedding_add(float* emb, const float* table, const long long* idx, int N, int D, void* stream);     /* unet.py:550 */
 int cdae_embedding_bwd(const float* demb, float* dtable, const long long* idx, int N, int D, void* stream);
 int cdae_axpby(float a, const float* x, float b, const float* y, float* out, long n, void* stream);          /* y may be NULL */
+int cdae_mul_scale(const float* x, const float* m, float scale, float* out, long n, void* stream);          /* nn.Dropout (unet.py:153): x * keep-mask / (1 - p), and its backward */
 int cdae_mul_rows(float* x, const float* m, int N, int D, void* stream);                                       /* unet.py:608-611 */
 int cdae_copy2d(const float* src, float* dst, long rows, int cols, long lds, long ldd, int accumulate, void* stream);  /* th.cat unet.py:628 */
 int cdae_nchw_to_nhwc(const float* src, float* dst, int N, int C, int HW, void* stream);

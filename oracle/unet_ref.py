@@ -190,8 +190,8 @@ def timestep_embedding(t, dim, max_period=10000):
     return e
 
 
-def resblock(sd, p, x, emb, ssn=True):
-    """unet.py:185-198."""
+def resblock(sd, p, x, emb, ssn=True, drop=None):
+    """unet.py:185-198.  drop: the training-mode nn.Dropout of out_layers (unet.py:153) as an explicit factor keep_mask / (1 - p)."""
     h = F.conv2d(silu(gn32(x, sd[p + ".in_layers.0.weight"], sd[p + ".in_layers.0.bias"])),
                  sd[p + ".in_layers.2.weight"], sd[p + ".in_layers.2.bias"], padding=1)
     e = F.linear(silu(emb), sd[p + ".emb_layers.1.weight"], sd[p + ".emb_layers.1.bias"])[:, :, None, None]
@@ -201,7 +201,10 @@ def resblock(sd, p, x, emb, ssn=True):
         h = g(h, sd[p + ".out_layers.0.weight"], sd[p + ".out_layers.0.bias"]) * (1 + e[:, :co]) + e[:, co:]
     else:
         h = g(h + e, sd[p + ".out_layers.0.weight"], sd[p + ".out_layers.0.bias"])
-    h = F.conv2d(silu(h), sd[p + ".out_layers.3.weight"], sd[p + ".out_layers.3.bias"], padding=1)
+    h = silu(h)
+    if drop is not None:
+        h = h * drop
+    h = F.conv2d(h, sd[p + ".out_layers.3.weight"], sd[p + ".out_layers.3.bias"], padding=1)
     k = p + ".skip_connection.weight"
     skip = F.conv2d(x, sd[k], sd[p + ".skip_connection.bias"]) if k in sd else x
     return skip + h

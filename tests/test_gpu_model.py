@@ -88,6 +88,39 @@ def test_resblock_golden(golden, tag, ci, co, ssn, precision):
         assert probe_err(p.grad, g, f"{tag}/g.{k}") < 2e-4, k
 
 
+@pytest.mark.parametrize("tag", ["drop_same", "drop_skip"])
+def test_resblock_training_dropout_golden(golden, tag, precision):
+    """G16: training-mode ResBlock with dropout > 0 against the reference, fed the keep mask the reference's nn.Dropout drew
+    (rng_override(dropout_mask=...)); eval mode is the identity; an un-injected mask keeps ~(1 - p) of the entries, scaled 1/(1-p)."""
+    from improved_diffusion.nn import Dropout, rng_override
+    from improved_diffusion.unet import ResBlock
+    g = golden("g16_dropout.npz")
+    meta = json.load(open(os.path.join(GOLDEN, "g16_dropout.json")))[tag]
+    blk = load_closed_form(ResBlock(meta["ci"], 512, meta["p"], out_channels=meta["co"], use_scale_shift_norm=meta["ssn"]), tag + ".")
+    blk.train()
+    x = synth(tag + ".x", meta["x_shape"]).to(DEV).requires_grad_(True)
+    e = synth(tag + ".emb", (meta["x_shape"][0], 512)).to(DEV).requires_grad_(True)
+    with rng_override(dropout_mask=torch.from_numpy(g[tag + "/mask"]).float().to(DEV)):
+        y = blk(x, e)
+    (y * synth(tag + ".gy", meta["y_shape"]).to(DEV)).sum().backward()
+    assert err(y, g[tag + "/y"]) < 1e-4
+    assert err(x.grad, g[tag + "/gx"]) < 1e-4
+    assert err(e.grad, g[tag + "/gemb"]) < 1e-4
+    for k, p in blk.named_parameters():
+        assert probe_err(p.grad, g, f"{tag}/g.{k}") < 2e-4, k
+    with torch.no_grad():                                   # train mode without grad: same mask, same values
+        with rng_override(dropout_mask=torch.from_numpy(g[tag + "/mask"]).float().to(DEV)):
+            assert err(blk(x, e), g[tag + "/y"]) < 1e-4
+        blk.eval()
+        assert err(blk(x, e), g[tag + "/y_eval"]) < 1e-4
+    d = Dropout(0.25).train()
+    v = torch.ones(1 << 20, device=DEV)
+    o = d(v)
+    kept = (o != 0).float().mean().item()
+    assert abs(kept - 0.75) < 5e-3 and err(o[o != 0], torch.full_like(o[o != 0], 1 / 0.75)) < 1e-6
+    assert d.eval()(v) is v
+
+
 @pytest.mark.parametrize("ch,T", [(96, 256), (128, 64), (64, 256), (64, 16)])
 def test_attention_block_golden(golden, ch, T):
     from improved_diffusion.unet import AttentionBlock

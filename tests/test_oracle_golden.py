@@ -109,6 +109,29 @@ def test_resblock(golden, tag, ci, co, ssn):
         probe_close(v.grad, g, f"{tag}/g.{k}", 1e-5)
 
 
+@pytest.mark.parametrize("tag", ["drop_same", "drop_skip"])
+def test_resblock_training_dropout(golden, tag):
+    """G16: the reference block in training mode with dropout > 0 (unet.py:153); the oracle takes the mask the reference drew."""
+    g = golden("g16_dropout.npz")
+    meta = json.load(open(os.path.join(GOLDEN, "g16_dropout.json")))[tag]
+    ci, co, ssn, pd = meta["ci"], meta["co"], meta["ssn"], meta["p"]
+    spec = _strip(U._layer_spec("b", ("res", ci, co), 512, ssn), "b")
+    sd = _block_sd(tag, spec)
+    x = synth(tag + ".x", meta["x_shape"]).requires_grad_(True)
+    e = synth(tag + ".emb", (meta["x_shape"][0], 512)).requires_grad_(True)
+    drop = torch.from_numpy(g[tag + "/mask"]).float() / (1.0 - pd)
+    bsd = {"b." + k: v for k, v in sd.items()}
+    y = U.resblock(bsd, "b", x, e, ssn, drop=drop)
+    (y * synth(tag + ".gy", meta["y_shape"])).sum().backward()
+    close(y.detach().numpy(), g[tag + "/y"], 1e-5)
+    close(x.grad.numpy(), g[tag + "/gx"], 1e-5, 1e-5)
+    close(e.grad.numpy(), g[tag + "/gemb"], 1e-5, 1e-5)
+    for k, v in sd.items():
+        probe_close(v.grad, g, f"{tag}/g.{k}", 1e-5)
+    with torch.no_grad():
+        close(U.resblock(bsd, "b", x, e, ssn).numpy(), g[tag + "/y_eval"], 1e-5)
+
+
 @pytest.mark.parametrize("ch,T", [(96, 256), (128, 64), (64, 256), (64, 16)])
 def test_attention_block(golden, ch, T):
     g = golden("g3_blocks.npz")

@@ -765,7 +765,39 @@ def g15_m32_b256(out_dir):
     np.savez_compressed(os.path.join(out_dir, "g15_m32_b256.npz"), **out)
 
 
-ALL = dict(G1=g1_schedules, G2=g2_temb, G3=g3_blocks, G4=g4_encoder, G5=g5_rep_loss, G6=g6_unet, G7=g7_train, G8=g8_ddim, G9=g9_vlb, G10=g10_flow, G11=g11_variants, G12=g12_full_train, G13=g13_guidance, G14=g14_p_sample_loop, G15=g15_m32_b256)
+# --------------------------------------------------------------------------- G16
+def g16_dropout(out_dir):
+    """Training-mode ResBlock with dropout > 0 (unet.py:153): the keep mask the reference's nn.Dropout drew is recorded next to the
+    outputs (a forward hook on the module: kept <=> output != 0 wherever the input != 0), so the product can be fed the same mask."""
+    out, meta = {}, {}
+    for tag, ci, co, ssn, pdrop, shape in [("drop_same", 128, 128, True, 0.3, (2, 128, 8, 8)), ("drop_skip", 64, 96, False, 0.1, (3, 64, 6, 6))]:
+        blk = runet.ResBlock(ci, 512, pdrop, out_channels=co, use_scale_shift_norm=ssn)
+        load_closed_form(blk, tag + ".")
+        blk.train()
+        seen = {}
+        drop = [m for m in blk.out_layers if isinstance(m, th.nn.Dropout)][0]
+        drop.register_forward_hook(lambda m, i, o: seen.update(mask=((o != 0) | (i[0] == 0)).float().detach()))
+        th.manual_seed(1234)
+        x = synth(tag + ".x", shape).requires_grad_(True)
+        e = synth(tag + ".emb", (shape[0], 512)).requires_grad_(True)
+        y = blk(x, e)
+        gy = synth(tag + ".gy", tuple(y.shape))
+        (y * gy).sum().backward()
+        out[f"{tag}/mask"] = seen["mask"].numpy().astype(np.uint8)
+        kept = float(seen["mask"].mean())
+        out[f"{tag}/y"], out[f"{tag}/gx"], out[f"{tag}/gemb"] = y.detach().numpy(), x.grad.numpy(), e.grad.numpy()
+        for k, p in blk.named_parameters():
+            flat_probe(f"{tag}/g.{k}", p.grad, out)
+        blk.eval()
+        with th.no_grad():
+            out[f"{tag}/y_eval"] = blk(x, e).numpy()
+        meta[tag] = dict(ci=ci, co=co, ssn=ssn, p=pdrop, x_shape=list(shape), y_shape=list(y.shape), kept=kept)
+    np.savez_compressed(os.path.join(out_dir, "g16_dropout.npz"), **out)
+    with open(os.path.join(out_dir, "g16_dropout.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
+ALL = dict(G16=g16_dropout, G1=g1_schedules, G2=g2_temb, G3=g3_blocks, G4=g4_encoder, G5=g5_rep_loss, G6=g6_unet, G7=g7_train, G8=g8_ddim, G9=g9_vlb, G10=g10_flow, G11=g11_variants, G12=g12_full_train, G13=g13_guidance, G14=g14_p_sample_loop, G15=g15_m32_b256)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
