@@ -91,6 +91,25 @@ int* cdae_range_flag_ptr();      // device-visible int[1], see GemmParams::range
 // MFMA stream (round-2 finding; visible in the ISA of every round-1 plane kernel).  Opaque asm leaves all waiting to the
 // kernel's own counted s_waitcnt.
 #ifdef __HIPCC__
+// sigmoid / SiLU (reference nn.py:13-15 SiLU = x * sigmoid(x)) on the two transcendental instructions: 1 / (1 + 2^t), t = -x log2(e),
+// with the rounding error of the product t carried into the result ((1 + r ln 2) correction), so the value is within ~2 ulp of the
+// exact one.  8 VALU instructions instead of the ~25 of `1 / (1 + expf(-x))` (range reduction, denormal scaling and an IEEE divide the
+// sigmoid does not need) — the normalisation kernels are VALU-bound on that sequence.  EVERY kernel uses this one definition, so the
+// activation planes of the different producers stay bit-identical.
+__device__ __forceinline__ float cdae_sigmoid(float x) {
+    const float c_hi = -1.44269502162933349609375f, c_lo = -1.925963033500011e-8f;        // -log2(e) = c_hi + c_lo
+    const float t = x * c_hi;
+    const float r = __builtin_fmaf(x, c_lo, __builtin_fmaf(x, c_hi, -t));                 // exact product minus t
+    const float e = __builtin_amdgcn_exp2f(t);
+    const float ec = __builtin_fmaf(e * 0.693147182464599609375f, r, e);                 // 2^(t + r)
+    return __builtin_amdgcn_rcpf(1.f + ec);
+}
+__device__ __forceinline__ float cdae_silu(float x) {
+    float y = x * cdae_sigmoid(x);
+    asm("" : "+v"(y));              // the rounded product, never contracted into a following add (bit-identical across translation units)
+    return y;
+}
+
 __device__ __forceinline__ void cdae_lds_dma16(const void* src, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_dst), "v"(src) : "memory", "m0");
 }

@@ -21,10 +21,10 @@ int grid_for(long total, int cap = 4096) {
 }
 
 __global__ void silu_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
-    GRID_STRIDE(i, n) { float v = x[i]; y[i] = v / (1.f + expf(-v)); }
+    GRID_STRIDE(i, n) { float v = x[i]; y[i] = cdae_silu(v); }
 }
 __global__ void silu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, long n) {
-    GRID_STRIDE(i, n) { float v = x[i], s = 1.f / (1.f + expf(-v)); dx[i] = dy[i] * s * (1.f + v * (1.f - s)); }
+    GRID_STRIDE(i, n) { float v = x[i], s = cdae_sigmoid(v); dx[i] = dy[i] * s * (1.f + v * (1.f - s)); }
 }
 
 // fp32 -> two f16 planes (hi = f16(x), lo = f16(x - hi)): the operand format of the pre-split GEMM kernel (weights, once per version)
@@ -157,10 +157,10 @@ __global__ __launch_bounds__(256) void wprep_all_kernel(const float* __restrict_
 
 // generic pointwise activations on a stored pre-activation (codes = the GEMM epilogue's: 1 SiLU, 2 LeakyReLU(0.01), 3 ReLU, 4 sigmoid)
 __device__ inline float act_apply(float v, int kind) {
-    if (kind == 1) return v / (1.f + expf(-v));
+    if (kind == 1) return cdae_silu(v);
     if (kind == 2) return v > 0.f ? v : 0.01f * v;
     if (kind == 3) return fmaxf(v, 0.f);
-    if (kind == 4) return 1.f / (1.f + expf(-v));
+    if (kind == 4) return cdae_sigmoid(v);
     return v;
 }
 __global__ void act_kernel(const float* __restrict__ x, float* __restrict__ y, long n, int kind) {
@@ -169,10 +169,10 @@ __global__ void act_kernel(const float* __restrict__ x, float* __restrict__ y, l
 __global__ void act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, long n, int kind) {
     GRID_STRIDE(i, n) {
         float v = x[i], g = dy[i], d = 1.f;
-        if (kind == 1) { float s = 1.f / (1.f + expf(-v)); d = s * (1.f + v * (1.f - s)); }
+        if (kind == 1) { float s = cdae_sigmoid(v); d = s * (1.f + v * (1.f - s)); }
         else if (kind == 2) d = v > 0.f ? 1.f : 0.01f;
         else if (kind == 3) d = v > 0.f ? 1.f : 0.f;
-        else if (kind == 4) { float s = 1.f / (1.f + expf(-v)); d = s * (1.f - s); }
+        else if (kind == 4) { float s = cdae_sigmoid(v); d = s * (1.f - s); }
         dx[i] = g * d;
     }
 }

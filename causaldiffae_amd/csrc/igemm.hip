@@ -416,7 +416,7 @@ __global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_ke
                         const float4 c01 = cf[0], c23 = cf[1];                // a0 b0 a1 b1 | a2 b2 a3 b3
                         float y0 = fmaf(ra[q].x, c01.x, c01.y), y1 = fmaf(ra[q].y, c01.z, c01.w);
                         float y2 = fmaf(ra[q].z, c23.x, c23.y), y3 = fmaf(ra[q].w, c23.z, c23.w);
-                        if (p.gn_silu) { y0 = y0 / (1.f + expf(-y0)); y1 = y1 / (1.f + expf(-y1)); y2 = y2 / (1.f + expf(-y2)); y3 = y3 / (1.f + expf(-y3)); }
+                        if (p.gn_silu) { y0 = cdae_silu(y0); y1 = cdae_silu(y1); y2 = cdae_silu(y2); y3 = cdae_silu(y3); }
                         asm volatile("" : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3));      // opaque before the split (attention.hip split8)
                         half4 hi, lo;
                         hi[0] = (_Float16)y0; hi[1] = (_Float16)y1; hi[2] = (_Float16)y2; hi[3] = (_Float16)y3;
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_ke
                 } else addr = (long)row * p.ldc + col;
                 float v = acc[i][j][r] * p.alpha + bv;
                 if (Rg) v += Rg[addr];
-                if (p.act == ACT_SILU) v = v / (1.f + expf(-v));
+                if (p.act == ACT_SILU) v = cdae_silu(v);
                 else if (p.act == ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
                 if (p.accumulate) v += Cg[addr];
                 Cg[addr] = v;
@@ -903,7 +903,7 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + LOADERS)) void ps_kernel(
                 } else addr = (long)row * p.ldc + col;
                 float v = acc[i][j][r] * p.alpha + bv;
                 if (Rg) v += Rg[addr];
-                if (p.act == ACT_SILU) v = v / (1.f + expf(-v));
+                if (p.act == ACT_SILU) v = cdae_silu(v);
                 else if (p.act == ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
                 if (p.accumulate) v += Cg[addr];
                 Cg[addr] = v;
@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(BM / WM_ * WAVES_N * 64, BM / WM_ * WAVES_N * BLOCK
                 const float4 c01 = cf[0], c23 = cf[1];              // a0 b0 a1 b1 | a2 b2 a3 b3
                 float y0 = fmaf(xv[q].x, c01.x, c01.y), y1 = fmaf(xv[q].y, c01.z, c01.w);
                 float y2 = fmaf(xv[q].z, c23.x, c23.y), y3 = fmaf(xv[q].w, c23.z, c23.w);
-                if (p.gn_silu) { y0 = y0 / (1.f + expf(-y0)); y1 = y1 / (1.f + expf(-y1)); y2 = y2 / (1.f + expf(-y2)); y3 = y3 / (1.f + expf(-y3)); }
+                if (p.gn_silu) { y0 = cdae_silu(y0); y1 = cdae_silu(y1); y2 = cdae_silu(y2); y3 = cdae_silu(y3); }
                 asm volatile("" : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3));      // opaque before the split (attention.hip split8)
                 half4 hi, lo;
                 hi[0] = (_Float16)y0; hi[1] = (_Float16)y1; hi[2] = (_Float16)y2; hi[3] = (_Float16)y3;
@@ -1285,7 +1285,7 @@ __global__ __launch_bounds__(BM / WM_ * WAVES_N * 64, BM / WM_ * WAVES_N * BLOCK
                 } else addr = (long)row * p.ldc + col;
                 float v = acc[i][j][r] * p.alpha + bv;
                 if (Rg) v += Rg[addr];
-                if (p.act == ACT_SILU) v = v / (1.f + expf(-v));
+                if (p.act == ACT_SILU) v = cdae_silu(v);
                 else if (p.act == ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
                 if (p.accumulate) v += Cg[addr];
                 Cg[addr] = v;
@@ -1346,7 +1346,7 @@ __global__ void splitk_reduce_kernel(const GemmParams p) {
         } else addr = (long)row * p.ldc + col;
         float v = s * p.alpha + (p.bias ? p.bias[col] : 0.f);
         if (p.res) v += (p.res + bo * p.c_bs0 + bi * p.c_bs1)[addr];
-        if (p.act == ACT_SILU) v = v / (1.f + expf(-v));
+        if (p.act == ACT_SILU) v = cdae_silu(v);
         else if (p.act == ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
         if (p.accumulate) v += Cg[addr];
         Cg[addr] = v;

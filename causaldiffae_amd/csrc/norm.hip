@@ -13,7 +13,7 @@
 
 namespace {
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.f + expf(-v)); }
+__device__ __forceinline__ float silu_f(float v) { return cdae_silu(v); }
 
 // ------------------------------------------------------------------ GroupNorm statistics
 // grid (nchunk, N), 256 threads.  partial[((n*nchunk + chunk)*G + g)*2 + {0,1}] = (sum, sumsq) of (x - pivot_g)
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
                 float u = xh * gm[i] + bt[i];
                 float h = u * a[i] + sh[i];
                 float dh = dv[i];
-                if (do_silu) { float s = 1.f / (1.f + expf(-h)); dh *= s * (1.f + h * (1.f - s)); }
+                if (do_silu) { float s = cdae_sigmoid(h); dh *= s * (1.f + h * (1.f - s)); }
                 float du = dh * a[i];
                 float dxh = du * gm[i];
                 A += dxh; B += dxh * xh;
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const float* __restrict_
             float xh = (xv[i] - mu) * rs;
             float h = (xh * gm + beta[c + i]) * a + sh;
             float dh = dv[i];
-            if (do_silu) { float s = 1.f / (1.f + expf(-h)); dh *= s * (1.f + h * (1.f - s)); }
+            if (do_silu) { float s = cdae_sigmoid(h); dh *= s * (1.f + h * (1.f - s)); }
             float dxh = dh * a * gm;
             o[i] = rs * (dxh - m1 - xh * m2);
         }

@@ -844,6 +844,9 @@ class LazyGN:
 _SKIPGN_ON = os.environ.get("CDAE_SKIP_GN", "1") != "0"      # dev switch: 0 = separate GroupNorm apply pass and 1x1 skip GEMM
 
 
+_SKIPGN_V2 = os.environ.get("CDAE_SKIPGN_V2", "1") != "0"        # dev switch: 0 = the igemm-loader version of the sweep
+
+
 def skip_gn_ok(lz, w):
     """The ResBlock's 1x1 skip conv can carry the block's first GroupNorm along (one sweep over the block input)?"""
     from ._lib import get_precision
@@ -864,6 +867,11 @@ def skip_gn_fused(lz, w, b=None):
     check(lib.cdae_gn_coef(ptr(lz.stats[0]), ptr(lz.stats[1]), ptr(lz.gamma), ptr(lz.beta), ptr(lz.ss), lz.ld_ss, ptr(coef), N, C, lz.groups, st))
     planes = torch.empty((2, N, H, W, C), dtype=torch.float16, device=dev)
     y = torch.empty((M, Nf), dtype=torch.float32, device=dev)
+    if _SKIPGN_V2 and lib.cdae_skip_gn_ok(M, Nf, C, C1, H * W):      # the HBM-stream kernel on pre-split weight planes
+        wh, wl = split_weight(w)
+        check(lib.cdae_skip_gn_fwd(ptr(lz.x1), C1, C1, ptr(lz.x2), 0 if lz.x2 is None else C - C1, ptr(wh), ptr(wl), C, ptr(b), ptr(y), Nf, ptr(coef),
+                                   1 if lz.silu else 0, ptr(planes[0]), ptr(planes[1]), M, Nf, C, H * W, st))
+        return y.reshape(N, H, W, Nf).permute(0, 3, 1, 2), SplitAct(planes[0], planes[1], lz.shape)
     ws, wsb = _sk(dev)
     check(lib.cdae_linear_fwd_cat_gn(ptr(lz.x1), C1, C1, ptr(lz.x2), 0 if lz.x2 is None else C - C1, ptr(w), C, ptr(b), ptr(y), Nf, ptr(coef),
                                      1 if lz.silu else 0, ptr(planes[0]), ptr(planes[1]), M, Nf, C, H * W, ws, wsb, st))

@@ -157,6 +157,14 @@ int cdae_linear_fwd_cat(const float* x1, long ld1, int K1, const float* x2, long
 int cdae_linear_fwd_cat_gn(const float* x1, long ld1, int K1, const float* x2, long ld2, const float* w, long ldw, const float* bias, float* y,
                            long ldy, const float* coef, int silu, unsigned short* s_hi, unsigned short* s_lo, int M, int N, int K, int HW,
                            float* splitk_ws, size_t splitk_ws_bytes, void* stream);
+/* The same sweep as its own HBM-stream kernel (skipgn.hip), on PRE-SPLIT weight planes w_hi / w_lo [N][K] (cdae_split_f16 of the 1x1
+   weight, row pitch ldw elements): x is read once through registers, split raw into LDS for the f16x3 GEMM and normalised into the
+   planes; bit-identical planes, y equal to cdae_linear_fwd_cat_gn's up to fp32 summation order.  cdae_skip_gn_ok: 1 when the shape
+   is supported (K, K1 % 32 == 0, M % HW == 0, the (a, b) table of the images a 128-row tile touches <= 16 KB). */
+int cdae_skip_gn_ok(int M, int N, int K, int K1, int HW);
+int cdae_skip_gn_fwd(const float* x1, long ld1, int K1, const float* x2, long ld2, const unsigned short* w_hi, const unsigned short* w_lo, long ldw,
+                     const float* bias, float* y, long ldy, const float* coef, int silu, unsigned short* s_hi, unsigned short* s_lo,
+                     int M, int N, int K, int HW, void* stream);
 /* two-source forms: channels [0, C1) are read from x1 (pixel pitch ld1), channels [C1, C) from x2 (pitch ld2) — the skip
    concatenation th.cat([h, hs.pop()], dim=1) (unet.py:629) consumed in place instead of being copied; x2 == NULL: one source */
 int cdae_gn_stats2(const float* x1, int ld1, const float* x2, int ld2, int C1, int N, int HW, int C, int groups, float eps, float* mean,

@@ -823,11 +823,16 @@ def test_resblock_training_node_two_sources(N, C1, C2, Cout, H):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,C1,C2,Cout,H", [(4, 128, 128, 128, 32), (2, 256, 128, 256, 16), (3, 512, 384, 512, 8), (2, 128, 0, 256, 32)])
-def test_skip_gemm_carries_groupnorm_planes(N, C1, C2, Cout, H):
-    """cdae_linear_fwd_cat_gn: the ResBlock's 1x1 skip conv whose loader also writes GroupNorm+SiLU of the (concatenated) block input as
-    f16 planes — the planes bit-identical to cdae_gn_apply_split2's, the GEMM result equal to cdae_linear_fwd_cat's."""
+@pytest.mark.parametrize("stream_kernel", [True, False])
+@pytest.mark.parametrize("N,C1,C2,Cout,H", [(4, 128, 128, 128, 32), (2, 256, 128, 256, 16), (3, 512, 384, 512, 8), (2, 128, 0, 256, 32),
+                                            (1, 64, 64, 96, 16), (6, 256, 0, 384, 4), (3, 128, 128, 384, 8), (1, 128, 128, 128, 64)])
+def test_skip_gemm_carries_groupnorm_planes(N, C1, C2, Cout, H, stream_kernel, monkeypatch):
+    """The ResBlock entry sweep (cdae_skip_gn_fwd, and the igemm-loader version cdae_linear_fwd_cat_gn it replaced): the 1x1 skip conv
+    that also writes GroupNorm+SiLU of the (concatenated) block input as f16 planes — the planes bit-identical to
+    cdae_gn_apply_split2's, the GEMM result equal to cdae_linear_fwd_cat's and to fp64.  Shapes: partial row tiles (M = 192, 80),
+    several images per 128-row tile, a partial column tile (Cout = 96), 3 column tiles, a table too large for LDS (falls back)."""
     from causaldiffae_amd import ops
+    monkeypatch.setattr(ops, "_SKIPGN_V2", stream_kernel)
     dev = "cuda:0"
     g = torch.Generator(device=dev).manual_seed(23)
     cl = torch.channels_last
@@ -848,6 +853,9 @@ def test_skip_gemm_carries_groupnorm_planes(N, C1, C2, Cout, H):
     assert torch.equal(planes.hi, ref_planes.hi) and torch.equal(planes.lo, ref_planes.lo)
     # the GEMM itself: same products, but the separate launch may split K on these small grids (different fp32 summation order)
     assert (skip - ref_skip).abs().max().item() < 2e-5 * ref_skip.abs().max().item()
+    xx = torch.cat([a, b], dim=1) if C2 else a
+    ref64 = torch.einsum("nchw,oc->nohw", xx.double(), w.reshape(Cout, C).double()) + bias.double()[None, :, None, None]
+    assert (skip.double() - ref64).abs().max().item() < 4e-6 * ref64.abs().max().item()
 
 
 @pytest.mark.gpu
