@@ -17,6 +17,7 @@ $HIPCC $FLAGS -c wgrad.hip -o build/wgrad.o & pids+=($!)
 $HIPCC $FLAGS -c stem.hip -o build/stem.o & pids+=($!)
 $HIPCC $FLAGS -c convwin.hip -o build/convwin.o & pids+=($!)
 $HIPCC $FLAGS -c skipgn.hip -o build/skipgn.o & pids+=($!)
+$HIPCC $FLAGS -c head.hip -o build/head.o & pids+=($!)
 for pid in "${pids[@]}"; do wait "$pid" || { echo "build.sh: a compile step failed" >&2; exit 1; }; done     # a bare `wait` would hide failures
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT build/igemm.o build/api.o build/norm.o build/elementwise.o build/prof.o build/attention.o build/wgrad.o build/stem.o build/convwin.o build/skipgn.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT build/igemm.o build/api.o build/norm.o build/elementwise.o build/prof.o build/attention.o build/wgrad.o build/stem.o build/convwin.o build/skipgn.o build/head.o
 echo "built $(realpath $OUT)"

@@ -8,6 +8,7 @@
 // ResBlock scale-shift unet.py:190-194, SiLU nn.py:430-432, BatchNorm2d+LeakyReLU nn.py:46-53,
 // softmax over keys unet.py:252.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "cdae_internal.h"
 #include "../../include/cdae.h"
 
@@ -148,6 +149,44 @@ __global__ __launch_bounds__(256) void gn_parts_channel_kernel(const float* __re
     if (cl == 0 && c < C) {
         for (int k = 1; k < 8; ++k) { s += sS[k][threadIdx.x]; q += sQ[k][threadIdx.x]; }
         chan[((long)n * C + c) * 2] = s; chan[((long)n * C + c) * 2 + 1] = q;
+    }
+}
+// Both steps in one launch: a block owns gpb whole groups (gpb * cpg <= 32 channels) of one image, sums their channels exactly as
+// gn_parts_channel_kernel does (8 chunk lanes per channel, double) and then the groups exactly as gn_parts_group_kernel does — the
+// same additions in the same order, so mean / rstd are bit-identical to the two-kernel form.
+__global__ __launch_bounds__(256) void gn_parts_stats_kernel(const float* __restrict__ part1, int C1, int nseg1, const float* __restrict__ part2,
+                                                              int C2, int nseg2, int N, int HW, int cpg, int G, int gpb, float eps,
+                                                              float* __restrict__ mean, float* __restrict__ rstd) {
+    __shared__ double sS[8][32], sQ[8][32];
+    const int n = blockIdx.y, g0 = blockIdx.x * gpb, cw = gpb * cpg;
+    const int cl = threadIdx.x >> 5, ci = threadIdx.x & 31, c = g0 * cpg + ci;
+    const bool live = ci < cw && g0 + ci / cpg < G;
+    double s = 0.0, q = 0.0;
+    if (live) {
+        const bool second = c >= C1;
+        const int Cs = second ? C2 : C1, nseg = second ? nseg2 : nseg1, nch = (HW / nseg) >> 5;
+        const float2* base = reinterpret_cast<const float2*>(second ? part2 : part1) + (second ? c - C1 : c);
+        for (int sg = 0; sg < nseg; ++sg) {
+            const float2* src = base + ((long)sg * N + n) * nch * Cs;
+            for (int k = cl; k < nch; k += 8) { const float2 v = src[(long)k * Cs]; s += v.x; q += v.y; }
+        }
+    }
+    sS[cl][ci] = s; sQ[cl][ci] = q;
+    __syncthreads();
+    if (cl == 0) {
+        for (int k = 1; k < 8; ++k) { s += sS[k][ci]; q += sQ[k][ci]; }
+        sS[0][ci] = s; sQ[0][ci] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x < gpb && g0 + threadIdx.x < G) {
+        const int g = threadIdx.x;
+        double gs = 0.0, gq = 0.0;
+        for (int j = g * cpg; j < (g + 1) * cpg; ++j) { gs += sS[0][j]; gq += sQ[0][j]; }
+        const double cnt = (double)HW * cpg, m = gs / cnt;
+        double var = gq / cnt - m * m;
+        if (var < 0.0) var = 0.0;
+        mean[n * G + g0 + g] = (float)m;
+        rstd[n * G + g0 + g] = (float)(1.0 / sqrt(var + (double)eps));
     }
 }
 __global__ void gn_parts_group_kernel(const double* __restrict__ chan, int C, int HW, int cpg, int G, float eps,
@@ -815,8 +854,16 @@ int cdae_gn_stats_from_parts(const float* part1, int C1, int nseg1, const float*
         return cdae_fail("gn_stats_from_parts: HW % 32 == 0, groups <= 256 and an 8-byte aligned workspace required");
     double* chan = reinterpret_cast<double*>(ws);
     cdae_prof_begin(PROF_GN, (double)N * (HW / 32) * C * 8.0, st);
-    hipLaunchKernelGGL(gn_parts_channel_kernel, dim3((C + 31) / 32, N), dim3(256), 0, st, part1, C1, nseg1, part2, C2, part2 ? nseg2 : 1, N, HW, chan);
-    hipLaunchKernelGGL(gn_parts_group_kernel, dim3(N), dim3(groups < 64 ? 64 : groups), 0, st, chan, C, HW, C / groups, groups, eps, mean, rstd);
+    const int cpg = C / groups;
+    static const int cfg_fused = getenv("CDAE_GN_PARTS_FUSED") ? atoi(getenv("CDAE_GN_PARTS_FUSED")) : 1;
+    if (cfg_fused && cpg <= 32) {
+        const int gpb = 32 / cpg;
+        hipLaunchKernelGGL(gn_parts_stats_kernel, dim3((groups + gpb - 1) / gpb, N), dim3(256), 0, st, part1, C1, nseg1, part2, C2, part2 ? nseg2 : 1, N, HW,
+                           cpg, groups, gpb, eps, mean, rstd);
+    } else {
+        hipLaunchKernelGGL(gn_parts_channel_kernel, dim3((C + 31) / 32, N), dim3(256), 0, st, part1, C1, nseg1, part2, C2, part2 ? nseg2 : 1, N, HW, chan);
+        hipLaunchKernelGGL(gn_parts_group_kernel, dim3(N), dim3(groups < 64 ? 64 : groups), 0, st, chan, C, HW, C / groups, groups, eps, mean, rstd);
+    }
     cdae_prof_end(PROF_GN, st);
     CHECK_LAUNCH("gn_stats_from_parts launch failed");
     return 0;

@@ -27,6 +27,7 @@ struct SkipGnParams {
     const float* x1; const float* x2; long ld1, ld2; int K1;          // columns [0, K1) from x1, [K1, K) from x2 (x2 == nullptr: K1 == K)
     const unsigned short* w_hi; const unsigned short* w_lo; long ldw;
     const float* bias; float* y; long ldy;
+    const float* res; long ldres;                                      // optional residual rows added to y
     const float* coef; int silu; unsigned short* s_hi; unsigned short* s_lo;
     int M, N, K, HW, nimg_tab;                                         // HW = rows per image; nimg_tab = images the LDS table holds per block
     int* range_flag;
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
     }
     (void)nmt;
     const int m0 = mt * SG_BM, n0 = nt * SG_BN;
-    const bool writes_planes = nt == 0;
+    const bool writes_planes = nt == 0 && p.s_hi != nullptr;           // (no planes wanted: the plain streaming GEMM)
 
     // ---- this thread's slice of the x tile: rows r and r + 64, channels 8 c8 .. 8 c8 + 7 of every 32-deep step
     const int r0 = tid >> 2, c8 = tid & 3;
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
                  : "+v"(A0), "+v"(A1), "+v"(B0), "+v"(B1) : "s"(CNT) : "memory", "scc")
 
     // ---- prologue: coefficient table, the first two x steps, first weight step
-    {
+    if (p.coef) {
         const int nfl = p.nimg_tab * p.K * 2;                          // floats; K % 32 == 0 so a multiple of 4
         const float* src = p.coef + (long)img0 * p.K * 2;
         const long lim = ((long)p.M / p.HW) * p.K * 2 - (long)img0 * p.K * 2;     // floats that exist behind img0
@@ -256,9 +257,11 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 float* dst = p.y + (long)(m0 + wm * 64 + i * 32 + 4 * hh) * p.ldy + n0 + wn * 64 + j * 32 + l31;
+                const float* rsrc = p.res ? p.res + (long)(m0 + wm * 64 + i * 32 + 4 * hh) * p.ldres + n0 + wn * 64 + j * 32 + l31 : nullptr;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float v = acc[i][j][r] + bv[j];
+                    float v = acc[i][j][r] + bv[j];
+                    if (rsrc) v += rsrc[(long)((r & 3) + 8 * (r >> 2)) * p.ldres];
                     dst[(long)((r & 3) + 8 * (r >> 2)) * p.ldy] = v;
                     bad |= !__builtin_isfinite(v);
                 }
@@ -277,7 +280,8 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
                 if (row >= p.M) continue;
-                const float v = acc[i][j][r] + bv;
+                float v = acc[i][j][r] + bv;
+                if (p.res) v += p.res[(long)row * p.ldres + col];
                 p.y[(long)row * p.ldy + col] = v;
                 bad |= !__builtin_isfinite(v);
             }
@@ -290,11 +294,32 @@ bool aligned16(const void* q) { return (reinterpret_cast<size_t>(q) & 15) == 0; 
 }  // namespace
 
 // images (coefficient sets) a 128-row tile can touch
-static int skipgn_tab_images(int HW) { return HW >= SG_BM ? (HW % SG_BM == 0 ? 1 : 2) : (SG_BM + HW - 1) / HW + 1; }
+static int skipgn_tab_images(int HW) {      // (row tiles start at multiples of 128)
+    if (HW >= SG_BM) return HW % SG_BM == 0 ? 1 : 2;
+    return SG_BM % HW == 0 ? SG_BM / HW : SG_BM / HW + 2;
+}
 
 extern "C" int cdae_skip_gn_ok(int M, int N, int K, int K1, int HW) {
     if (M <= 0 || N <= 0 || K <= 0 || HW <= 0 || M % HW || K % 32 || K1 % 32 || K1 > K) return 0;
     return (size_t)skipgn_tab_images(HW) * K * 8 <= 16384;            // tiles 64 KB + table <= 80 KB: two blocks per CU
+}
+
+static int skipgn_launch(SkipGnParams& p, void* stream) {
+    p.range_flag = cdae_range_flag_ptr();
+    const size_t smem = SG_TILES + (p.coef ? (size_t)p.nimg_tab * p.K * 8 : 0);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&skipgn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SG_TILES + 16384) != hipSuccess)
+            return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
+        attr_done = true;
+    }
+    const long blocks = (long)((p.M + SG_BM - 1) / SG_BM) * ((p.N + SG_BN - 1) / SG_BN);
+    hipStream_t st = (hipStream_t)stream;
+    cdae_prof_begin(PROF_IGEMM, 2.0 * p.M * p.N * p.K, st);
+    cdae_prof_note(PROF_IGEMM, 4.0 * p.M * ((p.s_hi ? 2.0 : 1.0) * p.K + (p.res ? 2.0 : 1.0) * p.N));
+    hipLaunchKernelGGL(skipgn_kernel, dim3((unsigned)blocks), dim3(256), smem, st, p);
+    cdae_prof_end(PROF_IGEMM, st);
+    return hipGetLastError() == hipSuccess ? 0 : cdae_fail("skipgn_kernel launch failed");
 }
 
 extern "C" int cdae_skip_gn_fwd(const float* x1, long ld1, int K1, const float* x2, long ld2, const unsigned short* w_hi, const unsigned short* w_lo,
@@ -307,22 +332,24 @@ extern "C" int cdae_skip_gn_fwd(const float* x1, long ld1, int K1, const float* 
         return cdae_fail("skip_gn_fwd: 16-byte aligned rows, weight planes, coefficients and planes required");
     SkipGnParams p;
     p.x1 = x1; p.x2 = x2; p.ld1 = ld1; p.ld2 = ld2; p.K1 = K1;
-    p.w_hi = w_hi; p.w_lo = w_lo; p.ldw = ldw; p.bias = bias; p.y = y; p.ldy = ldy;
+    p.w_hi = w_hi; p.w_lo = w_lo; p.ldw = ldw; p.bias = bias; p.y = y; p.ldy = ldy; p.res = nullptr; p.ldres = 0;
     p.coef = coef; p.silu = silu; p.s_hi = s_hi; p.s_lo = s_lo;
     p.M = M; p.N = N; p.K = K; p.HW = HW; p.nimg_tab = skipgn_tab_images(HW);
-    p.range_flag = cdae_range_flag_ptr();
-    const size_t smem = SG_TILES + (size_t)p.nimg_tab * K * 8;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&skipgn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SG_TILES + 16384) != hipSuccess)
-            return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
-        attr_done = true;
-    }
-    const long blocks = (long)((M + SG_BM - 1) / SG_BM) * ((N + SG_BN - 1) / SG_BN);
-    hipStream_t st = (hipStream_t)stream;
-    cdae_prof_begin(PROF_IGEMM, 2.0 * M * N * K, st);
-    cdae_prof_note(PROF_IGEMM, 4.0 * M * (2.0 * K + N));
-    hipLaunchKernelGGL(skipgn_kernel, dim3((unsigned)blocks), dim3(256), smem, st, p);
-    cdae_prof_end(PROF_IGEMM, st);
-    return hipGetLastError() == hipSuccess ? 0 : cdae_fail("skipgn_kernel launch failed");
+    return skipgn_launch(p, stream);
+}
+
+// The same kernel as a plain streaming GEMM: y = [x1 | x2] @ W^T + bias (+ res), fp32 rows in, pre-split weight planes, f16x3 products
+extern "C" int cdae_linear_fwd_stream(const float* x1, long ld1, int K1, const float* x2, long ld2, const unsigned short* w_hi,
+                                      const unsigned short* w_lo, long ldw, const float* bias, const float* res, long ldres, float* y, long ldy,
+                                      int M, int N, int K, void* stream) {
+    if (!x2) K1 = K;
+    if (M <= 0 || N <= 0 || K <= 0 || K % 32 || K1 % 32 || K1 > K) return cdae_fail("linear_fwd_stream: K (and K1) % 32 == 0 required");
+    if (ld1 % 4 || (x2 && ld2 % 4) || ldw % 8 || !aligned16(x1) || !aligned16(x2) || !aligned16(w_hi) || !aligned16(w_lo) || !x1 || !w_hi || !w_lo || !y)
+        return cdae_fail("linear_fwd_stream: 16-byte aligned rows and weight planes required");
+    SkipGnParams p;
+    p.x1 = x1; p.x2 = x2; p.ld1 = ld1; p.ld2 = ld2; p.K1 = K1;
+    p.w_hi = w_hi; p.w_lo = w_lo; p.ldw = ldw; p.bias = bias; p.y = y; p.ldy = ldy; p.res = res; p.ldres = ldres;
+    p.coef = nullptr; p.silu = 0; p.s_hi = nullptr; p.s_lo = nullptr;
+    p.M = M; p.N = N; p.K = K; p.HW = M; p.nimg_tab = 0;
+    return skipgn_launch(p, stream);
 }

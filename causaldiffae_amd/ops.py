@@ -166,6 +166,16 @@ def conv3x3(x, w, b=None, res=None, stride=1, up=False, out_nchw=False):
 
 
 # ----------------------------------------------------------------------------- linear / conv1x1 on rows
+_STREAM_GEMM = os.environ.get("CDAE_STREAM_GEMM", "1") != "0"      # dev switch: 0 = every linear / 1x1 conv through the igemm loader
+_STREAM_GEMM_MIN_ROWS = int(os.environ.get("CDAE_STREAM_GEMM_MIN_ROWS", "4096"))
+
+
+def _stream_gemm_ok(x, M, Nf, K, act, alpha, res):
+    from ._lib import get_precision
+    return (_STREAM_GEMM and get_precision() == "f16x3" and act == ACT_NONE and alpha == 1.0 and K % 32 == 0 and M >= _STREAM_GEMM_MIN_ROWS and Nf >= 64
+            and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and (res is None or (res.stride(1) == 1 and res.stride(0) % 4 == 0)))
+
+
 class _Linear(Function):
     @staticmethod
     def forward(ctx, x, w, b, res, act, alpha):
@@ -182,6 +192,12 @@ class _Linear(Function):
         elif act in (ACT_RELU, ACT_SIGMOID):      # not in the GEMM epilogue (cold path): activate in place
             check(lib.cdae_linear_fwd(ptr(x), x.stride(0), ptr(w), K, ptr(b), ptr(res), ptr(y), Nf, None, None, M, Nf, K, alpha, ACT_NONE, ws, wsb, stream()))
             check(lib.cdae_act_fwd(ptr(y), ptr(y), M * Nf, act, stream()))
+        elif _stream_gemm_ok(x, M, Nf, K, act, alpha, res):
+            root = w._base if (w._base is not None and w._base.numel() == w.numel() and w._base.data_ptr() == w.data_ptr()) else w
+            wh, wl = split_weight(root)        # (cached on the parameter, not on the per-call [Cout, Cin] view of a 1x1 conv weight)
+            # rows stream through registers once, weights come pre-split: the HBM-stream GEMM (skipgn.hip)
+            check(lib.cdae_linear_fwd_stream(ptr(x), x.stride(0), K, None, 0, ptr(wh), ptr(wl), K, ptr(b), ptr(res), 0 if res is None else res.stride(0),
+                                             ptr(y), Nf, M, Nf, K, stream()))
         else:
             check(lib.cdae_linear_fwd(ptr(x), x.stride(0), ptr(w), K, ptr(b), ptr(res), ptr(y), Nf, None, None, M, Nf, K, alpha, act, ws, wsb, stream()))
         ctx.save_for_backward(x, w, pre)
@@ -839,6 +855,29 @@ class LazyGN:
                                        N, H * W, C, C, self.groups, ptr(self.stats[0]), ptr(self.stats[1]), ptr(self.gamma), ptr(self.beta),
                                        ptr(self.ss), self.ld_ss, 1 if self.silu else 0, stream()))
         return SplitAct(planes[0], planes[1], self.shape)
+
+
+_HEAD_ON = os.environ.get("CDAE_HEAD_CONV", "1") != "0"      # dev switch: 0 = the output head through GroupNorm planes + the plane GEMM
+
+
+def head_conv_ok(lz, w):
+    """The UNet output head (GroupNorm -> SiLU -> conv3x3 to a few channels) on the exact-fp32 vector-ALU kernel?"""
+    N, C, H, W = lz.shape
+    return (_HEAD_ON and lz.x2 is None and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3) and w.shape[1] == C and w.permute(0, 2, 3, 1).is_contiguous()
+            and lz.x1.permute(0, 2, 3, 1).is_contiguous() and lib.cdae_head_conv_supported(C, w.shape[0], W) == 1)
+
+
+def head_conv(lz, w, b=None):
+    """y[N, Cout, H, W] (NCHW) = conv3x3(silu?(GroupNorm(x))) + b in one kernel, exact fp32 (no autograd)."""
+    N, C, H, W = lz.shape
+    dev = lz.x1.device
+    st = stream()
+    coef = torch.empty((N, C, 2), dtype=torch.float32, device=dev)
+    check(lib.cdae_gn_coef(ptr(lz.stats[0]), ptr(lz.stats[1]), ptr(lz.gamma), ptr(lz.beta), ptr(lz.ss), lz.ld_ss, ptr(coef), N, C, lz.groups, st))
+    y = torch.empty((N, w.shape[0], H, W), dtype=torch.float32, device=dev)
+    check(lib.cdae_head_conv_fwd(ptr(lz.x1), C, ptr(coef), 1 if lz.silu else 0, ptr(w), ptr(b), ptr(y),
+                                 N, H, W, C, w.shape[0], st))
+    return y
 
 
 _SKIPGN_ON = os.environ.get("CDAE_SKIP_GN", "1") != "0"      # dev switch: 0 = separate GroupNorm apply pass and 1x1 skip GEMM

@@ -162,6 +162,10 @@ int cdae_linear_fwd_cat_gn(const float* x1, long ld1, int K1, const float* x2, l
    planes; bit-identical planes, y equal to cdae_linear_fwd_cat_gn's up to fp32 summation order.  cdae_skip_gn_ok: 1 when the shape
    is supported (K, K1 % 32 == 0, M % HW == 0, the (a, b) table of the images a 128-row tile touches <= 16 KB). */
 int cdae_skip_gn_ok(int M, int N, int K, int K1, int HW);
+/* the same kernel without the GroupNorm side output: y = [x1 | x2] @ W^T + bias (+ res, row pitch ldres) for large row counts — the
+   attention proj_out with its residual (unet.py:231) and the other 1x1 convs / linears on fp32 rows (f16x3 products, K % 32 == 0) */
+int cdae_linear_fwd_stream(const float* x1, long ld1, int K1, const float* x2, long ld2, const unsigned short* w_hi, const unsigned short* w_lo,
+                           long ldw, const float* bias, const float* res, long ldres, float* y, long ldy, int M, int N, int K, void* stream);
 int cdae_skip_gn_fwd(const float* x1, long ld1, int K1, const float* x2, long ld2, const unsigned short* w_hi, const unsigned short* w_lo, long ldw,
                      const float* bias, float* y, long ldy, const float* coef, int silu, unsigned short* s_hi, unsigned short* s_lo,
                      int M, int N, int K, int HW, void* stream);
@@ -226,6 +230,12 @@ int cdae_conv3x3_dgrad_ps(const unsigned short* dy_hi, const unsigned short* dy_
 int cdae_conv3x3_stem_supported(int Cin, int Cout, int W);
 int cdae_conv3x3_stem(const float* x, long sn, long sy, long sx, long sc, const float* w, const float* bias, float* out, long ldo,
                       int N, int H, int W, int Cin, int Cout, void* stream);
+/* the UNet's output head (unet.py:495-499 self.out: GroupNorm32 -> SiLU -> conv3x3 to out_channels) as one kernel in exact fp32 on the
+   vector ALUs: y[N][Cout][H][W] = bias + conv3x3(silu?(x * a + b)), x NHWC rows (pixel pitch ldx), coef [N][Cin][2] from cdae_gn_coef,
+   w OHWI [Cout][3][3][Cin].  Cin % 32 == 0, W <= 64, Cout in {1, 2, 3, 4, 6, 8}; no-grad path only. */
+int cdae_head_conv_supported(int Cin, int Cout, int W);
+int cdae_head_conv_fwd(const float* x, long ldx, const float* coef, int silu, const float* w, const float* bias, float* y,
+                       int N, int H, int W, int Cin, int Cout, void* stream);
 int cdae_conv3x3_wgrad_fewout(const float* x, const float* dy, long lddy, float* dw, float* dbias, int N, int H, int W, int Cin, int Cout,
                               int accumulate, float* ws, size_t ws_bytes, void* stream);
 int cdae_conv3x3_wgrad_win_supported(int N, int H, int W, int Cin, int Cout);

@@ -20,6 +20,11 @@ def err(a, b):
     return (a.detach().cpu().double() - b.detach().cpu().double()).abs().max().item()
 
 
+def precision_scope_f16x3():
+    from causaldiffae_amd._lib import precision_scope
+    return precision_scope("f16x3")
+
+
 def chlast_param(w):
     return w.contiguous(memory_format=torch.channels_last).to(DEV)
 
@@ -35,6 +40,30 @@ def test_linear(M, N, K, act, precision):
     ref = F.linear(x.double(), w.double(), b.double()) + r.double()
     ref = [ref, ref * torch.sigmoid(ref), F.leaky_relu(ref, 0.01)][act]
     assert err(y, ref) < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K,bias,res", [(4096, 384, 384, True, True), (4100, 200, 96, True, False), (8192, 512, 512, False, True),
+                                            (32768, 128, 1024, False, False), (5000, 64, 32, True, True)])
+def test_linear_stream_kernel(M, N, K, bias, res):
+    """cdae_linear_fwd_stream (large-M linears / 1x1 convs in f16x3 mode: fp32 rows streamed once, pre-split weight planes) vs fp64 and
+    vs the igemm-loader kernel it replaces; partial row and column tiles, with and without bias / residual; a 1x1 conv weight view."""
+    from causaldiffae_amd import ops
+    x, w = rnd(M, K).to(DEV), (rnd(N, K, seed=1) / K ** 0.5).to(DEV)
+    b = rnd(N, seed=2).to(DEV) if bias else None
+    r = rnd(M, N, seed=3).to(DEV) if res else None
+    with precision_scope_f16x3():
+        assert ops._stream_gemm_ok(x, M, N, K, 0, 1.0, r)
+        y = ops.linear(x, w, b, res=r)
+        y4 = ops.linear(x, w.reshape(N, K, 1, 1), b, res=r)              # the [Cout, Cin, 1, 1] form of a 1x1 conv weight
+        saved, ops._STREAM_GEMM = ops._STREAM_GEMM, False
+        try:
+            old = ops.linear(x, w, b, res=r)
+        finally:
+            ops._STREAM_GEMM = saved
+    ref = F.linear(x.double(), w.double(), None if b is None else b.double()) + (0 if r is None else r.double())
+    assert torch.equal(y, y4)
+    assert err(y, ref) < 4e-6 * ref.abs().max().item()
+    assert err(y, old) < 4e-6 * ref.abs().max().item()
 
 
 def test_linear_backward():
@@ -856,6 +885,33 @@ def test_skip_gemm_carries_groupnorm_planes(N, C1, C2, Cout, H, stream_kernel, m
     xx = torch.cat([a, b], dim=1) if C2 else a
     ref64 = torch.einsum("nchw,oc->nohw", xx.double(), w.reshape(Cout, C).double()) + bias.double()[None, :, None, None]
     assert (skip.double() - ref64).abs().max().item() < 4e-6 * ref64.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C,Cout,H,W,silu", [(3, 128, 4, 64, 64, True), (2, 128, 3, 64, 64, True), (5, 128, 1, 32, 32, True), (2, 128, 8, 28, 28, True),
+                                               (2, 128, 6, 9, 7, False), (1, 128, 2, 8, 12, True)])
+def test_output_head_kernel_matches_fp64(N, C, Cout, H, W, silu):
+    """cdae_head_conv_fwd (GroupNorm -> SiLU -> conv3x3 to a few channels in one exact-fp32 kernel, the UNet's self.out) against
+    group_norm + conv2d in fp64: every supported channel count, image sizes that do not fill the 256-pixel tile, odd widths."""
+    import torch.nn.functional as F
+    from causaldiffae_amd import ops
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(41)
+    x = ops.to_nhwc(torch.randn(N, C, H, W, device=dev, generator=g) * 1.7 + 0.3)
+    gamma, beta = 1 + 0.2 * torch.randn(C, device=dev, generator=g), 0.2 * torch.randn(C, device=dev, generator=g)
+    w = (torch.randn(Cout, C, 3, 3, device=dev, generator=g) / (3 * C ** 0.5)).contiguous(memory_format=torch.channels_last)
+    b = 0.1 * torch.randn(Cout, device=dev, generator=g)
+    with torch.no_grad():
+        lz = ops.group_norm_lazy(x, gamma, beta, None, silu, 32, 1e-5)
+        assert ops.head_conv_ok(lz, w)
+        got = ops.head_conv(lz, w, b)
+        planes = ops.conv3x3_ps(lz.planes(), w, b, out_nchw=True)           # the path it replaces
+    h = F.group_norm(x.double(), 32, gamma.double(), beta.double(), 1e-5)
+    ref = F.conv2d(F.silu(h) if silu else h, w.double(), b.double(), padding=1)
+    assert got.shape == ref.shape and got.is_contiguous()
+    scale = ref.abs().max().item()
+    assert (got.double() - ref).abs().max().item() < 2e-6 * scale
+    assert (planes.double() - ref).abs().max().item() < 1e-5 * scale
 
 
 @pytest.mark.gpu
