@@ -57,7 +57,7 @@ SIGNATURES = {
     "cdae_head_conv_supported": [I, I, I],
     "cdae_head_conv_fwd": [P, L, P, I, P, P, P, I, I, I, I, I, P],
     "cdae_skip_gn_ok": [I, I, I, I, I],
-    "cdae_linear_fwd_stream": [P, L, I, P, L, P, P, L, P, P, L, P, L, I, I, I, P],
+    "cdae_linear_fwd_stream": [P, L, I, P, L, P, P, L, P, P, L, P, L, P, P, I, I, I, P],
     "cdae_skip_gn_fwd": [P, L, I, P, L, P, P, L, P, P, L, P, I, P, P, I, I, I, I, P],
     "cdae_gn_apply_split2": [P, I, P, I, I, P, P, I, I, I, I, I, P, P, P, P, P, I, I, P],
     "cdae_linear_dgrad": [P, L, P, L, P, L, I, I, I, I, P, SZ, P],

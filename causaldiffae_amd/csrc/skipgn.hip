@@ -28,6 +28,7 @@ struct SkipGnParams {
     const unsigned short* w_hi; const unsigned short* w_lo; long ldw;
     const float* bias; float* y; long ldy;
     const float* res; long ldres;                                      // optional residual rows added to y
+    unsigned short* c_hi; unsigned short* c_lo;                        // optional: y also as f16 hi / lo planes (row pitch ldy), the next conv's operand
     const float* coef; int silu; unsigned short* s_hi; unsigned short* s_lo;
     int M, N, K, HW, nimg_tab;                                         // HW = rows per image; nimg_tab = images the LDS table holds per block
     int* range_flag;
@@ -47,6 +48,14 @@ __device__ __forceinline__ void split8(const f32x4& u, const f32x4& v, u16x8& hi
 #pragma unroll
     for (int i = 0; i < 8; ++i) { h[i] = (_Float16)f[i]; l[i] = (_Float16)(f[i] - (float)h[i]); }
     hi = __builtin_bit_cast(u16x8, h); lo = __builtin_bit_cast(u16x8, l);
+}
+
+__device__ __forceinline__ void store_planes_sg(const SkipGnParams& p, long addr, float v) {      // as igemm.hip store_planes
+    asm volatile("" : "+v"(v));
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    p.c_hi[addr] = __builtin_bit_cast(unsigned short, h);
+    p.c_lo[addr] = __builtin_bit_cast(unsigned short, l);
 }
 
 __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
@@ -263,6 +272,7 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
                     float v = acc[i][j][r] + bv[j];
                     if (rsrc) v += rsrc[(long)((r & 3) + 8 * (r >> 2)) * p.ldres];
                     dst[(long)((r & 3) + 8 * (r >> 2)) * p.ldy] = v;
+                    if (p.c_hi) store_planes_sg(p, (dst - p.y) + (long)((r & 3) + 8 * (r >> 2)) * p.ldy, v);
                     bad |= !__builtin_isfinite(v);
                 }
             }
@@ -283,6 +293,7 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
                 float v = acc[i][j][r] + bv;
                 if (p.res) v += p.res[(long)row * p.ldres + col];
                 p.y[(long)row * p.ldy + col] = v;
+                if (p.c_hi) store_planes_sg(p, (long)row * p.ldy + col, v);
                 bad |= !__builtin_isfinite(v);
             }
         }
@@ -332,7 +343,7 @@ extern "C" int cdae_skip_gn_fwd(const float* x1, long ld1, int K1, const float* 
         return cdae_fail("skip_gn_fwd: 16-byte aligned rows, weight planes, coefficients and planes required");
     SkipGnParams p;
     p.x1 = x1; p.x2 = x2; p.ld1 = ld1; p.ld2 = ld2; p.K1 = K1;
-    p.w_hi = w_hi; p.w_lo = w_lo; p.ldw = ldw; p.bias = bias; p.y = y; p.ldy = ldy; p.res = nullptr; p.ldres = 0;
+    p.w_hi = w_hi; p.w_lo = w_lo; p.ldw = ldw; p.bias = bias; p.y = y; p.ldy = ldy; p.res = nullptr; p.ldres = 0; p.c_hi = nullptr; p.c_lo = nullptr;
     p.coef = coef; p.silu = silu; p.s_hi = s_hi; p.s_lo = s_lo;
     p.M = M; p.N = N; p.K = K; p.HW = HW; p.nimg_tab = skipgn_tab_images(HW);
     return skipgn_launch(p, stream);
@@ -341,14 +352,14 @@ extern "C" int cdae_skip_gn_fwd(const float* x1, long ld1, int K1, const float* 
 // The same kernel as a plain streaming GEMM: y = [x1 | x2] @ W^T + bias (+ res), fp32 rows in, pre-split weight planes, f16x3 products
 extern "C" int cdae_linear_fwd_stream(const float* x1, long ld1, int K1, const float* x2, long ld2, const unsigned short* w_hi,
                                       const unsigned short* w_lo, long ldw, const float* bias, const float* res, long ldres, float* y, long ldy,
-                                      int M, int N, int K, void* stream) {
+                                      unsigned short* c_hi, unsigned short* c_lo, int M, int N, int K, void* stream) {
     if (!x2) K1 = K;
     if (M <= 0 || N <= 0 || K <= 0 || K % 32 || K1 % 32 || K1 > K) return cdae_fail("linear_fwd_stream: K (and K1) % 32 == 0 required");
     if (ld1 % 4 || (x2 && ld2 % 4) || ldw % 8 || !aligned16(x1) || !aligned16(x2) || !aligned16(w_hi) || !aligned16(w_lo) || !x1 || !w_hi || !w_lo || !y)
         return cdae_fail("linear_fwd_stream: 16-byte aligned rows and weight planes required");
     SkipGnParams p;
     p.x1 = x1; p.x2 = x2; p.ld1 = ld1; p.ld2 = ld2; p.K1 = K1;
-    p.w_hi = w_hi; p.w_lo = w_lo; p.ldw = ldw; p.bias = bias; p.y = y; p.ldy = ldy; p.res = res; p.ldres = ldres;
+    p.w_hi = w_hi; p.w_lo = w_lo; p.ldw = ldw; p.bias = bias; p.y = y; p.ldy = ldy; p.res = res; p.ldres = ldres; p.c_hi = c_hi; p.c_lo = c_lo;
     p.coef = nullptr; p.silu = 0; p.s_hi = nullptr; p.s_lo = nullptr;
     p.M = M; p.N = N; p.K = K; p.HW = M; p.nimg_tab = 0;
     return skipgn_launch(p, stream);

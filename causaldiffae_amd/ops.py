@@ -197,7 +197,7 @@ class _Linear(Function):
             wh, wl = split_weight(root)        # (cached on the parameter, not on the per-call [Cout, Cin] view of a 1x1 conv weight)
             # rows stream through registers once, weights come pre-split: the HBM-stream GEMM (skipgn.hip)
             check(lib.cdae_linear_fwd_stream(ptr(x), x.stride(0), K, None, 0, ptr(wh), ptr(wl), K, ptr(b), ptr(res), 0 if res is None else res.stride(0),
-                                             ptr(y), Nf, M, Nf, K, stream()))
+                                             ptr(y), Nf, None, None, M, Nf, K, stream()))
         else:
             check(lib.cdae_linear_fwd(ptr(x), x.stride(0), ptr(w), K, ptr(b), ptr(res), ptr(y), Nf, None, None, M, Nf, K, alpha, act, ws, wsb, stream()))
         ctx.save_for_backward(x, w, pre)
@@ -1565,6 +1565,11 @@ def linear_emit(rows, w, b, res, shape):
     assert rows.stride(1) == 1 and w.numel() == Nf * K and w.is_contiguous() and Nf == C
     y = torch.empty((M, Nf), dtype=torch.float32, device=rows.device)
     planes = torch.empty((2, N, H, W, C), dtype=torch.float16, device=rows.device)
+    if _stream_gemm_ok(rows, M, Nf, K, ACT_NONE, 1.0, res):
+        wh, wl = split_weight(w)
+        check(lib.cdae_linear_fwd_stream(ptr(rows), rows.stride(0), K, None, 0, ptr(wh), ptr(wl), K, ptr(b), ptr(res), 0 if res is None else res.stride(0),
+                                         ptr(y), Nf, ptr(planes[0]), ptr(planes[1]), M, Nf, K, stream()))
+        return y, SplitAct(planes[0], planes[1], shape)
     ws, wsb = _sk(rows.device)
     check(lib.cdae_linear_fwd(ptr(rows), rows.stride(0), ptr(w), K, ptr(b), ptr(res), ptr(y), Nf, ptr(planes[0]), ptr(planes[1]),
                               M, Nf, K, 1.0, ACT_NONE, ws, wsb, stream()))

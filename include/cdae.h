@@ -165,7 +165,8 @@ int cdae_skip_gn_ok(int M, int N, int K, int K1, int HW);
 /* the same kernel without the GroupNorm side output: y = [x1 | x2] @ W^T + bias (+ res, row pitch ldres) for large row counts — the
    attention proj_out with its residual (unet.py:231) and the other 1x1 convs / linears on fp32 rows (f16x3 products, K % 32 == 0) */
 int cdae_linear_fwd_stream(const float* x1, long ld1, int K1, const float* x2, long ld2, const unsigned short* w_hi, const unsigned short* w_lo,
-                           long ldw, const float* bias, const float* res, long ldres, float* y, long ldy, int M, int N, int K, void* stream);
+                           long ldw, const float* bias, const float* res, long ldres, float* y, long ldy, unsigned short* c_hi, unsigned short* c_lo,
+                           int M, int N, int K, void* stream);      /* c_hi / c_lo (may be NULL): y also as f16 planes, row pitch ldy */
 int cdae_skip_gn_fwd(const float* x1, long ld1, int K1, const float* x2, long ld2, const unsigned short* w_hi, const unsigned short* w_lo, long ldw,
                      const float* bias, float* y, long ldy, const float* coef, int silu, unsigned short* s_hi, unsigned short* s_lo,
                      int M, int N, int K, int HW, void* stream);

@@ -64,6 +64,12 @@ def test_linear_stream_kernel(M, N, K, bias, res):
     assert torch.equal(y, y4)
     assert err(y, ref) < 4e-6 * ref.abs().max().item()
     assert err(y, old) < 4e-6 * ref.abs().max().item()
+    if M % 64 == 0 and N % 4 == 0:          # the same GEMM with its result also leaving as f16 planes (attention proj_out ahead of a resample conv)
+        with precision_scope_f16x3(), torch.no_grad():
+            y2, planes = ops.linear_emit(x, w, b, r, (M // 64, N, 8, 8))
+        assert torch.equal(y2, y)
+        hi = y.half()
+        assert torch.equal(planes.hi.reshape(-1, N), hi) and torch.equal(planes.lo.reshape(-1, N), (y - hi.float()).half())
 
 
 def test_linear_backward():
