@@ -28,6 +28,10 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef CW_DEV
+#define CW_DEV 0
+#endif
+
 namespace {
 
 __device__ __forceinline__ int fdiv_cw(int n, unsigned magic, int shift) {             // exact floor(n / d), see igemm.hip fdiv
@@ -197,7 +201,10 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
     int tile = blockIdx.x;
     if (tile >= ntiles) return;
     // dev (CDAE_PS_DBG & 32): s_memtime around the waits, summed per wave, written to the split-K workspace by lane 0 of the first 64 blocks
-    const bool stamps = (p.dbg & 32) != 0;
+    // dev ablations / stamps (CDAE_PS_DBG bits) exist only in a -DCW_DEV=1 build: as run-time tests they cost the K loop 15 scalar branches
+    // per step (and, with the de-phasing state, one around every MFMA triple: 4-5 % of the kernel)
+    const int dbg_ = CW_DEV ? p.dbg : 0;
+    const bool stamps = (dbg_ & 32) != 0;
     unsigned long long t_top = 0, t_vm = 0, t_bar = 0, t_epi = 0;
     auto now = [&]() -> unsigned long long { return stamps ? (unsigned long long)__builtin_readcyclecounter() : 0ull; };
     const unsigned long long t_begin = now();
@@ -206,9 +213,10 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
     // therefore starts with only the LOWER 64 rows of each wave's 128 (row tiles 0..3) of its first tile and finishes with the UPPER
     // 64: the same work, but its tile boundaries sit half a tile away from the first half's, so one block of a CU computes while
     // the other one stores.  part: 0 = all eight row tiles, 1 = tiles 0..3, 2 = tiles 4..7.
-    const int first_tile = tile;
-    bool high_pending = dephase_arg && blockIdx.x >= (gridDim.x >> 1) && first_tile + (int)gridDim.x < ntiles;
-    int part = high_pending ? 1 : 0;
+    // (de-phasing the two blocks of a CU by half a tile was built and measured slower — DESIGN.md "tried and dropped"; the run-time `part`
+    // it needed put a branch around every MFMA triple of the K loop, so it is compiled out: part is the constant 0)
+    constexpr int part = 0;
+    (void)dephase_arg;
     setup(tile);
     issue_prologue();
     while (true) {
@@ -256,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
             const unsigned b_n = b_lane + ((s + 1) & 1) * CW_B_STAGE;
             // the two waves of a SIMD belong to different blocks: alternating the issue priority by step parity lets one of them run
             // its MFMA burst unbroken while the other is at its mid-step wait (measured +2..3 %; CDAE_PS_DBG & 64 turns it off)
-            if (!(p.dbg & 64)) { if (s & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+            if (!(dbg_ & 64)) { if (s & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
             // outstanding LDS reads here, oldest first: A(0) [2], B(0) [2], B(1) [2], B(2) [2], B(3) [2]
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -268,17 +276,17 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                     if (reload_prev) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CW_WIN_DMAS) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     const unsigned long long t2_ = now();
-                    if (!(p.dbg & 8)) __builtin_amdgcn_s_barrier();
+                    if (!(dbg_ & 8)) __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
                     if (stamps) { const unsigned long long t3_ = now(); t_vm += t2_ - t1_; t_bar += t3_ - t2_; }
                     // NT = 4: a group lasts two steps only, so a reloaded half is read (look-ahead of the step after next) one step after
                     // it was requested: the window goes out BEFORE the weights and the next mid-step wait drains everything
                     bool reload = false;
                     if (ga > g_old) {              // every unit of g_old lies in finished steps: its half is free
-                        reload = g_old + 2 < g_end && !(p.dbg & 20);
+                        reload = g_old + 2 < g_end && !(dbg_ & 20);
                         if (NT == 4 && reload) issue_window(g_old + 2);
                     }
-                    if (s + 2 < nsteps && !(p.dbg & 4)) issue_weights(s & 1, gi, ti);
+                    if (s + 2 < nsteps && !(dbg_ & 4)) issue_weights(s & 1, gi, ti);
                     ti += 2;
                     if (ti >= NT) { ti -= NT; ++gi; }
                     reload_prev = false;
@@ -333,11 +341,10 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
 
         __builtin_amdgcn_s_setprio(0);
         // ---- tile done: stage the next tile's operands, then write this tile's result (the stores drain behind the next K loop)
-        const int em0 = m0, en0 = n0, eks = ks, epart = part;
-        int next = tile + gridDim.x;
-        bool has_next = part != 2 && next < ntiles;
-        part = 0;
-        if (!has_next && epart != 2 && high_pending) { next = first_tile; part = 2; has_next = true; high_pending = false; }
+        const int em0 = m0, en0 = n0, eks = ks;
+        constexpr int epart = part;
+        const int next = tile + gridDim.x;
+        const bool has_next = next < ntiles;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the look-ahead reads of the step that does not exist
         __builtin_amdgcn_s_barrier();                                    // every wave is done reading the window and the weight stages
         asm volatile("" ::: "memory");
@@ -347,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
         // accumulator tile (i, j): this lane holds rows 4 kg + r (r = 0..3) of column 16 j + lr; the four column tiles of a row are
         // stored back to back so that the 256 bytes a wave owns of each output row reach L2 together
         const bool interior = em0 + CW_BM <= p.M && en0 + CW_BN <= p.N;
-        if (p.dbg & 256) {}                                                // dev ablation: no epilogue
+        if (dbg_ & 256) {}                                                // dev ablation: no epilogue
         else if (interior && p.ksplit == 1 && !p.accumulate && !p.C_hi) {
             // the common case, kept lean (the general path below spends ~20 instructions per element on bounds and mode tests):
             // one row pointer per (tile, r), the four column tiles at immediate offsets

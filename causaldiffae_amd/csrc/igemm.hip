@@ -37,6 +37,13 @@ typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 
+// dev ablations / stamps of the plane kernels (CDAE_PS_DBG bits) exist only in a -DCW_DEV=1 build (EXTRA_HIPCC_FLAGS=-DCW_DEV=1 build.sh):
+// as run-time tests they sat in every K step of the production kernels
+#ifndef CW_DEV
+#define CW_DEV 0
+#endif
+#define PDBG(P) (CW_DEV ? (P).dbg : 0)
+
 namespace {
 
 constexpr int BK = 32;
@@ -758,7 +765,7 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + LOADERS)) void ps_kernel(
             const bool ok = tap_offset(p, r, ky, kx, o);
             if (ok && r.ok) off = (int)o;
         }
-        if ((p.dbg & 1) && off >= 0) off = (row & 15) * 64;
+        if ((PDBG(p) & 1) && off >= 0) off = (row & 15) * 64;
         taptab[idx] = off;
     }
 
@@ -799,7 +806,7 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + LOADERS)) void ps_kernel(
             char* const dst = sb + (q * LT + lwave * 64) * 16;
             dma(b_hi + (bok[q] ? boff[q] : zb_hi), dst);
             if constexpr (NPL == 2) dma(b_lo + (bok[q] ? boff[q] : zb_lo), dst + B_PLANE);
-            boff[q] += (p.dbg & 2) ? 0 : BK;
+            boff[q] += (PDBG(p) & 2) ? 0 : BK;
         }
     };
 
@@ -816,8 +823,8 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + LOADERS)) void ps_kernel(
 
     __syncthreads();                                                   // tap table visible
     constexpr int G = NPL * (A_P + B_P);                               // DMAs per wave per step
-    const bool nodma = (p.dbg & 4) != 0;
-    auto issue_next = [&](int stage) { issue(stage, (p.dbg & 1) ? 0 : tap, (p.dbg & 1) ? 0 : chunk * BK); advance(); };
+    const bool nodma = (PDBG(p) & 4) != 0;
+    auto issue_next = [&](int stage) { issue(stage, (PDBG(p) & 1) ? 0 : tap, (PDBG(p) & 1) ? 0 : chunk * BK); advance(); };
     if (loads_here && kt_begin < kt_end) issue_next(0);
     if constexpr (STAGES == 3) { if (kt_begin + 1 < kt_end) issue_next(1); }
 
@@ -833,14 +840,14 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + LOADERS)) void ps_kernel(
             // wave is done reading stage kt-1 == (kt+2) % 3, which the next DMAs overwrite.  No vmcnt(0) in the loop.
             if (kt + 1 < kt_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (!(p.dbg & 8)) __builtin_amdgcn_s_barrier();
+            if (!(PDBG(p) & 8)) __builtin_amdgcn_s_barrier();
             if (kt + 2 < kt_end && !nodma) issue_next(cur == 0 ? 2 : cur - 1);
         }
 
         const char* ac = lds + cur * STAGE;
         const char* bc = ac + NPL * A_PLANE;
         auto frag = [&](const char* plane, int row0, int sk) -> u16x8 {
-            const int row = (p.dbg & 16) ? 0 : row0 + l31;             // dbg 16: every lane reads the same 16 bytes (LDS broadcast, no bandwidth)
+            const int row = (PDBG(p) & 16) ? 0 : row0 + l31;             // dbg 16: every lane reads the same 16 bytes (LDS broadcast, no bandwidth)
             return *reinterpret_cast<const u16x8*>(plane + row * 64 + 16 * ((2 * sk + hh) ^ ((row >> 2) & 3)));
         };
         auto mma = [&](const u16x8& x, const u16x8& y, const f32x16& c) -> f32x16 {
@@ -1148,7 +1155,7 @@ __global__ __launch_bounds__(BM / WM_ * WAVES_N * 64, BM / WM_ * WAVES_N * BLOCK
     // diagnostic build only (CDAE_PS_DBG & 32): s_memtime stamps around the three segments of a step, summed per wave and
     // written to the split-K workspace by lane 0 of every wave of the first 64 blocks.  The stamps' lgkmcnt(0) serialises what the
     // real kernel overlaps: read the SHARES, never the run time of this mode.
-    const bool stamps = (p.dbg & 32) != 0;
+    const bool stamps = (PDBG(p) & 32) != 0;
     unsigned long long t_wait = 0, t_issue = 0, t_comp = 0, t_prev = 0;
     auto stamp = [&]() -> unsigned long long {
         unsigned long long t;
@@ -1183,7 +1190,7 @@ __global__ __launch_bounds__(BM / WM_ * WAVES_N * 64, BM / WM_ * WAVES_N * BLOCK
                 if (tap == 0 || last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPL * B_RB) : "memory");
                 __builtin_amdgcn_s_barrier();
-                if (!(p.dbg & 64)) {
+                if (!(PDBG(p) & 64)) {
                     const int t2 = tap + 2, ntap = t2 >= ntaps ? t2 - ntaps : t2, nchk = t2 >= ntaps ? chunk + 1 : chunk;
                     if (nchk < c_end) issue_B(stage >= 1 ? stage - 1 : 2, nchk, ntap);            // (stage + 2) % 3
                 }
@@ -1222,7 +1229,7 @@ __global__ __launch_bounds__(BM / WM_ * WAVES_N * 64, BM / WM_ * WAVES_N * BLOCK
                     bh[j] = *reinterpret_cast<const u16x8*>(bc + b);
                     if constexpr (NPL == 2) bl[j] = *reinterpret_cast<const u16x8*>(bc + B_PLANE + b);
                 }
-                if (!(p.dbg & 128)) __builtin_amdgcn_s_setprio(1);     // MFMA bursts win issue arbitration over other waves' staging work (+1-2 %)
+                if (!(PDBG(p) & 128)) __builtin_amdgcn_s_setprio(1);     // MFMA bursts win issue arbitration over other waves' staging work (+1-2 %)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1233,10 +1240,10 @@ __global__ __launch_bounds__(BM / WM_ * WAVES_N * 64, BM / WM_ * WAVES_N * BLOCK
                         }
                         acc[i][j] = mma(ah[i], bh[j], acc[i][j]);
                     }
-                if (!(p.dbg & 128)) __builtin_amdgcn_s_setprio(0);
+                if (!(PDBG(p) & 128)) __builtin_amdgcn_s_setprio(0);
             }
             if constexpr (BST == 3) {
-                if (p.dbg & 64) {     // late issue: the step's own MFMAs are queued before this wave joins the block's DMA burst
+                if (PDBG(p) & 64) {     // late issue: the step's own MFMAs are queued before this wave joins the block's DMA burst
                     const int t2 = tap + 2, ntap = t2 >= ntaps ? t2 - ntaps : t2, nchk = t2 >= ntaps ? chunk + 1 : chunk;
                     if (nchk < c_end) issue_B(stage >= 1 ? stage - 1 : 2, nchk, ntap);
                 }
