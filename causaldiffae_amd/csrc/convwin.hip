@@ -31,6 +31,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef CW_DEV
 #define CW_DEV 0
 #endif
+#ifndef CW_READ_EARLY
+#define CW_READ_EARLY 0      // 1: next-tile fragment reads in front of the tile's MFMAs (12 instead of 9 MFMAs to land): measured +-0 (same-box A/B)
+#endif
 
 namespace {
 
@@ -300,12 +303,28 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                 if (i == 0) CW_WAIT("s_waitcnt lgkmcnt(6)" : "+v"(ah[0]), "+v"(al[0]), "+v"(bh[0]), "+v"(bl[0]));
                 else CW_WAIT("s_waitcnt lgkmcnt(0)" : "+v"(ah[cur]), "+v"(al[cur]));
                 const bool en = part == 0 || ((i < 4) == (part == 1));        // wave-uniform: a half item skips the other half's MFMAs
+#if CW_READ_EARLY
+                // the next tile's fragment reads go out in front of this tile's MFMAs (its buffer was last read by tile i - 1, whose
+                // MFMAs are all issued) and have twelve MFMAs to land
+                __builtin_amdgcn_sched_barrier(0);
+                if (i == 0) { CW_READ_A(1, 1, wtap_c, a_c); }
+                else if (i == 1) { CW_READ_A(2, 0, wtap_c, a_c); }
+                else if (i == 2) { CW_READ_A(3, 1, wtap_c, a_c); }
+                else if (i == 3) { CW_READ_A(4, 0, wtap_c, a_c); }
+                else if (i == 4) { CW_READ_A(5, 1, wtap_c, a_c); }
+                else if (i == 5) { CW_READ_A(6, 0, wtap_c, a_c); }
+                else if (i == 6) { CW_READ_A(7, 1, wtap_c, a_c); }
+                __builtin_amdgcn_sched_barrier(0);
+#endif
                 if (en) {
                     acc[i][0] = mma(al[cur], bh[0], acc[i][0]);
                     acc[i][0] = mma(ah[cur], bl[0], acc[i][0]);
                     acc[i][0] = mma(ah[cur], bh[0], acc[i][0]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#if CW_READ_EARLY
+                if (i == 7) { CW_READ_A(0, 0, wtap_n, a_n); CW_READ_B(0, b_n); }      // next step: its first tile and the first dead weight fragments
+#else
                 // the next tile's fragment reads go out behind the first three MFMAs and have nine MFMAs to land
                 if (i == 0) { CW_READ_A(1, 1, wtap_c, a_c); }
                 else if (i == 1) { CW_READ_A(2, 0, wtap_c, a_c); }
@@ -315,6 +334,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                 else if (i == 5) { CW_READ_A(6, 0, wtap_c, a_c); }
                 else if (i == 6) { CW_READ_A(7, 1, wtap_c, a_c); }
                 else { CW_READ_A(0, 0, wtap_n, a_n); CW_READ_B(0, b_n); }      // next step: its first tile and the first dead weight fragments
+#endif
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 1; j < 4; ++j) {
