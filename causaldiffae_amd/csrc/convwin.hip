@@ -392,23 +392,38 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                 float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ii = 0; ii < 2; ++ii) {
+                    long ro[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        long ro;
                         if (up2) {
                             const int row = row0 + 32 * i2 + 16 * ii + r, x = row & (p.Wo - 1);             // Wo is a power of two here
-                            ro = (4L * row - 2 * x + p.ph_y * 2 * p.Wo + p.ph_x) * p.ldc;
-                        } else ro = (long)(32 * i2 + 16 * ii + r) * p.ldc;
+                            ro[r] = (4L * row - 2 * x + p.ph_y * 2 * p.Wo + p.ph_x) * p.ldc;
+                        } else ro[r] = (long)(32 * i2 + 16 * ii + r) * p.ldc;
+                    }
+                    // the residual values of the row tile are requested together: row by row, each pair of loads waited for vmcnt(0) — 64
+                    // exposed round trips per tile (and a drain of the next tile's operand DMAs each time)
+                    float rv[4][4];
+                    if (rbase) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) rv[r][j] = rbase[ro[r] + 16 * j];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) rv[r][j] = 0.f;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
                         float v[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = acc[2 * i2 + ii][j][r] * p.alpha + bv[j];
-                        if (rbase) {
+                        for (int j = 0; j < 4; ++j) v[j] = (acc[2 * i2 + ii][j][r] * p.alpha + bv[j]) + rv[r][j];
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] += rbase[ro + 16 * j];
-                        }
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) { cbase[ro + 16 * j] = v[j]; gs[j] += v[j]; gq[j] += v[j] * v[j]; }      // (nontemporal stores: measured +-0)
-                        if (!__builtin_isfinite(v[0] + v[1] + v[2] + v[3]) && p.range_flag) *p.range_flag = 1;      // f16 plane overflow surfaces as NaN / inf
+                        for (int j = 0; j < 4; ++j) { cbase[ro[r] + 16 * j] = v[j]; gs[j] += v[j]; gq[j] += v[j] * v[j]; }      // (nontemporal stores: measured +-0)
+                        // f16 plane overflow surfaces as NaN / inf.  (The branch per row also keeps hipcc's register allocation in check: with a
+                        // branch-free accumulated check the epilogue becomes one block and 230 VGPRs of accumulators are spilled.)
+                        if (!__builtin_isfinite(v[0] + v[1] + v[2] + v[3]) && p.range_flag) *p.range_flag = 1;
                     }
                 }
                 if (p.gn_part) {                                         // per (32-row chunk, column) partial sums of the final values

@@ -14,6 +14,7 @@ SHAPES = [(128, 128, 64, 7), (256, 128, 64, 2), (384, 128, 64, 1),
           (384, 512, 8, 1), (512, 512, 8, 10), (896, 512, 8, 1), (1024, 512, 8, 2)]
 if __name__ == "__main__":
     timing = "--time" in sys.argv
+    with_res = "--res" in sys.argv          # convs that carry the block's residual (conv2 of every ResBlock: half of the launches)
     for (ci, co, r, cnt) in SHAPES:
         x = ops.to_nhwc(torch.randn(B, ci, r, r, device="cuda:0"))
         planes = torch.empty((2, B, r, r, ci), dtype=torch.float16, device="cuda:0")
@@ -21,13 +22,14 @@ if __name__ == "__main__":
         xs = ops.SplitAct(planes[0], planes[1], (B, ci, r, r))
         w = (torch.randn(co, ci, 3, 3, device="cuda:0") / (9 * ci) ** .5).contiguous(memory_format=torch.channels_last)
         b = torch.randn(co, device="cuda:0")
+        res = ops.to_nhwc(torch.randn(B, co, r, r, device="cuda:0")) if with_res else None
         with torch.no_grad():
-            ops.conv3x3_ps(xs, w, b)
+            ops.conv3x3_ps(xs, w, b, res=res)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(3):
-                ops.conv3x3_ps(xs, w, b)
+                ops.conv3x3_ps(xs, w, b, res=res)
             e1.record()
             torch.cuda.synchronize()
         if timing:
