@@ -667,6 +667,30 @@ __global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_ke
             const int col = n0 + wn * WN + ((B_MC && PREC == 0) ? TN * l31 + j : j * 32 + l31);      // fp32 k-major B: interleaved column slots
             if (col >= p.N) continue;
             const float bv = (p.ksplit == 1 && p.bias) ? p.bias[col] : 0.f;
+            // residual / accumulate operands of the sub-tile's 16 rows are requested together, ahead of the loop (a test + load + use per
+            // element is one exposed memory round trip each: 16 per sub-tile); rows beyond M read element 0
+            float rv[16], cv[16];
+            if (p.ksplit == 1 && (Rg || p.accumulate)) {
+                long ad[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int slot = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    const int row = m0 + wm * WM + ((A_MC && PREC == 0) ? TM * slot + i : i * 32 + slot);
+                    if (p.out_mode == OUT_NCHW) {
+                        int img = row / p.out_hw, pix = row - img * p.out_hw;
+                        ad[r] = ((long)img * p.N + col) * p.out_hw + pix;
+                    } else ad[r] = (long)row * p.ldc + col;
+                    if (row >= p.M) ad[r] = 0;
+                }
+                if (Rg) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rv[r] = Rg[ad[r]];
+                }
+                if (p.accumulate) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cv[r] = Cg[ad[r]];
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int slot = (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -679,10 +703,10 @@ __global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_ke
                     addr = ((long)img * p.N + col) * p.out_hw + pix;
                 } else addr = (long)row * p.ldc + col;
                 float v = acc[i][j][r] * p.alpha + bv;
-                if (Rg) v += Rg[addr];
+                if (Rg) v += rv[r];
                 if (p.act == ACT_SILU) v = cdae_silu(v);
                 else if (p.act == ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
-                if (p.accumulate) v += Cg[addr];
+                if (p.accumulate) v += cv[r];
                 Cg[addr] = v;
                 if (!__builtin_isfinite(v) && p.range_flag) *p.range_flag = 1;
                 if (p.C_hi) store_planes(p, addr, v);
@@ -895,24 +919,45 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + LOADERS)) void ps_kernel(
             if (col >= p.N) continue;
             const float bv = (p.ksplit == 1 && p.bias) ? p.bias[col] : 0.f;
             float gs = 0.f, gq = 0.f;
+            auto out_addr = [&](int row) -> long {
+                if (p.out_mode == OUT_NCHW) {
+                    int img = row / p.out_hw, pix = row - img * p.out_hw;
+                    return ((long)img * p.N + col) * p.out_hw + pix;
+                } else if (p.out_mode == OUT_UP2) {
+                    const int x = row - fdiv(row, p.wo_magic, p.wo_shift) * p.Wo;          // (n, y, x) -> (n, 2y + ph_y, 2x + ph_x)
+                    return (4L * row - 2 * x + p.ph_y * 2 * p.Wo + p.ph_x) * p.ldc + col;
+                }
+                return (long)row * p.ldc + col;
+            };
+            // residual / accumulate operands of the sub-tile's 16 rows requested together (as in igemm_kernel's epilogue)
+            float rv[16], cv[16];
+            if (p.ksplit == 1 && (Rg || p.accumulate)) {
+                long ad[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    ad[r] = row < p.M ? out_addr(row) : 0;
+                }
+                if (Rg) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rv[r] = Rg[ad[r]];
+                }
+                if (p.accumulate) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cv[r] = Cg[ad[r]];
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
                 if (row >= p.M) continue;
                 if (p.ksplit > 1) { Cg[(long)row * p.N + col] = acc[i][j][r]; continue; }
-                long addr;
-                if (p.out_mode == OUT_NCHW) {
-                    int img = row / p.out_hw, pix = row - img * p.out_hw;
-                    addr = ((long)img * p.N + col) * p.out_hw + pix;
-                } else if (p.out_mode == OUT_UP2) {
-                    const int x = row - fdiv(row, p.wo_magic, p.wo_shift) * p.Wo;          // (n, y, x) -> (n, 2y + ph_y, 2x + ph_x)
-                    addr = (4L * row - 2 * x + p.ph_y * 2 * p.Wo + p.ph_x) * p.ldc + col;
-                } else addr = (long)row * p.ldc + col;
+                const long addr = out_addr(row);
                 float v = acc[i][j][r] * p.alpha + bv;
-                if (Rg) v += Rg[addr];
+                if (Rg) v += rv[r];
                 if (p.act == ACT_SILU) v = cdae_silu(v);
                 else if (p.act == ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
-                if (p.accumulate) v += Cg[addr];
+                if (p.accumulate) v += cv[r];
                 Cg[addr] = v;
                 if (!__builtin_isfinite(v) && p.range_flag) *p.range_flag = 1;
                 if (p.C_hi) store_planes(p, addr, v);

@@ -266,14 +266,26 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 float* dst = p.y + (long)(m0 + wm * 64 + i * 32 + 4 * hh) * p.ldy + n0 + wn * 64 + j * 32 + l31;
-                const float* rsrc = p.res ? p.res + (long)(m0 + wm * 64 + i * 32 + 4 * hh) * p.ldres + n0 + wn * 64 + j * 32 + l31 : nullptr;
+                // the sub-tile's 16 residual values are requested together (a test + load + use per element is one exposed round trip each)
+                float rv[16];
+                if (p.res) {
+                    const float* rsrc = p.res + (long)(m0 + wm * 64 + i * 32 + 4 * hh) * p.ldres + n0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rv[r] = rsrc[(long)((r & 3) + 8 * (r >> 2)) * p.ldres];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+                }
+                float vv[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float v = acc[i][j][r] + bv[j];
-                    if (rsrc) v += rsrc[(long)((r & 3) + 8 * (r >> 2)) * p.ldres];
-                    dst[(long)((r & 3) + 8 * (r >> 2)) * p.ldy] = v;
-                    if (p.c_hi) store_planes_sg(p, (dst - p.y) + (long)((r & 3) + 8 * (r >> 2)) * p.ldy, v);
-                    bad |= !__builtin_isfinite(v);
+                    vv[r] = (acc[i][j][r] + bv[j]) + rv[r];
+                    dst[(long)((r & 3) + 8 * (r >> 2)) * p.ldy] = vv[r];
+                    bad |= !__builtin_isfinite(vv[r]);
+                }
+                if (p.c_hi) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) store_planes_sg(p, (dst - p.y) + (long)((r & 3) + 8 * (r >> 2)) * p.ldy, vv[r]);
                 }
             }
         if (bad && p.range_flag) *p.range_flag = 1;
