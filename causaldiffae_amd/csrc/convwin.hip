@@ -440,6 +440,19 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+        } else if (interior && p.ksplit > 1) {
+            // split-K partial tile, interior: plain stores into slab eks (the general path spends ~8 instructions per element on tests)
+            float* __restrict__ cb = p.splitk_ws + (long)eks * (long)p.M * p.N + (long)(em0 + wm * 128 + 4 * kg) * p.N + en0 + wn * 64 + lr;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float* __restrict__ o = cb + (long)(16 * i + r) * p.N;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[16 * j] = acc[i][j][r];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         } else {
             float* __restrict__ Cg;
             const float* __restrict__ Rg = nullptr;
