@@ -176,8 +176,11 @@ int cdae_upconv3x3_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo
     if ((long)N * H * W * sx >= (1L << 31)) return cdae_fail("upconv3x3_fwd_ps: activation larger than 2^31 elements");
     if (sx % 8 || sy % 8 || sn % 8 || !aligned16(x_hi) || !aligned16(x_lo) || !aligned16(w4_hi) || !aligned16(w4_lo))
         return cdae_fail("upconv3x3_fwd_ps: planes must be 16-byte aligned with pixel pitch % 8 == 0");
-    for (int ph = 0; ph < 4; ++ph) {
+    static const int cfg_fused = getenv("CDAE_UPCONV_FUSED") ? atoi(getenv("CDAE_UPCONV_FUSED")) : 1;
+    for (int ph = cfg_fused ? -1 : 0; ph < 4; ++ph) {      // ph = -1: all four phases as one launch of the window kernel (4x the tiles: the low levels fill the chip)
         GemmParams p = base_params();
+        const bool all = ph < 0;
+        if (all) { ph = 0; p.nphase = 4; p.phase_w = (long)Cout * 4 * Cin; p.phase_gn = gn_part ? (long)(((long)N * H * W + 31) / 32) * Cout * 2 : 0; }
         p.presplit = 1; p.ps_taps = 4; p.ph_y = ph >> 1; p.ph_x = ph & 1;
         const long woff = (long)ph * Cout * 4 * Cin;
         p.A = reinterpret_cast<const float*>(x_hi); p.A_lo = x_lo;
@@ -190,8 +193,14 @@ int cdae_upconv3x3_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo
         p.amode = A_CONV_VEC; p.bmode = B_PLAIN_KC;
         p.conv_M = p.M; p.H = H; p.W = W; p.Cin = Cin; p.Ho = H; p.Wo = W; p.stride = 1; p.up = 0;
         p.sn = sn; p.sy = sy; p.sx = sx; p.sc = 1;
-        set_splitk(p, gn_part ? nullptr : splitk_ws, splitk_ws_bytes);
+        set_splitk(p, (gn_part || all) ? nullptr : splitk_ws, splitk_ws_bytes);
         const int rc = cdae_gemm_dispatch(p, stream);
+        if (all) {
+            if (rc == 0) return 0;
+            if (rc != 2) return rc;
+            ph = -1;                           // not taken as one launch: phase by phase
+            continue;
+        }
         if (rc) return rc;
     }
     return 0;

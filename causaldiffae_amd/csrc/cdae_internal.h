@@ -67,6 +67,9 @@ struct GemmParams {
     // igemm_kernel GNS: the (a, b) coefficients of the (at most two) images a 128-row tile touches are preloaded into LDS behind the
     // tiles (16 bytes x K), set by the launcher when that fits; 0 = read them from global memory inside the loop
     int gn_tab;
+    // convwin_kernel, sub-pixel up-conv: the four phases (ph_y, ph_x) of one conv as ONE launch.  nphase = 4: phase ph adds ph * phase_w
+    // elements to the weight planes and ph * phase_gn floats to gn_part, (ph_y, ph_x) = (ph >> 1, ph & 1); 0 / 1: p.ph_y, p.ph_x as given
+    int nphase; long phase_w, phase_gn;
 };
 
 int cdae_gemm_dispatch(GemmParams p, void* stream);

@@ -31,6 +31,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef CW_DEV
 #define CW_DEV 0
 #endif
+#ifndef CW_MID_LATE
+#define CW_MID_LATE 0
+#endif
+#ifndef CW_GEOM_LATE
+#define CW_GEOM_LATE 0
+#endif
 #ifndef CW_READ_EARLY
 #define CW_READ_EARLY 0      // 1: next-tile fragment reads in front of the tile's MFMAs (12 instead of 9 MFMAs to land): measured +-0 (same-box A/B)
 #endif
@@ -104,6 +110,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
 
     // ---- state of the tile being computed (a persistent block walks tiles blockIdx.x, + gridDim.x, ...)
     int m0, n0, ks, g_begin, g_end, nsteps;
+    int cph = 0, cph_y = p.ph_y, cph_x = p.ph_x;   // sub-pixel phase of the tile (NT = 4; all four phases of an up-conv can share one launch)
     unsigned aoffb[3];             // window DMA: byte offset (group 0) of this lane's 16 bytes of rows 32 (wave + 4 q) + lane / 2
     unsigned woffb;                // weight DMA: byte offset of row n0 + 32 wave + lane / 2 (tap 0, group 0)
     int tapmask[8];                // per 16-row tile: bit (3 ky + kx) set when tap (ky, kx) of this lane's pixel reads a real pixel
@@ -113,6 +120,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
             const unsigned G = (unsigned)ntiles, b = (unsigned)tile;
             const unsigned q = G >> 3, r = G & 7, x = b & 7;
             unsigned v = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+            if (NT == 4 && p.nphase > 1) { cph = v & 3; v >>= 2; cph_y = cph >> 1; cph_x = cph & 1; }      // phase fastest: the four phases of a tile read the same window
             nt = v % nnt; v /= nnt;
             mt = v % nmt; ks = v / nmt;
         }
@@ -130,6 +138,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
         }
         const int wrow = min(n0 + wave * 32 + (lane >> 1), p.N - 1);
         woffb = packed ? (unsigned)wrow * 32u + (lane & 1) * 16u : (unsigned)wrow * (unsigned)p.ldb * 2u + (lane & 1) * 16u;
+        if (NT == 4 && p.nphase > 1) woffb += (unsigned)cph * (unsigned)p.phase_w * 2u;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int m = m0 + wm * 128 + 16 * i + lr;
@@ -195,8 +204,8 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
         int gb = g, tb = t + 1;
         if (tb == NT) { tb = 0; ++gb; }
         const int my_t = selb ? tb : t, my_g = selb ? gb : g;
-        const int ky = NT == 9 ? (my_t * 11) >> 5 : (my_t >> 1) + p.ph_y;  // tap / 3 for tap < 9
-        const int kx = NT == 9 ? my_t - 3 * ky : (my_t & 1) + p.ph_x;
+        const int ky = NT == 9 ? (my_t * 11) >> 5 : (my_t >> 1) + cph_y;  // tap / 3 for tap < 9
+        const int kx = NT == 9 ? my_t - 3 * ky : (my_t & 1) + cph_x;
         wtap = 3 * ky + kx;
         addr = a_lane + (my_g & 1) * CW_A_HALF + (ky * W + kx - 1) * 32;
     };
@@ -263,7 +272,9 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
             int gn = ga, tn = ta + 2;          // first unit of the next step
             if (tn >= NT) { tn -= NT; ++gn; }
             int wtap_n; unsigned a_n;
+#if !CW_GEOM_LATE
             geom(gn, tn, wtap_n, a_n);
+#endif
             const unsigned b_n = b_lane + ((s + 1) & 1) * CW_B_STAGE;
             // the two waves of a SIMD belong to different blocks: alternating the issue priority by step parity lets one of them run
             // its MFMA burst unbroken while the other is at its mid-step wait (measured +2..3 %; CDAE_PS_DBG & 64 turns it off)
@@ -272,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int cur = i & 1;
-                if (i == 4) {
+                auto midstep = [&]() __attribute__((always_inline)) {
                     // ---- mid-step: every wave holds this step's weight fragments in registers, so the stage is free for step s + 2;
                     // the weights of step s + 1 (issued one step ago) must have landed; a window reload issued after them may stay in flight
                     const unsigned long long t1_ = now();
@@ -298,7 +309,10 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                         ++g_old;
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                }
+                };
+#if !CW_MID_LATE
+                if (i == 4) midstep();
+#endif
                 // tile 0 needs A(0) and B(0) of the ten reads in flight; every other tile's A pair is the only thing outstanding
                 if (i == 0) CW_WAIT("s_waitcnt lgkmcnt(6)" : "+v"(ah[0]), "+v"(al[0]), "+v"(bh[0]), "+v"(bl[0]));
                 else CW_WAIT("s_waitcnt lgkmcnt(0)" : "+v"(ah[cur]), "+v"(al[cur]));
@@ -340,11 +354,19 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                 for (int j = 1; j < 4; ++j) {
                     // tile 0: B(j) is the oldest of the reads in flight [B(j) .. B(3), A(1)]
                     if (i == 0) CW_WAIT("s_waitcnt lgkmcnt(%2)" : "+v"(bh[j]), "+v"(bl[j]) : "n"(8 - 2 * j));
+#if CW_GEOM_LATE
+                    if (i == 5 && j == 1) geom(gn, tn, wtap_n, a_n);      // the next step's geometry (~35 vector instructions) in the shadow of tile 5's MFMAs
+#endif
                     if (en) {
                         acc[i][j] = mma(al[cur], bh[j], acc[i][j]);
                         acc[i][j] = mma(ah[cur], bl[j], acc[i][j]);
                         acc[i][j] = mma(ah[cur], bh[j], acc[i][j]);
                     }
+#if CW_MID_LATE
+                    // the mid-step wait / barrier / DMA issue behind the first six MFMAs of tile 4 (they and the A(5) read only need registers
+                    // and the live window halves), so the matrix pipe has work queued while this wave is at the barrier
+                    if (i == 4 && j == 1) { __builtin_amdgcn_sched_barrier(0); midstep(); }
+#endif
                     if (i == 7) {
                         __builtin_amdgcn_sched_barrier(0);
                         if (j == 1) { CW_READ_B(1, b_n); } else if (j == 2) { CW_READ_B(2, b_n); } else { CW_READ_B(3, b_n); }
@@ -361,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
 
         __builtin_amdgcn_s_setprio(0);
         // ---- tile done: stage the next tile's operands, then write this tile's result (the stores drain behind the next K loop)
-        const int em0 = m0, en0 = n0, eks = ks;
+        const int em0 = m0, en0 = n0, eks = ks, eph = cph, eph_y = cph_y, eph_x = cph_x;
         constexpr int epart = part;
         const int next = tile + gridDim.x;
         const bool has_next = next < ntiles;
@@ -397,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                     for (int r = 0; r < 4; ++r) {
                         if (up2) {
                             const int row = row0 + 32 * i2 + 16 * ii + r, x = row & (p.Wo - 1);             // Wo is a power of two here
-                            ro[r] = (4L * row - 2 * x + p.ph_y * 2 * p.Wo + p.ph_x) * p.ldc;
+                            ro[r] = (4L * row - 2 * x + eph_y * 2 * p.Wo + eph_x) * p.ldc;
                         } else ro[r] = (long)(32 * i2 + 16 * ii + r) * p.ldc;
                     }
                     // the residual values of the row tile are requested together: row by row, each pair of loads waited for vmcnt(0) — 64
@@ -433,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                         s_ += __shfl_xor(s_, 16); q_ += __shfl_xor(q_, 16);
                         s_ += __shfl_xor(s_, 32); q_ += __shfl_xor(q_, 32);
                         if (kg == 0) {
-                            float* o = p.gn_part + ((long)((em0 + wm * 128 + 32 * i2) >> 5) * p.N + en0 + wn * 64 + lr + 16 * j) * 2;
+                            float* o = p.gn_part + (long)eph * p.phase_gn + ((long)((em0 + wm * 128 + 32 * i2) >> 5) * p.N + en0 + wn * 64 + lr + 16 * j) * 2;
                             o[0] = s_; o[1] = q_;
                         }
                     }
@@ -481,7 +503,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                                     long addr;
                                     if (p.out_mode == OUT_UP2) {
                                         const int x = row & (p.Wo - 1);
-                                        addr = (4L * row - 2 * x + p.ph_y * 2 * p.Wo + p.ph_x) * p.ldc + col;
+                                        addr = (4L * row - 2 * x + eph_y * 2 * p.Wo + eph_x) * p.ldc + col;
                                     } else addr = (long)row * p.ldc + col;
                                     float v = a * p.alpha + bv[j];
                                     if (Rg) v += Rg[addr];
@@ -502,7 +524,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                         s_ += __shfl_xor(s_, 16); q_ += __shfl_xor(q_, 16);
                         s_ += __shfl_xor(s_, 32); q_ += __shfl_xor(q_, 32);
                         if (kg == 0 && col0 + 16 * j < p.N) {
-                            float* o = p.gn_part + ((long)((em0 + wm * 128 + 32 * i2) >> 5) * p.N + col0 + 16 * j) * 2;
+                            float* o = p.gn_part + (long)eph * p.phase_gn + ((long)((em0 + wm * 128 + 32 * i2) >> 5) * p.N + col0 + 16 * j) * 2;
                             o[0] = s_; o[1] = q_;
                         }
                     }
@@ -532,7 +554,7 @@ int launch_convwin(const GemmParams& p, hipStream_t st) {
             return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
         attr_done = true;
     }
-    const long ntiles = (long)((p.M + CW_BM - 1) / CW_BM) * ((p.N + CW_BN - 1) / CW_BN) * p.ksplit;
+    const long ntiles = (long)((p.M + CW_BM - 1) / CW_BM) * ((p.N + CW_BN - 1) / CW_BN) * p.ksplit * (p.nphase > 1 ? p.nphase : 1);
     static const int cfg_persist = getenv("CDAE_CONVWIN_GRID") ? atoi(getenv("CDAE_CONVWIN_GRID")) : 512;      // two blocks per CU
     dim3 grid((unsigned)(ntiles < cfg_persist ? ntiles : cfg_persist));
     // measured: 128->128 at 64 x 64 519 vs 478 us, DDIM step 27.3 vs 25.8 ms — the two half items cost ~1.4 tiles (same DMA and LDS

@@ -1596,7 +1596,7 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
     if (p.gn_part && (ks > 1 || !p.presplit || (p.out_mode != OUT_ROWMAJOR && p.out_mode != OUT_UP2) || p.accumulate))
         return cdae_fail("GroupNorm partial sums from the epilogue need a pre-split, unsplit-K, row-major, non-accumulating launch");
 
-    cdae_prof_begin(PROF_IGEMM, 2.0 * p.M * p.N * (double)p.K * p.batch, st);
+    cdae_prof_begin(PROF_IGEMM, 2.0 * p.M * p.N * (double)p.K * p.batch * (p.nphase > 1 ? p.nphase : 1), st);
     int rc = -1;
 #define CASE(AM, BM_) if (p.amode == AM && p.bmode == BM_) rc = launch_tiles<AM, BM_>(p, big, scalar, st)
     if (p.presplit) {
@@ -1609,6 +1609,7 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
         const bool win_ok = cfg_win && p.amode == A_CONV_VEC && p.stride == 1 && !p.up && p.W <= 64 && big &&
                             p.sy == (long)p.W * p.sx && p.sn == (long)p.H * p.W * p.sx &&
                             (p.ps_taps == 4 ? p.out_mode == OUT_UP2 && !p.gn_coef && cfg_subpix : p.out_mode == OUT_ROWMAJOR);
+        if (p.nphase > 1 && (!win_ok || p.gn_coef)) { cdae_prof_end(PROF_IGEMM, st); return 2; }      // (only convwin_kernel walks the four phases itself)
         if (p.gn_coef && (!win_ok || (p.A2 && p.K1 % BK))) return cdae_fail("fused GroupNorm prologue: only on the window-resident conv path");
         if (win_ok && p.gn_coef) {
             const int nchunk = p.Cin / BK;
@@ -1633,7 +1634,7 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
             static const int cfg_cw = getenv("CDAE_CONVWIN") ? atoi(getenv("CDAE_CONVWIN")) : 1;
             static const int cfg_cw_min = getenv("CDAE_CONVWIN_MINTILES") ? atoi(getenv("CDAE_CONVWIN_MINTILES")) : 256;
             static const int cfg_cw_ks = getenv("CDAE_CONVWIN_SPLITK") ? atoi(getenv("CDAE_CONVWIN_SPLITK")) : 1;
-            const long cw_tiles = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
+            const long cw_tiles = (long)((p.M + 255) / 256) * ((p.N + 127) / 128) * (p.nphase > 1 ? p.nphase : 1);
             bool cw = cfg_cw && cdae_convwin_ok(p);
             if (cw) {
                 // fewer 256 x 128 tiles than block slots (two per CU): split K by whole 32-channel chunks (the low-resolution levels, and
@@ -1649,9 +1650,11 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
                 if (cw_tiles * kbest >= cfg_cw_min) p.ksplit = ks = kbest;
                 else cw = false;
             }
+            if (p.nphase > 1 && (!cw || ks > 1)) { cdae_prof_end(PROF_IGEMM, st); return 2; }      // fused phases only on the window kernel: the caller launches them one by one
             if (cw) {
                 // algorithmic bytes: both activation planes, both weight planes, the fp32 result (+ the residual read)
-                cdae_prof_note(PROF_CONVWIN, 4.0 * p.M * p.Cin + 4.0 * p.K * p.N + 4.0 * p.M * p.N * (p.res ? 2 : 1));
+                const double nph = p.nphase > 1 ? p.nphase : 1;      // (the phases of an up-conv share the input planes)
+                cdae_prof_note(PROF_CONVWIN, 4.0 * p.M * p.Cin + nph * (4.0 * p.K * p.N + 4.0 * p.M * p.N * (p.res ? 2 : 1)));
                 rc = cdae_convwin_launch(p, st);
             }
             else
