@@ -17,6 +17,16 @@
 #include "cdae_internal.h"
 #include "../../include/cdae.h"
 
+// SG_NT (compile-time experiment): bit 0 = nt on the streamed x loads, bit 1 = nontemporal plane stores
+#ifndef SG_NT
+#define SG_NT 0
+#endif
+#if SG_NT & 1
+#define SG_NT_LD " nt"
+#else
+#define SG_NT_LD ""
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -124,8 +134,8 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
         const bool first = (KK) < p.K1; /* block-uniform: a step never straddles the two sources */                        \
         const float* s0 = first ? p.x1 + xoff1[0] + (KK) : p.x2 + xoff2[0] + (KK);                                         \
         const float* s1 = first ? p.x1 + xoff1[1] + (KK) : p.x2 + xoff2[1] + (KK);                                         \
-        asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"                    \
-                     "global_load_dwordx4 %2, %5, off\n\tglobal_load_dwordx4 %3, %5, off offset:16"                         \
+        asm volatile("global_load_dwordx4 %0, %4, off" SG_NT_LD "\n\tglobal_load_dwordx4 %1, %4, off offset:16" SG_NT_LD "\n\t"  \
+                     "global_load_dwordx4 %2, %5, off" SG_NT_LD "\n\tglobal_load_dwordx4 %3, %5, off offset:16" SG_NT_LD       \
                      : "=&v"(A0), "=&v"(A1), "=&v"(B0), "=&v"(B1) : "v"(s0), "v"(s1) : "memory");                          \
     }
 // one statement for every count (different statements in an if / else chain would meet in phi nodes, i.e. register copies)
@@ -219,8 +229,13 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
 #pragma unroll
             for (int q = 0; q < 2; ++q)
                 if (rok[q]) {
+#if SG_NT & 2
+                    __builtin_nontemporal_store(nh[q], reinterpret_cast<u16x8*>(p.s_hi + soff[q] + k));
+                    __builtin_nontemporal_store(nl[q], reinterpret_cast<u16x8*>(p.s_lo + soff[q] + k));
+#else
                     *reinterpret_cast<u16x8*>(p.s_hi + soff[q] + k) = nh[q];
                     *reinterpret_cast<u16x8*>(p.s_lo + soff[q] + k) = nl[q];
+#endif
                 }
         }
 
