@@ -101,8 +101,11 @@ int* cdae_range_flag_ptr();      // device-visible int[1], see GemmParams::range
 // activation planes of the different producers stay bit-identical.
 __device__ __forceinline__ float cdae_sigmoid(float x) {
     const float c_hi = -1.44269502162933349609375f, c_lo = -1.925963033500011e-8f;        // -log2(e) = c_hi + c_lo
-    const float t = x * c_hi;
-    const float r = __builtin_fmaf(x, c_lo, __builtin_fmaf(x, c_hi, -t));                 // exact product minus t
+    // outside [-87, 100] the sigmoid is 0 / 1 to fp32 anyway; clamped there, 2^t stays finite (t <= 125.5) and a huge |x| cannot turn
+    // t or its residual into inf - inf
+    const float xc = __builtin_amdgcn_fmed3f(x, -87.f, 100.f);
+    const float t = xc * c_hi;
+    const float r = __builtin_fmaf(xc, c_lo, __builtin_fmaf(xc, c_hi, -t));               // exact product minus t
     const float e = __builtin_amdgcn_exp2f(t);
     const float ec = __builtin_fmaf(e * 0.693147182464599609375f, r, e);                 // 2^(t + r)
     return __builtin_amdgcn_rcpf(1.f + ec);

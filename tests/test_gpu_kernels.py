@@ -265,6 +265,22 @@ def test_timestep_embedding_and_small_ops():
     x = rnd(5, 512, lo=-30, hi=30)
     assert err(ops.softplus_eps(x.to(DEV)), F.softplus(x) + 1e-8) < 1e-6
     assert err(ops.silu(x.to(DEV)), F.silu(x)) < 2e-6
+    # the shared sigmoid (v_exp_f32 + v_rcp_f32, cdae_internal.h) over its whole range: relative error, large |x| (2^t overflows below -87),
+    # zeros, denormal results; forward and derivative
+    xe = torch.tensor([-1e4, -200.0, -104.0, -88.8, -87.5, -50.0, -20.0, -5.0, -1.0, -1e-3, -0.0, 0.0, 1e-3, 0.5, 1.0, 5.0, 20.0, 50.0, 88.0, 200.0, 1e4, 3e38])
+    xg = xe.to(DEV).requires_grad_(True)
+    y = ops.silu(xg)
+    y.sum().backward()
+    xr = xe.double().requires_grad_(True)
+    yr = F.silu(xr)
+    yr.sum().backward()
+    assert torch.isfinite(y).all() and torch.isfinite(xg.grad).all()
+    assert ((y.detach().cpu().double() - yr.detach()).abs() <= 4e-7 * yr.detach().abs() + 1e-30).all()          # (below -87 the result is x * 1.6e-38 instead of a denormal: absolute 1e-30)
+    assert ((xg.grad.cpu().double() - xr.grad).abs() <= 1e-6 * xr.grad.abs() + 1e-30).all()
+    xm = torch.linspace(-30, 30, 200001)
+    ym = ops.silu(xm.to(DEV)).cpu().double()
+    rel = ((ym - F.silu(xm.double())).abs() / F.silu(xm.double()).abs().clamp_min(1e-30)).max().item()
+    assert rel < 6e-7, rel
     a, b = ops.to_nhwc(rnd(2, 128, 4, 4).to(DEV)), ops.to_nhwc(rnd(2, 384, 4, 4, seed=1).to(DEV))
     assert err(ops.cat_channels(a, b), torch.cat([a.cpu(), b.cpu()], 1)) == 0.0
     assert err(ops.to_nchw(a), a.cpu()) == 0.0
