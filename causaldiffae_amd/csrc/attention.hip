@@ -87,15 +87,41 @@ __global__ __launch_bounds__(NKT >= 4 ? 256 : 64 * NKT) void attn_fused_kernel(c
 
     auto stage = [&](int key0, int which /*1 = K (KC layout), 2 = V (k-major)*/) {
         const int pitch = which == 1 ? KP : VP;
-        for (int item = tid; item < PASS * (CH / 4); item += THREADS) {
-            const int row = item / (CH / 4), f4 = item - row * (CH / 4);
-            const float4 v = *reinterpret_cast<const float4*>(base + (long)(key0 + row) * C3 + which * CH + f4 * 4);
-            half4 hi, lo;
-            hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
-            lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);
-            lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);
-            *reinterpret_cast<half4*>(lds + row * pitch + f4 * 8) = hi;
-            *reinterpret_cast<half4*>(lds + PLANE + row * pitch + f4 * 8) = lo;
+        // four 16-byte loads in flight per thread (a load - convert - store loop exposes one memory round trip per item: 8-16 per pass):
+        // 26 -> 20 us (ch 128, T 64), 194 -> 150 us (ch 64, T 256); NOT for ch 96 at T 256, where the extra live registers push the
+        // allocation past what the K Q^T phase needs and the kernel gets slower (94 -> 106 us): that shape keeps the plain loop
+        constexpr int ITEMS = PASS * (CH / 4) / THREADS, GRP = 4;
+        constexpr bool BATCH = !(CH == 96 && NKT == 8) && PASS * (CH / 4) % THREADS == 0 && ITEMS % GRP == 0;
+        if constexpr (!BATCH) {
+            for (int item = tid; item < PASS * (CH / 4); item += THREADS) {
+                const int row = item / (CH / 4), f4 = item - row * (CH / 4);
+                const float4 v = *reinterpret_cast<const float4*>(base + (long)(key0 + row) * C3 + which * CH + f4 * 4);
+                half4 hi, lo;
+                hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
+                lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);
+                lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);
+                *reinterpret_cast<half4*>(lds + row * pitch + f4 * 8) = hi;
+                *reinterpret_cast<half4*>(lds + PLANE + row * pitch + f4 * 8) = lo;
+            }
+        } else
+#pragma unroll
+        for (int i0 = 0; i0 < ITEMS; i0 += GRP) {
+            float4 v[GRP];
+#pragma unroll
+            for (int u = 0; u < GRP; ++u) {
+                const int item = tid + (i0 + u) * THREADS, row = item / (CH / 4), f4 = item - row * (CH / 4);
+                v[u] = *reinterpret_cast<const float4*>(base + (long)(key0 + row) * C3 + which * CH + f4 * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < GRP; ++u) {
+                const int item = tid + (i0 + u) * THREADS, row = item / (CH / 4), f4 = item - row * (CH / 4);
+                half4 hi, lo;
+                hi[0] = (_Float16)v[u].x; hi[1] = (_Float16)v[u].y; hi[2] = (_Float16)v[u].z; hi[3] = (_Float16)v[u].w;
+                lo[0] = (_Float16)(v[u].x - (float)hi[0]); lo[1] = (_Float16)(v[u].y - (float)hi[1]);
+                lo[2] = (_Float16)(v[u].z - (float)hi[2]); lo[3] = (_Float16)(v[u].w - (float)hi[3]);
+                *reinterpret_cast<half4*>(lds + row * pitch + f4 * 8) = hi;
+                *reinterpret_cast<half4*>(lds + PLANE + row * pitch + f4 * 8) = lo;
+            }
         }
     };
 
