@@ -316,15 +316,7 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
         const int p0 = chunk * pix_per_block, p1 = min(HW, p0 + pix_per_block);
         int ldxe;                                   // this thread's channel vector lives in one of the two sources (skip concatenation)
         const float* const xb = gn_src(x, ldx, x2, ld2, C1, (long)n * HW, c, ldxe);
-        for (int p = p0 + r; p < p1; p += rows) {
-            const long pix = (long)n * HW + p;
-            float xv[VEC], dv[VEC];
-            if (VEC == 4) {
-                float4 t = *reinterpret_cast<const float4*>(xb + (long)p * ldxe);
-                float4 d = *reinterpret_cast<const float4*>(dy + pix * lddy + c);
-                xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
-                dv[0] = d.x; dv[1] = d.y; dv[2] = d.z; dv[3] = d.w;
-            } else { xv[0] = xb[(long)p * ldxe]; dv[0] = dy[pix * lddy + c]; }
+        auto pixel = [&](const float* xv, const float* dv) {
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
                 float xh = (xv[i] - mu) * rs;
@@ -336,6 +328,36 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
                 float dxh = du * gm[i];
                 A += dxh; B += dxh * xh;
                 ch[i][0] += du * xh; ch[i][1] += du; ch[i][2] += dh * u; ch[i][3] += dh;
+            }
+        };
+        int p = p0 + r;
+        if (VEC == 4) {
+            const float* const db = dy + (long)n * HW * lddy + c;
+            // four pixels (eight 16-byte loads) in flight per thread; the pixels are accumulated in the same order as one by one
+            for (; p + 3 * rows < p1; p += 4 * rows) {
+                float4 t[4], d[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    t[u] = *reinterpret_cast<const float4*>(xb + (long)(p + u * rows) * ldxe);
+                    d[u] = *reinterpret_cast<const float4*>(db + (long)(p + u * rows) * lddy);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float xv[4] = {t[u].x, t[u].y, t[u].z, t[u].w}, dv[4] = {d[u].x, d[u].y, d[u].z, d[u].w};
+                    pixel(xv, dv);
+                }
+            }
+            for (; p < p1; p += rows) {
+                const float4 t = *reinterpret_cast<const float4*>(xb + (long)p * ldxe);
+                const float4 d = *reinterpret_cast<const float4*>(db + (long)p * lddy);
+                const float xv[4] = {t.x, t.y, t.z, t.w}, dv[4] = {d.x, d.y, d.z, d.w};
+                pixel(xv, dv);
+            }
+        } else {
+            for (; p < p1; p += rows) {
+                const long pix = (long)n * HW + p;
+                const float xv[1] = {xb[(long)p * ldxe]}, dv[1] = {dy[pix * lddy + c]};
+                pixel(xv, dv);
             }
         }
     }
@@ -513,6 +535,88 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const float* __restrict_
                 *reinterpret_cast<gn_bf4*>(dxb_lo + pix * C + c) = bl;
             }
         }
+    }
+}
+
+// Pass 3, streaming form (VEC == 4): grid (nchunk, N) like pass 1 — a thread owns one channel vector of one image for a range of
+// pixels, so every per-(image, channel) constant (mean, rstd, the group sums, gamma, beta, scale, shift) is loaded ONCE (the
+// grid-stride form above re-reads ~20 scalars per element, each a dependent round trip through L1) and the pixel loop is two pixels
+// of 16-byte loads in flight, fma / sigmoid, 16-byte stores.  Same per-element arithmetic in the same order: bit-identical results.
+__global__ __launch_bounds__(256) void gn_bwd_dx_stream_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                                                int HW, int C, int ldx, int lddy, int lddx, int cpg, int G, int pix_per_block,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                const float* __restrict__ ss, int ld_ss, int do_silu,
+                                                                const float* __restrict__ gsum, int accumulate,
+                                                                const float* __restrict__ dx_add, int ld_add,
+                                                                unsigned short* __restrict__ dxb_hi, unsigned short* __restrict__ dxb_lo,
+                                                                const float* __restrict__ x2, int ld2, int C1,
+                                                                float* __restrict__ dx2, int lddx2) {
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int E = C / 4, rows = 256 / E, tid = threadIdx.x;
+    const int r = tid / E, e = tid - r * E;
+    if (r >= rows) return;
+    const int c = e * 4, g = c / cpg;
+    const float mu = mean[n * G + g], rs = rstd[n * G + g];
+    const float m1 = gsum[(n * G + g) * 2], m2 = gsum[(n * G + g) * 2 + 1];
+    float gm[4], bt[4], a[4], sh[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        gm[i] = gamma[c + i]; bt[i] = beta[c + i];
+        a[i] = ss ? 1.f + ss[(long)n * ld_ss + c + i] : 1.f;
+        sh[i] = ss ? ss[(long)n * ld_ss + C + c + i] : 0.f;
+    }
+    const bool second = x2 != nullptr && c >= C1;
+    const long pixb = (long)n * HW;
+    const float* const xb = second ? x2 + pixb * ld2 + (c - C1) : x + pixb * ldx + c;
+    const int xl = second ? ld2 : ldx;
+    float* const ob = dx == nullptr ? nullptr : (second ? dx2 + pixb * lddx2 + (c - C1) : dx + pixb * lddx + c);
+    const int ol = second ? lddx2 : lddx;
+    const float* const db = dy + pixb * lddy + c;
+    const float* const ab = dx_add ? dx_add + pixb * ld_add + c : nullptr;
+    const int p0 = chunk * pix_per_block, p1 = min(HW, p0 + pix_per_block);
+    auto pixel = [&](int p, const float4& t, const float4& d, const float4& acc4, const float4& add4) {
+        const float xv[4] = {t.x, t.y, t.z, t.w}, dv[4] = {d.x, d.y, d.z, d.w};
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float xh = (xv[i] - mu) * rs;
+            float h = (xh * gm[i] + bt[i]) * a[i] + sh[i];
+            float dh = dv[i];
+            if (do_silu) { float s = cdae_sigmoid(h); dh *= s * (1.f + h * (1.f - s)); }
+            float dxh = dh * a[i] * gm[i];
+            o[i] = rs * (dxh - m1 - xh * m2);
+        }
+        if (accumulate) { o[0] += acc4.x; o[1] += acc4.y; o[2] += acc4.z; o[3] += acc4.w; }
+        if (ab) { o[0] += add4.x; o[1] += add4.y; o[2] += add4.z; o[3] += add4.w; }
+        if (ob) *reinterpret_cast<float4*>(ob + (long)p * ol) = make_float4(o[0], o[1], o[2], o[3]);
+        if (dxb_hi) {
+            gn_bf4 bh, bl;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { bh[i] = (__bf16)o[i]; bl[i] = (__bf16)(o[i] - (float)bh[i]); }
+            *reinterpret_cast<gn_bf4*>(dxb_hi + (pixb + p) * C + c) = bh;
+            *reinterpret_cast<gn_bf4*>(dxb_lo + (pixb + p) * C + c) = bl;
+        }
+    };
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    int p = p0 + r;
+    for (; p + rows < p1; p += 2 * rows) {                            // two pixels: up to eight 16-byte loads in flight
+        const int q = p + rows;
+        const float4 t0 = *reinterpret_cast<const float4*>(xb + (long)p * xl), t1 = *reinterpret_cast<const float4*>(xb + (long)q * xl);
+        const float4 d0 = *reinterpret_cast<const float4*>(db + (long)p * lddy), d1 = *reinterpret_cast<const float4*>(db + (long)q * lddy);
+        float4 c0 = z4, c1 = z4, e0 = z4, e1 = z4;
+        if (accumulate) { c0 = *reinterpret_cast<const float4*>(ob + (long)p * ol); c1 = *reinterpret_cast<const float4*>(ob + (long)q * ol); }
+        if (ab) { e0 = *reinterpret_cast<const float4*>(ab + (long)p * ld_add); e1 = *reinterpret_cast<const float4*>(ab + (long)q * ld_add); }
+        pixel(p, t0, d0, c0, e0);
+        pixel(q, t1, d1, c1, e1);
+    }
+    for (; p < p1; p += rows) {
+        const float4 t0 = *reinterpret_cast<const float4*>(xb + (long)p * xl);
+        const float4 d0 = *reinterpret_cast<const float4*>(db + (long)p * lddy);
+        float4 c0 = z4, e0 = z4;
+        if (accumulate) c0 = *reinterpret_cast<const float4*>(ob + (long)p * ol);
+        if (ab) e0 = *reinterpret_cast<const float4*>(ab + (long)p * ld_add);
+        pixel(p, t0, d0, c0, e0);
     }
 }
 
@@ -799,7 +903,11 @@ static int gn_bwd_impl(const float* x, const float* x2, int ld2, int C1, const f
     hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3((C + 63) / 64 + 1, N), dim3(256), 0, st, N, HW, C, cpg, groups, nchunk, gpart, cpart, gsum, d_scale_shift, ld_dss, ncp);
     if (N >= 8) hipLaunchKernelGGL(gn_bwd_param8_kernel, dim3((C + 31) / 32), dim3(256), 0, st, N, C, ncp, dgamma, dbeta, accumulate_params);
     else hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, st, N, C, ncp, dgamma, dbeta, accumulate_params);
-    if (VEC == 4) hipLaunchKernelGGL(gn_bwd_dx_kernel<4>, dim3(grid_for(total)), dim3(256), 0, st, x, dy, dx, total, HW, C, ldx, lddy, lddx, cpg, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gsum, accumulate_dx, dx_add, ld_add, dxb_hi, dxb_lo, x2, ld2, C1, dx2, lddx2);
+    static const int cfg_dxs = getenv("CDAE_GN_BWD_STREAM") ? atoi(getenv("CDAE_GN_BWD_STREAM")) : 1;
+    if (VEC == 4 && cfg_dxs && E <= 256 && (!accumulate_dx || dx))
+        hipLaunchKernelGGL(gn_bwd_dx_stream_kernel, dim3(nchunk, N), dim3(256), 0, st, x, dy, dx, HW, C, ldx, lddy, lddx, cpg, groups, ppb, mean, rstd, gamma, beta,
+                           scale_shift, ld_ss, silu, gsum, accumulate_dx, dx_add, ld_add, dxb_hi, dxb_lo, x2, ld2, C1, dx2, lddx2);
+    else if (VEC == 4) hipLaunchKernelGGL(gn_bwd_dx_kernel<4>, dim3(grid_for(total)), dim3(256), 0, st, x, dy, dx, total, HW, C, ldx, lddy, lddx, cpg, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gsum, accumulate_dx, dx_add, ld_add, dxb_hi, dxb_lo, x2, ld2, C1, dx2, lddx2);
     else hipLaunchKernelGGL(gn_bwd_dx_kernel<1>, dim3(grid_for(total)), dim3(256), 0, st, x, dy, dx, total, HW, C, ldx, lddy, lddx, cpg, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gsum, accumulate_dx, dx_add, ld_add, nullptr, nullptr, x2, ld2, C1, dx2, lddx2);
     cdae_prof_end(PROF_GN, st);
     CHECK_LAUNCH("gn_bwd launch failed");
