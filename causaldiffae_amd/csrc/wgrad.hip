@@ -182,11 +182,13 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void wgwin_kernel(const Wg
             const char* const dy_hi = dyb + st * D_STAGE + wm * D_SUB + lane_off;
             const char* const dy_lo = dy_hi + 2 * D_SUB;
             const char* const a_hi = lds + wn * A_SUB + lane_off;
-            const int row_own = slot0 * 16 + p.U0;     // ring row (before wrap) of the step's first own pixel
+            // ring row (before wrap) of the step's first own pixel: wave-uniform, but derived from the wave index (K group), which hipcc
+            // treats as divergent — readfirstlane moves it, and the tap arithmetic below, to the scalar unit
+            const int row_own = __builtin_amdgcn_readfirstlane(slot0 * 16 + p.U0);
             const int ring = p.RB * 16;
 #pragma unroll
             for (int ski = 0; ski < SKN; ++ski) {
-                const int sk = NWAVES == 8 ? 2 * kg + ski : ski;
+                const int sk = NWAVES == 8 ? __builtin_amdgcn_readfirstlane(2 * kg + ski) : ski;
                 u32x4 dh[3], dl[3];
                 dh[1] = frag(dy_hi + sk * 1024);
                 dl[1] = frag(dy_lo + sk * 1024);
@@ -199,7 +201,9 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void wgwin_kernel(const Wg
                     int rt = row_own + (t / 3 - 1) * p.W + (t % 3 - 1) + 16 * sk;
                     rt = rt < 0 ? rt + ring : rt;
                     rt = rt >= ring ? rt - ring : rt;
-                    return a_hi + rt * 64;
+                    // the ring row is wave-uniform: kept on the scalar unit (hipcc otherwise folds the per-lane offset in first and runs the
+                    // wrap arithmetic on the vector ALUs, ~9 instructions per tap beside the MFMAs)
+                    return a_hi + __builtin_amdgcn_readfirstlane(rt * 64);
                 };
                 u32x4 fh[3], fl[3];                        // fragment sets of taps t, t + 1, t + 2 (two taps = 6 MFMAs of lookahead)
                 fh[0] = frag(tap_src(0)); fl[0] = frag(tap_src(0) + 2 * A_SUB);
