@@ -1,4 +1,7 @@
 #!/bin/bash
-timeout 200 python3 -m pytest tests/test_gpu_kernels.py -x -q -k "window_conv or presplit or conv3x3 or upconv" 2>&1 | tail -3
-timeout 120 python3 tools/prof_shapes.py --time 2>&1 | grep -v amdgpu
-CDAE_PS_DBG=268 timeout 120 python3 tools/prof_shapes.py --time 2>&1 | grep -E "128->128 @64|256->256 @32"
+cp causaldiffae_amd/libcdae.so /tmp/keep.so; cp gpurun_ab_libD.so causaldiffae_amd/libcdae.so
+for D in 0 4 16 20 0; do
+  echo "== CDAE_PS_DBG=$D"
+  CDAE_PS_DBG=$D timeout 120 python3 tools/prof_shapes.py --time 2>&1 | grep -E "128->128 @64|256->256 @32|384->384 @16"
+done
+cp /tmp/keep.so causaldiffae_amd/libcdae.so
