@@ -58,7 +58,10 @@ SIGNATURES = {
     "cdae_head_conv_fwd": [P, L, P, I, P, P, P, I, I, I, I, I, P],
     "cdae_skip_gn_ok": [I, I, I, I, I],
     "cdae_linear_fwd_stream": [P, L, I, P, L, P, P, L, P, P, L, P, L, P, P, I, I, I, P],
-    "cdae_skip_gn_fwd": [P, L, I, P, L, P, P, L, P, P, L, P, I, P, P, I, I, I, I, P],
+    "cdae_skip_gn_fwd": [P, L, I, P, L, P, P, L, P, P, L, P, I, P, P, I, I, I, I, I, P],
+    "cdae_gn_apply_split2g": [P, I, P, I, I, P, P, I, I, I, I, P, P, P, P, P, I, I, P],
+    "cdae_planes_gm_to_pc": [P, P, P, P, L, I, P],
+    "cdae_conv3x3_fwd_psg": [P, P, L, L, L, I, P, P, P, P, P, P, P, L, I, P, P, P, I, I, I, I, I, I, I, P, SZ, P],
     "cdae_gn_apply_split2": [P, I, P, I, I, P, P, I, I, I, I, I, P, P, P, P, P, I, I, P],
     "cdae_linear_dgrad": [P, L, P, L, P, L, I, I, I, I, P, SZ, P],
     "cdae_linear_wgrad": [P, L, P, L, P, L, P, I, I, I, I, P, SZ, P],

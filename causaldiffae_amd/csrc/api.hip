@@ -117,6 +117,18 @@ int cdae_conv3x3_fwd_psk(const unsigned short* x_hi, const unsigned short* x_lo,
                          const unsigned short* w_lo, const unsigned short* wk_hi, const unsigned short* wk_lo, const float* bias, const float* res,
                          float* out, long ldo, int out_nchw, unsigned short* out_hi, unsigned short* out_lo, float* gn_part, int N, int H, int W,
                          int Cin, int Cout, int stride, int up, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    return cdae_conv3x3_fwd_psg(x_hi, x_lo, sn, sy, sx, 0, w_hi, w_lo, wk_hi, wk_lo, bias, res, out, ldo, out_nchw, out_hi, out_lo, gn_part, N, H, W, Cin, Cout,
+                                stride, up, splitk_ws, splitk_ws_bytes, stream);
+}
+
+// x_gm = 1: the activation planes are group-major, [Cin / 16][N H W][16] (cdae_gn_apply_split2g / cdae_skip_gn_fwd with planes_gm).  Only the
+// window kernel reads that layout: returns 3 (no error set) when the shape would run on another kernel — the caller converts with
+// cdae_planes_gm_to_pc and calls again with x_gm = 0.
+int cdae_conv3x3_fwd_psg(const unsigned short* x_hi, const unsigned short* x_lo, long sn, long sy, long sx, int x_gm, const unsigned short* w_hi,
+                         const unsigned short* w_lo, const unsigned short* wk_hi, const unsigned short* wk_lo, const float* bias, const float* res,
+                         float* out, long ldo, int out_nchw, unsigned short* out_hi, unsigned short* out_lo, float* gn_part, int N, int H, int W,
+                         int Cin, int Cout, int stride, int up, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    if (x_gm && (stride != 1 || up || out_nchw || Cin % 16)) return 3;
     if ((wk_hi != nullptr) != (wk_lo != nullptr) || !aligned16(wk_hi) || !aligned16(wk_lo)) return cdae_fail("conv3x3_fwd_psk: packed weights need both planes, 16-byte aligned");
     if (stride != 1 && stride != 2) return cdae_fail("conv3x3: stride must be 1 or 2");
     if (out_hi && (out_nchw || !out_lo)) return cdae_fail("conv3x3_fwd_ps: plane output needs both planes and a row-major result");
@@ -128,7 +140,7 @@ int cdae_conv3x3_fwd_psk(const unsigned short* x_hi, const unsigned short* x_lo,
     GemmParams p = base_params();
     p.presplit = 1;
     p.A = reinterpret_cast<const float*>(x_hi); p.A_lo = x_lo; p.B = reinterpret_cast<const float*>(w_hi); p.B_lo = w_lo;
-    p.Bk_hi = wk_hi; p.Bk_lo = wk_lo;
+    p.Bk_hi = wk_hi; p.Bk_lo = wk_lo; p.a_gm = x_gm;
     p.C = out; p.bias = bias; p.res = res; p.C_hi = out_hi; p.C_lo = out_lo; p.gn_part = gn_part;
     p.M = N * Ho * Wo; p.N = Cout; p.K = 9 * Cin;
     p.ldb = 9L * Cin; p.ldc = ldo;

@@ -70,6 +70,9 @@ struct GemmParams {
     // convwin_kernel, sub-pixel up-conv: the four phases (ph_y, ph_x) of one conv as ONE launch.  nphase = 4: phase ph adds ph * phase_w
     // elements to the weight planes and ph * phase_gn floats to gn_part, (ph_y, ph_x) = (ph >> 1, ph & 1); 0 / 1: p.ph_y, p.ph_x as given
     int nphase; long phase_w, phase_gn;
+    // convwin_kernel: the activation planes are GROUP-MAJOR, [Cin / 16][pixels][16] (written so by the GroupNorm apply kernel / the entry sweep
+    // on request): a 16-channel half-window is then one contiguous run of 32-byte rows — 8 cache lines per DMA instead of 32
+    int a_gm;
 };
 
 int cdae_gemm_dispatch(GemmParams p, void* stream);

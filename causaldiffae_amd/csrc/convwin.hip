@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const int pix = min(max(pix0 + (wave + 4 * q) * 32 + (lane >> 1), 0), p.M - 1);
-            aoffb[q] = (unsigned)pix * (unsigned)p.sx * 2u + (lane & 1) * 16u;
+            aoffb[q] = (p.a_gm ? (unsigned)pix * 32u : (unsigned)pix * (unsigned)p.sx * 2u) + (lane & 1) * 16u;
         }
         const int wrow = min(n0 + wave * 32 + (lane >> 1), p.N - 1);
         woffb = packed ? (unsigned)wrow * 32u + (lane & 1) * 16u : (unsigned)wrow * (unsigned)p.ldb * 2u + (lane & 1) * 16u;
@@ -156,12 +156,13 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
         }
     };
 
+    const int gstride = p.a_gm ? p.M * 32 : 32;                        // bytes between 16-channel groups of the activation planes
     auto issue_window = [&](int g) {                                  // group g -> half g & 1
         const unsigned dst = (g & 1) * CW_A_HALF + wave * 1024;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            cw_dma(a_hi, g * 32, aoffb[q], dst + q * 4096);
-            cw_dma(a_lo, g * 32, aoffb[q], dst + q * 4096 + CW_A_PLANE);
+            cw_dma(a_hi, g * gstride, aoffb[q], dst + q * 4096);
+            cw_dma(a_lo, g * gstride, aoffb[q], dst + q * 4096 + CW_A_PLANE);
         }
     };
     // weights of the step whose first unit is (g, t) -> stage

@@ -579,6 +579,24 @@ int cdae_embedding_bwd(const float* demb, float* dtable, const long long* idx, i
     LAUNCH1D(embedding_bwd_kernel, (long)N * D, demb, dtable, idx, N, D);
 }
 int cdae_axpby(float a, const float* x, float b, const float* y, float* out, long n, void* stream) { LAUNCH1D(axpby_kernel, n, a, x, b, y, out, n); }
+// group-major planes [C / 16][P][16] -> pixel-major [P][C] (16-byte pieces; both planes in one launch): for the consumers that do not read
+// the window conv kernel's layout (small shapes that fall back to the first-generation kernels)
+__global__ void planes_gm_to_pc_kernel(const uint4* __restrict__ a_hi, const uint4* __restrict__ a_lo, uint4* __restrict__ o_hi, uint4* __restrict__ o_lo,
+                                       long P, int C) {
+    const int G2 = C >> 3;                         // 16-byte pieces per pixel
+    const long total = P * G2;
+    GRID_STRIDE(i, total) {
+        const long pix = i / G2;
+        const int piece = (int)(i - pix * G2);
+        const long src = ((long)(piece >> 1) * P + pix) * 2 + (piece & 1);
+        o_hi[i] = a_hi[src]; o_lo[i] = a_lo[src];
+    }
+}
+int cdae_planes_gm_to_pc(const unsigned short* a_hi, const unsigned short* a_lo, unsigned short* o_hi, unsigned short* o_lo, long P, int C, void* stream) {
+    if (C % 16) return cdae_fail("planes_gm_to_pc: C % 16 == 0 required");
+    LAUNCH1D(planes_gm_to_pc_kernel, P * (C >> 3), reinterpret_cast<const uint4*>(a_hi), reinterpret_cast<const uint4*>(a_lo), reinterpret_cast<uint4*>(o_hi),
+             reinterpret_cast<uint4*>(o_lo), P, C);
+}
 int cdae_mul_scale(const float* x, const float* m, float scale, float* out, long n, void* stream) { LAUNCH1D(mul_scale_kernel, n, x, m, scale, out, n); }
 int cdae_mul_rows(float* x, const float* m, int N, int D, void* stream) { LAUNCH1D(mul_rows_kernel, (long)N * D, x, m, N, D); }
 int cdae_copy2d(const float* src, float* dst, long rows, int cols, long lds, long ldd, int accumulate, void* stream) {

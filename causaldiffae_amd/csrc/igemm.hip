@@ -1609,6 +1609,7 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
         const bool win_ok = cfg_win && p.amode == A_CONV_VEC && p.stride == 1 && !p.up && p.W <= 64 && big &&
                             p.sy == (long)p.W * p.sx && p.sn == (long)p.H * p.W * p.sx &&
                             (p.ps_taps == 4 ? p.out_mode == OUT_UP2 && !p.gn_coef && cfg_subpix : p.out_mode == OUT_ROWMAJOR);
+        if (p.a_gm && (!win_ok || p.gn_coef)) { cdae_prof_end(PROF_IGEMM, st); return 3; }
         if (p.nphase > 1 && (!win_ok || p.gn_coef)) { cdae_prof_end(PROF_IGEMM, st); return 2; }      // (only convwin_kernel walks the four phases itself)
         if (p.gn_coef && (!win_ok || (p.A2 && p.K1 % BK))) return cdae_fail("fused GroupNorm prologue: only on the window-resident conv path");
         if (win_ok && p.gn_coef) {
@@ -1650,6 +1651,7 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
                 if (cw_tiles * kbest >= cfg_cw_min) p.ksplit = ks = kbest;
                 else cw = false;
             }
+            if (p.a_gm && !cw) { cdae_prof_end(PROF_IGEMM, st); return 3; }                      // group-major planes: only convwin_kernel reads them (the caller converts)
             if (p.nphase > 1 && (!cw || ks > 1)) { cdae_prof_end(PROF_IGEMM, st); return 2; }      // fused phases only on the window kernel: the caller launches them one by one
             if (cw) {
                 // algorithmic bytes: both activation planes, both weight planes, the fp32 result (+ the residual read)

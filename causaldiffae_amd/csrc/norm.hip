@@ -218,7 +218,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                                                         const float* __restrict__ ss, int ld_ss, int do_silu,
                                                         unsigned short* __restrict__ y_hi = nullptr, unsigned short* __restrict__ y_lo = nullptr,
                                                         const float* __restrict__ x2 = nullptr, int ld2 = 0, int C1 = 0,
-                                                        unsigned short* __restrict__ yb_hi = nullptr, unsigned short* __restrict__ yb_lo = nullptr) {
+                                                        unsigned short* __restrict__ yb_hi = nullptr, unsigned short* __restrict__ yb_lo = nullptr,
+                                                        int plane_gm = 0) {
+    // plane_gm: the f16 planes are written group-major, [C / 16][N * HW][16] (the window conv kernel's contiguous half-windows)
     const int n = blockIdx.y, E = C / VEC, rows = 256 / E, tid = threadIdx.x;
     const int r = tid / E, e = tid - r * E;
     if (r >= rows) return;
@@ -244,6 +246,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     int p = p0 + r;
     if constexpr (VEC == 4) {
         const long hbase = (long)n * HW * ldy + c;
+        const long gbase = plane_gm ? ((long)(c >> 4) * gridDim.y * HW + (long)n * HW) * 16 + (c & 15) : hbase;
+        const long gld = plane_gm ? 16 : ldy;
         auto put = [&](int pp, const float4& v) {
             float r0 = apply(v.x, 0), r1 = apply(v.y, 1), r2 = apply(v.z, 2), r3 = apply(v.w, 3);
             if constexpr (SPLIT) {
@@ -252,8 +256,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                 hi[0] = (_Float16)r0; hi[1] = (_Float16)r1; hi[2] = (_Float16)r2; hi[3] = (_Float16)r3;
                 lo[0] = (_Float16)(r0 - (float)hi[0]); lo[1] = (_Float16)(r1 - (float)hi[1]);
                 lo[2] = (_Float16)(r2 - (float)hi[2]); lo[3] = (_Float16)(r3 - (float)hi[3]);
-                *reinterpret_cast<gn_half4*>(y_hi + hbase + (long)pp * ldy) = hi;
-                *reinterpret_cast<gn_half4*>(y_lo + hbase + (long)pp * ldy) = lo;
+                *reinterpret_cast<gn_half4*>(y_hi + gbase + (long)pp * gld) = hi;
+                *reinterpret_cast<gn_half4*>(y_lo + gbase + (long)pp * gld) = lo;
                 if (yb_hi) {       // training: the same values also as bf16 hi/lo planes, the wgrad kernel's operand format (wgrad.hip)
                     gn_bf4 bh, bl;
                     bh[0] = (__bf16)r0; bh[1] = (__bf16)r1; bh[2] = (__bf16)r2; bh[3] = (__bf16)r3;
@@ -275,6 +279,59 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     } else {
         for (; p < p1; p += rows) yp[(long)p * ldy] = apply(xp[(long)p * ldx], 0);
     }
+}
+
+// The same pass writing GROUP-MAJOR planes ([C / 16][N * HW][16]): grid (pixel chunks, N, C / 16); a block handles ONE 16-channel plane group,
+// four lanes per pixel (16 B of x each) and 64 consecutive pixels per pass, so a wave's plane store is 16 pixels x 32 B = one contiguous
+// 512-byte run (with the channel-vector mapping of gn_apply_kernel the same layout is 32-byte pieces 16 KB apart: 1.34 -> 1.76 ms per
+// DDIM step).  Same per-element arithmetic (folded affine, cdae_silu, opaque before the split): bit-identical values.
+__global__ __launch_bounds__(256) void gn_apply_gm_kernel(const float* __restrict__ x, int HW, int C, int ldx, int cpg, int G, int pix_per_block,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ ss, int ld_ss, int do_silu,
+                                                          unsigned short* __restrict__ y_hi, unsigned short* __restrict__ y_lo,
+                                                          const float* __restrict__ x2, int ld2, int C1) {
+    const int n = blockIdx.z, pg = blockIdx.x, tid = threadIdx.x;      // plane group fastest: the C / 16 blocks that read the same pixels' lines run together
+    const int ch4 = tid & 3, pl = tid >> 2;
+    const int c = pg * 16 + ch4 * 4, g = c / cpg;
+    const float mu = mean[n * G + g], rs = rstd[n * G + g];
+    float A[4], B[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        A[i] = rs * gamma[c + i];
+        B[i] = fmaf(-mu, A[i], beta[c + i]);
+        if (ss) {
+            const float sc = 1.f + ss[(long)n * ld_ss + c + i], sh = ss[(long)n * ld_ss + C + c + i];
+            A[i] *= sc;
+            B[i] = fmaf(B[i], sc, sh);
+        }
+    }
+    int ld;
+    const float* xp = gn_src(x, ldx, x2, ld2, C1, (long)n * HW, c, ld);
+    const long P = (long)gridDim.z * HW;
+    unsigned short* const oh = y_hi + ((long)pg * P + (long)n * HW) * 16 + ch4 * 4;
+    unsigned short* const ol = y_lo + ((long)pg * P + (long)n * HW) * 16 + ch4 * 4;
+    const int p0 = blockIdx.y * pix_per_block, p1 = min(HW, p0 + pix_per_block);
+    auto put = [&](int pp, const float4& v) {
+        float r0 = fmaf(v.x, A[0], B[0]), r1 = fmaf(v.y, A[1], B[1]), r2 = fmaf(v.z, A[2], B[2]), r3 = fmaf(v.w, A[3], B[3]);
+        if (do_silu) { r0 = silu_f(r0); r1 = silu_f(r1); r2 = silu_f(r2); r3 = silu_f(r3); }
+        asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));      // opaque before the split (attention.hip split8)
+        gn_half4 hi, lo;
+        hi[0] = (_Float16)r0; hi[1] = (_Float16)r1; hi[2] = (_Float16)r2; hi[3] = (_Float16)r3;
+        lo[0] = (_Float16)(r0 - (float)hi[0]); lo[1] = (_Float16)(r1 - (float)hi[1]);
+        lo[2] = (_Float16)(r2 - (float)hi[2]); lo[3] = (_Float16)(r3 - (float)hi[3]);
+        *reinterpret_cast<gn_half4*>(oh + (long)pp * 16) = hi;
+        *reinterpret_cast<gn_half4*>(ol + (long)pp * 16) = lo;
+    };
+    int p = p0 + pl;
+    for (; p + 3 * 64 < p1; p += 4 * 64) {
+        const float4 v0 = *reinterpret_cast<const float4*>(xp + (long)p * ld);
+        const float4 v1 = *reinterpret_cast<const float4*>(xp + (long)(p + 64) * ld);
+        const float4 v2 = *reinterpret_cast<const float4*>(xp + (long)(p + 128) * ld);
+        const float4 v3 = *reinterpret_cast<const float4*>(xp + (long)(p + 192) * ld);
+        put(p, v0); put(p + 64, v1); put(p + 128, v2); put(p + 192, v3);
+    }
+    for (; p < p1; p += 64) put(p, *reinterpret_cast<const float4*>(xp + (long)p * ld));
 }
 
 // ------------------------------------------------------------------ GroupNorm backward
@@ -996,12 +1053,20 @@ int cdae_gn_stats2(const float* x1, int ld1, const float* x2, int ld2, int C1, i
 
 static int gn_apply_split_impl(const float* x, int ldx, const float* x2, int ld2, int C1, unsigned short* y_hi, unsigned short* y_lo,
                                unsigned short* yb_hi, unsigned short* yb_lo, int N, int HW, int C, int ldy, int groups, const float* mean,
-                               const float* rstd, const float* gamma, const float* beta, const float* scale_shift, int ld_ss, int silu, void* stream);
+                               const float* rstd, const float* gamma, const float* beta, const float* scale_shift, int ld_ss, int silu, void* stream,
+                               int plane_gm = 0);
 
 int cdae_gn_apply_split2(const float* x, int ldx, const float* x2, int ld2, int C1, unsigned short* y_hi, unsigned short* y_lo, int N, int HW,
                          int C, int ldy, int groups, const float* mean, const float* rstd, const float* gamma, const float* beta,
                          const float* scale_shift, int ld_ss, int silu, void* stream) {
     return gn_apply_split_impl(x, ldx, x2, ld2, C1, y_hi, y_lo, nullptr, nullptr, N, HW, C, ldy, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, stream);
+}
+
+// cdae_gn_apply_split2 writing the planes GROUP-MAJOR: [C / 16][N * HW][16] instead of [N * HW][C] (operand layout of cdae_conv3x3_fwd_psg, x_gm = 1)
+int cdae_gn_apply_split2g(const float* x, int ldx, const float* x2, int ld2, int C1, unsigned short* y_hi, unsigned short* y_lo, int N, int HW,
+                          int C, int groups, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                          const float* scale_shift, int ld_ss, int silu, void* stream) {
+    return gn_apply_split_impl(x, ldx, x2, ld2, C1, y_hi, y_lo, nullptr, nullptr, N, HW, C, C, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, stream, 1);
 }
 
 int cdae_gn_apply_split_train(const float* x, unsigned short* y_hi, unsigned short* y_lo, unsigned short* yb_hi, unsigned short* yb_lo, int N,
@@ -1020,8 +1085,10 @@ int cdae_gn_apply_split_train2(const float* x1, int ld1, const float* x2, int ld
 
 static int gn_apply_split_impl(const float* x, int ldx, const float* x2, int ld2, int C1, unsigned short* y_hi, unsigned short* y_lo,
                                unsigned short* yb_hi, unsigned short* yb_lo, int N, int HW, int C, int ldy, int groups, const float* mean,
-                               const float* rstd, const float* gamma, const float* beta, const float* scale_shift, int ld_ss, int silu, void* stream) {
+                               const float* rstd, const float* gamma, const float* beta, const float* scale_shift, int ld_ss, int silu, void* stream,
+                               int plane_gm) {
     hipStream_t st = (hipStream_t)stream;
+    if (plane_gm && (C % 16 || ldy != C)) return cdae_fail("gn_apply_split: group-major planes need C % 16 == 0 and dense planes");
     const int cpg = C / groups;
     if (x2 && (ld2 % 4 || C1 % 4)) return cdae_fail("gn_apply_split2: second source needs 4-channel alignment");
     if (!(cpg % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0) || C / 4 > 256) return cdae_fail("gn_apply_split: needs channels-per-group % 4 == 0, C <= 1024");
@@ -1031,8 +1098,17 @@ static int gn_apply_split_impl(const float* x, int ldx, const float* x2, int ld2
     while (nchunk > 1 && (long)nchunk * N > 4096) nchunk >>= 1;
     const int ppb = (HW + nchunk - 1) / nchunk;
     cdae_prof_begin(PROF_GN, (double)N * HW * C * 8.0, st);
+    static const int cfg_gmk = getenv("CDAE_GN_APPLY_GM") ? atoi(getenv("CDAE_GN_APPLY_GM")) : 1;      // 0: group-major planes from the channel-vector kernel
+    if (plane_gm && cfg_gmk && !yb_hi && (!x2 || C1 % 16 == 0) && N <= 65535) {
+        int nch = HW / 256;                          // >= 4 pixels per thread
+        if (nch < 1) nch = 1;
+        while (nch > 1 && (long)nch * N * (C / 16) > 16384) nch >>= 1;
+        const int pp = (HW + nch - 1) / nch;
+        hipLaunchKernelGGL(gn_apply_gm_kernel, dim3(C / 16, nch, N), dim3(256), 0, st, x, HW, C, ldx, cpg, groups, pp, mean, rstd, gamma, beta, scale_shift,
+                           ld_ss, silu, y_hi, y_lo, x2, ld2, C1);
+    } else
     hipLaunchKernelGGL((gn_apply_kernel<4, true>), dim3(nchunk, N), dim3(256), 0, st, x, (float*)nullptr, HW, C, ldx, ldy, cpg, groups, ppb, mean, rstd,
-                       gamma, beta, scale_shift, ld_ss, silu, y_hi, y_lo, x2, ld2, C1, yb_hi, yb_lo);
+                       gamma, beta, scale_shift, ld_ss, silu, y_hi, y_lo, x2, ld2, C1, yb_hi, yb_lo, plane_gm);
     cdae_prof_end(PROF_GN, st);
     CHECK_LAUNCH("gn_apply_split launch failed");
     return 0;

@@ -39,6 +39,7 @@ struct SkipGnParams {
     const float* bias; float* y; long ldy;
     const float* res; long ldres;                                      // optional residual rows added to y
     unsigned short* c_hi; unsigned short* c_lo;                        // optional: y also as f16 hi / lo planes (row pitch ldy), the next conv's operand
+    int planes_gm;                                                     // s_hi / s_lo group-major: [K / 16][M][16] (convwin_kernel's contiguous half-windows)
     const float* coef; int silu; unsigned short* s_hi; unsigned short* s_lo;
     int M, N, K, HW, nimg_tab;                                         // HW = rows per image; nimg_tab = images the LDS table holds per block
     int* range_flag;
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
         const int mm = rok[q] ? m : 0;
         xoff1[q] = (long)mm * p.ld1 + c8 * 8;
         xoff2[q] = (long)mm * p.ld2 + c8 * 8 - p.K1;
-        soff[q] = (long)mm * p.K + c8 * 8;
+        soff[q] = p.planes_gm ? (long)mm * 16 + (c8 & 1) * 8 : (long)mm * p.K + c8 * 8;      // (+ k: the step's channel offset, see the stores)
         ioff[q] = (mm / p.HW - img0) * p.K * 2 + c8 * 16;             // float index of (image, channel 8 c8) in the table
         aoff[q] = row * 64 + 16 * (c8 ^ ((row >> 2) & 3));
     }
@@ -173,11 +174,9 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
         const int k = kt * SG_BK;
         char* const sa = lds + st * SG_STAGE;
         const bool more1 = kt + 1 < nk;                                // (at the top of step kt: x loads of step kt + 1 are the younger ones)
-        if (kt < 0) {                                                  // the two lead-in steps only issue: x of steps 0 and 1, weights of step 0
-            if (kt == -1) issue_b(0, 0);
-            if (kt + 2 < nk) SG_LOAD_X(x0a, x0b, x1a, x1b, k + 2 * SG_BK);
-            return;
-        }
+        const bool live = kt >= 0;                                     // the two lead-in steps (kt = -2, -1) only issue: x of steps 0 and 1, weights of step 0
+        u16x8 nh[2], nl[2];                                            // the normalised rows, split
+        if (live) {
         // (a partial row tile skips some plane stores: no fixed count)
         const int cnt = __builtin_amdgcn_readfirstlane((kt == 0 || !full_rows) ? 0 : (more1 ? 4 : 0) + (writes_planes ? 4 : 0));
         SG_WAIT_X(cnt, x0a, x0b, x1a, x1b);
@@ -190,7 +189,6 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
             *reinterpret_cast<u16x8*>(sa + aoff[1]) = hi;
             *reinterpret_cast<u16x8*>(sa + SG_A_PLANE + aoff[1]) = lo;
         }
-        u16x8 nh[2], nl[2];                                            // the normalised rows, split
         if (writes_planes) {
             float4 cf[2][4];
 #pragma unroll
@@ -224,17 +222,23 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
         }
         __syncthreads();                                               // stage st complete; nobody reads stage st ^ 1 any more
         if (more1) issue_b(st ^ 1, k + SG_BK);
+        } else if (kt == -1) issue_b(0, 0);
+        // ONE load statement per register set for lead-in and steady state alike: a second definition would meet this one in a phi node,
+        // i.e. possibly in v_mov copies of registers whose data has not landed (seen when the allocation changed: silent corruption)
         if (kt + 2 < nk) SG_LOAD_X(x0a, x0b, x1a, x1b, k + 2 * SG_BK);
+        if (!live) return;
         if (writes_planes) {
 #pragma unroll
             for (int q = 0; q < 2; ++q)
                 if (rok[q]) {
+                    // group-major: channels k + 8 c8 .. + 7 are half of group (k + 8 c8) / 16, at [group][row][8 (c8 & 1)]
+                    const long so = soff[q] + (p.planes_gm ? (long)((k >> 4) + (c8 >> 1)) * p.M * 16 : (long)k);
 #if SG_NT & 2
-                    __builtin_nontemporal_store(nh[q], reinterpret_cast<u16x8*>(p.s_hi + soff[q] + k));
-                    __builtin_nontemporal_store(nl[q], reinterpret_cast<u16x8*>(p.s_lo + soff[q] + k));
+                    __builtin_nontemporal_store(nh[q], reinterpret_cast<u16x8*>(p.s_hi + so));
+                    __builtin_nontemporal_store(nl[q], reinterpret_cast<u16x8*>(p.s_lo + so));
 #else
-                    *reinterpret_cast<u16x8*>(p.s_hi + soff[q] + k) = nh[q];
-                    *reinterpret_cast<u16x8*>(p.s_lo + soff[q] + k) = nl[q];
+                    *reinterpret_cast<u16x8*>(p.s_hi + so) = nh[q];
+                    *reinterpret_cast<u16x8*>(p.s_lo + so) = nl[q];
 #endif
                 }
         }
@@ -265,7 +269,13 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
                 }
         }
     };
-    for (int kt = -2; kt < nk; kt += 2) {                              // every x load is issued by the two statements inside this loop
+    // every x load is issued by the two statements inside this loop — and the loop must stay ONE copy: when hipcc peels the lead-in
+    // iterations, the peeled loads get registers of their own and the values reach the loop through v_mov copies of data still in flight
+    // (the start value is made opaque: with a visible -2 the "kt < 0" iterations are peeled)
+    int kt_first = -2;
+    asm volatile("" : "+s"(kt_first));
+#pragma clang loop unroll(disable)
+    for (int kt = kt_first; kt < nk; kt += 2) {
         step(c00, c01, c10, c11, kt, 0);
         if (kt + 1 < nk) step(n00, n01, n10, n11, kt + 1, 1);
     }
@@ -362,7 +372,7 @@ static int skipgn_launch(SkipGnParams& p, void* stream) {
 
 extern "C" int cdae_skip_gn_fwd(const float* x1, long ld1, int K1, const float* x2, long ld2, const unsigned short* w_hi, const unsigned short* w_lo,
                                 long ldw, const float* bias, float* y, long ldy, const float* coef, int silu, unsigned short* s_hi,
-                                unsigned short* s_lo, int M, int N, int K, int HW, void* stream) {
+                                unsigned short* s_lo, int planes_gm, int M, int N, int K, int HW, void* stream) {
     if (!x2) K1 = K;
     if (!cdae_skip_gn_ok(M, N, K, K1, HW)) return cdae_fail("skip_gn_fwd: K, K1 % 32 == 0, M a multiple of HW, coefficient table of a row tile <= 16 KB required");
     if (ld1 % 4 || (x2 && ld2 % 4) || ldw % 8 || !aligned16(x1) || !aligned16(x2) || !aligned16(w_hi) || !aligned16(w_lo) || !aligned16(coef) ||
@@ -371,7 +381,7 @@ extern "C" int cdae_skip_gn_fwd(const float* x1, long ld1, int K1, const float* 
     SkipGnParams p;
     p.x1 = x1; p.x2 = x2; p.ld1 = ld1; p.ld2 = ld2; p.K1 = K1;
     p.w_hi = w_hi; p.w_lo = w_lo; p.ldw = ldw; p.bias = bias; p.y = y; p.ldy = ldy; p.res = nullptr; p.ldres = 0; p.c_hi = nullptr; p.c_lo = nullptr;
-    p.coef = coef; p.silu = silu; p.s_hi = s_hi; p.s_lo = s_lo;
+    p.coef = coef; p.silu = silu; p.s_hi = s_hi; p.s_lo = s_lo; p.planes_gm = planes_gm;
     p.M = M; p.N = N; p.K = K; p.HW = HW; p.nimg_tab = skipgn_tab_images(HW);
     return skipgn_launch(p, stream);
 }
@@ -387,7 +397,7 @@ extern "C" int cdae_linear_fwd_stream(const float* x1, long ld1, int K1, const f
     SkipGnParams p;
     p.x1 = x1; p.x2 = x2; p.ld1 = ld1; p.ld2 = ld2; p.K1 = K1;
     p.w_hi = w_hi; p.w_lo = w_lo; p.ldw = ldw; p.bias = bias; p.y = y; p.ldy = ldy; p.res = res; p.ldres = ldres; p.c_hi = c_hi; p.c_lo = c_lo;
-    p.coef = nullptr; p.silu = 0; p.s_hi = nullptr; p.s_lo = nullptr;
+    p.coef = nullptr; p.silu = 0; p.s_hi = nullptr; p.s_lo = nullptr; p.planes_gm = 0;
     p.M = M; p.N = N; p.K = K; p.HW = M; p.nimg_tab = 0;
     return skipgn_launch(p, stream);
 }

@@ -683,10 +683,27 @@ def vb_terms(model_out, x_start, x_t, t, tab, T, mean_type, var_type, clip, free
 class SplitAct:
     """An activation stored as two f16 planes, x = hi + lo (2^-22 relative): what the pre-split GEMM kernel consumes.
     hi / lo are dense [N, H, W, C] half tensors; `shape` is the logical [N, C, H, W]."""
-    __slots__ = ("hi", "lo", "shape")
+    __slots__ = ("hi", "lo", "shape", "gm")
 
-    def __init__(self, hi, lo, shape):
-        self.hi, self.lo, self.shape = hi, lo, tuple(shape)
+    def __init__(self, hi, lo, shape, gm=False):
+        self.hi, self.lo, self.shape, self.gm = hi, lo, tuple(shape), gm
+
+    def pc(self):
+        """The same planes pixel-major ([N, H, W, C]).  gm planes are GROUP-major, [C / 16][N H W][16] — the layout in which the window conv
+        kernel fetches a 16-channel half-window as one contiguous run; every other consumer converts first (small shapes only)."""
+        if not self.gm:
+            return self
+        N, C, H, W = self.shape
+        out = torch.empty((2, N, H, W, C), dtype=torch.float16, device=self.hi.device)
+        check(lib.cdae_planes_gm_to_pc(ptr(self.hi), ptr(self.lo), ptr(out[0]), ptr(out[1]), N * H * W, C, stream()))
+        return SplitAct(out[0], out[1], self.shape)
+
+
+_PLANES_GM = os.environ.get("CDAE_PLANES_GM", "1") != "0"      # dev switch: 0 = pixel-major activation planes everywhere
+
+
+def planes_gm_ok(C):
+    return _PLANES_GM and C % 16 == 0
 
 
 _WSPLIT = {}
@@ -847,10 +864,15 @@ class LazyGN:
         self.x1, self.x2, self.shape, self.stats = x1, x2, tuple(shape), stats
         self.gamma, self.beta, self.ss, self.ld_ss, self.silu, self.groups = gamma, beta, ss, ld_ss, silu, groups
 
-    def planes(self):
+    def planes(self, gm=False):
         N, C, H, W = self.shape
         C1 = self.x1.shape[1]
         planes = torch.empty((2, N, H, W, C), dtype=torch.float16, device=self.x1.device)
+        if gm and planes_gm_ok(C):      # group-major, for a stride-1 conv3x3 on the window kernel
+            check(lib.cdae_gn_apply_split2g(ptr(self.x1), C1, ptr(self.x2), 0 if self.x2 is None else C - C1, C1, ptr(planes[0]), ptr(planes[1]),
+                                            N, H * W, C, self.groups, ptr(self.stats[0]), ptr(self.stats[1]), ptr(self.gamma), ptr(self.beta),
+                                            ptr(self.ss), self.ld_ss, 1 if self.silu else 0, stream()))
+            return SplitAct(planes[0], planes[1], self.shape, gm=True)
         check(lib.cdae_gn_apply_split2(ptr(self.x1), C1, ptr(self.x2), 0 if self.x2 is None else C - C1, C1, ptr(planes[0]), ptr(planes[1]),
                                        N, H * W, C, C, self.groups, ptr(self.stats[0]), ptr(self.stats[1]), ptr(self.gamma), ptr(self.beta),
                                        ptr(self.ss), self.ld_ss, 1 if self.silu else 0, stream()))
@@ -895,7 +917,7 @@ def skip_gn_ok(lz, w):
             and w.shape[0] >= 96 and N * H * W >= 96 and lz.x1.stride(1) == 1)
 
 
-def skip_gn_fused(lz, w, b=None):
+def skip_gn_fused(lz, w, b=None, gm=False):
     """(skip = conv1x1([x1 | x2], w) + b,  SplitAct of silu?(GroupNorm([x1 | x2]))) from ONE pass over the block input: the skip GEMM's
     loader also normalises the rows it stages and writes them as the f16 planes the block's first conv3x3 consumes (no autograd)."""
     N, C, H, W = lz.shape
@@ -908,9 +930,10 @@ def skip_gn_fused(lz, w, b=None):
     y = torch.empty((M, Nf), dtype=torch.float32, device=dev)
     if _SKIPGN_V2 and lib.cdae_skip_gn_ok(M, Nf, C, C1, H * W):      # the HBM-stream kernel on pre-split weight planes
         wh, wl = split_weight(w)
+        gm = bool(gm and planes_gm_ok(C))
         check(lib.cdae_skip_gn_fwd(ptr(lz.x1), C1, C1, ptr(lz.x2), 0 if lz.x2 is None else C - C1, ptr(wh), ptr(wl), C, ptr(b), ptr(y), Nf, ptr(coef),
-                                   1 if lz.silu else 0, ptr(planes[0]), ptr(planes[1]), M, Nf, C, H * W, st))
-        return y.reshape(N, H, W, Nf).permute(0, 3, 1, 2), SplitAct(planes[0], planes[1], lz.shape)
+                                   1 if lz.silu else 0, ptr(planes[0]), ptr(planes[1]), 1 if gm else 0, M, Nf, C, H * W, st))
+        return y.reshape(N, H, W, Nf).permute(0, 3, 1, 2), SplitAct(planes[0], planes[1], lz.shape, gm=gm)
     ws, wsb = _sk(dev)
     check(lib.cdae_linear_fwd_cat_gn(ptr(lz.x1), C1, C1, ptr(lz.x2), 0 if lz.x2 is None else C - C1, ptr(w), C, ptr(b), ptr(y), Nf, ptr(coef),
                                      1 if lz.silu else 0, ptr(planes[0]), ptr(planes[1]), M, Nf, C, H * W, ws, wsb, st))
@@ -1021,6 +1044,7 @@ def fold_upconv_weight(w):
 
 def upconv3x3_ps(xs, w, b=None, gn_stats=False):
     """nearest-2x upsample + conv3x3 of a SplitAct as four 2x2 sub-pixel convolutions (2.25x fewer multiply-adds)."""
+    xs = xs.pc()
     N, Cin, H, W = xs.shape
     Cout = w.shape[0]
     w_hi, w_lo = fold_upconv_weight(w)
@@ -1041,6 +1065,8 @@ def conv3x3_ps(xs, w, b=None, res=None, stride=1, up=False, out_nchw=False, emit
     """conv3x3 of a SplitAct with pre-split OHWI weights (no autograd); result fp32 like ops.conv3x3.  emit_split: the result
     also leaves the kernel as f16 planes, attached as `out._split` for a following conv.  gn_stats: the epilogue also leaves
     per-(32-pixel chunk, channel) partial sums (`out._gnparts`) from which the next GroupNorm takes its statistics."""
+    if xs.gm and (stride != 1 or up or out_nchw):
+        xs = xs.pc()
     if up and not res and not out_nchw and not emit_split:
         return upconv3x3_ps(xs, w, b, gn_stats)
     N, Cin, H, W = xs.shape
@@ -1063,9 +1089,14 @@ def conv3x3_ps(xs, w, b=None, res=None, stride=1, up=False, out_nchw=False, emit
         # the epilogue statistics — the next GroupNorm runs its own (small) statistics pass
         gn_stats = False
     parts = torch.empty(((M + 31) // 32, Cout, 2), dtype=torch.float32, device=dev) if gn_stats else None
-    check(lib.cdae_conv3x3_fwd_psk(ptr(xs.hi), ptr(xs.lo), H * W * Cin, W * Cin, Cin, ptr(w_hi), ptr(w_lo), *_pk(w, False), ptr(b), ptr(res), ptr(out), Cout,
-                                  1 if out_nchw else 0, ptr(planes[0]) if emit_split else None, ptr(planes[1]) if emit_split else None,
-                                  ptr(parts), N, H, W, Cin, Cout, stride, 1 if up else 0, ws, wsb, stream()))
+    def launch(a, gmflag):
+        return lib.cdae_conv3x3_fwd_psg(ptr(a.hi), ptr(a.lo), H * W * Cin, W * Cin, Cin, gmflag, ptr(w_hi), ptr(w_lo), *_pk(w, False), ptr(b), ptr(res), ptr(out), Cout,
+                                        1 if out_nchw else 0, ptr(planes[0]) if emit_split else None, ptr(planes[1]) if emit_split else None,
+                                        ptr(parts), N, H, W, Cin, Cout, stride, 1 if up else 0, ws, wsb, stream())
+    rc = launch(xs, 1 if xs.gm else 0)
+    if rc == 3:                       # group-major planes, but this shape does not run on the window kernel: pixel-major copy, once
+        rc = launch(xs.pc(), 0)
+    check(rc)
     if emit_split:
         out._split = SplitAct(planes[0], planes[1], (N, Cout, Ho, Wo))
     if gn_stats:
@@ -1578,6 +1609,7 @@ def linear_emit(rows, w, b, res, shape):
 
 def linear_ps(xs, w, b=None, res=None, act=ACT_NONE):
     """y = act(rows(xs) @ w^T + b + res) for a SplitAct seen as [N*H*W, C] rows (no autograd)."""
+    xs = xs.pc()
     N, C, H, W = xs.shape
     M, Nf = N * H * W, w.shape[0]
     assert w.numel() == Nf * C and w.is_contiguous()

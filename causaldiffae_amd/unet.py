@@ -173,7 +173,7 @@ class ResBlock(TimestepBlock):
         skip = None
         sk = self.skip_connection
         if isinstance(h, ops.LazyGN) and isinstance(sk, ConvNd) and sk.kernel_size == 1 and ops.skip_gn_ok(h, sk.weight):
-            skip, h = ops.skip_gn_fused(h, sk.weight, sk.bias)     # the 1x1 skip conv writes the normalised planes while it reads x
+            skip, h = ops.skip_gn_fused(h, sk.weight, sk.bias, gm=True)     # the 1x1 skip conv writes the normalised planes (group-major: the next conv is the window kernel) while it reads x
         fast = isinstance(h, (ops.SplitAct, ops.LazyGN))
         h = self.in_layers[2](h, gn_stats=True) if fast else self.in_layers[2](h)     # conv3x3 + bias (+ GroupNorm partial sums)
         if isinstance(emb, EmbAll):

@@ -168,7 +168,7 @@ int cdae_linear_fwd_stream(const float* x1, long ld1, int K1, const float* x2, l
                            long ldw, const float* bias, const float* res, long ldres, float* y, long ldy, unsigned short* c_hi, unsigned short* c_lo,
                            int M, int N, int K, void* stream);      /* c_hi / c_lo (may be NULL): y also as f16 planes, row pitch ldy */
 int cdae_skip_gn_fwd(const float* x1, long ld1, int K1, const float* x2, long ld2, const unsigned short* w_hi, const unsigned short* w_lo, long ldw,
-                     const float* bias, float* y, long ldy, const float* coef, int silu, unsigned short* s_hi, unsigned short* s_lo,
+                     const float* bias, float* y, long ldy, const float* coef, int silu, unsigned short* s_hi, unsigned short* s_lo, int planes_gm,
                      int M, int N, int K, int HW, void* stream);
 /* two-source forms: channels [0, C1) are read from x1 (pixel pitch ld1), channels [C1, C) from x2 (pitch ld2) — the skip
    concatenation th.cat([h, hs.pop()], dim=1) (unet.py:629) consumed in place instead of being copied; x2 == NULL: one source */
@@ -177,6 +177,18 @@ int cdae_gn_stats2(const float* x1, int ld1, const float* x2, int ld2, int C1, i
 int cdae_gn_apply_split2(const float* x, int ldx, const float* x2, int ld2, int C1, unsigned short* y_hi, unsigned short* y_lo, int N, int HW,
                          int C, int ldy, int groups, const float* mean, const float* rstd, const float* gamma, const float* beta,
                          const float* scale_shift, int ld_ss, int silu, void* stream);
+/* GROUP-MAJOR activation planes, [C / 16][N H W][16] instead of [N H W][C]: every 16-channel half-window of the window conv kernel is then
+   one contiguous run (8 cache lines per DMA instead of 32).  cdae_gn_apply_split2g writes them (also cdae_skip_gn_fwd with planes_gm = 1),
+   cdae_conv3x3_fwd_psg reads them with x_gm = 1 — or returns 3, with no error set, when that shape does not run on the window kernel: the
+   caller then converts with cdae_planes_gm_to_pc and calls again with x_gm = 0. */
+int cdae_gn_apply_split2g(const float* x, int ldx, const float* x2, int ld2, int C1, unsigned short* y_hi, unsigned short* y_lo, int N, int HW,
+                          int C, int groups, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                          const float* scale_shift, int ld_ss, int silu, void* stream);
+int cdae_planes_gm_to_pc(const unsigned short* a_hi, const unsigned short* a_lo, unsigned short* o_hi, unsigned short* o_lo, long P, int C, void* stream);
+int cdae_conv3x3_fwd_psg(const unsigned short* x_hi, const unsigned short* x_lo, long sn, long sy, long sx, int x_gm, const unsigned short* w_hi,
+                         const unsigned short* w_lo, const unsigned short* wk_hi, const unsigned short* wk_lo, const float* bias, const float* res,
+                         float* out, long ldo, int out_nchw, unsigned short* out_hi, unsigned short* out_lo, float* gn_part, int N, int H, int W,
+                         int Cin, int Cout, int stride, int up, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
 int cdae_gn_apply_split(const float* x, unsigned short* y_hi, unsigned short* y_lo, int N, int HW, int C, int ldx, int ldy, int groups,
                         const float* mean, const float* rstd, const float* gamma, const float* beta, const float* scale_shift, int ld_ss,
                         int silu, void* stream);

@@ -72,6 +72,43 @@ def test_linear_stream_kernel(M, N, K, bias, res):
         assert torch.equal(planes.hi.reshape(-1, N), hi) and torch.equal(planes.lo.reshape(-1, N), (y - hi.float()).half())
 
 
+@pytest.mark.parametrize("N,C1,C2,Cout,S", [(128, 128, 0, 128, 32), (32, 256, 128, 256, 32), (8, 128, 128, 128, 64), (96, 512, 384, 512, 8), (4, 128, 0, 128, 16)])
+def test_group_major_planes(N, C1, C2, Cout, S):
+    """Group-major activation planes ([C / 16][pixels][16]: the window conv kernel's contiguous half-windows): written by the GroupNorm apply
+    kernel and by the entry sweep, they hold exactly the pixel-major planes' values (cdae_planes_gm_to_pc), and the conv on them equals the
+    conv on the pixel-major planes bit for bit — on the window kernel, on split-K tiles and where the shape falls back to another kernel."""
+    from causaldiffae_amd import ops
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(51)
+    a = ops.to_nhwc(torch.randn(N, C1, S, S, device=dev, generator=g))
+    x = ops.CatAct(a, ops.to_nhwc(torch.randn(N, C2, S, S, device=dev, generator=g))) if C2 else a
+    C = C1 + C2
+    gamma, beta = 1 + 0.1 * torch.randn(C, device=dev, generator=g), 0.1 * torch.randn(C, device=dev, generator=g)
+    w = (torch.randn(Cout, C, 3, 3, device=dev, generator=g) / (3 * C ** 0.5)).contiguous(memory_format=torch.channels_last)
+    b = 0.1 * torch.randn(Cout, device=dev, generator=g)
+    res = ops.to_nhwc(torch.randn(N, Cout, S, S, device=dev, generator=g))
+    with torch.no_grad():
+        lz = ops.group_norm_lazy(x, gamma, beta, None, True, 32, 1e-5)
+        pc, gm = lz.planes(), lz.planes(gm=True)
+        assert gm.gm and not pc.gm
+        back = gm.pc()
+        assert torch.equal(back.hi, pc.hi) and torch.equal(back.lo, pc.lo)
+        y_pc = ops.conv3x3_ps(pc, w, b, res=res, gn_stats=True)
+        y_gm = ops.conv3x3_ps(gm, w, b, res=res, gn_stats=True)
+        assert torch.equal(y_pc, y_gm)
+        if hasattr(y_pc, "_gnparts"):
+            assert torch.equal(y_pc._gnparts, y_gm._gnparts)
+        assert torch.equal(ops.conv3x3_ps(gm, w, b, stride=2), ops.conv3x3_ps(pc, w, b, stride=2))       # converted on the way
+        if C2 or C != Cout:
+            ws = torch.randn(Cout, C, 1, 1, device=dev, generator=g) / C ** 0.5
+            if ops.skip_gn_ok(lz, ws):
+                s1, p1 = ops.skip_gn_fused(lz, ws, b)
+                s2, p2 = ops.skip_gn_fused(lz, ws, b, gm=True)
+                assert p2.gm and torch.equal(s1, s2)
+                q = p2.pc()
+                assert torch.equal(q.hi, p1.hi) and torch.equal(q.lo, p1.lo)
+
+
 def test_linear_backward():
     from causaldiffae_amd import ops
     M, N, K = 260, 384, 512
