@@ -285,14 +285,19 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
 // four lanes per pixel (16 B of x each) and 64 consecutive pixels per pass, so a wave's plane store is 16 pixels x 32 B = one contiguous
 // 512-byte run (with the channel-vector mapping of gn_apply_kernel the same layout is 32-byte pieces 16 KB apart: 1.34 -> 1.76 ms per
 // DDIM step).  Same per-element arithmetic (folded affine, cdae_silu, opaque before the split): bit-identical values.
+template <int GPB>
 __global__ __launch_bounds__(256) void gn_apply_gm_kernel(const float* __restrict__ x, int HW, int C, int ldx, int cpg, int G, int pix_per_block,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ ss, int ld_ss, int do_silu,
                                                           unsigned short* __restrict__ y_hi, unsigned short* __restrict__ y_lo,
                                                           const float* __restrict__ x2, int ld2, int C1) {
-    const int n = blockIdx.z, pg = blockIdx.x, tid = threadIdx.x;      // plane group fastest: the C / 16 blocks that read the same pixels' lines run together
-    const int ch4 = tid & 3, pl = tid >> 2;
+    // GPB plane groups per block: with two, the eight lanes of a pixel read one whole 128-byte line (32 channels) and a wave stores two runs of
+    // 256 contiguous bytes; with one (C % 32 != 0), 64-byte reads and one 512-byte run
+    constexpr int LPP = 4 * GPB, PPB = 256 / LPP;                      // lanes per pixel, pixels per pass
+    const int n = blockIdx.z, tid = threadIdx.x;                      // plane groups fastest: the blocks that read the same pixels' lines run together
+    const int lp = tid % LPP, pl = tid / LPP;
+    const int pg = blockIdx.x * GPB + lp / 4, ch4 = lp & 3;
     const int c = pg * 16 + ch4 * 4, g = c / cpg;
     const float mu = mean[n * G + g], rs = rstd[n * G + g];
     float A[4], B[4];
@@ -324,14 +329,14 @@ __global__ __launch_bounds__(256) void gn_apply_gm_kernel(const float* __restric
         *reinterpret_cast<gn_half4*>(ol + (long)pp * 16) = lo;
     };
     int p = p0 + pl;
-    for (; p + 3 * 64 < p1; p += 4 * 64) {
+    for (; p + 3 * PPB < p1; p += 4 * PPB) {
         const float4 v0 = *reinterpret_cast<const float4*>(xp + (long)p * ld);
-        const float4 v1 = *reinterpret_cast<const float4*>(xp + (long)(p + 64) * ld);
-        const float4 v2 = *reinterpret_cast<const float4*>(xp + (long)(p + 128) * ld);
-        const float4 v3 = *reinterpret_cast<const float4*>(xp + (long)(p + 192) * ld);
-        put(p, v0); put(p + 64, v1); put(p + 128, v2); put(p + 192, v3);
+        const float4 v1 = *reinterpret_cast<const float4*>(xp + (long)(p + PPB) * ld);
+        const float4 v2 = *reinterpret_cast<const float4*>(xp + (long)(p + 2 * PPB) * ld);
+        const float4 v3 = *reinterpret_cast<const float4*>(xp + (long)(p + 3 * PPB) * ld);
+        put(p, v0); put(p + PPB, v1); put(p + 2 * PPB, v2); put(p + 3 * PPB, v3);
     }
-    for (; p < p1; p += 64) put(p, *reinterpret_cast<const float4*>(xp + (long)p * ld));
+    for (; p < p1; p += PPB) put(p, *reinterpret_cast<const float4*>(xp + (long)p * ld));
 }
 
 // ------------------------------------------------------------------ GroupNorm backward
@@ -1100,12 +1105,15 @@ static int gn_apply_split_impl(const float* x, int ldx, const float* x2, int ld2
     cdae_prof_begin(PROF_GN, (double)N * HW * C * 8.0, st);
     static const int cfg_gmk = getenv("CDAE_GN_APPLY_GM") ? atoi(getenv("CDAE_GN_APPLY_GM")) : 1;      // 0: group-major planes from the channel-vector kernel
     if (plane_gm && cfg_gmk && !yb_hi && (!x2 || C1 % 16 == 0) && N <= 65535) {
-        int nch = HW / 256;                          // >= 4 pixels per thread
+        const int gpb = (C % 32 == 0 && (!x2 || C1 % 32 == 0)) ? 2 : 1;
+        int nch = HW / (gpb == 2 ? 128 : 256);       // >= 4 pixels per thread
         if (nch < 1) nch = 1;
-        while (nch > 1 && (long)nch * N * (C / 16) > 16384) nch >>= 1;
+        while (nch > 1 && (long)nch * N * (C / 16 / gpb) > 16384) nch >>= 1;
         const int pp = (HW + nch - 1) / nch;
-        hipLaunchKernelGGL(gn_apply_gm_kernel, dim3(C / 16, nch, N), dim3(256), 0, st, x, HW, C, ldx, cpg, groups, pp, mean, rstd, gamma, beta, scale_shift,
-                           ld_ss, silu, y_hi, y_lo, x2, ld2, C1);
+        if (gpb == 2) hipLaunchKernelGGL(gn_apply_gm_kernel<2>, dim3(C / 32, nch, N), dim3(256), 0, st, x, HW, C, ldx, cpg, groups, pp, mean, rstd, gamma, beta,
+                                         scale_shift, ld_ss, silu, y_hi, y_lo, x2, ld2, C1);
+        else hipLaunchKernelGGL(gn_apply_gm_kernel<1>, dim3(C / 16, nch, N), dim3(256), 0, st, x, HW, C, ldx, cpg, groups, pp, mean, rstd, gamma, beta, scale_shift,
+                                ld_ss, silu, y_hi, y_lo, x2, ld2, C1);
     } else
     hipLaunchKernelGGL((gn_apply_kernel<4, true>), dim3(nchunk, N), dim3(256), 0, st, x, (float*)nullptr, HW, C, ldx, ldy, cpg, groups, ppb, mean, rstd,
                        gamma, beta, scale_shift, ld_ss, silu, y_hi, y_lo, x2, ld2, C1, yb_hi, yb_lo, plane_gm);
