@@ -1,5 +1,7 @@
 #!/bin/bash
-timeout 300 python3 -m pytest tests/test_gpu_kernels.py -x -q -k "group_major or group_norm" 2>&1 | tail -1
-for R in 1 2; do for G in 0 1; do
-  echo "== CDAE_PLANES_GM=$G"; CDAE_PLANES_GM=$G timeout 300 python3 bench.py --no-cpu-baseline --no-train --no-fp32 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d['roofline']['frac'], d['roofline']['family_ms_per_step']['groupnorm'])"
+cp causaldiffae_amd/libcdae.so /tmp/keep.so; cp gpurun_ab_libD.so causaldiffae_amd/libcdae.so
+for A in "" "--gm"; do for D in 0 16 4 0; do
+  echo "== planes '$A' CDAE_PS_DBG=$D"
+  CDAE_PS_DBG=$D timeout 120 python3 tools/prof_shapes.py --time $A 2>&1 | grep -E "128->128 @64|256->256 @32|384->384 @16"
 done; done
+cp /tmp/keep.so causaldiffae_amd/libcdae.so

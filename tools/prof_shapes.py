@@ -20,6 +20,9 @@ if __name__ == "__main__":
         planes = torch.empty((2, B, r, r, ci), dtype=torch.float16, device="cuda:0")
         check(lib.cdae_split_f16(ptr(x), ptr(planes[0]), ptr(planes[1]), x.numel(), stream()))
         xs = ops.SplitAct(planes[0], planes[1], (B, ci, r, r))
+        if "--gm" in sys.argv:           # group-major planes, as the model's GroupNorm apply / entry sweep write them for these convs
+            with torch.no_grad():
+                xs = ops.group_norm_lazy(x, torch.ones(ci, device="cuda:0"), torch.zeros(ci, device="cuda:0"), None, True, 32, 1e-5).planes(gm=True)
         w = (torch.randn(co, ci, 3, 3, device="cuda:0") / (9 * ci) ** .5).contiguous(memory_format=torch.channels_last)
         b = torch.randn(co, device="cuda:0")
         res = ops.to_nhwc(torch.randn(B, co, r, r, device="cuda:0")) if with_res else None
