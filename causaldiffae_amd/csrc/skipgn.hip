@@ -21,6 +21,10 @@
 #ifndef SG_NT
 #define SG_NT 0
 #endif
+// SG_DEPTH: how many 32-channel steps ahead the x rows are requested (2 or 3 register sets of 16 VGPRs)
+#ifndef SG_DEPTH
+#define SG_DEPTH 2
+#endif
 #if SG_NT & 1
 #define SG_NT_LD " nt"
 #else
@@ -130,6 +134,9 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
     // s_waitcnt at the top of a step, which names the registers so that no use can move above it.
     typedef float f4 __attribute__((ext_vector_type(4)));
     f4 c00, c01, c10, c11, n00, n01, n10, n11;                         // [row pass][half]: x of an even / an odd step
+#if SG_DEPTH == 3
+    f4 m00, m01, m10, m11;                                             // third set: x is requested three steps ahead
+#endif
 #define SG_LOAD_X(A0, A1, B0, B1, KK)                                                                                      \
     {                                                                                                                      \
         const bool first = (KK) < p.K1; /* block-uniform: a step never straddles the two sources */                        \
@@ -143,7 +150,8 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
 #define SG_WAIT_X(CNT, A0, A1, B0, B1)                                                                                     \
     asm volatile("s_cmp_lg_u32 %4, 0\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(0)\n\ts_branch 3f\n"                           \
                  "1:\n\ts_cmp_lg_u32 %4, 4\n\ts_cbranch_scc1 2f\n\ts_waitcnt vmcnt(4)\n\ts_branch 3f\n"                      \
-                 "2:\n\ts_waitcnt vmcnt(8)\n3:"                                                                           \
+                 "2:\n\ts_cmp_lg_u32 %4, 8\n\ts_cbranch_scc1 4f\n\ts_waitcnt vmcnt(8)\n\ts_branch 3f\n"                      \
+                 "4:\n\ts_waitcnt vmcnt(12)\n3:"                                                                          \
                  : "+v"(A0), "+v"(A1), "+v"(B0), "+v"(B1) : "s"(CNT) : "memory", "scc")
 
     // ---- prologue: coefficient table, the first two x steps, first weight step
@@ -178,7 +186,9 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
         u16x8 nh[2], nl[2];                                            // the normalised rows, split
         if (live) {
         // (a partial row tile skips some plane stores: no fixed count)
-        const int cnt = __builtin_amdgcn_readfirstlane((kt == 0 || !full_rows) ? 0 : (more1 ? 4 : 0) + (writes_planes ? 4 : 0));
+        // younger than the weight DMAs of this step (issued in step kt - 1): the x loads that step issued behind them — those of step
+        // kt - 1 + SG_DEPTH — and its plane stores
+        const int cnt = __builtin_amdgcn_readfirstlane((kt == 0 || !full_rows) ? 0 : (kt - 1 + SG_DEPTH < nk ? 4 : 0) + (writes_planes ? 4 : 0));
         SG_WAIT_X(cnt, x0a, x0b, x1a, x1b);
         {
             u16x8 hi, lo;
@@ -223,9 +233,10 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
         __syncthreads();                                               // stage st complete; nobody reads stage st ^ 1 any more
         if (more1) issue_b(st ^ 1, k + SG_BK);
         } else if (kt == -1) issue_b(0, 0);
+        // (distance 3: at the top of step 1 the loads of step 2 AND 3 are younger than its weights; the lead-in issues x 0, 1, 2 then)
         // ONE load statement per register set for lead-in and steady state alike: a second definition would meet this one in a phi node,
         // i.e. possibly in v_mov copies of registers whose data has not landed (seen when the allocation changed: silent corruption)
-        if (kt + 2 < nk) SG_LOAD_X(x0a, x0b, x1a, x1b, k + 2 * SG_BK);
+        if (kt + SG_DEPTH < nk) SG_LOAD_X(x0a, x0b, x1a, x1b, k + SG_DEPTH * SG_BK);
         if (!live) return;
         if (writes_planes) {
 #pragma unroll
@@ -272,13 +283,22 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
     // every x load is issued by the two statements inside this loop — and the loop must stay ONE copy: when hipcc peels the lead-in
     // iterations, the peeled loads get registers of their own and the values reach the loop through v_mov copies of data still in flight
     // (the start value is made opaque: with a visible -2 the "kt < 0" iterations are peeled)
-    int kt_first = -2;
+    int kt_first = -SG_DEPTH;
     asm volatile("" : "+s"(kt_first));
+#if SG_DEPTH == 3
+#pragma clang loop unroll(disable)
+    for (int kt = kt_first; kt < nk; kt += 3) {                        // (stage = step parity: a run-time value here)
+        step(c00, c01, c10, c11, kt, kt & 1);
+        if (kt + 1 < nk) step(n00, n01, n10, n11, kt + 1, (kt + 1) & 1);
+        if (kt + 2 < nk) step(m00, m01, m10, m11, kt + 2, kt & 1);
+    }
+#else
 #pragma clang loop unroll(disable)
     for (int kt = kt_first; kt < nk; kt += 2) {
         step(c00, c01, c10, c11, kt, 0);
         if (kt + 1 < nk) step(n00, n01, n10, n11, kt + 1, 1);
     }
+#endif
 
     // ---- epilogue: y = acc + bias (row-major fp32)
     bool bad = false;
