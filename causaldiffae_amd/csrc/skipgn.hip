@@ -21,6 +21,10 @@
 #ifndef SG_NT
 #define SG_NT 0
 #endif
+// SG_ABL (dev ablations, timing only): 1 no output stores, 2 no plane stores, 4 no MFMAs, 8 no normalisation arithmetic
+#ifndef SG_ABL
+#define SG_ABL 0
+#endif
 // SG_DEPTH: how many 32-channel steps ahead the x rows are requested (2 or 3 register sets of 16 VGPRs)
 #ifndef SG_DEPTH
 #define SG_DEPTH 2
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
                     ys[2 * e] = fmaf(xs[2 * e], cf[q][e].x, cf[q][e].y);
                     ys[2 * e + 1] = fmaf(xs[2 * e + 1], cf[q][e].z, cf[q][e].w);
                 }
-                if (p.silu) {
+                if (p.silu && !(SG_ABL & 8)) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) ys[e] = cdae_silu(ys[e]);
                 }
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
         // i.e. possibly in v_mov copies of registers whose data has not landed (seen when the allocation changed: silent corruption)
         if (kt + SG_DEPTH < nk) SG_LOAD_X(x0a, x0b, x1a, x1b, k + SG_DEPTH * SG_BK);
         if (!live) return;
-        if (writes_planes) {
+        if (writes_planes && !(SG_ABL & 2)) {
 #pragma unroll
             for (int q = 0; q < 2; ++q)
                 if (rok[q]) {
@@ -274,6 +278,7 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
+                    if (SG_ABL & 4) { acc[i][j][0] += __builtin_bit_cast(float, (unsigned)(al[i][0] ^ bh[j][0] ^ ah[i][1] ^ bl[j][1])); continue; }
                     acc[i][j] = mma(al[i], bh[j], acc[i][j]);
                     acc[i][j] = mma(ah[i], bl[j], acc[i][j]);
                     acc[i][j] = mma(ah[i], bh[j], acc[i][j]);
@@ -325,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     vv[r] = (acc[i][j][r] + bv[j]) + rv[r];
-                    dst[(long)((r & 3) + 8 * (r >> 2)) * p.ldy] = vv[r];
+                    if (!(SG_ABL & 1) || vv[r] == 1.2345e30f) dst[(long)((r & 3) + 8 * (r >> 2)) * p.ldy] = vv[r];
                     bad |= !__builtin_isfinite(vv[r]);
                 }
                 if (p.c_hi) {
