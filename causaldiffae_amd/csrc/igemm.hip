@@ -1585,6 +1585,18 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
         ks = (int)((512 + tiles - 1) / tiles);
         if (ks > nk / 4) ks = nk / 4;
         if (ks > 64) ks = 64;
+        // 128 x 128 tiles run two blocks per CU (512 slots): 96 tiles x 6 splits = 576 blocks need a second, nearly empty round where
+        // x 5 = 480 do not.  Smallest rounds x (K-steps per split + ~8 steps of prologue / epilogue); CDAE_KS_ROUNDS=0: plain ceil
+        static const int cfg_rounds = getenv("CDAE_KS_ROUNDS") ? atoi(getenv("CDAE_KS_ROUNDS")) : 1;
+        if (cfg_rounds && big && ks > 1) {
+            long best_cost = -1; int best = 1;
+            for (int k = 1; k <= ks; ++k) {
+                const int per = (nk + k - 1) / k, kk = (nk + per - 1) / per;
+                const long cost = ((tiles * kk + 511) / 512) * (per + 8);
+                if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = kk; }      // kk: no empty splits
+            }
+            ks = best;
+        }
         size_t need = (size_t)ks * p.batch * p.M * p.N * sizeof(float);
         while (ks > 1 && need > p.splitk_ws_bytes) { --ks; need = (size_t)ks * p.batch * p.M * p.N * sizeof(float); }
         if (ks < 1) ks = 1;
@@ -1646,6 +1658,7 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
                     int k2 = (int)(512 / cw_tiles);
                     if (k2 > nchunk / 2) k2 = nchunk / 2;          // at least two chunks = 18 K-steps per split
                     while (k2 > 1 && (size_t)k2 * p.M * p.N * sizeof(float) > p.splitk_ws_bytes) --k2;
+                    if (k2 > 1) { const int c_per = (nchunk + k2 - 1) / k2; k2 = (nchunk + c_per - 1) / c_per; }      // 12 chunks over 5 splits are 3 + 3 + 3 + 3 + 0: no empty slabs
                     if (k2 > 1) kbest = k2;
                 }
                 if (cw_tiles * kbest >= cfg_cw_min) p.ksplit = ks = kbest;

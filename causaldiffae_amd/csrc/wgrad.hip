@@ -441,9 +441,23 @@ extern "C" int cdae_conv3x3_wgrad_win(const unsigned short* a_hi, const unsigned
     const long tiles = (long)(Cin / 64) * (Cout / 64);
     const size_t slab = (size_t)Cout * 9 * Cin * sizeof(float);
     static const int cfg_blocks = getenv("CDAE_WG_BLOCKS") ? atoi(getenv("CDAE_WG_BLOCKS")) : 256;      // grid target: one block per CU (measured 256 / 512 / 768: 39.6 / 39.7-40.9 / 40.6-43.2 ms per training step)
+    // K split: one block per CU fits (84-134 KB of LDS), so a grid of more than cfg_blocks runs in ROUNDS: 36 tiles x 8 splits = 288
+    // blocks take two rounds of steps / 8, x 7 = 252 blocks one round of steps / 7.  Pick the split with the smallest
+    // rounds x (steps per block + the fixed prologue / epilogue / finish, about twelve steps' worth); CDAE_WG_KS_CEIL=1 restores ceil(256 / tiles).
+    static const int cfg_ceil = getenv("CDAE_WG_KS_CEIL") ? atoi(getenv("CDAE_WG_KS_CEIL")) : 0;
     int ks = (int)((cfg_blocks + tiles - 1) / tiles);
     if (ks > p.steps) ks = p.steps;
     while (ks > 1 && (!splitk_ws || (size_t)ks * slab > splitk_ws_bytes)) --ks;
+    if (!cfg_ceil && ks > 1) {
+        long best_cost = -1; int best = 1;
+        for (int k = 1; k <= ks; ++k) {
+            const int sp = (p.steps + k - 1) / k, kk = (p.steps + sp - 1) / sp;
+            const long rounds = (tiles * kk + cfg_blocks - 1) / cfg_blocks;
+            const long cost = rounds * (sp + 12);
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = k; }
+        }
+        ks = best;
+    }
     p.steps_per = (p.steps + ks - 1) / ks;
     ks = (p.steps + p.steps_per - 1) / p.steps_per;    // no empty blocks
     p.ksplit = ks; p.accumulate = accumulate;
