@@ -88,6 +88,8 @@ enum { PROF_IGEMM = 0, PROF_GN = 1, PROF_SOFTMAX = 2, PROF_ELEMWISE = 3, PROF_OP
 void cdae_prof_begin(int family, double work, hipStream_t st);
 void cdae_prof_end(int family, hipStream_t st);
 void cdae_prof_note(int family, double bytes);
+void cdae_prof_tag(const char* tag);
+bool cdae_prof_on();
 int* cdae_range_flag_ptr();      // device-visible int[1], see GemmParams::range_flag
 
 // LDS-DMA (global_load_lds_dwordx4) issued through inline assembly: lane l's 16 bytes at `src` land at LDS byte address

@@ -1548,6 +1548,14 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
     }
     if (p.force_tile == 64) big = 0;
     if (p.force_tile == 128) big = 1;
+    static const bool cfg_dev = getenv("CDAE_GEMM_DEV") != nullptr;          // dev sweeps (tools/gemm_sweep.py): tile and split from the environment, per call
+    if (cfg_dev && !p.presplit) {
+        const char* e = getenv("CDAE_TILE_FORCE");
+        if (e && atoi(e) == 64) big = 0;
+        if (e && atoi(e) == 128 && p.M >= 96 && p.N >= 96) big = 1;
+        e = getenv("CDAE_KS_FORCE");
+        if (e && atoi(e) > 0 && p.ksplit_auto && p.splitk_ws) p.ksplit_force = atoi(e);
+    }
     static const int cfg_waves8 = getenv("CDAE_IGEMM_WAVES8") ? atoi(getenv("CDAE_IGEMM_WAVES8")) : 1;   // 8-wave 128x128 tiles by default
     p.waves8 = cfg_waves8;
     // precision: fp32 mode -> fp32 MFMA everywhere; split mode -> f16x3 for activation x weight GEMMs, bf16x3 when an
@@ -1584,15 +1592,16 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
     if (p.ksplit_auto && p.splitk_ws && tiles < cfg_mintiles && nk >= cfg_minnk) {
         ks = (int)((512 + tiles - 1) / tiles);
         if (ks > nk / 4) ks = nk / 4;
-        if (ks > 64) ks = 64;
+        if (ks > 128) ks = 128;             // (a 128 x 128 weight gradient over 131072 pixels: 64 splits 77 us, 128 splits 60 us)
         // 128 x 128 tiles run two blocks per CU (512 slots): 96 tiles x 6 splits = 576 blocks need a second, nearly empty round where
-        // x 5 = 480 do not.  Smallest rounds x (K-steps per split + ~8 steps of prologue / epilogue); CDAE_KS_ROUNDS=0: plain ceil
+        // x 5 = 480 do not.  Smallest rounds x (K-steps per split + ~8 steps of prologue / epilogue) + finish; CDAE_KS_ROUNDS=0: plain ceil
         static const int cfg_rounds = getenv("CDAE_KS_ROUNDS") ? atoi(getenv("CDAE_KS_ROUNDS")) : 1;
         if (cfg_rounds && big && ks > 1) {
             long best_cost = -1; int best = 1;
             for (int k = 1; k <= ks; ++k) {
                 const int per = (nk + k - 1) / k, kk = (nk + per - 1) / per;
-                const long cost = ((tiles * kk + 511) / 512) * (per + 8);
+                // a split also pays for the finish launch and the slab round trip: measured ~7 us = a dozen K-steps (8192 x 384 x 384: 22 us unsplit, 29 us in two)
+                const long cost = ((tiles * kk + 511) / 512) * (per + 8) + (kk > 1 ? 12 + kk / 4 : 0);
                 if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = kk; }      // kk: no empty splits
             }
             ks = best;
@@ -1609,6 +1618,12 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
         return cdae_fail("GroupNorm partial sums from the epilogue need a pre-split, unsplit-K, row-major, non-accumulating launch");
 
     cdae_prof_begin(PROF_IGEMM, 2.0 * p.M * p.N * (double)p.K * p.batch * (p.nphase > 1 ? p.nphase : 1), st);
+    if (cdae_prof_on()) {
+        char tag[128];
+        snprintf(tag, sizeof(tag), "gemm M=%d N=%d K=%d b=%d a%d b%d %s ks=%d prec=%d ps=%d taps=%d", p.M, p.N, p.K, p.batch, p.amode, p.bmode, big ? "128" : "64", ks, p.prec,
+                 p.presplit, p.ps_taps);
+        cdae_prof_tag(tag);
+    }
     int rc = -1;
 #define CASE(AM, BM_) if (p.amode == AM && p.bmode == BM_) rc = launch_tiles<AM, BM_>(p, big, scalar, st)
     if (p.presplit) {

@@ -499,10 +499,9 @@ __global__ __launch_bounds__(256) void gn_bwd_fold_kernel(int N, int HW, int C, 
 }
 
 // Pass 2b: dgamma[c] (+)= sum_n, dbeta[c] (+)= sum_n.  grid C/32, 256 threads = 8 image lanes x 32 channels (fixed fold order)
-__global__ __launch_bounds__(256) void gn_bwd_param8_kernel(int N, int C, const float* __restrict__ nc_part, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int accumulate) {
-    __shared__ double sA[8][32], sB[8][32];
-    const int cc = threadIdx.x & 31, nl = threadIdx.x >> 5, c = blockIdx.x * 32 + cc;
+__device__ __forceinline__ void gn_bwd_param8_block(int cblock, int N, int C, const float* __restrict__ nc_part, float* __restrict__ dgamma,
+                                                    float* __restrict__ dbeta, int accumulate, double (*sA)[32], double (*sB)[32]) {
+    const int cc = threadIdx.x & 31, nl = threadIdx.x >> 5, c = cblock * 32 + cc;
     double a = 0, b = 0;
     if (c < C)
         for (int n = nl; n < N; n += 8) { const float2 v = *reinterpret_cast<const float2*>(nc_part + ((long)n * C + c) * 2); a += v.x; b += v.y; }
@@ -515,6 +514,12 @@ __global__ __launch_bounds__(256) void gn_bwd_param8_kernel(int N, int C, const 
         dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)a;
         dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)b;
     }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_param8_kernel(int N, int C, const float* __restrict__ nc_part, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int accumulate) {
+    __shared__ double sA[8][32], sB[8][32];
+    gn_bwd_param8_block(blockIdx.x, N, C, nc_part, dgamma, dbeta, accumulate, sA, sB);
 }
 
 __global__ void gn_bwd_param_kernel(int N, int C, const float* __restrict__ nc_part, float* __restrict__ dgamma,
@@ -613,7 +618,17 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_stream_kernel(const float* __re
                                                                 const float* __restrict__ dx_add, int ld_add,
                                                                 unsigned short* __restrict__ dxb_hi, unsigned short* __restrict__ dxb_lo,
                                                                 const float* __restrict__ x2, int ld2, int C1,
-                                                                float* __restrict__ dx2, int lddx2) {
+                                                                float* __restrict__ dx2, int lddx2,
+                                                                int N, const float* __restrict__ nc_part, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta, int accumulate_params) {
+    if ((int)blockIdx.y == N) {       // (nc_part != nullptr) one extra row of blocks: pass 2b, dgamma / dbeta = the per-image sums folded over the batch
+        __shared__ double sA[8][32], sB[8][32];
+        for (int cb = blockIdx.x; cb * 32 < C; cb += gridDim.x) {
+            if (cb != (int)blockIdx.x) __syncthreads();
+            gn_bwd_param8_block(cb, N, C, nc_part, dgamma, dbeta, accumulate_params, sA, sB);
+        }
+        return;
+    }
     const int n = blockIdx.y, chunk = blockIdx.x;
     const int E = C / 4, rows = 256 / E, tid = threadIdx.x;
     const int r = tid / E, e = tid - r * E;
@@ -963,12 +978,19 @@ static int gn_bwd_impl(const float* x, const float* x2, int ld2, int C1, const f
     if (VEC == 4) hipLaunchKernelGGL(gn_bwd_partial_kernel<4>, dim3(nchunk, N), dim3(256), 0, st, x, dy, HW, C, ldx, lddy, cpg, groups, ppb, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gpart, cpart, x2, ld2, C1);
     else hipLaunchKernelGGL(gn_bwd_partial_kernel<1>, dim3(nchunk, N), dim3(256), 0, st, x, dy, HW, C, ldx, lddy, cpg, groups, ppb, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gpart, cpart, x2, ld2, C1);
     hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3((C + 63) / 64 + 1, N), dim3(256), 0, st, N, HW, C, cpg, groups, nchunk, gpart, cpart, gsum, d_scale_shift, ld_dss, ncp);
-    if (N >= 8) hipLaunchKernelGGL(gn_bwd_param8_kernel, dim3((C + 31) / 32), dim3(256), 0, st, N, C, ncp, dgamma, dbeta, accumulate_params);
-    else hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, st, N, C, ncp, dgamma, dbeta, accumulate_params);
     static const int cfg_dxs = getenv("CDAE_GN_BWD_STREAM") ? atoi(getenv("CDAE_GN_BWD_STREAM")) : 1;
-    if (VEC == 4 && cfg_dxs && E <= 256 && (!accumulate_dx || dx))
-        hipLaunchKernelGGL(gn_bwd_dx_stream_kernel, dim3(nchunk, N), dim3(256), 0, st, x, dy, dx, HW, C, ldx, lddy, lddx, cpg, groups, ppb, mean, rstd, gamma, beta,
-                           scale_shift, ld_ss, silu, gsum, accumulate_dx, dx_add, ld_add, dxb_hi, dxb_lo, x2, ld2, C1, dx2, lddx2);
+    const bool dx_stream = VEC == 4 && cfg_dxs && E <= 256 && (!accumulate_dx || dx);
+    // pass 2b (dgamma / dbeta over the batch) rides along as one extra row of blocks of the streaming dx launch (it only needs pass 2a's
+    // per-image sums, like dx): one launch less per GroupNorm, 56 per C64 training step; CDAE_GN_BWD_PARAM_ROW=0: its own launch
+    static const int cfg_prow = getenv("CDAE_GN_BWD_PARAM_ROW") ? atoi(getenv("CDAE_GN_BWD_PARAM_ROW")) : 1;
+    const bool param_row = dx_stream && cfg_prow && N >= 8;
+    if (param_row) {}
+    else if (N >= 8) hipLaunchKernelGGL(gn_bwd_param8_kernel, dim3((C + 31) / 32), dim3(256), 0, st, N, C, ncp, dgamma, dbeta, accumulate_params);
+    else hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, st, N, C, ncp, dgamma, dbeta, accumulate_params);
+    if (dx_stream)
+        hipLaunchKernelGGL(gn_bwd_dx_stream_kernel, dim3(nchunk, param_row ? N + 1 : N), dim3(256), 0, st, x, dy, dx, HW, C, ldx, lddy, lddx, cpg, groups, ppb, mean, rstd,
+                           gamma, beta, scale_shift, ld_ss, silu, gsum, accumulate_dx, dx_add, ld_add, dxb_hi, dxb_lo, x2, ld2, C1, dx2, lddx2,
+                           param_row ? N : -1, ncp, dgamma, dbeta, accumulate_params);
     else if (VEC == 4) hipLaunchKernelGGL(gn_bwd_dx_kernel<4>, dim3(grid_for(total)), dim3(256), 0, st, x, dy, dx, total, HW, C, ldx, lddy, lddx, cpg, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gsum, accumulate_dx, dx_add, ld_add, dxb_hi, dxb_lo, x2, ld2, C1, dx2, lddx2);
     else hipLaunchKernelGGL(gn_bwd_dx_kernel<1>, dim3(grid_for(total)), dim3(256), 0, st, x, dy, dx, total, HW, C, ldx, lddy, lddx, cpg, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gsum, accumulate_dx, dx_add, ld_add, nullptr, nullptr, x2, ld2, C1, dx2, lddx2);
     cdae_prof_end(PROF_GN, st);

@@ -2,6 +2,8 @@
 // Used by bench.py to measure the dominant kernel's average launch duration live (roofline.achieved);
 // disabled by default so the timed region and graph capture never see an event record.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -10,7 +12,7 @@
 
 namespace {
 thread_local std::string g_err;
-struct Rec { int fam; double work, bytes; hipEvent_t a, b; };
+struct Rec { int fam; double work, bytes; hipEvent_t a, b; std::string tag; };
 std::mutex g_mu;
 bool g_on = false;
 std::vector<Rec> g_recs;
@@ -18,6 +20,7 @@ std::vector<hipEvent_t> g_pool;
 thread_local hipEvent_t t_start = nullptr;
 thread_local double t_work = 0, t_bytes = 0;
 thread_local int t_fam = -1;
+thread_local char t_tag[128] = {0};
 
 hipEvent_t get_event() {
     if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
@@ -44,7 +47,7 @@ void cdae_prof_begin(int fam, double work, hipStream_t st) {
     if (!g_on) return;
     std::lock_guard<std::mutex> lk(g_mu);
     t_start = get_event();
-    t_work = work; t_bytes = 0; t_fam = fam;
+    t_work = work; t_bytes = 0; t_fam = fam; t_tag[0] = 0;
     hipEventRecord(t_start, st);
 }
 
@@ -54,12 +57,20 @@ void cdae_prof_note(int fam, double bytes) {
     t_fam = fam; t_bytes = bytes;
 }
 
+// dev aid: a free-form label (shape, tile, split) for the launch between begin and end; dumped per launch by cdae_prof_read when
+// CDAE_PROF_DUMP names a file
+void cdae_prof_tag(const char* tag) {
+    if (!g_on || !t_start || !tag) return;
+    snprintf(t_tag, sizeof(t_tag), "%s", tag);
+}
+bool cdae_prof_on() { return g_on; }
+
 void cdae_prof_end(int fam, hipStream_t st) {
     if (!g_on || !t_start) return;
     std::lock_guard<std::mutex> lk(g_mu);
     hipEvent_t e = get_event();
     hipEventRecord(e, st);
-    g_recs.push_back({t_fam >= 0 ? t_fam : fam, t_work, t_bytes, t_start, e});
+    g_recs.push_back({t_fam >= 0 ? t_fam : fam, t_work, t_bytes, t_start, e, std::string(t_tag)});
     t_start = nullptr;
 }
 
@@ -92,12 +103,15 @@ int cdae_prof_read(double* ms, double* work, double* bytes, long long* launches)
     if (hipDeviceSynchronize() != hipSuccess) return cdae_fail("hipDeviceSynchronize failed");
     std::lock_guard<std::mutex> lk(g_mu);
     for (int i = 0; i < PROF_NFAM; ++i) { ms[i] = 0; work[i] = 0; bytes[i] = 0; launches[i] = 0; }
+    FILE* dump = getenv("CDAE_PROF_DUMP") ? fopen(getenv("CDAE_PROF_DUMP"), "a") : nullptr;
     for (auto& r : g_recs) {
         float t = 0.f;
         hipEventElapsedTime(&t, r.a, r.b);
+        if (dump) fprintf(dump, "%d\t%.1f\t%.6g\t%s\n", r.fam, t * 1e3, r.work, r.tag.c_str());
         ms[r.fam] += t; work[r.fam] += r.work; bytes[r.fam] += r.bytes; launches[r.fam] += 1;
         g_pool.push_back(r.a); g_pool.push_back(r.b);
     }
+    if (dump) fclose(dump);
     g_recs.clear();
     return 0;
 }

@@ -474,6 +474,11 @@ extern "C" int cdae_conv3x3_wgrad_win(const unsigned short* a_hi, const unsigned
         attr_bytes = smem;
     }
     cdae_prof_begin(PROF_IGEMM, 2.0 * Cout * 9.0 * Cin * (double)N * p.HW, st);
+    if (cdae_prof_on()) {
+        char tag[128];
+        snprintf(tag, sizeof(tag), "wgwin %d->%d @%dx%d n=%d tiles=%ld ks=%d", Cin, Cout, H, W, N, tiles, ks);
+        cdae_prof_tag(tag);
+    }
     if (cfg_waves == 8) hipLaunchKernelGGL(wgwin_kernel<8>, dim3((unsigned)(tiles * ks)), dim3(512), smem, st, p);
     else hipLaunchKernelGGL(wgwin_kernel<4>, dim3((unsigned)(tiles * ks)), dim3(256), smem, st, p);
     int rc = hipGetLastError() == hipSuccess ? 0 : cdae_fail("wgwin_kernel launch failed");

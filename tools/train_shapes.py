@@ -1,0 +1,43 @@
+"""Dev tool: every contraction launch of one C64 batch-32 training step with its shape, tile and split (the library's per-launch
+profiling tags, CDAE_PROF_DUMP), folded by label: launches per step, average us, TFLOP/s.  Launches are timed with HIP events on the
+launch stream, back to back as in the real step."""
+import os, sys, collections, tempfile
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+dump = os.path.join(tempfile.gettempdir(), "cdae_prof_dump.tsv")
+if os.path.exists(dump):
+    os.remove(dump)
+os.environ["CDAE_PROF_DUMP"] = dump
+import torch
+import bench
+from causaldiffae_amd import _lib
+from improved_diffusion import script_util as su
+from improved_diffusion.image_datasets import load_data
+from improved_diffusion.train_util import TrainLoop
+dev = torch.device("cuda:0")
+cfg = {**su.model_and_diffusion_defaults(), "image_size": 64, "in_channels": 3, "n_vars": 4, "rep_cond": True, "causal_modeling": True}
+model, diff = su.create_model_and_diffusion(**cfg)
+bench.randomize(model, 4321)
+model.to(dev).train()
+data = load_data(data_dir="synthetic", batch_size=32, image_size=64, in_channels=3, n_vars=4, seed=0, device=dev)
+loop = TrainLoop(model=model, diffusion=diff, data=data, batch_size=32, microbatch=-1, lr=1e-4, ema_rate="0.9999", log_interval=10 ** 9,
+                 save_interval=10 ** 9, resume_checkpoint="", rep_cond=True, n_vars=4, causal_modeling=True, in_channels=3)
+diff.kl_weight = 0.1
+for _ in range(3):
+    b, c = next(data); loop.forward_backward(b, c); loop.optimize_normal()
+torch.cuda.synchronize()
+STEPS = 3
+_lib.prof_enable(True)
+for _ in range(STEPS):
+    b, c = next(data); loop.forward_backward(b, c); loop.optimize_normal()
+_lib.prof_read()
+_lib.prof_enable(False)
+agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
+for line in open(dump):
+    fam, us, work, tag = line.rstrip("\n").split("\t")
+    a = agg[(fam, tag)]
+    a[0] += 1; a[1] += float(us); a[2] += float(work)
+rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+tot = sum(v[1] for _, v in rows) / STEPS
+print(f"total {tot / 1e3:.2f} ms per step in tagged families")
+for (fam, tag), (n, us, work) in rows[:int(os.environ.get("TOP", "70"))]:
+    print(f"{us / STEPS / 1e3:7.3f} ms/step {n / STEPS:5.1f}x {us / n:8.1f} us {work / us / 1e6 if us else 0:7.1f} TF  fam{fam} {tag}")
