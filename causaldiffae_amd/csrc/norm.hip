@@ -864,7 +864,8 @@ int gn_chunks(int HW, int N, int E) {
     int rows = 256 / E;
     int nchunk = HW / (rows * 8);              // >= 8 pixels per thread
     if (nchunk < 1) nchunk = 1;
-    while (nchunk > 1 && (long)nchunk * N > 2048) nchunk >>= 1;
+    static const int cfg_cap = getenv("CDAE_GN_CHUNK_CAP") ? atoi(getenv("CDAE_GN_CHUNK_CAP")) : 1024;      // blocks per launch: 2048 / 1024 / 512 -> 30.0 / 29.7 / 29.8 ms per C64 training step (short blocks are all epilogue)
+    while (nchunk > 1 && (long)nchunk * N > cfg_cap) nchunk >>= 1;
     if (nchunk > CDAE_GN_MAX_CHUNKS) nchunk = CDAE_GN_MAX_CHUNKS;
     return nchunk;
 }
