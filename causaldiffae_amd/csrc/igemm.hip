@@ -1671,7 +1671,8 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
                 int kbest = ks;
                 if (cw_tiles * ks < 512 && cfg_cw_ks && p.ksplit_auto && p.splitk_ws && !p.gn_part) {
                     int k2 = (int)(512 / cw_tiles);
-                    if (k2 > nchunk / 2) k2 = nchunk / 2;          // at least two chunks = 18 K-steps per split
+                    static const int cfg_minchunk = getenv("CDAE_CONVWIN_MINCHUNK") ? atoi(getenv("CDAE_CONVWIN_MINCHUNK")) : 3;
+                    if (k2 > nchunk / cfg_minchunk) k2 = nchunk / cfg_minchunk;          // at least three chunks = 27 K-steps per split (1 / 2 / 3 / 4 / unsplit: 30.37 / 30.26 / 30.14 / 30.25 / 30.62 ms per C64 training step)
                     while (k2 > 1 && (size_t)k2 * p.M * p.N * sizeof(float) > p.splitk_ws_bytes) --k2;
                     if (k2 > 1) { const int c_per = (nchunk + k2 - 1) / k2; k2 = (nchunk + c_per - 1) / c_per; }      // 12 chunks over 5 splits are 3 + 3 + 3 + 3 + 0: no empty slabs
                     if (k2 > 1) kbest = k2;
