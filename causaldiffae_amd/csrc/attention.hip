@@ -46,9 +46,10 @@ __device__ __forceinline__ void split8(const float* v, u16x8& hi, u16x8& lo) {
     lo = __builtin_bit_cast(u16x8, l);
 }
 
-template <int CH, int NKT>
+template <int CH, int NKT, bool PROBS>
 __global__ __launch_bounds__(NKT >= 4 ? 256 : 64 * NKT) void attn_fused_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                                                int heads, float alpha, int* __restrict__ range_flag) {
+                                                                                float* __restrict__ probs, int heads, float alpha,
+                                                                                int* __restrict__ range_flag) {
     constexpr int T = 32 * NKT, WAVES = NKT >= 4 ? 4 : NKT, THREADS = 64 * WAVES;
     constexpr int PASS = T < 128 ? T : 128, NPASS = T / PASS, TPP = PASS / 32;       // keys per staging pass, passes, key tiles per pass
     constexpr int KSTEPS = CH / 16, CT = CH / 32;                                      // 16-deep MFMA steps over ch; 32-wide output tiles
@@ -161,6 +162,18 @@ __global__ __launch_bounds__(NKT >= 4 ? 256 : 64 * NKT) void attn_fused_kernel(c
     // the probabilities are split as p * 2^10 (values in [0, 1024]: their f16 lo parts stay NORMAL numbers — unscaled, every lo of a
     // p < 1/8 is an f16 subnormal) and the factor is taken out of O again at the end; powers of two, so nothing is rounded.
     const float inv = 1024.f / sum;
+    if constexpr (PROBS) {
+        // training forward: the normalised probabilities [B * heads][T][T] are kept for the backward (cdae_qkv_attention_bwd).  A lane owns
+        // one query row; registers 4 g .. 4 g + 3 of a key tile are four consecutive keys: one 16-byte store each
+        float* const prow = probs + ((long)bh * T + q0 + l31) * T + 4 * hh;
+        const float pin = inv * (1.f / 1024.f);
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(prow + 32 * kt + 8 * g) =
+                    make_float4(acc[kt][4 * g] * pin, acc[kt][4 * g + 1] * pin, acc[kt][4 * g + 2] * pin, acc[kt][4 * g + 3] * pin);
+    }
 
     // ---- phase 3: O = P V.  MFMA step sk of key tile kt consumes registers r = 8 sk .. 8 sk + 7 of acc[kt], i.e. the keys
     //      32 kt + 16 sk + 4 hh + {0,1,2,3, 8,9,10,11}: V is read in exactly that order (two transpose reads 8 rows apart).
@@ -223,18 +236,18 @@ __global__ __launch_bounds__(NKT >= 4 ? 256 : 64 * NKT) void attn_fused_kernel(c
         }
 }
 
-template <int CH, int NKT>
-int launch_attn(const float* qkv, float* out, int B, int heads, hipStream_t st) {
+template <int CH, int NKT, bool PROBS>
+int launch_attn(const float* qkv, float* out, float* probs, int B, int heads, hipStream_t st) {
     constexpr int T = 32 * NKT, WAVES = NKT >= 4 ? 4 : NKT, PASS = T < 128 ? T : 128;
     constexpr int KP = CH * 2 + 16, VP = (CH + 32) * 2;
     constexpr size_t smem = 2 * (size_t)PASS * (KP > VP ? KP : VP);
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fused_kernel<CH, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fused_kernel<CH, NKT, PROBS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
         attr_done = true;
     }
-    hipLaunchKernelGGL((attn_fused_kernel<CH, NKT>), dim3(T / (32 * WAVES), B * heads), dim3(64 * WAVES), smem, st, qkv, out, heads,
+    hipLaunchKernelGGL((attn_fused_kernel<CH, NKT, PROBS>), dim3(T / (32 * WAVES), B * heads), dim3(64 * WAVES), smem, st, qkv, out, probs, heads,
                        1.f / sqrtf((float)CH), cdae_range_flag_ptr());
     return hipGetLastError() == hipSuccess ? 0 : cdae_fail("attn_fused launch failed");
 }
@@ -245,15 +258,21 @@ extern "C" int cdae_qkv_attention_fused_supported(int T, int ch) {
     return (T == 64 || T == 256) && (ch == 64 || ch == 96 || ch == 128);
 }
 
-extern "C" int cdae_qkv_attention_fwd_fused(const float* qkv, float* out, int B, int T, int heads, int ch, void* stream) {
+// probs != nullptr: also writes the softmax probabilities [B * heads][T][T] (the training forward; one launch instead of GEMM, softmax, GEMM)
+extern "C" int cdae_qkv_attention_fwd_fused_p(const float* qkv, float* out, float* probs, int B, int T, int heads, int ch, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    if ((((size_t)qkv) & 15) || !cdae_qkv_attention_fused_supported(T, ch)) return cdae_fail("attention_fwd_fused: unsupported shape (T in {64, 256}, ch in {64, 96, 128})");
+    if ((((size_t)qkv) & 15) || (((size_t)probs) & 15) || !cdae_qkv_attention_fused_supported(T, ch))
+        return cdae_fail("attention_fwd_fused: unsupported shape (T in {64, 256}, ch in {64, 96, 128})");
     cdae_prof_begin(PROF_IGEMM, 4.0 * B * heads * (double)T * T * ch, st);
     int rc;
-#define ATT(CHV, NK) rc = launch_attn<CHV, NK>(qkv, out, B, heads, st)
+#define ATT(CHV, NK) rc = probs ? launch_attn<CHV, NK, true>(qkv, out, probs, B, heads, st) : launch_attn<CHV, NK, false>(qkv, out, nullptr, B, heads, st)
     if (T == 256) { if (ch == 64) ATT(64, 8); else if (ch == 96) ATT(96, 8); else ATT(128, 8); }
     else { if (ch == 64) ATT(64, 2); else if (ch == 96) ATT(96, 2); else ATT(128, 2); }
 #undef ATT
     cdae_prof_end(PROF_IGEMM, st);
     return rc;
+}
+
+extern "C" int cdae_qkv_attention_fwd_fused(const float* qkv, float* out, int B, int T, int heads, int ch, void* stream) {
+    return cdae_qkv_attention_fwd_fused_p(qkv, out, nullptr, B, T, heads, ch, stream);
 }

@@ -338,7 +338,11 @@ class _Attention(Function):
         dev = qkv.device
         out = torch.empty((B, T, C), dtype=torch.float32, device=dev)
         probs = torch.empty((B * heads, T, T), dtype=torch.float32, device=dev)
-        check(lib.cdae_qkv_attention_fwd(ptr(qkv), ptr(out), ptr(probs), B, T, heads, ch, stream()))
+        if _FUSED_ATTN_TRAIN and lib.cdae_get_default_precision() == 1 and lib.cdae_qkv_attention_fused_supported(T, ch):
+            # the inference kernel with the probabilities written out for the backward: one launch instead of GEMM, softmax, GEMM
+            check(lib.cdae_qkv_attention_fwd_fused_p(ptr(qkv), ptr(out), ptr(probs), B, T, heads, ch, stream()))
+        else:
+            check(lib.cdae_qkv_attention_fwd(ptr(qkv), ptr(out), ptr(probs), B, T, heads, ch, stream()))
         ctx.save_for_backward(qkv, probs)
         ctx.heads = heads
         return out
@@ -357,6 +361,7 @@ class _Attention(Function):
 
 
 _FUSED_ATTN_ON = os.environ.get("CDAE_FUSED_ATTN", "1") != "0"
+_FUSED_ATTN_TRAIN = os.environ.get("CDAE_FUSED_ATTN_TRAIN", "1") != "0"
 
 
 def qkv_attention(qkv_rows, heads):

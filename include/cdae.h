@@ -286,6 +286,9 @@ int cdae_qkv_attention_bwd(const float* qkv, const float* probs, const float* do
    cdae_qkv_attention_fused_supported tells; other shapes use cdae_qkv_attention_fwd. */
 int cdae_qkv_attention_fused_supported(int T, int ch);
 int cdae_qkv_attention_fwd_fused(const float* qkv, float* out, int B, int T, int heads, int ch, void* stream);
+/* The same kernel for the TRAINING forward: additionally writes the normalised probabilities [B*heads][T][T] that
+   cdae_qkv_attention_bwd reads (probs == NULL: as cdae_qkv_attention_fwd_fused).  One launch instead of GEMM, softmax, GEMM. */
+int cdae_qkv_attention_fwd_fused_p(const float* qkv, float* out, float* probs, int B, int T, int heads, int ch, void* stream);
 
 /* ---- normalisation / softmax (norm.hip) ------------------------------------------------------------------- */
 size_t cdae_gn_workspace_floats(int N, int C);

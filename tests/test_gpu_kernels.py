@@ -662,6 +662,35 @@ def test_fused_attention_rows_sum_to_one(B, T, heads, ch, seed):
     assert (o - 1.0).abs().max().item() < 2e-6
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,heads,ch", [(3, 256, 4, 96), (5, 64, 4, 128), (2, 256, 2, 64), (1, 64, 1, 96), (2, 256, 1, 128)])
+def test_fused_attention_training_forward_keeps_probabilities(B, T, heads, ch):
+    """The training forward on the one-kernel attention: the probabilities it writes for the backward, its output and the gradient of
+    qkv through cdae_qkv_attention_bwd, against an fp64 restatement of reference unet.py:239-253."""
+    from causaldiffae_amd import ops
+    from causaldiffae_amd._lib import check, lib, ptr, stream
+    g = torch.Generator(device="cuda:0").manual_seed(21)
+    qkv = (torch.randn(B, T, 3 * heads * ch, device="cuda:0", generator=g) * 1.1).requires_grad_(True)
+    assert ops._FUSED_ATTN_TRAIN and lib.cdae_qkv_attention_fused_supported(T, ch)
+    out = ops.qkv_attention(qkv, heads)
+    go = torch.randn(out.shape, device="cuda:0", generator=g)
+    out.backward(go)
+    probs = torch.empty((B * heads, T, T), dtype=torch.float32, device="cuda:0")
+    o2 = torch.empty_like(out)
+    check(lib.cdae_qkv_attention_fwd_fused_p(ptr(qkv.detach()), ptr(o2), ptr(probs), B, T, heads, ch, stream()))
+    xd = qkv.detach().double().requires_grad_(True)
+    x = xd.reshape(B, T, heads, 3, ch)
+    q, k, v = x[:, :, :, 0], x[:, :, :, 1], x[:, :, :, 2]
+    w = torch.softmax(torch.einsum("bthc,bshc->bhts", q, k) / ch ** 0.5, dim=-1)
+    exact = torch.einsum("bhts,bshc->bthc", w, v).reshape(B, T, heads * ch)
+    exact.backward(go.double())
+    assert torch.equal(o2, out.detach())
+    assert (probs.double() - w.detach().reshape(B * heads, T, T)).abs().max().item() < 2e-6
+    assert (probs.sum(-1) - 1.0).abs().max().item() < 2e-6
+    assert (out.detach().double() - exact.detach()).abs().max().item() < 2e-5 * max(1.0, exact.abs().max().item())
+    assert (qkv.grad.double() - xd.grad).abs().max().item() < 2e-4 * xd.grad.abs().max().item()
+
+
 # ----------------------------------------------------------------------------- training on the pre-split kernels
 def _wgrad_ref(a, dy):
     """fp64 weight / bias gradient of a stride-1 conv3x3 (NCHW a [N,Cin,H,W], dy [N,Cout,H,W]) in OHWI order."""
