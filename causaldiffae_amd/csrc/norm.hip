@@ -9,6 +9,7 @@
 // softmax over keys unet.py:252.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include "cdae_internal.h"
 #include "../../include/cdae.h"
 
@@ -892,6 +893,7 @@ int cdae_gn_stats(const float* x, int N, int HW, int C, int ldx, int groups, flo
     const int nchunk = gn_chunks(HW, N, E);
     const int ppb = (HW + nchunk - 1) / nchunk;
     cdae_prof_begin(PROF_GN, (double)N * HW * C * 4.0, st);
+    if (cdae_prof_on()) { char tag[96]; snprintf(tag, sizeof(tag), "cdae_gn_stats N=%d HW=%d C=%d", (int)N, (int)HW, (int)C); cdae_prof_tag(tag); }
     if (VEC == 4) hipLaunchKernelGGL(gn_partial_kernel<4>, dim3(nchunk, N), dim3(256), 0, st, x, HW, C, ldx, cpg, groups, ppb, ws);
     else hipLaunchKernelGGL(gn_partial_kernel<1>, dim3(nchunk, N), dim3(256), 0, st, x, HW, C, ldx, cpg, groups, ppb, ws);
     if (groups == 32) hipLaunchKernelGGL(gn_finalize32_kernel, dim3(N), dim3(256), 0, st, x, HW, ldx, cpg, nchunk, eps, ws, mean, rstd, (const float*)nullptr, 0, 0);
@@ -914,6 +916,7 @@ int cdae_gn_apply(const float* x, float* y, int N, int HW, int C, int ldx, int l
     while (nchunk > 1 && (long)nchunk * N > 4096) nchunk >>= 1;
     const int ppb = (HW + nchunk - 1) / nchunk;
     cdae_prof_begin(PROF_GN, (double)N * HW * C * 8.0, st);
+    if (cdae_prof_on()) { char tag[96]; snprintf(tag, sizeof(tag), "cdae_gn_apply N=%d HW=%d C=%d", (int)N, (int)HW, (int)C); cdae_prof_tag(tag); }
     if (VEC == 4) hipLaunchKernelGGL(gn_apply_kernel<4>, dim3(nchunk, N), dim3(256), 0, st, x, y, HW, C, ldx, ldy, cpg, groups, ppb, mean, rstd, gamma, beta, scale_shift, ld_ss, silu);
     else hipLaunchKernelGGL(gn_apply_kernel<1>, dim3(nchunk, N), dim3(256), 0, st, x, y, HW, C, ldx, ldy, cpg, groups, ppb, mean, rstd, gamma, beta, scale_shift, ld_ss, silu);
     cdae_prof_end(PROF_GN, st);
@@ -976,6 +979,7 @@ static int gn_bwd_impl(const float* x, const float* x2, int ld2, int C1, const f
     float* ncp = gsum + (size_t)N * groups * 2;
     const long total = (long)N * HW * E;
     cdae_prof_begin(PROF_GN, (double)N * HW * C * 20.0, st);
+    if (cdae_prof_on()) { char tag[96]; snprintf(tag, sizeof(tag), "gn_bwd_impl N=%d HW=%d C=%d", (int)N, (int)HW, (int)C); cdae_prof_tag(tag); }
     if (VEC == 4) hipLaunchKernelGGL(gn_bwd_partial_kernel<4>, dim3(nchunk, N), dim3(256), 0, st, x, dy, HW, C, ldx, lddy, cpg, groups, ppb, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gpart, cpart, x2, ld2, C1);
     else hipLaunchKernelGGL(gn_bwd_partial_kernel<1>, dim3(nchunk, N), dim3(256), 0, st, x, dy, HW, C, ldx, lddy, cpg, groups, ppb, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gpart, cpart, x2, ld2, C1);
     hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3((C + 63) / 64 + 1, N), dim3(256), 0, st, N, HW, C, cpg, groups, nchunk, gpart, cpart, gsum, d_scale_shift, ld_dss, ncp);
@@ -1032,6 +1036,7 @@ int cdae_gn_coef(const float* mean, const float* rstd, const float* gamma, const
     int blocks = (int)((total + 255) / 256);
     if (blocks > 1024) blocks = 1024;
     cdae_prof_begin(PROF_GN, (double)total * 16.0, st);
+    if (cdae_prof_on()) { char tag[96]; snprintf(tag, sizeof(tag), "cdae_gn_coef N=%d HW=%d C=%d", (int)N, (int)0, (int)0); cdae_prof_tag(tag); }
     hipLaunchKernelGGL(gn_coef_kernel, dim3(blocks), dim3(256), 0, st, mean, rstd, gamma, beta, scale_shift, ld_ss, C, C / groups, groups, coef, total);
     cdae_prof_end(PROF_GN, st);
     CHECK_LAUNCH("gn_coef launch failed");
@@ -1047,6 +1052,7 @@ int cdae_gn_stats_from_parts(const float* part1, int C1, int nseg1, const float*
         return cdae_fail("gn_stats_from_parts: HW % 32 == 0, groups <= 256 and an 8-byte aligned workspace required");
     double* chan = reinterpret_cast<double*>(ws);
     cdae_prof_begin(PROF_GN, (double)N * (HW / 32) * C * 8.0, st);
+    if (cdae_prof_on()) { char tag[96]; snprintf(tag, sizeof(tag), "cdae_gn_stats_from_parts N=%d HW=%d C=%d", (int)N, (int)HW, (int)C); cdae_prof_tag(tag); }
     const int cpg = C / groups;
     static const int cfg_fused = getenv("CDAE_GN_PARTS_FUSED") ? atoi(getenv("CDAE_GN_PARTS_FUSED")) : 1;
     if (cfg_fused && cpg <= 32) {
@@ -1071,6 +1077,7 @@ int cdae_gn_stats2(const float* x1, int ld1, const float* x2, int ld2, int C1, i
     const int nchunk = gn_chunks(HW, N, E);
     const int ppb = (HW + nchunk - 1) / nchunk;
     cdae_prof_begin(PROF_GN, (double)N * HW * C * 4.0, st);
+    if (cdae_prof_on()) { char tag[96]; snprintf(tag, sizeof(tag), "cdae_gn_stats2 N=%d HW=%d C=%d", (int)N, (int)HW, (int)C); cdae_prof_tag(tag); }
     hipLaunchKernelGGL(gn_partial_kernel<4>, dim3(nchunk, N), dim3(256), 0, st, x1, HW, C, ld1, cpg, groups, ppb, ws, x2, ld2, C1);
     if (groups == 32) hipLaunchKernelGGL(gn_finalize32_kernel, dim3(N), dim3(256), 0, st, x1, HW, ld1, cpg, nchunk, eps, ws, mean, rstd, x2, ld2, C1);
     else hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(groups < 64 ? 64 : groups), 0, st, x1, HW, ld1, cpg, groups, nchunk, eps, ws, mean, rstd, x2, ld2, C1);
@@ -1126,6 +1133,7 @@ static int gn_apply_split_impl(const float* x, int ldx, const float* x2, int ld2
     while (nchunk > 1 && (long)nchunk * N > 4096) nchunk >>= 1;
     const int ppb = (HW + nchunk - 1) / nchunk;
     cdae_prof_begin(PROF_GN, (double)N * HW * C * 8.0, st);
+    if (cdae_prof_on()) { char tag[96]; snprintf(tag, sizeof(tag), "gn_apply_split_impl N=%d HW=%d C=%d", (int)N, (int)HW, (int)C); cdae_prof_tag(tag); }
     static const int cfg_gmk = getenv("CDAE_GN_APPLY_GM") ? atoi(getenv("CDAE_GN_APPLY_GM")) : 1;      // 0: group-major planes from the channel-vector kernel
     if (plane_gm && cfg_gmk && !yb_hi && (!x2 || C1 % 16 == 0) && N <= 65535) {
         const int gpb = (C % 32 == 0 && (!x2 || C1 % 32 == 0)) ? 2 : 1;
