@@ -14,6 +14,7 @@
 //   * the (a, b) table of the images the row tile touches sits in LDS
 //   * one barrier per step; n-tiles of one row tile are neighbours inside an XCD so the second..fourth read of x hits its L2
 // Sums: k ascending in 32-deep steps, per 16-deep MFMA the order lo*hi, hi*lo, hi*hi — ps_kernel's order on the same planes.
+#include <stdio.h>
 #include "cdae_internal.h"
 #include "../../include/cdae.h"
 
@@ -48,7 +49,7 @@ struct SkipGnParams {
     const float* res; long ldres;                                      // optional residual rows added to y
     unsigned short* c_hi; unsigned short* c_lo;                        // optional: y also as f16 hi / lo planes (row pitch ldy), the next conv's operand
     int planes_gm;                                                     // s_hi / s_lo group-major: [K / 16][M][16] (convwin_kernel's contiguous half-windows)
-    const float* coef; int silu; unsigned short* s_hi; unsigned short* s_lo;
+    const float* coef; int silu; unsigned short* s_hi; unsigned short* s_lo; int norm_a;
     int M, N, K, HW, nimg_tab;                                         // HW = rows per image; nimg_tab = images the LDS table holds per block
     int* range_flag;
 };
@@ -77,6 +78,9 @@ __device__ __forceinline__ void store_planes_sg(const SkipGnParams& p, long addr
     p.c_lo[addr] = __builtin_bit_cast(unsigned short, l);
 }
 
+// NORMA: the GEMM operand itself is the normalised row, silu?(x * a + b) (a GroupNorm in front of a 1x1 conv: the attention block's qkv) —
+// every block folds the coefficients into the rows it stages; no plane side output in that mode.
+template <bool NORMA>
 __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* const lds = reinterpret_cast<char*>(smem);
@@ -165,6 +169,7 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
         const long lim = ((long)p.M / p.HW) * p.K * 2 - (long)img0 * p.K * 2;     // floats that exist behind img0
         for (int t = tid * 4; t < nfl; t += 1024)
             *reinterpret_cast<float4*>(ctab + t) = t < lim ? *reinterpret_cast<const float4*>(src + t) : make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();                                               // step 0 reads entries other waves wrote, before its own barrier
     }
     const int nk = p.K / SG_BK;
     const bool full_rows = m0 + SG_BM <= p.M;
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
         // kt - 1 + SG_DEPTH — and its plane stores
         const int cnt = __builtin_amdgcn_readfirstlane((kt == 0 || !full_rows) ? 0 : (kt - 1 + SG_DEPTH < nk ? 4 : 0) + (writes_planes ? 4 : 0));
         SG_WAIT_X(cnt, x0a, x0b, x1a, x1b);
-        {
+        if constexpr (!NORMA) {
             u16x8 hi, lo;
             split8(x0a, x0b, hi, lo);
             *reinterpret_cast<u16x8*>(sa + aoff[0]) = hi;
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
             *reinterpret_cast<u16x8*>(sa + aoff[1]) = hi;
             *reinterpret_cast<u16x8*>(sa + SG_A_PLANE + aoff[1]) = lo;
         }
-        if (writes_planes) {
+        if (NORMA || writes_planes) {
             float4 cf[2][4];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -232,6 +237,13 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(ys[e]));      // opaque before the split: same rounding sequence as gn_apply_kernel
                 split8(f4{ys[0], ys[1], ys[2], ys[3]}, f4{ys[4], ys[5], ys[6], ys[7]}, nh[q], nl[q]);
+            }
+        }
+        if constexpr (NORMA) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                *reinterpret_cast<u16x8*>(sa + aoff[q]) = nh[q];
+                *reinterpret_cast<u16x8*>(sa + SG_A_PLANE + aoff[q]) = nl[q];
             }
         }
         __syncthreads();                                               // stage st complete; nobody reads stage st ^ 1 any more
@@ -382,7 +394,8 @@ static int skipgn_launch(SkipGnParams& p, void* stream) {
     const size_t smem = SG_TILES + (p.coef ? (size_t)p.nimg_tab * p.K * 8 : 0);
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&skipgn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SG_TILES + 16384) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&skipgn_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SG_TILES + 16384) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&skipgn_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SG_TILES + 16384) != hipSuccess)
             return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
         attr_done = true;
     }
@@ -390,7 +403,9 @@ static int skipgn_launch(SkipGnParams& p, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     cdae_prof_begin(PROF_IGEMM, 2.0 * p.M * p.N * p.K, st);
     cdae_prof_note(PROF_IGEMM, 4.0 * p.M * ((p.s_hi ? 2.0 : 1.0) * p.K + (p.res ? 2.0 : 1.0) * p.N));
-    hipLaunchKernelGGL(skipgn_kernel, dim3((unsigned)blocks), dim3(256), smem, st, p);
+    if (cdae_prof_on()) { char tag[96]; snprintf(tag, sizeof(tag), "skipgn M=%d N=%d K=%d norm_a=%d planes=%d res=%d", p.M, p.N, p.K, p.norm_a, p.s_hi ? 1 : 0, p.res ? 1 : 0); cdae_prof_tag(tag); }
+    if (p.norm_a) hipLaunchKernelGGL(skipgn_kernel<true>, dim3((unsigned)blocks), dim3(256), smem, st, p);
+    else hipLaunchKernelGGL(skipgn_kernel<false>, dim3((unsigned)blocks), dim3(256), smem, st, p);
     cdae_prof_end(PROF_IGEMM, st);
     return hipGetLastError() == hipSuccess ? 0 : cdae_fail("skipgn_kernel launch failed");
 }
@@ -406,7 +421,7 @@ extern "C" int cdae_skip_gn_fwd(const float* x1, long ld1, int K1, const float* 
     SkipGnParams p;
     p.x1 = x1; p.x2 = x2; p.ld1 = ld1; p.ld2 = ld2; p.K1 = K1;
     p.w_hi = w_hi; p.w_lo = w_lo; p.ldw = ldw; p.bias = bias; p.y = y; p.ldy = ldy; p.res = nullptr; p.ldres = 0; p.c_hi = nullptr; p.c_lo = nullptr;
-    p.coef = coef; p.silu = silu; p.s_hi = s_hi; p.s_lo = s_lo; p.planes_gm = planes_gm;
+    p.coef = coef; p.silu = silu; p.s_hi = s_hi; p.s_lo = s_lo; p.planes_gm = planes_gm; p.norm_a = 0;
     p.M = M; p.N = N; p.K = K; p.HW = HW; p.nimg_tab = skipgn_tab_images(HW);
     return skipgn_launch(p, stream);
 }
@@ -422,7 +437,23 @@ extern "C" int cdae_linear_fwd_stream(const float* x1, long ld1, int K1, const f
     SkipGnParams p;
     p.x1 = x1; p.x2 = x2; p.ld1 = ld1; p.ld2 = ld2; p.K1 = K1;
     p.w_hi = w_hi; p.w_lo = w_lo; p.ldw = ldw; p.bias = bias; p.y = y; p.ldy = ldy; p.res = res; p.ldres = ldres; p.c_hi = c_hi; p.c_lo = c_lo;
-    p.coef = nullptr; p.silu = 0; p.s_hi = nullptr; p.s_lo = nullptr; p.planes_gm = 0;
+    p.coef = nullptr; p.silu = 0; p.s_hi = nullptr; p.s_lo = nullptr; p.planes_gm = 0; p.norm_a = 0;
     p.M = M; p.N = N; p.K = K; p.HW = M; p.nimg_tab = 0;
+    return skipgn_launch(p, stream);
+}
+
+// y = silu?(GroupNorm(x)) @ W^T + bias with the GroupNorm folded to per-(image, channel) (a, b) (cdae_gn_coef) and applied to the rows
+// as they are staged: GroupNorm -> 1x1 conv (the attention block's norm -> qkv, reference unet.py:213-228) in ONE pass over the fp32
+// input, no normalised tensor or planes in HBM.  Shapes as cdae_skip_gn_ok(M, N, K, K, HW).
+extern "C" int cdae_linear_fwd_stream_gn(const float* x, long ldx, const unsigned short* w_hi, const unsigned short* w_lo, long ldw, const float* bias,
+                                         float* y, long ldy, const float* coef, int silu, int M, int N, int K, int HW, void* stream) {
+    if (!cdae_skip_gn_ok(M, N, K, K, HW)) return cdae_fail("linear_fwd_stream_gn: K % 32 == 0, M a multiple of HW, coefficient table of a row tile <= 16 KB required");
+    if (ldx % 4 || ldw % 8 || !aligned16(x) || !aligned16(w_hi) || !aligned16(w_lo) || !aligned16(coef) || !x || !w_hi || !w_lo || !coef || !y)
+        return cdae_fail("linear_fwd_stream_gn: 16-byte aligned rows, weight planes and coefficients required");
+    SkipGnParams p;
+    p.x1 = x; p.x2 = nullptr; p.ld1 = ldx; p.ld2 = 0; p.K1 = K;
+    p.w_hi = w_hi; p.w_lo = w_lo; p.ldw = ldw; p.bias = bias; p.y = y; p.ldy = ldy; p.res = nullptr; p.ldres = 0; p.c_hi = nullptr; p.c_lo = nullptr;
+    p.coef = coef; p.silu = silu; p.s_hi = nullptr; p.s_lo = nullptr; p.planes_gm = 0; p.norm_a = 1;
+    p.M = M; p.N = N; p.K = K; p.HW = HW; p.nimg_tab = skipgn_tab_images(HW);
     return skipgn_launch(p, stream);
 }

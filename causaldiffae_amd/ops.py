@@ -1612,6 +1612,33 @@ def linear_emit(rows, w, b, res, shape):
     return y, SplitAct(planes[0], planes[1], shape)
 
 
+_LINEAR_GN = os.environ.get("CDAE_LINEAR_GN", "1") != "0"      # dev switch: 0 = GroupNorm planes first, then the plane GEMM
+
+
+def linear_gn_ok(lz, w):
+    """GroupNorm -> 1x1 conv (the attention block's norm -> qkv) as ONE pass over the fp32 rows on the streaming GEMM?"""
+    from ._lib import get_precision
+    N, C, H, W = lz.shape
+    return (_LINEAR_GN and _STREAM_GEMM and get_precision() == "f16x3" and lz.x2 is None and w.numel() == w.shape[0] * C and w.is_contiguous()
+            and lz.x1.stride(1) == 1 and N * H * W >= _STREAM_GEMM_MIN_ROWS and w.shape[0] >= 64
+            and lib.cdae_skip_gn_ok(N * H * W, w.shape[0], C, C, H * W) == 1)
+
+
+def linear_gn(lz, w, b=None):
+    """y[N*H*W, Nf] = rows(silu?(GroupNorm(x))) @ w^T + b: the normalisation is folded to per-(image, channel) coefficients and applied
+    while the streaming GEMM stages its rows — the normalised tensor never exists in HBM (no autograd)."""
+    N, C, H, W = lz.shape
+    M, Nf = N * H * W, w.shape[0]
+    dev = lz.x1.device
+    st = stream()
+    coef = torch.empty((N, C, 2), dtype=torch.float32, device=dev)
+    check(lib.cdae_gn_coef(ptr(lz.stats[0]), ptr(lz.stats[1]), ptr(lz.gamma), ptr(lz.beta), ptr(lz.ss), lz.ld_ss, ptr(coef), N, C, lz.groups, st))
+    wh, wl = split_weight(w)
+    y = torch.empty((M, Nf), dtype=torch.float32, device=dev)
+    check(lib.cdae_linear_fwd_stream_gn(ptr(lz.x1), C, ptr(wh), ptr(wl), C, ptr(b), ptr(y), Nf, ptr(coef), 1 if lz.silu else 0, M, Nf, C, H * W, st))
+    return y
+
+
 def linear_ps(xs, w, b=None, res=None, act=ACT_NONE):
     """y = act(rows(xs) @ w^T + b + res) for a SplitAct seen as [N*H*W, C] rows (no autograd)."""
     xs = xs.pc()

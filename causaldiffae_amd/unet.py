@@ -222,9 +222,16 @@ class AttentionBlock(nn.Module):
         N, C, H, W = x.shape
         T = H * W
         h = self.norm(x, split=True)                                                # GN, no activation
+        qkv = None
         if isinstance(h, ops.LazyGN):
-            h = h.planes()
-        if isinstance(h, ops.SplitAct):
+            w2 = self.qkv.weight.reshape(self.qkv.weight.shape[0], -1)
+            if ops.linear_gn_ok(h, w2):
+                qkv = ops.linear_gn(h, w2, self.qkv.bias)                           # norm -> qkv in one pass over x (no normalised tensor)
+            else:
+                h = h.planes()
+        if qkv is not None:
+            pass
+        elif isinstance(h, ops.SplitAct):
             qkv = ops.linear_ps(h, self.qkv.weight, self.qkv.bias)
         else:
             rows = h.permute(0, 2, 3, 1).reshape(N * T, C)

@@ -976,6 +976,36 @@ def test_skip_gemm_carries_groupnorm_planes(N, C1, C2, Cout, H, stream_kernel, m
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,C,Nf,H,silu", [(32, 384, 1152, 16, False), (64, 512, 1536, 8, False), (16, 256, 768, 16, True), (5, 384, 1152, 32, False),
+                                           (33, 128, 96, 12, True)])
+def test_groupnorm_linear_in_one_pass(N, C, Nf, H, silu):
+    """ops.linear_gn (cdae_linear_fwd_stream_gn: GroupNorm folded into the streaming GEMM's row loader — the attention block's
+    norm -> qkv) against the two-pass path (GroupNorm planes, then the plane GEMM: same operand values, other summation order) and fp64.
+    Shapes: both attention levels of the P64 / C64 UNets, several images per 128-row tile, a partial row tile and column tile."""
+    import torch.nn.functional as F
+    from causaldiffae_amd import ops
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(29)
+    x = (torch.randn(N, C, H, H, device=dev, generator=g) * 1.3 + 0.2).contiguous(memory_format=torch.channels_last)
+    gamma = 1 + 0.1 * torch.randn(C, device=dev, generator=g)
+    beta = 0.1 * torch.randn(C, device=dev, generator=g)
+    w = torch.randn(Nf, C, device=dev, generator=g) / C ** 0.5
+    bias = 0.1 * torch.randn(Nf, device=dev, generator=g)
+    with torch.no_grad():
+        lz = ops.group_norm_lazy(x, gamma, beta, None, silu, 32, 1e-5)
+        assert ops.linear_gn_ok(lz, w)
+        got = ops.linear_gn(lz, w, bias)
+        two = ops.linear_ps(lz.planes(), w, bias)
+    h = F.group_norm(x.double(), 32, gamma.double(), beta.double(), 1e-5)
+    if silu:
+        h = F.silu(h)
+    ref = h.permute(0, 2, 3, 1).reshape(N * H * H, C) @ w.double().t() + bias.double()
+    scale = ref.abs().max().item()
+    assert (got - two).abs().max().item() < 2e-5 * scale
+    assert (got.double() - ref).abs().max().item() < 6e-6 * scale
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N,C,Cout,H,W,silu", [(3, 128, 4, 64, 64, True), (2, 128, 3, 64, 64, True), (5, 128, 1, 32, 32, True), (2, 128, 8, 28, 28, True),
                                                (2, 128, 6, 9, 7, False), (1, 128, 2, 8, 12, True)])
 def test_output_head_kernel_matches_fp64(N, C, Cout, H, W, silu):
