@@ -21,7 +21,7 @@ python3 tools/pmc_summary.py --fetch $O/fetch --write $O/write --sq $O/sq --trac
     --label "f16x3, eager P64 DDIM steps, batch 128: every contraction that is not the window conv kernel" --out $O/${TAG}_igemm_pmc_summary_f16x3.json >> $O/summary.log 2>&1
 python3 tools/pmc_summary.py --fetch $O/fetch --write $O/write --sq $O/sq --trace $O/trace --kernels 'skipgn_kernel' \
     --label "f16x3, eager P64 DDIM steps, batch 128: ResBlock entry sweeps (1x1 skip conv + GroupNorm planes) and the streaming 1x1 GEMMs" --out $O/${TAG}_skipgn_pmc_summary_f16x3.json >> $O/summary.log 2>&1
-python3 tools/pmc_summary.py --fetch $O/fetch --write $O/write --sq $O/sq --trace $O/trace --kernels 'gn_apply_kernel' \
+python3 tools/pmc_summary.py --fetch $O/fetch --write $O/write --sq $O/sq --trace $O/trace --kernels 'gn_apply' \
     --label "eager P64 DDIM steps, batch 128: GroupNorm apply -> f16 planes" --out $O/${TAG}_gn_apply_pmc_summary.json >> $O/summary.log 2>&1
 cp $O/trace/*kernel_stats.csv $O/${TAG}_bench_ddim_p64_b128_kernel_stats_${VER}_f16x3.csv 2>/dev/null
 tail -60 $O/summary.log
