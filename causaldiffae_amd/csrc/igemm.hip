@@ -1486,16 +1486,18 @@ int launch_tiles(const GemmParams& p, int big, bool scalar, hipStream_t st) {
     if constexpr (AMODE == A_CONV_GEN) return cdae_fail("A_CONV_GEN is a scalar-only loader");
     else {
         if constexpr (AMODE == A_PLAIN_KC && BMODE == B_PLAIN_KC) {
-            static const int cfg_deep = getenv("CDAE_IGEMM_DEEP") ? atoi(getenv("CDAE_IGEMM_DEEP")) : 7;       // bit 0 plain fwd GEMM, 1 the GroupNorm-carrying skip GEMM, 2 linear dgrad / wgrad
+            static const int cfg_deep = getenv("CDAE_IGEMM_DEEP") ? atoi(getenv("CDAE_IGEMM_DEEP")) : 15;      // bit 0 plain fwd GEMM, 1 the GroupNorm-carrying skip GEMM, 2 linear dgrad / wgrad, 3 the same two on 64x64 tiles (2048x512x512: 19.7 -> 16.5 us)
             if (p.S_hi) {
                 if (p.prec != 1 || !big) return cdae_fail("GroupNorm side output: f16x3 mode and a grid of 128x128 tiles required");
                 return (cfg_deep & 2) ? launch<128, 128, AMODE, BMODE, false, 4, 1, true, true>(p, st) : launch<128, 128, AMODE, BMODE, false, 4, 1, true>(p, st);
             }
             if (p.prec == 1 && big && (cfg_deep & 1)) return launch<128, 128, AMODE, BMODE, false, 4, 1, false, true>(p, st);
+            if (p.prec == 1 && !big && (cfg_deep & 8)) return launch<64, 64, AMODE, BMODE, false, 2, 1, false, true>(p, st);
         }
         if constexpr ((AMODE == A_PLAIN_KC || AMODE == A_PLAIN_MC) && BMODE == B_PLAIN_MC) {     // linear / 1x1 dgrad and wgrad: the same latency-bound shape
-            static const int cfg_deep2 = getenv("CDAE_IGEMM_DEEP") ? atoi(getenv("CDAE_IGEMM_DEEP")) : 7;
+            static const int cfg_deep2 = getenv("CDAE_IGEMM_DEEP") ? atoi(getenv("CDAE_IGEMM_DEEP")) : 15;
             if (p.prec == 2 && big && (cfg_deep2 & 4)) return launch<128, 128, AMODE, BMODE, false, 4, 2, false, true>(p, st);
+            if (p.prec == 2 && !big && (cfg_deep2 & 8)) return launch<64, 64, AMODE, BMODE, false, 2, 2, false, true>(p, st);
         }
         if (p.prec == 1) return big ? launch<128, 128, AMODE, BMODE, false, 4, 1>(p, st) : launch<64, 64, AMODE, BMODE, false, 2, 1>(p, st);
         if (p.prec == 2) return big ? launch<128, 128, AMODE, BMODE, false, 4, 2>(p, st) : launch<64, 64, AMODE, BMODE, false, 2, 2>(p, st);

@@ -39,6 +39,9 @@ for kind, M, N, K, cnt in SHAPES:
         f = lambda: check(lib.cdae_linear_wgrad(ptr(x), K, ptr(dy), N, ptr(dw), K, ptr(db), M, N, K, 0, ws, wsb, st))
     os.environ.pop("CDAE_TILE_FORCE", None); os.environ.pop("CDAE_KS_FORCE", None)
     base = timed(f)
+    if os.environ.get("ONLY_DEFAULT"):
+        print(f"{kind:5s} rows={M:6d} N={N:4d} K={K:4d} x{cnt:2d}: default {base:6.1f} us")
+        continue
     res = []
     for tile in (64, 128):
         for ks in KS:
