@@ -46,11 +46,14 @@ __device__ __forceinline__ void split8(const float* v, u16x8& hi, u16x8& lo) {
     lo = __builtin_bit_cast(u16x8, l);
 }
 
+#ifndef ATT_WAVES8
+#define ATT_WAVES8 1      // T = 256: eight waves (all 256 queries of a (batch, head)) per block, K and V staged once instead of twice
+#endif
 template <int CH, int NKT, bool PROBS>
-__global__ __launch_bounds__(NKT >= 4 ? 256 : 64 * NKT) void attn_fused_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+__global__ __launch_bounds__((ATT_WAVES8 && NKT >= 8 && CH <= 96) ? 512 : NKT >= 4 ? 256 : 64 * NKT) void attn_fused_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                                 float* __restrict__ probs, int heads, float alpha,
                                                                                 int* __restrict__ range_flag) {
-    constexpr int T = 32 * NKT, WAVES = NKT >= 4 ? 4 : NKT, THREADS = 64 * WAVES;
+    constexpr int T = 32 * NKT, WAVES = (ATT_WAVES8 && NKT >= 8 && CH <= 96) ? 8 : NKT >= 4 ? 4 : NKT, THREADS = 64 * WAVES;
     constexpr int PASS = T < 128 ? T : 128, NPASS = T / PASS, TPP = PASS / 32;       // keys per staging pass, passes, key tiles per pass
     constexpr int KSTEPS = CH / 16, CT = CH / 32;                                      // 16-deep MFMA steps over ch; 32-wide output tiles
     constexpr int KP = CH * 2 + 16;                                                    // K plane row pitch in bytes (conflict-free b128 reads)
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(NKT >= 4 ? 256 : 64 * NKT) void attn_fused_kernel(c
 
 template <int CH, int NKT, bool PROBS>
 int launch_attn(const float* qkv, float* out, float* probs, int B, int heads, hipStream_t st) {
-    constexpr int T = 32 * NKT, WAVES = NKT >= 4 ? 4 : NKT, PASS = T < 128 ? T : 128;
+    constexpr int T = 32 * NKT, WAVES = (ATT_WAVES8 && NKT >= 8 && CH <= 96) ? 8 : NKT >= 4 ? 4 : NKT, PASS = T < 128 ? T : 128;
     constexpr int KP = CH * 2 + 16, VP = (CH + 32) * 2;
     constexpr size_t smem = 2 * (size_t)PASS * (KP > VP ? KP : VP);
     static bool attr_done = false;
