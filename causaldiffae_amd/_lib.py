@@ -71,6 +71,7 @@ SIGNATURES = {
     "cdae_qkv_attention_fused_supported": [I, I],
     "cdae_qkv_attention_fwd_fused": [P, P, I, I, I, I, P],
     "cdae_qkv_attention_fwd_fused_p": [P, P, P, I, I, I, I, P],
+    "cdae_qkv_attention_bwd_q_fused": [P, P, P, P, P, I, I, I, I, P],
     "cdae_qkv_attention_bwd": [P, P, P, P, P, I, I, I, I, P],
     "cdae_gn_workspace_floats": [I, I],
     "cdae_gn_stats": [P, I, I, I, I, I, F, P, P, P, P],

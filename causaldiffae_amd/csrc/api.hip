@@ -432,6 +432,15 @@ int cdae_qkv_attention_bwd(const float* qkv, const float* probs, const float* do
         p.amode = A_PLAIN_MC; p.bmode = B_PLAIN_MC; p.a_scalar = !(t4 && aligned16(probs)); p.b_scalar = !aligned16(dout); p.grad_operand = 1;
         if ((rc = cdae_gemm_dispatch(p, stream))) return rc;
     }
+    // query side in one launch (attention.hip): dP = dO V^T, the softmax backward and dQ = alpha dS K; dS lands in dprobs for the dK GEMM
+    // below.  Measured at batch 32: T = 64 58 vs 65 us for the whole backward, T = 256 135 vs 124 us (the kernel reads the probabilities
+    // twice and writes dS between two unoverlapped staging phases) -> by default only for T = 64.  CDAE_ATTN_BWD_FUSED=0 never, 2 wherever built
+    static const int cfg_fused = getenv("CDAE_ATTN_BWD_FUSED") ? atoi(getenv("CDAE_ATTN_BWD_FUSED")) : 1;
+    const bool fused_q = (cfg_fused >= 2 || (cfg_fused == 1 && T <= 64)) && cdae_get_default_precision() == CDAE_PREC_F16X3 && cdae_qkv_attention_fused_supported(T, ch) && aligned16(qkv) &&
+                         aligned16(probs) && aligned16(dout) && aligned16(dqkv) && aligned16(dprobs);
+    if (fused_q) {
+        if ((rc = cdae_qkv_attention_bwd_q_fused(qkv, probs, dout, dqkv, dprobs, B, T, heads, ch, stream))) return rc;
+    } else {
     {   // dP[t][s] = sum_c dO[t][c] V[s][c]
         GemmParams p = base_params();
         p.A = dout; p.B = qkv + 2 * ch; p.C = dprobs;
@@ -450,6 +459,7 @@ int cdae_qkv_attention_bwd(const float* qkv, const float* probs, const float* do
         p.a_bs0 = (long)heads * T * T; p.a_bs1 = (long)T * T; p.b_bs0 = T * C3; p.b_bs1 = 3L * ch; p.c_bs0 = T * C3; p.c_bs1 = 3L * ch;
         p.amode = A_PLAIN_KC; p.bmode = B_PLAIN_MC; p.a_scalar = !(t4 && aligned16(dprobs)); p.b_scalar = !aligned16(qkv); p.grad_operand = 1;
         if ((rc = cdae_gemm_dispatch(p, stream))) return rc;
+    }
     }
     {   // dK[s][c] = alpha sum_t dS[t][s] Q[t][c]
         GemmParams p = base_params();

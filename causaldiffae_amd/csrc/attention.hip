@@ -239,6 +239,206 @@ __global__ __launch_bounds__((ATT_WAVES8 && NKT >= 8 && CH <= 96) ? 512 : NKT >=
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Backward, query side, in ONE kernel (the structure of attn_fused_kernel with other operands): per (batch, head) and 32 queries per wave
+//     dP^T = V dO^T                      (like S^T = K Q^T: lane = query, registers = keys)
+//     dS   = P o (dP - rowsum(P o dP))   (softmax backward in registers; P is read from the forward's probabilities, twice, 16 bytes per lane)
+//     dQ   = alpha dS K                  (like O = P V)
+// dS is also written out ([B * heads][T][T], the layout of the probabilities) for the key-side GEMM dK = alpha dS^T Q; dV = P^T dO needs
+// nothing from here.  Replaces GEMM, softmax backward, GEMM.  Gradient operands: every product is bf16 hi/lo x3 (v_mfma_f32_32x32x16_bf16),
+// like the other backward contractions.
+typedef __bf16 att_bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 att_bf4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x16 mma_bf(const u16x8& a, const u16x8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(att_bf8, a), __builtin_bit_cast(att_bf8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void split8_bf(const float* v, u16x8& hi, u16x8& lo) {
+    att_bf8 h, l;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float x = v[i];
+        asm volatile("" : "+v"(x));
+        h[i] = (__bf16)x;
+        l[i] = (__bf16)(x - (float)h[i]);
+    }
+    hi = __builtin_bit_cast(u16x8, h);
+    lo = __builtin_bit_cast(u16x8, l);
+}
+
+template <int CH, int NKT>
+__global__ __launch_bounds__((ATT_WAVES8 && NKT >= 8 && CH <= 96) ? 512 : NKT >= 4 ? 256 : 64 * NKT)
+void attn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ probs, const float* __restrict__ dout, float* __restrict__ dqkv,
+                       float* __restrict__ ds, int heads, float alpha, int* __restrict__ range_flag) {
+    constexpr int T = 32 * NKT, WAVES = (ATT_WAVES8 && NKT >= 8 && CH <= 96) ? 8 : NKT >= 4 ? 4 : NKT, THREADS = 64 * WAVES;
+    constexpr int PASS = T < 128 ? T : 128, NPASS = T / PASS, TPP = PASS / 32;
+    constexpr int KSTEPS = CH / 16, CT = CH / 32;
+    constexpr int KP = CH * 2 + 16, VP = (CH + 32) * 2;
+    constexpr int PLANE = PASS * (KP > VP ? KP : VP);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const lds = reinterpret_cast<char*>(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
+    const int q0 = (blockIdx.x * WAVES + wave) * 32;
+    const long C3 = (long)heads * 3 * CH, C = (long)heads * CH;
+    const float* const base = qkv + (long)b * T * C3 + (long)h * 3 * CH;               // q at +0, k at +CH, v at +2CH
+
+    // ---- phase 0: dO fragments (B operand: lane = query column, 8 consecutive ch per lane and step)
+    u16x8 gh[KSTEPS], gl[KSTEPS];
+    {
+        const float* grow = dout + ((long)b * T + q0 + l31) * C + (long)h * CH;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            const float4 a = *reinterpret_cast<const float4*>(grow + s * 16 + 8 * hh);
+            const float4 c = *reinterpret_cast<const float4*>(grow + s * 16 + 8 * hh + 4);
+            const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+            split8_bf(v, gh[s], gl[s]);
+        }
+    }
+
+    f32x16 acc[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[kt][r] = 0.f;
+
+    // rows key0 .. key0 + PASS of the k (which = 1) or v (which = 2) slice as bf16 hi / lo planes, row pitch `pitch` bytes
+    auto stage = [&](int key0, int which, int pitch) {
+        for (int item = tid; item < PASS * (CH / 4); item += THREADS) {
+            const int row = item / (CH / 4), f4 = item - row * (CH / 4);
+            const float4 v = *reinterpret_cast<const float4*>(base + (long)(key0 + row) * C3 + which * CH + f4 * 4);
+            att_bf4 hi, lo;
+            hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
+            lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
+            lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
+            *reinterpret_cast<att_bf4*>(lds + row * pitch + f4 * 8) = hi;
+            *reinterpret_cast<att_bf4*>(lds + PLANE + row * pitch + f4 * 8) = lo;
+        }
+    };
+
+    // ---- phase 1: dP^T = V dO^T.  acc[kt][r] = dP[query = q0 + l31][key = 32 kt + (r & 3) + 8 (r >> 2) + 4 hh]
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        if (ps) __syncthreads();
+        stage(ps * PASS, 2, KP);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < TPP; ++t) {
+            const int kt = ps * TPP + t;
+            const char* arow = lds + (t * 32 + l31) * KP + 16 * hh;
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                const u16x8 vh = *reinterpret_cast<const u16x8*>(arow + s * 32);
+                const u16x8 vl = *reinterpret_cast<const u16x8*>(arow + PLANE + s * 32);
+                acc[kt] = mma_bf(vl, gh[s], acc[kt]);
+                acc[kt] = mma_bf(vh, gl[s], acc[kt]);
+                acc[kt] = mma_bf(vh, gh[s], acc[kt]);
+            }
+        }
+    }
+
+    // ---- phase 2: softmax backward in registers.  D = sum_keys P dP (in-lane, then across the two lane halves); dS = P (dP - D)
+    const long prow = ((long)bh * T + q0 + l31) * T + 4 * hh;
+    float D = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 pv = *reinterpret_cast<const float4*>(probs + prow + 32 * kt + 8 * g);
+            D = fmaf(pv.x, acc[kt][4 * g], D); D = fmaf(pv.y, acc[kt][4 * g + 1], D);
+            D = fmaf(pv.z, acc[kt][4 * g + 2], D); D = fmaf(pv.w, acc[kt][4 * g + 3], D);
+        }
+    D += __shfl_xor(D, 32);
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 pv = *reinterpret_cast<const float4*>(probs + prow + 32 * kt + 8 * g);
+            float4 d;
+            d.x = pv.x * (acc[kt][4 * g] - D); d.y = pv.y * (acc[kt][4 * g + 1] - D);
+            d.z = pv.z * (acc[kt][4 * g + 2] - D); d.w = pv.w * (acc[kt][4 * g + 3] - D);
+            acc[kt][4 * g] = d.x; acc[kt][4 * g + 1] = d.y; acc[kt][4 * g + 2] = d.z; acc[kt][4 * g + 3] = d.w;
+            *reinterpret_cast<float4*>(ds + prow + 32 * kt + 8 * g) = d;
+        }
+
+    // ---- phase 3: dQ = dS K (alpha at the end).  Same register-to-key permutation as O = P V in the forward
+    f32x16 o[CT];
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
+    const int q4 = (lane & 15) >> 2, p4 = lane & 3, chalf = 16 * ((lane >> 4) & 1);
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        __syncthreads();
+        stage(ps * PASS, 1, VP);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < TPP; ++t) {
+            const int kt = ps * TPP + t;
+#pragma unroll
+            for (int sk = 0; sk < 2; ++sk) {
+                float pv[8];
+#pragma unroll
+                for (int jx = 0; jx < 8; ++jx) pv[jx] = acc[kt][8 * sk + jx];
+                u16x8 ph, pl;
+                split8_bf(pv, ph, pl);
+                const int krow = t * 32 + 16 * sk + 4 * hh + q4;
+#pragma unroll
+                for (int j = 0; j < CT; ++j) {
+                    const char* src = lds + krow * VP + (j * 32 + chalf + 4 * p4) * 2;
+                    u16x8 kh, kl;
+                    {
+                        const fp16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(src));
+                        const fp16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(src + 8 * VP));
+                        const u16x4 a4 = __builtin_bit_cast(u16x4, a), c4 = __builtin_bit_cast(u16x4, c);
+                        kh[0] = a4[0]; kh[1] = a4[1]; kh[2] = a4[2]; kh[3] = a4[3]; kh[4] = c4[0]; kh[5] = c4[1]; kh[6] = c4[2]; kh[7] = c4[3];
+                    }
+                    {
+                        const fp16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(src + PLANE));
+                        const fp16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(src + PLANE + 8 * VP));
+                        const u16x4 a4 = __builtin_bit_cast(u16x4, a), c4 = __builtin_bit_cast(u16x4, c);
+                        kl[0] = a4[0]; kl[1] = a4[1]; kl[2] = a4[2]; kl[3] = a4[3]; kl[4] = c4[0]; kl[5] = c4[1]; kl[6] = c4[2]; kl[7] = c4[3];
+                    }
+                    o[j] = mma_bf(pl, kh, o[j]);
+                    o[j] = mma_bf(ph, kl, o[j]);
+                    o[j] = mma_bf(ph, kh, o[j]);
+                }
+            }
+        }
+    }
+
+    // ---- phase 4: dQ[query row][ch col] -> dqkv[b][q0 + row][h * 3 CH + col]   (the q slice of the head)
+    float* const obase = dqkv + ((long)b * T + q0) * C3 + (long)h * 3 * CH;
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const float v = o[j][r] * alpha;
+            obase[(long)row * C3 + j * 32 + l31] = v;
+            if (!__builtin_isfinite(v) && range_flag) *range_flag = 1;
+        }
+}
+
+template <int CH, int NKT>
+int launch_attn_bwd_q(const float* qkv, const float* probs, const float* dout, float* dqkv, float* ds, int B, int heads, hipStream_t st) {
+    constexpr int T = 32 * NKT, WAVES = (ATT_WAVES8 && NKT >= 8 && CH <= 96) ? 8 : NKT >= 4 ? 4 : NKT, PASS = T < 128 ? T : 128;
+    constexpr int KP = CH * 2 + 16, VP = (CH + 32) * 2;
+    constexpr size_t smem = 2 * (size_t)PASS * (KP > VP ? KP : VP);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_q_kernel<CH, NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((attn_bwd_q_kernel<CH, NKT>), dim3(T / (32 * WAVES), B * heads), dim3(64 * WAVES), smem, st, qkv, probs, dout, dqkv, ds, heads,
+                       1.f / sqrtf((float)CH), cdae_range_flag_ptr());
+    return hipGetLastError() == hipSuccess ? 0 : cdae_fail("attn_bwd_q launch failed");
+}
+
 template <int CH, int NKT, bool PROBS>
 int launch_attn(const float* qkv, float* out, float* probs, int B, int heads, hipStream_t st) {
     constexpr int T = 32 * NKT, WAVES = (ATT_WAVES8 && NKT >= 8 && CH <= 96) ? 8 : NKT >= 4 ? 4 : NKT, PASS = T < 128 ? T : 128;
@@ -278,4 +478,21 @@ extern "C" int cdae_qkv_attention_fwd_fused_p(const float* qkv, float* out, floa
 
 extern "C" int cdae_qkv_attention_fwd_fused(const float* qkv, float* out, int B, int T, int heads, int ch, void* stream) {
     return cdae_qkv_attention_fwd_fused_p(qkv, out, nullptr, B, T, heads, ch, stream);
+}
+
+// dS (into `ds`, [B * heads][T][T]) and dQ (into the q slices of dqkv) from the forward's probabilities and dout — the query side of the
+// attention backward (reference: autograd through unet.py:239-253) in one launch.  Shapes as cdae_qkv_attention_fused_supported.
+extern "C" int cdae_qkv_attention_bwd_q_fused(const float* qkv, const float* probs, const float* dout, float* dqkv, float* ds, int B, int T, int heads,
+                                              int ch, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (((((size_t)qkv) | ((size_t)probs) | ((size_t)dout) | ((size_t)dqkv) | ((size_t)ds)) & 15) || !cdae_qkv_attention_fused_supported(T, ch))
+        return cdae_fail("attention_bwd_q_fused: unsupported shape (T in {64, 256}, ch in {64, 96, 128}) or unaligned operands");
+    cdae_prof_begin(PROF_IGEMM, 4.0 * B * heads * (double)T * T * ch, st);
+    int rc;
+#define ATB(CHV, NK) rc = launch_attn_bwd_q<CHV, NK>(qkv, probs, dout, dqkv, ds, B, heads, st)
+    if (T == 256) { if (ch == 64) ATB(64, 8); else if (ch == 96) ATB(96, 8); else ATB(128, 8); }
+    else { if (ch == 64) ATB(64, 2); else if (ch == 96) ATB(96, 2); else ATB(128, 2); }
+#undef ATB
+    cdae_prof_end(PROF_IGEMM, st);
+    return rc;
 }

@@ -294,6 +294,10 @@ int cdae_qkv_attention_fwd_fused(const float* qkv, float* out, int B, int T, int
 /* The same kernel for the TRAINING forward: additionally writes the normalised probabilities [B*heads][T][T] that
    cdae_qkv_attention_bwd reads (probs == NULL: as cdae_qkv_attention_fwd_fused).  One launch instead of GEMM, softmax, GEMM. */
 int cdae_qkv_attention_fwd_fused_p(const float* qkv, float* out, float* probs, int B, int T, int heads, int ch, void* stream);
+/* The query side of the attention backward in one launch (same shapes): dP = dO V^T, dS = P o (dP - rowsum(P o dP)) written to ds
+   ([B*heads][T][T], for the dK GEMM), dQ = dS K / sqrt(ch) written to the q slices of dqkv.  cdae_qkv_attention_bwd uses it. */
+int cdae_qkv_attention_bwd_q_fused(const float* qkv, const float* probs, const float* dout, float* dqkv, float* ds, int B, int T, int heads, int ch,
+                                   void* stream);
 
 /* ---- normalisation / softmax (norm.hip) ------------------------------------------------------------------- */
 size_t cdae_gn_workspace_floats(int N, int C);

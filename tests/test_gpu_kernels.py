@@ -691,6 +691,33 @@ def test_fused_attention_training_forward_keeps_probabilities(B, T, heads, ch):
     assert (qkv.grad.double() - xd.grad).abs().max().item() < 2e-4 * xd.grad.abs().max().item()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,heads,ch", [(3, 256, 4, 96), (5, 64, 4, 128), (2, 256, 2, 64), (2, 64, 1, 96), (1, 256, 1, 128), (2, 64, 2, 64)])
+def test_attention_backward_query_side_in_one_kernel(B, T, heads, ch):
+    """cdae_qkv_attention_bwd_q_fused (dP = dO V^T, softmax backward, dQ = dS K / sqrt(ch) in one launch) against fp64: dS and the q slices
+    of dqkv, every (T, head dim) instantiation — the dispatcher itself only takes it for T = 64."""
+    from causaldiffae_amd._lib import check, lib, ptr, stream
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(31)
+    qkv = torch.randn(B, T, 3 * heads * ch, device=dev, generator=g) * 1.1
+    dout = torch.randn(B, T, heads * ch, device=dev, generator=g) * 1e-3            # gradient-sized values (bf16 planes: no underflow)
+    x = qkv.double().reshape(B, T, heads, 3, ch)
+    q, k, v = x[:, :, :, 0], x[:, :, :, 1], x[:, :, :, 2]
+    w = torch.softmax(torch.einsum("bthc,bshc->bhts", q, k) / ch ** 0.5, dim=-1)
+    go = dout.double().reshape(B, T, heads, ch)
+    dp = torch.einsum("bthc,bshc->bhts", go, v)
+    ds = w * (dp - (w * dp).sum(-1, keepdim=True))
+    dq = torch.einsum("bhts,bshc->bthc", ds, k) / ch ** 0.5
+    probs = w.float().reshape(B * heads, T, T).contiguous()
+    dqkv = torch.zeros_like(qkv)
+    ds_out = torch.empty_like(probs)
+    check(lib.cdae_qkv_attention_bwd_q_fused(ptr(qkv), ptr(probs), ptr(dout), ptr(dqkv), ptr(ds_out), B, T, heads, ch, stream()))
+    got_dq = dqkv.reshape(B, T, heads, 3, ch)[:, :, :, 0].double()
+    assert (ds_out.double() - ds.reshape(B * heads, T, T)).abs().max().item() < 1e-4 * ds.abs().max().item()
+    assert (got_dq - dq).abs().max().item() < 1e-4 * dq.abs().max().item()
+    assert dqkv.reshape(B, T, heads, 3, ch)[:, :, :, 1:].abs().max().item() == 0.0       # k / v slices untouched
+
+
 # ----------------------------------------------------------------------------- training on the pre-split kernels
 def _wgrad_ref(a, dy):
     """fp64 weight / bias gradient of a stride-1 conv3x3 (NCHW a [N,Cin,H,W], dy [N,Cout,H,W]) in OHWI order."""

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Dev tool: the model-level GPU tests with each new kernel switched off in turn (the fallbacks must stay green).
 #   /usr/local/graft/bin/gpurun --timeout 1800 -- 'bash tools/switch_matrix.sh'
-for SW in CDAE_SKIPGN_V2 CDAE_STREAM_GEMM CDAE_HEAD_CONV CDAE_SPLITK_REDUCE4 CDAE_GN_PARTS_FUSED CDAE_UPCONV_FUSED CDAE_PLANES_GM CDAE_GN_APPLY_GM CDAE_GN_BWD_STREAM CDAE_CONVWIN CDAE_LINEAR_GN CDAE_FUSED_ATTN_TRAIN CDAE_GN_BWD_PARAM_ROW CDAE_KS_ROUNDS; do
+for SW in CDAE_SKIPGN_V2 CDAE_STREAM_GEMM CDAE_HEAD_CONV CDAE_SPLITK_REDUCE4 CDAE_GN_PARTS_FUSED CDAE_UPCONV_FUSED CDAE_PLANES_GM CDAE_GN_APPLY_GM CDAE_GN_BWD_STREAM CDAE_CONVWIN CDAE_LINEAR_GN CDAE_FUSED_ATTN_TRAIN CDAE_GN_BWD_PARAM_ROW CDAE_KS_ROUNDS CDAE_ATTN_BWD_FUSED; do
   echo "== $SW=0"
   env $SW=0 timeout 600 python3 -m pytest tests/test_gpu_model.py -x -q -k "unet_forward or ddim_p64 or p_sample_loop or guided or full_model" 2>&1 | tail -2
 done
