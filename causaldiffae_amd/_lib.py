@@ -115,13 +115,15 @@ SIGNATURES = {
     "cdae_vb_terms_bwd": [P, P, P, P, P, I, I, I, I, I, P, P, I, L, P],
     "cdae_mse_rows": [P, P, P, I, L, P],
     "cdae_mse_rows_bwd": [P, P, P, P, I, L, P],
+    "cdae_tune_set": [I, I],
+    "cdae_tune_get": [I],
     "cdae_prof_enable": [I],
     "cdae_prof_read": [P, P, P, P],
 }
 _RESTYPES = {"cdae_last_error": ctypes.c_char_p, "cdae_gn_workspace_floats": SZ, "cdae_bn_workspace_floats": SZ, "cdae_workspace_bytes": SZ}
 
 TAB_ROWS = 12
-PROF_FAMILIES = ("igemm", "groupnorm", "softmax", "elementwise", "optimizer", "convwin")
+PROF_FAMILIES = ("igemm", "groupnorm", "softmax", "elementwise", "optimizer", "convwin", "convwin_dgrad", "convwin_up")
 
 
 class CdaeError(RuntimeError):
@@ -232,6 +234,14 @@ def range_check(what="a contraction"):
                              f"or was not finite; rerun with causaldiffae_amd.set_precision('fp32') (IEEE fp32 products, fp32 range)")
 
 
+def range_clear():
+    """Drop a stale range flag (raised by an earlier user of the library in this process whose own check has not run yet), so that
+    the next range_check reports on the work issued from here on."""
+    torch.cuda.synchronize()
+    bad = ctypes.c_int(0)
+    check(lib.cdae_range_status(ctypes.byref(bad)))
+
+
 class precision_scope:
     """with precision_scope("mixed16"): ... — the library's arithmetic mode for the duration of a block, restored on exit (a model
     converted with convert_to_fp16() applies it around its own forward and TrainLoop around forward + backward, so a second model
@@ -250,6 +260,28 @@ class precision_scope:
     def __exit__(self, *exc):
         if self.name is not None and self.prev != self.name:
             set_precision(self.prev)
+        return False
+
+
+TUNE_KEYS = {"convwin_min_tiles": 0, "convwin_splitk": 1}
+
+
+class tune_scope:
+    """with tune_scope(convwin_min_tiles=1): ... — move dispatch thresholds of the library (include/cdae.h, cdae_tune_set) for the
+    duration of a block; the parity tests use it to run small golden cases on the kernels the benchmark shapes dispatch."""
+
+    def __init__(self, **kv):
+        self.kv, self.prev = kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.prev[k] = lib.cdae_tune_get(TUNE_KEYS[k])
+            check(lib.cdae_tune_set(TUNE_KEYS[k], int(v)))
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.prev.items():
+            check(lib.cdae_tune_set(TUNE_KEYS[k], v))
         return False
 
 

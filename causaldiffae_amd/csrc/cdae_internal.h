@@ -80,11 +80,15 @@ int cdae_gemm_dispatch(GemmParams p, void* stream);
 bool cdae_convwin_ok(const GemmParams& p);
 int cdae_convwin_launch(const GemmParams& p, void* stream);
 
+// run-time dispatch thresholds (cdae_tune_set / cdae_tune_get in include/cdae.h; prof.hip holds the values)
+enum { TUNE_CONVWIN_MIN_TILES = 0, TUNE_CONVWIN_SPLITK = 1, TUNE_N = 2 };
+int cdae_tune(int key);
+
 // error reporting: sets the thread-local message returned by cdae_last_error(), returns -1
 int cdae_fail(const char* msg);
 
 // lightweight per-family profiling (HIP events on the launch stream), see prof.hip
-enum { PROF_IGEMM = 0, PROF_GN = 1, PROF_SOFTMAX = 2, PROF_ELEMWISE = 3, PROF_OPT = 4, PROF_CONVWIN = 5, PROF_NFAM = 6 };
+enum { PROF_IGEMM = 0, PROF_GN = 1, PROF_SOFTMAX = 2, PROF_ELEMWISE = 3, PROF_OPT = 4, PROF_CONVWIN = 5, PROF_CONVWIN_DGRAD = 6, PROF_CONVWIN_UP = 7, PROF_NFAM = 8 };
 void cdae_prof_begin(int family, double work, hipStream_t st);
 void cdae_prof_end(int family, hipStream_t st);
 void cdae_prof_note(int family, double bytes);

@@ -85,7 +85,7 @@ __device__ __forceinline__ void cw_dma(const void* sbase, int soff, unsigned vof
     return;
 #endif
     const char* base = reinterpret_cast<const char*>(sbase) + __builtin_amdgcn_readfirstlane(soff);
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane((int)lds_dst)), "v"(voff), "s"(base) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane((int)lds_dst)), "v"(voff), "s"(base) : "memory", "m0");
 }
 
 // NT = 9: the 3x3 window.  NT = 4: the 2x2 window of one sub-pixel phase (ph_y, ph_x) of nearest-2x-upsample + conv3x3 (tap t reads window
@@ -603,6 +603,7 @@ bool cdae_convwin_ok(const GemmParams& p) {
     if (p.W != 8 && p.W != 16 && p.W != 32 && p.W != 64) return false;            // tight window: tiles start on image-row boundaries
     if (p.Cin % 32 || p.ldb % 8 || p.sx % 8) return false;
     if ((long)p.M * p.sx * 2 >= (1L << 32) || (long)p.N * p.ldb * 2 >= (1L << 32)) return false;      // 32-bit byte offsets in the DMAs
+    if (p.a_gm && (long)p.M * p.Cin * 2 >= (1L << 31)) return false;      // group-major planes: the group base g * M * 32 is a signed 32-bit scalar offset
     return true;
 }
 

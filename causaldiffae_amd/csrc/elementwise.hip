@@ -105,12 +105,13 @@ __global__ __launch_bounds__(256) void wdgrad_planes_kernel(const float* __restr
 // planes of the dgrad weight ([Cin][9][Cout], taps flipped).  desc[i] = {weight offset in `flat` (elements), Cout, Cin, first tile};
 // a block = one 32 x 32 (co, ci) tile of one tap of one weight; output planes use the same element offsets, relative to the first
 // registered weight's offset `base`.
-struct WPrepDesc { long off; int Cout, Cin, tile0, pad; };
+struct WPrepDesc { long off; int Cout, Cin, tile0, flags; };      // flags bit 0: also write the K-group-major planes (Cout % 16 == 0 and Cin % 16 == 0)
 __global__ __launch_bounds__(256) void wprep_all_kernel(const float* __restrict__ flat, const WPrepDesc* __restrict__ desc, int nw, long base,
                                                         _Float16* __restrict__ fh, _Float16* __restrict__ fl, __bf16* __restrict__ bh,
                                                         __bf16* __restrict__ bl, _Float16* __restrict__ kfh, _Float16* __restrict__ kfl,
                                                         __bf16* __restrict__ kbh, __bf16* __restrict__ kbl) {
-    // kf* / kb* (optional): the same planes in K-group-major order [K / 16][9][rows][16] (cdae_conv_wpack's layout) at the same offsets
+    // kf* / kb* (optional): the same planes in K-group-major order [K / 16][9][rows][16] (cdae_conv_wpack's layout) at the same offsets, for the
+    // weights whose descriptor asks for them (a packed index of a weight with Cin % 16 != 0 would leave the weight's own region)
     __shared__ float tile[32][33];
     int lo = 0, hi = nw - 1;                       // last descriptor whose first tile <= blockIdx.x
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (desc[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void wprep_all_kernel(const float* __restrict_
             const _Float16 h = (_Float16)v;
             const _Float16 l = (_Float16)(v - (float)h);
             fh[o0 + i] = h; fl[o0 + i] = l;
-            if (kfh) {
+            if (kfh && (d.flags & 1)) {
                 const long k = o0 + (((long)(ci >> 4) * 9 + tap) * d.Cout + co) * 16 + (ci & 15);
                 kfh[k] = h; kfl[k] = l;
             }
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256) void wprep_all_kernel(const float* __restrict_
             const long o = o0 + ((long)ci * 9 + (8 - tap)) * d.Cout + co;
             const __bf16 l = (__bf16)(v - (float)h);
             bh[o] = h; bl[o] = l;
-            if (kbh) {
+            if (kbh && (d.flags & 1)) {
                 const long k = o0 + (((long)(co >> 4) * 9 + (8 - tap)) * d.Cin + ci) * 16 + (co & 15);
                 kbh[k] = h; kbl[k] = l;
             }

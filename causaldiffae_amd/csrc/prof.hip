@@ -41,10 +41,18 @@ int* cdae_range_flag_ptr() {
     return dev;
 }
 
+namespace {
+// defaults = the measured optimum on MI355X (dispatch table)
+int g_tune[TUNE_N] = {256, 1};
+}
+int cdae_tune(int key) { return key >= 0 && key < TUNE_N ? g_tune[key] : 0; }
+
 int cdae_fail(const char* msg) { g_err = msg ? msg : "unknown"; return -1; }
 
 void cdae_prof_begin(int fam, double work, hipStream_t st) {
     if (!g_on) return;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;      // a launch being captured into a graph has no time of its own
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return;
     std::lock_guard<std::mutex> lk(g_mu);
     t_start = get_event();
     t_work = work; t_bytes = 0; t_fam = fam; t_tag[0] = 0;
@@ -90,6 +98,14 @@ int cdae_range_status(int* nonfinite) {
     *v = 0;
     return 0;
 }
+
+int cdae_tune_set(int key, int value) {
+    if (key < 0 || key >= TUNE_N) return cdae_fail("tune_set: unknown key");
+    if (value < 0) return cdae_fail("tune_set: value must be >= 0");
+    g_tune[key] = value;
+    return 0;
+}
+int cdae_tune_get(int key) { return key >= 0 && key < TUNE_N ? g_tune[key] : -1; }
 
 int cdae_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_mu);

@@ -292,7 +292,15 @@ class GaussianDiffusion:
             from tqdm.auto import tqdm
             order = tqdm(order)
         runner = None
-        if use_graph and self._hot and denoised_fn is None and step_noise is None and (ddim and eta == 0.0):
+        if self._hot and img.is_cuda:
+            from ._lib import range_clear
+            range_clear()                       # the check at the end of this loop reports on this loop's work only
+        eligible = self._hot and denoised_fn is None and step_noise is None and ddim and eta == 0.0 and img.is_cuda
+        if use_graph is None:
+            # default: replay the step as a HIP graph wherever that is exact (static shapes, no per-step host input, deterministic DDIM,
+            # eval-mode network) and the loop is long enough to pay for one extra warm-up step and the capture
+            use_graph = eligible and not model.training and self.num_timesteps >= 8
+        if use_graph and eligible:
             # the replay updates its image buffer in place: never the caller's `noise` (the reference leaves it untouched)
             runner = _GraphStep(self, model, img.clone() if noise is not None and img.data_ptr() == noise.data_ptr() else img,
                                 model_kwargs, clip_denoised, w)
@@ -331,12 +339,14 @@ class GaussianDiffusion:
     yield_copies = True        # graph replay: yield clones of the static buffers (ddim_sample_loop itself turns this off: it keeps only the last)
 
     def ddim_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, model_kwargs=None,
-                                     device=None, progress=False, eta=0.0, w=None, step_noise=None, use_graph=False):
+                                     device=None, progress=False, eta=0.0, w=None, step_noise=None, use_graph=None):
         yield from self._loop(True, model, shape, noise, clip_denoised, denoised_fn, model_kwargs, device, progress, eta, w,
                               step_noise, use_graph)
 
     def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, model_kwargs=None, device=None,
-                         progress=False, eta=0.0, w=None, step_noise=None, use_graph=False):
+                         progress=False, eta=0.0, w=None, step_noise=None, use_graph=None):
+        """use_graph: None (default) = replay one captured step per iteration wherever eligible (see _loop), False = eager launches,
+        True = insist (still eager when a per-step host input — denoised_fn, step_noise, eta > 0 — rules the graph out)."""
         final = None
         self.yield_copies = False
         try:
@@ -345,7 +355,7 @@ class GaussianDiffusion:
                 final = sample
         finally:
             self.yield_copies = True
-        return final["sample"].clone() if use_graph else final["sample"]
+        return final["sample"].clone() if use_graph is not False else final["sample"]
 
     # ------------------------------------------------------------------ losses
     def prior(self, scale, label, dim):

@@ -739,15 +739,17 @@ class ConvWeightBank:
         span = max(o + w.numel() for o, w in zip(offs, self.weights)) - self.base
         self.f16 = torch.empty((2, span), dtype=torch.float16, device=dev)
         self.b16 = torch.empty((2, span), dtype=torch.bfloat16, device=dev)
-        # the same planes in K-group-major order for the second-generation window kernel (channel counts % 16 == 0 everywhere)
-        self.kpack = _KPACK_ON and all(w.shape[0] % 16 == 0 and w.shape[1] % 16 == 0 for w in self.weights)
+        # the same planes in K-group-major order for the second-generation window kernel: per weight, where both channel counts are
+        # multiples of 16 (the stem conv [128, 3, 3, 3] and the head conv [3, 128, 3, 3] of a UNet are in the bank too, and are not)
+        self.packable = {id(w) for w in self.weights if _KPACK_ON and w.shape[0] % 16 == 0 and w.shape[1] % 16 == 0}
+        self.kpack = bool(self.packable)
         self.kf16 = torch.empty((2, span), dtype=torch.float16, device=dev) if self.kpack else None
         self.kb16 = torch.empty((2, span), dtype=torch.bfloat16, device=dev) if self.kpack else None
-        desc = np.zeros(len(self.weights), dtype=np.dtype([("off", "<i8"), ("cout", "<i4"), ("cin", "<i4"), ("tile0", "<i4"), ("pad", "<i4")]))
+        desc = np.zeros(len(self.weights), dtype=np.dtype([("off", "<i8"), ("cout", "<i4"), ("cin", "<i4"), ("tile0", "<i4"), ("flags", "<i4")]))
         tiles, self.where = 0, {}
         for i, (o, w) in enumerate(zip(offs, self.weights)):
             Cout, Cin = w.shape[0], w.shape[1]
-            desc[i] = (o, Cout, Cin, tiles, 0)
+            desc[i] = (o, Cout, Cin, tiles, 1 if id(w) in self.packable else 0)
             tiles += 9 * ((Cout + 31) // 32) * ((Cin + 31) // 32)
             self.where[id(w)] = (o - self.base, w.numel())
         self.tiles = tiles
@@ -771,8 +773,8 @@ class ConvWeightBank:
         return buf[0, o:o + n], buf[1, o:o + n]
 
     def packed(self, w, bf16):
-        """K-group-major planes (cdae_conv_wpack's order) or (None, None)"""
-        if not self.kpack:
+        """K-group-major planes (cdae_conv_wpack's order), or (None, None) for a weight whose channel counts are not multiples of 16"""
+        if id(w) not in self.packable:
             return None, None
         self._refresh(w)
         o, n = self.where[id(w)]

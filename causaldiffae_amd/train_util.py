@@ -195,6 +195,18 @@ class FusedAdamWEMA:
             sd[n] = self.ema[i].as_strided(p.shape, p.stride(), o)
         return sd
 
+    def torch_state_dict(self):
+        """The Adam moments in torch.optim.AdamW.state_dict() layout over model.parameters() order — the format the reference's trainer
+        writes and loads under `opt<step>.pt` (train_util.py:159-169, 340-343), so either trainer resumes from the other's file."""
+        f = self.flat
+        where = {n: (p, o) for n, p, o in zip(f.names, f.params, f.offsets)}
+        order = [n for n, _ in self.model.named_parameters()]
+        view = lambda buf, n: buf.as_strided(where[n][0].shape, where[n][0].stride(), where[n][1]).detach().cpu().contiguous()
+        state = {i: {"step": th.tensor(float(self.t)), "exp_avg": view(self.m, n), "exp_avg_sq": view(self.v, n)} for i, n in enumerate(order)} if self.t > 0 else {}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(order)))}
+        return {"state": state, "param_groups": [group]}
+
     def broadcast_from_rank0(self):
         if dist.is_initialized() and dist.get_world_size() > 1:
             dist.broadcast(self.flat.flat, 0)
@@ -378,9 +390,27 @@ class TrainLoop:
         if self.step % self.log_interval == 0 and self.last_losses is not None:      # one host sync per log interval
             log_loss_dict(self.diffusion, self.last_t, {k: v * self.last_w for k, v in self.last_losses.items()})
             logger.logkv_mean("grad_norm", float(np.sqrt(self.opt.grad_sqsum())))
-            if dist_util.dev().type == "cuda":
-                from ._lib import range_check
-                range_check("training step")     # an operand left the f16 range of the split-precision planes: stop instead of training on NaNs
+            self.range_guard("training step")    # an operand left the f16 range of the split-precision planes: stop instead of training on NaNs
+
+    def range_guard(self, what):
+        """The library's range flag (include/cdae.h cdae_range_status), agreed on by ALL ranks: the flag is per process, and a rank that
+        raised alone would leave its peers waiting in the next bucket all-reduce until the RCCL timeout."""
+        if dist_util.dev().type != "cuda":
+            return
+        from ._lib import CdaeRangeError, range_check
+        bad = 0
+        try:
+            range_check(what)
+        except CdaeRangeError as e:
+            bad, err = 1, e
+        if self.world > 1:
+            backend = dist.get_backend()
+            flag = th.tensor([bad], dtype=th.int32, device=dist_util.dev() if backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()) and not bad:
+                raise CdaeRangeError(f"{what}: another rank reported a non-finite contraction result (f16 split-precision range); stopping with it")
+        if bad:
+            raise err
 
     def _load_resume_state(self, resume_checkpoint):
         """EMA per rate and the Adam moments of the checkpoint's step.  `ema_<rate>_<step>.pt` / `opt<step>.pt` (upstream
@@ -389,8 +419,10 @@ class TrainLoop:
         d, step = os.path.dirname(resume_checkpoint), self.resume_step
         f = self.opt.flat
 
-        def into(flat_buf, sd):
+        def into(flat_buf, sd, partial=False):
             for n, p, o in zip(f.names, f.params, f.offsets):
+                if partial and n not in sd:
+                    continue
                 flat_buf.as_strided(p.shape, p.stride(), o).copy_(sd[n])
 
         found = set()
@@ -405,12 +437,29 @@ class TrainLoop:
         opt_path = os.path.join(d, f"opt{step:06d}.pt")
         if os.path.exists(opt_path):
             st = dist_util.load_state_dict(opt_path, map_location="cpu")
-            into(self.opt.m, st["exp_avg"])
-            into(self.opt.v, st["exp_avg_sq"])
-            self.opt.t = int(st["step"])
+            if "state" in st and "param_groups" in st:
+                # torch.optim.AdamW.state_dict() — what the reference writes and reads under this name (train_util.py:159-169, 340-343) and
+                # what save() below writes: per-parameter state indexed in model.parameters() order
+                order = [n for n, _ in self.model.named_parameters()]
+                idx = [i for g in st["param_groups"] for i in g["params"]]
+                if len(idx) != len(order):
+                    logger.log(f"{opt_path}: optimizer state for {len(idx)} parameters, the model has {len(order)}; Adam moments start from zero")
+                    return
+                state = st["state"]
+                into(self.opt.m, {n: state[i]["exp_avg"] for n, i in zip(order, idx) if i in state}, partial=True)
+                into(self.opt.v, {n: state[i]["exp_avg_sq"] for n, i in zip(order, idx) if i in state}, partial=True)
+                steps = [int(float(state[i]["step"])) for i in idx if i in state]
+                self.opt.t = max(steps) if steps else 0
+            elif "exp_avg" in st and "exp_avg_sq" in st:          # round-1/2 private layout of this trainer
+                into(self.opt.m, st["exp_avg"])
+                into(self.opt.v, st["exp_avg_sq"])
+                self.opt.t = int(st["step"])
+            else:
+                logger.log(f"{opt_path}: unknown optimizer checkpoint layout (keys {sorted(st)[:4]}); Adam moments start from zero")
 
     # ------------------------------------------------------------------ checkpoints (names of train_util.py:319-345)
     def save(self):
+        self.range_guard("checkpoint")          # never write weights that consumed non-finite gradients
         if self.rank == 0:             # the reference writes on rank 1 only (so never in single-process runs): fixed, SURVEY Q6
             d = get_blob_logdir()
             if d:
@@ -422,11 +471,7 @@ class TrainLoop:
                     esd = {k: v.detach().cpu().contiguous() for k, v in self.opt.ema_state_dict(i).items()}
                     th.save(esd, os.path.join(d, "ema_checkpoint.pt"))          # the reference's name (one file, the last rate wins)
                     th.save(esd, os.path.join(d, f"ema_{rate}_{step:06d}.pt"))    # + one file per rate, so a resume restores every rate
-                f = self.opt.flat
-                names = set(f.names)
-                view = lambda buf: {n: buf.as_strided(p.shape, p.stride(), o).detach().cpu().contiguous() for n, p, o in zip(f.names, f.params, f.offsets)
-                                    if n in names}
-                th.save({"exp_avg": view(self.opt.m), "exp_avg_sq": view(self.opt.v), "step": self.opt.t}, os.path.join(d, f"opt{step:06d}.pt"))
+                th.save(self.opt.torch_state_dict(), os.path.join(d, f"opt{step:06d}.pt"))
         if dist.is_initialized():
             dist.barrier()
 

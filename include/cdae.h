@@ -22,7 +22,8 @@ extern "C" {
 #define CDAE_VERSION 1
 #define CDAE_GN_MAX_CHUNKS 64
 #define CDAE_BN_MAX_CHUNKS 256
-#define CDAE_PROF_FAMILIES 6      /* 0 igemm (every contraction but 5), 1 groupnorm, 2 softmax, 3 elementwise, 4 optimizer, 5 convwin (the window conv kernel) */
+#define CDAE_PROF_FAMILIES 8      /* 0 igemm (every contraction but 5-7), 1 groupnorm, 2 softmax, 3 elementwise, 4 optimizer, 5 convwin (convwin_kernel<f16, 9 taps>: the forward
+                                   * stride-1 conv3x3), 6 convwin_dgrad (convwin_kernel<bf16, 9 taps>), 7 convwin_up (convwin_kernel<f16, 4 taps>: sub-pixel up-conv phases) */
 
 /* rows of the fp32 coefficient table passed to the sampler kernels: tab[row * T + t]
  * (float32 roundings of the float64 tables of gaussian_diffusion.py:137-179, i.e. what
@@ -385,6 +386,16 @@ int cdae_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, lon
 int cdae_sqsum(const float* x, long n, double* out, void* stream);                                            /* grad-norm, train_util.py:299-303 */
 int cdae_mse_rows(const float* a, const float* b, float* out, int N, long per, void* stream);               /* mean_flat((a-b)^2), gaussian_diffusion.py:847 */
 int cdae_mse_rows_bwd(const float* a, const float* b, const float* gout, float* db, int N, long per, void* stream);
+
+/* ---- dispatch thresholds.  The dispatcher picks a kernel per shape from measured thresholds; these two can be moved at run time
+ * (process-wide, not thread-safe against concurrent launches).  The parity tests use them to run small golden cases through the
+ * kernels the large benchmark shapes dispatch; nothing else changes numerically relevant behaviour.
+ *   CDAE_TUNE_CONVWIN_MIN_TILES  (256) stride-1 conv3x3 on planes runs on convwin_kernel when 256x128 tiles x K splits >= this,
+ *                                else on the first-generation 128-row window kernel (smaller tiles fill the chip at small batch)
+ *   CDAE_TUNE_CONVWIN_SPLITK     (1)   0: convwin_kernel never splits K */
+enum { CDAE_TUNE_CONVWIN_MIN_TILES = 0, CDAE_TUNE_CONVWIN_SPLITK = 1 };
+int cdae_tune_set(int key, int value);
+int cdae_tune_get(int key);       /* -1: unknown key */
 
 /* ---- opt-in profiler (prof.hip): HIP events on the launch stream around every launch of a kernel family */
 int cdae_prof_enable(int on);

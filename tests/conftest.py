@@ -36,3 +36,31 @@ def precision(request):
     causaldiffae_amd.set_precision(request.param)
     yield request.param
     causaldiffae_amd.set_precision(old)
+
+
+class ExpectKernels:
+    """with expect_kernels(convwin=1, convwin_dgrad=1): ... — the block must have launched at least that many kernels of each named
+    profile family (include/cdae.h CDAE_PROF_FAMILIES), i.e. the test proves WHICH kernel produced the numbers it checks."""
+
+    def __init__(self, **minimum):
+        self.minimum, self.seen = minimum, None
+
+    def __enter__(self):
+        from causaldiffae_amd import _lib
+        _lib.prof_enable(True)
+        _lib.prof_read()
+        return self
+
+    def __exit__(self, et, ev, tb):
+        from causaldiffae_amd import _lib
+        self.seen = _lib.prof_read()
+        _lib.prof_enable(False)
+        if et is None:
+            for fam, n in self.minimum.items():
+                assert self.seen[fam]["launches"] >= n, (fam, {k: v["launches"] for k, v in self.seen.items()})
+        return False
+
+
+@pytest.fixture
+def expect_kernels():
+    return ExpectKernels

@@ -966,6 +966,99 @@ def test_resblock_training_node_two_sources(N, C1, C2, Cout, H):
         assert (f.double().reshape(r.shape) - r).abs().max().item() < 3e-5 * r.abs().max().item(), n
 
 
+# (N, C, Cout, H) of the C64 training benchmark at batch 32 per GPU (bench.py --train-batch 32) and of the sampling benchmark at batch
+# 128: at these sizes the dispatcher takes convwin_kernel<f16, 9> for the forward and convwin_kernel<bf16, 9> for dgrad (split-K at
+# the 16 x 16 and 8 x 8 levels) — the small cases above all run on the first-generation 128-row window kernel.
+BENCH_NODE_SHAPES = [(32, 128, 128, 64), (32, 256, 256, 32), (64, 384, 384, 16), (128, 512, 512, 8)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C,Cout,H", BENCH_NODE_SHAPES + [(32, 256, 128, 64)])
+def test_fused_gn_conv_training_node_on_benchmark_dispatch(N, C, Cout, H, expect_kernels):
+    """ops.gn_conv3x3 at the benchmark's sizes: forward on convwin_kernel<f16>, dgrad on convwin_kernel<bf16> (asserted from the
+    library's launch log), wgrad on wgwin_kernel — against torch autograd in fp64 at the bar of the small cases (2e-5 of each
+    tensor's own scale).  Reference ops: unet.py:185-198 forward / backward."""
+    from causaldiffae_amd import ops
+    with torch.enable_grad():
+        assert ops.train_presplit_ok((N, C, H, H), Cout)
+        with expect_kernels(convwin=1, convwin_dgrad=1):
+            fused = _gnconv_case(N, C, Cout, H, True, True, "fused")
+        ref = _gnconv_case(N, C, Cout, H, True, True, "f64")
+    for name, f, r in zip(("out", "dx", "dgamma", "dbeta", "dss", "dw", "db", "dres"), fused, ref):
+        sc = r.abs().max().item() + 1e-30
+        assert (f.double() - r).abs().max().item() / sc < 2e-5, name
+
+
+def _resblock_case(N, C1, C2, Cout, H, mode, seed=9):
+    """One ResBlock (identity / 1x1 skip; C2 > 0: the input is the skip concatenation [a | b]) forward + backward; mode "f64" = torch
+    autograd in fp64, "node" = ops.resblock_train.  Returns (names, tensors)."""
+    import torch.nn.functional as F
+    from causaldiffae_amd import ops
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(seed)
+    cl = torch.channels_last
+    C = C1 + C2
+
+    def rnd(*shape, scale=1.0):
+        return torch.randn(*shape, device=dev, generator=g) * scale
+
+    a0 = rnd(N, C1, H, H).contiguous(memory_format=cl)
+    b0 = rnd(N, C2, H, H).contiguous(memory_format=cl) if C2 else None
+    ss0 = rnd(N, 2 * Cout, scale=0.2)
+    p0 = dict(g1=1 + rnd(C, scale=0.1), b1=rnd(C, scale=0.1), w1=(rnd(Cout, C, 3, 3) / (3 * C ** 0.5)).contiguous(memory_format=cl),
+              c1b=rnd(Cout, scale=0.1), g2=1 + rnd(Cout, scale=0.1), b2=rnd(Cout, scale=0.1),
+              w2=(rnd(Cout, Cout, 3, 3) / (3 * Cout ** 0.5)).contiguous(memory_format=cl), c2b=rnd(Cout, scale=0.1))
+    if C != Cout:
+        p0.update(sw=rnd(Cout, C, 1, 1) / C ** 0.5, sb=rnd(Cout, scale=0.1))
+    dy = rnd(N, Cout, H, H).contiguous(memory_format=cl) * 1e-3
+    dt = torch.float64 if mode == "f64" else torch.float32
+    a, ss = a0.detach().to(dt).requires_grad_(), ss0.detach().to(dt).requires_grad_()
+    b = b0.detach().to(dt).requires_grad_() if C2 else None
+    p = {k: v.detach().to(dt).requires_grad_() for k, v in p0.items()}
+    if mode == "f64":
+        x = torch.cat([a, b], dim=1) if C2 else a
+        h = F.conv2d(F.silu(F.group_norm(x, 32, p["g1"], p["b1"], 1e-5)), p["w1"], p["c1b"], padding=1)
+        h = F.group_norm(h, 32, p["g2"], p["b2"], 1e-5) * (1 + ss[:, :Cout, None, None]) + ss[:, Cout:, None, None]
+        out = F.conv2d(F.silu(h), p["w2"], p["c2b"], padding=1) + (x if C == Cout else F.conv2d(x, p["sw"], p["sb"]))
+    else:
+        x = ops.cat_channels(a, b) if C2 else a
+        out = ops.resblock_train(x, ss, p["g1"], p["b1"], p["w1"], p["c1b"], p["g2"], p["b2"], p["w2"], p["c2b"], p.get("sw"), p.get("sb"))
+    out.backward(dy.to(dt))
+    names = ["out", "da"] + (["db"] if C2 else []) + ["dss"] + sorted(p0)
+    return names, [out.detach(), a.grad] + ([b.grad] if C2 else []) + [ss.grad] + [p[k].grad for k in sorted(p)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C1,C2,Cout,H", [(32, 128, 0, 128, 64), (32, 256, 0, 256, 32), (64, 384, 0, 384, 16), (128, 512, 0, 512, 8),
+                                             (32, 128, 0, 256, 32),        # 1x1 skip conv
+                                             (32, 256, 128, 128, 64),      # skip concatenation at the 64 x 64 level (last up block of the C64 UNet)
+                                             (32, 512, 384, 384, 16)])     # skip concatenation, split-K dgrad
+def test_resblock_training_node_on_benchmark_dispatch(N, C1, C2, Cout, H, expect_kernels):
+    """ops.resblock_train (the node bench.py's training leg spends its time in) at the benchmark's per-GPU sizes, incl. a 1x1-skip and
+    two two-source blocks: both convs' forward on convwin_kernel<f16>, both dgrads on convwin_kernel<bf16> (asserted from the launch
+    log), against torch autograd in fp64 for every input and parameter at the small cases' bar (3e-5 of each tensor's own scale)."""
+    with torch.enable_grad():
+        with expect_kernels(convwin=2, convwin_dgrad=2):
+            names, got = _resblock_case(N, C1, C2, Cout, H, "node")
+        _, ref = _resblock_case(N, C1, C2, Cout, H, "f64")
+    for n, f, r in zip(names, got, ref):
+        assert (f.double().reshape(r.shape) - r).abs().max().item() < 3e-5 * r.abs().max().item(), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C1,C2,Cout,H", [(2, 128, 0, 128, 64), (2, 256, 128, 128, 32), (3, 512, 0, 512, 8), (2, 128, 0, 256, 16)])
+def test_resblock_training_node_forced_onto_window_kernel(N, C1, C2, Cout, H, expect_kernels):
+    """The small shapes of the model-level goldens (N = 2) pushed through convwin_kernel forward and dgrad by the dispatch threshold
+    (cdae_tune_set CDAE_TUNE_CONVWIN_MIN_TILES = 1): partial tiles, one tile per block, split-K slabs of a few rows."""
+    from causaldiffae_amd._lib import tune_scope
+    with torch.enable_grad():
+        with tune_scope(convwin_min_tiles=1), expect_kernels(convwin=2, convwin_dgrad=2):
+            names, got = _resblock_case(N, C1, C2, Cout, H, "node", seed=23)
+        _, ref = _resblock_case(N, C1, C2, Cout, H, "f64", seed=23)
+    for n, f, r in zip(names, got, ref):
+        assert (f.double().reshape(r.shape) - r).abs().max().item() < 3e-5 * r.abs().max().item(), n
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("stream_kernel", [True, False])
 @pytest.mark.parametrize("N,C1,C2,Cout,H", [(4, 128, 128, 128, 32), (2, 256, 128, 256, 16), (3, 512, 384, 512, 8), (2, 128, 0, 256, 32),

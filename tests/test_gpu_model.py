@@ -248,6 +248,10 @@ def test_causal_layer_golden(golden):
 # ------------------------------------------------------------------ G6: full UNet forward at BASELINE shapes
 @pytest.mark.parametrize("tag", ["M32", "P64", "C64"])
 def test_unet_forward_golden(golden, tag, precision):
+    _unet_forward_check(golden, tag)
+
+
+def _unet_forward_check(golden, tag):
     from improved_diffusion.nn import rng_override
     g = golden("g6_unet.npz")
     model, diff, cfg = make(tag)
@@ -267,6 +271,10 @@ def test_unet_forward_golden(golden, tag, precision):
 
 # ------------------------------------------------------------------ G8: counterfactual pattern, single steps, DDIM-100
 def test_ddim_p64_golden(golden, precision):
+    _ddim_p64_check(golden)
+
+
+def _ddim_p64_check(golden):
     from improved_diffusion.nn import reparameterize
     from improved_diffusion.unet import ADJACENCY
     g = golden("g8_ddim.npz")
@@ -299,13 +307,16 @@ def test_ddim_p64_golden(golden, precision):
             assert err(o["sample"], g[f"p_step{tv}/sample"]) < 1e-4
         # DDIM-100 loop, eager and graph-replayed: both within 1e-4 of the reference's final sample
         k = 0
-        for o in diff.ddim_sample_loop_progressive(model, (N, 4, 64, 64), noise=x_t, model_kwargs=dict(z=zz)):
+        for o in diff.ddim_sample_loop_progressive(model, (N, 4, 64, 64), noise=x_t, model_kwargs=dict(z=zz), use_graph=False):
             k += 1
             if k in (1, 2, 10, 50, 100):
                 assert err(o["sample"], g[f"loop/sample_after{k}"]) < 1e-4, k
         final = diff.ddim_sample_loop(model, (N, 4, 64, 64), noise=x_t, model_kwargs=dict(z=zz), use_graph=True)
         assert err(final, g["loop/sample_after100"]) < 1e-4
         assert err(final, o["sample"]) == 0.0          # graph replay == eager, bit for bit
+        # the DEFAULT call of a reference script (image_causaldae_test.py:587-594: no use_graph argument) takes the replayed path
+        assert err(diff.ddim_sample_loop(model, (N, 4, 64, 64), noise=x_t, model_kwargs=dict(z=zz)), final) == 0.0
+        assert err(x_t, g["cf/x_t"]) < 1e-6              # and leaves the caller's noise untouched
 
 
 # ------------------------------------------------------------------ G7: training_losses + AdamW/EMA trajectory
@@ -386,6 +397,10 @@ def _full_train_step(g, tag, **extra):
 
 @pytest.mark.parametrize("tag", ["M32", "C64"])
 def test_full_model_training_step_golden(golden, tag, precision):
+    _full_model_training_check(golden, tag)
+
+
+def _full_model_training_check(golden, tag):
     """training_losses + backward (reference gaussian_diffusion.py:768-859) on the 41 M / 93 M parameter models bench.py trains:
     loss terms, the squared gradient norm and EVERY parameter's gradient (head + strided samples) against the reference's, each
     gradient judged relative to its own largest entry.  The backward GEMMs form bf16x3 products (2^-16 per product)."""
@@ -428,6 +443,10 @@ def test_use_checkpoint_gradients_golden(golden):
 
 # ------------------------------------------------------------------ G13: guidance w (reference gaussian_diffusion.py:277-285)
 def test_guided_ddim_step_golden(golden, precision):
+    _guided_check(golden)
+
+
+def _guided_check(golden):
     g = golden("g13_guidance.npz")
     model, diff, cfg = make("P64", respacing="ddim100")
     model.eval()
@@ -452,6 +471,10 @@ def test_guided_ddim_step_golden(golden, precision):
 
 # ------------------------------------------------------------------ G14: p_sample_loop end to end (reference gaussian_diffusion.py:416-504)
 def test_p_sample_loop_golden(golden, precision):
+    _p_sample_loop_check(golden)
+
+
+def _p_sample_loop_check(golden):
     g = golden("g14_p_sample_loop.npz")
     model, diff, cfg = make("M32", respacing="20")
     model.eval()
@@ -472,6 +495,115 @@ def test_p_sample_loop_golden(golden, precision):
     assert err(final, g["sample_after20"]) < 1e-4
     assert err(x_T, synth("M32.xT", (N, 1, 32, 32), -1.7, 1.7)) == 0.0          # the caller's noise is left untouched
 
+
+
+# ------------------------------------------------------------------ the same goldens through the kernels the BENCHMARK dispatches
+BENCH_DISPATCH_CASES = {
+    "unet_M32": (lambda g: _unet_forward_check(g, "M32"), dict(convwin=10, convwin_up=1)),
+    "unet_P64": (lambda g: _unet_forward_check(g, "P64"), dict(convwin=40, convwin_up=3)),
+    "unet_C64": (lambda g: _unet_forward_check(g, "C64"), dict(convwin=40, convwin_up=3)),
+    "ddim_p64": (lambda g: _ddim_p64_check(g), dict(convwin=40, convwin_up=3)),
+    "guided": (lambda g: _guided_check(g), dict(convwin=40, convwin_up=3)),
+    "p_sample_loop": (lambda g: _p_sample_loop_check(g), dict(convwin=10, convwin_up=1)),
+    "train_M32": (lambda g: _full_model_training_check(g, "M32"), dict(convwin=10, convwin_dgrad=10)),
+    "train_C64": (lambda g: _full_model_training_check(g, "C64"), dict(convwin=40, convwin_dgrad=40)),
+}
+
+
+@pytest.mark.parametrize("which", list(BENCH_DISPATCH_CASES))
+def test_goldens_on_benchmark_dispatch(golden, which, expect_kernels):
+    """The N = 2 goldens above dispatch the small-grid kernels (ps / pswin, pixel-major planes, four launches per up-conv).  bench.py's
+    batch 128 / 32 runs convwin_kernel<f16, 9> (forward), <bf16, 9> (dgrad) and <f16, 4> (fused sub-pixel phases) on group-major
+    planes instead.  Here the dispatch threshold is lowered (cdae_tune_set, include/cdae.h) so that the SAME reference-generated
+    fixtures — full UNet forwards, single DDIM / DDPM / guided steps, the DDIM-100 and p_sample loops, the 41 M / 93 M parameter
+    training steps with every gradient — are ASSEMBLED from the benchmark's kernels, and the launch log proves they ran
+    (reference: unet.py:525-632, gaussian_diffusion.py:277-285, 416-558, 768-859)."""
+    import causaldiffae_amd
+    from causaldiffae_amd._lib import tune_scope
+    fn, minimum = BENCH_DISPATCH_CASES[which]
+    assert causaldiffae_amd.get_precision() == "f16x3"
+    with tune_scope(convwin_min_tiles=1), expect_kernels(**minimum) as seen:
+        fn(golden)
+    if which.startswith("unet") or which in ("ddim_p64", "guided"):
+        assert seen.seen["convwin_dgrad"]["launches"] == 0
+
+
+def test_ddim_step_batch_invariance_at_benchmark_batch(golden, expect_kernels):
+    """One P64 DDIM step at bench.py's batch 128 whose images 0-1 are the G8 golden inputs: the eval-mode network is per-image
+    (GroupNorm, attention and the conditioning are all per sample), so rows 0-1 must equal the reference's N = 2 outputs to 1e-4
+    while the whole batch runs the production dispatch (512 tiles per 64 x 64 conv, split-K at 8 x 8, group-major planes, fused
+    up-conv phases) — no threshold is moved here."""
+    from improved_diffusion.nn import reparameterize
+    from improved_diffusion.unet import ADJACENCY
+    g = golden("g8_ddim.npz")
+    model, diff, cfg = make("P64", respacing="ddim100")
+    model.eval()
+    N, B = 2, 128
+    x, x0, c, z, _ = model_inputs("P64", cfg, N)
+    gen = torch.Generator().manual_seed(77)
+    with torch.no_grad():
+        A = torch.tensor(ADJACENCY["pendulum"], dtype=torch.float32)
+        mu, var = model.rep_emb.encode(x0.to(DEV))
+        z_post = model.causal_mask.nonlinearity_add_back_noise(mu, model.causal_mask.causal_masking(mu, A))
+        z_post[:, :128] = 0.2
+        zz = reparameterize(z_post, torch.ones_like(mu) * 0.001, eps=torch.from_numpy(g["cf/eps_draw"]).to(DEV))
+        t99 = torch.full((N,), 99, dtype=torch.int64, device=DEV)
+        x_t = diff.q_sample(x0.to(DEV), t99, noise=synth("P64.qnoise", (N, 4, 64, 64), -1.7, 1.7).to(DEV))
+        # 126 more images of the same statistics behind the two golden ones
+        xb = torch.cat([x_t, torch.randn(B - N, 4, 64, 64, generator=gen).to(DEV)], dim=0)
+        zb = torch.cat([zz, (0.2 + 0.03 * torch.randn(B - N, 512, generator=gen)).to(DEV)], dim=0)
+        for tv in (99, 0):
+            tt = torch.full((B,), tv, dtype=torch.int64, device=DEV)
+            amp = float(diff.sqrt_recipm1_alphas_cumprod[tv])
+            with expect_kernels(convwin=40, convwin_up=3):
+                o = diff.ddim_sample(model, xb, tt, model_kwargs=dict(z=zb))
+            assert err(o["sample"][:N], g[f"ddim_step{tv}/sample"]) < 1e-4, tv
+            assert err(o["pred_xstart"][:N], g[f"ddim_step{tv}/pred_xstart"]) < 1e-4 + 1e-5 * amp, tv
+            assert torch.isfinite(o["sample"]).all()
+
+
+def test_training_step_batch_invariance_at_benchmark_batch(golden, expect_kernels):
+    """The C64 training step at bench.py's batch 32 with images 0-1 = the G12 golden inputs.  GroupNorm / attention / conditioning are
+    per sample and the encoder's BatchNorm is the only batch coupling, so the encoder is put in eval mode for BOTH batch sizes (running
+    statistics) and the per-sample mse of rows 0-1 at batch 32 — production dispatch: convwin forward — must equal the same rows'
+    mse at batch 2 (small-grid kernels) to 1e-4; then the batch-32 backward must run convwin_kernel<bf16> dgrad and give finite
+    gradients whose squared norm is reproduced by a second run (1e-6: bias-gradient column sums use float atomics; a race in
+    split-K or the accumulate-in-place sinks would show as a far larger jump)."""
+    from improved_diffusion.nn import rng_override
+    g = golden("g12_full_train.npz")
+    model, diff, cfg = make("C64")
+    model.train()
+    model.rep_emb.eval()
+    for p in model.rep_emb.parameters():      # (the eval-mode BatchNorm has no backward here; the UNet torso is what this test is about)
+        p.requires_grad_(False)
+    diff.kl_weight = 0.3
+    B = 32
+    gen = torch.Generator().manual_seed(78)
+    x, x0, c, z, y = model_inputs("C64.train", cfg, 2)
+    noise2 = synth("C64.train.noise", tuple(x0.shape), -1.7, 1.7)
+    eps2 = torch.from_numpy(g["C64/eps_draw"])
+    x0b = torch.cat([x0, torch.rand(B - 2, *x0.shape[1:], generator=gen)], 0).to(DEV)
+    cb = torch.cat([c, torch.rand(B - 2, c.shape[1], generator=gen)], 0).to(DEV)
+    nb = torch.cat([noise2, torch.randn(B - 2, *x0.shape[1:], generator=gen).clamp(-1.7, 1.7)], 0).to(DEV)
+    eb = torch.cat([eps2, torch.randn(B - 2, eps2.shape[1], generator=gen)], 0).to(DEV)
+    tb = torch.cat([torch.tensor([37, 990]), torch.randint(0, 1000, (B - 2,), generator=gen)]).to(DEV)
+
+    def run(n, grads):
+        for p in model.parameters():
+            p.grad = None
+        with rng_override(eps_z=eb[:n]):
+            terms = diff.training_losses(model, x0b[:n], tb[:n], model_kwargs=dict(c=cb[:n]), noise=nb[:n], rep_cond=True, causal_modeling=True)
+        if grads:
+            terms["loss"].mean().backward()
+            return terms, sum(float((p.grad.double() ** 2).sum()) for p in model.parameters() if p.grad is not None)
+        return terms, None
+
+    small, _ = run(2, False)
+    with expect_kernels(convwin=40, convwin_dgrad=40):
+        big, sq1 = run(B, True)
+    assert err(big["mse"][:2], small["mse"]) < 1e-4 * float(small["mse"].abs().max())
+    _, sq2 = run(B, True)
+    assert np.isfinite(sq1) and sq1 > 0 and abs(sq1 - sq2) <= 1e-6 * sq1, (sq1, sq2)
 
 # ------------------------------------------------------------------ G15: BASELINE config [1] — reduced-precision torso at batch 256
 def test_mixed16_m32_batch256_loss_curve_golden(golden):
@@ -608,6 +740,67 @@ def test_trainloop_checkpoints(tmp_path, monkeypatch):
     for k, v in model2.state_dict().items():
         assert err(v, sd[k]) == 0.0, k
     assert err(loop2.opt.ema_state_dict(0)[k0], ema[k0]) == 0.0
+
+
+
+def test_trainloop_convs_get_packed_weight_planes(expect_kernels):
+    """Under TrainLoop every 3x3 conv weight is served by ops.ConvWeightBank (one launch per optimizer step).  The ResBlock convs must get
+    K-group-major planes there (convwin_kernel's contiguous weight DMA) although the bank also holds the stem and head convs, which
+    cannot be packed; the packed planes must equal a fresh cdae_conv_wpack of the OHWI planes, before and after an optimizer step."""
+    from causaldiffae_amd import ops
+    from causaldiffae_amd._lib import check, lib, ptr, stream
+    from improved_diffusion.train_util import FusedAdamWEMA
+    model, diff, cfg = make("C64")
+    opt = FusedAdamWEMA(model, lr=1e-3, ema_rates=[0.999])
+    named = dict(model.named_parameters())
+    w = named["input_blocks.4.0.in_layers.2.weight"]              # 128 -> 256
+    stem = named["input_blocks.0.0.weight"]
+    bank = opt.flat.conv_bank
+    assert bank is not None and ops._bank(w) is bank and ops._bank(stem) is bank
+    assert bank.packed(stem, False) == (None, None)
+    for step in range(2):
+        for bf16, rows, K in ((False, w.shape[0], w.shape[1]), (True, w.shape[1], w.shape[0])):
+            k_hi, k_lo = ops.packed_weight(w, bf16)
+            assert k_hi is not None
+            src = bank.planes(w, bf16)
+            want = torch.empty((2, w.numel()), dtype=src[0].dtype, device=DEV)
+            check(lib.cdae_conv_wpack(ptr(src[0]), ptr(src[1]), ptr(want[0]), ptr(want[1]), rows, 9, K, stream()))
+            assert torch.equal(k_hi.view(torch.int16), want[0].view(torch.int16)) and torch.equal(k_lo.view(torch.int16), want[1].view(torch.int16))
+        opt.flat.grad.normal_(generator=torch.Generator(device=DEV).manual_seed(3))
+        opt.step()
+
+
+def test_optimizer_file_interchanges_with_torch_adamw(tmp_path):
+    """opt<step>.pt written by TrainLoop.save loads into torch.optim.AdamW (what the reference's resume does, train_util.py:159-169), and
+    an opt file written BY torch.optim.AdamW.state_dict() (what the reference's save does, :340-343) resumes this trainer."""
+    from improved_diffusion import logger, script_util as su
+    from improved_diffusion.image_datasets import load_data
+    from improved_diffusion.train_util import TrainLoop
+    logger.configure(dir=str(tmp_path))
+    cfg = {**su.model_and_diffusion_defaults(), "rep_cond": True, "causal_modeling": True, **MODEL_CFG["T28"]}
+    np.random.seed(0)
+    model, diff = su.create_model_and_diffusion(**cfg)
+    load_closed_form(model)
+    data = load_data(data_dir="synthetic", batch_size=4, image_size=28, class_cond=True, in_channels=1, n_vars=2)
+    kw = dict(batch_size=4, microbatch=-1, lr=1e-4, ema_rate="0.9999", log_interval=10, save_interval=100, rep_cond=True, n_vars=2,
+              causal_modeling=True, in_channels=1)
+    loop = TrainLoop(model=model, diffusion=diff, data=data, resume_checkpoint="", **kw)
+    for _ in range(2):
+        loop.run_step(*next(data))
+        loop.step += 1
+    loop.save()
+    sd = torch.load(tmp_path / "opt000002.pt")
+    assert set(sd) == {"state", "param_groups"}
+    ref_model, _ = su.create_model_and_diffusion(**cfg)
+    ref_opt = torch.optim.AdamW(list(ref_model.parameters()), lr=1e-4, weight_decay=0.0)
+    ref_opt.load_state_dict(sd)                                  # the reference's resume path
+    # ... and back: a file in torch's own layout resumes this trainer with the same moments
+    torch.save(ref_opt.state_dict(), tmp_path / "opt000002.pt")
+    model2, diff2 = su.create_model_and_diffusion(**cfg)
+    load_closed_form(model2)
+    loop2 = TrainLoop(model=model2, diffusion=diff2, data=data, resume_checkpoint=str(tmp_path / "model000002.pt"), **kw)
+    assert loop2.opt.t == 2
+    assert err(loop2.opt.m, loop.opt.m) == 0.0 and err(loop2.opt.v, loop.opt.v) == 0.0 and float(loop.opt.m.abs().max()) > 0
 
 
 @pytest.mark.gpu
