@@ -115,6 +115,12 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
     unsigned woffb;                // weight DMA: byte offset of row n0 + 32 wave + lane / 2 (tap 0, group 0)
     int tapmask[8];                // per 16-row tile: bit (3 ky + kx) set when tap (ky, kx) of this lane's pixel reads a real pixel
     auto setup = [&](int tile) {
+        // lane coordinates through an opaque asm: hipcc otherwise hoists every lane-dependent sub-expression of this function (8 row
+        // indices, the DMA row offsets ...) out of the persistent loop and keeps them live across the K loop — the kernel sits at the
+        // 256-VGPR limit of two waves per SIMD and the allocator answers with spills whose reloads land INSIDE the K loop
+        int lane_s = lane;
+        asm volatile("" : "+v"(lane_s));
+        const int lr_s = lane_s & 15;
         int mt, nt;
         {       // XCD-aware decode: consecutive tiles of one XCD share the activation window / the weight tile in that XCD's L2
             const unsigned G = (unsigned)ntiles, b = (unsigned)tile;
@@ -124,6 +130,10 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
             nt = v % nnt; v /= nnt;
             mt = v % nmt; ks = v / nmt;
         }
+        // the tile coordinates are wave-uniform, but the divisions above run on the vector ALU: without the readfirstlane everything
+        // derived from them (K-loop bounds, the weight / window DMA offsets) stays in VGPRs and the K loop carries v_mul_lo_u32 (quarter
+        // rate) and v_readfirstlane where s_mul_i32 does the job beside the MFMAs
+        mt = __builtin_amdgcn_readfirstlane(mt); nt = __builtin_amdgcn_readfirstlane(nt); ks = __builtin_amdgcn_readfirstlane(ks);
         m0 = mt * CW_BM; n0 = nt * CW_BN;
         const int c_begin = ks * c_per, c_end = max(min(nchunk, c_begin + c_per), c_begin);       // the last splits of an uneven division are empty
         g_begin = 2 * c_begin; g_end = 2 * c_end;                     // 16-channel groups of this K split
@@ -133,15 +143,15 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
         // addressed by padding taps (redirected out of range) or feeds output columns that are never stored
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            const int pix = min(max(pix0 + (wave + 4 * q) * 32 + (lane >> 1), 0), p.M - 1);
-            aoffb[q] = (p.a_gm ? (unsigned)pix * 32u : (unsigned)pix * (unsigned)p.sx * 2u) + (lane & 1) * 16u;
+            const int pix = min(max(pix0 + (wave + 4 * q) * 32 + (lane_s >> 1), 0), p.M - 1);
+            aoffb[q] = (p.a_gm ? (unsigned)pix * 32u : (unsigned)pix * (unsigned)p.sx * 2u) + (lane_s & 1) * 16u;
         }
-        const int wrow = min(n0 + wave * 32 + (lane >> 1), p.N - 1);
-        woffb = packed ? (unsigned)wrow * 32u + (lane & 1) * 16u : (unsigned)wrow * (unsigned)p.ldb * 2u + (lane & 1) * 16u;
+        const int wrow = min(n0 + wave * 32 + (lane_s >> 1), p.N - 1);
+        woffb = packed ? (unsigned)wrow * 32u + (lane_s & 1) * 16u : (unsigned)wrow * (unsigned)p.ldb * 2u + (lane_s & 1) * 16u;
         if (NT == 4 && p.nphase > 1) woffb += (unsigned)cph * (unsigned)p.phase_w * 2u;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int m = m0 + wm * 128 + 16 * i + lr;
+            const int m = m0 + wm * 128 + 16 * i + lr_s;
             const bool ok = m < p.M;
             const int mm = ok ? m : 0;
             const int n = fdiv_cw(mm, p.hw_magic, p.hw_shift), rem = mm - n * p.hw;
@@ -187,8 +197,8 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
         else issue_weights(1, g_begin, 2);
     };
 
-    const unsigned a_lane = (wm * 128 + lr) * 32 + pc * 16;            // byte offset of (tile 0 row, piece) in a window plane
-    const unsigned b_lane = CW_B_BASE + (selb ? CW_B_KH : 0) + (wn * 64 + lr) * 32 + pc * 16;
+    unsigned a_lane = (wm * 128 + lr) * 32 + pc * 16;            // byte offset of (tile 0 row, piece) in a window plane (re-pinned in front of every K loop)
+    unsigned b_lane = CW_B_BASE + (selb ? CW_B_KH : 0) + (wn * 64 + lr) * 32 + pc * 16;
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -268,6 +278,16 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
             CW_READ_A(0, 0, wtap_c, a_c);
             CW_READ_B(0, b_c); CW_READ_B(1, b_c); CW_READ_B(2, b_c); CW_READ_B(3, b_c);
         }
+        // Per-lane loop state that the register allocator spills around the epilogue must be back in registers HERE: a scratch reload is a
+        // vector-memory load, and when its first use sits inside the K loop hipcc's waitcnt pass puts `s_waitcnt vmcnt(0)` in front of that
+        // use — a full drain of the weight / window DMAs just issued, every K step (round 2's kernel had exactly that at the top of its
+        // loop; tools/isa_lint.py finds it and tests/test_host_cpu.py::test_window_conv_k_loop_has_no_compiler_drain guards it).
+        // The empty asm pins the values; the builtin wait (vmcnt only: the fragment reads above stay in flight) tells the pass that every
+        // reload up to here has landed — nothing is outstanding in vmcnt at this point anyway (the tile's operands were waited for above).
+        asm volatile("" : "+v"(wtap_c), "+v"(a_c), "+v"(b_c), "+v"(woffb), "+v"(a_lane), "+v"(b_lane), "+v"(aoffb[0]), "+v"(aoffb[1]), "+v"(aoffb[2]));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(tapmask[i]));
+        __builtin_amdgcn_s_waitcnt(0x0F70);
 
         for (int s = 0; s < nsteps; ++s) {
             int gn = ga, tn = ta + 2;          // first unit of the next step
@@ -397,18 +417,22 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
         // accumulator tile (i, j): this lane holds rows 4 kg + r (r = 0..3) of column 16 j + lr; the four column tiles of a row are
         // stored back to back so that the 256 bytes a wave owns of each output row reach L2 together
         const bool interior = em0 + CW_BM <= p.M && en0 + CW_BN <= p.N;
+        // lane coordinates of the epilogue through an opaque asm (as in setup): the row / column offsets and pointers derived from them are
+        // recomputed here, once per tile, instead of being hoisted out of the persistent loop and kept live across the K loop
+        int lr_ = lr, kg_ = kg;
+        asm volatile("" : "+v"(lr_), "+v"(kg_));
         if (dbg_ & 256) {}                                                // dev ablation: no epilogue
         else if (interior && p.ksplit == 1 && !p.accumulate && !p.C_hi) {
             // the common case, kept lean (the general path below spends ~20 instructions per element on bounds and mode tests):
             // one row pointer per (tile, r), the four column tiles at immediate offsets
             const bool up2 = p.out_mode == OUT_UP2;       // sub-pixel phase: GEMM row (n, y, x) -> output pixel (n, 2y + ph_y, 2x + ph_x)
-            const int row0 = em0 + wm * 128 + 4 * kg;
-            const long lane_off = (up2 ? 0 : (long)row0 * p.ldc) + en0 + wn * 64 + lr;
+            const int row0 = em0 + wm * 128 + 4 * kg_;
+            const long lane_off = (up2 ? 0 : (long)row0 * p.ldc) + en0 + wn * 64 + lr_;
             float* __restrict__ cbase = p.C + lane_off;
             const float* __restrict__ rbase = p.res ? p.res + lane_off : nullptr;
             float bv[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bv[j] = p.bias ? p.bias[en0 + wn * 64 + lr + 16 * j] : 0.f;
+            for (int j = 0; j < 4; ++j) bv[j] = p.bias ? p.bias[en0 + wn * 64 + lr_ + 16 * j] : 0.f;
 #pragma unroll
             for (int i2 = 0; i2 < 4; ++i2) {
                 if (epart != 0 && ((i2 < 2) != (epart == 1))) continue;      // a half item owns only its own row tiles
@@ -455,8 +479,8 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                         float s_ = gs[j], q_ = gq[j];
                         s_ += __shfl_xor(s_, 16); q_ += __shfl_xor(q_, 16);
                         s_ += __shfl_xor(s_, 32); q_ += __shfl_xor(q_, 32);
-                        if (kg == 0) {
-                            float* o = p.gn_part + (long)eph * p.phase_gn + ((long)((em0 + wm * 128 + 32 * i2) >> 5) * p.N + en0 + wn * 64 + lr + 16 * j) * 2;
+                        if (kg_ == 0) {
+                            float* o = p.gn_part + (long)eph * p.phase_gn + ((long)((em0 + wm * 128 + 32 * i2) >> 5) * p.N + en0 + wn * 64 + lr_ + 16 * j) * 2;
                             o[0] = s_; o[1] = q_;
                         }
                     }
@@ -465,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
             }
         } else if (interior && p.ksplit > 1) {
             // split-K partial tile, interior: plain stores into slab eks (the general path spends ~8 instructions per element on tests)
-            float* __restrict__ cb = p.splitk_ws + (long)eks * (long)p.M * p.N + (long)(em0 + wm * 128 + 4 * kg) * p.N + en0 + wn * 64 + lr;
+            float* __restrict__ cb = p.splitk_ws + (long)eks * (long)p.M * p.N + (long)(em0 + wm * 128 + 4 * kg_) * p.N + en0 + wn * 64 + lr_;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
 #pragma unroll
@@ -481,7 +505,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
             const float* __restrict__ Rg = nullptr;
             if (p.ksplit > 1) Cg = p.splitk_ws + (long)eks * (long)p.M * p.N;
             else { Cg = p.C; Rg = p.res; }
-            const int col0 = en0 + wn * 64 + lr;
+            const int col0 = en0 + wn * 64 + lr_;
             float bv[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) bv[j] = (col0 + 16 * j < p.N && p.ksplit == 1 && p.bias) ? p.bias[col0 + 16 * j] : 0.f;
@@ -493,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                 for (int ii = 0; ii < 2; ++ii) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int row = em0 + wm * 128 + 32 * i2 + 16 * ii + 4 * kg + r;
+                        const int row = em0 + wm * 128 + 32 * i2 + 16 * ii + 4 * kg_ + r;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const int col = col0 + 16 * j;
@@ -524,7 +548,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                         float s_ = gs[j], q_ = gq[j];
                         s_ += __shfl_xor(s_, 16); q_ += __shfl_xor(q_, 16);
                         s_ += __shfl_xor(s_, 32); q_ += __shfl_xor(q_, 32);
-                        if (kg == 0 && col0 + 16 * j < p.N) {
+                        if (kg_ == 0 && col0 + 16 * j < p.N) {
                             float* o = p.gn_part + (long)eph * p.phase_gn + ((long)((em0 + wm * 128 + 32 * i2) >> 5) * p.N + col0 + 16 * j) * 2;
                             o[0] = s_; o[1] = q_;
                         }

@@ -1622,8 +1622,8 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
     cdae_prof_begin(PROF_IGEMM, 2.0 * p.M * p.N * (double)p.K * p.batch * (p.nphase > 1 ? p.nphase : 1), st);
     if (cdae_prof_on()) {
         char tag[128];
-        snprintf(tag, sizeof(tag), "gemm M=%d N=%d K=%d b=%d a%d b%d %s ks=%d prec=%d ps=%d taps=%d", p.M, p.N, p.K, p.batch, p.amode, p.bmode, big ? "128" : "64", ks, p.prec,
-                 p.presplit, p.ps_taps);
+        snprintf(tag, sizeof(tag), "gemm M=%d N=%d K=%d b=%d a%d b%d %s ks=%d prec=%d ps=%d taps=%d res=%d gn=%d", p.M, p.N, p.K, p.batch, p.amode, p.bmode, big ? "128" : "64", ks, p.prec,
+                 p.presplit, p.ps_taps, p.res != nullptr, p.gn_part != nullptr);
         cdae_prof_tag(tag);
     }
     int rc = -1;

@@ -552,9 +552,11 @@ def test_groupnorm_statistics_from_conv_epilogue(N, Cin, Cout, S, stride, cat):
         # the statistics epilogue excludes split-K, so the two launches may partition K differently: fp32 rounding of the sum only
         assert (y - plain).abs().max().item() < 4e-6 * max(1.0, plain.abs().max().item())
         So = y.shape[2]
-        parts = y._gnparts.double()
-        yr = y.permute(0, 2, 3, 1).reshape(-1, 32, Cout).double()
-        assert (parts[:, :, 0] - yr.sum(1)).abs().max().item() < 1e-4 and (parts[:, :, 1] - (yr * yr).sum(1)).abs().max().item() < 1e-3
+        # per-(32-row chunk, column) slots; a kernel may put the sum of a group of chunks of one image into the group's first slot and
+        # zeros into the others (convwin_kernel: 128 rows, 64 for 8 x 8 images): what the consumer adds up is the sum per image
+        parts = y._gnparts.double().reshape(N, -1, Cout, 2).sum(1)
+        yr = y.permute(0, 2, 3, 1).reshape(N, -1, Cout).double()
+        assert (parts[:, :, 0] - yr.sum(1)).abs().max().item() < 1e-4 * yr.shape[1] / 32 and (parts[:, :, 1] - (yr * yr).sum(1)).abs().max().item() < 1e-3 * yr.shape[1] / 32
         if cat:
             w2 = (torch.randn(128, Cin, 3, 3, device="cuda:0", generator=g) / (9 * Cin) ** 0.5).contiguous(memory_format=torch.channels_last)
             y2 = ops.conv3x3_ps(_split_nhwc(x), w2, None, gn_stats=True)
@@ -622,7 +624,8 @@ def test_fused_groupnorm_conv_is_bit_identical(N, C1, C2, Cout, S, ss, res):
     assert (got._split.hi.float() + got._split.lo.float() - ref._split.hi.float() - ref._split.lo.float()).abs().max().item() < 4e-6 * scale
     # (the plane path drops the statistics epilogue where the window kernel would rather split K: both must then be absent or agree)
     if hasattr(ref, "_gnparts") and hasattr(got, "_gnparts"):
-        assert (got._gnparts - ref._gnparts).abs().max().item() < 1e-3 * max(1.0, ref._gnparts.abs().max().item())
+        pg, pr = (t._gnparts.double().reshape(N, -1, Cout, 2).sum(1) for t in (got, ref))      # per image: kernels differ in how they fill the chunk slots
+        assert (pg - pr).abs().max().item() < 1e-6 * max(1.0, pr.abs().max().item())
 
 
 @pytest.mark.gpu

@@ -599,7 +599,7 @@ def test_training_step_batch_invariance_at_benchmark_batch(golden, expect_kernel
         return terms, None
 
     small, _ = run(2, False)
-    with expect_kernels(convwin=40, convwin_dgrad=40):
+    with expect_kernels(convwin=30, convwin_dgrad=30):      # (the 8 x 8 level stays on the 128-row window kernel at this batch)
         big, sq1 = run(B, True)
     assert err(big["mse"][:2], small["mse"]) < 1e-4 * float(small["mse"].abs().max())
     _, sq2 = run(B, True)

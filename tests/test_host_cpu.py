@@ -221,3 +221,24 @@ def test_optimizer_checkpoint_uses_torch_adamw_layout():
         assert torch.equal(got[i]["exp_avg"].flatten(), opt.m[o:o + p.numel()])
         assert torch.equal(got[i]["exp_avg_sq"].flatten(), opt.v[o:o + p.numel()])
         assert float(got[i]["step"]) == 3.0
+
+
+def test_window_conv_k_loop_has_no_compiler_drain():
+    """convwin_kernel (the dominant kernel of both benchmark legs) runs at the 256-VGPR limit of two waves per SIMD.  When hipcc's
+    register allocator spills a value that the K loop uses, the reload — a vector-memory load — gets `s_waitcnt vmcnt(0)` in front of
+    its first use INSIDE the loop: a full drain of the weight / window LDS-DMAs every K step (round 2's build had one at the loop top).
+    The loop must contain no compiler-inserted vmcnt wait and no scratch traffic, in all three instantiations (tools/isa_lint.py)."""
+    import importlib.util, shutil
+    if not shutil.which("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not installed")
+    spec = importlib.util.spec_from_file_location("isa_lint", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "isa_lint.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    kernels = [r for r in mod.lint("convwin") if "convwin_kernel" in r["kernel"]]
+    assert len(kernels) == 3
+    for r in kernels:
+        assert r["loops"], r["kernel"]
+        for lp in r["loops"]:
+            assert lp["mfmas"] == 96 and lp["barriers"] == 1, (r["kernel"], lp)
+            assert not lp["vmcnt_waits"] and not lp["scratch"], (r["kernel"], lp)
+        assert 0 <= r["vgpr_spills"] <= 16, (r["kernel"], r["vgpr_spills"])

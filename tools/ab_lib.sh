@@ -5,6 +5,6 @@ CMD=${AB_CMD:-"python3 tools/prof_shapes.py --time ${AB_ARGS:-}"}
 cp causaldiffae_amd/libcdae.so /tmp/libcdae_keep.so
 for R in 1 2; do for L in gpurun_ab_lib?.so; do
   cp $L causaldiffae_amd/libcdae.so
-  echo "== $L"; timeout 300 $CMD 2>&1 | grep -v amdgpu | grep -E "${AB_GREP:-128->128 @64|256->128 @64|256->256 @32|384->384 @16|512->512 @ 8|value}" | cut -c1-200
+  echo "== $L"; timeout 300 $CMD 2>&1 | grep -v amdgpu | grep -E "${AB_GREP:-128->128 @64|256->128 @64|256->256 @32|384->384 @16|512->512 @ 8|value}" | cut -c1-6000
 done; done
 cp /tmp/libcdae_keep.so causaldiffae_amd/libcdae.so

@@ -1,0 +1,68 @@
+"""Dev: compile one translation unit of csrc/ to gfx950 assembly and list, per kernel, what the COMPILER put into the loops that
+contain MFMAs: `s_waitcnt` it inserted itself (not from inline asm), scratch (spill) traffic, and the instruction mix.  A compiler
+vmcnt wait inside a software-pipelined DMA loop is a full drain of the LDS-DMAs the loop has just issued (a spill reload is a
+vector-memory load: its first use inside the loop gets `s_waitcnt vmcnt(0)`): this is the check that it is not there.
+
+    python tools/isa_lint.py convwin [extra hipcc flags]      (runs here: hipcc cross-compiles without a GPU)
+"""
+import collections, os, re, subprocess, sys, tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def lint(unit, extra=()):
+    """[{kernel, lines, mfmas, scratch_ops, vgpr_spills, loops: [{start, end, instructions, mfmas, lds_ops, compiler_waits, vmcnt_waits, scratch}]}]"""
+    src = os.path.join(ROOT, "causaldiffae_amd", "csrc", unit + ".hip")
+    out = os.path.join(tempfile.gettempdir(), f"isa_{unit}.s")
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only"]
+    if unit == "elementwise":
+        flags.append("-ffp-contract=off")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", *flags, *extra, "-o", out, src], stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    lines = text.split("\n")
+    spills = dict(re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text))
+    res = []
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_Z\w+:\s", l)]
+    for s in starts:
+        e = next(k for k in range(s, len(lines)) if "s_endpgm" in lines[k])
+        body = lines[s:e + 1]
+        sym = lines[s].split(":")[0]
+        name = subprocess.run(["c++filt", sym], capture_output=True, text=True).stdout.strip()
+        in_asm, tagged = False, []
+        for l in body:
+            t = l.strip()
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True
+            elif t.startswith(";;#ASMEND"):
+                in_asm = False
+            tagged.append((t, in_asm))
+        labels = {m.group(1): k for k, (t, _) in enumerate(tagged) for m in [re.match(r"^(\.LBB\d+_\d+):", t)] if m}
+        loops = []
+        for k, (t, _) in enumerate(tagged):
+            m = re.search(r"s_c?branch\w* (\.LBB\d+_\d+)", t)
+            if m and m.group(1) in labels and labels[m.group(1)] < k:
+                loops.append((labels[m.group(1)], k))
+        mfma_loops = [(a, b) for a, b in loops if any("v_mfma" in tagged[k][0] for k in range(a, b))]
+        inner = [(a, b) for a, b in mfma_loops if not any((c > a or d < b) and c >= a and d <= b for c, d in mfma_loops if (c, d) != (a, b))]
+        rec = dict(kernel=name, lines=len(body), mfmas=sum("v_mfma" in t for t, _ in tagged), scratch_ops=sum(t.startswith("scratch_") for t, _ in tagged),
+                   vgpr_spills=int(spills.get(sym, -1)), loops=[])
+        for a, b in sorted(set(inner)):
+            seg = tagged[a:b + 1]
+            mix = collections.Counter(t.split()[0] for t, _ in seg if t and not t.startswith((";", ".")))
+            cw = [(a + k, t) for k, (t, ia) in enumerate(seg) if t.startswith("s_waitcnt") and not ia]
+            rec["loops"].append(dict(start=a, end=b, instructions=sum(mix.values()), mfmas=sum(v for k_, v in mix.items() if k_.startswith("v_mfma")),
+                                     lds_ops=sum(v for k_, v in mix.items() if k_.startswith("ds_")), s_nop=mix["s_nop"], barriers=mix["s_barrier"],
+                                     compiler_waits=len(cw), vmcnt_waits=[x for x in cw if "vmcnt" in x[1]],
+                                     scratch=[(a + k, t[:60]) for k, (t, _) in enumerate(seg) if t.startswith("scratch_")]))
+        res.append(rec)
+    return res
+
+
+if __name__ == "__main__":
+    for r in lint(sys.argv[1], sys.argv[2:]):
+        print(f"== {r['kernel'][:100]}: {r['lines']} lines, {r['mfmas']} MFMAs, {r['scratch_ops']} scratch ops, {r['vgpr_spills']} VGPR spills")
+        for lp in r["loops"]:
+            print(f"   loop @{lp['start']}-{lp['end']}: {lp['instructions']} instructions, {lp['mfmas']} MFMAs, {lp['lds_ops']} LDS ops, {lp['s_nop']} s_nop, {lp['barriers']} barriers")
+            print(f"      compiler-inserted waits: {lp['compiler_waits']} in all; on vmcnt (DMA / load drains): {lp['vmcnt_waits'] if lp['vmcnt_waits'] else 'none'}")
+            if lp["scratch"]:
+                print(f"      SPILL traffic inside the loop: {lp['scratch']}")
