@@ -6,12 +6,19 @@ images: BASELINE.json config "Pendulum 64x64, 4 causal vars, DDIM-100 counterfac
 batch 128 (the per-GPU share of config 5).  The sampling batch is sharded over ranks with no collective in
 the loop (weak scaling).  Prints ONE JSON line (rank 0).
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Headline: EXACTLY K timed steps per timed region (graph replay of the step the public ddim_sample_loop captures), `--regions` regions
+back to back (default 3): `value` is the median region, min / max beside it.  Secondary legs, all in the same line (single-GPU runs
+only unless stated): the whole public DDIM-100 loop (default call and use_graph=False), the guided loop (w = 2: two forwards per
+step), IEEE-fp32 products (sampling and training), the C64 training step (every rank), BASELINE config [1] (M32, batch 256: f16x3 and
+the mixed16 torso), the CPU oracle baseline.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -23,6 +30,8 @@ sys.path.insert(0, ROOT)
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
 F16_MFMA_PEAK_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (spec)
 GFLOP_PER_IMAGE_STEP_P64 = 60.63       # SURVEY §8d (torch FlopCounter on the reference forward)
+GFLOP_PER_IMAGE_TRAIN_C64 = 181.86
+GFLOP_PER_IMAGE_TRAIN_M32 = 3 * 12.63
 
 
 def randomize(model, seed):
@@ -55,6 +64,24 @@ def host_cores():
     return n
 
 
+def thread_cpu():
+    """CPU seconds of every thread of this process (utime + stime from /proc/self/task): who spends the host cores of a step"""
+    tick, out = os.sysconf("SC_CLK_TCK"), {}
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            f = open(f"/proc/self/task/{tid}/stat").read()
+            rest = f[f.rindex(")") + 2:].split()
+            out[int(tid)] = (f[f.index("(") + 1:f.rindex(")")], (int(rest[11]) + int(rest[12])) / tick)
+        except (OSError, ValueError):
+            pass
+    return out
+
+
+def spread(values):
+    """median / min / max of per-region rates (the pool's boxes differ by +-3 %, one short sample is not a stable number)"""
+    return {"median": statistics.median(values), "min": min(values), "max": max(values), "regions": len(values)}
+
+
 def _cpu_train_step(U, D, sd, cfg, sch, x0, c, y, steps):
     """Oracle training steps on the host: training_losses + backward + AdamW/EMA (reference train_util.py:232-297)."""
     names = [k for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k and "num_batches" not in k]
@@ -81,7 +108,7 @@ def _cpu_train_step(U, D, sd, cfg, sch, x0, c, y, steps):
     return steps / (time.perf_counter() - t0)
 
 
-def cpu_baseline(ddim_steps=6, batch=16):
+def cpu_baseline(ddim_steps=6, batch=16, train_steps=3):
     """The oracle (torch-CPU restatement of the reference, pinned to the reference's own outputs by tests/test_oracle_golden.py)
     timed on this host's cores: the headline P64 DDIM step, the C64 training step, and BASELINE config [0] (MorphoMNIST 32x32,
     T = 1000, batch 16: sampling step and training step).  Bounded samples, a few tens of seconds in all."""
@@ -109,9 +136,9 @@ def cpu_baseline(ddim_steps=6, batch=16):
     cfg_c = U.default_cfg(image_size=64, in_channels=3, n_vars=4, rep_cond=True, causal_modeling=True)
     sd_c = fill_state_dict(U.param_spec(cfg_c))
     sps = _cpu_train_step(U, D, sd_c, cfg_c, D.Schedule(1000, "linear", "", True), synth("bench.cpu.x0c", (batch, 3, 64, 64), 0.0, 1.0),
-                          synth("bench.cpu.cc", (batch, 4), 0.0, 1.0), None, 1)
+                          synth("bench.cpu.cc", (batch, 4), 0.0, 1.0), None, train_steps)
     out["train"] = {"value": sps, "unit": "train-steps/s", "images_per_sec": sps * batch, "cores": cores, "kind": "port",
-                    "sample": f"oracle training_losses + backward + AdamW/EMA, C64 batch {batch}, 1 step after 1 warm-up, {note}"}
+                    "sample": f"oracle training_losses + backward + AdamW/EMA, C64 batch {batch}, {train_steps} steps after 1 warm-up, {note}"}
     # --- BASELINE config [0]: MorphoMNIST 32x32, 2 causal vars, T = 1000, batch 16
     cfg_m = U.default_cfg(image_size=32, in_channels=1, n_vars=2, rep_cond=True, causal_modeling=True, class_cond=True)
     sd_m = fill_state_dict(U.param_spec(cfg_m))
@@ -124,34 +151,38 @@ def cpu_baseline(ddim_steps=6, batch=16):
         t0 = time.perf_counter()
         D.sample_loop(sch_m, fm, xm, ddim=False, n_steps=10, noises=[torch.zeros_like(xm)] * 1000)
         dtm = time.perf_counter() - t0
-    sps_m = _cpu_train_step(U, D, sd_m, cfg_m, sch_m, synth("bench.cpu.x0m", (16, 1, 32, 32), 0.0, 1.0), synth("bench.cpu.cm", (16, 2), 0.0, 1.0), ym, 2)
+    sps_m = _cpu_train_step(U, D, sd_m, cfg_m, sch_m, synth("bench.cpu.x0m", (16, 1, 32, 32), 0.0, 1.0), synth("bench.cpu.cm", (16, 2), 0.0, 1.0), ym, 3)
     out["config0_m32"] = {"p_sample_image_steps_per_sec": 16 * 10 / dtm, "samples_per_sec_T1000": 16 * 10 / dtm / 1000.0,
                           "train_steps_per_sec": sps_m, "cores": cores, "kind": "port",
-                          "sample": f"oracle, MorphoMNIST 32x32 C=1, 2 causal vars, class_cond, T=1000, batch 16: 10 p_sample steps and 2 training "
+                          "sample": f"oracle, MorphoMNIST 32x32 C=1, 2 causal vars, class_cond, T=1000, batch 16: 10 p_sample steps and 3 training "
                                     f"steps after 1 warm-up each, {note}"}
     return out
 
 
-def train_bench(dev, world, rank, steps, warmup, batch):
-    """Training leg of the metric: CausalCircuit 64x64 C=3 (BASELINE config 4), per-GPU batch `batch`, one optimizer
-    step = forward + backward + bucketed gradient all-reduce (RCCL, overlapped with backward) + fused AdamW/EMA."""
+def train_bench(dev, world, rank, steps, warmup, batch, regions=1, image_size=64, in_channels=3, n_vars=4, use_fp16=False, class_cond=False,
+                workload=None):
+    """Training leg of the metric: CausalCircuit 64x64 C=3 (BASELINE config 4) by default, per-GPU batch `batch`, one optimizer
+    step = forward + backward + bucketed gradient all-reduce (RCCL, overlapped with backward) + fused AdamW/EMA.  `regions` timed
+    regions of exactly `steps` steps each; the reported value is the median region (max over ranks per region)."""
     import numpy as np
+    import causaldiffae_amd
     from improved_diffusion import script_util as su
     from improved_diffusion.image_datasets import load_data
     from improved_diffusion.train_util import TrainLoop
-    cfg = {**su.model_and_diffusion_defaults(), "image_size": 64, "in_channels": 3, "n_vars": 4, "rep_cond": True,
-           "causal_modeling": True}
+    cfg = {**su.model_and_diffusion_defaults(), "image_size": image_size, "in_channels": in_channels, "n_vars": n_vars, "rep_cond": True,
+           "causal_modeling": True, "class_cond": class_cond}
     model, diff = su.create_model_and_diffusion(**cfg)
     randomize(model, 4321)
     model.to(dev).train()
     np.random.seed(1000 + rank)
     # HBM-resident synthetic pool + gather kernel: the feed the training script uses (`--host_feed` off), no host work per step
-    data = load_data(data_dir="synthetic", batch_size=batch, image_size=64, in_channels=3, n_vars=4, seed=rank,
-                     device=None if os.environ.get("CDAE_BENCH_HOST_FEED") == "1" else dev)
+    data = load_data(data_dir="synthetic", batch_size=batch, image_size=image_size, in_channels=in_channels, n_vars=n_vars, seed=rank,
+                     class_cond=class_cond, device=None if os.environ.get("CDAE_BENCH_HOST_FEED") == "1" else dev)
     loop = TrainLoop(model=model, diffusion=diff, data=data, batch_size=batch, microbatch=-1, lr=1e-4, ema_rate="0.9999",
-                     log_interval=10 ** 9, save_interval=10 ** 9, resume_checkpoint="", rep_cond=True, n_vars=4,
-                     causal_modeling=True, in_channels=3)
+                     log_interval=10 ** 9, save_interval=10 ** 9, resume_checkpoint="", rep_cond=True, n_vars=n_vars,
+                     causal_modeling=True, in_channels=in_channels, use_fp16=use_fp16)
     diff.kl_weight = 0.1
+    nparams = sum(p.numel() for p in model.parameters())
 
     def sync():
         torch.cuda.synchronize()
@@ -164,42 +195,64 @@ def train_bench(dev, world, rank, steps, warmup, batch):
         b, c = next(data)
         loop.forward_backward(b, c)
         loop.optimize_normal()
-    sync()
-    t0, c0 = time.perf_counter(), time.process_time()
-    for _ in range(steps):
-        b, c = next(data)
-        loop.forward_backward(b, c)
-        loop.optimize_normal()
-    sync()
-    dt, cpu = time.perf_counter() - t0, time.process_time() - c0
-    if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = tt.item()
+    rates, cpus = [], []
+    th0 = thread_cpu()
+    for _ in range(regions):
+        sync()
+        t0, c0 = time.perf_counter(), time.process_time()
+        for _ in range(steps):
+            b, c = next(data)
+            loop.forward_backward(b, c)
+            loop.optimize_normal()
+        sync()
+        dt, cpu = time.perf_counter() - t0, time.process_time() - c0
+        if world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([dt, cpu], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt, cpu = tt[0].item(), tt[1].item()          # the slowest rank's wall time, the hungriest rank's CPU time
+        rates.append(steps / dt)
+        cpus.append(1e3 * cpu / steps)
+    th1 = thread_cpu()
+    per_thread = sorted(((name, 1e3 * (cpu - th0.get(tid, ("", 0.0))[1]) / (steps * regions)) for tid, (name, cpu) in th1.items()), key=lambda kv: -kv[1])
     loss = float(loop.last_losses["loss"].mean().item())
-    return {"value": steps / dt, "unit": "train-steps/s", "ms_per_step": 1e3 * dt / steps, "batch_per_gpu": batch,
-            "global_batch": batch * world, "images_per_sec": batch * world * steps / dt,
-            "model_tflops": batch * world * steps / dt * 181.86 / 1e3,
-            "dtype": "f32 in/out/accumulate/optimizer; forward products f16x3 (2^-22), bf16x3 (2^-16) products in dgrad/wgrad",
+    sps = statistics.median(rates)
+    gflop = GFLOP_PER_IMAGE_TRAIN_C64 if image_size == 64 else GFLOP_PER_IMAGE_TRAIN_M32
+    prec = getattr(model, "_cdae_precision", None) or causaldiffae_amd.get_precision()
+    dtype = {"f16x3": "f32 in/out/accumulate/optimizer; forward products f16x3 (2^-22), bf16x3 (2^-16) products in dgrad/wgrad",
+             "fp32": "f32 everywhere: IEEE fp32 products on v_mfma_f32_32x32x2_f32, forward and backward",
+             "mixed16": "f32 master weights / accumulate / optimizer; single f16 plane forward, single bf16 plane backward (the reduced-precision torso)"}[prec]
+    roof = {"f16x3": F16_MFMA_PEAK_TFLOPS / 3, "fp32": FP32_MFMA_PEAK_TFLOPS, "mixed16": F16_MFMA_PEAK_TFLOPS}[prec]
+    tf = batch * world * sps * gflop / 1e3
+    host_ms = statistics.median(cpus)
+    quota = host_cores()
+    return {"value": sps, "unit": "train-steps/s", "ms_per_step": 1e3 / sps, "spread": spread(rates), "batch_per_gpu": batch,
+            "global_batch": batch * world, "images_per_sec": batch * world * sps, "model_tflops": tf, "roof_tflops": roof * world,
+            "frac_of_roof": tf / (roof * world), "precision_mode": prec, "dtype": dtype,
             "steps": steps, "warmup": warmup, "last_loss": loss,
-            "host_cpu_ms_per_step": 1e3 * cpu / steps, "dist_backend": (torch.distributed.get_backend() if world > 1 else None),
-            "workload": "CausalCircuit 64x64 C=3 CausalDiffAE training step (fwd+bwd+all-reduce+AdamW/EMA), 93.4M params"}
+            # CPU time of the hungriest rank (all its threads) per step; `world` such ranks share the cgroup quota on one node
+            "host_cpu_ms_per_step": host_ms, "host_cpu_over_step": host_ms * sps / 1e3, "host_cpu_quota_cores": quota,
+            "host_bound_risk": bool(world * host_ms * sps / 1e3 > 0.8 * quota),
+            "host_cpu_ms_per_step_by_thread": [[n, round(v, 2)] for n, v in per_thread[:6] if v >= 0.05],
+            "dist_backend": (torch.distributed.get_backend() if world > 1 else None),
+            "workload": workload or f"CausalCircuit 64x64 C=3 CausalDiffAE training step (fwd+bwd+all-reduce+AdamW/EMA), {nparams / 1e6:.1f}M params"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--regions", type=int, default=3, help="timed regions of exactly --steps steps each (median reported)")
     ap.add_argument("--batch", type=int, default=128, help="images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--precision", choices=["f16x3", "fp32"], default=None, help="arithmetic of the K-contiguous contractions")
     ap.add_argument("--train-batch", type=int, default=32)
-    ap.add_argument("--train-steps", type=int, default=20)
-    ap.add_argument("--no-fp32", action="store_true", help="skip the secondary IEEE-fp32-product leg")
+    ap.add_argument("--train-steps", type=int, default=50)
+    ap.add_argument("--no-fp32", action="store_true", help="skip the secondary IEEE-fp32-product legs")
+    ap.add_argument("--no-extra", action="store_true", help="skip the public-loop, guidance and config [1] legs")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -224,6 +277,33 @@ def main():
 
     if args.precision:
         causaldiffae_amd.set_precision(args.precision)
+    prec0 = causaldiffae_amd.get_precision()
+    single = world == 1
+    # ---- training legs FIRST, in a process that has not replayed a HIP graph yet: the sampling legs below leave runtime helper threads
+    # behind (one of them busy-waiting: 6-28 ms of CPU per training step measured when the order is reversed) that a training job does not have
+    train = None
+    if not args.no_train:
+        try:
+            train = train_bench(dev, world, rank, args.train_steps, 5, args.train_batch, regions=max(1, args.regions))
+            if single and not args.no_fp32:
+                causaldiffae_amd.set_precision("fp32")
+                try:
+                    torch.cuda.empty_cache()
+                    train["fp32_mode"] = train_bench(dev, world, rank, 6, 2, args.train_batch)
+                finally:
+                    causaldiffae_amd.set_precision(prec0)
+            if single and not args.no_extra:
+                # BASELINE config [1]: MorphoMNIST 32x32 CausalDiffAE training, batch 256 — parity mode and the reduced-precision torso
+                torch.cuda.empty_cache()
+                m32 = dict(image_size=32, in_channels=1, n_vars=2, class_cond=True)
+                wl = "BASELINE config [1]: MorphoMNIST 32x32 C=1, 2 causal vars, class-conditional, batch 256 training step"
+                train["config1_m32_b256"] = {"f16x3": train_bench(dev, world, rank, 20, 3, 256, regions=2, workload=wl, **m32)}
+                torch.cuda.empty_cache()
+                train["config1_m32_b256"]["mixed16"] = train_bench(dev, world, rank, 20, 3, 256, regions=2, use_fp16=True, workload=wl + " (use_fp16)", **m32)
+                a, b = train["config1_m32_b256"]["mixed16"]["value"], train["config1_m32_b256"]["f16x3"]["value"]
+                train["config1_m32_b256"]["mixed16_over_f16x3"] = a / b
+        except Exception as e:                      # never lose the headline line to the secondary leg
+            train = {**(train or {}), "error": f"{type(e).__name__}: {e}"[:300]}
     cfg = {**su.model_and_diffusion_defaults(), "image_size": 64, "in_channels": 4, "n_vars": 4, "rep_cond": True,
            "causal_modeling": True, "timestep_respacing": "ddim100"}
     model, diff = su.create_model_and_diffusion(**cfg)
@@ -252,35 +332,51 @@ def main():
                 dist.barrier()
                 torch.cuda.synchronize()
 
-        def timed_ddim(steps, warmup):
-            """EXACTLY `steps` timed DDIM steps (graph replay unless --no-graph) after `warmup` untimed ones, max over ranks"""
-            if args.no_graph:
-                state = {"img": x_t.clone()}
-
-                def do_step(k):
-                    state["img"] = diff.ddim_sample(model, state["img"], steps_tab[k % T], model_kwargs=kw)["sample"]
-            else:
-                runner = _GraphStep(diff, model, x_t.clone(), kw, True, None)
-
-                def do_step(k):
-                    runner.step(k % T)
-            for k in range(max(1, warmup)):
-                do_step(k)
-            sync()
-            t0 = time.perf_counter()
-            for k in range(steps):
-                do_step(warmup + k)
-            sync()
-            dt = time.perf_counter() - t0
+        def max_over_ranks(dt):
             if world > 1:
                 tt = torch.tensor([dt], dtype=torch.float64, device=dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 dt = tt.item()
             return dt
 
+        def timed_ddim(steps, warmup, regions=1, w=None):
+            """`regions` regions of EXACTLY `steps` timed DDIM steps (the graph the public loop replays, unless --no-graph) after `warmup`
+            untimed ones; seconds per region, max over ranks"""
+            if args.no_graph:
+                state = {"img": x_t.clone()}
+
+                def do_step(k):
+                    state["img"] = diff.ddim_sample(model, state["img"], steps_tab[k % T], model_kwargs=kw, w=w)["sample"]
+            else:
+                runner = _GraphStep(diff, model, x_t.clone(), kw, True, w)
+
+                def do_step(k):
+                    runner.step(k % T)
+            for k in range(max(1, warmup)):
+                do_step(k)
+            out, k0 = [], warmup
+            for _ in range(regions):
+                sync()
+                t0 = time.perf_counter()
+                for k in range(steps):
+                    do_step(k0 + k)
+                sync()
+                out.append(max_over_ranks(time.perf_counter() - t0))
+                k0 += steps
+            return out
+
+        def public_loop(**kwargs):
+            """One call of the PUBLIC API exactly as scripts/image_causaldae_test.py:587-594 makes it: all T steps, seconds (max over ranks)"""
+            sync()
+            t0 = time.perf_counter()
+            diff.ddim_sample_loop(model, (N, 4, 64, 64), noise=x_t, model_kwargs=kw, **kwargs)
+            sync()
+            return max_over_ranks(time.perf_counter() - t0)
+
         def roofline(prec, eager_steps=2):
             """HIP events on the launch stream around every launch of the contraction families during eager steps, outside the timed
-            region.  The dominant kernel (the window conv, convwin_kernel) is reported by itself; `all_contractions` is the whole family."""
+            region.  The dominant kernel (the window conv, convwin_kernel<f16, 9 taps>) is reported by itself; `all_contractions` is every
+            contraction family."""
             img2 = x_t.clone()
             diff.ddim_sample(model, img2, steps_tab[0], model_kwargs=kw)
             torch.cuda.synchronize()
@@ -293,12 +389,13 @@ def main():
             # dense f16 peak / 3; fp32: the fp32 MFMA peak
             peak = F16_MFMA_PEAK_TFLOPS / 3.0 if prec == "f16x3" else FP32_MFMA_PEAK_TFLOPS
             cw, ig = prof["convwin"], prof["igemm"]
-            dom = cw if cw["launches"] > 0 and cw["ms"] >= 0.4 * (cw["ms"] + ig["ms"]) else ig
-            name = ("convwin_kernel<f16> (convwin.hip: stride-1 conv3x3 on pre-split f16 hi/lo planes, window resident in LDS, "
+            fams = [prof[k] for k in ("igemm", "convwin", "convwin_dgrad", "convwin_up")]
+            fam_ms, fam_work, fam_n = (sum(f[k] for f in fams) for k in ("ms", "work", "launches"))
+            dom = cw if cw["launches"] > 0 and cw["ms"] >= 0.4 * fam_ms else ig
+            name = ("convwin_kernel<f16, 9 taps> (convwin.hip: stride-1 conv3x3 on pre-split f16 hi/lo planes, window resident in LDS, "
                     "v_mfma_f32_16x16x32_f16 x3 per product, fp32 accumulate)" if dom is cw else
                     ("igemm_kernel (v_mfma_f32_32x32x2_f32, IEEE fp32 products)" if prec == "fp32" else "pswin / ps / igemm_kernel family (f16x3)"))
             ach = dom["work"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
-            fam_ms, fam_work, fam_n = cw["ms"] + ig["ms"], cw["work"] + ig["work"], cw["launches"] + ig["launches"]
             r = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s (algorithmic 2MNK)", "frac": ach / peak,
                  "precision_mode": prec, "launches_per_step": dom["launches"] // eager_steps,
                  "avg_launch_us": 1e3 * dom["ms"] / max(1, dom["launches"]), "flops_per_launch_avg": dom["work"] / max(1, dom["launches"]),
@@ -308,7 +405,8 @@ def main():
                  # reference's formulation), so this is below the reference-algorithm rate `model_tflops` implies
                  "flops_convention": "executed 2MNK per launch (sub-pixel up-convs at folded size)",
                  # register-resident MFMA loops on random operands sustain 1650 (32x32x16) / 1980 (16x16x32) TFLOP/s on this part
-                 # (tools/hiptests/mfma_peak.hip, profiles/r02_mfma_sustained.txt): 660 TFLOP/s in f16x3 terms for the 16x16x32 kernel
+                 # (tools/hiptests/mfma_peak.hip, profiles/r02_mfma_sustained.txt; the chip holds ~1.85 GHz under MFMA load):
+                 # 660 TFLOP/s in f16x3 terms for the 16x16x32 kernel
                  "frac_of_sustained_mfma": (ach / (1980.0 / 3.0)) if prec == "f16x3" else None,
                  "all_contractions": {"achieved": fam_work / (fam_ms * 1e-3) / 1e12 if fam_ms > 0 else 0.0, "launches_per_step": fam_n // eager_steps,
                                       "ms_per_step": fam_ms / eager_steps},
@@ -317,8 +415,9 @@ def main():
             # HBM traffic of the dominant kernel: PMC counters cannot be read in-process (separate rocprofv3 --pmc passes of this same
             # command, folded by tools/pmc_summary.py and committed under profiles/)
             traffic = traffic_src = None
-            pmc_file = os.path.join(ROOT, "profiles", f"r02_convwin_pmc_summary_{prec}.json" if dom is cw else f"r01_igemm_pmc_summary_{prec}.json")
-            if os.path.exists(pmc_file) and N == 128:
+            cands = [f"r03_convwin_pmc_summary_{prec}.json", f"r02_convwin_pmc_summary_{prec}.json"] if dom is cw else [f"r01_igemm_pmc_summary_{prec}.json"]
+            pmc_file = next((os.path.join(ROOT, "profiles", c) for c in cands if os.path.exists(os.path.join(ROOT, "profiles", c))), None)
+            if pmc_file and N == 128:
                 pm = json.load(open(pmc_file))
                 traffic, traffic_src = pm["hbm_traffic_bytes_per_launch"], f"profiles/{os.path.basename(pmc_file)} (rocprofv3 --pmc, same workload)"
             alg = dom["bytes"] / max(1, dom["launches"]) if dom["bytes"] > 0 else None
@@ -326,33 +425,44 @@ def main():
                       "algorithmic_bytes_per_launch": alg, "traffic_ratio": (traffic / alg) if traffic and alg else None})
             return r
 
-        prec0 = causaldiffae_amd.get_precision()
-        dt = timed_ddim(args.steps, args.warmup)
+        region_s = timed_ddim(args.steps, args.warmup, max(1, args.regions))
+        dt = statistics.median(region_s)
         roof = roofline(prec0) if rank == 0 else None
+        extra = {}
+        if single and not args.no_extra:
+            # the drop-in call: the whole DDIM-100 loop through the public API (default = graph replay where eligible), and eagerly
+            public_loop()                                       # untimed: allocator warm-up + graph capture paths
+            d_s = [public_loop() for _ in range(2)]
+            e_s = [public_loop(use_graph=False)]
+            extra["public_ddim_sample_loop"] = {
+                "call": "diffusion.ddim_sample_loop(model, (128, 4, 64, 64), noise=x_T, model_kwargs={'z': z})  [scripts/image_causaldae_test.py:587-594]",
+                "steps_per_call": T, "default_ms_per_step": 1e3 * min(d_s) / T, "default_calls_s": d_s,
+                "default_image_steps_per_sec": N * T / min(d_s), "default_includes": "graph capture of one step + 100 replays per call",
+                "eager_ms_per_step": 1e3 * min(e_s) / T, "eager_image_steps_per_sec": N * T / min(e_s)}
+            # config 5 (classifier-free masking / guidance): two forwards per step, gaussian_diffusion.py:277-285 — "report both"
+            kg = max(10, min(args.steps, 20))
+            g_s = timed_ddim(kg, 2, 2, w=2.0)
+            extra["guided_w2"] = {"value": N * kg / min(g_s), "unit": "image-steps/s", "ms_per_step": 1e3 * min(g_s) / kg, "steps": kg, "regions": 2,
+                                  "forwards_per_step": 2, "model_tflops": 2 * N * kg / min(g_s) * GFLOP_PER_IMAGE_STEP_P64 / 1e3,
+                                  "workload": "the same P64 DDIM step with guidance w = 2 (conditional + unconditional forward per step)"}
         # secondary leg (single GPU): the other product mode — IEEE fp32 products on v_mfma_f32_32x32x2_f32 against its own roof
         other = None
-        if world == 1 and not args.no_fp32:
+        if single and not args.no_fp32:
             alt = "fp32" if prec0 == "f16x3" else "f16x3"
             causaldiffae_amd.set_precision(alt)
             try:
-                k2 = max(2, min(args.steps, 4))
-                dt2 = timed_ddim(k2, 1)
+                k2 = 12
+                s2 = timed_ddim(k2, 2, 2)
+                dt2 = min(s2)
                 other = {"precision_mode": alt, "value": N * k2 / dt2, "unit": "image-steps/s", "ms_per_step": 1e3 * dt2 / k2, "steps": k2,
-                         "warmup": 1, "model_tflops": N * k2 / dt2 * GFLOP_PER_IMAGE_STEP_P64 / 1e3, "roofline": roofline(alt, 1)}
+                         "regions": 2, "warmup": 2, "model_tflops": N * k2 / dt2 * GFLOP_PER_IMAGE_STEP_P64 / 1e3, "roofline": roofline(alt, 1)}
             finally:
                 causaldiffae_amd.set_precision(prec0)
 
-    train = None
-    if not args.no_train:
-        del model
-        torch.cuda.empty_cache()
-        try:
-            train = train_bench(dev, world, rank, args.train_steps, 3, args.train_batch)
-        except Exception as e:                      # never lose the headline line to the secondary leg
-            train = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank != 0:
         return
     value = world * N * args.steps / dt
+    rates = [world * N * args.steps / s for s in region_s]
     dtype_of = {"fp32": "f32 (IEEE fp32 products, v_mfma_f32_32x32x2_f32)",
                 "f16x3": "f32 in/out/accumulate; products as f16x3 split (hi*hi + hi*lo + lo*hi on f16 MFMA, 2^-22 relative)"}
     out = {
@@ -363,14 +473,16 @@ def main():
         "config": {"workload": "Pendulum 64x64 C=4, 4 causal vars, DDIM-100 counterfactual sampling (encode -> intervene -> "
                                "q_sample -> ddim steps), UNet 93.45M params", "batch_per_gpu": N, "global_batch": N * world,
                    "parallelism": f"batch-sharded x{world}, no collectives", "hip_graph": not args.no_graph},
+        "timed_regions": {"each": f"exactly {args.steps} steps", "value_is": "median region", **spread(rates)},
         "dist_backend": (dist.get_backend() if world > 1 else None), "ranks_in_group": (dist.get_world_size() if world > 1 else 1),
         "samples_per_sec_ddim100": value / 100.0,
         "model_tflops": value * GFLOP_PER_IMAGE_STEP_P64 / 1e3,
         "roofline": roof,
         "other_precision": other,
         "train": train,
+        **extra,
     }
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline and single:
         out["cpu_baseline"] = cpu_baseline()
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         if train and "value" in train:

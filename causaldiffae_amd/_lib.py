@@ -32,7 +32,6 @@ SIGNATURES = {
     "cdae_conv3x3_fwd_psk": [P, P, L, L, L, P, P, P, P, P, P, P, L, I, P, P, P, I, I, I, I, I, I, I, P, SZ, P],
     "cdae_conv3x3_dgrad_psk": [P, P, P, P, P, P, P, L, I, I, I, I, I, P, SZ, P],
     "cdae_conv_wpack": [P, P, P, P, I, I, I, P],
-    "cdae_conv3x3_fwd_gn": [P, L, I, P, L, P, I, P, P, P, P, P, L, P, P, P, I, I, I, I, I, P, SZ, P],
     "cdae_gn_coef": [P, P, P, P, P, I, P, I, I, I, P],
     "cdae_gn_stats_from_parts": [P, I, I, P, I, I, I, I, I, F, P, P, P, P],
     "cdae_upconv3x3_fwd_ps": [P, P, L, L, L, P, P, P, P, L, P, I, I, I, I, I, P, SZ, P],
@@ -171,6 +170,19 @@ def ptr(t):
         raise CdaeError("causaldiffae_amd ops need tensors on an MI355X device (got a CPU tensor); "
                         "there is no CPU fallback — the CPU oracle lives in oracle/ for tests only")
     return t.data_ptr()
+
+
+def ptr2(t):
+    """(pointer of t[0], pointer of t[1]) of a [2, ...] plane pair without building the two view tensors (`t[i]` is an aten::select:
+    ~1500 of them per training step)"""
+    if t is None:
+        return None, None
+    if isinstance(t, (tuple, list)):          # a pair of separate plane tensors
+        return ptr(t[0]), ptr(t[1])
+    if not t.is_cuda:
+        raise CdaeError("causaldiffae_amd ops need tensors on an MI355X device (got a CPU tensor)")
+    p = t.data_ptr()
+    return p, p + t.stride(0) * t.element_size()
 
 
 _ws = {}

@@ -56,8 +56,7 @@ int cdae_conv3x3_fwd(const float* x, long sn, long sy, long sx, long sc, const f
     if (up && stride != 1) return cdae_fail("conv3x3: fused upsample needs stride 1");
     const int Ho = up ? 2 * H : (H - 1) / stride + 1, Wo = up ? 2 * W : (W - 1) / stride + 1;
     // the network's input conv (1..4 channels): exact-fp32 streaming kernel of stem.hip instead of a 36-deep implicit GEMM
-    static const int cfg_stem = getenv("CDAE_STEM") ? atoi(getenv("CDAE_STEM")) : 1;      // dev switch: 0 = implicit GEMM for the input conv
-    if (cfg_stem && stride == 1 && !up && !out_nchw && !res && cdae_conv3x3_stem_supported(Cin, Cout, W) && ldo % 4 == 0 && aligned16(out) && aligned16(bias) &&
+    if (stride == 1 && !up && !out_nchw && !res && cdae_conv3x3_stem_supported(Cin, Cout, W) && ldo % 4 == 0 && aligned16(out) && aligned16(bias) &&
         cdae_get_default_precision() != CDAE_PREC_MIXED16)
         return cdae_conv3x3_stem(x, sn, sy, sx, sc, w, bias, out, ldo, N, H, W, Cin, Cout, stream);
     GemmParams p = base_params();
@@ -153,31 +152,6 @@ int cdae_conv3x3_fwd_psg(const unsigned short* x_hi, const unsigned short* x_lo,
     return cdae_gemm_dispatch(p, stream);
 }
 
-// GroupNorm (+scale-shift, +SiLU) -> conv3x3 (stride 1) in ONE kernel: x1 / x2 are the fp32 INPUT of the norm (two sources = the
-// skip concatenation), coef its per-(image, channel) affine from cdae_gn_coef; weights as pre-split planes.
-int cdae_conv3x3_fwd_gn(const float* x1, long ld1, int C1, const float* x2, long ld2, const float* coef, int silu, const unsigned short* w_hi,
-                        const unsigned short* w_lo, const float* bias, const float* res, float* out, long ldo, unsigned short* out_hi,
-                        unsigned short* out_lo, float* gn_part, int N, int H, int W, int Cin, int Cout, float* splitk_ws, size_t splitk_ws_bytes,
-                        void* stream) {
-    if ((long)N * H * W >= (1L << 31) / 4) return cdae_fail("conv3x3_fwd_gn: too many pixels");
-    if (ld1 % 4 || (x2 && (ld2 % 4 || C1 % 32)) || Cin % 32 || !aligned16(x1) || !aligned16(x2) || !aligned16(coef) || !aligned16(w_hi) || !aligned16(w_lo))
-        return cdae_fail("conv3x3_fwd_gn: 16-byte aligned rows, Cin % 32 == 0 (and C1 % 32 == 0 with two sources) required");
-    if (out_hi && !out_lo) return cdae_fail("conv3x3_fwd_gn: plane output needs both planes");
-    GemmParams p = base_params();
-    p.presplit = 1;
-    p.A = x1; p.lda = ld1; p.A2 = x2; p.lda2 = ld2; p.K1 = x2 ? C1 : Cin; p.gn_coef = coef; p.gn_silu = silu;
-    p.B = reinterpret_cast<const float*>(w_hi); p.B_lo = w_lo;
-    p.C = out; p.bias = bias; p.res = res; p.C_hi = out_hi; p.C_lo = out_lo; p.gn_part = gn_part;
-    p.M = N * H * W; p.N = Cout; p.K = 9 * Cin;
-    p.ldb = 9L * Cin; p.ldc = ldo;
-    p.out_mode = OUT_ROWMAJOR; p.out_hw = H * W;
-    p.amode = A_CONV_VEC; p.bmode = B_PLAIN_KC;
-    p.conv_M = p.M; p.H = H; p.W = W; p.Cin = Cin; p.Ho = H; p.Wo = W; p.stride = 1; p.up = 0;
-    p.sx = Cin; p.sy = (long)W * Cin; p.sn = (long)H * W * Cin; p.sc = 1;      // logical geometry of the (virtual) normalised tensor
-    set_splitk(p, gn_part ? nullptr : splitk_ws, splitk_ws_bytes);
-    return cdae_gemm_dispatch(p, stream);
-}
-
 // nearest-2x upsample + conv3x3 as four 2x2 convolutions of the LOW-resolution input, one per output parity (ph_y, ph_x):
 // rows 2y+ph_y-1 .. 2y+ph_y+1 of the upsampled image are input rows {y-1+ph_y, y+ph_y} with the 3 kernel rows folded 1+2 or
 // 2+1, likewise for columns — 16 instead of 36 multiply-adds per (pixel, channel pair).  w4 = [4 phases][Cout][2][2][Cin]
@@ -188,7 +162,7 @@ int cdae_upconv3x3_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo
     if ((long)N * H * W * sx >= (1L << 31)) return cdae_fail("upconv3x3_fwd_ps: activation larger than 2^31 elements");
     if (sx % 8 || sy % 8 || sn % 8 || !aligned16(x_hi) || !aligned16(x_lo) || !aligned16(w4_hi) || !aligned16(w4_lo))
         return cdae_fail("upconv3x3_fwd_ps: planes must be 16-byte aligned with pixel pitch % 8 == 0");
-    static const int cfg_fused = getenv("CDAE_UPCONV_FUSED") ? atoi(getenv("CDAE_UPCONV_FUSED")) : 1;
+    static const int cfg_fused = CDAE_DEV_INT("CDAE_UPCONV_FUSED", 1);
     for (int ph = cfg_fused ? -1 : 0; ph < 4; ++ph) {      // ph = -1: all four phases as one launch of the window kernel (4x the tiles: the low levels fill the chip)
         GemmParams p = base_params();
         const bool all = ph < 0;
@@ -435,7 +409,7 @@ int cdae_qkv_attention_bwd(const float* qkv, const float* probs, const float* do
     // query side in one launch (attention.hip): dP = dO V^T, the softmax backward and dQ = alpha dS K; dS lands in dprobs for the dK GEMM
     // below.  Measured at batch 32: T = 64 58 vs 65 us for the whole backward, T = 256 135 vs 124 us (the kernel reads the probabilities
     // twice and writes dS between two unoverlapped staging phases) -> by default only for T = 64.  CDAE_ATTN_BWD_FUSED=0 never, 2 wherever built
-    static const int cfg_fused = getenv("CDAE_ATTN_BWD_FUSED") ? atoi(getenv("CDAE_ATTN_BWD_FUSED")) : 1;
+    static const int cfg_fused = CDAE_DEV_INT("CDAE_ATTN_BWD_FUSED", 1);
     const bool fused_q = (cfg_fused >= 2 || (cfg_fused == 1 && T <= 64)) && cdae_get_default_precision() == CDAE_PREC_F16X3 && cdae_qkv_attention_fused_supported(T, ch) && aligned16(qkv) &&
                          aligned16(probs) && aligned16(dout) && aligned16(dqkv) && aligned16(dprobs);
     if (fused_q) {

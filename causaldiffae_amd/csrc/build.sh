@@ -5,15 +5,15 @@ set -euo pipefail
 cd "$(dirname "$0")"
 OUT=../libcdae.so
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="${EXTRA_HIPCC_FLAGS:-} --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -I../../include"
-UNITS="igemm api norm elementwise prof attention wgrad stem convwin skipgn head"
+FLAGS="${EXTRA_HIPCC_FLAGS:-} --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -Wno-inline-asm -I../../include"
+UNITS="igemm planes api norm elementwise prof attention wgrad stem convwin skipgn head"
 mkdir -p build
 if [ "$(cat build/.flags 2>/dev/null || true)" != "$FLAGS" ]; then FORCE=1; fi
 echo "$FLAGS" > build/.flags
 pids=()
 for u in $UNITS; do
     obj=build/$u.o
-    if [ "${FORCE:-0}" = 1 ] || [ ! -f $obj ] || [ $u.hip -nt $obj ] || [ cdae_internal.h -nt $obj ] || [ ../../include/cdae.h -nt $obj ]; then
+    if [ "${FORCE:-0}" = 1 ] || [ ! -f $obj ] || [ $u.hip -nt $obj ] || [ cdae_internal.h -nt $obj ] || [ gemm_common.h -nt $obj ] || [ ../../include/cdae.h -nt $obj ]; then
         extra=""
         [ $u = elementwise ] && extra="-ffp-contract=off"       # sampler updates round like the reference's separate ATen ops
         $HIPCC $FLAGS $extra -c $u.hip -o $obj & pids+=($!)

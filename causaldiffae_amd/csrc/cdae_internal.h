@@ -79,6 +79,21 @@ int cdae_gemm_dispatch(GemmParams p, void* stream);
 // convwin.hip: second-generation window-resident conv3x3 on pre-split planes
 bool cdae_convwin_ok(const GemmParams& p);
 int cdae_convwin_launch(const GemmParams& p, void* stream);
+// planes.hip: dispatch of a contraction on pre-split planes (convwin / pswin / ps kernels); 0 ok, -1 error, 2 / 3 see planes.hip
+int cdae_planes_dispatch(GemmParams& p, int big, int& ks, hipStream_t st);
+
+// Developer switches.  The shipped library reads NO environment variable for its dispatch (only CDAE_IGEMM_PREC, the documented default
+// precision, and CDAE_PROF_DUMP, the profiler's per-launch dump file): CDAE_DEV_INT(name, default) is the constant `default` unless the
+// library is built with -DCW_DEV=1 (EXTRA_HIPCC_FLAGS), in which case it reads the environment once — ablation / sweep builds only.
+#ifndef CW_DEV
+#define CW_DEV 0
+#endif
+#if CW_DEV
+#include <stdlib.h>
+#define CDAE_DEV_INT(NAME, DFLT) ([]() -> int { static const int v_ = getenv(NAME) ? atoi(getenv(NAME)) : (int)(DFLT); return v_; }())
+#else
+#define CDAE_DEV_INT(NAME, DFLT) (DFLT)
+#endif
 
 // run-time dispatch thresholds (cdae_tune_set / cdae_tune_get in include/cdae.h; prof.hip holds the values)
 enum { TUNE_CONVWIN_MIN_TILES = 0, TUNE_CONVWIN_SPLITK = 1, TUNE_N = 2 };

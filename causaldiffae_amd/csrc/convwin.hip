@@ -28,18 +28,9 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-#ifndef CW_DEV
-#define CW_DEV 0
-#endif
-#ifndef CW_MID_LATE
-#define CW_MID_LATE 0
-#endif
-#ifndef CW_GEOM_LATE
-#define CW_GEOM_LATE 0
-#endif
-#ifndef CW_READ_EARLY
-#define CW_READ_EARLY 0      // 1: next-tile fragment reads in front of the tile's MFMAs (12 instead of 9 MFMAs to land): measured +-0 (same-box A/B)
-#endif
+// (Compile-time variants of the K loop that were measured and removed — next-tile fragment reads in front of the tile's MFMAs, the mid-step
+// wait behind six of tile 4's MFMAs, the next step's geometry inside tile 5's MFMA burst, de-phasing the two blocks of a CU by half a
+// tile, a channel-major result tile with 16-byte stores: docs/NOTES.md.)
 
 namespace {
 
@@ -76,14 +67,7 @@ __device__ __forceinline__ u32x4 cw_lds_read(unsigned addr) {
 // lane l's 16 bytes at (base + voff) -> LDS byte lds_dst + 16 l; base and lds_dst wave-uniform, voff a 32-bit byte offset
 // (sbase a kernel-argument pointer, soff a uniform byte offset: readfirstlane pins the sum to the scalar unit — hipcc is free to
 // compute uniform values on the vector ALU and would then hand the "s" operand a VGPR pair)
-#ifndef CW_VARIANT
-#define CW_VARIANT 0
-#endif
 __device__ __forceinline__ void cw_dma(const void* sbase, int soff, unsigned voff, unsigned lds_dst) {
-#if CW_VARIANT & 1
-    cdae_lds_dma16(reinterpret_cast<const char*>(sbase) + soff + voff, (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst));
-    return;
-#endif
     const char* base = reinterpret_cast<const char*>(sbase) + __builtin_amdgcn_readfirstlane(soff);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane((int)lds_dst)), "v"(voff), "s"(base) : "memory", "m0");
 }
@@ -91,7 +75,7 @@ __device__ __forceinline__ void cw_dma(const void* sbase, int soff, unsigned vof
 // NT = 9: the 3x3 window.  NT = 4: the 2x2 window of one sub-pixel phase (ph_y, ph_x) of nearest-2x-upsample + conv3x3 (tap t reads window
 // position (t / 2 + ph_y, t % 2 + ph_x) of the same 3x3 neighbourhood; weights [rows][4][K]; result scattered to (2y + ph_y, 2x + ph_x)).
 template <bool BF, int NT>
-__global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, const int ntiles, const int dephase_arg) {
+__global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, const int ntiles) {
     typedef const unsigned short* hp;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -231,15 +215,6 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
     unsigned long long t_top = 0, t_vm = 0, t_bar = 0, t_epi = 0;
     auto now = [&]() -> unsigned long long { return stamps ? (unsigned long long)__builtin_readcyclecounter() : 0ull; };
     const unsigned long long t_begin = now();
-    // De-phasing (tiles >= 2 per block): all persistent blocks otherwise reach their stores together and the chip-wide burst
-    // (268 MB at ~5.3 TB/s for a 128-channel result at 64 x 64, batch 128) stalls every wave at once.  The second half of the grid
-    // therefore starts with only the LOWER 64 rows of each wave's 128 (row tiles 0..3) of its first tile and finishes with the UPPER
-    // 64: the same work, but its tile boundaries sit half a tile away from the first half's, so one block of a CU computes while
-    // the other one stores.  part: 0 = all eight row tiles, 1 = tiles 0..3, 2 = tiles 4..7.
-    // (de-phasing the two blocks of a CU by half a tile was built and measured slower — DESIGN.md "tried and dropped"; the run-time `part`
-    // it needed put a branch around every MFMA triple of the K loop, so it is compiled out: part is the constant 0)
-    constexpr int part = 0;
-    (void)dephase_arg;
     setup(tile);
     issue_prologue();
     while (true) {
@@ -260,20 +235,11 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
         unsigned b_c = b_lane;                 // this step's weight stage
         u32x4 bh[4], bl[4], ah[2], al[2];
         // fragment address of padding taps -> out of range -> zeros
-#if CW_VARIANT & 2
-        extern __shared__ __attribute__((aligned(16))) char lds[];
-#define CW_READ_A(I, BUF, WTAP, ADDR) { const unsigned m_ = (unsigned)__builtin_amdgcn_sbfe(tapmask[I], WTAP, 1); \
-            const unsigned ad_ = m_ ? ADDR + (I) * 512 : a_lane; \
-            ah[BUF] = *reinterpret_cast<const u32x4*>(lds + ad_) & m_; al[BUF] = *reinterpret_cast<const u32x4*>(lds + ad_ + CW_A_PLANE) & m_; }
-#define CW_READ_B(J, ADDR) { bh[J] = *reinterpret_cast<const u32x4*>(lds + ADDR + (J) * 512); bl[J] = *reinterpret_cast<const u32x4*>(lds + ADDR + (J) * 512 + CW_B_PLANE); }
-#define CW_WAIT(...)
-#else
 #define CW_READ_A(I, BUF, WTAP, ADDR) { const unsigned m_ = (unsigned)__builtin_amdgcn_sbfe(tapmask[I], WTAP, 1); \
             const unsigned ad_ = (ADDR & m_) | (CW_OOB & ~m_); \
             ah[BUF] = cw_lds_read<(I) * 512>(ad_); al[BUF] = cw_lds_read<(I) * 512 + CW_A_PLANE>(ad_); }
 #define CW_READ_B(J, ADDR) { bh[J] = cw_lds_read<(J) * 512>(ADDR); bl[J] = cw_lds_read<(J) * 512 + CW_B_PLANE>(ADDR); }
 #define CW_WAIT(...) asm volatile(__VA_ARGS__)
-#endif
         if (nsteps > 0) {
             CW_READ_A(0, 0, wtap_c, a_c);
             CW_READ_B(0, b_c); CW_READ_B(1, b_c); CW_READ_B(2, b_c); CW_READ_B(3, b_c);
@@ -293,9 +259,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
             int gn = ga, tn = ta + 2;          // first unit of the next step
             if (tn >= NT) { tn -= NT; ++gn; }
             int wtap_n; unsigned a_n;
-#if !CW_GEOM_LATE
             geom(gn, tn, wtap_n, a_n);
-#endif
             const unsigned b_n = b_lane + ((s + 1) & 1) * CW_B_STAGE;
             // the two waves of a SIMD belong to different blocks: alternating the issue priority by step parity lets one of them run
             // its MFMA burst unbroken while the other is at its mid-step wait (measured +2..3 %; CDAE_PS_DBG & 64 turns it off)
@@ -331,35 +295,14 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 };
-#if !CW_MID_LATE
                 if (i == 4) midstep();
-#endif
                 // tile 0 needs A(0) and B(0) of the ten reads in flight; every other tile's A pair is the only thing outstanding
                 if (i == 0) CW_WAIT("s_waitcnt lgkmcnt(6)" : "+v"(ah[0]), "+v"(al[0]), "+v"(bh[0]), "+v"(bl[0]));
                 else CW_WAIT("s_waitcnt lgkmcnt(0)" : "+v"(ah[cur]), "+v"(al[cur]));
-                const bool en = part == 0 || ((i < 4) == (part == 1));        // wave-uniform: a half item skips the other half's MFMAs
-#if CW_READ_EARLY
-                // the next tile's fragment reads go out in front of this tile's MFMAs (its buffer was last read by tile i - 1, whose
-                // MFMAs are all issued) and have twelve MFMAs to land
+                acc[i][0] = mma(al[cur], bh[0], acc[i][0]);
+                acc[i][0] = mma(ah[cur], bl[0], acc[i][0]);
+                acc[i][0] = mma(ah[cur], bh[0], acc[i][0]);
                 __builtin_amdgcn_sched_barrier(0);
-                if (i == 0) { CW_READ_A(1, 1, wtap_c, a_c); }
-                else if (i == 1) { CW_READ_A(2, 0, wtap_c, a_c); }
-                else if (i == 2) { CW_READ_A(3, 1, wtap_c, a_c); }
-                else if (i == 3) { CW_READ_A(4, 0, wtap_c, a_c); }
-                else if (i == 4) { CW_READ_A(5, 1, wtap_c, a_c); }
-                else if (i == 5) { CW_READ_A(6, 0, wtap_c, a_c); }
-                else if (i == 6) { CW_READ_A(7, 1, wtap_c, a_c); }
-                __builtin_amdgcn_sched_barrier(0);
-#endif
-                if (en) {
-                    acc[i][0] = mma(al[cur], bh[0], acc[i][0]);
-                    acc[i][0] = mma(ah[cur], bl[0], acc[i][0]);
-                    acc[i][0] = mma(ah[cur], bh[0], acc[i][0]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#if CW_READ_EARLY
-                if (i == 7) { CW_READ_A(0, 0, wtap_n, a_n); CW_READ_B(0, b_n); }      // next step: its first tile and the first dead weight fragments
-#else
                 // the next tile's fragment reads go out behind the first three MFMAs and have nine MFMAs to land
                 if (i == 0) { CW_READ_A(1, 1, wtap_c, a_c); }
                 else if (i == 1) { CW_READ_A(2, 0, wtap_c, a_c); }
@@ -369,25 +312,14 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                 else if (i == 5) { CW_READ_A(6, 0, wtap_c, a_c); }
                 else if (i == 6) { CW_READ_A(7, 1, wtap_c, a_c); }
                 else { CW_READ_A(0, 0, wtap_n, a_n); CW_READ_B(0, b_n); }      // next step: its first tile and the first dead weight fragments
-#endif
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 1; j < 4; ++j) {
                     // tile 0: B(j) is the oldest of the reads in flight [B(j) .. B(3), A(1)]
                     if (i == 0) CW_WAIT("s_waitcnt lgkmcnt(%2)" : "+v"(bh[j]), "+v"(bl[j]) : "n"(8 - 2 * j));
-#if CW_GEOM_LATE
-                    if (i == 5 && j == 1) geom(gn, tn, wtap_n, a_n);      // the next step's geometry (~35 vector instructions) in the shadow of tile 5's MFMAs
-#endif
-                    if (en) {
-                        acc[i][j] = mma(al[cur], bh[j], acc[i][j]);
-                        acc[i][j] = mma(ah[cur], bl[j], acc[i][j]);
-                        acc[i][j] = mma(ah[cur], bh[j], acc[i][j]);
-                    }
-#if CW_MID_LATE
-                    // the mid-step wait / barrier / DMA issue behind the first six MFMAs of tile 4 (they and the A(5) read only need registers
-                    // and the live window halves), so the matrix pipe has work queued while this wave is at the barrier
-                    if (i == 4 && j == 1) { __builtin_amdgcn_sched_barrier(0); midstep(); }
-#endif
+                    acc[i][j] = mma(al[cur], bh[j], acc[i][j]);
+                    acc[i][j] = mma(ah[cur], bl[j], acc[i][j]);
+                    acc[i][j] = mma(ah[cur], bh[j], acc[i][j]);
                     if (i == 7) {
                         __builtin_amdgcn_sched_barrier(0);
                         if (j == 1) { CW_READ_B(1, b_n); } else if (j == 2) { CW_READ_B(2, b_n); } else { CW_READ_B(3, b_n); }
@@ -405,7 +337,6 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
         __builtin_amdgcn_s_setprio(0);
         // ---- tile done: stage the next tile's operands, then write this tile's result (the stores drain behind the next K loop)
         const int em0 = m0, en0 = n0, eks = ks, eph = cph, eph_y = cph_y, eph_x = cph_x;
-        constexpr int epart = part;
         const int next = tile + gridDim.x;
         const bool has_next = next < ntiles;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the look-ahead reads of the step that does not exist
@@ -435,7 +366,6 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
             for (int j = 0; j < 4; ++j) bv[j] = p.bias ? p.bias[en0 + wn * 64 + lr_ + 16 * j] : 0.f;
 #pragma unroll
             for (int i2 = 0; i2 < 4; ++i2) {
-                if (epart != 0 && ((i2 < 2) != (epart == 1))) continue;      // a half item owns only its own row tiles
                 float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ii = 0; ii < 2; ++ii) {
@@ -511,7 +441,6 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
             for (int j = 0; j < 4; ++j) bv[j] = (col0 + 16 * j < p.N && p.ksplit == 1 && p.bias) ? p.bias[col0 + 16 * j] : 0.f;
 #pragma unroll
             for (int i2 = 0; i2 < 4; ++i2) {
-                if (epart != 0 && ((i2 < 2) != (epart == 1))) continue;
                 float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ii = 0; ii < 2; ++ii) {
@@ -580,12 +509,9 @@ int launch_convwin(const GemmParams& p, hipStream_t st) {
         attr_done = true;
     }
     const long ntiles = (long)((p.M + CW_BM - 1) / CW_BM) * ((p.N + CW_BN - 1) / CW_BN) * p.ksplit * (p.nphase > 1 ? p.nphase : 1);
-    static const int cfg_persist = getenv("CDAE_CONVWIN_GRID") ? atoi(getenv("CDAE_CONVWIN_GRID")) : 512;      // two blocks per CU
+    static const int cfg_persist = CDAE_DEV_INT("CDAE_CONVWIN_GRID", 512);      // persistent blocks: two per CU
     dim3 grid((unsigned)(ntiles < cfg_persist ? ntiles : cfg_persist));
-    // measured: 128->128 at 64 x 64 519 vs 478 us, DDIM step 27.3 vs 25.8 ms — the two half items cost ~1.4 tiles (same DMA and LDS
-    // traffic as a whole tile each), more than the overlapped store burst returns at four tiles per block: off by default
-    static const int cfg_dephase = getenv("CDAE_CONVWIN_DEPHASE") ? atoi(getenv("CDAE_CONVWIN_DEPHASE")) : 0;
-    hipLaunchKernelGGL((convwin_kernel<BF, NT>), grid, dim3(256), CW_LDS, st, p, (int)ntiles, (int)(cfg_dephase && ntiles >= 2 * (long)cfg_persist));
+    hipLaunchKernelGGL((convwin_kernel<BF, NT>), grid, dim3(256), CW_LDS, st, p, (int)ntiles);
     return hipGetLastError() == hipSuccess ? 0 : cdae_fail("convwin_kernel launch failed");
 }
 

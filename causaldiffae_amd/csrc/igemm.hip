@@ -21,94 +21,9 @@
 // k-major operands as [32][rows+4] with interleaved MFMA row slots (ds_read_b64 along rows).  Register-staged double
 // buffering: tile t+1's global loads are issued before the MFMAs of tile t and written to the
 // other LDS buffer afterwards (one barrier per K-step).
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <stdlib.h>
-#include <type_traits>
-#include "cdae_internal.h"
-#include "../../include/cdae.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
-typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
-typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
-
-// dev ablations / stamps of the plane kernels (CDAE_PS_DBG bits) exist only in a -DCW_DEV=1 build (EXTRA_HIPCC_FLAGS=-DCW_DEV=1 build.sh):
-// as run-time tests they sat in every K step of the production kernels
-#ifndef CW_DEV
-#define CW_DEV 0
-#endif
-#define PDBG(P) (CW_DEV ? (P).dbg : 0)
+#include "gemm_common.h"
 
 namespace {
-
-constexpr int BK = 32;
-constexpr int LDK = BK + 4;     // row pitch (floats) of a K-contiguous LDS tile
-
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-
-// ---- conv gather geometry for one GEMM row (an output pixel, or for wgrad a reduction pixel)
-struct PixRow {
-    long base;     // element offset of image n
-    int iy0, ix0;  // top-left input coordinate of the 3x3 window (already * stride - pad)
-    int ok;        // row < M
-};
-
-// exact floor(n / d) for n < 2^31 with a host-computed (magic, shift): (mulhi(n, magic) + n) >> shift
-__device__ __forceinline__ int fdiv(int n, unsigned magic, int shift) {
-    return (int)((__umulhi((unsigned)n, magic) + (unsigned)n) >> shift);
-}
-
-// Everything below is straight-line (no branches, no early returns): any control flow in the gather geometry ends
-// up between the tile loads and makes hipcc serialise them with vmcnt waits.  The mode switches (stride / fused
-// upsample / transposed stride-2 gather) are folded into host-computed constants g_*.
-__device__ __forceinline__ PixRow make_pixrow(const GemmParams& p, int m) {
-    PixRow r;
-    r.ok = m < p.conv_M;
-    const int mm = r.ok ? m : 0;
-    const int n = fdiv(mm, p.hw_magic, p.hw_shift);
-    const int rem = mm - n * p.hw;
-    const int oy = fdiv(rem, p.wo_magic, p.wo_shift), ox = rem - oy * p.Wo;
-    r.base = (long)n * p.sn;
-    r.iy0 = oy * p.g_mul + p.g_add;         // conv: o*stride - 1;  transposed gather: o + 1
-    r.ix0 = ox * p.g_mul + p.g_add;
-    return r;
-}
-
-// offset (elements) of the input pixel under window tap (ky,kx); false when the tap reads padding
-__device__ __forceinline__ bool tap_offset(const GemmParams& p, const PixRow& r, int ky, int kx, long& off) {
-    const int ty = r.iy0 + p.g_sign * ky, tx = r.ix0 + p.g_sign * kx;      // transposed gather walks the taps backwards
-    const bool ok = ((ty | tx) >= 0) & (((ty | tx) & p.g_pm) == 0) & (ty < (p.H << p.g_sh)) & (tx < (p.W << p.g_sh));
-    const int iy = ty >> p.g_sh, ix = tx >> p.g_sh;                       // >>1: fused upsample source / stride-2 transpose
-    off = ok ? r.base + (long)iy * p.sy + (long)ix * p.sx : 0;
-    return ok;
-}
-
-// Branch-free guarded loads.  A conditional `ok ? load : 0` makes hipcc branch around every load and wait
-// vmcnt(0) before the next one (all tile loads of a K-step serialised), and a value select after the load drags
-// the vmcnt wait in front of the MFMAs.  Selecting the ADDRESS instead (a zero-filled device constant when !ok)
-// keeps the loads unconditional, back-to-back and un-waited until the LDS store after the MFMAs.
-__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // non-const: stays in the global address space (a constant-space pointer turns the select into flat loads)
-
-__device__ __forceinline__ float4 ld4_if(const float* /*unused*/, const float* p, bool ok) {
-    return ld4(ok ? p : g_zero16);
-}
-__device__ __forceinline__ float ld1_if(const float* /*unused*/, const float* p, bool ok) {
-    return *(ok ? p : g_zero16);
-}
-
-// second output of an epilogue: v as f16 hi/lo planes
-__device__ __forceinline__ void store_planes(const GemmParams& p, long addr, float v) {
-    asm volatile("" : "+v"(v));        // opaque: no second, differently rounded f16 conversion folded into the producing fma (see attention.hip split8)
-    const _Float16 h = (_Float16)v;
-    const _Float16 l = (_Float16)(v - (float)h);
-    p.C_hi[addr] = __builtin_bit_cast(unsigned short, h);
-    p.C_lo[addr] = __builtin_bit_cast(unsigned short, l);
-}
 
 // SCALAR = element-wise operand loads (odd K / pitch / alignment, tiny channel counts); only built for 64x64 tiles.
 //
@@ -714,663 +629,6 @@ __global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_ke
         }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// ps_kernel: the same f16x3 product on operands that are ALREADY split into f16 planes in HBM (activations by the
-// producing GroupNorm kernel, weights once per weight version).  The main loop then has no conversion VALU and no
-// register staging: every 16-byte piece of a tile goes global -> LDS by LDS-DMA (global_load_lds_dwordx4), the planes
-// keep the [rows][64 B] image of the in-kernel-split path (16-B chunks XOR-swizzled by (row>>2)&3 — applied on the
-// per-lane SOURCE address, the LDS destination of a DMA is lane-linear), and the fragment reads / MFMAs are unchanged.
-// One barrier per 32-deep step: wait own DMAs -> barrier -> issue the next stage's DMAs -> 12 MFMAs per wave.
-// The conv gather's per-row tap offsets (9 per output pixel, -1 = padding) are computed once into an LDS table.
-__device__ __attribute__((aligned(16))) unsigned g_zero_ps[4] = {0u, 0u, 0u, 0u};
-
-// LOADERS > 0: that many extra waves do nothing but issue the DMAs (an LDS-DMA costs its issuing wave 60-180 cycles, four per
-// step in a wave that also has 12 MFMAs to issue); the compute waves then only read fragments and issue MFMAs.
-// BF: the planes hold bf16 (gradient operands: full fp32 range, 16 significand bits over the two planes) instead of f16.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NPL, int STAGES, int LOADERS = 0, bool BF = false>
-__global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + LOADERS)) void ps_kernel(const GemmParams p) {
-    constexpr int NCOMP = WAVES_M * WAVES_N, THREADS = 64 * (NCOMP + LOADERS);
-    constexpr int LT = LOADERS ? 64 * LOADERS : THREADS;               // threads that issue DMAs
-    constexpr int RPP = LT / 4;                                        // tile rows covered by one DMA pass
-    static_assert(LOADERS == 0 || STAGES == 2, "loader waves are built for the 2-stage loop");
-    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
-    static_assert(STAGES == 2 || STAGES == 3, "2 stages: one __syncthreads per step; 3 stages: DMAs stay in flight across a raw barrier");
-    constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;                // bytes per 16-bit plane
-    constexpr int STAGE = NPL * (A_PLANE + B_PLANE);
-    constexpr int A_P = BM / RPP, B_P = BN / RPP;                      // 16-byte pieces per thread per plane
-    static_assert(A_P >= 1 && B_P >= 1, "tile smaller than one DMA pass");
-    typedef const unsigned short* hp;
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    char* const lds = reinterpret_cast<char*>(smem);
-    int* const taptab = reinterpret_cast<int*>(lds + STAGES * STAGE);  // [taps][BM] element offsets, -1 = zero row
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, hh = lane >> 5;
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const bool is_loader = LOADERS > 0 && wave >= NCOMP;               // wave-uniform role
-    const bool loads_here = LOADERS == 0 || is_loader;
-    const int ltid = LOADERS ? tid - 64 * NCOMP : tid, lwave = LOADERS ? wave - NCOMP : wave;   // index among the DMA-issuing threads
-
-    const int nmt = (p.M + BM - 1) / BM, nnt = (p.N + BN - 1) / BN;
-    int mt, nt, ks;
-    {
-        const unsigned G = gridDim.x, b = blockIdx.x;
-        const unsigned q = G >> 3, r = G & 7, x = b & 7;
-        unsigned v = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-        nt = v % nnt; v /= nnt;
-        mt = v % nmt; ks = v / nmt;
-    }
-    const int m0 = mt * BM, n0 = nt * BN;
-    const hp a_hi = reinterpret_cast<hp>(p.A), a_lo = p.A_lo;
-    const hp b_hi = reinterpret_cast<hp>(p.B), b_lo = p.B_lo;
-    // padding rows read a zero page.  The select is done on the element OFFSET (zero page expressed relative to each plane):
-    // selecting between two pointers makes hipcc branch around two different load forms.
-    const hp zero = reinterpret_cast<hp>(g_zero_ps);
-    const long za_hi = zero - a_hi, za_lo = NPL == 2 ? zero - a_lo : 0, zb_hi = zero - b_hi, zb_lo = NPL == 2 ? zero - b_lo : 0;
-
-    const int taps = p.amode == A_CONV_VEC ? (p.ps_taps == 4 ? 4 : 9) : 1;
-    const int cpt = (taps == 1 ? p.K : p.Cin) / BK;                    // 32-deep steps per tap
-    const int nk_total = taps * cpt;
-    const int nk_per = (nk_total + p.ksplit - 1) / p.ksplit;
-    const int kt_begin = ks * nk_per;
-    const int kt_end = min(nk_total, kt_begin + nk_per);
-
-    for (int idx = tid; idx < taps * BM; idx += THREADS) {
-        const int tap = idx / BM, row = idx - tap * BM, m = m0 + row;
-        int off = -1;
-        if (taps == 1) { if (m < p.M) off = m * (int)p.lda; }
-        else {
-            const PixRow r = make_pixrow(p, m);
-            long o;
-            // 9 taps: the 3x3 window; 4 taps: the 2x2 window of one sub-pixel phase, shifted by (ph_y, ph_x)
-            const int ky = taps == 9 ? tap / 3 : (tap >> 1) + p.ph_y, kx = taps == 9 ? tap - 3 * (tap / 3) : (tap & 1) + p.ph_x;
-            const bool ok = tap_offset(p, r, ky, kx, o);
-            if (ok && r.ok) off = (int)o;
-        }
-        if ((PDBG(p) & 1) && off >= 0) off = (row & 15) * 64;
-        taptab[idx] = off;
-    }
-
-    // B rows are loop invariant: per piece a running pointer (or the zero page for rows >= N)
-    long boff[B_P];                // element offset of this thread's piece in the weight planes
-    bool bok[B_P];
-#pragma unroll
-    for (int q = 0; q < B_P; ++q) {
-        const int row = ((ltid >> 2) + RPP * q) & (BN - 1), c = (ltid & 3) ^ ((row >> 2) & 3);      // (& mask: compute waves of a loader build carry a dummy index)
-        bok[q] = n0 + row < p.N;
-        boff[q] = (long)(bok[q] ? n0 + row : 0) * p.ldb + (long)kt_begin * BK + c * 8;
-    }
-    int acol[A_P];                 // this thread's 16-byte chunk inside the 32-deep k slice, in elements
-    int arow[A_P];
-#pragma unroll
-    for (int q = 0; q < A_P; ++q) { arow[q] = ((ltid >> 2) + RPP * q) & (BM - 1); acol[q] = 8 * ((ltid & 3) ^ ((arow[q] >> 2) & 3)); }
-
-    // LDS-DMA through inline asm (cdae_lds_dma16): with the builtin, hipcc drains the DMAs (vmcnt(0)) in front of the next LDS read that
-    // might alias their destination — i.e. right after they were issued, before the MFMAs they were meant to overlap
-    auto dma = [&](hp src, char* dst_wave_base) {
-        cdae_lds_dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst_wave_base - lds)));
-    };
-    // issue the DMAs of one 32-deep step (tap, channel offset kc) into `stage`; B pointers advance by one step
-    auto issue = [&](int stage, int tap, int kc) {
-        char* const sa = lds + stage * STAGE;
-        char* const sb = sa + NPL * A_PLANE;
-#pragma unroll
-        for (int q = 0; q < A_P; ++q) {
-            const int off = taptab[tap * BM + arow[q]];
-            const long e = (long)off + kc + acol[q];
-            const bool ok = off >= 0;
-            char* const dst = sa + (q * LT + lwave * 64) * 16;
-            dma(a_hi + (ok ? e : za_hi), dst);
-            if constexpr (NPL == 2) dma(a_lo + (ok ? e : za_lo), dst + A_PLANE);
-        }
-#pragma unroll
-        for (int q = 0; q < B_P; ++q) {
-            char* const dst = sb + (q * LT + lwave * 64) * 16;
-            dma(b_hi + (bok[q] ? boff[q] : zb_hi), dst);
-            if constexpr (NPL == 2) dma(b_lo + (bok[q] ? boff[q] : zb_lo), dst + B_PLANE);
-            boff[q] += (PDBG(p) & 2) ? 0 : BK;
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    int tap = kt_begin / cpt, chunk = kt_begin - tap * cpt;            // position of the NEXT step to issue
-    auto advance = [&]() { ++chunk; const bool wrap = chunk == cpt; chunk = wrap ? 0 : chunk; tap += wrap ? 1 : 0; };
-
-    __syncthreads();                                                   // tap table visible
-    constexpr int G = NPL * (A_P + B_P);                               // DMAs per wave per step
-    const bool nodma = (PDBG(p) & 4) != 0;
-    auto issue_next = [&](int stage) { issue(stage, (PDBG(p) & 1) ? 0 : tap, (PDBG(p) & 1) ? 0 : chunk * BK); advance(); };
-    if (loads_here && kt_begin < kt_end) issue_next(0);
-    if constexpr (STAGES == 3) { if (kt_begin + 1 < kt_end) issue_next(1); }
-
-    int cur = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        if constexpr (STAGES == 2) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's DMAs of stage `cur` have landed
-            __syncthreads();                                           // ... everyone's have, and stage cur^1 is no longer read
-            if (loads_here && kt + 1 < kt_end && !nodma) issue_next(cur ^ 1);
-            if (is_loader) { cur ^= 1; continue; }                     // loader waves: back to the barrier
-        } else {
-            // stage kt landed when at most the G DMAs of stage kt+1 are still outstanding; the barrier also tells that every
-            // wave is done reading stage kt-1 == (kt+2) % 3, which the next DMAs overwrite.  No vmcnt(0) in the loop.
-            if (kt + 1 < kt_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (!(PDBG(p) & 8)) __builtin_amdgcn_s_barrier();
-            if (kt + 2 < kt_end && !nodma) issue_next(cur == 0 ? 2 : cur - 1);
-        }
-
-        const char* ac = lds + cur * STAGE;
-        const char* bc = ac + NPL * A_PLANE;
-        auto frag = [&](const char* plane, int row0, int sk) -> u16x8 {
-            const int row = (PDBG(p) & 16) ? 0 : row0 + l31;             // dbg 16: every lane reads the same 16 bytes (LDS broadcast, no bandwidth)
-            return *reinterpret_cast<const u16x8*>(plane + row * 64 + 16 * ((2 * sk + hh) ^ ((row >> 2) & 3)));
-        };
-        auto mma = [&](const u16x8& x, const u16x8& y, const f32x16& c) -> f32x16 {
-            if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, x), __builtin_bit_cast(bf8, y), c, 0, 0, 0);
-            else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, x), __builtin_bit_cast(half8, y), c, 0, 0, 0);
-        };
-#pragma unroll
-        for (int sk = 0; sk < 2; ++sk) {
-            u16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                ah[i] = frag(ac, wm * WM + i * 32, sk);
-                if constexpr (NPL == 2) al[i] = frag(ac + A_PLANE, wm * WM + i * 32, sk);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                bh[j] = frag(bc, wn * WN + j * 32, sk);
-                if constexpr (NPL == 2) bl[j] = frag(bc + B_PLANE, wn * WN + j * 32, sk);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if constexpr (NPL == 2) {
-                        acc[i][j] = mma(al[i], bh[j], acc[i][j]);        // same order as the in-kernel-split path: bit-identical sums
-                        acc[i][j] = mma(ah[i], bl[j], acc[i][j]);
-                    }
-                    acc[i][j] = mma(ah[i], bh[j], acc[i][j]);
-                }
-        }
-        cur = cur + 1 == STAGES ? 0 : cur + 1;
-    }
-
-    // ---------------------------------------------------------------- epilogue (as igemm_kernel's, K-contiguous case)
-    if (is_loader) return;
-    float* __restrict__ Cg;
-    const float* __restrict__ Rg = nullptr;
-    if (p.ksplit > 1) Cg = p.splitk_ws + (long)ks * (long)p.M * p.N;
-    else { Cg = p.C; Rg = p.res; }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * WN + j * 32 + l31;
-            if (col >= p.N) continue;
-            const float bv = (p.ksplit == 1 && p.bias) ? p.bias[col] : 0.f;
-            float gs = 0.f, gq = 0.f;
-            auto out_addr = [&](int row) -> long {
-                if (p.out_mode == OUT_NCHW) {
-                    int img = row / p.out_hw, pix = row - img * p.out_hw;
-                    return ((long)img * p.N + col) * p.out_hw + pix;
-                } else if (p.out_mode == OUT_UP2) {
-                    const int x = row - fdiv(row, p.wo_magic, p.wo_shift) * p.Wo;          // (n, y, x) -> (n, 2y + ph_y, 2x + ph_x)
-                    return (4L * row - 2 * x + p.ph_y * 2 * p.Wo + p.ph_x) * p.ldc + col;
-                }
-                return (long)row * p.ldc + col;
-            };
-            // residual / accumulate operands of the sub-tile's 16 rows requested together (as in igemm_kernel's epilogue)
-            float rv[16], cv[16];
-            if (p.ksplit == 1 && (Rg || p.accumulate)) {
-                long ad[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    ad[r] = row < p.M ? out_addr(row) : 0;
-                }
-                if (Rg) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) rv[r] = Rg[ad[r]];
-                }
-                if (p.accumulate) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) cv[r] = Cg[ad[r]];
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (row >= p.M) continue;
-                if (p.ksplit > 1) { Cg[(long)row * p.N + col] = acc[i][j][r]; continue; }
-                const long addr = out_addr(row);
-                float v = acc[i][j][r] * p.alpha + bv;
-                if (Rg) v += rv[r];
-                if (p.act == ACT_SILU) v = cdae_silu(v);
-                else if (p.act == ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
-                if (p.accumulate) v += cv[r];
-                Cg[addr] = v;
-                if (!__builtin_isfinite(v) && p.range_flag) *p.range_flag = 1;
-                if (p.C_hi) store_planes(p, addr, v);
-                gs += v; gq += v * v;
-            }
-            if (p.gn_part && p.ksplit == 1) {           // this wave owns the whole 32 x 32 sub-tile: one deterministic write per (chunk, column)
-                gs += __shfl_xor(gs, 32); gq += __shfl_xor(gq, 32);
-                if (hh == 0) {
-                    float* o = p.gn_part + ((long)((m0 + wm * WM + i * 32) >> 5) * p.N + col) * 2;
-                    o[0] = gs; o[1] = gq;
-                }
-            }
-        }
-}
-
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NPL, int STAGES, int LOADERS = 0, bool BF = false>
-int launch_ps(const GemmParams& p, hipStream_t st) {
-    const int taps = p.amode == A_CONV_VEC ? (p.ps_taps == 4 ? 4 : 9) : 1;
-    constexpr size_t tiles = (size_t)STAGES * NPL * (BM + BN) * 64;
-    const size_t smem = tiles + (size_t)taps * BM * sizeof(int);
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ps_kernel<BM, BN, WAVES_M, WAVES_N, NPL, STAGES, LOADERS, BF>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(tiles + 9 * BM * sizeof(int))) != hipSuccess)
-            return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
-        attr_done = true;
-    }
-    dim3 grid((unsigned)((long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.ksplit));
-    hipLaunchKernelGGL((ps_kernel<BM, BN, WAVES_M, WAVES_N, NPL, STAGES, LOADERS, BF>), grid, dim3(64 * (WAVES_M * WAVES_N + LOADERS)), smem, st, p);
-    return hipGetLastError() == hipSuccess ? 0 : cdae_fail("ps_kernel launch failed");
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// pswin_kernel: stride-1 conv3x3 on pre-split planes with the activation WINDOW resident in LDS.  The 9 taps of a tile of
-// 128 consecutive output pixels read the same input pixels shifted by (ky-1)*W + (kx-1), so per 32-channel chunk the block
-// loads one window of 128 + 2W + 2 pixel rows ONCE (instead of nine 128-row tiles) and every tap reads its A fragments from
-// the window at a row offset; pixels that fall outside the image (or into the neighbouring image of the batch) are masked
-// to zero in the fragment registers by a per-lane 9-bit tap mask.  Per step (chunk, tap) only the 128 x 32 weight tile is
-// staged (double-buffered).  A-operand traffic drops 4.5x (W = 64) .. 7.9x (W = 8), bytes per step from 32 KB to ~20 KB.
-// K order is (chunk, tap, channel) — the sums differ from ps_kernel's (tap, channel) order by fp32 rounding only.
-// BST = 3 weight stages (rows up to 32 pixels: the window is small enough for two blocks per CU): the DMAs of step s+2 are in
-// flight while step s computes, and the loop waits with a counted vmcnt instead of draining.
-// GNA: the window is not copied from pre-split planes but PRODUCED in the kernel from the GroupNorm's fp32 input: every thread
-// keeps the next chunk's float4s in registers (loaded one chunk ahead), folds y = silu?(x * a + b) with the per-(image, channel)
-// coefficients (a 1-KB LDS-DMA per chunk), splits to f16 hi/lo and writes the same swizzled window image.  This is the
-// reference's ResBlock prologue (GroupNorm -> SiLU -> conv3x3, unet.py:187-197) without the normalised tensor ever existing in HBM.
-// BM = 256 (4 x 2 waves of 64 x 64): twice the MFMAs per step and per staged weight byte.  Its window is TIGHT — exactly BM + 2W
-// rows (384 at W = 64, so that window + two weight stages are 80 KB and two blocks still share a CU): the two corner rows of the
-// loose window are only ever read by masked taps when tiles start on an image-row boundary (BM % W == 0), so their reads clamp.
-template <int BN, int NPL, int BST, int MAXWIN, int WAVES_N = 4, bool GNA = false, int BM = 128, bool TIGHT = (BM == 256), int BLOCKS = 2, bool BF = false, int WM_ = 64>
-__global__ __launch_bounds__(BM / WM_ * WAVES_N * 64, BM / WM_ * WAVES_N * BLOCKS / 4) void pswin_kernel(const GemmParams p) {     // BLOCKS blocks per CU; WM_ = rows of a wave tile
-    constexpr int WAVES_M = BM / WM_, NW = WAVES_M * WAVES_N, THREADS = 64 * NW;
-    static_assert(!GNA || (BST == 2 && BM == 128), "the fused-GroupNorm window is built for the 2-stage weight ring and 128-row tiles");
-    constexpr int G_SLOTS = (MAXWIN * 8 + THREADS - 1) / THREADS;        // float4s of a window chunk per thread
-    constexpr int WM = WM_, WN = BN / WAVES_N, TM = WM_ / 32, TN = WN / 32;
-    static_assert(MAXWIN % 16 == 0 && (BST == 2 || BST == 3), "window rows come in 16-row DMA blocks");
-    constexpr int A_PLANE = MAXWIN * 64, B_PLANE = BN * 64;
-    constexpr int A_SLOTS = (2 * (MAXWIN / 16) + NW - 1) / NW;          // 2 planes x 16-row blocks over the block's waves
-    constexpr int B_RB = (BN / 16) / NW;                                // 16-row weight blocks per wave
-    typedef const unsigned short* hp;
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    char* const lds = reinterpret_cast<char*>(smem);
-    char* const awin = lds;                                             // [NPL][MAXWIN][64 B]
-    char* const bst = lds + NPL * A_PLANE;                              // [BST stages][NPL][BN][64 B]
-    char* const coefb = bst + BST * NPL * B_PLANE;                      // GNA: [2][4 images][32 channels][a, b] floats
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, hh = lane >> 5;
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-
-    const int nmt = (p.M + BM - 1) / BM, nnt = (p.N + BN - 1) / BN;
-    int mt, nt, ks;
-    {
-        const unsigned G = gridDim.x, b = blockIdx.x;
-        const unsigned q = G >> 3, r = G & 7, x = b & 7;
-        unsigned v = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-        nt = v % nnt; v /= nnt;
-        mt = v % nmt; ks = v / nmt;
-    }
-    const int m0 = mt * BM, n0 = nt * BN;
-    const hp a_hi = reinterpret_cast<hp>(p.A), a_lo = p.A_lo;
-    const hp b_hi = reinterpret_cast<hp>(p.B), b_lo = p.B_lo;
-    const hp zero = reinterpret_cast<hp>(g_zero_ps);
-    const long za_hi = zero - a_hi, za_lo = NPL == 2 ? zero - a_lo : 0, zb_hi = zero - b_hi, zb_lo = NPL == 2 ? zero - b_lo : 0;
-
-    const int W = p.W, win = BM + 2 * W + (TIGHT ? 0 : 2), NB = (win + 15) >> 4;      // window rows, 16-row DMA blocks per plane
-    const int pix0 = m0 - W - (TIGHT ? 0 : 1);                          // flattened input pixel of window row 0
-    const int nchunk = p.Cin / BK;
-    const int c_per = (nchunk + p.ksplit - 1) / p.ksplit;
-    const int c_begin = ks * c_per, c_end = min(nchunk, c_begin + c_per);
-
-    // ---- GNA: this thread's float4 slots of a window chunk (item = tid + THREADS q: window row item / 8, channels 4 (item % 8) .. +3)
-    int gpix[G_SLOTS], gimg[G_SLOTS];          // flattened pixel (or -1) and image index relative to the window's first image
-    float4 xv[G_SLOTS];
-    const int pix_first = max(pix0, 0), img_first = fdiv(pix_first, p.hw_magic, p.hw_shift), img_last = fdiv(p.M - 1, p.hw_magic, p.hw_shift);
-    if constexpr (GNA) {
-#pragma unroll
-        for (int q = 0; q < G_SLOTS; ++q) {
-            const int item = tid + THREADS * q, j = item >> 3, pix = pix0 + j;
-            const bool ok = j < win && pix >= 0 && pix < p.M;
-            gpix[q] = ok ? pix : -1;
-            gimg[q] = ok ? min(fdiv(pix, p.hw_magic, p.hw_shift) - img_first, 3) : 0;
-        }
-    }
-    const float* const gzero = reinterpret_cast<const float*>(g_zero_ps);
-    auto gna_load = [&](int chunk) {           // issue the global loads of one chunk of the window into registers
-        const int c0 = chunk * BK + (tid & 7) * 4;
-        const bool second = p.A2 && c0 >= p.K1;
-        const float* src = second ? p.A2 : p.A;
-        const long pitch = second ? p.lda2 : p.lda;
-        const int cc = second ? c0 - p.K1 : c0;
-#pragma unroll
-        for (int q = 0; q < G_SLOTS; ++q)
-            xv[q] = ld4(gpix[q] >= 0 ? src + (long)gpix[q] * pitch + cc : gzero);
-    };
-    auto gna_coef_dma = [&](int chunk, int buf) {      // wave 0: (a, b) of 4 images x 32 channels -> 1 KB of LDS
-        if (wave == 0) {
-            const int img = min(img_first + (lane >> 4), img_last);
-            const float* src = p.gn_coef + ((long)img * p.Cin + chunk * BK) * 2 + (lane & 15) * 4;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(coefb + buf * 1024), 16, 0, 0);
-        }
-    };
-    auto gna_stage = [&](int buf) {            // registers -> normalise (+SiLU) -> f16 hi/lo -> swizzled window image
-#pragma unroll
-        for (int q = 0; q < G_SLOTS; ++q) {
-            const int item = tid + THREADS * q, j = item >> 3, f4 = item & 7;
-            if (j < MAXWIN) {
-                const float4* cf = reinterpret_cast<const float4*>(coefb + buf * 1024 + gimg[q] * 256 + f4 * 32);
-                const float4 c01 = cf[0], c23 = cf[1];              // a0 b0 a1 b1 | a2 b2 a3 b3
-                float y0 = fmaf(xv[q].x, c01.x, c01.y), y1 = fmaf(xv[q].y, c01.z, c01.w);
-                float y2 = fmaf(xv[q].z, c23.x, c23.y), y3 = fmaf(xv[q].w, c23.z, c23.w);
-                if (p.gn_silu) { y0 = cdae_silu(y0); y1 = cdae_silu(y1); y2 = cdae_silu(y2); y3 = cdae_silu(y3); }
-                asm volatile("" : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3));      // opaque before the split (attention.hip split8)
-                half4 hi, lo;
-                hi[0] = (_Float16)y0; hi[1] = (_Float16)y1; hi[2] = (_Float16)y2; hi[3] = (_Float16)y3;
-                const int off = j * 64 + 16 * ((f4 >> 1) ^ ((j >> 2) & 3)) + 8 * (f4 & 1);
-                *reinterpret_cast<half4*>(awin + off) = hi;
-                if constexpr (NPL == 2) {
-                    lo[0] = (_Float16)(y0 - (float)hi[0]); lo[1] = (_Float16)(y1 - (float)hi[1]);
-                    lo[2] = (_Float16)(y2 - (float)hi[2]); lo[3] = (_Float16)(y3 - (float)hi[3]);
-                    *reinterpret_cast<half4*>(awin + A_PLANE + off) = lo;
-                }
-            }
-        }
-    };
-
-    // ---- A window DMA slots of this wave: piece pc = wave + 8q covers plane pc / NB, rows 16 (pc % NB) .. +15
-    int aoff[A_SLOTS];             // element offset of this lane's 16 bytes at chunk 0, or -1 (outside the tensor)
-#pragma unroll
-    for (int q = 0; q < A_SLOTS; ++q) {
-        const int pc = wave + NW * q, pl = pc >= NB ? 1 : 0, rb = pc - pl * NB;
-        const int j = rb * 16 + (lane >> 2);                             // window row
-        const int pix = pix0 + j;                                        // flattened input pixel (n, y, x)
-        const int c = (lane & 3) ^ ((j >> 2) & 3);
-        aoff[q] = (pix >= 0 && pix < p.M && j < win) ? pix * (int)p.sx + c * 8 : -1;
-    }
-    // ---- B tile pieces: wave w stages the 16-row blocks w, w + NW, ... (hi and lo)
-    long boff[B_RB];
-    bool bok[B_RB];
-#pragma unroll
-    for (int q = 0; q < B_RB; ++q) {
-        const int row = (wave + NW * q) * 16 + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
-        bok[q] = n0 + row < p.N;
-        boff[q] = (long)(bok[q] ? n0 + row : 0) * p.ldb + c * 8;
-    }
-    // LDS-DMA through inline asm (cdae_lds_dma16): with the builtin, hipcc drains the DMAs (vmcnt(0)) in front of the next LDS read that
-    // might alias their destination — i.e. right after they were issued, before the MFMAs they were meant to overlap
-    auto dma = [&](hp src, char* dst_wave_base) {
-        cdae_lds_dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst_wave_base - lds)));
-    };
-    auto issue_A = [&](int chunk) {
-#pragma unroll
-        for (int q = 0; q < A_SLOTS; ++q) {
-            const int pc = wave + NW * q;
-            if (pc < NPL * NB) {                                         // wave-uniform
-                const int pl = pc >= NB ? 1 : 0, rb = pc - pl * NB;
-                const bool ok = aoff[q] >= 0;
-                const long e = (long)aoff[q] + chunk * BK;
-                char* const dst = awin + pl * A_PLANE + rb * 1024;
-                if (pl == 0) dma(a_hi + (ok ? e : za_hi), dst);
-                else dma(a_lo + (ok ? e : za_lo), dst);
-            }
-        }
-    };
-    auto issue_B = [&](int stage, int chunk, int tap) {
-#pragma unroll
-        for (int q = 0; q < B_RB; ++q) {
-            char* const dst = bst + stage * (NPL * B_PLANE) + (wave + NW * q) * 1024;
-            const long e = boff[q] + (long)tap * p.Cin + chunk * BK;
-            dma(b_hi + (bok[q] ? e : zb_hi), dst);
-            if constexpr (NPL == 2) dma(b_lo + (bok[q] ? e : zb_lo), dst + B_PLANE);
-        }
-    };
-
-    // ---- per-lane tap masks of the wave's two 32-row sub-tiles: bit (3 ky + kx) set when tap (ky, kx) reads a real pixel
-    int tapmask[TM], jrow[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int r = wm * WM + i * 32 + l31, m = m0 + r;
-        jrow[i] = r;                                                     // window row of tap (0, 0); tap (ky, kx) adds ky*W + kx
-        const PixRow pr = make_pixrow(p, m);                            // iy0 = y - 1, ix0 = x - 1 (stride 1)
-        int mk = 0;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int ty = pr.iy0 + t / 3, tx = pr.ix0 + t % 3;
-            mk |= (pr.ok && ty >= 0 && ty < p.H && tx >= 0 && tx < W) ? (1 << t) : 0;
-        }
-        tapmask[i] = mk;
-    }
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    auto mma = [&](const u16x8& x, const u16x8& y, const f32x16& c) -> f32x16 {
-        if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, x), __builtin_bit_cast(bf8, y), c, 0, 0, 0);
-        else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, x), __builtin_bit_cast(half8, y), c, 0, 0, 0);
-    };
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-    if (c_begin < c_end) {
-        if constexpr (GNA) {
-            gna_load(c_begin); gna_coef_dma(c_begin, 0); issue_B(0, c_begin, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                                             // coefficients visible
-            gna_stage(0);
-            if (c_begin + 1 < c_end) { gna_load(c_begin + 1); gna_coef_dma(c_begin + 1, 1); }
-        } else {
-            issue_A(c_begin); issue_B(0, c_begin, 0);
-            if constexpr (BST == 3) issue_B(1, c_begin, 1);
-        }
-    }
-    // diagnostic build only (CDAE_PS_DBG & 32): s_memtime stamps around the three segments of a step, summed per wave and
-    // written to the split-K workspace by lane 0 of every wave of the first 64 blocks.  The stamps' lgkmcnt(0) serialises what the
-    // real kernel overlaps: read the SHARES, never the run time of this mode.
-    const bool stamps = (PDBG(p) & 32) != 0;
-    unsigned long long t_wait = 0, t_issue = 0, t_comp = 0, t_prev = 0;
-    auto stamp = [&]() -> unsigned long long {
-        unsigned long long t;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-        return t;
-    };
-    if (stamps) t_prev = stamp();
-    int stage = 0;
-    // ntaps = 9: the 3x3 window; 4: the 2x2 window of one sub-pixel phase (ph_y, ph_x) of an upsample + conv — tap t reads window
-    // position (t / 2 + ph_y, t % 2 + ph_x) of the same 3x3 neighbourhood, so window, masks and row shifts are shared.
-    const int ntaps = p.ps_taps == 4 ? 4 : 9, lasttap = ntaps - 1;
-    for (int chunk = c_begin; chunk < c_end; ++chunk) {
-#pragma unroll 1
-        for (int tap = 0; tap < ntaps; ++tap) {       // not unrolled: nine copies keep every tap's addresses and masks live (197 VGPRs)
-            if constexpr (BST == 2) {
-                // GNA, tap 0: the weight DMAs are older than the next chunk's register prefetch (<= G_SLOTS loads + one coefficient
-                // DMA issued after them), so a counted wait retires the weights and leaves the prefetch in flight
-                if (GNA && tap == 0 && chunk + 1 < c_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GNA ? G_SLOTS : 0) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if constexpr (GNA) {         // raw barrier: __syncthreads() would drain the register prefetch with its own vmcnt(0)
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                } else __syncthreads();
-                if (stamps) { const unsigned long long t = stamp(); t_wait += t - t_prev; t_prev = t; }
-                const int ntap = tap == lasttap ? 0 : tap + 1, nchk = tap == lasttap ? chunk + 1 : chunk;     // stage the next step's weight tile
-                if (nchk < c_end) issue_B(stage ^ 1, nchk, ntap);
-                if (stamps) { const unsigned long long t = stamp(); t_issue += t - t_prev; t_prev = t; }
-            } else {
-                // weights of this step landed when only the next step's NPL pieces may still be in flight; at tap 0 the window
-                // (issued last) must be complete too, and on the very last step nothing younger exists: drain.
-                const bool last = chunk + 1 == c_end && tap == lasttap;
-                if (tap == 0 || last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPL * B_RB) : "memory");
-                __builtin_amdgcn_s_barrier();
-                if (!(PDBG(p) & 64)) {
-                    const int t2 = tap + 2, ntap = t2 >= ntaps ? t2 - ntaps : t2, nchk = t2 >= ntaps ? chunk + 1 : chunk;
-                    if (nchk < c_end) issue_B(stage >= 1 ? stage - 1 : 2, nchk, ntap);            // (stage + 2) % 3
-                }
-            }
-            const int ky = ntaps == 9 ? tap / 3 : (tap >> 1) + p.ph_y, kx = ntaps == 9 ? tap - 3 * ky : (tap & 1) + p.ph_x;
-            const int wtap = ky * 3 + kx, shift = ky * W + kx - (TIGHT ? 1 : 0);          // wtap: position in the 3x3 neighbourhood (mask bit)
-            const char* bc = bst + stage * (NPL * B_PLANE);
-            unsigned amask[TM];
-            int abase[TM];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                amask[i] = (tapmask[i] >> wtap) & 1 ? 0xffffffffu : 0u;
-                int j = jrow[i] + shift;
-                if constexpr (TIGHT) j = min(max(j, 0), win - 1);            // the clamped reads belong to masked taps
-                abase[i] = j * 64 + 16 * (hh ^ ((j >> 2) & 3));           // sk = 0 chunk; sk = 1 flips chunk bit 1 (+-32 bytes)
-            }
-#pragma unroll
-            for (int sk = 0; sk < 2; ++sk) {
-                u16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int a = abase[i] ^ (sk * 32);
-                    u32x4 h4 = *reinterpret_cast<const u32x4*>(awin + a);
-                    h4 &= amask[i];
-                    ah[i] = __builtin_bit_cast(u16x8, h4);
-                    if constexpr (NPL == 2) {
-                        u32x4 l4 = *reinterpret_cast<const u32x4*>(awin + A_PLANE + a);
-                        l4 &= amask[i];
-                        al[i] = __builtin_bit_cast(u16x8, l4);
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int row = wn * WN + j * 32 + l31;
-                    const int b = row * 64 + 16 * ((2 * sk + hh) ^ ((row >> 2) & 3));
-                    bh[j] = *reinterpret_cast<const u16x8*>(bc + b);
-                    if constexpr (NPL == 2) bl[j] = *reinterpret_cast<const u16x8*>(bc + B_PLANE + b);
-                }
-                if (!(PDBG(p) & 128)) __builtin_amdgcn_s_setprio(1);     // MFMA bursts win issue arbitration over other waves' staging work (+1-2 %)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        if constexpr (NPL == 2) {
-                            acc[i][j] = mma(al[i], bh[j], acc[i][j]);
-                            acc[i][j] = mma(ah[i], bl[j], acc[i][j]);
-                        }
-                        acc[i][j] = mma(ah[i], bh[j], acc[i][j]);
-                    }
-                if (!(PDBG(p) & 128)) __builtin_amdgcn_s_setprio(0);
-            }
-            if constexpr (BST == 3) {
-                if (PDBG(p) & 64) {     // late issue: the step's own MFMAs are queued before this wave joins the block's DMA burst
-                    const int t2 = tap + 2, ntap = t2 >= ntaps ? t2 - ntaps : t2, nchk = t2 >= ntaps ? chunk + 1 : chunk;
-                    if (nchk < c_end) issue_B(stage >= 1 ? stage - 1 : 2, nchk, ntap);
-                }
-            }
-            stage = stage + 1 == BST ? 0 : stage + 1;
-            if (stamps) { const unsigned long long t = stamp(); t_comp += t - t_prev; t_prev = t; }
-        }
-        if (chunk + 1 < c_end) {
-            if constexpr (GNA) {
-                __syncthreads();                                         // every wave is done with this chunk's window
-                gna_stage((chunk + 1 - c_begin) & 1);                    // its registers and coefficients landed steps ago
-                if (chunk + 2 < c_end) { gna_load(chunk + 2); gna_coef_dma(chunk + 2, (chunk + 2 - c_begin) & 1); }
-            } else {
-                __builtin_amdgcn_s_barrier();                            // every wave is done with this chunk's window
-                issue_A(chunk + 1);                                      // lands before the vmcnt(0) + barrier of the next step
-            }
-        }
-    }
-
-    if (stamps && blockIdx.x < 64 && lane == 0 && p.splitk_ws && p.ksplit == 1) {
-        unsigned long long* o = reinterpret_cast<unsigned long long*>(p.splitk_ws) + (blockIdx.x * NW + wave) * 4;
-        o[0] = t_wait; o[1] = t_issue; o[2] = t_comp; o[3] = stamp() - t_prev;
-    }
-    // ---------------------------------------------------------------- epilogue (row-major result)
-    float* __restrict__ Cg;
-    const float* __restrict__ Rg = nullptr;
-    if (p.ksplit > 1) Cg = p.splitk_ws + (long)ks * (long)p.M * p.N;
-    else { Cg = p.C; Rg = p.res; }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * WN + j * 32 + l31;
-            if (col >= p.N) continue;
-            const float bv = (p.ksplit == 1 && p.bias) ? p.bias[col] : 0.f;
-            float gs = 0.f, gq = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (row >= p.M) continue;
-                if (p.ksplit > 1) { Cg[(long)row * p.N + col] = acc[i][j][r]; continue; }
-                long addr;
-                if (p.out_mode == OUT_UP2) {
-                    const int x = row - fdiv(row, p.wo_magic, p.wo_shift) * p.Wo;          // (n, y, x) -> (n, 2y + ph_y, 2x + ph_x)
-                    addr = (4L * row - 2 * x + p.ph_y * 2 * p.Wo + p.ph_x) * p.ldc + col;
-                } else addr = (long)row * p.ldc + col;
-                float v = acc[i][j][r] * p.alpha + bv;
-                if (Rg) v += Rg[addr];
-                if (p.act == ACT_SILU) v = cdae_silu(v);
-                else if (p.act == ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
-                if (p.accumulate) v += Cg[addr];
-                Cg[addr] = v;
-                if (!__builtin_isfinite(v) && p.range_flag) *p.range_flag = 1;
-                if (p.C_hi) store_planes(p, addr, v);
-                gs += v; gq += v * v;
-            }
-            if (p.gn_part && p.ksplit == 1) {
-                gs += __shfl_xor(gs, 32); gq += __shfl_xor(gq, 32);
-                if (hh == 0) {
-                    float* o = p.gn_part + ((long)((m0 + wm * WM + i * 32) >> 5) * p.N + col) * 2;
-                    o[0] = gs; o[1] = gq;
-                }
-            }
-        }
-}
-
-template <int BN, int NPL, int BST, int MAXWIN, int WAVES_N = 4, bool GNA = false, int BM = 128, bool TIGHT = (BM == 256), int BLOCKS = 2, bool BF = false, int WM_ = 64>
-int launch_pswin(const GemmParams& p, hipStream_t st) {
-    constexpr size_t smem = (size_t)NPL * MAXWIN * 64 + (size_t)BST * NPL * BN * 64 + (GNA ? 2048 : 0);
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N, GNA, BM, TIGHT, BLOCKS, BF, WM_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-            return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
-        attr_done = true;
-    }
-    dim3 grid((unsigned)((long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.ksplit));
-    static const size_t pad = getenv("CDAE_PS_PAD_LDS") ? (size_t)atoi(getenv("CDAE_PS_PAD_LDS")) : 0;       // dev: force fewer blocks per CU
-    if (pad) hipFuncSetAttribute(reinterpret_cast<const void*>(&pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N, GNA, BM, TIGHT, BLOCKS, BF, WM_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem + pad));
-    hipLaunchKernelGGL((pswin_kernel<BN, NPL, BST, MAXWIN, WAVES_N, GNA, BM, TIGHT, BLOCKS, BF, WM_>), grid, dim3(BM / WM_ * WAVES_N * 64), smem + pad, st, p);
-    return hipGetLastError() == hipSuccess ? 0 : cdae_fail("pswin_kernel launch failed");
-}
-
 // split-K finish: C = alpha * sum_s slab[s] + bias (+res) (-> act), deterministic order
 __global__ void splitk_reduce_kernel(const GemmParams p) {
     long total = (long)p.batch * p.M * p.N;
@@ -1470,7 +728,7 @@ int launch(const GemmParams& p, hipStream_t st) {
     size_t smem = tiles;
     if constexpr (GNS) {
         // a 128-row tile touches at most two images when an image has >= 64 rows... in general ceil(128 / hw) + 1: table only for hw >= 128 or hw == 64
-        static const int cfg_tab = getenv("CDAE_GNS_TAB") ? atoi(getenv("CDAE_GNS_TAB")) : 1;
+        static const int cfg_tab = CDAE_DEV_INT("CDAE_GNS_TAB", 1);
         const bool two = p.hw >= BM || (p.hw * 2 == BM);
         q.gn_tab = cfg_tab && two && (size_t)16 * p.K <= tab_max && p.K % 4 == 0 && p.ksplit == 1 && p.batch == 1;
         if (q.gn_tab) smem += (size_t)16 * p.K;
@@ -1486,7 +744,7 @@ int launch_tiles(const GemmParams& p, int big, bool scalar, hipStream_t st) {
     if constexpr (AMODE == A_CONV_GEN) return cdae_fail("A_CONV_GEN is a scalar-only loader");
     else {
         if constexpr (AMODE == A_PLAIN_KC && BMODE == B_PLAIN_KC) {
-            static const int cfg_deep = getenv("CDAE_IGEMM_DEEP") ? atoi(getenv("CDAE_IGEMM_DEEP")) : 15;      // bit 0 plain fwd GEMM, 1 the GroupNorm-carrying skip GEMM, 2 linear dgrad / wgrad, 3 the same two on 64x64 tiles (2048x512x512: 19.7 -> 16.5 us)
+            static const int cfg_deep = CDAE_DEV_INT("CDAE_IGEMM_DEEP", 15);      // bit 0 plain fwd GEMM, 1 the GroupNorm-carrying skip GEMM, 2 linear dgrad / wgrad, 3 the same two on 64x64 tiles (2048x512x512: 19.7 -> 16.5 us)
             if (p.S_hi) {
                 if (p.prec != 1 || !big) return cdae_fail("GroupNorm side output: f16x3 mode and a grid of 128x128 tiles required");
                 return (cfg_deep & 2) ? launch<128, 128, AMODE, BMODE, false, 4, 1, true, true>(p, st) : launch<128, 128, AMODE, BMODE, false, 4, 1, true>(p, st);
@@ -1495,7 +753,7 @@ int launch_tiles(const GemmParams& p, int big, bool scalar, hipStream_t st) {
             if (p.prec == 1 && !big && (cfg_deep & 8)) return launch<64, 64, AMODE, BMODE, false, 2, 1, false, true>(p, st);
         }
         if constexpr ((AMODE == A_PLAIN_KC || AMODE == A_PLAIN_MC) && BMODE == B_PLAIN_MC) {     // linear / 1x1 dgrad and wgrad: the same latency-bound shape
-            static const int cfg_deep2 = getenv("CDAE_IGEMM_DEEP") ? atoi(getenv("CDAE_IGEMM_DEEP")) : 15;
+            static const int cfg_deep2 = CDAE_DEV_INT("CDAE_IGEMM_DEEP", 15);
             if (p.prec == 2 && big && (cfg_deep2 & 4)) return launch<128, 128, AMODE, BMODE, false, 4, 2, false, true>(p, st);
             if (p.prec == 2 && !big && (cfg_deep2 & 8)) return launch<64, 64, AMODE, BMODE, false, 2, 2, false, true>(p, st);
         }
@@ -1550,15 +808,16 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
     }
     if (p.force_tile == 64) big = 0;
     if (p.force_tile == 128) big = 1;
-    static const bool cfg_dev = getenv("CDAE_GEMM_DEV") != nullptr;          // dev sweeps (tools/gemm_sweep.py): tile and split from the environment, per call
-    if (cfg_dev && !p.presplit) {
+#if CW_DEV
+    if (getenv("CDAE_GEMM_DEV") && !p.presplit) {          // dev sweeps (tools/gemm_sweep.py): tile and split from the environment, per call
         const char* e = getenv("CDAE_TILE_FORCE");
         if (e && atoi(e) == 64) big = 0;
         if (e && atoi(e) == 128 && p.M >= 96 && p.N >= 96) big = 1;
         e = getenv("CDAE_KS_FORCE");
         if (e && atoi(e) > 0 && p.ksplit_auto && p.splitk_ws) p.ksplit_force = atoi(e);
     }
-    static const int cfg_waves8 = getenv("CDAE_IGEMM_WAVES8") ? atoi(getenv("CDAE_IGEMM_WAVES8")) : 1;   // 8-wave 128x128 tiles by default
+#endif
+    static const int cfg_waves8 = CDAE_DEV_INT("CDAE_IGEMM_WAVES8", 1);   // 8-wave 128x128 tiles by default
     p.waves8 = cfg_waves8;
     // precision: fp32 mode -> fp32 MFMA everywhere; split mode -> f16x3 for activation x weight GEMMs, bf16x3 when an
     // operand is a gradient (api.hip marks those with grad_operand)
@@ -1568,16 +827,6 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
     }
     if (p.A2 && !p.gn_coef && (p.amode != A_PLAIN_KC || p.a_scalar || p.K1 % BK || p.batch != 1)) return cdae_fail("two-source A: vectorised A_PLAIN_KC only, K1 % 32 == 0");
     p.range_flag = cdae_range_flag_ptr();
-    if (p.presplit) {
-        static const int cfg_dbg = getenv("CDAE_PS_DBG") ? atoi(getenv("CDAE_PS_DBG")) : 0;
-        p.dbg = cfg_dbg;
-        if (!((p.amode == A_CONV_VEC || p.amode == A_PLAIN_KC) && p.bmode == B_PLAIN_KC) || p.batch != 1)
-            return cdae_fail("pre-split operands: only K-contiguous conv / plain GEMMs without batch");
-        const int kin = p.amode == A_CONV_VEC ? p.Cin : p.K;
-        if (kin % BK || p.K % BK || p.ldb % 8 || (p.amode == A_PLAIN_KC && p.lda % 8) || (p.prec != 1 && p.prec != 2 && p.prec != 3))
-            return cdae_fail("pre-split operands: need K (Cin) % 32 == 0, 16-byte aligned rows and a 16-bit split precision mode");
-        if (p.prec == 2 && (p.gn_coef || p.ps_taps == 4)) return cdae_fail("pre-split bf16 planes: plain conv3x3 / GEMM only");
-    }
     if (p.amode == A_PLAIN_MC && p.M % 4) p.a_scalar = 1;          // vector k-major loaders read 4 rows / columns at once
     if (p.bmode != B_PLAIN_KC && p.N % 4) p.b_scalar = 1;
     const bool scalar = p.a_scalar || p.b_scalar || p.amode == A_CONV_GEN;
@@ -1589,15 +838,15 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
     const long tiles = big ? tiles_big : tiles_small;
     const int nk = (p.K + BK - 1) / BK;
     int ks = 1;
-    static const int cfg_mintiles = getenv("CDAE_KS_MINTILES") ? atoi(getenv("CDAE_KS_MINTILES")) : 256;
-    static const int cfg_minnk = getenv("CDAE_KS_MINNK") ? atoi(getenv("CDAE_KS_MINNK")) : 8;
+    static const int cfg_mintiles = CDAE_DEV_INT("CDAE_KS_MINTILES", 256);
+    static const int cfg_minnk = CDAE_DEV_INT("CDAE_KS_MINNK", 8);
     if (p.ksplit_auto && p.splitk_ws && tiles < cfg_mintiles && nk >= cfg_minnk) {
         ks = (int)((512 + tiles - 1) / tiles);
         if (ks > nk / 4) ks = nk / 4;
         if (ks > 128) ks = 128;             // (a 128 x 128 weight gradient over 131072 pixels: 64 splits 77 us, 128 splits 60 us)
         // 128 x 128 tiles run two blocks per CU (512 slots): 96 tiles x 6 splits = 576 blocks need a second, nearly empty round where
         // x 5 = 480 do not.  Smallest rounds x (K-steps per split + ~8 steps of prologue / epilogue) + finish; CDAE_KS_ROUNDS=0: plain ceil
-        static const int cfg_rounds = getenv("CDAE_KS_ROUNDS") ? atoi(getenv("CDAE_KS_ROUNDS")) : 1;
+        static const int cfg_rounds = CDAE_DEV_INT("CDAE_KS_ROUNDS", 1);
         if (cfg_rounds && big && ks > 1) {
             long best_cost = -1; int best = 1;
             for (int k = 1; k <= ks; ++k) {
@@ -1629,88 +878,8 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
     int rc = -1;
 #define CASE(AM, BM_) if (p.amode == AM && p.bmode == BM_) rc = launch_tiles<AM, BM_>(p, big, scalar, st)
     if (p.presplit) {
-        static const int cfg_tile = getenv("CDAE_PS_TILE") ? atoi(getenv("CDAE_PS_TILE")) : 128;   // 256: measured 6 % slower end to end (1 block per CU)
-        const long tiles_256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
-        const bool huge = cfg_tile == 256 && big && tiles_256 * ks >= 200;            // 256x128 tiles, 1 block / CU, 3-stage DMA ring
-        static const int cfg_win = getenv("CDAE_PS_WIN") ? atoi(getenv("CDAE_PS_WIN")) : 1;
-        static const int cfg_subpix = getenv("CDAE_PS_WIN_SUBPIX") ? atoi(getenv("CDAE_PS_WIN_SUBPIX")) : 1;      // sub-pixel phases on the window kernel
-        // cdae_tune_set(CDAE_TUNE_CONVWIN_MIN_TILES, <= 1): every shape convwin_kernel can take runs on it, whatever the grid size (the
-        // parity tests push the small golden cases through the kernel the benchmark shapes dispatch)
-        if (cdae_tune(TUNE_CONVWIN_MIN_TILES) <= 1 && p.amode == A_CONV_VEC && p.stride == 1 && !p.up && cdae_convwin_ok(p)) big = 1;
-        // window-resident form: stride-1 3x3 convs on a dense NHWC tensor, rows up to 64 pixels, row-major result
-        const bool win_ok = cfg_win && p.amode == A_CONV_VEC && p.stride == 1 && !p.up && p.W <= 64 && big &&
-                            p.sy == (long)p.W * p.sx && p.sn == (long)p.H * p.W * p.sx &&
-                            (p.ps_taps == 4 ? p.out_mode == OUT_UP2 && !p.gn_coef && cfg_subpix : p.out_mode == OUT_ROWMAJOR);
-        if (p.a_gm && (!win_ok || p.gn_coef)) { cdae_prof_end(PROF_IGEMM, st); return 3; }
-        if (p.nphase > 1 && (!win_ok || p.gn_coef)) { cdae_prof_end(PROF_IGEMM, st); return 2; }      // (only convwin_kernel walks the four phases itself)
-        if (p.gn_coef && (!win_ok || (p.A2 && p.K1 % BK))) return cdae_fail("fused GroupNorm prologue: only on the window-resident conv path");
-        if (win_ok && p.gn_coef) {
-            const int nchunk = p.Cin / BK;
-            if (p.ksplit > nchunk) p.ksplit = nchunk;
-            ks = p.ksplit;
-            rc = p.prec == 1 ? launch_pswin<128, 2, 2, 272, 4, true>(p, st) : launch_pswin<128, 1, 2, 272, 4, true>(p, st);
-        } else
-        if (win_ok) {
-            const int nchunk = p.Cin / BK;
-            if (p.ksplit > nchunk) p.ksplit = nchunk;              // K is split by whole channel chunks here
-            ks = p.ksplit;
-            const bool deep = p.W <= 32 && cfg_win == 3;           // CDAE_PS_WIN=3: 3-stage weight ring where it fits (measured: no gain over 2 stages)
-            static const int cfg_bm = getenv("CDAE_PS_WIN_BM") ? atoi(getenv("CDAE_PS_WIN_BM")) : 256;
-            // 256-row tiles: rows must divide the tile (tight window) and the larger grid must still fill two blocks per CU
-            const bool tall2 = cfg_bm == 256 && 256 % p.W == 0 && (long)((p.M + 255) / 256) * ((p.N + 127) / 128) * ks >= 512;
-            const bool tall = tall2 && p.prec == 1;
-            static const int cfg_wm = getenv("CDAE_PS_WIN_WM") ? atoi(getenv("CDAE_PS_WIN_WM")) : 64;
-            // rows of 16 or 8 pixels: the tight window is 160 rows, 52.5 KB with the two weight stages: THREE blocks (24 waves) per CU
-            static const int cfg_b3 = getenv("CDAE_PS_WIN_B3") ? atoi(getenv("CDAE_PS_WIN_B3")) : 0;     // measured: +2 % at 16x16, -8 % at 8x8 -> off
-            const bool small_rows = cfg_b3 && p.prec == 1 && p.W <= 16 && 128 % p.W == 0 && cfg_win == 1;
-            // second-generation window kernel (convwin.hip): 4 waves of 128 x 64, 16x16x32 MFMA, staggered half-window reloads
-            static const int cfg_cw = getenv("CDAE_CONVWIN") ? atoi(getenv("CDAE_CONVWIN")) : 1;
-            const int cfg_cw_min = cdae_tune(TUNE_CONVWIN_MIN_TILES);
-            const int cfg_cw_ks = cdae_tune(TUNE_CONVWIN_SPLITK);
-            const long cw_tiles = (long)((p.M + 255) / 256) * ((p.N + 127) / 128) * (p.nphase > 1 ? p.nphase : 1);
-            bool cw = cfg_cw && cdae_convwin_ok(p);
-            if (cw) {
-                // fewer 256 x 128 tiles than block slots (two per CU): split K by whole 32-channel chunks (the low-resolution levels, and
-                // everything below 64 x 64 at training batch sizes).  floor, not ceil: 96 tiles x 6 = 576 would need a second, nearly
-                // empty round of blocks; x 5 = 480 runs in one
-                int kbest = ks;
-                if (cw_tiles * ks < 512 && cfg_cw_ks && p.ksplit_auto && p.splitk_ws && !p.gn_part) {
-                    int k2 = (int)(512 / cw_tiles);
-                    static const int cfg_minchunk = getenv("CDAE_CONVWIN_MINCHUNK") ? atoi(getenv("CDAE_CONVWIN_MINCHUNK")) : 3;
-                    if (k2 > nchunk / cfg_minchunk) k2 = nchunk / cfg_minchunk;          // at least three chunks = 27 K-steps per split (1 / 2 / 3 / 4 / unsplit: 30.37 / 30.26 / 30.14 / 30.25 / 30.62 ms per C64 training step)
-                    while (k2 > 1 && (size_t)k2 * p.M * p.N * sizeof(float) > p.splitk_ws_bytes) --k2;
-                    if (k2 > 1) { const int c_per = (nchunk + k2 - 1) / k2; k2 = (nchunk + c_per - 1) / c_per; }      // 12 chunks over 5 splits are 3 + 3 + 3 + 3 + 0: no empty slabs
-                    if (k2 > 1) kbest = k2;
-                }
-                if (cw_tiles * kbest >= cfg_cw_min) p.ksplit = ks = kbest;
-                else cw = false;
-            }
-            if (p.a_gm && !cw) { cdae_prof_end(PROF_IGEMM, st); return 3; }                      // group-major planes: only convwin_kernel reads them (the caller converts)
-            if (p.nphase > 1 && (!cw || ks > 1)) { cdae_prof_end(PROF_IGEMM, st); return 2; }      // fused phases only on the window kernel: the caller launches them one by one
-            if (cw) {
-                // algorithmic bytes: both activation planes, both weight planes, the fp32 result (+ the residual read)
-                const double nph = p.nphase > 1 ? p.nphase : 1;      // (the phases of an up-conv share the input planes)
-                cdae_prof_note(p.ps_taps == 4 ? PROF_CONVWIN_UP : p.prec == 2 ? PROF_CONVWIN_DGRAD : PROF_CONVWIN, 4.0 * p.M * p.Cin + nph * (4.0 * p.K * p.N + 4.0 * p.M * p.N * (p.res ? 2 : 1)));
-                rc = cdae_convwin_launch(p, st);
-            }
-            else
-            if (p.prec == 2) rc = tall2 ? launch_pswin<128, 2, 2, 384, 2, false, 256, true, 2, true>(p, st) : launch_pswin<128, 2, 2, 272, 4, false, 128, false, 2, true>(p, st);
-            else if (tall && cfg_wm == 128) rc = launch_pswin<128, 2, 2, 384, 2, false, 256, true, 2, false, 128>(p, st);      // 4 waves of 128 x 64
-            else if (tall) rc = launch_pswin<128, 2, 2, 384, 2, false, 256>(p, st);
-            else if (small_rows) rc = launch_pswin<128, 2, 2, 160, 4, false, 128, true, 3>(p, st);
-            else
-            if (p.prec == 1 && cfg_win == 4) rc = launch_pswin<128, 2, 2, 272, 2>(p, st);       // CDAE_PS_WIN=4: 4 waves of 64x64 per block
-            else if (p.prec == 1) rc = deep ? launch_pswin<128, 2, 3, 208>(p, st) : launch_pswin<128, 2, 2, 272>(p, st);
-            else rc = deep ? launch_pswin<128, 1, 3, 208>(p, st) : launch_pswin<128, 1, 2, 272>(p, st);
-        }
-        static const int cfg_loaders = getenv("CDAE_PS_LOADERS") ? atoi(getenv("CDAE_PS_LOADERS")) : 0;
-        if (win_ok) {}
-        else if (p.prec == 2) rc = big ? launch_ps<128, 128, 2, 4, 2, 2, 0, true>(p, st) : launch_ps<64, 64, 2, 2, 2, 2, 0, true>(p, st);
-        else
-        if (p.prec == 1 && big && !huge && cfg_loaders == 4) rc = launch_ps<128, 128, 2, 4, 2, 2, 4>(p, st);
-        else if (p.prec == 1 && big && !huge && cfg_loaders == 2) rc = launch_ps<128, 128, 2, 4, 2, 2, 2>(p, st);
-        else if (p.prec == 1) rc = huge ? launch_ps<256, 128, 4, 2, 2, 3>(p, st) : big ? launch_ps<128, 128, 2, 4, 2, 2>(p, st) : launch_ps<64, 64, 2, 2, 2, 2>(p, st);
-        else rc = huge ? launch_ps<256, 128, 4, 2, 1, 3>(p, st) : big ? launch_ps<128, 128, 2, 4, 1, 2>(p, st) : launch_ps<64, 64, 2, 2, 1, 2>(p, st);
+        rc = cdae_planes_dispatch(p, big, ks, st);          // planes.hip: convwin / pswin / ps kernels
+        if (rc == 2 || rc == 3) { cdae_prof_end(PROF_IGEMM, st); return rc; }
     }
     else CASE(A_PLAIN_KC, B_PLAIN_KC);
     else CASE(A_CONV_VEC, B_PLAIN_KC);
@@ -1724,7 +893,7 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
 #undef CASE
     if (rc == 0 && ks > 1) {
         long total = (long)p.batch * p.M * p.N;
-        static const int cfg_red4 = getenv("CDAE_SPLITK_REDUCE4") ? atoi(getenv("CDAE_SPLITK_REDUCE4")) : 1;
+        static const int cfg_red4 = CDAE_DEV_INT("CDAE_SPLITK_REDUCE4", 1);
         auto al16 = [](const void* q) { return (reinterpret_cast<size_t>(q) & 15) == 0; };
         const bool vec4 = cfg_red4 && p.batch == 1 && p.out_mode == OUT_ROWMAJOR && p.N % 4 == 0 && p.ldc % 4 == 0 && al16(p.C) && al16(p.res) && al16(p.bias) &&
                           al16(p.splitk_ws) && ((long)p.M * p.N) % 4 == 0;

@@ -865,7 +865,7 @@ int gn_chunks(int HW, int N, int E) {
     int rows = 256 / E;
     int nchunk = HW / (rows * 8);              // >= 8 pixels per thread
     if (nchunk < 1) nchunk = 1;
-    static const int cfg_cap = getenv("CDAE_GN_CHUNK_CAP") ? atoi(getenv("CDAE_GN_CHUNK_CAP")) : 1024;      // blocks per launch: 2048 / 1024 / 512 -> 30.0 / 29.7 / 29.8 ms per C64 training step (short blocks are all epilogue)
+    static const int cfg_cap = CDAE_DEV_INT("CDAE_GN_CHUNK_CAP", 1024);      // blocks per launch: 2048 / 1024 / 512 -> 30.0 / 29.7 / 29.8 ms per C64 training step (short blocks are all epilogue)
     while (nchunk > 1 && (long)nchunk * N > cfg_cap) nchunk >>= 1;
     if (nchunk > CDAE_GN_MAX_CHUNKS) nchunk = CDAE_GN_MAX_CHUNKS;
     return nchunk;
@@ -983,11 +983,11 @@ static int gn_bwd_impl(const float* x, const float* x2, int ld2, int C1, const f
     if (VEC == 4) hipLaunchKernelGGL(gn_bwd_partial_kernel<4>, dim3(nchunk, N), dim3(256), 0, st, x, dy, HW, C, ldx, lddy, cpg, groups, ppb, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gpart, cpart, x2, ld2, C1);
     else hipLaunchKernelGGL(gn_bwd_partial_kernel<1>, dim3(nchunk, N), dim3(256), 0, st, x, dy, HW, C, ldx, lddy, cpg, groups, ppb, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gpart, cpart, x2, ld2, C1);
     hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3((C + 63) / 64 + 1, N), dim3(256), 0, st, N, HW, C, cpg, groups, nchunk, gpart, cpart, gsum, d_scale_shift, ld_dss, ncp);
-    static const int cfg_dxs = getenv("CDAE_GN_BWD_STREAM") ? atoi(getenv("CDAE_GN_BWD_STREAM")) : 1;
+    static const int cfg_dxs = CDAE_DEV_INT("CDAE_GN_BWD_STREAM", 1);
     const bool dx_stream = VEC == 4 && cfg_dxs && E <= 256 && (!accumulate_dx || dx);
     // pass 2b (dgamma / dbeta over the batch) rides along as one extra row of blocks of the streaming dx launch (it only needs pass 2a's
     // per-image sums, like dx): one launch less per GroupNorm, 56 per C64 training step; CDAE_GN_BWD_PARAM_ROW=0: its own launch
-    static const int cfg_prow = getenv("CDAE_GN_BWD_PARAM_ROW") ? atoi(getenv("CDAE_GN_BWD_PARAM_ROW")) : 1;
+    static const int cfg_prow = CDAE_DEV_INT("CDAE_GN_BWD_PARAM_ROW", 1);
     const bool param_row = dx_stream && cfg_prow && N >= 8;
     if (param_row) {}
     else if (N >= 8) hipLaunchKernelGGL(gn_bwd_param8_kernel, dim3((C + 31) / 32), dim3(256), 0, st, N, C, ncp, dgamma, dbeta, accumulate_params);
@@ -1054,7 +1054,7 @@ int cdae_gn_stats_from_parts(const float* part1, int C1, int nseg1, const float*
     cdae_prof_begin(PROF_GN, (double)N * (HW / 32) * C * 8.0, st);
     if (cdae_prof_on()) { char tag[96]; snprintf(tag, sizeof(tag), "cdae_gn_stats_from_parts N=%d HW=%d C=%d", (int)N, (int)HW, (int)C); cdae_prof_tag(tag); }
     const int cpg = C / groups;
-    static const int cfg_fused = getenv("CDAE_GN_PARTS_FUSED") ? atoi(getenv("CDAE_GN_PARTS_FUSED")) : 1;
+    static const int cfg_fused = CDAE_DEV_INT("CDAE_GN_PARTS_FUSED", 1);
     if (cfg_fused && cpg <= 32) {
         const int gpb = 32 / cpg;
         hipLaunchKernelGGL(gn_parts_stats_kernel, dim3((groups + gpb - 1) / gpb, N), dim3(256), 0, st, part1, C1, nseg1, part2, C2, part2 ? nseg2 : 1, N, HW,
@@ -1134,7 +1134,7 @@ static int gn_apply_split_impl(const float* x, int ldx, const float* x2, int ld2
     const int ppb = (HW + nchunk - 1) / nchunk;
     cdae_prof_begin(PROF_GN, (double)N * HW * C * 8.0, st);
     if (cdae_prof_on()) { char tag[96]; snprintf(tag, sizeof(tag), "gn_apply_split_impl N=%d HW=%d C=%d", (int)N, (int)HW, (int)C); cdae_prof_tag(tag); }
-    static const int cfg_gmk = getenv("CDAE_GN_APPLY_GM") ? atoi(getenv("CDAE_GN_APPLY_GM")) : 1;      // 0: group-major planes from the channel-vector kernel
+    static const int cfg_gmk = CDAE_DEV_INT("CDAE_GN_APPLY_GM", 1);      // 0: group-major planes from the channel-vector kernel
     if (plane_gm && cfg_gmk && !yb_hi && (!x2 || C1 % 16 == 0) && N <= 65535) {
         const int gpb = (C % 32 == 0 && (!x2 || C1 % 32 == 0)) ? 2 : 1;
         int nch = HW / (gpb == 2 ? 128 : 256);       // >= 4 pixels per thread

@@ -1,0 +1,594 @@
+// planes.hip — the first-generation contraction kernels on operands that are ALREADY split into 16-bit planes in HBM (f16 hi / lo for
+// activation x weight products, bf16 hi / lo where an operand is a gradient, one plane in the mixed16 mode), gfx950 only:
+//   ps_kernel     plain GEMMs and conv gathers (stride 2, 2x2 sub-pixel phases, small grids), every 16-byte piece global -> LDS by LDS-DMA
+//   pswin_kernel  stride-1 conv3x3 with the activation window resident in LDS (128- or 256-row tiles)
+// and the dispatch between them and convwin_kernel (convwin.hip, the second-generation window kernel that takes the large grids).
+// Reference ops: the convolutions / 1x1 GEMMs of improved_diffusion/unet.py:143-162, 185-198, 213-231 (plain fp32 ATen there).
+#include "gemm_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// ps_kernel: the same f16x3 product on operands that are ALREADY split into f16 planes in HBM (activations by the
+// producing GroupNorm kernel, weights once per weight version).  The main loop then has no conversion VALU and no
+// register staging: every 16-byte piece of a tile goes global -> LDS by LDS-DMA (global_load_lds_dwordx4), the planes
+// keep the [rows][64 B] image of the in-kernel-split path (16-B chunks XOR-swizzled by (row>>2)&3 — applied on the
+// per-lane SOURCE address, the LDS destination of a DMA is lane-linear), and the fragment reads / MFMAs are unchanged.
+// One barrier per 32-deep step: wait own DMAs -> barrier -> issue the next stage's DMAs -> 12 MFMAs per wave.
+// The conv gather's per-row tap offsets (9 per output pixel, -1 = padding) are computed once into an LDS table.
+static __device__ __attribute__((aligned(16))) unsigned g_zero_ps[4] = {0u, 0u, 0u, 0u};
+
+// (Dedicated loader waves, a 256 x 128 tile with a 3-stage DMA ring: built in round 1, measured slower, removed — docs/NOTES.md.)
+// BF: the planes hold bf16 (gradient operands: full fp32 range, 16 significand bits over the two planes) instead of f16.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NPL, bool BF = false>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void ps_kernel(const GemmParams p) {
+    constexpr int THREADS = 64 * WAVES_M * WAVES_N, LT = THREADS, STAGES = 2;
+    constexpr int RPP = LT / 4;                                        // tile rows covered by one DMA pass
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
+    constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;                // bytes per 16-bit plane
+    constexpr int STAGE = NPL * (A_PLANE + B_PLANE);
+    constexpr int A_P = BM / RPP, B_P = BN / RPP;                      // 16-byte pieces per thread per plane
+    static_assert(A_P >= 1 && B_P >= 1, "tile smaller than one DMA pass");
+    typedef const unsigned short* hp;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const lds = reinterpret_cast<char*>(smem);
+    int* const taptab = reinterpret_cast<int*>(lds + STAGES * STAGE);  // [taps][BM] element offsets, -1 = zero row
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int ltid = tid, lwave = wave;
+
+    const int nmt = (p.M + BM - 1) / BM, nnt = (p.N + BN - 1) / BN;
+    int mt, nt, ks;
+    {
+        const unsigned G = gridDim.x, b = blockIdx.x;
+        const unsigned q = G >> 3, r = G & 7, x = b & 7;
+        unsigned v = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+        nt = v % nnt; v /= nnt;
+        mt = v % nmt; ks = v / nmt;
+    }
+    const int m0 = mt * BM, n0 = nt * BN;
+    const hp a_hi = reinterpret_cast<hp>(p.A), a_lo = p.A_lo;
+    const hp b_hi = reinterpret_cast<hp>(p.B), b_lo = p.B_lo;
+    // padding rows read a zero page.  The select is done on the element OFFSET (zero page expressed relative to each plane):
+    // selecting between two pointers makes hipcc branch around two different load forms.
+    const hp zero = reinterpret_cast<hp>(g_zero_ps);
+    const long za_hi = zero - a_hi, za_lo = NPL == 2 ? zero - a_lo : 0, zb_hi = zero - b_hi, zb_lo = NPL == 2 ? zero - b_lo : 0;
+
+    const int taps = p.amode == A_CONV_VEC ? (p.ps_taps == 4 ? 4 : 9) : 1;
+    const int cpt = (taps == 1 ? p.K : p.Cin) / BK;                    // 32-deep steps per tap
+    const int nk_total = taps * cpt;
+    const int nk_per = (nk_total + p.ksplit - 1) / p.ksplit;
+    const int kt_begin = ks * nk_per;
+    const int kt_end = min(nk_total, kt_begin + nk_per);
+
+    for (int idx = tid; idx < taps * BM; idx += THREADS) {
+        const int tap = idx / BM, row = idx - tap * BM, m = m0 + row;
+        int off = -1;
+        if (taps == 1) { if (m < p.M) off = m * (int)p.lda; }
+        else {
+            const PixRow r = make_pixrow(p, m);
+            long o;
+            // 9 taps: the 3x3 window; 4 taps: the 2x2 window of one sub-pixel phase, shifted by (ph_y, ph_x)
+            const int ky = taps == 9 ? tap / 3 : (tap >> 1) + p.ph_y, kx = taps == 9 ? tap - 3 * (tap / 3) : (tap & 1) + p.ph_x;
+            const bool ok = tap_offset(p, r, ky, kx, o);
+            if (ok && r.ok) off = (int)o;
+        }
+        if ((PDBG(p) & 1) && off >= 0) off = (row & 15) * 64;
+        taptab[idx] = off;
+    }
+
+    // B rows are loop invariant: per piece a running pointer (or the zero page for rows >= N)
+    long boff[B_P];                // element offset of this thread's piece in the weight planes
+    bool bok[B_P];
+#pragma unroll
+    for (int q = 0; q < B_P; ++q) {
+        const int row = ((ltid >> 2) + RPP * q) & (BN - 1), c = (ltid & 3) ^ ((row >> 2) & 3);
+        bok[q] = n0 + row < p.N;
+        boff[q] = (long)(bok[q] ? n0 + row : 0) * p.ldb + (long)kt_begin * BK + c * 8;
+    }
+    int acol[A_P];                 // this thread's 16-byte chunk inside the 32-deep k slice, in elements
+    int arow[A_P];
+#pragma unroll
+    for (int q = 0; q < A_P; ++q) { arow[q] = ((ltid >> 2) + RPP * q) & (BM - 1); acol[q] = 8 * ((ltid & 3) ^ ((arow[q] >> 2) & 3)); }
+
+    // LDS-DMA through inline asm (cdae_lds_dma16): with the builtin, hipcc drains the DMAs (vmcnt(0)) in front of the next LDS read that
+    // might alias their destination — i.e. right after they were issued, before the MFMAs they were meant to overlap
+    auto dma = [&](hp src, char* dst_wave_base) {
+        cdae_lds_dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst_wave_base - lds)));
+    };
+    // issue the DMAs of one 32-deep step (tap, channel offset kc) into `stage`; B pointers advance by one step
+    auto issue = [&](int stage, int tap, int kc) {
+        char* const sa = lds + stage * STAGE;
+        char* const sb = sa + NPL * A_PLANE;
+#pragma unroll
+        for (int q = 0; q < A_P; ++q) {
+            const int off = taptab[tap * BM + arow[q]];
+            const long e = (long)off + kc + acol[q];
+            const bool ok = off >= 0;
+            char* const dst = sa + (q * LT + lwave * 64) * 16;
+            dma(a_hi + (ok ? e : za_hi), dst);
+            if constexpr (NPL == 2) dma(a_lo + (ok ? e : za_lo), dst + A_PLANE);
+        }
+#pragma unroll
+        for (int q = 0; q < B_P; ++q) {
+            char* const dst = sb + (q * LT + lwave * 64) * 16;
+            dma(b_hi + (bok[q] ? boff[q] : zb_hi), dst);
+            if constexpr (NPL == 2) dma(b_lo + (bok[q] ? boff[q] : zb_lo), dst + B_PLANE);
+            boff[q] += (PDBG(p) & 2) ? 0 : BK;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int tap = kt_begin / cpt, chunk = kt_begin - tap * cpt;            // position of the NEXT step to issue
+    auto advance = [&]() { ++chunk; const bool wrap = chunk == cpt; chunk = wrap ? 0 : chunk; tap += wrap ? 1 : 0; };
+
+    __syncthreads();                                                   // tap table visible
+    const bool nodma = (PDBG(p) & 4) != 0;
+    auto issue_next = [&](int stage) { issue(stage, (PDBG(p) & 1) ? 0 : tap, (PDBG(p) & 1) ? 0 : chunk * BK); advance(); };
+    if (kt_begin < kt_end) issue_next(0);
+
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's DMAs of stage `cur` have landed
+        __syncthreads();                                               // ... everyone's have, and stage cur^1 is no longer read
+        if (kt + 1 < kt_end && !nodma) issue_next(cur ^ 1);
+
+        const char* ac = lds + cur * STAGE;
+        const char* bc = ac + NPL * A_PLANE;
+        auto frag = [&](const char* plane, int row0, int sk) -> u16x8 {
+            const int row = (PDBG(p) & 16) ? 0 : row0 + l31;             // dbg 16: every lane reads the same 16 bytes (LDS broadcast, no bandwidth)
+            return *reinterpret_cast<const u16x8*>(plane + row * 64 + 16 * ((2 * sk + hh) ^ ((row >> 2) & 3)));
+        };
+        auto mma = [&](const u16x8& x, const u16x8& y, const f32x16& c) -> f32x16 {
+            if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, x), __builtin_bit_cast(bf8, y), c, 0, 0, 0);
+            else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, x), __builtin_bit_cast(half8, y), c, 0, 0, 0);
+        };
+#pragma unroll
+        for (int sk = 0; sk < 2; ++sk) {
+            u16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = frag(ac, wm * WM + i * 32, sk);
+                if constexpr (NPL == 2) al[i] = frag(ac + A_PLANE, wm * WM + i * 32, sk);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[j] = frag(bc, wn * WN + j * 32, sk);
+                if constexpr (NPL == 2) bl[j] = frag(bc + B_PLANE, wn * WN + j * 32, sk);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (NPL == 2) {
+                        acc[i][j] = mma(al[i], bh[j], acc[i][j]);        // same order as the in-kernel-split path: bit-identical sums
+                        acc[i][j] = mma(ah[i], bl[j], acc[i][j]);
+                    }
+                    acc[i][j] = mma(ah[i], bh[j], acc[i][j]);
+                }
+        }
+        cur ^= 1;
+    }
+
+    // ---------------------------------------------------------------- epilogue (as igemm_kernel's, K-contiguous case)
+    float* __restrict__ Cg;
+    const float* __restrict__ Rg = nullptr;
+    if (p.ksplit > 1) Cg = p.splitk_ws + (long)ks * (long)p.M * p.N;
+    else { Cg = p.C; Rg = p.res; }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * WN + j * 32 + l31;
+            if (col >= p.N) continue;
+            const float bv = (p.ksplit == 1 && p.bias) ? p.bias[col] : 0.f;
+            float gs = 0.f, gq = 0.f;
+            auto out_addr = [&](int row) -> long {
+                if (p.out_mode == OUT_NCHW) {
+                    int img = row / p.out_hw, pix = row - img * p.out_hw;
+                    return ((long)img * p.N + col) * p.out_hw + pix;
+                } else if (p.out_mode == OUT_UP2) {
+                    const int x = row - fdiv(row, p.wo_magic, p.wo_shift) * p.Wo;          // (n, y, x) -> (n, 2y + ph_y, 2x + ph_x)
+                    return (4L * row - 2 * x + p.ph_y * 2 * p.Wo + p.ph_x) * p.ldc + col;
+                }
+                return (long)row * p.ldc + col;
+            };
+            // residual / accumulate operands of the sub-tile's 16 rows requested together (as in igemm_kernel's epilogue)
+            float rv[16], cv[16];
+            if (p.ksplit == 1 && (Rg || p.accumulate)) {
+                long ad[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    ad[r] = row < p.M ? out_addr(row) : 0;
+                }
+                if (Rg) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rv[r] = Rg[ad[r]];
+                }
+                if (p.accumulate) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cv[r] = Cg[ad[r]];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (row >= p.M) continue;
+                if (p.ksplit > 1) { Cg[(long)row * p.N + col] = acc[i][j][r]; continue; }
+                const long addr = out_addr(row);
+                float v = acc[i][j][r] * p.alpha + bv;
+                if (Rg) v += rv[r];
+                if (p.act == ACT_SILU) v = cdae_silu(v);
+                else if (p.act == ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
+                if (p.accumulate) v += cv[r];
+                Cg[addr] = v;
+                if (!__builtin_isfinite(v) && p.range_flag) *p.range_flag = 1;
+                if (p.C_hi) store_planes(p, addr, v);
+                gs += v; gq += v * v;
+            }
+            if (p.gn_part && p.ksplit == 1) {           // this wave owns the whole 32 x 32 sub-tile: one deterministic write per (chunk, column)
+                gs += __shfl_xor(gs, 32); gq += __shfl_xor(gq, 32);
+                if (hh == 0) {
+                    float* o = p.gn_part + ((long)((m0 + wm * WM + i * 32) >> 5) * p.N + col) * 2;
+                    o[0] = gs; o[1] = gq;
+                }
+            }
+        }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NPL, bool BF = false>
+int launch_ps(const GemmParams& p, hipStream_t st) {
+    const int taps = p.amode == A_CONV_VEC ? (p.ps_taps == 4 ? 4 : 9) : 1;
+    constexpr size_t tiles = (size_t)2 * NPL * (BM + BN) * 64;
+    const size_t smem = tiles + (size_t)taps * BM * sizeof(int);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ps_kernel<BM, BN, WAVES_M, WAVES_N, NPL, BF>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(tiles + 9 * BM * sizeof(int))) != hipSuccess)
+            return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
+        attr_done = true;
+    }
+    dim3 grid((unsigned)((long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.ksplit));
+    hipLaunchKernelGGL((ps_kernel<BM, BN, WAVES_M, WAVES_N, NPL, BF>), grid, dim3(64 * WAVES_M * WAVES_N), smem, st, p);
+    return hipGetLastError() == hipSuccess ? 0 : cdae_fail("ps_kernel launch failed");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pswin_kernel: stride-1 conv3x3 on pre-split planes with the activation WINDOW resident in LDS.  The 9 taps of a tile of
+// 128 consecutive output pixels read the same input pixels shifted by (ky-1)*W + (kx-1), so per 32-channel chunk the block
+// loads one window of 128 + 2W + 2 pixel rows ONCE (instead of nine 128-row tiles) and every tap reads its A fragments from
+// the window at a row offset; pixels that fall outside the image (or into the neighbouring image of the batch) are masked
+// to zero in the fragment registers by a per-lane 9-bit tap mask.  Per step (chunk, tap) only the 128 x 32 weight tile is
+// staged (double-buffered).  A-operand traffic drops 4.5x (W = 64) .. 7.9x (W = 8), bytes per step from 32 KB to ~20 KB.
+// K order is (chunk, tap, channel) — the sums differ from ps_kernel's (tap, channel) order by fp32 rounding only.
+// (A 3-stage weight ring, three blocks per CU for short rows, 128 x 64 wave tiles, and the window PRODUCED in the kernel from the
+// GroupNorm's fp32 input — the literal GroupNorm -> SiLU -> conv3x3 fusion of unet.py:187-197 — were built, measured slower and
+// removed: docs/NOTES.md.)
+// BM = 256 (4 x 2 waves of 64 x 64): twice the MFMAs per step and per staged weight byte.  Its window is TIGHT — exactly BM + 2W
+// rows (384 at W = 64, so that window + two weight stages are 80 KB and two blocks still share a CU): the two corner rows of the
+// loose window are only ever read by masked taps when tiles start on an image-row boundary (BM % W == 0), so their reads clamp.
+template <int NPL, int MAXWIN, int WAVES_N, int BM, bool BF = false>
+__global__ __launch_bounds__(BM / 64 * WAVES_N * 64, BM / 64 * WAVES_N * 2 / 4) void pswin_kernel(const GemmParams p) {     // two blocks per CU
+    constexpr int BN = 128, BST = 2, WM_ = 64;
+    constexpr bool TIGHT = BM == 256;
+    constexpr int WAVES_M = BM / WM_, NW = WAVES_M * WAVES_N;
+    constexpr int WM = WM_, WN = BN / WAVES_N, TM = WM_ / 32, TN = WN / 32;
+    static_assert(MAXWIN % 16 == 0, "window rows come in 16-row DMA blocks");
+    constexpr int A_PLANE = MAXWIN * 64, B_PLANE = BN * 64;
+    constexpr int A_SLOTS = (2 * (MAXWIN / 16) + NW - 1) / NW;          // 2 planes x 16-row blocks over the block's waves
+    constexpr int B_RB = (BN / 16) / NW;                                // 16-row weight blocks per wave
+    typedef const unsigned short* hp;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const lds = reinterpret_cast<char*>(smem);
+    char* const awin = lds;                                             // [NPL][MAXWIN][64 B]
+    char* const bst = lds + NPL * A_PLANE;                              // [BST stages][NPL][BN][64 B]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    const int nmt = (p.M + BM - 1) / BM, nnt = (p.N + BN - 1) / BN;
+    int mt, nt, ks;
+    {
+        const unsigned G = gridDim.x, b = blockIdx.x;
+        const unsigned q = G >> 3, r = G & 7, x = b & 7;
+        unsigned v = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+        nt = v % nnt; v /= nnt;
+        mt = v % nmt; ks = v / nmt;
+    }
+    const int m0 = mt * BM, n0 = nt * BN;
+    const hp a_hi = reinterpret_cast<hp>(p.A), a_lo = p.A_lo;
+    const hp b_hi = reinterpret_cast<hp>(p.B), b_lo = p.B_lo;
+    const hp zero = reinterpret_cast<hp>(g_zero_ps);
+    const long za_hi = zero - a_hi, za_lo = NPL == 2 ? zero - a_lo : 0, zb_hi = zero - b_hi, zb_lo = NPL == 2 ? zero - b_lo : 0;
+
+    const int W = p.W, win = BM + 2 * W + (TIGHT ? 0 : 2), NB = (win + 15) >> 4;      // window rows, 16-row DMA blocks per plane
+    const int pix0 = m0 - W - (TIGHT ? 0 : 1);                          // flattened input pixel of window row 0
+    const int nchunk = p.Cin / BK;
+    const int c_per = (nchunk + p.ksplit - 1) / p.ksplit;
+    const int c_begin = ks * c_per, c_end = min(nchunk, c_begin + c_per);
+
+    // ---- A window DMA slots of this wave: piece pc = wave + 8q covers plane pc / NB, rows 16 (pc % NB) .. +15
+    int aoff[A_SLOTS];             // element offset of this lane's 16 bytes at chunk 0, or -1 (outside the tensor)
+#pragma unroll
+    for (int q = 0; q < A_SLOTS; ++q) {
+        const int pc = wave + NW * q, pl = pc >= NB ? 1 : 0, rb = pc - pl * NB;
+        const int j = rb * 16 + (lane >> 2);                             // window row
+        const int pix = pix0 + j;                                        // flattened input pixel (n, y, x)
+        const int c = (lane & 3) ^ ((j >> 2) & 3);
+        aoff[q] = (pix >= 0 && pix < p.M && j < win) ? pix * (int)p.sx + c * 8 : -1;
+    }
+    // ---- B tile pieces: wave w stages the 16-row blocks w, w + NW, ... (hi and lo)
+    long boff[B_RB];
+    bool bok[B_RB];
+#pragma unroll
+    for (int q = 0; q < B_RB; ++q) {
+        const int row = (wave + NW * q) * 16 + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
+        bok[q] = n0 + row < p.N;
+        boff[q] = (long)(bok[q] ? n0 + row : 0) * p.ldb + c * 8;
+    }
+    // LDS-DMA through inline asm (cdae_lds_dma16): with the builtin, hipcc drains the DMAs (vmcnt(0)) in front of the next LDS read that
+    // might alias their destination — i.e. right after they were issued, before the MFMAs they were meant to overlap
+    auto dma = [&](hp src, char* dst_wave_base) {
+        cdae_lds_dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst_wave_base - lds)));
+    };
+    auto issue_A = [&](int chunk) {
+#pragma unroll
+        for (int q = 0; q < A_SLOTS; ++q) {
+            const int pc = wave + NW * q;
+            if (pc < NPL * NB) {                                         // wave-uniform
+                const int pl = pc >= NB ? 1 : 0, rb = pc - pl * NB;
+                const bool ok = aoff[q] >= 0;
+                const long e = (long)aoff[q] + chunk * BK;
+                char* const dst = awin + pl * A_PLANE + rb * 1024;
+                if (pl == 0) dma(a_hi + (ok ? e : za_hi), dst);
+                else dma(a_lo + (ok ? e : za_lo), dst);
+            }
+        }
+    };
+    auto issue_B = [&](int stage, int chunk, int tap) {
+#pragma unroll
+        for (int q = 0; q < B_RB; ++q) {
+            char* const dst = bst + stage * (NPL * B_PLANE) + (wave + NW * q) * 1024;
+            const long e = boff[q] + (long)tap * p.Cin + chunk * BK;
+            dma(b_hi + (bok[q] ? e : zb_hi), dst);
+            if constexpr (NPL == 2) dma(b_lo + (bok[q] ? e : zb_lo), dst + B_PLANE);
+        }
+    };
+
+    // ---- per-lane tap masks of the wave's two 32-row sub-tiles: bit (3 ky + kx) set when tap (ky, kx) reads a real pixel
+    int tapmask[TM], jrow[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm * WM + i * 32 + l31, m = m0 + r;
+        jrow[i] = r;                                                     // window row of tap (0, 0); tap (ky, kx) adds ky*W + kx
+        const PixRow pr = make_pixrow(p, m);                            // iy0 = y - 1, ix0 = x - 1 (stride 1)
+        int mk = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ty = pr.iy0 + t / 3, tx = pr.ix0 + t % 3;
+            mk |= (pr.ok && ty >= 0 && ty < p.H && tx >= 0 && tx < W) ? (1 << t) : 0;
+        }
+        tapmask[i] = mk;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto mma = [&](const u16x8& x, const u16x8& y, const f32x16& c) -> f32x16 {
+        if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, x), __builtin_bit_cast(bf8, y), c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, x), __builtin_bit_cast(half8, y), c, 0, 0, 0);
+    };
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+    if (c_begin < c_end) { issue_A(c_begin); issue_B(0, c_begin, 0); }
+    int stage = 0;
+    // ntaps = 9: the 3x3 window; 4: the 2x2 window of one sub-pixel phase (ph_y, ph_x) of an upsample + conv — tap t reads window
+    // position (t / 2 + ph_y, t % 2 + ph_x) of the same 3x3 neighbourhood, so window, masks and row shifts are shared.
+    const int ntaps = p.ps_taps == 4 ? 4 : 9, lasttap = ntaps - 1;
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+#pragma unroll 1
+        for (int tap = 0; tap < ntaps; ++tap) {       // not unrolled: nine copies keep every tap's addresses and masks live (197 VGPRs)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            {
+                const int ntap = tap == lasttap ? 0 : tap + 1, nchk = tap == lasttap ? chunk + 1 : chunk;     // stage the next step's weight tile
+                if (nchk < c_end) issue_B(stage ^ 1, nchk, ntap);
+            }
+            const int ky = ntaps == 9 ? tap / 3 : (tap >> 1) + p.ph_y, kx = ntaps == 9 ? tap - 3 * ky : (tap & 1) + p.ph_x;
+            const int wtap = ky * 3 + kx, shift = ky * W + kx - (TIGHT ? 1 : 0);          // wtap: position in the 3x3 neighbourhood (mask bit)
+            const char* bc = bst + stage * (NPL * B_PLANE);
+            unsigned amask[TM];
+            int abase[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                amask[i] = (tapmask[i] >> wtap) & 1 ? 0xffffffffu : 0u;
+                int j = jrow[i] + shift;
+                if constexpr (TIGHT) j = min(max(j, 0), win - 1);            // the clamped reads belong to masked taps
+                abase[i] = j * 64 + 16 * (hh ^ ((j >> 2) & 3));           // sk = 0 chunk; sk = 1 flips chunk bit 1 (+-32 bytes)
+            }
+#pragma unroll
+            for (int sk = 0; sk < 2; ++sk) {
+                u16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int a = abase[i] ^ (sk * 32);
+                    u32x4 h4 = *reinterpret_cast<const u32x4*>(awin + a);
+                    h4 &= amask[i];
+                    ah[i] = __builtin_bit_cast(u16x8, h4);
+                    if constexpr (NPL == 2) {
+                        u32x4 l4 = *reinterpret_cast<const u32x4*>(awin + A_PLANE + a);
+                        l4 &= amask[i];
+                        al[i] = __builtin_bit_cast(u16x8, l4);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int row = wn * WN + j * 32 + l31;
+                    const int b = row * 64 + 16 * ((2 * sk + hh) ^ ((row >> 2) & 3));
+                    bh[j] = *reinterpret_cast<const u16x8*>(bc + b);
+                    if constexpr (NPL == 2) bl[j] = *reinterpret_cast<const u16x8*>(bc + B_PLANE + b);
+                }
+                if (!(PDBG(p) & 128)) __builtin_amdgcn_s_setprio(1);     // MFMA bursts win issue arbitration over other waves' staging work (+1-2 %)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (NPL == 2) {
+                            acc[i][j] = mma(al[i], bh[j], acc[i][j]);
+                            acc[i][j] = mma(ah[i], bl[j], acc[i][j]);
+                        }
+                        acc[i][j] = mma(ah[i], bh[j], acc[i][j]);
+                    }
+                if (!(PDBG(p) & 128)) __builtin_amdgcn_s_setprio(0);
+            }
+            stage ^= 1;
+        }
+        if (chunk + 1 < c_end) {
+            __builtin_amdgcn_s_barrier();                                // every wave is done with this chunk's window
+            issue_A(chunk + 1);                                          // lands before the vmcnt(0) + barrier of the next step
+        }
+    }
+
+    // ---------------------------------------------------------------- epilogue (row-major result)
+    float* __restrict__ Cg;
+    const float* __restrict__ Rg = nullptr;
+    if (p.ksplit > 1) Cg = p.splitk_ws + (long)ks * (long)p.M * p.N;
+    else { Cg = p.C; Rg = p.res; }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * WN + j * 32 + l31;
+            if (col >= p.N) continue;
+            const float bv = (p.ksplit == 1 && p.bias) ? p.bias[col] : 0.f;
+            float gs = 0.f, gq = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (row >= p.M) continue;
+                if (p.ksplit > 1) { Cg[(long)row * p.N + col] = acc[i][j][r]; continue; }
+                long addr;
+                if (p.out_mode == OUT_UP2) {
+                    const int x = row - fdiv(row, p.wo_magic, p.wo_shift) * p.Wo;          // (n, y, x) -> (n, 2y + ph_y, 2x + ph_x)
+                    addr = (4L * row - 2 * x + p.ph_y * 2 * p.Wo + p.ph_x) * p.ldc + col;
+                } else addr = (long)row * p.ldc + col;
+                float v = acc[i][j][r] * p.alpha + bv;
+                if (Rg) v += Rg[addr];
+                if (p.act == ACT_SILU) v = cdae_silu(v);
+                else if (p.act == ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
+                if (p.accumulate) v += Cg[addr];
+                Cg[addr] = v;
+                if (!__builtin_isfinite(v) && p.range_flag) *p.range_flag = 1;
+                if (p.C_hi) store_planes(p, addr, v);
+                gs += v; gq += v * v;
+            }
+            if (p.gn_part && p.ksplit == 1) {
+                gs += __shfl_xor(gs, 32); gq += __shfl_xor(gq, 32);
+                if (hh == 0) {
+                    float* o = p.gn_part + ((long)((m0 + wm * WM + i * 32) >> 5) * p.N + col) * 2;
+                    o[0] = gs; o[1] = gq;
+                }
+            }
+        }
+}
+
+template <int NPL, int MAXWIN, int WAVES_N, int BM, bool BF = false>
+int launch_pswin(const GemmParams& p, hipStream_t st) {
+    constexpr int BN = 128;
+    constexpr size_t smem = (size_t)NPL * MAXWIN * 64 + (size_t)2 * NPL * BN * 64;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pswin_kernel<NPL, MAXWIN, WAVES_N, BM, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
+        attr_done = true;
+    }
+    dim3 grid((unsigned)((long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.ksplit));
+    hipLaunchKernelGGL((pswin_kernel<NPL, MAXWIN, WAVES_N, BM, BF>), grid, dim3(BM / 64 * WAVES_N * 64), smem, st, p);
+    return hipGetLastError() == hipSuccess ? 0 : cdae_fail("pswin_kernel launch failed");
+}
+
+}  // namespace
+
+// The pre-split branch of cdae_gemm_dispatch (igemm.hip): picks convwin_kernel / pswin_kernel / ps_kernel for p (K-contiguous operands on
+// planes).  big: 128 x 128 tiles fill the chip; ks: the K split chosen for 128 / 64 tiles (the window kernels re-derive theirs by whole
+// 32-channel chunks and report it back).  Returns 0, -1 (error), 2 (fused phases not taken: launch them one by one) or 3 (group-major
+// planes not taken: convert and call again); *launched = a kernel is in flight (the caller then runs the split-K finish).
+int cdae_planes_dispatch(GemmParams& p, int big, int& ks, hipStream_t st) {
+    if (!((p.amode == A_CONV_VEC || p.amode == A_PLAIN_KC) && p.bmode == B_PLAIN_KC) || p.batch != 1)
+        return cdae_fail("pre-split operands: only K-contiguous conv / plain GEMMs without batch");
+    const int kin = p.amode == A_CONV_VEC ? p.Cin : p.K;
+    if (kin % BK || p.K % BK || p.ldb % 8 || (p.amode == A_PLAIN_KC && p.lda % 8) || (p.prec != 1 && p.prec != 2 && p.prec != 3))
+        return cdae_fail("pre-split operands: need K (Cin) % 32 == 0, 16-byte aligned rows and a 16-bit split precision mode");
+    if (p.prec == 2 && (p.gn_coef || p.ps_taps == 4)) return cdae_fail("pre-split bf16 planes: plain conv3x3 / GEMM only");
+    if (p.gn_coef) return cdae_fail("GroupNorm applied inside the conv kernel was removed (measured slower than writing planes once)");
+    p.dbg = CDAE_DEV_INT("CDAE_PS_DBG", 0);
+    // cdae_tune_set(CDAE_TUNE_CONVWIN_MIN_TILES, <= 1): every shape convwin_kernel can take runs on it, whatever the grid size (the
+    // parity tests push the small golden cases through the kernel the benchmark shapes dispatch)
+    const int cw_min = cdae_tune(TUNE_CONVWIN_MIN_TILES);
+    if (cw_min <= 1 && p.amode == A_CONV_VEC && p.stride == 1 && !p.up && cdae_convwin_ok(p)) big = 1;
+    // window-resident form: stride-1 3x3 convs (and the 2x2 sub-pixel phases of an up-conv) on a dense NHWC tensor, rows up to 64 pixels
+    const bool win_ok = p.amode == A_CONV_VEC && p.stride == 1 && !p.up && p.W <= 64 && big &&
+                        p.sy == (long)p.W * p.sx && p.sn == (long)p.H * p.W * p.sx &&
+                        (p.ps_taps == 4 ? p.out_mode == OUT_UP2 : p.out_mode == OUT_ROWMAJOR);
+    if (p.a_gm && !win_ok) return 3;
+    if (p.nphase > 1 && !win_ok) return 2;          // (only convwin_kernel walks the four phases itself)
+    if (win_ok) {
+        const int nchunk = p.Cin / BK;
+        if (p.ksplit > nchunk) p.ksplit = nchunk;              // K is split by whole channel chunks here
+        ks = p.ksplit;
+        // second-generation window kernel (convwin.hip): 256 x 128 tiles, two blocks per CU.  Fewer tiles than block slots: split K by whole
+        // 32-channel chunks (the low-resolution levels, and everything below 64 x 64 at training batch sizes).  floor, not ceil: 96 tiles x 6 =
+        // 576 would need a second, nearly empty round of blocks; x 5 = 480 runs in one.  At least three chunks = 27 K-steps per split.
+        const long cw_tiles = (long)((p.M + 255) / 256) * ((p.N + 127) / 128) * (p.nphase > 1 ? p.nphase : 1);
+        bool cw = cdae_convwin_ok(p);
+        if (cw) {
+            int kbest = ks;
+            if (cw_tiles * ks < 512 && cdae_tune(TUNE_CONVWIN_SPLITK) && p.ksplit_auto && p.splitk_ws && !p.gn_part) {
+                int k2 = (int)(512 / cw_tiles);
+                if (k2 > nchunk / 3) k2 = nchunk / 3;
+                while (k2 > 1 && (size_t)k2 * p.M * p.N * sizeof(float) > p.splitk_ws_bytes) --k2;
+                if (k2 > 1) { const int c_per = (nchunk + k2 - 1) / k2; k2 = (nchunk + c_per - 1) / c_per; }      // 12 chunks over 5 splits are 3 + 3 + 3 + 3 + 0: no empty slabs
+                if (k2 > 1) kbest = k2;
+            }
+            if (cw_tiles * kbest >= cw_min) p.ksplit = ks = kbest;
+            else cw = false;
+        }
+        if (p.a_gm && !cw) return 3;                      // group-major planes: only convwin_kernel reads them (the caller converts)
+        if (p.nphase > 1 && (!cw || ks > 1)) return 2;      // fused phases only on the window kernel: the caller launches them one by one
+        if (cw) {
+            // algorithmic bytes: both activation planes, both weight planes, the fp32 result (+ the residual read)
+            const double nph = p.nphase > 1 ? p.nphase : 1;      // (the phases of an up-conv share the input planes)
+            cdae_prof_note(p.ps_taps == 4 ? PROF_CONVWIN_UP : p.prec == 2 ? PROF_CONVWIN_DGRAD : PROF_CONVWIN,
+                           4.0 * p.M * p.Cin + nph * (4.0 * p.K * p.N + 4.0 * p.M * p.N * (p.res ? 2 : 1)));
+            return cdae_convwin_launch(p, st);
+        }
+        // first-generation window kernel: 256-row tiles where rows divide the tile (tight window) and the grid still fills two blocks per CU
+        const bool tall = 256 % p.W == 0 && (long)((p.M + 255) / 256) * ((p.N + 127) / 128) * ks >= 512;
+        if (p.prec == 2) return tall ? launch_pswin<2, 384, 2, 256, true>(p, st) : launch_pswin<2, 272, 4, 128, true>(p, st);
+        if (p.prec == 1) return tall ? launch_pswin<2, 384, 2, 256>(p, st) : launch_pswin<2, 272, 4, 128>(p, st);
+        return launch_pswin<1, 272, 4, 128>(p, st);
+    }
+    if (p.prec == 2) return big ? launch_ps<128, 128, 2, 4, 2, true>(p, st) : launch_ps<64, 64, 2, 2, 2, true>(p, st);
+    if (p.prec == 1) return big ? launch_ps<128, 128, 2, 4, 2>(p, st) : launch_ps<64, 64, 2, 2, 2>(p, st);
+    return big ? launch_ps<128, 128, 2, 4, 1>(p, st) : launch_ps<64, 64, 2, 2, 1>(p, st);
+}

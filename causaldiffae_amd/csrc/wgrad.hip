@@ -447,11 +447,11 @@ extern "C" int cdae_conv3x3_wgrad_win(const unsigned short* a_hi, const unsigned
     }
     const long tiles = (long)(Cin / 64) * (Cout / 64);
     const size_t slab = (size_t)Cout * 9 * Cin * sizeof(float);
-    static const int cfg_blocks = getenv("CDAE_WG_BLOCKS") ? atoi(getenv("CDAE_WG_BLOCKS")) : 256;      // grid target: one block per CU (measured 256 / 512 / 768: 39.6 / 39.7-40.9 / 40.6-43.2 ms per training step)
+    static const int cfg_blocks = CDAE_DEV_INT("CDAE_WG_BLOCKS", 256);      // grid target: one block per CU (measured 256 / 512 / 768: 39.6 / 39.7-40.9 / 40.6-43.2 ms per training step)
     // K split: one block per CU fits (84-134 KB of LDS), so a grid of more than cfg_blocks runs in ROUNDS: 36 tiles x 8 splits = 288
     // blocks take two rounds of steps / 8, x 7 = 252 blocks one round of steps / 7.  Pick the split with the smallest
     // rounds x (steps per block + the fixed prologue / epilogue / finish, about twelve steps' worth); CDAE_WG_KS_CEIL=1 restores ceil(256 / tiles).
-    static const int cfg_ceil = getenv("CDAE_WG_KS_CEIL") ? atoi(getenv("CDAE_WG_KS_CEIL")) : 0;
+    static const int cfg_ceil = CDAE_DEV_INT("CDAE_WG_KS_CEIL", 0);
     int ks = (int)((cfg_blocks + tiles - 1) / tiles);
     if (ks > p.steps) ks = p.steps;
     while (ks > 1 && (!splitk_ws || (size_t)ks * slab > splitk_ws_bytes)) --ks;
@@ -472,7 +472,7 @@ extern "C" int cdae_conv3x3_wgrad_win(const unsigned short* a_hi, const unsigned
     p.colsum = dbias;
     if (dbias && !accumulate && hipMemsetAsync(dbias, 0, sizeof(float) * Cout, st) != hipSuccess) return cdae_fail("dbias memset failed");
     const size_t smem = (size_t)4 * (p.RB + 1) * 16 * 64 + 2 * 4 * 64 * 64;
-    static const int cfg_waves = getenv("CDAE_WG_WAVES") ? atoi(getenv("CDAE_WG_WAVES")) : 8;
+    static const int cfg_waves = CDAE_DEV_INT("CDAE_WG_WAVES", 8);
     static size_t attr_bytes = 0;
     if (smem > attr_bytes) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgwin_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||

@@ -141,8 +141,6 @@ class ConvNd(nn.Module):
         if isinstance(x, ops.LazyGN):          # GroupNorm output not written yet: fuse it into the conv where the kernel exists
             if self.kernel_size == 3 and out_nchw and res is None and not up and self.stride == 1 and not emit_split and ops.head_conv_ok(x, self.weight):
                 return ops.head_conv(x, self.weight, self.bias)          # the output head: a few channels, exact fp32
-            if self.kernel_size == 3 and ops.gn_conv_ok(x, self.out_channels, self.stride, up, out_nchw):
-                return ops.conv3x3_gn(x, self.weight, self.bias, res=res, emit_split=emit_split, gn_stats=gn_stats)
             x = x.planes(gm=self.kernel_size == 3 and self.stride == 1 and not up and not out_nchw)      # group-major for the window conv kernel
         if isinstance(x, ops.SplitAct):
             assert self.kernel_size == 3

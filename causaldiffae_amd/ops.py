@@ -12,7 +12,7 @@ import weakref
 import torch
 from torch.autograd import Function
 
-from ._lib import check, lib, ptr, splitk_ws, stream, workspace, workspace_bytes, SPLITK_BYTES, WS_GN_PARTS
+from ._lib import check, lib, ptr, ptr2, splitk_ws, stream, workspace, workspace_bytes, SPLITK_BYTES, WS_GN_PARTS
 
 ACT_NONE, ACT_SILU, ACT_LRELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3, 4
 
@@ -20,11 +20,16 @@ ACT_NONE, ACT_SILU, ACT_LRELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3, 4
 # ----------------------------------------------------------------------------- layout helpers
 def new_act(N, C, H, W, device):
     """Fresh activation: logical [N,C,H,W], NHWC storage."""
-    return torch.empty((N, H, W, C), dtype=torch.float32, device=device).permute(0, 3, 1, 2)
+    return torch.empty_strided((N, C, H, W), (H * W * C, 1, W * C, C), dtype=torch.float32, device=device)
 
 
 def is_nhwc(x):
-    return x.dim() == 4 and x.permute(0, 2, 3, 1).is_contiguous()
+    """channel-contiguous rows, dense: strides (H W C, 1, W C, C) — checked on the strides (no view objects: this runs ~300 times per training step)"""
+    if x.dim() != 4:
+        return False
+    N, C, H, W = x.shape
+    sn, sc, sh, sw = x.stride()
+    return (sc == 1 or C == 1) and (sw == C or W == 1) and (sh == W * C or H == 1) and (sn == H * W * C or N == 1)
 
 
 class _Relayout(Function):
@@ -66,7 +71,7 @@ def to_nchw(x):
 
 def ohwi(w):
     """Physical OHWI view check of a logical [Cout,Cin,3,3] weight (copy only if someone re-laid it out)."""
-    if w.permute(0, 2, 3, 1).is_contiguous():
+    if w.dim() == 4 and is_nhwc(w):
         return w
     return w.contiguous(memory_format=torch.channels_last)
 
@@ -286,10 +291,10 @@ class _GroupNorm(Function):
         ws = workspace(dev, "gn", 4 * lib.cdae_gn_workspace_floats(N, C))
         y = new_act(N, C, H, W, dev)
         st = stream()
-        check(lib.cdae_gn_stats(ptr(x), N, H * W, C, C, groups, eps, ptr(stats[0]), ptr(stats[1]), ptr(ws), st))
+        check(lib.cdae_gn_stats(ptr(x), N, H * W, C, C, groups, eps, *ptr2(stats), ptr(ws), st))
         if ss is not None:
             assert ss.shape == (N, 2 * C) and ss.is_contiguous()
-        check(lib.cdae_gn_apply(ptr(x), ptr(y), N, H * W, C, C, C, groups, ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta),
+        check(lib.cdae_gn_apply(ptr(x), ptr(y), N, H * W, C, C, C, groups, *ptr2(stats), ptr(gamma), ptr(beta),
                                 ptr(ss), 2 * C, 1 if silu else 0, st))
         ctx.save_for_backward(x, gamma, beta, ss, stats)
         ctx.cfg = (silu, groups)
@@ -310,7 +315,7 @@ class _GroupNorm(Function):
         dbeta = gb if direct else torch.empty_like(beta)
         dss = torch.empty_like(ss) if ss is not None else None
         ws = workspace(dev, "gn", 4 * lib.cdae_gn_workspace_floats(N, C))
-        check(lib.cdae_gn_bwd(ptr(x), ptr(dy), ptr(dx), N, H * W, C, C, C, C, groups, ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta),
+        check(lib.cdae_gn_bwd(ptr(x), ptr(dy), ptr(dx), N, H * W, C, C, C, C, groups, *ptr2(stats), ptr(gamma), ptr(beta),
                               ptr(ss), 2 * C, 1 if silu else 0, ptr(dgamma), ptr(dbeta), 1 if direct else 0, ptr(dss), 2 * C, 0, ptr(ws), stream()))
         if direct:
             dgamma = dbeta = None
@@ -590,7 +595,7 @@ class _BnLrelu(Function):
         aux = torch.empty((4, C), dtype=torch.float32, device=dev)      # scale, shift, save_mean, save_rstd
         ws = workspace(dev, "bn", 4 * lib.cdae_bn_workspace_floats(C))
         check(lib.cdae_bn_lrelu_fwd(ptr(x), ptr(y), N * H * W, C, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), 1 if training else 0,
-                                    eps, momentum, slope, ptr(aux[0]), ptr(aux[1]), ptr(aux[2]), ptr(aux[3]), ptr(ws), stream()))
+                                    eps, momentum, slope, *ptr2(aux), ptr(aux[2]), ptr(aux[3]), ptr(ws), stream()))
         ctx.save_for_backward(x, gamma, beta, aux)
         ctx.cfg = (training, slope)
         ctx.sinks = (_sink(gamma), _sink(beta))
@@ -611,7 +616,7 @@ class _BnLrelu(Function):
         dg = gg if direct else torch.empty_like(gamma)
         db = gb if direct else torch.empty_like(beta)
         ws = workspace(dev, "bn", 4 * lib.cdae_bn_workspace_floats(C))
-        check(lib.cdae_bn_lrelu_bwd(ptr(x), ptr(dy), ptr(dx), N * H * W, C, ptr(gamma), ptr(aux[0]), ptr(aux[1]), ptr(aux[2]), ptr(aux[3]), slope,
+        check(lib.cdae_bn_lrelu_bwd(ptr(x), ptr(dy), ptr(dx), N * H * W, C, ptr(gamma), *ptr2(aux), ptr(aux[2]), ptr(aux[3]), slope,
                                     ptr(dg), ptr(db), 1 if direct else 0, ptr(ws), stream()))
         if direct:
             dg = db = None
@@ -700,7 +705,7 @@ class SplitAct:
             return self
         N, C, H, W = self.shape
         out = torch.empty((2, N, H, W, C), dtype=torch.float16, device=self.hi.device)
-        check(lib.cdae_planes_gm_to_pc(ptr(self.hi), ptr(self.lo), ptr(out[0]), ptr(out[1]), N * H * W, C, stream()))
+        check(lib.cdae_planes_gm_to_pc(ptr(self.hi), ptr(self.lo), *ptr2(out), N * H * W, C, stream()))
         return SplitAct(out[0], out[1], self.shape)
 
 
@@ -713,10 +718,6 @@ def planes_gm_ok(C):
 
 _WSPLIT = {}
 _PRESPLIT_ON = os.environ.get("CDAE_PRESPLIT", "1") != "0"      # dev switch: 0 = in-kernel split everywhere
-# GroupNorm applied inside the conv's window staging (ops.conv3x3_gn): correct (bit-identical, tested) but measured 5 % SLOWER end to
-# end than writing planes once — every n-tile block and every halo row re-normalises the same pixels (2-8x the work of the standalone
-# pass, in VALU the kernel cannot spare).  Opt-in.
-_GNCONV_ON = os.environ.get("CDAE_GNCONV", "0") == "1"
 _WEIGHT_EPOCH = [0]
 
 
@@ -754,7 +755,7 @@ class ConvWeightBank:
             self.where[id(w)] = (o - self.base, w.numel())
         self.tiles = tiles
         self.desc = torch.from_numpy(desc.view(np.uint8).copy()).to(dev)
-        self.epoch, self.versions = None, {}
+        self.epoch, self.versions, self._ptrs = None, {}, {}
         for w in self.weights:
             _BANK_OF[id(w)] = (weakref.ref(w), self)
 
@@ -771,6 +772,25 @@ class ConvWeightBank:
         o, n = self.where[id(w)]
         buf = self.b16 if bf16 else self.f16
         return buf[0, o:o + n], buf[1, o:o + n]
+
+    def pointers(self, w, bf16):
+        """(hi, lo, packed hi, packed lo) device pointers of a registered weight's planes (packed: None where the weight is not packable).
+        Plain integers, cached per weight — the buffers never move, and the training step asks ~130 times (a slice pair per ask otherwise)."""
+        self._refresh(w)
+        key = (id(w), bf16)
+        hit = self._ptrs.get(key)
+        if hit is None:
+            o, _ = self.where[id(w)]
+            buf, kbuf = (self.b16, self.kb16) if bf16 else (self.f16, self.kf16)
+            hi = buf.data_ptr() + 2 * o
+            lo = hi + 2 * buf.stride(0)
+            if id(w) in self.packable:
+                khi = kbuf.data_ptr() + 2 * o
+                hit = (hi, lo, khi, khi + 2 * kbuf.stride(0))
+            else:
+                hit = (hi, lo, None, None)
+            self._ptrs[key] = hit
+        return hit
 
     def packed(self, w, bf16):
         """K-group-major planes (cdae_conv_wpack's order), or (None, None) for a weight whose channel counts are not multiples of 16"""
@@ -813,7 +833,7 @@ def split_weight(w):
         return hit[2], hit[3]
     n = w.numel()
     planes = torch.empty((2, n), dtype=torch.float16, device=w.device)
-    check(lib.cdae_split_f16(ptr(w), ptr(planes[0]), ptr(planes[1]), n, stream()))
+    check(lib.cdae_split_f16(ptr(w), *ptr2(planes), n, stream()))
     if len(_WSPLIT) > 4096:
         for k in [k for k, v in _WSPLIT.items() if v[0]() is None]:
             del _WSPLIT[k]
@@ -841,12 +861,22 @@ def packed_weight(w, bf16=False):
     Cout, Cin = w.shape[0], w.shape[1]
     rows, K = (Cin, Cout) if bf16 else (Cout, Cin)
     out = torch.empty((2, w.numel()), dtype=src[0].dtype, device=w.device)
-    check(lib.cdae_conv_wpack(ptr(src[0]), ptr(src[1]), ptr(out[0]), ptr(out[1]), rows, 9, K, stream()))
+    check(lib.cdae_conv_wpack(*ptr2(src), *ptr2(out), rows, 9, K, stream()))
     if len(_WPACK) > 4096:
         for k in [k for k, v in _WPACK.items() if v[0]() is None]:
             del _WPACK[k]
     _WPACK[(id(w), bf16)] = (weakref.ref(w), tag, out[0], out[1])
     return out[0], out[1]
+
+
+def _wptrs(w, bf16):
+    """(hi, lo, packed hi, packed lo) pointers of a conv3x3 weight's operand planes: f16 OHWI (forward) or the bf16 dgrad planes"""
+    bank = _bank(w)
+    if bank is not None:
+        return bank.pointers(w, bf16)
+    hi, lo = dgrad_weight(w) if bf16 else split_weight(w)
+    k_hi, k_lo = packed_weight(w, bf16)
+    return ptr(hi), ptr(lo), ptr(k_hi), ptr(k_lo)
 
 
 def _pk(w, bf16):
@@ -863,8 +893,8 @@ def presplit_ok():
 
 class LazyGN:
     """A GroupNorm (+scale-shift, +SiLU) whose statistics are known but whose output has not been written: the consumer decides.
-    A stride-1 conv3x3 on the window-resident path applies it while staging its activation window (`conv3x3_gn`, the tensor never
-    exists in HBM); anything else calls `.planes()` and gets the usual pre-split f16 planes."""
+    The 1x1 skip conv of a ResBlock (skip_gn_fused), the attention block's qkv GEMM (linear_gn) and the output head (head_conv) apply it
+    while they stream the fp32 rows; anything else calls `.planes()` and gets the pre-split f16 planes."""
     __slots__ = ("x1", "x2", "shape", "stats", "gamma", "beta", "ss", "ld_ss", "silu", "groups")
 
     def __init__(self, x1, x2, shape, stats, gamma, beta, ss, ld_ss, silu, groups):
@@ -876,11 +906,11 @@ class LazyGN:
         C1 = self.x1.shape[1]
         planes = torch.empty((2, N, H, W, C), dtype=torch.float16, device=self.x1.device)
         if gm and planes_gm_ok(C):      # group-major, for a stride-1 conv3x3 on the window kernel
-            check(lib.cdae_gn_apply_split2g(ptr(self.x1), C1, ptr(self.x2), 0 if self.x2 is None else C - C1, C1, ptr(planes[0]), ptr(planes[1]),
+            check(lib.cdae_gn_apply_split2g(ptr(self.x1), C1, ptr(self.x2), 0 if self.x2 is None else C - C1, C1, *ptr2(planes),
                                             N, H * W, C, self.groups, ptr(self.stats[0]), ptr(self.stats[1]), ptr(self.gamma), ptr(self.beta),
                                             ptr(self.ss), self.ld_ss, 1 if self.silu else 0, stream()))
             return SplitAct(planes[0], planes[1], self.shape, gm=True)
-        check(lib.cdae_gn_apply_split2(ptr(self.x1), C1, ptr(self.x2), 0 if self.x2 is None else C - C1, C1, ptr(planes[0]), ptr(planes[1]),
+        check(lib.cdae_gn_apply_split2(ptr(self.x1), C1, ptr(self.x2), 0 if self.x2 is None else C - C1, C1, *ptr2(planes),
                                        N, H * W, C, C, self.groups, ptr(self.stats[0]), ptr(self.stats[1]), ptr(self.gamma), ptr(self.beta),
                                        ptr(self.ss), self.ld_ss, 1 if self.silu else 0, stream()))
         return SplitAct(planes[0], planes[1], self.shape)
@@ -939,11 +969,11 @@ def skip_gn_fused(lz, w, b=None, gm=False):
         wh, wl = split_weight(w)
         gm = bool(gm and planes_gm_ok(C))
         check(lib.cdae_skip_gn_fwd(ptr(lz.x1), C1, C1, ptr(lz.x2), 0 if lz.x2 is None else C - C1, ptr(wh), ptr(wl), C, ptr(b), ptr(y), Nf, ptr(coef),
-                                   1 if lz.silu else 0, ptr(planes[0]), ptr(planes[1]), 1 if gm else 0, M, Nf, C, H * W, st))
+                                   1 if lz.silu else 0, *ptr2(planes), 1 if gm else 0, M, Nf, C, H * W, st))
         return y.reshape(N, H, W, Nf).permute(0, 3, 1, 2), SplitAct(planes[0], planes[1], lz.shape, gm=gm)
     ws, wsb = _sk(dev)
     check(lib.cdae_linear_fwd_cat_gn(ptr(lz.x1), C1, C1, ptr(lz.x2), 0 if lz.x2 is None else C - C1, ptr(w), C, ptr(b), ptr(y), Nf, ptr(coef),
-                                     1 if lz.silu else 0, ptr(planes[0]), ptr(planes[1]), M, Nf, C, H * W, ws, wsb, st))
+                                     1 if lz.silu else 0, *ptr2(planes), M, Nf, C, H * W, ws, wsb, st))
     return y.reshape(N, H, W, Nf).permute(0, 3, 1, 2), SplitAct(planes[0], planes[1], lz.shape)
 
 
@@ -969,10 +999,10 @@ def group_norm_lazy(x, gamma, beta, scale_shift=None, silu=False, groups=32, eps
         # the producing conv(s) left per-chunk partial sums behind: no statistics pass over the tensor
         check(lib.cdae_gn_stats_from_parts(ptr(p1), C1, getattr(x1, "_gnseg", 1), ptr(p2), 0 if x2 is None else C - C1,
                                            1 if x2 is None else getattr(x2, "_gnseg", 1), N, H * W, groups, eps,
-                                           ptr(stats[0]), ptr(stats[1]), ptr(workspace(dev, "gnparts", workspace_bytes(WS_GN_PARTS, N, C))), st))
+                                           *ptr2(stats), ptr(workspace(dev, "gnparts", workspace_bytes(WS_GN_PARTS, N, C))), st))
     else:
         ws = workspace(dev, "gn", 4 * lib.cdae_gn_workspace_floats(N, C))
-        check(lib.cdae_gn_stats2(ptr(x1), C1, ptr(x2), ld2, C1, N, H * W, C, groups, eps, ptr(stats[0]), ptr(stats[1]), ptr(ws), st))
+        check(lib.cdae_gn_stats2(ptr(x1), C1, ptr(x2), ld2, C1, N, H * W, C, groups, eps, *ptr2(stats), ptr(ws), st))
     return LazyGN(x1, x2, (N, C, H, W), stats, gamma, beta, scale_shift, ld_ss, silu, groups)
 
 
@@ -980,42 +1010,6 @@ def group_norm_split(x, gamma, beta, scale_shift=None, silu=False, groups=32, ep
     """GroupNorm (+ scale-shift, + SiLU) whose result is written directly as f16 hi/lo planes (no autograd).  x may be a CatAct:
     both kernels then read the two sources in place."""
     return group_norm_lazy(x, gamma, beta, scale_shift, silu, groups, eps).planes()
-
-
-def gn_conv_ok(lz, Cout, stride, up, out_nchw):
-    """Can this LazyGN be applied inside the window-resident conv kernel?  (the dispatcher's own conditions)"""
-    N, C, H, W = lz.shape
-    M = N * H * W
-    return (_GNCONV_ON and stride == 1 and not up and not out_nchw and W <= 64 and C % 32 == 0 and Cout >= 96 and M >= 96
-            and (lz.x2 is None or lz.x1.shape[1] % 32 == 0) and ((M + 127) // 128) * ((Cout + 127) // 128) >= 192)
-
-
-def conv3x3_gn(lz, w, b=None, res=None, emit_split=False, gn_stats=False):
-    """conv3x3(stride 1) of a LazyGN: GroupNorm -> (scale-shift) -> SiLU -> conv in one kernel (no autograd)."""
-    N, Cin, H, W = lz.shape
-    Cout = w.shape[0]
-    w_hi, w_lo = split_weight(ohwi(w))
-    dev = lz.x1.device
-    coef = torch.empty((N, Cin, 2), dtype=torch.float32, device=dev)
-    st = stream()
-    check(lib.cdae_gn_coef(ptr(lz.stats[0]), ptr(lz.stats[1]), ptr(lz.gamma), ptr(lz.beta), ptr(lz.ss), lz.ld_ss, ptr(coef), N, Cin, lz.groups, st))
-    out = new_act(N, Cout, H, W, dev)
-    if res is not None:
-        res = to_nhwc(res)
-    M = N * H * W
-    planes = torch.empty((2, N, H, W, Cout), dtype=torch.float16, device=dev) if emit_split else None
-    gn_stats = gn_stats and (H * W) % 32 == 0 and ((M + 127) // 128) * ((Cout + 127) // 128) >= 256
-    parts = torch.empty(((M + 31) // 32, Cout, 2), dtype=torch.float32, device=dev) if gn_stats else None
-    C1 = lz.x1.shape[1]
-    ws, wsb = _sk(dev)
-    check(lib.cdae_conv3x3_fwd_gn(ptr(lz.x1), C1, C1, ptr(lz.x2), 0 if lz.x2 is None else Cin - C1, ptr(coef), 1 if lz.silu else 0,
-                                  ptr(w_hi), ptr(w_lo), ptr(b), ptr(res), ptr(out), Cout, ptr(planes[0]) if emit_split else None,
-                                  ptr(planes[1]) if emit_split else None, ptr(parts), N, H, W, Cin, Cout, ws, wsb, st))
-    if emit_split:
-        out._split = SplitAct(planes[0], planes[1], (N, Cout, H, W))
-    if gn_stats:
-        out._gnparts = parts
-    return out
 
 
 def can_split(C, groups=32):
@@ -1044,7 +1038,7 @@ def fold_upconv_weight(w):
     w4 = torch.stack(phases, dim=0).contiguous()
     n = w4.numel()
     planes = torch.empty((2, n), dtype=torch.float16, device=w.device)
-    check(lib.cdae_split_f16(ptr(w4), ptr(planes[0]), ptr(planes[1]), n, stream()))
+    check(lib.cdae_split_f16(ptr(w4), *ptr2(planes), n, stream()))
     _W4[id(w)] = (weakref.ref(w), tag, planes[0], planes[1])
     return planes[0], planes[1]
 
@@ -1098,7 +1092,7 @@ def conv3x3_ps(xs, w, b=None, res=None, stride=1, up=False, out_nchw=False, emit
     parts = torch.empty(((M + 31) // 32, Cout, 2), dtype=torch.float32, device=dev) if gn_stats else None
     def launch(a, gmflag):
         return lib.cdae_conv3x3_fwd_psg(ptr(a.hi), ptr(a.lo), H * W * Cin, W * Cin, Cin, gmflag, ptr(w_hi), ptr(w_lo), *_pk(w, False), ptr(b), ptr(res), ptr(out), Cout,
-                                        1 if out_nchw else 0, ptr(planes[0]) if emit_split else None, ptr(planes[1]) if emit_split else None,
+                                        1 if out_nchw else 0, *(ptr2(planes) if emit_split else (None, None)),
                                         ptr(parts), N, H, W, Cin, Cout, stride, 1 if up else 0, ws, wsb, stream())
     rc = launch(xs, 1 if xs.gm else 0)
     if rc == 3:                       # group-major planes, but this shape does not run on the window kernel: pixel-major copy, once
@@ -1136,7 +1130,7 @@ def dgrad_weight(w):
         return hit[2], hit[3]
     Cout, Cin = w.shape[0], w.shape[1]
     planes = torch.empty((2, w.numel()), dtype=torch.bfloat16, device=w.device)
-    check(lib.cdae_wdgrad_planes(ptr(w), ptr(planes[0]), ptr(planes[1]), Cout, Cin, stream()))
+    check(lib.cdae_wdgrad_planes(ptr(w), *ptr2(planes), Cout, Cin, stream()))
     if len(_WDGRAD) > 4096:
         for k in [k for k, v in _WDGRAD.items() if v[0]() is None]:
             del _WDGRAD[k]
@@ -1159,21 +1153,21 @@ class _GNConvPS(Function):
         st = stream()
         stats = torch.empty((2, N, groups), dtype=torch.float32, device=dev)
         gws = workspace(dev, "gn", 4 * lib.cdae_gn_workspace_floats(N, C))
-        check(lib.cdae_gn_stats(ptr(x), N, H * W, C, C, groups, eps, ptr(stats[0]), ptr(stats[1]), ptr(gws), st))
+        check(lib.cdae_gn_stats(ptr(x), N, H * W, C, C, groups, eps, *ptr2(stats), ptr(gws), st))
         ld_ss = 2 * C
         if ss is not None:         # [N, 2C] rows; may be a column slice of the batched emb_layers GEMM (row pitch > 2C)
             assert ss.shape == (N, 2 * C) and ss.stride(1) == 1 and ss.dtype == torch.float32
             ld_ss = ss.stride(0)
         planes = torch.empty((2, N, H, W, C), dtype=torch.float16, device=dev)            # forward operand (dropped after the conv)
         bplanes = torch.empty((2, N, H, W, C), dtype=torch.bfloat16, device=dev)          # kept for wgrad
-        check(lib.cdae_gn_apply_split_train(ptr(x), ptr(planes[0]), ptr(planes[1]), ptr(bplanes[0]), ptr(bplanes[1]), N, H * W, C, C, C, groups,
-                                            ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta), ptr(ss), ld_ss, 1 if silu else 0, st))
+        check(lib.cdae_gn_apply_split_train(ptr(x), *ptr2(planes), *ptr2(bplanes), N, H * W, C, C, C, groups,
+                                            *ptr2(stats), ptr(gamma), ptr(beta), ptr(ss), ld_ss, 1 if silu else 0, st))
         w_hi, w_lo = split_weight(w)
         out = new_act(N, Cout, H, W, dev)
         if res is not None:
             res = to_nhwc(res)
         ws, wsb = _sk(dev)
-        check(lib.cdae_conv3x3_fwd_psk(ptr(planes[0]), ptr(planes[1]), H * W * C, W * C, C, ptr(w_hi), ptr(w_lo), *_pk(w, False), ptr(b), ptr(res), ptr(out), Cout,
+        check(lib.cdae_conv3x3_fwd_psk(*ptr2(planes), H * W * C, W * C, C, ptr(w_hi), ptr(w_lo), *_pk(w, False), ptr(b), ptr(res), ptr(out), Cout,
                                       0, None, None, None, N, H, W, C, Cout, 1, 0, ws, wsb, st))
         ctx.save_for_backward(x, gamma, beta, ss, stats, bplanes, w)
         ctx.cfg = (silu, groups, b is not None, res is not None)
@@ -1194,7 +1188,7 @@ class _GNConvPS(Function):
         (gg, rg), (gbt, rbt), (gw, rw), (gb, rb) = ctx.sinks
         dx = dgamma = dbeta = dss = dw = db = dres = None
         dplanes = torch.empty((2, N, H, W, Cout), dtype=torch.bfloat16, device=dev)          # dy once as bf16 planes: dgrad and wgrad
-        check(lib.cdae_split_bf16(ptr(dy), ptr(dplanes[0]), ptr(dplanes[1]), dy.numel(), st))
+        check(lib.cdae_split_bf16(ptr(dy), *ptr2(dplanes), dy.numel(), st))
         # --- wgrad: saved activation planes x gradient planes, window kernel
         if ctx.needs_input_grad[4]:
             direct = gw is not None and w.stride() == gw.stride() and (not has_b or gb is not None)
@@ -1203,7 +1197,7 @@ class _GNConvPS(Function):
             else:
                 dw = torch.empty_like(w)
                 db = torch.empty(Cout, dtype=torch.float32, device=dev) if has_b else None
-            check(lib.cdae_conv3x3_wgrad_win(ptr(planes[0]), ptr(planes[1]), ptr(dplanes[0]), ptr(dplanes[1]), ptr(dw), ptr(db), N, H, W, C, Cout,
+            check(lib.cdae_conv3x3_wgrad_win(*ptr2(planes), *ptr2(dplanes), ptr(dw), ptr(db), N, H, W, C, Cout,
                                              1 if direct else 0, ws, wsb, st))
             if direct:
                 dw = db = None
@@ -1212,7 +1206,7 @@ class _GNConvPS(Function):
         if any(ctx.needs_input_grad[:4]):
             wt_hi, wt_lo = dgrad_weight(w)
             dyn = new_act(N, C, H, W, dev)
-            check(lib.cdae_conv3x3_dgrad_psk(ptr(dplanes[0]), ptr(dplanes[1]), ptr(wt_hi), ptr(wt_lo), *_pk(w, True), ptr(dyn), C, N, H, W, C, Cout, ws, wsb, st))
+            check(lib.cdae_conv3x3_dgrad_psk(*ptr2(dplanes), ptr(wt_hi), ptr(wt_lo), *_pk(w, True), ptr(dyn), C, N, H, W, C, Cout, ws, wsb, st))
             dx = new_act(N, C, H, W, dev)
             direct = gg is not None and gbt is not None
             dgamma = gg if direct else torch.empty_like(gamma)
@@ -1220,7 +1214,7 @@ class _GNConvPS(Function):
             sink = ctx.ss_sink
             dss = None if ss is None else (sink if sink is not None else torch.empty((N, 2 * C), dtype=torch.float32, device=dev))
             gws = workspace(dev, "gn", 4 * lib.cdae_gn_workspace_floats(N, C))
-            check(lib.cdae_gn_bwd(ptr(x), ptr(dyn), ptr(dx), N, H * W, C, C, C, C, groups, ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta),
+            check(lib.cdae_gn_bwd(ptr(x), ptr(dyn), ptr(dx), N, H * W, C, C, C, C, groups, *ptr2(stats), ptr(gamma), ptr(beta),
                                   ptr(ss), 2 * C if ss is None else ss.stride(0), 1 if silu else 0, ptr(dgamma), ptr(dbeta), 1 if direct else 0,
                                   ptr(dss), 2 * C if dss is None else dss.stride(0), 0, ptr(gws), st))
             if sink is not None:
@@ -1247,11 +1241,11 @@ class _UpConvPS(Function):
         st = stream()
         planes = torch.empty((2, N, 2 * H, 2 * W, C), dtype=torch.float16, device=dev)
         bplanes = torch.empty((2, N, 2 * H, 2 * W, C), dtype=torch.bfloat16, device=dev)
-        check(lib.cdae_upsample2_split(ptr(x), ptr(planes[0]), ptr(planes[1]), ptr(bplanes[0]), ptr(bplanes[1]), N, H, W, C, st))
+        check(lib.cdae_upsample2_split(ptr(x), *ptr2(planes), *ptr2(bplanes), N, H, W, C, st))
         w_hi, w_lo = split_weight(w)
         out = new_act(N, Cout, 2 * H, 2 * W, dev)
         ws, wsb = _sk(dev)
-        check(lib.cdae_conv3x3_fwd_psk(ptr(planes[0]), ptr(planes[1]), 4 * H * W * C, 2 * W * C, C, ptr(w_hi), ptr(w_lo), *_pk(w, False), ptr(b), None, ptr(out), Cout,
+        check(lib.cdae_conv3x3_fwd_psk(*ptr2(planes), 4 * H * W * C, 2 * W * C, C, ptr(w_hi), ptr(w_lo), *_pk(w, False), ptr(b), None, ptr(out), Cout,
                                       0, None, None, None, N, 2 * H, 2 * W, C, Cout, 1, 0, ws, wsb, st))
         ctx.save_for_backward(bplanes, w)
         ctx.cfg = (b is not None, (N, C, H, W))
@@ -1270,7 +1264,7 @@ class _UpConvPS(Function):
         (gw, rw), (gb, rb) = ctx.sinks
         dx = dw = db = None
         dplanes = torch.empty((2, N, 2 * H, 2 * W, Cout), dtype=torch.bfloat16, device=dev)
-        check(lib.cdae_split_bf16(ptr(dy), ptr(dplanes[0]), ptr(dplanes[1]), dy.numel(), st))
+        check(lib.cdae_split_bf16(ptr(dy), *ptr2(dplanes), dy.numel(), st))
         if ctx.needs_input_grad[1]:
             direct = gw is not None and w.stride() == gw.stride() and (not has_b or gb is not None)
             if direct:
@@ -1278,7 +1272,7 @@ class _UpConvPS(Function):
             else:
                 dw = torch.empty_like(w)
                 db = torch.empty(Cout, dtype=torch.float32, device=dev) if has_b else None
-            check(lib.cdae_conv3x3_wgrad_win(ptr(bplanes[0]), ptr(bplanes[1]), ptr(dplanes[0]), ptr(dplanes[1]), ptr(dw), ptr(db), N, 2 * H, 2 * W, C,
+            check(lib.cdae_conv3x3_wgrad_win(*ptr2(bplanes), *ptr2(dplanes), ptr(dw), ptr(db), N, 2 * H, 2 * W, C,
                                              Cout, 1 if direct else 0, ws, wsb, st))
             if direct:
                 dw = db = None
@@ -1286,7 +1280,7 @@ class _UpConvPS(Function):
         if ctx.needs_input_grad[0]:
             wt_hi, wt_lo = dgrad_weight(w)
             dxu = new_act(N, C, 2 * H, 2 * W, dev)
-            check(lib.cdae_conv3x3_dgrad_psk(ptr(dplanes[0]), ptr(dplanes[1]), ptr(wt_hi), ptr(wt_lo), *_pk(w, True), ptr(dxu), C, N, 2 * H, 2 * W, C, Cout, ws, wsb, st))
+            check(lib.cdae_conv3x3_dgrad_psk(*ptr2(dplanes), ptr(wt_hi), ptr(wt_lo), *_pk(w, True), ptr(dxu), C, N, 2 * H, 2 * W, C, Cout, ws, wsb, st))
             dx = new_act(N, C, H, W, dev)
             check(lib.cdae_sumpool2(ptr(dxu), ptr(dx), N, H, W, C, st))
         return dx, dw, db
@@ -1322,24 +1316,23 @@ def _rb_gn_planes(x, gamma, beta, ss, silu, groups, eps, st, x2=None):
     bplanes = torch.empty((2, N, H, W, C), dtype=torch.bfloat16, device=dev)
     ld_ss = 2 * C if ss is None else ss.stride(0)
     if x2 is None:
-        check(lib.cdae_gn_stats(ptr(x), N, H * W, C, C, groups, eps, ptr(stats[0]), ptr(stats[1]), ptr(gws), st))
-        check(lib.cdae_gn_apply_split_train(ptr(x), ptr(planes[0]), ptr(planes[1]), ptr(bplanes[0]), ptr(bplanes[1]), N, H * W, C, C, C, groups,
-                                            ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta), ptr(ss), ld_ss, 1 if silu else 0, st))
+        check(lib.cdae_gn_stats(ptr(x), N, H * W, C, C, groups, eps, *ptr2(stats), ptr(gws), st))
+        check(lib.cdae_gn_apply_split_train(ptr(x), *ptr2(planes), *ptr2(bplanes), N, H * W, C, C, C, groups,
+                                            *ptr2(stats), ptr(gamma), ptr(beta), ptr(ss), ld_ss, 1 if silu else 0, st))
     else:
         C2 = C - C1
-        check(lib.cdae_gn_stats2(ptr(x), C1, ptr(x2), C2, C1, N, H * W, C, groups, eps, ptr(stats[0]), ptr(stats[1]), ptr(gws), st))
-        check(lib.cdae_gn_apply_split_train2(ptr(x), C1, ptr(x2), C2, C1, ptr(planes[0]), ptr(planes[1]), ptr(bplanes[0]), ptr(bplanes[1]), N, H * W, C,
-                                             C, groups, ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta), ptr(ss), ld_ss, 1 if silu else 0, st))
+        check(lib.cdae_gn_stats2(ptr(x), C1, ptr(x2), C2, C1, N, H * W, C, groups, eps, *ptr2(stats), ptr(gws), st))
+        check(lib.cdae_gn_apply_split_train2(ptr(x), C1, ptr(x2), C2, C1, *ptr2(planes), *ptr2(bplanes), N, H * W, C,
+                                             C, groups, *ptr2(stats), ptr(gamma), ptr(beta), ptr(ss), ld_ss, 1 if silu else 0, st))
     return stats, planes, bplanes
 
 
 def _rb_conv(planes, w, b, res, shape, Cout, st):
     N, C, H, W = shape
     dev = planes.device
-    w_hi, w_lo = split_weight(w)
     out = new_act(N, Cout, H, W, dev)
     ws, wsb = _sk(dev)
-    check(lib.cdae_conv3x3_fwd_psk(ptr(planes[0]), ptr(planes[1]), H * W * C, W * C, C, ptr(w_hi), ptr(w_lo), *_pk(w, False), ptr(b), ptr(res), ptr(out), Cout,
+    check(lib.cdae_conv3x3_fwd_psk(*ptr2(planes), H * W * C, W * C, C, *_wptrs(w, False), ptr(b), ptr(res), ptr(out), Cout,
                                   0, None, None, None, N, H, W, C, Cout, 1, 0, ws, wsb, st))
     return out
 
@@ -1358,14 +1351,13 @@ def _rb_conv_bwd(bplanes, dplanes, w, sinks, has_b, shape, Cout, need_w, st):
         else:
             dw = torch.empty_like(w)
             db = torch.empty(Cout, dtype=torch.float32, device=dev) if has_b else None
-        check(lib.cdae_conv3x3_wgrad_win(ptr(bplanes[0]), ptr(bplanes[1]), ptr(dplanes[0]), ptr(dplanes[1]), ptr(dw), ptr(db), N, H, W, C, Cout,
+        check(lib.cdae_conv3x3_wgrad_win(*ptr2(bplanes), *ptr2(dplanes), ptr(dw), ptr(db), N, H, W, C, Cout,
                                          1 if direct else 0, ws, wsb, st))
         if direct:
             dw = db = None
             _done(rw, rb)
-    wt_hi, wt_lo = dgrad_weight(w)
     dyn = new_act(N, C, H, W, dev)
-    check(lib.cdae_conv3x3_dgrad_psk(ptr(dplanes[0]), ptr(dplanes[1]), ptr(wt_hi), ptr(wt_lo), *_pk(w, True), ptr(dyn), C, N, H, W, C, Cout, ws, wsb, st))
+    check(lib.cdae_conv3x3_dgrad_psk(*ptr2(dplanes), *_wptrs(w, True), ptr(dyn), C, N, H, W, C, Cout, ws, wsb, st))
     return dyn, dw, db
 
 
@@ -1435,10 +1427,10 @@ class _ResBlockPS(Function):
             sink = ctx.ss_sink if ssv is not None else None
             dss = None if ssv is None else (sink if sink is not None else torch.empty((N, 2 * Cn), dtype=torch.float32, device=dev))
             gws = workspace(dev, "gn", 4 * lib.cdae_gn_workspace_floats(N, Cn))
-            check(lib.cdae_gn_bwd_ex(ptr(xin), ptr(dyn), ptr(dx), N, H * W, Cn, Cn, Cn, Cn, groups, ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(beta),
+            check(lib.cdae_gn_bwd_ex(ptr(xin), ptr(dyn), ptr(dx), N, H * W, Cn, Cn, Cn, Cn, groups, *ptr2(stats), ptr(gamma), ptr(beta),
                                      ptr(ssv), 2 * Cn if ssv is None else ssv.stride(0), 1, ptr(dgamma), ptr(dbeta), 1 if direct else 0,
                                      ptr(dss), 2 * Cn if dss is None else dss.stride(0), 1 if acc_dx else 0, ptr(dx_add), Cn,
-                                     ptr(planes_out[0]) if planes_out is not None else None, ptr(planes_out[1]) if planes_out is not None else None,
+                                     *(ptr2(planes_out) if planes_out is not None else (None, None)),
                                      ptr(gws), st))
             if direct:
                 dgamma = dbeta = None
@@ -1447,7 +1439,7 @@ class _ResBlockPS(Function):
 
         # ---- second half: conv2 and GN2
         dplanes = torch.empty((2, N, H, W, Cout), dtype=torch.bfloat16, device=dev)
-        check(lib.cdae_split_bf16(ptr(dout), ptr(dplanes[0]), ptr(dplanes[1]), dout.numel(), st))
+        check(lib.cdae_split_bf16(ptr(dout), *ptr2(dplanes), dout.numel(), st))
         dyn2, dw2, dc2b = _rb_conv_bwd(bplanes2, dplanes, w2, (sw2, sc2b), has_c2b, (N, Cout, H, W), Cout, need[9], st)
         # dh leaves GN2's backward as bf16 planes only (it is nothing but conv1's dy); `dplanes` is reused for it
         dg2, db2, dss = gn_bwd(h, dyn2, stats2, g2, b2, ss, (sg2, sb2), Cout, None, False, None, dplanes)
@@ -1606,10 +1598,10 @@ def linear_emit(rows, w, b, res, shape):
     if _stream_gemm_ok(rows, M, Nf, K, ACT_NONE, 1.0, res):
         wh, wl = split_weight(w)
         check(lib.cdae_linear_fwd_stream(ptr(rows), rows.stride(0), K, None, 0, ptr(wh), ptr(wl), K, ptr(b), ptr(res), 0 if res is None else res.stride(0),
-                                         ptr(y), Nf, ptr(planes[0]), ptr(planes[1]), M, Nf, K, stream()))
+                                         ptr(y), Nf, *ptr2(planes), M, Nf, K, stream()))
         return y, SplitAct(planes[0], planes[1], shape)
     ws, wsb = _sk(rows.device)
-    check(lib.cdae_linear_fwd(ptr(rows), rows.stride(0), ptr(w), K, ptr(b), ptr(res), ptr(y), Nf, ptr(planes[0]), ptr(planes[1]),
+    check(lib.cdae_linear_fwd(ptr(rows), rows.stride(0), ptr(w), K, ptr(b), ptr(res), ptr(y), Nf, *ptr2(planes),
                               M, Nf, K, 1.0, ACT_NONE, ws, wsb, stream()))
     return y, SplitAct(planes[0], planes[1], shape)
 

@@ -10,6 +10,7 @@ microbatching, KL-weight warm-up, lr anneal, EMA, checkpoint names) on an MI355X
 """
 import copy
 import os
+import time
 
 import numpy as np
 import torch as th
@@ -268,6 +269,7 @@ class TrainLoop:
         self._graphs, self._graph_failed, self._eager_steps = {}, False, 0
         ra = os.environ.get("CDAE_TRAIN_RUNAHEAD", "1")
         self.run_ahead, self._step_events = (None if ra in ("", "none") else max(1, int(ra))), []
+        self.throttle_poll_s = float(os.environ.get("CDAE_TRAIN_THROTTLE_POLL", "0.0005"))
 
     # ------------------------------------------------------------------ loop
     def run_loop(self):
@@ -389,11 +391,16 @@ class TrainLoop:
         launch threads and RCCL's proxies."""
         if self.run_ahead is None or dist_util.dev().type != "cuda":
             return
-        ev = th.cuda.Event(blocking=True)
+        ev = th.cuda.Event()
         ev.record()
         self._step_events.append(ev)
         if len(self._step_events) > self.run_ahead:
-            self._step_events.pop(0).synchronize()
+            old = self._step_events.pop(0)
+            if self.throttle_poll_s > 0:
+                while not old.query():              # (hipEventSynchronize spins, blocking-sync flag or not: measured 43 vs 38 ms of CPU per step)
+                    time.sleep(self.throttle_poll_s)
+            else:
+                old.synchronize()
 
     def _anneal_lr(self):
         self._lr = self.lr

@@ -127,14 +127,6 @@ int cdae_conv3x3_dgrad_psk(const unsigned short* dy_hi, const unsigned short* dy
 int cdae_gn_stats_from_parts(const float* part1, int C1, int nseg1 /* 1, or 4 for a sub-pixel up-conv result */, const float* part2, int C2,
                              int nseg2, int N, int HW, int groups, float eps, float* mean, float* rstd,
                              float* ws /* N * (C1 + C2) * 4 floats, 8-byte aligned */, void* stream);
-/* The ResBlock prologue GroupNorm32 -> SiLU -> conv3x3 (unet.py:142-146,154-161,187-197) as ONE kernel: the conv stages its
-   activation window from the norm's fp32 INPUT (x1 | x2 = the skip concatenation, pixel pitches ld1 / ld2) and applies the norm,
-   scale-shift and SiLU on the way into LDS; the normalised tensor never exists in HBM.  coef = cdae_gn_coef's [N][Cin][2] affine.
-   Stride 1, rows <= 64 pixels, dense NHWC; results bit-identical to cdae_gn_apply_split + cdae_conv3x3_fwd_ps. */
-int cdae_conv3x3_fwd_gn(const float* x1, long ld1, int C1, const float* x2, long ld2, const float* coef, int silu, const unsigned short* w_hi,
-                        const unsigned short* w_lo, const float* bias, const float* res, float* out, long ldo, unsigned short* out_hi,
-                        unsigned short* out_lo, float* gn_part, int N, int H, int W, int Cin, int Cout, float* splitk_ws, size_t splitk_ws_bytes,
-                        void* stream);
 int cdae_gn_coef(const float* mean, const float* rstd, const float* gamma, const float* beta, const float* scale_shift, int ld_ss, float* coef,
                  int N, int C, int groups, void* stream);
 /* nearest-2x upsample + conv3x3 (unet.py:67-76) as four 2x2 sub-pixel convolutions of the low-resolution input: 2.25x fewer
