@@ -56,8 +56,7 @@ int cdae_conv3x3_fwd(const float* x, long sn, long sy, long sx, long sc, const f
     if (up && stride != 1) return cdae_fail("conv3x3: fused upsample needs stride 1");
     const int Ho = up ? 2 * H : (H - 1) / stride + 1, Wo = up ? 2 * W : (W - 1) / stride + 1;
     // the network's input conv (1..4 channels): exact-fp32 streaming kernel of stem.hip instead of a 36-deep implicit GEMM
-    if (stride == 1 && !up && !out_nchw && !res && cdae_conv3x3_stem_supported(Cin, Cout, W) && ldo % 4 == 0 && aligned16(out) && aligned16(bias) &&
-        cdae_get_default_precision() != CDAE_PREC_MIXED16)
+    if (stride == 1 && !up && !out_nchw && !res && cdae_conv3x3_stem_supported(Cin, Cout, W) && ldo % 4 == 0 && aligned16(out) && aligned16(bias))
         return cdae_conv3x3_stem(x, sn, sy, sx, sc, w, bias, out, ldo, N, H, W, Cin, Cout, stream);
     GemmParams p = base_params();
     p.A = x; p.B = w; p.C = out; p.bias = bias; p.res = res;
@@ -236,7 +235,7 @@ int cdae_conv3x3_wgrad(const float* x, long sn, long sy, long sx, long sc, const
     const int Ho = up ? 2 * H : (H - 1) / stride + 1, Wo = up ? 2 * W : (W - 1) / stride + 1;
     // a handful of output channels over a dense NHWC input (the UNet's `out` conv): the sliding-window FMA kernel of wgrad.hip
     if (Cout <= 8 && stride == 1 && !up && sc == 1 && Cin % 4 == 0 && Cin >= 32 && sx == Cin && sy == (long)W * Cin && sn == (long)H * W * Cin &&
-        splitk_ws && cdae_get_default_precision() != CDAE_PREC_MIXED16)
+        splitk_ws)       // (exact fp32 in every precision mode: a 1..8-row GEMM has nothing for the matrix cores — as igemm it took 969 us on the M32 model)
         return cdae_conv3x3_wgrad_fewout(x, dy, lddy, dw, dbias, N, H, W, Cin, Cout, accumulate, splitk_ws, splitk_ws_bytes, stream);
     GemmParams p = base_params();
     p.A = dy; p.B = x; p.C = dw;
@@ -273,7 +272,8 @@ int cdae_conv3x3_dgrad_psk(const unsigned short* dy_hi, const unsigned short* dy
     if (Cout % 32 || !aligned16(dy_hi) || !aligned16(dy_lo) || !aligned16(wt_hi) || !aligned16(wt_lo))
         return cdae_fail("conv3x3_dgrad_ps: Cout % 32 == 0 and 16-byte aligned planes required");
     GemmParams p = base_params();
-    p.presplit = 1; p.prec = 2; p.grad_operand = 1;
+    p.presplit = 1; p.grad_operand = 1;
+    p.prec = cdae_get_default_precision() == CDAE_PREC_MIXED16 ? 4 : 2;      // bf16 planes: hi / lo pairs (bf16x3) or the hi plane alone (mixed16)
     p.A = reinterpret_cast<const float*>(dy_hi); p.A_lo = dy_lo; p.B = reinterpret_cast<const float*>(wt_hi); p.B_lo = wt_lo;
     p.Bk_hi = wtk_hi; p.Bk_lo = wtk_lo;
     p.C = dx;

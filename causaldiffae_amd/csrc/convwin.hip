@@ -50,7 +50,7 @@ constexpr int CW_BM = 256, CW_BN = 128;
 constexpr int CW_A_PLANE = 12288, CW_A_HALF = 2 * CW_A_PLANE;               // 384 rows x 32 B
 constexpr int CW_B_BASE = 2 * CW_A_HALF, CW_B_KH = 4096, CW_B_PLANE = 2 * CW_B_KH, CW_B_STAGE = 2 * CW_B_PLANE;
 constexpr int CW_LDS = CW_B_BASE + 2 * CW_B_STAGE;                           // 81920
-constexpr int CW_WIN_DMAS = 6;                                               // window DMAs per wave per reload: 3 row blocks x 2 planes
+constexpr int CW_WIN_ROWBLOCKS = 3;                                          // window DMAs per wave per reload: 3 row blocks x NPL planes
 // Fragment reads of taps that fall on padding go to an LDS address beyond every allocation: the hardware returns zeros for
 // out-of-range DS reads (tools/hiptests/lds_oob.hip; tests/test_gpu_kernels.py::test_lds_out_of_range_reads_return_zero), which
 // replaces eight v_and per 16-row tile and K-step — the loop's vector-issue budget belongs to the MFMAs.
@@ -74,7 +74,9 @@ __device__ __forceinline__ void cw_dma(const void* sbase, int soff, unsigned vof
 
 // NT = 9: the 3x3 window.  NT = 4: the 2x2 window of one sub-pixel phase (ph_y, ph_x) of nearest-2x-upsample + conv3x3 (tap t reads window
 // position (t / 2 + ph_y, t % 2 + ph_x) of the same 3x3 neighbourhood; weights [rows][4][K]; result scattered to (2y + ph_y, 2x + ph_x)).
-template <bool BF, int NT>
+// NPL = 2: hi / lo plane pairs, three MFMAs per product (the fp32-parity modes).  NPL = 1: ONE plane per operand and one MFMA per product —
+// the reduced-precision torso (`mixed16`: f16 forward, bf16 dgrad); the lo halves of the LDS image stay unused.
+template <bool BF, int NT, int NPL = 2>
 __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, const int ntiles) {
     typedef const unsigned short* hp;
 
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             cw_dma(a_hi, g * gstride, aoffb[q], dst + q * 4096);
-            cw_dma(a_lo, g * gstride, aoffb[q], dst + q * 4096 + CW_A_PLANE);
+            if constexpr (NPL == 2) cw_dma(a_lo, g * gstride, aoffb[q], dst + q * 4096 + CW_A_PLANE);
         }
     };
     // weights of the step whose first unit is (g, t) -> stage
@@ -169,8 +171,10 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
         else { ea = (t * p.Cin + g * 16) * 2; eb = (tb * p.Cin + gb * 16) * 2; }
         cw_dma(b_hi, ea, woffb, dst);
         cw_dma(b_hi, eb, woffb, dst + CW_B_KH);
-        cw_dma(b_lo, ea, woffb, dst + CW_B_PLANE);
-        cw_dma(b_lo, eb, woffb, dst + CW_B_PLANE + CW_B_KH);
+        if constexpr (NPL == 2) {
+            cw_dma(b_lo, ea, woffb, dst + CW_B_PLANE);
+            cw_dma(b_lo, eb, woffb, dst + CW_B_PLANE + CW_B_KH);
+        }
     };
     auto issue_prologue = [&]() {
         if (nsteps == 0) return;
@@ -233,12 +237,14 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
         int wtap_c; unsigned a_c;
         geom(ga, ta, wtap_c, a_c);
         unsigned b_c = b_lane;                 // this step's weight stage
-        u32x4 bh[4], bl[4], ah[2], al[2];
+        u32x4 bh[4], ah[2], bl_[NPL == 2 ? 4 : 1], al_[NPL == 2 ? 2 : 1];      // (one plane: the lo names alias the hi registers)
+#define al(C) (NPL == 2 ? al_[(NPL == 2) * (C)] : ah[C])
+#define bl(J) (NPL == 2 ? bl_[(NPL == 2) * (J)] : bh[J])
         // fragment address of padding taps -> out of range -> zeros
 #define CW_READ_A(I, BUF, WTAP, ADDR) { const unsigned m_ = (unsigned)__builtin_amdgcn_sbfe(tapmask[I], WTAP, 1); \
             const unsigned ad_ = (ADDR & m_) | (CW_OOB & ~m_); \
-            ah[BUF] = cw_lds_read<(I) * 512>(ad_); al[BUF] = cw_lds_read<(I) * 512 + CW_A_PLANE>(ad_); }
-#define CW_READ_B(J, ADDR) { bh[J] = cw_lds_read<(J) * 512>(ADDR); bl[J] = cw_lds_read<(J) * 512 + CW_B_PLANE>(ADDR); }
+            ah[BUF] = cw_lds_read<(I) * 512>(ad_); if constexpr (NPL == 2) al(BUF) = cw_lds_read<(I) * 512 + CW_A_PLANE>(ad_); }
+#define CW_READ_B(J, ADDR) { bh[J] = cw_lds_read<(J) * 512>(ADDR); if constexpr (NPL == 2) bl(J) = cw_lds_read<(J) * 512 + CW_B_PLANE>(ADDR); }
 #define CW_WAIT(...) asm volatile(__VA_ARGS__)
         if (nsteps > 0) {
             CW_READ_A(0, 0, wtap_c, a_c);
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                     // ---- mid-step: every wave holds this step's weight fragments in registers, so the stage is free for step s + 2;
                     // the weights of step s + 1 (issued one step ago) must have landed; a window reload issued after them may stay in flight
                     const unsigned long long t1_ = now();
-                    if (reload_prev) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CW_WIN_DMAS) : "memory");
+                    if (reload_prev) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CW_WIN_ROWBLOCKS * NPL) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     const unsigned long long t2_ = now();
                     if (!(dbg_ & 8)) __builtin_amdgcn_s_barrier();
@@ -297,10 +303,18 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                 };
                 if (i == 4) midstep();
                 // tile 0 needs A(0) and B(0) of the ten reads in flight; every other tile's A pair is the only thing outstanding
-                if (i == 0) CW_WAIT("s_waitcnt lgkmcnt(6)" : "+v"(ah[0]), "+v"(al[0]), "+v"(bh[0]), "+v"(bl[0]));
-                else CW_WAIT("s_waitcnt lgkmcnt(0)" : "+v"(ah[cur]), "+v"(al[cur]));
-                acc[i][0] = mma(al[cur], bh[0], acc[i][0]);
-                acc[i][0] = mma(ah[cur], bl[0], acc[i][0]);
+                // (one plane: never list a register twice — the aliased lo names would make hipcc copy a fragment whose read is still in flight)
+                if constexpr (NPL == 2) {
+                    if (i == 0) CW_WAIT("s_waitcnt lgkmcnt(6)" : "+v"(ah[0]), "+v"(al(0)), "+v"(bh[0]), "+v"(bl(0)));
+                    else CW_WAIT("s_waitcnt lgkmcnt(0)" : "+v"(ah[cur]), "+v"(al(cur)));
+                } else {
+                    if (i == 0) CW_WAIT("s_waitcnt lgkmcnt(3)" : "+v"(ah[0]), "+v"(bh[0]));
+                    else CW_WAIT("s_waitcnt lgkmcnt(0)" : "+v"(ah[cur]));
+                }
+                if constexpr (NPL == 2) {
+                    acc[i][0] = mma(al(cur), bh[0], acc[i][0]);
+                    acc[i][0] = mma(ah[cur], bl(0), acc[i][0]);
+                }
                 acc[i][0] = mma(ah[cur], bh[0], acc[i][0]);
                 __builtin_amdgcn_sched_barrier(0);
                 // the next tile's fragment reads go out behind the first three MFMAs and have nine MFMAs to land
@@ -316,9 +330,12 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
 #pragma unroll
                 for (int j = 1; j < 4; ++j) {
                     // tile 0: B(j) is the oldest of the reads in flight [B(j) .. B(3), A(1)]
-                    if (i == 0) CW_WAIT("s_waitcnt lgkmcnt(%2)" : "+v"(bh[j]), "+v"(bl[j]) : "n"(8 - 2 * j));
-                    acc[i][j] = mma(al[cur], bh[j], acc[i][j]);
-                    acc[i][j] = mma(ah[cur], bl[j], acc[i][j]);
+                    if constexpr (NPL == 2) { if (i == 0) CW_WAIT("s_waitcnt lgkmcnt(%2)" : "+v"(bh[j]), "+v"(bl(j)) : "n"(8 - 2 * j)); }
+                    else { if (i == 0) CW_WAIT("s_waitcnt lgkmcnt(%1)" : "+v"(bh[j]) : "n"(4 - j)); }
+                    if constexpr (NPL == 2) {
+                        acc[i][j] = mma(al(cur), bh[j], acc[i][j]);
+                        acc[i][j] = mma(ah[cur], bl(j), acc[i][j]);
+                    }
                     acc[i][j] = mma(ah[cur], bh[j], acc[i][j]);
                     if (i == 7) {
                         __builtin_amdgcn_sched_barrier(0);
@@ -330,6 +347,8 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
             }
             ta = tn; ga = gn; wtap_c = wtap_n; a_c = a_n; b_c = b_n;
         }
+#undef al
+#undef bl
 #undef CW_READ_A
 #undef CW_READ_B
 #undef CW_WAIT
@@ -500,18 +519,18 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
     }
 }
 
-template <bool BF, int NT>
+template <bool BF, int NT, int NPL = 2>
 int launch_convwin(const GemmParams& p, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convwin_kernel<BF, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convwin_kernel<BF, NT, NPL>), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS) != hipSuccess)
             return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
         attr_done = true;
     }
     const long ntiles = (long)((p.M + CW_BM - 1) / CW_BM) * ((p.N + CW_BN - 1) / CW_BN) * p.ksplit * (p.nphase > 1 ? p.nphase : 1);
     static const int cfg_persist = CDAE_DEV_INT("CDAE_CONVWIN_GRID", 512);      // persistent blocks: two per CU
     dim3 grid((unsigned)(ntiles < cfg_persist ? ntiles : cfg_persist));
-    hipLaunchKernelGGL((convwin_kernel<BF, NT>), grid, dim3(256), CW_LDS, st, p, (int)ntiles);
+    hipLaunchKernelGGL((convwin_kernel<BF, NT, NPL>), grid, dim3(256), CW_LDS, st, p, (int)ntiles);
     return hipGetLastError() == hipSuccess ? 0 : cdae_fail("convwin_kernel launch failed");
 }
 
@@ -547,7 +566,8 @@ extern "C" int cdae_conv_wpack(const unsigned short* w_hi, const unsigned short*
 
 // Shapes this kernel takes (the dispatcher has already checked: stride 1, dense NHWC planes, row-major output).
 bool cdae_convwin_ok(const GemmParams& p) {
-    if (p.prec != 1 && p.prec != 2) return false;
+    if (p.prec < 1 || p.prec > 4) return false;                           // 1 / 2: f16 / bf16 plane pairs; 3 / 4: one f16 / bf16 plane (3x3 only)
+    if (p.prec > 2 && p.ps_taps == 4) return false;
     if (p.gn_coef || p.A2 || p.act != ACT_NONE) return false;
     if (p.ps_taps == 4 ? (p.out_mode != OUT_UP2 || p.prec != 1 || p.Bk_hi) : p.out_mode != OUT_ROWMAJOR) return false;
     if (p.W != 8 && p.W != 16 && p.W != 32 && p.W != 64) return false;            // tight window: tiles start on image-row boundaries
@@ -560,5 +580,7 @@ bool cdae_convwin_ok(const GemmParams& p) {
 int cdae_convwin_launch(const GemmParams& p, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (p.ps_taps == 4) return launch_convwin<false, 4>(p, st);
+    if (p.prec == 3) return launch_convwin<false, 9, 1>(p, st);          // mixed16: one f16 plane
+    if (p.prec == 4) return launch_convwin<true, 9, 1>(p, st);           // mixed16, gradient operand: one bf16 plane
     return p.prec == 2 ? launch_convwin<true, 9>(p, st) : launch_convwin<false, 9>(p, st);
 }

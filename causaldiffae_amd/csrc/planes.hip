@@ -537,9 +537,9 @@ int cdae_planes_dispatch(GemmParams& p, int big, int& ks, hipStream_t st) {
     if (!((p.amode == A_CONV_VEC || p.amode == A_PLAIN_KC) && p.bmode == B_PLAIN_KC) || p.batch != 1)
         return cdae_fail("pre-split operands: only K-contiguous conv / plain GEMMs without batch");
     const int kin = p.amode == A_CONV_VEC ? p.Cin : p.K;
-    if (kin % BK || p.K % BK || p.ldb % 8 || (p.amode == A_PLAIN_KC && p.lda % 8) || (p.prec != 1 && p.prec != 2 && p.prec != 3))
+    if (kin % BK || p.K % BK || p.ldb % 8 || (p.amode == A_PLAIN_KC && p.lda % 8) || (p.prec < 1 || p.prec > 4))
         return cdae_fail("pre-split operands: need K (Cin) % 32 == 0, 16-byte aligned rows and a 16-bit split precision mode");
-    if (p.prec == 2 && (p.gn_coef || p.ps_taps == 4)) return cdae_fail("pre-split bf16 planes: plain conv3x3 / GEMM only");
+    if ((p.prec == 2 || p.prec == 4) && (p.gn_coef || p.ps_taps == 4)) return cdae_fail("pre-split bf16 planes: plain conv3x3 / GEMM only");
     if (p.gn_coef) return cdae_fail("GroupNorm applied inside the conv kernel was removed (measured slower than writing planes once)");
     p.dbg = CDAE_DEV_INT("CDAE_PS_DBG", 0);
     // cdae_tune_set(CDAE_TUNE_CONVWIN_MIN_TILES, <= 1): every shape convwin_kernel can take runs on it, whatever the grid size (the
@@ -578,7 +578,7 @@ int cdae_planes_dispatch(GemmParams& p, int big, int& ks, hipStream_t st) {
         if (cw) {
             // algorithmic bytes: both activation planes, both weight planes, the fp32 result (+ the residual read)
             const double nph = p.nphase > 1 ? p.nphase : 1;      // (the phases of an up-conv share the input planes)
-            cdae_prof_note(p.ps_taps == 4 ? PROF_CONVWIN_UP : p.prec == 2 ? PROF_CONVWIN_DGRAD : PROF_CONVWIN,
+            cdae_prof_note(p.ps_taps == 4 ? PROF_CONVWIN_UP : (p.prec == 2 || p.prec == 4) ? PROF_CONVWIN_DGRAD : PROF_CONVWIN,
                            4.0 * p.M * p.Cin + nph * (4.0 * p.K * p.N + 4.0 * p.M * p.N * (p.res ? 2 : 1)));
             return cdae_convwin_launch(p, st);
         }
@@ -586,9 +586,10 @@ int cdae_planes_dispatch(GemmParams& p, int big, int& ks, hipStream_t st) {
         const bool tall = 256 % p.W == 0 && (long)((p.M + 255) / 256) * ((p.N + 127) / 128) * ks >= 512;
         if (p.prec == 2) return tall ? launch_pswin<2, 384, 2, 256, true>(p, st) : launch_pswin<2, 272, 4, 128, true>(p, st);
         if (p.prec == 1) return tall ? launch_pswin<2, 384, 2, 256>(p, st) : launch_pswin<2, 272, 4, 128>(p, st);
-        return launch_pswin<1, 272, 4, 128>(p, st);
+        return p.prec == 4 ? launch_pswin<1, 272, 4, 128, true>(p, st) : launch_pswin<1, 272, 4, 128>(p, st);
     }
     if (p.prec == 2) return big ? launch_ps<128, 128, 2, 4, 2, true>(p, st) : launch_ps<64, 64, 2, 2, 2, true>(p, st);
     if (p.prec == 1) return big ? launch_ps<128, 128, 2, 4, 2>(p, st) : launch_ps<64, 64, 2, 2, 2>(p, st);
+    if (p.prec == 4) return big ? launch_ps<128, 128, 2, 4, 1, true>(p, st) : launch_ps<64, 64, 2, 2, 1, true>(p, st);
     return big ? launch_ps<128, 128, 2, 4, 1>(p, st) : launch_ps<64, 64, 2, 2, 1>(p, st);
 }

@@ -55,7 +55,8 @@ __device__ __forceinline__ int fdiv(int n, unsigned magic, int shift) {
 // LDS image: activations [plane 2][channel half 2][(RB + 1) * 16 rows][64 B], dy [stage 2][plane 2][channel half 2][64 rows][64 B]
 // NWAVES = 8: the block splits every 64-pixel step over two groups of 4 waves (pixels 0..31 / 32..63 of the step), i.e. two waves
 // per SIMD that cover each other's LDS latency; the second group's accumulators are added to the first's through LDS at the end.
-template <int NWAVES>
+// NPL = 1 (the `mixed16` torso): one bf16 plane per operand, one MFMA per product; the lo sub-planes are neither staged nor read.
+template <int NWAVES, int NPL = 2>
 __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void wgwin_kernel(const WgParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* const lds = reinterpret_cast<char*>(smem);
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void wgwin_kernel(const Wg
 
     // ---- DMA roles: wave w stages sub-plane (P = w >> 1, half = w & 1) of both operands
     const int dP = (wave >> 1) & 1, dH = wave & 1;
-    const bool dma_a = NWAVES == 4 || kg == 0, dma_d = NWAVES == 4 || kg == 1;      // 8 waves: group 0 stages activations, group 1 dy
+    const bool dma_a = (NWAVES == 4 || kg == 0) && (NPL == 2 || dP == 0), dma_d = (NWAVES == 4 || kg == 1) && (NPL == 2 || dP == 0);      // 8 waves: group 0 stages activations, group 1 dy
     const unsigned short* const a_src = (dP ? p.a_lo : p.a_hi) + ci0 + dH * 32 + (lane & 3) * 8;
     const unsigned short* const d_src = (dP ? p.d_lo : p.d_hi) + co0 + dH * 32 + (lane & 3) * 8;
     char* const a_dst = lds + (dP * 2 + dH) * A_SUB;
@@ -191,10 +192,14 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void wgwin_kernel(const Wg
                 const int sk = NWAVES == 8 ? __builtin_amdgcn_readfirstlane(2 * kg + ski) : ski;
                 u32x4 dh[3], dl[3];
                 dh[1] = frag(dy_hi + sk * 1024);
-                dl[1] = frag(dy_lo + sk * 1024);
-                dh[0] = dh[1]; dh[0][0] &= mL[ski]; dl[0] = dl[1]; dl[0][0] &= mL[ski];
-                dh[2] = dh[1]; dh[2][3] &= mR[ski]; dl[2] = dl[1]; dl[2][3] &= mR[ski];
-                if (do_colsum) { accb = mma(dh[1], ones, accb); accb = mma(dl[1], ones, accb); }
+                dh[0] = dh[1]; dh[0][0] &= mL[ski];
+                dh[2] = dh[1]; dh[2][3] &= mR[ski];
+                if constexpr (NPL == 2) {
+                    dl[1] = frag(dy_lo + sk * 1024);
+                    dl[0] = dl[1]; dl[0][0] &= mL[ski];
+                    dl[2] = dl[1]; dl[2][3] &= mR[ski];
+                }
+                if (do_colsum) { accb = mma(dh[1], ones, accb); if constexpr (NPL == 2) accb = mma(dl[1], ones, accb); }
                 // software pipeline over the taps: tap t + 1's fragments are requested BEFORE tap t's MFMAs are issued (left to itself
                 // hipcc reads each fragment right in front of its first use and waits for it: MFMA busy 0.44)
                 auto tap_src = [&](int t) -> const char* {
@@ -206,18 +211,20 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void wgwin_kernel(const Wg
                     return a_hi + __builtin_amdgcn_readfirstlane(rt * 64);
                 };
                 u32x4 fh[3], fl[3];                        // fragment sets of taps t, t + 1, t + 2 (two taps = 6 MFMAs of lookahead)
-                fh[0] = frag(tap_src(0)); fl[0] = frag(tap_src(0) + 2 * A_SUB);
-                fh[1] = frag(tap_src(1)); fl[1] = frag(tap_src(1) + 2 * A_SUB);
+                fh[0] = frag(tap_src(0)); if constexpr (NPL == 2) fl[0] = frag(tap_src(0) + 2 * A_SUB);
+                fh[1] = frag(tap_src(1)); if constexpr (NPL == 2) fl[1] = frag(tap_src(1) + 2 * A_SUB);
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
                     const int kx = t % 3;
                     if (t + 2 < 9) {
                         const char* src = tap_src(t + 2);
-                        fh[(t + 2) % 3] = frag(src); fl[(t + 2) % 3] = frag(src + 2 * A_SUB);
+                        fh[(t + 2) % 3] = frag(src); if constexpr (NPL == 2) fl[(t + 2) % 3] = frag(src + 2 * A_SUB);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    acc[t] = mma(dl[kx], fh[t % 3], acc[t]);
-                    acc[t] = mma(dh[kx], fl[t % 3], acc[t]);
+                    if constexpr (NPL == 2) {
+                        acc[t] = mma(dl[kx], fh[t % 3], acc[t]);
+                        acc[t] = mma(dh[kx], fl[t % 3], acc[t]);
+                    }
                     acc[t] = mma(dh[kx], fh[t % 3], acc[t]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -472,22 +479,23 @@ extern "C" int cdae_conv3x3_wgrad_win(const unsigned short* a_hi, const unsigned
     p.colsum = dbias;
     if (dbias && !accumulate && hipMemsetAsync(dbias, 0, sizeof(float) * Cout, st) != hipSuccess) return cdae_fail("dbias memset failed");
     const size_t smem = (size_t)4 * (p.RB + 1) * 16 * 64 + 2 * 4 * 64 * 64;
-    static const int cfg_waves = CDAE_DEV_INT("CDAE_WG_WAVES", 8);
+    // one bf16 plane per operand in the reduced-precision mode (the lo pointers are ignored), hi / lo pairs otherwise
+    const bool single = cdae_get_default_precision() == CDAE_PREC_MIXED16;
     static size_t attr_bytes = 0;
     if (smem > attr_bytes) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgwin_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&wgwin_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgwin_kernel<8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&wgwin_kernel<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
         attr_bytes = smem;
     }
     cdae_prof_begin(PROF_IGEMM, 2.0 * Cout * 9.0 * Cin * (double)N * p.HW, st);
     if (cdae_prof_on()) {
         char tag[128];
-        snprintf(tag, sizeof(tag), "wgwin %d->%d @%dx%d n=%d tiles=%ld ks=%d", Cin, Cout, H, W, N, tiles, ks);
+        snprintf(tag, sizeof(tag), "wgwin %d->%d @%dx%d n=%d tiles=%ld ks=%d planes=%d", Cin, Cout, H, W, N, tiles, ks, single ? 1 : 2);
         cdae_prof_tag(tag);
     }
-    if (cfg_waves == 8) hipLaunchKernelGGL(wgwin_kernel<8>, dim3((unsigned)(tiles * ks)), dim3(512), smem, st, p);
-    else hipLaunchKernelGGL(wgwin_kernel<4>, dim3((unsigned)(tiles * ks)), dim3(256), smem, st, p);
+    if (single) hipLaunchKernelGGL((wgwin_kernel<8, 1>), dim3((unsigned)(tiles * ks)), dim3(512), smem, st, p);
+    else hipLaunchKernelGGL((wgwin_kernel<8, 2>), dim3((unsigned)(tiles * ks)), dim3(512), smem, st, p);
     int rc = hipGetLastError() == hipSuccess ? 0 : cdae_fail("wgwin_kernel launch failed");
     if (rc == 0 && ks > 1) {
         const long n4 = (long)Cout * 9 * Cin / 4;

@@ -1111,11 +1111,12 @@ _WDGRAD = {}
 
 
 def train_presplit_ok(x, Cout, groups=32):
-    """GroupNorm -> (SiLU) -> conv3x3 as ONE autograd node on the pre-split kernels: grad mode, f16x3 precision, and a shape the
-    window wgrad kernel takes (channel counts % 64, rows of 8..64 pixels)."""
+    """GroupNorm -> (SiLU) -> conv3x3 as ONE autograd node on the pre-split kernels: grad mode, a plane precision mode (f16x3: hi / lo
+    pairs, three MFMAs per product; mixed16: the hi plane alone, one MFMA per product) and a shape the window wgrad kernel takes
+    (channel counts % 64, rows of 8..64 pixels)."""
     from ._lib import get_precision
     N, C, H, W = x if isinstance(x, tuple) else x.shape
-    return (_TRAIN_PS_ON and torch.is_grad_enabled() and get_precision() == "f16x3" and C % groups == 0 and (C // groups) % 4 == 0
+    return (_TRAIN_PS_ON and torch.is_grad_enabled() and get_precision() in ("f16x3", "mixed16") and C % groups == 0 and (C // groups) % 4 == 0
             and lib.cdae_conv3x3_wgrad_win_supported(N, H, W, C, Cout) == 1)
 
 
@@ -1289,7 +1290,7 @@ class _UpConvPS(Function):
 def upconv3x3_train_ok(x, Cout):
     from ._lib import get_precision
     N, C, H, W = x.shape
-    return (_TRAIN_PS_ON and torch.is_grad_enabled() and get_precision() == "f16x3" and x.dim() == 4
+    return (_TRAIN_PS_ON and torch.is_grad_enabled() and get_precision() in ("f16x3", "mixed16") and x.dim() == 4
             and lib.cdae_conv3x3_wgrad_win_supported(N, 2 * H, 2 * W, C, Cout) == 1)
 
 

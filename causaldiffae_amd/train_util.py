@@ -118,8 +118,21 @@ class GradBuckets:
         while self.next_launch < len(self.buckets) and self.buckets[self.next_launch]["pending"] == 0:
             b = self.buckets[self.next_launch]
             if b["work"] is None:
-                b["work"] = dist.all_reduce(self.flat.grad[b["lo"]:b["hi"]], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                b["work"] = self._all_reduce(b)
             self.next_launch += 1
+
+    def _all_reduce(self, b):
+        """Asynchronous all-reduce of one bucket, ordered EXPLICITLY behind the kernels that wrote it: the backward kernels were enqueued
+        through the C-ABI on the raw HIP stream of the thread that ran them (autograd's device thread), and this hook may run on another
+        thread — an event recorded on the launch stream and waited for on the stream the collective is issued from makes the ordering
+        independent of what torch believes the current stream of either thread to be (RCCL's own stream then waits on that one)."""
+        grad = self.flat.grad[b["lo"]:b["hi"]]
+        if grad.is_cuda:
+            ev = th.cuda.Event()
+            launch = th.cuda.ExternalStream(stream(), device=grad.device)      # the stream ops.* enqueue on (torch's current stream of this thread)
+            ev.record(launch)
+            th.cuda.current_stream(grad.device).wait_event(ev)
+        return dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _make_hook(self, i):
         def hook(_p):
@@ -148,7 +161,7 @@ class GradBuckets:
             return
         for b in self.buckets:             # in index order, like the hooks
             if b["work"] is None:
-                b["work"] = dist.all_reduce(self.flat.grad[b["lo"]:b["hi"]], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                b["work"] = self._all_reduce(b)
         for b in self.buckets:
             b["work"].wait()
         self.flat.grad.mul_(1.0 / self.world)

@@ -1028,6 +1028,27 @@ def test_resblock_training_node_forced_onto_window_kernel(N, C1, C2, Cout, H, ex
         assert (f.double().reshape(r.shape) - r).abs().max().item() < 3e-5 * r.abs().max().item(), n
 
 
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C1,C2,Cout,H", [(32, 128, 0, 128, 64), (32, 256, 128, 256, 32), (4, 128, 0, 256, 16), (64, 512, 0, 512, 8)])
+def test_resblock_training_node_mixed16_single_plane_kernels(N, C1, C2, Cout, H, expect_kernels):
+    """The reduced-precision torso (`mixed16`, reference unet.py:501-507 / fp16_util.py:9-15: an fp16 torso with fp32 master weights) on the
+    fused ResBlock node: ONE f16 plane per operand in the forward convs, ONE bf16 plane in dgrad and wgrad (convwin_kernel<.., 1 plane>,
+    wgwin_kernel<8, 1 plane>: one MFMA per product).  Against fp64 at the accuracy a 2^-8 (bf16) / 2^-11 (f16) significand gives — and
+    well away from the f16x3 path's 3e-5, i.e. the single-plane kernels really ran."""
+    from causaldiffae_amd._lib import precision_scope
+    with torch.enable_grad():
+        with precision_scope("mixed16"), expect_kernels(**({"convwin": 2, "convwin_dgrad": 2} if N >= 32 else {})):
+            names, got = _resblock_case(N, C1, C2, Cout, H, "node", seed=31)
+        _, ref = _resblock_case(N, C1, C2, Cout, H, "f64", seed=31)
+    worst = 0.0
+    for n, f, r in zip(names, got, ref):
+        e = (f.double().reshape(r.shape) - r).abs().max().item() / r.abs().max().item()
+        assert e < (4e-3 if n == "out" else 3e-2), (n, e)
+        worst = max(worst, e)
+    assert worst > 1e-4, worst
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("stream_kernel", [True, False])
 @pytest.mark.parametrize("N,C1,C2,Cout,H", [(4, 128, 128, 128, 32), (2, 256, 128, 256, 16), (3, 512, 384, 512, 8), (2, 128, 0, 256, 32),

@@ -1269,6 +1269,34 @@ def test_data_parallel_split_shards_gloo(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu(tmp_path):
+    """bench.py under the driver's launch line (`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`) with gloo
+    standing in for RCCL on the one GPU a test box has: both ranks enter the collectives (ranks_in_group == 2), the sampling leg is
+    batch-sharded (global batch = 2 x per-GPU batch, no collective in the loop), the training leg all-reduces its gradient buckets,
+    and the line carries the host-CPU accounting an 8-rank node needs (per-rank CPU per step against the cgroup quota)."""
+    import json, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {**os.environ, "CDAE_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--regions", "1",
+                        "--batch", "16", "--train-batch", "4", "--train-steps", "3"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]            # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_in_group"] == 2 and d["dist_backend"] == "gloo" and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 32 and d["steps"] == 3 and d["value"] > 0
+    t = d["train"]
+    assert "error" not in t, t
+    assert t["global_batch"] == 8 and t["dist_backend"] == "gloo" and np.isfinite(t["last_loss"])
+    assert t["host_cpu_ms_per_step"] > 0 and isinstance(t["host_bound_risk"], bool) and t["host_cpu_quota_cores"] >= 1
+
+
 @pytest.mark.gpu
 def test_encoder_classifier_matches_torch_modules():
     """nn.GaussianConvEncoderClf (the evaluation classifier the reference's image_causaldae_test.py builds): same state-dict layout as

@@ -14,13 +14,17 @@ from improved_diffusion import script_util as su
 from improved_diffusion.image_datasets import load_data
 from improved_diffusion.train_util import TrainLoop
 dev = torch.device("cuda:0")
-cfg = {**su.model_and_diffusion_defaults(), "image_size": 64, "in_channels": 3, "n_vars": 4, "rep_cond": True, "causal_modeling": True}
+M32 = os.environ.get("MODEL", "c64") == "m32"          # MODEL=m32 BATCH=256 FP16=1: BASELINE config [1] on the reduced-precision torso
+B = int(os.environ.get("BATCH", "256" if M32 else "32"))
+SZ, CH, NV = (32, 1, 2) if M32 else (64, 3, 4)
+cfg = {**su.model_and_diffusion_defaults(), "image_size": SZ, "in_channels": CH, "n_vars": NV, "rep_cond": True, "causal_modeling": True, "class_cond": M32}
 model, diff = su.create_model_and_diffusion(**cfg)
 bench.randomize(model, 4321)
 model.to(dev).train()
-data = load_data(data_dir="synthetic", batch_size=32, image_size=64, in_channels=3, n_vars=4, seed=0, device=dev)
-loop = TrainLoop(model=model, diffusion=diff, data=data, batch_size=32, microbatch=-1, lr=1e-4, ema_rate="0.9999", log_interval=10 ** 9,
-                 save_interval=10 ** 9, resume_checkpoint="", rep_cond=True, n_vars=4, causal_modeling=True, in_channels=3)
+data = load_data(data_dir="synthetic", batch_size=B, image_size=SZ, in_channels=CH, n_vars=NV, seed=0, device=dev, class_cond=M32)
+loop = TrainLoop(model=model, diffusion=diff, data=data, batch_size=B, microbatch=-1, lr=1e-4, ema_rate="0.9999", log_interval=10 ** 9,
+                 save_interval=10 ** 9, resume_checkpoint="", rep_cond=True, n_vars=NV, causal_modeling=True, in_channels=CH,
+                 use_fp16=os.environ.get("FP16") == "1")
 diff.kl_weight = 0.1
 for _ in range(3):
     b, c = next(data); loop.forward_backward(b, c); loop.optimize_normal()
