@@ -9,6 +9,10 @@ from improved_diffusion.train_util import TrainLoop
 import bench
 
 dev = torch.device("cuda:0")
+if os.environ.get("SETDEV") == "1":
+    torch.cuda.set_device(0)
+if os.environ.get("AVAIL") == "1":
+    assert torch.cuda.is_available() and torch.cuda.device_count() >= 1
 TICK = os.sysconf("SC_CLK_TCK")
 
 

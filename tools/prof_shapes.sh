@@ -13,6 +13,6 @@ timeout 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_C
 timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o f -- $CMD > $O/fetch.log 2>&1
 timeout 200 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/write -o w -- $CMD > $O/write.log 2>&1
 cd $R
-python3 tools/prof_shapes_fold.py $O > $O/r02_conv_shapes.md 2> $O/fold.err
-cat $O/timing.txt | grep -v amdgpu; cat $O/r02_conv_shapes.md; cat $O/fold.err | tail -3
+python3 tools/prof_shapes_fold.py $O > $O/r03_conv_shapes.md 2> $O/fold.err
+cat $O/timing.txt | grep -v amdgpu; cat $O/r03_conv_shapes.md; cat $O/fold.err | tail -3
 rm -rf $O/trace $O/sq $O/fetch $O/write

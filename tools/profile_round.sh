@@ -3,13 +3,13 @@
 #   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/profile_round.sh r02 v1'
 # Every rocprofv3 call runs under `timeout` (a pass that aborts inside the profiler otherwise hangs until gpurun's own limit).
 set -u
-TAG=${1:-r02}; VER=${2:-v1}
+TAG=${1:-r03}; VER=${2:-v1}
 export TMPDIR=/tmp
 R=$PWD
 O=$R/gpurun_out/prof_$VER
 mkdir -p $O
 cd /tmp
-CMD="python3 $R/bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-train --no-fp32"
+CMD="python3 $R/bench.py --steps 1 --warmup 1 --regions 1 --no-graph --no-cpu-baseline --no-train --no-fp32 --no-extra"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- $CMD > $O/trace.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o f -- $CMD > $O/fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/write -o w -- $CMD > $O/write.log 2>&1

@@ -2,7 +2,7 @@
 # Training-step profile on the GPU box: kernel stats + PMC passes (run through gpurun from the repo root):
 #   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/profile_train.sh r01 v10'
 set -u
-TAG=${1:-r02}; VER=${2:-v1}
+TAG=${1:-r03}; VER=${2:-v1}
 export TMPDIR=/tmp
 R=$PWD
 O=$R/gpurun_out/proftrain_$VER
