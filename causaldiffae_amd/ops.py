@@ -1305,9 +1305,16 @@ def gn_conv3x3(x, gamma, beta, scale_shift, w, b=None, res=None, silu=True, grou
     return _GNConvPS.apply(x, gamma, beta, scale_shift, w, b, res, silu, groups, eps, sink)
 
 
+def _rb_parts(t, HW):
+    """(partial sums, segments) the producing conv left on a tensor for the next GroupNorm, or None."""
+    p = getattr(t, "_gnparts", None) if t is not None else None
+    return (p, getattr(t, "_gnseg", 1)) if p is not None and HW % 32 == 0 else None
+
+
 def _rb_gn_planes(x, gamma, beta, ss, silu, groups, eps, st, x2=None):
     """GroupNorm statistics + (scale-shift, SiLU) written as f16 planes (forward conv operand) and bf16 planes (kept for wgrad).
-    x2: the second source of a skip concatenation read in place (channels [C1, C))."""
+    x2: the second source of a skip concatenation read in place (channels [C1, C)).  Where the producing conv(s) left partial sums
+    on the tensor(s) (`_gnparts`, see _rb_conv) the statistics come from those and the tensor is read once, by the apply pass."""
     N, C1, H, W = x.shape
     C = C1 + (0 if x2 is None else x2.shape[1])
     dev = x.device
@@ -1316,25 +1323,43 @@ def _rb_gn_planes(x, gamma, beta, ss, silu, groups, eps, st, x2=None):
     planes = torch.empty((2, N, H, W, C), dtype=torch.float16, device=dev)
     bplanes = torch.empty((2, N, H, W, C), dtype=torch.bfloat16, device=dev)
     ld_ss = 2 * C if ss is None else ss.stride(0)
+    p1, p2 = _rb_parts(x, H * W), _rb_parts(x2, H * W)
+    from_parts = p1 is not None and (x2 is None or p2 is not None)
+    if from_parts:
+        check(lib.cdae_gn_stats_from_parts(ptr(p1[0]), C1, p1[1], ptr(p2[0]) if p2 else None, C - C1, p2[1] if p2 else 1, N, H * W, groups, eps,
+                                           *ptr2(stats), ptr(workspace(dev, "gnparts", workspace_bytes(WS_GN_PARTS, N, C))), st))
     if x2 is None:
-        check(lib.cdae_gn_stats(ptr(x), N, H * W, C, C, groups, eps, *ptr2(stats), ptr(gws), st))
+        if not from_parts:
+            check(lib.cdae_gn_stats(ptr(x), N, H * W, C, C, groups, eps, *ptr2(stats), ptr(gws), st))
         check(lib.cdae_gn_apply_split_train(ptr(x), *ptr2(planes), *ptr2(bplanes), N, H * W, C, C, C, groups,
                                             *ptr2(stats), ptr(gamma), ptr(beta), ptr(ss), ld_ss, 1 if silu else 0, st))
     else:
         C2 = C - C1
-        check(lib.cdae_gn_stats2(ptr(x), C1, ptr(x2), C2, C1, N, H * W, C, groups, eps, *ptr2(stats), ptr(gws), st))
+        if not from_parts:
+            check(lib.cdae_gn_stats2(ptr(x), C1, ptr(x2), C2, C1, N, H * W, C, groups, eps, *ptr2(stats), ptr(gws), st))
         check(lib.cdae_gn_apply_split_train2(ptr(x), C1, ptr(x2), C2, C1, *ptr2(planes), *ptr2(bplanes), N, H * W, C,
                                              C, groups, *ptr2(stats), ptr(gamma), ptr(beta), ptr(ss), ld_ss, 1 if silu else 0, st))
     return stats, planes, bplanes
 
 
+_RB_PARTS_ON = os.environ.get("CDAE_TRAIN_GNPARTS", "1") != "0"     # dev switch: 0 = every GroupNorm runs its own statistics pass
+
+
 def _rb_conv(planes, w, b, res, shape, Cout, st):
+    """Stride-1 conv3x3 of the training node.  Where the unsplit grid fills the chip (conv3x3_ps's rule) the epilogue also leaves the
+    next GroupNorm's partial sums on the result (`out._gnparts`)."""
     N, C, H, W = shape
     dev = planes.device
     out = new_act(N, Cout, H, W, dev)
     ws, wsb = _sk(dev)
+    M = N * H * W
+    parts = None
+    if _RB_PARTS_ON and (H * W) % 32 == 0 and ((M + 255) // 256) * ((Cout + 127) // 128) >= 256:
+        parts = torch.empty((M // 32, Cout, 2), dtype=torch.float32, device=dev)
     check(lib.cdae_conv3x3_fwd_psk(*ptr2(planes), H * W * C, W * C, C, *_wptrs(w, False), ptr(b), ptr(res), ptr(out), Cout,
-                                  0, None, None, None, N, H, W, C, Cout, 1, 0, ws, wsb, st))
+                                  0, None, None, ptr(parts), N, H, W, C, Cout, 1, 0, ws, wsb, st))
+    if parts is not None:
+        out._gnparts = parts
     return out
 
 

@@ -1,0 +1,41 @@
+"""Dev: wall time of the C64 batch-32 training step (the bench's train leg alone), for A/B runs under environment switches:
+    python tools/exp_train.py            ;  CDAE_TRAIN_GNPARTS=0 python tools/exp_train.py
+Prints ms per step of REGIONS regions of STEPS steps each (defaults 3 x 40)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from improved_diffusion import script_util as su
+from improved_diffusion.image_datasets import load_data
+from improved_diffusion.train_util import TrainLoop
+
+dev = torch.device("cuda:0")
+B = int(os.environ.get("BATCH", "32"))
+STEPS, REGIONS = int(os.environ.get("STEPS", "40")), int(os.environ.get("REGIONS", "3"))
+cfg = {**su.model_and_diffusion_defaults(), "image_size": 64, "in_channels": 3, "n_vars": 4, "rep_cond": True, "causal_modeling": True}
+model, diff = su.create_model_and_diffusion(**cfg)
+bench.randomize(model, 4321)
+model.to(dev).train()
+data = load_data(data_dir="synthetic", batch_size=B, image_size=64, in_channels=3, n_vars=4, seed=0, device=dev)
+loop = TrainLoop(model=model, diffusion=diff, data=data, batch_size=B, microbatch=-1, lr=1e-4, ema_rate="0.9999", log_interval=10 ** 9,
+                 save_interval=10 ** 9, resume_checkpoint="", rep_cond=True, n_vars=4, causal_modeling=True, in_channels=3)
+diff.kl_weight = 0.1
+
+
+def step():
+    b, c = next(data)
+    loop.forward_backward(b, c)
+    loop.optimize_normal()
+
+
+for _ in range(8):
+    step()
+out = []
+for _ in range(REGIONS):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(STEPS):
+        step()
+    torch.cuda.synchronize()
+    out.append((time.perf_counter() - t0) / STEPS * 1e3)
+print("train ms/step:", " ".join(f"{v:.3f}" for v in out), "| env:", {k: v for k, v in os.environ.items() if k.startswith("CDAE_")})
