@@ -7,19 +7,19 @@
 // exactly as they lie, and the MFMA fragments come out of LDS through the hardware transpose read (ds_read_b64_tr_b16).  Both
 // operands are bf16 hi/lo planes (x = hi + lo, 16 significand bits, full fp32 range — gradients underflow f16): dy from
 // cdae_split_bf16, a from the GroupNorm that produced the conv input (cdae_gn_apply_split_train).  Each product is
-// hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+// hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 with fp32 accumulation.
 //
-// Tiling: a block owns 64 output x 64 input channels, ALL 9 taps, and a contiguous range of 64-pixel K steps; 4 waves of
-// 32 x 32 x 9 taps (144 accumulator registers).  The 9 taps of a step read the same activation pixels shifted by
+// Tiling: a block owns 64 output x 64 input channels, ALL 9 taps, and a contiguous range of 64-pixel K steps; a wave owns
+// 64 x 16 x 9 taps (144 accumulator registers).  The 9 taps of a step read the same activation pixels shifted by
 // (ky-1)*W + (kx-1), so the activations live in a RING of pixel rows in LDS: every pixel row is fetched once per block (not 9
 // times) and a step only loads the 64 new rows.  The images of the batch are laid out in a virtual pixel stream with G >= W+1
 // zero rows between them (served from a zero line), which makes the vertical padding and the image boundaries ordinary rows;
-// the horizontal padding (x-1 at x == 0, x+1 at x == W-1) is a mask on the dy fragments (element 0 / element 7 of a lane's 8
-// pixels, because steps start on multiples of 64 and W divides 64).
-// Ring rows come in 16-row DMA blocks; a tap's 16 rows may start anywhere, so slot 0 is mirrored behind the last slot and reads
-// never wrap inside a fragment.  Split-K over the pixel range: each block writes its partial [Cout][9*Cin] slab, reduced in a
+// the horizontal padding (x-1 at x == 0, x+1 at x == W-1) is a mask on the activation fragments (element 0 / element 7 of a
+// lane's 8 pixels, because steps start on multiples of 64 and W divides 64).
+// Ring rows come in 16-row DMA blocks; a tap's 32 rows may start anywhere, so slots 0 and 1 are mirrored behind the last slot and
+// reads never wrap inside a fragment.  Split-K over the pixel range: each block writes its partial [Cout][9*Cin] slab, reduced in a
 // fixed order by wg_reduce_kernel (deterministic), or stores directly when one block covers all pixels.
-// The bias gradient (column sums of dy) rides along as two extra MFMAs per 16-pixel step against a ones operand in the blocks of
+// The bias gradient (column sums of dy) rides along as extra MFMAs against a ones operand in one wave per K group of the blocks of
 // the first input-channel tile.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -52,27 +52,31 @@ __device__ __forceinline__ int fdiv(int n, unsigned magic, int shift) {
     return (int)((__umulhi((unsigned)n, magic) + (unsigned)n) >> shift);
 }
 
-// LDS image: activations [plane 2][channel half 2][(RB + 1) * 16 rows][64 B], dy [stage 2][plane 2][channel half 2][64 rows][64 B]
-// NWAVES = 8: the block splits every 64-pixel step over two groups of 4 waves (pixels 0..31 / 32..63 of the step), i.e. two waves
-// per SIMD that cover each other's LDS latency; the second group's accumulators are added to the first's through LDS at the end.
+// LDS image: activations [plane 2][channel half 2][(RB + 2) * 16 rows][64 B], dy [stage 2][plane 2][channel half 2][64 rows][64 B].
+// 8 waves = two K groups of 4 (pixels 0..31 / 32..63 of every 64-pixel step; two waves per SIMD that cover each other's LDS latency);
+// the second group's accumulators are added to the first's through LDS at the end.  A wave owns ALL 64 output channels x 16 input
+// channels, and its group's 32 pixels of a step are ONE 32-deep step of v_mfma_f32_16x16x32_bf16 (the shape that holds its clock under
+// load, see convwin.hip).  The dy fragments (4 channel sub-tiles x hi / lo) are read once per step and serve all 9 taps; a tap reads
+// only its 16-channel activation fragment pair: 2.9 KB of LDS reads per tap and wave (a 32 x 32 wave tile on 32x32x16 MFMAs needs
+// 4.4 KB and kept the LDS pipe ~70 % busy beside the MFMAs: 5.02 -> 4.74 ms over the step's 47 wgrads).  The horizontal padding mask
+// sits on the tap's activation fragment (masked copies of the 8 dy fragments would not fit the registers).  A fragment spans 32 ring
+// rows, so slots 0 AND 1 are mirrored behind the ring.
 // NPL = 1 (the `mixed16` torso): one bf16 plane per operand, one MFMA per product; the lo sub-planes are neither staged nor read.
-template <int NWAVES, int NPL = 2>
-__global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void wgwin_kernel(const WgParams p) {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int NPL = 2>
+__global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* const lds = reinterpret_cast<char*>(smem);
-    const int RROWS = (p.RB + 1) * 16;                 // ring rows incl. the mirror of slot 0
+    const int RROWS = (p.RB + 2) * 16;                 // ring rows incl. the mirrors of slots 0 and 1
     const int A_SUB = RROWS * 64;                      // bytes per (plane, half) sub-plane
     char* const dyb = lds + 4 * A_SUB;                 // dy stages
     constexpr int D_SUB = 64 * 64, D_STAGE = 4 * D_SUB;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int hh = lane >> 5, l31 = lane & 31;
-    const int wm = (wave >> 1) & 1, wn = wave & 1;     // wave tile: output channels 32 wm.., input channels 32 wn..
-    const int kg = wave >> 2;                          // K group (NWAVES = 8): 16-pixel sub-steps 2 kg, 2 kg + 1 of every step
-    constexpr int SKN = NWAVES == 8 ? 2 : 4;
+    const int l15 = lane & 15, k4 = lane >> 4;
+    const int wn = wave & 3;                           // wave tile: input channels 16 wn .. + 15, all 64 output channels
+    const int kg = wave >> 2;                          // K group: pixels 32 kg .. + 31 of every step
     const int nci = p.Cin >> 6, nco = p.Cout >> 6;
-    // blocks b and b + 8 run on the same XCD (and share its L2): give every XCD a contiguous run of virtual ids, so that the channel
-    // tiles of one pixel range — which read the same dy / activation rows — meet in one L2
     int b;
     {
         const unsigned G = gridDim.x, bb = blockIdx.x, q = G >> 3, r = G & 7, x = bb & 7;
@@ -84,81 +88,80 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void wgwin_kernel(const Wg
     const int ci0 = cit * 64, co0 = cot * 64;
     const int s_begin = ks * p.steps_per, s_end = min(p.steps, s_begin + p.steps_per);
 
-    // ---- DMA roles: wave w stages sub-plane (P = w >> 1, half = w & 1) of both operands
+    // ---- DMA roles: wave w stages sub-plane (P = w >> 1, half = w & 1); group 0 the activations, group 1 dy
     const int dP = (wave >> 1) & 1, dH = wave & 1;
-    const bool dma_a = (NWAVES == 4 || kg == 0) && (NPL == 2 || dP == 0), dma_d = (NWAVES == 4 || kg == 1) && (NPL == 2 || dP == 0);      // 8 waves: group 0 stages activations, group 1 dy
+    const bool dma_a = kg == 0 && (NPL == 2 || dP == 0), dma_d = kg == 1 && (NPL == 2 || dP == 0);
     const unsigned short* const a_src = (dP ? p.a_lo : p.a_hi) + ci0 + dH * 32 + (lane & 3) * 8;
     const unsigned short* const d_src = (dP ? p.d_lo : p.d_hi) + co0 + dH * 32 + (lane & 3) * 8;
     char* const a_dst = lds + (dP * 2 + dH) * A_SUB;
-    // LDS-DMA through inline asm (cdae_lds_dma16): with the builtin, hipcc drains the DMAs (vmcnt(0)) in front of the next LDS read that
-    // might alias their destination — i.e. right after they were issued, before the MFMAs they were meant to overlap
     auto dma = [&](const void* src, char* dst_wave_base) {
         cdae_lds_dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst_wave_base - lds)));
     };
-    // one 16-row block of the virtual stream (rows u = 16 blk .. +15) into ring slot `slot`
+    // U0, HW and the period are multiples of 16, so a 16-row block lies entirely inside one image or entirely in a gap: which one is
+    // decided on the scalar unit (the block index is uniform), and a lane only adds the block's offset to its own row pointer
+    const unsigned short* const a_lane = a_src + (long)(lane >> 2) * p.Cin;
+    const unsigned short* const d_lane = d_src + (long)(lane >> 2) * p.Cout;
     auto issue_a = [&](int blk, int slot) {
-        const int v = blk * 16 + (lane >> 2) - p.U0;
+        const int v = __builtin_amdgcn_readfirstlane(blk * 16 - p.U0);
         const int vv = v < 0 ? 0 : v;
         const int img = fdiv(vv, p.period_magic, p.period_shift);
         const int q = vv - img * p.period;
         const bool ok = v >= 0 && q < p.HW && img < p.N;
-        const void* src = ok ? (const void*)(a_src + ((long)img * p.HW + q) * p.Cin) : (const void*)g_zero_wg;
+        const long off = ((long)img * p.HW + q) * p.Cin;
+        const void* src = ok ? (const void*)(a_lane + off) : (const void*)g_zero_wg;
         dma(src, a_dst + slot * 1024);
-        if (slot == 0) dma(src, a_dst + p.RB * 1024);
+        if (slot < 2) dma(src, a_dst + (p.RB + slot) * 1024);
     };
     auto issue_d = [&](int pix0, int stage) {
         char* const dst = dyb + stage * D_STAGE + (dP * 2 + dH) * D_SUB;
 #pragma unroll
         for (int blk = 0; blk < 4; ++blk)
-            dma(d_src + (long)(pix0 + blk * 16 + (lane >> 2)) * p.Cout, dst + blk * 1024);
+            dma(d_lane + (long)(pix0 + blk * 16) * p.Cout, dst + blk * 1024);
     };
 
-    // ---- fragment addressing (ds_read_b64_tr_b16: lane 4q+p of a 16-lane group addresses row k+q, 4 columns at 4p, and receives
-    //      column (lane & 15) of those 4 rows; two reads 4 rows apart give the lane its 8 consecutive k)
-    const int q4 = (lane & 15) >> 2, p4 = lane & 3;
-    const int lane_off = (8 * hh + q4) * 64 + 32 * ((lane >> 4) & 1) + 8 * p4;
+    // ---- fragments: 16 channels x 32 pixels; lane (column l15, k block k4) gets pixels 8 k4 .. + 7 through two transpose reads 4 rows apart
+    const int q4 = l15 >> 2, p4 = lane & 3;
+    const int lane_off = (8 * k4 + q4) * 64 + 8 * p4;
     auto trread = [&](const char* src) -> u32x2 {
         const fp16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(src));
         return __builtin_bit_cast(u32x2, v);
     };
-    auto frag = [&](const char* src) -> u32x4 {        // rows k .. k+3 and k+4 .. k+7
+    auto frag = [&](const char* src) -> u32x4 {
         const u32x2 a = trread(src), c = trread(src + 256);
         u32x4 r; r[0] = a[0]; r[1] = a[1]; r[2] = c[0]; r[3] = c[1];
         return r;
     };
-    auto mma = [&](const u32x4& x, const u32x4& y, const f32x16& c) -> f32x16 {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, x), __builtin_bit_cast(bf8, y), c, 0, 0, 0);
+    auto mma = [&](const u32x4& x, const u32x4& y, const f32x4& c) -> f32x4 {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, x), __builtin_bit_cast(bf8, y), c, 0, 0, 0);
     };
 
-    f32x16 acc[9];
+    f32x4 acc[9][4];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    f32x16 accb;
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+            for (int r = 0; r < 4; ++r) acc[t][c][r] = 0.f;
+    f32x4 accb[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) accb[c][r] = 0.f;
     const bool do_colsum = p.colsum != nullptr && cit == 0 && wn == 0;
     u32x4 ones; ones[0] = ones[1] = ones[2] = ones[3] = 0x3F803F80u;       // bf16 1.0 pairs
 
-    // horizontal padding masks of this lane's 8 pixels in 16-pixel step sk: x0 = (16 sk + 8 hh) mod W
-    unsigned mL[SKN], mR[SKN];
-#pragma unroll
-    for (int ski = 0; ski < SKN; ++ski) {
-        const int sk = NWAVES == 8 ? 2 * kg + ski : ski;
-        const int x0 = (16 * sk + 8 * hh) & (p.W - 1);
-        mL[ski] = x0 == 0 ? 0xFFFF0000u : 0xFFFFFFFFu;          // tap kx = 0 reads x - 1: the pixel at x == 0 (element 0) contributes nothing
-        mR[ski] = x0 == p.W - 8 ? 0x0000FFFFu : 0xFFFFFFFFu;    // tap kx = 2 reads x + 1: the pixel at x == W - 1 (element 7)
-    }
+    // horizontal padding: this lane's 8 pixels start at x0 = (32 kg + 8 k4) mod W (steps start on multiples of 64 and W divides 64)
+    const int x0 = (32 * kg + 8 * k4) & (p.W - 1);
+    const unsigned mL = x0 == 0 ? 0xFFFF0000u : 0xFFFFFFFFu;           // tap kx = 0 reads x - 1: the pixel at x == 0 (element 0) contributes nothing
+    const unsigned mR = x0 == p.W - 8 ? 0x0000FFFFu : 0xFFFFFFFFu;     // tap kx = 2 reads x + 1: the pixel at x == W - 1 (element 7)
 
     if (s_begin < s_end) {
-        const int hb = p.U0 >> 4;                      // halo blocks each side of a step's 4 blocks
-        // position of step s in the virtual stream
+        const int hb = p.U0 >> 4;
         int img = (s_begin * 64) / p.HW, q = s_begin * 64 - img * p.HW;
-        int B0 = (img * p.period + q + p.U0) >> 4;     // first block of the step's own 64 rows
-        int slot0 = 0;                                 // ring slot of block B0 - hb (the window's first block)
-        int next_blk = B0 - hb, next_slot = 0;         // next block to load and its slot
-        auto load_upto = [&](int blk_end) {            // uniform loop
+        int B0 = (img * p.period + q + p.U0) >> 4;
+        int slot0 = 0;
+        int next_blk = B0 - hb, next_slot = 0;
+        auto load_upto = [&](int blk_end) {
             for (; next_blk < blk_end; ++next_blk) {
                 if (dma_a) issue_a(next_blk, next_slot);
                 next_slot = next_slot + 1 == p.RB ? 0 : next_slot + 1;
@@ -169,9 +172,9 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void wgwin_kernel(const Wg
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
+        const int kg_s = __builtin_amdgcn_readfirstlane(kg);
         for (int s = s_begin; s < s_end; ++s) {
             const int st = (s - s_begin) & 1;
-            // ---- prefetch step s + 1
             int img_n = img, q_n = q + 64;
             if (q_n == p.HW) { q_n = 0; ++img_n; }
             const int B0n = (img_n * p.period + q_n + p.U0) >> 4;
@@ -179,57 +182,50 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void wgwin_kernel(const Wg
                 load_upto(B0n + 4 + hb);
                 if (dma_d) issue_d((s + 1) * 64, st ^ 1);
             }
-            // ---- compute step s: window rows start at ring row slot0 * 16 (block B0 - hb); the step's own rows at + 16 hb
-            const char* const dy_hi = dyb + st * D_STAGE + wm * D_SUB + lane_off;
-            const char* const dy_lo = dy_hi + 2 * D_SUB;
-            const char* const a_hi = lds + wn * A_SUB + lane_off;
-            // ring row (before wrap) of the step's first own pixel: wave-uniform, but derived from the wave index (K group), which hipcc
-            // treats as divergent — readfirstlane moves it, and the tap arithmetic below, to the scalar unit
-            const int row_own = __builtin_amdgcn_readfirstlane(slot0 * 16 + p.U0);
+            // ---- compute: this K group's 32 pixels of step s
+            const char* const dy_hi = dyb + st * D_STAGE + kg_s * (32 * 64) + lane_off;
+            const char* const a_hi = lds + (wn >> 1) * A_SUB + (wn & 1) * 32 + lane_off;
+            const int row_own = __builtin_amdgcn_readfirstlane(slot0 * 16 + p.U0 + 32 * kg_s);
             const int ring = p.RB * 16;
+            u32x4 dh[4], dl[4];
 #pragma unroll
-            for (int ski = 0; ski < SKN; ++ski) {
-                const int sk = NWAVES == 8 ? __builtin_amdgcn_readfirstlane(2 * kg + ski) : ski;
-                u32x4 dh[3], dl[3];
-                dh[1] = frag(dy_hi + sk * 1024);
-                dh[0] = dh[1]; dh[0][0] &= mL[ski];
-                dh[2] = dh[1]; dh[2][3] &= mR[ski];
-                if constexpr (NPL == 2) {
-                    dl[1] = frag(dy_lo + sk * 1024);
-                    dl[0] = dl[1]; dl[0][0] &= mL[ski];
-                    dl[2] = dl[1]; dl[2][3] &= mR[ski];
-                }
-                if (do_colsum) { accb = mma(dh[1], ones, accb); if constexpr (NPL == 2) accb = mma(dl[1], ones, accb); }
-                // software pipeline over the taps: tap t + 1's fragments are requested BEFORE tap t's MFMAs are issued (left to itself
-                // hipcc reads each fragment right in front of its first use and waits for it: MFMA busy 0.44)
-                auto tap_src = [&](int t) -> const char* {
-                    int rt = row_own + (t / 3 - 1) * p.W + (t % 3 - 1) + 16 * sk;
-                    rt = rt < 0 ? rt + ring : rt;
-                    rt = rt >= ring ? rt - ring : rt;
-                    // the ring row is wave-uniform: kept on the scalar unit (hipcc otherwise folds the per-lane offset in first and runs the
-                    // wrap arithmetic on the vector ALUs, ~9 instructions per tap beside the MFMAs)
-                    return a_hi + __builtin_amdgcn_readfirstlane(rt * 64);
-                };
-                u32x4 fh[3], fl[3];                        // fragment sets of taps t, t + 1, t + 2 (two taps = 6 MFMAs of lookahead)
-                fh[0] = frag(tap_src(0)); if constexpr (NPL == 2) fl[0] = frag(tap_src(0) + 2 * A_SUB);
-                fh[1] = frag(tap_src(1)); if constexpr (NPL == 2) fl[1] = frag(tap_src(1) + 2 * A_SUB);
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int kx = t % 3;
-                    if (t + 2 < 9) {
-                        const char* src = tap_src(t + 2);
-                        fh[(t + 2) % 3] = frag(src); if constexpr (NPL == 2) fl[(t + 2) % 3] = frag(src + 2 * A_SUB);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (NPL == 2) {
-                        acc[t] = mma(dl[kx], fh[t % 3], acc[t]);
-                        acc[t] = mma(dh[kx], fl[t % 3], acc[t]);
-                    }
-                    acc[t] = mma(dh[kx], fh[t % 3], acc[t]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+            for (int c = 0; c < 4; ++c) {
+                dh[c] = frag(dy_hi + (c >> 1) * D_SUB + (c & 1) * 32);
+                if constexpr (NPL == 2) dl[c] = frag(dy_hi + (2 + (c >> 1)) * D_SUB + (c & 1) * 32);
             }
-            // ---- advance
+            if (do_colsum) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { accb[c] = mma(dh[c], ones, accb[c]); if constexpr (NPL == 2) accb[c] = mma(dl[c], ones, accb[c]); }
+            }
+            auto tap_src = [&](int t) -> const char* {
+                int rt = row_own + (t / 3 - 1) * p.W + (t % 3 - 1);
+                rt = rt < 0 ? rt + ring : rt;
+                rt = rt >= ring ? rt - ring : rt;
+                return a_hi + __builtin_amdgcn_readfirstlane(rt * 64);
+            };
+            u32x4 fh[3], fl[3];                        // fragment sets of taps t, t + 1, t + 2
+            fh[0] = frag(tap_src(0)); if constexpr (NPL == 2) fl[0] = frag(tap_src(0) + 2 * A_SUB);
+            fh[1] = frag(tap_src(1)); if constexpr (NPL == 2) fl[1] = frag(tap_src(1) + 2 * A_SUB);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int kx = t % 3, cur = t % 3;
+                if (t + 2 < 9) {
+                    const char* src = tap_src(t + 2);
+                    fh[(t + 2) % 3] = frag(src); if constexpr (NPL == 2) fl[(t + 2) % 3] = frag(src + 2 * A_SUB);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (kx == 0) { fh[cur][0] &= mL; if constexpr (NPL == 2) fl[cur][0] &= mL; }
+                if (kx == 2) { fh[cur][3] &= mR; if constexpr (NPL == 2) fl[cur][3] &= mR; }
+                if constexpr (NPL == 2) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[t][c] = mma(dl[c], fh[cur], acc[t][c]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[t][c] = mma(dh[c], fl[cur], acc[t][c]);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[t][c] = mma(dh[c], fh[cur], acc[t][c]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             const int adv = B0n - B0;
             slot0 += adv; slot0 = slot0 >= p.RB ? slot0 - p.RB : slot0;
             B0 = B0n; img = img_n; q = q_n;
@@ -238,9 +234,9 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void wgwin_kernel(const Wg
         }
     }
 
-    if constexpr (NWAVES == 8) {
-        // fold the second K group into the first through LDS (the ring is dead now), three taps at a time: [wave & 3][3 + 1][16][64] floats
-        float* const xch = reinterpret_cast<float*>(lds) + (wave & 3) * (4 * 16 * 64) + lane;
+    // fold the second K group into the first through LDS (the ring is dead now), three taps at a time: [wave & 3][48 + 16][64] floats
+    {
+        float* const xch = reinterpret_cast<float*>(lds) + (wave & 3) * (64 * 64) + lane;
 #pragma unroll
         for (int round = 0; round < 3; ++round) {
             __syncthreads();
@@ -248,10 +244,14 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void wgwin_kernel(const Wg
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) xch[(t * 16 + r) * 64] = acc[3 * round + t][r];
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) xch[((t * 4 + c) * 4 + r) * 64] = acc[3 * round + t][c][r];
                 if (round == 0) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) xch[(3 * 16 + r) * 64] = accb[r];
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) xch[(48 + c * 4 + r) * 64] = accb[c][r];
                 }
             }
             __syncthreads();
@@ -259,31 +259,38 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void wgwin_kernel(const Wg
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[3 * round + t][r] += xch[(t * 16 + r) * 64];
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[3 * round + t][c][r] += xch[((t * 4 + c) * 4 + r) * 64];
                 if (round == 0) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) accb[r] += xch[(3 * 16 + r) * 64];
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) accb[c][r] += xch[(48 + c * 4 + r) * 64];
                 }
             }
         }
         if (kg == 1) return;
     }
 
-    // ---- epilogue: D[row = co][col = ci] of tap t -> out[(co0 + 32 wm + row) * 9 Cin + t * Cin + ci0 + 32 wn + col]
+    // ---- epilogue: D[row = co][col = ci] of (tap t, output sub-tile c): row 16 c + 4 k4 + r, column 16 wn + l15
     const long ldo = 9L * p.Cin;
-    float* const ob = p.out + (p.ksplit > 1 ? (long)ks * p.Cout * ldo : 0L) + (long)(co0 + wm * 32) * ldo + ci0 + wn * 32 + l31;
+    float* const ob = p.out + (p.ksplit > 1 ? (long)ks * p.Cout * ldo : 0L) + (long)(co0 + 4 * k4) * ldo + ci0 + wn * 16 + l15;
     const bool accum = p.ksplit == 1 && p.accumulate;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-            float* o = ob + (long)row * ldo + t * p.Cin;
-            *o = accum ? *o + acc[t][r] : acc[t][r];
-        }
-    if (do_colsum && l31 == 0) {
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) atomicAdd(p.colsum + co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh, accb[r]);
+            for (int r = 0; r < 4; ++r) {
+                float* o = ob + (long)(16 * c + r) * ldo + t * p.Cin;
+                *o = accum ? *o + acc[t][c][r] : acc[t][c][r];
+            }
+    if (do_colsum && l15 == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(p.colsum + co0 + 16 * c + 4 * k4 + r, accb[c][r]);
     }
 }
 
@@ -478,13 +485,13 @@ extern "C" int cdae_conv3x3_wgrad_win(const unsigned short* a_hi, const unsigned
     p.out = ks > 1 ? splitk_ws : dw;
     p.colsum = dbias;
     if (dbias && !accumulate && hipMemsetAsync(dbias, 0, sizeof(float) * Cout, st) != hipSuccess) return cdae_fail("dbias memset failed");
-    const size_t smem = (size_t)4 * (p.RB + 1) * 16 * 64 + 2 * 4 * 64 * 64;
+    const size_t smem = (size_t)4 * (p.RB + 2) * 16 * 64 + 2 * 4 * 64 * 64;
     // one bf16 plane per operand in the reduced-precision mode (the lo pointers are ignored), hi / lo pairs otherwise
     const bool single = cdae_get_default_precision() == CDAE_PREC_MIXED16;
     static size_t attr_bytes = 0;
     if (smem > attr_bytes) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgwin_kernel<8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&wgwin_kernel<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgwin_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&wgwin_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
         attr_bytes = smem;
     }
@@ -494,8 +501,8 @@ extern "C" int cdae_conv3x3_wgrad_win(const unsigned short* a_hi, const unsigned
         snprintf(tag, sizeof(tag), "wgwin %d->%d @%dx%d n=%d tiles=%ld ks=%d planes=%d", Cin, Cout, H, W, N, tiles, ks, single ? 1 : 2);
         cdae_prof_tag(tag);
     }
-    if (single) hipLaunchKernelGGL((wgwin_kernel<8, 1>), dim3((unsigned)(tiles * ks)), dim3(512), smem, st, p);
-    else hipLaunchKernelGGL((wgwin_kernel<8, 2>), dim3((unsigned)(tiles * ks)), dim3(512), smem, st, p);
+    if (single) hipLaunchKernelGGL((wgwin_kernel<1>), dim3((unsigned)(tiles * ks)), dim3(512), smem, st, p);
+    else hipLaunchKernelGGL((wgwin_kernel<2>), dim3((unsigned)(tiles * ks)), dim3(512), smem, st, p);
     int rc = hipGetLastError() == hipSuccess ? 0 : cdae_fail("wgwin_kernel launch failed");
     if (rc == 0 && ks > 1) {
         const long n4 = (long)Cout * 9 * Cin / 4;

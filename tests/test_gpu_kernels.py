@@ -1034,7 +1034,7 @@ def test_resblock_training_node_forced_onto_window_kernel(N, C1, C2, Cout, H, ex
 def test_resblock_training_node_mixed16_single_plane_kernels(N, C1, C2, Cout, H, expect_kernels):
     """The reduced-precision torso (`mixed16`, reference unet.py:501-507 / fp16_util.py:9-15: an fp16 torso with fp32 master weights) on the
     fused ResBlock node: ONE f16 plane per operand in the forward convs, ONE bf16 plane in dgrad and wgrad (convwin_kernel<.., 1 plane>,
-    wgwin_kernel<8, 1 plane>: one MFMA per product).  Against fp64 at the accuracy a 2^-8 (bf16) / 2^-11 (f16) significand gives — and
+    wgwin_kernel<1 plane>: one MFMA per product).  Against fp64 at the accuracy a 2^-8 (bf16) / 2^-11 (f16) significand gives — and
     well away from the f16x3 path's 3e-5, i.e. the single-plane kernels really ran."""
     from causaldiffae_amd._lib import precision_scope
     with torch.enable_grad():
