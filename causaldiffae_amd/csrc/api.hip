@@ -410,7 +410,7 @@ int cdae_qkv_attention_bwd(const float* qkv, const float* probs, const float* do
     // below.  Measured at batch 32: T = 64 58 vs 65 us for the whole backward, T = 256 135 vs 124 us (the kernel reads the probabilities
     // twice and writes dS between two unoverlapped staging phases) -> by default only for T = 64.  CDAE_ATTN_BWD_FUSED=0 never, 2 wherever built
     static const int cfg_fused = CDAE_DEV_INT("CDAE_ATTN_BWD_FUSED", 1);
-    const bool fused_q = (cfg_fused >= 2 || (cfg_fused == 1 && T <= 64)) && cdae_get_default_precision() == CDAE_PREC_F16X3 && cdae_qkv_attention_fused_supported(T, ch) && aligned16(qkv) &&
+    const bool fused_q = (cfg_fused >= 2 || (cfg_fused == 1 && T <= 64)) && cdae_get_default_precision() != CDAE_PREC_FP32 && cdae_qkv_attention_fused_supported(T, ch) && aligned16(qkv) &&
                          aligned16(probs) && aligned16(dout) && aligned16(dqkv) && aligned16(dprobs);
     if (fused_q) {
         if ((rc = cdae_qkv_attention_bwd_q_fused(qkv, probs, dout, dqkv, dprobs, B, T, heads, ch, stream))) return rc;

@@ -988,7 +988,10 @@ static int gn_bwd_impl(const float* x, const float* x2, int ld2, int C1, const f
     // pass 2b (dgamma / dbeta over the batch) rides along as one extra row of blocks of the streaming dx launch (it only needs pass 2a's
     // per-image sums, like dx): one launch less per GroupNorm, 56 per C64 training step; CDAE_GN_BWD_PARAM_ROW=0: its own launch
     static const int cfg_prow = CDAE_DEV_INT("CDAE_GN_BWD_PARAM_ROW", 1);
-    const bool param_row = dx_stream && cfg_prow && N >= 8;
+    // (the row has only nchunk blocks, each walking ceil(C / 32 / nchunk) channel blocks x N / 8 images one after the other: at N = 256
+    // and one chunk that serial walk was 80 of the 101 us of a 16-pixel GroupNorm backward — then the fold gets its own C / 32 blocks)
+    const long prow_serial = (long)(((C + 31) / 32 + nchunk - 1) / nchunk) * ((N + 7) / 8);
+    const bool param_row = dx_stream && cfg_prow && N >= 8 && prow_serial <= 64;
     if (param_row) {}
     else if (N >= 8) hipLaunchKernelGGL(gn_bwd_param8_kernel, dim3((C + 31) / 32), dim3(256), 0, st, N, C, ncp, dgamma, dbeta, accumulate_params);
     else hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, st, N, C, ncp, dgamma, dbeta, accumulate_params);

@@ -343,7 +343,7 @@ class _Attention(Function):
         dev = qkv.device
         out = torch.empty((B, T, C), dtype=torch.float32, device=dev)
         probs = torch.empty((B * heads, T, T), dtype=torch.float32, device=dev)
-        if _FUSED_ATTN_TRAIN and lib.cdae_get_default_precision() == 1 and lib.cdae_qkv_attention_fused_supported(T, ch):
+        if _FUSED_ATTN_TRAIN and lib.cdae_get_default_precision() in (1, 2) and lib.cdae_qkv_attention_fused_supported(T, ch):      # (mixed16: the fused kernel keeps its split products)
             # the inference kernel with the probabilities written out for the backward: one launch instead of GEMM, softmax, GEMM
             check(lib.cdae_qkv_attention_fwd_fused_p(ptr(qkv), ptr(out), ptr(probs), B, T, heads, ch, stream()))
         else:
@@ -377,7 +377,7 @@ def qkv_attention(qkv_rows, heads):
     B, T, C3 = qkv_rows.shape
     ch = C3 // 3 // heads
     if (_FUSED_ATTN_ON and not torch.is_grad_enabled() and qkv_rows.dtype == torch.float32
-            and lib.cdae_get_default_precision() == 1 and lib.cdae_qkv_attention_fused_supported(T, ch)):
+            and lib.cdae_get_default_precision() in (1, 2) and lib.cdae_qkv_attention_fused_supported(T, ch)):
         out = torch.empty((B, T, C3 // 3), dtype=torch.float32, device=qkv_rows.device)
         check(lib.cdae_qkv_attention_fwd_fused(ptr(qkv_rows), ptr(out), B, T, heads, ch, stream()))
         return out
