@@ -243,3 +243,26 @@ def test_window_conv_k_loop_has_no_compiler_drain():
             assert lp["mfmas"] == (32 if single else 96) and lp["barriers"] == 1, (r["kernel"], lp)
             assert not lp["vmcnt_waits"] and not lp["scratch"], (r["kernel"], lp)
         assert 0 <= r["vgpr_spills"] <= 16, (r["kernel"], r["vgpr_spills"])
+
+
+
+def test_wgrad_window_kernel_step_loop_is_clean():
+    """wgwin_kernel (weight gradients: a sixth of the training step) keeps 144 accumulator registers, eight dy fragments and a three-deep
+    activation fragment pipeline in 242 VGPRs: no spills at all, and its step loop — one barrier per 64-pixel step — holds the 9 taps x
+    4 sub-tiles x (3 | 1) MFMAs (+ the bias-gradient MFMAs) with no compiler-inserted vmcnt wait (the kernel's own counted wait is inline asm)."""
+    import importlib.util, shutil
+    if not shutil.which("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not installed")
+    spec = importlib.util.spec_from_file_location("isa_lint", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "isa_lint.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    kernels = [r for r in mod.lint("wgrad") if "wgwin_kernel" in r["kernel"]]
+    assert len(kernels) == 2          # hi / lo plane pairs, and the single-plane mixed16 form
+    for r in kernels:
+        single = "<1>" in r["kernel"]
+        assert r["vgpr_spills"] == 0 and r["scratch_ops"] == 0, (r["kernel"], r["vgpr_spills"])
+        steps = [lp for lp in r["loops"] if lp["barriers"] == 1]
+        assert len(steps) == 1, (r["kernel"], r["loops"])
+        lp = steps[0]
+        assert lp["mfmas"] == (36 + 4 if single else 108 + 8), (r["kernel"], lp)
+        assert not lp["vmcnt_waits"] and not lp["scratch"], (r["kernel"], lp)
