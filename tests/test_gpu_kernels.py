@@ -1328,14 +1328,36 @@ def test_window_conv_is_race_free_and_deterministic(N, Cin, Cout, S, up):
     assert (first[:2].double() - exact).abs().max().item() < 2e-5 * max(1.0, exact.abs().max().item())
 
 
+ODD_WINDOW_SHAPES = [(5, 64, 96, 8, False),        # M = 320: second tile has 64 rows; N = 96 < 128 columns
+                     (129, 512, 512, 8, True),     # odd batch at the 8 x 8 level: M % 256 = 64, four n-tiles, residual
+                     (3, 128, 160, 16, False),     # M = 768 = 3 tiles of one image each; second n-tile 32 columns wide
+                     (7, 96, 128, 32, True),       # Cin = 96: three 32-channel chunks
+                     (1, 32, 32, 64, False),       # one image, one chunk (18 K-steps), 16 tiles
+                     (2, 256, 384, 32, False)]     # three n-tiles
+
+
 @pytest.mark.gpu
-def test_window_conv_odd_shapes():
-    """Partial last tiles in M and N, Cin of three chunks, one-image and odd-batch problems on the second-generation window kernel
-    (forced onto them by CDAE_CONVWIN_MINTILES=1; at production sizes the dispatcher routes e.g. batch 129 at the 8 x 8 level there)."""
-    import os, subprocess, sys
-    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "convwin_odd_worker.py")
-    r = subprocess.run([sys.executable, worker], env={**os.environ, "CDAE_CONVWIN_MINTILES": "1", "CDAE_CONVWIN_SPLITK": "0"}, capture_output=True,
-                       text=True, timeout=600)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-    r = subprocess.run([sys.executable, worker], env={**os.environ, "CDAE_CONVWIN_MINTILES": "1"}, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]          # the same with split-K allowed
+@pytest.mark.parametrize("splitk", [0, 1])
+def test_window_conv_odd_shapes(splitk, expect_kernels):
+    """Partial last tiles in M and N, Cin of three chunks, one-image and odd-batch problems on the second-generation window kernel,
+    forced onto them by the dispatch threshold (cdae_tune_set; at production sizes the dispatcher routes e.g. batch 129 at the 8 x 8
+    level there), with and without its K split; the launch log proves the window kernel produced every result."""
+    from causaldiffae_amd import ops
+    from causaldiffae_amd._lib import check, lib, ptr, stream, tune_scope, range_check
+    g = torch.Generator(device="cuda:0").manual_seed(41)
+    for (N, ci, co, S, res) in ODD_WINDOW_SHAPES:
+        x = ops.to_nhwc(torch.randn(N, ci, S, S, device="cuda:0", generator=g))
+        w = (torch.randn(co, ci, 3, 3, device="cuda:0", generator=g) / (9 * ci) ** 0.5).contiguous(memory_format=torch.channels_last)
+        b = torch.randn(co, device="cuda:0", generator=g)
+        r = ops.to_nhwc(torch.randn(N, co, S, S, device="cuda:0", generator=g)) if res else None
+        planes = torch.empty((2, N, S, S, ci), dtype=torch.float16, device="cuda:0")
+        check(lib.cdae_split_f16(ptr(x), ptr(planes[0]), ptr(planes[1]), x.numel(), stream()))
+        with torch.no_grad(), tune_scope(convwin_min_tiles=1, convwin_splitk=splitk), expect_kernels(convwin=1):
+            y = ops.conv3x3_ps(ops.SplitAct(planes[0], planes[1], (N, ci, S, S)), w, b, res=r)
+        exact = F.conv2d(x.double().contiguous(), w.double(), b.double(), padding=1)
+        if res:
+            exact = exact + r.double()
+        assert torch.isfinite(y).all()
+        e = (y.double() - exact).abs().max().item() / max(1.0, exact.abs().max().item())
+        assert e < 2e-5, ((N, ci, co, S, res), e)
+    range_check("odd shapes")
