@@ -34,6 +34,8 @@ SIGNATURES = {
     "cdae_conv_wpack": [P, P, P, P, I, I, I, P],
     "cdae_gn_coef": [P, P, P, P, P, I, P, I, I, I, P],
     "cdae_gn_stats_from_parts": [P, I, I, P, I, I, I, I, I, F, P, P, P, P],
+    "cdae_gn_stats_from_parts_coef": [P, I, I, P, I, I, I, I, I, F, P, P, P, P, P, I, P, P, P],
+    "cdae_gn_stats2_coef": [P, I, P, I, I, I, I, I, I, F, P, P, P, P, P, I, P, P, P],
     "cdae_upconv3x3_fwd_ps": [P, P, L, L, L, P, P, P, P, L, P, I, I, I, I, I, P, SZ, P],
     "cdae_linear_fwd_ps": [P, P, L, P, P, L, P, P, P, L, I, I, I, F, I, P, SZ, P],
     "cdae_split_f16": [P, P, P, L, P],

@@ -75,11 +75,28 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
     }
 }
 
+// (a, b) of y = x * a + b for one (image, channel): GroupNorm + affine (+ scale-shift) folded — THE definition, used by gn_coef_kernel and
+// by the statistics kernels that emit the table themselves (one launch less per GroupNorm whose consumer streams the fp32 rows)
+__device__ __forceinline__ void gn_coef_one(float mu, float rs, float gm, float bt, const float* __restrict__ ss, long ss_row, int C, int c,
+                                            float* __restrict__ out) {
+    float a = rs * gm;
+    float b = fmaf(-mu, a, bt);
+    if (ss) {
+        const float sc = 1.f + ss[ss_row + c], sh = ss[ss_row + C + c];
+        a *= sc;
+        b = fmaf(b, sc, sh);
+    }
+    out[0] = a; out[1] = b;
+}
+
 // G == 32 (GroupNorm32, every norm of the model): grid N, 256 threads = 8 chunk lanes x 32 groups; the serial per-thread walk over
 // up to 128 chunks below costs ~10 us of pure latency per launch, 56 launches per network pass
 __global__ __launch_bounds__(256) void gn_finalize32_kernel(const float* __restrict__ x, int HW, int ldx, int cpg, int nchunk, float eps,
                                                             const float* __restrict__ partial, float* __restrict__ mean, float* __restrict__ rstd,
-                                                            const float* __restrict__ x2, int ld2, int C1) {
+                                                            const float* __restrict__ x2, int ld2, int C1,
+                                                            const float* __restrict__ gamma = nullptr, const float* __restrict__ beta = nullptr,
+                                                            const float* __restrict__ ss = nullptr, int ld_ss = 0, int C = 0,
+                                                            float* __restrict__ coef = nullptr) {
     __shared__ double sS[8][32], sQ[8][32];
     const int n = blockIdx.x, g = threadIdx.x & 31, cl = threadIdx.x >> 5;
     double s = 0.0, q = 0.0;
@@ -99,8 +116,11 @@ __global__ __launch_bounds__(256) void gn_finalize32_kernel(const float* __restr
         const double m = s / cnt;
         double var = q / cnt - m * m;
         if (var < 0.0) var = 0.0;
-        mean[n * 32 + g] = (float)(pivot + m);
-        rstd[n * 32 + g] = (float)(1.0 / sqrt(var + (double)eps));
+        const float mu = (float)(pivot + m), rs = (float)(1.0 / sqrt(var + (double)eps));
+        mean[n * 32 + g] = mu;
+        rstd[n * 32 + g] = rs;
+        if (coef)
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) gn_coef_one(mu, rs, gamma[c], beta[c], ss, (long)n * ld_ss, C, c, coef + ((long)n * C + c) * 2);
     }
 }
 
@@ -157,7 +177,9 @@ __global__ __launch_bounds__(256) void gn_parts_channel_kernel(const float* __re
 // same additions in the same order, so mean / rstd are bit-identical to the two-kernel form.
 __global__ __launch_bounds__(256) void gn_parts_stats_kernel(const float* __restrict__ part1, int C1, int nseg1, const float* __restrict__ part2,
                                                               int C2, int nseg2, int N, int HW, int cpg, int G, int gpb, float eps,
-                                                              float* __restrict__ mean, float* __restrict__ rstd) {
+                                                              float* __restrict__ mean, float* __restrict__ rstd,
+                                                              const float* __restrict__ gamma = nullptr, const float* __restrict__ beta = nullptr,
+                                                              const float* __restrict__ ss = nullptr, int ld_ss = 0, float* __restrict__ coef = nullptr) {
     __shared__ double sS[8][32], sQ[8][32];
     const int n = blockIdx.y, g0 = blockIdx.x * gpb, cw = gpb * cpg;
     const int cl = threadIdx.x >> 5, ci = threadIdx.x & 31, c = g0 * cpg + ci;
@@ -186,8 +208,13 @@ __global__ __launch_bounds__(256) void gn_parts_stats_kernel(const float* __rest
         const double cnt = (double)HW * cpg, m = gs / cnt;
         double var = gq / cnt - m * m;
         if (var < 0.0) var = 0.0;
-        mean[n * G + g0 + g] = (float)m;
-        rstd[n * G + g0 + g] = (float)(1.0 / sqrt(var + (double)eps));
+        const float mu = (float)m, rs = (float)(1.0 / sqrt(var + (double)eps));
+        mean[n * G + g0 + g] = mu;
+        rstd[n * G + g0 + g] = rs;
+        if (coef) {
+            const int C = G * cpg;
+            for (int c = (g0 + g) * cpg; c < (g0 + g + 1) * cpg; ++c) gn_coef_one(mu, rs, gamma[c], beta[c], ss, (long)n * ld_ss, C, c, coef + ((long)n * C + c) * 2);
+        }
     }
 }
 __global__ void gn_parts_group_kernel(const double* __restrict__ chan, int C, int HW, int cpg, int G, float eps,
@@ -1019,15 +1046,7 @@ __global__ void gn_coef_kernel(const float* __restrict__ mean, const float* __re
                                float* __restrict__ coef, long total) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int n = (int)(i / C), c = (int)(i - (long)n * C), g = c / cpg;
-        const float mu = mean[n * G + g], rs = rstd[n * G + g];
-        float a = rs * gamma[c];
-        float b = fmaf(-mu, a, beta[c]);
-        if (ss) {
-            const float sc = 1.f + ss[(long)n * ld_ss + c], sh = ss[(long)n * ld_ss + C + c];
-            a *= sc;
-            b = fmaf(b, sc, sh);
-        }
-        coef[i * 2] = a; coef[i * 2 + 1] = b;
+        gn_coef_one(mean[n * G + g], rstd[n * G + g], gamma[c], beta[c], ss, (long)n * ld_ss, C, c, coef + i * 2);
     }
 }
 
@@ -1048,6 +1067,12 @@ int cdae_gn_coef(const float* mean, const float* rstd, const float* gamma, const
 
 int cdae_gn_stats_from_parts(const float* part1, int C1, int nseg1, const float* part2, int C2, int nseg2, int N, int HW, int groups, float eps,
                              float* mean, float* rstd, float* ws /* >= N * C * 4 floats */, void* stream) {
+    return cdae_gn_stats_from_parts_coef(part1, C1, nseg1, part2, C2, nseg2, N, HW, groups, eps, mean, rstd, nullptr, nullptr, nullptr, 0, nullptr, ws, stream);
+}
+
+int cdae_gn_stats_from_parts_coef(const float* part1, int C1, int nseg1, const float* part2, int C2, int nseg2, int N, int HW, int groups, float eps,
+                                  float* mean, float* rstd, const float* gamma, const float* beta, const float* scale_shift, int ld_ss, float* coef,
+                                  float* ws, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int C = C1 + C2;
     if (nseg1 < 1 || HW % (32 * nseg1) || (part2 && (nseg2 < 1 || HW % (32 * nseg2)))) return cdae_fail("gn_stats_from_parts: HW must be a multiple of 32 per segment");
@@ -1061,8 +1086,9 @@ int cdae_gn_stats_from_parts(const float* part1, int C1, int nseg1, const float*
     if (cfg_fused && cpg <= 32) {
         const int gpb = 32 / cpg;
         hipLaunchKernelGGL(gn_parts_stats_kernel, dim3((groups + gpb - 1) / gpb, N), dim3(256), 0, st, part1, C1, nseg1, part2, C2, part2 ? nseg2 : 1, N, HW,
-                           cpg, groups, gpb, eps, mean, rstd);
+                           cpg, groups, gpb, eps, mean, rstd, gamma, beta, scale_shift, ld_ss, coef);
     } else {
+        if (coef) return cdae_fail("gn_stats_from_parts_coef: the coefficient table needs at most 32 channels per group");
         hipLaunchKernelGGL(gn_parts_channel_kernel, dim3((C + 31) / 32, N), dim3(256), 0, st, part1, C1, nseg1, part2, C2, part2 ? nseg2 : 1, N, HW, chan);
         hipLaunchKernelGGL(gn_parts_group_kernel, dim3(N), dim3(groups < 64 ? 64 : groups), 0, st, chan, C, HW, C / groups, groups, eps, mean, rstd);
     }
@@ -1073,7 +1099,13 @@ int cdae_gn_stats_from_parts(const float* part1, int C1, int nseg1, const float*
 
 int cdae_gn_stats2(const float* x1, int ld1, const float* x2, int ld2, int C1, int N, int HW, int C, int groups, float eps, float* mean,
                    float* rstd, float* ws, void* stream) {
+    return cdae_gn_stats2_coef(x1, ld1, x2, ld2, C1, N, HW, C, groups, eps, mean, rstd, nullptr, nullptr, nullptr, 0, nullptr, ws, stream);
+}
+
+int cdae_gn_stats2_coef(const float* x1, int ld1, const float* x2, int ld2, int C1, int N, int HW, int C, int groups, float eps, float* mean,
+                        float* rstd, const float* gamma, const float* beta, const float* scale_shift, int ld_ss, float* coef, float* ws, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    if (coef && (groups != 32 || !gamma || !beta)) return cdae_fail("gn_stats2_coef: the coefficient table needs 32 groups, gamma and beta");
     const int cpg = C / groups;
     if (!(cpg % 4 == 0 && ld1 % 4 == 0 && ld2 % 4 == 0 && C1 % 4 == 0) || C / 4 > 256) return cdae_fail("gn_stats2: needs 4-channel vectors, C <= 1024");
     const int E = C / 4;
@@ -1082,7 +1114,8 @@ int cdae_gn_stats2(const float* x1, int ld1, const float* x2, int ld2, int C1, i
     cdae_prof_begin(PROF_GN, (double)N * HW * C * 4.0, st);
     if (cdae_prof_on()) { char tag[96]; snprintf(tag, sizeof(tag), "cdae_gn_stats2 N=%d HW=%d C=%d", (int)N, (int)HW, (int)C); cdae_prof_tag(tag); }
     hipLaunchKernelGGL(gn_partial_kernel<4>, dim3(nchunk, N), dim3(256), 0, st, x1, HW, C, ld1, cpg, groups, ppb, ws, x2, ld2, C1);
-    if (groups == 32) hipLaunchKernelGGL(gn_finalize32_kernel, dim3(N), dim3(256), 0, st, x1, HW, ld1, cpg, nchunk, eps, ws, mean, rstd, x2, ld2, C1);
+    if (groups == 32) hipLaunchKernelGGL(gn_finalize32_kernel, dim3(N), dim3(256), 0, st, x1, HW, ld1, cpg, nchunk, eps, ws, mean, rstd, x2, ld2, C1, gamma, beta,
+                                         scale_shift, ld_ss, C, coef);
     else hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(groups < 64 ? 64 : groups), 0, st, x1, HW, ld1, cpg, groups, nchunk, eps, ws, mean, rstd, x2, ld2, C1);
     cdae_prof_end(PROF_GN, st);
     CHECK_LAUNCH("gn_stats2 launch failed");

@@ -180,11 +180,12 @@ class GroupNorm32(nn.Module):
         self.weight = nn.Parameter(th.ones(num_channels))
         self.bias = nn.Parameter(th.zeros(num_channels))
 
-    def forward(self, x, scale_shift=None, silu=False, split=False):
+    def forward(self, x, scale_shift=None, silu=False, split=False, coef=False):
         """split=True: the caller feeds the result straight into a conv3x3 / 1x1 GEMM; in no-grad f16 modes it is then written
-        as pre-split f16 planes (ops.SplitAct) for the LDS-DMA kernel."""
+        as pre-split f16 planes (ops.SplitAct) for the LDS-DMA kernel.  coef=True: the consumer is likely to apply the norm itself from
+        the per-(image, channel) coefficient table (ops.LazyGN.coefficients) — the statistics launch writes that table as well."""
         if split and len(x.shape) == 4 and ops.presplit_ok() and ops.can_split(self.num_channels, self.num_groups):
-            return ops.group_norm_lazy(x, self.weight, self.bias, scale_shift, silu, self.num_groups, self.eps)
+            return ops.group_norm_lazy(x, self.weight, self.bias, scale_shift, silu, self.num_groups, self.eps, want_coef=coef)
         if scale_shift is not None and not scale_shift.is_contiguous():          # a column slice of the batched emb_layers GEMM
             scale_shift = scale_shift.contiguous()
         return ops.group_norm(ops.materialize(x), self.weight, self.bias, scale_shift, silu, self.num_groups, self.eps)

@@ -895,11 +895,21 @@ class LazyGN:
     """A GroupNorm (+scale-shift, +SiLU) whose statistics are known but whose output has not been written: the consumer decides.
     The 1x1 skip conv of a ResBlock (skip_gn_fused), the attention block's qkv GEMM (linear_gn) and the output head (head_conv) apply it
     while they stream the fp32 rows; anything else calls `.planes()` and gets the pre-split f16 planes."""
-    __slots__ = ("x1", "x2", "shape", "stats", "gamma", "beta", "ss", "ld_ss", "silu", "groups")
+    __slots__ = ("x1", "x2", "shape", "stats", "gamma", "beta", "ss", "ld_ss", "silu", "groups", "coef")
 
-    def __init__(self, x1, x2, shape, stats, gamma, beta, ss, ld_ss, silu, groups):
+    def __init__(self, x1, x2, shape, stats, gamma, beta, ss, ld_ss, silu, groups, coef=None):
         self.x1, self.x2, self.shape, self.stats = x1, x2, tuple(shape), stats
         self.gamma, self.beta, self.ss, self.ld_ss, self.silu, self.groups = gamma, beta, ss, ld_ss, silu, groups
+        self.coef = coef                # [N, C, 2] (a, b) table, when the statistics kernel already wrote it (group_norm_lazy)
+
+    def coefficients(self):
+        """y = x * a + b per (image, channel): from the statistics launch where it wrote them, else one small launch (cdae_gn_coef)"""
+        if self.coef is None:
+            N, C = self.shape[0], self.shape[1]
+            self.coef = torch.empty((N, C, 2), dtype=torch.float32, device=self.x1.device)
+            check(lib.cdae_gn_coef(ptr(self.stats[0]), ptr(self.stats[1]), ptr(self.gamma), ptr(self.beta), ptr(self.ss), self.ld_ss, ptr(self.coef),
+                                   N, C, self.groups, stream()))
+        return self.coef
 
     def planes(self, gm=False):
         N, C, H, W = self.shape
@@ -931,8 +941,7 @@ def head_conv(lz, w, b=None):
     N, C, H, W = lz.shape
     dev = lz.x1.device
     st = stream()
-    coef = torch.empty((N, C, 2), dtype=torch.float32, device=dev)
-    check(lib.cdae_gn_coef(ptr(lz.stats[0]), ptr(lz.stats[1]), ptr(lz.gamma), ptr(lz.beta), ptr(lz.ss), lz.ld_ss, ptr(coef), N, C, lz.groups, st))
+    coef = lz.coefficients()
     y = torch.empty((N, w.shape[0], H, W), dtype=torch.float32, device=dev)
     check(lib.cdae_head_conv_fwd(ptr(lz.x1), C, ptr(coef), 1 if lz.silu else 0, ptr(w), ptr(b), ptr(y),
                                  N, H, W, C, w.shape[0], st))
@@ -961,8 +970,7 @@ def skip_gn_fused(lz, w, b=None, gm=False):
     C1, M, Nf = lz.x1.shape[1], N * H * W, w.shape[0]
     dev = lz.x1.device
     st = stream()
-    coef = torch.empty((N, C, 2), dtype=torch.float32, device=dev)
-    check(lib.cdae_gn_coef(ptr(lz.stats[0]), ptr(lz.stats[1]), ptr(lz.gamma), ptr(lz.beta), ptr(lz.ss), lz.ld_ss, ptr(coef), N, C, lz.groups, st))
+    coef = lz.coefficients()
     planes = torch.empty((2, N, H, W, C), dtype=torch.float16, device=dev)
     y = torch.empty((M, Nf), dtype=torch.float32, device=dev)
     if _SKIPGN_V2 and lib.cdae_skip_gn_ok(M, Nf, C, C1, H * W):      # the HBM-stream kernel on pre-split weight planes
@@ -977,7 +985,7 @@ def skip_gn_fused(lz, w, b=None, gm=False):
     return y.reshape(N, H, W, Nf).permute(0, 3, 1, 2), SplitAct(planes[0], planes[1], lz.shape)
 
 
-def group_norm_lazy(x, gamma, beta, scale_shift=None, silu=False, groups=32, eps=1e-5):
+def group_norm_lazy(x, gamma, beta, scale_shift=None, silu=False, groups=32, eps=1e-5, want_coef=False):
     """Statistics of a GroupNorm over x (a tensor or a CatAct), taken from the producing convs' partial sums where they exist;
     returns a LazyGN (no autograd)."""
     if isinstance(x, CatAct):
@@ -994,16 +1002,19 @@ def group_norm_lazy(x, gamma, beta, scale_shift=None, silu=False, groups=32, eps
         ld_ss = scale_shift.stride(0)
     stats = torch.empty((2, N, groups), dtype=torch.float32, device=dev)
     st = stream()
+    # the (a, b) table of consumers that apply the norm themselves, written by the statistics launch (GroupNorm32 shapes only)
+    coef = torch.empty((N, C, 2), dtype=torch.float32, device=dev) if want_coef and groups == 32 and C // groups <= 32 else None
+    cargs = (ptr(gamma), ptr(beta), ptr(scale_shift), ld_ss, ptr(coef)) if coef is not None else (None, None, None, 0, None)
     p1, p2 = getattr(x1, "_gnparts", None), getattr(x2, "_gnparts", None) if x2 is not None else None
     if p1 is not None and (x2 is None or p2 is not None) and (H * W) % 32 == 0:
         # the producing conv(s) left per-chunk partial sums behind: no statistics pass over the tensor
-        check(lib.cdae_gn_stats_from_parts(ptr(p1), C1, getattr(x1, "_gnseg", 1), ptr(p2), 0 if x2 is None else C - C1,
-                                           1 if x2 is None else getattr(x2, "_gnseg", 1), N, H * W, groups, eps,
-                                           *ptr2(stats), ptr(workspace(dev, "gnparts", workspace_bytes(WS_GN_PARTS, N, C))), st))
+        check(lib.cdae_gn_stats_from_parts_coef(ptr(p1), C1, getattr(x1, "_gnseg", 1), ptr(p2), 0 if x2 is None else C - C1,
+                                                1 if x2 is None else getattr(x2, "_gnseg", 1), N, H * W, groups, eps,
+                                                *ptr2(stats), *cargs, ptr(workspace(dev, "gnparts", workspace_bytes(WS_GN_PARTS, N, C))), st))
     else:
         ws = workspace(dev, "gn", 4 * lib.cdae_gn_workspace_floats(N, C))
-        check(lib.cdae_gn_stats2(ptr(x1), C1, ptr(x2), ld2, C1, N, H * W, C, groups, eps, *ptr2(stats), ptr(ws), st))
-    return LazyGN(x1, x2, (N, C, H, W), stats, gamma, beta, scale_shift, ld_ss, silu, groups)
+        check(lib.cdae_gn_stats2_coef(ptr(x1), C1, ptr(x2), ld2, C1, N, H * W, C, groups, eps, *ptr2(stats), *cargs, ptr(ws), st))
+    return LazyGN(x1, x2, (N, C, H, W), stats, gamma, beta, scale_shift, ld_ss, silu, groups, coef)
 
 
 def group_norm_split(x, gamma, beta, scale_shift=None, silu=False, groups=32, eps=1e-5):
@@ -1651,8 +1662,7 @@ def linear_gn(lz, w, b=None):
     M, Nf = N * H * W, w.shape[0]
     dev = lz.x1.device
     st = stream()
-    coef = torch.empty((N, C, 2), dtype=torch.float32, device=dev)
-    check(lib.cdae_gn_coef(ptr(lz.stats[0]), ptr(lz.stats[1]), ptr(lz.gamma), ptr(lz.beta), ptr(lz.ss), lz.ld_ss, ptr(coef), N, C, lz.groups, st))
+    coef = lz.coefficients()
     wh, wl = split_weight(w)
     y = torch.empty((M, Nf), dtype=torch.float32, device=dev)
     check(lib.cdae_linear_fwd_stream_gn(ptr(lz.x1), C, ptr(wh), ptr(wl), C, ptr(b), ptr(y), Nf, ptr(coef), 1 if lz.silu else 0, M, Nf, C, H * W, st))

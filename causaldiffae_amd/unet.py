@@ -169,9 +169,10 @@ class ResBlock(TimestepBlock):
                 x = ops.materialize(x)                              # grad mode off the fused path: a real (differentiable) concatenation
         if not isinstance(x, ops.CatAct):                          # CatAct: the skip concatenation, read in place by GN and the 1x1 skip
             x = ops.to_nhwc(x)
-        h = self.in_layers[0](x, silu=True, split=True)            # GN + SiLU (pre-split f16 planes on the inference path)
-        skip = None
         sk = self.skip_connection
+        # (coef: a 1x1 skip conv will apply this GroupNorm itself while it streams x — the statistics launch then writes its (a, b) table too)
+        h = self.in_layers[0](x, silu=True, split=True, coef=isinstance(sk, ConvNd) and sk.kernel_size == 1)      # GN + SiLU (pre-split f16 planes on the inference path)
+        skip = None
         if isinstance(h, ops.LazyGN) and isinstance(sk, ConvNd) and sk.kernel_size == 1 and ops.skip_gn_ok(h, sk.weight):
             skip, h = ops.skip_gn_fused(h, sk.weight, sk.bias, gm=True)     # the 1x1 skip conv writes the normalised planes (group-major: the next conv is the window kernel) while it reads x
         fast = isinstance(h, (ops.SplitAct, ops.LazyGN))
@@ -221,7 +222,7 @@ class AttentionBlock(nn.Module):
         x = ops.to_nhwc(x)
         N, C, H, W = x.shape
         T = H * W
-        h = self.norm(x, split=True)                                                # GN, no activation
+        h = self.norm(x, split=True, coef=True)                                     # GN, no activation (folded into the qkv GEMM where that is built)
         qkv = None
         if isinstance(h, ops.LazyGN):
             w2 = self.qkv.weight.reshape(self.qkv.weight.shape[0], -1)
@@ -439,5 +440,5 @@ class UNetModel(nn.Module):
         h = self.middle_block(h, emb)
         for module in self.output_blocks:
             h = module(ops.cat_channels(h, hs.pop()), emb)
-        h = self.out[0](h, silu=True, split=True)
+        h = self.out[0](h, silu=True, split=True, coef=True)
         return self.out[2](h, out_nchw=True), mu, var, z_post, mask

@@ -133,6 +133,14 @@ int cdae_gn_stats_from_parts(const float* part1, int C1, int nseg1 /* 1, or 4 fo
                              float* ws /* N * (C1 + C2) * 4 floats, 8-byte aligned */, void* stream);
 int cdae_gn_coef(const float* mean, const float* rstd, const float* gamma, const float* beta, const float* scale_shift, int ld_ss, float* coef,
                  int N, int C, int groups, void* stream);
+/* The same statistics with cdae_gn_coef's table [N][C][2] written by the statistics kernel itself (coef != NULL: gamma, beta and the
+   optional scale-shift rows are then required; 32 groups / at most 32 channels per group): one launch less per GroupNorm whose
+   consumer streams the fp32 rows (cdae_skip_gn_fwd, cdae_linear_fwd_stream_gn, cdae_head_conv).  Bit-identical to cdae_gn_coef. */
+int cdae_gn_stats_from_parts_coef(const float* part1, int C1, int nseg1, const float* part2, int C2, int nseg2, int N, int HW, int groups, float eps,
+                                  float* mean, float* rstd, const float* gamma, const float* beta, const float* scale_shift, int ld_ss, float* coef,
+                                  float* ws, void* stream);
+int cdae_gn_stats2_coef(const float* x1, int ld1, const float* x2, int ld2, int C1, int N, int HW, int C, int groups, float eps, float* mean,
+                        float* rstd, const float* gamma, const float* beta, const float* scale_shift, int ld_ss, float* coef, float* ws, void* stream);
 /* nearest-2x upsample + conv3x3 (unet.py:67-76) as four 2x2 sub-pixel convolutions of the low-resolution input: 2.25x fewer
    multiply-adds than convolving the upsampled image.  w4 = [4][Cout][2][2][Cin] folded weights as hi / lo planes. */
 int cdae_upconv3x3_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, long sn, long sy, long sx, const unsigned short* w4_hi,

@@ -573,6 +573,50 @@ def test_groupnorm_statistics_from_conv_epilogue(N, Cin, Cout, S, stride, cat):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("from_parts,cat,with_ss", [(False, False, True), (False, True, False), (True, False, True), (True, True, False)])
+def test_groupnorm_coefficient_table_from_statistics_launch(from_parts, cat, with_ss):
+    """The per-(image, channel) (a, b) table that the statistics kernels write on request (cdae_gn_stats2_coef /
+    cdae_gn_stats_from_parts_coef: one launch less per GroupNorm whose consumer applies it while streaming the rows) is bit-identical to
+    the table cdae_gn_coef computes from the same statistics — for a plain tensor, the two-source concatenation and a scale-shift slice."""
+    from causaldiffae_amd import ops
+    from causaldiffae_amd._lib import check, lib, ptr, stream
+    g = torch.Generator(device="cuda:0").manual_seed(14)
+    N, S = 64, 32
+    x = ops.to_nhwc(torch.randn(N, 128, S, S, device="cuda:0", generator=g))
+    with torch.no_grad():
+        if from_parts:
+            w = (torch.randn(256, 128, 3, 3, device="cuda:0", generator=g) / 34.0).contiguous(memory_format=torch.channels_last)
+            a = ops.conv3x3_ps(_split_nhwc(x), w, None, gn_stats=True)
+            w2 = (torch.randn(128, 128, 3, 3, device="cuda:0", generator=g) / 34.0).contiguous(memory_format=torch.channels_last)
+            b = ops.conv3x3_ps(_split_nhwc(x), w2, None, gn_stats=True)
+            assert hasattr(a, "_gnparts") and hasattr(b, "_gnparts")
+        else:
+            a = ops.to_nhwc(torch.randn(N, 256, S, S, device="cuda:0", generator=g))
+            b = ops.to_nhwc(torch.randn(N, 128, S, S, device="cuda:0", generator=g))
+        src = ops.CatAct(a, b) if cat else a
+        C = src.shape[1]
+        gamma, beta = torch.randn(C, device="cuda:0", generator=g), torch.randn(C, device="cuda:0", generator=g)
+        wide = torch.randn(N, 4 * C, device="cuda:0", generator=g)
+        ss = wide[:, C:3 * C] if with_ss else None                  # a column slice with a row pitch of 4 C, as the batched emb GEMM hands it over
+        lz = ops.group_norm_lazy(src, gamma, beta, ss, True, want_coef=True)
+        assert lz.coef is not None
+        got = lz.coefficients().clone()
+        ref = torch.empty_like(got)
+        check(lib.cdae_gn_coef(ptr(lz.stats[0]), ptr(lz.stats[1]), ptr(gamma), ptr(beta), ptr(ss), lz.ld_ss, ptr(ref), N, C, 32, stream()))
+        plain = ops.group_norm_lazy(src, gamma, beta, ss, True)
+        assert plain.coef is None and torch.equal(plain.stats, lz.stats) and torch.equal(plain.coefficients(), ref)
+    assert torch.equal(got, ref)
+    # and it is the GroupNorm: x * a + b == (x - mean) * rstd * gamma + beta (* (1 + scale) + shift)
+    xs = torch.cat([a, b], dim=1) if cat else a
+    mean, rstd = lz.stats[0].double().repeat_interleave(C // 32, dim=1), lz.stats[1].double().repeat_interleave(C // 32, dim=1)
+    y = (xs.double() - mean[:, :, None, None]) * rstd[:, :, None, None] * gamma.double()[None, :, None, None] + beta.double()[None, :, None, None]
+    if with_ss:
+        y = y * (1 + ss[:, :C].double())[:, :, None, None] + ss[:, C:].double()[:, :, None, None]
+    z = xs.double() * got[:, :, 0].double()[:, :, None, None] + got[:, :, 1].double()[:, :, None, None]
+    assert (y - z).abs().max().item() < 2e-5 * max(1.0, y.abs().max().item())
+
+
+@pytest.mark.gpu
 def test_groupnorm_statistics_from_upconv_phases():
     """A sub-pixel up-conv leaves four segments of partial sums (one per output parity); the next GroupNorm folds them."""
     from causaldiffae_amd import ops
