@@ -573,6 +573,38 @@ def test_groupnorm_statistics_from_conv_epilogue(N, Cin, Cout, S, stride, cat):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_window_conv_random_shapes(seed, expect_kernels):
+    """Seeded fuzz of the window conv kernel's geometry: batch, channel counts (multiples of 16 / 32 that give partial n-tiles and odd
+    chunk counts), image side, residual, K split — every case forced onto convwin_kernel by the dispatch threshold and checked against
+    F.conv2d in fp64 at the bar of the fixed cases (2e-5 of the largest output)."""
+    import random
+    from causaldiffae_amd import ops
+    from causaldiffae_amd._lib import check, lib, ptr, stream, tune_scope, range_check
+    rng = random.Random(1000 + seed)
+    g = torch.Generator(device="cuda:0").manual_seed(77 + seed)
+    for _ in range(8):
+        S = rng.choice([8, 16, 32, 64])
+        N = rng.randint(1, 9 if S >= 32 else 40)
+        ci, co = 32 * rng.randint(1, 12), 16 * rng.randint(2, 24)
+        res, splitk = rng.random() < 0.5, rng.randint(0, 1)
+        x = ops.to_nhwc(torch.randn(N, ci, S, S, device="cuda:0", generator=g))
+        w = (torch.randn(co, ci, 3, 3, device="cuda:0", generator=g) / (9 * ci) ** 0.5).contiguous(memory_format=torch.channels_last)
+        b = torch.randn(co, device="cuda:0", generator=g)
+        r = ops.to_nhwc(torch.randn(N, co, S, S, device="cuda:0", generator=g)) if res else None
+        planes = torch.empty((2, N, S, S, ci), dtype=torch.float16, device="cuda:0")
+        check(lib.cdae_split_f16(ptr(x), ptr(planes[0]), ptr(planes[1]), x.numel(), stream()))
+        with torch.no_grad(), tune_scope(convwin_min_tiles=1, convwin_splitk=splitk), expect_kernels(convwin=1):
+            y = ops.conv3x3_ps(ops.SplitAct(planes[0], planes[1], (N, ci, S, S)), w, b, res=r)
+        exact = F.conv2d(x.double().contiguous(), w.double(), b.double(), padding=1)
+        if res:
+            exact = exact + r.double()
+        e = (y.double() - exact).abs().max().item() / max(1.0, exact.abs().max().item())
+        assert torch.isfinite(y).all() and e < 2e-5, ((N, ci, co, S, res, splitk), e)
+    range_check("random shapes")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("from_parts,cat,with_ss", [(False, False, True), (False, True, False), (True, False, True), (True, True, False)])
 def test_groupnorm_coefficient_table_from_statistics_launch(from_parts, cat, with_ss):
     """The per-(image, channel) (a, b) table that the statistics kernels write on request (cdae_gn_stats2_coef /
@@ -759,6 +791,24 @@ def _wgrad_ref(a, dy):
 def test_wgrad_window_kernel_matches_fp64(N, H, W, Cin, Cout, accumulate):
     """cdae_conv3x3_wgrad_win (LDS-ring window, transpose-read fragments, bf16 hi/lo planes) against autograd in fp64; operands are
     exactly representable as hi + lo so the comparison sees only the fp32 accumulation."""
+    _wgrad_window_case(N, H, W, Cin, Cout, accumulate)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1])
+def test_wgrad_window_kernel_random_shapes(seed):
+    """Seeded fuzz of the window wgrad kernel's geometry (image count, side, non-square images, channel tiles, accumulate): the ring,
+    the image gaps, the mirror slots and the K split see block boundaries at every phase."""
+    import random
+    rng = random.Random(2000 + seed)
+    for _ in range(8):
+        W = rng.choice([8, 16, 32, 64])
+        H = rng.choice([h for h in (8, 16, 32, 64) if (h * W) % 64 == 0 and h * W <= 4096])
+        N = rng.randint(1, 6 if H * W >= 1024 else 48)
+        _wgrad_window_case(N, H, W, 64 * rng.randint(1, 6), 64 * rng.randint(1, 6), rng.randint(0, 1))
+
+
+def _wgrad_window_case(N, H, W, Cin, Cout, accumulate):
     from causaldiffae_amd._lib import check, lib, ptr, stream, splitk_ws, SPLITK_BYTES
     dev = "cuda:0"
     g = torch.Generator(device=dev).manual_seed(11)
