@@ -796,6 +796,37 @@ def test_wgrad_window_kernel_matches_fp64(N, H, W, Cin, Cout, accumulate):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", [0, 1])
+def test_window_dgrad_random_shapes(seed, expect_kernels):
+    """Seeded fuzz of the data-gradient instantiation of the window conv kernel (convwin_kernel<bf16>: bf16 hi/lo planes of dy, flipped-tap
+    [Cin][9][Cout] weight planes in K-group-major order), forced by the dispatch threshold with and without its K split, against
+    torch.nn.grad.conv2d_input in fp64.  dy is exactly hi + lo, the weight is rounded to bf16 x 2 (2^-16): bar 3e-5 of the largest value."""
+    import random
+    from causaldiffae_amd import ops
+    from causaldiffae_amd._lib import check, lib, ptr, ptr2, stream, tune_scope, splitk_ws, SPLITK_BYTES, range_check
+    rng = random.Random(3000 + seed)
+    g = torch.Generator(device="cuda:0").manual_seed(91 + seed)
+    dev = torch.device("cuda:0")
+    for _ in range(6):
+        S = rng.choice([8, 16, 32, 64])
+        N = rng.randint(1, 6 if S >= 32 else 36)
+        ci, co = 16 * rng.randint(2, 20), 32 * rng.randint(1, 10)
+        splitk = rng.randint(0, 1)
+        w = (torch.randn(co, ci, 3, 3, device=dev, generator=g) / (9 * co) ** 0.5).contiguous(memory_format=torch.channels_last)
+        dy = torch.randn(N, S, S, co, device=dev, generator=g) * 1e-3
+        dp = torch.empty((2, N, S, S, co), dtype=torch.bfloat16, device=dev)
+        check(lib.cdae_split_bf16(ptr(dy), ptr(dp[0]), ptr(dp[1]), dy.numel(), stream()))
+        dy_q = (dp[0].double() + dp[1].double()).permute(0, 3, 1, 2).contiguous()
+        dx = ops.new_act(N, ci, S, S, dev)
+        with tune_scope(convwin_min_tiles=1, convwin_splitk=splitk), expect_kernels(convwin_dgrad=1):
+            check(lib.cdae_conv3x3_dgrad_psk(*ptr2(dp), *ops._wptrs(w, True), ptr(dx), ci, N, S, S, ci, co, ptr(splitk_ws(dev)), SPLITK_BYTES, stream()))
+        exact = torch.nn.grad.conv2d_input((N, ci, S, S), w.double().contiguous(), dy_q, padding=1)
+        e = (dx.double() - exact).abs().max().item() / exact.abs().max().item()
+        assert torch.isfinite(dx).all() and e < 3e-5, ((N, ci, co, S, splitk), e)
+    range_check("dgrad random shapes")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1])
 def test_wgrad_window_kernel_random_shapes(seed):
     """Seeded fuzz of the window wgrad kernel's geometry (image count, side, non-square images, channel tiles, accumulate): the ring,
     the image gaps, the mirror slots and the K split see block boundaries at every phase."""
