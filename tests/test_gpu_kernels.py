@@ -483,6 +483,38 @@ def test_upconv_subpixel_matches_upsample_conv(N, Cin, Cout, S):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1])
+def test_upconv_subpixel_random_shapes(seed, expect_kernels):
+    """Seeded fuzz of the fused sub-pixel up-conv (four 2 x 2 phases of the window kernel in one launch, with and without the epilogue
+    statistics), forced by the dispatch threshold, against upsample + conv2d in fp64; the GroupNorm partial sums must add up to the
+    per-image sums of the result."""
+    import random
+    from causaldiffae_amd import ops
+    from causaldiffae_amd._lib import tune_scope, range_check
+    rng = random.Random(4000 + seed)
+    g = torch.Generator(device="cuda:0").manual_seed(55 + seed)
+    for _ in range(5):
+        S = rng.choice([8, 16, 32])
+        N = rng.randint(1, 6 if S == 32 else 24)
+        ci, co = 32 * rng.randint(1, 10), 32 * rng.randint(1, 10)
+        stats = rng.random() < 0.5
+        x = ops.to_nhwc(torch.randn(N, ci, S, S, device="cuda:0", generator=g))
+        w = (torch.randn(co, ci, 3, 3, device="cuda:0", generator=g) / (9 * ci) ** 0.5).contiguous(memory_format=torch.channels_last)
+        b = torch.randn(co, device="cuda:0", generator=g)
+        with torch.no_grad(), tune_scope(convwin_min_tiles=1), expect_kernels(convwin_up=1):
+            y = ops.upconv3x3_ps(_split_nhwc(x), w, b, gn_stats=stats)
+        exact = F.conv2d(F.interpolate(x.contiguous().double(), scale_factor=2, mode="nearest"), w.double(), b.double(), padding=1)
+        e = (y.double() - exact).abs().max().item() / max(1.0, exact.abs().max().item())
+        assert torch.isfinite(y).all() and e < 2e-5, ((N, ci, co, S, stats), e)
+        if hasattr(y, "_gnparts"):
+            parts = y._gnparts.double().reshape(4, N, -1, co, 2).sum((0, 2))
+            yr = y.permute(0, 2, 3, 1).reshape(N, -1, co).double()
+            assert (parts[:, :, 0] - yr.sum(1)).abs().max().item() < 1e-4 * yr.shape[1] / 32, (N, ci, co, S)
+            assert (parts[:, :, 1] - (yr * yr).sum(1)).abs().max().item() < 1e-3 * yr.shape[1] / 32, (N, ci, co, S)
+    range_check("upconv random shapes")
+
+
+@pytest.mark.gpu
 def test_epilogue_plane_outputs():
     """conv / linear epilogues that also emit the result as f16 hi/lo planes (input of a following pre-split conv)."""
     from causaldiffae_amd import ops
