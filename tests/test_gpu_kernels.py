@@ -1243,6 +1243,46 @@ def test_skip_gemm_carries_groupnorm_planes(N, C1, C2, Cout, H, stream_kernel, m
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1])
+def test_skip_sweep_random_shapes(seed):
+    """Seeded fuzz of the ResBlock entry sweep (skipgn_kernel): one or two sources, channel counts in steps of 32, partial row and column
+    tiles, pixel-major and group-major plane output, with the coefficient table taken from the statistics launch — planes bit-identical
+    to the GroupNorm apply kernel's, the 1x1 GEMM against fp64."""
+    import random
+    from causaldiffae_amd import ops
+    rng = random.Random(5000 + seed)
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(61 + seed)
+    cl = torch.channels_last
+    done = 0
+    while done < 6:
+        H = rng.choice([8, 16, 32])
+        N = rng.randint(1, 5 if H == 32 else 20)
+        C1, C2, Cout = 32 * rng.randint(1, 8), 32 * rng.randint(0, 6), 32 * rng.randint(2, 12)
+        C = C1 + C2
+        if (C // 32) % 4:                         # the plane kernels want 4-channel vectors inside a group
+            continue
+        a = torch.randn(N, C1, H, H, device=dev, generator=g).contiguous(memory_format=cl)
+        b = torch.randn(N, C2, H, H, device=dev, generator=g).contiguous(memory_format=cl) if C2 else None
+        gamma, beta = 1 + 0.1 * torch.randn(C, device=dev, generator=g), 0.1 * torch.randn(C, device=dev, generator=g)
+        w = torch.randn(Cout, C, 1, 1, device=dev, generator=g) / C ** 0.5
+        bias = 0.1 * torch.randn(Cout, device=dev, generator=g)
+        gm = rng.random() < 0.5
+        with torch.no_grad():
+            x = ops.CatAct(a, b) if C2 else a
+            lz = ops.group_norm_lazy(x, gamma, beta, None, True, 32, 1e-5, want_coef=True)
+            if not ops.skip_gn_ok(lz, w):
+                continue
+            skip, planes = ops.skip_gn_fused(lz, w, bias, gm=gm)
+            ref_planes = lz.planes(gm=gm)
+        assert planes.gm == ref_planes.gm and torch.equal(planes.hi, ref_planes.hi) and torch.equal(planes.lo, ref_planes.lo), (N, C1, C2, Cout, H, gm)
+        xx = torch.cat([a, b], dim=1) if C2 else a
+        ref64 = torch.einsum("nchw,oc->nohw", xx.double(), w.reshape(Cout, C).double()) + bias.double()[None, :, None, None]
+        assert (skip.double() - ref64).abs().max().item() < 4e-6 * ref64.abs().max().item(), (N, C1, C2, Cout, H, gm)
+        done += 1
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N,C,Nf,H,silu", [(32, 384, 1152, 16, False), (64, 512, 1536, 8, False), (16, 256, 768, 16, True), (5, 384, 1152, 32, False),
                                            (33, 128, 96, 12, True)])
 def test_groupnorm_linear_in_one_pass(N, C, Nf, H, silu):
