@@ -233,6 +233,9 @@ def train_bench(dev, world, rank, steps, warmup, batch, regions=1, image_size=64
             # CPU time of the hungriest rank (all its threads) per step; `world` such ranks share the cgroup quota on one node
             "host_cpu_ms_per_step": host_ms, "host_cpu_over_step": host_ms * sps / 1e3, "host_cpu_quota_cores": quota,
             "host_bound_risk": bool(world * host_ms * sps / 1e3 > 0.8 * quota),
+            # the driver's scaling run puts EIGHT such ranks under one cgroup quota: cores they would need vs 0.8 x the quota (this process's
+            # quota stands in for the node's: the 1-GPU lease and the 8-GPU node are provisioned alike)
+            "host_cores_needed_at_world8": 8 * host_ms * sps / 1e3, "host_bound_risk_at_world8": bool(8 * host_ms * sps / 1e3 > 0.8 * quota),
             "host_cpu_ms_per_step_by_thread": [[n, round(v, 2)] for n, v in per_thread[:6] if v >= 0.05],
             "dist_backend": (torch.distributed.get_backend() if world > 1 else None),
             "workload": workload or f"CausalCircuit 64x64 C=3 CausalDiffAE training step (fwd+bwd+all-reduce+AdamW/EMA), {nparams / 1e6:.1f}M params"}
@@ -415,7 +418,9 @@ def main():
             # HBM traffic of the dominant kernel: PMC counters cannot be read in-process (separate rocprofv3 --pmc passes of this same
             # command, folded by tools/pmc_summary.py and committed under profiles/)
             traffic = traffic_src = None
-            cands = [f"r03_convwin_pmc_summary_{prec}.json", f"r02_convwin_pmc_summary_{prec}.json"] if dom is cw else [f"r01_igemm_pmc_summary_{prec}.json"]
+            # (convwin: the 9-TAP instantiation's own summary — the 4-tap sub-pixel kernel is a separate kernel name and a separate file)
+            stem = "convwin9" if dom is cw else "igemm"
+            cands = [f"r04_{stem}_pmc_summary_{prec}.json"] + ([f"r03_convwin_pmc_summary_{prec}.json"] if dom is cw else [f"r01_igemm_pmc_summary_{prec}.json"])
             pmc_file = next((os.path.join(ROOT, "profiles", c) for c in cands if os.path.exists(os.path.join(ROOT, "profiles", c))), None)
             if pmc_file and N == 128:
                 pm = json.load(open(pmc_file))
@@ -445,17 +450,50 @@ def main():
             extra["guided_w2"] = {"value": N * kg / min(g_s), "unit": "image-steps/s", "ms_per_step": 1e3 * min(g_s) / kg, "steps": kg, "regions": 2,
                                   "forwards_per_step": 2, "model_tflops": 2 * N * kg / min(g_s) * GFLOP_PER_IMAGE_STEP_P64 / 1e3,
                                   "workload": "the same P64 DDIM step with guidance w = 2 (conditional + unconditional forward per step)"}
+            # SURVEY §8d config 3 names N in {16, 128}: the small batch is launch- and latency-bound (the ~300-launch graph matters most there)
+            n16 = 16
+            x16, kw16 = x_t[:n16].clone(), dict(z=z[:n16].clone())
+            k16 = max(20, min(args.steps, 50))
+
+            def run16(graph):
+                if graph:
+                    r16 = _GraphStep(diff, model, x16.clone(), kw16, True, None)
+                    step16 = lambda k: r16.step(k % T)
+                else:
+                    st16 = {"img": x16.clone()}
+                    tab16 = diff._step_table(dev, n16)
+
+                    def step16(k):
+                        st16["img"] = diff.ddim_sample(model, st16["img"], tab16[k % T], model_kwargs=kw16)["sample"]
+                for k in range(3):
+                    step16(k)
+                ts = []
+                for r in range(3):
+                    sync()
+                    t0 = time.perf_counter()
+                    for k in range(k16):
+                        step16(3 + r * k16 + k)
+                    sync()
+                    ts.append(time.perf_counter() - t0)
+                return statistics.median(ts)
+            d16, e16 = run16(True), run16(False)
+            extra["batch16"] = {"value": n16 * k16 / d16, "unit": "image-steps/s", "ms_per_step": 1e3 * d16 / k16, "steps": k16, "regions": 3,
+                                "eager_ms_per_step": 1e3 * e16 / k16, "eager_image_steps_per_sec": n16 * k16 / e16,
+                                "model_tflops": n16 * k16 / d16 * GFLOP_PER_IMAGE_STEP_P64 / 1e3,
+                                "frac_of_roof": n16 * k16 / d16 * GFLOP_PER_IMAGE_STEP_P64 / 1e3 / (F16_MFMA_PEAK_TFLOPS / 3.0 if prec0 == "f16x3" else FP32_MFMA_PEAK_TFLOPS),
+                                "workload": "the same P64 DDIM step at batch 16 (SURVEY 8d config 3, N = 16): graph replay; eager launches beside it"}
         # secondary leg (single GPU): the other product mode — IEEE fp32 products on v_mfma_f32_32x32x2_f32 against its own roof
         other = None
         if single and not args.no_fp32:
             alt = "fp32" if prec0 == "f16x3" else "f16x3"
             causaldiffae_amd.set_precision(alt)
             try:
-                k2 = 12
-                s2 = timed_ddim(k2, 2, 2)
-                dt2 = min(s2)
+                k2, r2 = max(20, min(args.steps, 30)), 3           # the headline's rigor: >= 20 steps x 3 regions, median region
+                s2 = timed_ddim(k2, 3, r2)
+                dt2 = statistics.median(s2)
                 other = {"precision_mode": alt, "value": N * k2 / dt2, "unit": "image-steps/s", "ms_per_step": 1e3 * dt2 / k2, "steps": k2,
-                         "regions": 2, "warmup": 2, "model_tflops": N * k2 / dt2 * GFLOP_PER_IMAGE_STEP_P64 / 1e3, "roofline": roofline(alt, 1)}
+                         "regions": r2, "warmup": 3, "spread": spread([N * k2 / s_ for s_ in s2]),
+                         "model_tflops": N * k2 / dt2 * GFLOP_PER_IMAGE_STEP_P64 / 1e3, "roofline": roofline(alt, 2)}
             finally:
                 causaldiffae_amd.set_precision(prec0)
 

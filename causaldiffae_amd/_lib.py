@@ -24,26 +24,30 @@ SIGNATURES = {
     "cdae_range_status": [P],
     "cdae_set_default_precision": [I],
     "cdae_get_default_precision": [],
-    "cdae_conv3x3_fwd": [P, L, L, L, L, P, P, P, P, L, I, I, I, I, I, I, I, I, P, SZ, P],
+    "cdae_conv3x3_fwd": [P, L, L, L, L, P, P, P, P, P, L, I, I, I, I, I, I, I, I, P, SZ, P],
     "cdae_conv3x3_dgrad": [P, L, P, P, L, I, I, I, I, I, I, I, I, P, SZ, P],
     "cdae_conv3x3_wgrad": [P, L, L, L, L, P, L, P, P, I, I, I, I, I, I, I, I, P, SZ, P],
-    "cdae_linear_fwd": [P, L, P, L, P, P, P, L, P, P, I, I, I, F, I, P, SZ, P],
-    "cdae_conv3x3_fwd_ps": [P, P, L, L, L, P, P, P, P, P, L, I, P, P, P, I, I, I, I, I, I, I, P, SZ, P],
-    "cdae_conv3x3_fwd_psk": [P, P, L, L, L, P, P, P, P, P, P, P, L, I, P, P, P, I, I, I, I, I, I, I, P, SZ, P],
+    "cdae_linear_fwd": [P, L, P, L, P, P, P, P, L, P, P, I, I, I, F, I, P, SZ, P],
+    "cdae_conv3x3_fwd_ps": [P, P, L, L, L, P, P, P, P, P, P, L, I, P, P, P, I, I, I, I, I, I, I, P, SZ, P],
+    "cdae_conv3x3_fwd_psk": [P, P, L, L, L, P, P, P, P, P, P, P, P, L, I, P, P, P, I, I, I, I, I, I, I, P, SZ, P],
     "cdae_conv3x3_dgrad_psk": [P, P, P, P, P, P, P, L, I, I, I, I, I, P, SZ, P],
     "cdae_conv_wpack": [P, P, P, P, I, I, I, P],
     "cdae_gn_coef": [P, P, P, P, P, I, P, I, I, I, P],
     "cdae_gn_stats_from_parts": [P, I, I, P, I, I, I, I, I, F, P, P, P, P],
     "cdae_gn_stats_from_parts_coef": [P, I, I, P, I, I, I, I, I, F, P, P, P, P, P, I, P, P, P],
     "cdae_gn_stats2_coef": [P, I, P, I, I, I, I, I, I, F, P, P, P, P, P, I, P, P, P],
-    "cdae_upconv3x3_fwd_ps": [P, P, L, L, L, P, P, P, P, L, P, I, I, I, I, I, P, SZ, P],
-    "cdae_linear_fwd_ps": [P, P, L, P, P, L, P, P, P, L, I, I, I, F, I, P, SZ, P],
+    "cdae_upconv3x3_fwd_ps": [P, P, L, L, L, P, P, P, P, P, L, P, I, I, I, I, I, P, SZ, P],
+    "cdae_linear_fwd_ps": [P, P, L, P, P, L, P, P, P, P, L, I, I, I, F, I, P, SZ, P],
     "cdae_split_f16": [P, P, P, L, P],
+    "cdae_split_f16w": [P, P, P, P, L, P],
+    "cdae_weight_scales": [P, P, I, I, P, P, P],
+    "cdae_weight_scales_chunk": [],
+    "cdae_weight_scale1": [P, L, P, P, P],
     "cdae_split_bf16": [P, P, P, L, P],
     "cdae_upsample2_split": [P, P, P, P, P, I, I, I, I, P],
     "cdae_wdgrad_planes": [P, P, P, I, I, P],
     "cdae_wprep_all": [P, P, I, I, L, P, P, P, P, P],
-    "cdae_wprep_all_k": [P, P, I, I, L, P, P, P, P, P, P, P, P, P],
+    "cdae_wprep_all_k": [P, P, I, I, L, P, P, P, P, P, P, P, P, P, P],
     "cdae_conv3x3_dgrad_ps": [P, P, P, P, P, L, I, I, I, I, I, P, SZ, P],
     "cdae_conv3x3_stem_supported": [I, I, I],
     "cdae_conv3x3_stem": [P, L, L, L, L, P, P, P, L, I, I, I, I, I, P],
@@ -53,17 +57,17 @@ SIGNATURES = {
     "cdae_gn_apply_split_train": [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, I, I, P],
     "cdae_gn_apply_split": [P, P, P, I, I, I, I, I, I, P, P, P, P, P, I, I, P],
     "cdae_gn_stats2": [P, I, P, I, I, I, I, I, I, F, P, P, P, P],
-    "cdae_linear_fwd_cat": [P, L, I, P, L, P, L, P, P, L, I, I, I, P, SZ, P],
-    "cdae_linear_fwd_cat_gn": [P, L, I, P, L, P, L, P, P, L, P, I, P, P, I, I, I, I, P, SZ, P],
+    "cdae_linear_fwd_cat": [P, L, I, P, L, P, L, P, P, P, L, I, I, I, P, SZ, P],
+    "cdae_linear_fwd_cat_gn": [P, L, I, P, L, P, L, P, P, P, L, P, I, P, P, I, I, I, I, P, SZ, P],
     "cdae_head_conv_supported": [I, I, I],
     "cdae_head_conv_fwd": [P, L, P, I, P, P, P, I, I, I, I, I, P],
     "cdae_skip_gn_ok": [I, I, I, I, I],
-    "cdae_linear_fwd_stream": [P, L, I, P, L, P, P, L, P, P, L, P, L, P, P, I, I, I, P],
-    "cdae_linear_fwd_stream_gn": [P, L, P, P, L, P, P, L, P, I, I, I, I, I, P],
-    "cdae_skip_gn_fwd": [P, L, I, P, L, P, P, L, P, P, L, P, I, P, P, I, I, I, I, I, P],
+    "cdae_linear_fwd_stream": [P, L, I, P, L, P, P, L, P, P, P, L, P, L, P, P, I, I, I, P],
+    "cdae_linear_fwd_stream_gn": [P, L, P, P, L, P, P, P, L, P, I, I, I, I, I, P],
+    "cdae_skip_gn_fwd": [P, L, I, P, L, P, P, L, P, P, P, L, P, I, P, P, I, I, I, I, I, P],
     "cdae_gn_apply_split2g": [P, I, P, I, I, P, P, I, I, I, I, P, P, P, P, P, I, I, P],
     "cdae_planes_gm_to_pc": [P, P, P, P, L, I, P],
-    "cdae_conv3x3_fwd_psg": [P, P, L, L, L, I, P, P, P, P, P, P, P, L, I, P, P, P, I, I, I, I, I, I, I, P, SZ, P],
+    "cdae_conv3x3_fwd_psg": [P, P, L, L, L, I, P, P, P, P, P, P, P, P, L, I, P, P, P, I, I, I, I, I, I, I, P, SZ, P],
     "cdae_gn_apply_split2": [P, I, P, I, I, P, P, I, I, I, I, I, P, P, P, P, P, I, I, P],
     "cdae_linear_dgrad": [P, L, P, L, P, L, I, I, I, I, P, SZ, P],
     "cdae_linear_wgrad": [P, L, P, L, P, L, P, I, I, I, I, P, SZ, P],
@@ -237,23 +241,40 @@ class CdaeRangeError(CdaeError):
     pass
 
 
+_RANGE_PENDING = [None]        # a flag found raised by range_clear: kept for the next range_check (whoever issued that work has not checked yet)
+
+
 def range_check(what="a contraction"):
     """Synchronise, read and clear the library's range flag; raise if any contraction produced a non-finite value since the last
-    check (an operand beyond the f16 range of the split-precision planes, or a genuinely non-finite input)."""
+    check (an operand beyond the f16 range of the split-precision planes, or a genuinely non-finite input) — including a flag that
+    a range_clear() in between found raised and set aside."""
     torch.cuda.synchronize()
     bad = ctypes.c_int(0)
     check(lib.cdae_range_status(ctypes.byref(bad)))
-    if bad.value:
-        raise CdaeRangeError(f"{what}: non-finite result — an operand left the range of the f16 split-precision planes (|x| < 65520) "
+    pending, _RANGE_PENDING[0] = _RANGE_PENDING[0], None
+    if bad.value or pending:
+        whose = what if bad.value else f"{what} (raised by earlier work: {pending})"
+        raise CdaeRangeError(f"{whose}: non-finite result — an operand left the range of the f16 split-precision planes (|x| < 65520) "
                              f"or was not finite; rerun with causaldiffae_amd.set_precision('fp32') (IEEE fp32 products, fp32 range)")
 
 
-def range_clear():
-    """Drop a stale range flag (raised by an earlier user of the library in this process whose own check has not run yet), so that
-    the next range_check reports on the work issued from here on."""
+def range_clear(owner="work issued before a sampling loop"):
+    """Start a fresh reporting interval: the next range_check then speaks for the work issued from here on.  A flag that is ALREADY
+    raised (e.g. by training steps since the trainer's last range_guard, when a sampling callback runs in between) is not dropped:
+    it is set aside and re-raised by the next range_check — after this loop's own check has passed — so the trainer's guard in
+    save() still sees it."""
     torch.cuda.synchronize()
     bad = ctypes.c_int(0)
     check(lib.cdae_range_status(ctypes.byref(bad)))
+    if bad.value and _RANGE_PENDING[0] is None:
+        _RANGE_PENDING[0] = owner
+
+
+def range_take_pending():
+    """-> the description of a set-aside flag (or None), clearing it: for a caller that wants to check ITS work only and report
+    earlier work separately (the sampling loop)."""
+    pending, _RANGE_PENDING[0] = _RANGE_PENDING[0], None
+    return pending
 
 
 class precision_scope:

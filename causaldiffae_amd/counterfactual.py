@@ -12,34 +12,40 @@ from .nn import reparameterize
 from .unet import ADJACENCY
 
 
-def encode_with_intervention(model, batch, A, var_index=None, value=None, var=0.001, eps=None, intervene_on="z_post"):
+def encode_with_intervention(model, batch, A, var_index=None, value=None, var=0.001, eps=None, intervene_on="z_post", columns=None):
     """-> z [N, rep_dim] conditioning the decoder.
 
     mu = encoder mean of `batch`; z_pre = A^T mu; z_post = MLP(z_pre) + mu; then the slice of variable `var_index`
-    (rep_dim / n_vars wide) is overwritten with `value` — on z_post (pendulum / circuit branches of the script) or on
-    mu before the causal layer (`intervene_on="mu"`, the MorphoMNIST branch) — and z = z_post + sqrt(var) * eps."""
+    (rep_dim / n_vars wide; or the explicit column range `columns` = (lo, hi), as the script's traversal hard-codes one) is
+    overwritten with `value` — on z_post (pendulum / circuit branches of the script) or on mu before the causal layer
+    (`intervene_on="mu"`, the MorphoMNIST branch and the traversal) — and z = z_post + sqrt(var) * eps."""
     mu, _ = model.rep_emb.encode(batch)
     nv = model.n_vars
     d = mu.shape[1] // nv
+    sl = None
+    if columns is not None:
+        sl = slice(int(columns[0]), int(columns[1]))
+    elif var_index is not None:
+        sl = slice(var_index * d, (var_index + 1) * d)
     if not getattr(model, "causal_modeling", True):      # DiffAE (image_diffae_test.py:270-300): no causal layer, edit mu itself
-        if var_index is not None:
+        if sl is not None:
             mu = mu.clone()
-            mu[:, var_index * d:(var_index + 1) * d] = value
+            mu[:, sl] = value
         return reparameterize(mu, th.full_like(mu, var), eps=eps)
     A = th.as_tensor(A, dtype=th.float32)
-    if var_index is not None and intervene_on == "mu":
+    if sl is not None and intervene_on == "mu":
         mu = mu.clone()
-        mu[:, var_index * d:(var_index + 1) * d] = value
+        mu[:, sl] = value
     z_pre = model.causal_mask.causal_masking(mu, A)
     z_post = model.causal_mask.nonlinearity_add_back_noise(mu, z_pre)
-    if var_index is not None and intervene_on == "z_post":
-        z_post[:, var_index * d:(var_index + 1) * d] = value
+    if sl is not None and intervene_on == "z_post":
+        z_post[:, sl] = value
     return reparameterize(z_post, th.full_like(z_post, var), eps=eps)
 
 
 def counterfactual_sample(model, diffusion, batch, A="circuit", var_index=None, value=None, *, use_ddim=True, eta=0.0, w=None,
                           clip_denoised=True, extra_kwargs=None, q_noise=None, z_eps=None, intervene_on="z_post",
-                          use_graph=True, shard=False, gather=False):
+                          use_graph=True, shard=False, gather=False, columns=None):
     """Counterfactual images for `batch` [N,C,S,S] (values in the training range) under do(var_index := value).
 
     Returns the decoded samples (this rank's shard unless gather=True).  `shard=True` splits the batch over the ranks of
@@ -54,7 +60,7 @@ def counterfactual_sample(model, diffusion, batch, A="circuit", var_index=None, 
     dev = next(model.parameters()).device
     batch = batch.to(dev)
     with th.no_grad():
-        z = encode_with_intervention(model, batch, A, var_index, value, eps=z_eps, intervene_on=intervene_on)
+        z = encode_with_intervention(model, batch, A, var_index, value, eps=z_eps, intervene_on=intervene_on, columns=columns)
         t_last = th.full((batch.shape[0],), diffusion.num_timesteps - 1, dtype=th.int64, device=dev)
         noise = th.randn_like(batch) if q_noise is None else q_noise.to(dev)
         x_t = diffusion.q_sample(batch, t_last, noise=noise)          # the script starts from a noised input, not pure noise
@@ -70,10 +76,36 @@ def counterfactual_sample(model, diffusion, batch, A="circuit", var_index=None, 
     return sample
 
 
-def latent_traversal(model, diffusion, batch, A, var_index, values, **kw):
-    """One counterfactual batch per intervention value (reference traversal loop, image_causaldae_test.py:481-531)."""
-    return [counterfactual_sample(model, diffusion, batch, A, var_index, float(v), **kw) for v in values]
+def traversal_values(start=-0.5, step=0.15, count=8):
+    """The intervention values of the script's traversal: `value = -0.5`, then `value += 0.15` eight times in a Python float
+    (image_causaldae_test.py:503-529) — the ACCUMULATED doubles, not start + i * step."""
+    out, v = [], float(start)
+    for _ in range(count):
+        out.append(v)
+        v += step
+    return out
 
+
+def latent_traversal(model, diffusion, batch, A, var_index=None, values=None, *, columns=None, intervene_on=None, q_noise=None, z_eps=None, **kw):
+    """One counterfactual batch per intervention value: the reference's traversal loop (image_causaldae_test.py:481-531).
+
+    As there: the noised start x_t = q_sample(batch, T - 1, noise) is computed ONCE and shared by every value (one noise draw, or
+    `q_noise`); every value gets a FRESH reparameterisation draw (`z_eps`: None, one tensor for all, or a list with one per value).
+    Called with neither `var_index` nor `columns` it is the script itself: `mu[:, 16:32] = value` before the causal layer for
+    value = -0.5, -0.35, ... (traversal_values()).  With `var_index` the edit goes to that variable's rep_dim / n_vars wide slice, on
+    z_post unless `intervene_on="mu"`."""
+    if var_index is None and columns is None:
+        columns = (16, 32)                       # the script's hard-coded slice
+        intervene_on = intervene_on or "mu"
+    intervene_on = intervene_on or "z_post"
+    values = traversal_values() if values is None else [float(v) for v in values]
+    if q_noise is None:
+        q_noise = th.randn_like(batch)
+    if not isinstance(z_eps, (list, tuple)):
+        z_eps = [z_eps] * len(values)
+    assert len(z_eps) == len(values)
+    return [counterfactual_sample(model, diffusion, batch, A, var_index, v, columns=columns, intervene_on=intervene_on, q_noise=q_noise, z_eps=e, **kw)
+            for v, e in zip(values, z_eps)]
 
 
 def label_conditional_sample(model, diffusion, batch, cond, var_index=None, value=None, *, from_input=True, use_ddim=True, eta=0.0,

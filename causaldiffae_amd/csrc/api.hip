@@ -49,7 +49,7 @@ int cdae_colsum(const float* x, long ldx, float* out, long rows, int cols, int a
     return hipGetLastError() == hipSuccess ? 0 : cdae_fail("colsum launch failed");
 }
 
-int cdae_conv3x3_fwd(const float* x, long sn, long sy, long sx, long sc, const float* w, const float* bias, const float* res,
+int cdae_conv3x3_fwd(const float* x, long sn, long sy, long sx, long sc, const float* w, const float* w_scale, const float* bias, const float* res,
                      float* out, long ldo, int out_nchw, int N, int H, int W, int Cin, int Cout, int stride, int up,
                      float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
     if (stride != 1 && stride != 2) return cdae_fail("conv3x3: stride must be 1 or 2");
@@ -59,7 +59,7 @@ int cdae_conv3x3_fwd(const float* x, long sn, long sy, long sx, long sc, const f
     if (stride == 1 && !up && !out_nchw && !res && cdae_conv3x3_stem_supported(Cin, Cout, W) && ldo % 4 == 0 && aligned16(out) && aligned16(bias))
         return cdae_conv3x3_stem(x, sn, sy, sx, sc, w, bias, out, ldo, N, H, W, Cin, Cout, stream);
     GemmParams p = base_params();
-    p.A = x; p.B = w; p.C = out; p.bias = bias; p.res = res;
+    p.A = x; p.B = w; p.w_scale = w_scale; p.C = out; p.bias = bias; p.res = res;
     p.M = N * Ho * Wo; p.N = Cout; p.K = 9 * Cin;
     p.ldb = 9L * Cin; p.ldc = ldo;
     p.out_mode = out_nchw ? OUT_NCHW : OUT_ROWMAJOR; p.out_hw = Ho * Wo;
@@ -103,19 +103,19 @@ size_t cdae_workspace_bytes(int op, const long* dims, int ndims) {
 }
 
 int cdae_conv3x3_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, long sn, long sy, long sx, const unsigned short* w_hi,
-                        const unsigned short* w_lo, const float* bias, const float* res, float* out, long ldo, int out_nchw,
+                        const unsigned short* w_lo, const float* w_scale, const float* bias, const float* res, float* out, long ldo, int out_nchw,
                         unsigned short* out_hi, unsigned short* out_lo, float* gn_part, int N, int H, int W,
                         int Cin, int Cout, int stride, int up, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
-    return cdae_conv3x3_fwd_psk(x_hi, x_lo, sn, sy, sx, w_hi, w_lo, nullptr, nullptr, bias, res, out, ldo, out_nchw, out_hi, out_lo, gn_part, N, H, W, Cin,
+    return cdae_conv3x3_fwd_psk(x_hi, x_lo, sn, sy, sx, w_hi, w_lo, nullptr, nullptr, w_scale, bias, res, out, ldo, out_nchw, out_hi, out_lo, gn_part, N, H, W, Cin,
                                 Cout, stride, up, splitk_ws, splitk_ws_bytes, stream);
 }
 
 // the same with the weights ALSO in K-group-major order (wk_hi / wk_lo from cdae_conv_wpack, may be null): the window kernel's layout
 int cdae_conv3x3_fwd_psk(const unsigned short* x_hi, const unsigned short* x_lo, long sn, long sy, long sx, const unsigned short* w_hi,
-                         const unsigned short* w_lo, const unsigned short* wk_hi, const unsigned short* wk_lo, const float* bias, const float* res,
+                         const unsigned short* w_lo, const unsigned short* wk_hi, const unsigned short* wk_lo, const float* w_scale, const float* bias, const float* res,
                          float* out, long ldo, int out_nchw, unsigned short* out_hi, unsigned short* out_lo, float* gn_part, int N, int H, int W,
                          int Cin, int Cout, int stride, int up, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
-    return cdae_conv3x3_fwd_psg(x_hi, x_lo, sn, sy, sx, 0, w_hi, w_lo, wk_hi, wk_lo, bias, res, out, ldo, out_nchw, out_hi, out_lo, gn_part, N, H, W, Cin, Cout,
+    return cdae_conv3x3_fwd_psg(x_hi, x_lo, sn, sy, sx, 0, w_hi, w_lo, wk_hi, wk_lo, w_scale, bias, res, out, ldo, out_nchw, out_hi, out_lo, gn_part, N, H, W, Cin, Cout,
                                 stride, up, splitk_ws, splitk_ws_bytes, stream);
 }
 
@@ -123,7 +123,7 @@ int cdae_conv3x3_fwd_psk(const unsigned short* x_hi, const unsigned short* x_lo,
 // window kernel reads that layout: returns 3 (no error set) when the shape would run on another kernel — the caller converts with
 // cdae_planes_gm_to_pc and calls again with x_gm = 0.
 int cdae_conv3x3_fwd_psg(const unsigned short* x_hi, const unsigned short* x_lo, long sn, long sy, long sx, int x_gm, const unsigned short* w_hi,
-                         const unsigned short* w_lo, const unsigned short* wk_hi, const unsigned short* wk_lo, const float* bias, const float* res,
+                         const unsigned short* w_lo, const unsigned short* wk_hi, const unsigned short* wk_lo, const float* w_scale, const float* bias, const float* res,
                          float* out, long ldo, int out_nchw, unsigned short* out_hi, unsigned short* out_lo, float* gn_part, int N, int H, int W,
                          int Cin, int Cout, int stride, int up, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
     if (x_gm && (stride != 1 || up || out_nchw || Cin % 16)) return 3;
@@ -138,7 +138,7 @@ int cdae_conv3x3_fwd_psg(const unsigned short* x_hi, const unsigned short* x_lo,
     GemmParams p = base_params();
     p.presplit = 1;
     p.A = reinterpret_cast<const float*>(x_hi); p.A_lo = x_lo; p.B = reinterpret_cast<const float*>(w_hi); p.B_lo = w_lo;
-    p.Bk_hi = wk_hi; p.Bk_lo = wk_lo; p.a_gm = x_gm;
+    p.Bk_hi = wk_hi; p.Bk_lo = wk_lo; p.a_gm = x_gm; p.w_scale = w_scale;
     p.C = out; p.bias = bias; p.res = res; p.C_hi = out_hi; p.C_lo = out_lo; p.gn_part = gn_part;
     p.M = N * Ho * Wo; p.N = Cout; p.K = 9 * Cin;
     p.ldb = 9L * Cin; p.ldc = ldo;
@@ -156,7 +156,7 @@ int cdae_conv3x3_fwd_psg(const unsigned short* x_hi, const unsigned short* x_lo,
 // 2+1, likewise for columns — 16 instead of 36 multiply-adds per (pixel, channel pair).  w4 = [4 phases][Cout][2][2][Cin]
 // folded weights (hi / lo planes); the result lands in out[N, 2H, 2W, Cout] rows of pitch ldo.
 int cdae_upconv3x3_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, long sn, long sy, long sx, const unsigned short* w4_hi,
-                          const unsigned short* w4_lo, const float* bias, float* out, long ldo, float* gn_part, int N, int H, int W, int Cin,
+                          const unsigned short* w4_lo, const float* w_scale, const float* bias, float* out, long ldo, float* gn_part, int N, int H, int W, int Cin,
                           int Cout, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
     if ((long)N * H * W * sx >= (1L << 31)) return cdae_fail("upconv3x3_fwd_ps: activation larger than 2^31 elements");
     if (sx % 8 || sy % 8 || sn % 8 || !aligned16(x_hi) || !aligned16(x_lo) || !aligned16(w4_hi) || !aligned16(w4_lo))
@@ -170,7 +170,7 @@ int cdae_upconv3x3_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo
         const long woff = (long)ph * Cout * 4 * Cin;
         p.A = reinterpret_cast<const float*>(x_hi); p.A_lo = x_lo;
         p.B = reinterpret_cast<const float*>(w4_hi + woff); p.B_lo = w4_lo + woff;
-        p.C = out; p.bias = bias;
+        p.C = out; p.bias = bias; p.w_scale = w_scale;
         p.M = N * H * W; p.N = Cout; p.K = 4 * Cin;
         p.ldb = 4L * Cin; p.ldc = ldo;
         p.out_mode = OUT_UP2;
@@ -192,14 +192,14 @@ int cdae_upconv3x3_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo
 }
 
 int cdae_linear_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, long ldx, const unsigned short* w_hi, const unsigned short* w_lo,
-                       long ldw, const float* bias, const float* res, float* y, long ldy, int M, int N, int K, float alpha, int act,
+                       long ldw, const float* w_scale, const float* bias, const float* res, float* y, long ldy, int M, int N, int K, float alpha, int act,
                        float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
     if ((long)M * ldx >= (1L << 31)) return cdae_fail("linear_fwd_ps: activation larger than 2^31 elements");
     if (!aligned16(x_hi) || !aligned16(x_lo) || !aligned16(w_hi) || !aligned16(w_lo)) return cdae_fail("linear_fwd_ps: planes must be 16-byte aligned");
     GemmParams p = base_params();
     p.presplit = 1;
     p.A = reinterpret_cast<const float*>(x_hi); p.A_lo = x_lo; p.B = reinterpret_cast<const float*>(w_hi); p.B_lo = w_lo;
-    p.C = y; p.bias = bias; p.res = res;
+    p.C = y; p.bias = bias; p.res = res; p.w_scale = w_scale;
     p.M = M; p.N = N; p.K = K; p.lda = ldx; p.ldb = ldw; p.ldc = ldy; p.alpha = alpha; p.act = act;
     p.amode = A_PLAIN_KC; p.bmode = B_PLAIN_KC;
     set_splitk(p, splitk_ws, splitk_ws_bytes);
@@ -287,11 +287,11 @@ int cdae_conv3x3_dgrad_psk(const unsigned short* dy_hi, const unsigned short* dy
     return cdae_gemm_dispatch(p, stream);
 }
 
-int cdae_linear_fwd(const float* x, long ldx, const float* w, long ldw, const float* bias, const float* res, float* y, long ldy,
+int cdae_linear_fwd(const float* x, long ldx, const float* w, long ldw, const float* w_scale, const float* bias, const float* res, float* y, long ldy,
                     unsigned short* y_hi, unsigned short* y_lo, int M, int N, int K, float alpha, int act, float* splitk_ws,
                     size_t splitk_ws_bytes, void* stream) {
     GemmParams p = base_params();
-    p.A = x; p.B = w; p.C = y; p.bias = bias; p.res = res; p.C_hi = y_hi; p.C_lo = y_lo;
+    p.A = x; p.B = w; p.w_scale = w_scale; p.C = y; p.bias = bias; p.res = res; p.C_hi = y_hi; p.C_lo = y_lo;
     if (y_hi && !y_lo) return cdae_fail("linear_fwd: plane output needs both planes");
     p.M = M; p.N = N; p.K = K; p.lda = ldx; p.ldb = ldw; p.ldc = ldy; p.alpha = alpha; p.act = act;
     p.amode = A_PLAIN_KC; p.bmode = B_PLAIN_KC;
@@ -302,12 +302,12 @@ int cdae_linear_fwd(const float* x, long ldx, const float* w, long ldw, const fl
 }
 
 // y = [x1 | x2] @ w^T + bias: the K range split over two row-major sources (a channel concatenation read in place)
-int cdae_linear_fwd_cat(const float* x1, long ld1, int K1, const float* x2, long ld2, const float* w, long ldw, const float* bias, float* y,
+int cdae_linear_fwd_cat(const float* x1, long ld1, int K1, const float* x2, long ld2, const float* w, long ldw, const float* w_scale, const float* bias, float* y,
                         long ldy, int M, int N, int K, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
     if (K1 % 32 || K % 4 || ld1 % 4 || ld2 % 4 || ldw % 4 || !aligned16(x1) || !aligned16(x2) || !aligned16(w))
         return cdae_fail("linear_fwd_cat: K1 % 32 == 0 and 16-byte aligned rows required");
     GemmParams p = base_params();
-    p.A = x1; p.A2 = x2; p.lda2 = ld2; p.K1 = K1; p.B = w; p.C = y; p.bias = bias;
+    p.A = x1; p.A2 = x2; p.lda2 = ld2; p.K1 = K1; p.B = w; p.w_scale = w_scale; p.C = y; p.bias = bias;
     p.M = M; p.N = N; p.K = K; p.lda = ld1; p.ldb = ldw; p.ldc = ldy;
     p.amode = A_PLAIN_KC; p.bmode = B_PLAIN_KC;
     set_splitk(p, splitk_ws, splitk_ws_bytes);
@@ -317,14 +317,14 @@ int cdae_linear_fwd_cat(const float* x1, long ld1, int K1, const float* x2, long
 // cdae_linear_fwd_cat that ALSO writes GroupNorm(+SiLU)([x1 | x2]) as f16 hi/lo planes [M][K] while the rows pass through its loader:
 // the ResBlock's 1x1 skip conv and the normalisation pass of its first GroupNorm in one sweep over the block input.  coef [N][K][2]
 // from cdae_gn_coef; HW = pixels per image (rows per coefficient set).  x2 may be NULL (one source).
-int cdae_linear_fwd_cat_gn(const float* x1, long ld1, int K1, const float* x2, long ld2, const float* w, long ldw, const float* bias, float* y,
+int cdae_linear_fwd_cat_gn(const float* x1, long ld1, int K1, const float* x2, long ld2, const float* w, long ldw, const float* w_scale, const float* bias, float* y,
                            long ldy, const float* coef, int silu, unsigned short* s_hi, unsigned short* s_lo, int M, int N, int K, int HW,
                            float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
     if ((x2 && K1 % 32) || K % 32 || ld1 % 4 || (x2 && ld2 % 4) || ldw % 4 || !aligned16(x1) || !aligned16(x2) || !aligned16(w) || !aligned16(coef) ||
         !aligned16(s_hi) || !aligned16(s_lo) || !s_hi || !s_lo || !coef || HW <= 0 || M % HW)
         return cdae_fail("linear_fwd_cat_gn: K (and K1) % 32 == 0, 16-byte aligned rows / planes / coefficients, M a multiple of HW required");
     GemmParams p = base_params();
-    p.A = x1; p.A2 = x2; p.lda2 = ld2; p.K1 = x2 ? K1 : K; p.B = w; p.C = y; p.bias = bias;
+    p.A = x1; p.A2 = x2; p.lda2 = ld2; p.K1 = x2 ? K1 : K; p.B = w; p.w_scale = w_scale; p.C = y; p.bias = bias;
     p.M = M; p.N = N; p.K = K; p.lda = ld1; p.ldb = ldw; p.ldc = ldy;
     p.amode = A_PLAIN_KC; p.bmode = B_PLAIN_KC;
     p.gn_coef = coef; p.gn_silu = silu; p.S_hi = s_hi; p.S_lo = s_lo;

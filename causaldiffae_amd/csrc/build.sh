@@ -8,8 +8,9 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="${EXTRA_HIPCC_FLAGS:-} --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -Wno-inline-asm -I../../include"
 UNITS="igemm planes api norm elementwise prof attention wgrad stem convwin skipgn head"
 mkdir -p build
-if [ "$(cat build/.flags 2>/dev/null || true)" != "$FLAGS" ]; then FORCE=1; fi
-echo "$FLAGS" > build/.flags
+# (the flag record is written only after every compile step has succeeded: a failed build after a flag change must not leave
+#  objects of the old flag set looking current)
+if [ "$(cat build/.flags 2>/dev/null || true)" != "$FLAGS" ]; then FORCE=1; rm -f build/.flags; fi
 pids=()
 for u in $UNITS; do
     obj=build/$u.o
@@ -20,6 +21,7 @@ for u in $UNITS; do
     fi
 done
 for pid in "${pids[@]:-}"; do [ -z "$pid" ] || wait "$pid" || { echo "build.sh: a compile step failed" >&2; exit 1; }; done     # a bare `wait` would hide failures
+echo "$FLAGS" > build/.flags
 objs=""
 for u in $UNITS; do objs="$objs build/$u.o"; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $objs

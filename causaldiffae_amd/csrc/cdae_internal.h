@@ -17,6 +17,10 @@ struct GemmParams {
     int batch, batch_inner;
     long a_bs0, a_bs1, b_bs0, b_bs1, c_bs0, c_bs1;
     float alpha;
+    // scale record {2^k, 2^-k} of the WEIGHT operand (cdae_weight_scales; device memory, nullptr: unscaled).  Pre-split weight planes
+    // hold w * 2^k (elementwise.hip: keeps the lo plane of small weights a normal f16) and the fp32-operand kernels multiply the B tile by
+    // [0] before they split it; every epilogue / split-K finish multiplies the sum by [1] on top of alpha.
+    const float* w_scale;
     int act, out_mode, out_hw, accumulate;
     int amode, bmode;
     int a_scalar, b_scalar;   // operand not 16-byte vectorisable (odd K / pitch / alignment): element-wise loads

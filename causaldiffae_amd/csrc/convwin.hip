@@ -371,6 +371,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
         // recomputed here, once per tile, instead of being hoisted out of the persistent loop and kept live across the K loop
         int lr_ = lr, kg_ = kg;
         asm volatile("" : "+v"(lr_), "+v"(kg_));
+        const float alpha_ = p.w_scale ? p.alpha * p.w_scale[1] : p.alpha;      // the weight planes hold w * 2^k: the exact 2^-k rides on alpha
         if (dbg_ & 256) {}                                                // dev ablation: no epilogue
         else if (interior && p.ksplit == 1 && !p.accumulate && !p.C_hi) {
             // the common case, kept lean (the general path below spends ~20 instructions per element on bounds and mode tests):
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                     for (int r = 0; r < 4; ++r) {
                         float v[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = (acc[2 * i2 + ii][j][r] * p.alpha + bv[j]) + rv[r][j];
+                        for (int j = 0; j < 4; ++j) v[j] = (acc[2 * i2 + ii][j][r] * alpha_ + bv[j]) + rv[r][j];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) { cbase[ro[r] + 16 * j] = v[j]; gs[j] += v[j]; gq[j] += v[j] * v[j]; }      // (nontemporal stores: measured +-0)
                         // f16 plane overflow surfaces as NaN / inf.  (The branch per row also keeps hipcc's register allocation in check: with a
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                                         const int x = row & (p.Wo - 1);
                                         addr = (4L * row - 2 * x + eph_y * 2 * p.Wo + eph_x) * p.ldc + col;
                                     } else addr = (long)row * p.ldc + col;
-                                    float v = a * p.alpha + bv[j];
+                                    float v = a * alpha_ + bv[j];
                                     if (Rg) v += Rg[addr];
                                     if (p.accumulate) v += Cg[addr];
                                     Cg[addr] = v;
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                         float s_ = gs[j], q_ = gq[j];
                         s_ += __shfl_xor(s_, 16); q_ += __shfl_xor(q_, 16);
                         s_ += __shfl_xor(s_, 32); q_ += __shfl_xor(q_, 32);
-                        if (kg_ == 0 && col0 + 16 * j < p.N) {
+                        if (kg_ == 0 && col0 + 16 * j < p.N && em0 + wm * 128 + 32 * i2 < p.M) {      // chunks beyond the last row have no slot
                             float* o = p.gn_part + (long)eph * p.phase_gn + ((long)((em0 + wm * 128 + 32 * i2) >> 5) * p.N + col0 + 16 * j) * 2;
                             o[0] = s_; o[1] = q_;
                         }

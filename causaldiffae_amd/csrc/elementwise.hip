@@ -40,6 +40,73 @@ __global__ void split_f16_kernel(const float4* __restrict__ src, ew_half4* __res
     }
 }
 
+// ---- per-tensor power-of-two scale of WEIGHT planes.  hi = f16(w), lo = f16(w - hi) loses its second half as soon as |w| < 2^-3: lo is then an
+// f16 SUBNORMAL and the pair is fixed point with an LSB of 2^-24 (|w| ~ 0.01: 1e-5 relative, 100x the fp32 epsilon) — and network weights live
+// exactly there (+-sqrt(3 / fan_in) <= 0.03 for every 3x3 conv).  So weight planes hold w * 2^k with k = 14 - floor(log2(max |w|)) per tensor
+// (scaled maximum in [2^14, 2^15): below the f16 maximum with room for the rounding), which keeps lo normal for every element above
+// 2^-18 of the tensor's maximum and bounds the error of ANY element by 2^-39 of that maximum; the contraction's epilogue multiplies by the
+// exact 2^-k.  A scale record is two floats {2^k, 2^-k}; max |w| == 0 or a non-finite maximum gives {1, 1} (non-finite weights then surface
+// through the range flag as before).
+__device__ __forceinline__ float wscale_from_maxbits(unsigned bits) {       // bits of max |w| (sign cleared) -> 2^k
+    const int ex = (int)(bits >> 23);
+    if (ex == 0 || ex == 255) return 1.f;                                    // zero / subnormal maximum, inf, NaN
+    int k = 14 - (ex - 127);
+    k = k > 126 ? 126 : (k < -126 ? -126 : k);
+    return __builtin_bit_cast(float, (unsigned)(k + 127) << 23);
+}
+
+struct WScaleDesc { long off; long n; int chunk0; int pad; };                // chunk0: running sum of ceil(n / WS_CHUNK)
+constexpr int WS_CHUNK = 8192;
+__global__ __launch_bounds__(256) void wscale_max_kernel(const float* __restrict__ flat, const WScaleDesc* __restrict__ desc, int nw, unsigned* __restrict__ maxbits) {
+    int lo = 0, hi = nw - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (desc[mid].chunk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+    const WScaleDesc d = desc[lo];
+    const long c0 = (long)(blockIdx.x - d.chunk0) * WS_CHUNK;
+    const long c1 = c0 + WS_CHUNK < d.n ? c0 + WS_CHUNK : d.n;
+    const float* w = flat + d.off;
+    unsigned m = 0;
+    for (long i = c0 + threadIdx.x; i < c1; i += 256) {
+        const unsigned b = __builtin_bit_cast(unsigned, w[i]) & 0x7FFFFFFFu;      // |w| as an integer: monotone in the magnitude, NaN sorts above inf
+        m = b > m ? b : m;
+    }
+    for (int o = 32; o; o >>= 1) { const unsigned t = __shfl_xor(m, o); m = t > m ? t : m; }
+    __shared__ unsigned wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; ++i) m = wm[i] > m ? wm[i] : m;
+        atomicMax(maxbits + lo, m);
+    }
+}
+__global__ __launch_bounds__(256) void wscale_max1_kernel(const float* __restrict__ w, long n, unsigned* __restrict__ maxbits) {      // one tensor
+    unsigned m = 0;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const unsigned b = __builtin_bit_cast(unsigned, w[i]) & 0x7FFFFFFFu;
+        m = b > m ? b : m;
+    }
+    for (int o = 32; o; o >>= 1) { const unsigned t = __shfl_xor(m, o); m = t > m ? t : m; }
+    if ((threadIdx.x & 63) == 0) atomicMax(maxbits, m);
+}
+__global__ void wscale_finish_kernel(const unsigned* __restrict__ maxbits, float* __restrict__ rec, int nw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nw) return;
+    const float s = wscale_from_maxbits(maxbits[i]);
+    rec[2 * i] = s; rec[2 * i + 1] = 1.f / s;                                // exact: a power of two
+}
+// hi = f16(x * 2^k), lo = f16(x * 2^k - hi), the scale read from a record (the multiplication is exact)
+__global__ void split_f16w_kernel(const float4* __restrict__ src, const float* __restrict__ rec, ew_half4* __restrict__ hi, ew_half4* __restrict__ lo, long n4) {
+    const float sc = rec[0];
+    GRID_STRIDE(i, n4) {
+        float4 v = src[i];
+        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+        ew_half4 h, l;
+        h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+        l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]);
+        l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);
+        hi[i] = h; lo[i] = l;
+    }
+}
+
 // fp32 -> two bf16 planes (hi = bf16(x), lo = bf16(x - hi)): gradients on the pre-split path (full fp32 range, 16 significand bits)
 typedef __bf16 ew_bf4 __attribute__((ext_vector_type(4)));
 __global__ void split_bf16_kernel(const float4* __restrict__ src, ew_bf4* __restrict__ hi, ew_bf4* __restrict__ lo, long n4) {
@@ -109,13 +176,16 @@ struct WPrepDesc { long off; int Cout, Cin, tile0, flags; };      // flags bit 0
 __global__ __launch_bounds__(256) void wprep_all_kernel(const float* __restrict__ flat, const WPrepDesc* __restrict__ desc, int nw, long base,
                                                         _Float16* __restrict__ fh, _Float16* __restrict__ fl, __bf16* __restrict__ bh,
                                                         __bf16* __restrict__ bl, _Float16* __restrict__ kfh, _Float16* __restrict__ kfl,
-                                                        __bf16* __restrict__ kbh, __bf16* __restrict__ kbl) {
+                                                        __bf16* __restrict__ kbh, __bf16* __restrict__ kbl, const float* __restrict__ wscale) {
+    // wscale (optional): scale records {2^k, 2^-k} per weight (cdae_weight_scales over the same descriptors' tensors, same order): the f16
+    // planes then hold w * 2^k; the bf16 dgrad planes (fp32 exponent range: no subnormal problem) stay unscaled
     // kf* / kb* (optional): the same planes in K-group-major order [K / 16][9][rows][16] (cdae_conv_wpack's layout) at the same offsets, for the
     // weights whose descriptor asks for them (a packed index of a weight with Cin % 16 != 0 would leave the weight's own region)
     __shared__ float tile[32][33];
     int lo = 0, hi = nw - 1;                       // last descriptor whose first tile <= blockIdx.x
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (desc[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
     const WPrepDesc d = desc[lo];
+    const float fsc = wscale ? wscale[2 * (d.flags >> 8)] : 1.f;          // flags: bit 0 packable, bits 8.. the weight's record index
     int t = blockIdx.x - d.tile0;
     const int nci = (d.Cin + 31) >> 5, nco = (d.Cout + 31) >> 5;
     const int cit = t % nci; t /= nci;
@@ -129,8 +199,9 @@ __global__ __launch_bounds__(256) void wprep_all_kernel(const float* __restrict_
         if (co < d.Cout && ci < d.Cin) {
             const long i = ((long)co * 9 + tap) * d.Cin + ci;
             v = w[i];
-            const _Float16 h = (_Float16)v;
-            const _Float16 l = (_Float16)(v - (float)h);
+            const float vs = v * fsc;
+            const _Float16 h = (_Float16)vs;
+            const _Float16 l = (_Float16)(vs - (float)h);
             fh[o0 + i] = h; fl[o0 + i] = l;
             if (kfh && (d.flags & 1)) {
                 const long k = o0 + (((long)(ci >> 4) * 9 + tap) * d.Cout + co) * 16 + (ci & 15);
@@ -532,6 +603,29 @@ int cdae_split_f16(const float* src, unsigned short* hi, unsigned short* lo, lon
     if (n % 4 || (((size_t)src | (size_t)hi | (size_t)lo) & 7)) return cdae_fail("split_f16: n % 4 == 0 and 8-byte aligned planes required");
     LAUNCH1D(split_f16_kernel, n / 4, (const float4*)src, (ew_half4*)hi, (ew_half4*)lo, n / 4);
 }
+int cdae_split_f16w(const float* src, const float* w_scale, unsigned short* hi, unsigned short* lo, long n, void* stream) {
+    if (!w_scale) return cdae_split_f16(src, hi, lo, n, stream);
+    if (n % 4 || (((size_t)src | (size_t)hi | (size_t)lo) & 7)) return cdae_fail("split_f16w: n % 4 == 0 and 8-byte aligned planes required");
+    LAUNCH1D(split_f16w_kernel, n / 4, (const float4*)src, w_scale, (ew_half4*)hi, (ew_half4*)lo, n / 4);
+}
+int cdae_weight_scales(const float* flat, const void* desc, int nw, int total_chunks, float* records, unsigned* scratch, void* stream) {
+    if (nw <= 0) return 0;
+    if (!flat || !desc || !records || !scratch || total_chunks <= 0) return cdae_fail("weight_scales: flat, desc, records and scratch (nw uint32) required");
+    if (hipMemsetAsync(scratch, 0, sizeof(unsigned) * nw, ST) != hipSuccess) return cdae_fail("weight_scales: memset failed");
+    cdae_prof_begin(PROF_ELEMWISE, 0.0, ST);
+    hipLaunchKernelGGL(wscale_max_kernel, dim3(total_chunks), dim3(256), 0, ST, flat, (const WScaleDesc*)desc, nw, scratch);
+    hipLaunchKernelGGL(wscale_finish_kernel, dim3((nw + 255) / 256), dim3(256), 0, ST, scratch, records, nw);
+    cdae_prof_end(PROF_ELEMWISE, ST);
+    return hipGetLastError() == hipSuccess ? 0 : cdae_fail("weight_scales launch failed");
+}
+int cdae_weight_scales_chunk(void) { return WS_CHUNK; }
+int cdae_weight_scale1(const float* w, long n, float* record, unsigned* scratch, void* stream) {
+    if (!w || n <= 0 || !record || !scratch) return cdae_fail("weight_scale1: w, record (2 floats) and scratch (1 uint32) required");
+    if (hipMemsetAsync(scratch, 0, sizeof(unsigned), ST) != hipSuccess) return cdae_fail("weight_scale1: memset failed");
+    hipLaunchKernelGGL(wscale_max1_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, ST, w, n, scratch);
+    hipLaunchKernelGGL(wscale_finish_kernel, dim3(1), dim3(64), 0, ST, scratch, record, 1);
+    return hipGetLastError() == hipSuccess ? 0 : cdae_fail("weight_scale1 launch failed");
+}
 int cdae_split_bf16(const float* src, unsigned short* hi, unsigned short* lo, long n, void* stream) {
     if (n % 4 || (((size_t)src & 15) | (((size_t)hi | (size_t)lo) & 7))) return cdae_fail("split_bf16: n % 4 == 0, 16-byte aligned source and 8-byte aligned planes required");
     LAUNCH1D(split_bf16_kernel, n / 4, (const float4*)src, (ew_bf4*)hi, (ew_bf4*)lo, n / 4);
@@ -546,16 +640,16 @@ int cdae_upsample2_split(const float* x, unsigned short* f_hi, unsigned short* f
 int cdae_wprep_all(const float* flat, const void* desc, int nw, int total_tiles, long base, unsigned short* f_hi, unsigned short* f_lo,
                    unsigned short* b_hi, unsigned short* b_lo, void* stream) {
     if (nw <= 0 || total_tiles <= 0) return 0;
-    return cdae_wprep_all_k(flat, desc, nw, total_tiles, base, f_hi, f_lo, b_hi, b_lo, nullptr, nullptr, nullptr, nullptr, stream);
+    return cdae_wprep_all_k(flat, desc, nw, total_tiles, base, f_hi, f_lo, b_hi, b_lo, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
 }
 // + the K-group-major copies for the second-generation window kernel (all four NULL, or all four given; Cin, Cout % 16 == 0 then)
 int cdae_wprep_all_k(const float* flat, const void* desc, int nw, int total_tiles, long base, unsigned short* f_hi, unsigned short* f_lo,
                      unsigned short* b_hi, unsigned short* b_lo, unsigned short* kf_hi, unsigned short* kf_lo, unsigned short* kb_hi,
-                     unsigned short* kb_lo, void* stream) {
+                     unsigned short* kb_lo, const float* w_scales, void* stream) {
     if (nw <= 0 || total_tiles <= 0) return 0;
     if ((kf_hi || kf_lo || kb_hi || kb_lo) && !(kf_hi && kf_lo && kb_hi && kb_lo)) return cdae_fail("wprep_all_k: give all four packed planes or none");
     hipLaunchKernelGGL(wprep_all_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, flat, (const WPrepDesc*)desc, nw, base, (_Float16*)f_hi,
-                       (_Float16*)f_lo, (__bf16*)b_hi, (__bf16*)b_lo, (_Float16*)kf_hi, (_Float16*)kf_lo, (__bf16*)kb_hi, (__bf16*)kb_lo);
+                       (_Float16*)f_lo, (__bf16*)b_hi, (__bf16*)b_lo, (_Float16*)kf_hi, (_Float16*)kf_lo, (__bf16*)kb_hi, (__bf16*)kb_lo, w_scales);
     return hipGetLastError() == hipSuccess ? 0 : cdae_fail("wprep_all launch failed");
 }
 int cdae_wdgrad_planes(const float* w, unsigned short* hi, unsigned short* lo, int Cout, int Cin, void* stream) {

@@ -293,6 +293,7 @@ __global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_ke
         }
     };
 
+    const float bsc = (PREC != 0 && p.w_scale) ? p.w_scale[0] : 1.f;
     // split a float4 into hi/lo 16-bit planes (f16 for PREC 1, bf16 for PREC 2) and store 8 B into each plane
     auto store_split = [&](char* tile, int plane_bytes, int off, const float4& v) {
         if constexpr (BF) {
@@ -371,11 +372,13 @@ __global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_ke
             }
 #pragma unroll
             for (int q = 0; q < B_V4; ++q) {
-                if constexpr (!B_MC) store_split(bc, B_PLANE, kc_off((tid >> 3) + RPP * q, tid & 7), rb[q]);
+                // f16 planes: the weight operand goes in as w * 2^k (p.w_scale, see cdae_internal.h) so that its lo plane stays normal
+                const float4 rbs = (!BF && p.w_scale) ? make_float4(rb[q].x * bsc, rb[q].y * bsc, rb[q].z * bsc, rb[q].w * bsc) : rb[q];
+                if constexpr (!B_MC) store_split(bc, B_PLANE, kc_off((tid >> 3) + RPP * q, tid & 7), rbs);
                 else {
                     const int idx = tid + THREADS * q;
                     const int kk = idx / (BN / 4), j4 = idx - kk * (BN / 4);
-                    store_split(bc, B_PLANE, (kk * PBM + j4 * 4) * 2, rb[q]);
+                    store_split(bc, B_PLANE, (kk * PBM + j4 * 4) * 2, rbs);
                 }
             }
             return;
@@ -567,6 +570,7 @@ __global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_ke
 
     // ---------------------------------------------------------------- epilogue
     // C layout of v_mfma_f32_32x32xK (dtype independent): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const float alpha_ = p.w_scale ? p.alpha * p.w_scale[1] : p.alpha;      // scaled weight planes / B tile: the exact 2^-k rides on alpha
     float* __restrict__ Cg;
     const float* __restrict__ Rg = nullptr;
     if (p.ksplit > 1) {
@@ -617,7 +621,7 @@ __global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_ke
                     int img = row / p.out_hw, pix = row - img * p.out_hw;
                     addr = ((long)img * p.N + col) * p.out_hw + pix;
                 } else addr = (long)row * p.ldc + col;
-                float v = acc[i][j][r] * p.alpha + bv;
+                float v = acc[i][j][r] * alpha_ + bv;
                 if (Rg) v += rv[r];
                 if (p.act == ACT_SILU) v = cdae_silu(v);
                 else if (p.act == ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
@@ -632,6 +636,8 @@ __global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_ke
 // split-K finish: C = alpha * sum_s slab[s] + bias (+res) (-> act), deterministic order
 __global__ void splitk_reduce_kernel(const GemmParams p) {
     long total = (long)p.batch * p.M * p.N;
+    const float alpha_ = p.w_scale ? p.alpha * p.w_scale[1] : p.alpha;      // scaled weight planes / B tile: the exact 2^-k rides on alpha
+
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         long bz = idx / ((long)p.M * p.N), rem = idx - bz * (long)p.M * p.N;
         int row = rem / p.N, col = rem - (long)row * p.N;
@@ -654,7 +660,7 @@ __global__ void splitk_reduce_kernel(const GemmParams p) {
             const int x = row - fdiv(row, p.wo_magic, p.wo_shift) * p.Wo;
             addr = (4L * row - 2 * x + p.ph_y * 2 * p.Wo + p.ph_x) * p.ldc + col;
         } else addr = (long)row * p.ldc + col;
-        float v = s * p.alpha + (p.bias ? p.bias[col] : 0.f);
+        float v = s * alpha_ + (p.bias ? p.bias[col] : 0.f);
         if (p.res) v += (p.res + bo * p.c_bs0 + bi * p.c_bs1)[addr];
         if (p.act == ACT_SILU) v = cdae_silu(v);
         else if (p.act == ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
@@ -672,6 +678,7 @@ __global__ __launch_bounds__(256) void splitk_reduce4_kernel(const GemmParams p)
     const int n4 = p.N >> 2;
     const long total4 = (long)p.M * n4, kstride4 = total4;
     const float4* __restrict__ ws = reinterpret_cast<const float4*>(p.splitk_ws);
+    const float alpha_ = p.w_scale ? p.alpha * p.w_scale[1] : p.alpha;      // scaled weight planes / B tile: the exact 2^-k rides on alpha
     bool bad = false;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total4; idx += (long)gridDim.x * blockDim.x) {
         const int row = (int)(idx / n4), c4 = (int)(idx - (long)row * n4);
@@ -688,7 +695,7 @@ __global__ __launch_bounds__(256) void splitk_reduce4_kernel(const GemmParams p)
         for (; k < p.ksplit; ++k) { const float4 v = slab[k * kstride4]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
         const long addr = (long)row * p.ldc + 4 * c4;
         const float4 b = p.bias ? *reinterpret_cast<const float4*>(p.bias + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float v[4] = {s.x * p.alpha + b.x, s.y * p.alpha + b.y, s.z * p.alpha + b.z, s.w * p.alpha + b.w};
+        float v[4] = {s.x * alpha_ + b.x, s.y * alpha_ + b.y, s.z * alpha_ + b.z, s.w * alpha_ + b.w};
         if (p.res) { const float4 r = *reinterpret_cast<const float4*>(p.res + addr); v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
         if (p.act == ACT_SILU) {
 #pragma unroll
@@ -831,6 +838,10 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
     if (p.bmode != B_PLAIN_KC && p.N % 4) p.b_scalar = 1;
     const bool scalar = p.a_scalar || p.b_scalar || p.amode == A_CONV_GEN;
     if (scalar) big = 0;
+    // the weight-operand scale applies where the weight goes through F16 planes: pre-split planes carry it already (their producer applied
+    // it), the fp32-operand kernels apply it to the B tile in their f16 modes (vectorised loaders); everywhere else (fp32 MFMA, bf16 planes,
+    // the scalar fp32 loaders) the operand is used as it is and the epilogue must not unscale
+    if (!p.presplit && ((p.prec != 1 && p.prec != 3) || scalar)) p.w_scale = nullptr;
     if (p.bmode == B_CONV_MC && !scalar) {           // a vectorised wgrad block must sit inside one tap
         if (p.Cin % 128 != 0) big = 0;
         if (p.Cin % 64 != 0) return cdae_fail("B_CONV_MC needs Cin % 64 == 0");
@@ -869,6 +880,13 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
         return cdae_fail("GroupNorm partial sums from the epilogue need a pre-split, unsplit-K, row-major, non-accumulating launch");
 
     cdae_prof_begin(PROF_IGEMM, 2.0 * p.M * p.N * (double)p.K * p.batch * (p.nphase > 1 ? p.nphase : 1), st);
+    if (!p.presplit) {
+        // algorithmic bytes of an fp32-operand contraction: each operand once (a conv gather: the gathered TENSOR, not its im2col rows),
+        // the result once (+ the residual read)
+        const bool conv = p.amode == A_CONV_VEC || p.amode == A_CONV_GEN;
+        const double a_el = conv ? (double)(p.conv_M / (p.Ho * p.Wo > 0 ? p.Ho * p.Wo : 1)) * p.H * p.W * p.Cin : (double)p.M * p.K;
+        cdae_prof_note(PROF_IGEMM, 4.0 * p.batch * (a_el + (double)p.N * p.K + (double)p.M * p.N * (p.res ? 2 : 1)));
+    }
     if (cdae_prof_on()) {
         char tag[128];
         snprintf(tag, sizeof(tag), "gemm M=%d N=%d K=%d b=%d a%d b%d %s ks=%d prec=%d ps=%d taps=%d res=%d gn=%d", p.M, p.N, p.K, p.batch, p.amode, p.bmode, big ? "128" : "64", ks, p.prec,

@@ -182,6 +182,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void ps_kernel(const GemmPa
     }
 
     // ---------------------------------------------------------------- epilogue (as igemm_kernel's, K-contiguous case)
+    const float alpha_ = p.w_scale ? p.alpha * p.w_scale[1] : p.alpha;      // scaled weight planes / B tile: the exact 2^-k rides on alpha
     float* __restrict__ Cg;
     const float* __restrict__ Rg = nullptr;
     if (p.ksplit > 1) Cg = p.splitk_ws + (long)ks * (long)p.M * p.N;
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void ps_kernel(const GemmPa
                 if (row >= p.M) continue;
                 if (p.ksplit > 1) { Cg[(long)row * p.N + col] = acc[i][j][r]; continue; }
                 const long addr = out_addr(row);
-                float v = acc[i][j][r] * p.alpha + bv;
+                float v = acc[i][j][r] * alpha_ + bv;
                 if (Rg) v += rv[r];
                 if (p.act == ACT_SILU) v = cdae_silu(v);
                 else if (p.act == ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void ps_kernel(const GemmPa
             }
             if (p.gn_part && p.ksplit == 1) {           // this wave owns the whole 32 x 32 sub-tile: one deterministic write per (chunk, column)
                 gs += __shfl_xor(gs, 32); gq += __shfl_xor(gq, 32);
-                if (hh == 0) {
+                if (hh == 0 && m0 + wm * WM + i * 32 < p.M) {      // (a chunk that starts beyond the last row has no slot in the [ceil(M / 32)] buffer)
                     float* o = p.gn_part + ((long)((m0 + wm * WM + i * 32) >> 5) * p.N + col) * 2;
                     o[0] = gs; o[1] = gq;
                 }
@@ -470,6 +471,7 @@ __global__ __launch_bounds__(BM / 64 * WAVES_N * 64, BM / 64 * WAVES_N * 2 / 4) 
     }
 
     // ---------------------------------------------------------------- epilogue (row-major result)
+    const float alpha_ = p.w_scale ? p.alpha * p.w_scale[1] : p.alpha;      // scaled weight planes / B tile: the exact 2^-k rides on alpha
     float* __restrict__ Cg;
     const float* __restrict__ Rg = nullptr;
     if (p.ksplit > 1) Cg = p.splitk_ws + (long)ks * (long)p.M * p.N;
@@ -492,7 +494,7 @@ __global__ __launch_bounds__(BM / 64 * WAVES_N * 64, BM / 64 * WAVES_N * 2 / 4) 
                     const int x = row - fdiv(row, p.wo_magic, p.wo_shift) * p.Wo;          // (n, y, x) -> (n, 2y + ph_y, 2x + ph_x)
                     addr = (4L * row - 2 * x + p.ph_y * 2 * p.Wo + p.ph_x) * p.ldc + col;
                 } else addr = (long)row * p.ldc + col;
-                float v = acc[i][j][r] * p.alpha + bv;
+                float v = acc[i][j][r] * alpha_ + bv;
                 if (Rg) v += Rg[addr];
                 if (p.act == ACT_SILU) v = cdae_silu(v);
                 else if (p.act == ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
@@ -504,7 +506,7 @@ __global__ __launch_bounds__(BM / 64 * WAVES_N * 64, BM / 64 * WAVES_N * 2 / 4) 
             }
             if (p.gn_part && p.ksplit == 1) {
                 gs += __shfl_xor(gs, 32); gq += __shfl_xor(gq, 32);
-                if (hh == 0) {
+                if (hh == 0 && m0 + wm * WM + i * 32 < p.M) {      // (a chunk that starts beyond the last row has no slot in the [ceil(M / 32)] buffer)
                     float* o = p.gn_part + ((long)((m0 + wm * WM + i * 32) >> 5) * p.N + col) * 2;
                     o[0] = gs; o[1] = gq;
                 }

@@ -45,6 +45,7 @@ typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 struct SkipGnParams {
     const float* x1; const float* x2; long ld1, ld2; int K1;          // columns [0, K1) from x1, [K1, K) from x2 (x2 == nullptr: K1 == K)
     const unsigned short* w_hi; const unsigned short* w_lo; long ldw;
+    const float* w_scale;                                              // scale record of the weight planes ({2^k, 2^-k}, nullptr: unscaled): y = acc * 2^-k + bias
     const float* bias; float* y; long ldy;
     const float* res; long ldres;                                      // optional residual rows added to y
     unsigned short* c_hi; unsigned short* c_lo;                        // optional: y also as f16 hi / lo planes (row pitch ldy), the next conv's operand
@@ -317,7 +318,8 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
     }
 #endif
 
-    // ---- epilogue: y = acc + bias (row-major fp32)
+    // ---- epilogue: y = acc (* 2^-k of scaled weight planes) + bias (row-major fp32)
+    const float unsc = p.w_scale ? p.w_scale[1] : 1.f;
     bool bad = false;
     if (m0 + SG_BM <= p.M && n0 + SG_BN <= p.N) {                      // interior tile: straight-line stores (a branch per row makes hipcc wait for each store)
         float bv[2];
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
                 float vv[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    vv[r] = (acc[i][j][r] + bv[j]) + rv[r];
+                    vv[r] = (acc[i][j][r] * unsc + bv[j]) + rv[r];
                     if (!(SG_ABL & 1) || vv[r] == 1.2345e30f) dst[(long)((r & 3) + 8 * (r >> 2)) * p.ldy] = vv[r];
                     bad |= !__builtin_isfinite(vv[r]);
                 }
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
                 if (row >= p.M) continue;
-                float v = acc[i][j][r] + bv;
+                float v = acc[i][j][r] * unsc + bv;
                 if (p.res) v += p.res[(long)row * p.ldres + col];
                 p.y[(long)row * p.ldy + col] = v;
                 if (p.c_hi) store_planes_sg(p, (long)row * p.ldy + col, v);
@@ -411,7 +413,7 @@ static int skipgn_launch(SkipGnParams& p, void* stream) {
 }
 
 extern "C" int cdae_skip_gn_fwd(const float* x1, long ld1, int K1, const float* x2, long ld2, const unsigned short* w_hi, const unsigned short* w_lo,
-                                long ldw, const float* bias, float* y, long ldy, const float* coef, int silu, unsigned short* s_hi,
+                                long ldw, const float* w_scale, const float* bias, float* y, long ldy, const float* coef, int silu, unsigned short* s_hi,
                                 unsigned short* s_lo, int planes_gm, int M, int N, int K, int HW, void* stream) {
     if (!x2) K1 = K;
     if (!cdae_skip_gn_ok(M, N, K, K1, HW)) return cdae_fail("skip_gn_fwd: K, K1 % 32 == 0, M a multiple of HW, coefficient table of a row tile <= 16 KB required");
@@ -420,7 +422,7 @@ extern "C" int cdae_skip_gn_fwd(const float* x1, long ld1, int K1, const float* 
         return cdae_fail("skip_gn_fwd: 16-byte aligned rows, weight planes, coefficients and planes required");
     SkipGnParams p;
     p.x1 = x1; p.x2 = x2; p.ld1 = ld1; p.ld2 = ld2; p.K1 = K1;
-    p.w_hi = w_hi; p.w_lo = w_lo; p.ldw = ldw; p.bias = bias; p.y = y; p.ldy = ldy; p.res = nullptr; p.ldres = 0; p.c_hi = nullptr; p.c_lo = nullptr;
+    p.w_hi = w_hi; p.w_lo = w_lo; p.ldw = ldw; p.w_scale = w_scale; p.bias = bias; p.y = y; p.ldy = ldy; p.res = nullptr; p.ldres = 0; p.c_hi = nullptr; p.c_lo = nullptr;
     p.coef = coef; p.silu = silu; p.s_hi = s_hi; p.s_lo = s_lo; p.planes_gm = planes_gm; p.norm_a = 0;
     p.M = M; p.N = N; p.K = K; p.HW = HW; p.nimg_tab = skipgn_tab_images(HW);
     return skipgn_launch(p, stream);
@@ -428,7 +430,7 @@ extern "C" int cdae_skip_gn_fwd(const float* x1, long ld1, int K1, const float* 
 
 // The same kernel as a plain streaming GEMM: y = [x1 | x2] @ W^T + bias (+ res), fp32 rows in, pre-split weight planes, f16x3 products
 extern "C" int cdae_linear_fwd_stream(const float* x1, long ld1, int K1, const float* x2, long ld2, const unsigned short* w_hi,
-                                      const unsigned short* w_lo, long ldw, const float* bias, const float* res, long ldres, float* y, long ldy,
+                                      const unsigned short* w_lo, long ldw, const float* w_scale, const float* bias, const float* res, long ldres, float* y, long ldy,
                                       unsigned short* c_hi, unsigned short* c_lo, int M, int N, int K, void* stream) {
     if (!x2) K1 = K;
     if (M <= 0 || N <= 0 || K <= 0 || K % 32 || K1 % 32 || K1 > K) return cdae_fail("linear_fwd_stream: K (and K1) % 32 == 0 required");
@@ -436,7 +438,7 @@ extern "C" int cdae_linear_fwd_stream(const float* x1, long ld1, int K1, const f
         return cdae_fail("linear_fwd_stream: 16-byte aligned rows and weight planes required");
     SkipGnParams p;
     p.x1 = x1; p.x2 = x2; p.ld1 = ld1; p.ld2 = ld2; p.K1 = K1;
-    p.w_hi = w_hi; p.w_lo = w_lo; p.ldw = ldw; p.bias = bias; p.y = y; p.ldy = ldy; p.res = res; p.ldres = ldres; p.c_hi = c_hi; p.c_lo = c_lo;
+    p.w_hi = w_hi; p.w_lo = w_lo; p.ldw = ldw; p.w_scale = w_scale; p.bias = bias; p.y = y; p.ldy = ldy; p.res = res; p.ldres = ldres; p.c_hi = c_hi; p.c_lo = c_lo;
     p.coef = nullptr; p.silu = 0; p.s_hi = nullptr; p.s_lo = nullptr; p.planes_gm = 0; p.norm_a = 0;
     p.M = M; p.N = N; p.K = K; p.HW = M; p.nimg_tab = 0;
     return skipgn_launch(p, stream);
@@ -445,14 +447,14 @@ extern "C" int cdae_linear_fwd_stream(const float* x1, long ld1, int K1, const f
 // y = silu?(GroupNorm(x)) @ W^T + bias with the GroupNorm folded to per-(image, channel) (a, b) (cdae_gn_coef) and applied to the rows
 // as they are staged: GroupNorm -> 1x1 conv (the attention block's norm -> qkv, reference unet.py:213-228) in ONE pass over the fp32
 // input, no normalised tensor or planes in HBM.  Shapes as cdae_skip_gn_ok(M, N, K, K, HW).
-extern "C" int cdae_linear_fwd_stream_gn(const float* x, long ldx, const unsigned short* w_hi, const unsigned short* w_lo, long ldw, const float* bias,
+extern "C" int cdae_linear_fwd_stream_gn(const float* x, long ldx, const unsigned short* w_hi, const unsigned short* w_lo, long ldw, const float* w_scale, const float* bias,
                                          float* y, long ldy, const float* coef, int silu, int M, int N, int K, int HW, void* stream) {
     if (!cdae_skip_gn_ok(M, N, K, K, HW)) return cdae_fail("linear_fwd_stream_gn: K % 32 == 0, M a multiple of HW, coefficient table of a row tile <= 16 KB required");
     if (ldx % 4 || ldw % 8 || !aligned16(x) || !aligned16(w_hi) || !aligned16(w_lo) || !aligned16(coef) || !x || !w_hi || !w_lo || !coef || !y)
         return cdae_fail("linear_fwd_stream_gn: 16-byte aligned rows, weight planes and coefficients required");
     SkipGnParams p;
     p.x1 = x; p.x2 = nullptr; p.ld1 = ldx; p.ld2 = 0; p.K1 = K;
-    p.w_hi = w_hi; p.w_lo = w_lo; p.ldw = ldw; p.bias = bias; p.y = y; p.ldy = ldy; p.res = nullptr; p.ldres = 0; p.c_hi = nullptr; p.c_lo = nullptr;
+    p.w_hi = w_hi; p.w_lo = w_lo; p.ldw = ldw; p.w_scale = w_scale; p.bias = bias; p.y = y; p.ldy = ldy; p.res = nullptr; p.ldres = 0; p.c_hi = nullptr; p.c_lo = nullptr;
     p.coef = coef; p.silu = silu; p.s_hi = nullptr; p.s_lo = nullptr; p.planes_gm = 0; p.norm_a = 1;
     p.M = M; p.N = N; p.K = K; p.HW = HW; p.nimg_tab = skipgn_tab_images(HW);
     return skipgn_launch(p, stream);

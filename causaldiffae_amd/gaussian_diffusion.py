@@ -299,16 +299,23 @@ class GaussianDiffusion:
         if use_graph is None:
             # default: replay the step as a HIP graph wherever that is exact (static shapes, no per-step host input, deterministic DDIM,
             # eval-mode network) and the loop is long enough to pay for one extra warm-up step and the capture
-            use_graph = eligible and not model.training and self.num_timesteps >= 8
+            # (a plain callable — a model_fn wrapper, a partial — has no `.training`: it may hide per-call host work, so it runs eagerly)
+            soft = True
+            use_graph = (eligible and isinstance(model, th.nn.Module) and not model.training and self.num_timesteps >= 8)
+        else:
+            soft = False                        # use_graph=True insists: a failed capture propagates
         if use_graph and eligible:
             # the replay updates its image buffer in place: never the caller's `noise` (the reference leaves it untouched)
             runner = _GraphStep(self, model, img.clone() if noise is not None and img.data_ptr() == noise.data_ptr() else img,
-                                model_kwargs, clip_denoised, w)
+                                model_kwargs, clip_denoised, w, soft=soft)
         for k in order:
             t = steps[k]
             with th.no_grad():
                 if runner is not None:
                     out = runner.step(k)
+                    if out is None:                # the default path could not capture this step: continue eagerly from the saved image
+                        img, runner = runner.img, None
+                if runner is not None:
                     if self.yield_copies:          # the progressive generators hand out fresh tensors like the reference does
                         out = {k_: v.clone() for k_, v in out.items()}
                 elif ddim:
@@ -322,8 +329,13 @@ class GaussianDiffusion:
                 yield out
                 img = out["sample"]
         if self._hot:
-            from ._lib import range_check
-            range_check("sampling loop")        # never hand back a sample that went through an overflowed f16 plane (raises CdaeRangeError)
+            from ._lib import _RANGE_PENDING, range_check, range_take_pending
+            earlier = range_take_pending()      # a flag raised BEFORE this loop belongs to whoever issued that work (the trainer's guard)
+            try:
+                range_check("sampling loop")    # never hand back a sample that went through an overflowed f16 plane (raises CdaeRangeError)
+            finally:
+                if earlier is not None:
+                    _RANGE_PENDING[0] = earlier
 
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, model_kwargs=None,
                                   device=None, progress=False, step_noise=None):
@@ -462,13 +474,16 @@ class GaussianDiffusion:
         return {"total_bpd": vb.sum(dim=1) + prior_bpd, "prior_bpd": prior_bpd, "vb": vb, "xstart_mse": xstart_mse, "mse": mse}
 
 
+_GRAPH_FALLBACK_LOGGED = False
+
+
 class _GraphStep:
     """One DDIM step (network + fused update) captured once into a HIP graph and replayed per step.
 
     Static buffers: the image (updated in place by the replay), the step counter row.  Kills the per-step
     Python/launch overhead of the ~300 kernel launches (the reference issues 557 + 13 H2D copies)."""
 
-    def __init__(self, diffusion, model, img, model_kwargs, clip, w):
+    def __init__(self, diffusion, model, img, model_kwargs, clip, w, soft=False):
         self.d = diffusion
         self.img = img
         self.t = th.empty((img.shape[0],), dtype=th.int64, device=img.device)
@@ -477,26 +492,46 @@ class _GraphStep:
         self.pred = th.empty_like(img)
         self.kw, self.clip, self.w, self.model = model_kwargs, clip, w, model
         self.graph = None
+        self.soft = soft            # True: the caller did not ask for a graph (use_graph=None) — a failed capture falls back to eager
 
     def _body(self):
         eps = self.d._model_eps(self.model, self.img, self.t, self.kw, self.w)
         self.d._fused_update(True, self.img, eps, self.t, self.clip, 0.0, None, sample_out=self.out, pred_out=self.pred)
         self.img.copy_(self.out)
 
-    def step(self, k):
-        self.t.copy_(self.steps[k])
-        if self.graph is None:
-            # warm-up on a side stream (allocator + workspace growth), then capture
-            s = th.cuda.Stream()
-            s.wait_stream(th.cuda.current_stream())
-            saved = self.img.clone()
+    def _capture(self):
+        # warm-up on a side stream (allocator + workspace growth), then capture
+        s = th.cuda.Stream()
+        s.wait_stream(th.cuda.current_stream())
+        saved = self.img.clone()
+        try:
             with th.cuda.stream(s):
                 self._body()
             th.cuda.current_stream().wait_stream(s)
             self.img.copy_(saved)
-            self.graph = th.cuda.CUDAGraph()
-            with th.cuda.graph(self.graph):
+            graph = th.cuda.CUDAGraph()
+            with th.cuda.graph(graph):
                 self._body()
+        except Exception as e:      # a host sync / pageable H2D copy / allocation the capture cannot record (e.g. a CPU tensor in model_kwargs)
+            th.cuda.synchronize()
             self.img.copy_(saved)
+            if not self.soft:
+                raise
+            global _GRAPH_FALLBACK_LOGGED
+            if not _GRAPH_FALLBACK_LOGGED:
+                _GRAPH_FALLBACK_LOGGED = True
+                import warnings
+                warnings.warn(f"ddim_sample_loop: this step cannot be captured into a HIP graph ({type(e).__name__}: {e}); running eagerly")
+            return False
+        self.img.copy_(saved)
+        self.graph = graph
+        return True
+
+    def step(self, k):
+        """-> {"sample", "pred_xstart"} (static buffers), or None when the default path could not capture the step (self.img is then the
+        untouched image of step k: the loop continues eagerly from it)."""
+        self.t.copy_(self.steps[k])
+        if self.graph is None and not self._capture():
+            return None
         self.graph.replay()
         return {"sample": self.img, "pred_xstart": self.pred}

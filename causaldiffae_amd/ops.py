@@ -120,7 +120,7 @@ class _Conv3x3(Function):
         if res is not None:
             res = to_nhwc(res)
         ws, wsb = _sk(dev)
-        check(lib.cdae_conv3x3_fwd(ptr(x), x.stride(0), x.stride(2), x.stride(3), x.stride(1), ptr(w), ptr(b), ptr(res),
+        check(lib.cdae_conv3x3_fwd(ptr(x), x.stride(0), x.stride(2), x.stride(3), x.stride(1), ptr(w), ptr(weight_scale(w_in)), ptr(b), ptr(res),
                                    ptr(out), Cout, 1 if out_nchw else 0, N, H, W, Cin, Cout, stride, 1 if up else 0,
                                    ws, wsb, stream()))
         ctx.save_for_backward(x, w)
@@ -191,20 +191,20 @@ class _Linear(Function):
         y = torch.empty((M, Nf), dtype=torch.float32, device=x.device)
         pre = torch.empty_like(y) if (act != ACT_NONE and any(ctx.needs_input_grad[:4])) else None   # grad mode is off inside forward
         ws, wsb = _sk(x.device)
+        wsc = ptr(weight_scale(w))
         if pre is not None:      # keep the pre-activation for the backward
-            check(lib.cdae_linear_fwd(ptr(x), x.stride(0), ptr(w), K, ptr(b), ptr(res), ptr(pre), Nf, None, None, M, Nf, K, alpha, ACT_NONE, ws, wsb, stream()))
+            check(lib.cdae_linear_fwd(ptr(x), x.stride(0), ptr(w), K, wsc, ptr(b), ptr(res), ptr(pre), Nf, None, None, M, Nf, K, alpha, ACT_NONE, ws, wsb, stream()))
             check(lib.cdae_act_fwd(ptr(pre), ptr(y), M * Nf, act, stream()))
         elif act in (ACT_RELU, ACT_SIGMOID):      # not in the GEMM epilogue (cold path): activate in place
-            check(lib.cdae_linear_fwd(ptr(x), x.stride(0), ptr(w), K, ptr(b), ptr(res), ptr(y), Nf, None, None, M, Nf, K, alpha, ACT_NONE, ws, wsb, stream()))
+            check(lib.cdae_linear_fwd(ptr(x), x.stride(0), ptr(w), K, wsc, ptr(b), ptr(res), ptr(y), Nf, None, None, M, Nf, K, alpha, ACT_NONE, ws, wsb, stream()))
             check(lib.cdae_act_fwd(ptr(y), ptr(y), M * Nf, act, stream()))
         elif _stream_gemm_ok(x, M, Nf, K, act, alpha, res):
-            root = w._base if (w._base is not None and w._base.numel() == w.numel() and w._base.data_ptr() == w.data_ptr()) else w
-            wh, wl = split_weight(root)        # (cached on the parameter, not on the per-call [Cout, Cin] view of a 1x1 conv weight)
+            wh, wl, wsp = split_weight(_root(w))        # (cached on the parameter, not on the per-call [Cout, Cin] view of a 1x1 conv weight)
             # rows stream through registers once, weights come pre-split: the HBM-stream GEMM (skipgn.hip)
-            check(lib.cdae_linear_fwd_stream(ptr(x), x.stride(0), K, None, 0, ptr(wh), ptr(wl), K, ptr(b), ptr(res), 0 if res is None else res.stride(0),
+            check(lib.cdae_linear_fwd_stream(ptr(x), x.stride(0), K, None, 0, ptr(wh), ptr(wl), K, ptr(wsp), ptr(b), ptr(res), 0 if res is None else res.stride(0),
                                              ptr(y), Nf, None, None, M, Nf, K, stream()))
         else:
-            check(lib.cdae_linear_fwd(ptr(x), x.stride(0), ptr(w), K, ptr(b), ptr(res), ptr(y), Nf, None, None, M, Nf, K, alpha, act, ws, wsb, stream()))
+            check(lib.cdae_linear_fwd(ptr(x), x.stride(0), ptr(w), K, wsc, ptr(b), ptr(res), ptr(y), Nf, None, None, M, Nf, K, alpha, act, ws, wsb, stream()))
         ctx.save_for_backward(x, w, pre)
         ctx.cfg = (act, alpha, b is not None, res is not None)
         ctx.sinks = (_sink(w), _sink(b))
@@ -472,12 +472,13 @@ def conv1x1_cat(x, w, b=None):
     rb = x.b.permute(0, 2, 3, 1).reshape(M, C - C1)
     y = torch.empty((M, Nf), dtype=torch.float32, device=ra.device)
     ws, wsb = _sk(ra.device)
+    wsc = ptr(weight_scale(w))
     if C1 % 32 == 0:                  # one GEMM whose K range walks the two sources
-        check(lib.cdae_linear_fwd_cat(ptr(ra), C1, C1, ptr(rb), C - C1, ptr(w), C, ptr(b), ptr(y), Nf, M, Nf, C, ws, wsb, stream()))
-    else:                             # two accumulating GEMMs
+        check(lib.cdae_linear_fwd_cat(ptr(ra), C1, C1, ptr(rb), C - C1, ptr(w), C, wsc, ptr(b), ptr(y), Nf, M, Nf, C, ws, wsb, stream()))
+    else:                             # two accumulating GEMMs (both column ranges of the weight share its one scale)
         wp = w.data_ptr()
-        check(lib.cdae_linear_fwd(ptr(ra), C1, wp, C, ptr(b), None, ptr(y), Nf, None, None, M, Nf, C1, 1.0, ACT_NONE, ws, wsb, stream()))
-        check(lib.cdae_linear_fwd(ptr(rb), C - C1, wp + 4 * C1, C, None, ptr(y), ptr(y), Nf, None, None, M, Nf, C - C1, 1.0, ACT_NONE, ws, wsb, stream()))
+        check(lib.cdae_linear_fwd(ptr(ra), C1, wp, C, wsc, ptr(b), None, ptr(y), Nf, None, None, M, Nf, C1, 1.0, ACT_NONE, ws, wsb, stream()))
+        check(lib.cdae_linear_fwd(ptr(rb), C - C1, wp + 4 * C1, C, wsc, None, ptr(y), ptr(y), Nf, None, None, M, Nf, C - C1, 1.0, ACT_NONE, ws, wsb, stream()))
     return y.reshape(N, H, W, Nf).permute(0, 3, 1, 2)
 
 
@@ -726,6 +727,91 @@ def bump_weight_epoch():
     _WEIGHT_EPOCH[0] += 1
 
 
+class ScaleTable:
+    """Scale records {2^k, 2^-k} (include/cdae.h, cdae_weight_scales) of MANY weight tensors that live in one flat fp32 buffer
+    (train_util.FlatParams), refreshed by ONE pass per weight version.  weight_scale() serves registered tensors from here; extra
+    (offset, length) spans — e.g. the concatenated emb_layers weights that one batched GEMM consumes — can be registered as well."""
+
+    def __init__(self, flat, tensors):
+        import numpy as np
+        self.flat, self.tensors = flat, list(tensors)
+        dev = flat.device
+        chunk = lib.cdae_weight_scales_chunk()
+        desc = np.zeros(len(self.tensors), dtype=np.dtype([("off", "<i8"), ("n", "<i8"), ("chunk0", "<i4"), ("pad", "<i4")]))
+        chunks = 0
+        self.index = {}
+        for i, t in enumerate(self.tensors):
+            assert t.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr(), "ScaleTable: tensor is not a view of the flat buffer"
+            # (a strided view: its span from first to last element; dense for every parameter FlatParams re-homes)
+            desc[i] = ((t.data_ptr() - flat.data_ptr()) // 4, t.numel(), chunks, 0)
+            chunks += (t.numel() + chunk - 1) // chunk
+            self.index[id(t)] = i
+        self.chunks = chunks
+        self.desc = torch.from_numpy(desc.view(np.uint8).copy()).to(dev)
+        self.records = torch.ones((len(self.tensors), 2), dtype=torch.float32, device=dev)
+        self.scratch = torch.zeros(len(self.tensors), dtype=torch.int32, device=dev)
+        self.epoch, self.versions = None, None
+        for t in self.tensors:
+            _SCALE_OF[id(t)] = (weakref.ref(t), self)
+
+    def refresh(self):
+        if self.epoch != _WEIGHT_EPOCH[0] or self.versions != [t._version for t in self.tensors]:
+            check(lib.cdae_weight_scales(ptr(self.flat), ptr(self.desc), len(self.tensors), self.chunks, ptr(self.records), ptr(self.scratch), stream()))
+            self.epoch, self.versions = _WEIGHT_EPOCH[0], [t._version for t in self.tensors]
+
+    def record(self, t):
+        self.refresh()
+        return self.records[self.index[id(t)]]
+
+    def pointer(self, t):
+        self.refresh()
+        return self.records.data_ptr() + 8 * self.index[id(t)]
+
+
+_SCALE_OF = {}
+_WSCALE = {}
+_WSCALE_ON = os.environ.get("CDAE_WSCALE", "1") != "0"      # dev switch: 0 = unscaled weight planes (the round-1..3 arithmetic)
+
+
+def register_scale_table(flat, tensors):
+    """Called by train_util.FlatParams: every weight (dim >= 2) that is a view of `flat` gets its scale record from one table."""
+    for k in [k for k, (ref, _) in _SCALE_OF.items() if ref() is None]:
+        del _SCALE_OF[k]
+    ts = [t for t in tensors if t.dim() >= 2 and t.dtype == torch.float32]
+    return ScaleTable(flat, ts) if ts and _WSCALE_ON else None
+
+
+def _root(w):
+    """the parameter behind a same-storage view (the [Cout, Cin] view `linear` makes of a 1x1 conv weight): caches key on the parameter"""
+    b = w._base
+    return b if (b is not None and b.numel() == w.numel() and b.data_ptr() == w.data_ptr()) else w
+
+
+def weight_scale(w):
+    """Scale record [2] = {2^k, 2^-k} of a weight tensor (float32, on the device): the f16 modes hand weights to the matrix cores as
+    w * 2^k so that the lo plane of small weights stays a normal f16; None when scaling is switched off.  From the FlatParams table
+    where the tensor is registered, else computed once per weight version (cached like split_weight)."""
+    if not _WSCALE_ON:
+        return None
+    w = _root(w)
+    hit = _SCALE_OF.get(id(w))
+    if hit is not None and hit[0]() is w:
+        return hit[1].record(w)
+    tag = (w.data_ptr(), w._version, _WEIGHT_EPOCH[0])
+    hit = _WSCALE.get(id(w))
+    if hit is not None and hit[0]() is w and hit[1] == tag:
+        return hit[2]
+    assert w.dtype == torch.float32 and (w.is_contiguous() or (w.dim() == 4 and w.permute(0, 2, 3, 1).is_contiguous())), "weight_scale needs a dense fp32 weight"
+    rec = torch.empty(2, dtype=torch.float32, device=w.device)
+    scratch = torch.empty(1, dtype=torch.int32, device=w.device)
+    check(lib.cdae_weight_scale1(ptr(w), w.numel(), ptr(rec), ptr(scratch), stream()))
+    if len(_WSCALE) > 4096:
+        for k in [k for k, v in _WSCALE.items() if v[0]() is None]:
+            del _WSCALE[k]
+    _WSCALE[id(w)] = (weakref.ref(w), tag, rec)
+    return rec
+
+
 class ConvWeightBank:
     """Operand planes of MANY conv3x3 weights that live in one flat fp32 buffer (train_util.FlatParams): f16 hi/lo in OHWI order for
     the forward convs and bf16 hi/lo of the dgrad weights, all refreshed by ONE launch per weight version (cdae_wprep_all) instead of
@@ -748,9 +834,17 @@ class ConvWeightBank:
         self.kb16 = torch.empty((2, span), dtype=torch.bfloat16, device=dev) if self.kpack else None
         desc = np.zeros(len(self.weights), dtype=np.dtype([("off", "<i8"), ("cout", "<i4"), ("cin", "<i4"), ("tile0", "<i4"), ("flags", "<i4")]))
         tiles, self.where = 0, {}
+        # scale records of the f16 planes: the FlatParams-wide table where the weights are registered in one, else a table of the bank's own
+        tabs = {id(_SCALE_OF[id(w)][1]) for w in self.weights if id(w) in _SCALE_OF and _SCALE_OF[id(w)][0]() is w}
+        if not _WSCALE_ON:
+            self.scales = None
+        elif len(tabs) == 1 and all(id(w) in _SCALE_OF for w in self.weights):
+            self.scales = _SCALE_OF[id(self.weights[0])][1]
+        else:
+            self.scales = ScaleTable(flat, self.weights)
         for i, (o, w) in enumerate(zip(offs, self.weights)):
             Cout, Cin = w.shape[0], w.shape[1]
-            desc[i] = (o, Cout, Cin, tiles, 1 if id(w) in self.packable else 0)
+            desc[i] = (o, Cout, Cin, tiles, (1 if id(w) in self.packable else 0) | ((self.scales.index[id(w)] if self.scales is not None else 0) << 8))
             tiles += 9 * ((Cout + 31) // 32) * ((Cin + 31) // 32)
             self.where[id(w)] = (o - self.base, w.numel())
         self.tiles = tiles
@@ -762,19 +856,25 @@ class ConvWeightBank:
     def _refresh(self, w):
         if self.epoch != _WEIGHT_EPOCH[0] or self.versions.get(id(w)) != w._version:
             k = self.kpack
+            if self.scales is not None:
+                self.scales.refresh()
             check(lib.cdae_wprep_all_k(ptr(self.flat), ptr(self.desc), len(self.weights), self.tiles, self.base, ptr(self.f16[0]), ptr(self.f16[1]),
                                        ptr(self.b16[0]), ptr(self.b16[1]), ptr(self.kf16[0]) if k else None, ptr(self.kf16[1]) if k else None,
-                                       ptr(self.kb16[0]) if k else None, ptr(self.kb16[1]) if k else None, stream()))
+                                       ptr(self.kb16[0]) if k else None, ptr(self.kb16[1]) if k else None,
+                                       ptr(self.scales.records) if self.scales is not None else None, stream()))
             self.epoch, self.versions = _WEIGHT_EPOCH[0], {id(x): x._version for x in self.weights}
 
     def planes(self, w, bf16):
+        """(hi, lo) bf16 dgrad planes, or (hi, lo, scale record) of the f16 forward planes (record None: unscaled)"""
         self._refresh(w)
         o, n = self.where[id(w)]
-        buf = self.b16 if bf16 else self.f16
-        return buf[0, o:o + n], buf[1, o:o + n]
+        if bf16:
+            return self.b16[0, o:o + n], self.b16[1, o:o + n]
+        return self.f16[0, o:o + n], self.f16[1, o:o + n], (self.scales.record(w) if self.scales is not None else None)
 
     def pointers(self, w, bf16):
-        """(hi, lo, packed hi, packed lo) device pointers of a registered weight's planes (packed: None where the weight is not packable).
+        """(hi, lo, packed hi, packed lo) device pointers of a registered weight's planes (packed: None where the weight is not packable),
+        + the scale record's pointer for the f16 planes.
         Plain integers, cached per weight — the buffers never move, and the training step asks ~130 times (a slice pair per ask otherwise)."""
         self._refresh(w)
         key = (id(w), bf16)
@@ -789,6 +889,8 @@ class ConvWeightBank:
                 hit = (hi, lo, khi, khi + 2 * kbuf.stride(0))
             else:
                 hit = (hi, lo, None, None)
+            if not bf16:
+                hit = hit + ((self.scales.records.data_ptr() + 8 * self.scales.index[id(w)]) if self.scales is not None else None,)
             self._ptrs[key] = hit
         return hit
 
@@ -820,9 +922,10 @@ def _bank(w):
 
 
 def split_weight(w):
-    """(hi, lo) f16 planes of a weight in its PHYSICAL element order (OHWI for channels_last 3x3 weights, [N][K] for linear /
-    1x1 weights).  Cached per tensor object (weak reference) and validated against (storage pointer, autograd version,
-    weight epoch), so a new tensor that happens to reuse a freed address never sees stale planes."""
+    """(hi, lo, scale record) — f16 planes of w * 2^k in the weight's PHYSICAL element order (OHWI for channels_last 3x3 weights,
+    [N][K] for linear / 1x1 weights) and the record {2^k, 2^-k} the consuming kernel unscales with (weight_scale; None: unscaled).
+    Cached per tensor object (weak reference) and validated against (storage pointer, autograd version, weight epoch), so a new
+    tensor that happens to reuse a freed address never sees stale planes."""
     assert w.is_contiguous() or (w.dim() == 4 and w.permute(0, 2, 3, 1).is_contiguous()), "split_weight needs a dense weight"
     bank = _bank(w)
     if bank is not None:
@@ -830,15 +933,16 @@ def split_weight(w):
     tag = (w.data_ptr(), w._version, _WEIGHT_EPOCH[0])
     hit = _WSPLIT.get(id(w))
     if hit is not None and hit[0]() is w and hit[1] == tag:
-        return hit[2], hit[3]
+        return hit[2], hit[3], hit[4]
     n = w.numel()
     planes = torch.empty((2, n), dtype=torch.float16, device=w.device)
-    check(lib.cdae_split_f16(ptr(w), *ptr2(planes), n, stream()))
+    sc = weight_scale(w)
+    check(lib.cdae_split_f16w(ptr(w), ptr(sc), *ptr2(planes), n, stream()))
     if len(_WSPLIT) > 4096:
         for k in [k for k, v in _WSPLIT.items() if v[0]() is None]:
             del _WSPLIT[k]
-    _WSPLIT[id(w)] = (weakref.ref(w), tag, planes[0], planes[1])
-    return planes[0], planes[1]
+    _WSPLIT[id(w)] = (weakref.ref(w), tag, planes[0], planes[1], sc)
+    return planes[0], planes[1], sc
 
 
 _KPACK_ON = os.environ.get("CDAE_KPACK", "1") != "0"       # dev switch: 0 = OHWI weight planes only (first-generation window kernel)
@@ -853,7 +957,7 @@ def packed_weight(w, bf16=False):
     bank = _bank(w)
     if bank is not None:
         return bank.packed(w, bf16)
-    src = dgrad_weight(w) if bf16 else split_weight(w)
+    src = dgrad_weight(w) if bf16 else split_weight(w)[:2]
     tag = (src[0].data_ptr(), w.data_ptr(), w._version, _WEIGHT_EPOCH[0])
     hit = _WPACK.get((id(w), bf16))
     if hit is not None and hit[0]() is w and hit[1] == tag:
@@ -870,13 +974,17 @@ def packed_weight(w, bf16=False):
 
 
 def _wptrs(w, bf16):
-    """(hi, lo, packed hi, packed lo) pointers of a conv3x3 weight's operand planes: f16 OHWI (forward) or the bf16 dgrad planes"""
+    """(hi, lo, packed hi, packed lo) pointers of a conv3x3 weight's operand planes: the bf16 dgrad planes, or the f16 OHWI (forward)
+    planes followed by their scale record's pointer — the argument order of the _psk entry points"""
     bank = _bank(w)
     if bank is not None:
         return bank.pointers(w, bf16)
-    hi, lo = dgrad_weight(w) if bf16 else split_weight(w)
     k_hi, k_lo = packed_weight(w, bf16)
-    return ptr(hi), ptr(lo), ptr(k_hi), ptr(k_lo)
+    if bf16:
+        hi, lo = dgrad_weight(w)
+        return ptr(hi), ptr(lo), ptr(k_hi), ptr(k_lo)
+    hi, lo, sc = split_weight(w)
+    return ptr(hi), ptr(lo), ptr(k_hi), ptr(k_lo), ptr(sc)
 
 
 def _pk(w, bf16):
@@ -974,13 +1082,13 @@ def skip_gn_fused(lz, w, b=None, gm=False):
     planes = torch.empty((2, N, H, W, C), dtype=torch.float16, device=dev)
     y = torch.empty((M, Nf), dtype=torch.float32, device=dev)
     if _SKIPGN_V2 and lib.cdae_skip_gn_ok(M, Nf, C, C1, H * W):      # the HBM-stream kernel on pre-split weight planes
-        wh, wl = split_weight(w)
+        wh, wl, wsp = split_weight(_root(w))
         gm = bool(gm and planes_gm_ok(C))
-        check(lib.cdae_skip_gn_fwd(ptr(lz.x1), C1, C1, ptr(lz.x2), 0 if lz.x2 is None else C - C1, ptr(wh), ptr(wl), C, ptr(b), ptr(y), Nf, ptr(coef),
+        check(lib.cdae_skip_gn_fwd(ptr(lz.x1), C1, C1, ptr(lz.x2), 0 if lz.x2 is None else C - C1, ptr(wh), ptr(wl), C, ptr(wsp), ptr(b), ptr(y), Nf, ptr(coef),
                                    1 if lz.silu else 0, *ptr2(planes), 1 if gm else 0, M, Nf, C, H * W, st))
         return y.reshape(N, H, W, Nf).permute(0, 3, 1, 2), SplitAct(planes[0], planes[1], lz.shape, gm=gm)
     ws, wsb = _sk(dev)
-    check(lib.cdae_linear_fwd_cat_gn(ptr(lz.x1), C1, C1, ptr(lz.x2), 0 if lz.x2 is None else C - C1, ptr(w), C, ptr(b), ptr(y), Nf, ptr(coef),
+    check(lib.cdae_linear_fwd_cat_gn(ptr(lz.x1), C1, C1, ptr(lz.x2), 0 if lz.x2 is None else C - C1, ptr(w), C, ptr(weight_scale(w)), ptr(b), ptr(y), Nf, ptr(coef),
                                      1 if lz.silu else 0, *ptr2(planes), M, Nf, C, H * W, ws, wsb, st))
     return y.reshape(N, H, W, Nf).permute(0, 3, 1, 2), SplitAct(planes[0], planes[1], lz.shape)
 
@@ -1033,11 +1141,11 @@ _W4 = {}
 def fold_upconv_weight(w):
     """[4 phases][Cout][2][2][Cin] weights of the sub-pixel form of nearest-2x-upsample + conv3x3 (cdae_upconv3x3_fwd_ps): for
     output parity p the three kernel rows fold as {0 | 1+2} (p = 0) or {0+1 | 2} (p = 1), same for columns.  Cached like
-    split_weight; returns the (hi, lo) planes."""
+    split_weight; returns the (hi, lo) planes of the folded weights * 2^k and their scale record."""
     tag = (w.data_ptr(), w._version, _WEIGHT_EPOCH[0])
     hit = _W4.get(id(w))
     if hit is not None and hit[0]() is w and hit[1] == tag:
-        return hit[2], hit[3]
+        return hit[2], hit[3], hit[4]
     k = w.detach().permute(0, 2, 3, 1).float()                      # [Cout, 3, 3, Cin]
     rows = ((k[:, 0:1], k[:, 1:2] + k[:, 2:3]), (k[:, 0:1] + k[:, 1:2], k[:, 2:3]))
     phases = []
@@ -1049,9 +1157,10 @@ def fold_upconv_weight(w):
     w4 = torch.stack(phases, dim=0).contiguous()
     n = w4.numel()
     planes = torch.empty((2, n), dtype=torch.float16, device=w.device)
-    check(lib.cdae_split_f16(ptr(w4), *ptr2(planes), n, stream()))
-    _W4[id(w)] = (weakref.ref(w), tag, planes[0], planes[1])
-    return planes[0], planes[1]
+    sc = weight_scale(w4)                                            # of the FOLDED tensor (sums of up to four taps)
+    check(lib.cdae_split_f16w(ptr(w4), ptr(sc), *ptr2(planes), n, stream()))
+    _W4[id(w)] = (weakref.ref(w), tag, planes[0], planes[1], sc)
+    return planes[0], planes[1], sc
 
 
 def upconv3x3_ps(xs, w, b=None, gn_stats=False):
@@ -1059,14 +1168,14 @@ def upconv3x3_ps(xs, w, b=None, gn_stats=False):
     xs = xs.pc()
     N, Cin, H, W = xs.shape
     Cout = w.shape[0]
-    w_hi, w_lo = fold_upconv_weight(w)
+    w_hi, w_lo, w_sc = fold_upconv_weight(w)
     dev = xs.hi.device
     out = new_act(N, Cout, 2 * H, 2 * W, dev)
     ws, wsb = _sk(dev)
     M = N * H * W
     gn_stats = gn_stats and (H * W) % 32 == 0 and ((M + 127) // 128) * ((Cout + 127) // 128) >= 256
     parts = torch.empty((4, M // 32, Cout, 2), dtype=torch.float32, device=dev) if gn_stats else None
-    check(lib.cdae_upconv3x3_fwd_ps(ptr(xs.hi), ptr(xs.lo), H * W * Cin, W * Cin, Cin, ptr(w_hi), ptr(w_lo), ptr(b), ptr(out), Cout,
+    check(lib.cdae_upconv3x3_fwd_ps(ptr(xs.hi), ptr(xs.lo), H * W * Cin, W * Cin, Cin, ptr(w_hi), ptr(w_lo), ptr(w_sc), ptr(b), ptr(out), Cout,
                                     ptr(parts), N, H, W, Cin, Cout, ws, wsb, stream()))
     if gn_stats:
         out._gnparts, out._gnseg = parts, 4
@@ -1083,7 +1192,7 @@ def conv3x3_ps(xs, w, b=None, res=None, stride=1, up=False, out_nchw=False, emit
         return upconv3x3_ps(xs, w, b, gn_stats)
     N, Cin, H, W = xs.shape
     Cout = w.shape[0]
-    w_hi, w_lo = split_weight(ohwi(w))                 # channels_last storage == OHWI (ohwi() returns w itself then: cached)
+    w_hi, w_lo, w_sc = split_weight(ohwi(w))           # channels_last storage == OHWI (ohwi() returns w itself then: cached)
     Ho = 2 * H if up else (H - 1) // stride + 1
     Wo = 2 * W if up else (W - 1) // stride + 1
     dev = xs.hi.device
@@ -1102,7 +1211,7 @@ def conv3x3_ps(xs, w, b=None, res=None, stride=1, up=False, out_nchw=False, emit
         gn_stats = False
     parts = torch.empty(((M + 31) // 32, Cout, 2), dtype=torch.float32, device=dev) if gn_stats else None
     def launch(a, gmflag):
-        return lib.cdae_conv3x3_fwd_psg(ptr(a.hi), ptr(a.lo), H * W * Cin, W * Cin, Cin, gmflag, ptr(w_hi), ptr(w_lo), *_pk(w, False), ptr(b), ptr(res), ptr(out), Cout,
+        return lib.cdae_conv3x3_fwd_psg(ptr(a.hi), ptr(a.lo), H * W * Cin, W * Cin, Cin, gmflag, ptr(w_hi), ptr(w_lo), *_pk(w, False), ptr(w_sc), ptr(b), ptr(res), ptr(out), Cout,
                                         1 if out_nchw else 0, *(ptr2(planes) if emit_split else (None, None)),
                                         ptr(parts), N, H, W, Cin, Cout, stride, 1 if up else 0, ws, wsb, stream())
     rc = launch(xs, 1 if xs.gm else 0)
@@ -1174,12 +1283,12 @@ class _GNConvPS(Function):
         bplanes = torch.empty((2, N, H, W, C), dtype=torch.bfloat16, device=dev)          # kept for wgrad
         check(lib.cdae_gn_apply_split_train(ptr(x), *ptr2(planes), *ptr2(bplanes), N, H * W, C, C, C, groups,
                                             *ptr2(stats), ptr(gamma), ptr(beta), ptr(ss), ld_ss, 1 if silu else 0, st))
-        w_hi, w_lo = split_weight(w)
+        w_hi, w_lo, w_sc = split_weight(w)
         out = new_act(N, Cout, H, W, dev)
         if res is not None:
             res = to_nhwc(res)
         ws, wsb = _sk(dev)
-        check(lib.cdae_conv3x3_fwd_psk(*ptr2(planes), H * W * C, W * C, C, ptr(w_hi), ptr(w_lo), *_pk(w, False), ptr(b), ptr(res), ptr(out), Cout,
+        check(lib.cdae_conv3x3_fwd_psk(*ptr2(planes), H * W * C, W * C, C, ptr(w_hi), ptr(w_lo), *_pk(w, False), ptr(w_sc), ptr(b), ptr(res), ptr(out), Cout,
                                       0, None, None, None, N, H, W, C, Cout, 1, 0, ws, wsb, st))
         ctx.save_for_backward(x, gamma, beta, ss, stats, bplanes, w)
         ctx.cfg = (silu, groups, b is not None, res is not None)
@@ -1254,10 +1363,10 @@ class _UpConvPS(Function):
         planes = torch.empty((2, N, 2 * H, 2 * W, C), dtype=torch.float16, device=dev)
         bplanes = torch.empty((2, N, 2 * H, 2 * W, C), dtype=torch.bfloat16, device=dev)
         check(lib.cdae_upsample2_split(ptr(x), *ptr2(planes), *ptr2(bplanes), N, H, W, C, st))
-        w_hi, w_lo = split_weight(w)
+        w_hi, w_lo, w_sc = split_weight(w)
         out = new_act(N, Cout, 2 * H, 2 * W, dev)
         ws, wsb = _sk(dev)
-        check(lib.cdae_conv3x3_fwd_psk(*ptr2(planes), 4 * H * W * C, 2 * W * C, C, ptr(w_hi), ptr(w_lo), *_pk(w, False), ptr(b), None, ptr(out), Cout,
+        check(lib.cdae_conv3x3_fwd_psk(*ptr2(planes), 4 * H * W * C, 2 * W * C, C, ptr(w_hi), ptr(w_lo), *_pk(w, False), ptr(w_sc), ptr(b), None, ptr(out), Cout,
                                       0, None, None, None, N, 2 * H, 2 * W, C, Cout, 1, 0, ws, wsb, st))
         ctx.save_for_backward(bplanes, w)
         ctx.cfg = (b is not None, (N, C, H, W))
@@ -1429,11 +1538,12 @@ class _ResBlockPS(Function):
         else:                               # 1x1 skip conv on the NHWC rows
             skip = new_act(N, Cout, H, W, dev)
             ws, wsb = _sk(dev)
+            swsc = ptr(weight_scale(sw))
             if x2 is None:
-                check(lib.cdae_linear_fwd(ptr(x), C, ptr(sw), C, ptr(sb), None, ptr(skip), Cout, None, None, N * H * W, Cout, C, 1.0, ACT_NONE,
+                check(lib.cdae_linear_fwd(ptr(x), C, ptr(sw), C, swsc, ptr(sb), None, ptr(skip), Cout, None, None, N * H * W, Cout, C, 1.0, ACT_NONE,
                                           ws, wsb, st))
             else:
-                check(lib.cdae_linear_fwd_cat(ptr(x), C1, C1, ptr(x2), C - C1, ptr(sw), C, ptr(sb), ptr(skip), Cout, N * H * W, Cout, C, ws, wsb, st))
+                check(lib.cdae_linear_fwd_cat(ptr(x), C1, C1, ptr(x2), C - C1, ptr(sw), C, swsc, ptr(sb), ptr(skip), Cout, N * H * W, Cout, C, ws, wsb, st))
         out = _rb_conv(planes, w2, c2b, skip, (N, Cout, H, W), Cout, st)
         del planes
         ctx.save_for_backward(x, h, ss, stats1, stats2, bplanes1, bplanes2, g1, b1, w1, g2, b2, w2, sw, x2)
@@ -1569,7 +1679,7 @@ class _EmbAllTrain(Function):
         check(lib.cdae_silu_fwd(ptr(emb), ptr(s), emb.numel(), st))
         out = torch.empty((N, T), dtype=torch.float32, device=dev)
         ws, wsb = _sk(dev)
-        check(lib.cdae_linear_fwd(ptr(s), K, ptr(W), K, ptr(b), None, ptr(out), T, None, None, N, T, K, 1.0, ACT_NONE, ws, wsb, st))
+        check(lib.cdae_linear_fwd(ptr(s), K, ptr(W), K, ptr(weight_scale(W)), ptr(b), None, ptr(out), T, None, None, N, T, K, 1.0, ACT_NONE, ws, wsb, st))
         dall = torch.zeros((N, T), dtype=torch.float32, device=dev)
         flat["_dall"] = dall
         ctx.save_for_backward(emb, s)
@@ -1633,12 +1743,12 @@ def linear_emit(rows, w, b, res, shape):
     y = torch.empty((M, Nf), dtype=torch.float32, device=rows.device)
     planes = torch.empty((2, N, H, W, C), dtype=torch.float16, device=rows.device)
     if _stream_gemm_ok(rows, M, Nf, K, ACT_NONE, 1.0, res):
-        wh, wl = split_weight(w)
-        check(lib.cdae_linear_fwd_stream(ptr(rows), rows.stride(0), K, None, 0, ptr(wh), ptr(wl), K, ptr(b), ptr(res), 0 if res is None else res.stride(0),
+        wh, wl, wsp = split_weight(_root(w))
+        check(lib.cdae_linear_fwd_stream(ptr(rows), rows.stride(0), K, None, 0, ptr(wh), ptr(wl), K, ptr(wsp), ptr(b), ptr(res), 0 if res is None else res.stride(0),
                                          ptr(y), Nf, *ptr2(planes), M, Nf, K, stream()))
         return y, SplitAct(planes[0], planes[1], shape)
     ws, wsb = _sk(rows.device)
-    check(lib.cdae_linear_fwd(ptr(rows), rows.stride(0), ptr(w), K, ptr(b), ptr(res), ptr(y), Nf, *ptr2(planes),
+    check(lib.cdae_linear_fwd(ptr(rows), rows.stride(0), ptr(w), K, ptr(weight_scale(w)), ptr(b), ptr(res), ptr(y), Nf, *ptr2(planes),
                               M, Nf, K, 1.0, ACT_NONE, ws, wsb, stream()))
     return y, SplitAct(planes[0], planes[1], shape)
 
@@ -1663,9 +1773,9 @@ def linear_gn(lz, w, b=None):
     dev = lz.x1.device
     st = stream()
     coef = lz.coefficients()
-    wh, wl = split_weight(w)
+    wh, wl, wsp = split_weight(_root(w))
     y = torch.empty((M, Nf), dtype=torch.float32, device=dev)
-    check(lib.cdae_linear_fwd_stream_gn(ptr(lz.x1), C, ptr(wh), ptr(wl), C, ptr(b), ptr(y), Nf, ptr(coef), 1 if lz.silu else 0, M, Nf, C, H * W, st))
+    check(lib.cdae_linear_fwd_stream_gn(ptr(lz.x1), C, ptr(wh), ptr(wl), C, ptr(wsp), ptr(b), ptr(y), Nf, ptr(coef), 1 if lz.silu else 0, M, Nf, C, H * W, st))
     return y
 
 
@@ -1675,9 +1785,9 @@ def linear_ps(xs, w, b=None, res=None, act=ACT_NONE):
     N, C, H, W = xs.shape
     M, Nf = N * H * W, w.shape[0]
     assert w.numel() == Nf * C and w.is_contiguous()
-    w_hi, w_lo = split_weight(w)
+    w_hi, w_lo, w_sc = split_weight(_root(w))
     y = torch.empty((M, Nf), dtype=torch.float32, device=xs.hi.device)
     ws, wsb = _sk(xs.hi.device)
-    check(lib.cdae_linear_fwd_ps(ptr(xs.hi), ptr(xs.lo), C, ptr(w_hi), ptr(w_lo), C, ptr(b), ptr(res), ptr(y), Nf, M, Nf, C, 1.0, act,
+    check(lib.cdae_linear_fwd_ps(ptr(xs.hi), ptr(xs.lo), C, ptr(w_hi), ptr(w_lo), C, ptr(w_sc), ptr(b), ptr(res), ptr(y), Nf, M, Nf, C, 1.0, act,
                                  ws, wsb, stream()))
     return y

@@ -54,7 +54,7 @@ class FlatParams:
             # backward kernels accumulate straight into this view (ops._sink): no temporaries, no autograd add kernels
             p._grad_view = p.grad
             p._grad_ready = None
-        self.conv_bank = ops.register_conv_bank(self.flat, self.params) if dev.type == "cuda" else None
+        emb_w = None
         if lead:
             blocks, ws, bs = group
             T, K = sum(w.shape[0] for w in ws), ws[0].shape[1]
@@ -62,8 +62,14 @@ class FlatParams:
             for blk, w in zip(blocks, ws):
                 offs.append((id(blk), o, w.shape[0]))
                 o += w.shape[0]
-            model._emb_flat = dict(w=self.flat[:T * K].view(T, K), b=self.flat[T * K:T * K + T], gw=self.grad[:T * K].view(T, K),
+            emb_w = self.flat[:T * K].view(T, K)
+            model._emb_flat = dict(w=emb_w, b=self.flat[T * K:T * K + T], gw=self.grad[:T * K].view(T, K),
                                    gb=self.grad[T * K:T * K + T], params=lead, offs=offs)
+        # power-of-two scale records of every weight the f16 modes hand to the matrix cores (ops.weight_scale): one pass per weight
+        # version over the flat buffer, the concatenated emb_layers weight (ONE GEMM operand) as a tensor of its own; then the operand
+        # planes of the 3x3 convs (which consume their records)
+        self.scale_table = ops.register_scale_table(self.flat, self.params + ([emb_w] if emb_w is not None else [])) if dev.type == "cuda" else None
+        self.conv_bank = ops.register_conv_bank(self.flat, self.params) if dev.type == "cuda" else None
 
     def zero_grad(self):
         self.grad.zero_()
@@ -122,16 +128,13 @@ class GradBuckets:
             self.next_launch += 1
 
     def _all_reduce(self, b):
-        """Asynchronous all-reduce of one bucket, ordered EXPLICITLY behind the kernels that wrote it: the backward kernels were enqueued
-        through the C-ABI on the raw HIP stream of the thread that ran them (autograd's device thread), and this hook may run on another
-        thread — an event recorded on the launch stream and waited for on the stream the collective is issued from makes the ordering
-        independent of what torch believes the current stream of either thread to be (RCCL's own stream then waits on that one)."""
+        """Asynchronous all-reduce of one bucket.  Ordering behind the kernels that wrote it is same-stream ordering: the hooks
+        (`_grad_ready` from ops._done and autograd's post-accumulate hook) run on the thread that enqueued the backward kernels —
+        autograd's device thread, whose current stream is the forward's stream — and the C-ABI launches go to exactly that stream
+        (`_lib.stream()` = torch's current stream of the calling thread); the process group makes its own stream wait on the current
+        stream before the collective starts.  No event of our own: one recorded here would be recorded on, and waited for by, the
+        same stream."""
         grad = self.flat.grad[b["lo"]:b["hi"]]
-        if grad.is_cuda:
-            ev = th.cuda.Event()
-            launch = th.cuda.ExternalStream(stream(), device=grad.device)      # the stream ops.* enqueue on (torch's current stream of this thread)
-            ev.record(launch)
-            th.cuda.current_stream(grad.device).wait_event(ev)
         return dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _make_hook(self, i):

@@ -1,12 +1,21 @@
 """UNetModel noise predictor with the reference's constructor, forward signature and state-dict layout
 (reference improved_diffusion/unet.py), executed by the HIP kernels behind ops.py.
 
-Fusion map (what one launch replaces in the reference's eager ATen stream):
-  GroupNorm32 + (1+scale)*.+shift + SiLU      -> gn_stats + gn_apply            (unet.py:186,190-194)
-  conv3x3 + bias + residual add               -> one igemm launch               (unet.py:186,194,198)
-  F.interpolate(nearest 2x) + conv3x3         -> upsample folded into the gather (unet.py:76-78)
-  qkv 1x1 / proj_out 1x1 (+ residual)         -> GEMM over NHWC rows            (unet.py:226,230-231)
-  QKVAttention                                -> 2 batched MFMA GEMMs + wave-shuffle softmax (unet.py:239-253)
+Fusion map (what one launch replaces in the reference's eager ATen stream; kernels and dispatch table: DESIGN.md §4-5):
+  GroupNorm32 statistics                        -> the producing conv's epilogue partial sums + one small finish launch (with the
+                                                   folded (a, b) table), or gn_partial + finalize where no producer left sums
+  GroupNorm32 + (1+scale)*.+shift + SiLU        -> written ONCE as the next conv's f16 hi/lo operand planes, group-major
+                                                   (gn_apply_gm; training: f16 + bf16 planes)                 (unet.py:186,190-194)
+  ResBlock entry with a 1x1 skip conv           -> skipgn_kernel: skip GEMM + first GroupNorm's planes from one sweep over the
+                                                   (concatenated, never materialised) block input              (unet.py:143-147,165-171)
+  conv3x3 + bias + residual (+ next GN's sums)  -> convwin_kernel on the planes (window resident in LDS)      (unet.py:186,194,198)
+  F.interpolate(nearest 2x) + conv3x3           -> four folded 2x2 sub-pixel convs of the LOW-res input, one launch (unet.py:76-78)
+  GroupNorm -> qkv 1x1                          -> skipgn_kernel<NORMA>: the norm applied to the rows as they stream  (unet.py:226)
+  QKVAttention                                  -> attn_fused_kernel: QK^T, fp32 softmax in registers, PV — one launch (unet.py:239-253)
+  proj_out 1x1 + residual                       -> streaming GEMM over NHWC rows                              (unet.py:230-231)
+  22 emb_layers Linear(SiLU(emb))               -> ONE batched GEMM per forward                               (unet.py:148-154)
+  output head GN -> SiLU -> conv3x3 (C <= 8)    -> head_conv_kernel, exact fp32 on the vector ALUs             (unet.py:474-478)
+Training: a ResBlock is one autograd node (ops.resblock_train), the Upsample conv another, the embedding projections a third.
 """
 from abc import abstractmethod
 

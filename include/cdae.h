@@ -92,7 +92,7 @@ int cdae_get_default_precision(void);
  *   w   : OHWI [Cout][3][3][Cin];  bias [Cout] or NULL;  res: optional residual, same layout as out
  *   out : [N,Ho,Wo,Cout] row pitch ldo (out_nchw=0) or NCHW contiguous (out_nchw=1)
  *   Ho = up ? 2H : (H-1)/stride+1 (same for W).  splitk_ws may be NULL (disables split-K). */
-int cdae_conv3x3_fwd(const float* x, long sn, long sy, long sx, long sc, const float* w, const float* bias, const float* res,
+int cdae_conv3x3_fwd(const float* x, long sn, long sy, long sx, long sc, const float* w, const float* w_scale, const float* bias, const float* res,
                      float* out, long ldo, int out_nchw, int N, int H, int W, int Cin, int Cout, int stride, int up,
                      float* splitk_ws, size_t splitk_ws_bytes, void* stream);
 /* dgrad: dx[N,H,W,Cin] (pitch lddx) from dy[N,Ho,Wo,Cout] (pitch lddy).  For up=1 dx is the gradient w.r.t.
@@ -102,7 +102,7 @@ int cdae_conv3x3_fwd(const float* x, long sn, long sy, long sx, long sc, const f
    global -> LDS by LDS-DMA with no conversion work in the main loop; results are bit-identical to cdae_conv3x3_fwd /
    cdae_linear_fwd in f16x3 mode.  Strides in elements of a plane; Cin (K) % 32 == 0, pixel pitch % 8 == 0. */
 int cdae_conv3x3_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, long sn, long sy, long sx, const unsigned short* w_hi,
-                        const unsigned short* w_lo, const float* bias, const float* res, float* out, long ldo, int out_nchw,
+                        const unsigned short* w_lo, const float* w_scale, const float* bias, const float* res, float* out, long ldo, int out_nchw,
                         unsigned short* out_hi, unsigned short* out_lo,
                         float* gn_part /* optional [ceil(M/32)][Cout][2]: per (32-pixel chunk, channel) sum and sum of squares of the
                                           result, consumed by cdae_gn_stats_from_parts; disables split-K */,
@@ -120,7 +120,7 @@ int cdae_conv3x3_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, 
 int cdae_conv_wpack(const unsigned short* w_hi, const unsigned short* w_lo, unsigned short* k_hi, unsigned short* k_lo, int rows, int taps,
                     int K, void* stream);
 int cdae_conv3x3_fwd_psk(const unsigned short* x_hi, const unsigned short* x_lo, long sn, long sy, long sx, const unsigned short* w_hi,
-                         const unsigned short* w_lo, const unsigned short* wk_hi, const unsigned short* wk_lo, const float* bias, const float* res,
+                         const unsigned short* w_lo, const unsigned short* wk_hi, const unsigned short* wk_lo, const float* w_scale, const float* bias, const float* res,
                          float* out, long ldo, int out_nchw, unsigned short* out_hi, unsigned short* out_lo, float* gn_part, int N, int H, int W,
                          int Cin, int Cout, int stride, int up, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
 int cdae_conv3x3_dgrad_psk(const unsigned short* dy_hi, const unsigned short* dy_lo, const unsigned short* wt_hi, const unsigned short* wt_lo,
@@ -144,22 +144,37 @@ int cdae_gn_stats2_coef(const float* x1, int ld1, const float* x2, int ld2, int 
 /* nearest-2x upsample + conv3x3 (unet.py:67-76) as four 2x2 sub-pixel convolutions of the low-resolution input: 2.25x fewer
    multiply-adds than convolving the upsampled image.  w4 = [4][Cout][2][2][Cin] folded weights as hi / lo planes. */
 int cdae_upconv3x3_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, long sn, long sy, long sx, const unsigned short* w4_hi,
-                          const unsigned short* w4_lo, const float* bias, float* out, long ldo,
+                          const unsigned short* w4_lo, const float* w_scale, const float* bias, float* out, long ldo,
                           float* gn_part /* optional [4][N*H*W/32][Cout][2] partial sums, one segment per phase */,
                           int N, int H, int W, int Cin, int Cout, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
 int cdae_linear_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, long ldx, const unsigned short* w_hi, const unsigned short* w_lo,
-                       long ldw, const float* bias, const float* res, float* y, long ldy, int M, int N, int K, float alpha, int act,
+                       long ldw, const float* w_scale, const float* bias, const float* res, float* y, long ldy, int M, int N, int K, float alpha, int act,
                        float* splitk_ws, size_t splitk_ws_bytes, void* stream);
 int cdae_split_f16(const float* src, unsigned short* hi, unsigned short* lo, long n, void* stream);
+/* WEIGHT operands of the f16 modes are scaled by an exact power of two per tensor.  hi = f16(w), lo = f16(w - hi) degenerates for
+   |w| < 2^-3: lo is then an f16 subnormal and the pair is fixed point with a 2^-24 LSB (|w| ~ 0.01: 1e-5 relative) — and conv / linear
+   weights live there.  A scale record is two floats {2^k, 2^-k}, k = 14 - floor(log2 max|w|) (scaled maximum in [2^14, 2^15); {1, 1} for an
+   all-zero or non-finite tensor): weight planes hold w * 2^k (cdae_split_f16w, cdae_wprep_all_k), the fp32-operand kernels multiply the
+   weight tile by 2^k before they split it, and every epilogue multiplies the sum by the exact 2^-k.  The pair then represents every
+   element to 2^-22 relative or 2^-39 of the tensor's largest magnitude, whichever is larger, for ANY weight scale.  Every entry point
+   below that takes a weight takes the record as `w_scale` (device pointer; NULL = the operand is unscaled).  bf16 planes (gradient
+   operands, dgrad weights) have fp32's exponent range and are never scaled.
+   cdae_weight_scales: records of MANY tensors of one fp32 buffer in one pass.  desc = nw records {long offset, long n, int chunk0, int
+   pad} (elements; chunk0 = running sum of ceil(n / cdae_weight_scales_chunk())), total_chunks = that sum; records [nw][2] floats,
+   scratch nw uint32.  cdae_weight_scale1: one tensor. */
+int cdae_weight_scales(const float* flat, const void* desc, int nw, int total_chunks, float* records, unsigned* scratch, void* stream);
+int cdae_weight_scales_chunk(void);
+int cdae_weight_scale1(const float* w, long n, float* record, unsigned* scratch, void* stream);
+int cdae_split_f16w(const float* src, const float* w_scale, unsigned short* hi, unsigned short* lo, long n, void* stream);
 /* y = [x1 | x2] @ w^T + bias with the K range split over two row-major sources (the 1x1 skip conv of a ResBlock fed by the
    skip concatenation, unet.py:629,198); K1 % 32 == 0 */
-int cdae_linear_fwd_cat(const float* x1, long ld1, int K1, const float* x2, long ld2, const float* w, long ldw, const float* bias, float* y,
+int cdae_linear_fwd_cat(const float* x1, long ld1, int K1, const float* x2, long ld2, const float* w, long ldw, const float* w_scale, const float* bias, float* y,
                         long ldy, int M, int N, int K, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
 /* cdae_linear_fwd_cat + the block's first GroupNorm in the same sweep: besides y, the n-tile-0 blocks write
    silu?(x * a + b) (coef [N][K][2] from cdae_gn_coef: bit-identical to cdae_gn_apply_split2) as f16 hi/lo planes s_hi / s_lo [M][K],
    i.e. the operand of the block's first conv3x3 — ResBlock skip_connection (unet.py:171,198) and in_layers[0:2] (unet.py:135-137,187)
    over ONE read of the (concatenated) block input.  HW = pixels per image; x2 may be NULL.  f16x3 mode, M >= 96, N >= 96. */
-int cdae_linear_fwd_cat_gn(const float* x1, long ld1, int K1, const float* x2, long ld2, const float* w, long ldw, const float* bias, float* y,
+int cdae_linear_fwd_cat_gn(const float* x1, long ld1, int K1, const float* x2, long ld2, const float* w, long ldw, const float* w_scale, const float* bias, float* y,
                            long ldy, const float* coef, int silu, unsigned short* s_hi, unsigned short* s_lo, int M, int N, int K, int HW,
                            float* splitk_ws, size_t splitk_ws_bytes, void* stream);
 /* The same sweep as its own HBM-stream kernel (skipgn.hip), on PRE-SPLIT weight planes w_hi / w_lo [N][K] (cdae_split_f16 of the 1x1
@@ -170,15 +185,15 @@ int cdae_skip_gn_ok(int M, int N, int K, int K1, int HW);
 /* the same kernel without the GroupNorm side output: y = [x1 | x2] @ W^T + bias (+ res, row pitch ldres) for large row counts — the
    attention proj_out with its residual (unet.py:231) and the other 1x1 convs / linears on fp32 rows (f16x3 products, K % 32 == 0) */
 int cdae_linear_fwd_stream(const float* x1, long ld1, int K1, const float* x2, long ld2, const unsigned short* w_hi, const unsigned short* w_lo,
-                           long ldw, const float* bias, const float* res, long ldres, float* y, long ldy, unsigned short* c_hi, unsigned short* c_lo,
+                           long ldw, const float* w_scale, const float* bias, const float* res, long ldres, float* y, long ldy, unsigned short* c_hi, unsigned short* c_lo,
                            int M, int N, int K, void* stream);      /* c_hi / c_lo (may be NULL): y also as f16 planes, row pitch ldy */
 /* y[M][N] = silu?(GroupNorm(x))[M][K] @ W^T + bias with the GroupNorm folded to per-(image, channel) coefficients (cdae_gn_coef) and
    applied to the fp32 rows as they are staged — GroupNorm -> 1x1 conv in one pass (AttentionBlock norm -> qkv, unet.py:213-228).
    f16x3 products on pre-split weight planes; shapes as cdae_skip_gn_ok(M, N, K, K, HW). */
-int cdae_linear_fwd_stream_gn(const float* x, long ldx, const unsigned short* w_hi, const unsigned short* w_lo, long ldw, const float* bias,
+int cdae_linear_fwd_stream_gn(const float* x, long ldx, const unsigned short* w_hi, const unsigned short* w_lo, long ldw, const float* w_scale, const float* bias,
                               float* y, long ldy, const float* coef, int silu, int M, int N, int K, int HW, void* stream);
 int cdae_skip_gn_fwd(const float* x1, long ld1, int K1, const float* x2, long ld2, const unsigned short* w_hi, const unsigned short* w_lo, long ldw,
-                     const float* bias, float* y, long ldy, const float* coef, int silu, unsigned short* s_hi, unsigned short* s_lo, int planes_gm,
+                     const float* w_scale, const float* bias, float* y, long ldy, const float* coef, int silu, unsigned short* s_hi, unsigned short* s_lo, int planes_gm,
                      int M, int N, int K, int HW, void* stream);
 /* two-source forms: channels [0, C1) are read from x1 (pixel pitch ld1), channels [C1, C) from x2 (pitch ld2) — the skip
    concatenation th.cat([h, hs.pop()], dim=1) (unet.py:629) consumed in place instead of being copied; x2 == NULL: one source */
@@ -196,7 +211,7 @@ int cdae_gn_apply_split2g(const float* x, int ldx, const float* x2, int ld2, int
                           const float* scale_shift, int ld_ss, int silu, void* stream);
 int cdae_planes_gm_to_pc(const unsigned short* a_hi, const unsigned short* a_lo, unsigned short* o_hi, unsigned short* o_lo, long P, int C, void* stream);
 int cdae_conv3x3_fwd_psg(const unsigned short* x_hi, const unsigned short* x_lo, long sn, long sy, long sx, int x_gm, const unsigned short* w_hi,
-                         const unsigned short* w_lo, const unsigned short* wk_hi, const unsigned short* wk_lo, const float* bias, const float* res,
+                         const unsigned short* w_lo, const unsigned short* wk_hi, const unsigned short* wk_lo, const float* w_scale, const float* bias, const float* res,
                          float* out, long ldo, int out_nchw, unsigned short* out_hi, unsigned short* out_lo, float* gn_part, int N, int H, int W,
                          int Cin, int Cout, int stride, int up, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
 int cdae_gn_apply_split(const float* x, unsigned short* y_hi, unsigned short* y_lo, int N, int HW, int C, int ldx, int ldy, int groups,
@@ -242,7 +257,9 @@ int cdae_wprep_all(const float* flat, const void* desc, int nw, int total_tiles,
                    unsigned short* b_hi, unsigned short* b_lo, void* stream);
 int cdae_wprep_all_k(const float* flat, const void* desc, int nw, int total_tiles, long base, unsigned short* f_hi, unsigned short* f_lo,
                      unsigned short* b_hi, unsigned short* b_lo, unsigned short* kf_hi, unsigned short* kf_lo, unsigned short* kb_hi,
-                     unsigned short* kb_lo /* K-group-major copies (cdae_conv_wpack's order), all NULL or all given */, void* stream);
+                     unsigned short* kb_lo /* K-group-major copies (cdae_conv_wpack's order), all NULL or all given */,
+                     const float* w_scales /* scale records (cdae_weight_scales) applied to the f16 planes: record index = desc.flags >> 8; NULL: unscaled */,
+                     void* stream);
 int cdae_conv3x3_dgrad_ps(const unsigned short* dy_hi, const unsigned short* dy_lo, const unsigned short* wt_hi, const unsigned short* wt_lo,
                           float* dx, long lddx, int N, int H, int W, int Cin, int Cout, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
 /* wgrad of a stride-1 conv3x3 with 1..8 output channels over a dense NHWC fp32 input (the `out` conv, unet.py:474-478): sliding-window
@@ -273,7 +290,7 @@ int cdae_conv3x3_wgrad(const float* x, long sn, long sy, long sx, long sc, const
 /* y[M][N] = act(alpha * x[M][K] @ w[N][K]^T + bias + res) — replaces nn.Linear (unet.py:354-379, emb_layers
  * :148-154, nn.py:57-58,233-237) and the 1x1 convs (skip_connection unet.py:171, qkv/proj_out unet.py:216-218)
  * on NHWC rows.  act: 0 none, 1 SiLU, 2 LeakyReLU(0.01). */
-int cdae_linear_fwd(const float* x, long ldx, const float* w, long ldw, const float* bias, const float* res, float* y, long ldy,
+int cdae_linear_fwd(const float* x, long ldx, const float* w, long ldw, const float* w_scale, const float* bias, const float* res, float* y, long ldy,
                     unsigned short* y_hi, unsigned short* y_lo /* optional: the result also as f16 hi/lo planes, pitch ldy */,
                     int M, int N, int K, float alpha, int act, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
 /* dx[M][K] (+)= dy[M][N] @ w[N][K] */

@@ -57,6 +57,42 @@ def fill_value(key, shape, salt=0):
     return torch.from_numpy(v.reshape(shape).astype(np.float32))
 
 
+ZERO_INIT_SUFFIXES = ("out_layers.3.weight", "out_layers.3.bias", "proj_out.weight", "proj_out.bias")
+
+
+def fill_value_trained(key, shape, salt=0):
+    """"Trained-like" value for state-dict entry `key`: matrices / conv kernels get LOG-UNIFORM magnitudes over four decades with
+    a random sign, |w| = 10^(-4 v) * g / sqrt(fan_in), v uniform in [0, 1) — heavy-tailed and mostly small, the shape of a trained
+    network's weight histogram (the uniform fill of fill_value never leaves one binade and a half).  g = 4.292 makes the variance
+    1 / fan_in like fill_value's.  A quarter of the reference's zero-initialised layers (nn.py:516-522 zero_module: the last conv of a
+    ResBlock, the attention proj_out) are LEFT ZERO, chosen by a hash of the key: a partially trained network, and the all-zero
+    tensor case of the weight-scale records.  Vectors (norm gains, biases) as in fill_value."""
+    shape = tuple(int(s) for s in shape)
+    if len(shape) < 2:
+        return fill_value(key, shape, salt)
+    if key.endswith(ZERO_INIT_SUFFIXES[0]) or key.endswith(ZERO_INIT_SUFFIXES[2]):
+        if zlib.crc32(key.encode()) % 4 == 0:
+            return torch.zeros(shape, dtype=torch.float32)
+    n = int(np.prod(shape))
+    u = uniform_pm1(n, key_seed(key, salt))                       # sign
+    v = (uniform_pm1(n, key_seed(key, salt + 7)) + 1.0) * 0.5     # exponent
+    fan_in = int(np.prod(shape[1:]))
+    g = 1.0 / np.sqrt((1.0 - 1e-8) / (8.0 * np.log(10.0)))       # 1 / rms of 10^(-4 v)
+    w = np.where(u < 0, -1.0, 1.0) * np.power(10.0, -4.0 * v) * (g / np.sqrt(fan_in))
+    return torch.from_numpy(w.reshape(shape).astype(np.float32))
+
+
+def fill_state_dict_trained(spec, salt=0):
+    return OrderedDict((k, fill_value_trained(k, s, salt)) for k, s in spec)
+
+
+def synth_noise(name, shape):
+    """Closed-form stand-in for a unit-variance noise draw (uniform in +-sqrt(3)): both sides of a fixture generate it, so a 1000-step
+    ancestral loop needs no stored noise."""
+    r = float(np.sqrt(3.0))
+    return synth(name, shape, -r, r)
+
+
 def fill_state_dict(spec, salt=0):
     """spec: iterable of (key, shape) -> OrderedDict key -> tensor."""
     return OrderedDict((k, fill_value(k, s, salt)) for k, s in spec)

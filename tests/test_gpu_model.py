@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle.closed_form import fill_value, synth
+from oracle.closed_form import fill_value, fill_value_trained, synth, synth_noise
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -497,8 +497,148 @@ def _p_sample_loop_check(golden):
 
 
 
+# ------------------------------------------------------------------ G17..G20: the LONG loops BASELINE's configs name, trained-like weights, traversal
+def _counterfactual_start(model, diff, cfg, g, N, t_last, tag="P64"):
+    """encode -> causal layer -> do(z_post[:, :128] := 0.2) -> reparameterize -> q_sample(t_last), checked against the fixture's own start"""
+    from improved_diffusion.nn import reparameterize
+    from improved_diffusion.unet import ADJACENCY
+    x, x0, c, z, _ = model_inputs(tag, cfg, N)
+    A = torch.tensor(ADJACENCY["pendulum"], dtype=torch.float32)
+    mu, var = model.rep_emb.encode(x0.to(DEV))
+    z_pre = model.causal_mask.causal_masking(mu, A)
+    z_post = model.causal_mask.nonlinearity_add_back_noise(mu, z_pre)
+    z_post[:, :128] = 0.2
+    zz = reparameterize(z_post, torch.ones_like(mu) * 0.001, eps=torch.from_numpy(g["eps_draw"]).to(DEV))
+    assert err(zz, g["z"]) < 2e-5
+    tl = torch.full((N,), t_last, dtype=torch.int64, device=DEV)
+    x_t = diff.q_sample(x0.to(DEV), tl, noise=synth(tag + ".qnoise", (N, cfg["in_channels"], cfg["image_size"], cfg["image_size"]), -1.7, 1.7).to(DEV))
+    assert err(x_t, g["x_t"]) < 1e-6
+    return x_t, zz
+
+
+def test_ddim250_p64_golden(golden, precision):
+    _ddim250_check(golden)
+
+
+def _ddim250_check(golden):
+    """BASELINE config [4] (P64, "ddim250"): all 250 sequential steps of the reference's loop (gaussian_diffusion.py:598-680,
+    respace.py:30-37) — the error of 250 network evaluations compounds and stays within 1e-4; eager, graph replay and the default call."""
+    g = golden("g17_ddim250.npz")
+    model, diff, cfg = make("P64", respacing="ddim250")
+    model.eval()
+    N = 2
+    assert diff.num_timesteps == 250
+    with torch.no_grad():
+        x_t, zz = _counterfactual_start(model, diff, cfg, g, N, 249)
+        k = 0
+        for o in diff.ddim_sample_loop_progressive(model, (N, 4, 64, 64), noise=x_t, model_kwargs=dict(z=zz), use_graph=False):
+            k += 1
+            if k in (1, 25, 125, 250):
+                assert err(o["sample"], g[f"sample_after{k}"]) < 1e-4, (k, err(o["sample"], g[f"sample_after{k}"]))
+        assert k == 250
+        final = diff.ddim_sample_loop(model, (N, 4, 64, 64), noise=x_t, model_kwargs=dict(z=zz))       # the default: graph replay
+        assert err(final, g["sample_after250"]) < 1e-4 and err(final, o["sample"]) == 0.0
+
+
+def test_p_sample_loop_t1000_golden(golden, precision):
+    _p_sample_t1000_check(golden)
+
+
+def _p_sample_t1000_check(golden):
+    """BASELINE config [0] (M32, T = 1000, ancestral sampling): 1000 sequential p_sample steps (gaussian_diffusion.py:383-504) with the
+    per-step noise in closed form on both sides (oracle.closed_form.synth_noise; the generator patches th.randn_like)."""
+    g = golden("g18_p_sample_t1000.npz")
+    model, diff, cfg = make("M32", respacing="")
+    model.eval()
+    N = 2
+    assert diff.num_timesteps == 1000
+    x, x0, c, z, y = model_inputs("M32", cfg, N)
+    kw = dict(z=z.to(DEV), y=y.to(DEV))
+    x_T = synth("M32.xT", (N, 1, 32, 32), -1.7, 1.7).to(DEV)
+
+    class Noise:                       # step k's draw, generated when the loop asks for it
+        def __getitem__(self, k):
+            return synth_noise(f"G18.noise.{k}", (N, 1, 32, 32)).to(DEV)
+
+    with torch.no_grad():
+        k = 0
+        for o in diff.p_sample_loop_progressive(model, (N, 1, 32, 32), noise=x_T, model_kwargs=kw, step_noise=Noise()):
+            k += 1
+            if k in (1, 10, 100, 500, 900, 1000):
+                e = err(o["sample"], g[f"sample_after{k}"])
+                assert e < 1e-4, (k, e)
+                assert err(o["pred_xstart"], g[f"pred_xstart_after{k}"]) < 1e-4 + 1e-5 * float(diff.sqrt_recipm1_alphas_cumprod[1000 - k]), k
+        assert k == 1000
+
+
+def make_trained_like(tag, respacing=""):
+    from improved_diffusion import script_util as su
+    cfg = {**su.model_and_diffusion_defaults(), "rep_cond": True, "causal_modeling": True, **MODEL_CFG[tag], "timestep_respacing": respacing}
+    model, diff = su.create_model_and_diffusion(**cfg)
+    model.load_state_dict({k: fill_value_trained(k, v.shape) for k, v in model.state_dict().items()})
+    return model.to(DEV), diff, cfg
+
+
+def test_trained_like_weights_p64_golden(golden, precision):
+    _trained_like_check(golden)
+
+
+def _trained_like_check(golden):
+    """P64 with a trained-like weight distribution (log-uniform magnitudes over four decades, a quarter of the zero-initialised layers
+    left zero; oracle.closed_form.fill_value_trained): one forward, one DDIM step and the DDIM-100 loop against the reference.  This is
+    the case the per-tensor scale of the weight planes exists for (most weights far below 2^-3)."""
+    g = golden("g19_trained_like.npz")
+    model, diff, cfg = make_trained_like("P64", respacing="ddim100")
+    model.eval()
+    N = 2
+    zero = [k for k, v in model.state_dict().items() if v.dim() >= 2 and float(v.abs().max()) == 0.0]
+    assert zero == list(g["zero_keys"]) and len(zero) >= 4
+    x, x0, c, z, _ = model_inputs("P64", cfg, N)
+    with torch.no_grad():
+        e, *_ = model(x.to(DEV), torch.tensor([37.0, 990.0], device=DEV), z=z.to(DEV))
+        assert err(e, g["eps_z"]) < 1e-4, err(e, g["eps_z"])
+        x_t, zz = _counterfactual_start(model, diff, cfg, g, N, 99)
+        o = diff.ddim_sample(model, x_t, torch.full((N,), 99, dtype=torch.int64, device=DEV), model_kwargs=dict(z=zz))
+        assert err(o["sample"], g["step99/sample"]) < 1e-4
+        assert err(o["pred_xstart"], g["step99/pred_xstart"]) < 1e-4 + 1e-5 * float(diff.sqrt_recipm1_alphas_cumprod[99])
+        k = 0
+        for o in diff.ddim_sample_loop_progressive(model, (N, 4, 64, 64), noise=x_t, model_kwargs=dict(z=zz), use_graph=False):
+            k += 1
+            if k in (1, 10, 50, 100):
+                assert err(o["sample"], g[f"loop/sample_after{k}"]) < 1e-4, (k, err(o["sample"], g[f"loop/sample_after{k}"]))
+        final = diff.ddim_sample_loop(model, (N, 4, 64, 64), noise=x_t, model_kwargs=dict(z=zz))
+        assert err(final, g["loop/sample_after100"]) < 1e-4 and err(final, o["sample"]) == 0.0
+
+
+def test_latent_traversal_golden(golden):
+    _traversal_check(golden)
+
+
+def _traversal_check(golden):
+    """The evaluation script's traversal loop (image_causaldae_test.py:481-531) through counterfactual.latent_traversal's DEFAULT call:
+    shared x_t, eight accumulated values from -0.5, mu[:, 16:32] edited before the causal layer, a fresh draw per value, DDIM-250."""
+    from improved_diffusion.counterfactual import latent_traversal, traversal_values
+    g = golden("g20_traversal.npz")
+    model, diff, cfg = make("P64", respacing="ddim250")
+    model.eval()
+    N = 2
+    x, x0, c, z, _ = model_inputs("P64", cfg, N)
+    assert traversal_values() == [float(v) for v in g["values"]]              # the accumulated doubles, bit for bit
+    draws = [torch.from_numpy(d).to(DEV) for d in g["eps_draws"]]
+    out = latent_traversal(model, diff, x0, "pendulum", z_eps=draws, q_noise=synth("P64.qnoise", (N, 4, 64, 64), -1.7, 1.7))
+    assert len(out) == 8
+    for i, s_ in enumerate(out):
+        e = err(s_, g[f"sample{i}"])
+        assert e < 1e-4, (i, e)
+    assert err(out[0], out[7]) > 1e-3
+
+
 # ------------------------------------------------------------------ the same goldens through the kernels the BENCHMARK dispatches
 BENCH_DISPATCH_CASES = {
+    "ddim250_p64": (lambda g: _ddim250_check(g), dict(convwin=40, convwin_up=3)),
+    "p_sample_t1000": (lambda g: _p_sample_t1000_check(g), dict(convwin=10, convwin_up=1)),
+    "trained_like": (lambda g: _trained_like_check(g), dict(convwin=40, convwin_up=3)),
+    "traversal": (lambda g: _traversal_check(g), dict(convwin=40, convwin_up=3)),
     "unet_M32": (lambda g: _unet_forward_check(g, "M32"), dict(convwin=10, convwin_up=1)),
     "unet_P64": (lambda g: _unet_forward_check(g, "P64"), dict(convwin=40, convwin_up=3)),
     "unet_C64": (lambda g: _unet_forward_check(g, "C64"), dict(convwin=40, convwin_up=3)),
@@ -524,7 +664,7 @@ def test_goldens_on_benchmark_dispatch(golden, which, expect_kernels):
     assert causaldiffae_amd.get_precision() == "f16x3"
     with tune_scope(convwin_min_tiles=1), expect_kernels(**minimum) as seen:
         fn(golden)
-    if which.startswith("unet") or which in ("ddim_p64", "guided"):
+    if which.startswith("unet") or which in ("ddim_p64", "guided", "ddim250_p64", "trained_like", "traversal"):
         assert seen.seen["convwin_dgrad"]["launches"] == 0
 
 

@@ -199,7 +199,14 @@ def test_conv_weight_bank_packs_per_weight():
     assert bank.packed(stem, False) == (None, None)
     import numpy as np
     flags = bank.desc.numpy().view(np.dtype([("off", "<i8"), ("cout", "<i4"), ("cin", "<i4"), ("tile0", "<i4"), ("flags", "<i4")]))["flags"]
-    assert [int(f) for f in flags] == [1 if (w.shape[0] % 16 == 0 and w.shape[1] % 16 == 0) else 0 for w in ws]
+    assert [int(f) & 1 for f in flags] == [1 if (w.shape[0] % 16 == 0 and w.shape[1] % 16 == 0) else 0 for w in ws]
+    # bits 8..: the weight's record in the scale table (cdae_wprep_all_k scales the f16 planes by 2^k of that record)
+    assert bank.scales is not None and [int(f) >> 8 for f in flags] == [bank.scales.index[id(w)] for w in ws]
+    chunk = ops.lib.cdae_weight_scales_chunk()
+    sdesc = bank.scales.desc.numpy().view(np.dtype([("off", "<i8"), ("n", "<i8"), ("chunk0", "<i4"), ("pad", "<i4")]))
+    assert [int(o) for o in sdesc["off"]] == [(w.data_ptr() - flat.data_ptr()) // 4 for w in ws] and [int(n) for n in sdesc["n"]] == [w.numel() for w in ws]
+    assert [int(c) for c in sdesc["chunk0"]] == list(np.cumsum([0] + [(w.numel() + chunk - 1) // chunk for w in ws])[:-1])
+    assert bank.scales.chunks == sum((w.numel() + chunk - 1) // chunk for w in ws)
 
 
 def test_optimizer_checkpoint_uses_torch_adamw_layout():

@@ -10,7 +10,7 @@ import torch
 from oracle import diffusion_ref as D
 from oracle import schedule as S
 from oracle import unet_ref as U
-from oracle.closed_form import fill_state_dict, fill_value, synth
+from oracle.closed_form import fill_state_dict, fill_state_dict_trained, fill_value, synth, synth_noise
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 TOL = 2e-6          # same ATen CPU kernels, different op grouping
@@ -685,3 +685,105 @@ def test_p_sample_loop_m32(golden):
     for k in (1, 10, 20):
         close(trace[k - 1].numpy(), g[f"sample_after{k}"], 5e-5)
     close(final.numpy(), g["sample_after20"], 5e-5)
+
+
+# ------------------------------------------------------------------ G17..G20: the long loops, trained-like weights, traversal
+def _cf_start(sd, cfg, g, sch, N, t_last):
+    x, x0, c, z, _ = model_inputs("P64", cfg, N)
+    A = torch.tensor(U.ADJ["pendulum"], dtype=torch.float32)
+    mu, _ = U.encode(sd, x0, U.n_encoder_layers(sd))
+    z_post = U.nonlinearity_add_back_noise(sd, mu, U.causal_masking(mu, A, 4), 4)
+    z_post[:, :128] = 0.2
+    zz = U.reparameterize(z_post, torch.full_like(mu, 0.001), torch.from_numpy(g["eps_draw"]))
+    close(zz.numpy(), g["z"], 1e-5)
+    x_t = D.q_sample(sch, x0, torch.full((N,), t_last, dtype=torch.int64), synth("P64.qnoise", (N, 4, 64, 64), -1.7, 1.7))
+    close(x_t.numpy(), g["x_t"], 1e-6)
+    return x_t, zz
+
+
+def test_ddim250_p64(golden):
+    """BASELINE config [4]: the 250-step deterministic loop of the reference, restated (gaussian_diffusion.py:598-680)"""
+    g = golden("g17_ddim250.npz")
+    cfg = model_cfg("P64")
+    sd = fill_state_dict(U.param_spec(cfg))
+    sch = D.Schedule(1000, "linear", "ddim250", True)
+    assert sch.T == 250
+    with torch.no_grad():
+        x_t, zz = _cf_start(sd, cfg, g, sch, 2, 249)
+        trace = []
+        D.sample_loop(sch, lambda xx, tm: U.unet_forward(sd, cfg, xx, tm, z=zz)[0], x_t, ddim=True, trace=trace)
+    for k in (1, 25, 125, 250):
+        close(trace[k - 1].numpy(), g[f"sample_after{k}"], 1e-4)
+
+
+def test_p_sample_loop_t1000_m32(golden):
+    """BASELINE config [0]: 1000 ancestral steps (gaussian_diffusion.py:416-504), per-step noise in closed form"""
+    g = golden("g18_p_sample_t1000.npz")
+    cfg = model_cfg("M32")
+    sd = fill_state_dict(U.param_spec(cfg))
+    sch = D.Schedule(1000, "linear", "", True)
+    N = 2
+    z = synth("M32.z", (N, 512))
+    y = torch.tensor([(3 * i + 1) % 10 for i in range(N)], dtype=torch.int64)
+    x_T = synth("M32.xT", (N, 1, 32, 32), -1.7, 1.7)
+
+    class Noise:
+        def __getitem__(self, k):
+            return synth_noise(f"G18.noise.{k}", (N, 1, 32, 32))
+
+    trace = []
+    with torch.no_grad():
+        D.sample_loop(sch, lambda x, tm: U.unet_forward(sd, cfg, x, tm, y=y, z=z)[0], x_T, ddim=False, noises=Noise(), trace=trace)
+    for k in (1, 10, 100, 500, 900, 1000):
+        close(trace[k - 1].numpy(), g[f"sample_after{k}"], 1e-4)
+
+
+def test_trained_like_weights_p64(golden):
+    """P64 with log-uniform weight magnitudes (closed_form.fill_value_trained): forward, one step and the DDIM-100 loop"""
+    g = golden("g19_trained_like.npz")
+    cfg = model_cfg("P64")
+    sd = fill_state_dict_trained(U.param_spec(cfg))
+    assert [k for k, v in sd.items() if v.dim() >= 2 and float(v.abs().max()) == 0.0] == list(g["zero_keys"])
+    sch = D.Schedule(1000, "linear", "ddim100", True)
+    N = 2
+    x, x0, c, z, _ = model_inputs("P64", cfg, N)
+    with torch.no_grad():
+        e = U.unet_forward(sd, cfg, x, torch.tensor([37.0, 990.0]), z=z)[0]
+        close(e.numpy(), g["eps_z"], 3e-5)
+        x_t, zz = _cf_start(sd, cfg, g, sch, N, 99)
+        model_fn = lambda xx, tm: U.unet_forward(sd, cfg, xx, tm, z=zz)[0]
+        t99 = torch.full((N,), 99, dtype=torch.int64)
+        o = D.ddim_step(sch, model_fn(x_t, sch.model_t(t99)), x_t, t99)
+        close(o["sample"].numpy(), g["step99/sample"], 3e-5)
+        trace = []
+        D.sample_loop(sch, model_fn, x_t, ddim=True, trace=trace)
+    for k in (1, 10, 50, 100):
+        close(trace[k - 1].numpy(), g[f"loop/sample_after{k}"], 1e-4)
+
+
+def test_traversal_p64(golden):
+    """The script's traversal (image_causaldae_test.py:481-531) restated on the oracle: the eight conditioning vectors z (mu[:, 16:32]
+    := the accumulated value, causal layer, fresh draw) for every value, and the whole DDIM-250 decode for the LAST value (one of
+    eight: the CPU suite stays within minutes; the GPU test decodes all eight)."""
+    g = golden("g20_traversal.npz")
+    cfg = model_cfg("P64")
+    sd = fill_state_dict(U.param_spec(cfg))
+    sch = D.Schedule(1000, "linear", "ddim250", True)
+    N = 2
+    x, x0, c, z, _ = model_inputs("P64", cfg, N)
+    A = torch.tensor(U.ADJ["pendulum"], dtype=torch.float32)
+    value, zs = -0.5, []
+    with torch.no_grad():
+        x_t = D.q_sample(sch, x0, torch.full((N,), 249, dtype=torch.int64), synth("P64.qnoise", (N, 4, 64, 64), -1.7, 1.7))
+        close(x_t.numpy(), g["x_t"], 1e-6)
+        for i in range(8):
+            assert value == float(g["values"][i])
+            mu, _ = U.encode(sd, x0, U.n_encoder_layers(sd))
+            mu[:, 16:32] = value
+            z_post = U.nonlinearity_add_back_noise(sd, mu, U.causal_masking(mu, A, 4), 4)
+            zz = U.reparameterize(z_post, torch.full_like(mu, 0.001), torch.from_numpy(g["eps_draws"][i]))
+            close(zz.numpy(), g[f"z{i}"], 1e-5)
+            zs.append(zz)
+            value += 0.15
+        final = D.sample_loop(sch, lambda xx, tm: U.unet_forward(sd, cfg, xx, tm, z=zs[7])[0], x_t, ddim=True)
+    close(final.numpy(), g["sample7"], 1e-4)

@@ -1,0 +1,43 @@
+"""Dev tool: which Python call sites issue ATen kernels / hipMemcpy calls inside ONE eager P64 DDIM step (batch 128) — the step the public
+loop captures into its graph.  torch.profiler CPU op tree: every outermost aten:: op that launches a kernel or a memcpy, folded by the
+innermost stack frame inside this repo."""
+import os, sys, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from torch.profiler import profile, ProfilerActivity
+import bench
+from improved_diffusion import script_util as su
+
+dev = torch.device("cuda:0")
+N = int(os.environ.get("N", "128"))
+cfg = {**su.model_and_diffusion_defaults(), "image_size": 64, "in_channels": 4, "n_vars": 4, "rep_cond": True, "causal_modeling": True, "timestep_respacing": "ddim100"}
+model, diff = su.create_model_and_diffusion(**cfg)
+bench.randomize(model, 1234)
+model.to(dev).eval()
+x = torch.randn(N, 4, 64, 64, device=dev)
+z = torch.randn(N, 512, device=dev)
+tab = diff._step_table(dev, N)
+with torch.no_grad():
+    for k in range(3):
+        x = diff.ddim_sample(model, x, tab[k], model_kwargs=dict(z=z))["sample"]
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
+        x = diff.ddim_sample(model, x, tab[3], model_kwargs=dict(z=z))["sample"]
+        torch.cuda.synchronize()
+cnt = collections.Counter()
+for e in prof.events():
+    if not e.name.startswith("aten::") and "emcpy" not in e.name and "emset" not in e.name:
+        continue
+    p, chain = e.cpu_parent, []
+    while p is not None:
+        chain.append(p.name)
+        p = p.cpu_parent
+    if any(n.startswith("aten::") for n in chain):
+        continue                                        # outermost aten op only
+    kern = [k.name[:60] for k in (e.kernels or [])]
+    if not kern and "emcpy" not in e.name and "emset" not in e.name:
+        continue                                        # views / metadata ops launch nothing
+    st = [s for s in (e.stack or []) if "causaldiffae_amd" in s or "bench" in s]
+    cnt[(e.name, ",".join(kern)[:90], st[0][-70:] if st else "", str(e.input_shapes)[:50])] += 1
+for k, c in cnt.most_common(80):
+    print(c, *k, sep=" | ")

@@ -21,7 +21,7 @@ for (ci, co, r, cnt) in [(128, 128, 64, 7), (256, 128, 64, 2), (384, 128, 64, 1)
     dx = torch.empty_like(x); dw = torch.empty_like(w); db = torch.empty(co, device=DEV)
     sn, sy, sx, sc = r * r * ci, r * ci, ci, 1
     fl = 2.0 * B * r * r * co * 9 * ci
-    t_f = timeit(lambda: check(lib.cdae_conv3x3_fwd(ptr(x), sn, sy, sx, sc, ptr(w), None, None, ptr(y), co, 0, B, r, r, ci, co, 1, 0, ptr(ws), SPLITK_BYTES, stream())))
+    t_f = timeit(lambda: check(lib.cdae_conv3x3_fwd(ptr(x), sn, sy, sx, sc, ptr(w), None, None, None, ptr(y), co, 0, B, r, r, ci, co, 1, 0, ptr(ws), SPLITK_BYTES, stream())))
     t_d = timeit(lambda: check(lib.cdae_conv3x3_dgrad(ptr(dy), co, ptr(w), ptr(dx), ci, B, r, r, ci, co, 1, 0, 0, ptr(ws), SPLITK_BYTES, stream())))
     t_w = timeit(lambda: check(lib.cdae_conv3x3_wgrad(ptr(x), sn, sy, sx, sc, ptr(dy), co, ptr(dw), None, B, r, r, ci, co, 1, 0, 0, ptr(ws), SPLITK_BYTES, stream())))
     print(f"Cin{ci:5d} Cout{co:4d} res{r:3d} x{cnt:2d}: fwd {t_f:7.3f} ms {fl/t_f/1e9:6.1f} TF | dgrad {t_d:7.3f} ms {fl/t_d/1e9:6.1f} TF | wgrad {t_w:7.3f} ms {fl/t_w/1e9:6.1f} TF")

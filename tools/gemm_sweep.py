@@ -32,7 +32,7 @@ for kind, M, N, K, cnt in SHAPES:
     ws, wsb = ops._sk(dev)
     st = stream()
     if kind == "fwd":
-        f = lambda: check(lib.cdae_linear_fwd(ptr(x), K, ptr(w), K, None, None, ptr(y), N, None, None, M, N, K, 1.0, 0, ws, wsb, st))
+        f = lambda: check(lib.cdae_linear_fwd(ptr(x), K, ptr(w), K, None, None, None, ptr(y), N, None, None, M, N, K, 1.0, 0, ws, wsb, st))
     elif kind == "dgrad":
         f = lambda: check(lib.cdae_linear_dgrad(ptr(dy), N, ptr(w), K, ptr(dx), K, M, N, K, 0, ws, wsb, st))
     else:

@@ -27,7 +27,7 @@ from improved_diffusion import respace as rrespace                 # noqa: E402
 from improved_diffusion import script_util as rsu                  # noqa: E402
 from improved_diffusion import unet as runet                       # noqa: E402
 
-from oracle.closed_form import fill_value, synth                   # noqa: E402
+from oracle.closed_form import fill_value, fill_value_trained, synth, synth_noise   # noqa: E402
 from oracle.unet_ref import ADJ, encoder_dims                      # noqa: E402
 
 th.set_grad_enabled(True)
@@ -797,7 +797,166 @@ def g16_dropout(out_dir):
         json.dump(meta, f, indent=1)
 
 
-ALL = dict(G16=g16_dropout, G1=g1_schedules, G2=g2_temb, G3=g3_blocks, G4=g4_encoder, G5=g5_rep_loss, G6=g6_unet, G7=g7_train, G8=g8_ddim, G9=g9_vlb, G10=g10_flow, G11=g11_variants, G12=g12_full_train, G13=g13_guidance, G14=g14_p_sample_loop, G15=g15_m32_b256)
+
+# --------------------------------------------------------------------------- G17..G20: the long loops and a trained-like weight distribution
+def _counterfactual_start(model, diff, base, N, t_last, A, tag="P64"):
+    """encode -> causal layer -> do(z_post[:, :128] := 0.2) -> reparameterize(var = 0.001) -> q_sample(t_last): the pendulum branch of
+    image_causaldae_test.py:535-594; returns (x_t, z, eps draw)"""
+    x, x0, c, z, _ = model_inputs(tag, base, N)
+    mu, var = model.rep_emb.encode(x0)
+    var = th.ones_like(mu) * 0.001
+    z_pre = model.causal_mask.causal_masking(mu, A)
+    z_post = model.causal_mask.nonlinearity_add_back_noise(mu, z_pre)
+    z_post[:, :128] = 0.2
+    th.manual_seed(5)
+    zz = rnn.reparameterize(z_post, var)
+    th.manual_seed(5)
+    eps = th.randn(N, 512)
+    noise = synth(tag + ".qnoise", (N, base["in_channels"], base["image_size"], base["image_size"]), -1.7, 1.7)
+    x_t = diff.q_sample(x0, th.full((N,), t_last, dtype=th.int64), noise=noise)
+    return x_t, zz, eps
+
+
+def g17_ddim250(out_dir):
+    """BASELINE config [4]: P64, "ddim250" (respace.py:30-37), the whole 250-step deterministic loop (gaussian_diffusion.py:598-680)."""
+    out = {}
+    N = 2
+    model, diff, base = make("P64", respacing="ddim250")
+    model.eval()
+    assert diff.num_timesteps == 250
+    A = th.tensor(ADJ["pendulum"], dtype=th.float32)
+    with th.no_grad():
+        x_t, zz, eps = _counterfactual_start(model, diff, base, N, 249, A)
+        out["x_t"], out["z"], out["eps_draw"] = x_t.numpy(), zz.numpy(), eps.numpy()
+        k = 0
+        for o in diff.ddim_sample_loop_progressive(model, (N, 4, 64, 64), noise=x_t, model_kwargs=dict(z=zz)):
+            k += 1
+            if k in (1, 25, 125, 250):
+                out[f"sample_after{k}"] = o["sample"].numpy()
+        assert k == 250
+    np.savez_compressed(os.path.join(out_dir, "g17_ddim250.npz"), **out)
+
+
+class _ClosedFormRandnLike:
+    """th.randn_like -> a closed-form unit-variance draw by call count (oracle.closed_form.synth_noise), so that a 1000-step ancestral
+    loop (one randn_like per step, gaussian_diffusion.py:402) is reproducible without storing 1000 noise tensors."""
+
+    def __init__(self, prefix):
+        self.prefix, self.k = prefix, 0
+
+    def __enter__(self):
+        self.orig = th.randn_like
+
+        def fake(x, **kw):
+            v = synth_noise(f"{self.prefix}.{self.k}", tuple(x.shape))
+            self.k += 1
+            return v
+
+        th.randn_like = fake
+        return self
+
+    def __exit__(self, *exc):
+        th.randn_like = self.orig
+        return False
+
+
+def g18_p_sample_t1000(out_dir):
+    """BASELINE config [0]: M32, T = 1000, ancestral sampling end to end (gaussian_diffusion.py:416-504), batch 2."""
+    out = {}
+    N = 2
+    model, diff, base = make("M32", respacing="")
+    model.eval()
+    assert diff.num_timesteps == 1000
+    x, x0, c, z, y = model_inputs("M32", base, N)
+    with th.no_grad():
+        x_T = synth("M32.xT", (N, 1, 32, 32), -1.7, 1.7)
+        with _ClosedFormRandnLike("G18.noise") as rl:
+            k = 0
+            for o in diff.p_sample_loop_progressive(model, (N, 1, 32, 32), noise=x_T, model_kwargs=dict(z=z, y=y)):
+                k += 1
+                if k in (1, 10, 100, 500, 900, 1000):
+                    out[f"sample_after{k}"] = o["sample"].numpy()
+                    out[f"pred_xstart_after{k}"] = o["pred_xstart"].numpy()
+            assert k == 1000 and rl.k == 1000
+    np.savez_compressed(os.path.join(out_dir, "g18_p_sample_t1000.npz"), **out)
+
+
+def load_trained_like(module):
+    sd = module.state_dict()
+    for k in sd:
+        sd[k] = fill_value_trained(k, sd[k].shape)
+    module.load_state_dict(sd)
+    return module
+
+
+def g19_trained_like(out_dir):
+    """P64 with a TRAINED-LIKE weight distribution (oracle.closed_form.fill_value_trained: log-uniform magnitudes over four decades,
+    a quarter of the zero-initialised layers left zero): one forward, the encoder path, and the DDIM-100 loop."""
+    out = {}
+    N = 2
+    model, diff, base = make("P64", respacing="ddim100")
+    load_trained_like(model)
+    model.eval()
+    A = th.tensor(ADJ["pendulum"], dtype=th.float32)
+    x, x0, c, z, _ = model_inputs("P64", base, N)
+    zero = [k for k, v in model.state_dict().items() if v.dim() >= 2 and float(v.abs().max()) == 0.0]
+    out["zero_keys"] = np.array(zero)
+    with th.no_grad():
+        t = th.tensor([37.0, 990.0])
+        e, *_ = model(x, t, z=z)
+        out["eps_z"] = e.numpy()
+        x_t, zz, eps = _counterfactual_start(model, diff, base, N, 99, A)
+        out["x_t"], out["z"], out["eps_draw"] = x_t.numpy(), zz.numpy(), eps.numpy()
+        o = diff.ddim_sample(model, x_t, th.full((N,), 99, dtype=th.int64), model_kwargs=dict(z=zz))
+        out["step99/sample"], out["step99/pred_xstart"] = o["sample"].numpy(), o["pred_xstart"].numpy()
+        k = 0
+        for o in diff.ddim_sample_loop_progressive(model, (N, 4, 64, 64), noise=x_t, model_kwargs=dict(z=zz)):
+            k += 1
+            if k in (1, 10, 50, 100):
+                out[f"loop/sample_after{k}"] = o["sample"].numpy()
+    np.savez_compressed(os.path.join(out_dir, "g19_trained_like.npz"), **out)
+
+
+def g20_traversal(out_dir):
+    """The latent traversal of the evaluation script (image_causaldae_test.py:481-531, pendulum branch, `traversal == True`), restated
+    call for call on the reference's model and diffusion: x_t = q_sample(batch, t = 249, noise) ONCE; then for eight values
+    -0.5, -0.35, ... (value += 0.15 in a Python float): mu[:, 16:32] = value (the script's hard-coded columns, before the causal layer),
+    z = reparameterize(causal layer(mu), 0.001) with a FRESH draw per value, ddim_sample_loop(noise = x_t, z).  "ddim250" so that
+    t = 249 is the last spaced step, as in the script's launch configuration."""
+    out = {}
+    N = 2
+    model, diff, base = make("P64", respacing="ddim250")
+    model.eval()
+    A = th.tensor(ADJ["pendulum"], dtype=th.float32)
+    x, x0, c, z, _ = model_inputs("P64", base, N)
+    batch = x0
+    with th.no_grad():
+        noise = synth("P64.qnoise", (N, 4, 64, 64), -1.7, 1.7)          # the script: th.randn_like(batch)
+        t = th.ones((batch.shape[0]), dtype=th.int64) * 249
+        x_t = diff.q_sample(batch, t, noise=noise)
+        out["x_t"] = x_t.numpy()
+        value = -0.5
+        values, draws = [], []
+        for i in range(8):
+            mu, var = model.rep_emb.encode(batch)
+            var = th.ones(mu.shape) * 0.001
+            mu[:, 16:32] = th.ones((N, 16)) * value
+            z_pre = model.causal_mask.causal_masking(mu, A)
+            z_post = model.causal_mask.nonlinearity_add_back_noise(mu, z_pre)
+            th.manual_seed(100 + i)
+            zz = rnn.reparameterize(z_post, var)
+            th.manual_seed(100 + i)
+            draws.append(th.randn(N, 512).numpy())
+            sample = diff.ddim_sample_loop(model, (N, 4, 64, 64), noise=x_t, clip_denoised=True, model_kwargs=dict(z=zz), w=None)
+            out[f"z{i}"], out[f"sample{i}"] = zz.numpy(), sample.numpy()
+            values.append(value)
+            value += 0.15
+        out["values"] = np.array(values, dtype=np.float64)
+        out["eps_draws"] = np.stack(draws)
+    np.savez_compressed(os.path.join(out_dir, "g20_traversal.npz"), **out)
+
+
+ALL = dict(G16=g16_dropout, G1=g1_schedules, G2=g2_temb, G3=g3_blocks, G4=g4_encoder, G5=g5_rep_loss, G6=g6_unet, G7=g7_train, G8=g8_ddim, G9=g9_vlb, G10=g10_flow, G11=g11_variants, G12=g12_full_train, G13=g13_guidance, G14=g14_p_sample_loop, G15=g15_m32_b256, G17=g17_ddim250, G18=g18_p_sample_t1000, G19=g19_trained_like, G20=g20_traversal)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
