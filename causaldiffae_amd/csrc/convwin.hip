@@ -76,9 +76,14 @@ __device__ __forceinline__ void cw_dma(const void* sbase, int soff, unsigned vof
 // position (t / 2 + ph_y, t % 2 + ph_x) of the same 3x3 neighbourhood; weights [rows][4][K]; result scattered to (2y + ph_y, 2x + ph_x)).
 // NPL = 2: hi / lo plane pairs, three MFMAs per product (the fp32-parity modes).  NPL = 1: ONE plane per operand and one MFMA per product —
 // the reduced-precision torso (`mixed16`: f16 forward, bf16 dgrad); the lo halves of the LDS image stay unused.
-template <bool BF, int NT, int NPL = 2>
+// NJ: 16-column MFMA tiles per wave = the n-tile is 32 NJ columns wide (two waves side by side).  4: 256 x 128 tiles.  3: 256 x 96 — for
+// Cout = 384 at the 16 x 16 level of a batch-128 step, where 128 m-tiles x 3 n-tiles of 128 are 384 blocks for 512 block slots (a quarter of
+// the CUs run one block instead of two) and 128 x 4 n-tiles of 96 are exactly 512.  The weight stage keeps its 128-row geometry (rows beyond
+// the n-tile are loaded and never read).
+template <bool BF, int NT, int NPL = 2, int NJ = 4>
 __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, const int ntiles) {
     typedef const unsigned short* hp;
+    constexpr int BN = 32 * NJ, WNC = 16 * NJ;                         // n-tile width, columns per wave
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
     const bool selb = kg >= 2;                                       // this lane feeds K 16..31 of every MFMA: the step's SECOND unit
     const int wm = wave >> 1, wn = wave & 1;
 
-    const int nmt = (p.M + CW_BM - 1) / CW_BM, nnt = (p.N + CW_BN - 1) / CW_BN;
+    const int nmt = (p.M + CW_BM - 1) / CW_BM, nnt = (p.N + BN - 1) / BN;
     const hp a_hi = reinterpret_cast<hp>(p.A), a_lo = p.A_lo;
     const bool packed = p.Bk_hi != nullptr;                            // weights [K / 16][9][rows][16]: a (group, tap) unit is one contiguous run
     const hp b_hi = packed ? p.Bk_hi : reinterpret_cast<hp>(p.B), b_lo = packed ? p.Bk_lo : p.B_lo;
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
         // derived from them (K-loop bounds, the weight / window DMA offsets) stays in VGPRs and the K loop carries v_mul_lo_u32 (quarter
         // rate) and v_readfirstlane where s_mul_i32 does the job beside the MFMAs
         mt = __builtin_amdgcn_readfirstlane(mt); nt = __builtin_amdgcn_readfirstlane(nt); ks = __builtin_amdgcn_readfirstlane(ks);
-        m0 = mt * CW_BM; n0 = nt * CW_BN;
+        m0 = mt * CW_BM; n0 = nt * BN;
         const int c_begin = ks * c_per, c_end = max(min(nchunk, c_begin + c_per), c_begin);       // the last splits of an uneven division are empty
         g_begin = 2 * c_begin; g_end = 2 * c_end;                     // 16-channel groups of this K split
         nsteps = ((g_end - g_begin) * NT) >> 1;                        // K-steps of two (group, tap) units each (0: the slab is zeros)
@@ -186,13 +191,13 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
     };
 
     unsigned a_lane = (wm * 128 + lr) * 32 + pc * 16;            // byte offset of (tile 0 row, piece) in a window plane (re-pinned in front of every K loop)
-    unsigned b_lane = CW_B_BASE + (selb ? CW_B_KH : 0) + (wn * 64 + lr) * 32 + pc * 16;
+    unsigned b_lane = CW_B_BASE + (selb ? CW_B_KH : 0) + (wn * WNC + lr) * 32 + pc * 16;
 
-    f32x4 acc[8][4];
+    f32x4 acc[8][NJ];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto mma = [&](const u32x4& x, const u32x4& y, const f32x4& c) -> f32x4 {
         if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, x), __builtin_bit_cast(bf8, y), c, 0, 0, 0);
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
         int wtap_c; unsigned a_c;
         geom(ga, ta, wtap_c, a_c);
         unsigned b_c = b_lane;                 // this step's weight stage
-        u32x4 bh[4], ah[2], bl_[NPL == 2 ? 4 : 1], al_[NPL == 2 ? 2 : 1];      // (one plane: the lo names alias the hi registers)
+        u32x4 bh[NJ], ah[2], bl_[NPL == 2 ? NJ : 1], al_[NPL == 2 ? 2 : 1];      // (one plane: the lo names alias the hi registers)
 #define al(C) (NPL == 2 ? al_[(NPL == 2) * (C)] : ah[C])
 #define bl(J) (NPL == 2 ? bl_[(NPL == 2) * (J)] : bh[J])
         // fragment address of padding taps -> out of range -> zeros
@@ -248,7 +253,8 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
 #define CW_WAIT(...) asm volatile(__VA_ARGS__)
         if (nsteps > 0) {
             CW_READ_A(0, 0, wtap_c, a_c);
-            CW_READ_B(0, b_c); CW_READ_B(1, b_c); CW_READ_B(2, b_c); CW_READ_B(3, b_c);
+            CW_READ_B(0, b_c); CW_READ_B(1, b_c); CW_READ_B(2, b_c);
+            if constexpr (NJ == 4) CW_READ_B(3, b_c);
         }
         // Per-lane loop state that the register allocator spills around the epilogue must be back in registers HERE: a scratch reload is a
         // vector-memory load, and when its first use sits inside the K loop hipcc's waitcnt pass puts `s_waitcnt vmcnt(0)` in front of that
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
             // the two waves of a SIMD belong to different blocks: alternating the issue priority by step parity lets one of them run
             // its MFMA burst unbroken while the other is at its mid-step wait (measured +2..3 %; CDAE_PS_DBG & 64 turns it off)
             if (!(dbg_ & 64)) { if (s & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-            // outstanding LDS reads here, oldest first: A(0) [2], B(0) [2], B(1) [2], B(2) [2], B(3) [2]
+            // outstanding LDS reads here, oldest first: A(0) [2], B(0) [2], B(1) [2], B(2) [2], B(3) [2]      (NJ = 4, two planes)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int cur = i & 1;
@@ -305,10 +311,10 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                 // tile 0 needs A(0) and B(0) of the ten reads in flight; every other tile's A pair is the only thing outstanding
                 // (one plane: never list a register twice — the aliased lo names would make hipcc copy a fragment whose read is still in flight)
                 if constexpr (NPL == 2) {
-                    if (i == 0) CW_WAIT("s_waitcnt lgkmcnt(6)" : "+v"(ah[0]), "+v"(al(0)), "+v"(bh[0]), "+v"(bl(0)));
+                    if (i == 0) CW_WAIT("s_waitcnt lgkmcnt(%4)" : "+v"(ah[0]), "+v"(al(0)), "+v"(bh[0]), "+v"(bl(0)) : "n"(2 * (NJ - 1)));
                     else CW_WAIT("s_waitcnt lgkmcnt(0)" : "+v"(ah[cur]), "+v"(al(cur)));
                 } else {
-                    if (i == 0) CW_WAIT("s_waitcnt lgkmcnt(3)" : "+v"(ah[0]), "+v"(bh[0]));
+                    if (i == 0) CW_WAIT("s_waitcnt lgkmcnt(%2)" : "+v"(ah[0]), "+v"(bh[0]) : "n"(NJ - 1));
                     else CW_WAIT("s_waitcnt lgkmcnt(0)" : "+v"(ah[cur]));
                 }
                 if constexpr (NPL == 2) {
@@ -328,10 +334,10 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                 else { CW_READ_A(0, 0, wtap_n, a_n); CW_READ_B(0, b_n); }      // next step: its first tile and the first dead weight fragments
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 1; j < 4; ++j) {
-                    // tile 0: B(j) is the oldest of the reads in flight [B(j) .. B(3), A(1)]
-                    if constexpr (NPL == 2) { if (i == 0) CW_WAIT("s_waitcnt lgkmcnt(%2)" : "+v"(bh[j]), "+v"(bl(j)) : "n"(8 - 2 * j)); }
-                    else { if (i == 0) CW_WAIT("s_waitcnt lgkmcnt(%1)" : "+v"(bh[j]) : "n"(4 - j)); }
+                for (int j = 1; j < NJ; ++j) {
+                    // tile 0: B(j) is the oldest of the reads in flight [B(j) .. B(NJ - 1), A(1)]
+                    if constexpr (NPL == 2) { if (i == 0) CW_WAIT("s_waitcnt lgkmcnt(%2)" : "+v"(bh[j]), "+v"(bl(j)) : "n"(2 * (NJ - j))); }
+                    else { if (i == 0) CW_WAIT("s_waitcnt lgkmcnt(%1)" : "+v"(bh[j]) : "n"(NJ - j)); }
                     if constexpr (NPL == 2) {
                         acc[i][j] = mma(al(cur), bh[j], acc[i][j]);
                         acc[i][j] = mma(ah[cur], bl(j), acc[i][j]);
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                     acc[i][j] = mma(ah[cur], bh[j], acc[i][j]);
                     if (i == 7) {
                         __builtin_amdgcn_sched_barrier(0);
-                        if (j == 1) { CW_READ_B(1, b_n); } else if (j == 2) { CW_READ_B(2, b_n); } else { CW_READ_B(3, b_n); }
+                        if (j == 1) { CW_READ_B(1, b_n); } else if (j == 2) { CW_READ_B(2, b_n); } else { if constexpr (NJ == 4) CW_READ_B(3, b_n); }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
 
         // accumulator tile (i, j): this lane holds rows 4 kg + r (r = 0..3) of column 16 j + lr; the four column tiles of a row are
         // stored back to back so that the 256 bytes a wave owns of each output row reach L2 together
-        const bool interior = em0 + CW_BM <= p.M && en0 + CW_BN <= p.N;
+        const bool interior = em0 + CW_BM <= p.M && en0 + BN <= p.N;
         // lane coordinates of the epilogue through an opaque asm (as in setup): the row / column offsets and pointers derived from them are
         // recomputed here, once per tile, instead of being hoisted out of the persistent loop and kept live across the K loop
         int lr_ = lr, kg_ = kg;
@@ -378,15 +384,17 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
             // one row pointer per (tile, r), the four column tiles at immediate offsets
             const bool up2 = p.out_mode == OUT_UP2;       // sub-pixel phase: GEMM row (n, y, x) -> output pixel (n, 2y + ph_y, 2x + ph_x)
             const int row0 = em0 + wm * 128 + 4 * kg_;
-            const long lane_off = (up2 ? 0 : (long)row0 * p.ldc) + en0 + wn * 64 + lr_;
+            const long lane_off = (up2 ? 0 : (long)row0 * p.ldc) + en0 + wn * WNC + lr_;
             float* __restrict__ cbase = p.C + lane_off;
             const float* __restrict__ rbase = p.res ? p.res + lane_off : nullptr;
-            float bv[4];
+            float bv[NJ];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bv[j] = p.bias ? p.bias[en0 + wn * 64 + lr_ + 16 * j] : 0.f;
+            for (int j = 0; j < NJ; ++j) bv[j] = p.bias ? p.bias[en0 + wn * WNC + lr_ + 16 * j] : 0.f;
 #pragma unroll
             for (int i2 = 0; i2 < 4; ++i2) {
-                float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
+                float gs[NJ], gq[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) { gs[j] = 0.f; gq[j] = 0.f; }
 #pragma unroll
                 for (int ii = 0; ii < 2; ++ii) {
                     long ro[4];
@@ -399,38 +407,41 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                     }
                     // the residual values of the row tile are requested together: row by row, each pair of loads waited for vmcnt(0) — 64
                     // exposed round trips per tile (and a drain of the next tile's operand DMAs each time)
-                    float rv[4][4];
+                    float rv[4][NJ];
                     if (rbase) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) rv[r][j] = rbase[ro[r] + 16 * j];
+                            for (int j = 0; j < NJ; ++j) rv[r][j] = rbase[ro[r] + 16 * j];
                     } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) rv[r][j] = 0.f;
+                            for (int j = 0; j < NJ; ++j) rv[r][j] = 0.f;
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float v[4];
+                        float v[NJ];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = (acc[2 * i2 + ii][j][r] * alpha_ + bv[j]) + rv[r][j];
+                        for (int j = 0; j < NJ; ++j) v[j] = (acc[2 * i2 + ii][j][r] * alpha_ + bv[j]) + rv[r][j];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) { cbase[ro[r] + 16 * j] = v[j]; gs[j] += v[j]; gq[j] += v[j] * v[j]; }      // (nontemporal stores: measured +-0)
+                        for (int j = 0; j < NJ; ++j) { cbase[ro[r] + 16 * j] = v[j]; gs[j] += v[j]; gq[j] += v[j] * v[j]; }      // (nontemporal stores: measured +-0)
                         // f16 plane overflow surfaces as NaN / inf.  (The branch per row also keeps hipcc's register allocation in check: with a
                         // branch-free accumulated check the epilogue becomes one block and 230 VGPRs of accumulators are spilled.)
-                        if (!__builtin_isfinite(v[0] + v[1] + v[2] + v[3]) && p.range_flag) *p.range_flag = 1;
+                        float vs_ = v[0];
+#pragma unroll
+                        for (int j = 1; j < NJ; ++j) vs_ += v[j];
+                        if (!__builtin_isfinite(vs_) && p.range_flag) *p.range_flag = 1;
                     }
                 }
                 if (p.gn_part) {                                         // per (32-row chunk, column) partial sums of the final values
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < NJ; ++j) {
                         float s_ = gs[j], q_ = gq[j];
                         s_ += __shfl_xor(s_, 16); q_ += __shfl_xor(q_, 16);
                         s_ += __shfl_xor(s_, 32); q_ += __shfl_xor(q_, 32);
                         if (kg_ == 0) {
-                            float* o = p.gn_part + (long)eph * p.phase_gn + ((long)((em0 + wm * 128 + 32 * i2) >> 5) * p.N + en0 + wn * 64 + lr_ + 16 * j) * 2;
+                            float* o = p.gn_part + (long)eph * p.phase_gn + ((long)((em0 + wm * 128 + 32 * i2) >> 5) * p.N + en0 + wn * WNC + lr_ + 16 * j) * 2;
                             o[0] = s_; o[1] = q_;
                         }
                     }
@@ -439,14 +450,14 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
             }
         } else if (interior && p.ksplit > 1) {
             // split-K partial tile, interior: plain stores into slab eks (the general path spends ~8 instructions per element on tests)
-            float* __restrict__ cb = p.splitk_ws + (long)eks * (long)p.M * p.N + (long)(em0 + wm * 128 + 4 * kg_) * p.N + en0 + wn * 64 + lr_;
+            float* __restrict__ cb = p.splitk_ws + (long)eks * (long)p.M * p.N + (long)(em0 + wm * 128 + 4 * kg_) * p.N + en0 + wn * WNC + lr_;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float* __restrict__ o = cb + (long)(16 * i + r) * p.N;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[16 * j] = acc[i][j][r];
+                    for (int j = 0; j < NJ; ++j) o[16 * j] = acc[i][j][r];
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -455,20 +466,22 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
             const float* __restrict__ Rg = nullptr;
             if (p.ksplit > 1) Cg = p.splitk_ws + (long)eks * (long)p.M * p.N;
             else { Cg = p.C; Rg = p.res; }
-            const int col0 = en0 + wn * 64 + lr_;
-            float bv[4];
+            const int col0 = en0 + wn * WNC + lr_;
+            float bv[NJ];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bv[j] = (col0 + 16 * j < p.N && p.ksplit == 1 && p.bias) ? p.bias[col0 + 16 * j] : 0.f;
+            for (int j = 0; j < NJ; ++j) bv[j] = (col0 + 16 * j < p.N && p.ksplit == 1 && p.bias) ? p.bias[col0 + 16 * j] : 0.f;
 #pragma unroll
             for (int i2 = 0; i2 < 4; ++i2) {
-                float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
+                float gs[NJ], gq[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) { gs[j] = 0.f; gq[j] = 0.f; }
 #pragma unroll
                 for (int ii = 0; ii < 2; ++ii) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = em0 + wm * 128 + 32 * i2 + 16 * ii + 4 * kg_ + r;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
+                        for (int j = 0; j < NJ; ++j) {
                             const int col = col0 + 16 * j;
                             if (row < p.M && col < p.N) {
                                 const float a = acc[2 * i2 + ii][j][r];
@@ -493,7 +506,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                 }
                 if (p.gn_part && p.ksplit == 1) {                        // per (32-row chunk, column) partial sums of the final values
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < NJ; ++j) {
                         float s_ = gs[j], q_ = gq[j];
                         s_ += __shfl_xor(s_, 16); q_ += __shfl_xor(q_, 16);
                         s_ += __shfl_xor(s_, 32); q_ += __shfl_xor(q_, 32);
@@ -512,7 +525,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (stamps && blockIdx.x < 64 && lane == 0 && p.splitk_ws && p.ksplit == 1) {
         unsigned long long* o = reinterpret_cast<unsigned long long*>(p.splitk_ws) + (blockIdx.x * 4 + wave) * 8;
@@ -520,18 +533,18 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
     }
 }
 
-template <bool BF, int NT, int NPL = 2>
+template <bool BF, int NT, int NPL = 2, int NJ = 4>
 int launch_convwin(const GemmParams& p, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convwin_kernel<BF, NT, NPL>), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convwin_kernel<BF, NT, NPL, NJ>), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS) != hipSuccess)
             return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
         attr_done = true;
     }
-    const long ntiles = (long)((p.M + CW_BM - 1) / CW_BM) * ((p.N + CW_BN - 1) / CW_BN) * p.ksplit * (p.nphase > 1 ? p.nphase : 1);
+    const long ntiles = (long)((p.M + CW_BM - 1) / CW_BM) * ((p.N + 32 * NJ - 1) / (32 * NJ)) * p.ksplit * (p.nphase > 1 ? p.nphase : 1);
     static const int cfg_persist = CDAE_DEV_INT("CDAE_CONVWIN_GRID", 512);      // persistent blocks: two per CU
     dim3 grid((unsigned)(ntiles < cfg_persist ? ntiles : cfg_persist));
-    hipLaunchKernelGGL((convwin_kernel<BF, NT, NPL>), grid, dim3(256), CW_LDS, st, p, (int)ntiles);
+    hipLaunchKernelGGL((convwin_kernel<BF, NT, NPL, NJ>), grid, dim3(256), CW_LDS, st, p, (int)ntiles);
     return hipGetLastError() == hipSuccess ? 0 : cdae_fail("convwin_kernel launch failed");
 }
 
@@ -583,5 +596,14 @@ int cdae_convwin_launch(const GemmParams& p, void* stream) {
     if (p.ps_taps == 4) return launch_convwin<false, 4>(p, st);
     if (p.prec == 3) return launch_convwin<false, 9, 1>(p, st);          // mixed16: one f16 plane
     if (p.prec == 4) return launch_convwin<true, 9, 1>(p, st);           // mixed16, gradient operand: one bf16 plane
-    return p.prec == 2 ? launch_convwin<true, 9>(p, st) : launch_convwin<false, 9>(p, st);
+    if (p.prec == 2) return launch_convwin<true, 9>(p, st);
+    // 96-column tiles where they fill the block slots (two per CU) better than 128-column ones: Cout = 384 at 16 x 16 and batch 128
+    // (384 -> 512 blocks); never with split-K (the slabs are laid out for any tile width, but the dispatcher sized the split for 128)
+    const int nj3 = cdae_tune(TUNE_CONVWIN_NJ3);                          // 0 auto, 1 wherever it applies (parity tests), -1 never
+    if (nj3 >= 0 && p.ksplit == 1 && p.N % 96 == 0) {
+        const long mt = (p.M + CW_BM - 1) / CW_BM, t4 = mt * ((p.N + 127) / 128), t3 = mt * (p.N / 96);
+        auto fill = [](long t) { return (double)t / (double)(((t + 511) / 512) * 512); };
+        if (nj3 > 0 || fill(t3) > fill(t4) + 0.1) return launch_convwin<false, 9, 2, 3>(p, st);
+    }
+    return launch_convwin<false, 9>(p, st);
 }

@@ -22,7 +22,7 @@
 #ifndef SG_NT
 #define SG_NT 0
 #endif
-// SG_ABL (dev ablations, timing only): 1 no output stores, 2 no plane stores, 4 no MFMAs, 8 no normalisation arithmetic
+// SG_ABL (dev ablations, timing only): 1 no output stores, 2 no plane stores, 4 no MFMAs, 8 no normalisation arithmetic, 16 no weight DMAs after step 0
 #ifndef SG_ABL
 #define SG_ABL 0
 #endif
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
             }
         }
         __syncthreads();                                               // stage st complete; nobody reads stage st ^ 1 any more
-        if (more1) issue_b(st ^ 1, k + SG_BK);
+        if (more1 && !(SG_ABL & 16)) issue_b(st ^ 1, k + SG_BK);        // (dev ablation 16: the weight tile of step 0 serves every step — no weight traffic)
         } else if (kt == -1) issue_b(0, 0);
         // (distance 3: at the top of step 1 the loads of step 2 AND 3 are younger than its weights; the lead-in issues x 0, 1, 2 then)
         // ONE load statement per register set for lead-in and steady state alike: a second definition would meet this one in a phi node,

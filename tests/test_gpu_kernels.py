@@ -637,6 +637,45 @@ def test_window_conv_random_shapes(seed, expect_kernels):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1])
+def test_window_conv_96_column_tiles(seed, expect_kernels):
+    """convwin_kernel<f16, 9, pairs, NJ = 3>: 256 x 96 tiles (the dispatcher picks them for Cout = 384 at 16 x 16 and batch 128, where
+    they fill the 512 block slots and 128-column tiles fill 384).  Forced here (cdae_tune_set CONVWIN_NJ3 = 1) onto small cases with
+    Cout in {96, 192, 288, 384}: against F.conv2d in fp64, bit-identical to the 128-column instantiation (same K order per output
+    element), with residual, partial row tiles, and the epilogue's GroupNorm partial sums equal to those of the 128-column kernel."""
+    import random
+    from causaldiffae_amd import ops
+    from causaldiffae_amd._lib import tune_scope, range_check
+    rng = random.Random(500 + seed)
+    g = torch.Generator(device="cuda:0").manual_seed(91 + seed)
+    for case in range(6):
+        S = rng.choice([8, 16, 32])
+        N = rng.randint(1, 6 if S >= 32 else 24)
+        ci, co = 32 * rng.randint(1, 8), 96 * rng.randint(1, 4)
+        res = rng.random() < 0.5
+        stats = case % 2 == 0 and (S * S) % 32 == 0
+        x = ops.to_nhwc(torch.randn(N, ci, S, S, device="cuda:0", generator=g))
+        w = (torch.randn(co, ci, 3, 3, device="cuda:0", generator=g) / (9 * ci) ** 0.5).contiguous(memory_format=torch.channels_last)
+        b = torch.randn(co, device="cuda:0", generator=g)
+        r = ops.to_nhwc(torch.randn(N, co, S, S, device="cuda:0", generator=g)) if res else None
+        xs = _split_nhwc(x)
+        with torch.no_grad(), tune_scope(convwin_min_tiles=1, convwin_splitk=0):
+            with tune_scope(convwin_nj3=1), expect_kernels(convwin=1):
+                y3 = ops.conv3x3_ps(xs, w, b, res=r, gn_stats=stats)
+            with tune_scope(convwin_nj3=-1), expect_kernels(convwin=1):
+                y4 = ops.conv3x3_ps(xs, w, b, res=r, gn_stats=stats)
+        exact = F.conv2d(x.double().contiguous(), w.double(), b.double(), padding=1)
+        if res:
+            exact = exact + r.double()
+        e = (y3.double() - exact).abs().max().item() / max(1.0, exact.abs().max().item())
+        assert torch.isfinite(y3).all() and e < 2e-5, ((N, ci, co, S, res), e)
+        assert torch.equal(y3, y4), (N, ci, co, S, res)
+        if stats and hasattr(y4, "_gnparts"):
+            assert hasattr(y3, "_gnparts") and torch.equal(y3._gnparts, y4._gnparts)
+    range_check("96-column tiles")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("from_parts,cat,with_ss", [(False, False, True), (False, True, False), (True, False, True), (True, True, False)])
 def test_groupnorm_coefficient_table_from_statistics_launch(from_parts, cat, with_ss):
     """The per-(image, channel) (a, b) table that the statistics kernels write on request (cdae_gn_stats2_coef /

@@ -824,6 +824,46 @@ def test_mixed16_training_tracks_fp32():
     assert ref != low          # the reduced-precision path really ran
 
 
+def test_default_ddim_loop_falls_back_to_eager_when_capture_fails():
+    """The public ddim_sample_loop replays a HIP graph BY DEFAULT (use_graph=None).  A step that cannot be captured — a host sync inside
+    a wrapper module, a plain callable — must then run eagerly with the same result instead of turning a call that used to work into an
+    error; only use_graph=True insists (round-3 advisor finding)."""
+    import warnings
+    model, diff, cfg = make("T28", respacing="ddim10")
+    model.eval()
+    N = 2
+    x, x0, c, z, y = model_inputs("T28", cfg, N)
+    x_T = synth("T28.xT", (N, 1, 28, 28), -1.7, 1.7).to(DEV)
+    kw = dict(z=z.to(DEV), y=y.to(DEV))
+
+    class Syncing(torch.nn.Module):             # a wrapper that reads a value back on the host in every call: not capturable
+        def __init__(self, inner):
+            super().__init__()
+            self.inner, self.calls = inner, 0
+
+        def forward(self, x, t, **k):
+            self.calls += 1
+            float(t[0].item())
+            return self.inner(x, t, **k)
+
+    with torch.no_grad():
+        ref = diff.ddim_sample_loop(model, (N, 1, 28, 28), noise=x_T, model_kwargs=kw, use_graph=False)
+        wrapped = Syncing(model).eval()
+        with warnings.catch_warnings(record=True) as wlog:
+            warnings.simplefilter("always")
+            got = diff.ddim_sample_loop(wrapped, (N, 1, 28, 28), noise=x_T, model_kwargs=kw)                  # default: tries the graph, falls back
+        assert err(got, ref) == 0.0 and wrapped.calls >= 10
+        assert any("running eagerly" in str(w.message) for w in wlog) or wrapped.calls == 10
+        got = diff.ddim_sample_loop(lambda xx, tt, **k: model(xx, tt, **k), (N, 1, 28, 28), noise=x_T, model_kwargs=kw,
+                                    device=torch.device(DEV))                                               # a plain callable: eager, no AttributeError
+        assert err(got, ref) == 0.0
+        with pytest.raises(Exception):
+            diff.ddim_sample_loop(Syncing(model).eval(), (N, 1, 28, 28), noise=x_T, model_kwargs=kw, use_graph=True)
+        torch.cuda.synchronize()
+        again = diff.ddim_sample_loop(model, (N, 1, 28, 28), noise=x_T, model_kwargs=kw)                       # the process still captures afterwards
+        assert err(again, ref) == 0.0
+
+
 # ------------------------------------------------------------------ SURVEY §8f.2: counterfactual driver == the script's explicit sequence
 def test_counterfactual_driver_golden(golden):
     from improved_diffusion.counterfactual import counterfactual_sample, latent_traversal

@@ -242,12 +242,13 @@ def test_window_conv_k_loop_has_no_compiler_drain():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     kernels = [r for r in mod.lint("convwin") if "convwin_kernel" in r["kernel"]]
-    assert len(kernels) == 5          # <f16 | bf16, 9 taps> x <plane pairs | one plane> and <f16, 4 taps, pairs>
+    assert len(kernels) == 6          # <f16 | bf16, 9 taps> x <plane pairs | one plane>, <f16, 4 taps, pairs>, and the 96-column tile <f16, 9, pairs, 3>
     for r in kernels:
         assert r["loops"], r["kernel"]
-        single = ", 1>" in r["kernel"]
+        args = [a.strip() for a in r["kernel"].split("convwin_kernel<")[1].split(">")[0].split(",")]      # BF, taps, planes, column tiles per wave
+        want = 8 * int(args[3]) * (3 if args[2] == "2" else 1)
         for lp in r["loops"]:
-            assert lp["mfmas"] == (32 if single else 96) and lp["barriers"] == 1, (r["kernel"], lp)
+            assert lp["mfmas"] == want and lp["barriers"] == 1, (r["kernel"], lp)
             assert not lp["vmcnt_waits"] and not lp["scratch"], (r["kernel"], lp)
         assert 0 <= r["vgpr_spills"] <= 16, (r["kernel"], r["vgpr_spills"])
 

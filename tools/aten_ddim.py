@@ -24,20 +24,30 @@ with torch.no_grad():
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
         x = diff.ddim_sample(model, x, tab[3], model_kwargs=dict(z=z))["sample"]
         torch.cuda.synchronize()
+VIEWS = {"aten::view", "aten::reshape", "aten::permute", "aten::slice", "aten::select", "aten::as_strided", "aten::expand", "aten::empty", "aten::empty_like",
+         "aten::empty_strided", "aten::t", "aten::transpose", "aten::unsqueeze", "aten::squeeze", "aten::detach", "aten::alias", "aten::_unsafe_view",
+         "aten::result_type", "aten::is_nonzero", "aten::item", "aten::_local_scalar_dense", "aten::lift_fresh", "aten::detach_", "aten::resize_",
+         "aten::unflatten", "aten::flatten", "aten::chunk", "aten::split", "aten::narrow", "aten::unbind", "aten::stride", "aten::size", "aten::numel"}
 cnt = collections.Counter()
 for e in prof.events():
-    if not e.name.startswith("aten::") and "emcpy" not in e.name and "emset" not in e.name:
+    if not (e.name.startswith("aten::") or "emcpy" in e.name or "emset" in e.name):
+        continue
+    if e.name in VIEWS:
         continue
     p, chain = e.cpu_parent, []
     while p is not None:
         chain.append(p.name)
         p = p.cpu_parent
-    if any(n.startswith("aten::") for n in chain):
-        continue                                        # outermost aten op only
-    kern = [k.name[:60] for k in (e.kernels or [])]
-    if not kern and "emcpy" not in e.name and "emset" not in e.name:
-        continue                                        # views / metadata ops launch nothing
-    st = [s for s in (e.stack or []) if "causaldiffae_amd" in s or "bench" in s]
-    cnt[(e.name, ",".join(kern)[:90], st[0][-70:] if st else "", str(e.input_shapes)[:50])] += 1
+    if any(n.startswith("aten::") and n not in VIEWS for n in chain):
+        continue                                        # outermost computing aten op only
+    st = [s_ for s_ in (e.stack or []) if "causaldiffae_amd" in s_ or "bench" in s_]
+    cnt[(e.name, st[0][-80:] if st else "", str(e.input_shapes)[:60])] += 1
 for k, c in cnt.most_common(80):
     print(c, *k, sep=" | ")
+print("---- device kernels that are not libcdae's")
+kc = collections.Counter()
+for e in prof.events():
+    if e.device_type is not None and str(e.device_type).endswith("CUDA") and ("at::native" in e.name or "rocclr" in e.name or "emcpy" in e.name.lower()):
+        kc[e.name[:110]] += 1
+for k, c in kc.most_common(40):
+    print(c, k, sep=" | ")

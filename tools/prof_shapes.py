@@ -15,6 +15,9 @@ SHAPES = [(128, 128, 64, 7), (256, 128, 64, 2), (384, 128, 64, 1),
 if __name__ == "__main__":
     timing = "--time" in sys.argv
     with_res = "--res" in sys.argv          # convs that carry the block's residual (conv2 of every ResBlock: half of the launches)
+    gn = "--gn" in sys.argv                 # the epilogue also leaves the next GroupNorm's partial sums, as in the model
+    if os.environ.get("NJ3"):               # dev: force / forbid the 96-column tiles (cdae_tune_set CONVWIN_NJ3)
+        check(lib.cdae_tune_set(2, int(os.environ["NJ3"])))
     for (ci, co, r, cnt) in SHAPES:
         x = ops.to_nhwc(torch.randn(B, ci, r, r, device="cuda:0"))
         planes = torch.empty((2, B, r, r, ci), dtype=torch.float16, device="cuda:0")
@@ -27,12 +30,12 @@ if __name__ == "__main__":
         b = torch.randn(co, device="cuda:0")
         res = ops.to_nhwc(torch.randn(B, co, r, r, device="cuda:0")) if with_res else None
         with torch.no_grad():
-            ops.conv3x3_ps(xs, w, b, res=res)
+            ops.conv3x3_ps(xs, w, b, res=res, gn_stats=gn)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(3):
-                ops.conv3x3_ps(xs, w, b, res=res)
+                ops.conv3x3_ps(xs, w, b, res=res, gn_stats=gn)
             e1.record()
             torch.cuda.synchronize()
         if timing:
