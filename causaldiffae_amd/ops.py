@@ -103,6 +103,57 @@ def _done(*cbs):
             cb()
 
 
+# ----------------------------------------------------------------------------- weight gradients on a side stream
+# A layer's weight gradient is off the critical path of backward: nothing but the optimizer (and the gradient all-reduce) reads it, while
+# the data gradient feeds the next layer.  At training batch sizes most backward kernels leave block slots empty (a 1x1 conv's dgrad at
+# 16 x 16 is 192 tiles for 512 slots), so the wgrad launches that accumulate STRAIGHT INTO the flat gradient buffer go to a second HIP
+# stream and fill them; the main stream carries on with the dgrad chain.  Ordering: the side stream waits for the main stream at every
+# launch (its operands — dy, the saved activation planes — were produced there); whoever reads gradients joins first (`side_join`:
+# TrainLoop before the optimizer step / gradient norm, GradBuckets before a bucket's all-reduce).  The side stream has its own split-K
+# workspace.  Tensors the side stream reads are `record_stream`ed, so the caching allocator does not recycle them under it.
+_WGRAD_SIDE_ON = os.environ.get("CDAE_WGRAD_STREAM", "1") != "0"      # dev switch: 0 = everything on the one stream
+_SIDE = {}
+
+
+def _side(dev):
+    st = _SIDE.get(dev.index)
+    if st is None:
+        st = _SIDE[dev.index] = dict(stream=torch.cuda.Stream(device=dev), dirty=False)
+    return st
+
+
+def side_launch(dev, tensors, fn):
+    """Run `fn(raw_stream, splitk_ws_ptr, splitk_ws_bytes)` — a wgrad launch that accumulates into the flat gradient buffer — on the
+    side stream, behind everything issued to the current stream so far.  `tensors`: what the launch reads (kept alive for it)."""
+    if not _WGRAD_SIDE_ON:
+        ws, wsb = _sk(dev)
+        fn(stream(), ws, wsb)
+        return
+    sd = _side(dev)
+    side = sd["stream"]
+    side.wait_stream(torch.cuda.current_stream(dev))
+    for t in tensors:
+        if t is not None:
+            t.record_stream(side)
+    fn(side.cuda_stream, ptr(workspace(dev, "splitk_side", SPLITK_BYTES)), SPLITK_BYTES)
+    if not sd["dirty"]:
+        sd["dirty"] = True
+        # the stream that called backward() joins the side stream when the backward pass ends: `.backward()` then returns with every
+        # gradient ordered behind it on that stream, like a single-stream backward (and a graph capture of the step closes its fork)
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(side_join)
+        except RuntimeError:        # not inside a backward pass: the caller joins (side_join)
+            pass
+
+
+def side_join(dev=None):
+    """The current stream waits for every wgrad launch issued to the side stream so far (no host sync)."""
+    for idx, sd in _SIDE.items():
+        if sd["dirty"] and (dev is None or dev.index == idx):
+            torch.cuda.current_stream(sd["stream"].device).wait_stream(sd["stream"])
+            sd["dirty"] = False
+
+
 # ----------------------------------------------------------------------------- conv3x3
 class _Conv3x3(Function):
     @staticmethod
@@ -156,11 +207,15 @@ class _Conv3x3(Function):
             else:
                 dw = torch.empty_like(w)           # same OHWI storage as the parameter
                 db = torch.empty(Cout, dtype=torch.float32, device=dev) if has_b else None
-            check(lib.cdae_conv3x3_wgrad(ptr(x), x.stride(0), x.stride(2), x.stride(3), x.stride(1), ptr(dy), Cout, ptr(dw), ptr(db),
-                                         N, H, W, Cin, Cout, stride, 1 if up else 0, 1 if direct else 0, ws, wsb, stream()))
+            def wg(st_, ws_, wsb_, dw=dw, db=db):
+                check(lib.cdae_conv3x3_wgrad(ptr(x), x.stride(0), x.stride(2), x.stride(3), x.stride(1), ptr(dy), Cout, ptr(dw), ptr(db),
+                                             N, H, W, Cin, Cout, stride, 1 if up else 0, 1 if direct else 0, ws_, wsb_, st_))
             if direct:
+                side_launch(dev, (x, dy), wg)
                 dw = db = None
                 _done(rw, rb)
+            else:
+                wg(stream(), ws, wsb)
         if has_res and ctx.needs_input_grad[3]:
             dres = dy
         return dx, dw, db, dres, None, None, None
@@ -235,11 +290,15 @@ class _Linear(Function):
             dw = gw if direct else torch.empty_like(w)
             if want_b:              # bias gradient = column sums of dy, fused into the wgrad kernel (alpha is 1 for layers with a bias)
                 db = gb if direct else torch.empty(Nf, dtype=torch.float32, device=dev)
-            check(lib.cdae_linear_wgrad(ptr(x), x.stride(0), ptr(dya), Nf, ptr(dw), K, ptr(db) if want_b else None, M, Nf, K,
-                                        1 if direct else 0, ws, wsb, stream()))
+            def wg(st_, ws_, wsb_, dw=dw, db=db):
+                check(lib.cdae_linear_wgrad(ptr(x), x.stride(0), ptr(dya), Nf, ptr(dw), K, ptr(db) if want_b else None, M, Nf, K,
+                                            1 if direct else 0, ws_, wsb_, st_))
             if direct:
+                side_launch(dev, (x, dya), wg)
                 dw = db = None
                 _done(rw, rb if want_b else None)
+            else:
+                wg(stream(), ws, wsb)
         elif want_b:
             direct = gb is not None
             db = gb if direct else torch.empty(Nf, dtype=torch.float32, device=dev)
@@ -1318,11 +1377,15 @@ class _GNConvPS(Function):
             else:
                 dw = torch.empty_like(w)
                 db = torch.empty(Cout, dtype=torch.float32, device=dev) if has_b else None
-            check(lib.cdae_conv3x3_wgrad_win(*ptr2(planes), *ptr2(dplanes), ptr(dw), ptr(db), N, H, W, C, Cout,
-                                             1 if direct else 0, ws, wsb, st))
+            def wg(st_, ws_, wsb_, dw=dw, db=db):
+                check(lib.cdae_conv3x3_wgrad_win(*ptr2(planes), *ptr2(dplanes), ptr(dw), ptr(db), N, H, W, C, Cout,
+                                                 1 if direct else 0, ws_, wsb_, st_))
             if direct:
+                side_launch(dev, (planes, dplanes), wg)
                 dw = db = None
                 _done(rw, rb)
+            else:
+                wg(st, ws, wsb)
         # --- dgrad on the window kernel, then through the GroupNorm
         if any(ctx.needs_input_grad[:4]):
             wt_hi, wt_lo = dgrad_weight(w)
@@ -1393,11 +1456,15 @@ class _UpConvPS(Function):
             else:
                 dw = torch.empty_like(w)
                 db = torch.empty(Cout, dtype=torch.float32, device=dev) if has_b else None
-            check(lib.cdae_conv3x3_wgrad_win(*ptr2(bplanes), *ptr2(dplanes), ptr(dw), ptr(db), N, 2 * H, 2 * W, C,
-                                             Cout, 1 if direct else 0, ws, wsb, st))
+            def wg(st_, ws_, wsb_, dw=dw, db=db):
+                check(lib.cdae_conv3x3_wgrad_win(*ptr2(bplanes), *ptr2(dplanes), ptr(dw), ptr(db), N, 2 * H, 2 * W, C,
+                                                 Cout, 1 if direct else 0, ws_, wsb_, st_))
             if direct:
+                side_launch(dev, (bplanes, dplanes), wg)
                 dw = db = None
                 _done(rw, rb)
+            else:
+                wg(st, ws, wsb)
         if ctx.needs_input_grad[0]:
             wt_hi, wt_lo = dgrad_weight(w)
             dxu = new_act(N, C, 2 * H, 2 * W, dev)
@@ -1497,11 +1564,15 @@ def _rb_conv_bwd(bplanes, dplanes, w, sinks, has_b, shape, Cout, need_w, st):
         else:
             dw = torch.empty_like(w)
             db = torch.empty(Cout, dtype=torch.float32, device=dev) if has_b else None
-        check(lib.cdae_conv3x3_wgrad_win(*ptr2(bplanes), *ptr2(dplanes), ptr(dw), ptr(db), N, H, W, C, Cout,
-                                         1 if direct else 0, ws, wsb, st))
+        def wg(st_, ws_, wsb_, dw=dw, db=db):
+            check(lib.cdae_conv3x3_wgrad_win(*ptr2(bplanes), *ptr2(dplanes), ptr(dw), ptr(db), N, H, W, C, Cout,
+                                             1 if direct else 0, ws_, wsb_, st_))
         if direct:
+            side_launch(dev, (bplanes, dplanes), wg)
             dw = db = None
             _done(rw, rb)
+        else:
+            wg(st, ws, wsb)
     dyn = new_act(N, C, H, W, dev)
     check(lib.cdae_conv3x3_dgrad_psk(*ptr2(dplanes), *_wptrs(w, True), ptr(dyn), C, N, H, W, C, Cout, ws, wsb, st))
     return dyn, dw, db
@@ -1588,7 +1659,9 @@ class _ResBlockPS(Function):
         dplanes = torch.empty((2, N, H, W, Cout), dtype=torch.bfloat16, device=dev)
         check(lib.cdae_split_bf16(ptr(dout), *ptr2(dplanes), dout.numel(), st))
         dyn2, dw2, dc2b = _rb_conv_bwd(bplanes2, dplanes, w2, (sw2, sc2b), has_c2b, (N, Cout, H, W), Cout, need[9], st)
-        # dh leaves GN2's backward as bf16 planes only (it is nothing but conv1's dy); `dplanes` is reused for it
+        # dh leaves GN2's backward as bf16 planes only (it is nothing but conv1's dy).  (A buffer of its own: conv2's wgrad may still be
+        # reading `dplanes` on the side stream.)
+        dplanes = torch.empty_like(dplanes) if _WGRAD_SIDE_ON else dplanes
         dg2, db2, dss = gn_bwd(h, dyn2, stats2, g2, b2, ss, (sg2, sb2), Cout, None, False, None, dplanes)
         del dyn2
         # ---- first half: conv1, then GN1 with the residual gradient folded in
@@ -1609,7 +1682,9 @@ class _ResBlockPS(Function):
                 dx = new_act(N, C, H, W, dev)
                 check(lib.cdae_linear_dgrad(ptr(dout), Cout, ptr(sw), C, ptr(dx), C, M, Cout, C, 0, ws, wsb, st))
                 dg1, db1, _ = gn_bwd(x, dyn1, stats1, g1, b1, None, (sg1, sb1), C, dx, True, None, None)
-                check(lib.cdae_linear_wgrad(ptr(x), C, ptr(dout), Cout, ptr(dsw), C, ptr(dsb), M, Cout, C, acc, ws, wsb, st))
+                def wg(st_, ws_, wsb_):
+                    check(lib.cdae_linear_wgrad(ptr(x), C, ptr(dout), Cout, ptr(dsw), C, ptr(dsb), M, Cout, C, acc, ws_, wsb_, st_))
+                side_launch(dev, (x, dout), wg) if direct else wg(st, ws, wsb)
             else:
                 # two sources: the skip conv's dgrad / wgrad column ranges go to / come from the two tensors, then the first GroupNorm's
                 # backward accumulates onto both
@@ -1628,8 +1703,10 @@ class _ResBlockPS(Function):
                 if dirn:
                     dg1 = db1 = None
                     _done(rg, rb_)
-                check(lib.cdae_linear_wgrad(ptr(x), C1, ptr(dout), Cout, ptr(dsw), C, ptr(dsb), M, Cout, C1, acc, ws, wsb, st))
-                check(lib.cdae_linear_wgrad(ptr(x2), C2, ptr(dout), Cout, dsw.data_ptr() + 4 * C1, C, None, M, Cout, C2, acc, ws, wsb, st))
+                def wg(st_, ws_, wsb_):
+                    check(lib.cdae_linear_wgrad(ptr(x), C1, ptr(dout), Cout, ptr(dsw), C, ptr(dsb), M, Cout, C1, acc, ws_, wsb_, st_))
+                    check(lib.cdae_linear_wgrad(ptr(x2), C2, ptr(dout), Cout, dsw.data_ptr() + 4 * C1, C, None, M, Cout, C2, acc, ws_, wsb_, st_))
+                side_launch(dev, (x, x2, dout), wg) if direct else wg(st, ws, wsb)
             if direct:
                 dsw = dsb = None
                 _done(rsw, rsb if has_sb else None)
@@ -1705,7 +1782,7 @@ class _EmbAllTrain(Function):
             check(lib.cdae_linear_dgrad(ptr(dall), T, ptr(W), K, ptr(ds), K, N, T, K, 0, ws, wsb, st))
             demb = torch.empty_like(ds)
             check(lib.cdae_silu_bwd(ptr(emb), ptr(ds), ptr(demb), ds.numel(), st))
-        check(lib.cdae_linear_wgrad(ptr(s), K, ptr(dall), T, ptr(gw), K, ptr(gb), N, T, K, 1, ws, wsb, st))
+        side_launch(dev, (s, dall), lambda st_, ws_, wsb_: check(lib.cdae_linear_wgrad(ptr(s), K, ptr(dall), T, ptr(gw), K, ptr(gb), N, T, K, 1, ws_, wsb_, st_)))
         for p in flat["params"]:
             cb = getattr(p, "_grad_ready", None)
             if cb is not None:

@@ -135,6 +135,7 @@ class GradBuckets:
         stream before the collective starts.  No event of our own: one recorded here would be recorded on, and waited for by, the
         same stream."""
         grad = self.flat.grad[b["lo"]:b["hi"]]
+        ops.side_join()             # weight gradients are written on ops' side stream: this stream waits for them before the collective reads them
         return dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _make_hook(self, i):
@@ -187,15 +188,18 @@ class FusedAdamWEMA:
         self._sq = th.zeros(1, dtype=th.float64, device=self.flat.flat.device)
 
     def zero_grad(self):
+        ops.side_join()                  # (no weight-gradient launch of the previous step may still be accumulating: see ops.side_launch)
         self.flat.zero_grad()
 
     def grad_sqsum(self):
+        ops.side_join()
         check(lib.cdae_sqsum(ptr(self.flat.grad), self.flat.numel, ptr(self._sq), stream()))
         return float(self._sq.item())
 
     def step(self, lr=None):
         self.t += 1
         f = self.flat
+        ops.side_join()                  # backward() already joined ops' weight-gradient stream; a caller that wrote gradients otherwise has not
         first = self.ema[0] if self.ema else None
         check(lib.cdae_adamw_ema(ptr(f.flat), ptr(f.grad), ptr(self.m), ptr(self.v), ptr(first), f.numel,
                                  self.lr if lr is None else lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
