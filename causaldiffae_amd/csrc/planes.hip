@@ -565,8 +565,9 @@ int cdae_planes_dispatch(GemmParams& p, int big, int& ks, hipStream_t st) {
         bool cw = cdae_convwin_ok(p);
         if (cw) {
             int kbest = ks;
-            if (cw_tiles * ks < 512 && cdae_tune(TUNE_CONVWIN_SPLITK) && p.ksplit_auto && p.splitk_ws && !p.gn_part) {
-                int k2 = (int)(512 / cw_tiles);
+            static const int cfg_slots = CDAE_DEV_INT("CDAE_CONVWIN_SPLIT_SLOTS", 512);      // block slots the K split tries to fill (two per CU)
+            if (cw_tiles * ks < cfg_slots && cdae_tune(TUNE_CONVWIN_SPLITK) && p.ksplit_auto && p.splitk_ws && !p.gn_part) {
+                int k2 = (int)(cfg_slots / cw_tiles);
                 if (k2 > nchunk / 3) k2 = nchunk / 3;
                 while (k2 > 1 && (size_t)k2 * p.M * p.N * sizeof(float) > p.splitk_ws_bytes) --k2;
                 if (k2 > 1) { const int c_per = (nchunk + k2 - 1) / k2; k2 = (nchunk + c_per - 1) / c_per; }      // 12 chunks over 5 splits are 3 + 3 + 3 + 3 + 0: no empty slabs

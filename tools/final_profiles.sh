@@ -1,10 +1,10 @@
 #!/bin/bash
 # Round-end evidence in one gpurun call: PMC + kernel stats of the DDIM step and of the training step, per-shape tables.
 #   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/final_profiles.sh r02 v2'
-TAG=${1:-r03}; VER=${2:-v2}
+TAG=${1:-r04}; VER=${2:-v1}
 bash tools/profile_round.sh $TAG $VER 2>&1 | tail -40
 bash tools/profile_train.sh $TAG $VER 2>&1 | tail -25
-bash tools/prof_shapes.sh 2>&1 | tail -30
+bash tools/prof_shapes.sh $TAG 2>&1 | tail -45
 mkdir -p gpurun_out/micro
 timeout 200 python3 tools/prof_skip.py > gpurun_out/micro/skip.txt 2>&1; grep -v amdgpu gpurun_out/micro/skip.txt
 timeout 200 python3 tools/prof_head.py > gpurun_out/micro/head.txt 2>&1; grep -v amdgpu gpurun_out/micro/head.txt
