@@ -77,6 +77,9 @@ struct GemmParams {
     // convwin_kernel: the activation planes are GROUP-MAJOR, [Cin / 16][pixels][16] (written so by the GroupNorm apply kernel / the entry sweep
     // on request): a 16-channel half-window is then one contiguous run of 32-byte rows — 8 cache lines per DMA instead of 32
     int a_gm;
+    // convwin_kernel: 16-column MFMA tiles per wave (n-tile = 32 cw_nj columns): 4 (256 x 128 tiles), or 3 / 2 where the narrower tile
+    // fills the 512 block slots clearly better (planes.hip decides, before it sizes a K split)
+    int cw_nj;
 };
 
 int cdae_gemm_dispatch(GemmParams p, void* stream);

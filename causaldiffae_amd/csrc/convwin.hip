@@ -253,7 +253,8 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
 #define CW_WAIT(...) asm volatile(__VA_ARGS__)
         if (nsteps > 0) {
             CW_READ_A(0, 0, wtap_c, a_c);
-            CW_READ_B(0, b_c); CW_READ_B(1, b_c); CW_READ_B(2, b_c);
+            CW_READ_B(0, b_c); CW_READ_B(1, b_c);
+            if constexpr (NJ >= 3) CW_READ_B(2, b_c);
             if constexpr (NJ == 4) CW_READ_B(3, b_c);
         }
         // Per-lane loop state that the register allocator spills around the epilogue must be back in registers HERE: a scratch reload is a
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                     acc[i][j] = mma(ah[cur], bh[j], acc[i][j]);
                     if (i == 7) {
                         __builtin_amdgcn_sched_barrier(0);
-                        if (j == 1) { CW_READ_B(1, b_n); } else if (j == 2) { CW_READ_B(2, b_n); } else { if constexpr (NJ == 4) CW_READ_B(3, b_n); }
+                        if (j == 1) { CW_READ_B(1, b_n); } else if (j == 2) { if constexpr (NJ >= 3) CW_READ_B(2, b_n); } else { if constexpr (NJ == 4) CW_READ_B(3, b_n); }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -596,14 +597,6 @@ int cdae_convwin_launch(const GemmParams& p, void* stream) {
     if (p.ps_taps == 4) return launch_convwin<false, 4>(p, st);
     if (p.prec == 3) return launch_convwin<false, 9, 1>(p, st);          // mixed16: one f16 plane
     if (p.prec == 4) return launch_convwin<true, 9, 1>(p, st);           // mixed16, gradient operand: one bf16 plane
-    if (p.prec == 2) return launch_convwin<true, 9>(p, st);
-    // 96-column tiles where they fill the block slots (two per CU) better than 128-column ones: Cout = 384 at 16 x 16 and batch 128
-    // (384 -> 512 blocks); never with split-K (the slabs are laid out for any tile width, but the dispatcher sized the split for 128)
-    const int nj3 = cdae_tune(TUNE_CONVWIN_NJ3);                          // 0 auto, 1 wherever it applies (parity tests), -1 never
-    if (nj3 >= 0 && p.ksplit == 1 && p.N % 96 == 0) {
-        const long mt = (p.M + CW_BM - 1) / CW_BM, t4 = mt * ((p.N + 127) / 128), t3 = mt * (p.N / 96);
-        auto fill = [](long t) { return (double)t / (double)(((t + 511) / 512) * 512); };
-        if (nj3 > 0 || fill(t3) > fill(t4) + 0.1) return launch_convwin<false, 9, 2, 3>(p, st);
-    }
-    return launch_convwin<false, 9>(p, st);
+    if (p.cw_nj == 3 && p.prec == 1) return launch_convwin<false, 9, 2, 3>(p, st);      // planes.hip chose the tile width
+    return p.prec == 2 ? launch_convwin<true, 9>(p, st) : launch_convwin<false, 9>(p, st);
 }

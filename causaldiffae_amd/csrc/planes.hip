@@ -561,8 +561,20 @@ int cdae_planes_dispatch(GemmParams& p, int big, int& ks, hipStream_t st) {
         // second-generation window kernel (convwin.hip): 256 x 128 tiles, two blocks per CU.  Fewer tiles than block slots: split K by whole
         // 32-channel chunks (the low-resolution levels, and everything below 64 x 64 at training batch sizes).  floor, not ceil: 96 tiles x 6 =
         // 576 would need a second, nearly empty round of blocks; x 5 = 480 runs in one.  At least three chunks = 27 K-steps per split.
-        const long cw_tiles = (long)((p.M + 255) / 256) * ((p.N + 127) / 128) * (p.nphase > 1 ? p.nphase : 1);
         bool cw = cdae_convwin_ok(p);
+        // n-tile width.  128 columns, or 96 where that fills the 512 block slots (two per CU) without a K split and 128 does not: Cout = 384
+        // at 16 x 16 and batch 128 (128 m-tiles x 3 = 384 blocks -> x 4 = 512: -12 % on those convs).  Measured and left out: 64-column tiles
+        // for 256 channels at 32 x 32 and batch 32 (training forward / dgrad, 256 -> 512 blocks: +-0 on the step), and narrow tiles combined
+        // with a K split at 8 x 8 (256 x 64 tiles x 2 splits instead of 256 x 128 x 4: 183 vs 163 us at K = 8064).
+        // TUNE_CONVWIN_NJ3: 0 auto, 1 wherever 96 columns apply (parity tests), -1 never.
+        p.cw_nj = 4;
+        const int tune_nj = cdae_tune(TUNE_CONVWIN_NJ3);
+        if (cw && tune_nj >= 0 && p.ps_taps != 4 && p.prec == 1 && ks == 1 && p.N % 96 == 0) {
+            const long mt = (p.M + 255) / 256;
+            auto fill = [](long t) { return (double)t / (double)(((t + 511) / 512) * 512); };
+            if (tune_nj > 0 || (fill(mt * (p.N / 96)) >= 0.9 && fill(mt * (p.N / 96)) > fill(mt * ((p.N + 127) / 128)) + 0.1)) p.cw_nj = 3;
+        }
+        const long cw_tiles = (long)((p.M + 255) / 256) * ((p.N + 32 * p.cw_nj - 1) / (32 * p.cw_nj)) * (p.nphase > 1 ? p.nphase : 1);
         if (cw) {
             int kbest = ks;
             static const int cfg_slots = CDAE_DEV_INT("CDAE_CONVWIN_SPLIT_SLOTS", 512);      // block slots the K split tries to fill (two per CU)

@@ -415,7 +415,7 @@ int cdae_mse_rows_bwd(const float* a, const float* b, const float* gout, float* 
  *                                else on the first-generation 128-row window kernel (smaller tiles fill the chip at small batch)
  *   CDAE_TUNE_CONVWIN_SPLITK     (1)   0: convwin_kernel never splits K
  *   CDAE_TUNE_CONVWIN_NJ3        (0)   256 x 96 tiles of the forward window kernel (Cout % 96 == 0, unsplit K): 0 = where they fill the
- *                                      block slots at least 0.1 better than 256 x 128 tiles, 1 = wherever they apply (tests), -1 = never */
+ *                                      block slots and 256 x 128 tiles do not, 1 = wherever they apply (tests), -1 = never */
 enum { CDAE_TUNE_CONVWIN_MIN_TILES = 0, CDAE_TUNE_CONVWIN_SPLITK = 1, CDAE_TUNE_CONVWIN_NJ3 = 2 };
 int cdae_tune_set(int key, int value);
 int cdae_tune_get(int key);       /* -1: unknown key */

@@ -11,6 +11,9 @@ from improved_diffusion.train_util import TrainLoop
 
 dev = torch.device("cuda:0")
 B = int(os.environ.get("BATCH", "32"))
+if os.environ.get("NJ3"):
+    from causaldiffae_amd._lib import lib as _l
+    _l.cdae_tune_set(2, int(os.environ["NJ3"]))
 STEPS, REGIONS = int(os.environ.get("STEPS", "40")), int(os.environ.get("REGIONS", "3"))
 cfg = {**su.model_and_diffusion_defaults(), "image_size": 64, "in_channels": 3, "n_vars": 4, "rep_cond": True, "causal_modeling": True}
 model, diff = su.create_model_and_diffusion(**cfg)
