@@ -120,6 +120,8 @@ SIGNATURES = {
     "cdae_vb_terms_bwd": [P, P, P, P, P, I, I, I, I, I, P, P, I, L, P],
     "cdae_mse_rows": [P, P, P, I, L, P],
     "cdae_mse_rows_bwd": [P, P, P, P, I, L, P],
+    "cdae_rep_loss": [P, P, P, P, P, I, I, I, P],
+    "cdae_rep_loss_bwd": [P, P, P, P, P, P, P, P, I, I, I, P],
     "cdae_tune_set": [I, I],
     "cdae_tune_get": [I],
     "cdae_prof_enable": [I],

@@ -587,6 +587,35 @@ __global__ void mse_rows_bwd_kernel(const float* __restrict__ a, const float* __
     GRID_STRIDE(i, total) { db[i] = -2.f * (a[i] - b[i]) * gout[i / per] / (float)per; }
 }
 
+// representation loss (reference gaussian_diffusion.py:727-766 with nn.py:440-457): per sample
+//   kld[n] = sum_j 0.5 (-log var + var + mu^2 - 1)  [KL(N(mu, var) || N(0, I))]  (+ sum_i sum_{j in slice i} 0.5 (z_post - c_i)^2
+//   [KL(N(z_post_i, I) || N(c_i, I)): the prior mean of variable i is its label c_i, reference :718-725 with scale [[0, 1]]])
+// as ONE kernel instead of ~50 ATen launches (and as many autograd nodes) per direction.  One wave per sample; j ascending per lane.
+__global__ void rep_loss_kernel(const float* __restrict__ mu, const float* __restrict__ var, const float* __restrict__ zp, const float* __restrict__ c,
+                                float* __restrict__ out, int D, int nv) {
+    const int n = blockIdx.x, d = nv > 0 ? D / nv : D;
+    float s = 0.f;
+    for (int j = threadIdx.x; j < D; j += 64) {
+        const float m = mu[(long)n * D + j], v = var[(long)n * D + j];
+        float t = 0.5f * (((0.f - logf(v)) + v + m * m) - 1.f);
+        if (zp) { const float df = zp[(long)n * D + j] - c[n * nv + j / d]; t += 0.5f * (((0.f - 0.f) + 1.f + df * df) - 1.f); }
+        s += t;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (threadIdx.x == 0) out[n] = s;
+}
+__global__ void rep_loss_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ var, const float* __restrict__ zp, const float* __restrict__ c,
+                                    const float* __restrict__ g, float* __restrict__ dmu, float* __restrict__ dvar, float* __restrict__ dzp, int D, int nv, long total) {
+    const int d = nv > 0 ? D / nv : D;
+    GRID_STRIDE(i, total) {
+        const int n = (int)(i / D), j = (int)(i - (long)n * D);
+        const float gn = g[n], v = var[i];
+        dmu[i] = gn * mu[i];
+        dvar[i] = gn * 0.5f * (1.f - 1.f / v);
+        if (dzp) dzp[i] = gn * (zp[i] - c[n * nv + j / d]);
+    }
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
@@ -774,6 +803,16 @@ int cdae_mse_rows(const float* a, const float* b, float* out, int N, long per, v
     hipLaunchKernelGGL(mse_rows_kernel, dim3(N), dim3(256), 0, ST, a, b, out, per);
     if (hipGetLastError() != hipSuccess) return cdae_fail("mse_rows launch failed");
     return 0;
+}
+int cdae_rep_loss(const float* mu, const float* var, const float* z_post, const float* c, float* out, int N, int D, int nv, void* stream) {
+    if (N <= 0 || D <= 0 || !mu || !var || !out || (z_post && (!c || nv <= 0 || D % nv))) return cdae_fail("rep_loss: mu, var, out (and c, nv | D with z_post) required");
+    hipLaunchKernelGGL(rep_loss_kernel, dim3(N), dim3(64), 0, ST, mu, var, z_post, c, out, D, z_post ? nv : 0);
+    return hipGetLastError() == hipSuccess ? 0 : cdae_fail("rep_loss launch failed");
+}
+int cdae_rep_loss_bwd(const float* mu, const float* var, const float* z_post, const float* c, const float* gout, float* dmu, float* dvar, float* dz_post,
+                      int N, int D, int nv, void* stream) {
+    if (N <= 0 || D <= 0 || !mu || !var || !gout || !dmu || !dvar || (z_post && (!c || !dz_post || nv <= 0 || D % nv))) return cdae_fail("rep_loss_bwd: bad arguments");
+    LAUNCH1D(rep_loss_bwd_kernel, (long)N * D, mu, var, z_post, c, gout, dmu, dvar, z_post ? dz_post : nullptr, D, z_post ? nv : 0, (long)N * D);
 }
 int cdae_mse_rows_bwd(const float* a, const float* b, const float* gout, float* db, int N, long per, void* stream) {
     LAUNCH1D(mse_rows_bwd_kernel, N * per, a, b, gout, db, per, N * per);

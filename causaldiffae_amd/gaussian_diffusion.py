@@ -383,6 +383,10 @@ class GaussianDiffusion:
     def representation_loss(self, mu, var, z_post, causal_modeling, mask, c):
         """KL(N(mu,var) || N(0,I)) + sum_i KL(N(z_post_i, I) || N(c_i, I)), optionally mask-averaged (reference :727-766)."""
         num_vars = c.shape[1]
+        if mu.is_cuda and mu.dim() == 2 and mu.dtype == th.float32 and (not causal_modeling or mu.shape[1] % num_vars == 0):
+            # one kernel each way (the prior mean of variable i with the reference's scale [[0, 1]] is the label c_i itself)
+            kld = ops.rep_loss(mu, var, z_post if causal_modeling else None, c.to(mu.device).float() if causal_modeling else None)
+            return th.sum(kld * mask) / th.sum(mask) if mask is not None else kld
         scale = np.array([[0, 1]] * num_vars)
         kld = kl_normal(mu, var, th.zeros_like(mu), th.ones_like(var))
         if causal_modeling:

@@ -429,6 +429,9 @@ class CausalModeling(nn.Module):
     def nonlinearity_add_back_noise(self, u, z_pre):
         N = u.shape[0]
         d = self.latent_dim // self.num_var
-        u3 = u.reshape(N, self.num_var, d)
-        outs = [self.nonlinearities[str(i)](z_pre[:, i, :], res=u3[:, i, :].contiguous()) for i in range(self.num_var)]
+        # (unbind, not z_pre[:, i]: one UnbindBackward node = one stack kernel per tensor in the backward, where every SelectBackward is a
+        #  zeros + copy + add on the full tensor)
+        zs = z_pre.unbind(1)
+        us = u.reshape(N, self.num_var, d).unbind(1)
+        outs = [self.nonlinearities[str(i)](zs[i], res=us[i].contiguous()) for i in range(self.num_var)]
         return th.cat(outs, dim=1)

@@ -715,6 +715,39 @@ def mse_rows(target, pred):
     return _MseRows.apply(target, pred)
 
 
+class _RepLoss(Function):
+    """KL(N(mu, var) || N(0, I)) + sum_i KL(N(z_post_i, I) || N(c_i, I)) per sample (reference gaussian_diffusion.py:727-766) as one
+    kernel per direction; the reference's chain of element-wise ops is ~50 launches and autograd nodes each way."""
+
+    @staticmethod
+    def forward(ctx, mu, var, z_post, c):
+        mu, var = _f32c(mu), _f32c(var)
+        N, D = mu.shape
+        nv = 0
+        if z_post is not None:
+            z_post, c = _f32c(z_post).reshape(N, D), _f32c(c)
+            nv = c.shape[1]
+        out = torch.empty(N, dtype=torch.float32, device=mu.device)
+        check(lib.cdae_rep_loss(ptr(mu), ptr(var), ptr(z_post), ptr(c), ptr(out), N, D, nv, stream()))
+        ctx.save_for_backward(mu, var, z_post, c)
+        ctx.nv = nv
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        mu, var, z_post, c = ctx.saved_tensors
+        N, D = mu.shape
+        g = _f32c(g)
+        dmu, dvar = torch.empty_like(mu), torch.empty_like(var)
+        dzp = torch.empty_like(z_post) if z_post is not None else None
+        check(lib.cdae_rep_loss_bwd(ptr(mu), ptr(var), ptr(z_post), ptr(c), ptr(g), ptr(dmu), ptr(dvar), ptr(dzp), N, D, ctx.nv, stream()))
+        return dmu, dvar, dzp, None
+
+
+def rep_loss(mu, var, z_post=None, c=None):
+    return _RepLoss.apply(mu, var, z_post, c)
+
+
 class _VbTerms(Function):
     """One variational-bound term per sample in bits/dim (gaussian_diffusion.py:682-715) with its gradient with respect to the
     raw model output [N, C or 2C, H, W]; `freeze_mean` zeroes the mean half's gradient (the hybrid loss, :822-825)."""

@@ -407,6 +407,12 @@ int cdae_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, lon
 int cdae_sqsum(const float* x, long n, double* out, void* stream);                                            /* grad-norm, train_util.py:299-303 */
 int cdae_mse_rows(const float* a, const float* b, float* out, int N, long per, void* stream);               /* mean_flat((a-b)^2), gaussian_diffusion.py:847 */
 int cdae_mse_rows_bwd(const float* a, const float* b, const float* gout, float* db, int N, long per, void* stream);
+/* representation loss per sample (gaussian_diffusion.py:727-766, nn.py:440-457): out[n] = KL(N(mu, var) || N(0, I)) summed over D
+   (+ sum over the nv latent slices of KL(N(z_post_i, I) || N(c[n][i], I)) when z_post is given: the causal prior whose mean is the
+   label, :718-725).  _bwd: gradients with respect to mu, var and z_post for an upstream gout[N]. */
+int cdae_rep_loss(const float* mu, const float* var, const float* z_post, const float* c, float* out, int N, int D, int nv, void* stream);
+int cdae_rep_loss_bwd(const float* mu, const float* var, const float* z_post, const float* c, const float* gout, float* dmu, float* dvar, float* dz_post,
+                      int N, int D, int nv, void* stream);
 
 /* ---- dispatch thresholds.  The dispatcher picks a kernel per shape from measured thresholds; these two can be moved at run time
  * (process-wide, not thread-safe against concurrent launches).  The parity tests use them to run small golden cases through the

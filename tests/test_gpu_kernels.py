@@ -1402,6 +1402,48 @@ def test_stem_conv_matches_fp64(N, Cin, Cout, H, W, nchw):
     assert (got.double() - ref).abs().max().item() < 2e-6 * ref.abs().max().item()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("causal,nv", [(True, 4), (True, 2), (False, 4)])
+def test_representation_loss_kernel(causal, nv):
+    """cdae_rep_loss / _bwd (one launch each way) against the reference's chain of element-wise ops (gaussian_diffusion.py:727-766 with
+    nn.py:440-457: kl_normal(mu, var, 0, 1) + sum_i kl_normal(z_post_i, 1, c_i, 1)) in fp64: values and the gradients with respect to
+    mu, var and z_post; and GaussianDiffusion.representation_loss takes that path (masked and unmasked)."""
+    from causaldiffae_amd import ops
+    from causaldiffae_amd.nn import kl_normal
+    from improved_diffusion import script_util as su
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(3)
+    N, D = 7, 512
+    mu = torch.randn(N, D, device=dev, generator=g, requires_grad=True)
+    var = (torch.rand(N, D, device=dev, generator=g) * 2 + 1e-3).requires_grad_(True)
+    zp = torch.randn(N, D, device=dev, generator=g, requires_grad=True)
+    c = torch.rand(N, nv, device=dev, generator=g)
+    w = torch.randn(N, device=dev, generator=g)
+    out = ops.rep_loss(mu, var, zp if causal else None, c if causal else None)
+    (out * w).sum().backward()
+    mu64, var64, zp64 = (t.detach().double().requires_grad_(True) for t in (mu, var, zp))
+    ref = kl_normal(mu64, var64, torch.zeros_like(mu64), torch.ones_like(var64))
+    if causal:
+        d = D // nv
+        for i in range(nv):
+            zi = zp64.reshape(N, nv, d)[:, i]
+            ref = ref + kl_normal(zi, torch.ones_like(zi), c.double()[:, i:i + 1].expand(-1, d), torch.ones_like(zi))
+    (ref * w.double()).sum().backward()
+    assert (out.double() - ref).abs().max().item() < 2e-6 * ref.abs().max().item()
+    for got, want in ((mu.grad, mu64.grad), (var.grad, var64.grad)) + (((zp.grad, zp64.grad),) if causal else ()):
+        assert (got.double() - want).abs().max().item() < 2e-6 * want.abs().max().item()
+    if not causal:
+        assert zp.grad is None
+    _, diff = su.create_model_and_diffusion(**{**su.model_and_diffusion_defaults(), "image_size": 32, "in_channels": 1, "n_vars": nv, "rep_cond": True,
+                                              "causal_modeling": causal, "num_channels": 32, "num_res_blocks": 1})
+    with torch.no_grad():
+        k1 = diff.representation_loss(mu, var, zp, causal, None, c)
+        mask = (torch.arange(N, device=dev) % 2).float()
+        k2 = diff.representation_loss(mu, var, zp, causal, mask, c)
+    assert (k1.double() - ref.detach()).abs().max().item() < 2e-6 * ref.abs().max().item()
+    assert abs(k2.item() - ((ref.detach() * mask.double()).sum() / mask.sum()).item()) < 2e-6 * ref.abs().max().item()
+
+
 # ------------------------------------------------------------------ dynamic range of the split-precision (f16x3) contractions
 def _rel(got, exact):
     return (got.double().cpu() - exact.cpu()).abs().max().item() / exact.abs().max().item()
