@@ -146,7 +146,8 @@ int cdae_conv3x3_fwd_psg(const unsigned short* x_hi, const unsigned short* x_lo,
     p.amode = A_CONV_VEC; p.bmode = B_PLAIN_KC;
     p.conv_M = p.M; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.up = up;
     p.sn = sn; p.sy = sy; p.sx = sx; p.sc = 1;
-    set_splitk(p, (out_nchw || gn_part) ? nullptr : splitk_ws, splitk_ws_bytes);      // epilogue statistics need the final values: no split-K
+    // (GroupNorm partial sums with a K split come from the finish kernel; not with plane output or a strided / up-sampling conv)
+    set_splitk(p, (out_nchw || (gn_part && (out_hi || stride != 1 || up))) ? nullptr : splitk_ws, splitk_ws_bytes);
     if (out_nchw && res) return cdae_fail("conv3x3: residual with NCHW output unsupported");
     return cdae_gemm_dispatch(p, stream);
 }

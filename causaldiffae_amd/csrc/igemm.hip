@@ -715,6 +715,65 @@ __global__ __launch_bounds__(256) void splitk_reduce4_kernel(const GemmParams p)
     if (bad && p.range_flag) *p.range_flag = 1;
 }
 
+// The split-K finish that ALSO leaves the next GroupNorm's partial sums (p.gn_part, [ceil(M / 32)][N][2]: per 32-row chunk and column the
+// sum and the sum of squares of the final values) — what the unsplit epilogues of the plane kernels do, for the convs whose K was split
+// (the 8 x 8 level at batch 128, everything below 64 x 64 at training batch sizes): the statistics pass over the tensor (gn_partial +
+// finalize) goes away.  Row-major fp32 result, N % 4 == 0, no activation / accumulation / plane output.  One block = 32 rows x 128 columns:
+// thread (rg = t / 32, c4 = t % 32) finishes rows rg, rg + 8, rg + 16, rg + 24 of one float4 column group — the slab additions in
+// splitk_reduce4_kernel's order — and the eight row groups of a column are added in a fixed order through LDS (deterministic).
+__global__ __launch_bounds__(256) void splitk_reduce_gn_kernel(const GemmParams p) {
+    __shared__ float sh[2][8][128];
+    const float alpha_ = p.w_scale ? p.alpha * p.w_scale[1] : p.alpha;
+    const int ncb = (p.N + 127) >> 7;
+    const int chunk = blockIdx.x / ncb, cb = blockIdx.x - chunk * ncb;
+    const int c4 = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int col = cb * 128 + c4 * 4;
+    const long slab = (long)p.M * p.N;
+    float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+    bool bad = false;
+    if (col < p.N) {
+        const float4 b = p.bias ? *reinterpret_cast<const float4*>(p.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = chunk * 32 + rg + 8 * i;
+            if (row >= p.M) continue;
+            const float* src = p.splitk_ws + (long)row * p.N + col;
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            int k = 0;
+            for (; k + 4 <= p.ksplit; k += 4) {
+                const float4 v0 = *reinterpret_cast<const float4*>(src + k * slab), v1 = *reinterpret_cast<const float4*>(src + (k + 1) * slab),
+                             v2 = *reinterpret_cast<const float4*>(src + (k + 2) * slab), v3 = *reinterpret_cast<const float4*>(src + (k + 3) * slab);
+                s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+                s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+                s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+                s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+            }
+            for (; k < p.ksplit; ++k) { const float4 v = *reinterpret_cast<const float4*>(src + k * slab); s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+            const long addr = (long)row * p.ldc + col;
+            float v[4] = {s.x * alpha_ + b.x, s.y * alpha_ + b.y, s.z * alpha_ + b.z, s.w * alpha_ + b.w};
+            if (p.res) { const float4 r = *reinterpret_cast<const float4*>(p.res + addr); v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+            *reinterpret_cast<float4*>(p.C + addr) = make_float4(v[0], v[1], v[2], v[3]);
+            bad |= !__builtin_isfinite(v[0] + v[1] + v[2] + v[3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s4[e] += v[e]; q4[e] += v[e] * v[e]; }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sh[0][rg][c4 * 4 + e] = s4[e]; sh[1][rg][c4 * 4 + e] = q4[e]; }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int c = cb * 128 + threadIdx.x;
+        if (c < p.N) {
+            float s_ = 0.f, q_ = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) { s_ += sh[0][g][threadIdx.x]; q_ += sh[1][g][threadIdx.x]; }
+            float* o = p.gn_part + ((long)chunk * p.N + c) * 2;
+            o[0] = s_; o[1] = q_;
+        }
+    }
+    if (bad && p.range_flag) *p.range_flag = 1;
+}
+
 template <int BM, int BN, int AMODE, int BMODE, bool SCALAR, int WAVES_N = 2, int PREC = 0, bool GNS = false, bool DEEP = false>
 int launch(const GemmParams& p, hipStream_t st) {
     constexpr bool A_MC = (AMODE == A_PLAIN_MC);
@@ -876,8 +935,12 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
     if (ks > 1 && (!p.splitk_ws || (size_t)ks * p.batch * p.M * p.N * sizeof(float) > p.splitk_ws_bytes))
         return cdae_fail("split-K workspace too small");
     p.ksplit = ks;
-    if (p.gn_part && (ks > 1 || !p.presplit || (p.out_mode != OUT_ROWMAJOR && p.out_mode != OUT_UP2) || p.accumulate))
-        return cdae_fail("GroupNorm partial sums from the epilogue need a pre-split, unsplit-K, row-major, non-accumulating launch");
+    // GroupNorm partial sums: from the epilogue of an unsplit plane kernel, or — K split — from the finish kernel (row-major fp32 result,
+    // N % 4 == 0, no activation / accumulation / plane output)
+    const bool gn_finish_ok = p.gn_part && p.presplit && p.out_mode == OUT_ROWMAJOR && !p.accumulate && p.act == ACT_NONE && !p.C_hi && p.batch == 1 &&
+                              p.N % 4 == 0 && p.ldc % 4 == 0;
+    if (p.gn_part && ((ks > 1 && !gn_finish_ok) || !p.presplit || (p.out_mode != OUT_ROWMAJOR && p.out_mode != OUT_UP2) || p.accumulate))
+        return cdae_fail("GroupNorm partial sums need a pre-split, row-major, non-accumulating launch (K split: fp32 result with N % 4 == 0 and no activation)");
 
     cdae_prof_begin(PROF_IGEMM, 2.0 * p.M * p.N * (double)p.K * p.batch * (p.nphase > 1 ? p.nphase : 1), st);
     if (!p.presplit) {
@@ -918,7 +981,12 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
         if (vec4) total >>= 2;
         int blocks = (int)((total + 255) / 256);
         if (blocks > 4096) blocks = 4096;
-        if (vec4) hipLaunchKernelGGL(splitk_reduce4_kernel, dim3(blocks), dim3(256), 0, st, p);
+        if (p.gn_part && !gn_finish_ok) rc = cdae_fail("K was split but this launch cannot leave GroupNorm partial sums from the finish");
+        else if (p.gn_part) {
+            if (!(al16(p.C) && al16(p.res) && al16(p.bias) && al16(p.splitk_ws))) rc = cdae_fail("split-K finish with GroupNorm sums: 16-byte aligned result, residual, bias and workspace required");
+            else hipLaunchKernelGGL(splitk_reduce_gn_kernel, dim3((unsigned)(((p.M + 31) / 32) * ((p.N + 127) / 128))), dim3(256), 0, st, p);
+        }
+        else if (vec4) hipLaunchKernelGGL(splitk_reduce4_kernel, dim3(blocks), dim3(256), 0, st, p);
         else hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
         if (hipGetLastError() != hipSuccess) rc = cdae_fail("splitk reduce launch failed");
     }

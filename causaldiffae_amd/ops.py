@@ -1296,11 +1296,8 @@ def conv3x3_ps(xs, w, b=None, res=None, stride=1, up=False, out_nchw=False, emit
     M = N * Ho * Wo
     # statistics need the final values in the epilogue, i.e. no split-K: only where the unsplit grid fills the chip anyway
     # (the dispatcher's own rule: >= 256 tiles of 128 x 128), and where a 32-pixel chunk never straddles two images
-    gn_stats = gn_stats and not out_nchw and (Ho * Wo) % 32 == 0 and ((M + 127) // 128) * ((Cout + 127) // 128) >= 256
-    if gn_stats and stride == 1 and not up and ((M + 255) // 256) * ((Cout + 127) // 128) < 256:
-        # the window kernel's 256 x 128 tiles would not fill the chip here (the 8 x 8 level): it splits K instead, which rules out
-        # the epilogue statistics — the next GroupNorm runs its own (small) statistics pass
-        gn_stats = False
+    # (where the window kernel splits K — the 8 x 8 level — the sums come from the split-K finish kernel instead of the epilogue)
+    gn_stats = gn_stats and not out_nchw and (Ho * Wo) % 32 == 0 and Cout % 4 == 0 and ((M + 127) // 128) * ((Cout + 127) // 128) >= 256
     parts = torch.empty(((M + 31) // 32, Cout, 2), dtype=torch.float32, device=dev) if gn_stats else None
     def launch(a, gmflag):
         return lib.cdae_conv3x3_fwd_psg(ptr(a.hi), ptr(a.lo), H * W * Cin, W * Cin, Cin, gmflag, ptr(w_hi), ptr(w_lo), *_pk(w, False), ptr(w_sc), ptr(b), ptr(res), ptr(out), Cout,
@@ -1563,6 +1560,7 @@ def _rb_gn_planes(x, gamma, beta, ss, silu, groups, eps, st, x2=None):
 
 
 _RB_PARTS_ON = os.environ.get("CDAE_TRAIN_GNPARTS", "1") != "0"     # dev switch: 0 = every GroupNorm runs its own statistics pass
+_RB_PARTS_MIN_TILES = int(os.environ.get("CDAE_TRAIN_GNPARTS_MIN_TILES", "64"))      # (below: the statistics pass over a small tensor is cheaper than the sums' own traffic)
 
 
 def _rb_conv(planes, w, b, res, shape, Cout, st):
@@ -1574,7 +1572,7 @@ def _rb_conv(planes, w, b, res, shape, Cout, st):
     ws, wsb = _sk(dev)
     M = N * H * W
     parts = None
-    if _RB_PARTS_ON and (H * W) % 32 == 0 and ((M + 255) // 256) * ((Cout + 127) // 128) >= 256:
+    if _RB_PARTS_ON and (H * W) % 32 == 0 and Cout % 4 == 0 and ((M + 255) // 256) * ((Cout + 127) // 128) >= _RB_PARTS_MIN_TILES:
         parts = torch.empty((M // 32, Cout, 2), dtype=torch.float32, device=dev)
     check(lib.cdae_conv3x3_fwd_psk(*ptr2(planes), H * W * C, W * C, C, *_wptrs(w, False), ptr(b), ptr(res), ptr(out), Cout,
                                   0, None, None, ptr(parts), N, H, W, C, Cout, 1, 0, ws, wsb, st))

@@ -676,6 +676,40 @@ def test_window_conv_96_column_tiles(seed, expect_kernels):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("res", [False, True])
+def test_groupnorm_sums_from_split_k_finish(res, expect_kernels):
+    """Where the window kernel splits K (the 8 x 8 level at batch 128: 128 tiles for 512 block slots) the next GroupNorm's partial sums
+    come from the split-K finish kernel (splitk_reduce_gn_kernel) instead of the conv epilogue.  Against the unsplit launch of the same
+    conv: identical result tensor up to the slab summation order, partial sums equal to 1e-5 of their scale, and the GroupNorm planes
+    computed from them equal to those from a statistics pass over the tensor."""
+    from causaldiffae_amd import ops
+    from causaldiffae_amd._lib import tune_scope
+    g = torch.Generator(device="cuda:0").manual_seed(41)
+    N, ci, co, S = 128, 256, 512, 8
+    x = ops.to_nhwc(torch.randn(N, ci, S, S, device="cuda:0", generator=g))
+    w = (torch.randn(co, ci, 3, 3, device="cuda:0", generator=g) / (9 * ci) ** 0.5).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(co, device="cuda:0", generator=g)
+    r = ops.to_nhwc(torch.randn(N, co, S, S, device="cuda:0", generator=g)) if res else None
+    gamma, beta = torch.rand(co, device="cuda:0", generator=g) + 0.5, torch.randn(co, device="cuda:0", generator=g)
+    xs = _split_nhwc(x)
+    with torch.no_grad():
+        with expect_kernels(convwin=1):
+            y_split = ops.conv3x3_ps(xs, w, b, res=r, gn_stats=True)                 # 32 x 4 tiles -> 4 K splits + the finish
+        with tune_scope(convwin_splitk=0):                                           # unsplit: 128 tiles run on the small-grid plane kernel, sums from its epilogue
+            y_one = ops.conv3x3_ps(xs, w, b, res=r, gn_stats=True)
+        assert hasattr(y_split, "_gnparts") and hasattr(y_one, "_gnparts")
+        scale = y_one.abs().max().item()
+        assert (y_split - y_one).abs().max().item() < 2e-6 * scale
+        ps, po = y_split._gnparts.double(), y_one._gnparts.double()
+        assert ps.shape == po.shape == (N * S * S // 32, co, 2)
+        assert (ps - po).abs().max().item() < 1e-5 * po.abs().max().item()
+        got = ops.group_norm_split(y_split, gamma, beta, None, True)                 # statistics from the finish kernel's sums
+        ref = ops.group_norm_split(y_split.detach().clone(), gamma, beta, None, True)     # a clone carries no sums: statistics pass
+    d = ((got.hi.float() + got.lo.float()) - (ref.hi.float() + ref.lo.float())).abs().max().item()
+    assert d < 2e-5, d
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("from_parts,cat,with_ss", [(False, False, True), (False, True, False), (True, False, True), (True, True, False)])
 def test_groupnorm_coefficient_table_from_statistics_launch(from_parts, cat, with_ss):
     """The per-(image, channel) (a, b) table that the statistics kernels write on request (cdae_gn_stats2_coef /
