@@ -51,6 +51,7 @@ SIGNATURES = {
     "cdae_conv3x3_dgrad_ps": [P, P, P, P, P, L, I, I, I, I, I, P, SZ, P],
     "cdae_conv3x3_stem_supported": [I, I, I],
     "cdae_conv3x3_stem": [P, L, L, L, L, P, P, P, L, I, I, I, I, I, P],
+    "cdae_conv3x3_stem_gn": [P, L, L, L, L, P, P, P, L, P, I, I, I, I, I, P],
     "cdae_conv3x3_wgrad_fewout": [P, P, L, P, P, I, I, I, I, I, I, P, SZ, P],
     "cdae_conv3x3_wgrad_win_supported": [I, I, I, I, I],
     "cdae_conv3x3_wgrad_win": [P, P, P, P, P, P, I, I, I, I, I, I, P, SZ, P],

@@ -14,7 +14,10 @@ namespace {
 
 template <int CIN>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x, long sn, long sy, long sx, long sc, const float* __restrict__ w,
-                                                        const float* __restrict__ bias, float* __restrict__ out, long ldo, int H, int W, int Cout) {
+                                                        const float* __restrict__ bias, float* __restrict__ out, long ldo, int H, int W, int Cout,
+                                                        float* __restrict__ gn_part) {
+    // gn_part (optional, W % 32 == 0, W <= 128): per (32-pixel chunk, channel) sum and sum of squares of the result, [N H W / 32][Cout][2] —
+    // the first ResBlock's GroupNorm (and the last decoder block's, which reads this tensor as its skip input) then need no statistics pass
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int K = 9 * CIN;
     const int cg = Cout >> 2;                          // channel groups of 4
@@ -32,10 +35,14 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
     __syncthreads();
     const int ppp = 256 / cg;                           // pixels per pass
     const int g = tid % cg, pl = tid / cg;
-    if (pl >= ppp) return;
     float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bias) b4 = *reinterpret_cast<const float4*>(bias + 4 * g);
-    for (int px = pl; px < W; px += ppp) {
+    if (bias && pl < ppp) b4 = *reinterpret_cast<const float4*>(bias + 4 * g);
+    float gs[4][4], gq[4][4];                           // [chunk of the row][channel of the group]
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gs[c][e] = 0.f; gq[c][e] = 0.f; }
+    for (int px = pl; px < W && pl < ppp; px += ppp) {
         float4 acc = b4;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
@@ -48,6 +55,38 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
                     acc.x = fmaf(v, ww.x, acc.x); acc.y = fmaf(v, ww.y, acc.y); acc.z = fmaf(v, ww.z, acc.z); acc.w = fmaf(v, ww.w, acc.w);
                 }
         *reinterpret_cast<float4*>(out + ((long)(n * H + y) * W + px) * ldo + 4 * g) = acc;
+        if (gn_part) {
+            const float v[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if ((px >> 5) == c) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { gs[c][e] += v[e]; gq[c][e] += v[e] * v[e]; }
+                }
+        }
+    }
+    if (!gn_part) return;
+    // the ppp pixel lanes of a channel group, added in a fixed order through LDS (behind the weights and the input rows)
+    float* const red = in + 3 * (W + 2) * CIN;          // [chunk][pl][Cout][2]
+    const int nch = W >> 5;
+    if (pl < ppp) {
+        for (int c = 0; c < nch; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float s_ = 0.f, q_ = 0.f;
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) if (cc == c) { s_ = gs[cc][e]; q_ = gq[cc][e]; }
+                red[((c * ppp + pl) * Cout + 4 * g + e) * 2] = s_;
+                red[((c * ppp + pl) * Cout + 4 * g + e) * 2 + 1] = q_;
+            }
+    }
+    __syncthreads();
+    for (int i = tid; i < nch * Cout; i += 256) {
+        const int c = i / Cout, co = i - c * Cout;
+        float s_ = 0.f, q_ = 0.f;
+        for (int l = 0; l < ppp; ++l) { s_ += red[((c * ppp + l) * Cout + co) * 2]; q_ += red[((c * ppp + l) * Cout + co) * 2 + 1]; }
+        float* o = gn_part + (((long)(n * H + y) * nch + c) * Cout + co) * 2;
+        o[0] = s_; o[1] = q_;
     }
 }
 
@@ -59,16 +98,27 @@ extern "C" int cdae_conv3x3_stem_supported(int Cin, int Cout, int W) {
 
 extern "C" int cdae_conv3x3_stem(const float* x, long sn, long sy, long sx, long sc, const float* w, const float* bias, float* out, long ldo,
                                  int N, int H, int W, int Cin, int Cout, void* stream) {
+    return cdae_conv3x3_stem_gn(x, sn, sy, sx, sc, w, bias, out, ldo, nullptr, N, H, W, Cin, Cout, stream);
+}
+
+// + gn_part (may be NULL): [N H W / 32][Cout][2] partial sums of the result for the next GroupNorm (cdae_gn_stats_from_parts); W % 32 == 0, W <= 128
+extern "C" int cdae_conv3x3_stem_gn(const float* x, long sn, long sy, long sx, long sc, const float* w, const float* bias, float* out, long ldo,
+                                    float* gn_part, int N, int H, int W, int Cin, int Cout, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (!cdae_conv3x3_stem_supported(Cin, Cout, W) || ldo % 4 || (((size_t)out | (size_t)bias) & 15))
         return cdae_fail("conv3x3_stem: 1..4 input channels, Cout % 4 == 0, 16-byte aligned output rows required");
-    const size_t smem = (size_t)(9 * Cin * Cout + 3 * (W + 2) * Cin) * sizeof(float);
+    size_t smem = (size_t)(9 * Cin * Cout + 3 * (W + 2) * Cin) * sizeof(float);
+    if (gn_part) {
+        if (W % 32 || W > 128) return cdae_fail("conv3x3_stem_gn: partial sums need W % 32 == 0 and W <= 128");
+        smem += (size_t)(W / 32) * (256 / (Cout / 4)) * Cout * 2 * sizeof(float);
+        if (smem > 160 * 1024) return cdae_fail("conv3x3_stem_gn: LDS budget exceeded");
+    }
     cdae_prof_begin(PROF_IGEMM, 2.0 * N * H * W * 9.0 * Cin * Cout, st);
 #define STEM(C) do { \
         static size_t attr = 0; \
         if (smem > attr) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_conv_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) \
             return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed"); attr = smem; } \
-        hipLaunchKernelGGL(stem_conv_kernel<C>, dim3(N * H), dim3(256), smem, st, x, sn, sy, sx, sc, w, bias, out, ldo, H, W, Cout); } while (0)
+        hipLaunchKernelGGL(stem_conv_kernel<C>, dim3(N * H), dim3(256), smem, st, x, sn, sy, sx, sc, w, bias, out, ldo, H, W, Cout, gn_part); } while (0)
     switch (Cin) { case 1: STEM(1); break; case 2: STEM(2); break; case 3: STEM(3); break; default: STEM(4); }
 #undef STEM
     cdae_prof_end(PROF_IGEMM, st);

@@ -151,6 +151,8 @@ class ConvNd(nn.Module):
                 return ops.conv1x1_cat(x, self.weight, self.bias)
             x = ops.materialize(x)
         if self.kernel_size == 3:
+            if self.stride == 1 and res is None and not up and not out_nchw and ops.presplit_ok() and ops.stem_conv_gn_ok(x, self.weight):
+                return ops.stem_conv_gn(x, self.weight, self.bias)          # the network's input conv: its result carries the GroupNorm sums
             return ops.conv3x3(x, self.weight, self.bias, res=res, stride=self.stride, up=up, out_nchw=out_nchw)
         if x.dim() == 3:       # [B, C, T] (AttentionBlock convention)
             y = ops.conv1x1(x.unsqueeze(-1), self.weight, self.bias, None if res is None else res.unsqueeze(-1))

@@ -225,6 +225,24 @@ def conv3x3(x, w, b=None, res=None, stride=1, up=False, out_nchw=False):
     return _Conv3x3.apply(x, w, b, res, stride, up, out_nchw)
 
 
+def stem_conv_gn_ok(x, w):
+    """The UNet's input conv (1..4 channels) on the streaming fp32 kernel WITH the next GroupNorm's partial sums (no autograd)?"""
+    return (not torch.is_grad_enabled() and x.dim() == 4 and x.dtype == torch.float32 and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3) and x.shape[3] % 32 == 0
+            and x.shape[3] <= 128 and w.permute(0, 2, 3, 1).is_contiguous() and lib.cdae_conv3x3_stem_supported(x.shape[1], w.shape[0], x.shape[3]) == 1)
+
+
+def stem_conv_gn(x, w, b=None):
+    """y = conv3x3(x, w) + b on the input-conv kernel, `y._gnparts` = per (32-pixel chunk, channel) sums for the GroupNorms that read y"""
+    N, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    out = new_act(N, Cout, H, W, x.device)
+    parts = torch.empty((N * H * W // 32, Cout, 2), dtype=torch.float32, device=x.device)
+    check(lib.cdae_conv3x3_stem_gn(ptr(x), x.stride(0), x.stride(2), x.stride(3), x.stride(1), ptr(w), ptr(b), ptr(out), Cout, ptr(parts),
+                                   N, H, W, Cin, Cout, stream()))
+    out._gnparts = parts
+    return out
+
+
 # ----------------------------------------------------------------------------- linear / conv1x1 on rows
 _STREAM_GEMM = os.environ.get("CDAE_STREAM_GEMM", "1") != "0"      # dev switch: 0 = every linear / 1x1 conv through the igemm loader
 _STREAM_GEMM_MIN_ROWS = int(os.environ.get("CDAE_STREAM_GEMM_MIN_ROWS", "4096"))

@@ -268,6 +268,9 @@ int cdae_conv3x3_dgrad_ps(const unsigned short* dy_hi, const unsigned short* dy_
 /* the UNet's input conv (unet.py:395-399; 1..4 input channels, stride 1, NHWC rows out): exact fp32 on the vector ALUs, one output image
    row per block; cdae_conv3x3_fwd routes such shapes here.  x may have any element strides (the model input is NCHW). */
 int cdae_conv3x3_stem_supported(int Cin, int Cout, int W);
+/* cdae_conv3x3_stem that also leaves the next GroupNorm's partial sums: gn_part [N H W / 32][Cout][2] (may be NULL; W % 32 == 0, W <= 128) */
+int cdae_conv3x3_stem_gn(const float* x, long sn, long sy, long sx, long sc, const float* w, const float* bias, float* out, long ldo,
+                         float* gn_part, int N, int H, int W, int Cin, int Cout, void* stream);
 int cdae_conv3x3_stem(const float* x, long sn, long sy, long sx, long sc, const float* w, const float* bias, float* out, long ldo,
                       int N, int H, int W, int Cin, int Cout, void* stream);
 /* the UNet's output head (unet.py:495-499 self.out: GroupNorm32 -> SiLU -> conv3x3 to out_channels) as one kernel in exact fp32 on the

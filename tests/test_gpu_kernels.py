@@ -1478,6 +1478,34 @@ def test_representation_loss_kernel(causal, nv):
     assert abs(k2.item() - ((ref.detach() * mask.double()).sum() / mask.sum()).item()) < 2e-6 * ref.abs().max().item()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,Cin,Cout,S", [(3, 4, 128, 64), (5, 1, 128, 32), (2, 3, 256, 64), (2, 4, 128, 128)])
+def test_stem_conv_leaves_groupnorm_sums(N, Cin, Cout, S):
+    """cdae_conv3x3_stem_gn: the input conv's result (bit-identical to the plain stem kernel) with per (32-pixel chunk, channel) sums and
+    sums of squares attached; a GroupNorm that takes its statistics from them equals one that runs its own statistics pass."""
+    from causaldiffae_amd import ops
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(17)
+    x = torch.randn(N, Cin, S, S, device=dev, generator=g)
+    w = (torch.randn(Cout, Cin, 3, 3, device=dev, generator=g) / (3 * Cin ** 0.5)).contiguous(memory_format=torch.channels_last)
+    b = 0.1 * torch.randn(Cout, device=dev, generator=g)
+    with torch.no_grad():
+        assert ops.stem_conv_gn_ok(x, w)
+        y = ops.stem_conv_gn(x, w, b)
+        plain = ops.conv3x3(x, w, b)
+        assert torch.equal(y, plain)
+        rows = y.permute(0, 2, 3, 1).reshape(-1, 32, Cout).double()
+        parts = y._gnparts.double()
+        assert parts.shape == (N * S * S // 32, Cout, 2)
+        assert (parts[:, :, 0] - rows.sum(1)).abs().max().item() < 1e-5 * rows.sum(1).abs().max().item()
+        assert (parts[:, :, 1] - (rows * rows).sum(1)).abs().max().item() < 1e-5 * (rows * rows).sum(1).abs().max().item()
+        gamma, beta = torch.rand(Cout, device=dev, generator=g) + 0.5, torch.randn(Cout, device=dev, generator=g)
+        got = ops.group_norm_split(y, gamma, beta, None, True)
+        ref = ops.group_norm_split(plain, gamma, beta, None, True)
+    d = ((got.hi.float() + got.lo.float()) - (ref.hi.float() + ref.lo.float())).abs().max().item()
+    assert d < 2e-5, d
+
+
 # ------------------------------------------------------------------ dynamic range of the split-precision (f16x3) contractions
 def _rel(got, exact):
     return (got.double().cpu() - exact.cpu()).abs().max().item() / exact.abs().max().item()
