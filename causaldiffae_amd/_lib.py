@@ -64,6 +64,7 @@ SIGNATURES = {
     "cdae_head_conv_fwd": [P, L, P, I, P, P, P, I, I, I, I, I, P],
     "cdae_skip_gn_ok": [I, I, I, I, I],
     "cdae_linear_fwd_stream": [P, L, I, P, L, P, P, L, P, P, P, L, P, L, P, P, I, I, I, P],
+    "cdae_linear_fwd_stream_gn_part": [P, L, I, P, L, P, P, L, P, P, P, L, P, L, P, P, P, I, I, I, P],
     "cdae_linear_fwd_stream_gn": [P, L, P, P, L, P, P, P, L, P, I, I, I, I, I, P],
     "cdae_skip_gn_fwd": [P, L, I, P, L, P, P, L, P, P, P, L, P, I, P, P, I, I, I, I, I, P],
     "cdae_gn_apply_split2g": [P, I, P, I, I, P, P, I, I, I, I, P, P, P, P, P, I, I, P],

@@ -49,6 +49,7 @@ struct SkipGnParams {
     const float* bias; float* y; long ldy;
     const float* res; long ldres;                                      // optional residual rows added to y
     unsigned short* c_hi; unsigned short* c_lo;                        // optional: y also as f16 hi / lo planes (row pitch ldy), the next conv's operand
+    float* gn_part;                                                    // optional: per (32-row chunk, column) sum / sum of squares of y, [M / 32][N][2] (M % 32 == 0)
     int planes_gm;                                                     // s_hi / s_lo group-major: [K / 16][M][16] (convwin_kernel's contiguous half-windows)
     const float* coef; int silu; unsigned short* s_hi; unsigned short* s_lo; int norm_a;
     int M, N, K, HW, nimg_tab;                                         // HW = rows per image; nimg_tab = images the LDS table holds per block
@@ -351,6 +352,16 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) store_planes_sg(p, (dst - p.y) + (long)((r & 3) + 8 * (r >> 2)) * p.ldy, vv[r]);
                 }
+                if (p.gn_part) {        // this wave owns the whole 32 x 32 sub-tile: the two lane halves hold its 16 + 16 rows of a column
+                    float gs = 0.f, gq = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { gs += vv[r]; gq += vv[r] * vv[r]; }
+                    gs += __shfl_xor(gs, 32); gq += __shfl_xor(gq, 32);
+                    if (hh == 0) {
+                        float* o = p.gn_part + ((long)((m0 + wm * 64 + i * 32) >> 5) * p.N + n0 + wn * 64 + j * 32 + l31) * 2;
+                        o[0] = gs; o[1] = gq;
+                    }
+                }
             }
         if (bad && p.range_flag) *p.range_flag = 1;
         return;
@@ -362,6 +373,7 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
             const int col = n0 + wn * 64 + j * 32 + l31;
             if (col >= p.N) continue;
             const float bv = p.bias ? p.bias[col] : 0.f;
+            float gs = 0.f, gq = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -371,6 +383,14 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
                 p.y[(long)row * p.ldy + col] = v;
                 if (p.c_hi) store_planes_sg(p, (long)row * p.ldy + col, v);
                 bad |= !__builtin_isfinite(v);
+                gs += v; gq += v * v;
+            }
+            if (p.gn_part) {            // (M % 32 == 0: a chunk is inside the tensor or not at all)
+                gs += __shfl_xor(gs, 32); gq += __shfl_xor(gq, 32);
+                if (hh == 0 && m0 + wm * 64 + i * 32 < p.M) {
+                    float* o = p.gn_part + ((long)((m0 + wm * 64 + i * 32) >> 5) * p.N + col) * 2;
+                    o[0] = gs; o[1] = gq;
+                }
             }
         }
     if (bad && p.range_flag) *p.range_flag = 1;
@@ -423,7 +443,7 @@ extern "C" int cdae_skip_gn_fwd(const float* x1, long ld1, int K1, const float* 
     SkipGnParams p;
     p.x1 = x1; p.x2 = x2; p.ld1 = ld1; p.ld2 = ld2; p.K1 = K1;
     p.w_hi = w_hi; p.w_lo = w_lo; p.ldw = ldw; p.w_scale = w_scale; p.bias = bias; p.y = y; p.ldy = ldy; p.res = nullptr; p.ldres = 0; p.c_hi = nullptr; p.c_lo = nullptr;
-    p.coef = coef; p.silu = silu; p.s_hi = s_hi; p.s_lo = s_lo; p.planes_gm = planes_gm; p.norm_a = 0;
+    p.coef = coef; p.silu = silu; p.s_hi = s_hi; p.s_lo = s_lo; p.planes_gm = planes_gm; p.norm_a = 0; p.gn_part = nullptr;
     p.M = M; p.N = N; p.K = K; p.HW = HW; p.nimg_tab = skipgn_tab_images(HW);
     return skipgn_launch(p, stream);
 }
@@ -432,14 +452,23 @@ extern "C" int cdae_skip_gn_fwd(const float* x1, long ld1, int K1, const float* 
 extern "C" int cdae_linear_fwd_stream(const float* x1, long ld1, int K1, const float* x2, long ld2, const unsigned short* w_hi,
                                       const unsigned short* w_lo, long ldw, const float* w_scale, const float* bias, const float* res, long ldres, float* y, long ldy,
                                       unsigned short* c_hi, unsigned short* c_lo, int M, int N, int K, void* stream) {
+    return cdae_linear_fwd_stream_gn_part(x1, ld1, K1, x2, ld2, w_hi, w_lo, ldw, w_scale, bias, res, ldres, y, ldy, c_hi, c_lo, nullptr, M, N, K, stream);
+}
+
+// + gn_part (may be NULL; M % 32 == 0): [M / 32][N][2] per (32-row chunk, column) sum and sum of squares of y — the statistics of a GroupNorm
+// that reads y (the attention block's proj_out + residual feeds the next ResBlock's first norm) without a pass over the tensor
+extern "C" int cdae_linear_fwd_stream_gn_part(const float* x1, long ld1, int K1, const float* x2, long ld2, const unsigned short* w_hi,
+                                              const unsigned short* w_lo, long ldw, const float* w_scale, const float* bias, const float* res, long ldres,
+                                              float* y, long ldy, unsigned short* c_hi, unsigned short* c_lo, float* gn_part, int M, int N, int K, void* stream) {
     if (!x2) K1 = K;
+    if (gn_part && M % 32) return cdae_fail("linear_fwd_stream: partial sums need M % 32 == 0");
     if (M <= 0 || N <= 0 || K <= 0 || K % 32 || K1 % 32 || K1 > K) return cdae_fail("linear_fwd_stream: K (and K1) % 32 == 0 required");
     if (ld1 % 4 || (x2 && ld2 % 4) || ldw % 8 || !aligned16(x1) || !aligned16(x2) || !aligned16(w_hi) || !aligned16(w_lo) || !x1 || !w_hi || !w_lo || !y)
         return cdae_fail("linear_fwd_stream: 16-byte aligned rows and weight planes required");
     SkipGnParams p;
     p.x1 = x1; p.x2 = x2; p.ld1 = ld1; p.ld2 = ld2; p.K1 = K1;
     p.w_hi = w_hi; p.w_lo = w_lo; p.ldw = ldw; p.w_scale = w_scale; p.bias = bias; p.y = y; p.ldy = ldy; p.res = res; p.ldres = ldres; p.c_hi = c_hi; p.c_lo = c_lo;
-    p.coef = nullptr; p.silu = 0; p.s_hi = nullptr; p.s_lo = nullptr; p.planes_gm = 0; p.norm_a = 0;
+    p.coef = nullptr; p.silu = 0; p.s_hi = nullptr; p.s_lo = nullptr; p.planes_gm = 0; p.norm_a = 0; p.gn_part = gn_part;
     p.M = M; p.N = N; p.K = K; p.HW = M; p.nimg_tab = 0;
     return skipgn_launch(p, stream);
 }
@@ -455,7 +484,7 @@ extern "C" int cdae_linear_fwd_stream_gn(const float* x, long ldx, const unsigne
     SkipGnParams p;
     p.x1 = x; p.x2 = nullptr; p.ld1 = ldx; p.ld2 = 0; p.K1 = K;
     p.w_hi = w_hi; p.w_lo = w_lo; p.ldw = ldw; p.w_scale = w_scale; p.bias = bias; p.y = y; p.ldy = ldy; p.res = nullptr; p.ldres = 0; p.c_hi = nullptr; p.c_lo = nullptr;
-    p.coef = coef; p.silu = silu; p.s_hi = nullptr; p.s_lo = nullptr; p.planes_gm = 0; p.norm_a = 1;
+    p.coef = coef; p.silu = silu; p.s_hi = nullptr; p.s_lo = nullptr; p.planes_gm = 0; p.norm_a = 1; p.gn_part = nullptr;
     p.M = M; p.N = N; p.K = K; p.HW = HW; p.nimg_tab = skipgn_tab_images(HW);
     return skipgn_launch(p, stream);
 }

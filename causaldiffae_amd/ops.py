@@ -1859,6 +1859,21 @@ def emb_all_train(emb, flat):
     return slices
 
 
+def linear_stream_gn(rows, w, b, res, HW):
+    """y = rows @ w^T + b + res on the streaming GEMM (no autograd) with the partial sums of a GroupNorm that reads y attached
+    (`y._gnparts`: [M / 32][Nf][2]) — or None where that kernel does not apply (the caller takes ops.linear)."""
+    M, K = rows.shape
+    Nf = w.shape[0]
+    if not (presplit_ok() and HW % 32 == 0 and M % 32 == 0 and w.numel() == Nf * K and w.is_contiguous() and _stream_gemm_ok(rows, M, Nf, K, ACT_NONE, 1.0, res)):
+        return None
+    y = torch.empty((M, Nf), dtype=torch.float32, device=rows.device)
+    parts = torch.empty((M // 32, Nf, 2), dtype=torch.float32, device=rows.device)
+    wh, wl, wsp = split_weight(_root(w))
+    check(lib.cdae_linear_fwd_stream_gn_part(ptr(rows), rows.stride(0), K, None, 0, ptr(wh), ptr(wl), K, ptr(wsp), ptr(b), ptr(res), 0 if res is None else res.stride(0),
+                                             ptr(y), Nf, None, None, ptr(parts), M, Nf, K, stream()))
+    return y, parts
+
+
 def linear_emit(rows, w, b, res, shape):
     """y = rows @ w^T + b + res (no autograd) whose result also leaves the kernel as f16 planes: returns (y, SplitAct) for the
     logical [N, C, H, W] `shape` the rows belong to."""

@@ -253,6 +253,12 @@ class AttentionBlock(nn.Module):
             out = out.reshape(N, H, W, C).permute(0, 3, 1, 2)
             out._split = planes
             return out
+        w2 = self.proj_out.weight.reshape(C, C)
+        hit = None if th.is_grad_enabled() else ops.linear_stream_gn(a.reshape(N * T, C), w2, self.proj_out.bias, xr, T)
+        if hit is not None:                     # streaming GEMM whose epilogue leaves the next ResBlock's GroupNorm sums on the result
+            out = hit[0].reshape(N, H, W, C).permute(0, 3, 1, 2)
+            out._gnparts = hit[1]
+            return out
         out = ops.linear(a.reshape(N * T, C), self.proj_out.weight, self.proj_out.bias, res=xr)
         return out.reshape(N, H, W, C).permute(0, 3, 1, 2)
 

@@ -187,6 +187,10 @@ int cdae_skip_gn_ok(int M, int N, int K, int K1, int HW);
 int cdae_linear_fwd_stream(const float* x1, long ld1, int K1, const float* x2, long ld2, const unsigned short* w_hi, const unsigned short* w_lo,
                            long ldw, const float* w_scale, const float* bias, const float* res, long ldres, float* y, long ldy, unsigned short* c_hi, unsigned short* c_lo,
                            int M, int N, int K, void* stream);      /* c_hi / c_lo (may be NULL): y also as f16 planes, row pitch ldy */
+/* the same + gn_part (may be NULL; M % 32 == 0): [M / 32][N][2] per (32-row chunk, column) sum / sum of squares of y for cdae_gn_stats_from_parts */
+int cdae_linear_fwd_stream_gn_part(const float* x1, long ld1, int K1, const float* x2, long ld2, const unsigned short* w_hi, const unsigned short* w_lo,
+                                   long ldw, const float* w_scale, const float* bias, const float* res, long ldres, float* y, long ldy, unsigned short* c_hi,
+                                   unsigned short* c_lo, float* gn_part, int M, int N, int K, void* stream);
 /* y[M][N] = silu?(GroupNorm(x))[M][K] @ W^T + bias with the GroupNorm folded to per-(image, channel) coefficients (cdae_gn_coef) and
    applied to the fp32 rows as they are staged — GroupNorm -> 1x1 conv in one pass (AttentionBlock norm -> qkv, unet.py:213-228).
    f16x3 products on pre-split weight planes; shapes as cdae_skip_gn_ok(M, N, K, K, HW). */

@@ -1479,6 +1479,32 @@ def test_representation_loss_kernel(causal, nv):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,C,HW", [(8192, 384, 256), (4096 + 64, 512, 64)])
+def test_streaming_gemm_leaves_groupnorm_sums(M, C, HW):
+    """cdae_linear_fwd_stream_gn_part (the attention block's proj_out + residual): result bit-identical to the streaming GEMM without
+    sums, per (32-row chunk, column) sums equal to those of the result rows — also with a partial last row tile."""
+    from causaldiffae_amd import ops
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(29)
+    rows = torch.randn(M, C, device=dev, generator=g)
+    res = torch.randn(M, C, device=dev, generator=g)
+    w = torch.randn(C, C, device=dev, generator=g) / C ** 0.5
+    b = torch.randn(C, device=dev, generator=g)
+    with torch.no_grad():
+        hit = ops.linear_stream_gn(rows, w, b, res, HW)
+        assert hit is not None
+        y, parts = hit
+        plain = ops.linear(rows, w, b, res=res)
+    assert torch.equal(y, plain)
+    exact = rows.double() @ w.double().t() + b.double() + res.double()
+    assert (y.double() - exact).abs().max().item() < 6e-6 * exact.abs().max().item()
+    r3 = y.double().reshape(M // 32, 32, C)
+    assert parts.shape == (M // 32, C, 2)
+    assert (parts[:, :, 0].double() - r3.sum(1)).abs().max().item() < 1e-5 * r3.sum(1).abs().max().item()
+    assert (parts[:, :, 1].double() - (r3 * r3).sum(1)).abs().max().item() < 1e-5 * (r3 * r3).sum(1).abs().max().item()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N,Cin,Cout,S", [(3, 4, 128, 64), (5, 1, 128, 32), (2, 3, 256, 64), (2, 4, 128, 128)])
 def test_stem_conv_leaves_groupnorm_sums(N, Cin, Cout, S):
     """cdae_conv3x3_stem_gn: the input conv's result (bit-identical to the plain stem kernel) with per (32-pixel chunk, channel) sums and
