@@ -236,6 +236,9 @@ def train_bench(dev, world, rank, steps, warmup, batch, regions=1, image_size=64
             # the driver's scaling run puts EIGHT such ranks under one cgroup quota: cores they would need vs 0.8 x the quota (this process's
             # quota stands in for the node's: the 1-GPU lease and the 8-GPU node are provisioned alike)
             "host_cores_needed_at_world8": 8 * host_ms * sps / 1e3, "host_bound_risk_at_world8": bool(8 * host_ms * sps / 1e3 > 0.8 * quota),
+            # weight gradients on a second HIP stream (ops.side_launch): on where a rank has >= 2.5 host cores to itself (the stream keeps a
+            # runtime helper thread busy), i.e. OFF for eight ranks under a 16-core quota — see `world8_policy` for that configuration's numbers
+            "wgrad_side_stream": bool(__import__("causaldiffae_amd").ops.wgrad_side_stream_on()),
             "host_cpu_ms_per_step_by_thread": [[n, round(v, 2)] for n, v in per_thread[:6] if v >= 0.05],
             "dist_backend": (torch.distributed.get_backend() if world > 1 else None),
             "workload": workload or f"CausalCircuit 64x64 C=3 CausalDiffAE training step (fwd+bwd+all-reduce+AdamW/EMA), {nparams / 1e6:.1f}M params"}
@@ -288,6 +291,17 @@ def main():
     if not args.no_train:
         try:
             train = train_bench(dev, world, rank, args.train_steps, 5, args.train_batch, regions=max(1, args.regions))
+            if single and train.get("wgrad_side_stream"):
+                # what each of eight ranks under this box's quota would run: the side stream off (ops._host_cores_per_rank() < 2.5)
+                from causaldiffae_amd import ops as _ops
+                _ops._WGRAD_SIDE_ON = False
+                try:
+                    torch.cuda.empty_cache()
+                    w8 = train_bench(dev, world, rank, 20, 3, args.train_batch)
+                    train["world8_policy"] = {k: w8[k] for k in ("value", "ms_per_step", "host_cpu_ms_per_step", "host_cpu_over_step", "host_cores_needed_at_world8",
+                                                                  "host_bound_risk_at_world8", "host_cpu_ms_per_step_by_thread", "wgrad_side_stream")}
+                finally:
+                    _ops._WGRAD_SIDE_ON = True
             if single and not args.no_fp32:
                 causaldiffae_amd.set_precision("fp32")
                 try:

@@ -111,46 +111,89 @@ def _done(*cbs):
 # launch (its operands — dy, the saved activation planes — were produced there); whoever reads gradients joins first (`side_join`:
 # TrainLoop before the optimizer step / gradient norm, GradBuckets before a bucket's all-reduce).  The side stream has its own split-K
 # workspace.  Tensors the side stream reads are `record_stream`ed, so the caching allocator does not recycle them under it.
-_WGRAD_SIDE_ON = os.environ.get("CDAE_WGRAD_STREAM", "1") != "0"      # dev switch: 0 = everything on the one stream
+def _host_cores_per_rank():
+    """CPUs this rank may use: min(affinity, cgroup quota) / ranks on this node"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n / max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+
+
+# CDAE_WGRAD_STREAM: 1 / 0, default "auto" = on where the rank has at least 2.5 host cores to itself.  The second stream keeps a ROCm
+# runtime helper thread busy (measured per C64 batch-32 step: 41 -> 48 ms of process CPU for 28.5 -> 27.5 ms of wall); eight ranks under
+# a 16-core quota would then need 13.9 cores — the step would turn host-bound for a 4 % kernel-side gain.
+_WGRAD_SIDE_ON = {"1": True, "0": False}.get(os.environ.get("CDAE_WGRAD_STREAM", "auto"), None)
+# One cross-stream dependency per launch.  Handing launches over in GROUPS of 3 ... 24 (one event per group) was measured: +-0 on the
+# step and on the helper thread's CPU — the dependencies themselves are not what costs.
+_SIDE_GROUP = int(os.environ.get("CDAE_WGRAD_GROUP", "1"))
 _SIDE = {}
+
+
+def wgrad_side_stream_on():
+    global _WGRAD_SIDE_ON
+    if _WGRAD_SIDE_ON is None:
+        _WGRAD_SIDE_ON = _host_cores_per_rank() >= 2.5
+    return _WGRAD_SIDE_ON
 
 
 def _side(dev):
     st = _SIDE.get(dev.index)
     if st is None:
-        st = _SIDE[dev.index] = dict(stream=torch.cuda.Stream(device=dev), dirty=False)
+        st = _SIDE[dev.index] = dict(stream=torch.cuda.Stream(device=dev), dirty=False, pending=[], hooked=False)
     return st
+
+
+def _side_flush(sd, dev):
+    if not sd["pending"]:
+        return
+    side = sd["stream"]
+    side.wait_stream(torch.cuda.current_stream(dev))
+    ws, wsb = ptr(workspace(dev, "splitk_side", SPLITK_BYTES)), SPLITK_BYTES
+    for tensors, fn in sd["pending"]:
+        for t in tensors:
+            if t is not None:
+                t.record_stream(side)
+        fn(side.cuda_stream, ws, wsb)
+    sd["pending"] = []
+    sd["dirty"] = True
 
 
 def side_launch(dev, tensors, fn):
     """Run `fn(raw_stream, splitk_ws_ptr, splitk_ws_bytes)` — a wgrad launch that accumulates into the flat gradient buffer — on the
-    side stream, behind everything issued to the current stream so far.  `tensors`: what the launch reads (kept alive for it)."""
-    if not _WGRAD_SIDE_ON:
+    side stream, behind everything issued to the current stream so far (possibly a little later: launches are flushed in groups).
+    `tensors`: what the launch reads — kept alive until the flush, then `record_stream`ed.  They must not be overwritten afterwards."""
+    if not wgrad_side_stream_on():
         ws, wsb = _sk(dev)
         fn(stream(), ws, wsb)
         return
     sd = _side(dev)
-    side = sd["stream"]
-    side.wait_stream(torch.cuda.current_stream(dev))
-    for t in tensors:
-        if t is not None:
-            t.record_stream(side)
-    fn(side.cuda_stream, ptr(workspace(dev, "splitk_side", SPLITK_BYTES)), SPLITK_BYTES)
-    if not sd["dirty"]:
-        sd["dirty"] = True
+    sd["pending"].append((tensors, fn))
+    if not sd["hooked"]:
         # the stream that called backward() joins the side stream when the backward pass ends: `.backward()` then returns with every
         # gradient ordered behind it on that stream, like a single-stream backward (and a graph capture of the step closes its fork)
         try:
             torch.autograd.Variable._execution_engine.queue_callback(side_join)
+            sd["hooked"] = True
         except RuntimeError:        # not inside a backward pass: the caller joins (side_join)
             pass
+    if len(sd["pending"]) >= _SIDE_GROUP:
+        _side_flush(sd, dev)
 
 
 def side_join(dev=None):
-    """The current stream waits for every wgrad launch issued to the side stream so far (no host sync)."""
+    """The current stream waits for every wgrad launch handed to side_launch so far (no host sync)."""
     for idx, sd in _SIDE.items():
-        if sd["dirty"] and (dev is None or dev.index == idx):
-            torch.cuda.current_stream(sd["stream"].device).wait_stream(sd["stream"])
+        if dev is not None and dev.index != idx:
+            continue
+        sd["hooked"] = False
+        sdev = sd["stream"].device
+        _side_flush(sd, sdev)
+        if sd["dirty"]:
+            torch.cuda.current_stream(sdev).wait_stream(sd["stream"])
             sd["dirty"] = False
 
 
@@ -1710,7 +1753,7 @@ class _ResBlockPS(Function):
         dyn2, dw2, dc2b = _rb_conv_bwd(bplanes2, dplanes, w2, (sw2, sc2b), has_c2b, (N, Cout, H, W), Cout, need[9], st)
         # dh leaves GN2's backward as bf16 planes only (it is nothing but conv1's dy).  (A buffer of its own: conv2's wgrad may still be
         # reading `dplanes` on the side stream.)
-        dplanes = torch.empty_like(dplanes) if _WGRAD_SIDE_ON else dplanes
+        dplanes = torch.empty_like(dplanes) if wgrad_side_stream_on() else dplanes
         dg2, db2, dss = gn_bwd(h, dyn2, stats2, g2, b2, ss, (sg2, sb2), Cout, None, False, None, dplanes)
         del dyn2
         # ---- first half: conv1, then GN1 with the residual gradient folded in
@@ -1731,7 +1774,7 @@ class _ResBlockPS(Function):
                 dx = new_act(N, C, H, W, dev)
                 check(lib.cdae_linear_dgrad(ptr(dout), Cout, ptr(sw), C, ptr(dx), C, M, Cout, C, 0, ws, wsb, st))
                 dg1, db1, _ = gn_bwd(x, dyn1, stats1, g1, b1, None, (sg1, sb1), C, dx, True, None, None)
-                def wg(st_, ws_, wsb_):
+                def wg(st_, ws_, wsb_, dsw=dsw, dsb=dsb):        # (bound now: the launch may run after these names were cleared)
                     check(lib.cdae_linear_wgrad(ptr(x), C, ptr(dout), Cout, ptr(dsw), C, ptr(dsb), M, Cout, C, acc, ws_, wsb_, st_))
                 side_launch(dev, (x, dout), wg) if direct else wg(st, ws, wsb)
             else:
@@ -1752,7 +1795,7 @@ class _ResBlockPS(Function):
                 if dirn:
                     dg1 = db1 = None
                     _done(rg, rb_)
-                def wg(st_, ws_, wsb_):
+                def wg(st_, ws_, wsb_, dsw=dsw, dsb=dsb):
                     check(lib.cdae_linear_wgrad(ptr(x), C1, ptr(dout), Cout, ptr(dsw), C, ptr(dsb), M, Cout, C1, acc, ws_, wsb_, st_))
                     check(lib.cdae_linear_wgrad(ptr(x2), C2, ptr(dout), Cout, dsw.data_ptr() + 4 * C1, C, None, M, Cout, C2, acc, ws_, wsb_, st_))
                 side_launch(dev, (x, x2, dout), wg) if direct else wg(st, ws, wsb)
