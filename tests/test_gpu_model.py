@@ -745,6 +745,27 @@ def test_training_step_batch_invariance_at_benchmark_batch(golden, expect_kernel
     _, sq2 = run(B, True)
     assert np.isfinite(sq1) and sq1 > 0 and abs(sq1 - sq2) <= 1e-6 * sq1, (sq1, sq2)
 
+    # GRADIENTS at the benchmark batch (round-3 review): with samples 2..31 weighted zero the batch-32 loss IS the batch-2 loss, so every
+    # parameter gradient of the batch-32 backward (convwin dgrad, window wgrad, split-K finishes, the side stream) must equal the batch-2
+    # backward's (small-grid kernels) — 2e-4 of each gradient's own maximum, the bar of the reference-gradient fixtures
+    def grads_of(n, mask):
+        for p in model.parameters():
+            p.grad = None
+        with rng_override(eps_z=eb[:n]):
+            terms = diff.training_losses(model, x0b[:n], tb[:n], model_kwargs=dict(c=cb[:n]), noise=nb[:n], rep_cond=True, causal_modeling=True)
+        ((terms["loss"] * mask).sum() / mask.sum()).backward()
+        torch.cuda.synchronize()
+        return {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    g2 = grads_of(2, torch.ones(2, device=DEV))
+    mask = torch.zeros(B, device=DEV)
+    mask[:2] = 1.0
+    with expect_kernels(convwin_dgrad=30):
+        g32 = grads_of(B, mask)
+    assert set(g2) == set(g32) and len(g2) > 300, (len(g2), len(g32), sorted(set(g2) ^ set(g32))[:6])
+    worst = max((err(g32[k], g2[k]) / max(float(g2[k].abs().max()), 1e-30), k) for k in g2 if float(g2[k].abs().max()) > 0)
+    assert worst[0] < 2e-4, worst
+
 # ------------------------------------------------------------------ G15: BASELINE config [1] — reduced-precision torso at batch 256
 def test_mixed16_m32_batch256_loss_curve_golden(golden):
     """BASELINE 'MorphoMNIST 32x32 CausalDiffAE training, bf16, batch 256': three optimizer steps of the `mixed16` torso (single
