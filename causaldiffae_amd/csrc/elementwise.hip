@@ -65,10 +65,18 @@ __global__ __launch_bounds__(256) void wscale_max_kernel(const float* __restrict
     const long c1 = c0 + WS_CHUNK < d.n ? c0 + WS_CHUNK : d.n;
     const float* w = flat + d.off;
     unsigned m = 0;
-    for (long i = c0 + threadIdx.x; i < c1; i += 256) {
-        const unsigned b = __builtin_bit_cast(unsigned, w[i]) & 0x7FFFFFFFu;      // |w| as an integer: monotone in the magnitude, NaN sorts above inf
-        m = b > m ? b : m;
+    // |w| as an integer: monotone in the magnitude, NaN sorts above inf.  16-byte loads over the aligned middle of the chunk (tensor offsets
+    // in the flat buffer are arbitrary), scalar loads for the ends
+    const long a0 = c0 + ((4 - ((d.off + c0) & 3)) & 3);                          // first element whose address is 16-byte aligned
+    const long a1 = a0 <= c1 ? a0 + ((c1 - a0) & ~3L) : c1;
+    for (long i = c0 + threadIdx.x; i < (a0 < c1 ? a0 : c1); i += 256) { const unsigned b = __builtin_bit_cast(unsigned, w[i]) & 0x7FFFFFFFu; m = b > m ? b : m; }
+    for (long i = a0 + 4L * threadIdx.x; i + 3 < a1 + 0 && i < a1; i += 1024) {
+        const uint4 v = *reinterpret_cast<const uint4*>(w + i);
+        const unsigned b0 = v.x & 0x7FFFFFFFu, b1 = v.y & 0x7FFFFFFFu, b2 = v.z & 0x7FFFFFFFu, b3 = v.w & 0x7FFFFFFFu;
+        const unsigned p0 = b0 > b1 ? b0 : b1, p1 = b2 > b3 ? b2 : b3, pm = p0 > p1 ? p0 : p1;
+        m = pm > m ? pm : m;
     }
+    for (long i = (a1 > c0 ? a1 : c0) + threadIdx.x; i < c1; i += 256) { const unsigned b = __builtin_bit_cast(unsigned, w[i]) & 0x7FFFFFFFu; m = b > m ? b : m; }
     for (int o = 32; o; o >>= 1) { const unsigned t = __shfl_xor(m, o); m = t > m ? t : m; }
     __shared__ unsigned wm[4];
     if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;

@@ -1641,12 +1641,13 @@ def test_weight_scale_records():
     for t in cases:
         rec = ops.weight_scale(t)
         assert tuple(rec.tolist()) == expect(t), (t.flatten()[:4], rec.tolist(), expect(t))
-    # the table form: tensors packed into one flat buffer (offsets multiples of 4 elements)
+    # the table form: tensors packed into one flat buffer at ARBITRARY element offsets (the max pass reads 16-byte vectors over the aligned
+    # middle of a chunk and scalars at its ends)
     lens = [t.numel() for t in cases]
-    offs, o = [], 0
-    for n in lens:
+    offs, o = [], 1
+    for k, n in enumerate(lens):
         offs.append(o)
-        o += (n + 3) // 4 * 4
+        o += n + (k % 3)
     flat = torch.zeros(o, device=dev)
     views = []
     for t, of in zip(cases, offs):
