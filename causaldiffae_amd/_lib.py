@@ -46,6 +46,8 @@ SIGNATURES = {
     "cdae_split_bf16": [P, P, P, L, P],
     "cdae_upsample2_split": [P, P, P, P, P, I, I, I, I, P],
     "cdae_wdgrad_planes": [P, P, P, I, I, P],
+    "cdae_s2dgrad_wfold": [P, P, P, I, I, P],
+    "cdae_conv3x3_s2_dgrad_ps": [P, P, P, P, P, L, I, I, I, I, I, P, SZ, P],
     "cdae_wprep_all": [P, P, I, I, L, P, P, P, P, P],
     "cdae_wprep_all_k": [P, P, I, I, L, P, P, P, P, P, P, P, P, P, P],
     "cdae_conv3x3_dgrad_ps": [P, P, P, P, P, L, I, I, I, I, I, P, SZ, P],

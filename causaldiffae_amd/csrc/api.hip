@@ -258,6 +258,41 @@ int cdae_conv3x3_wgrad(const float* x, long sn, long sy, long sx, long sc, const
     return rc;
 }
 
+// dgrad of a STRIDE-2 conv3x3 (pad 1) on the pre-split kernels, as four 2 x 2 sub-pixel convolutions of dy (elementwise.hip s2dgrad_wfold_kernel):
+// dy bf16 hi / lo planes [N, Ho, Wo, Cout] dense, w4 the folded bf16 planes [4][Cin][2][2][Cout] (cdae_s2dgrad_wfold), dx fp32 [N, 2 Ho, 2 Wo, Cin]
+// rows of pitch lddx.  Returns 0, -1 (error) or 2 (shape not taken: the caller runs cdae_conv3x3_dgrad).
+int cdae_conv3x3_s2_dgrad_ps(const unsigned short* dy_hi, const unsigned short* dy_lo, const unsigned short* w4_hi, const unsigned short* w4_lo, float* dx,
+                             long lddx, int N, int Ho, int Wo, int Cin, int Cout, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    if (Cout % 32 || Cin % 4 || Wo < 2 || (Wo & (Wo - 1)) || (long)N * Ho * Wo * Cout >= (1L << 31)) return 2;
+    if (!aligned16(dy_hi) || !aligned16(dy_lo) || !aligned16(w4_hi) || !aligned16(w4_lo)) return cdae_fail("conv3x3_s2_dgrad_ps: planes must be 16-byte aligned");
+    for (int ph = -1; ph < 4; ++ph) {      // ph = -1: all four phases as one launch of the window kernel
+        GemmParams p = base_params();
+        const bool all = ph < 0;
+        if (all) { ph = 0; p.nphase = 4; p.phase_w = (long)Cin * 4 * Cout; }
+        p.presplit = 1; p.ps_taps = 4; p.ph_y = ph >> 1; p.ph_x = ph & 1; p.grad_operand = 1;
+        const long woff = (long)ph * Cin * 4 * Cout;
+        p.A = reinterpret_cast<const float*>(dy_hi); p.A_lo = dy_lo;
+        p.B = reinterpret_cast<const float*>(w4_hi + woff); p.B_lo = w4_lo + woff;
+        p.C = dx;
+        p.M = N * Ho * Wo; p.N = Cin; p.K = 4 * Cout;
+        p.ldb = 4L * Cout; p.ldc = lddx;
+        p.out_mode = OUT_UP2;
+        p.amode = A_CONV_VEC; p.bmode = B_PLAIN_KC;
+        p.conv_M = p.M; p.H = Ho; p.W = Wo; p.Cin = Cout; p.Ho = Ho; p.Wo = Wo; p.stride = 1; p.up = 0;
+        p.sn = (long)Ho * Wo * Cout; p.sy = (long)Wo * Cout; p.sx = Cout; p.sc = 1;
+        set_splitk(p, all ? nullptr : splitk_ws, splitk_ws_bytes);
+        const int rc = cdae_gemm_dispatch(p, stream);
+        if (all) {
+            if (rc == 0) return 0;
+            if (rc != 2) return rc;
+            ph = -1;
+            continue;
+        }
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 // dgrad of a stride-1 conv3x3 on the pre-split kernels: dx = conv3x3(dy, wt), dy as bf16 hi/lo planes (cdae_split_bf16, dense NHWC,
 // pixel pitch Cout) and wt = the flipped / transposed weight planes of cdae_wdgrad_planes ([Cin][9][Cout])
 int cdae_conv3x3_dgrad_ps(const unsigned short* dy_hi, const unsigned short* dy_lo, const unsigned short* wt_hi, const unsigned short* wt_lo,

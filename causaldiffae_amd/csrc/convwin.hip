@@ -584,7 +584,7 @@ bool cdae_convwin_ok(const GemmParams& p) {
     if (p.prec < 1 || p.prec > 4) return false;                           // 1 / 2: f16 / bf16 plane pairs; 3 / 4: one f16 / bf16 plane (3x3 only)
     if (p.prec > 2 && p.ps_taps == 4) return false;
     if (p.gn_coef || p.A2 || p.act != ACT_NONE) return false;
-    if (p.ps_taps == 4 ? (p.out_mode != OUT_UP2 || p.prec != 1 || p.Bk_hi) : p.out_mode != OUT_ROWMAJOR) return false;
+    if (p.ps_taps == 4 ? (p.out_mode != OUT_UP2 || (p.prec != 1 && p.prec != 2) || p.Bk_hi) : p.out_mode != OUT_ROWMAJOR) return false;      // (4 taps, bf16: the stride-2 conv's dgrad as sub-pixel phases)
     if (p.W != 8 && p.W != 16 && p.W != 32 && p.W != 64) return false;            // tight window: tiles start on image-row boundaries
     if (p.Cin % 32 || p.ldb % 8 || p.sx % 8) return false;
     if ((long)p.M * p.sx * 2 >= (1L << 32) || (long)p.N * p.ldb * 2 >= (1L << 32)) return false;      // 32-bit byte offsets in the DMAs
@@ -594,7 +594,7 @@ bool cdae_convwin_ok(const GemmParams& p) {
 
 int cdae_convwin_launch(const GemmParams& p, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    if (p.ps_taps == 4) return launch_convwin<false, 4>(p, st);
+    if (p.ps_taps == 4) return p.prec == 2 ? launch_convwin<true, 4>(p, st) : launch_convwin<false, 4>(p, st);
     if (p.prec == 3) return launch_convwin<false, 9, 1>(p, st);          // mixed16: one f16 plane
     if (p.prec == 4) return launch_convwin<true, 9, 1>(p, st);           // mixed16, gradient operand: one bf16 plane
     if (p.cw_nj == 3 && p.prec == 1) return launch_convwin<false, 9, 2, 3>(p, st);      // planes.hip chose the tile width

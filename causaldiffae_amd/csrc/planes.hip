@@ -541,7 +541,7 @@ int cdae_planes_dispatch(GemmParams& p, int big, int& ks, hipStream_t st) {
     const int kin = p.amode == A_CONV_VEC ? p.Cin : p.K;
     if (kin % BK || p.K % BK || p.ldb % 8 || (p.amode == A_PLAIN_KC && p.lda % 8) || (p.prec < 1 || p.prec > 4))
         return cdae_fail("pre-split operands: need K (Cin) % 32 == 0, 16-byte aligned rows and a 16-bit split precision mode");
-    if ((p.prec == 2 || p.prec == 4) && (p.gn_coef || p.ps_taps == 4)) return cdae_fail("pre-split bf16 planes: plain conv3x3 / GEMM only");
+    if ((p.prec == 2 || p.prec == 4) && (p.gn_coef || (p.ps_taps == 4 && p.prec == 4))) return cdae_fail("pre-split bf16 planes: plain conv3x3 / GEMM / bf16x3 sub-pixel phases only");
     if (p.gn_coef) return cdae_fail("GroupNorm applied inside the conv kernel was removed (measured slower than writing planes once)");
     p.dbg = CDAE_DEV_INT("CDAE_PS_DBG", 0);
     // cdae_tune_set(CDAE_TUNE_CONVWIN_MIN_TILES, <= 1): every shape convwin_kernel can take runs on it, whatever the grid size (the

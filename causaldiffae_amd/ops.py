@@ -241,7 +241,8 @@ class _Conv3x3(Function):
                 check(lib.cdae_sumpool2(ptr(dxu), ptr(dx), N, H, W, Cin, stream()))
             else:
                 dx = new_act(N, Cin, H, W, dev)
-                check(lib.cdae_conv3x3_dgrad(ptr(dy), Cout, ptr(w), ptr(dx), Cin, N, H, W, Cin, Cout, stride, 0, 0, ws, wsb, stream()))
+                if not (stride == 2 and _s2_dgrad_ps(dy, w, dx, N, H, W, Cin, Cout, ws, wsb)):
+                    check(lib.cdae_conv3x3_dgrad(ptr(dy), Cout, ptr(w), ptr(dx), Cin, N, H, W, Cin, Cout, stride, 0, 0, ws, wsb, stream()))
         if ctx.needs_input_grad[1]:
             (gw, rw), (gb, rb) = ctx.sinks
             direct = gw is not None and w.stride() == gw.stride() and (not has_b or gb is not None)
@@ -262,6 +263,36 @@ class _Conv3x3(Function):
         if has_res and ctx.needs_input_grad[3]:
             dres = dy
         return dx, dw, db, dres, None, None, None
+
+
+_S2DGRAD = {}
+_S2DGRAD_ON = os.environ.get("CDAE_S2_DGRAD_PS", "1") != "0"      # dev switch: 0 = the stride-2 dgrad through the fp32-operand gather kernel
+
+
+def _s2_dgrad_ps(dy, w, dx, N, H, W, Cin, Cout, ws, wsb):
+    """dgrad of a stride-2 conv3x3 (Downsample) as four sub-pixel phases on the plane kernels (bf16x3 products, like every gradient
+    contraction of the f16x3 mode): True when it ran.  The folded weight planes are cached per weight version."""
+    from ._lib import get_precision
+    if not (_S2DGRAD_ON and get_precision() == "f16x3" and H % 2 == 0 and W % 2 == 0 and Cout % 32 == 0 and Cin % 4 == 0 and (W // 2) & (W // 2 - 1) == 0
+            and W // 2 >= 8 and w.permute(0, 2, 3, 1).is_contiguous()):
+        return False
+    tag = (w.data_ptr(), w._version, _WEIGHT_EPOCH[0])
+    hit = _S2DGRAD.get(id(w))
+    if hit is None or hit[0]() is not w or hit[1] != tag:
+        planes = torch.empty((2, 16 * Cin * Cout), dtype=torch.bfloat16, device=w.device)
+        check(lib.cdae_s2dgrad_wfold(ptr(w), *ptr2(planes), Cout, Cin, stream()))
+        if len(_S2DGRAD) > 256:
+            for k in [k for k, v in _S2DGRAD.items() if v[0]() is None]:
+                del _S2DGRAD[k]
+        hit = _S2DGRAD[id(w)] = (weakref.ref(w), tag, planes)
+    Ho, Wo = H // 2, W // 2
+    dplanes = torch.empty((2, N, Ho, Wo, Cout), dtype=torch.bfloat16, device=dy.device)
+    check(lib.cdae_split_bf16(ptr(dy), *ptr2(dplanes), dy.numel(), stream()))
+    rc = lib.cdae_conv3x3_s2_dgrad_ps(*ptr2(dplanes), *ptr2(hit[2]), ptr(dx), Cin, N, Ho, Wo, Cin, Cout, ws, wsb, stream())
+    if rc == 2:
+        return False
+    check(rc)
+    return True
 
 
 def conv3x3(x, w, b=None, res=None, stride=1, up=False, out_nchw=False):

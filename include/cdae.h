@@ -254,6 +254,13 @@ int cdae_upsample2_split(const float* x, unsigned short* f_hi, unsigned short* f
                          int W, int C, void* stream);
 int cdae_split_bf16(const float* src, unsigned short* hi, unsigned short* lo, long n, void* stream);
 int cdae_wdgrad_planes(const float* w, unsigned short* hi, unsigned short* lo, int Cout, int Cin, void* stream);
+/* dgrad of a STRIDE-2 conv3x3 (Downsample, unet.py:82-105) as four 2x2 sub-pixel convolutions of dy on the plane kernels (2.25x fewer
+   multiply-adds than the masked 9-tap gather of cdae_conv3x3_dgrad): cdae_s2dgrad_wfold writes the folded bf16 hi / lo weight planes
+   [4 phases][Cin][2][2][Cout] of an OHWI weight; cdae_conv3x3_s2_dgrad_ps takes dy as bf16 planes [N, Ho, Wo, Cout] and writes
+   dx [N, 2 Ho, 2 Wo, Cin] (rows of pitch lddx).  Returns 2 (no error set) for a shape it does not take. */
+int cdae_s2dgrad_wfold(const float* w, unsigned short* hi, unsigned short* lo, int Cout, int Cin, void* stream);
+int cdae_conv3x3_s2_dgrad_ps(const unsigned short* dy_hi, const unsigned short* dy_lo, const unsigned short* w4_hi, const unsigned short* w4_lo, float* dx,
+                             long lddx, int N, int Ho, int Wo, int Cin, int Cout, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
 /* cdae_split_f16 + cdae_wdgrad_planes for MANY conv3x3 weights in one launch (once per optimizer step).  The weights live in one
    fp32 buffer `flat`; desc = nw records {long offset (elements); int Cout, Cin, first_tile, pad} with first_tile the running sum of
    9 * ceil(Cout/32) * ceil(Cin/32); every output plane is addressed by (weight offset - base). */

@@ -1532,6 +1532,37 @@ def test_stem_conv_leaves_groupnorm_sums(N, Cin, Cout, S):
     assert d < 2e-5, d
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,Cin,Cout,S", [(32, 128, 128, 64), (8, 256, 256, 32), (4, 384, 384, 16), (2, 64, 96, 16), (3, 32, 64, 32)])
+def test_stride2_conv_dgrad_as_subpixel_phases(N, Cin, Cout, S, expect_kernels):
+    """dgrad of the Downsample conv (stride 2, pad 1: reference unet.py:82-105) as four 2 x 2 sub-pixel convolutions of dy on the plane
+    kernels (cdae_conv3x3_s2_dgrad_ps: the window kernel's 4-tap bf16 instantiation where the grid fills the chip, the small-grid plane
+    kernels phase by phase elsewhere) against conv2d's autograd in fp64 at the gradient bar (2e-4 of the gradient's maximum; bf16x3 =
+    2^-16 products), and against the masked 9-tap gather it replaces."""
+    from causaldiffae_amd import ops
+    g = torch.Generator(device="cuda:0").manual_seed(61)
+    x = ops.to_nhwc(torch.randn(N, Cin, S, S, device="cuda:0", generator=g)).requires_grad_(True)
+    w = (torch.randn(Cout, Cin, 3, 3, device="cuda:0", generator=g) / (9 * Cin) ** 0.5).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    gy = torch.randn(N, Cout, S // 2, S // 2, device="cuda:0", generator=g) * 1e-3          # gradient-sized values
+    from causaldiffae_amd._lib import precision_scope
+    with precision_scope("f16x3"):
+        y = ops.conv3x3(x, w, None, stride=2)
+        want = dict(convwin_up=1) if N * (S // 2) ** 2 // 256 * ((Cin + 127) // 128) * 4 >= 256 and (Cout // 32) < 6 else {}
+        with expect_kernels(**want):
+            (dx_new,) = torch.autograd.grad(y, x, gy, retain_graph=True)
+        ops._S2DGRAD_ON = False
+        try:
+            (dx_old,) = torch.autograd.grad(y, x, gy, retain_graph=True)
+        finally:
+            ops._S2DGRAD_ON = True
+    xd, wd = x.detach().double().contiguous().requires_grad_(True), w.detach().double()
+    (dx_ref,) = torch.autograd.grad(F.conv2d(xd, wd, stride=2, padding=1), xd, gy.double())
+    scale = dx_ref.abs().max().item()
+    assert torch.isfinite(dx_new).all()
+    assert (dx_new.double() - dx_ref).abs().max().item() < 2e-4 * scale, (dx_new.double() - dx_ref).abs().max().item() / scale
+    assert (dx_old.double() - dx_ref).abs().max().item() < 2e-4 * scale
+
+
 # ------------------------------------------------------------------ dynamic range of the split-precision (f16x3) contractions
 def _rel(got, exact):
     return (got.double().cpu() - exact.cpu()).abs().max().item() / exact.abs().max().item()
