@@ -199,11 +199,28 @@ def ptr2(t):
 
 _ws = {}
 _ws_retired = []
+_WS_LANE = [0]
+
+
+class ws_lane:
+    """with ws_lane(k): ... — the scratch buffers (`workspace`) of lane k.  Work issued to DIFFERENT streams that may overlap on the device
+    must not share split-K slabs / norm partials: each concurrent stream of launches runs under its own lane (lane 0 = the default)."""
+
+    def __init__(self, k):
+        self.k, self.prev = int(k), 0
+
+    def __enter__(self):
+        self.prev, _WS_LANE[0] = _WS_LANE[0], self.k
+        return self
+
+    def __exit__(self, *exc):
+        _WS_LANE[0] = self.prev
+        return False
 
 
 def workspace(device, name, nbytes):
-    """Persistent per-device scratch buffers (split-K slabs, norm partials); grown on demand, never shrunk."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), name)
+    """Persistent per-device (and per-lane, see ws_lane) scratch buffers (split-K slabs, norm partials); grown on demand, never shrunk."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _WS_LANE[0], name)
     buf = _ws.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
         if buf is not None:
