@@ -934,21 +934,27 @@ class ScaleTable:
         self.desc = torch.from_numpy(desc.view(np.uint8).copy()).to(dev)
         self.records = torch.ones((len(self.tensors), 2), dtype=torch.float32, device=dev)
         self.scratch = torch.zeros(len(self.tensors), dtype=torch.int32, device=dev)
-        self.epoch, self.versions = None, None
+        self.epoch, self.versions, self._views = None, [None] * len(self.tensors), {}
         for t in self.tensors:
             _SCALE_OF[id(t)] = (weakref.ref(t), self)
 
-    def refresh(self):
-        if self.epoch != _WEIGHT_EPOCH[0] or self.versions != [t._version for t in self.tensors]:
-            check(lib.cdae_weight_scales(ptr(self.flat), ptr(self.desc), len(self.tensors), self.chunks, ptr(self.records), ptr(self.scratch), stream()))
-            self.epoch, self.versions = _WEIGHT_EPOCH[0], [t._version for t in self.tensors]
+    def refresh(self, t=None):
+        """One pass over all tensors when the weight epoch moved (the optimizer kernel rewrote the flat buffer) or the asked-for tensor's
+        autograd version did (an in-place torch op); the common call is two comparisons (this runs ~150 times per training step)."""
+        if self.epoch == _WEIGHT_EPOCH[0] and (t is None or self.versions[self.index[id(t)]] == t._version):
+            return
+        check(lib.cdae_weight_scales(ptr(self.flat), ptr(self.desc), len(self.tensors), self.chunks, ptr(self.records), ptr(self.scratch), stream()))
+        self.epoch, self.versions = _WEIGHT_EPOCH[0], [x._version for x in self.tensors]
 
     def record(self, t):
-        self.refresh()
-        return self.records[self.index[id(t)]]
+        self.refresh(t)
+        hit = self._views.get(id(t))
+        if hit is None:
+            hit = self._views[id(t)] = self.records[self.index[id(t)]]
+        return hit
 
     def pointer(self, t):
-        self.refresh()
+        self.refresh(t)
         return self.records.data_ptr() + 8 * self.index[id(t)]
 
 
