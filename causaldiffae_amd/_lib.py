@@ -47,6 +47,8 @@ SIGNATURES = {
     "cdae_upsample2_split": [P, P, P, P, P, I, I, I, I, P],
     "cdae_wdgrad_planes": [P, P, P, I, I, P],
     "cdae_s2dgrad_wfold": [P, P, P, I, I, P],
+    "cdae_wt_planes_bf16": [P, L, P, P, I, I, P],
+    "cdae_linear_dgrad_stream": [P, L, P, P, L, P, L, I, I, I, P],
     "cdae_conv3x3_s2_dgrad_ps": [P, P, P, P, P, L, I, I, I, I, I, P, SZ, P],
     "cdae_wprep_all": [P, P, I, I, L, P, P, P, P, P],
     "cdae_wprep_all_k": [P, P, I, I, L, P, P, P, P, P, P, P, P, P, P],

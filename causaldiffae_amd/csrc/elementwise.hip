@@ -235,6 +235,23 @@ __global__ __launch_bounds__(256) void wprep_all_kernel(const float* __restrict_
     }
 }
 
+// W [N][K] (row pitch ldw) -> bf16 hi / lo planes of W^T, [K][N] dense: the weight operand of the streaming dgrad GEMM (skipgn.hip,
+// cdae_linear_dgrad_stream: dx = dy @ W reads W^T rows K-contiguous).  32 x 32 tiles through LDS.
+__global__ __launch_bounds__(256) void wt_planes_bf16_kernel(const float* __restrict__ w, long ldw, __bf16* __restrict__ hi, __bf16* __restrict__ lo, int N, int K) {
+    __shared__ float tile[32][33];
+    const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) tile[r][tx] = (n0 + r < N && k0 + tx < K) ? w[(long)(n0 + r) * ldw + k0 + tx] : 0.f;
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int k = k0 + r, n = n0 + tx;
+        if (k < K && n < N) {
+            const float v = tile[tx][r];
+            const __bf16 h = (__bf16)v;
+            hi[(long)k * N + n] = h; lo[(long)k * N + n] = (__bf16)(v - (float)h);
+        }
+    }
+}
+
 // dgrad of a STRIDE-2 conv3x3 (pad 1; the UNet's Downsample, reference unet.py:82-105) as four sub-pixel phases: input pixel (2y + py, 2x + px)
 // receives dy[(2y + py + 1 - ky) / 2][...] w[ky] for the ky of matching parity — py = 0: ky = 1 (dy row y); py = 1: ky = 2 (row y) and ky = 0
 // (row y + 1).  That is the 2 x 2 window of convwin_kernel's 4-tap form (tap t reads low-res row y - 1 + t / 2 + py): folded weights
@@ -709,6 +726,11 @@ int cdae_wprep_all_k(const float* flat, const void* desc, int nw, int total_tile
     hipLaunchKernelGGL(wprep_all_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, flat, (const WPrepDesc*)desc, nw, base, (_Float16*)f_hi,
                        (_Float16*)f_lo, (__bf16*)b_hi, (__bf16*)b_lo, (_Float16*)kf_hi, (_Float16*)kf_lo, (__bf16*)kb_hi, (__bf16*)kb_lo, w_scales);
     return hipGetLastError() == hipSuccess ? 0 : cdae_fail("wprep_all launch failed");
+}
+int cdae_wt_planes_bf16(const float* w, long ldw, unsigned short* hi, unsigned short* lo, int N, int K, void* stream) {
+    if (N <= 0 || K <= 0 || !w || !hi || !lo) return cdae_fail("wt_planes_bf16: empty weight");
+    hipLaunchKernelGGL(wt_planes_bf16_kernel, dim3((K + 31) / 32, (N + 31) / 32), dim3(256), 0, ST, w, ldw, (__bf16*)hi, (__bf16*)lo, N, K);
+    return hipGetLastError() == hipSuccess ? 0 : cdae_fail("wt_planes_bf16 launch failed");
 }
 int cdae_s2dgrad_wfold(const float* w, unsigned short* hi, unsigned short* lo, int Cout, int Cin, void* stream) {
     if (Cout <= 0 || Cin <= 0 || !w || !hi || !lo) return cdae_fail("s2dgrad_wfold: empty weight");

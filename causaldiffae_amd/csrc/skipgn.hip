@@ -64,12 +64,22 @@ constexpr int SG_TILES = 2 * SG_STAGE;                                 // two st
 __device__ __attribute__((aligned(16))) unsigned g_zero_sg[4] = {0u, 0u, 0u, 0u};
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// BF: bf16 hi / lo (16 significand bits, fp32's exponent range) — the operand is a GRADIENT (the streaming dgrad GEMM)
+template <bool BF = false>
 __device__ __forceinline__ void split8(const f32x4& u, const f32x4& v, u16x8& hi, u16x8& lo) {
     float f[8] = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
-    half8 h, l;
+    if constexpr (BF) {
+        bf16x8 h, l;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { h[i] = (_Float16)f[i]; l[i] = (_Float16)(f[i] - (float)h[i]); }
-    hi = __builtin_bit_cast(u16x8, h); lo = __builtin_bit_cast(u16x8, l);
+        for (int i = 0; i < 8; ++i) { h[i] = (__bf16)f[i]; l[i] = (__bf16)(f[i] - (float)h[i]); }
+        hi = __builtin_bit_cast(u16x8, h); lo = __builtin_bit_cast(u16x8, l);
+    } else {
+        half8 h, l;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { h[i] = (_Float16)f[i]; l[i] = (_Float16)(f[i] - (float)h[i]); }
+        hi = __builtin_bit_cast(u16x8, h); lo = __builtin_bit_cast(u16x8, l);
+    }
 }
 
 __device__ __forceinline__ void store_planes_sg(const SkipGnParams& p, long addr, float v) {      // as igemm.hip store_planes
@@ -82,7 +92,9 @@ __device__ __forceinline__ void store_planes_sg(const SkipGnParams& p, long addr
 
 // NORMA: the GEMM operand itself is the normalised row, silu?(x * a + b) (a GroupNorm in front of a 1x1 conv: the attention block's qkv) —
 // every block folds the coefficients into the rows it stages; no plane side output in that mode.
-template <bool NORMA>
+// BF: bf16 planes and MFMAs — x is a gradient (dy) and the weight planes are the bf16 hi / lo planes of W^T: dx = dy @ W as a streaming GEMM
+// (no GroupNorm side, no plane outputs in that form).
+template <bool NORMA, bool BF = false>
 __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* const lds = reinterpret_cast<char*>(smem);
@@ -203,10 +215,10 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
         SG_WAIT_X(cnt, x0a, x0b, x1a, x1b);
         if constexpr (!NORMA) {
             u16x8 hi, lo;
-            split8(x0a, x0b, hi, lo);
+            split8<BF>(x0a, x0b, hi, lo);
             *reinterpret_cast<u16x8*>(sa + aoff[0]) = hi;
             *reinterpret_cast<u16x8*>(sa + SG_A_PLANE + aoff[0]) = lo;
-            split8(x1a, x1b, hi, lo);
+            split8<BF>(x1a, x1b, hi, lo);
             *reinterpret_cast<u16x8*>(sa + aoff[1]) = hi;
             *reinterpret_cast<u16x8*>(sa + SG_A_PLANE + aoff[1]) = lo;
         }
@@ -279,7 +291,8 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
             return *reinterpret_cast<const u16x8*>(plane + row * 64 + 16 * ((2 * sk + hh) ^ ((row >> 2) & 3)));
         };
         auto mma = [&](const u16x8& x, const u16x8& y, const f32x16& c) -> f32x16 {
-            return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, x), __builtin_bit_cast(half8, y), c, 0, 0, 0);
+            if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), c, 0, 0, 0);
+            else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, x), __builtin_bit_cast(half8, y), c, 0, 0, 0);
         };
 #pragma unroll
         for (int sk = 0; sk < 2; ++sk) {
@@ -411,12 +424,13 @@ extern "C" int cdae_skip_gn_ok(int M, int N, int K, int K1, int HW) {
     return (size_t)skipgn_tab_images(HW) * K * 8 <= 16384;            // tiles 64 KB + table <= 80 KB: two blocks per CU
 }
 
-static int skipgn_launch(SkipGnParams& p, void* stream) {
+static int skipgn_launch(SkipGnParams& p, void* stream, bool bf = false) {
     p.range_flag = cdae_range_flag_ptr();
     const size_t smem = SG_TILES + (p.coef ? (size_t)p.nimg_tab * p.K * 8 : 0);
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&skipgn_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SG_TILES + 16384) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&skipgn_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SG_TILES + 16384) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(&skipgn_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SG_TILES + 16384) != hipSuccess)
             return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
         attr_done = true;
@@ -426,7 +440,8 @@ static int skipgn_launch(SkipGnParams& p, void* stream) {
     cdae_prof_begin(PROF_IGEMM, 2.0 * p.M * p.N * p.K, st);
     cdae_prof_note(PROF_IGEMM, 4.0 * p.M * ((p.s_hi ? 2.0 : 1.0) * p.K + (p.res ? 2.0 : 1.0) * p.N));
     if (cdae_prof_on()) { char tag[96]; snprintf(tag, sizeof(tag), "skipgn M=%d N=%d K=%d norm_a=%d planes=%d res=%d", p.M, p.N, p.K, p.norm_a, p.s_hi ? 1 : 0, p.res ? 1 : 0); cdae_prof_tag(tag); }
-    if (p.norm_a) hipLaunchKernelGGL(skipgn_kernel<true>, dim3((unsigned)blocks), dim3(256), smem, st, p);
+    if (bf) hipLaunchKernelGGL((skipgn_kernel<false, true>), dim3((unsigned)blocks), dim3(256), smem, st, p);
+    else if (p.norm_a) hipLaunchKernelGGL(skipgn_kernel<true>, dim3((unsigned)blocks), dim3(256), smem, st, p);
     else hipLaunchKernelGGL(skipgn_kernel<false>, dim3((unsigned)blocks), dim3(256), smem, st, p);
     cdae_prof_end(PROF_IGEMM, st);
     return hipGetLastError() == hipSuccess ? 0 : cdae_fail("skipgn_kernel launch failed");
@@ -488,3 +503,20 @@ extern "C" int cdae_linear_fwd_stream_gn(const float* x, long ldx, const unsigne
     p.M = M; p.N = N; p.K = K; p.HW = HW; p.nimg_tab = skipgn_tab_images(HW);
     return skipgn_launch(p, stream);
 }
+
+// dx[M][K] = dy[M][N] @ W[N][K] (the data gradient of a linear layer / 1x1 conv, reference autograd of nn.Linear / conv1x1) as the same
+// streaming kernel on bf16: dy fp32 rows in (split to bf16 hi / lo on the way, full fp32 range), wt_hi / wt_lo the bf16 planes of W^T
+// ([K][N], pitch ldwt: cdae_wt_planes_bf16), bf16x3 products, fp32 accumulate.  N % 32 == 0.
+extern "C" int cdae_linear_dgrad_stream(const float* dy, long lddy, const unsigned short* wt_hi, const unsigned short* wt_lo, long ldwt, float* dx, long lddx,
+                                        int M, int N, int K, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || N % 32) return cdae_fail("linear_dgrad_stream: N % 32 == 0 required");
+    if (lddy % 4 || ldwt % 8 || !aligned16(dy) || !aligned16(wt_hi) || !aligned16(wt_lo) || !dy || !wt_hi || !wt_lo || !dx)
+        return cdae_fail("linear_dgrad_stream: 16-byte aligned rows and weight planes required");
+    SkipGnParams p;
+    p.x1 = dy; p.x2 = nullptr; p.ld1 = lddy; p.ld2 = 0; p.K1 = N;
+    p.w_hi = wt_hi; p.w_lo = wt_lo; p.ldw = ldwt; p.w_scale = nullptr; p.bias = nullptr; p.y = dx; p.ldy = lddx; p.res = nullptr; p.ldres = 0; p.c_hi = nullptr; p.c_lo = nullptr;
+    p.coef = nullptr; p.silu = 0; p.s_hi = nullptr; p.s_lo = nullptr; p.planes_gm = 0; p.norm_a = 0; p.gn_part = nullptr;
+    p.M = M; p.N = K; p.K = N; p.HW = M; p.nimg_tab = 0;
+    return skipgn_launch(p, stream, true);
+}
+

@@ -328,6 +328,44 @@ def _stream_gemm_ok(x, M, Nf, K, act, alpha, res):
             and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and (res is None or (res.stride(1) == 1 and res.stride(0) % 4 == 0)))
 
 
+_WT_PLANES = {}
+_DGRAD_STREAM_ON = os.environ.get("CDAE_DGRAD_STREAM", "1") != "0"      # dev switch: 0 = every linear dgrad through the tiled fp32-operand kernel
+
+
+def wt_planes(w):
+    """bf16 hi / lo planes of W^T ([K][N] for a weight [N][K]) — the weight operand of the streaming dgrad GEMM; cached per weight version"""
+    w = _root(w)
+    tag = (w.data_ptr(), w._version, _WEIGHT_EPOCH[0])
+    hit = _WT_PLANES.get(id(w))
+    if hit is not None and hit[0]() is w and hit[1] == tag:
+        return hit[2]
+    Nw = w.shape[0]
+    K = w.numel() // Nw
+    planes = torch.empty((2, K * Nw), dtype=torch.bfloat16, device=w.device)
+    check(lib.cdae_wt_planes_bf16(ptr(w), K, *ptr2(planes), Nw, K, stream()))
+    if len(_WT_PLANES) > 1024:
+        for k in [k for k, v in _WT_PLANES.items() if v[0]() is None]:
+            del _WT_PLANES[k]
+    _WT_PLANES[id(w)] = (weakref.ref(w), tag, planes)
+    return planes
+
+
+def linear_dgrad(dy, lddy, w, dx, lddx, M, Nw, K, k0=0, kcols=None):
+    """dx[M][kcols] = dy[M][Nw] @ W[Nw][k0 : k0 + kcols] for a dense weight [Nw][K] (the data gradient of y = x W^T).  Large-M layers in the
+    f16x3 mode (every 1x1 conv of the 64 x 64 ... 16 x 16 levels): the streaming kernel on bf16 planes of W^T; else the tiled
+    fp32-operand GEMM."""
+    from ._lib import get_precision
+    kc = K if kcols is None else kcols
+    if (_DGRAD_STREAM_ON and get_precision() == "f16x3" and M >= _STREAM_GEMM_MIN_ROWS and Nw % 32 == 0 and kc >= 64 and lddy % 4 == 0 and dy.data_ptr() % 16 == 0
+            and (k0 * Nw) % 8 == 0 and w.is_contiguous()):
+        planes = wt_planes(w)
+        hi = planes.data_ptr() + 2 * k0 * Nw                      # rows k0 .. of W^T
+        check(lib.cdae_linear_dgrad_stream(ptr(dy), lddy, hi, hi + 2 * planes.stride(0), Nw, ptr(dx), lddx, M, Nw, kc, stream()))
+        return
+    ws, wsb = _sk(dy.device)
+    check(lib.cdae_linear_dgrad(ptr(dy), lddy, w.data_ptr() + 4 * k0, K, ptr(dx), lddx, M, Nw, kc, 0, ws, wsb, stream()))
+
+
 class _Linear(Function):
     @staticmethod
     def forward(ctx, x, w, b, res, act, alpha):
@@ -374,7 +412,7 @@ class _Linear(Function):
         dya = dy if alpha == 1.0 else dy * alpha
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=dev)
-            check(lib.cdae_linear_dgrad(ptr(dya), Nf, ptr(w), K, ptr(dx), K, M, Nf, K, 0, ws, wsb, stream()))
+            linear_dgrad(dya, Nf, w, dx, K, M, Nf, K)
         (gw, rw), (gb, rb) = ctx.sinks
         want_b = has_b and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
@@ -1809,7 +1847,7 @@ class _ResBlockPS(Function):
             acc = 1 if direct else 0
             if x2 is None:
                 dx = new_act(N, C, H, W, dev)
-                check(lib.cdae_linear_dgrad(ptr(dout), Cout, ptr(sw), C, ptr(dx), C, M, Cout, C, 0, ws, wsb, st))
+                linear_dgrad(dout, Cout, sw, dx, C, M, Cout, C)
                 dg1, db1, _ = gn_bwd(x, dyn1, stats1, g1, b1, None, (sg1, sb1), C, dx, True, None, None)
                 def wg(st_, ws_, wsb_, dsw=dsw, dsb=dsb):        # (bound now: the launch may run after these names were cleared)
                     check(lib.cdae_linear_wgrad(ptr(x), C, ptr(dout), Cout, ptr(dsw), C, ptr(dsb), M, Cout, C, acc, ws_, wsb_, st_))
@@ -1819,8 +1857,8 @@ class _ResBlockPS(Function):
                 # backward accumulates onto both
                 C2 = C - C1
                 dx, dx2 = new_act(N, C1, H, W, dev), new_act(N, C2, H, W, dev)
-                check(lib.cdae_linear_dgrad(ptr(dout), Cout, ptr(sw), C, ptr(dx), C1, M, Cout, C1, 0, ws, wsb, st))
-                check(lib.cdae_linear_dgrad(ptr(dout), Cout, sw.data_ptr() + 4 * C1, C, ptr(dx2), C2, M, Cout, C2, 0, ws, wsb, st))
+                linear_dgrad(dout, Cout, sw, dx, C1, M, Cout, C, 0, C1)          # the two column ranges of the skip weight: the two sources
+                linear_dgrad(dout, Cout, sw, dx2, C2, M, Cout, C, C1, C2)
                 (gg, rg), (gb_, rb_) = sg1, sb1
                 dirn = gg is not None and gb_ is not None
                 dg1 = gg if dirn else torch.empty_like(g1)

@@ -259,6 +259,12 @@ int cdae_wdgrad_planes(const float* w, unsigned short* hi, unsigned short* lo, i
    [4 phases][Cin][2][2][Cout] of an OHWI weight; cdae_conv3x3_s2_dgrad_ps takes dy as bf16 planes [N, Ho, Wo, Cout] and writes
    dx [N, 2 Ho, 2 Wo, Cin] (rows of pitch lddx).  Returns 2 (no error set) for a shape it does not take. */
 int cdae_s2dgrad_wfold(const float* w, unsigned short* hi, unsigned short* lo, int Cout, int Cin, void* stream);
+/* The data gradient of a linear layer / 1x1 conv on the streaming kernel (skipgn.hip), for the large-M layers where the tiled fp32-operand
+   GEMM is latency-bound: dx[M][K] = dy[M][N] @ W[N][K] with dy fp32 rows (split to bf16 hi / lo on the way into LDS) and the bf16 planes
+   of W^T ([K][N], pitch ldwt) from cdae_wt_planes_bf16 (once per weight version); bf16x3 products, N % 32 == 0. */
+int cdae_wt_planes_bf16(const float* w, long ldw, unsigned short* hi, unsigned short* lo, int N, int K, void* stream);
+int cdae_linear_dgrad_stream(const float* dy, long lddy, const unsigned short* wt_hi, const unsigned short* wt_lo, long ldwt, float* dx, long lddx,
+                             int M, int N, int K, void* stream);
 int cdae_conv3x3_s2_dgrad_ps(const unsigned short* dy_hi, const unsigned short* dy_lo, const unsigned short* w4_hi, const unsigned short* w4_lo, float* dx,
                              long lddx, int N, int Ho, int Wo, int Cin, int Cout, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
 /* cdae_split_f16 + cdae_wdgrad_planes for MANY conv3x3 weights in one launch (once per optimizer step).  The weights live in one

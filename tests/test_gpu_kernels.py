@@ -1533,6 +1533,36 @@ def test_stem_conv_leaves_groupnorm_sums(N, Cin, Cout, S):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,k0,kc", [(8192, 384, 384, 0, None), (131072, 128, 256, 0, 128), (131072, 128, 256, 128, 128), (4096 + 96, 1152, 384, 0, None),
+                                          (32768, 256, 640, 384, 256)])
+def test_linear_dgrad_streaming_bf16(M, N, K, k0, kc):
+    """dx = dy @ W[:, k0 : k0 + kc] on the streaming kernel (skipgn_kernel<false, bf16>: dy split to bf16 hi / lo on its way into LDS,
+    bf16 planes of W^T from cdae_wt_planes_bf16) against fp64 at the gradient bar (2e-4 of the gradient's maximum) and against the tiled
+    fp32-operand GEMM it replaces for large M; gradient-sized dy (1e-4 ... 1e-9: bf16 keeps fp32's range), partial row tile, column range."""
+    from causaldiffae_amd import ops
+    from causaldiffae_amd._lib import precision_scope
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(83)
+    dy = torch.randn(M, N, device=dev, generator=g) * torch.logspace(-4, -9, N, device=dev)[None, :]
+    w = torch.randn(N, K, device=dev, generator=g) / K ** 0.5
+    cols = K if kc is None else kc
+    with precision_scope("f16x3"), torch.no_grad():
+        dx = torch.empty(M, cols, device=dev)
+        ops.linear_dgrad(dy, N, w, dx, cols, M, N, K, k0, kc)
+        ops._DGRAD_STREAM_ON = False
+        try:
+            dx_old = torch.empty(M, cols, device=dev)
+            ops.linear_dgrad(dy, N, w, dx_old, cols, M, N, K, k0, kc)
+        finally:
+            ops._DGRAD_STREAM_ON = True
+    ref = dy.double() @ w.double()[:, k0:k0 + cols]
+    scale = ref.abs().max().item()
+    assert torch.isfinite(dx).all()
+    assert (dx.double() - ref).abs().max().item() < 2e-4 * scale, (dx.double() - ref).abs().max().item() / scale
+    assert (dx_old.double() - ref).abs().max().item() < 2e-4 * scale
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N,Cin,Cout,S", [(32, 128, 128, 64), (8, 256, 256, 32), (4, 384, 384, 16), (2, 64, 96, 16), (3, 32, 64, 32)])
 def test_stride2_conv_dgrad_as_subpixel_phases(N, Cin, Cout, S, expect_kernels):
     """dgrad of the Downsample conv (stride 2, pad 1: reference unet.py:82-105) as four 2 x 2 sub-pixel convolutions of dy on the plane
