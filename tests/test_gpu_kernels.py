@@ -676,6 +676,33 @@ def test_window_conv_96_column_tiles(seed, expect_kernels):
 
 
 @pytest.mark.gpu
+def test_groupnorm_sums_with_a_partial_last_row_tile():
+    """Epilogue GroupNorm sums when M % 256 != 0 (batch 130 at 8 x 8: 32.5 row tiles of 256; round-3 advisor finding: the last tile's
+    chunks beyond M used to be written past the end of the [M / 32] buffer).  A canary row behind the buffer must stay untouched, and
+    every real chunk must hold the sums of its 32 rows."""
+    from causaldiffae_amd import ops
+    from causaldiffae_amd._lib import check, lib, ptr, ptr2, stream, splitk_ws, SPLITK_BYTES, tune_scope
+    g = torch.Generator(device="cuda:0").manual_seed(47)
+    N, ci, co, S = 130, 64, 1024, 8
+    M = N * S * S
+    x = ops.to_nhwc(torch.randn(N, ci, S, S, device="cuda:0", generator=g))
+    w = (torch.randn(co, ci, 3, 3, device="cuda:0", generator=g) / (9 * ci) ** 0.5).contiguous(memory_format=torch.channels_last)
+    xs = _split_nhwc(x)
+    w_hi, w_lo, w_sc = ops.split_weight(w)
+    out = ops.new_act(N, co, S, S, "cuda:0")
+    chunks = M // 32
+    buf = torch.full((chunks + 8, co, 2), -7.0, device="cuda:0")          # 8 canary chunks behind the real ones
+    with torch.no_grad(), tune_scope(convwin_splitk=0):
+        check(lib.cdae_conv3x3_fwd_psg(ptr(xs.hi), ptr(xs.lo), S * S * ci, S * ci, ci, 0, ptr(w_hi), ptr(w_lo), None, None, ptr(w_sc), None, None, ptr(out), co,
+                                       0, None, None, ptr(buf), N, S, S, ci, co, 1, 0, ptr(splitk_ws(x.device)), SPLITK_BYTES, stream()))
+    torch.cuda.synchronize()
+    assert (buf[chunks:] == -7.0).all(), "sums written beyond the [M / 32] buffer"
+    rows = out.permute(0, 2, 3, 1).reshape(chunks, 32, co).double()
+    assert (buf[:chunks, :, 0].double() - rows.sum(1)).abs().max().item() < 1e-5 * rows.sum(1).abs().max().item()
+    assert (buf[:chunks, :, 1].double() - (rows * rows).sum(1)).abs().max().item() < 1e-5 * (rows * rows).sum(1).abs().max().item()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("res", [False, True])
 def test_groupnorm_sums_from_split_k_finish(res, expect_kernels):
     """Where the window kernel splits K (the 8 x 8 level at batch 128: 128 tiles for 512 block slots) the next GroupNorm's partial sums

@@ -5,7 +5,8 @@
 # switch from the environment (thresholds: cdae_tune_set; compile-time experiments: a -DCW_DEV=1 build).
 #   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/switch_matrix.sh'
 for SW in CDAE_SKIPGN_V2 CDAE_SKIP_GN CDAE_STREAM_GEMM CDAE_HEAD_CONV CDAE_PLANES_GM CDAE_LINEAR_GN CDAE_FUSED_ATTN CDAE_FUSED_ATTN_TRAIN CDAE_KPACK \
-          CDAE_PRESPLIT CDAE_TRAIN_PRESPLIT CDAE_TRAIN_RBNODE CDAE_TRAIN_GNPARTS CDAE_TRAIN_EMBALL CDAE_TRAIN_CAT CDAE_WEIGHT_BANK; do
+          CDAE_PRESPLIT CDAE_TRAIN_PRESPLIT CDAE_TRAIN_RBNODE CDAE_TRAIN_GNPARTS CDAE_TRAIN_EMBALL CDAE_TRAIN_CAT CDAE_WEIGHT_BANK \
+          CDAE_WSCALE CDAE_WGRAD_STREAM CDAE_S2_DGRAD_PS CDAE_DGRAD_STREAM; do
   echo "== $SW=0"
   env $SW=0 timeout 900 python3 -m pytest tests/test_gpu_model.py -x -q -k "(unet_forward or ddim_p64 or p_sample_loop or guided or full_model or trainloop) and not packed_weight and not benchmark_dispatch" 2>&1 | tail -2
 done
