@@ -264,6 +264,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("CDAE_WATCHDOG_S"):          # dev: every thread's stack to stderr and exit if the run is still going after that many seconds
+        import ctypes, faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["CDAE_WATCHDOG_S"]), exit=True)
+        ctypes.CDLL(None).prctl(0x59616D61, ctypes.c_ulong(-1), 0, 0, 0)      # PR_SET_PTRACER_ANY: a debugger started beside the job may attach
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the product path has no CPU fallback)"
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
@@ -272,7 +276,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # "nccl" is RCCL on ROCm; CDAE_DIST_BACKEND=gloo exists only to exercise the N>1 code path on a 1-GPU box
-        dist.init_process_group(os.environ.get("CDAE_DIST_BACKEND", "nccl"), init_method="env://")
+        import datetime
+        tmo = {"timeout": datetime.timedelta(seconds=int(os.environ["CDAE_DIST_TIMEOUT_S"]))} if os.environ.get("CDAE_DIST_TIMEOUT_S") else {}
+        dist.init_process_group(os.environ.get("CDAE_DIST_BACKEND", "nccl"), init_method="env://", **tmo)
 
     import causaldiffae_amd  # noqa: F401
     from causaldiffae_amd import _lib

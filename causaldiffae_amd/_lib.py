@@ -32,6 +32,7 @@ SIGNATURES = {
     "cdae_conv3x3_fwd_psk": [P, P, L, L, L, P, P, P, P, P, P, P, P, L, I, P, P, P, I, I, I, I, I, I, I, P, SZ, P],
     "cdae_conv3x3_dgrad_psk": [P, P, P, P, P, P, P, L, I, I, I, I, I, P, SZ, P],
     "cdae_conv_wpack": [P, P, P, P, I, I, I, P],
+    "cdae_convwin_lds_probe": [P],
     "cdae_gn_coef": [P, P, P, P, P, I, P, I, I, I, P],
     "cdae_gn_stats_from_parts": [P, I, I, P, I, I, I, I, I, F, P, P, P, P],
     "cdae_gn_stats_from_parts_coef": [P, I, I, P, I, I, I, I, I, F, P, P, P, P, P, I, P, P, P],

@@ -112,7 +112,10 @@ def _done(*cbs):
 # TrainLoop before the optimizer step / gradient norm, GradBuckets before a bucket's all-reduce).  The side stream has its own split-K
 # workspace.  Tensors the side stream reads are `record_stream`ed, so the caching allocator does not recycle them under it.
 def _host_cores_per_rank():
-    """CPUs this rank may use: min(affinity, cgroup quota) / ranks on this node"""
+    """CPUs this rank may use: min(affinity, cgroup quota) / ranks on this node (CDAE_HOST_CORES overrides the node's count: for a
+    launcher that knows a quota this process cannot see)"""
+    if os.environ.get("CDAE_HOST_CORES"):
+        return float(os.environ["CDAE_HOST_CORES"]) / max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
     n = len(os.sched_getaffinity(0))
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()

@@ -89,6 +89,7 @@ class GradBuckets:
     def __init__(self, flat, bucket_bytes=64 << 20, group=None):
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._gloo = dist.is_initialized() and dist.get_backend(group) == "gloo"
         self.buckets, self.bucket_of = [], {}
         hi, acc, members = flat.numel, 0, []
         for i in range(len(flat.params) - 1, -1, -1):
@@ -136,6 +137,13 @@ class GradBuckets:
         same stream."""
         grad = self.flat.grad[b["lo"]:b["hi"]]
         ops.side_join()             # weight gradients are written on ops' side stream: this stream waits for them before the collective reads them
+        if self._gloo and grad.is_cuda:
+            # gloo (the stand-in for RCCL on a one-GPU test box) stages the bucket through pinned memory on a pool stream that waits for an
+            # event of the launch stream.  With four processes time-slicing ONE GPU and no other cross-stream traffic (side stream off) that
+            # wait never returned from the second step on (every rank's launch stream stalled, found with tools/hang_bt.sh; two ranks, or
+            # AMD_SERIALIZE_KERNEL=3, or the side stream's own waits make it go away).  RCCL runs its kernels on the device and has no such
+            # staging copy; for gloo the host simply waits for the launch stream first.
+            th.cuda.current_stream(grad.device).synchronize()
         return dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _make_hook(self, i):
@@ -166,8 +174,22 @@ class GradBuckets:
         for b in self.buckets:             # in index order, like the hooks
             if b["work"] is None:
                 b["work"] = self._all_reduce(b)
-        for b in self.buckets:
-            b["work"].wait()
+        if os.environ.get("CDAE_DEBUG_DIST"):          # dev: does the launch stream drain while the collectives are outstanding?
+            import sys, time as _t
+            ev = th.cuda.Event(); ev.record()
+            t0 = _t.time()
+            while not ev.query() and _t.time() - t0 < 20:
+                _t.sleep(0.05)
+            print(f"[rank {dist.get_rank()}] launch stream drained: {ev.query()} after {_t.time() - t0:.2f} s; works completed: "
+                  f"{[bb['work'].is_completed() for bb in self.buckets]}", file=sys.stderr, flush=True)
+        for i, b in enumerate(self.buckets):
+            try:
+                b["work"].wait()
+            except Exception as e:
+                import sys
+                print(f"[rank {dist.get_rank()}] bucket {i} of {len(self.buckets)} [{b['lo']}:{b['hi']}] wait failed: {e!r}; completed: "
+                      f"{[bb['work'].is_completed() for bb in self.buckets]}", file=sys.stderr, flush=True)
+                raise
         self.flat.grad.mul_(1.0 / self.world)
         self.reset()
 

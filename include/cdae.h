@@ -114,9 +114,13 @@ int cdae_conv3x3_fwd_ps(const unsigned short* x_hi, const unsigned short* x_lo, 
    weights of cdae_wdgrad_planes).  cdae_conv3x3_fwd_psk / cdae_conv3x3_dgrad_psk = the _ps entry points with the packed planes
    passed along (NULL: identical to _ps; the library falls back to the first-generation kernels).
    Hardware dependency of that kernel: the zero padding of a tap that falls outside the image is an LDS read at an address beyond the
-   block's allocation, which gfx950 returns as zeros (no fault, no wrap) — measured, not documented; tests/test_gpu_kernels.py
-   test_lds_out_of_range_reads_return_zero pins it, and a part that behaves differently must take the first-generation kernels
-   (cdae_tune_set(CDAE_TUNE_CONVWIN_MIN_TILES, 1 << 30)). */
+   block's allocation, which gfx950 returns as zeros (no fault, no wrap) — measured, not documented.  The library CHECKS it itself,
+   once per device, before the kernel's first launch (a 512-block probe that fills both LDS allocations of every CU and reads the
+   addresses the kernel uses): on a part that answers anything else every window-conv launch FAILS with a message instead of
+   computing wrong borders; such a part takes the first-generation kernels with cdae_tune_set(CDAE_TUNE_CONVWIN_MIN_TILES, 1 << 30).
+   cdae_convwin_lds_probe runs (or re-reads) that check: 0 = zeros confirmed, 2 = not checkable now (the stream is capturing),
+   1 = the device fails it.  tests/test_gpu_kernels.py test_lds_out_of_range_reads_return_zero covers the stand-alone probe too. */
+int cdae_convwin_lds_probe(void* stream);
 int cdae_conv_wpack(const unsigned short* w_hi, const unsigned short* w_lo, unsigned short* k_hi, unsigned short* k_lo, int rows, int taps,
                     int K, void* stream);
 int cdae_conv3x3_fwd_psk(const unsigned short* x_hi, const unsigned short* x_lo, long sn, long sy, long sx, const unsigned short* w_hi,

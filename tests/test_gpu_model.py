@@ -1499,6 +1499,37 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+def test_bench_four_ranks_world8_policy_on_one_gpu():
+    """Four ranks (gloo, all on cuda:0) under the driver's launch line, with the host-core budget an EIGHT-rank node gives each rank
+    (CDAE_HOST_CORES=8 over four ranks = 2 cores per rank, like a 16-core quota over eight): `ops.wgrad_side_stream_on()` must answer
+    False (the second stream's runtime helper thread does not fit that budget) and the training leg must run to the end in that
+    configuration.  It did not before round 4's fix: from the second step on every rank's launch stream stalled behind gloo's staging
+    copies (tools/hang_bt.sh; GradBuckets._all_reduce now lets the host wait for the launch stream first — gloo only).  Per-rank CPU per
+    step is NOT asserted here: with gloo the host-side reduction of 374 MB of gradients dominates it (hundreds of ms); the number that
+    stands for an RCCL rank is `train.world8_policy.host_cpu_over_step` of the single-rank bench line (0.88 cores per rank)."""
+    import json, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {**os.environ, "CDAE_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "CDAE_HOST_CORES": "8", "CDAE_WATCHDOG_S": "240"}
+    env.pop("CDAE_WGRAD_STREAM", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1", "--regions", "1",
+                        "--batch", "8", "--train-batch", "8", "--train-steps", "4", "--no-cpu-baseline", "--no-fp32", "--no-extra"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["ranks_in_group"] == 4 and d["config"]["global_batch"] == 32 and d["value"] > 0
+    t = d["train"]
+    assert "error" not in t, t
+    assert t["wgrad_side_stream"] is False and t["global_batch"] == 32 and t["dist_backend"] == "gloo" and np.isfinite(t["last_loss"])
+    assert t["host_cpu_ms_per_step"] > 0 and len(t["host_cpu_ms_per_step_by_thread"]) >= 2
+
+
+@pytest.mark.gpu
 def test_encoder_classifier_matches_torch_modules():
     """nn.GaussianConvEncoderClf (the evaluation classifier the reference's image_causaldae_test.py builds): same state-dict layout as
     the reference module, forward == Linear(flatten(strided conv -> BatchNorm(eval) -> LeakyReLU stack)) built from plain torch modules."""
