@@ -1861,6 +1861,26 @@ def test_lds_out_of_range_reads_return_zero(tmp_path):
 
 
 @pytest.mark.gpu
+def test_library_lds_probe_confirms_zero_reads():
+    """The check the library runs itself before the first window-conv launch on a device (cdae_convwin_lds_probe): 0 on this part;
+    2 while the stream is capturing (nothing can be waited for there), and the capture stays valid."""
+    from causaldiffae_amd._lib import lib, stream
+    assert lib.cdae_convwin_lds_probe(stream()) == 0
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    x = torch.zeros(8, device="cuda:0")
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            rc = lib.cdae_convwin_lds_probe(stream())
+            x += 1
+    assert rc in (0, 2)            # (0: the per-device answer is cached after the first check)
+    g.replay()
+    torch.cuda.synchronize()
+    assert x.sum().item() == 8
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N,Cin,Cout,S,up", [(64, 128, 128, 64, False),      # 1024 tiles, four per persistent block
                                              (128, 256, 256, 32, False),     # K = 2304, two n-tiles share a window
                                              (128, 512, 512, 8, False),      # 8x8 level: split-K slabs + reduce
