@@ -9,7 +9,7 @@
 //   * one block = 128 rows x 128 output columns, 4 waves (2 x 2 of 64 x 64), two blocks per CU
 //   * x goes global -> registers (2 x 2 dwordx4 per thread and 32-channel step, issued one step ahead and left in flight across
 //     the MFMA phase), is split raw into the [row][64 B] swizzled LDS image ps_kernel uses (ds_write_b128), and the same registers
-//     are normalised and stored as 16-byte pieces of the planes (only by the n-tile-0 block of a row tile)
+//     are normalised and stored as 16-byte pieces of the planes (by ONE of the row tile's n-tile blocks: the steps are dealt out round robin)
 //   * the weight tile of the step arrives by LDS-DMA from the pre-split planes (L2 resident), one step ahead
 //   * the (a, b) table of the images the row tile touches sits in LDS
 //   * one barrier per step; n-tiles of one row tile are neighbours inside an XCD so the second..fourth read of x hits its L2
@@ -29,6 +29,12 @@
 // SG_DEPTH: how many 32-channel steps ahead the x rows are requested (2 or 3 register sets of 16 VGPRs)
 #ifndef SG_DEPTH
 #define SG_DEPTH 2
+#endif
+// SG_BALANCE: 1 = the plane-writing steps of a row tile are dealt out over its n-tile blocks, 0 = n-tile 0 writes all planes,
+// 2 = as 1 but with the turn visible to the optimiser: the build in which hipcc copied the in-flight x registers in front of the counted
+// wait (tests/test_host_cpu.py::test_entry_sweep_never_copies_registers_of_loads_in_flight keeps it as its known-bad sample — never ship it)
+#ifndef SG_BALANCE
+#define SG_BALANCE 1
 #endif
 #if SG_NT & 1
 #define SG_NT_LD " nt"
@@ -113,7 +119,18 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
     }
     (void)nmt;
     const int m0 = mt * SG_BM, n0 = nt * SG_BN;
-    const bool writes_planes = nt == 0 && p.s_hi != nullptr;           // (no planes wanted: the plain streaming GEMM)
+    // Who writes the normalised planes of a row tile: every n-tile block holds all of x, so the 32-channel steps are dealt out round
+    // robin (step kt belongs to the block with nt == kt % nnt) — the SiLU + split arithmetic and the plane stores, the larger part of
+    // a step's vector work, are spread over the row tile's blocks instead of making the nt == 0 block the slow one (SG_BALANCE=0:
+    // that block writes everything).  The values do not depend on who computes them.
+    const bool planes_out = p.s_hi != nullptr;                         // (no planes wanted: the plain streaming GEMM)
+    auto writes_planes_at = [&](int kt) -> bool {
+        int turn = SG_BALANCE ? kt % nnt : 0;
+#if SG_BALANCE != 2
+        asm volatile("" : "+s"(turn));          // opaque: nothing about the step loop may be specialised on whose turn it is
+#endif
+        return planes_out && turn == nt;
+    };
 
     // ---- this thread's slice of the x tile: rows r and r + 64, channels 8 c8 .. 8 c8 + 7 of every 32-deep step
     const int r0 = tid >> 2, c8 = tid & 3;
@@ -198,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
 
     // One 32-deep step on the register set (x0a, x0b | x1a, x1b) = rows r0 and r0 + 64 of step kt, LDS stage st (compile-time).
     // Vector-memory operations of a step, in issue order: [before the barrier: nothing] weight DMAs of step kt + 1 (4), x loads of
-    // step kt + 2 (4, into the registers this step just consumed), plane stores of step kt (4, n-tile 0 only).  The counter is in
+    // step kt + 2 (4, into the registers this step just consumed), plane stores of step kt (4, in the block the step belongs to).  The counter is in
     // order, so the wait at the top of step kt + 1 ("weights kt + 1 landed", which also covers x of step kt + 1 from two steps ago)
     // leaves the younger x loads and stores in flight.
     auto step = [&](f4& x0a, f4& x0b, f4& x1a, f4& x1b, const int kt, const int st) {
@@ -206,12 +223,13 @@ __global__ __launch_bounds__(256, 2) void skipgn_kernel(const SkipGnParams p) {
         char* const sa = lds + st * SG_STAGE;
         const bool more1 = kt + 1 < nk;                                // (at the top of step kt: x loads of step kt + 1 are the younger ones)
         const bool live = kt >= 0;                                     // the two lead-in steps (kt = -2, -1) only issue: x of steps 0 and 1, weights of step 0
+        const bool writes_planes = live && writes_planes_at(kt);
         u16x8 nh[2], nl[2];                                            // the normalised rows, split
         if (live) {
         // (a partial row tile skips some plane stores: no fixed count)
         // younger than the weight DMAs of this step (issued in step kt - 1): the x loads that step issued behind them — those of step
         // kt - 1 + SG_DEPTH — and its plane stores
-        const int cnt = __builtin_amdgcn_readfirstlane((kt == 0 || !full_rows) ? 0 : (kt - 1 + SG_DEPTH < nk ? 4 : 0) + (writes_planes ? 4 : 0));
+        const int cnt = __builtin_amdgcn_readfirstlane((kt == 0 || !full_rows) ? 0 : (kt - 1 + SG_DEPTH < nk ? 4 : 0) + (writes_planes_at(kt - 1) ? 4 : 0));
         SG_WAIT_X(cnt, x0a, x0b, x1a, x1b);
         if constexpr (!NORMA) {
             u16x8 hi, lo;

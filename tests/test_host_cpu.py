@@ -274,3 +274,25 @@ def test_wgrad_window_kernel_step_loop_is_clean():
         lp = steps[0]
         assert lp["mfmas"] == (36 + 4 if single else 108 + 8), (r["kernel"], lp)
         assert not lp["vmcnt_waits"] and not lp["scratch"], (r["kernel"], lp)
+
+
+def test_entry_sweep_never_copies_registers_of_loads_in_flight():
+    """skipgn_kernel (ResBlock entry sweeps, GroupNorm -> qkv, the streaming 1x1 GEMMs) requests its fp32 rows two steps ahead from
+    inline assembly and waits for them with its own counted `s_waitcnt`.  The compiler does not know those registers are in flight: in
+    one build variant of round 4 (whose turn a step is, left visible to the optimiser: -DSG_BALANCE=2) the register allocator tied the
+    wait's "+v" operands to other registers and COPIED the sixteen x registers in front of the wait — garbage planes and NaN sums on
+    the GPU, non-deterministically.  The shipped build must contain no such copy in any instantiation; the known-bad variant must be
+    caught by the same check (so the check itself is known to see the pattern)."""
+    import importlib.util, shutil
+    if not shutil.which("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not installed")
+    spec = importlib.util.spec_from_file_location("isa_lint", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "isa_lint.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    good = mod.inflight_copies("skipgn", "skipgn_kernel")
+    assert len(good) == 3, list(good)                  # <plain | normalised A> f16, and the bf16 streaming dgrad form
+    for name, r in good.items():
+        assert r["asm_load_registers"] == 32, (name, r)      # two register sets of 16: the steps kt and kt + 1
+        assert not r["copies"], (name, r["copies"][:4])
+    bad = mod.inflight_copies("skipgn", "skipgn_kernel", extra=("-DSG_BALANCE=2",))
+    assert any(r["copies"] for r in bad.values()), "the known-bad variant no longer shows the pattern: the check may have gone blind"

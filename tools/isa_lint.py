@@ -58,6 +58,53 @@ def lint(unit, extra=()):
     return res
 
 
+def inflight_copies(unit, kernel_substr, extra=()):
+    """{kernel: [copy instructions]}: `v_mov` / `v_accvgpr_write` instructions whose SOURCE is a destination register of a
+    `global_load_dwordx4` issued from inline assembly.  Such loads are invisible to the compiler's wait-count pass (the kernel waits
+    for them with its own counted `s_waitcnt`), so a register copy the allocator places between the load and that wait — which it does
+    when an asm "+v" operand ends up tied to a different register than the load's output — copies data that has not landed
+    (skipgn_kernel, round 4: wrong planes and NaN sums in one build variant, nothing in the source had changed)."""
+    src = os.path.join(ROOT, "causaldiffae_amd", "csrc", unit + ".hip")
+    out = os.path.join(tempfile.gettempdir(), f"isa_copies_{unit}.s")
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only"]
+    subprocess.check_call(["/opt/rocm/bin/hipcc", *flags, *extra, "-o", out, src], stderr=subprocess.DEVNULL)
+    lines = open(out).read().split("\n")
+    res = {}
+    for s in [i for i, l in enumerate(lines) if re.match(r"^_Z\w+:\s*", l)]:
+        sym = lines[s].split(":")[0]
+        name = subprocess.run(["c++filt", sym], capture_output=True, text=True).stdout.strip()
+        if kernel_substr not in name:
+            continue
+        e = next(k for k in range(s, len(lines)) if "s_endpgm" in lines[k])
+        dst, in_asm = set(), False
+        for l in lines[s:e]:
+            t = l.strip()
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True
+            elif t.startswith(";;#ASMEND"):
+                in_asm = False
+            m = re.match(r"global_load_dwordx4 v\[(\d+):(\d+)\], v\[\d+:\d+\], off", t)
+            if m and in_asm:
+                dst.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        bad = []
+        for l in lines[s:e]:
+            t = l.strip()
+            m = re.match(r"(v_mov_b32_e32|v_mov_b64_e32|v_accvgpr_write_b32) (\S+), (\S+)", t)
+            if not m:
+                continue
+            regs = set()
+            mm = re.match(r"v\[(\d+):(\d+)\]", m.group(3))
+            if mm:
+                regs = set(range(int(mm.group(1)), int(mm.group(2)) + 1))
+            mm = re.match(r"v(\d+)$", m.group(3))
+            if mm:
+                regs = {int(mm.group(1))}
+            if regs & dst:
+                bad.append(t)
+        res[name] = dict(asm_load_registers=len(dst), copies=bad)
+    return res
+
+
 if __name__ == "__main__":
     for r in lint(sys.argv[1], sys.argv[2:]):
         print(f"== {r['kernel'][:100]}: {r['lines']} lines, {r['mfmas']} MFMAs, {r['scratch_ops']} scratch ops, {r['vgpr_spills']} VGPR spills")

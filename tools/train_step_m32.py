@@ -1,0 +1,9 @@
+"""Dev tool: a few training steps of BASELINE config [1] (M32, batch 256; argv[2] = 1: use_fp16 / mixed16) for rocprofv3 kernel traces."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+dev = torch.device("cuda:0")
+fp16 = len(sys.argv) > 2 and sys.argv[2] == "1"
+r = bench.train_bench(dev, 1, 0, int(sys.argv[1]) if len(sys.argv) > 1 else 3, 2, 256, use_fp16=fp16, workload="M32", image_size=32, in_channels=1, n_vars=2, class_cond=True)
+print({k: r[k] for k in ("value", "ms_per_step", "precision_mode")})
