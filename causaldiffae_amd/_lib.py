@@ -324,7 +324,7 @@ class precision_scope:
         return False
 
 
-TUNE_KEYS = {"convwin_min_tiles": 0, "convwin_splitk": 1, "convwin_nj3": 2}
+TUNE_KEYS = {"convwin_min_tiles": 0, "convwin_splitk": 1, "convwin_nj3": 2, "head_mfma": 3}
 
 
 class tune_scope:

@@ -103,7 +103,7 @@ int cdae_planes_dispatch(GemmParams& p, int big, int& ks, hipStream_t st);
 #endif
 
 // run-time dispatch thresholds (cdae_tune_set / cdae_tune_get in include/cdae.h; prof.hip holds the values)
-enum { TUNE_CONVWIN_MIN_TILES = 0, TUNE_CONVWIN_SPLITK = 1, TUNE_CONVWIN_NJ3 = 2, TUNE_N = 3 };
+enum { TUNE_CONVWIN_MIN_TILES = 0, TUNE_CONVWIN_SPLITK = 1, TUNE_CONVWIN_NJ3 = 2, TUNE_HEAD_MFMA = 3, TUNE_N = 4 };
 int cdae_tune(int key);
 
 // error reporting: sets the thread-local message returned by cdae_last_error(), returns -1

@@ -1,4 +1,4 @@
-// head_conv_kernel: the UNet output head (reference unet.py:495-499: self.out = GroupNorm32 -> SiLU -> zero-initialised conv3x3 to
+// head_mfma_kernel (default) / head_conv_kernel (the scalar form, CDAE_TUNE_HEAD_MFMA = 0): the UNet output head (reference unet.py:495-499: self.out = GroupNorm32 -> SiLU -> zero-initialised conv3x3 to
 // out_channels, 1..8 channels) in ONE kernel and in exact fp32 on the vector ALUs:
 //     y[n][co][p] = bias[co] + sum_{tap, c} silu(x[n][p + tap][c] * a[n][c] + b[n][c]) * w[co][tap][c]        (NCHW out, zero padding)
 // Why not the MFMA path: with 4 output channels a 64-wide n-tile is 94 % padding and the plane GEMM streams every activation nine
@@ -114,6 +114,134 @@ __global__ __launch_bounds__(256, 2) void head_conv_kernel(const HeadParams p) {
     }
 }
 
+// The same head on the matrix cores, still in exact fp32 products: v_mfma_f32_4x4x1_16b_f32 is sixteen independent 4 x 4 x 1 outer
+// products per instruction — lane l supplies A = its pixel's activation for ONE input channel and B = the weight of output channel
+// l % 4 for that channel, and the sixteen blocks are sixteen groups of four neighbouring pixels: one instruction = 64 pixels x 4
+// output channels x 1 input channel (tools/hiptests/mfma4x4.hip pins the lane mapping: D[lane 4 b + j][reg i] = A[lane 4 b + i] *
+// B[lane 4 b + j]).  Per 16 bytes of window and 16 bytes of weights read from LDS a lane issues four of them, where the scalar form
+// above needs 4 CO fused multiply-adds and as many weight operands through the scalar cache (its limiter: 277 us for 4 channels at
+// batch 128; this form is bound by the two LDS reads per four instructions).  Staging, window geometry and border handling are the
+// scalar kernel's; the weights of the chunk sit in LDS as [tap][4 G output channels][32 + 4 pad] (rows of absent channels zero).
+// Sums: per output, input channels 4 j + e with e even / odd go to two accumulators (independent MFMA chains), added at the end.
+// G: groups of four output channels (1: Cout <= 4, 2: Cout 6 or 8).
+template <int G>
+__global__ __launch_bounds__(256, 2) void head_mfma_kernel(const HeadParams p, int CO) {
+    extern __shared__ __attribute__((aligned(16))) float win[];      // [rows + 1][HD_PITCH] window, then [9][4 G][HD_PITCH] weights
+    typedef float hd_f4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int HW = p.H * p.W, W = p.W;
+    const int n = blockIdx.x / p.tiles_per_image, p0 = (blockIdx.x - n * p.tiles_per_image) * HD_TP;
+    const int rows = HD_TP + 2 * W + 2;
+    const int zrow = rows;
+    float* const wl = win + (rows + 1) * HD_PITCH;
+
+    const int pix = p0 + tid;
+    const int py = pix / W, px = pix - py * W;
+    int toff[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int dy = t / 3 - 1, dx = t % 3 - 1;
+        const bool wraps = (dx < 0 && px == 0) || (dx > 0 && px == W - 1);
+        toff[t] = (wraps ? zrow : tid + W + 1 + dy * W + dx) * HD_PITCH;
+    }
+    for (int i = tid; i < HD_PITCH; i += 256) win[zrow * HD_PITCH + i] = 0.f;
+
+    const int c4 = tid & 7, lrow = tid >> 3;
+    const float* xin = p.x + (long)n * HW * p.ldx;
+    const float* cf = p.coef + (long)n * p.Cin * 2;
+
+    hd_f4 acc[G][2];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { acc[g][0] = hd_f4{0.f, 0.f, 0.f, 0.f}; acc[g][1] = hd_f4{0.f, 0.f, 0.f, 0.f}; }
+
+    for (int k0 = 0; k0 < p.Cin; k0 += HD_KC) {
+        const float4 ab0 = *reinterpret_cast<const float4*>(cf + (k0 + 4 * c4) * 2);
+        const float4 ab1 = *reinterpret_cast<const float4*>(cf + (k0 + 4 * c4) * 2 + 4);
+        constexpr int LR = (HD_TP + 2 * 64 + 2 + 31) / 32;
+        float4 xv[LR];
+#pragma unroll
+        for (int i = 0; i < LR; ++i) {
+            const int r = lrow + 32 * i, q = p0 - W - 1 + r;
+            const bool ok = r < rows && q >= 0 && q < HW;
+            xv[i] = *reinterpret_cast<const float4*>(xin + (ok ? (long)q * p.ldx + k0 + 4 * c4 : 0));
+        }
+        // this chunk's weights: float4 pieces (tap t, output channel co, channels 4 c .. 4 c + 3), 9 x 4 G x 8 of them
+        float4 wv[(9 * 4 * G * 8 + 255) / 256];
+#pragma unroll
+        for (int i = 0; i < (9 * 4 * G * 8 + 255) / 256; ++i) {
+            const int idx = tid + 256 * i, c = idx & 7, co = (idx >> 3) % (4 * G), t = idx / (32 * G);
+            wv[i] = (idx < 9 * 4 * G * 8 && co < CO) ? *reinterpret_cast<const float4*>(p.w + ((long)co * 9 + t) * p.Cin + k0 + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (k0) __syncthreads();                                       // everyone is done reading the previous window and weights
+#pragma unroll
+        for (int i = 0; i < LR; ++i) {
+            const int r = lrow + 32 * i, q = p0 - W - 1 + r;
+            if (r < rows) {
+                float4 v;
+                v.x = fmaf(xv[i].x, ab0.x, ab0.y); v.y = fmaf(xv[i].y, ab0.z, ab0.w);
+                v.z = fmaf(xv[i].z, ab1.x, ab1.y); v.w = fmaf(xv[i].w, ab1.z, ab1.w);
+                if (p.silu) { v.x = cdae_silu(v.x); v.y = cdae_silu(v.y); v.z = cdae_silu(v.z); v.w = cdae_silu(v.w); }
+                if (!(q >= 0 && q < HW)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(win + r * HD_PITCH + 4 * c4) = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < (9 * 4 * G * 8 + 255) / 256; ++i) {
+            const int idx = tid + 256 * i, c = idx & 7, row = idx >> 3;          // row = t * 4 G + co
+            if (idx < 9 * 4 * G * 8) *reinterpret_cast<float4*>(wl + row * HD_PITCH + 4 * c) = wv[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float* src = win + toff[t];
+            const float* wsrc = wl + (t * 4 * G + (lane & 3)) * HD_PITCH;
+#pragma unroll
+            for (int j = 0; j < HD_KC / 4; ++j) {
+                const float4 a = *reinterpret_cast<const float4*>(src + 4 * j);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const float4 b = *reinterpret_cast<const float4*>(wsrc + g * 4 * HD_PITCH + 4 * j);
+                    acc[g][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, b.x, acc[g][0], 0, 0, 0);
+                    acc[g][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, b.y, acc[g][1], 0, 0, 0);
+                    acc[g][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.z, b.z, acc[g][0], 0, 0, 0);
+                    acc[g][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, b.w, acc[g][1], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // lane 4 b + j of a wave holds output channel 4 g + j of the wave's pixels 4 b .. 4 b + 3
+    const int pb = p0 + (tid & ~63) + (lane & ~3);
+    bool bad = false;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int co = 4 * g + (lane & 3);
+        if (co >= CO) continue;
+        const float bv = p.bias ? p.bias[co] : 0.f;
+        float* dst = p.y + ((long)n * CO + co) * HW + pb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v = (acc[g][0][i] + acc[g][1][i]) + bv;
+            if (pb + i < HW) dst[i] = v;
+            bad |= !__builtin_isfinite(v);
+        }
+    }
+    if (bad && p.range_flag) *p.range_flag = 1;
+}
+
+template <int G>
+int launch_head_mfma(const HeadParams& p, int CO, hipStream_t st) {
+    const size_t smem = ((size_t)(HD_TP + 2 * p.W + 3) + 9 * 4 * G) * HD_PITCH * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&head_mfma_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(((HD_TP + 2 * 64 + 3) + 9 * 4 * G) * HD_PITCH * sizeof(float))) != hipSuccess)
+            return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(head_mfma_kernel<G>, dim3((unsigned)(p.N * p.tiles_per_image)), dim3(256), smem, st, p, CO);
+    return hipGetLastError() == hipSuccess ? 0 : cdae_fail("head_mfma_kernel launch failed");
+}
+
 template <int CO>
 int launch_head(const HeadParams& p, hipStream_t st) {
     const size_t smem = (size_t)(HD_TP + 2 * p.W + 3) * HD_PITCH * sizeof(float);
@@ -147,6 +275,11 @@ extern "C" int cdae_head_conv_fwd(const float* x, long ldx, const float* coef, i
     cdae_prof_begin(PROF_IGEMM, 2.0 * N * H * W * 9.0 * Cin * Cout, st);
     cdae_prof_note(PROF_IGEMM, 4.0 * N * H * W * (Cin + Cout));
     int rc;
+    if (cdae_tune(TUNE_HEAD_MFMA)) {
+        rc = Cout <= 4 ? launch_head_mfma<1>(p, Cout, st) : launch_head_mfma<2>(p, Cout, st);
+        cdae_prof_end(PROF_IGEMM, st);
+        return rc;
+    }
     switch (Cout) {
         case 1: rc = launch_head<1>(p, st); break;
         case 2: rc = launch_head<2>(p, st); break;

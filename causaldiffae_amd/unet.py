@@ -14,7 +14,7 @@ Fusion map (what one launch replaces in the reference's eager ATen stream; kerne
   QKVAttention                                  -> attn_fused_kernel: QK^T, fp32 softmax in registers, PV — one launch (unet.py:239-253)
   proj_out 1x1 + residual                       -> streaming GEMM over NHWC rows                              (unet.py:230-231)
   22 emb_layers Linear(SiLU(emb))               -> ONE batched GEMM per forward                               (unet.py:148-154)
-  output head GN -> SiLU -> conv3x3 (C <= 8)    -> head_conv_kernel, exact fp32 on the vector ALUs             (unet.py:474-478)
+  output head GN -> SiLU -> conv3x3 (C <= 8)    -> head_mfma_kernel, exact fp32 products on v_mfma_f32_4x4x1    (unet.py:474-478)
 Training: a ResBlock is one autograd node (ops.resblock_train), the Upsample conv another, the embedding projections a third.
 """
 from abc import abstractmethod

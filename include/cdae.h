@@ -445,8 +445,10 @@ int cdae_rep_loss_bwd(const float* mu, const float* var, const float* z_post, co
  *                                else on the first-generation 128-row window kernel (smaller tiles fill the chip at small batch)
  *   CDAE_TUNE_CONVWIN_SPLITK     (1)   0: convwin_kernel never splits K
  *   CDAE_TUNE_CONVWIN_NJ3        (0)   256 x 96 tiles of the forward window kernel (Cout % 96 == 0, unsplit K): 0 = where they fill the
- *                                      block slots and 256 x 128 tiles do not, 1 = wherever they apply (tests), -1 = never */
-enum { CDAE_TUNE_CONVWIN_MIN_TILES = 0, CDAE_TUNE_CONVWIN_SPLITK = 1, CDAE_TUNE_CONVWIN_NJ3 = 2 };
+ *                                      block slots and 256 x 128 tiles do not, 1 = wherever they apply (tests), -1 = never
+ *   CDAE_TUNE_HEAD_MFMA          (1)   the output head (cdae_head_conv_fwd) on v_mfma_f32_4x4x1 (exact fp32 products, like the scalar
+ *                                      form it replaces: 0 = that form; the two differ in summation order only) */
+enum { CDAE_TUNE_CONVWIN_MIN_TILES = 0, CDAE_TUNE_CONVWIN_SPLITK = 1, CDAE_TUNE_CONVWIN_NJ3 = 2, CDAE_TUNE_HEAD_MFMA = 3 };
 int cdae_tune_set(int key, int value);
 int cdae_tune_get(int key);       /* -1: unknown key */
 

@@ -1415,9 +1415,11 @@ def test_groupnorm_linear_in_one_pass(N, C, Nf, H, silu):
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,C,Cout,H,W,silu", [(3, 128, 4, 64, 64, True), (2, 128, 3, 64, 64, True), (5, 128, 1, 32, 32, True), (2, 128, 8, 28, 28, True),
                                                (2, 128, 6, 9, 7, False), (1, 128, 2, 8, 12, True)])
-def test_output_head_kernel_matches_fp64(N, C, Cout, H, W, silu):
+@pytest.mark.parametrize("mfma", [1, 0])
+def test_output_head_kernel_matches_fp64(N, C, Cout, H, W, silu, mfma):
     """cdae_head_conv_fwd (GroupNorm -> SiLU -> conv3x3 to a few channels in one exact-fp32 kernel, the UNet's self.out) against
-    group_norm + conv2d in fp64: every supported channel count, image sizes that do not fill the 256-pixel tile, odd widths."""
+    group_norm + conv2d in fp64: every supported channel count, image sizes that do not fill the 256-pixel tile, odd widths — on the
+    4 x 4 x 1 matrix-core form (the default) and on the scalar form it replaced (CDAE_TUNE_HEAD_MFMA = 0)."""
     import torch.nn.functional as F
     from causaldiffae_amd import ops
     dev = "cuda:0"
@@ -1429,7 +1431,9 @@ def test_output_head_kernel_matches_fp64(N, C, Cout, H, W, silu):
     with torch.no_grad():
         lz = ops.group_norm_lazy(x, gamma, beta, None, silu, 32, 1e-5)
         assert ops.head_conv_ok(lz, w)
-        got = ops.head_conv(lz, w, b)
+        from causaldiffae_amd._lib import tune_scope
+        with tune_scope(head_mfma=mfma):
+            got = ops.head_conv(lz, w, b)
         planes = ops.conv3x3_ps(lz.planes(), w, b, out_nchw=True)           # the path it replaces
     h = F.group_norm(x.double(), 32, gamma.double(), beta.double(), 1e-5)
     ref = F.conv2d(F.silu(h) if silu else h, w.double(), b.double(), padding=1)

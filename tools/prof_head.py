@@ -12,7 +12,10 @@ for (N, C, Cout, S) in [(128, 128, 4, 64), (128, 128, 3, 64), (256, 128, 1, 32)]
     b = torch.randn(Cout, device=dev)
     with torch.no_grad():
         lz = ops.group_norm_lazy(x, gamma, beta, None, True, 32, 1e-5)
-        for name, fn in [("head kernel", lambda: ops.head_conv(lz, w, b)), ("planes + GEMM", lambda: ops.conv3x3_ps(lz.planes(), w, b, out_nchw=True))]:
+        from causaldiffae_amd._lib import check, lib
+        def scalar():
+            check(lib.cdae_tune_set(3, 0)); ops.head_conv(lz, w, b); check(lib.cdae_tune_set(3, 1))
+        for name, fn in [("head, 4x4x1 MFMA", lambda: ops.head_conv(lz, w, b)), ("head, scalar form", scalar), ("planes + GEMM", lambda: ops.conv3x3_ps(lz.planes(), w, b, out_nchw=True))]:
             fn(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -20,4 +23,4 @@ for (N, C, Cout, S) in [(128, 128, 4, 64), (128, 128, 3, 64), (256, 128, 1, 32)]
                 fn()
             e1.record(); torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / 5
-            print(f"N={N} C={C}->{Cout} @{S}x{S}  {name:14s} {us:8.1f} us   (input read floor {4.0 * N * S * S * C / 8e6:6.1f} us at 8 TB/s)")
+            print(f"N={N} C={C}->{Cout} @{S}x{S}  {name:18s} {us:8.1f} us   (input read floor {4.0 * N * S * S * C / 8e6:6.1f} us at 8 TB/s)")
