@@ -1945,3 +1945,21 @@ def test_window_conv_odd_shapes(splitk, expect_kernels):
         e = (y.double() - exact).abs().max().item() / max(1.0, exact.abs().max().item())
         assert e < 2e-5, ((N, ci, co, S, res), e)
     range_check("odd shapes")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,H,W,C", [(3, 16, 16, 256), (2, 5, 7, 96), (2, 4, 6, 6), (1, 3, 3, 5)])
+def test_sumpool2_matches_avg_pool(N, H, W, C):
+    """cdae_sumpool2 (the gradient of the fused nearest-2x upsample: NHWC [N, 2H, 2W, C] -> [N, H, W, C] sums of 2 x 2 pixels): the four-
+    channel vector form (C % 4 == 0) and the scalar form (C = 6, 5) against 4 * avg_pool2d; same order of additions, so exact."""
+    import torch.nn.functional as F
+    from causaldiffae_amd._lib import check, lib, ptr, stream
+    g = torch.Generator(device="cuda:0").manual_seed(9)
+    src = torch.randn(N, 2 * H, 2 * W, C, device="cuda:0", generator=g)
+    dst = torch.empty(N, H, W, C, device="cuda:0")
+    check(lib.cdae_sumpool2(ptr(src), ptr(dst), N, H, W, C, stream()))
+    s = src.reshape(N, H, 2, W, 2, C)
+    want = (s[:, :, 0, :, 0] + s[:, :, 0, :, 1]) + (s[:, :, 1, :, 0] + s[:, :, 1, :, 1])
+    assert torch.equal(dst, want)
+    ref = 4 * F.avg_pool2d(src.permute(0, 3, 1, 2).double(), 2).permute(0, 2, 3, 1)
+    assert (dst.double() - ref).abs().max().item() < 1e-5
