@@ -312,7 +312,7 @@ def main():
                 causaldiffae_amd.set_precision("fp32")
                 try:
                     torch.cuda.empty_cache()
-                    train["fp32_mode"] = train_bench(dev, world, rank, 8, 3, args.train_batch)
+                    train["fp32_mode"] = train_bench(dev, world, rank, 6, 3, args.train_batch, regions=3)      # (median of three regions: a single region of this leg has shown 66 and 73 ms on one box)
                 finally:
                     causaldiffae_amd.set_precision(prec0)
             if single and not args.no_extra:
