@@ -26,8 +26,15 @@ typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef ATT_ABL
+#define ATT_ABL 0         // dev ablation (timing only): 1 = no MFMAs in the fused forward
+#endif
 __device__ __forceinline__ f32x16 mma(const u16x8& a, const u16x8& b, const f32x16& c) {
+#if ATT_ABL & 1
+    f32x16 r = c; r[0] += __builtin_bit_cast(float, (unsigned)(a[0] ^ b[1])); return r;
+#else
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+#endif
 }
 // 8 fp32 -> f16 hi / lo fragments.  The empty asm makes each value opaque: when x is the result of a multiply, hipcc otherwise
 // converts it to f16 twice — v_cvt_pk_f16_f32 of the fp32 product for the fragment, but v_fma_mixlo_f16 of the UNROUNDED
@@ -89,36 +96,26 @@ __global__ __launch_bounds__((ATT_WAVES8 && NKT >= 8 && CH <= 96) ? 512 : NKT >=
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[kt][r] = 0.f;
 
-    auto stage = [&](int key0, int which /*1 = K (KC layout), 2 = V (k-major)*/) {
+    // Staging of a pass of keys (K rows, then V rows) is split into its two halves so that the global loads of the NEXT pass are in
+    // flight while the matrix cores work on the current one (round 4: the kernel runs one 512-thread block per CU at T = 256, so nothing
+    // else hides them — without MFMAs the T = 256, ch = 96 launch takes 51 of its 83 us): stage_load requests this thread's 16-byte
+    // pieces into registers, stage_commit (after the pass's MFMAs and a barrier) splits them into the LDS planes.
+    constexpr int ITEMS = (PASS * (CH / 4) + THREADS - 1) / THREADS;
+    constexpr bool EXACT = PASS * (CH / 4) % THREADS == 0;
+    auto stage_load = [&](float4 (&v)[ITEMS], int key0, int which /*1 = K (KC layout), 2 = V (k-major)*/) {
+#pragma unroll
+        for (int u = 0; u < ITEMS; ++u) {
+            const int item = tid + u * THREADS, row = item / (CH / 4), f4 = item - row * (CH / 4);
+            if (EXACT || item < PASS * (CH / 4)) v[u] = *reinterpret_cast<const float4*>(base + (long)(key0 + row) * C3 + which * CH + f4 * 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);             // the requests go out HERE, in front of the MFMA phase that follows
+    };
+    auto stage_commit = [&](const float4 (&v)[ITEMS], int which) {
         const int pitch = which == 1 ? KP : VP;
-        // four 16-byte loads in flight per thread (a load - convert - store loop exposes one memory round trip per item: 8-16 per pass):
-        // 26 -> 20 us (ch 128, T 64), 194 -> 150 us (ch 64, T 256); NOT for ch 96 at T 256, where the extra live registers push the
-        // allocation past what the K Q^T phase needs and the kernel gets slower (94 -> 106 us): that shape keeps the plain loop
-        constexpr int ITEMS = PASS * (CH / 4) / THREADS, GRP = 4;
-        constexpr bool BATCH = !(CH == 96 && NKT == 8) && PASS * (CH / 4) % THREADS == 0 && ITEMS % GRP == 0;
-        if constexpr (!BATCH) {
-            for (int item = tid; item < PASS * (CH / 4); item += THREADS) {
-                const int row = item / (CH / 4), f4 = item - row * (CH / 4);
-                const float4 v = *reinterpret_cast<const float4*>(base + (long)(key0 + row) * C3 + which * CH + f4 * 4);
-                half4 hi, lo;
-                hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
-                lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);
-                lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);
-                *reinterpret_cast<half4*>(lds + row * pitch + f4 * 8) = hi;
-                *reinterpret_cast<half4*>(lds + PLANE + row * pitch + f4 * 8) = lo;
-            }
-        } else
 #pragma unroll
-        for (int i0 = 0; i0 < ITEMS; i0 += GRP) {
-            float4 v[GRP];
-#pragma unroll
-            for (int u = 0; u < GRP; ++u) {
-                const int item = tid + (i0 + u) * THREADS, row = item / (CH / 4), f4 = item - row * (CH / 4);
-                v[u] = *reinterpret_cast<const float4*>(base + (long)(key0 + row) * C3 + which * CH + f4 * 4);
-            }
-#pragma unroll
-            for (int u = 0; u < GRP; ++u) {
-                const int item = tid + (i0 + u) * THREADS, row = item / (CH / 4), f4 = item - row * (CH / 4);
+        for (int u = 0; u < ITEMS; ++u) {
+            const int item = tid + u * THREADS, row = item / (CH / 4), f4 = item - row * (CH / 4);
+            if (EXACT || item < PASS * (CH / 4)) {
                 half4 hi, lo;
                 hi[0] = (_Float16)v[u].x; hi[1] = (_Float16)v[u].y; hi[2] = (_Float16)v[u].z; hi[3] = (_Float16)v[u].w;
                 lo[0] = (_Float16)(v[u].x - (float)hi[0]); lo[1] = (_Float16)(v[u].y - (float)hi[1]);
@@ -128,12 +125,25 @@ __global__ __launch_bounds__((ATT_WAVES8 && NKT >= 8 && CH <= 96) ? 512 : NKT >=
             }
         }
     };
+    float4 stg[ITEMS];
+    // PIPE: the next pass is requested in front of the current pass's MFMAs.  Measured per shape (same box, tools/prof_attn.py): T = 256,
+    // ch = 96: 81 -> 72 us, T = 64, ch = 128: 19.6 -> 18.3; ch = 64 (the 32 x 32 models): 103 -> 104-113 and 17.6 -> 18.8 — the 24 live
+    // staging registers cost those instantiations more than the overlap returns, so they keep the load - commit - compute order.
+    constexpr bool PIPE = CH >= 96;
 
+    if constexpr (PIPE) { stage_load(stg, 0, 1); stage_commit(stg, 1); }
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
-        if (ps) __syncthreads();
-        stage(ps * PASS, 1);
-        __syncthreads();
+        if constexpr (!PIPE) {
+            if (ps) __syncthreads();
+            stage_load(stg, ps * PASS, 1);
+            stage_commit(stg, 1);
+        }
+        __syncthreads();                                                                // pass ps of K is in LDS
+        if constexpr (PIPE) {
+            if (ps + 1 < NPASS) stage_load(stg, (ps + 1) * PASS, 1);                    // next: the following K pass, or the first V pass
+            else stage_load(stg, 0, 2);
+        }
 #pragma unroll
         for (int t = 0; t < TPP; ++t) {
             const int kt = ps * TPP + t;
@@ -146,6 +156,10 @@ __global__ __launch_bounds__((ATT_WAVES8 && NKT >= 8 && CH <= 96) ? 512 : NKT >=
                 acc[kt] = mma(kh, ql[s], acc[kt]);
                 acc[kt] = mma(kh, qh[s], acc[kt]);
             }
+        }
+        if constexpr (PIPE) {
+            __syncthreads();                                                            // everyone is done with pass ps
+            stage_commit(stg, ps + 1 < NPASS ? 1 : 2);
         }
     }
 
@@ -188,9 +202,13 @@ __global__ __launch_bounds__((ATT_WAVES8 && NKT >= 8 && CH <= 96) ? 512 : NKT >=
     const int q4 = (lane & 15) >> 2, p4 = lane & 3, chalf = 16 * ((lane >> 4) & 1);
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
-        __syncthreads();
-        stage(ps * PASS, 2);
-        __syncthreads();
+        if constexpr (!PIPE) {
+            __syncthreads();
+            stage_load(stg, ps * PASS, 2);
+            stage_commit(stg, 2);
+        }
+        __syncthreads();                                                                // pass ps of V is in LDS
+        if constexpr (PIPE) { if (ps + 1 < NPASS) stage_load(stg, (ps + 1) * PASS, 2); }
 #pragma unroll
         for (int t = 0; t < TPP; ++t) {
             const int kt = ps * TPP + t;
@@ -222,6 +240,12 @@ __global__ __launch_bounds__((ATT_WAVES8 && NKT >= 8 && CH <= 96) ? 512 : NKT >=
                     o[j] = mma(ph, vl, o[j]);
                     o[j] = mma(ph, vh, o[j]);
                 }
+            }
+        }
+        if constexpr (PIPE) {
+            if (ps + 1 < NPASS) {
+                __syncthreads();
+                stage_commit(stg, 2);
             }
         }
     }
