@@ -141,7 +141,9 @@ class ConvNd(nn.Module):
         if isinstance(x, ops.LazyGN):          # GroupNorm output not written yet: fuse it into the conv where the kernel exists
             if self.kernel_size == 3 and out_nchw and res is None and not up and self.stride == 1 and not emit_split and ops.head_conv_ok(x, self.weight):
                 return ops.head_conv(x, self.weight, self.bias)          # the output head: a few channels, exact fp32
-            x = x.planes(gm=self.kernel_size == 3 and self.stride == 1 and not up and not out_nchw)      # group-major for the window conv kernel
+            N_, C_, H_, W_ = x.shape
+            x = x.planes(gm=self.kernel_size == 3 and self.stride == 1 and not up and not out_nchw
+                         and ops.gm_wanted(N_, H_, W_, C_, self.weight.shape[0]))      # group-major for the window conv kernel (where this conv runs on it)
         if isinstance(x, ops.SplitAct):
             assert self.kernel_size == 3
             return ops.conv3x3_ps(x, self.weight, self.bias, res=res, stride=self.stride, up=up, out_nchw=out_nchw, emit_split=emit_split,

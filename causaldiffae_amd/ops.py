@@ -942,6 +942,22 @@ def planes_gm_ok(C):
     return _PLANES_GM and C % 16 == 0
 
 
+# Group-major planes are read by the window conv kernel only.  Whether a conv runs on it is the library's decision (tile counts, K
+# splits, dispatch thresholds): a shape it answered "not taken" for (cdae_conv3x3_fwd_psg returns 3, the caller converts once) is
+# remembered here, and whoever writes that conv's input planes next time writes them pixel-major straight away — at batch 16 most of a
+# DDIM step's convs are below the window kernel's grid threshold (25 conversion launches per step before this).
+_GM_REJECT = set()
+
+
+def _gm_key(N, H, W, Cin, Cout):
+    return (N, H, W, Cin, Cout, lib.cdae_tune_get(0), lib.cdae_tune_get(1))
+
+
+def gm_wanted(N, H, W, Cin, Cout):
+    """group-major planes for the stride-1 conv3x3 (N, H, W, Cin) -> Cout?"""
+    return planes_gm_ok(Cin) and _gm_key(N, H, W, Cin, Cout) not in _GM_REJECT
+
+
 _WSPLIT = {}
 _PRESPLIT_ON = os.environ.get("CDAE_PRESPLIT", "1") != "0"      # dev switch: 0 = in-kernel split everywhere
 _WEIGHT_EPOCH = [0]
@@ -1413,6 +1429,9 @@ def upconv3x3_ps(xs, w, b=None, gn_stats=False):
     return out
 
 
+_PS_PARTS_MIN_TILES = int(os.environ.get("CDAE_PS_GNPARTS_MIN_TILES", "256"))      # 128 x 128 tiles from which a conv's epilogue / split-K finish leaves GroupNorm sums
+
+
 def conv3x3_ps(xs, w, b=None, res=None, stride=1, up=False, out_nchw=False, emit_split=False, gn_stats=False):
     """conv3x3 of a SplitAct with pre-split OHWI weights (no autograd); result fp32 like ops.conv3x3.  emit_split: the result
     also leaves the kernel as f16 planes, attached as `out._split` for a following conv.  gn_stats: the epilogue also leaves
@@ -1436,14 +1455,15 @@ def conv3x3_ps(xs, w, b=None, res=None, stride=1, up=False, out_nchw=False, emit
     # statistics need the final values in the epilogue, i.e. no split-K: only where the unsplit grid fills the chip anyway
     # (the dispatcher's own rule: >= 256 tiles of 128 x 128), and where a 32-pixel chunk never straddles two images
     # (where the window kernel splits K — the 8 x 8 level — the sums come from the split-K finish kernel instead of the epilogue)
-    gn_stats = gn_stats and not out_nchw and (Ho * Wo) % 32 == 0 and Cout % 4 == 0 and ((M + 127) // 128) * ((Cout + 127) // 128) >= 256
+    gn_stats = gn_stats and not out_nchw and (Ho * Wo) % 32 == 0 and Cout % 4 == 0 and ((M + 127) // 128) * ((Cout + 127) // 128) >= _PS_PARTS_MIN_TILES
     parts = torch.empty(((M + 31) // 32, Cout, 2), dtype=torch.float32, device=dev) if gn_stats else None
     def launch(a, gmflag):
         return lib.cdae_conv3x3_fwd_psg(ptr(a.hi), ptr(a.lo), H * W * Cin, W * Cin, Cin, gmflag, ptr(w_hi), ptr(w_lo), *_pk(w, False), ptr(w_sc), ptr(b), ptr(res), ptr(out), Cout,
                                         1 if out_nchw else 0, *(ptr2(planes) if emit_split else (None, None)),
                                         ptr(parts), N, H, W, Cin, Cout, stride, 1 if up else 0, ws, wsb, stream())
     rc = launch(xs, 1 if xs.gm else 0)
-    if rc == 3:                       # group-major planes, but this shape does not run on the window kernel: pixel-major copy, once
+    if rc == 3:                       # group-major planes, but this shape does not run on the window kernel: pixel-major copy, this once
+        _GM_REJECT.add(_gm_key(N, H, W, Cin, Cout))      # (gm_wanted: the producer writes pixel-major planes for this conv from now on)
         rc = launch(xs.pc(), 0)
     check(rc)
     if emit_split:

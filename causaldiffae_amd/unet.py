@@ -183,7 +183,9 @@ class ResBlock(TimestepBlock):
         h = self.in_layers[0](x, silu=True, split=True, coef=isinstance(sk, ConvNd) and sk.kernel_size == 1)      # GN + SiLU (pre-split f16 planes on the inference path)
         skip = None
         if isinstance(h, ops.LazyGN) and isinstance(sk, ConvNd) and sk.kernel_size == 1 and ops.skip_gn_ok(h, sk.weight):
-            skip, h = ops.skip_gn_fused(h, sk.weight, sk.bias, gm=True)     # the 1x1 skip conv writes the normalised planes (group-major: the next conv is the window kernel) while it reads x
+            N_, C_, H_, W_ = h.shape
+            # the 1x1 skip conv writes the normalised planes (group-major where the next conv runs on the window kernel) while it reads x
+            skip, h = ops.skip_gn_fused(h, sk.weight, sk.bias, gm=ops.gm_wanted(N_, H_, W_, C_, self.in_layers[2].weight.shape[0]))
         fast = isinstance(h, (ops.SplitAct, ops.LazyGN))
         h = self.in_layers[2](h, gn_stats=True) if fast else self.in_layers[2](h)     # conv3x3 + bias (+ GroupNorm partial sums)
         if isinstance(emb, EmbAll):
