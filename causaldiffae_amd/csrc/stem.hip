@@ -12,6 +12,8 @@
 
 namespace {
 
+constexpr int STEM_ROWS = 4;
+
 template <int CIN>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x, long sn, long sy, long sx, long sc, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ out, long ldo, int H, int W, int Cout,
@@ -23,11 +25,16 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
     const int cg = Cout >> 2;                          // channel groups of 4
     float* const wl = smem;                             // [K][Cout]   (k = tap * CIN + ci)
     float* const in = smem + K * Cout;                  // [3][W + 2][CIN], zero padded
-    const int n = blockIdx.x / H, y = blockIdx.x - n * H, tid = threadIdx.x;
+    // A block owns STEM_ROWS consecutive output rows of one image (round 4; one row before): the weight transposition into LDS — 9 CIN
+    // Cout scattered 4-byte writes, as long as a row's arithmetic — is paid once per block instead of once per row.
+    const int rblocks = (H + STEM_ROWS - 1) / STEM_ROWS;
+    const int n = blockIdx.x / rblocks, y0 = (blockIdx.x - n * rblocks) * STEM_ROWS, tid = threadIdx.x;
     for (int i = tid; i < K * Cout; i += 256) {         // OHWI weight [co][tap][ci] -> [k][co]
         const int co = i / K, k = i - co * K;
         wl[k * Cout + co] = w[i];
     }
+    for (int y = y0; y < y0 + STEM_ROWS && y < H; ++y) {
+    if (y > y0) __syncthreads();                        // everyone is done with the previous row's inputs (and its reduction buffer)
     for (int i = tid; i < 3 * (W + 2) * CIN; i += 256) {
         const int ci = i % CIN, xx = (i / CIN) % (W + 2) - 1, yy = y + i / (CIN * (W + 2)) - 1;
         in[i] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? x[n * sn + yy * sy + xx * sx + ci * sc] : 0.f;
@@ -65,7 +72,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
                 }
         }
     }
-    if (!gn_part) return;
+    if (!gn_part) continue;
     // the ppp pixel lanes of a channel group, added in a fixed order through LDS (behind the weights and the input rows)
     float* const red = in + 3 * (W + 2) * CIN;          // [chunk][pl][Cout][2]
     const int nch = W >> 5;
@@ -87,6 +94,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
         for (int l = 0; l < ppp; ++l) { s_ += red[((c * ppp + l) * Cout + co) * 2]; q_ += red[((c * ppp + l) * Cout + co) * 2 + 1]; }
         float* o = gn_part + (((long)(n * H + y) * nch + c) * Cout + co) * 2;
         o[0] = s_; o[1] = q_;
+    }
     }
 }
 
@@ -118,7 +126,7 @@ extern "C" int cdae_conv3x3_stem_gn(const float* x, long sn, long sy, long sx, l
         static size_t attr = 0; \
         if (smem > attr) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_conv_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) \
             return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed"); attr = smem; } \
-        hipLaunchKernelGGL(stem_conv_kernel<C>, dim3(N * H), dim3(256), smem, st, x, sn, sy, sx, sc, w, bias, out, ldo, H, W, Cout, gn_part); } while (0)
+        hipLaunchKernelGGL(stem_conv_kernel<C>, dim3(N * ((H + STEM_ROWS - 1) / STEM_ROWS)), dim3(256), smem, st, x, sn, sy, sx, sc, w, bias, out, ldo, H, W, Cout, gn_part); } while (0)
     switch (Cin) { case 1: STEM(1); break; case 2: STEM(2); break; case 3: STEM(3); break; default: STEM(4); }
 #undef STEM
     cdae_prof_end(PROF_IGEMM, st);
