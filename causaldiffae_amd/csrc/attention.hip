@@ -53,6 +53,12 @@ __device__ __forceinline__ void split8(const float* v, u16x8& hi, u16x8& lo) {
     lo = __builtin_bit_cast(u16x8, l);
 }
 
+// Row pitch in bytes of a k-major plane that is read with ds_read_b64_tr_b16 (V in the forward, K in the query-side backward).  ch = 96
+// would make (ch + 32) * 2 = 256 bytes = all 64 banks: the four key rows a 16-lane group of the transpose read touches then sit on the
+// same banks (measured on the forward: LDS bank-conflict cycles = 56 % of the LDS-active cycles of that instantiation); 288 bytes puts
+// consecutive rows eight banks apart.
+constexpr int att_vp(int ch) { return (ch + 32) * 2 + ((ch + 32) * 2 % 256 == 0 ? 32 : 0); }
+
 #ifndef ATT_WAVES8
 #define ATT_WAVES8 1      // T = 256: eight waves (all 256 queries of a (batch, head)) per block, K and V staged once instead of twice
 #endif
@@ -64,7 +70,7 @@ __global__ __launch_bounds__((ATT_WAVES8 && NKT >= 8 && CH <= 96) ? 512 : NKT >=
     constexpr int PASS = T < 128 ? T : 128, NPASS = T / PASS, TPP = PASS / 32;       // keys per staging pass, passes, key tiles per pass
     constexpr int KSTEPS = CH / 16, CT = CH / 32;                                      // 16-deep MFMA steps over ch; 32-wide output tiles
     constexpr int KP = CH * 2 + 16;                                                    // K plane row pitch in bytes (conflict-free b128 reads)
-    constexpr int VP = (CH + 32) * 2;                                                  // V plane row pitch in bytes (k-major, transpose reads)
+    constexpr int VP = att_vp(CH);                                                     // V plane row pitch in bytes (k-major, transpose reads)
     constexpr int PLANE = PASS * (KP > VP ? KP : VP);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* const lds = reinterpret_cast<char*>(smem);                                   // [2 planes][PASS rows][pitch]
@@ -297,7 +303,7 @@ void attn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ 
     constexpr int T = 32 * NKT, WAVES = (ATT_WAVES8 && NKT >= 8 && CH <= 96) ? 8 : NKT >= 4 ? 4 : NKT, THREADS = 64 * WAVES;
     constexpr int PASS = T < 128 ? T : 128, NPASS = T / PASS, TPP = PASS / 32;
     constexpr int KSTEPS = CH / 16, CT = CH / 32;
-    constexpr int KP = CH * 2 + 16, VP = (CH + 32) * 2;
+    constexpr int KP = CH * 2 + 16, VP = att_vp(CH);
     constexpr int PLANE = PASS * (KP > VP ? KP : VP);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* const lds = reinterpret_cast<char*>(smem);
@@ -450,7 +456,7 @@ void attn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ 
 template <int CH, int NKT>
 int launch_attn_bwd_q(const float* qkv, const float* probs, const float* dout, float* dqkv, float* ds, int B, int heads, hipStream_t st) {
     constexpr int T = 32 * NKT, WAVES = (ATT_WAVES8 && NKT >= 8 && CH <= 96) ? 8 : NKT >= 4 ? 4 : NKT, PASS = T < 128 ? T : 128;
-    constexpr int KP = CH * 2 + 16, VP = (CH + 32) * 2;
+    constexpr int KP = CH * 2 + 16, VP = att_vp(CH);
     constexpr size_t smem = 2 * (size_t)PASS * (KP > VP ? KP : VP);
     static bool attr_done = false;
     if (!attr_done) {
@@ -466,7 +472,7 @@ int launch_attn_bwd_q(const float* qkv, const float* probs, const float* dout, f
 template <int CH, int NKT, bool PROBS>
 int launch_attn(const float* qkv, float* out, float* probs, int B, int heads, hipStream_t st) {
     constexpr int T = 32 * NKT, WAVES = (ATT_WAVES8 && NKT >= 8 && CH <= 96) ? 8 : NKT >= 4 ? 4 : NKT, PASS = T < 128 ? T : 128;
-    constexpr int KP = CH * 2 + 16, VP = (CH + 32) * 2;
+    constexpr int KP = CH * 2 + 16, VP = att_vp(CH);
     constexpr size_t smem = 2 * (size_t)PASS * (KP > VP ? KP : VP);
     static bool attr_done = false;
     if (!attr_done) {
