@@ -23,15 +23,16 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int K = 9 * CIN;
     const int cg = Cout >> 2;                          // channel groups of 4
-    float* const wl = smem;                             // [K][Cout]   (k = tap * CIN + ci)
-    float* const in = smem + K * Cout;                  // [3][W + 2][CIN], zero padded
+    float* const wl = smem;                             // [K][Cout + 4]   (k = tap * CIN + ci)
+    const int WP = Cout + 4;                            // weight row pitch: the transposing writes below go to banks 4 k + co instead of all to bank co
+    float* const in = smem + K * WP;                    // [3][W + 2][CIN], zero padded
     // A block owns STEM_ROWS consecutive output rows of one image (round 4; one row before): the weight transposition into LDS — 9 CIN
     // Cout scattered 4-byte writes, as long as a row's arithmetic — is paid once per block instead of once per row.
     const int rblocks = (H + STEM_ROWS - 1) / STEM_ROWS;
     const int n = blockIdx.x / rblocks, y0 = (blockIdx.x - n * rblocks) * STEM_ROWS, tid = threadIdx.x;
     for (int i = tid; i < K * Cout; i += 256) {         // OHWI weight [co][tap][ci] -> [k][co]
         const int co = i / K, k = i - co * K;
-        wl[k * Cout + co] = w[i];
+        wl[k * WP + co] = w[i];
     }
     for (int y = y0; y < y0 + STEM_ROWS && y < H; ++y) {
     if (y > y0) __syncthreads();                        // everyone is done with the previous row's inputs (and its reduction buffer)
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
 #pragma unroll
                 for (int ci = 0; ci < CIN; ++ci) {
                     const float v = in[(ky * (W + 2) + px + kx) * CIN + ci];
-                    const float4 ww = *reinterpret_cast<const float4*>(wl + ((ky * 3 + kx) * CIN + ci) * Cout + 4 * g);
+                    const float4 ww = *reinterpret_cast<const float4*>(wl + ((ky * 3 + kx) * CIN + ci) * WP + 4 * g);
                     acc.x = fmaf(v, ww.x, acc.x); acc.y = fmaf(v, ww.y, acc.y); acc.z = fmaf(v, ww.z, acc.z); acc.w = fmaf(v, ww.w, acc.w);
                 }
         *reinterpret_cast<float4*>(out + ((long)(n * H + y) * W + px) * ldo + 4 * g) = acc;
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
 }  // namespace
 
 extern "C" int cdae_conv3x3_stem_supported(int Cin, int Cout, int W) {
-    return Cin >= 1 && Cin <= 4 && Cout % 4 == 0 && Cout >= 4 && Cout <= 1024 && W >= 1 && (size_t)(9 * Cin * Cout + 3 * (W + 2) * Cin) * 4 <= 160 * 1024;
+    return Cin >= 1 && Cin <= 4 && Cout % 4 == 0 && Cout >= 4 && Cout <= 1024 && W >= 1 && (size_t)(9 * Cin * (Cout + 4) + 3 * (W + 2) * Cin) * 4 <= 160 * 1024;
 }
 
 extern "C" int cdae_conv3x3_stem(const float* x, long sn, long sy, long sx, long sc, const float* w, const float* bias, float* out, long ldo,
@@ -115,7 +116,7 @@ extern "C" int cdae_conv3x3_stem_gn(const float* x, long sn, long sy, long sx, l
     hipStream_t st = (hipStream_t)stream;
     if (!cdae_conv3x3_stem_supported(Cin, Cout, W) || ldo % 4 || (((size_t)out | (size_t)bias) & 15))
         return cdae_fail("conv3x3_stem: 1..4 input channels, Cout % 4 == 0, 16-byte aligned output rows required");
-    size_t smem = (size_t)(9 * Cin * Cout + 3 * (W + 2) * Cin) * sizeof(float);
+    size_t smem = (size_t)(9 * Cin * (Cout + 4) + 3 * (W + 2) * Cin) * sizeof(float);
     if (gn_part) {
         if (W % 32 || W > 128) return cdae_fail("conv3x3_stem_gn: partial sums need W % 32 == 0 and W <= 128");
         smem += (size_t)(W / 32) * (256 / (Cout / 4)) * Cout * 2 * sizeof(float);
