@@ -244,6 +244,48 @@ def train_bench(dev, world, rank, steps, warmup, batch, regions=1, image_size=64
             "workload": workload or f"CausalCircuit 64x64 C=3 CausalDiffAE training step (fwd+bwd+all-reduce+AdamW/EMA), {nparams / 1e6:.1f}M params"}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` started bare (no launcher, WORLD_SIZE unset): start N fresh rank processes of this same command — one
+    per GPU, env:// rendezvous on 127.0.0.1 — BEFORE this process touches the GPU, relay rank 0's JSON line, exit non-zero if any rank
+    fails.  (Never a re-exec of a process that initialised HIP; torch.cuda.device_count() does not.)  With fewer devices than ranks
+    (a one-GPU test box) the ranks share devices and gloo stands in for RCCL unless CDAE_DIST_BACKEND says otherwise."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ndev = torch.cuda.device_count()
+    procs = []
+    for r in range(n):
+        env = {**os.environ, "RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
+               "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")}
+        if 0 < ndev < n:
+            env.setdefault("CDAE_DIST_BACKEND", "gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True if r == 0 else None))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while any(p.poll() is None for p in procs):
+        failed = next((p for p in procs if p.poll() not in (None, 0)), None)
+        if failed is not None:            # a dead rank leaves its peers waiting in the next collective: end them (exact PIDs we started)
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.2)
+    codes = [p.wait() for p in procs]
+    reader.join(10)
+    sys.stdout.write("".join(c for c in chunks if c))
+    sys.stdout.flush()
+    if failed is not None or any(codes):
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+        sys.exit((failed.returncode if failed is not None else next(c for c in codes if c)) or 1)
+    sys.exit(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -260,6 +302,9 @@ def main():
     ap.add_argument("--no-fp32", action="store_true", help="skip the secondary IEEE-fp32-product legs")
     ap.add_argument("--no-extra", action="store_true", help="skip the public-loop, guidance and config [1] legs")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args.gpus)            # does not return
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -290,6 +335,9 @@ def main():
     if args.precision:
         causaldiffae_amd.set_precision(args.precision)
     prec0 = causaldiffae_amd.get_precision()
+    # what THIS box sustains (register-resident MFMA loop, flat HBM copy; outside every timed region): the pool's boxes differ by +-3 %,
+    # the fractions below are reported against the nominal peaks AND against these
+    box = _lib.calibrate(dev) if rank == 0 else None
     single = world == 1
     # ---- training legs FIRST, in a process that has not replayed a HIP graph yet: the sampling legs below leave runtime helper threads
     # behind (one of them busy-waiting: 6-28 ms of CPU per training step measured when the order is reversed) that a training job does not have
@@ -427,10 +475,9 @@ def main():
                  # 2MNK as EXECUTED: the three upsample convs run in their folded sub-pixel form (2.25x fewer multiply-adds than the
                  # reference's formulation), so this is below the reference-algorithm rate `model_tflops` implies
                  "flops_convention": "executed 2MNK per launch (sub-pixel up-convs at folded size)",
-                 # register-resident MFMA loops on random operands sustain 1650 (32x32x16) / 1980 (16x16x32) TFLOP/s on this part
-                 # (tools/hiptests/mfma_peak.hip, profiles/r02_mfma_sustained.txt; the chip holds ~1.85 GHz under MFMA load):
-                 # 660 TFLOP/s in f16x3 terms for the 16x16x32 kernel
-                 "frac_of_sustained_mfma": (ach / (1980.0 / 3.0)) if prec == "f16x3" else None,
+                 # against what a register-resident v_mfma_f32_16x16x32_f16 loop sustains on THIS box in THIS process (`box`,
+                 # cdae_calib_mfma: ~1900-1980 TFLOP/s at the ~1.85 GHz the chip holds under MFMA load; / 3 in f16x3 terms)
+                 "frac_of_sustained_mfma": (ach / (box["mfma_sustained_tflops"] / 3.0)) if prec == "f16x3" and box else None,
                  "all_contractions": {"achieved": fam_work / (fam_ms * 1e-3) / 1e12 if fam_ms > 0 else 0.0, "launches_per_step": fam_n // eager_steps,
                                       "ms_per_step": fam_ms / eager_steps},
                  "family_ms_per_step": {k: v["ms"] / eager_steps for k, v in prof.items()}}
@@ -440,14 +487,28 @@ def main():
             traffic = traffic_src = None
             # (convwin: the 9-TAP instantiation's own summary — the 4-tap sub-pixel kernel is a separate kernel name and a separate file)
             stem = "convwin9" if dom is cw else "igemm"
-            cands = [f"r04_{stem}_pmc_summary_{prec}.json"] + ([f"r03_convwin_pmc_summary_{prec}.json"] if dom is cw else [f"r01_igemm_pmc_summary_{prec}.json"])
+            cands = [f"r05_{stem}_pmc_summary_{prec}.json", f"r04_{stem}_pmc_summary_{prec}.json"] + ([f"r03_convwin_pmc_summary_{prec}.json"] if dom is cw else [f"r01_igemm_pmc_summary_{prec}.json"])
             pmc_file = next((os.path.join(ROOT, "profiles", c) for c in cands if os.path.exists(os.path.join(ROOT, "profiles", c))), None)
             if pmc_file and N == 128:
                 pm = json.load(open(pmc_file))
                 traffic, traffic_src = pm["hbm_traffic_bytes_per_launch"], f"profiles/{os.path.basename(pmc_file)} (rocprofv3 --pmc, same workload)"
             alg = dom["bytes"] / max(1, dom["launches"]) if dom["bytes"] > 0 else None
-            r.update({"traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
+            r.update({"traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src, "traffic_measured_in_run": False,
                       "algorithmic_bytes_per_launch": alg, "traffic_ratio": (traffic / alg) if traffic and alg else None})
+            # the fused sub-pixel up-conv (convwin_kernel<f16, 4 taps>: nearest-2x + conv3x3 as four 2x2 phases of the low-res input) by itself
+            up = prof["convwin_up"]
+            if up["launches"] > 0 and up["ms"] > 0:
+                ach4 = up["work"] / (up["ms"] * 1e-3) / 1e12
+                alg4 = up["bytes"] / up["launches"] if up["bytes"] > 0 else None
+                pm4 = next((os.path.join(ROOT, "profiles", c) for c in (f"r05_convwin4_pmc_summary_{prec}.json", f"r04_convwin4_pmc_summary_{prec}.json")
+                            if os.path.exists(os.path.join(ROOT, "profiles", c))), None)
+                t4 = json.load(open(pm4))["hbm_traffic_bytes_per_launch"] if pm4 and N == 128 else None
+                r["upconv_4tap"] = {"kernel": "convwin_kernel<f16, 4 taps>", "bound": "mfma", "achieved": ach4, "peak": peak, "frac": ach4 / peak,
+                                    "unit": "TFLOP/s (executed 2MNK, folded 2x2 phases)", "launches_per_step": up["launches"] // eager_steps,
+                                    "avg_launch_us": 1e3 * up["ms"] / up["launches"], "ms_per_step": up["ms"] / eager_steps,
+                                    "frac_of_sustained_mfma": (ach4 / (box["mfma_sustained_tflops"] / 3.0)) if prec == "f16x3" and box else None,
+                                    "algorithmic_bytes_per_launch": alg4, "traffic": t4, "traffic_ratio": (t4 / alg4) if t4 and alg4 else None,
+                                    "traffic_source": f"profiles/{os.path.basename(pm4)}" if t4 else None, "traffic_measured_in_run": False}
             return r
 
         region_s = timed_ddim(args.steps, args.warmup, max(1, args.regions))
@@ -536,6 +597,10 @@ def main():
         "samples_per_sec_ddim100": value / 100.0,
         "model_tflops": value * GFLOP_PER_IMAGE_STEP_P64 / 1e3,
         "roofline": roof,
+        "box": box,
+        # the whole step against the nominal roof and against this box's sustained MFMA rate (f16x3: / 3)
+        "whole_step_frac_of_roof": value * GFLOP_PER_IMAGE_STEP_P64 / 1e3 / world / (F16_MFMA_PEAK_TFLOPS / 3.0 if prec0 == "f16x3" else FP32_MFMA_PEAK_TFLOPS),
+        "whole_step_frac_of_sustained_mfma": (value * GFLOP_PER_IMAGE_STEP_P64 / 1e3 / world / (box["mfma_sustained_tflops"] / 3.0)) if box and prec0 == "f16x3" else None,
         "other_precision": other,
         "train": train,
         **extra,

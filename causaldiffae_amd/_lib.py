@@ -121,6 +121,7 @@ SIGNATURES = {
     "cdae_reparam": [P, P, F, P, P, L, P],
     "cdae_causal_mask": [P, P, P, I, I, I, I, P],
     "cdae_adamw_ema": [P, P, P, P, P, L, D, D, D, D, D, I, D, D, P],
+    "cdae_adamw_ema_multi": [P, P, P, P, P, P, I, L, D, D, D, D, D, I, D, P],
     "cdae_sqsum": [P, L, P, P],
     "cdae_p_mean_variance": [P, P, P, P, I, I, I, I, P, P, P, P, P, P, I, L, P],
     "cdae_vb_terms": [P, P, P, P, P, I, I, I, I, P, P, I, L, P],
@@ -133,6 +134,8 @@ SIGNATURES = {
     "cdae_tune_get": [I],
     "cdae_prof_enable": [I],
     "cdae_prof_read": [P, P, P, P],
+    "cdae_calib_mfma": [P, SZ, I, P, P, P],
+    "cdae_calib_copy": [P, P, SZ, I, P, P],
 }
 _RESTYPES = {"cdae_last_error": ctypes.c_char_p, "cdae_gn_workspace_floats": SZ, "cdae_bn_workspace_floats": SZ, "cdae_workspace_bytes": SZ}
 
@@ -344,6 +347,18 @@ class tune_scope:
         for k, v in self.prev.items():
             check(lib.cdae_tune_set(TUNE_KEYS[k], v))
         return False
+
+
+def calibrate(device, copy_bytes=1 << 30):
+    """{mfma_sustained_tflops, sclk_under_load_ghz, hbm_copy_tbps} of THIS box, measured through the library (cdae_calib_*): what bench.py
+    normalises its roofline fractions with.  Synchronises; ~0.1 s."""
+    scratch = torch.empty((4 << 20) + 8192, dtype=torch.uint8, device=device)
+    tf, ghz, tb = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0)
+    check(lib.cdae_calib_mfma(ptr(scratch), scratch.numel(), 20000, ctypes.byref(tf), ctypes.byref(ghz), stream()))
+    src = torch.empty(copy_bytes // 4, dtype=torch.float32, device=device).normal_()
+    dst = torch.empty_like(src)
+    check(lib.cdae_calib_copy(ptr(src), ptr(dst), copy_bytes, 5, ctypes.byref(tb), stream()))
+    return {"mfma_sustained_tflops": tf.value, "sclk_under_load_ghz": ghz.value, "hbm_copy_tbps": tb.value}
 
 
 def prof_enable(on):

@@ -500,6 +500,26 @@ __global__ void adamw_ema_kernel(float* __restrict__ p, const float* __restrict_
     }
 }
 
+// the same update with up to four EMA buffers (TrainLoop's "--ema_rate 0.999,0.9999"): every further rate was an ATen mul_ + add_ pass
+// over the flat buffer (16 B / parameter each) behind the optimizer kernel
+struct EmaSet { float* buf[4]; float rate[4]; int n; };
+__global__ void adamw_ema_multi_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                       EmaSet es, long n, float lr, float b1, float b2, float eps, float wd,
+                                       float bc1, float sqrt_bc2, float grad_scale) {
+    GRID_STRIDE(i, n) {
+        float gi = g[i] * grad_scale;
+        float pi = p[i] * (1.f - lr * wd);
+        float mi = m[i] * b1 + (1.f - b1) * gi;
+        float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+        float denom = sqrtf(vi) / sqrt_bc2 + eps;
+        pi = pi - (lr / bc1) * (mi / denom);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < es.n) es.buf[k][i] = es.buf[k][i] * es.rate[k] + (1.f - es.rate[k]) * pi;
+    }
+}
+
 __global__ void sqsum_kernel(const float* __restrict__ x, long n, double* __restrict__ out) {
     double s = 0.0;
     GRID_STRIDE(i, n) { double v = x[i]; s += v * v; }
@@ -865,6 +885,21 @@ int cdae_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, lon
                        (float)weight_decay, bc1, sqrt_bc2, (float)ema_rate, (float)grad_scale);
     cdae_prof_end(PROF_OPT, ST);
     if (hipGetLastError() != hipSuccess) return cdae_fail("adamw_ema launch failed");
+    return 0;
+}
+int cdae_adamw_ema_multi(float* p, const float* g, float* m, float* v, float* const* emas, const double* ema_rates, int n_ema, long n, double lr,
+                         double beta1, double beta2, double eps, double weight_decay, int step, double grad_scale, void* stream) {
+    if (n_ema < 0 || n_ema > 4 || (n_ema && (!emas || !ema_rates))) return cdae_fail("adamw_ema_multi: 0..4 EMA buffers (host arrays of pointers and rates)");
+    EmaSet es{};
+    es.n = n_ema;
+    for (int k = 0; k < n_ema; ++k) { if (!emas[k]) return cdae_fail("adamw_ema_multi: NULL EMA buffer"); es.buf[k] = emas[k]; es.rate[k] = (float)ema_rates[k]; }
+    const float bc1 = (float)(1.0 - pow(beta1, (double)step));
+    const float sqrt_bc2 = (float)sqrt(1.0 - pow(beta2, (double)step));
+    cdae_prof_begin(PROF_OPT, (double)n * (24.0 + 8.0 * n_ema), ST);
+    hipLaunchKernelGGL(adamw_ema_multi_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, ST, p, g, m, v, es, n, (float)lr, (float)beta1, (float)beta2, (float)eps,
+                       (float)weight_decay, bc1, sqrt_bc2, (float)grad_scale);
+    cdae_prof_end(PROF_OPT, ST);
+    if (hipGetLastError() != hipSuccess) return cdae_fail("adamw_ema_multi launch failed");
     return 0;
 }
 int cdae_sqsum(const float* x, long n, double* out, void* stream) {

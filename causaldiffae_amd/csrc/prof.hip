@@ -82,7 +82,89 @@ void cdae_prof_end(int fam, hipStream_t st) {
     t_start = nullptr;
 }
 
+namespace {
+typedef float calib_f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 calib_half8 __attribute__((ext_vector_type(8)));
+// register-resident v_mfma_f32_16x16x32_f16 loop, three dependent MFMAs per accumulator like the f16x3 product (the form of
+// tools/hiptests/mfma_peak.hip's best case): what THIS box's matrix cores sustain on random operands at the clock the part holds
+// under that load.  clk[0] += shader cycles (s_memtime), clk[1] += 100 MHz ticks (s_memrealtime) of one wave per block.
+__global__ void __launch_bounds__(64) calib_mfma_kernel(const calib_half8* __restrict__ in, float* __restrict__ out, int iters,
+                                                        unsigned long long* __restrict__ clk) {
+    calib_half8 a0 = in[threadIdx.x], a1 = in[threadIdx.x + 64], b0 = in[threadIdx.x + 128], b1 = in[threadIdx.x + 192];
+    calib_f32x4 c[8] = {};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            c[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b0, c[q], 0, 0, 0);
+            c[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b1, c[q], 0, 0, 0);
+            c[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, c[q], 0, 0, 0);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+    for (int q = 0; q < 8; ++q) for (int r = 0; r < 4; ++r) s += c[q][r];
+    out[blockIdx.x * 64 + threadIdx.x] = s;
+    if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) { atomicAdd(&clk[0], t1 - t0); atomicAdd(&clk[1], r1 - r0); }
+}
+__global__ void __launch_bounds__(256) calib_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) dst[i] = src[i];
+}
+}  // namespace
+
 extern "C" {
+
+// Box calibration for bench.py (outside its timed regions): the sustained f16 MFMA rate and the shader clock under that load.
+// scratch: >= 4 MiB + 4 KiB of device memory the call may overwrite.
+int cdae_calib_mfma(void* scratch, size_t scratch_bytes, int iters, double* tflops, double* sclk_ghz, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = 256 * 4 * 2;                       // two waves per SIMD, as the window conv kernel runs
+    const size_t need = 4096 + 16 + (size_t)blocks * 64 * 4;
+    if (!scratch || scratch_bytes < need || iters <= 0 || !tflops || !sclk_ghz) return cdae_fail("calib_mfma: scratch too small or bad arguments");
+    _Float16 h[256 * 8];
+    unsigned seed = 12345u;
+    for (int i = 0; i < 256 * 8; ++i) { seed = seed * 1664525u + 1013904223u; h[i] = (_Float16)((((seed >> 8) & 0xffff) / 65536.f - 0.5f) * 0.05f); }
+    char* base = (char*)scratch;
+    unsigned long long* clk = (unsigned long long*)(base + 4096);
+    float* out = (float*)(base + 4096 + 16);
+    if (hipMemcpyAsync(base, h, sizeof(h), hipMemcpyHostToDevice, st) != hipSuccess) return cdae_fail("calib_mfma: upload failed");
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0.f;
+    unsigned long long hclk[2] = {0, 0};
+    for (int rep = 0; rep < 2; ++rep) {                   // the first launch warms the clocks up
+        hipMemsetAsync(clk, 0, 16, st);
+        hipEventRecord(e0, st);
+        hipLaunchKernelGGL(calib_mfma_kernel, dim3(blocks), dim3(64), 0, st, (const calib_half8*)base, out, iters, clk);
+        hipEventRecord(e1, st);
+        if (hipEventSynchronize(e1) != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); return cdae_fail("calib_mfma: kernel failed"); }
+    }
+    hipEventElapsedTime(&ms, e0, e1);
+    hipMemcpy(hclk, clk, 16, hipMemcpyDeviceToHost);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *tflops = (double)blocks * iters * 24 * 2.0 * 16 * 16 * 32 / (ms * 1e-3) / 1e12;
+    *sclk_ghz = hclk[1] ? (double)hclk[0] / (double)hclk[1] * 0.1 : 0.0;
+    return 0;
+}
+
+// HBM copy rate (read + write bytes per second) of a flat float4 copy src -> dst of `bytes` bytes (use >= 1 GiB: beyond the 256 MiB MALL)
+int cdae_calib_copy(const void* src, void* dst, size_t bytes, int reps, double* tbps, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!src || !dst || bytes < 4096 || bytes % 16 || reps <= 0 || !tbps) return cdae_fail("calib_copy: bad arguments");
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const long n4 = (long)(bytes / 16);
+    hipLaunchKernelGGL(calib_copy_kernel, dim3(256 * 16), dim3(256), 0, st, (const float4*)src, (float4*)dst, n4);
+    hipEventRecord(e0, st);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(calib_copy_kernel, dim3(256 * 16), dim3(256), 0, st, (const float4*)src, (float4*)dst, n4);
+    hipEventRecord(e1, st);
+    if (hipEventSynchronize(e1) != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); return cdae_fail("calib_copy: kernel failed"); }
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *tbps = 2.0 * (double)bytes * reps / (ms * 1e-3) / 1e12;
+    return 0;
+}
 
 const char* cdae_last_error(void) { return g_err.c_str(); }
 

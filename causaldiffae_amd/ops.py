@@ -146,7 +146,7 @@ def wgrad_side_stream_on():
 def _side(dev):
     st = _SIDE.get(dev.index)
     if st is None:
-        st = _SIDE[dev.index] = dict(stream=torch.cuda.Stream(device=dev), dirty=False, pending=[], hooked=False)
+        st = _SIDE[dev.index] = dict(stream=torch.cuda.Stream(device=dev), dirty=False, pending=[], hooked=None, held=[])
     return st
 
 
@@ -165,22 +165,37 @@ def _side_flush(sd, dev):
     sd["dirty"] = True
 
 
-def side_launch(dev, tensors, fn):
+def _graph_task():
+    """id of the autograd graph task this thread is executing (-1 outside a backward pass)"""
+    try:
+        return torch._C._current_graph_task_id()
+    except AttributeError:
+        return -1
+
+
+def side_launch(dev, tensors, fn, hold=()):
     """Run `fn(raw_stream, splitk_ws_ptr, splitk_ws_bytes)` — a wgrad launch that accumulates into the flat gradient buffer — on the
     side stream, behind everything issued to the current stream so far (possibly a little later: launches are flushed in groups).
-    `tensors`: what the launch reads — kept alive until the flush, then `record_stream`ed.  They must not be overwritten afterwards."""
+    `tensors`: what the launch reads — kept alive until the flush, then `record_stream`ed (which guards against the allocator recycling
+    them, not against later WRITES).  `hold`: operands that are also handed back to autograd as a gradient (`dres = dy`): a reference
+    is kept until side_join, so the engine's input buffer sees use_count > 1 and accumulates out of place instead of adding into a
+    buffer the queued launch still reads."""
     if not wgrad_side_stream_on():
         ws, wsb = _sk(dev)
         fn(stream(), ws, wsb)
         return
     sd = _side(dev)
     sd["pending"].append((tensors, fn))
-    if not sd["hooked"]:
+    if hold:
+        sd["held"].extend(t for t in hold if t is not None)
+    task = _graph_task()
+    if task >= 0 and sd["hooked"] != task:
         # the stream that called backward() joins the side stream when the backward pass ends: `.backward()` then returns with every
-        # gradient ordered behind it on that stream, like a single-stream backward (and a graph capture of the step closes its fork)
+        # gradient ordered behind it on that stream, like a single-stream backward (and a graph capture of the step closes its fork).
+        # Keyed on the graph task: a backward that raised after registering drops its callback, and the next one registers its own.
         try:
             torch.autograd.Variable._execution_engine.queue_callback(side_join)
-            sd["hooked"] = True
+            sd["hooked"] = task
         except RuntimeError:        # not inside a backward pass: the caller joins (side_join)
             pass
     if len(sd["pending"]) >= _SIDE_GROUP:
@@ -192,12 +207,13 @@ def side_join(dev=None):
     for idx, sd in _SIDE.items():
         if dev is not None and dev.index != idx:
             continue
-        sd["hooked"] = False
+        sd["hooked"] = None
         sdev = sd["stream"].device
         _side_flush(sd, sdev)
         if sd["dirty"]:
             torch.cuda.current_stream(sdev).wait_stream(sd["stream"])
             sd["dirty"] = False
+        sd["held"] = []
 
 
 # ----------------------------------------------------------------------------- conv3x3
@@ -258,7 +274,7 @@ class _Conv3x3(Function):
                 check(lib.cdae_conv3x3_wgrad(ptr(x), x.stride(0), x.stride(2), x.stride(3), x.stride(1), ptr(dy), Cout, ptr(dw), ptr(db),
                                              N, H, W, Cin, Cout, stride, 1 if up else 0, 1 if direct else 0, ws_, wsb_, st_))
             if direct:
-                side_launch(dev, (x, dy), wg)
+                side_launch(dev, (x, dy), wg, hold=(dy,) if has_res else ())
                 dw = db = None
                 _done(rw, rb)
             else:
@@ -427,7 +443,7 @@ class _Linear(Function):
                 check(lib.cdae_linear_wgrad(ptr(x), x.stride(0), ptr(dya), Nf, ptr(dw), K, ptr(db) if want_b else None, M, Nf, K,
                                             1 if direct else 0, ws_, wsb_, st_))
             if direct:
-                side_launch(dev, (x, dya), wg)
+                side_launch(dev, (x, dya), wg, hold=(dya,) if (has_res and dya is dy) else ())
                 dw = db = None
                 _done(rw, rb if want_b else None)
             else:
@@ -992,6 +1008,7 @@ class ScaleTable:
         self.records = torch.ones((len(self.tensors), 2), dtype=torch.float32, device=dev)
         self.scratch = torch.zeros(len(self.tensors), dtype=torch.int32, device=dev)
         self.epoch, self.versions, self._views = None, [None] * len(self.tensors), {}
+        self.generation = 0             # bumped whenever the records are rewritten: planes prepared with older records are stale (ConvWeightBank)
         for t in self.tensors:
             _SCALE_OF[id(t)] = (weakref.ref(t), self)
 
@@ -1002,6 +1019,7 @@ class ScaleTable:
             return
         check(lib.cdae_weight_scales(ptr(self.flat), ptr(self.desc), len(self.tensors), self.chunks, ptr(self.records), ptr(self.scratch), stream()))
         self.epoch, self.versions = _WEIGHT_EPOCH[0], [x._version for x in self.tensors]
+        self.generation += 1
 
     def record(self, t):
         self.refresh(t)
@@ -1096,20 +1114,25 @@ class ConvWeightBank:
             self.where[id(w)] = (o - self.base, w.numel())
         self.tiles = tiles
         self.desc = torch.from_numpy(desc.view(np.uint8).copy()).to(dev)
-        self.epoch, self.versions, self._ptrs = None, {}, {}
+        self.epoch, self.versions, self._ptrs, self.scale_gen = None, {}, {}, None
         for w in self.weights:
             _BANK_OF[id(w)] = (weakref.ref(w), self)
 
     def _refresh(self, w):
-        if self.epoch != _WEIGHT_EPOCH[0] or self.versions.get(id(w)) != w._version:
+        # the records first, asked for THIS weight: a version-only change (an in-place torch op, load_state_dict after registration) must
+        # rewrite its 2^k before the planes are rebuilt with it; and planes built with records that were rewritten since (by anyone's
+        # refresh of the shared table) are stale whatever the weight's own version says — the kernels unscale with the CURRENT record
+        if self.scales is not None:
+            self.scales.refresh(w)
+        if (self.epoch != _WEIGHT_EPOCH[0] or self.versions.get(id(w)) != w._version
+                or (self.scales is not None and self.scale_gen != self.scales.generation)):
             k = self.kpack
-            if self.scales is not None:
-                self.scales.refresh()
             check(lib.cdae_wprep_all_k(ptr(self.flat), ptr(self.desc), len(self.weights), self.tiles, self.base, ptr(self.f16[0]), ptr(self.f16[1]),
                                        ptr(self.b16[0]), ptr(self.b16[1]), ptr(self.kf16[0]) if k else None, ptr(self.kf16[1]) if k else None,
                                        ptr(self.kb16[0]) if k else None, ptr(self.kb16[1]) if k else None,
                                        ptr(self.scales.records) if self.scales is not None else None, stream()))
             self.epoch, self.versions = _WEIGHT_EPOCH[0], {id(x): x._version for x in self.weights}
+            self.scale_gen = self.scales.generation if self.scales is not None else None
 
     def planes(self, w, bf16):
         """(hi, lo) bf16 dgrad planes, or (hi, lo, scale record) of the f16 forward planes (record None: unscaled)"""

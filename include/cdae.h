@@ -428,6 +428,11 @@ int cdae_causal_mask(const float* u, const float* A, float* out, int N, int nv, 
 /* AdamW + EMA over flat fp32 buffers (train_util.py:292-297, nn.py:503-513); ema may be NULL */
 int cdae_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, long n, double lr, double beta1, double beta2, double eps,
                    double weight_decay, int step, double ema_rate, double grad_scale, void* stream);
+/* the same step with 0..4 EMA buffers in ONE pass (train_util.py:292-297 loops `update_ema` over every rate of "--ema_rate a,b");
+   emas / ema_rates are HOST arrays of n_ema device pointers / rates; grad_scale multiplies the gradient as it is read (1 / world: the
+   mean of the all-reduced sum, train_util.py:111-118, without a pass of its own) */
+int cdae_adamw_ema_multi(float* p, const float* g, float* m, float* v, float* const* emas, const double* ema_rates, int n_ema, long n, double lr,
+                         double beta1, double beta2, double eps, double weight_decay, int step, double grad_scale, void* stream);
 int cdae_sqsum(const float* x, long n, double* out, void* stream);                                            /* grad-norm, train_util.py:299-303 */
 int cdae_mse_rows(const float* a, const float* b, float* out, int N, long per, void* stream);               /* mean_flat((a-b)^2), gaussian_diffusion.py:847 */
 int cdae_mse_rows_bwd(const float* a, const float* b, const float* gout, float* db, int N, long per, void* stream);
@@ -456,6 +461,12 @@ int cdae_tune_get(int key);       /* -1: unknown key */
 int cdae_prof_enable(int on);
 /* per family since the last read: milliseconds, flops (2MNK as executed), algorithmic bytes (convwin: each operand and the result once), launches */
 int cdae_prof_read(double* ms, double* work, double* bytes, long long* launches);
+/* box calibration (bench.py reports it beside every roofline fraction: the pool's boxes differ by +-3 %): the f16 MFMA rate a
+   register-resident v_mfma_f32_16x16x32_f16 loop sustains on random operands (TFLOP/s, two waves per SIMD on every CU) with the shader
+   clock the part holds under that load (GHz, s_memtime over s_memrealtime), and the read + write rate of a flat HBM copy (TB/s).
+   Both synchronise the stream; scratch >= 4 MiB + 8 KiB of device memory. */
+int cdae_calib_mfma(void* scratch, size_t scratch_bytes, int iters, double* tflops, double* sclk_ghz, void* stream);
+int cdae_calib_copy(const void* src, void* dst, size_t bytes, int reps, double* tbps, void* stream);
 
 #ifdef __cplusplus
 }

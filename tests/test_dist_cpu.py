@@ -78,6 +78,18 @@ def _worker(rank, world, port, q):
         loss_on(xs[rank]).backward()
         buckets.finish()
         err = (flat.grad - want).abs().max().item()
+        # overlap: while backward is still running (the gradient has only just reached the FIRST layer's output) the buckets of the later
+        # layers must already have been handed to the process group — not queued up for finish()
+        flat.zero_grad()
+        seen = {}
+        h0 = model[0](xs[rank])
+        h0.register_hook(lambda g_: seen.update(launched=buckets.next_launch, in_flight=sum(b["work"] is not None for b in buckets.buckets),
+                                                first_fired=buckets.fired[0]))
+        (model[1:5](h0).pow(2).mean() + model.conv(torch.ones(1, 4, 5, 5)).mean() * xs[rank].mean()).backward()
+        assert seen["launched"] >= 1 and seen["in_flight"] >= 1 and not seen["first_fired"], seen
+        buckets.finish(average=False)                                   # TrainLoop's call: the SUM stays, the optimizer kernel scales by 1 / world
+        err_sum = (flat.grad / world - want).abs().max().item()
+        assert err_sum < 1e-6, err_sum
         lo, hi = dist_util.shard_range(1024 + 3, rank, world)
         got = dist_util.gather_samples(torch.full((2, 3), float(rank)))
         # uneven shards (n % world != 0: the low rank owns one row more) — every rank must still see all rows in rank order
