@@ -132,7 +132,7 @@ def _host_cores_per_rank():
 _WGRAD_SIDE_ON = {"1": True, "0": False}.get(os.environ.get("CDAE_WGRAD_STREAM", "auto"), None)
 # One cross-stream dependency per launch.  Handing launches over in GROUPS of 3 ... 24 (one event per group) was measured: +-0 on the
 # step and on the helper thread's CPU — the dependencies themselves are not what costs.
-_SIDE_GROUP = int(os.environ.get("CDAE_WGRAD_GROUP", "1"))
+_SIDE_GROUP = 1
 _SIDE = {}
 
 
@@ -285,7 +285,7 @@ class _Conv3x3(Function):
 
 
 _S2DGRAD = {}
-_S2DGRAD_ON = os.environ.get("CDAE_S2_DGRAD_PS", "1") != "0"      # dev switch: 0 = the stride-2 dgrad through the fp32-operand gather kernel
+_S2DGRAD_ON = True      # path toggle (tests only, see PATH TOGGLES below): False = the stride-2 dgrad through the fp32-operand gather kernel
 
 
 def _s2_dgrad_ps(dy, w, dx, N, H, W, Cin, Cout, ws, wsb):
@@ -337,8 +337,8 @@ def stem_conv_gn(x, w, b=None):
 
 
 # ----------------------------------------------------------------------------- linear / conv1x1 on rows
-_STREAM_GEMM = os.environ.get("CDAE_STREAM_GEMM", "1") != "0"      # dev switch: 0 = every linear / 1x1 conv through the igemm loader
-_STREAM_GEMM_MIN_ROWS = int(os.environ.get("CDAE_STREAM_GEMM_MIN_ROWS", "4096"))
+_STREAM_GEMM = True      # path toggle (tests only, see PATH TOGGLES below): False = every linear / 1x1 conv through the igemm loader
+_STREAM_GEMM_MIN_ROWS = 4096
 
 
 def _stream_gemm_ok(x, M, Nf, K, act, alpha, res):
@@ -348,7 +348,7 @@ def _stream_gemm_ok(x, M, Nf, K, act, alpha, res):
 
 
 _WT_PLANES = {}
-_DGRAD_STREAM_ON = os.environ.get("CDAE_DGRAD_STREAM", "1") != "0"      # dev switch: 0 = every linear dgrad through the tiled fp32-operand kernel
+_DGRAD_STREAM_ON = True      # path toggle (tests only, see PATH TOGGLES below): False = every linear dgrad through the tiled fp32-operand kernel
 
 
 def wt_planes(w):
@@ -573,8 +573,8 @@ class _Attention(Function):
         return dqkv, None
 
 
-_FUSED_ATTN_ON = os.environ.get("CDAE_FUSED_ATTN", "1") != "0"
-_FUSED_ATTN_TRAIN = os.environ.get("CDAE_FUSED_ATTN_TRAIN", "1") != "0"
+_FUSED_ATTN_ON = True
+_FUSED_ATTN_TRAIN = True
 
 
 def qkv_attention(qkv_rows, heads):
@@ -654,7 +654,7 @@ class CatAct:
         self.shape = (a.shape[0], a.shape[1] + b.shape[1], a.shape[2], a.shape[3])
 
 
-_TRAIN_CAT_ON = os.environ.get("CDAE_TRAIN_CAT", "1") != "0"      # dev switch: 0 = materialise the skip concatenation in training
+_TRAIN_CAT_ON = True      # path toggle (tests only, see PATH TOGGLES below): False = materialise the skip concatenation in training
 
 
 def cat_channels(a, b):
@@ -951,7 +951,7 @@ class SplitAct:
         return SplitAct(out[0], out[1], self.shape)
 
 
-_PLANES_GM = os.environ.get("CDAE_PLANES_GM", "1") != "0"      # dev switch: 0 = pixel-major activation planes everywhere
+_PLANES_GM = True      # path toggle (tests only, see PATH TOGGLES below): False = pixel-major activation planes everywhere
 
 
 def planes_gm_ok(C):
@@ -975,7 +975,7 @@ def gm_wanted(N, H, W, Cin, Cout):
 
 
 _WSPLIT = {}
-_PRESPLIT_ON = os.environ.get("CDAE_PRESPLIT", "1") != "0"      # dev switch: 0 = in-kernel split everywhere
+_PRESPLIT_ON = True      # path toggle (tests only, see PATH TOGGLES below): False = in-kernel split everywhere
 _WEIGHT_EPOCH = [0]
 
 
@@ -1035,7 +1035,7 @@ class ScaleTable:
 
 _SCALE_OF = {}
 _WSCALE = {}
-_WSCALE_ON = os.environ.get("CDAE_WSCALE", "1") != "0"      # dev switch: 0 = unscaled weight planes (the round-1..3 arithmetic)
+_WSCALE_ON = True      # path toggle (tests only, see PATH TOGGLES below): False = unscaled weight planes (the round-1..3 arithmetic)
 
 
 def register_scale_table(flat, tensors):
@@ -1175,6 +1175,7 @@ class ConvWeightBank:
 
 
 _BANK_OF = {}
+_WEIGHT_BANK_ON = True
 
 
 def register_conv_bank(flat, params):
@@ -1183,7 +1184,7 @@ def register_conv_bank(flat, params):
         del _BANK_OF[k]
     ws = [p for p in params if p.dim() == 4 and tuple(p.shape[2:]) == (3, 3) and p.permute(0, 2, 3, 1).is_contiguous() and p.numel() % 8 == 0
           and ((p.data_ptr() - flat.data_ptr()) // 4) % 8 == 0]
-    return ConvWeightBank(flat, ws) if ws and os.environ.get("CDAE_WEIGHT_BANK", "1") != "0" else None
+    return ConvWeightBank(flat, ws) if ws and _WEIGHT_BANK_ON else None
 
 
 def _bank(w):
@@ -1215,7 +1216,7 @@ def split_weight(w):
     return planes[0], planes[1], sc
 
 
-_KPACK_ON = os.environ.get("CDAE_KPACK", "1") != "0"       # dev switch: 0 = OHWI weight planes only (first-generation window kernel)
+_KPACK_ON = True       # path toggle (tests only, see PATH TOGGLES below): False = OHWI weight planes only (first-generation window kernel)
 _WPACK = {}
 
 
@@ -1304,7 +1305,7 @@ class LazyGN:
         return SplitAct(planes[0], planes[1], self.shape)
 
 
-_HEAD_ON = os.environ.get("CDAE_HEAD_CONV", "1") != "0"      # dev switch: 0 = the output head through GroupNorm planes + the plane GEMM
+_HEAD_ON = True      # path toggle (tests only, see PATH TOGGLES below): False = the output head through GroupNorm planes + the plane GEMM
 
 
 def head_conv_ok(lz, w):
@@ -1326,10 +1327,10 @@ def head_conv(lz, w, b=None):
     return y
 
 
-_SKIPGN_ON = os.environ.get("CDAE_SKIP_GN", "1") != "0"      # dev switch: 0 = separate GroupNorm apply pass and 1x1 skip GEMM
+_SKIPGN_ON = True      # path toggle (tests only, see PATH TOGGLES below): False = separate GroupNorm apply pass and 1x1 skip GEMM
 
 
-_SKIPGN_V2 = os.environ.get("CDAE_SKIPGN_V2", "1") != "0"        # dev switch: 0 = the igemm-loader version of the sweep
+_SKIPGN_V2 = True        # path toggle (tests only, see PATH TOGGLES below): False = the igemm-loader version of the sweep
 
 
 def skip_gn_ok(lz, w):
@@ -1452,7 +1453,7 @@ def upconv3x3_ps(xs, w, b=None, gn_stats=False):
     return out
 
 
-_PS_PARTS_MIN_TILES = int(os.environ.get("CDAE_PS_GNPARTS_MIN_TILES", "256"))      # 128 x 128 tiles from which a conv's epilogue / split-K finish leaves GroupNorm sums
+_PS_PARTS_MIN_TILES = 256      # 128 x 128 tiles from which a conv's epilogue / split-K finish leaves GroupNorm sums
 
 
 def conv3x3_ps(xs, w, b=None, res=None, stride=1, up=False, out_nchw=False, emit_split=False, gn_stats=False):
@@ -1497,7 +1498,7 @@ def conv3x3_ps(xs, w, b=None, res=None, stride=1, up=False, out_nchw=False, emit
 
 
 # ----------------------------------------------------------------------------- training on the pre-split kernels
-_TRAIN_PS_ON = os.environ.get("CDAE_TRAIN_PRESPLIT", "1") != "0"      # dev switch: 0 = separate GroupNorm / conv3x3 Functions (in-kernel split)
+_TRAIN_PS_ON = True      # path toggle (tests only, see PATH TOGGLES below): False = separate GroupNorm / conv3x3 Functions (in-kernel split)
 _WDGRAD = {}
 
 
@@ -1741,8 +1742,8 @@ def _rb_gn_planes(x, gamma, beta, ss, silu, groups, eps, st, x2=None):
     return stats, planes, bplanes
 
 
-_RB_PARTS_ON = os.environ.get("CDAE_TRAIN_GNPARTS", "1") != "0"     # dev switch: 0 = every GroupNorm runs its own statistics pass
-_RB_PARTS_MIN_TILES = int(os.environ.get("CDAE_TRAIN_GNPARTS_MIN_TILES", "64"))      # (below: the statistics pass over a small tensor is cheaper than the sums' own traffic)
+_RB_PARTS_ON = True     # path toggle (tests only, see PATH TOGGLES below): False = every GroupNorm runs its own statistics pass
+_RB_PARTS_MIN_TILES = 64      # (below: the statistics pass over a small tensor is cheaper than the sums' own traffic)
 
 
 def _rb_conv(planes, w, b, res, shape, Cout, st):
@@ -1926,7 +1927,7 @@ class _ResBlockPS(Function):
         return dx, dss, None, dg1, db1, dw1, dc1b, dg2, db2, dw2, dc2b, dsw, dsb, None, None, dx2
 
 
-_RBNODE_ON = os.environ.get("CDAE_TRAIN_RBNODE", "1") != "0"      # dev switch: 0 = two fused GN-conv nodes per ResBlock
+_RBNODE_ON = True      # path toggle (tests only, see PATH TOGGLES below): False = two fused GN-conv nodes per ResBlock
 
 
 def resblock_node_ok():
@@ -2003,7 +2004,7 @@ class _EmbAllTrain(Function):
         return demb, None
 
 
-_EMBALL_ON = os.environ.get("CDAE_TRAIN_EMBALL", "1") != "0"      # dev switch: 0 = one Linear per ResBlock
+_EMBALL_ON = True      # path toggle (tests only, see PATH TOGGLES below): False = one Linear per ResBlock
 
 
 def emb_all_train_ok(model):
@@ -2058,7 +2059,7 @@ def linear_emit(rows, w, b, res, shape):
     return y, SplitAct(planes[0], planes[1], shape)
 
 
-_LINEAR_GN = os.environ.get("CDAE_LINEAR_GN", "1") != "0"      # dev switch: 0 = GroupNorm planes first, then the plane GEMM
+_LINEAR_GN = True      # path toggle (tests only, see PATH TOGGLES below): False = GroupNorm planes first, then the plane GEMM
 
 
 def linear_gn_ok(lz, w):
@@ -2096,3 +2097,35 @@ def linear_ps(xs, w, b=None, res=None, act=ACT_NONE):
     check(lib.cdae_linear_fwd_ps(ptr(xs.hi), ptr(xs.lo), C, ptr(w_hi), ptr(w_lo), C, ptr(w_sc), ptr(b), ptr(res), ptr(y), Nf, M, Nf, C, 1.0, act,
                                  ws, wsb, stream()))
     return y
+
+
+# ----------------------------------------------------------------------------- PATH TOGGLES
+# The module-level `_X = True` flags above each guard one fused path whose unfused predecessor is still what small / odd shapes run.
+# They are CONSTANTS of the product: nothing here reads the environment (the two deployment knobs that do — CDAE_WGRAD_STREAM and
+# CDAE_HOST_CORES, the side-stream policy of a rank — are documented in DESIGN.md §7).  The test suite flips one at a time to keep the
+# predecessor paths green (`tests/conftest.py --paths-off`, `path_scope`), a dev tool can do the same.
+PATH_TOGGLES = {"skipgn_v2": "_SKIPGN_V2", "skip_gn": "_SKIPGN_ON", "stream_gemm": "_STREAM_GEMM", "head_conv": "_HEAD_ON", "planes_gm": "_PLANES_GM",
+                "linear_gn": "_LINEAR_GN", "fused_attn": "_FUSED_ATTN_ON", "fused_attn_train": "_FUSED_ATTN_TRAIN", "kpack": "_KPACK_ON",
+                "presplit": "_PRESPLIT_ON", "train_presplit": "_TRAIN_PS_ON", "train_rbnode": "_RBNODE_ON", "train_gnparts": "_RB_PARTS_ON",
+                "train_emball": "_EMBALL_ON", "train_cat": "_TRAIN_CAT_ON", "weight_bank": "_WEIGHT_BANK_ON", "wscale": "_WSCALE_ON",
+                "s2_dgrad_ps": "_S2DGRAD_ON", "dgrad_stream": "_DGRAD_STREAM_ON", "wgrad_stream": "_WGRAD_SIDE_ON"}
+
+
+class path_scope:
+    """with ops.path_scope(stream_gemm=False): ... — one or more fused paths off (or on) for the duration of a block"""
+
+    def __init__(self, **kv):
+        self.kv, self.prev = kv, {}
+
+    def __enter__(self):
+        g = globals()
+        for k, v in self.kv.items():
+            self.prev[k] = g[PATH_TOGGLES[k]]
+            g[PATH_TOGGLES[k]] = bool(v)
+        return self
+
+    def __exit__(self, *exc):
+        g = globals()
+        for k, v in self.prev.items():
+            g[PATH_TOGGLES[k]] = v
+        return False

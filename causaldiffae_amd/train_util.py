@@ -176,14 +176,6 @@ class GradBuckets:
         for b in self.buckets:             # in index order, like the hooks
             if b["work"] is None:
                 b["work"] = self._all_reduce(b)
-        if os.environ.get("CDAE_DEBUG_DIST"):          # dev: does the launch stream drain while the collectives are outstanding?
-            import sys, time as _t
-            ev = th.cuda.Event(); ev.record()
-            t0 = _t.time()
-            while not ev.query() and _t.time() - t0 < 20:
-                _t.sleep(0.05)
-            print(f"[rank {dist.get_rank()}] launch stream drained: {ev.query()} after {_t.time() - t0:.2f} s; works completed: "
-                  f"{[bb['work'].is_completed() for bb in self.buckets]}", file=sys.stderr, flush=True)
         for i, b in enumerate(self.buckets):
             try:
                 b["work"].wait()
@@ -285,7 +277,7 @@ class TrainLoop:
     def __init__(self, *, model, diffusion, data, batch_size, microbatch, lr, ema_rate, log_interval, save_interval,
                  resume_checkpoint, use_fp16=False, fp16_scale_growth=1e-3, schedule_sampler=None, weight_decay=0.0,
                  lr_anneal_steps=0, rep_cond=False, n_vars=None, causal_modeling=False, flow_based=False, in_channels=3,
-                 masking=False, bucket_mb=64, use_graph=None):
+                 masking=False, bucket_mb=64, use_graph=False, run_ahead=1, throttle_poll_s=0.0005):
         if use_fp16:       # reduced-precision torso; fp32 master weights are the only weights, bf16 gradients need no loss scaling
             model.convert_to_fp16()        # marks THIS model (the mode is scoped to its forward / backward, not process-wide)
         self.model, self.diffusion, self.data = model, diffusion, data
@@ -316,11 +308,11 @@ class TrainLoop:
         self.use_ddp = self.world > 1
         self.ddp_model = self.model
         self.last_losses = None
-        self.use_graph = os.environ.get("CDAE_TRAIN_GRAPH", "0") == "1" if use_graph is None else bool(use_graph)
+        self.use_graph = bool(use_graph)
         self._graphs, self._graph_failed, self._eager_steps = {}, False, 0
-        ra = os.environ.get("CDAE_TRAIN_RUNAHEAD", "1")
-        self.run_ahead, self._step_events = (None if ra in ("", "none") else max(1, int(ra))), []
-        self.throttle_poll_s = float(os.environ.get("CDAE_TRAIN_THROTTLE_POLL", "0.0005"))
+        # run_ahead: optimizer steps the host may enqueue beyond the one the GPU executes (None: unbounded); see _throttle
+        self.run_ahead, self._step_events = (None if run_ahead is None else max(1, int(run_ahead))), []
+        self.throttle_poll_s = float(throttle_poll_s)
 
     # ------------------------------------------------------------------ loop
     def run_loop(self):
@@ -349,7 +341,7 @@ class TrainLoop:
         GPU, sets the step time.  With static shapes (one microbatch, uniform timestep sampling) the whole forward + backward is
         captured once into a hipGraph and replayed; inputs, timesteps, loss weights and the KL weight live in static buffers.
         The gradient all-reduce (world > 1) and the optimizer kernel stay outside the graph.
-        OPT-IN (use_graph=True / CDAE_TRAIN_GRAPH=1): gradients match the eager step to its own run-to-run noise (6e-6), but on
+        OPT-IN (use_graph=True): gradients match the eager step to its own run-to-run noise (6e-6), but on
         ROCm 7.2 replaying the 1600-node graph measured 48.9 ms against 42.0 ms for eager launches on the same MI355X box — the
         eager launch queue already overlaps with execution, graph nodes do not."""
         return (self.use_graph and not self._graph_failed and th.cuda.is_available() and isinstance(self.schedule_sampler, UniformSampler)

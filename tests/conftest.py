@@ -10,8 +10,19 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def pytest_addoption(parser):
+    parser.addoption("--paths-off", default="", help="comma-separated names of causaldiffae_amd.ops.PATH_TOGGLES to switch off for the whole session "
+                                                     "(tools/switch_matrix.sh: the predecessor of each fused path must stay green)")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    off = [n for n in config.getoption("--paths-off").split(",") if n]
+    if off:
+        from causaldiffae_amd import ops
+        g = vars(ops)
+        for n in off:
+            g[ops.PATH_TOGGLES[n]] = False
 
 
 @pytest.fixture(scope="session")

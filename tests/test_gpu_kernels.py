@@ -1963,3 +1963,98 @@ def test_sumpool2_matches_avg_pool(N, H, W, C):
     assert torch.equal(dst, want)
     ref = 4 * F.avg_pool2d(src.permute(0, 3, 1, 2).double(), 2).permute(0, 2, 3, 1)
     assert (dst.double() - ref).abs().max().item() < 1e-5
+
+
+@pytest.mark.gpu
+def test_conv_bank_follows_in_place_weight_change():
+    """A banked conv3x3 weight changed IN PLACE by a torch op (autograd version moves, the weight epoch does not): the bank must refresh
+    the weight's scale record BEFORE it rebuilds the planes.  Before round 5 `ConvWeightBank._refresh` asked the table for a refresh
+    without naming the tensor, got none, built planes of w_new * 2^k_old and the kernel unscaled them with 2^-k_new: a silent factor
+    2^(k_old - k_new) on the output (and f16 overflow one bit later).  Also: records rewritten on behalf of ANOTHER tensor make the
+    bank rebuild (generation counter)."""
+    import torch.nn.functional as F
+    from causaldiffae_amd import ops
+    from causaldiffae_amd.train_util import FlatParams
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(11)
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Conv2d(32, 64, 3, padding=1).to(memory_format=torch.channels_last)
+            self.b = torch.nn.Conv2d(64, 32, 3, padding=1).to(memory_format=torch.channels_last)
+
+    m = M()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+    m.to(dev)
+    flat = FlatParams(m)
+    assert flat.conv_bank is not None and flat.scale_table is not None
+    x = torch.randn(2, 32, 16, 16, generator=g).to(dev)
+
+    def run(conv, xin):
+        with torch.no_grad():
+            xs = ops.to_nhwc(xin)
+            planes = torch.empty((2,) + tuple(xs.permute(0, 2, 3, 1).shape), dtype=torch.float16, device=dev)
+            from causaldiffae_amd._lib import check, lib, ptr, ptr2, stream
+            check(lib.cdae_split_f16(ptr(xs), *ptr2(planes), xs.numel(), stream()))
+            out = ops.conv3x3_ps(ops.SplitAct(planes[0], planes[1], xs.shape), conv.weight, conv.bias)
+        want = F.conv2d(xin.double().cpu(), conv.weight.detach().double().cpu(), conv.bias.detach().double().cpu(), padding=1)
+        return (out.cpu().double() - want).abs().max().item() / want.abs().max().item()
+
+    assert run(m.a, x) < 1e-5
+    with torch.no_grad():
+        m.a.weight.mul_(16.0)                       # version-only change: k moves by 4
+    assert run(m.a, x) < 1e-5
+    with torch.no_grad():
+        m.a.weight.mul_(1.0 / 1024.0)
+    assert run(m.a, x) < 1e-5
+    # another tensor's refresh rewrites the shared records; the bank's planes of `a` must stay consistent with them
+    y = torch.randn(2, 64, 16, 16, generator=g).to(dev)
+    with torch.no_grad():
+        m.b.weight.mul_(64.0)
+    ops.weight_scale(m.b.weight)                    # refreshes the table on behalf of b (bank not involved)
+    assert run(m.a, x) < 1e-5 and run(m.b, y) < 1e-5
+
+
+@pytest.mark.gpu
+def test_adamw_multi_ema_and_grad_scale():
+    """cdae_adamw_ema_multi: AdamW on grad_scale * g + up to four EMA buffers in one pass == torch.optim.AdamW on the scaled gradient
+    followed by the reference's update_ema per rate (train_util.py:292-297, nn.py:503-513)."""
+    import ctypes
+    from causaldiffae_amd._lib import check, lib, ptr, stream
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(3)
+    n = 100003
+    p0, gr = torch.randn(n, generator=g), torch.randn(n, generator=g) * 3.0
+    rates = [0.999, 0.9999, 0.5]
+    ref = torch.nn.Parameter(p0.double().clone())
+    opt = torch.optim.AdamW([ref], lr=1e-3, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8)
+    emas_ref = [p0.double().clone() for _ in rates]
+    p, m, v = p0.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    emas = [p0.to(dev).clone() for _ in rates]
+    grad = gr.to(dev)
+    ptrs = (ctypes.c_void_p * 3)(*[e.data_ptr() for e in emas])
+    rs = (ctypes.c_double * 3)(*rates)
+    for step in range(1, 4):
+        ref.grad = gr.double() * 0.125
+        opt.step()
+        for e, r in zip(emas_ref, rates):
+            e.mul_(r).add_(ref.detach(), alpha=1 - r)
+        check(lib.cdae_adamw_ema_multi(ptr(p), ptr(grad), ptr(m), ptr(v), ptrs, rs, 3, n, 1e-3, 0.9, 0.999, 1e-8, 0.01, step, 0.125, stream()))
+    assert (p.cpu().double() - ref.detach()).abs().max().item() < 2e-6
+    for e, er in zip(emas, emas_ref):
+        assert (e.cpu().double() - er).abs().max().item() < 2e-6
+    assert lib.cdae_adamw_ema_multi(ptr(p), ptr(grad), ptr(m), ptr(v), ptrs, rs, 5, n, 1e-3, 0.9, 0.999, 1e-8, 0.01, 1, 1.0, stream()) != 0
+
+
+@pytest.mark.gpu
+def test_box_calibration_is_plausible():
+    """cdae_calib_mfma / cdae_calib_copy (bench.py's `box` record): a sustained f16 MFMA rate between half and all of the 2.5 PFLOP/s dense
+    peak at a shader clock between 1 and 2.6 GHz, and an HBM copy rate between 2 and 8 TB/s."""
+    from causaldiffae_amd import _lib
+    box = _lib.calibrate(torch.device("cuda:0"), copy_bytes=1 << 29)
+    assert 1200.0 < box["mfma_sustained_tflops"] < 2600.0, box
+    assert 1.0 < box["sclk_under_load_ghz"] < 2.6, box
+    assert 2.0 < box["hbm_copy_tbps"] < 8.5, box

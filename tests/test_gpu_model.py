@@ -1499,6 +1499,31 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+def test_bench_gpus_flag_launches_its_own_ranks():
+    """`python bench.py --gpus 2` started BARE (no launcher, WORLD_SIZE unset — the way the driver starts `--gpus 1`): the script starts
+    two fresh rank processes itself before touching the GPU and relays rank 0's single line (n_gpus == ranks_in_group == 2).  On a
+    one-GPU box the ranks share the device and gloo stands in for RCCL."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "CDAE_DIST_BACKEND")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--regions", "1", "--batch", "8",
+                        "--train-batch", "4", "--train-steps", "2", "--no-cpu-baseline", "--no-fp32", "--no-extra"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_in_group"] == 2 and d["config"]["global_batch"] == 16 and d["value"] > 0
+    assert d["dist_backend"] == ("gloo" if torch.cuda.device_count() < 2 else "nccl")
+    assert d["train"]["global_batch"] == 8 and "error" not in d["train"]
+    # a failing rank ends the whole launch with a non-zero code instead of leaving its peers in a collective
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--batch", "8"],
+                       env={**env, "CDAE_DIST_BACKEND": "no_such_backend"}, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.gpu
 def test_bench_four_ranks_world8_policy_on_one_gpu():
     """Four ranks (gloo, all on cuda:0) under the driver's launch line, with the host-core budget an EIGHT-rank node gives each rank
     (CDAE_HOST_CORES=8 over four ranks = 2 cores per rank, like a 16-core quota over eight): `ops.wgrad_side_stream_on()` must answer
