@@ -130,6 +130,21 @@ SIGNATURES = {
     "cdae_mse_rows_bwd": [P, P, P, P, I, L, P],
     "cdae_rep_loss": [P, P, P, P, P, I, I, I, P],
     "cdae_rep_loss_bwd": [P, P, P, P, P, P, P, P, I, I, I, P],
+    "cdae_conv3x3_fwd16": [P, L, L, L, P, P, P, P, P, L, P, I, I, I, I, I, P, SZ, P],
+    "cdae_conv3x3_dgrad16": [P, P, P, P, L, I, I, I, I, I, P, SZ, P],
+    "cdae_gemm16_ps": [P, L, P, L, P, P, P, L, P, I, I, I, I, I, P, SZ, P],
+    "cdae_linear_fwd_io": [P, L, P, L, P, P, P, P, L, I, I, I, I, P, SZ, P],
+    "cdae_linear_dgrad_io": [P, L, P, L, P, L, I, I, I, I, P, SZ, P],
+    "cdae_linear_wgrad_io": [P, L, P, L, P, L, P, I, I, I, I, I, P, SZ, P],
+    "cdae_gn_stats16": [P, I, P, I, I, I, I, I, I, F, P, P, P, P, P, I, P, P, P],
+    "cdae_gn_apply16": [P, I, P, I, I, P, I, I, I, I, I, P, P, P, P, P, I, I, P],
+    "cdae_gn_bwd16": [P, I, P, I, I, P, I, P, I, P, I, I, I, I, I, P, P, P, P, P, I, I, P, P, I, P, I, I, P, I, P, P],
+    "cdae_gn_parts16": [P, L, P, L, I, P],
+    "cdae_cast_f32_bf16": [P, P, L, P],
+    "cdae_cast_bf16_f32": [P, P, L, P],
+    "cdae_upsample2_16": [P, P, I, I, I, I, P],
+    "cdae_sumpool2_16": [P, P, I, I, I, I, P],
+    "cdae_wprep_all_m16": [P, P, I, I, L, P, P, P, P, P, P, P, P, P, P],
     "cdae_tune_set": [I, I],
     "cdae_tune_get": [I],
     "cdae_prof_enable": [I],

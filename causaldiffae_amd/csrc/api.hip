@@ -398,6 +398,107 @@ int cdae_linear_wgrad(const float* x, long ldx, const float* dy, long lddy, floa
     return cdae_gemm_dispatch(p, stream);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The 16-bit torso (reference unet.py:501-507 convert_to_fp16 + fp16_util.py:9-15: half activations between the layers; here bf16, the
+// dtype BASELINE config [1] names): activations and gradients are bf16 NHWC rows, which ARE the one-plane operands of the matrix-core
+// kernels; accumulation fp32; results rounded to bf16 once, in the epilogue.  `io` bits: 1 = the result (and an accumulate read) is bf16,
+// 2 = the residual is bf16, 4 / 8 = the A / B operand of an fp32-operand kernel is a bf16 tensor.
+static int conv16_params(GemmParams& p, const void* a16, long sn, long sy, long sx, const void* w16, const void* wk16, int ldb, const float* bias,
+                         const void* res, void* out, long ldo, float* gn_part, int N, int H, int W, int Cin, int Cout, int io) {
+    if ((long)N * H * W * sx >= (1L << 31)) return cdae_fail("conv3x3 (16-bit): activation larger than 2^31 elements");
+    if (sx % 8 || sy % 8 || sn % 8 || !aligned16(a16) || !aligned16(w16) || !aligned16(wk16) || Cin % 32) return cdae_fail("conv3x3 (16-bit): Cin % 32 == 0, 16-byte aligned rows required");
+    p = base_params();
+    p.presplit = 1; p.prec = 4; p.io16 = io;
+    p.A = reinterpret_cast<const float*>(a16); p.A_lo = reinterpret_cast<const unsigned short*>(a16);
+    p.B = reinterpret_cast<const float*>(w16); p.B_lo = reinterpret_cast<const unsigned short*>(w16);
+    p.Bk_hi = p.Bk_lo = reinterpret_cast<const unsigned short*>(wk16);
+    p.C = reinterpret_cast<float*>(out); p.bias = bias; p.res = reinterpret_cast<const float*>(res); p.gn_part = gn_part;
+    p.M = N * H * W; p.N = Cout; p.K = 9 * Cin; p.ldb = ldb; p.ldc = ldo;
+    p.out_mode = OUT_ROWMAJOR; p.out_hw = H * W;
+    p.amode = A_CONV_VEC; p.bmode = B_PLAIN_KC;
+    p.conv_M = p.M; p.H = H; p.W = W; p.Cin = Cin; p.Ho = H; p.Wo = W; p.stride = 1; p.up = 0;
+    p.sn = sn; p.sy = sy; p.sx = sx; p.sc = 1;
+    return 0;
+}
+
+// out16 = conv3x3(x16, w) + bias (+ res16), stride 1: x16 bf16 [N, H, W, Cin] rows of pitch sx, w16 the bf16 OHWI weights, wk16 the same
+// K-group-major (or NULL), out16 / res16 bf16 rows of pitch ldo; gn_part as in cdae_conv3x3_fwd_ps (sums of the ROUNDED values)
+int cdae_conv3x3_fwd16(const void* x16, long sn, long sy, long sx, const void* w16, const void* wk16, const float* bias, const void* res16, void* out16,
+                       long ldo, float* gn_part, int N, int H, int W, int Cin, int Cout, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    GemmParams p;
+    if (conv16_params(p, x16, sn, sy, sx, w16, wk16, 9 * Cin, bias, res16, out16, ldo, gn_part, N, H, W, Cin, Cout, 1 | (res16 ? 2 : 0))) return -1;
+    set_splitk(p, splitk_ws, splitk_ws_bytes);
+    return cdae_gemm_dispatch(p, stream);
+}
+
+// dx16 = conv3x3(dy16, wt): dy16 bf16 [N, H, W, Cout] dense, wt16 / wtk16 the bf16 dgrad weights ([Cin][9][Cout] flipped; K-group-major)
+int cdae_conv3x3_dgrad16(const void* dy16, const void* wt16, const void* wtk16, void* dx16, long lddx, int N, int H, int W, int Cin, int Cout,
+                         float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    GemmParams p;
+    if (conv16_params(p, dy16, (long)H * W * Cout, (long)W * Cout, Cout, wt16, wtk16, 9 * Cout, nullptr, nullptr, dx16, lddx, nullptr, N, H, W, Cout, Cin, 1)) return -1;
+    p.grad_operand = 1;
+    set_splitk(p, splitk_ws, splitk_ws_bytes);
+    return cdae_gemm_dispatch(p, stream);
+}
+
+// c[M][N] (+)= a16[M][K] . b16[N][K]^T + bias (+ res) on the plane GEMM: both operands bf16 rows, K contiguous (a 1x1 conv / linear
+// forward with b16 = the bf16 weight, its data gradient with b16 = the bf16 W^T); c / res fp32 or bf16 by `io`
+int cdae_gemm16_ps(const void* a16, long lda, const void* b16, long ldb, const float* bias, const void* res, void* c, long ldc, float* gn_part, int M, int N,
+                   int K, int io, int accumulate, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    if ((long)M * lda >= (1L << 31)) return cdae_fail("gemm16_ps: operand larger than 2^31 elements");
+    if (!aligned16(a16) || !aligned16(b16) || K % 32 || lda % 8 || ldb % 8) return cdae_fail("gemm16_ps: K % 32 == 0 and 16-byte aligned rows required");
+    GemmParams p = base_params();
+    p.presplit = 1; p.prec = 4; p.io16 = io & 3;
+    p.A = reinterpret_cast<const float*>(a16); p.A_lo = reinterpret_cast<const unsigned short*>(a16);
+    p.B = reinterpret_cast<const float*>(b16); p.B_lo = reinterpret_cast<const unsigned short*>(b16);
+    p.C = reinterpret_cast<float*>(c); p.bias = bias; p.res = reinterpret_cast<const float*>(res); p.gn_part = gn_part; p.accumulate = accumulate;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.amode = A_PLAIN_KC; p.bmode = B_PLAIN_KC;
+    set_splitk(p, (accumulate || gn_part) ? nullptr : splitk_ws, splitk_ws_bytes);
+    return cdae_gemm_dispatch(p, stream);
+}
+
+// the fp32-operand linear entry points with 16-bit tensors on some sides (io bits above; single-plane bf16 products)
+int cdae_linear_fwd_io(const float* x, long ldx, const float* w, long ldw, const float* w_scale, const float* bias, const void* res, void* y, long ldy,
+                       int M, int N, int K, int io, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    GemmParams p = base_params();
+    p.A = x; p.B = w; p.w_scale = w_scale; p.C = reinterpret_cast<float*>(y); p.bias = bias; p.res = reinterpret_cast<const float*>(res);
+    p.M = M; p.N = N; p.K = K; p.lda = ldx; p.ldb = ldw; p.ldc = ldy; p.io16 = io & 3;
+    p.amode = A_PLAIN_KC; p.bmode = B_PLAIN_KC;
+    if (!(K % 4 == 0 && ldx % 4 == 0 && aligned16(x) && ldw % 4 == 0 && aligned16(w))) return cdae_fail("linear_fwd_io: 16-byte aligned fp32 rows required");
+    p.prec = 3;
+    set_splitk(p, splitk_ws, splitk_ws_bytes);
+    return cdae_gemm_dispatch(p, stream);
+}
+int cdae_linear_dgrad_io(const float* dy, long lddy, const float* w, long ldw, void* dx, long lddx, int M, int N, int K, int io,
+                         float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    GemmParams p = base_params();
+    p.A = dy; p.B = w; p.C = reinterpret_cast<float*>(dx);
+    p.M = M; p.N = K; p.K = N; p.lda = lddy; p.ldb = ldw; p.ldc = lddx; p.grad_operand = 1; p.io16 = io & 1; p.prec = 4;
+    p.amode = A_PLAIN_KC; p.bmode = B_PLAIN_MC;
+    if (!(N % 4 == 0 && lddy % 4 == 0 && aligned16(dy) && ldw % 4 == 0 && aligned16(w) && K % 4 == 0)) return cdae_fail("linear_dgrad_io: 16-byte aligned fp32 rows required");
+    set_splitk(p, splitk_ws, splitk_ws_bytes);
+    return cdae_gemm_dispatch(p, stream);
+}
+// dw[N][K] (+)= dy^T . x over M rows, dbias (+)= column sums of dy; dy / x fp32 or bf16 rows by io bits 4 / 8
+int cdae_linear_wgrad_io(const void* x, long ldx, const void* dy, long lddy, float* dw, long lddw, float* dbias, int M, int N, int K, int io,
+                         int accumulate, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    GemmParams p = base_params();
+    p.A = reinterpret_cast<const float*>(dy); p.B = reinterpret_cast<const float*>(x); p.C = dw;
+    p.M = N; p.N = K; p.K = M; p.lda = lddy; p.ldb = ldx; p.ldc = lddw; p.accumulate = accumulate; p.grad_operand = 1; p.prec = 4;
+    p.io16 = io & 12;
+    p.amode = A_PLAIN_MC; p.bmode = B_PLAIN_MC;
+    if (!(lddy % 4 == 0 && ldx % 4 == 0 && N % 4 == 0 && K % 4 == 0 && ((size_t)dy & 7) == 0 && ((size_t)x & 7) == 0 &&
+          ((io & 4) || aligned16(dy)) && ((io & 8) || aligned16(x))))
+        return cdae_fail("linear_wgrad_io: 4-element aligned rows required");
+    set_splitk(p, splitk_ws, splitk_ws_bytes);
+    if (dbias) {
+        if (!accumulate && hipMemsetAsync(dbias, 0, sizeof(float) * N, (hipStream_t)stream) != hipSuccess) return cdae_fail("dbias memset failed");
+        p.colsum_out = dbias;
+    }
+    return cdae_gemm_dispatch(p, stream);
+}
+
 int cdae_qkv_attention_fwd(const float* qkv, float* out, float* probs, int B, int T, int heads, int ch, void* stream) {
     const long C = (long)heads * ch, C3 = 3 * C;
     if (ch % 4) return cdae_fail("attention: head dim must be a multiple of 4");

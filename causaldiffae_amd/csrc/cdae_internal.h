@@ -80,6 +80,10 @@ struct GemmParams {
     // convwin_kernel: 16-column MFMA tiles per wave (n-tile = 32 cw_nj columns): 4 (256 x 128 tiles), or 3 / 2 where the narrower tile
     // fills the 512 block slots clearly better (planes.hip decides, before it sizes a K split)
     int cw_nj;
+    // 16-bit torso (the single-plane modes only, prec 3 / 4): bit 0 — C (and the accumulate read) is a bf16 tensor, bit 1 — res is; bit 2 — the
+    // A operand of an fp32-operand kernel is a bf16 tensor, bit 3 — the B operand is (igemm.hip k-major loaders).  Values are rounded to
+    // bf16 BEFORE they enter GroupNorm partial sums, so the statistics describe the tensor that was stored.
+    int io16;
 };
 
 int cdae_gemm_dispatch(GemmParams p, void* stream);
@@ -145,6 +149,18 @@ __device__ __forceinline__ float cdae_silu(float x) {
     float y = x * cdae_sigmoid(x);
     asm("" : "+v"(y));              // the rounded product, never contracted into a following add (bit-identical across translation units)
     return y;
+}
+
+// result / residual element access of the epilogues that serve the 16-bit torso (GemmParams::io16)
+__device__ __forceinline__ float cdae_round_c(const GemmParams& p, float v) { return (p.io16 & 1) ? (float)(__bf16)v : v; }
+__device__ __forceinline__ void cdae_store_c(const GemmParams& p, float* C, long addr, float v) {
+    if (p.io16 & 1) reinterpret_cast<__bf16*>(C)[addr] = (__bf16)v; else C[addr] = v;
+}
+__device__ __forceinline__ float cdae_load_c(const GemmParams& p, const float* C, long addr) {
+    return (p.io16 & 1) ? (float)reinterpret_cast<const __bf16*>(C)[addr] : C[addr];
+}
+__device__ __forceinline__ float cdae_load_res(const GemmParams& p, const float* R, long addr) {
+    return (p.io16 & 2) ? (float)reinterpret_cast<const __bf16*>(R)[addr] : R[addr];
 }
 
 __device__ __forceinline__ void cdae_lds_dma16(const void* src, unsigned lds_dst) {

@@ -80,7 +80,8 @@ __device__ __forceinline__ void cw_dma(const void* sbase, int soff, unsigned vof
 // Cout = 384 at the 16 x 16 level of a batch-128 step, where 128 m-tiles x 3 n-tiles of 128 are 384 blocks for 512 block slots (a quarter of
 // the CUs run one block instead of two) and 128 x 4 n-tiles of 96 are exactly 512.  The weight stage keeps its 128-row geometry (rows beyond
 // the n-tile are loaded and never read).
-template <bool BF, int NT, int NPL = 2, int NJ = 4>
+// IO16 (one-plane instantiations of the 16-bit torso): the result and the residual are bf16 rows (GemmParams::io16 bits 0 and 1 both set)
+template <bool BF, int NT, int NPL = 2, int NJ = 4, bool IO16 = false>
 __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, const int ntiles) {
     typedef const unsigned short* hp;
     constexpr int BN = 32 * NJ, WNC = 16 * NJ;                         // n-tile width, columns per wave
@@ -388,6 +389,8 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
             const long lane_off = (up2 ? 0 : (long)row0 * p.ldc) + en0 + wn * WNC + lr_;
             float* __restrict__ cbase = p.C + lane_off;
             const float* __restrict__ rbase = p.res ? p.res + lane_off : nullptr;
+            __bf16* __restrict__ cbase16 = reinterpret_cast<__bf16*>(p.C) + lane_off;
+            const __bf16* __restrict__ rbase16 = reinterpret_cast<const __bf16*>(p.res) + lane_off;
             float bv[NJ];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) bv[j] = p.bias ? p.bias[en0 + wn * WNC + lr_ + 16 * j] : 0.f;
@@ -413,7 +416,7 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
 #pragma unroll
-                            for (int j = 0; j < NJ; ++j) rv[r][j] = rbase[ro[r] + 16 * j];
+                            for (int j = 0; j < NJ; ++j) { if constexpr (IO16) rv[r][j] = (float)rbase16[ro[r] + 16 * j]; else rv[r][j] = rbase[ro[r] + 16 * j]; }
                     } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
@@ -425,8 +428,13 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                         float v[NJ];
 #pragma unroll
                         for (int j = 0; j < NJ; ++j) v[j] = (acc[2 * i2 + ii][j][r] * alpha_ + bv[j]) + rv[r][j];
+                        if constexpr (IO16) {
+#pragma unroll
+                            for (int j = 0; j < NJ; ++j) { const __bf16 h_ = (__bf16)v[j]; cbase16[ro[r] + 16 * j] = h_; v[j] = (float)h_; gs[j] += v[j]; gq[j] += v[j] * v[j]; }
+                        } else {
 #pragma unroll
                         for (int j = 0; j < NJ; ++j) { cbase[ro[r] + 16 * j] = v[j]; gs[j] += v[j]; gq[j] += v[j] * v[j]; }      // (nontemporal stores: measured +-0)
+                        }
                         // f16 plane overflow surfaces as NaN / inf.  (The branch per row also keeps hipcc's register allocation in check: with a
                         // branch-free accumulated check the epilogue becomes one block and 230 VGPRs of accumulators are spilled.)
                         float vs_ = v[0];
@@ -534,18 +542,18 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
     }
 }
 
-template <bool BF, int NT, int NPL = 2, int NJ = 4>
+template <bool BF, int NT, int NPL = 2, int NJ = 4, bool IO16 = false>
 int launch_convwin(const GemmParams& p, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convwin_kernel<BF, NT, NPL, NJ>), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convwin_kernel<BF, NT, NPL, NJ, IO16>), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS) != hipSuccess)
             return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
         attr_done = true;
     }
     const long ntiles = (long)((p.M + CW_BM - 1) / CW_BM) * ((p.N + 32 * NJ - 1) / (32 * NJ)) * p.ksplit * (p.nphase > 1 ? p.nphase : 1);
     static const int cfg_persist = CDAE_DEV_INT("CDAE_CONVWIN_GRID", 512);      // persistent blocks: two per CU
     dim3 grid((unsigned)(ntiles < cfg_persist ? ntiles : cfg_persist));
-    hipLaunchKernelGGL((convwin_kernel<BF, NT, NPL, NJ>), grid, dim3(256), CW_LDS, st, p, (int)ntiles);
+    hipLaunchKernelGGL((convwin_kernel<BF, NT, NPL, NJ, IO16>), grid, dim3(256), CW_LDS, st, p, (int)ntiles);
     return hipGetLastError() == hipSuccess ? 0 : cdae_fail("convwin_kernel launch failed");
 }
 
@@ -584,6 +592,9 @@ bool cdae_convwin_ok(const GemmParams& p) {
     if (p.prec < 1 || p.prec > 4) return false;                           // 1 / 2: f16 / bf16 plane pairs; 3 / 4: one f16 / bf16 plane (3x3 only)
     if (p.prec > 2 && p.ps_taps == 4) return false;
     if (p.gn_coef || p.A2 || p.act != ACT_NONE) return false;
+    // 16-bit rows (IO16 instantiation): interior tiles only — its edge path stores fp32 (a runtime choice of the element type there cost 350
+    // spilled registers) — and both the result and the residual bf16
+    if ((p.io16 & 3) && (p.M % CW_BM || p.N % CW_BN || p.prec != 4 || p.accumulate || p.C_hi || (p.io16 & 3) != ((p.res ? 2 : 0) | 1))) return false;
     if (p.ps_taps == 4 ? (p.out_mode != OUT_UP2 || (p.prec != 1 && p.prec != 2) || p.Bk_hi) : p.out_mode != OUT_ROWMAJOR) return false;      // (4 taps, bf16: the stride-2 conv's dgrad as sub-pixel phases)
     if (p.W != 8 && p.W != 16 && p.W != 32 && p.W != 64) return false;            // tight window: tiles start on image-row boundaries
     if (p.Cin % 32 || p.ldb % 8 || p.sx % 8) return false;
@@ -651,6 +662,10 @@ int cdae_convwin_launch(const GemmParams& p, void* stream) {
         return cdae_fail("convwin: out-of-range LDS reads do not return zeros on this device (or the in-range control failed): the window conv kernel's padding taps would be wrong");
     if (p.ps_taps == 4) return p.prec == 2 ? launch_convwin<true, 4>(p, st) : launch_convwin<false, 4>(p, st);
     if (p.prec == 3) return launch_convwin<false, 9, 1>(p, st);          // mixed16: one f16 plane
+    if (p.io16 & 3) {                                                     // the 16-bit torso: bf16 result (and residual) rows
+        if (p.prec != 4 || (p.io16 & 3) != ((p.res ? 2 : 0) | 1)) return cdae_fail("convwin: 16-bit rows need one bf16 plane per operand, a bf16 result and (if any) a bf16 residual");
+        return launch_convwin<true, 9, 1, 4, true>(p, st);
+    }
     if (p.prec == 4) return launch_convwin<true, 9, 1>(p, st);           // mixed16, gradient operand: one bf16 plane
     if (p.cw_nj == 3 && p.prec == 1) return launch_convwin<false, 9, 2, 3>(p, st);      // planes.hip chose the tile width
     return p.prec == 2 ? launch_convwin<true, 9>(p, st) : launch_convwin<false, 9>(p, st);

@@ -184,7 +184,11 @@ struct WPrepDesc { long off; int Cout, Cin, tile0, flags; };      // flags bit 0
 __global__ __launch_bounds__(256) void wprep_all_kernel(const float* __restrict__ flat, const WPrepDesc* __restrict__ desc, int nw, long base,
                                                         _Float16* __restrict__ fh, _Float16* __restrict__ fl, __bf16* __restrict__ bh,
                                                         __bf16* __restrict__ bl, _Float16* __restrict__ kfh, _Float16* __restrict__ kfl,
-                                                        __bf16* __restrict__ kbh, __bf16* __restrict__ kbl, const float* __restrict__ wscale) {
+                                                        __bf16* __restrict__ kbh, __bf16* __restrict__ kbl, const float* __restrict__ wscale,
+                                                        int lo_as_fwd16 = 0) {
+    // lo_as_fwd16 (the 16-bit torso, where the lo planes are never read): bl / kbl receive the bf16 FORWARD weights instead — OHWI order at
+    // bl, K-group-major [Cin / 16][9][Cout][16] at kbl — the operand of the bf16 forward conv (activations are bf16 there, so the f16 planes
+    // cannot pair with them on the matrix cores)
     // wscale (optional): scale records {2^k, 2^-k} per weight (cdae_weight_scales over the same descriptors' tensors, same order): the f16
     // planes then hold w * 2^k; the bf16 dgrad planes (fp32 exponent range: no subnormal problem) stay unscaled
     // kf* / kb* (optional): the same planes in K-group-major order [K / 16][9][rows][16] (cdae_conv_wpack's layout) at the same offsets, for the
@@ -211,9 +215,11 @@ __global__ __launch_bounds__(256) void wprep_all_kernel(const float* __restrict_
             const _Float16 h = (_Float16)vs;
             const _Float16 l = (_Float16)(vs - (float)h);
             fh[o0 + i] = h; fl[o0 + i] = l;
+            if (lo_as_fwd16) bl[o0 + i] = (__bf16)v;
             if (kfh && (d.flags & 1)) {
                 const long k = o0 + (((long)(ci >> 4) * 9 + tap) * d.Cout + co) * 16 + (ci & 15);
                 kfh[k] = h; kfl[k] = l;
+                if (lo_as_fwd16) kbl[k] = (__bf16)v;
             }
         }
         tile[r][tx] = v;
@@ -226,10 +232,10 @@ __global__ __launch_bounds__(256) void wprep_all_kernel(const float* __restrict_
             const __bf16 h = (__bf16)v;
             const long o = o0 + ((long)ci * 9 + (8 - tap)) * d.Cout + co;
             const __bf16 l = (__bf16)(v - (float)h);
-            bh[o] = h; bl[o] = l;
+            bh[o] = h; if (!lo_as_fwd16) bl[o] = l;
             if (kbh && (d.flags & 1)) {
                 const long k = o0 + (((long)(co >> 4) * 9 + (8 - tap)) * d.Cin + ci) * 16 + (co & 15);
-                kbh[k] = h; kbl[k] = l;
+                kbh[k] = h; if (!lo_as_fwd16) kbl[k] = l;
             }
         }
     }
@@ -400,6 +406,57 @@ __global__ void sumpool2_kernel(const float* __restrict__ src, float* __restrict
 
 // the same, four channels per thread (C % 4 == 0, 16-byte aligned tensors): one index decomposition per float4 and 16-byte accesses —
 // the scalar form above spends three 64-bit divisions on every element (79 -> ~40 us for the 64 x 64 -> 32 x 32 gradient at batch 32)
+// ---- 16-bit torso glue (bf16 NHWC rows; ew_bf4 = 4 channels = 8 bytes)
+__global__ void cast_f32_bf16_kernel(const float4* __restrict__ x, ew_bf4* __restrict__ y, long n4) {
+    GRID_STRIDE(i, n4) { const float4 v = x[i]; ew_bf4 o; o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w; y[i] = o; }
+}
+__global__ void cast_bf16_f32_kernel(const ew_bf4* __restrict__ x, float4* __restrict__ y, long n4) {
+    GRID_STRIDE(i, n4) { const ew_bf4 v = x[i]; y[i] = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]); }
+}
+__global__ void upsample2_16_kernel(const ew_bf4* __restrict__ x, ew_bf4* __restrict__ y, int H, int W, int C4, long total) {
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C4);
+        long pix = i / C4;
+        const int xx = (int)(pix % W); pix /= W;
+        const int yy = (int)(pix % H);
+        const long n = pix / H;
+        const ew_bf4 v = x[i];
+        const long o = ((n * 2 * H + 2 * yy) * 2 * W + 2 * xx) * C4 + c, row = 2L * W * C4;
+        y[o] = v; y[o + C4] = v; y[o + row] = v; y[o + row + C4] = v;
+    }
+}
+__global__ void sumpool2_16_kernel(const ew_bf4* __restrict__ src, ew_bf4* __restrict__ dst, int N, int H, int W, int C4) {
+    const long total = (long)N * H * W * C4;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C4); long r = i / C4; const int x = (int)(r % W); r /= W; const int y = (int)(r % H); const int n = (int)(r / H);
+        const ew_bf4* s = src + (((long)n * 2 * H + 2 * y) * 2 * W + 2 * x) * C4 + c;
+        const ew_bf4 a = s[0], b = s[C4], d = s[(long)2 * W * C4], e = s[(long)2 * W * C4 + C4];
+        ew_bf4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (__bf16)(((float)a[k] + (float)b[k]) + ((float)d[k] + (float)e[k]));
+        dst[i] = o;
+    }
+}
+// per (32-row chunk, channel) sums (sum, sum of squares) of a bf16 [M][C] tensor: the format the conv epilogues leave behind
+// (GemmParams::gn_part) for producers that cannot (ATen adds of the skip stack, casts), consumed by cdae_gn_stats_from_parts
+__global__ __launch_bounds__(256) void gn_parts16_kernel(const __bf16* __restrict__ x, long ldx, float* __restrict__ parts, long M, int C) {
+    const int c4n = C >> 2;
+    const long total = ((M + 31) >> 5) * c4n;
+    GRID_STRIDE(i, total) {
+        const long chunk = i / c4n; const int c4 = (int)(i - chunk * c4n);
+        float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+        const long r0 = chunk * 32, r1 = r0 + 32 < M ? r0 + 32 : M;
+        for (long r = r0; r < r1; ++r) {
+            const ew_bf4 v = *reinterpret_cast<const ew_bf4*>(x + r * ldx + 4 * c4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float f = (float)v[k]; s[k] += f; q[k] += f * f; }
+        }
+        float* o = parts + (chunk * C + 4 * c4) * 2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o[2 * k] = s[k]; o[2 * k + 1] = q[k]; }
+    }
+}
+
 __global__ void sumpool2_v4_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int N, int H, int W, int C4) {
     const long total = (long)N * H * W * C4;
     GRID_STRIDE(i, total) {
@@ -758,6 +815,38 @@ int cdae_wprep_all_k(const float* flat, const void* desc, int nw, int total_tile
     hipLaunchKernelGGL(wprep_all_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, flat, (const WPrepDesc*)desc, nw, base, (_Float16*)f_hi,
                        (_Float16*)f_lo, (__bf16*)b_hi, (__bf16*)b_lo, (_Float16*)kf_hi, (_Float16*)kf_lo, (__bf16*)kb_hi, (__bf16*)kb_lo, w_scales);
     return hipGetLastError() == hipSuccess ? 0 : cdae_fail("wprep_all launch failed");
+}
+// cdae_wprep_all_k for the 16-bit torso: the lo planes of the bf16 dgrad weights (never read by the one-plane kernels) receive the bf16
+// FORWARD weights instead — OHWI order at b_lo, K-group-major at kb_lo
+int cdae_wprep_all_m16(const float* flat, const void* desc, int nw, int total_tiles, long base, unsigned short* f_hi, unsigned short* f_lo,
+                       unsigned short* b_hi, unsigned short* b_lo, unsigned short* kf_hi, unsigned short* kf_lo, unsigned short* kb_hi,
+                       unsigned short* kb_lo, const float* w_scales, void* stream) {
+    if (nw <= 0 || total_tiles <= 0) return 0;
+    if (!(kf_hi && kf_lo && kb_hi && kb_lo)) return cdae_fail("wprep_all_m16: all packed planes required");
+    hipLaunchKernelGGL(wprep_all_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, flat, (const WPrepDesc*)desc, nw, base, (_Float16*)f_hi,
+                       (_Float16*)f_lo, (__bf16*)b_hi, (__bf16*)b_lo, (_Float16*)kf_hi, (_Float16*)kf_lo, (__bf16*)kb_hi, (__bf16*)kb_lo, w_scales, 1);
+    return hipGetLastError() == hipSuccess ? 0 : cdae_fail("wprep_all_m16 launch failed");
+}
+int cdae_cast_f32_bf16(const float* x, void* y, long n, void* stream) {
+    if (n % 4 || (((size_t)x) & 15) || (((size_t)y) & 7)) return cdae_fail("cast_f32_bf16: n % 4 == 0 and aligned buffers required");
+    LAUNCH1D(cast_f32_bf16_kernel, n / 4, (const float4*)x, (ew_bf4*)y, n / 4);
+}
+int cdae_cast_bf16_f32(const void* x, float* y, long n, void* stream) {
+    if (n % 4 || (((size_t)y) & 15) || (((size_t)x) & 7)) return cdae_fail("cast_bf16_f32: n % 4 == 0 and aligned buffers required");
+    LAUNCH1D(cast_bf16_f32_kernel, n / 4, (const ew_bf4*)x, (float4*)y, n / 4);
+}
+int cdae_upsample2_16(const void* x, void* y, int N, int H, int W, int C, void* stream) {
+    if (C % 4) return cdae_fail("upsample2_16: C % 4 == 0 required");
+    const long total = (long)N * H * W * (C / 4);
+    LAUNCH1D(upsample2_16_kernel, total, (const ew_bf4*)x, (ew_bf4*)y, H, W, C / 4, total);
+}
+int cdae_sumpool2_16(const void* src, void* dst, int N, int H, int W, int C, void* stream) {
+    if (C % 4) return cdae_fail("sumpool2_16: C % 4 == 0 required");
+    LAUNCH1D(sumpool2_16_kernel, (long)N * H * W * (C / 4), (const ew_bf4*)src, (ew_bf4*)dst, N, H, W, C / 4);
+}
+int cdae_gn_parts16(const void* x, long ldx, float* parts, long M, int C, void* stream) {
+    if (C % 4 || ldx % 4) return cdae_fail("gn_parts16: C % 4 == 0 required");
+    LAUNCH1D(gn_parts16_kernel, ((M + 31) / 32) * (C / 4), (const __bf16*)x, ldx, parts, M, C);
 }
 int cdae_wt_planes_bf16(const float* w, long ldw, unsigned short* hi, unsigned short* lo, int N, int K, void* stream) {
     if (N <= 0 || K <= 0 || !w || !hi || !lo) return cdae_fail("wt_planes_bf16: empty weight");

@@ -212,6 +212,21 @@ __global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_ke
                 ra[q] = make_float4(v[0], v[1], v[2], v[3]);
             }
         } else {   // A_PLAIN_MC: element (i,k) at Ag + k*lda + i
+            if constexpr (PREC == 4 && !SCALAR) {
+                if (p.io16 & 4) {          // (block-uniform) the operand is a bf16 tensor: four elements = 8 bytes, kept RAW in ra[q].x/.y until store_tiles
+                    const unsigned short* A16 = reinterpret_cast<const unsigned short*>(p.A) + (Ag - p.A);
+#pragma unroll
+                    for (int q = 0; q < A_V4; ++q) {
+                        const int idx = tid + THREADS * q;
+                        const int kk = idx / (BM / 4), i4 = idx - kk * (BM / 4);
+                        const int k = k0 + kk, i = m0 + i4 * 4;
+                        const bool ok = k < p.K && i < p.M;
+                        const float2 raw = *reinterpret_cast<const float2*>(ok ? reinterpret_cast<const float*>(A16 + (long)k * p.lda + i) : g_zero16);
+                        ra[q] = make_float4(raw.x, raw.y, 0.f, 0.f);
+                    }
+                    return;
+                }
+            }
 #pragma unroll
             for (int q = 0; q < A_V4; ++q) {
                 const int idx = tid + THREADS * q;
@@ -244,6 +259,21 @@ __global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_ke
                 }
             }
         } else {
+            if constexpr (PREC == 4 && !SCALAR && BMODE == B_PLAIN_MC) {
+                if (p.io16 & 8) {          // (block-uniform) bf16 B operand, raw as above
+                    const unsigned short* B16 = reinterpret_cast<const unsigned short*>(p.B) + (Bg - p.B);
+#pragma unroll
+                    for (int q = 0; q < B_V4; ++q) {
+                        const int idx = tid + THREADS * q;
+                        const int kk = idx / (BN / 4), j4 = idx - kk * (BN / 4);
+                        const int k = k0 + kk, j = n0 + j4 * 4;
+                        const bool ok = k < p.K && j < p.N;
+                        const float2 raw = *reinterpret_cast<const float2*>(ok ? reinterpret_cast<const float*>(B16 + (long)k * p.ldb + j) : g_zero16);
+                        rb[q] = make_float4(raw.x, raw.y, 0.f, 0.f);
+                    }
+                    return;
+                }
+            }
 #pragma unroll
             for (int q = 0; q < B_V4; ++q) {
                 const int idx = tid + THREADS * q;
@@ -352,10 +382,20 @@ __global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_ke
                 }
             }
         }
+        const bool a_raw16 = PREC == 4 && A_MC && (p.io16 & 4), b_raw16 = PREC == 4 && BMODE == B_PLAIN_MC && (p.io16 & 8);
         if constexpr (A_MC) {
             if (do_colsum) {
+                if (a_raw16) {
+#pragma unroll
+                    for (int q = 0; q < A_V4; ++q) {
+                        const unsigned u0 = __builtin_bit_cast(unsigned, ra[q].x), u1 = __builtin_bit_cast(unsigned, ra[q].y);
+                        colsum.x += __builtin_bit_cast(float, u0 << 16); colsum.y += __builtin_bit_cast(float, u0 & 0xffff0000u);
+                        colsum.z += __builtin_bit_cast(float, u1 << 16); colsum.w += __builtin_bit_cast(float, u1 & 0xffff0000u);
+                    }
+                } else {
 #pragma unroll
                 for (int q = 0; q < A_V4; ++q) { colsum.x += ra[q].x; colsum.y += ra[q].y; colsum.z += ra[q].z; colsum.w += ra[q].w; }
+                }
             }
         }
         if constexpr (PREC != 0) {
@@ -367,7 +407,8 @@ __global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_ke
                 else {
                     const int idx = tid + THREADS * q;
                     const int kk = idx / (BM / 4), i4 = idx - kk * (BM / 4);
-                    store_split(ac, A_PLANE, (kk * PAM + i4 * 4) * 2, ra[q]);
+                    if (a_raw16) *reinterpret_cast<float2*>(ac + (kk * PAM + i4 * 4) * 2) = make_float2(ra[q].x, ra[q].y);      // already bf16
+                    else store_split(ac, A_PLANE, (kk * PAM + i4 * 4) * 2, ra[q]);
                 }
             }
 #pragma unroll
@@ -378,7 +419,8 @@ __global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_ke
                 else {
                     const int idx = tid + THREADS * q;
                     const int kk = idx / (BN / 4), j4 = idx - kk * (BN / 4);
-                    store_split(bc, B_PLANE, (kk * PBM + j4 * 4) * 2, rbs);
+                    if (b_raw16) *reinterpret_cast<float2*>(bc + (kk * PBM + j4 * 4) * 2) = make_float2(rb[q].x, rb[q].y);
+                    else store_split(bc, B_PLANE, (kk * PBM + j4 * 4) * 2, rbs);
                 }
             }
             return;
@@ -603,11 +645,11 @@ __global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_ke
                 }
                 if (Rg) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) rv[r] = Rg[ad[r]];
+                    for (int r = 0; r < 16; ++r) rv[r] = (PREC == 3 || PREC == 4) ? cdae_load_res(p, Rg, ad[r]) : Rg[ad[r]];
                 }
                 if (p.accumulate) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) cv[r] = Cg[ad[r]];
+                    for (int r = 0; r < 16; ++r) cv[r] = (PREC == 3 || PREC == 4) ? cdae_load_c(p, Cg, ad[r]) : Cg[ad[r]];
                 }
             }
 #pragma unroll
@@ -626,7 +668,8 @@ __global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_ke
                 if (p.act == ACT_SILU) v = cdae_silu(v);
                 else if (p.act == ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
                 if (p.accumulate) v += cv[r];
-                Cg[addr] = v;
+                if constexpr (PREC == 3 || PREC == 4) cdae_store_c(p, Cg, addr, v);
+                else Cg[addr] = v;
                 if (!__builtin_isfinite(v) && p.range_flag) *p.range_flag = 1;
                 if (p.C_hi) store_planes(p, addr, v);
             }
@@ -661,11 +704,11 @@ __global__ void splitk_reduce_kernel(const GemmParams p) {
             addr = (4L * row - 2 * x + p.ph_y * 2 * p.Wo + p.ph_x) * p.ldc + col;
         } else addr = (long)row * p.ldc + col;
         float v = s * alpha_ + (p.bias ? p.bias[col] : 0.f);
-        if (p.res) v += (p.res + bo * p.c_bs0 + bi * p.c_bs1)[addr];
+        if (p.res) v += cdae_load_res(p, p.res, bo * p.c_bs0 + bi * p.c_bs1 + addr);
         if (p.act == ACT_SILU) v = cdae_silu(v);
         else if (p.act == ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
-        if (p.accumulate) v += Cg[addr];
-        Cg[addr] = v;
+        if (p.accumulate) v += cdae_load_c(p, Cg, addr);
+        cdae_store_c(p, Cg, addr, v);
         if (!__builtin_isfinite(v) && p.range_flag) *p.range_flag = 1;
         if (p.C_hi) store_planes(p, addr, v);
     }
@@ -696,7 +739,10 @@ __global__ __launch_bounds__(256) void splitk_reduce4_kernel(const GemmParams p)
         const long addr = (long)row * p.ldc + 4 * c4;
         const float4 b = p.bias ? *reinterpret_cast<const float4*>(p.bias + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
         float v[4] = {s.x * alpha_ + b.x, s.y * alpha_ + b.y, s.z * alpha_ + b.z, s.w * alpha_ + b.w};
-        if (p.res) { const float4 r = *reinterpret_cast<const float4*>(p.res + addr); v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+        if (p.res) {
+            if (p.io16 & 2) { for (int e = 0; e < 4; ++e) v[e] += cdae_load_res(p, p.res, addr + e); }
+            else { const float4 r = *reinterpret_cast<const float4*>(p.res + addr); v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+        }
         if (p.act == ACT_SILU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = cdae_silu(v[e]);
@@ -704,8 +750,12 @@ __global__ __launch_bounds__(256) void splitk_reduce4_kernel(const GemmParams p)
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
         }
+        if (p.io16 & 1) {
+            for (int e = 0; e < 4; ++e) { if (p.accumulate) v[e] += cdae_load_c(p, p.C, addr + e); cdae_store_c(p, p.C, addr + e, v[e]); }
+        } else {
         if (p.accumulate) { const float4 c = *reinterpret_cast<const float4*>(p.C + addr); v[0] += c.x; v[1] += c.y; v[2] += c.z; v[3] += c.w; }
         *reinterpret_cast<float4*>(p.C + addr) = make_float4(v[0], v[1], v[2], v[3]);
+        }
         bad |= !__builtin_isfinite(v[0] + v[1] + v[2] + v[3]);
         if (p.C_hi) {
 #pragma unroll
@@ -751,8 +801,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_gn_kernel(const GemmParams 
             for (; k < p.ksplit; ++k) { const float4 v = *reinterpret_cast<const float4*>(src + k * slab); s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
             const long addr = (long)row * p.ldc + col;
             float v[4] = {s.x * alpha_ + b.x, s.y * alpha_ + b.y, s.z * alpha_ + b.z, s.w * alpha_ + b.w};
-            if (p.res) { const float4 r = *reinterpret_cast<const float4*>(p.res + addr); v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
-            *reinterpret_cast<float4*>(p.C + addr) = make_float4(v[0], v[1], v[2], v[3]);
+            if (p.res) {
+                if (p.io16 & 2) { for (int e = 0; e < 4; ++e) v[e] += cdae_load_res(p, p.res, addr + e); }
+                else { const float4 r = *reinterpret_cast<const float4*>(p.res + addr); v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+            }
+            if (p.io16 & 1) { for (int e = 0; e < 4; ++e) { v[e] = cdae_round_c(p, v[e]); cdae_store_c(p, p.C, addr + e, v[e]); } }
+            else *reinterpret_cast<float4*>(p.C + addr) = make_float4(v[0], v[1], v[2], v[3]);
             bad |= !__builtin_isfinite(v[0] + v[1] + v[2] + v[3]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { s4[e] += v[e]; q4[e] += v[e] * v[e]; }

@@ -17,19 +17,39 @@ namespace {
 
 __device__ __forceinline__ float silu_f(float v) { return cdae_silu(v); }
 
+// Storage type of an activation / gradient tensor: float (the parity modes) or __bf16 (the half-precision torso: the reference's
+// convert_to_fp16 placement, unet.py:501-507 — 16-bit activations between the layers, fp32 statistics inside GroupNorm32, nn.py:435-437).
+// Every kernel below computes in fp32 registers; only the loads and stores differ.
+typedef __bf16 gn_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ldv4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ldv4(const __bf16* p) {
+    const gn_bf16x4 v = *reinterpret_cast<const gn_bf16x4*>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+__device__ __forceinline__ void stv4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void stv4(__bf16* p, const float4& v) {
+    gn_bf16x4 o; o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+    *reinterpret_cast<gn_bf16x4*>(p) = o;
+}
+__device__ __forceinline__ float ldv1(const float* p) { return *p; }
+__device__ __forceinline__ float ldv1(const __bf16* p) { return (float)*p; }
+__device__ __forceinline__ void stv1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stv1(__bf16* p, float v) { *p = (__bf16)v; }
+
 // ------------------------------------------------------------------ GroupNorm statistics
 // grid (nchunk, N), 256 threads.  partial[((n*nchunk + chunk)*G + g)*2 + {0,1}] = (sum, sumsq) of (x - pivot_g)
 // Two-source form (x2 != nullptr): channels [0, C1) come from x (pitch ldx), channels [C1, C) from x2 (pitch ld2) — the UNet's
 // skip concatenation th.cat([h, hs.pop()], dim=1) (unet.py:629) read in place instead of being copied into one tensor.
-__device__ __forceinline__ const float* gn_src(const float* x, int ldx, const float* x2, int ld2, int C1, long npix0, int c, int& ld) {
+template <typename T>
+__device__ __forceinline__ const T* gn_src(const T* x, int ldx, const T* x2, int ld2, int C1, long npix0, int c, int& ld) {
     if (x2 && c >= C1) { ld = ld2; return x2 + npix0 * ld2 + (c - C1); }
     ld = ldx;
     return x + npix0 * ldx + c;
 }
-template <int VEC>
-__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, int HW, int C, int ldx, int cpg, int G,
+template <int VEC, typename T = float>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, int HW, int C, int ldx, int cpg, int G,
                                                           int pix_per_block, float* __restrict__ partial,
-                                                          const float* __restrict__ x2 = nullptr, int ld2 = 0, int C1 = 0) {
+                                                          const T* __restrict__ x2 = nullptr, int ld2 = 0, int C1 = 0) {
     __shared__ float sS[256], sQ[256];
     const int n = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
     const int E = C / VEC;
@@ -41,8 +61,8 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
     if (active) {
         const int g = (e * VEC) / cpg;
         int ld, ldp;
-        const float* xe = gn_src(x, ldx, x2, ld2, C1, (long)n * HW, e * VEC, ld);         // this thread's channel vector at pixel 0
-        const float pivot = *gn_src(x, ldx, x2, ld2, C1, (long)n * HW, g * cpg, ldp);
+        const T* xe = gn_src(x, ldx, x2, ld2, C1, (long)n * HW, e * VEC, ld);         // this thread's channel vector at pixel 0
+        const float pivot = ldv1(gn_src(x, ldx, x2, ld2, C1, (long)n * HW, g * cpg, ldp));
         const int p0 = chunk * pix_per_block, p1 = min(HW, p0 + pix_per_block);
         int p = p0 + r;
         if (VEC == 4) {
@@ -52,15 +72,15 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
                 Q += (a * a + b * b) + (c * c + d * d);
             };
             for (; p + 3 * rows < p1; p += 4 * rows) {        // four independent 16-byte loads in flight
-                float4 v0 = *reinterpret_cast<const float4*>(xe + (long)p * ld);
-                float4 v1 = *reinterpret_cast<const float4*>(xe + (long)(p + rows) * ld);
-                float4 v2 = *reinterpret_cast<const float4*>(xe + (long)(p + 2 * rows) * ld);
-                float4 v3 = *reinterpret_cast<const float4*>(xe + (long)(p + 3 * rows) * ld);
+                float4 v0 = ldv4(xe + (long)p * ld);
+                float4 v1 = ldv4(xe + (long)(p + rows) * ld);
+                float4 v2 = ldv4(xe + (long)(p + 2 * rows) * ld);
+                float4 v3 = ldv4(xe + (long)(p + 3 * rows) * ld);
                 acc4(v0); acc4(v1); acc4(v2); acc4(v3);
             }
-            for (; p < p1; p += rows) acc4(*reinterpret_cast<const float4*>(xe + (long)p * ld));
+            for (; p < p1; p += rows) acc4(ldv4(xe + (long)p * ld));
         } else {
-            for (; p < p1; p += rows) { float a = xe[(long)p * ld] - pivot; S += a; Q += a * a; }
+            for (; p < p1; p += rows) { float a = ldv1(xe + (long)p * ld) - pivot; S += a; Q += a * a; }
         }
     }
     sS[tid] = S; sQ[tid] = Q;
@@ -91,9 +111,10 @@ __device__ __forceinline__ void gn_coef_one(float mu, float rs, float gm, float 
 
 // G == 32 (GroupNorm32, every norm of the model): grid N, 256 threads = 8 chunk lanes x 32 groups; the serial per-thread walk over
 // up to 128 chunks below costs ~10 us of pure latency per launch, 56 launches per network pass
-__global__ __launch_bounds__(256) void gn_finalize32_kernel(const float* __restrict__ x, int HW, int ldx, int cpg, int nchunk, float eps,
+template <typename T = float>
+__global__ __launch_bounds__(256) void gn_finalize32_kernel(const T* __restrict__ x, int HW, int ldx, int cpg, int nchunk, float eps,
                                                             const float* __restrict__ partial, float* __restrict__ mean, float* __restrict__ rstd,
-                                                            const float* __restrict__ x2, int ld2, int C1,
+                                                            const T* __restrict__ x2, int ld2, int C1,
                                                             const float* __restrict__ gamma = nullptr, const float* __restrict__ beta = nullptr,
                                                             const float* __restrict__ ss = nullptr, int ld_ss = 0, int C = 0,
                                                             float* __restrict__ coef = nullptr) {
@@ -112,7 +133,7 @@ __global__ __launch_bounds__(256) void gn_finalize32_kernel(const float* __restr
         for (int k = 0; k < 8; ++k) { s += sS[k][g]; q += sQ[k][g]; }
         const double cnt = (double)HW * cpg;
         int ldp;
-        const double pivot = *gn_src(x, ldx, x2, ld2, C1, (long)n * HW, g * cpg, ldp);
+        const double pivot = ldv1(gn_src(x, ldx, x2, ld2, C1, (long)n * HW, g * cpg, ldp));
         const double m = s / cnt;
         double var = q / cnt - m * m;
         if (var < 0.0) var = 0.0;
@@ -238,14 +259,14 @@ __global__ void gn_parts_group_kernel(const double* __restrict__ chan, int C, in
 // of the pre-split conv / GEMM kernel (igemm.hip ps_kernel), so the consumer's main loop has no conversion work.
 typedef _Float16 gn_half4 __attribute__((ext_vector_type(4)));
 typedef __bf16 gn_bf4 __attribute__((ext_vector_type(4)));
-template <int VEC, bool SPLIT = false>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, float* __restrict__ y, int HW, int C, int ldx, int ldy,
+template <int VEC, bool SPLIT = false, typename T = float>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, int HW, int C, int ldx, int ldy,
                                                         int cpg, int G, int pix_per_block,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ ss, int ld_ss, int do_silu,
                                                         unsigned short* __restrict__ y_hi = nullptr, unsigned short* __restrict__ y_lo = nullptr,
-                                                        const float* __restrict__ x2 = nullptr, int ld2 = 0, int C1 = 0,
+                                                        const T* __restrict__ x2 = nullptr, int ld2 = 0, int C1 = 0,
                                                         unsigned short* __restrict__ yb_hi = nullptr, unsigned short* __restrict__ yb_lo = nullptr,
                                                         int plane_gm = 0) {
     // plane_gm: the f16 planes are written group-major, [C / 16][N * HW][16] (the window conv kernel's contiguous half-windows)
@@ -266,9 +287,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
         }
     }
     int ldxe;
-    const float* xp = gn_src(x, ldx, x2, ld2, C1, (long)n * HW, c, ldxe);
+    const T* xp = gn_src(x, ldx, x2, ld2, C1, (long)n * HW, c, ldxe);
     ldx = ldxe;
-    float* yp = y + (long)n * HW * ldy + c;
+    T* yp = y + (long)n * HW * ldy + c;
     const int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
     auto apply = [&](float v, int i) { float h = fmaf(v, A[i], B[i]); return do_silu ? silu_f(h) : h; };
     int p = p0 + r;
@@ -294,18 +315,18 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                     *reinterpret_cast<gn_bf4*>(yb_hi + hbase + (long)pp * ldy) = bh;
                     *reinterpret_cast<gn_bf4*>(yb_lo + hbase + (long)pp * ldy) = bl;
                 }
-            } else *reinterpret_cast<float4*>(yp + (long)pp * ldy) = make_float4(r0, r1, r2, r3);
+            } else stv4(yp + (long)pp * ldy, make_float4(r0, r1, r2, r3));
         };
         for (; p + 3 * rows < p1; p += 4 * rows) {
-            float4 v0 = *reinterpret_cast<const float4*>(xp + (long)p * ldx);
-            float4 v1 = *reinterpret_cast<const float4*>(xp + (long)(p + rows) * ldx);
-            float4 v2 = *reinterpret_cast<const float4*>(xp + (long)(p + 2 * rows) * ldx);
-            float4 v3 = *reinterpret_cast<const float4*>(xp + (long)(p + 3 * rows) * ldx);
+            float4 v0 = ldv4(xp + (long)p * ldx);
+            float4 v1 = ldv4(xp + (long)(p + rows) * ldx);
+            float4 v2 = ldv4(xp + (long)(p + 2 * rows) * ldx);
+            float4 v3 = ldv4(xp + (long)(p + 3 * rows) * ldx);
             put(p, v0); put(p + rows, v1); put(p + 2 * rows, v2); put(p + 3 * rows, v3);
         }
-        for (; p < p1; p += rows) put(p, *reinterpret_cast<const float4*>(xp + (long)p * ldx));
+        for (; p < p1; p += rows) put(p, ldv4(xp + (long)p * ldx));
     } else {
-        for (; p < p1; p += rows) yp[(long)p * ldy] = apply(xp[(long)p * ldx], 0);
+        for (; p < p1; p += rows) stv1(yp + (long)p * ldy, apply(ldv1(xp + (long)p * ldx), 0));
     }
 }
 
@@ -374,15 +395,15 @@ __global__ __launch_bounds__(256) void gn_apply_gm_kernel(const float* __restric
 //   dgamma[c] += sum du*xh, dbeta[c] += sum du, dscale[n][c] = sum_p dh*u, dshift[n][c] = sum_p dh
 // Pass 1 (this kernel): per (n, chunk) partial sums  [G][2] (sum dxh, sum dxh*xh) and per-channel
 // partials [C][4] (du*xh, du, dh*u, dh).  grid (nchunk, N).
-template <int VEC>
-__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+template <int VEC, typename T = float>
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                               int HW, int C, int ldx, int lddy, int cpg, int G, int pix_per_block,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               const float* __restrict__ ss, int ld_ss, int do_silu,
                                                               float* __restrict__ gpart /*[N][nchunk][G][2]*/,
                                                               float* __restrict__ cpart /*[N][nchunk][C][4]*/,
-                                                              const float* __restrict__ x2 = nullptr, int ld2 = 0, int C1 = 0) {
+                                                              const T* __restrict__ x2 = nullptr, int ld2 = 0, int C1 = 0) {
     __shared__ float sA[256], sB[256];
     __shared__ float sC[256 * 4 * 4];          // per thread VEC x 4 channel sums (only when rows > 1)
     const int n = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
@@ -405,7 +426,7 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
         }
         const int p0 = chunk * pix_per_block, p1 = min(HW, p0 + pix_per_block);
         int ldxe;                                   // this thread's channel vector lives in one of the two sources (skip concatenation)
-        const float* const xb = gn_src(x, ldx, x2, ld2, C1, (long)n * HW, c, ldxe);
+        const T* const xb = gn_src(x, ldx, x2, ld2, C1, (long)n * HW, c, ldxe);
         auto pixel = [&](const float* xv, const float* dv) {
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
@@ -422,14 +443,14 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
         };
         int p = p0 + r;
         if (VEC == 4) {
-            const float* const db = dy + (long)n * HW * lddy + c;
+            const T* const db = dy + (long)n * HW * lddy + c;
             // four pixels (eight 16-byte loads) in flight per thread; the pixels are accumulated in the same order as one by one
             for (; p + 3 * rows < p1; p += 4 * rows) {
                 float4 t[4], d[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    t[u] = *reinterpret_cast<const float4*>(xb + (long)(p + u * rows) * ldxe);
-                    d[u] = *reinterpret_cast<const float4*>(db + (long)(p + u * rows) * lddy);
+                    t[u] = ldv4(xb + (long)(p + u * rows) * ldxe);
+                    d[u] = ldv4(db + (long)(p + u * rows) * lddy);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -438,15 +459,15 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
                 }
             }
             for (; p < p1; p += rows) {
-                const float4 t = *reinterpret_cast<const float4*>(xb + (long)p * ldxe);
-                const float4 d = *reinterpret_cast<const float4*>(db + (long)p * lddy);
+                const float4 t = ldv4(xb + (long)p * ldxe);
+                const float4 d = ldv4(db + (long)p * lddy);
                 const float xv[4] = {t.x, t.y, t.z, t.w}, dv[4] = {d.x, d.y, d.z, d.w};
                 pixel(xv, dv);
             }
         } else {
             for (; p < p1; p += rows) {
                 const long pix = (long)n * HW + p;
-                const float xv[1] = {xb[(long)p * ldxe]}, dv[1] = {dy[pix * lddy + c]};
+                const float xv[1] = {ldv1(xb + (long)p * ldxe)}, dv[1] = {ldv1(dy + pix * lddy + c)};
                 pixel(xv, dv);
             }
         }
@@ -562,17 +583,17 @@ __global__ void gn_bwd_param_kernel(int N, int C, const float* __restrict__ nc_p
 }
 
 // Pass 3: dx
-template <int VEC>
-__global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+template <int VEC, typename T = float>
+__global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
                                                          long total_vec, int HW, int C, int ldx, int lddy, int lddx, int cpg, int G,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ ss, int ld_ss, int do_silu,
                                                          const float* __restrict__ gsum, int accumulate,
-                                                         const float* __restrict__ dx_add = nullptr, int ld_add = 0,
+                                                         const T* __restrict__ dx_add = nullptr, int ld_add = 0,
                                                          unsigned short* __restrict__ dxb_hi = nullptr, unsigned short* __restrict__ dxb_lo = nullptr,
-                                                         const float* __restrict__ x2 = nullptr, int ld2 = 0, int C1 = 0,
-                                                         float* __restrict__ dx2 = nullptr, int lddx2 = 0) {
+                                                         const T* __restrict__ x2 = nullptr, int ld2 = 0, int C1 = 0,
+                                                         T* __restrict__ dx2 = nullptr, int lddx2 = 0) {
     // x2 / dx2: channels [C1, C) of the normalised tensor live in a second source (the skip concatenation read in place); their
     // gradient goes to dx2 [pixels][C - C1]
     // dx_add: a second gradient of the same tensor (the ResBlock's residual path) added on the way out instead of by a separate
@@ -586,14 +607,14 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const float* __restrict_
         const float m1 = gsum[(n * G + g) * 2], m2 = gsum[(n * G + g) * 2 + 1];
         float xv[VEC], dv[VEC], o[VEC];
         const bool second = x2 != nullptr && c >= C1;
-        const float* const xp = second ? x2 + pix * ld2 + (c - C1) : x + pix * ldx + c;
-        float* const dxp = dx == nullptr ? nullptr : (second ? dx2 + pix * lddx2 + (c - C1) : dx + pix * lddx + c);
+        const T* const xp = second ? x2 + pix * ld2 + (c - C1) : x + pix * ldx + c;
+        T* const dxp = dx == nullptr ? nullptr : (second ? dx2 + pix * lddx2 + (c - C1) : dx + pix * lddx + c);
         if (VEC == 4) {
-            float4 t = *reinterpret_cast<const float4*>(xp);
-            float4 d = *reinterpret_cast<const float4*>(dy + pix * lddy + c);
+            float4 t = ldv4(xp);
+            float4 d = ldv4(dy + pix * lddy + c);
             xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
             dv[0] = d.x; dv[1] = d.y; dv[2] = d.z; dv[3] = d.w;
-        } else { xv[0] = *xp; dv[0] = dy[pix * lddy + c]; }
+        } else { xv[0] = ldv1(xp); dv[0] = ldv1(dy + pix * lddy + c); }
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             float gm = gamma[c + i];
@@ -608,19 +629,19 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const float* __restrict_
         }
         if (accumulate) {
             if (VEC == 4) {
-                float4 t = *reinterpret_cast<const float4*>(dxp);
+                float4 t = ldv4(dxp);
                 o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
-            } else o[0] += *dxp;
+            } else o[0] += ldv1(dxp);
         }
         if (dx_add) {
             if (VEC == 4) {
-                float4 t = *reinterpret_cast<const float4*>(dx_add + pix * ld_add + c);
+                float4 t = ldv4(dx_add + pix * ld_add + c);
                 o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
-            } else o[0] += dx_add[pix * ld_add + c];
+            } else o[0] += ldv1(dx_add + pix * ld_add + c);
         }
         if (dx) {
-            if (VEC == 4) *reinterpret_cast<float4*>(dxp) = make_float4(o[0], o[1], o[2], o[3]);
-            else *dxp = o[0];
+            if (VEC == 4) stv4(dxp, make_float4(o[0], o[1], o[2], o[3]));
+            else stv1(dxp, o[0]);
         }
         if constexpr (VEC == 4) {
             if (dxb_hi) {
@@ -638,16 +659,17 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const float* __restrict_
 // pixels, so every per-(image, channel) constant (mean, rstd, the group sums, gamma, beta, scale, shift) is loaded ONCE (the
 // grid-stride form above re-reads ~20 scalars per element, each a dependent round trip through L1) and the pixel loop is two pixels
 // of 16-byte loads in flight, fma / sigmoid, 16-byte stores.  Same per-element arithmetic in the same order: bit-identical results.
-__global__ __launch_bounds__(256) void gn_bwd_dx_stream_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+template <typename T = float>
+__global__ __launch_bounds__(256) void gn_bwd_dx_stream_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
                                                                 int HW, int C, int ldx, int lddy, int lddx, int cpg, int G, int pix_per_block,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 const float* __restrict__ ss, int ld_ss, int do_silu,
                                                                 const float* __restrict__ gsum, int accumulate,
-                                                                const float* __restrict__ dx_add, int ld_add,
+                                                                const T* __restrict__ dx_add, int ld_add,
                                                                 unsigned short* __restrict__ dxb_hi, unsigned short* __restrict__ dxb_lo,
-                                                                const float* __restrict__ x2, int ld2, int C1,
-                                                                float* __restrict__ dx2, int lddx2,
+                                                                const T* __restrict__ x2, int ld2, int C1,
+                                                                T* __restrict__ dx2, int lddx2,
                                                                 int N, const float* __restrict__ nc_part, float* __restrict__ dgamma,
                                                                 float* __restrict__ dbeta, int accumulate_params) {
     if ((int)blockIdx.y == N) {       // (nc_part != nullptr) one extra row of blocks: pass 2b, dgamma / dbeta = the per-image sums folded over the batch
@@ -674,12 +696,12 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_stream_kernel(const float* __re
     }
     const bool second = x2 != nullptr && c >= C1;
     const long pixb = (long)n * HW;
-    const float* const xb = second ? x2 + pixb * ld2 + (c - C1) : x + pixb * ldx + c;
+    const T* const xb = second ? x2 + pixb * ld2 + (c - C1) : x + pixb * ldx + c;
     const int xl = second ? ld2 : ldx;
-    float* const ob = dx == nullptr ? nullptr : (second ? dx2 + pixb * lddx2 + (c - C1) : dx + pixb * lddx + c);
+    T* const ob = dx == nullptr ? nullptr : (second ? dx2 + pixb * lddx2 + (c - C1) : dx + pixb * lddx + c);
     const int ol = second ? lddx2 : lddx;
-    const float* const db = dy + pixb * lddy + c;
-    const float* const ab = dx_add ? dx_add + pixb * ld_add + c : nullptr;
+    const T* const db = dy + pixb * lddy + c;
+    const T* const ab = dx_add ? dx_add + pixb * ld_add + c : nullptr;
     const int p0 = chunk * pix_per_block, p1 = min(HW, p0 + pix_per_block);
     auto pixel = [&](int p, const float4& t, const float4& d, const float4& acc4, const float4& add4) {
         const float xv[4] = {t.x, t.y, t.z, t.w}, dv[4] = {d.x, d.y, d.z, d.w};
@@ -695,7 +717,7 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_stream_kernel(const float* __re
         }
         if (accumulate) { o[0] += acc4.x; o[1] += acc4.y; o[2] += acc4.z; o[3] += acc4.w; }
         if (ab) { o[0] += add4.x; o[1] += add4.y; o[2] += add4.z; o[3] += add4.w; }
-        if (ob) *reinterpret_cast<float4*>(ob + (long)p * ol) = make_float4(o[0], o[1], o[2], o[3]);
+        if (ob) stv4(ob + (long)p * ol, make_float4(o[0], o[1], o[2], o[3]));
         if (dxb_hi) {
             gn_bf4 bh, bl;
 #pragma unroll
@@ -708,20 +730,20 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_stream_kernel(const float* __re
     int p = p0 + r;
     for (; p + rows < p1; p += 2 * rows) {                            // two pixels: up to eight 16-byte loads in flight
         const int q = p + rows;
-        const float4 t0 = *reinterpret_cast<const float4*>(xb + (long)p * xl), t1 = *reinterpret_cast<const float4*>(xb + (long)q * xl);
-        const float4 d0 = *reinterpret_cast<const float4*>(db + (long)p * lddy), d1 = *reinterpret_cast<const float4*>(db + (long)q * lddy);
+        const float4 t0 = ldv4(xb + (long)p * xl), t1 = ldv4(xb + (long)q * xl);
+        const float4 d0 = ldv4(db + (long)p * lddy), d1 = ldv4(db + (long)q * lddy);
         float4 c0 = z4, c1 = z4, e0 = z4, e1 = z4;
-        if (accumulate) { c0 = *reinterpret_cast<const float4*>(ob + (long)p * ol); c1 = *reinterpret_cast<const float4*>(ob + (long)q * ol); }
-        if (ab) { e0 = *reinterpret_cast<const float4*>(ab + (long)p * ld_add); e1 = *reinterpret_cast<const float4*>(ab + (long)q * ld_add); }
+        if (accumulate) { c0 = ldv4(ob + (long)p * ol); c1 = ldv4(ob + (long)q * ol); }
+        if (ab) { e0 = ldv4(ab + (long)p * ld_add); e1 = ldv4(ab + (long)q * ld_add); }
         pixel(p, t0, d0, c0, e0);
         pixel(q, t1, d1, c1, e1);
     }
     for (; p < p1; p += rows) {
-        const float4 t0 = *reinterpret_cast<const float4*>(xb + (long)p * xl);
-        const float4 d0 = *reinterpret_cast<const float4*>(db + (long)p * lddy);
+        const float4 t0 = ldv4(xb + (long)p * xl);
+        const float4 d0 = ldv4(db + (long)p * lddy);
         float4 c0 = z4, e0 = z4;
-        if (accumulate) c0 = *reinterpret_cast<const float4*>(ob + (long)p * ol);
-        if (ab) e0 = *reinterpret_cast<const float4*>(ab + (long)p * ld_add);
+        if (accumulate) c0 = ldv4(ob + (long)p * ol);
+        if (ab) e0 = ldv4(ab + (long)p * ld_add);
         pixel(p, t0, d0, c0, e0);
     }
 }
@@ -903,6 +925,57 @@ int gn_chunks(int HW, int N, int E) {
 
 #define CHECK_LAUNCH(msg) do { if (hipGetLastError() != hipSuccess) return cdae_fail(msg); } while (0)
 
+template <typename T>
+static int gn_bwd_impl(const T* x, const T* x2, int ld2, int C1, const T* dy, T* dx, T* dx2, int lddx2, int N, int HW, int C, int ldx,
+                       int lddy, int lddx, int groups, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                       const float* scale_shift, int ld_ss, int silu, float* dgamma, float* dbeta, int accumulate_params, float* d_scale_shift,
+                       int ld_dss, int accumulate_dx, const T* dx_add, int ld_add, unsigned short* dxb_hi, unsigned short* dxb_lo, float* ws,
+                       void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!dx && !dxb_hi) return cdae_fail("gn_bwd: no output for dx");
+    if ((dxb_hi != nullptr) != (dxb_lo != nullptr)) return cdae_fail("gn_bwd: both bf16 planes or none");
+    if (!dx && accumulate_dx) return cdae_fail("gn_bwd: accumulate_dx needs the fp32 dx");
+    if (dxb_hi && !((C / groups) % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && (!dx || lddx % 4 == 0) && (!dx_add || ld_add % 4 == 0)))
+        return cdae_fail("gn_bwd: plane output needs the 4-channel vector path");
+    const int cpg = C / groups;
+    const int VEC = (cpg % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && (!dx || lddx % 4 == 0) && (!dx_add || ld_add % 4 == 0)) ? 4 : 1;
+    const int E = C / VEC;
+    if (E > 256) return cdae_fail("gn_bwd: unsupported channel count");
+    const int nchunk = gn_chunks(HW, N, E);
+    const int ppb = (HW + nchunk - 1) / nchunk;
+    float* gpart = ws;
+    float* cpart = gpart + (size_t)N * nchunk * groups * 2;
+    float* gsum = cpart + (size_t)N * nchunk * C * 4;
+    float* ncp = gsum + (size_t)N * groups * 2;
+    const long total = (long)N * HW * E;
+    cdae_prof_begin(PROF_GN, (double)N * HW * C * 5.0 * sizeof(T), st);
+    if (cdae_prof_on()) { char tag[96]; snprintf(tag, sizeof(tag), "gn_bwd_impl N=%d HW=%d C=%d B=%d", (int)N, (int)HW, (int)C, (int)sizeof(T)); cdae_prof_tag(tag); }
+    if (VEC == 4) hipLaunchKernelGGL((gn_bwd_partial_kernel<4, T>), dim3(nchunk, N), dim3(256), 0, st, x, dy, HW, C, ldx, lddy, cpg, groups, ppb, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gpart, cpart, x2, ld2, C1);
+    else hipLaunchKernelGGL((gn_bwd_partial_kernel<1, T>), dim3(nchunk, N), dim3(256), 0, st, x, dy, HW, C, ldx, lddy, cpg, groups, ppb, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gpart, cpart, x2, ld2, C1);
+    hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3((C + 63) / 64 + 1, N), dim3(256), 0, st, N, HW, C, cpg, groups, nchunk, gpart, cpart, gsum, d_scale_shift, ld_dss, ncp);
+    static const int cfg_dxs = CDAE_DEV_INT("CDAE_GN_BWD_STREAM", 1);
+    const bool dx_stream = VEC == 4 && cfg_dxs && E <= 256 && (!accumulate_dx || dx);
+    // pass 2b (dgamma / dbeta over the batch) rides along as one extra row of blocks of the streaming dx launch (it only needs pass 2a's
+    // per-image sums, like dx): one launch less per GroupNorm, 56 per C64 training step; CDAE_GN_BWD_PARAM_ROW=0: its own launch
+    static const int cfg_prow = CDAE_DEV_INT("CDAE_GN_BWD_PARAM_ROW", 1);
+    // (the row has only nchunk blocks, each walking ceil(C / 32 / nchunk) channel blocks x N / 8 images one after the other: at N = 256
+    // and one chunk that serial walk was 80 of the 101 us of a 16-pixel GroupNorm backward — then the fold gets its own C / 32 blocks)
+    const long prow_serial = (long)(((C + 31) / 32 + nchunk - 1) / nchunk) * ((N + 7) / 8);
+    const bool param_row = dx_stream && cfg_prow && N >= 8 && prow_serial <= 64;
+    if (param_row) {}
+    else if (N >= 8) hipLaunchKernelGGL(gn_bwd_param8_kernel, dim3((C + 31) / 32), dim3(256), 0, st, N, C, ncp, dgamma, dbeta, accumulate_params);
+    else hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, st, N, C, ncp, dgamma, dbeta, accumulate_params);
+    if (dx_stream)
+        hipLaunchKernelGGL((gn_bwd_dx_stream_kernel<T>), dim3(nchunk, param_row ? N + 1 : N), dim3(256), 0, st, x, dy, dx, HW, C, ldx, lddy, lddx, cpg, groups, ppb, mean, rstd,
+                           gamma, beta, scale_shift, ld_ss, silu, gsum, accumulate_dx, dx_add, ld_add, dxb_hi, dxb_lo, x2, ld2, C1, dx2, lddx2,
+                           param_row ? N : -1, ncp, dgamma, dbeta, accumulate_params);
+    else if (VEC == 4) hipLaunchKernelGGL((gn_bwd_dx_kernel<4, T>), dim3(grid_for(total)), dim3(256), 0, st, x, dy, dx, total, HW, C, ldx, lddy, lddx, cpg, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gsum, accumulate_dx, dx_add, ld_add, dxb_hi, dxb_lo, x2, ld2, C1, dx2, lddx2);
+    else hipLaunchKernelGGL((gn_bwd_dx_kernel<1, T>), dim3(grid_for(total)), dim3(256), 0, st, x, dy, dx, total, HW, C, ldx, lddy, lddx, cpg, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gsum, accumulate_dx, dx_add, ld_add, (unsigned short*)nullptr, (unsigned short*)nullptr, x2, ld2, C1, dx2, lddx2);
+    cdae_prof_end(PROF_GN, st);
+    CHECK_LAUNCH("gn_bwd launch failed");
+    return 0;
+}
+
 extern "C" {
 
 // workspace floats needed by cdae_gn_stats / cdae_gn_bwd
@@ -924,7 +997,7 @@ int cdae_gn_stats(const float* x, int N, int HW, int C, int ldx, int groups, flo
     if (cdae_prof_on()) { char tag[96]; snprintf(tag, sizeof(tag), "cdae_gn_stats N=%d HW=%d C=%d", (int)N, (int)HW, (int)C); cdae_prof_tag(tag); }
     if (VEC == 4) hipLaunchKernelGGL(gn_partial_kernel<4>, dim3(nchunk, N), dim3(256), 0, st, x, HW, C, ldx, cpg, groups, ppb, ws);
     else hipLaunchKernelGGL(gn_partial_kernel<1>, dim3(nchunk, N), dim3(256), 0, st, x, HW, C, ldx, cpg, groups, ppb, ws);
-    if (groups == 32) hipLaunchKernelGGL(gn_finalize32_kernel, dim3(N), dim3(256), 0, st, x, HW, ldx, cpg, nchunk, eps, ws, mean, rstd, (const float*)nullptr, 0, 0);
+    if (groups == 32) hipLaunchKernelGGL((gn_finalize32_kernel<float>), dim3(N), dim3(256), 0, st, x, HW, ldx, cpg, nchunk, eps, ws, mean, rstd, (const float*)nullptr, 0, 0);
     else hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(groups < 64 ? 64 : groups), 0, st, x, HW, ldx, cpg, groups, nchunk, eps, ws, mean, rstd);
     cdae_prof_end(PROF_GN, st);
     CHECK_LAUNCH("gn_stats launch failed");
@@ -960,18 +1033,13 @@ int cdae_gn_bwd(const float* x, const float* dy, float* dx, int N, int HW, int C
                           accumulate_params, d_scale_shift, ld_dss, accumulate_dx, nullptr, 0, nullptr, nullptr, ws, stream);
 }
 
-static int gn_bwd_impl(const float* x, const float* x2, int ld2, int C1, const float* dy, float* dx, float* dx2, int lddx2, int N, int HW, int C, int ldx,
-                       int lddy, int lddx, int groups, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                       const float* scale_shift, int ld_ss, int silu, float* dgamma, float* dbeta, int accumulate_params, float* d_scale_shift,
-                       int ld_dss, int accumulate_dx, const float* dx_add, int ld_add, unsigned short* dxb_hi, unsigned short* dxb_lo, float* ws,
-                       void* stream);
 
 int cdae_gn_bwd_ex(const float* x, const float* dy, float* dx, int N, int HW, int C, int ldx, int lddy, int lddx, int groups,
                    const float* mean, const float* rstd, const float* gamma, const float* beta, const float* scale_shift, int ld_ss, int silu,
                    float* dgamma, float* dbeta, int accumulate_params, float* d_scale_shift, int ld_dss, int accumulate_dx,
                    const float* dx_add, int ld_add, unsigned short* dxb_hi, unsigned short* dxb_lo, float* ws, void* stream) {
-    return gn_bwd_impl(x, nullptr, 0, C, dy, dx, nullptr, 0, N, HW, C, ldx, lddy, lddx, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, dgamma,
-                       dbeta, accumulate_params, d_scale_shift, ld_dss, accumulate_dx, dx_add, ld_add, dxb_hi, dxb_lo, ws, stream);
+    return gn_bwd_impl<float>(x, nullptr, 0, C, dy, dx, nullptr, 0, N, HW, C, ldx, lddy, lddx, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, dgamma,
+                              dbeta, accumulate_params, d_scale_shift, ld_dss, accumulate_dx, dx_add, ld_add, dxb_hi, dxb_lo, ws, stream);
 }
 
 int cdae_gn_bwd_cat(const float* x1, int ld1, const float* x2, int ld2, int C1, const float* dy, int lddy, float* dx1, int lddx1, float* dx2, int lddx2,
@@ -980,57 +1048,67 @@ int cdae_gn_bwd_cat(const float* x1, int ld1, const float* x2, int ld2, int C1, 
                     int ld_dss, int accumulate_dx, float* ws, void* stream) {
     if (!x2 || !dx1 || !dx2 || C1 <= 0 || C1 >= C || C1 % 4 || ld1 % 4 || ld2 % 4 || lddx1 % 4 || lddx2 % 4 || (C / groups) % 4)
         return cdae_fail("gn_bwd_cat: two sources with 4-channel aligned widths and pitches required");
-    return gn_bwd_impl(x1, x2, ld2, C1, dy, dx1, dx2, lddx2, N, HW, C, ld1, lddy, lddx1, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, dgamma,
-                       dbeta, accumulate_params, d_scale_shift, ld_dss, accumulate_dx, nullptr, 0, nullptr, nullptr, ws, stream);
+    return gn_bwd_impl<float>(x1, x2, ld2, C1, dy, dx1, dx2, lddx2, N, HW, C, ld1, lddy, lddx1, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, dgamma,
+                              dbeta, accumulate_params, d_scale_shift, ld_dss, accumulate_dx, nullptr, 0, nullptr, nullptr, ws, stream);
 }
 
-static int gn_bwd_impl(const float* x, const float* x2, int ld2, int C1, const float* dy, float* dx, float* dx2, int lddx2, int N, int HW, int C, int ldx,
-                       int lddy, int lddx, int groups, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                       const float* scale_shift, int ld_ss, int silu, float* dgamma, float* dbeta, int accumulate_params, float* d_scale_shift,
-                       int ld_dss, int accumulate_dx, const float* dx_add, int ld_add, unsigned short* dxb_hi, unsigned short* dxb_lo, float* ws,
-                       void* stream) {
+// GroupNorm32 backward on a 16-bit torso (bf16 rows in, bf16 rows out; statistics, folds and parameter gradients fp32): x / x2 the (one
+// or two) sources of the normalised tensor, dy the gradient of the norm's output, dx / dx2 its input gradient(s), dx_add a second
+// gradient of the same tensor added on the way out (the ResBlock's residual path).
+int cdae_gn_bwd16(const void* x, int ldx, const void* x2, int ld2, int C1, const void* dy, int lddy, void* dx, int lddx, void* dx2, int lddx2,
+                  int N, int HW, int C, int groups, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                  const float* scale_shift, int ld_ss, int silu, float* dgamma, float* dbeta, int accumulate_params, float* d_scale_shift,
+                  int ld_dss, int accumulate_dx, const void* dx_add, int ld_add, float* ws, void* stream) {
+    if ((C / groups) % 4 || ldx % 4 || lddy % 4 || lddx % 4 || (x2 && (ld2 % 4 || C1 % 4 || !dx2 || lddx2 % 4)) || (dx_add && ld_add % 4))
+        return cdae_fail("gn_bwd16: 4-channel aligned widths and pitches required");
+    typedef __bf16 B;
+    return gn_bwd_impl<B>((const B*)x, (const B*)x2, ld2, x2 ? C1 : C, (const B*)dy, (B*)dx, (B*)dx2, lddx2, N, HW, C, ldx, lddy, lddx, groups, mean, rstd, gamma,
+                          beta, scale_shift, ld_ss, silu, dgamma, dbeta, accumulate_params, d_scale_shift, ld_dss, accumulate_dx, (const B*)dx_add, ld_add,
+                          nullptr, nullptr, ws, stream);
+}
+
+
+// GroupNorm32 statistics of a bf16 tensor (one or two sources: a channel concatenation read in place), fp32 sums — what the reference's
+// GroupNorm32 computes after its .float() (nn.py:435-437); optionally the folded (a, b) table like cdae_gn_stats2_coef
+int cdae_gn_stats16(const void* x1, int ld1, const void* x2, int ld2, int C1, int N, int HW, int C, int groups, float eps, float* mean, float* rstd,
+                    const float* gamma, const float* beta, const float* scale_shift, int ld_ss, float* coef, float* ws, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    if (!dx && !dxb_hi) return cdae_fail("gn_bwd: no output for dx");
-    if ((dxb_hi != nullptr) != (dxb_lo != nullptr)) return cdae_fail("gn_bwd: both bf16 planes or none");
-    if (!dx && accumulate_dx) return cdae_fail("gn_bwd: accumulate_dx needs the fp32 dx");
-    if (dxb_hi && !((C / groups) % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && (!dx || lddx % 4 == 0) && (!dx_add || ld_add % 4 == 0)))
-        return cdae_fail("gn_bwd: plane output needs the 4-channel vector path");
+    typedef __bf16 B;
+    if (groups != 32 || C % 32 || (coef && (!gamma || !beta))) return cdae_fail("gn_stats16: GroupNorm32 only (coef needs gamma and beta)");
     const int cpg = C / groups;
-    const int VEC = (cpg % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && (!dx || lddx % 4 == 0) && (!dx_add || ld_add % 4 == 0)) ? 4 : 1;
-    const int E = C / VEC;
-    if (E > 256) return cdae_fail("gn_bwd: unsupported channel count");
+    if (!(cpg % 4 == 0 && ld1 % 4 == 0 && (!x2 || (ld2 % 4 == 0 && C1 % 4 == 0))) || C / 4 > 256) return cdae_fail("gn_stats16: needs 4-channel vectors, C <= 1024");
+    const int E = C / 4;
     const int nchunk = gn_chunks(HW, N, E);
     const int ppb = (HW + nchunk - 1) / nchunk;
-    float* gpart = ws;
-    float* cpart = gpart + (size_t)N * nchunk * groups * 2;
-    float* gsum = cpart + (size_t)N * nchunk * C * 4;
-    float* ncp = gsum + (size_t)N * groups * 2;
-    const long total = (long)N * HW * E;
-    cdae_prof_begin(PROF_GN, (double)N * HW * C * 20.0, st);
-    if (cdae_prof_on()) { char tag[96]; snprintf(tag, sizeof(tag), "gn_bwd_impl N=%d HW=%d C=%d", (int)N, (int)HW, (int)C); cdae_prof_tag(tag); }
-    if (VEC == 4) hipLaunchKernelGGL(gn_bwd_partial_kernel<4>, dim3(nchunk, N), dim3(256), 0, st, x, dy, HW, C, ldx, lddy, cpg, groups, ppb, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gpart, cpart, x2, ld2, C1);
-    else hipLaunchKernelGGL(gn_bwd_partial_kernel<1>, dim3(nchunk, N), dim3(256), 0, st, x, dy, HW, C, ldx, lddy, cpg, groups, ppb, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gpart, cpart, x2, ld2, C1);
-    hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3((C + 63) / 64 + 1, N), dim3(256), 0, st, N, HW, C, cpg, groups, nchunk, gpart, cpart, gsum, d_scale_shift, ld_dss, ncp);
-    static const int cfg_dxs = CDAE_DEV_INT("CDAE_GN_BWD_STREAM", 1);
-    const bool dx_stream = VEC == 4 && cfg_dxs && E <= 256 && (!accumulate_dx || dx);
-    // pass 2b (dgamma / dbeta over the batch) rides along as one extra row of blocks of the streaming dx launch (it only needs pass 2a's
-    // per-image sums, like dx): one launch less per GroupNorm, 56 per C64 training step; CDAE_GN_BWD_PARAM_ROW=0: its own launch
-    static const int cfg_prow = CDAE_DEV_INT("CDAE_GN_BWD_PARAM_ROW", 1);
-    // (the row has only nchunk blocks, each walking ceil(C / 32 / nchunk) channel blocks x N / 8 images one after the other: at N = 256
-    // and one chunk that serial walk was 80 of the 101 us of a 16-pixel GroupNorm backward — then the fold gets its own C / 32 blocks)
-    const long prow_serial = (long)(((C + 31) / 32 + nchunk - 1) / nchunk) * ((N + 7) / 8);
-    const bool param_row = dx_stream && cfg_prow && N >= 8 && prow_serial <= 64;
-    if (param_row) {}
-    else if (N >= 8) hipLaunchKernelGGL(gn_bwd_param8_kernel, dim3((C + 31) / 32), dim3(256), 0, st, N, C, ncp, dgamma, dbeta, accumulate_params);
-    else hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, st, N, C, ncp, dgamma, dbeta, accumulate_params);
-    if (dx_stream)
-        hipLaunchKernelGGL(gn_bwd_dx_stream_kernel, dim3(nchunk, param_row ? N + 1 : N), dim3(256), 0, st, x, dy, dx, HW, C, ldx, lddy, lddx, cpg, groups, ppb, mean, rstd,
-                           gamma, beta, scale_shift, ld_ss, silu, gsum, accumulate_dx, dx_add, ld_add, dxb_hi, dxb_lo, x2, ld2, C1, dx2, lddx2,
-                           param_row ? N : -1, ncp, dgamma, dbeta, accumulate_params);
-    else if (VEC == 4) hipLaunchKernelGGL(gn_bwd_dx_kernel<4>, dim3(grid_for(total)), dim3(256), 0, st, x, dy, dx, total, HW, C, ldx, lddy, lddx, cpg, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gsum, accumulate_dx, dx_add, ld_add, dxb_hi, dxb_lo, x2, ld2, C1, dx2, lddx2);
-    else hipLaunchKernelGGL(gn_bwd_dx_kernel<1>, dim3(grid_for(total)), dim3(256), 0, st, x, dy, dx, total, HW, C, ldx, lddy, lddx, cpg, groups, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gsum, accumulate_dx, dx_add, ld_add, nullptr, nullptr, x2, ld2, C1, dx2, lddx2);
+    cdae_prof_begin(PROF_GN, (double)N * HW * C * 2.0, st);
+    if (cdae_prof_on()) { char tag[96]; snprintf(tag, sizeof(tag), "cdae_gn_stats16 N=%d HW=%d C=%d", (int)N, (int)HW, (int)C); cdae_prof_tag(tag); }
+    hipLaunchKernelGGL((gn_partial_kernel<4, B>), dim3(nchunk, N), dim3(256), 0, st, (const B*)x1, HW, C, ld1, cpg, groups, ppb, ws, (const B*)x2, ld2, x2 ? C1 : C);
+    hipLaunchKernelGGL((gn_finalize32_kernel<B>), dim3(N), dim3(256), 0, st, (const B*)x1, HW, ld1, cpg, nchunk, eps, ws, mean, rstd, (const B*)x2, ld2, x2 ? C1 : C,
+                       gamma, beta, scale_shift, ld_ss, C, coef);
     cdae_prof_end(PROF_GN, st);
-    CHECK_LAUNCH("gn_bwd launch failed");
+    CHECK_LAUNCH("gn_stats16 launch failed");
+    return 0;
+}
+
+// y = silu?(GroupNorm(x) * (1 + scale) + shift), bf16 rows in (one or two sources), bf16 rows out: in the 16-bit torso the result IS the
+// next conv's operand plane (and the tensor the weight gradient reads back)
+int cdae_gn_apply16(const void* x1, int ld1, const void* x2, int ld2, int C1, void* y, int ldy, int N, int HW, int C, int groups, const float* mean,
+                    const float* rstd, const float* gamma, const float* beta, const float* scale_shift, int ld_ss, int silu, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    typedef __bf16 B;
+    const int cpg = C / groups;
+    if (!(cpg % 4 == 0 && ld1 % 4 == 0 && ldy % 4 == 0 && (!x2 || (ld2 % 4 == 0 && C1 % 4 == 0))) || C / 4 > 256) return cdae_fail("gn_apply16: needs 4-channel vectors, C <= 1024");
+    const int E = C / 4, rows = 256 / E;
+    int nchunk = HW / (rows * 16);
+    if (nchunk < 1) nchunk = 1;
+    while (nchunk > 1 && (long)nchunk * N > 4096) nchunk >>= 1;
+    const int ppb = (HW + nchunk - 1) / nchunk;
+    cdae_prof_begin(PROF_GN, (double)N * HW * C * 4.0, st);
+    if (cdae_prof_on()) { char tag[96]; snprintf(tag, sizeof(tag), "cdae_gn_apply16 N=%d HW=%d C=%d", (int)N, (int)HW, (int)C); cdae_prof_tag(tag); }
+    hipLaunchKernelGGL((gn_apply_kernel<4, false, B>), dim3(nchunk, N), dim3(256), 0, st, (const B*)x1, (B*)y, HW, C, ld1, ldy, cpg, groups, ppb, mean, rstd, gamma, beta,
+                       scale_shift, ld_ss, silu, (unsigned short*)nullptr, (unsigned short*)nullptr, (const B*)x2, ld2, x2 ? C1 : C);
+    cdae_prof_end(PROF_GN, st);
+    CHECK_LAUNCH("gn_apply16 launch failed");
     return 0;
 }
 
@@ -1115,7 +1193,7 @@ int cdae_gn_stats2_coef(const float* x1, int ld1, const float* x2, int ld2, int 
     cdae_prof_begin(PROF_GN, (double)N * HW * C * 4.0, st);
     if (cdae_prof_on()) { char tag[96]; snprintf(tag, sizeof(tag), "cdae_gn_stats2 N=%d HW=%d C=%d", (int)N, (int)HW, (int)C); cdae_prof_tag(tag); }
     hipLaunchKernelGGL(gn_partial_kernel<4>, dim3(nchunk, N), dim3(256), 0, st, x1, HW, C, ld1, cpg, groups, ppb, ws, x2, ld2, C1);
-    if (groups == 32) hipLaunchKernelGGL(gn_finalize32_kernel, dim3(N), dim3(256), 0, st, x1, HW, ld1, cpg, nchunk, eps, ws, mean, rstd, x2, ld2, C1, gamma, beta,
+    if (groups == 32) hipLaunchKernelGGL((gn_finalize32_kernel<float>), dim3(N), dim3(256), 0, st, x1, HW, ld1, cpg, nchunk, eps, ws, mean, rstd, x2, ld2, C1, gamma, beta,
                                          scale_shift, ld_ss, C, coef);
     else hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(groups < 64 ? 64 : groups), 0, st, x1, HW, ld1, cpg, groups, nchunk, eps, ws, mean, rstd, x2, ld2, C1);
     cdae_prof_end(PROF_GN, st);

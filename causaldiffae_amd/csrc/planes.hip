@@ -216,11 +216,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void ps_kernel(const GemmPa
                 }
                 if (Rg) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) rv[r] = Rg[ad[r]];
+                    for (int r = 0; r < 16; ++r) rv[r] = NPL == 1 ? cdae_load_res(p, Rg, ad[r]) : Rg[ad[r]];
                 }
                 if (p.accumulate) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) cv[r] = Cg[ad[r]];
+                    for (int r = 0; r < 16; ++r) cv[r] = NPL == 1 ? cdae_load_c(p, Cg, ad[r]) : Cg[ad[r]];
                 }
             }
 #pragma unroll
@@ -234,7 +234,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void ps_kernel(const GemmPa
                 if (p.act == ACT_SILU) v = cdae_silu(v);
                 else if (p.act == ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
                 if (p.accumulate) v += cv[r];
-                Cg[addr] = v;
+                if constexpr (NPL == 1) { v = cdae_round_c(p, v); cdae_store_c(p, Cg, addr, v); }
+                else Cg[addr] = v;
                 if (!__builtin_isfinite(v) && p.range_flag) *p.range_flag = 1;
                 if (p.C_hi) store_planes(p, addr, v);
                 gs += v; gq += v * v;
@@ -495,11 +496,12 @@ __global__ __launch_bounds__(BM / 64 * WAVES_N * 64, BM / 64 * WAVES_N * 2 / 4) 
                     addr = (4L * row - 2 * x + p.ph_y * 2 * p.Wo + p.ph_x) * p.ldc + col;
                 } else addr = (long)row * p.ldc + col;
                 float v = acc[i][j][r] * alpha_ + bv;
-                if (Rg) v += Rg[addr];
+                if (Rg) v += NPL == 1 ? cdae_load_res(p, Rg, addr) : Rg[addr];
                 if (p.act == ACT_SILU) v = cdae_silu(v);
                 else if (p.act == ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
-                if (p.accumulate) v += Cg[addr];
-                Cg[addr] = v;
+                if (p.accumulate) v += NPL == 1 ? cdae_load_c(p, Cg, addr) : Cg[addr];
+                if constexpr (NPL == 1) { v = cdae_round_c(p, v); cdae_store_c(p, Cg, addr, v); }
+                else Cg[addr] = v;
                 if (!__builtin_isfinite(v) && p.range_flag) *p.range_flag = 1;
                 if (p.C_hi) store_planes(p, addr, v);
                 gs += v; gq += v * v;

@@ -658,6 +658,9 @@ _TRAIN_CAT_ON = True      # path toggle (tests only, see PATH TOGGLES below): Fa
 
 
 def cat_channels(a, b):
+    if a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 4:      # the 16-bit torso: read in place by ops16's ResBlock node
+        from .ops16 import rows16
+        return CatAct(rows16(a), rows16(b))
     if presplit_ok() and a.dim() == 4 and a.shape[1] % 4 == 0 and b.shape[1] % 4 == 0:
         return CatAct(to_nhwc(a), to_nhwc(b))
     if (_TRAIN_CAT_ON and _TRAIN_PS_ON and _RBNODE_ON and torch.is_grad_enabled() and (a.requires_grad or b.requires_grad) and a.dim() == 4 and a.shape[1] % 32 == 0 and b.shape[1] % 32 == 0
@@ -1114,7 +1117,7 @@ class ConvWeightBank:
             self.where[id(w)] = (o - self.base, w.numel())
         self.tiles = tiles
         self.desc = torch.from_numpy(desc.view(np.uint8).copy()).to(dev)
-        self.epoch, self.versions, self._ptrs, self.scale_gen = None, {}, {}, None
+        self.epoch, self.versions, self._ptrs, self.scale_gen, self.m16 = None, {}, {}, None, None
         for w in self.weights:
             _BANK_OF[id(w)] = (weakref.ref(w), self)
 
@@ -1124,14 +1127,18 @@ class ConvWeightBank:
         # refresh of the shared table) are stale whatever the weight's own version says — the kernels unscale with the CURRENT record
         if self.scales is not None:
             self.scales.refresh(w)
-        if (self.epoch != _WEIGHT_EPOCH[0] or self.versions.get(id(w)) != w._version
+        # the 16-bit torso (mixed16) reads ONE plane per operand: the lo planes of the bf16 dgrad weights then carry the bf16 FORWARD weights
+        # (OHWI at b16[1], K-group-major at kb16[1]); a mode change rebuilds the planes
+        m16 = self.kpack and _TORSO16_ON and lib.cdae_get_default_precision() == 2
+        if (self.epoch != _WEIGHT_EPOCH[0] or self.versions.get(id(w)) != w._version or self.m16 != m16
                 or (self.scales is not None and self.scale_gen != self.scales.generation)):
             k = self.kpack
-            check(lib.cdae_wprep_all_k(ptr(self.flat), ptr(self.desc), len(self.weights), self.tiles, self.base, ptr(self.f16[0]), ptr(self.f16[1]),
-                                       ptr(self.b16[0]), ptr(self.b16[1]), ptr(self.kf16[0]) if k else None, ptr(self.kf16[1]) if k else None,
-                                       ptr(self.kb16[0]) if k else None, ptr(self.kb16[1]) if k else None,
-                                       ptr(self.scales.records) if self.scales is not None else None, stream()))
-            self.epoch, self.versions = _WEIGHT_EPOCH[0], {id(x): x._version for x in self.weights}
+            prep = lib.cdae_wprep_all_m16 if m16 else lib.cdae_wprep_all_k
+            check(prep(ptr(self.flat), ptr(self.desc), len(self.weights), self.tiles, self.base, ptr(self.f16[0]), ptr(self.f16[1]),
+                       ptr(self.b16[0]), ptr(self.b16[1]), ptr(self.kf16[0]) if k else None, ptr(self.kf16[1]) if k else None,
+                       ptr(self.kb16[0]) if k else None, ptr(self.kb16[1]) if k else None,
+                       ptr(self.scales.records) if self.scales is not None else None, stream()))
+            self.epoch, self.versions, self.m16 = _WEIGHT_EPOCH[0], {id(x): x._version for x in self.weights}, m16
             self.scale_gen = self.scales.generation if self.scales is not None else None
 
     def planes(self, w, bf16):
@@ -1164,6 +1171,18 @@ class ConvWeightBank:
             self._ptrs[key] = hit
         return hit
 
+    def pointers16(self, w):
+        """(forward OHWI, forward K-group-major | None, dgrad [Cin][9][Cout], dgrad K-group-major | None) bf16 plane pointers of a
+        registered weight for the 16-bit torso (mixed16 mode: _refresh wrote the forward planes into the lo slots)"""
+        self._refresh(w)
+        assert self.m16, "pointers16: the 16-bit torso needs the mixed16 precision mode"
+        o, _ = self.where[id(w)]
+        f = self.b16.data_ptr() + 2 * self.b16.stride(0) + 2 * o
+        d = self.b16.data_ptr() + 2 * o
+        if id(w) in self.packable:
+            return f, self.kb16.data_ptr() + 2 * self.kb16.stride(0) + 2 * o, d, self.kb16.data_ptr() + 2 * o
+        return f, None, d, None
+
     def packed(self, w, bf16):
         """K-group-major planes (cdae_conv_wpack's order), or (None, None) for a weight whose channel counts are not multiples of 16"""
         if id(w) not in self.packable:
@@ -1176,6 +1195,63 @@ class ConvWeightBank:
 
 _BANK_OF = {}
 _WEIGHT_BANK_ON = True
+_TORSO16_ON = True      # path toggle: False = the mixed16 mode keeps fp32 activation storage (single-plane products only, the round-3 torso)
+
+# ---- bf16 image of a whole flat parameter buffer (train_util.FlatParams): the 1x1 / linear weights of the 16-bit torso are views of it
+_FLAT16 = []
+
+
+def register_flat16(flat):
+    """Called by train_util.FlatParams: weights that are views of `flat` get their bf16 copy from ONE cast of the buffer per weight version."""
+    _FLAT16[:] = [e for e in _FLAT16 if e["ref"]() is not None]
+    _FLAT16.append(dict(ref=weakref.ref(flat), img=None, epoch=None, versions={}))
+
+
+def flat16_pointer(w):
+    """device pointer of the bf16 copy of `w` inside its flat buffer's bf16 image, or None (not a view of a registered buffer)"""
+    if not _FLAT16:
+        return None
+    sp = w.untyped_storage().data_ptr()
+    for e in _FLAT16:
+        flat = e["ref"]()
+        if flat is None or flat.untyped_storage().data_ptr() != sp or not w.is_contiguous():
+            continue
+        if e["epoch"] != _WEIGHT_EPOCH[0] or e["versions"].get(id(w), w._version) != w._version:
+            if e["img"] is None:
+                e["img"] = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device)
+            n4 = flat.numel() // 4 * 4
+            check(lib.cdae_cast_f32_bf16(ptr(flat), ptr(e["img"]), n4, stream()))
+            if n4 < flat.numel():
+                e["img"][n4:].copy_(flat[n4:])
+            e["epoch"], e["versions"] = _WEIGHT_EPOCH[0], {}
+        e["versions"][id(w)] = w._version
+        return e["img"].data_ptr() + (w.data_ptr() - flat.data_ptr()) // 2
+    return None
+
+
+_CONV16 = {}
+
+
+def conv_planes16(w):
+    """pointers16 of a conv3x3 weight (OHWI storage) that is not in a bank: built per weight version from the existing plane helpers"""
+    tag = (w.data_ptr(), w._version, _WEIGHT_EPOCH[0])
+    hit = _CONV16.get(id(w))
+    if hit is None or hit[0]() is not w or hit[1] != tag:
+        Cout, Cin = w.shape[0], w.shape[1]
+        fwd = w.detach().permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).reshape(-1)
+        d_hi, _ = dgrad_weight(w)
+        fk = dk = None
+        if Cout % 16 == 0 and Cin % 16 == 0:
+            fk = torch.empty((2, w.numel()), dtype=torch.bfloat16, device=w.device)
+            check(lib.cdae_conv_wpack(ptr(fwd), ptr(fwd), *ptr2(fk), Cout, 9, Cin, stream()))
+            dk = torch.empty((2, w.numel()), dtype=torch.bfloat16, device=w.device)
+            check(lib.cdae_conv_wpack(ptr(d_hi), ptr(d_hi), *ptr2(dk), Cin, 9, Cout, stream()))
+        if len(_CONV16) > 1024:
+            for k in [k for k, v in _CONV16.items() if v[0]() is None]:
+                del _CONV16[k]
+        hit = _CONV16[id(w)] = (weakref.ref(w), tag, fwd, fk, d_hi, dk)
+    _, _, fwd, fk, d_hi, dk = hit
+    return fwd.data_ptr(), (None if fk is None else fk.data_ptr()), d_hi.data_ptr(), (None if dk is None else dk.data_ptr())
 
 
 def register_conv_bank(flat, params):
@@ -2108,7 +2184,7 @@ PATH_TOGGLES = {"skipgn_v2": "_SKIPGN_V2", "skip_gn": "_SKIPGN_ON", "stream_gemm
                 "linear_gn": "_LINEAR_GN", "fused_attn": "_FUSED_ATTN_ON", "fused_attn_train": "_FUSED_ATTN_TRAIN", "kpack": "_KPACK_ON",
                 "presplit": "_PRESPLIT_ON", "train_presplit": "_TRAIN_PS_ON", "train_rbnode": "_RBNODE_ON", "train_gnparts": "_RB_PARTS_ON",
                 "train_emball": "_EMBALL_ON", "train_cat": "_TRAIN_CAT_ON", "weight_bank": "_WEIGHT_BANK_ON", "wscale": "_WSCALE_ON",
-                "s2_dgrad_ps": "_S2DGRAD_ON", "dgrad_stream": "_DGRAD_STREAM_ON", "wgrad_stream": "_WGRAD_SIDE_ON"}
+                "s2_dgrad_ps": "_S2DGRAD_ON", "dgrad_stream": "_DGRAD_STREAM_ON", "wgrad_stream": "_WGRAD_SIDE_ON", "torso16": "_TORSO16_ON"}
 
 
 class path_scope:

@@ -70,6 +70,8 @@ class FlatParams:
         # planes of the 3x3 convs (which consume their records)
         self.scale_table = ops.register_scale_table(self.flat, self.params + ([emb_w] if emb_w is not None else [])) if dev.type == "cuda" else None
         self.conv_bank = ops.register_conv_bank(self.flat, self.params) if dev.type == "cuda" else None
+        if dev.type == "cuda":
+            ops.register_flat16(self.flat)          # the 16-bit torso's 1x1 / linear weights: one bf16 image of the buffer per weight version
 
     def zero_grad(self):
         self.grad.zero_()

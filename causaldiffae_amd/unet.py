@@ -22,7 +22,7 @@ from abc import abstractmethod
 import torch as th
 import torch.nn as nn
 
-from . import ops
+from . import ops, ops16
 from .nn import (
     CausalModeling,
     ConvNd,
@@ -96,6 +96,10 @@ class Upsample(nn.Module):
 
     def forward(self, x):
         assert x.shape[1] == self.channels
+        if x.dtype == th.bfloat16:             # the 16-bit torso
+            if ops16.upconv_ok(x, self.channels):
+                return ops16.upconv_train(x, self.conv.weight, self.conv.bias)
+            return ops16.to16(self.forward(ops16.to32(x)))
         xs = getattr(x, "_split", None)        # pre-split planes left by the producing kernel (inference): sub-pixel form
         if xs is not None and ops.presplit_ok():
             return self.conv(xs, up=True, gn_stats=True)
@@ -114,6 +118,8 @@ class Downsample(nn.Module):
 
     def forward(self, x):
         assert x.shape[1] == self.channels
+        if x.dtype == th.bfloat16:             # the 16-bit torso: the three stride-2 convs run the fp32-operand kernels between two casts
+            return ops16.to16(self.op(ops16.to32(x)))
         xs = getattr(x, "_split", None)
         if xs is not None and ops.presplit_ok():
             return self.op(xs, gn_stats=True)
@@ -170,7 +176,24 @@ class ResBlock(TimestepBlock):
             return ops.gn_conv3x3(h, n2.weight, n2.bias, emb_out, c2.weight, c2.bias, skip, True, n2.num_groups, n2.eps)
         return ops.gn_conv3x3(h + emb_out[:, :, None, None], n2.weight, n2.bias, None, c2.weight, c2.bias, skip, True, n2.num_groups, n2.eps)
 
+    def _forward16(self, x, emb):
+        """bf16 residual stream (ops16): the whole block as one node where the 16-bit kernels take the shape, else the fp32-storage
+        path between two casts (the 4 x 4 level)"""
+        n1, c1, n2, c2 = self.in_layers[0], self.in_layers[2], self.out_layers[0], self.out_layers[3]
+        sk = self.skip_connection
+        cat = isinstance(x, ops.CatAct)
+        if (self.use_scale_shift_norm and (self.dropout == 0 or not self.training) and (isinstance(sk, Identity) or sk.kernel_size == 1)
+                and not (cat and isinstance(sk, Identity)) and ops16.resblock_ok(x, c1.out_channels, n1.num_groups)):
+            emb_out = emb.slices[id(self)] if isinstance(emb, EmbAll) else self.emb_layers[1](ops.silu(emb))
+            one = isinstance(sk, Identity)
+            return ops16.resblock_train(x, emb_out, n1.weight, n1.bias, c1.weight, c1.bias, n2.weight, n2.bias, c2.weight, c2.bias,
+                                        None if one else sk.weight, None if one else sk.bias, n1.num_groups, n1.eps)
+        x32 = ops16.to32(th.cat([x.a, x.b], dim=1).contiguous(memory_format=th.channels_last)) if cat else ops16.to32(x)
+        return ops16.to16(self._forward(x32, emb))
+
     def _forward(self, x, emb):
+        if (x.a if isinstance(x, ops.CatAct) else x).dtype == th.bfloat16:
+            return self._forward16(x, emb)
         if th.is_grad_enabled():
             if self._train_fused(x):
                 return self._forward_train(x, emb)
@@ -230,6 +253,10 @@ class AttentionBlock(nn.Module):
         return checkpoint(self._forward, (x,), self.parameters(), self.use_checkpoint)
 
     def _forward(self, x):
+        if x.dtype == th.bfloat16:             # the 16-bit torso: the block as one node on the bf16 residual stream
+            if ops16.attn_ok(x, self.num_heads):
+                return ops16.attention_block(x, self.norm, self.qkv, self.proj_out, self.num_heads)
+            return ops16.to16(self._forward(ops16.to32(x)))
         x = ops.to_nhwc(x)
         N, C, H, W = x.shape
         T = H * W
@@ -451,11 +478,16 @@ class UNetModel(nn.Module):
             emb = EmbAll(emb, ops.emb_all_train(emb, self._emb_flat))      # one GEMM for the 22 emb_layers, fwd and bwd
         hs = []
         h = x.float()
-        for module in self.input_blocks:
+        t16 = ops16.torso16_on() and h.is_cuda     # convert_to_fp16 (reference unet.py:501-507): bf16 activations from the input conv to the head
+        for i, module in enumerate(self.input_blocks):
             h = module(h, emb)
+            if t16 and i == 0:
+                h = ops16.to16(h)
             hs.append(h)
         h = self.middle_block(h, emb)
         for module in self.output_blocks:
             h = module(ops.cat_channels(h, hs.pop()), emb)
+        if t16:
+            h = ops16.to32(h)                      # the output head normalises and convolves in fp32 (reference unet.py:630 h.type(x.dtype))
         h = self.out[0](h, silu=True, split=True, coef=True)
         return self.out[2](h, out_nchw=True), mu, var, z_post, mask

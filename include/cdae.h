@@ -457,6 +457,40 @@ enum { CDAE_TUNE_CONVWIN_MIN_TILES = 0, CDAE_TUNE_CONVWIN_SPLITK = 1, CDAE_TUNE_
 int cdae_tune_set(int key, int value);
 int cdae_tune_get(int key);       /* -1: unknown key */
 
+/* ---- the 16-bit torso (reference unet.py:501-507 convert_to_fp16, fp16_util.py:9-15; GroupNorm32 computes in fp32, nn.py:435-437):
+   activations and gradients are bf16 NHWC rows (void*), accumulation and statistics fp32.  `io` bits: 1 the result is bf16, 2 the
+   residual is bf16, 4 / 8 the A / B operand of an fp32-operand entry point is bf16. */
+int cdae_conv3x3_fwd16(const void* x16, long sn, long sy, long sx, const void* w16, const void* wk16, const float* bias, const void* res16, void* out16,
+                       long ldo, float* gn_part, int N, int H, int W, int Cin, int Cout, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
+int cdae_conv3x3_dgrad16(const void* dy16, const void* wt16, const void* wtk16, void* dx16, long lddx, int N, int H, int W, int Cin, int Cout,
+                         float* splitk_ws, size_t splitk_ws_bytes, void* stream);
+int cdae_gemm16_ps(const void* a16, long lda, const void* b16, long ldb, const float* bias, const void* res, void* c, long ldc, float* gn_part, int M, int N,
+                   int K, int io, int accumulate, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
+int cdae_linear_fwd_io(const float* x, long ldx, const float* w, long ldw, const float* w_scale, const float* bias, const void* res, void* y, long ldy,
+                       int M, int N, int K, int io, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
+int cdae_linear_dgrad_io(const float* dy, long lddy, const float* w, long ldw, void* dx, long lddx, int M, int N, int K, int io,
+                         float* splitk_ws, size_t splitk_ws_bytes, void* stream);
+int cdae_linear_wgrad_io(const void* x, long ldx, const void* dy, long lddy, float* dw, long lddw, float* dbias, int M, int N, int K, int io,
+                         int accumulate, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
+/* GroupNorm32 on bf16 rows (one or two sources = a channel concatenation read in place): statistics (+ the folded (a, b) table), apply
+   (+ scale-shift, + SiLU) to bf16 rows, backward (dx / dx2 bf16, parameter and scale-shift gradients fp32) */
+int cdae_gn_stats16(const void* x1, int ld1, const void* x2, int ld2, int C1, int N, int HW, int C, int groups, float eps, float* mean, float* rstd,
+                    const float* gamma, const float* beta, const float* scale_shift, int ld_ss, float* coef, float* ws, void* stream);
+int cdae_gn_apply16(const void* x1, int ld1, const void* x2, int ld2, int C1, void* y, int ldy, int N, int HW, int C, int groups, const float* mean,
+                    const float* rstd, const float* gamma, const float* beta, const float* scale_shift, int ld_ss, int silu, void* stream);
+int cdae_gn_bwd16(const void* x, int ldx, const void* x2, int ld2, int C1, const void* dy, int lddy, void* dx, int lddx, void* dx2, int lddx2,
+                  int N, int HW, int C, int groups, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                  const float* scale_shift, int ld_ss, int silu, float* dgamma, float* dbeta, int accumulate_params, float* d_scale_shift,
+                  int ld_dss, int accumulate_dx, const void* dx_add, int ld_add, float* ws, void* stream);
+int cdae_gn_parts16(const void* x, long ldx, float* parts, long M, int C, void* stream);      /* [ceil(M / 32)][C][2] sums of a bf16 tensor */
+int cdae_cast_f32_bf16(const float* x, void* y, long n, void* stream);
+int cdae_cast_bf16_f32(const void* x, float* y, long n, void* stream);
+int cdae_upsample2_16(const void* x, void* y, int N, int H, int W, int C, void* stream);       /* nearest 2x of bf16 NHWC rows (unet.py:76-78) */
+int cdae_sumpool2_16(const void* src, void* dst, int N, int H, int W, int C, void* stream);    /* its gradient: 2x2 sum pool */
+int cdae_wprep_all_m16(const float* flat, const void* desc, int nw, int total_tiles, long base, unsigned short* f_hi, unsigned short* f_lo,
+                       unsigned short* b_hi, unsigned short* b_lo, unsigned short* kf_hi, unsigned short* kf_lo, unsigned short* kb_hi,
+                       unsigned short* kb_lo, const float* w_scales, void* stream);
+
 /* ---- opt-in profiler (prof.hip): HIP events on the launch stream around every launch of a kernel family */
 int cdae_prof_enable(int on);
 /* per family since the last read: milliseconds, flops (2MNK as executed), algorithmic bytes (convwin: each operand and the result once), launches */

@@ -1,0 +1,234 @@
+"""The 16-bit torso (causaldiffae_amd/ops16.py; reference unet.py:501-507 convert_to_fp16, fp16_util.py:9-15, nn.py:435-437):
+bf16 activations / gradients between the layers, fp32 GroupNorm statistics, fp32 master weights and weight gradients.  Checked against
+float64 torch restatements of the reference modules at bf16's own bar (activations carry 8 significand bits: 2e-2 of each tensor's
+scale), and the full-model loss against the fp32-storage product path and the reference's G15 loss curve."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-30)
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).double()
+
+
+@pytest.fixture
+def mixed16():
+    import causaldiffae_amd
+    old = causaldiffae_amd.get_precision()
+    causaldiffae_amd.set_precision("mixed16")
+    yield
+    causaldiffae_amd.set_precision(old)
+
+
+def test_gn16_kernels_match_float64(mixed16):
+    """cdae_gn_stats16 / cdae_gn_apply16 / cdae_gn_bwd16 on bf16 rows (two sources, scale-shift, SiLU, residual add) against float64
+    autograd of the same bf16-rounded inputs: outputs to bf16 rounding (4e-3 of the tensor scale), parameter gradients to 2e-3."""
+    from causaldiffae_amd import ops16
+    from causaldiffae_amd._lib import check, lib, ptr, ptr2, stream, workspace
+    g = torch.Generator().manual_seed(0)
+    N, C1, C2, H, W, G = 3, 64, 64, 8, 8, 32
+    C = C1 + C2
+    x1 = (torch.randn(N, H, W, C1, generator=g) * 1.5 + 0.3).to(torch.bfloat16)
+    x2 = (torch.randn(N, H, W, C2, generator=g) * 0.7 - 0.2).to(torch.bfloat16)
+    gamma, beta = torch.randn(C, generator=g) * 0.5 + 1.0, torch.randn(C, generator=g) * 0.2
+    ss = torch.randn(N, 2 * C, generator=g) * 0.3
+    dy = (torch.randn(N, H, W, C, generator=g)).to(torch.bfloat16)
+    add1 = torch.randn(N, H, W, C1, generator=g).to(torch.bfloat16)
+    # float64 reference
+    xr = torch.cat([x1, x2], dim=-1).double().requires_grad_(True)
+    gr, br, sr = gamma.double().requires_grad_(True), beta.double().requires_grad_(True), ss.double().requires_grad_(True)
+    h = F.group_norm(xr.permute(0, 3, 1, 2), G, gr, br, 1e-5).permute(0, 2, 3, 1)
+    y = F.silu(h * (1 + sr[:, None, None, :C]) + sr[:, None, None, C:])
+    y.backward(dy.double())
+    d = lambda t: t.to(DEV)
+    x1d, x2d, dyd = d(x1), d(x2), d(dy)
+    st = stream()
+    stats = torch.empty((2, N, G), dtype=torch.float32, device=DEV)
+    gws = workspace(torch.device(DEV), "gn", 4 * lib.cdae_gn_workspace_floats(N, C))
+    check(lib.cdae_gn_stats16(ptr(x1d), C1, ptr(x2d), C2, C1, N, H * W, C, G, 1e-5, *ptr2(stats), None, None, None, 0, None, ptr(gws), st))
+    yd = torch.empty((N, H, W, C), dtype=torch.bfloat16, device=DEV)
+    gd, bd, sd = d(gamma), d(beta), d(ss)
+    check(lib.cdae_gn_apply16(ptr(x1d), C1, ptr(x2d), C2, C1, ptr(yd), C, N, H * W, C, G, *ptr2(stats), ptr(gd), ptr(bd), ptr(sd), 2 * C, 1, st))
+    assert _rel(yd, y) < 6e-3
+    dx1 = d(add1).clone()                                    # accumulate_dx: starts from an existing gradient
+    dx2 = torch.zeros((N, H, W, C2), dtype=torch.bfloat16, device=DEV)
+    dgamma, dbeta = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dss = torch.empty((N, 2 * C), device=DEV)
+    check(lib.cdae_gn_bwd16(ptr(x1d), C1, ptr(x2d), C2, C1, ptr(dyd), C, ptr(dx1), C1, ptr(dx2), C2, N, H * W, C, G, *ptr2(stats), ptr(gd), ptr(bd),
+                            ptr(sd), 2 * C, 1, ptr(dgamma), ptr(dbeta), 0, ptr(dss), 2 * C, 1, None, C, ptr(gws), st))
+    want1 = xr.grad[..., :C1] + add1.double()
+    assert _rel(dx1, want1) < 8e-3 and _rel(dx2, xr.grad[..., C1:]) < 8e-3
+    assert _rel(dgamma, gr.grad) < 2e-3 and _rel(dbeta, br.grad) < 2e-3 and _rel(dss, sr.grad) < 2e-3
+
+
+@pytest.mark.parametrize("shape", [(4, 256, 128, 16, True), (2, 128, 256, 32, False), (2, 128, 128, 8, False)])
+def test_resblock16_against_float64(mixed16, shape):
+    """ops16.resblock_train (identity / 1x1 skip, two-source input) against a float64 restatement of the reference ResBlock
+    (unet.py:156-199) on the same bf16-rounded input: output, input gradients and every parameter gradient to bf16's bar."""
+    from causaldiffae_amd import ops, ops16
+    N, C, Cout, HW, cat = shape
+    H = W = HW
+    g = torch.Generator().manual_seed(1)
+    C1 = C // 2 if cat else C
+    x = (torch.randn(N, C, H, W, generator=g)).to(torch.bfloat16)
+    P = dict(g1=torch.randn(C, generator=g) * 0.3 + 1, b1=torch.randn(C, generator=g) * 0.1,
+             w1=torch.randn(Cout, C, 3, 3, generator=g) * (1.0 / (9 * C)) ** 0.5, c1b=torch.randn(Cout, generator=g) * 0.1,
+             g2=torch.randn(Cout, generator=g) * 0.3 + 1, b2=torch.randn(Cout, generator=g) * 0.1,
+             w2=torch.randn(Cout, Cout, 3, 3, generator=g) * (1.0 / (9 * Cout)) ** 0.5, c2b=torch.randn(Cout, generator=g) * 0.1)
+    if C != Cout or cat:
+        P["sw"], P["sb"] = torch.randn(Cout, C, generator=g) * (1.0 / C) ** 0.5, torch.randn(Cout, generator=g) * 0.1
+    ss = torch.randn(N, 2 * Cout, generator=g) * 0.3
+    dout = torch.randn(N, Cout, H, W, generator=g).to(torch.bfloat16)
+    # reference
+    R = {k: v.double().requires_grad_(True) for k, v in P.items()}
+    xr, sr = x.double().requires_grad_(True), ss.double().requires_grad_(True)
+    h = F.conv2d(F.silu(F.group_norm(xr, 32, R["g1"], R["b1"], 1e-5)), R["w1"], R["c1b"], padding=1)
+    h2 = F.group_norm(h, 32, R["g2"], R["b2"], 1e-5) * (1 + sr[:, :Cout, None, None]) + sr[:, Cout:, None, None]
+    skip = xr if "sw" not in R else F.conv2d(xr, R["sw"][:, :, None, None], R["sb"])
+    out = F.conv2d(F.silu(h2), R["w2"], R["c2b"], padding=1) + skip
+    out.backward(dout.double())
+    # product
+    D = {k: v.to(DEV) for k, v in P.items()}
+    for k in ("w1", "w2"):
+        D[k] = D[k].contiguous(memory_format=torch.channels_last)
+    D = {k: v.requires_grad_(True) for k, v in D.items()}
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    sd = ss.to(DEV).requires_grad_(True)
+    if cat:
+        xa, xb = xd[:, :C1].contiguous(memory_format=torch.channels_last).detach().requires_grad_(True), xd[:, C1:].contiguous(memory_format=torch.channels_last).detach().requires_grad_(True)
+        xin = ops.CatAct(ops16.rows16(xa), ops16.rows16(xb))
+    else:
+        xin = xd
+    o = ops16.resblock_train(xin, sd, D["g1"], D["b1"], D["w1"], D["c1b"], D["g2"], D["b2"], D["w2"], D["c2b"], D.get("sw"), D.get("sb"))
+    assert o.dtype == torch.bfloat16 and _rel(o, out) < 1.5e-2
+    o.backward(dout.to(DEV))
+    ops.side_join()
+    torch.cuda.synchronize()
+    gx = torch.cat([xa.grad, xb.grad], dim=1) if cat else xd.grad
+    assert _rel(gx, xr.grad) < 3e-2, _rel(gx, xr.grad)
+    assert _rel(sd.grad, sr.grad) < 2e-2
+    for k in P:
+        got = D[k].grad
+        want = R[k].grad
+        assert got is not None, k
+        assert _rel(got.reshape(want.shape), want) < 2.5e-2, (k, _rel(got.reshape(want.shape), want))
+
+
+def test_attention_block16_and_upconv16_against_float64(mixed16):
+    """ops16.attention_block (reference unet.py:223-253) and ops16.upconv_train (unet.py:86-104) against float64 restatements."""
+    from causaldiffae_amd import ops, ops16
+    from causaldiffae_amd.nn import conv_nd, normalization
+    g = torch.Generator().manual_seed(2)
+    N, C, H, W, heads = 2, 128, 8, 8, 4
+    norm, qkv, proj = normalization(C), conv_nd(1, C, 3 * C, 1), conv_nd(1, C, C, 1)
+    with torch.no_grad():
+        for p in list(norm.parameters()) + list(qkv.parameters()) + list(proj.parameters()):
+            p.copy_(torch.randn(p.shape, generator=g) * (0.3 if p.dim() == 1 else (1.0 / C) ** 0.5))
+        norm.weight.add_(1.0)
+    ref = [p.detach().double().clone().requires_grad_(True) for p in (norm.weight, norm.bias, qkv.weight, qkv.bias, proj.weight, proj.bias)]
+    x = torch.randn(N, C, H, W, generator=g).to(torch.bfloat16)
+    dout = torch.randn(N, C, H, W, generator=g).to(torch.bfloat16)
+    xr = x.double().requires_grad_(True)
+    T, ch = H * W, C // heads
+    hN = F.group_norm(xr, 32, ref[0], ref[1], 1e-5).reshape(N, C, T)
+    q_ = F.conv1d(hN, ref[2], ref[3]).reshape(N * heads, 3 * ch, T)
+    q, k, v = q_.split(ch, dim=1)
+    sc = 1 / ch ** 0.25
+    wgt = torch.softmax(torch.einsum("bct,bcs->bts", q * sc, k * sc), dim=-1)
+    a = torch.einsum("bts,bcs->bct", wgt, v).reshape(N, C, T)
+    out = (xr.reshape(N, C, T) + F.conv1d(a, ref[4], ref[5])).reshape(N, C, H, W)
+    out.backward(dout.double())
+    for m in (norm, qkv, proj):
+        m.to(DEV)
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    o = ops16.attention_block(xd, norm, qkv, proj, heads)
+    assert o.dtype == torch.bfloat16 and _rel(o, out) < 1.5e-2
+    o.backward(dout.to(DEV))
+    ops.side_join()
+    assert _rel(xd.grad, xr.grad) < 3e-2
+    for got, want in zip((norm.weight, norm.bias, qkv.weight, qkv.bias, proj.weight, proj.bias), ref):
+        assert _rel(got.grad.reshape(want.shape), want.grad) < 2.5e-2
+    # up-conv
+    C, Co = 64, 64
+    w = (torch.randn(Co, C, 3, 3, generator=g) * (1.0 / (9 * C)) ** 0.5)
+    b = torch.randn(Co, generator=g) * 0.1
+    x = torch.randn(4, C, 8, 8, generator=g).to(torch.bfloat16)
+    dout = torch.randn(4, Co, 16, 16, generator=g).to(torch.bfloat16)
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    out = F.conv2d(F.interpolate(xr, scale_factor=2, mode="nearest"), wr, br, padding=1)
+    out.backward(dout.double())
+    wd = w.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    bd = b.to(DEV).requires_grad_(True)
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    assert ops16.upconv_ok(xd, Co)
+    o = ops16.upconv_train(xd, wd, bd)
+    assert _rel(o, out) < 1.5e-2
+    o.backward(dout.to(DEV))
+    ops.side_join()
+    assert _rel(xd.grad, xr.grad) < 2e-2 and _rel(wd.grad, wr.grad) < 2e-2 and _rel(bd.grad, br.grad) < 2e-2
+
+
+def test_full_model_step_on_the_16bit_torso_matches_fp32_storage():
+    """One training_losses + backward of the M32 model (BASELINE config [1]'s architecture) with convert_to_fp16(): the 16-bit torso against
+    the same model in the parity mode — loss within 2e-2, every large gradient tensor within 8e-2 of its own scale and well
+    correlated; and with the torso toggled off (fp32 storage, one-plane products: the round-3 behaviour) the same bar holds."""
+    import bench
+    from causaldiffae_amd import ops
+    from improved_diffusion import script_util as su
+    from improved_diffusion.train_util import TrainLoop
+    dev = torch.device(DEV)
+    g = torch.Generator().manual_seed(5)
+    N = 8
+    x0 = torch.rand(N, 1, 32, 32, generator=g) * 2 - 1
+    cond = {"c": torch.rand(N, 2, generator=g), "y": torch.randint(0, 10, (N,), generator=g)}
+    t = torch.randint(0, 1000, (N,), generator=g)
+    noise = torch.randn(N, 1, 32, 32, generator=g)
+
+    def run(fp16, torso=True):
+        cfg = {**su.model_and_diffusion_defaults(), "image_size": 32, "in_channels": 1, "n_vars": 2, "rep_cond": True, "causal_modeling": True,
+               "class_cond": True}
+        model, diff = su.create_model_and_diffusion(**cfg)
+        bench.randomize(model, 4321)
+        model.to(dev).train()
+        loop = TrainLoop(model=model, diffusion=diff, data=iter(()), batch_size=N, microbatch=-1, lr=1e-4, ema_rate="0.9999", log_interval=10 ** 9,
+                         save_interval=10 ** 9, resume_checkpoint="", rep_cond=True, n_vars=2, causal_modeling=True, in_channels=1, use_fp16=fp16)
+        diff.kl_weight = 0.1
+        from causaldiffae_amd._lib import precision_scope
+        with ops.path_scope(torso16=torso), precision_scope(getattr(model, "_cdae_precision", None)):
+            loop.opt.zero_grad()
+            torch.manual_seed(9)
+            losses = diff.training_losses(model, x0.to(dev), t.to(dev), model_kwargs={k: v.to(dev) for k, v in cond.items()}, noise=noise.to(dev),
+                                          rep_cond=True, causal_modeling=True)
+            losses["loss"].mean().backward()
+            ops.side_join()
+        torch.cuda.synchronize()
+        f = loop.opt.flat
+        return losses["loss"].mean().item(), {n: f.grad[o:o + p.numel()].clone() for n, p, o in zip(f.names, f.params, f.offsets)}
+
+    l32, g32 = run(False)
+    for torso in (True, False):
+        l16, g16 = run(True, torso)
+        assert abs(l16 - l32) < 2e-2 * abs(l32), (torso, l16, l32)
+        worst = []
+        for n in g32:
+            a, b = g16[n].double(), g32[n].double()
+            if b.numel() < 4096 or b.abs().max().item() == 0.0:
+                continue
+            rel = (a - b).abs().max().item() / b.abs().max().item()
+            cos = (a * b).sum().item() / (a.norm().item() * b.norm().item() + 1e-30)
+            worst.append((rel, cos, n))
+        assert max(w[0] for w in worst) < 0.12 and min(w[1] for w in worst) > 0.985, (torso, sorted(worst)[-3:], sorted(worst, key=lambda w: w[1])[:3])
