@@ -139,6 +139,9 @@ SIGNATURES = {
     "cdae_gn_stats16": [P, I, P, I, I, I, I, I, I, F, P, P, P, P, P, I, P, P, P],
     "cdae_gn_apply16": [P, I, P, I, I, P, I, I, I, I, I, P, P, P, P, P, I, I, P],
     "cdae_gn_bwd16": [P, I, P, I, I, P, I, P, I, P, I, I, I, I, I, P, P, P, P, P, I, I, P, P, I, P, I, I, P, I, P, P],
+    "cdae_attn16_supported": [I, I],
+    "cdae_attn16_fwd": [P, P, P, I, I, I, I, P],
+    "cdae_attn16_bwd": [P, P, P, P, P, P, I, I, I, I, P],
     "cdae_gn_parts16": [P, L, P, L, I, P],
     "cdae_cast_f32_bf16": [P, P, L, P],
     "cdae_cast_bf16_f32": [P, P, L, P],

@@ -412,8 +412,9 @@ def upconv_train(x, w, b=None):
 class _AttnBlock16(Function):
     """The whole AttentionBlock (reference unet.py:223-253) as one node on a bf16 residual stream:
         out = x + proj(attention(qkv(GroupNorm(x)))).
-    The normalised rows are bf16 (the qkv GEMM's operand), qkv / the attention core / its output stay fp32 (the reference keeps the
-    softmax in fp32, unet.py:250-252), the projection rounds the sum with the bf16 residual once."""
+    Where attn16.hip has the shape (T in {64, 256}) everything between the norm and the projection is bf16 rows and the attention
+    core keeps no [T, T] tensor (log-sum-exp per query, probabilities recomputed in the backward); else (the 4 x 4 level) qkv / the
+    core / its output stay fp32 as on the fp32-storage path.  The softmax is fp32 in registers either way (unet.py:250-252)."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, wqkv, bqkv, wproj, bproj, heads, groups, eps):
@@ -423,30 +424,38 @@ class _AttnBlock16(Function):
         dev = x.device
         st = stream()
         ch = C // heads
+        core16 = lib.cdae_attn16_supported(T, ch) == 1
         stats = _gn_stats(x, None, N, C, T, groups, eps, st)
         xn = _gn_apply(x, None, stats, gamma, beta, None, False, N, C, H, W, groups, st)
-        wq = wqkv.reshape(3 * C, C)
-        qkv = torch.empty((N, T, 3 * C), dtype=torch.float32, device=dev)
-        _gemm16(xn, C, w16(wq), C, bqkv, None, qkv, 3 * C, None, M, 3 * C, C, 0)
-        a = torch.empty((N, T, C), dtype=torch.float32, device=dev)
-        probs = torch.empty((N * heads, T, T), dtype=torch.float32, device=dev)
-        if lib.cdae_qkv_attention_fused_supported(T, ch):
-            check(lib.cdae_qkv_attention_fwd_fused_p(ptr(qkv), ptr(a), ptr(probs), N, T, heads, ch, st))
-        else:
-            check(lib.cdae_qkv_attention_fwd(ptr(qkv), ptr(a), ptr(probs), N, T, heads, ch, st))
+        wq, wp = wqkv.reshape(3 * C, C), wproj.reshape(C, C)
         out = new_act16(N, C, H, W, dev)
-        wp = wproj.reshape(C, C)
         ws, wsb = _sk(dev)
-        check(lib.cdae_linear_fwd_io(ptr(a), C, ptr(wp), C, ptr(ops.weight_scale(wp)), ptr(bproj), ptr(x), ptr(out), C, M, C, C, 3, ws, wsb, st))
-        ctx.save_for_backward(x, stats, xn, qkv, probs, a, gamma, beta, wq, wp)
-        ctx.cfg = (heads, groups, bqkv is not None, bproj is not None, tuple(wqkv.shape), tuple(wproj.shape))
+        if core16:
+            qkv = torch.empty((N, T, 3 * C), dtype=BF16, device=dev)
+            _gemm16(xn, C, w16(wq), C, bqkv, None, qkv, 3 * C, None, M, 3 * C, C, 1)
+            a = torch.empty((N, T, C), dtype=BF16, device=dev)
+            aux = torch.empty((N * heads, T), dtype=torch.float32, device=dev)            # log-sum-exp per query
+            check(lib.cdae_attn16_fwd(ptr(qkv), ptr(a), ptr(aux), N, T, heads, ch, st))
+            _gemm16(a, C, w16(wp), C, bproj, x, out, C, None, M, C, C, 3)
+        else:
+            qkv = torch.empty((N, T, 3 * C), dtype=torch.float32, device=dev)
+            _gemm16(xn, C, w16(wq), C, bqkv, None, qkv, 3 * C, None, M, 3 * C, C, 0)
+            a = torch.empty((N, T, C), dtype=torch.float32, device=dev)
+            aux = torch.empty((N * heads, T, T), dtype=torch.float32, device=dev)         # probabilities
+            if lib.cdae_qkv_attention_fused_supported(T, ch):
+                check(lib.cdae_qkv_attention_fwd_fused_p(ptr(qkv), ptr(a), ptr(aux), N, T, heads, ch, st))
+            else:
+                check(lib.cdae_qkv_attention_fwd(ptr(qkv), ptr(a), ptr(aux), N, T, heads, ch, st))
+            check(lib.cdae_linear_fwd_io(ptr(a), C, ptr(wp), C, ptr(ops.weight_scale(wp)), ptr(bproj), ptr(x), ptr(out), C, M, C, C, 3, ws, wsb, st))
+        ctx.save_for_backward(x, stats, xn, qkv, aux, a, gamma, beta, wq, wp)
+        ctx.cfg = (heads, groups, bqkv is not None, bproj is not None, tuple(wqkv.shape), tuple(wproj.shape), core16)
         ctx.sinks = (ops._sink(gamma), ops._sink(beta), ops._sink(wqkv), ops._sink(bqkv), ops._sink(wproj), ops._sink(bproj))
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, stats, xn, qkv, probs, a, gamma, beta, wq, wp = ctx.saved_tensors
-        heads, groups, has_bq, has_bp, shape_q, shape_p = ctx.cfg
+        x, stats, xn, qkv, aux, a, gamma, beta, wq, wp = ctx.saved_tensors
+        heads, groups, has_bq, has_bp, shape_q, shape_p, core16 = ctx.cfg
         sg, sb_, swq, sbq, swp, sbp = ctx.sinks
         N, C, H, W = x.shape
         T, M = H * W, N * H * W
@@ -456,7 +465,7 @@ class _AttnBlock16(Function):
         dout = rows16(dout)
         ws, wsb = _sk(dev)
 
-        def wgrad(x_t, ldx, dy_t, lddy, w2d, sinks, has_b, Nw, K, io):
+        def wgrad(x_t, ldx, dy_t, lddy, sinks, has_b, Nw, K, io):
             (gw, rw), (gb, rb) = sinks
             direct = gw is not None and gw.is_contiguous() and (not has_b or gb is not None)
             dw = gw.reshape(Nw, K) if direct else torch.empty((Nw, K), dtype=torch.float32, device=dev)
@@ -471,19 +480,28 @@ class _AttnBlock16(Function):
             wg(st, ws, wsb)
             return dw, db
 
-        # ---- proj: da = dout @ Wp (fp32 out), dWp = dout^T a
-        da = torch.empty((N, T, C), dtype=torch.float32, device=dev)
-        _gemm16(dout, C, wt16(wp), C, None, None, da, C, None, M, C, C, 0)
-        dwp, dbp = wgrad(a, C, dout, C, wp, (swp, sbp), has_bp, C, C, 4)
-        # ---- attention core (fp32, as the fp32-storage path)
-        dqkv = torch.empty_like(qkv)
-        dprobs = torch.empty_like(probs)
-        check(lib.cdae_qkv_attention_bwd(ptr(qkv), ptr(probs), ptr(da), ptr(dqkv), ptr(dprobs), N, T, heads, ch, st))
-        del dprobs, da
-        # ---- qkv: dxn = dqkv @ Wq (bf16 out), dWq = dqkv^T xn
         dxn = torch.empty((N, H, W, C), dtype=BF16, device=dev)
-        check(lib.cdae_linear_dgrad_io(ptr(dqkv), 3 * C, ptr(wq), C, ptr(dxn), C, M, 3 * C, C, 1, ws, wsb, st))
-        dwq, dbq = wgrad(xn, C, dqkv, 3 * C, wq, (swq, sbq), has_bq, 3 * C, C, 8)
+        if core16:
+            # ---- proj: da = dout @ Wp, dWp = dout^T a;  core: dqkv from q, k, v, out, lse;  qkv: dxn = dqkv @ Wq, dWq = dqkv^T xn — all bf16 rows
+            da = torch.empty((N, T, C), dtype=BF16, device=dev)
+            _gemm16(dout, C, wt16(wp), C, None, None, da, C, None, M, C, C, 1)
+            dwp, dbp = wgrad(a, C, dout, C, (swp, sbp), has_bp, C, C, 12)
+            dqkv = torch.empty_like(qkv)
+            dsum = torch.empty_like(aux)
+            check(lib.cdae_attn16_bwd(ptr(qkv), ptr(a), ptr(da), ptr(aux), ptr(dsum), ptr(dqkv), N, T, heads, ch, st))
+            del da
+            _gemm16(dqkv, 3 * C, wt16(wq), 3 * C, None, None, dxn, C, None, M, C, 3 * C, 1)
+            dwq, dbq = wgrad(xn, C, dqkv, 3 * C, (swq, sbq), has_bq, 3 * C, C, 12)
+        else:
+            da = torch.empty((N, T, C), dtype=torch.float32, device=dev)
+            _gemm16(dout, C, wt16(wp), C, None, None, da, C, None, M, C, C, 0)
+            dwp, dbp = wgrad(a, C, dout, C, (swp, sbp), has_bp, C, C, 4)
+            dqkv = torch.empty_like(qkv)
+            dprobs = torch.empty_like(aux)
+            check(lib.cdae_qkv_attention_bwd(ptr(qkv), ptr(aux), ptr(da), ptr(dqkv), ptr(dprobs), N, T, heads, ch, st))
+            del dprobs, da
+            check(lib.cdae_linear_dgrad_io(ptr(dqkv), 3 * C, ptr(wq), C, ptr(dxn), C, M, 3 * C, C, 1, ws, wsb, st))
+            dwq, dbq = wgrad(xn, C, dqkv, 3 * C, (swq, sbq), has_bq, 3 * C, C, 8)
         # ---- GroupNorm backward with the residual gradient folded in
         dx = new_act16(N, C, H, W, dev)
         dg, db, _ = _gn_bwd(x, None, dxn, dx, None, stats, gamma, beta, None, False, (sg, sb_), None, N, C, T, groups, False, dout, st)

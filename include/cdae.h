@@ -482,6 +482,13 @@ int cdae_gn_bwd16(const void* x, int ldx, const void* x2, int ld2, int C1, const
                   int N, int HW, int C, int groups, const float* mean, const float* rstd, const float* gamma, const float* beta,
                   const float* scale_shift, int ld_ss, int silu, float* dgamma, float* dbeta, int accumulate_params, float* d_scale_shift,
                   int ld_dss, int accumulate_dx, const void* dx_add, int ld_add, float* ws, void* stream);
+/* QKVAttention on bf16 rows (unet.py:239-253), forward and backward without a [T, T] tensor in memory: lse [B * heads][T] = log-sum-exp
+   of the scaled scores (kept for the backward, which recomputes the probabilities), dsum [B * heads][T] scratch.  T in {64, 256},
+   ch in {64, 96, 128}. */
+int cdae_attn16_supported(int T, int ch);
+int cdae_attn16_fwd(const void* qkv16, void* out16, float* lse, int B, int T, int heads, int ch, void* stream);
+int cdae_attn16_bwd(const void* qkv16, const void* out16, const void* dout16, const float* lse, float* dsum, void* dqkv16, int B, int T,
+                    int heads, int ch, void* stream);
 int cdae_gn_parts16(const void* x, long ldx, float* parts, long M, int C, void* stream);      /* [ceil(M / 32)][C][2] sums of a bf16 tensor */
 int cdae_cast_f32_bf16(const float* x, void* y, long n, void* stream);
 int cdae_cast_bf16_f32(const void* x, float* y, long n, void* stream);

@@ -128,12 +128,14 @@ def test_resblock16_against_float64(mixed16, shape):
         assert _rel(got.reshape(want.shape), want) < 2.5e-2, (k, _rel(got.reshape(want.shape), want))
 
 
-def test_attention_block16_and_upconv16_against_float64(mixed16):
-    """ops16.attention_block (reference unet.py:223-253) and ops16.upconv_train (unet.py:86-104) against float64 restatements."""
+@pytest.mark.parametrize("C,heads", [(128, 4), (256, 4)])
+def test_attention_block16_and_upconv16_against_float64(mixed16, C, heads):
+    """ops16.attention_block (reference unet.py:223-253; C = 256: the bf16 attention core of attn16.hip, C = 128: ch = 32, the fp32 core
+    between bf16 rows) and ops16.upconv_train (unet.py:86-104) against float64 restatements."""
     from causaldiffae_amd import ops, ops16
     from causaldiffae_amd.nn import conv_nd, normalization
     g = torch.Generator().manual_seed(2)
-    N, C, H, W, heads = 2, 128, 8, 8, 4
+    N, H, W = 2, 8, 8
     norm, qkv, proj = normalization(C), conv_nd(1, C, 3 * C, 1), conv_nd(1, C, C, 1)
     with torch.no_grad():
         for p in list(norm.parameters()) + list(qkv.parameters()) + list(proj.parameters()):
@@ -232,3 +234,35 @@ def test_full_model_step_on_the_16bit_torso_matches_fp32_storage():
             cos = (a * b).sum().item() / (a.norm().item() * b.norm().item() + 1e-30)
             worst.append((rel, cos, n))
         assert max(w[0] for w in worst) < 0.12 and min(w[1] for w in worst) > 0.985, (torso, sorted(worst)[-3:], sorted(worst, key=lambda w: w[1])[:3])
+
+
+@pytest.mark.parametrize("T,ch,heads,B", [(256, 64, 4, 3), (64, 128, 2, 5), (64, 96, 4, 2), (256, 96, 1, 2)])
+def test_attn16_kernels_against_float64(T, ch, heads, B):
+    """cdae_attn16_fwd / cdae_attn16_bwd (bf16 rows, no [T, T] tensor in memory: log-sum-exp per query, probabilities recomputed in the
+    backward, D = rowsum(dO o O)) against float64 softmax attention of the same bf16-rounded q, k, v (reference unet.py:239-253)."""
+    from causaldiffae_amd._lib import check, lib, ptr, stream
+    g = torch.Generator().manual_seed(T + ch)
+    C = heads * ch
+    qkv = (torch.randn(B, T, 3 * C, generator=g) * 1.2).to(torch.bfloat16)
+    dout = torch.randn(B, T, C, generator=g).to(torch.bfloat16)
+    r = qkv.double().reshape(B, T, heads, 3, ch).requires_grad_(True)
+    q, k, v = r[:, :, :, 0], r[:, :, :, 1], r[:, :, :, 2]                          # [B, T, heads, ch]
+    w = torch.softmax(torch.einsum("bthc,bshc->bhts", q, k) / ch ** 0.5, dim=-1)
+    o = torch.einsum("bhts,bshc->bthc", w, v).reshape(B, T, C)
+    o.backward(dout.double())
+    qd, dd = qkv.to(DEV), dout.to(DEV)
+    out = torch.empty((B, T, C), dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty((B * heads, T), dtype=torch.float32, device=DEV)
+    assert lib.cdae_attn16_supported(T, ch) == 1
+    check(lib.cdae_attn16_fwd(ptr(qd), ptr(out), ptr(lse), B, T, heads, ch, stream()))
+    assert _rel(out, o) < 1.2e-2
+    want_lse = torch.logsumexp(torch.einsum("bthc,bshc->bhts", q, k) / ch ** 0.5, dim=-1).reshape(B * heads, T)
+    assert (lse.cpu().double() - want_lse.detach()).abs().max().item() < 1e-3
+    dqkv = torch.empty_like(qd)
+    dsum = torch.empty_like(lse)
+    check(lib.cdae_attn16_bwd(ptr(qd), ptr(out), ptr(dd), ptr(lse), ptr(dsum), ptr(dqkv), B, T, heads, ch, stream()))
+    want = r.grad.reshape(B, T, 3 * C)
+    got = dqkv.cpu().double().reshape(B, T, heads, 3, ch)
+    wantr = want.reshape(B, T, heads, 3, ch)
+    for i, name in enumerate("qkv"):
+        assert _rel(got[:, :, :, i], wantr[:, :, :, i]) < 2.5e-2, (name, _rel(got[:, :, :, i], wantr[:, :, :, i]))
