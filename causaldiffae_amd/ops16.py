@@ -12,6 +12,8 @@ softmax and the optimizer stay fp32.  Here the torso dtype is bf16 (BASELINE con
 A ResBlock, an AttentionBlock and the Upsample conv are one autograd node each.  Shapes the 16-bit kernels do not take (the 4 x 4
 level: rows shorter than the window kernels' minimum) run the fp32-storage nodes of ops.py between two casts.
 """
+import weakref
+
 import torch
 from torch.autograd import Function
 
@@ -117,11 +119,12 @@ def w16(w):
         return hit
     tag = (w.data_ptr(), w._version, ops._WEIGHT_EPOCH[0])
     c = _W16.get(id(w))
-    if c is None or c[0] != tag:
-        if len(_W16) > 4096:
-            _W16.clear()
-        c = _W16[id(w)] = (tag, w.detach().to(BF16).contiguous())
-    return c[1].data_ptr()
+    if c is None or c[0]() is not w or c[1] != tag:          # (weak reference: a new tensor may reuse a freed one's id AND address)
+        if len(_W16) > 1024:
+            for k in [k for k, v in _W16.items() if v[0]() is None]:
+                del _W16[k]
+        c = _W16[id(w)] = (weakref.ref(w), tag, w.detach().to(BF16).contiguous())
+    return c[2].data_ptr()
 
 
 def wt16(w):

@@ -75,12 +75,24 @@ def test_gn16_kernels_match_float64(mixed16):
     assert _rel(dgamma, gr.grad) < 2e-3 and _rel(dbeta, br.grad) < 2e-3 and _rel(dss, sr.grad) < 2e-3
 
 
-@pytest.mark.parametrize("shape", [(4, 256, 128, 16, True), (2, 128, 256, 32, False), (2, 128, 128, 8, False)])
-def test_resblock16_against_float64(mixed16, shape):
+@pytest.mark.parametrize("window_kernel", [False, True])
+@pytest.mark.parametrize("shape", [(4, 256, 128, 16, True), (2, 128, 256, 32, False), (4, 128, 128, 8, False)])
+def test_resblock16_against_float64(mixed16, shape, window_kernel, expect_kernels):
     """ops16.resblock_train (identity / 1x1 skip, two-source input) against a float64 restatement of the reference ResBlock
-    (unet.py:156-199) on the same bf16-rounded input: output, input gradients and every parameter gradient to bf16's bar."""
+    (unet.py:156-199) on the same bf16-rounded input: output, input gradients and every parameter gradient to bf16's bar — on the
+    small-grid plane kernels these shapes dispatch by themselves, and on the window kernel's bf16-row instantiation the benchmark's
+    shapes run (forced with cdae_tune_set, asserted from the launch log)."""
     from causaldiffae_amd import ops, ops16
+    from causaldiffae_amd._lib import tune_scope
+    import contextlib
     N, C, Cout, HW, cat = shape
+    with (tune_scope(convwin_min_tiles=1) if window_kernel else contextlib.nullcontext()), \
+            (expect_kernels(convwin_dgrad=4) if window_kernel else contextlib.nullcontext()):
+        _resblock16_case(N, C, Cout, HW, cat)
+
+
+def _resblock16_case(N, C, Cout, HW, cat):
+    from causaldiffae_amd import ops, ops16
     H = W = HW
     g = torch.Generator().manual_seed(1)
     C1 = C // 2 if cat else C
