@@ -60,6 +60,7 @@ SIGNATURES = {
     "cdae_conv3x3_wgrad_fewout": [P, P, L, P, P, I, I, I, I, I, I, P, SZ, P],
     "cdae_conv3x3_wgrad_win_supported": [I, I, I, I, I],
     "cdae_conv3x3_wgrad_win": [P, P, P, P, P, P, I, I, I, I, I, I, P, SZ, P],
+    "cdae_conv3x3_wgrad_win_group": [P, I, P, SZ, P],
     "cdae_gn_apply_split_train": [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, I, I, P],
     "cdae_gn_apply_split": [P, P, P, I, I, I, I, I, I, P, P, P, P, P, I, I, P],
     "cdae_gn_stats2": [P, I, P, I, I, I, I, I, I, F, P, P, P, P],
@@ -163,6 +164,12 @@ PROF_FAMILIES = ("igemm", "groupnorm", "softmax", "elementwise", "optimizer", "c
 
 class CdaeError(RuntimeError):
     pass
+
+
+class WgItem(ctypes.Structure):
+    """cdae_wg_item (include/cdae.h): one weight gradient of a group launch"""
+    _fields_ = [("a_hi", P), ("a_lo", P), ("dy_hi", P), ("dy_lo", P), ("dw", P), ("dbias", P),
+                ("N", I), ("H", I), ("W", I), ("Cin", I), ("Cout", I), ("accumulate", I)]
 
 
 def _load():

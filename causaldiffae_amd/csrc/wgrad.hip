@@ -46,6 +46,13 @@ struct WgParams {
     int U0, RB;              // rows before image 0 (16 * halo blocks); ring size in 16-row blocks
 };
 
+// A GROUP of weight gradients as one launch (round 5): at the 8 x 8 / 16 x 16 levels of a batch-32 step one conv has 36-128 (Cout, Cin) tiles for
+// 256 CUs, so each launch split its pixel range 2-7 ways, wrote [ksplit][Cout][9 Cin] slabs (37 MB per launch on average) and paid a finish
+// launch; the six to ten convs of a level together fill the chip unsplit.  The descriptors travel in the kernel arguments (scalar loads),
+// block b belongs to the descriptor d with start[d] <= b < start[d + 1].
+constexpr int WG_MAXD = 12;
+struct WgGroup { WgParams d[WG_MAXD]; int start[WG_MAXD + 1]; int nd; };
+
 __device__ __attribute__((aligned(16))) unsigned g_zero_wg[4] = {0u, 0u, 0u, 0u};
 
 __device__ __forceinline__ int fdiv(int n, unsigned magic, int shift) {
@@ -64,7 +71,11 @@ __device__ __forceinline__ int fdiv(int n, unsigned magic, int shift) {
 // NPL = 1 (the `mixed16` torso): one bf16 plane per operand, one MFMA per product; the lo sub-planes are neither staged nor read.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int NPL = 2>
-__global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgParams p) {
+__global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgGroup grp) {
+    int di = 0;
+    while (di + 1 < grp.nd && (int)blockIdx.x >= grp.start[di + 1]) ++di;           // (uniform: scalar compares on kernel arguments)
+    const WgParams& p = grp.d[di];
+    const unsigned gb0 = (unsigned)grp.start[di], gG = (unsigned)(grp.start[di + 1] - grp.start[di]);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* const lds = reinterpret_cast<char*>(smem);
     const int RROWS = (p.RB + 2) * 16;                 // ring rows incl. the mirrors of slots 0 and 1
@@ -79,7 +90,7 @@ __global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgParams p) {
     const int nci = p.Cin >> 6, nco = p.Cout >> 6;
     int b;
     {
-        const unsigned G = gridDim.x, bb = blockIdx.x, q = G >> 3, r = G & 7, x = bb & 7;
+        const unsigned G = gG, bb = blockIdx.x - gb0, q = G >> 3, r = G & 7, x = bb & 7;
         b = (int)((x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bb >> 3));
     }
     const int cit = b % nci; b /= nci;
@@ -438,79 +449,121 @@ extern "C" int cdae_conv3x3_wgrad_win_supported(int N, int H, int W, int Cin, in
            (long)N * H * W * (Cin > Cout ? Cin : Cout) < (1L << 31);
 }
 
+// One launch for up to WG_MAXD weight gradients (items[i]: the arguments of cdae_conv3x3_wgrad_win).  The pixel ranges are split so that
+// every block of the launch walks about the same number of 64-pixel steps and the blocks come in whole rounds of 256 (one per CU): with
+// enough (Cout, Cin) tiles in the group nothing is split at all — no slabs, no finish launch.
+extern "C" int cdae_conv3x3_wgrad_win_group(const cdae_wg_item* items, int n, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n <= 0) return 0;
+    if (!items) return cdae_fail("conv3x3_wgrad_win_group: no items");
+    const bool single = cdae_get_default_precision() == CDAE_PREC_MIXED16;      // one bf16 plane per operand in the reduced-precision mode
+    for (int i0 = 0; i0 < n; i0 += WG_MAXD) {
+        const int nd = n - i0 < WG_MAXD ? n - i0 : WG_MAXD;
+        WgGroup g;
+        long tiles[WG_MAXD];
+        size_t slab[WG_MAXD], smem = 0;
+        long tiles_all = 0;
+        double flops = 0;
+        for (int d = 0; d < nd; ++d) {
+            const cdae_wg_item& it = items[i0 + d];
+            if (!cdae_conv3x3_wgrad_win_supported(it.N, it.H, it.W, it.Cin, it.Cout))
+                return cdae_fail("conv3x3_wgrad_win: needs W a power of two in [8, 64], H*W % 64 == 0, Cin % 64 == 0, Cout % 64 == 0");
+            if ((((size_t)it.a_hi | (size_t)it.a_lo | (size_t)it.dy_hi | (size_t)it.dy_lo | (size_t)it.dw) & 15)) return cdae_fail("conv3x3_wgrad_win: 16-byte aligned operands required");
+            WgParams& p = g.d[d];
+            p.a_hi = it.a_hi; p.a_lo = it.a_lo; p.d_hi = it.dy_hi; p.d_lo = it.dy_lo;
+            p.N = it.N; p.HW = it.H * it.W; p.W = it.W; p.Cin = it.Cin; p.Cout = it.Cout;
+            p.steps = it.N * p.HW / 64;
+            const int hb = it.W / 16 + 1;                      // 16 hb >= W + 1
+            const int G = 16 * hb;                             // zero rows between images
+            p.U0 = 16 * hb; p.period = p.HW + G;
+            p.RB = 8 + G / 16 + 2 * hb + 1;                    // live window (4 + 2 hb) + the largest prefetch (4 + G/16) + 1 spare
+            int sh = 0;
+            while ((1u << sh) < (unsigned)p.period) ++sh;
+            p.period_magic = (unsigned)(((unsigned long long)((1ull << sh) - (unsigned)p.period) << 32) / (unsigned)p.period) + 1u;
+            p.period_shift = sh;
+            p.accumulate = it.accumulate; p.colsum = it.dbias;
+            tiles[d] = (long)(it.Cin / 64) * (it.Cout / 64);
+            slab[d] = (size_t)it.Cout * 9 * it.Cin * sizeof(float);
+            tiles_all += tiles[d];
+            const size_t sm = (size_t)4 * (p.RB + 2) * 16 * 64 + 2 * 4 * 64 * 64;
+            if (sm > smem) smem = sm;
+            flops += 2.0 * it.Cout * 9.0 * it.Cin * (double)it.N * p.HW;
+            if (it.dbias && !it.accumulate && hipMemsetAsync(it.dbias, 0, sizeof(float) * it.Cout, st) != hipSuccess) return cdae_fail("dbias memset failed");
+        }
+        // S = steps per block.  Candidates: every steps_d / k; cost = rounds of 256 blocks x (S + ~12 steps of prologue / epilogue / fold) + what
+        // the splits cost (slab round trip + finish launch, about a dozen steps' worth, once per launch that has any)
+        static const int cfg_blocks = CDAE_DEV_INT("CDAE_WG_BLOCKS", 256);      // one block per CU fits (84-134 KB of LDS)
+        int bestS = 1 << 30; long best_cost = -1;
+        for (int d = 0; d < nd; ++d)
+            for (int k = 1; k <= 256; ++k) {
+                const int S = (g.d[d].steps + k - 1) / k;
+                if (S < 1) break;
+                long blocks = 0; bool any = false; size_t need = 0;
+                for (int e = 0; e < nd; ++e) {
+                    const int ks = (g.d[e].steps + S - 1) / S;
+                    blocks += tiles[e] * ks;
+                    if (ks > 1) { any = true; need += (size_t)ks * slab[e]; }
+                }
+                if (need > splitk_ws_bytes || (need && !splitk_ws)) continue;
+                const long rounds = (blocks + cfg_blocks - 1) / cfg_blocks;
+                const long cost = rounds * (S + 12) + (any ? 12 : 0);
+                if (best_cost < 0 || cost < best_cost || (cost == best_cost && S > bestS)) { best_cost = cost; bestS = S; }
+                if (blocks > 4 * cfg_blocks) break;
+            }
+        if (best_cost < 0) return cdae_fail("conv3x3_wgrad_win_group: split-K workspace too small");
+        int nblk = 0;
+        float* wsp = splitk_ws;
+        for (int d = 0; d < nd; ++d) {
+            WgParams& p = g.d[d];
+            int ks = (p.steps + bestS - 1) / bestS;
+            p.steps_per = (p.steps + ks - 1) / ks;
+            ks = (p.steps + p.steps_per - 1) / p.steps_per;    // no empty blocks
+            p.ksplit = ks;
+            p.out = ks > 1 ? wsp : items[i0 + d].dw;
+            if (ks > 1) wsp += (size_t)ks * slab[d] / sizeof(float);
+            g.start[d] = nblk;
+            nblk += (int)(tiles[d] * ks);
+        }
+        for (int d = nd; d <= WG_MAXD; ++d) g.start[d] = nblk;
+        g.nd = nd;
+        static size_t attr_bytes = 0;
+        if (smem > attr_bytes) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgwin_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&wgwin_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+                return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
+            attr_bytes = smem;
+        }
+        cdae_prof_begin(PROF_IGEMM, flops, st);
+        if (cdae_prof_on()) {
+            char tag[128];
+            const WgParams& p = g.d[0];
+            snprintf(tag, sizeof(tag), "wgwin x%d %d->%d @%dx%d n=%d tiles=%ld blocks=%d S=%d ks0=%d planes=%d", nd, p.Cin, p.Cout, p.HW / p.W, p.W, p.N, tiles_all, nblk, bestS,
+                     p.ksplit, single ? 1 : 2);
+            cdae_prof_tag(tag);
+        }
+        if (single) hipLaunchKernelGGL((wgwin_kernel<1>), dim3((unsigned)nblk), dim3(512), smem, st, g);
+        else hipLaunchKernelGGL((wgwin_kernel<2>), dim3((unsigned)nblk), dim3(512), smem, st, g);
+        int rc = hipGetLastError() == hipSuccess ? 0 : cdae_fail("wgwin_kernel launch failed");
+        for (int d = 0; d < nd && rc == 0; ++d) {
+            const WgParams& p = g.d[d];
+            if (p.ksplit <= 1) continue;
+            const long n4 = (long)p.Cout * 9 * p.Cin / 4;
+            int blocks = (int)((n4 + 255) / 256);
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(wg_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)p.out, (float4*)items[i0 + d].dw, n4, p.ksplit, p.accumulate);
+            if (hipGetLastError() != hipSuccess) rc = cdae_fail("wg_reduce launch failed");
+        }
+        cdae_prof_end(PROF_IGEMM, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 extern "C" int cdae_conv3x3_wgrad_win(const unsigned short* a_hi, const unsigned short* a_lo, const unsigned short* dy_hi, const unsigned short* dy_lo,
                                       float* dw, float* dbias, int N, int H, int W, int Cin, int Cout, int accumulate, float* splitk_ws,
                                       size_t splitk_ws_bytes, void* stream) {
-    hipStream_t st = (hipStream_t)stream;
-    if (!cdae_conv3x3_wgrad_win_supported(N, H, W, Cin, Cout))
-        return cdae_fail("conv3x3_wgrad_win: needs W a power of two in [8, 64], H*W % 64 == 0, Cin % 64 == 0, Cout % 64 == 0");
-    if ((((size_t)a_hi | (size_t)a_lo | (size_t)dy_hi | (size_t)dy_lo | (size_t)dw) & 15)) return cdae_fail("conv3x3_wgrad_win: 16-byte aligned operands required");
-    WgParams p;
-    p.a_hi = a_hi; p.a_lo = a_lo; p.d_hi = dy_hi; p.d_lo = dy_lo;
-    p.N = N; p.HW = H * W; p.W = W; p.Cin = Cin; p.Cout = Cout;
-    p.steps = N * p.HW / 64;
-    const int hb = W / 16 + 1;                         // 16 hb >= W + 1
-    const int G = 16 * hb;                             // zero rows between images
-    p.U0 = 16 * hb; p.period = p.HW + G;
-    p.RB = 8 + G / 16 + 2 * hb + 1;                    // live window (4 + 2 hb) + the largest prefetch (4 + G/16) + 1 spare
-    {
-        int sh = 0;
-        while ((1u << sh) < (unsigned)p.period) ++sh;
-        p.period_magic = (unsigned)(((unsigned long long)((1ull << sh) - (unsigned)p.period) << 32) / (unsigned)p.period) + 1u;
-        p.period_shift = sh;
-    }
-    const long tiles = (long)(Cin / 64) * (Cout / 64);
-    const size_t slab = (size_t)Cout * 9 * Cin * sizeof(float);
-    static const int cfg_blocks = CDAE_DEV_INT("CDAE_WG_BLOCKS", 256);      // grid target: one block per CU (measured 256 / 512 / 768: 39.6 / 39.7-40.9 / 40.6-43.2 ms per training step)
-    // K split: one block per CU fits (84-134 KB of LDS), so a grid of more than cfg_blocks runs in ROUNDS: 36 tiles x 8 splits = 288
-    // blocks take two rounds of steps / 8, x 7 = 252 blocks one round of steps / 7.  Pick the split with the smallest
-    // rounds x (steps per block + the fixed prologue / epilogue / finish, about twelve steps' worth); CDAE_WG_KS_CEIL=1 restores ceil(256 / tiles).
-    static const int cfg_ceil = CDAE_DEV_INT("CDAE_WG_KS_CEIL", 0);
-    int ks = (int)((cfg_blocks + tiles - 1) / tiles);
-    if (ks > p.steps) ks = p.steps;
-    while (ks > 1 && (!splitk_ws || (size_t)ks * slab > splitk_ws_bytes)) --ks;
-    if (!cfg_ceil && ks > 1) {
-        long best_cost = -1; int best = 1;
-        for (int k = 1; k <= ks; ++k) {
-            const int sp = (p.steps + k - 1) / k, kk = (p.steps + sp - 1) / sp;
-            const long rounds = (tiles * kk + cfg_blocks - 1) / cfg_blocks;
-            const long cost = rounds * (sp + 12);
-            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = k; }
-        }
-        ks = best;
-    }
-    p.steps_per = (p.steps + ks - 1) / ks;
-    ks = (p.steps + p.steps_per - 1) / p.steps_per;    // no empty blocks
-    p.ksplit = ks; p.accumulate = accumulate;
-    p.out = ks > 1 ? splitk_ws : dw;
-    p.colsum = dbias;
-    if (dbias && !accumulate && hipMemsetAsync(dbias, 0, sizeof(float) * Cout, st) != hipSuccess) return cdae_fail("dbias memset failed");
-    const size_t smem = (size_t)4 * (p.RB + 2) * 16 * 64 + 2 * 4 * 64 * 64;
-    // one bf16 plane per operand in the reduced-precision mode (the lo pointers are ignored), hi / lo pairs otherwise
-    const bool single = cdae_get_default_precision() == CDAE_PREC_MIXED16;
-    static size_t attr_bytes = 0;
-    if (smem > attr_bytes) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgwin_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&wgwin_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-            return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
-        attr_bytes = smem;
-    }
-    cdae_prof_begin(PROF_IGEMM, 2.0 * Cout * 9.0 * Cin * (double)N * p.HW, st);
-    if (cdae_prof_on()) {
-        char tag[128];
-        snprintf(tag, sizeof(tag), "wgwin %d->%d @%dx%d n=%d tiles=%ld ks=%d planes=%d", Cin, Cout, H, W, N, tiles, ks, single ? 1 : 2);
-        cdae_prof_tag(tag);
-    }
-    if (single) hipLaunchKernelGGL((wgwin_kernel<1>), dim3((unsigned)(tiles * ks)), dim3(512), smem, st, p);
-    else hipLaunchKernelGGL((wgwin_kernel<2>), dim3((unsigned)(tiles * ks)), dim3(512), smem, st, p);
-    int rc = hipGetLastError() == hipSuccess ? 0 : cdae_fail("wgwin_kernel launch failed");
-    if (rc == 0 && ks > 1) {
-        const long n4 = (long)Cout * 9 * Cin / 4;
-        int blocks = (int)((n4 + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(wg_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)splitk_ws, (float4*)dw, n4, ks, accumulate);
-        if (hipGetLastError() != hipSuccess) rc = cdae_fail("wg_reduce launch failed");
-    }
-    cdae_prof_end(PROF_IGEMM, st);
-    return rc;
+    cdae_wg_item it;
+    it.a_hi = a_hi; it.a_lo = a_lo; it.dy_hi = dy_hi; it.dy_lo = dy_lo; it.dw = dw; it.dbias = dbias;
+    it.N = N; it.H = H; it.W = W; it.Cin = Cin; it.Cout = Cout; it.accumulate = accumulate;
+    return cdae_conv3x3_wgrad_win_group(&it, 1, splitk_ws, splitk_ws_bytes, stream);
 }

@@ -6,6 +6,7 @@ the reference's NCHW API while every kernel sees coalesced channel-contiguous ro
 keep the reference's logical [Cout, Cin, 3, 3] shape (state-dict compatible) with channels_last
 storage = OHWI.  Nothing here computes on the host; a CPU tensor raises (see _lib.ptr).
 """
+import ctypes
 import os
 import weakref
 
@@ -202,8 +203,78 @@ def side_launch(dev, tensors, fn, hold=()):
         _side_flush(sd, dev)
 
 
+# ---- weight gradients of a resolution level as ONE launch (cdae_conv3x3_wgrad_win_group).  At the 8 x 8 / 16 x 16 levels of a batch-32 step a
+# single conv has 36-128 (Cout, Cin) tiles for 256 CUs: launched one by one each wgrad split its pixel range, wrote slabs and paid a
+# finish launch; the convs of a level together fill the chip unsplit.  wgrad_win() defers a launch, the group goes out when the level
+# changes, when it holds twelve items, and — always — before anyone reads gradients (side_join: end of backward, a bucket's all-reduce).
+_WG_GROUP_ON = True        # path toggle: False = every window wgrad as its own launch
+_WG_PENDING = {}
+
+
+def wgrad_win(dev, a_planes, d_planes, dw, db, N, H, W, Cin, Cout):
+    """dw (+)= the weight gradient of a stride-1 conv3x3 from its operand planes (a [2, N, H, W, Cin] or one bf16 tensor, likewise dy),
+    accumulated into the flat-gradient views dw / db — deferred into the level's group launch."""
+    from ._lib import WgItem
+    a_hi, a_lo = ptr2(a_planes) if (isinstance(a_planes, (tuple, list)) or a_planes.dim() == 5) else (ptr(a_planes), ptr(a_planes))
+    d_hi, d_lo = ptr2(d_planes) if (isinstance(d_planes, (tuple, list)) or d_planes.dim() == 5) else (ptr(d_planes), ptr(d_planes))
+    item = WgItem(a_hi, a_lo, d_hi, d_lo, ptr(dw), ptr(db), N, H, W, Cin, Cout, 1)
+    if not _WG_GROUP_ON:
+        def one(st_, ws_, wsb_, item=item):
+            check(lib.cdae_conv3x3_wgrad_win_group(ctypes.byref(item), 1, ws_, wsb_, st_))
+        side_launch(dev, (a_planes, d_planes), one)
+        return
+    pend = _WG_PENDING.setdefault(dev.index, dict(key=None, items=[], keep=[], prec=None))
+    if pend["items"] and (pend["key"] != (H, W) or len(pend["items"]) >= 12):
+        _wg_flush(dev)
+    pend["key"], pend["prec"] = (H, W), lib.cdae_get_default_precision()
+    pend["items"].append(item)
+    pend["keep"].extend((a_planes, d_planes))
+    _hook_backward_end(_side(dev) if wgrad_side_stream_on() else _WG_HOOK.setdefault(dev.index, dict(hooked=None)))
+
+
+_WG_HOOK = {}
+
+
+def _wg_flush(dev):
+    pend = _WG_PENDING.get(dev.index)
+    if not pend or not pend["items"]:
+        return
+    items, keep, prec = pend["items"], tuple(pend["keep"]), pend["prec"]
+    pend["items"], pend["keep"] = [], []
+    from ._lib import WgItem
+    arr = (WgItem * len(items))(*items)
+
+    def group(st_, ws_, wsb_, arr=arr, n=len(items), prec=prec):
+        cur = lib.cdae_get_default_precision()          # the group runs in the mode its convs were issued in (a flush may come from outside the model's scope)
+        if cur != prec:
+            lib.cdae_set_default_precision(prec)
+        try:
+            check(lib.cdae_conv3x3_wgrad_win_group(arr, n, ws_, wsb_, st_))
+        finally:
+            if cur != prec:
+                lib.cdae_set_default_precision(cur)
+    side_launch(dev, keep, group)
+
+
+def _hook_backward_end(sd):
+    """the stream that called backward() joins (side_join) when the backward pass ends — keyed on the graph task, see side_launch"""
+    task = _graph_task()
+    if task >= 0 and sd["hooked"] != task:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(side_join)
+            sd["hooked"] = task
+        except RuntimeError:
+            pass
+
+
 def side_join(dev=None):
-    """The current stream waits for every wgrad launch handed to side_launch so far (no host sync)."""
+    """The current stream waits for every wgrad launch handed to side_launch so far (no host sync); deferred weight-gradient groups go
+    out first."""
+    for idx in list(_WG_PENDING):
+        if dev is None or dev.index == idx:
+            _wg_flush(torch.device("cuda", idx))
+    for h in _WG_HOOK.values():
+        h["hooked"] = None
     for idx, sd in _SIDE.items():
         if dev is not None and dev.index != idx:
             continue
@@ -1670,7 +1741,7 @@ class _GNConvPS(Function):
                 check(lib.cdae_conv3x3_wgrad_win(*ptr2(planes), *ptr2(dplanes), ptr(dw), ptr(db), N, H, W, C, Cout,
                                                  1 if direct else 0, ws_, wsb_, st_))
             if direct:
-                side_launch(dev, (planes, dplanes), wg)
+                wgrad_win(dev, planes, dplanes, dw, db, N, H, W, C, Cout)
                 dw = db = None
                 _done(rw, rb)
             else:
@@ -1749,7 +1820,7 @@ class _UpConvPS(Function):
                 check(lib.cdae_conv3x3_wgrad_win(*ptr2(bplanes), *ptr2(dplanes), ptr(dw), ptr(db), N, 2 * H, 2 * W, C,
                                                  Cout, 1 if direct else 0, ws_, wsb_, st_))
             if direct:
-                side_launch(dev, (bplanes, dplanes), wg)
+                wgrad_win(dev, bplanes, dplanes, dw, db, N, 2 * H, 2 * W, C, Cout)
                 dw = db = None
                 _done(rw, rb)
             else:
@@ -1858,7 +1929,7 @@ def _rb_conv_bwd(bplanes, dplanes, w, sinks, has_b, shape, Cout, need_w, st):
             check(lib.cdae_conv3x3_wgrad_win(*ptr2(bplanes), *ptr2(dplanes), ptr(dw), ptr(db), N, H, W, C, Cout,
                                              1 if direct else 0, ws_, wsb_, st_))
         if direct:
-            side_launch(dev, (bplanes, dplanes), wg)
+            wgrad_win(dev, bplanes, dplanes, dw, db, N, H, W, C, Cout)
             dw = db = None
             _done(rw, rb)
         else:
@@ -1951,7 +2022,7 @@ class _ResBlockPS(Function):
         dyn2, dw2, dc2b = _rb_conv_bwd(bplanes2, dplanes, w2, (sw2, sc2b), has_c2b, (N, Cout, H, W), Cout, need[9], st)
         # dh leaves GN2's backward as bf16 planes only (it is nothing but conv1's dy).  (A buffer of its own: conv2's wgrad may still be
         # reading `dplanes` on the side stream.)
-        dplanes = torch.empty_like(dplanes) if wgrad_side_stream_on() else dplanes
+        dplanes = torch.empty_like(dplanes) if (wgrad_side_stream_on() or _WG_GROUP_ON) else dplanes
         dg2, db2, dss = gn_bwd(h, dyn2, stats2, g2, b2, ss, (sg2, sb2), Cout, None, False, None, dplanes)
         del dyn2
         # ---- first half: conv1, then GN1 with the residual gradient folded in
@@ -2184,7 +2255,7 @@ PATH_TOGGLES = {"skipgn_v2": "_SKIPGN_V2", "skip_gn": "_SKIPGN_ON", "stream_gemm
                 "linear_gn": "_LINEAR_GN", "fused_attn": "_FUSED_ATTN_ON", "fused_attn_train": "_FUSED_ATTN_TRAIN", "kpack": "_KPACK_ON",
                 "presplit": "_PRESPLIT_ON", "train_presplit": "_TRAIN_PS_ON", "train_rbnode": "_RBNODE_ON", "train_gnparts": "_RB_PARTS_ON",
                 "train_emball": "_EMBALL_ON", "train_cat": "_TRAIN_CAT_ON", "weight_bank": "_WEIGHT_BANK_ON", "wscale": "_WSCALE_ON",
-                "s2_dgrad_ps": "_S2DGRAD_ON", "dgrad_stream": "_DGRAD_STREAM_ON", "wgrad_stream": "_WGRAD_SIDE_ON", "torso16": "_TORSO16_ON"}
+                "s2_dgrad_ps": "_S2DGRAD_ON", "dgrad_stream": "_DGRAD_STREAM_ON", "wgrad_stream": "_WGRAD_SIDE_ON", "torso16": "_TORSO16_ON", "wgrad_group": "_WG_GROUP_ON"}
 
 
 class path_scope:

@@ -233,7 +233,7 @@ def _conv_bwd(a16, dy16, w, sinks, has_b, N, H, W, Cin, Cout, need_w, st):
             check(lib.cdae_conv3x3_wgrad_win(ptr(a16), ptr(a16), ptr(dy16), ptr(dy16), ptr(dw), ptr(db), N, H, W, Cin, Cout,
                                              1 if direct else 0, ws_, wsb_, st_))
         if direct:
-            ops.side_launch(dev, (a16, dy16), wg)
+            ops.wgrad_win(dev, a16, dy16, dw, db, N, H, W, Cin, Cout)          # into the level's group launch
             dw = db = None
             ops._done(rw, rb)
         else:

@@ -303,6 +303,15 @@ int cdae_head_conv_fwd(const float* x, long ldx, const float* coef, int silu, co
 int cdae_conv3x3_wgrad_fewout(const float* x, const float* dy, long lddy, float* dw, float* dbias, int N, int H, int W, int Cin, int Cout,
                               int accumulate, float* ws, size_t ws_bytes, void* stream);
 int cdae_conv3x3_wgrad_win_supported(int N, int H, int W, int Cin, int Cout);
+/* one weight gradient of a GROUP launch: the arguments of cdae_conv3x3_wgrad_win */
+typedef struct cdae_wg_item {
+    const unsigned short* a_hi; const unsigned short* a_lo; const unsigned short* dy_hi; const unsigned short* dy_lo;
+    float* dw; float* dbias;
+    int N, H, W, Cin, Cout, accumulate;
+} cdae_wg_item;
+/* n weight gradients (any mix of shapes) in ONE launch per 12 items: the convs of a resolution level together fill the chip without
+   splitting their pixel ranges — no [ksplit][Cout][9 Cin] slabs, no finish launches (autograd's conv backward, nn.py:470-480) */
+int cdae_conv3x3_wgrad_win_group(const cdae_wg_item* items, int n, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
 int cdae_conv3x3_wgrad_win(const unsigned short* a_hi, const unsigned short* a_lo, const unsigned short* dy_hi, const unsigned short* dy_lo,
                            float* dw, float* dbias, int N, int H, int W, int Cin, int Cout, int accumulate, float* splitk_ws,
                            size_t splitk_ws_bytes, void* stream);

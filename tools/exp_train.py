@@ -10,6 +10,10 @@ from improved_diffusion.image_datasets import load_data
 from improved_diffusion.train_util import TrainLoop
 
 dev = torch.device("cuda:0")
+if os.environ.get("OFF"):               # OFF=name,name: fused paths of causaldiffae_amd.ops.PATH_TOGGLES switched off for this run (same-box A/B)
+    from causaldiffae_amd import ops as _ops
+    for _n in os.environ["OFF"].split(","):
+        setattr(_ops, _ops.PATH_TOGGLES[_n], False)
 B = int(os.environ.get("BATCH", "32"))
 if os.environ.get("NJ3"):
     from causaldiffae_amd._lib import lib as _l
@@ -41,4 +45,4 @@ for _ in range(REGIONS):
         step()
     torch.cuda.synchronize()
     out.append((time.perf_counter() - t0) / STEPS * 1e3)
-print("train ms/step:", " ".join(f"{v:.3f}" for v in out), "| env:", {k: v for k, v in os.environ.items() if k.startswith("CDAE_")})
+print("train ms/step:", " ".join(f"{v:.3f}" for v in out), "| env:", {k: v for k, v in os.environ.items() if k.startswith("CDAE_") or k == "OFF"})
