@@ -230,6 +230,7 @@ def ptr2(t):
 
 _ws = {}
 _ws_retired = []
+_PROBED = set()
 _WS_LANE = [0]
 
 
@@ -252,6 +253,12 @@ class ws_lane:
 def workspace(device, name, nbytes):
     """Persistent per-device (and per-lane, see ws_lane) scratch buffers (split-K slabs, norm partials); grown on demand, never shrunk."""
     key = (device.index if device.index is not None else torch.cuda.current_device(), _WS_LANE[0], name)
+    if key[0] not in _PROBED and not torch.cuda.is_current_stream_capturing():
+        # the window conv kernel's padding taps rely on out-of-range LDS reads returning zeros: the library checks that once per device
+        # (cdae_convwin_lds_probe allocates and synchronises) — here, at the first workspace of the device, not inside a launch
+        _PROBED.add(key[0])
+        with torch.cuda.device(key[0]):
+            check(lib.cdae_convwin_lds_probe(stream()))
     buf = _ws.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
         if buf is not None:

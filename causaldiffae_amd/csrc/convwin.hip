@@ -21,6 +21,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <atomic>
+#include <mutex>
 #include "cdae_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -629,10 +631,15 @@ __global__ __launch_bounds__(256, 2) void cw_oob_probe_kernel(unsigned* __restri
 }
 
 static int cw_oob_checked(hipStream_t st) {          // 1 = zeros confirmed, 0 = not checkable now (stream is capturing), -1 = failed
-    static int state[64] = {0};
+    // (the binding runs the probe when it first creates a workspace on a device — causaldiffae_amd/_lib.py — so launches normally find the
+    //  answer here and never allocate or synchronise; the lazy path below remains for callers of the bare C-ABI)
+    static std::atomic<int> state[64];
+    static std::mutex mu;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return cdae_fail("convwin: hipGetDevice failed"), -1;
-    if (state[dev]) return state[dev];
+    if (const int s = state[dev].load(std::memory_order_acquire)) return s;
+    std::lock_guard<std::mutex> lk(mu);
+    if (const int s = state[dev].load(std::memory_order_acquire)) return s;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return 0;      // a warm-up launch outside the capture has normally decided already
     unsigned* d = nullptr;
@@ -646,8 +653,8 @@ static int cw_oob_checked(hipStream_t st) {          // 1 = zeros confirmed, 0 =
     }
     if (d) (void)hipFree(d);
     if (!ok) { cdae_fail("convwin: the out-of-range LDS read probe could not run"); return -1; }
-    state[dev] = h == 0 ? 1 : -1;
-    return state[dev];
+    state[dev].store(h == 0 ? 1 : -1, std::memory_order_release);
+    return state[dev].load();
 }
 
 extern "C" int cdae_convwin_lds_probe(void* stream) {

@@ -581,7 +581,8 @@ int cdae_planes_dispatch(GemmParams& p, int big, int& ks, hipStream_t st) {
             int kbest = ks;
             static const int cfg_slots = CDAE_DEV_INT("CDAE_CONVWIN_SPLIT_SLOTS", 512);      // block slots the K split tries to fill (two per CU)
             if (cw_tiles * ks < cfg_slots && cdae_tune(TUNE_CONVWIN_SPLITK) && p.ksplit_auto && p.splitk_ws &&
-                (!p.gn_part || (p.N % 4 == 0 && p.ldc % 4 == 0 && !p.C_hi && p.ps_taps != 4))) {      // (statistics with a split: from the finish kernel, igemm.hip)
+                (!p.gn_part || (p.N % 4 == 0 && p.ldc % 4 == 0 && !p.C_hi && p.ps_taps != 4 && p.act == ACT_NONE && !p.accumulate && p.batch == 1 &&
+                                p.out_mode == OUT_ROWMAJOR))) {      // (statistics with a split come from the finish kernel: igemm.hip gn_finish_ok, the same predicate)
                 int k2 = (int)(cfg_slots / cw_tiles);
                 if (k2 > nchunk / 3) k2 = nchunk / 3;
                 while (k2 > 1 && (size_t)k2 * p.M * p.N * sizeof(float) > p.splitk_ws_bytes) --k2;

@@ -15,7 +15,7 @@ cfg = {**su.model_and_diffusion_defaults(), "image_size": 64, "in_channels": 4, 
 model, diff = su.create_model_and_diffusion(**cfg)
 bench.randomize(model, 1234)
 model.to(dev).eval()
-N = 128
+N = int(os.environ.get("BATCH", "128"))
 x = torch.randn(N, 4, 64, 64, device=dev)
 kw = dict(z=torch.randn(N, 512, device=dev))
 tab = diff._step_table(dev, N)
