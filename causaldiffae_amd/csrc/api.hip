@@ -270,6 +270,7 @@ int cdae_conv3x3_s2_dgrad_ps(const unsigned short* dy_hi, const unsigned short* 
         const bool all = ph < 0;
         if (all) { ph = 0; p.nphase = 4; p.phase_w = (long)Cin * 4 * Cout; }
         p.presplit = 1; p.ps_taps = 4; p.ph_y = ph >> 1; p.ph_x = ph & 1; p.grad_operand = 1;
+        p.prec = 2;            // bf16 hi / lo pairs in every split mode (the one-plane window kernel has no 4-tap form: mixed16 ran the masked 9-tap gather, 176 us per Downsample)
         const long woff = (long)ph * Cin * 4 * Cout;
         p.A = reinterpret_cast<const float*>(dy_hi); p.A_lo = dy_lo;
         p.B = reinterpret_cast<const float*>(w4_hi + woff); p.B_lo = w4_lo + woff;

@@ -363,7 +363,7 @@ def _s2_dgrad_ps(dy, w, dx, N, H, W, Cin, Cout, ws, wsb):
     """dgrad of a stride-2 conv3x3 (Downsample) as four sub-pixel phases on the plane kernels (bf16x3 products, like every gradient
     contraction of the f16x3 mode): True when it ran.  The folded weight planes are cached per weight version."""
     from ._lib import get_precision
-    if not (_S2DGRAD_ON and get_precision() == "f16x3" and H % 2 == 0 and W % 2 == 0 and Cout % 32 == 0 and Cin % 4 == 0 and (W // 2) & (W // 2 - 1) == 0
+    if not (_S2DGRAD_ON and get_precision() in ("f16x3", "mixed16") and H % 2 == 0 and W % 2 == 0 and Cout % 32 == 0 and Cin % 4 == 0 and (W // 2) & (W // 2 - 1) == 0
             and W // 2 >= 8 and w.permute(0, 2, 3, 1).is_contiguous()):
         return False
     tag = (w.data_ptr(), w._version, _WEIGHT_EPOCH[0])

@@ -197,8 +197,18 @@ def _w16_conv(w):
 
 
 def conv_ok(N, H, W, Cin, Cout):
-    """a stride-1 conv3x3 the 16-bit nodes take: the window wgrad kernel's shapes, statistics chunks inside one image"""
-    return (H * W) % 32 == 0 and lib.cdae_conv3x3_wgrad_win_supported(N, H, W, Cin, Cout) == 1
+    """a stride-1 conv3x3 the 16-bit nodes take: channel counts the plane kernels accept.  Rows of 8 .. 64 pixels run the window kernels
+    (forward / dgrad / grouped wgrad); shorter rows (the 4 x 4 level) the plane GEMM's conv gather for forward and dgrad and the
+    fp32-operand wgrad on casts of the two (tiny) operands."""
+    return Cin % 32 == 0 and Cout % 32 == 0 and W >= 4 and H >= 4 and long_ok(N, H, W, max(Cin, Cout))
+
+
+def long_ok(N, H, W, C):
+    return N * H * W * C < (1 << 31)
+
+
+def _win_ok(N, H, W, Cin, Cout):
+    return lib.cdae_conv3x3_wgrad_win_supported(N, H, W, Cin, Cout) == 1
 
 
 def _conv_fwd(a16, w, b, res16, N, H, W, Cin, Cout, st, want_parts=True):
@@ -232,7 +242,20 @@ def _conv_bwd(a16, dy16, w, sinks, has_b, N, H, W, Cin, Cout, need_w, st):
         def wg(st_, ws_, wsb_, dw=dw, db=db):
             check(lib.cdae_conv3x3_wgrad_win(ptr(a16), ptr(a16), ptr(dy16), ptr(dy16), ptr(dw), ptr(db), N, H, W, Cin, Cout,
                                              1 if direct else 0, ws_, wsb_, st_))
-        if direct:
+        if not _win_ok(N, H, W, Cin, Cout):
+            # rows too short for the window kernel (4 x 4): the fp32-operand implicit GEMM on casts of the two small operands
+            a32, d32 = to32_raw(a16.permute(0, 3, 1, 2)), to32_raw(dy16.permute(0, 3, 1, 2))
+
+            def wg32(st_, ws_, wsb_, dw=dw, db=db):
+                check(lib.cdae_conv3x3_wgrad(ptr(a32), H * W * Cin, W * Cin, Cin, 1, ptr(d32), Cout, ptr(dw), ptr(db), N, H, W, Cin, Cout, 1, 0,
+                                             1 if direct else 0, ws_, wsb_, st_))
+            if direct:
+                ops.side_launch(dev, (a32, d32), wg32)
+                dw = db = None
+                ops._done(rw, rb)
+            else:
+                wg32(st, ws, wsb)
+        elif direct:
             ops.wgrad_win(dev, a16, dy16, dw, db, N, H, W, Cin, Cout)          # into the level's group launch
             dw = db = None
             ops._done(rw, rb)

@@ -76,7 +76,7 @@ def test_gn16_kernels_match_float64(mixed16):
 
 
 @pytest.mark.parametrize("window_kernel", [False, True])
-@pytest.mark.parametrize("shape", [(4, 256, 128, 16, True), (2, 128, 256, 32, False), (4, 128, 128, 8, False)])
+@pytest.mark.parametrize("shape", [(4, 256, 128, 16, True), (2, 128, 256, 32, False), (4, 128, 128, 8, False), (8, 256, 256, 4, False), (8, 512, 256, 4, True)])
 def test_resblock16_against_float64(mixed16, shape, window_kernel, expect_kernels):
     """ops16.resblock_train (identity / 1x1 skip, two-source input) against a float64 restatement of the reference ResBlock
     (unet.py:156-199) on the same bf16-rounded input: output, input gradients and every parameter gradient to bf16's bar — on the
@@ -86,6 +86,8 @@ def test_resblock16_against_float64(mixed16, shape, window_kernel, expect_kernel
     from causaldiffae_amd._lib import tune_scope
     import contextlib
     N, C, Cout, HW, cat = shape
+    if window_kernel and HW < 8:
+        pytest.skip("4 x 4 rows: the plane GEMM's conv gather, not the window kernel")
     with (tune_scope(convwin_min_tiles=1) if window_kernel else contextlib.nullcontext()), \
             (expect_kernels(convwin_dgrad=4) if window_kernel else contextlib.nullcontext()):
         _resblock16_case(N, C, Cout, HW, cat)

@@ -3,6 +3,10 @@ export TMPDIR=/tmp
 R=$PWD
 O=$R/gpurun_out/m32q
 mkdir -p $O
-python3 tools/train_step_m32.py 20 1 2>&1 | tail -1
-CDAE_WGRAD_STREAM=0 MODEL=m32 BATCH=256 FP16=1 TOP=60 timeout 300 python3 tools/train_shapes.py > $O/m32_shapes_fp16.txt 2>&1
-grep -E "gn_bwd|gn_apply|fam6|total" $O/m32_shapes_fp16.txt | head -34
+cd /tmp
+export CDAE_WGRAD_STREAM=0
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python3 $R/tools/train_step_m32.py 3 1 > $O/trace.log 2>&1
+python3 $R/tools/step_timeline.py $O/trace --end adamw_ema > $O/r05_m32_b256_mixed16_timeline_serial.txt 2>&1
+cp $O/trace/*kernel_stats.csv $O/r05_train_m32_b256_mixed16_kernel_stats_serial.csv
+rm -rf $O/trace
+head -70 $O/r05_m32_b256_mixed16_timeline_serial.txt
