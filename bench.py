@@ -214,6 +214,18 @@ def train_bench(dev, world, rank, steps, warmup, batch, regions=1, image_size=64
         rates.append(steps / dt)
         cpus.append(1e3 * cpu / steps)
     th1 = thread_cpu()
+    # kernel-family milliseconds of one step (HIP events around every launch of the library, outside the timed regions): where the step goes
+    from causaldiffae_amd import _lib as _l
+    torch.cuda.synchronize()
+    _l.prof_enable(True)
+    _l.prof_read()
+    for _ in range(2):
+        b, c = next(data)
+        loop.forward_backward(b, c)
+        loop.optimize_normal()
+    fam = _l.prof_read()
+    _l.prof_enable(False)
+    family_ms = {k: round(v["ms"] / 2, 3) for k, v in fam.items()}
     per_thread = sorted(((name, 1e3 * (cpu - th0.get(tid, ("", 0.0))[1]) / (steps * regions)) for tid, (name, cpu) in th1.items()), key=lambda kv: -kv[1])
     loss = float(loop.last_losses["loss"].mean().item())
     sps = statistics.median(rates)
@@ -230,6 +242,8 @@ def train_bench(dev, world, rank, steps, warmup, batch, regions=1, image_size=64
             "global_batch": batch * world, "images_per_sec": batch * world * sps, "model_tflops": tf, "roof_tflops": roof * world,
             "frac_of_roof": tf / (roof * world), "precision_mode": prec, "dtype": dtype,
             "steps": steps, "warmup": warmup, "last_loss": loss,
+            # (sum of kernel durations by family; with the side stream on, concurrent kernels both count in full)
+            "family_ms_per_step": family_ms,
             # CPU time of the hungriest rank (all its threads) per step; `world` such ranks share the cgroup quota on one node
             "host_cpu_ms_per_step": host_ms, "host_cpu_over_step": host_ms * sps / 1e3, "host_cpu_quota_cores": quota,
             "host_bound_risk": bool(world * host_ms * sps / 1e3 > 0.8 * quota),

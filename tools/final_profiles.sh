@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-end evidence in one gpurun call: PMC + kernel stats of the DDIM step and of the training step, per-shape tables.
 #   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/final_profiles.sh r02 v2'
-TAG=${1:-r04}; VER=${2:-v1}
+TAG=${1:-r05}; VER=${2:-v1}
 bash tools/profile_round.sh $TAG $VER 2>&1 | tail -40
 bash tools/profile_train.sh $TAG $VER 2>&1 | tail -25
 bash tools/prof_shapes.sh $TAG 2>&1 | tail -45

@@ -3,7 +3,7 @@
 #   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/profile_round.sh r02 v1'
 # Every rocprofv3 call runs under `timeout` (a pass that aborts inside the profiler otherwise hangs until gpurun's own limit).
 set -u
-TAG=${1:-r04}; VER=${2:-v1}
+TAG=${1:-r05}; VER=${2:-v1}
 export TMPDIR=/tmp
 R=$PWD
 O=$R/gpurun_out/prof_$VER

@@ -2,7 +2,7 @@
 # Training-step profile on the GPU box: kernel stats + PMC passes (run through gpurun from the repo root):
 #   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/profile_train.sh r01 v10'
 set -u
-TAG=${1:-r04}; VER=${2:-v1}
+TAG=${1:-r05}; VER=${2:-v1}
 export TMPDIR=/tmp
 R=$PWD
 O=$R/gpurun_out/proftrain_$VER
@@ -20,7 +20,7 @@ for K in wgwin_kernel 'convwin_kernel<true' 'convwin_kernel<false'; do
       --label "f16x3 / bf16x3, C64 training step, batch 32" --out $O/${TAG}_train_pmc_${N}.json >> $O/summary.log 2>&1
 done
 cp $O/trace/*kernel_stats.csv $O/${TAG}_train_c64_b32_kernel_stats_${VER}.csv 2>/dev/null
-python3 tools/step_timeline.py $O/trace --end adamw_ema_kernel > $O/${TAG}_train_step_timeline_${VER}.txt 2>&1
+python3 tools/step_timeline.py $O/trace --end adamw_ema > $O/${TAG}_train_step_timeline_${VER}.txt 2>&1
 tail -60 $O/summary.log
 rm -rf $O/fetch $O/write $O/sq $O/trace/*kernel_trace.csv 2>/dev/null
 du -sh $O

@@ -13,8 +13,8 @@ export CDAE_WGRAD_STREAM=0
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python3 $R/tools/train_step.py 3 32 > $O/trace.log 2>&1
 cd $R
 cp $O/trace/*kernel_stats.csv $O/${TAG}_train_c64_b32_kernel_stats_${VER}_serial.csv 2>/dev/null
-python3 tools/step_timeline.py $O/trace --end adamw_ema_kernel > $O/${TAG}_train_step_timeline_${VER}_serial.txt 2>&1
-python3 tools/step_timeline.py $O/trace --end adamw_ema_kernel --list > $O/${TAG}_train_step_list_${VER}_serial.txt 2>&1
+python3 tools/step_timeline.py $O/trace --end adamw_ema > $O/${TAG}_train_step_timeline_${VER}_serial.txt 2>&1
+python3 tools/step_timeline.py $O/trace --end adamw_ema --list > $O/${TAG}_train_step_list_${VER}_serial.txt 2>&1
 rm -rf $O/trace
 timeout 300 python3 tools/train_shapes.py > $O/train_shapes_serial.txt 2>&1
 timeout 300 python3 tools/exp_train.py > $O/exp_serial.txt 2>&1

@@ -2,7 +2,7 @@
 kernel's duration and the idle gap in front of it, (b) per-kernel-name totals of that step.  A step ends at `--end` (default: ddim_update_kernel).
 
     rocprofv3 --kernel-trace --output-format csv -d DIR -o t -- python3 bench.py --steps 2 --warmup 1 --regions 1 --no-graph ...
-    python3 tools/step_timeline.py DIR [--end adamw_ema_kernel] [--list]
+    python3 tools/step_timeline.py DIR [--end adamw_ema] [--list]
 """
 import collections, csv, glob, re, sys
 
