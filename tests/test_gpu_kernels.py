@@ -971,6 +971,50 @@ def test_wgrad_window_kernel_random_shapes(seed):
         _wgrad_window_case(N, H, W, 64 * rng.randint(1, 6), 64 * rng.randint(1, 6), rng.randint(0, 1))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_wgrad_window_group_launch(seed):
+    """cdae_conv3x3_wgrad_win_group: several weight gradients of DIFFERENT shapes (channel tiles, image sides, batch) in one launch —
+    descriptors in the kernel arguments, every block finds its own; the group's splits are sized together, so some members run split
+    (slabs + finish) and some unsplit in the same launch; more than twelve items go out as several launches.  Each member against
+    autograd in fp64 at the single launch's bar, accumulate on and off."""
+    import ctypes, random
+    from causaldiffae_amd._lib import WgItem, check, lib, ptr, stream, splitk_ws, SPLITK_BYTES
+    dev = "cuda:0"
+    rng = random.Random(500 + seed)
+    g = torch.Generator(device=dev).manual_seed(40 + seed)
+    n_items = [3, 7, 14][seed]
+    items, keep, checks = [], [], []
+    for i in range(n_items):
+        W = rng.choice([8, 16, 32])
+        H = W
+        N = rng.randint(1, 3 if W == 32 else 12)
+        Cin, Cout, acc = 64 * rng.randint(1, 4), 64 * rng.randint(1, 4), rng.randint(0, 1)
+        a = torch.randn(N, H, W, Cin, device=dev, generator=g)
+        dy = torch.randn(N, H, W, Cout, device=dev, generator=g) * 1e-3
+        ap = torch.empty((2, N, H, W, Cin), dtype=torch.bfloat16, device=dev)
+        dp = torch.empty((2, N, H, W, Cout), dtype=torch.bfloat16, device=dev)
+        check(lib.cdae_split_bf16(ptr(a), ptr(ap[0]), ptr(ap[1]), a.numel(), stream()))
+        check(lib.cdae_split_bf16(ptr(dy), ptr(dp[0]), ptr(dp[1]), dy.numel(), stream()))
+        dw0 = torch.randn(Cout, 3, 3, Cin, device=dev, generator=g) * 1e-2
+        db0 = torch.randn(Cout, device=dev, generator=g) * 1e-2
+        dw, db = dw0.clone(), db0.clone()
+        items.append(WgItem(ptr(ap[0]), ptr(ap[1]), ptr(dp[0]), ptr(dp[1]), ptr(dw), ptr(db), N, H, W, Cin, Cout, acc))
+        keep.append((ap, dp))
+        checks.append((ap, dp, dw0, db0, dw, db, acc))
+    arr = (WgItem * n_items)(*items)
+    check(lib.cdae_conv3x3_wgrad_win_group(arr, n_items, ptr(splitk_ws(torch.device(dev))), SPLITK_BYTES, stream()))
+    torch.cuda.synchronize()
+    for ap, dp, dw0, db0, dw, db, acc in checks:
+        a_q = (ap[0].float() + ap[1].float()).permute(0, 3, 1, 2)
+        dy_q = (dp[0].float() + dp[1].float()).permute(0, 3, 1, 2)
+        ref_w, ref_b = _wgrad_ref(a_q, dy_q)
+        if acc:
+            ref_w, ref_b = ref_w + dw0.double(), ref_b + db0.double()
+        assert (dw.double() - ref_w).abs().max().item() < 3e-5 * ref_w.abs().max().item()
+        assert (db.double() - ref_b).abs().max().item() < 3e-5 * ref_b.abs().max().item()
+
+
 def _wgrad_window_case(N, H, W, Cin, Cout, accumulate):
     from causaldiffae_amd._lib import check, lib, ptr, stream, splitk_ws, SPLITK_BYTES
     dev = "cuda:0"
