@@ -141,6 +141,7 @@ SIGNATURES = {
     "cdae_gn_apply16": [P, I, P, I, I, P, I, I, I, I, I, P, P, P, P, P, I, I, P],
     "cdae_gn_bwd16": [P, I, P, I, I, P, I, P, I, P, I, I, I, I, I, P, P, P, P, P, I, I, P, P, I, P, I, I, P, I, P, P],
     "cdae_attn16_supported": [I, I],
+    "cdae_rows16_supported": [I, I, I, I, I],
     "cdae_attn16_fwd": [P, P, P, I, I, I, I, P],
     "cdae_attn16_bwd": [P, P, P, P, P, P, I, I, I, I, P],
     "cdae_gn_parts16": [P, L, P, L, I, P],
@@ -359,7 +360,7 @@ class precision_scope:
         return False
 
 
-TUNE_KEYS = {"convwin_min_tiles": 0, "convwin_splitk": 1, "convwin_nj3": 2, "head_mfma": 3}
+TUNE_KEYS = {"convwin_min_tiles": 0, "convwin_splitk": 1, "convwin_nj3": 2, "head_mfma": 3, "rows16_min_m": 4, "rows16_ring": 5}
 
 
 class tune_scope:

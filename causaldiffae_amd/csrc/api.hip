@@ -448,6 +448,8 @@ int cdae_gemm16_ps(const void* a16, long lda, const void* b16, long ldb, const f
                    int K, int io, int accumulate, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
     if ((long)M * lda >= (1L << 31)) return cdae_fail("gemm16_ps: operand larger than 2^31 elements");
     if (!aligned16(a16) || !aligned16(b16) || K % 32 || lda % 8 || ldb % 8) return cdae_fail("gemm16_ps: K % 32 == 0 and 16-byte aligned rows required");
+    if (cdae_rows16_ok(a16, lda, b16, ldb, bias, res, c, ldc, gn_part, M, N, K, io, accumulate))
+        return cdae_rows16_gemm(a16, lda, b16, ldb, bias, res, c, ldc, M, N, K, io, stream);
     GemmParams p = base_params();
     p.presplit = 1; p.prec = 4; p.io16 = io & 3;
     p.A = reinterpret_cast<const float*>(a16); p.A_lo = reinterpret_cast<const unsigned short*>(a16);

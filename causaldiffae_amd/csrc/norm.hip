@@ -150,6 +150,69 @@ __global__ __launch_bounds__(256) void gn_finalize32_kernel(const T* __restrict_
     }
 }
 
+// Small images (the 8 x 8 / 16 x 16 levels, everything at the sampling script's batch 16): partial + finalize are two launches of pure
+// latency (6.7 + 3.8 us on 2 MB).  One block per (image, group) instead: grid (32, N), 256 threads walk the group's HW x cpg / 4 channel
+// vectors, fp32 sums of (x - pivot) per thread, f64 from the wave reduction on.  Same definition of mean / rstd / (a, b) as above.
+template <typename T = float>
+__global__ __launch_bounds__(256) void gn_stats_group_kernel(const T* __restrict__ x, int HW, int ldx, int cpg, float eps,
+                                                             float* __restrict__ mean, float* __restrict__ rstd,
+                                                             const T* __restrict__ x2, int ld2, int C1,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ ss, int ld_ss, int C, float* __restrict__ coef) {
+    __shared__ double sS[4], sQ[4];
+    __shared__ float sMR[2];
+    const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    const int vpp = cpg >> 2, total = HW * vpp;
+    int ldp;
+    const float pivot = ldv1(gn_src(x, ldx, x2, ld2, C1, (long)n * HW, g * cpg, ldp));
+    float S = 0.f, Q = 0.f;
+    auto acc4 = [&](const float4& v) {
+        float a = v.x - pivot, b = v.y - pivot, c = v.z - pivot, d = v.w - pivot;
+        S += (a + b) + (c + d);
+        Q += (a * a + b * b) + (c * c + d * d);
+    };
+    auto addr = [&](int idx) -> const T* {
+        const int pix = idx / vpp, v = idx - pix * vpp;
+        int ld;
+        const T* b = gn_src(x, ldx, x2, ld2, C1, (long)n * HW, g * cpg + 4 * v, ld);
+        return b + (long)pix * ld;
+    };
+    int idx = tid;
+    for (; idx + 3 * 256 < total; idx += 4 * 256) {
+        const float4 v0 = ldv4(addr(idx)), v1 = ldv4(addr(idx + 256)), v2 = ldv4(addr(idx + 512)), v3 = ldv4(addr(idx + 768));
+        acc4(v0); acc4(v1); acc4(v2); acc4(v3);
+    }
+    for (; idx < total; idx += 256) acc4(ldv4(addr(idx)));
+    double s = S, q = Q;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_down(s, o, 64); q += __shfl_down(q, o, 64); }
+    if ((tid & 63) == 0) { sS[tid >> 6] = s; sQ[tid >> 6] = q; }
+    __syncthreads();
+    if (tid == 0) {
+        s = (sS[0] + sS[1]) + (sS[2] + sS[3]); q = (sQ[0] + sQ[1]) + (sQ[2] + sQ[3]);
+        const double cnt = (double)HW * cpg;
+        const double m = s / cnt;
+        double var = q / cnt - m * m;
+        if (var < 0.0) var = 0.0;
+        const float mu = (float)((double)pivot + m), rs = (float)(1.0 / sqrt(var + (double)eps));
+        mean[n * 32 + g] = mu;
+        rstd[n * 32 + g] = rs;
+        sMR[0] = mu; sMR[1] = rs;
+    }
+    if (coef) {
+        __syncthreads();
+        if (tid < cpg) {
+            const int c = g * cpg + tid;
+            gn_coef_one(sMR[0], sMR[1], gamma[c], beta[c], ss, (long)n * ld_ss, C, c, coef + ((long)n * C + c) * 2);
+        }
+    }
+}
+// the one-launch form pays when the two-launch form is latency: a group's walk of at most 16 vectors per thread
+inline bool gn_small(int HW, int cpg, int groups) {
+    static const int cfg = CDAE_DEV_INT("CDAE_GN_SMALL", 1);
+    return cfg && groups == 32 && cpg % 4 == 0 && cpg <= 256 && (long)HW * (cpg >> 2) <= 4096 && HW <= 1024;
+}
+
 // grid N, G threads: stats[n*G+g] = mean, stats[N*G + n*G+g] = rstd
 __global__ void gn_finalize_kernel(const float* __restrict__ x, int HW, int ldx, int cpg, int G, int nchunk, float eps,
                                    const float* __restrict__ partial, float* __restrict__ mean, float* __restrict__ rstd,
@@ -1003,6 +1066,13 @@ int cdae_gn_stats(const float* x, int N, int HW, int C, int ldx, int groups, flo
     const int ppb = (HW + nchunk - 1) / nchunk;
     cdae_prof_begin(PROF_GN, (double)N * HW * C * 4.0, st);
     if (cdae_prof_on()) { char tag[96]; snprintf(tag, sizeof(tag), "cdae_gn_stats N=%d HW=%d C=%d", (int)N, (int)HW, (int)C); cdae_prof_tag(tag); }
+    if (VEC == 4 && gn_small(HW, cpg, groups)) {
+        hipLaunchKernelGGL((gn_stats_group_kernel<float>), dim3(32, N), dim3(256), 0, st, x, HW, ldx, cpg, eps, mean, rstd, (const float*)nullptr, 0, 0,
+                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, C, (float*)nullptr);
+        cdae_prof_end(PROF_GN, st);
+        CHECK_LAUNCH("gn_stats launch failed");
+        return 0;
+    }
     if (VEC == 4) hipLaunchKernelGGL(gn_partial_kernel<4>, dim3(nchunk, N), dim3(256), 0, st, x, HW, C, ldx, cpg, groups, ppb, ws);
     else hipLaunchKernelGGL(gn_partial_kernel<1>, dim3(nchunk, N), dim3(256), 0, st, x, HW, C, ldx, cpg, groups, ppb, ws);
     if (groups == 32) hipLaunchKernelGGL((gn_finalize32_kernel<float>), dim3(N), dim3(256), 0, st, x, HW, ldx, cpg, nchunk, eps, ws, mean, rstd, (const float*)nullptr, 0, 0);
@@ -1090,6 +1160,13 @@ int cdae_gn_stats16(const void* x1, int ld1, const void* x2, int ld2, int C1, in
     const int ppb = (HW + nchunk - 1) / nchunk;
     cdae_prof_begin(PROF_GN, (double)N * HW * C * 2.0, st);
     if (cdae_prof_on()) { char tag[96]; snprintf(tag, sizeof(tag), "cdae_gn_stats16 N=%d HW=%d C=%d", (int)N, (int)HW, (int)C); cdae_prof_tag(tag); }
+    if (gn_small(HW, cpg, groups)) {
+        hipLaunchKernelGGL((gn_stats_group_kernel<B>), dim3(32, N), dim3(256), 0, st, (const B*)x1, HW, ld1, cpg, eps, mean, rstd, (const B*)x2, ld2, x2 ? C1 : C,
+                           gamma, beta, scale_shift, ld_ss, C, coef);
+        cdae_prof_end(PROF_GN, st);
+        CHECK_LAUNCH("gn_stats16 launch failed");
+        return 0;
+    }
     hipLaunchKernelGGL((gn_partial_kernel<4, B>), dim3(nchunk, N), dim3(256), 0, st, (const B*)x1, HW, C, ld1, cpg, groups, ppb, ws, (const B*)x2, ld2, x2 ? C1 : C);
     hipLaunchKernelGGL((gn_finalize32_kernel<B>), dim3(N), dim3(256), 0, st, (const B*)x1, HW, ld1, cpg, nchunk, eps, ws, mean, rstd, (const B*)x2, ld2, x2 ? C1 : C,
                        gamma, beta, scale_shift, ld_ss, C, coef);
@@ -1200,6 +1277,13 @@ int cdae_gn_stats2_coef(const float* x1, int ld1, const float* x2, int ld2, int 
     const int ppb = (HW + nchunk - 1) / nchunk;
     cdae_prof_begin(PROF_GN, (double)N * HW * C * 4.0, st);
     if (cdae_prof_on()) { char tag[96]; snprintf(tag, sizeof(tag), "cdae_gn_stats2 N=%d HW=%d C=%d", (int)N, (int)HW, (int)C); cdae_prof_tag(tag); }
+    if (gn_small(HW, cpg, groups)) {
+        hipLaunchKernelGGL((gn_stats_group_kernel<float>), dim3(32, N), dim3(256), 0, st, x1, HW, ld1, cpg, eps, mean, rstd, x2, ld2, C1, gamma, beta,
+                           scale_shift, ld_ss, C, coef);
+        cdae_prof_end(PROF_GN, st);
+        CHECK_LAUNCH("gn_stats2 launch failed");
+        return 0;
+    }
     hipLaunchKernelGGL(gn_partial_kernel<4>, dim3(nchunk, N), dim3(256), 0, st, x1, HW, C, ld1, cpg, groups, ppb, ws, x2, ld2, C1);
     if (groups == 32) hipLaunchKernelGGL((gn_finalize32_kernel<float>), dim3(N), dim3(256), 0, st, x1, HW, ld1, cpg, nchunk, eps, ws, mean, rstd, x2, ld2, C1, gamma, beta,
                                          scale_shift, ld_ss, C, coef);

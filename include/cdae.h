@@ -461,8 +461,15 @@ int cdae_rep_loss_bwd(const float* mu, const float* var, const float* z_post, co
  *   CDAE_TUNE_CONVWIN_NJ3        (0)   256 x 96 tiles of the forward window kernel (Cout % 96 == 0, unsplit K): 0 = where they fill the
  *                                      block slots and 256 x 128 tiles do not, 1 = wherever they apply (tests), -1 = never
  *   CDAE_TUNE_HEAD_MFMA          (1)   the output head (cdae_head_conv_fwd) on v_mfma_f32_4x4x1 (exact fp32 products, like the scalar
- *                                      form it replaces: 0 = that form; the two differ in summation order only) */
-enum { CDAE_TUNE_CONVWIN_MIN_TILES = 0, CDAE_TUNE_CONVWIN_SPLITK = 1, CDAE_TUNE_CONVWIN_NJ3 = 2, CDAE_TUNE_HEAD_MFMA = 3 };
+ *                                      form it replaces: 0 = that form; the two differ in summation order only)
+ *   CDAE_TUNE_ROWS16_MIN_M       (8192) cdae_gemm16_ps with at least this many rows (K in {64, 128, 192, 256}, bf16 result / residual, no
+ *                                      GroupNorm sums / accumulation) runs on the streaming kernel of rows16.hip (weight fragments in
+ *                                      registers, activation rows global -> registers); below it on the plane GEMM, whose split-K
+ *                                      covers short row counts.  1: wherever it applies (tests)
+ *   CDAE_TUNE_ROWS16_RING        (1)   K = 256, N % 256 == 0 of that kernel: the rows of a step reach the four waves of a block through
+ *                                      an LDS ring filled by LDS-DMA several steps ahead; 0: every wave loads them into registers itself */
+enum { CDAE_TUNE_CONVWIN_MIN_TILES = 0, CDAE_TUNE_CONVWIN_SPLITK = 1, CDAE_TUNE_CONVWIN_NJ3 = 2, CDAE_TUNE_HEAD_MFMA = 3, CDAE_TUNE_ROWS16_MIN_M = 4,
+       CDAE_TUNE_ROWS16_RING = 5 };
 int cdae_tune_set(int key, int value);
 int cdae_tune_get(int key);       /* -1: unknown key */
 
@@ -499,6 +506,9 @@ int cdae_attn16_fwd(const void* qkv16, void* out16, float* lse, int B, int T, in
 int cdae_attn16_bwd(const void* qkv16, const void* out16, const void* dout16, const float* lse, float* dsum, void* dqkv16, int B, int T,
                     int heads, int ch, void* stream);
 int cdae_gn_parts16(const void* x, long ldx, float* parts, long M, int C, void* stream);      /* [ceil(M / 32)][C][2] sums of a bf16 tensor */
+/* 1: cdae_gemm16_ps with these dimensions (16-byte aligned operands, no GroupNorm sums, no accumulation) runs on the streaming
+   kernel of rows16.hip; 0: on the plane GEMM */
+int cdae_rows16_supported(int M, int N, int K, int io, int has_res);
 int cdae_cast_f32_bf16(const float* x, void* y, long n, void* stream);
 int cdae_cast_bf16_f32(const void* x, float* y, long n, void* stream);
 int cdae_upsample2_16(const void* x, void* y, int N, int H, int W, int C, void* stream);       /* nearest 2x of bf16 NHWC rows (unet.py:76-78) */

@@ -781,6 +781,47 @@ def test_groupnorm_coefficient_table_from_statistics_launch(from_parts, cat, wit
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,C,C1,S,bf16", [(16, 512, 0, 8, False), (16, 640, 384, 16, False), (32, 256, 0, 32, False), (3, 128, 0, 4, False),
+                                            (16, 512, 256, 8, True), (32, 256, 0, 16, True), (256, 256, 0, 4, True)])
+def test_groupnorm_statistics_one_launch_small_images(N, C, C1, S, bf16):
+    """Images of at most 4096 channel vectors per group take the one-launch statistics kernel (gn_stats_group_kernel: one block per
+    (image, group)) instead of partial + finalize: mean, rstd and the (a, b) table against an f64 statistic of the same rows, one and two
+    sources (a group that straddles the concatenation boundary included: C1 = 384 with 20 channels per group), fp32 and bf16 rows."""
+    from causaldiffae_amd._lib import check, lib, ptr, stream, workspace
+    g = torch.Generator(device="cuda:0").manual_seed(19)
+    dt = torch.bfloat16 if bf16 else torch.float32
+    x = (torch.randn(N, S, S, C, device="cuda:0", generator=g) * 1.7 + 0.6).to(dt)
+    a, b = (x[..., :C1].contiguous(), x[..., C1:].contiguous()) if C1 else (x, None)
+    gamma, beta = torch.randn(C, device="cuda:0", generator=g), torch.randn(C, device="cuda:0", generator=g)
+    ss = torch.randn(N, 2 * C, device="cuda:0", generator=g)
+    mean, rstd = torch.empty(N, 32, device="cuda:0"), torch.empty(N, 32, device="cuda:0")
+    coef = torch.empty(N, C, 2, device="cuda:0")
+    ws = workspace(torch.device("cuda:0"), "gn_test", 64 << 20)
+    ld1 = a.shape[-1]
+    if bf16:
+        check(lib.cdae_gn_stats16(ptr(a), ld1, ptr(b), b.shape[-1] if b is not None else 0, C1, N, S * S, C, 32, 1e-5, ptr(mean), ptr(rstd), ptr(gamma),
+                                  ptr(beta), ptr(ss), 2 * C, ptr(coef), ptr(ws), stream()))
+    else:
+        check(lib.cdae_gn_stats2_coef(ptr(a), ld1, ptr(b), b.shape[-1] if b is not None else 4, C1, N, S * S, C, 32, 1e-5, ptr(mean), ptr(rstd),
+                                      ptr(gamma), ptr(beta), ptr(ss), 2 * C, ptr(coef), ptr(ws), stream()))
+    xd = x.double().reshape(N, S * S, 32, C // 32)
+    m = xd.mean(dim=(1, 3))
+    v = xd.var(dim=(1, 3), unbiased=False)
+    r = 1.0 / torch.sqrt(v + 1e-5)
+    assert (mean.double() - m).abs().max().item() < 2e-6 * max(1.0, m.abs().max().item())
+    assert ((rstd.double() - r).abs() / r).max().item() < 2e-6
+    A = (r.repeat_interleave(C // 32, dim=1) * gamma.double()[None])
+    B = beta.double()[None] - m.repeat_interleave(C // 32, dim=1) * A
+    A2, B2 = A * (1 + ss[:, :C].double()), B * (1 + ss[:, :C].double()) + ss[:, C:].double()
+    assert (coef[:, :, 0].double() - A2).abs().max().item() < 1e-5 * max(1.0, A2.abs().max().item())
+    assert (coef[:, :, 1].double() - B2).abs().max().item() < 1e-5 * max(1.0, B2.abs().max().item())
+    if not bf16 and not C1:
+        m2, r2 = torch.empty_like(mean), torch.empty_like(rstd)
+        check(lib.cdae_gn_stats(ptr(x), N, S * S, C, C, 32, 1e-5, ptr(m2), ptr(r2), ptr(ws), stream()))
+        assert torch.equal(m2, mean) and torch.equal(r2, rstd)
+
+
+@pytest.mark.gpu
 def test_groupnorm_statistics_from_upconv_phases():
     """A sub-pixel up-conv leaves four segments of partial sums (one per output parity); the next GroupNorm folds them."""
     from causaldiffae_amd import ops

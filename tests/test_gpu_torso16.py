@@ -280,3 +280,61 @@ def test_attn16_kernels_against_float64(T, ch, heads, B):
     wantr = want.reshape(B, T, heads, 3, ch)
     for i, name in enumerate("qkv"):
         assert _rel(got[:, :, :, i], wantr[:, :, :, i]) < 2.5e-2, (name, _rel(got[:, :, :, i], wantr[:, :, :, i]))
+
+
+@pytest.mark.parametrize("M,N,K,io,bias,res", [
+    (5000, 256, 256, 1, True, False),        # ragged last row step
+    (16384, 768, 256, 1, True, False),       # qkv: three column blocks of four waves
+    (16384, 128, 128, 3, True, True),        # one 128-column group: the four waves of a block take four row steps; bf16 residual
+    (8192, 256, 128, 1, False, False),       # two groups: two row steps per block; no bias
+    (8200, 384, 256, 3, True, True),         # six groups: blocks of two
+    (33000, 256, 256, 3, True, True),        # more steps than wave slots: the persistent loop, both row buffers
+    (8200, 128, 64, 3, True, True),          # two K blocks
+    (4099, 768, 256, 3, True, True),         # ragged rows, three column blocks
+    (4100, 256, 192, 1, True, False),        # six K blocks
+    (5, 128, 128, 1, True, False),           # fewer rows than one step
+    (8192, 256, 768, 1, False, False),       # K > 256: stays on the plane GEMM (both calls identical)
+    (4100, 128, 128, 0, True, False),        # fp32 result: plane GEMM
+])
+def test_rows16_streaming_gemm(M, N, K, io, bias, res):
+    """rows16_reg_kernel (the torso's 1 x 1 convs / linears at large row counts: weight panel resident in LDS, activation fragments
+    global -> registers, operand-swapped MFMA so a lane owns 16 consecutive result columns) against float64 of the same bf16 operands, and
+    against the plane GEMM the same entry point dispatched before (identical up to the K order of fp32 additions and one bf16 rounding)."""
+    from causaldiffae_amd._lib import check, lib, ptr, stream, tune_scope
+    from causaldiffae_amd.ops16 import _sk
+    g = torch.Generator(device=DEV).manual_seed(23)
+    a = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=DEV, generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, device=DEV, generator=g) if bias else None
+    rdt = torch.bfloat16 if io & 2 else torch.float32
+    r = torch.randn(M, N, device=DEV, generator=g).to(rdt) if res else None
+    cdt = torch.bfloat16 if io & 1 else torch.float32
+    ws, wsb = _sk(torch.device(DEV))
+    outs = []
+    # the plane GEMM, then the streaming kernel wherever it has a form (K in {64, 128, 192, 256}, bf16 result / residual)
+    for cfg in (dict(rows16_min_m=1 << 30), dict(rows16_min_m=1), dict(rows16_min_m=1, rows16_ring=0)):
+        c = torch.full((M, N), float("nan"), device=DEV, dtype=cdt)
+        with tune_scope(**cfg):
+            check(lib.cdae_gemm16_ps(ptr(a), K, ptr(w), K, ptr(b), ptr(r), ptr(c), N, None, M, N, K, io, 0, ws, wsb, stream()))
+        outs.append(c)
+    ref = a.double() @ w.double().t()
+    if bias:
+        ref = ref + b.double()[None]
+    if res:
+        ref = ref + r.double()
+    tol = 6e-3 if io & 1 else 2e-5           # bf16 result: one rounding (2^-8 relative); fp32: accumulation order
+    scale = ref.abs().max().item()
+    for o in outs:
+        assert torch.isfinite(o).all()
+        assert (o.double() - ref).abs().max().item() < tol * scale
+
+
+def test_rows16_is_what_the_torso_launches():
+    """At BASELINE config [1]'s row counts cdae_gemm16_ps takes the streaming kernel, below the threshold (and for K > 256, fp32 results)
+    the plane GEMM: the library's own dispatch predicate."""
+    from causaldiffae_amd._lib import lib
+    assert lib.cdae_tune_get(4) == 8192
+    assert lib.cdae_rows16_supported(65536, 256, 256, 1, 0) == 1 and lib.cdae_rows16_supported(262144, 128, 128, 3, 1) == 1
+    assert lib.cdae_rows16_supported(65536, 768, 256, 1, 0) == 1
+    assert lib.cdae_rows16_supported(4096, 256, 256, 1, 0) == 0 and lib.cdae_rows16_supported(65536, 256, 768, 1, 0) == 0
+    assert lib.cdae_rows16_supported(65536, 256, 256, 0, 0) == 0
