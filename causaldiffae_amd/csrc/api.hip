@@ -486,6 +486,8 @@ int cdae_linear_dgrad_io(const float* dy, long lddy, const float* w, long ldw, v
 // dw[N][K] (+)= dy^T . x over M rows, dbias (+)= column sums of dy; dy / x fp32 or bf16 rows by io bits 4 / 8
 int cdae_linear_wgrad_io(const void* x, long ldx, const void* dy, long lddy, float* dw, long lddw, float* dbias, int M, int N, int K, int io,
                          int accumulate, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    if (splitk_ws && cdae_wg16_ok(x, ldx, dy, lddy, dw, lddw, M, N, K, io, splitk_ws_bytes))
+        return cdae_wg16(x, ldx, dy, lddy, dw, lddw, dbias, M, N, K, accumulate, splitk_ws, splitk_ws_bytes, stream);
     GemmParams p = base_params();
     p.A = reinterpret_cast<const float*>(dy); p.B = reinterpret_cast<const float*>(x); p.C = dw;
     p.M = N; p.N = K; p.K = M; p.lda = lddy; p.ldb = ldx; p.ldc = lddw; p.accumulate = accumulate; p.grad_operand = 1; p.prec = 4;

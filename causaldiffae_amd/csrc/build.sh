@@ -6,7 +6,7 @@ cd "$(dirname "$0")"
 OUT=../libcdae.so
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="${EXTRA_HIPCC_FLAGS:-} --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -Wno-inline-asm -I../../include"
-UNITS="igemm planes api norm elementwise prof attention attn16 rows16 wgrad stem convwin skipgn head"
+UNITS="igemm planes api norm elementwise prof attention attn16 rows16 wg16 wgrad stem convwin skipgn head"
 mkdir -p build
 # (the flag record is written only after every compile step has succeeded: a failed build after a flag change must not leave
 #  objects of the old flag set looking current)

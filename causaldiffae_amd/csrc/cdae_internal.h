@@ -87,6 +87,13 @@ struct GemmParams {
 };
 
 int cdae_gemm_dispatch(GemmParams p, void* stream);
+#ifdef __HIPCC__
+int cdae_splitk_finish(const GemmParams& p, bool gn_finish_ok, hipStream_t st);      // igemm.hip
+#endif
+// wg16.hip: weight gradient of a 1 x 1 conv / linear from bf16 rows (cdae_linear_wgrad_io dispatches)
+int cdae_wg16_ok(const void* x, long ldx, const void* dy, long lddy, const float* dw, long lddw, int M, int N, int K, int io, size_t ws_bytes);
+int cdae_wg16(const void* x, long ldx, const void* dy, long lddy, float* dw, long lddw, float* dbias, int M, int N, int K, int accumulate, float* ws,
+              size_t ws_bytes, void* stream);
 // convwin.hip: second-generation window-resident conv3x3 on pre-split planes
 bool cdae_convwin_ok(const GemmParams& p);
 int cdae_convwin_launch(const GemmParams& p, void* stream);

@@ -728,6 +728,15 @@ __global__ __launch_bounds__(256) void splitk_reduce4_kernel(const GemmParams p)
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         const float4* slab = ws + idx;
         int k = 0;
+        // (many slabs over a small result — wg16.hip's row splits — leave few threads, each with a long chain of loads: eight in flight;
+        //  the additions stay in slab order, so the result does not depend on which loop ran)
+        for (; k + 8 <= p.ksplit; k += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = slab[(k + u) * kstride4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
         for (; k + 4 <= p.ksplit; k += 4) {
             const float4 v0 = slab[k * kstride4], v1 = slab[(k + 1) * kstride4], v2 = slab[(k + 2) * kstride4], v3 = slab[(k + 3) * kstride4];
             s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
@@ -901,6 +910,29 @@ extern "C" int cdae_set_default_precision(int prec) {
     return 0;
 }
 
+// The finish of a K-split launch: p.ksplit dense [batch][M][N] slabs at p.splitk_ws -> C (alpha, bias, residual, activation, accumulate,
+// plane output), optionally leaving the next GroupNorm's partial sums.  Also what wg16.hip's weight-gradient kernel ends with.
+int cdae_splitk_finish(const GemmParams& p, bool gn_finish_ok, hipStream_t st) {
+    int rc = 0;
+    long total = (long)p.batch * p.M * p.N;
+    static const int cfg_red4 = CDAE_DEV_INT("CDAE_SPLITK_REDUCE4", 1);
+    auto al16 = [](const void* q) { return (reinterpret_cast<size_t>(q) & 15) == 0; };
+    const bool vec4 = cfg_red4 && p.batch == 1 && p.out_mode == OUT_ROWMAJOR && p.N % 4 == 0 && p.ldc % 4 == 0 && al16(p.C) && al16(p.res) && al16(p.bias) &&
+                      al16(p.splitk_ws) && ((long)p.M * p.N) % 4 == 0;
+    if (vec4) total >>= 2;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (p.gn_part && !gn_finish_ok) rc = cdae_fail("K was split but this launch cannot leave GroupNorm partial sums from the finish");
+    else if (p.gn_part) {
+        if (!(al16(p.C) && al16(p.res) && al16(p.bias) && al16(p.splitk_ws))) rc = cdae_fail("split-K finish with GroupNorm sums: 16-byte aligned result, residual, bias and workspace required");
+        else hipLaunchKernelGGL(splitk_reduce_gn_kernel, dim3((unsigned)(((p.M + 31) / 32) * ((p.N + 127) / 128))), dim3(256), 0, st, p);
+    }
+    else if (vec4) hipLaunchKernelGGL(splitk_reduce4_kernel, dim3(blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+    if (hipGetLastError() != hipSuccess) rc = cdae_fail("splitk reduce launch failed");
+    return rc;
+}
+
 // Heuristics: 128x128 tiles when they fill the chip (>= ~1 block per CU), else 64x64; split-K when even
 // 64x64 tiles leave CUs idle and K is deep (low-resolution levels at small batch, wgrad).
 int cdae_gemm_dispatch(GemmParams p, void* stream) {
@@ -1026,24 +1058,7 @@ int cdae_gemm_dispatch(GemmParams p, void* stream) {
     else CASE(A_CONV_GEN, B_WDGRAD_MC);
     else rc = cdae_fail("unsupported igemm operand mode combination");
 #undef CASE
-    if (rc == 0 && ks > 1) {
-        long total = (long)p.batch * p.M * p.N;
-        static const int cfg_red4 = CDAE_DEV_INT("CDAE_SPLITK_REDUCE4", 1);
-        auto al16 = [](const void* q) { return (reinterpret_cast<size_t>(q) & 15) == 0; };
-        const bool vec4 = cfg_red4 && p.batch == 1 && p.out_mode == OUT_ROWMAJOR && p.N % 4 == 0 && p.ldc % 4 == 0 && al16(p.C) && al16(p.res) && al16(p.bias) &&
-                          al16(p.splitk_ws) && ((long)p.M * p.N) % 4 == 0;
-        if (vec4) total >>= 2;
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 4096) blocks = 4096;
-        if (p.gn_part && !gn_finish_ok) rc = cdae_fail("K was split but this launch cannot leave GroupNorm partial sums from the finish");
-        else if (p.gn_part) {
-            if (!(al16(p.C) && al16(p.res) && al16(p.bias) && al16(p.splitk_ws))) rc = cdae_fail("split-K finish with GroupNorm sums: 16-byte aligned result, residual, bias and workspace required");
-            else hipLaunchKernelGGL(splitk_reduce_gn_kernel, dim3((unsigned)(((p.M + 31) / 32) * ((p.N + 127) / 128))), dim3(256), 0, st, p);
-        }
-        else if (vec4) hipLaunchKernelGGL(splitk_reduce4_kernel, dim3(blocks), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
-        if (hipGetLastError() != hipSuccess) rc = cdae_fail("splitk reduce launch failed");
-    }
+    if (rc == 0 && ks > 1) rc = cdae_splitk_finish(p, gn_finish_ok, st);
     cdae_prof_end(PROF_IGEMM, st);
     return rc;
 }

@@ -188,24 +188,26 @@ __global__ __launch_bounds__(256, 2) void rows16_ring_kernel(const RowsParams p)
     const unsigned a_base = (unsigned)(size_t)a_ring, r_base = (unsigned)(size_t)r_ring;        // LDS byte addresses (the low 32 bits of a shared pointer)
     // this lane's share of a step: rows 4 wave + 2 e + (lane >> 5), LDS piece lane & 31 <- global piece swizzled with the row
     const int ja = lane & 31;
+    // (a fetch past the block's last step keeps the operation count of the loop static — the vmcnt below is a constant — but must not
+    //  cost bandwidth: every lane then reads the same 16 bytes of the weight, one hot cache line, into a slot nobody reads again)
     auto fetch = [&](int r, int slot) {
-        const int rc = r <= last ? r : last;
+        const bool live = r <= last;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int rl = 4 * wave + 2 * e + (lane >> 5);
-            int row = rc * 16 + rl;
+            int row = r * 16 + rl;
             if (row >= p.M) row = p.M - 1;
             const int pc = (ja & 16) | ((ja ^ rl) & 15);
-            cdae_lds_dma16(p.A + (long)row * p.lda + pc * 8, a_base + slot * STEP_B + (4 * wave + 2 * e) * 512);
+            cdae_lds_dma16(live ? p.A + (long)row * p.lda + pc * 8 : p.B, a_base + slot * STEP_B + (4 * wave + 2 * e) * 512);
         }
         if (RES) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int rl = 8 * e + (lane >> 3);
-                int row = rc * 16 + rl;
+                int row = r * 16 + rl;
                 if (row >= p.M) row = p.M - 1;
                 const int pc = (lane & 7) ^ ((rl >> 1) & 7);
-                cdae_lds_dma16(p.res + (long)row * p.ldc + n0 + pc * 8, r_base + (slot * 4 + wave) * RES_B + e * 1024);
+                cdae_lds_dma16(live ? p.res + (long)row * p.ldc + n0 + pc * 8 : p.B, r_base + (slot * 4 + wave) * RES_B + e * 1024);
             }
         }
     };

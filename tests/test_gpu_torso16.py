@@ -338,3 +338,41 @@ def test_rows16_is_what_the_torso_launches():
     assert lib.cdae_rows16_supported(65536, 768, 256, 1, 0) == 1
     assert lib.cdae_rows16_supported(4096, 256, 256, 1, 0) == 0 and lib.cdae_rows16_supported(65536, 256, 768, 1, 0) == 0
     assert lib.cdae_rows16_supported(65536, 256, 256, 0, 0) == 0
+
+
+@pytest.mark.parametrize("M,N,K,acc,wide,bias", [
+    (8192, 256, 256, False, False, True),       # four tiles of dW on one XCD per row range
+    (5000, 256, 256, True, False, True),        # rows not a multiple of the 32-row step (zero-filled tail), accumulate into dW / dbias
+    (16384, 768, 256, False, True, True),       # twelve tiles; operands are column slices of wider tensors (row pitch > channels)
+    (40000, 128, 128, False, False, True),      # one tile, many row splits
+    (8192, 128, 256, False, False, False),      # no bias gradient
+    (66000, 256, 128, False, False, True),
+])
+def test_wg16_weight_gradient_from_bf16_rows(M, N, K, acc, wide, bias):
+    """wg16_kernel (weight / bias gradient of the torso's 1 x 1 convs and linears: rows by LDS-DMA ring, transpose-read fragments,
+    row-split partial slabs + the general finish) against float64 of the same bf16 operands, and against the general GEMM path the same
+    entry point (cdae_linear_wgrad_io, io = 12) took before."""
+    from causaldiffae_amd._lib import check, lib, ptr, stream, tune_scope
+    from causaldiffae_amd.ops16 import _sk
+    g = torch.Generator(device=DEV).manual_seed(31)
+    xw = torch.randn(M, K + (64 if wide else 0), device=DEV, generator=g).to(torch.bfloat16)
+    dw_ = torch.randn(M, N + (128 if wide else 0), device=DEV, generator=g).to(torch.bfloat16)
+    x, dy = xw[:, :K], dw_[:, (128 if wide else 0):]
+    init_w = torch.randn(N, K, device=DEV, generator=g)
+    init_b = torch.randn(N, device=DEV, generator=g)
+    ws, wsb = _sk(torch.device(DEV))
+    outs = []
+    for min_m in (1, 1 << 30):
+        dW, db = init_w.clone(), init_b.clone()
+        with tune_scope(rows16_min_m=min_m):
+            check(lib.cdae_linear_wgrad_io(ptr(x), xw.shape[1], ptr(dy), dw_.shape[1], ptr(dW), K, ptr(db) if bias else None, M, N, K, 12, 1 if acc else 0,
+                                           ws, wsb, stream()))
+        outs.append((dW, db))
+    ref_w = dy.double().t() @ x.double() + (init_w.double() if acc else 0)
+    ref_b = dy.double().sum(0) + (init_b.double() if acc else 0)
+    sw, sb = ref_w.abs().max().item(), ref_b.abs().max().item()
+    for dW, db in outs:
+        assert torch.isfinite(dW).all()
+        assert (dW.double() - ref_w).abs().max().item() < 2e-5 * sw
+        if bias:
+            assert (db.double() - ref_b).abs().max().item() < 2e-5 * sb
