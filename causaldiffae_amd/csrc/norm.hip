@@ -207,10 +207,12 @@ __global__ __launch_bounds__(256) void gn_stats_group_kernel(const T* __restrict
         }
     }
 }
-// the one-launch form pays when the two-launch form is latency: a group's walk of at most 16 vectors per thread
-inline bool gn_small(int HW, int cpg, int groups) {
+// the one-launch form pays where the two-launch form is pure latency (11 us): a group's walk of at most 16 vectors per thread AND a tensor
+// of a few MB — a block reads cpg-channel pieces of its image's rows (32..64 bytes each), which streams at a fraction of the chunked
+// kernel's rate (N = 256, 1024 pixels, 128 channels: 142 us against 25)
+inline bool gn_small(int N, int HW, int C, int cpg, int groups, int elt) {
     static const int cfg = CDAE_DEV_INT("CDAE_GN_SMALL", 1);
-    return cfg && groups == 32 && cpg % 4 == 0 && cpg <= 256 && (long)HW * (cpg >> 2) <= 4096 && HW <= 1024;
+    return cfg && groups == 32 && cpg % 4 == 0 && cpg <= 256 && (long)HW * (cpg >> 2) <= 4096 && HW <= 1024 && (long)N * HW * C * elt <= (6L << 20);
 }
 
 // grid N, G threads: stats[n*G+g] = mean, stats[N*G + n*G+g] = rstd
@@ -1066,7 +1068,7 @@ int cdae_gn_stats(const float* x, int N, int HW, int C, int ldx, int groups, flo
     const int ppb = (HW + nchunk - 1) / nchunk;
     cdae_prof_begin(PROF_GN, (double)N * HW * C * 4.0, st);
     if (cdae_prof_on()) { char tag[96]; snprintf(tag, sizeof(tag), "cdae_gn_stats N=%d HW=%d C=%d", (int)N, (int)HW, (int)C); cdae_prof_tag(tag); }
-    if (VEC == 4 && gn_small(HW, cpg, groups)) {
+    if (VEC == 4 && gn_small(N, HW, C, cpg, groups, 4)) {
         hipLaunchKernelGGL((gn_stats_group_kernel<float>), dim3(32, N), dim3(256), 0, st, x, HW, ldx, cpg, eps, mean, rstd, (const float*)nullptr, 0, 0,
                            (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, C, (float*)nullptr);
         cdae_prof_end(PROF_GN, st);
@@ -1160,7 +1162,7 @@ int cdae_gn_stats16(const void* x1, int ld1, const void* x2, int ld2, int C1, in
     const int ppb = (HW + nchunk - 1) / nchunk;
     cdae_prof_begin(PROF_GN, (double)N * HW * C * 2.0, st);
     if (cdae_prof_on()) { char tag[96]; snprintf(tag, sizeof(tag), "cdae_gn_stats16 N=%d HW=%d C=%d", (int)N, (int)HW, (int)C); cdae_prof_tag(tag); }
-    if (gn_small(HW, cpg, groups)) {
+    if (gn_small(N, HW, C, cpg, groups, 2)) {
         hipLaunchKernelGGL((gn_stats_group_kernel<B>), dim3(32, N), dim3(256), 0, st, (const B*)x1, HW, ld1, cpg, eps, mean, rstd, (const B*)x2, ld2, x2 ? C1 : C,
                            gamma, beta, scale_shift, ld_ss, C, coef);
         cdae_prof_end(PROF_GN, st);
@@ -1277,7 +1279,7 @@ int cdae_gn_stats2_coef(const float* x1, int ld1, const float* x2, int ld2, int 
     const int ppb = (HW + nchunk - 1) / nchunk;
     cdae_prof_begin(PROF_GN, (double)N * HW * C * 4.0, st);
     if (cdae_prof_on()) { char tag[96]; snprintf(tag, sizeof(tag), "cdae_gn_stats2 N=%d HW=%d C=%d", (int)N, (int)HW, (int)C); cdae_prof_tag(tag); }
-    if (gn_small(HW, cpg, groups)) {
+    if (gn_small(N, HW, C, cpg, groups, 4)) {
         hipLaunchKernelGGL((gn_stats_group_kernel<float>), dim3(32, N), dim3(256), 0, st, x1, HW, ld1, cpg, eps, mean, rstd, x2, ld2, C1, gamma, beta,
                            scale_shift, ld_ss, C, coef);
         cdae_prof_end(PROF_GN, st);

@@ -784,7 +784,7 @@ def test_groupnorm_coefficient_table_from_statistics_launch(from_parts, cat, wit
 @pytest.mark.parametrize("N,C,C1,S,bf16", [(16, 512, 0, 8, False), (16, 640, 384, 16, False), (32, 256, 0, 32, False), (3, 128, 0, 4, False),
                                             (16, 512, 256, 8, True), (32, 256, 0, 16, True), (256, 256, 0, 4, True)])
 def test_groupnorm_statistics_one_launch_small_images(N, C, C1, S, bf16):
-    """Images of at most 4096 channel vectors per group take the one-launch statistics kernel (gn_stats_group_kernel: one block per
+    """Tensors of a few MB whose groups hold at most 4096 channel vectors take the one-launch statistics kernel (gn_stats_group_kernel: one block per
     (image, group)) instead of partial + finalize: mean, rstd and the (a, b) table against an f64 statistic of the same rows, one and two
     sources (a group that straddles the concatenation boundary included: C1 = 384 with 20 channels per group), fp32 and bf16 rows."""
     from causaldiffae_amd._lib import check, lib, ptr, stream, workspace
