@@ -387,6 +387,11 @@ def main():
                 train["config1_m32_b256"]["mixed16"] = train_bench(dev, world, rank, 20, 3, 256, regions=2, use_fp16=True, workload=wl + " (use_fp16)", **m32)
                 a, b = train["config1_m32_b256"]["mixed16"]["value"], train["config1_m32_b256"]["f16x3"]["value"]
                 train["config1_m32_b256"]["mixed16_over_f16x3"] = a / b
+                # the same torso under the C64 leg's own workload (reference: `--use_fp16 True` on the 64 x 64 configuration); the leg's headline
+                # value above stays the parity mode's
+                torch.cuda.empty_cache()
+                train["mixed16_torso"] = train_bench(dev, world, rank, 20, 3, args.train_batch, regions=2, use_fp16=True)
+                train["mixed16_torso_over_f16x3"] = train["mixed16_torso"]["value"] / train["value"]
         except Exception as e:                      # never lose the headline line to the secondary leg
             train = {**(train or {}), "error": f"{type(e).__name__}: {e}"[:300]}
     cfg = {**su.model_and_diffusion_defaults(), "image_size": 64, "in_channels": 4, "n_vars": 4, "rep_cond": True,

@@ -198,9 +198,11 @@ def test_attention_block16_and_upconv16_against_float64(mixed16, C, heads):
     assert _rel(xd.grad, xr.grad) < 2e-2 and _rel(wd.grad, wr.grad) < 2e-2 and _rel(bd.grad, br.grad) < 2e-2
 
 
-def test_full_model_step_on_the_16bit_torso_matches_fp32_storage():
-    """One training_losses + backward of the M32 model (BASELINE config [1]'s architecture) with convert_to_fp16(): the 16-bit torso against
-    the same model in the parity mode — loss within 2e-2, every large gradient tensor within 8e-2 of its own scale and well
+@pytest.mark.parametrize("arch", ["m32", "c64"])
+def test_full_model_step_on_the_16bit_torso_matches_fp32_storage(arch):
+    """One training_losses + backward of the M32 model (BASELINE config [1]'s architecture) and of the C64 model (64 x 64, 93 M parameters:
+    channel counts of 384 / 512 and attention head widths the bf16 attention core does not take) with convert_to_fp16(): the 16-bit torso
+    against the same model in the parity mode — loss within 2e-2, every large gradient tensor within 8e-2 of its own scale and well
     correlated; and with the torso toggled off (fp32 storage, one-plane products: the round-3 behaviour) the same bar holds."""
     import bench
     from causaldiffae_amd import ops
@@ -208,20 +210,22 @@ def test_full_model_step_on_the_16bit_torso_matches_fp32_storage():
     from improved_diffusion.train_util import TrainLoop
     dev = torch.device(DEV)
     g = torch.Generator().manual_seed(5)
-    N = 8
-    x0 = torch.rand(N, 1, 32, 32, generator=g) * 2 - 1
-    cond = {"c": torch.rand(N, 2, generator=g), "y": torch.randint(0, 10, (N,), generator=g)}
+    S, Cin, nv, N = (32, 1, 2, 8) if arch == "m32" else (64, 3, 4, 4)
+    x0 = torch.rand(N, Cin, S, S, generator=g) * 2 - 1
+    cond = {"c": torch.rand(N, nv, generator=g)}
+    if arch == "m32":
+        cond["y"] = torch.randint(0, 10, (N,), generator=g)
     t = torch.randint(0, 1000, (N,), generator=g)
-    noise = torch.randn(N, 1, 32, 32, generator=g)
+    noise = torch.randn(N, Cin, S, S, generator=g)
 
     def run(fp16, torso=True):
-        cfg = {**su.model_and_diffusion_defaults(), "image_size": 32, "in_channels": 1, "n_vars": 2, "rep_cond": True, "causal_modeling": True,
-               "class_cond": True}
+        cfg = {**su.model_and_diffusion_defaults(), "image_size": S, "in_channels": Cin, "n_vars": nv, "rep_cond": True, "causal_modeling": True,
+               "class_cond": arch == "m32"}
         model, diff = su.create_model_and_diffusion(**cfg)
         bench.randomize(model, 4321)
         model.to(dev).train()
         loop = TrainLoop(model=model, diffusion=diff, data=iter(()), batch_size=N, microbatch=-1, lr=1e-4, ema_rate="0.9999", log_interval=10 ** 9,
-                         save_interval=10 ** 9, resume_checkpoint="", rep_cond=True, n_vars=2, causal_modeling=True, in_channels=1, use_fp16=fp16)
+                         save_interval=10 ** 9, resume_checkpoint="", rep_cond=True, n_vars=nv, causal_modeling=True, in_channels=Cin, use_fp16=fp16)
         diff.kl_weight = 0.1
         from causaldiffae_amd._lib import precision_scope
         with ops.path_scope(torso16=torso), precision_scope(getattr(model, "_cdae_precision", None)):

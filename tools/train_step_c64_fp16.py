@@ -1,0 +1,10 @@
+"""Dev tool: the C64 batch-32 training step on the 16-bit torso (use_fp16 / mixed16) — not a bench leg (the C64 leg is quoted in the parity
+mode); what the torso does for the reference's largest configuration."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+dev = torch.device("cuda:0")
+for fp16 in (True, False):
+    r = bench.train_bench(dev, 1, 0, int(sys.argv[1]) if len(sys.argv) > 1 else 20, 3, 32, regions=2, use_fp16=fp16)
+    print({k: r[k] for k in ("value", "ms_per_step", "precision_mode", "last_loss")})
