@@ -201,7 +201,7 @@ def test_attention_block16_and_upconv16_against_float64(mixed16, C, heads):
 @pytest.mark.parametrize("arch", ["m32", "c64"])
 def test_full_model_step_on_the_16bit_torso_matches_fp32_storage(arch):
     """One training_losses + backward of the M32 model (BASELINE config [1]'s architecture) and of the C64 model (64 x 64, 93 M parameters:
-    channel counts of 384 / 512 and attention head widths the bf16 attention core does not take) with convert_to_fp16(): the 16-bit torso
+    channel counts of 384 / 512 that the streaming 1 x 1 kernels do not take, attention heads of 96 and 128 channels) with convert_to_fp16(): the 16-bit torso
     against the same model in the parity mode — loss within 2e-2, every large gradient tensor within 8e-2 of its own scale and well
     correlated; and with the torso toggled off (fp32 storage, one-plane products: the round-3 behaviour) the same bar holds."""
     import bench
