@@ -37,6 +37,8 @@ struct RowsParams {
     int M, N, K, tiles, panels, lanes, rsub;
 };
 
+constexpr int R16_RING_LDS = 76 * 1024;      // ring bytes per block of the LDS-ring form (two blocks per CU with the bias table beside it)
+
 __device__ __forceinline__ float bf2f(unsigned short u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
 
 // The loops below are written WITHOUT data-dependent branches around their memory operations: rows past M are clamped to M - 1 (their
@@ -157,11 +159,17 @@ __global__ __launch_bounds__(256, 2) void rows16_reg_kernel(const RowsParams p) 
 //   one piece each) then covers the 64 banks once; the DMA lands linearly, so the swizzle is applied to the GLOBAL address of a lane.
 //   vmcnt: per step a wave issues 2 (+ 2) DMAs and 2 stores; at the wait of step s the operations younger than DMA(s) are D store pairs
 //   and D - 1 DMA groups, all counted statically (rows past the end are clamped like above, the ring keeps fetching the last step).
-template <bool RES>
+template <int KB, int NSW, bool RES>
 __global__ __launch_bounds__(256, 2) void rows16_ring_kernel(const RowsParams p) {
-    constexpr int KB = 8, NSW = 4, D = RES ? 3 : 5, R = D + 1;
-    constexpr int STEP_B = 16 * 512, RES_B = 16 * 128;                   // bytes of a step's rows; of a wave's residual piece
-    constexpr int WAITN = D * 2 + (D - 1) * (RES ? 4 : 2);
+    // KB = K / 32 (a multiple of 4: the four waves fetch a quarter of a step each), NSW = 4 (64 channels per wave: K = 256) or 2 (32
+    // channels per wave: K = 384, 512 — the weight fragments stay at 96 / 128 VGPRs)
+    constexpr int ROW_B = KB * 64, STEP_B = 16 * ROW_B;                   // bytes of a row, of a step's rows
+    constexpr int CW = NSW * 16, RROW_B = CW * 2, RES_B = 16 * RROW_B;    // a wave's channels; bytes of a residual row, of a wave's residual piece
+    constexpr int NA = KB / 4, NR = RES ? RES_B / 1024 : 0;               // DMAs per wave and step: rows, residual
+    constexpr int STORES = CW / 32;                                       // (16 consecutive columns per lane = two stores; 8 = one)
+    constexpr int D = (R16_RING_LDS / (STEP_B + (RES ? 4 * RES_B : 0))) - 1 > 5 ? 5 : (R16_RING_LDS / (STEP_B + (RES ? 4 * RES_B : 0))) - 1, R = D + 1;
+    constexpr int WAITN = D * STORES + (D - 1) * (NA + NR);
+    static_assert(KB % 4 == 0 && (NSW == 4 || NSW == 2) && D >= 2, "rows16 ring: unsupported shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* a_ring = lds;
     unsigned char* r_ring = lds + R * STEP_B;                            // [slot][wave][RES_B]
@@ -170,43 +178,45 @@ __global__ __launch_bounds__(256, 2) void rows16_ring_kernel(const RowsParams p)
     const int i16 = lane & 15, q = lane >> 4;
     const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
     const int cb = slot0 % p.panels, tl = slot0 / p.panels;
-    const int n0 = (cb * 4 + wave) * 64;
+    const int n0 = (cb * 4 + wave) * CW;
     const int step = 8 * p.lanes;
     int rs = xcd + 8 * tl;
-    bias_s[tid] = p.bias ? p.bias[cb * 256 + tid] : 0.f;
+    if (tid < 4 * CW) bias_s[tid] = p.bias ? p.bias[cb * 4 * CW + tid] : 0.f;
     if (rs >= p.tiles) return;                                            // (block-uniform)
     const int last = rs + ((p.tiles - 1 - rs) / step) * step;
 
+    // weight fragments; subtile s, index i -> column n0 + (CW / 4) (i >> 2) + 4 s + (i & 3): a lane then owns CW / 4 consecutive columns
     bf8 b[KB][NSW];
 #pragma unroll
     for (int s = 0; s < NSW; ++s) {
-        const int col = n0 + 16 * (i16 >> 2) + 4 * s + (i16 & 3);
+        const int col = n0 + (CW / 4) * (i16 >> 2) + 4 * s + (i16 & 3);
         const unsigned short* src = p.B + (long)col * p.ldb + q * 8;
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) b[kb][s] = *reinterpret_cast<const bf8*>(src + kb * 32);
     }
     const unsigned a_base = (unsigned)(size_t)a_ring, r_base = (unsigned)(size_t)r_ring;        // LDS byte addresses (the low 32 bits of a shared pointer)
-    // this lane's share of a step: rows 4 wave + 2 e + (lane >> 5), LDS piece lane & 31 <- global piece swizzled with the row
-    const int ja = lane & 31;
+    // this wave's share of a step: the 16 KB 16-byte pieces [wave 16 KB, (wave + 1) 16 KB) of the step's linear image (row = piece / 4 KB);
+    // the LDS piece <- the global piece with its low four index bits XORed with the row
     // (a fetch past the block's last step keeps the operation count of the loop static — the vmcnt below is a constant — but must not
     //  cost bandwidth: every lane then reads the same 16 bytes of the weight, one hot cache line, into a slot nobody reads again)
     auto fetch = [&](int r, int slot) {
         const bool live = r <= last;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int rl = 4 * wave + 2 * e + (lane >> 5);
+        for (int e = 0; e < NA; ++e) {
+            const int g = wave * 16 * KB + 64 * e + lane, rl = g / (4 * KB), pl = g - rl * 4 * KB;
             int row = r * 16 + rl;
             if (row >= p.M) row = p.M - 1;
-            const int pc = (ja & 16) | ((ja ^ rl) & 15);
-            cdae_lds_dma16(live ? p.A + (long)row * p.lda + pc * 8 : p.B, a_base + slot * STEP_B + (4 * wave + 2 * e) * 512);
+            const int pc = (pl & ~15) | ((pl ^ rl) & 15);
+            cdae_lds_dma16(live ? p.A + (long)row * p.lda + pc * 8 : p.B, a_base + slot * STEP_B + (wave * 16 * KB + 64 * e) * 16);
         }
         if (RES) {
+            constexpr int PPR = RROW_B / 16;                              // residual pieces per row: 8 (64 channels) or 4 (32)
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int rl = 8 * e + (lane >> 3);
+            for (int e = 0; e < NR; ++e) {
+                const int g = 64 * e + lane, rl = g / PPR, pl = g - rl * PPR;
                 int row = r * 16 + rl;
                 if (row >= p.M) row = p.M - 1;
-                const int pc = (lane & 7) ^ ((rl >> 1) & 7);
+                const int pc = pl ^ ((rl >> (PPR == 8 ? 1 : 2)) & (PPR - 1));
                 cdae_lds_dma16(live ? p.res + (long)row * p.ldc + n0 + pc * 8 : p.B, r_base + (slot * 4 + wave) * RES_B + e * 1024);
             }
         }
@@ -214,63 +224,67 @@ __global__ __launch_bounds__(256, 2) void rows16_ring_kernel(const RowsParams p)
 #pragma unroll
     for (int d = 0; d < D; ++d) fetch(rs + d * step, d);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const float* bias_l = bias_s + wave * 64 + 16 * q;
+    constexpr int CPL = CW / 4;                                           // consecutive columns per lane: 16 or 8
+    const float* bias_l = bias_s + wave * CW + CPL * q;
     int slot = 0;
     while (true) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
         __syncthreads();
         fetch(rs + D * step, slot == 0 ? R - 1 : slot - 1);
-        const unsigned char* al = a_ring + slot * STEP_B + i16 * 512;
+        const unsigned char* al = a_ring + slot * STEP_B + i16 * ROW_B;
         f32x4 acc[NSW];
 #pragma unroll
         for (int s = 0; s < NSW; ++s) acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
             const int pl = kb * 4 + q;
-            const bf8 av = *reinterpret_cast<const bf8*>(al + (((pl & 16) | ((pl ^ i16) & 15)) << 4));
+            const bf8 av = *reinterpret_cast<const bf8*>(al + (((pl & ~15) | ((pl ^ i16) & 15)) << 4));
 #pragma unroll
             for (int s = 0; s < NSW; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[kb][s], av, acc[s], 0, 0, 0);
         }
         int row = rs * 16 + i16;
         if (row >= p.M) row = p.M - 1;
-        float v[16];
+        float v[CPL];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NSW; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[4 * j + e] = acc[j][e];
-        u16x8 rv[2];
+        u16x8 rv[CPL / 8];
         if (RES) {
-            const unsigned char* rl = r_ring + (slot * 4 + wave) * RES_B + i16 * 128;
-            const int sw = (i16 >> 1) & 7;
-            rv[0] = *reinterpret_cast<const u16x8*>(rl + (((2 * q) ^ sw) << 4));
-            rv[1] = *reinterpret_cast<const u16x8*>(rl + (((2 * q + 1) ^ sw) << 4));
+            constexpr int PPR = RROW_B / 16;
+            const unsigned char* rl = r_ring + (slot * 4 + wave) * RES_B + i16 * RROW_B;
+            const int sw = (i16 >> (PPR == 8 ? 1 : 2)) & (PPR - 1);
+#pragma unroll
+            for (int h = 0; h < CPL / 8; ++h) rv[h] = *reinterpret_cast<const u16x8*>(rl + ((((CPL / 8) * q + h) ^ sw) << 4));
         }
-        r16_store<16, RES>(v, bias_l, rv, p.C + (long)row * p.ldc + n0 + 16 * q);
+        r16_store<CPL, RES>(v, bias_l, rv, p.C + (long)row * p.ldc + n0 + CPL * q);
         if (rs + step > last) break;
         rs += step;
         slot = slot == R - 1 ? 0 : slot + 1;
     }
 }
 
-template <bool RES>
+template <int KB, int NSW, bool RES>
 int launch_rows16_ring(RowsParams& p, hipStream_t st) {
-    constexpr int D = RES ? 3 : 5, R = D + 1;
-    constexpr int smem = R * 16 * 512 + (RES ? R * 4 * 16 * 128 : 0) + 256 * 4;
+    constexpr int STEP_B = 16 * KB * 64, RES_B = 16 * NSW * 32;
+    constexpr int D0 = (R16_RING_LDS / (STEP_B + (RES ? 4 * RES_B : 0))) - 1, D = D0 > 5 ? 5 : D0, R = D + 1;
+    constexpr int smem = R * STEP_B + (RES ? R * 4 * RES_B : 0) + 4 * NSW * 16 * 4;
+    static_assert(2 * smem <= 160 * 1024, "two blocks per CU");
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rows16_ring_kernel<RES>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rows16_ring_kernel<KB, NSW, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
             return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
         attr_done = true;
     }
     p.rsub = 1;
-    p.panels = p.N / 256;
+    p.panels = p.N / (4 * NSW * 16);
     p.tiles = (p.M + 15) / 16;
     int lanes = 64 / p.panels;
     if (lanes < 1) lanes = 1;
     const int need = (p.tiles + 7) / 8;
     if (lanes > need) lanes = need;
     p.lanes = lanes;
-    hipLaunchKernelGGL(rows16_ring_kernel<RES>, dim3(8 * p.panels * lanes), dim3(256), smem, st, p);
+    hipLaunchKernelGGL((rows16_ring_kernel<KB, NSW, RES>), dim3(8 * p.panels * lanes), dim3(256), smem, st, p);
     return hipGetLastError() == hipSuccess ? 0 : cdae_fail("rows16 (LDS ring) launch failed");
 }
 
@@ -300,7 +314,7 @@ int cdae_rows16_ok(const void* a16, long lda, const void* b16, long ldb, const f
     auto al16 = [](const void* q) { return (reinterpret_cast<size_t>(q) & 15) == 0; };
     if (gn_part || accumulate || M < cdae_tune(TUNE_ROWS16_MIN_M)) return 0;
     if (!(io & 1) || (res && !(io & 2))) return 0;                              // bf16 result, bf16 residual
-    if (!(K == 64 || K == 128 || K == 192 || K == 256)) return 0;
+    if (!(K == 64 || K == 128 || K == 192 || K == 256 || ((K == 384 || K == 512) && N % 128 == 0))) return 0;
     if ((long)M * (lda > ldc ? lda : ldc) >= (1L << 31)) return 0;
     if (N % (K <= 128 ? 128 : 64) || N > 8192) return 0;
     if (lda % 8 || ldb % 8 || ldc % 8 || !al16(a16) || !al16(b16) || !al16(c) || !al16(res) || (reinterpret_cast<size_t>(bias) & 3)) return 0;
@@ -328,7 +342,10 @@ int cdae_rows16_gemm(const void* a16, long lda, const void* b16, long ldb, const
         cdae_prof_tag(tag);
     }
     int rc;
-    if (K == 256 && N % 256 == 0 && cdae_tune(TUNE_ROWS16_RING)) rc = p.res ? launch_rows16_ring<true>(p, st) : launch_rows16_ring<false>(p, st);
+    const bool ring = cdae_tune(TUNE_ROWS16_RING) != 0;
+    if (K == 256 && N % 256 == 0 && ring) rc = p.res ? launch_rows16_ring<8, 4, true>(p, st) : launch_rows16_ring<8, 4, false>(p, st);
+    else if (K == 384) rc = p.res ? launch_rows16_ring<12, 2, true>(p, st) : launch_rows16_ring<12, 2, false>(p, st);
+    else if (K == 512) rc = p.res ? launch_rows16_ring<16, 2, true>(p, st) : launch_rows16_ring<16, 2, false>(p, st);
     else if (K == 256) rc = launch_rows16<8, 4>(p, st);
     else if (K == 192) rc = launch_rows16<6, 4>(p, st);
     else if (K == 128) rc = launch_rows16<4, 8>(p, st);

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void wg16_kernel(const Wg16Params p) {
 int cdae_wg16_ok(const void* x, long ldx, const void* dy, long lddy, const float* dw, long lddw, int M, int N, int K, int io, size_t ws_bytes) {
     static const int cfg = CDAE_DEV_INT("CDAE_WG16", 1);
     auto al16 = [](const void* q) { return (reinterpret_cast<size_t>(q) & 15) == 0; };
-    if (!cfg || (io & 12) != 12 || M < cdae_tune(TUNE_ROWS16_MIN_M) / 2) return 0;
+    if (!cfg || (io & 12) != 12 || (long)M < 2L * cdae_tune(TUNE_ROWS16_MIN_M)) return 0;
     if (N % 128 || K % 128 || N > 4096 || K > 4096) return 0;
     if (ldx % 8 || lddy % 8 || lddw % 4 || !al16(x) || !al16(dy) || !al16(dw)) return 0;
     if (ws_bytes < (size_t)8 * N * K * sizeof(float)) return 0;

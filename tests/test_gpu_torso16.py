@@ -296,6 +296,10 @@ def test_attn16_kernels_against_float64(T, ch, heads, B):
     (8200, 128, 64, 3, True, True),          # two K blocks
     (4099, 768, 256, 3, True, True),         # ragged rows, three column blocks
     (4100, 256, 192, 1, True, False),        # six K blocks
+    (8200, 384, 384, 3, True, True),         # K = 384: 32 channels per wave, three DMAs of 1.33 rows per wave and step, residual ring of 64-byte rows
+    (8192, 1152, 384, 1, True, False),       # nine column blocks
+    (4100, 512, 512, 3, True, True),         # K = 512: two steps in flight beside the residual ring
+    (2048, 1536, 512, 1, False, False),
     (5, 128, 128, 1, True, False),           # fewer rows than one step
     (8192, 256, 768, 1, False, False),       # K > 256: stays on the plane GEMM (both calls identical)
     (4100, 128, 128, 0, True, False),        # fp32 result: plane GEMM
@@ -337,10 +341,10 @@ def test_rows16_is_what_the_torso_launches():
     """At BASELINE config [1]'s row counts cdae_gemm16_ps takes the streaming kernel, below the threshold (and for K > 256, fp32 results)
     the plane GEMM: the library's own dispatch predicate."""
     from causaldiffae_amd._lib import lib
-    assert lib.cdae_tune_get(4) == 8192
+    assert lib.cdae_tune_get(4) == 2048
     assert lib.cdae_rows16_supported(65536, 256, 256, 1, 0) == 1 and lib.cdae_rows16_supported(262144, 128, 128, 3, 1) == 1
     assert lib.cdae_rows16_supported(65536, 768, 256, 1, 0) == 1
-    assert lib.cdae_rows16_supported(4096, 256, 256, 1, 0) == 0 and lib.cdae_rows16_supported(65536, 256, 768, 1, 0) == 0
+    assert lib.cdae_rows16_supported(1024, 256, 256, 1, 0) == 0 and lib.cdae_rows16_supported(65536, 256, 768, 1, 0) == 0
     assert lib.cdae_rows16_supported(65536, 256, 256, 0, 0) == 0
 
 

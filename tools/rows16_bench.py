@@ -8,7 +8,7 @@ from causaldiffae_amd.ops16 import _sk
 
 dev = torch.device("cuda:0")
 SHAPES = [(65536, 256, 256, 0), (65536, 256, 256, 1), (65536, 768, 256, 0), (65536, 256, 768, 0), (262144, 128, 128, 0), (262144, 128, 128, 1),
-          (16384, 256, 256, 0), (16384, 256, 256, 1), (16384, 768, 256, 0), (16384, 256, 768, 0), (4096, 256, 256, 0), (8192, 384, 384, 0)]
+          (16384, 256, 256, 0), (16384, 256, 256, 1), (16384, 768, 256, 0), (16384, 256, 768, 0), (4096, 256, 256, 0), (8192, 384, 384, 0), (8192, 384, 384, 1), (8192, 1152, 384, 0), (2048, 512, 512, 0), (2048, 512, 512, 1), (2048, 1536, 512, 0)]
 ws, wsb = _sk(dev)
 
 

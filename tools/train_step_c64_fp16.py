@@ -5,6 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 dev = torch.device("cuda:0")
+if os.environ.get("ROWS16_MIN_M"):          # A/B of the streaming kernels' row threshold (include/cdae.h, CDAE_TUNE_ROWS16_MIN_M)
+    from causaldiffae_amd._lib import lib as _l
+    _l.cdae_tune_set(4, int(os.environ["ROWS16_MIN_M"]))
 for fp16 in (True, False):
     r = bench.train_bench(dev, 1, 0, int(sys.argv[1]) if len(sys.argv) > 1 else 20, 3, 32, regions=2, use_fp16=fp16)
     print({k: r[k] for k in ("value", "ms_per_step", "precision_mode", "last_loss")})

@@ -4,6 +4,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 dev = torch.device("cuda:0")
+if os.environ.get("ROWS16_MIN_M"):          # A/B of the streaming kernels' row threshold (include/cdae.h, CDAE_TUNE_ROWS16_MIN_M)
+    from causaldiffae_amd._lib import lib as _l
+    _l.cdae_tune_set(4, int(os.environ["ROWS16_MIN_M"]))
 fp16 = len(sys.argv) > 2 and sys.argv[2] == "1"
 r = bench.train_bench(dev, 1, 0, int(sys.argv[1]) if len(sys.argv) > 1 else 3, 2, 256, use_fp16=fp16, workload="M32", image_size=32, in_channels=1, n_vars=2, class_cond=True)
 print({k: r[k] for k in ("value", "ms_per_step", "precision_mode")})
