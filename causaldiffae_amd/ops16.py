@@ -8,6 +8,9 @@ softmax and the optimizer stay fp32.  Here the torso dtype is bf16 (BASELINE con
   * conv3x3 / 1x1 epilogues round to bf16 once and leave the next GroupNorm's partial sums of the ROUNDED values;
   * GroupNorm32 forward / backward read and write bf16 rows with fp32 statistics (norm.hip, templated on the storage type);
   * weight gradients accumulate in fp32 straight into the flat gradient buffer, like the fp32-storage path.
+  * the 1x1 convs / linears (skip_connection, qkv, proj_out) and their weight gradients are HBM streams at these row counts: the library
+    runs them on rows16.hip / wg16.hip behind cdae_gemm16_ps / cdae_linear_wgrad_io (weight fragments in registers, rows through an
+    LDS-DMA ring), smaller or odd shapes on the plane GEMM.
 
 A ResBlock, an AttentionBlock and the Upsample conv are one autograd node each.  Shapes the 16-bit kernels do not take (the 4 x 4
 level: rows shorter than the window kernels' minimum) run the fp32-storage nodes of ops.py between two casts.
