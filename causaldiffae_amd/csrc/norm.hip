@@ -126,9 +126,17 @@ __global__ __launch_bounds__(256) void gn_finalize32_kernel(const T* __restrict_
     __shared__ double sS[8][32], sQ[8][32];
     const int n = blockIdx.x, g = threadIdx.x & 31, cl = threadIdx.x >> 5;
     double s = 0.0, q = 0.0;
-    for (int c = cl; c < nchunk; c += 8) {
-        const float2 v = *reinterpret_cast<const float2*>(partial + (((long)n * nchunk + c) * 32 + g) * 2);
-        s += v.x; q += v.y;
+    {
+        int c = cl;
+        for (; c + 24 < nchunk; c += 32) {          // four chunk records in flight; same order of additions
+            const float2 v0 = *reinterpret_cast<const float2*>(partial + (((long)n * nchunk + c) * 32 + g) * 2), v1 = *reinterpret_cast<const float2*>(partial + (((long)n * nchunk + c + 8) * 32 + g) * 2),
+                         v2 = *reinterpret_cast<const float2*>(partial + (((long)n * nchunk + c + 16) * 32 + g) * 2), v3 = *reinterpret_cast<const float2*>(partial + (((long)n * nchunk + c + 24) * 32 + g) * 2);
+            s += v0.x; q += v0.y; s += v1.x; q += v1.y; s += v2.x; q += v2.y; s += v3.x; q += v3.y;
+        }
+        for (; c < nchunk; c += 8) {
+            const float2 v = *reinterpret_cast<const float2*>(partial + (((long)n * nchunk + c) * 32 + g) * 2);
+            s += v.x; q += v.y;
+        }
     }
     sS[cl][g] = s; sQ[cl][g] = q;
     __syncthreads();
@@ -591,10 +599,21 @@ __global__ __launch_bounds__(256) void gn_bwd_fold_kernel(int N, int HW, int C, 
     if ((int)blockIdx.x < cblocks) {
         const int c = blockIdx.x * 64 + col;
         if (c < C)
-            for (int k = cl; k < nchunk; k += 4) {
+        {
+            int k = cl;
+            for (; k + 12 < nchunk; k += 16) {      // four chunk records in flight; same order of additions
+                const float4 p0 = *reinterpret_cast<const float4*>(cpart + (((long)n * nchunk + k) * C + c) * 4), p1 = *reinterpret_cast<const float4*>(cpart + (((long)n * nchunk + k + 4) * C + c) * 4),
+                             p2 = *reinterpret_cast<const float4*>(cpart + (((long)n * nchunk + k + 8) * C + c) * 4), p3 = *reinterpret_cast<const float4*>(cpart + (((long)n * nchunk + k + 12) * C + c) * 4);
+                v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w;
+                v[0] += p1.x; v[1] += p1.y; v[2] += p1.z; v[3] += p1.w;
+                v[0] += p2.x; v[1] += p2.y; v[2] += p2.z; v[3] += p2.w;
+                v[0] += p3.x; v[1] += p3.y; v[2] += p3.z; v[3] += p3.w;
+            }
+            for (; k < nchunk; k += 4) {
                 const float4 pp = *reinterpret_cast<const float4*>(cpart + (((long)n * nchunk + k) * C + c) * 4);
                 v[0] += pp.x; v[1] += pp.y; v[2] += pp.z; v[3] += pp.w;
             }
+        }
         for (int i = 0; i < 4; ++i) red[cl][col][i] = v[i];
         __syncthreads();
         if (cl == 0 && c < C) {
@@ -632,7 +651,15 @@ __device__ __forceinline__ void gn_bwd_param8_block(int cblock, int N, int C, co
     const int cc = threadIdx.x & 31, nl = threadIdx.x >> 5, c = cblock * 32 + cc;
     double a = 0, b = 0;
     if (c < C)
-        for (int n = nl; n < N; n += 8) { const float2 v = *reinterpret_cast<const float2*>(nc_part + ((long)n * C + c) * 2); a += v.x; b += v.y; }
+    {
+        int n = nl;
+        for (; n + 24 < N; n += 32) {       // four images in flight per lane (batch 256: 32 images per lane, each load a round trip when taken one by one); same order of additions
+            const float2 v0 = *reinterpret_cast<const float2*>(nc_part + ((long)n * C + c) * 2), v1 = *reinterpret_cast<const float2*>(nc_part + ((long)(n + 8) * C + c) * 2),
+                         v2 = *reinterpret_cast<const float2*>(nc_part + ((long)(n + 16) * C + c) * 2), v3 = *reinterpret_cast<const float2*>(nc_part + ((long)(n + 24) * C + c) * 2);
+            a += v0.x; b += v0.y; a += v1.x; b += v1.y; a += v2.x; b += v2.y; a += v3.x; b += v3.y;
+        }
+        for (; n < N; n += 8) { const float2 v = *reinterpret_cast<const float2*>(nc_part + ((long)n * C + c) * 2); a += v.x; b += v.y; }
+    }
     sA[nl][cc] = a; sB[nl][cc] = b;
     __syncthreads();
     if (nl == 0 && c < C) {
