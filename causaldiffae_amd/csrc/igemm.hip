@@ -688,6 +688,13 @@ __global__ void splitk_reduce_kernel(const GemmParams p) {
         const float* slab = p.splitk_ws + bz * (long)p.M * p.N + rem;
         const long kstride = (long)p.batch * p.M * p.N;
         int k = 0;
+        for (; k + 8 <= p.ksplit; k += 8) {          // eight slab loads in flight; same order of additions
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = slab[(k + u) * kstride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
         for (; k + 4 <= p.ksplit; k += 4) {          // four slab loads in flight (the dependent-add loop alone waits a round trip per slab); same order of additions
             const float v0 = slab[k * kstride], v1 = slab[(k + 1) * kstride], v2 = slab[(k + 2) * kstride], v3 = slab[(k + 3) * kstride];
             s += v0; s += v1; s += v2; s += v3;

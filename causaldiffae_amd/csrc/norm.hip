@@ -886,7 +886,18 @@ __global__ void bn_finalize_kernel(const float* __restrict__ x, long rows_total,
     float m, v;
     if (training) {
         double s = 0, q = 0;
-        for (int k = 0; k < nchunk; ++k) { s += partial[((long)k * C + c) * 2]; q += partial[((long)k * C + c) * 2 + 1]; }
+        {
+            const float2* pp = reinterpret_cast<const float2*>(partial) + c;
+            int k = 0;
+            for (; k + 8 <= nchunk; k += 8) {       // eight chunk records in flight (one block walks up to 1024 of them: 23 us one by one at batch 256); same order of additions
+                float2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = pp[(long)(k + u) * C];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { s += v[u].x; q += v[u].y; }
+            }
+            for (; k < nchunk; ++k) { const float2 v = pp[(long)k * C]; s += v.x; q += v.y; }
+        }
         double cnt = (double)rows_total, mm = s / cnt, var = q / cnt - mm * mm;
         if (var < 0) var = 0;
         m = (float)(x[c] + mm); v = (float)var;
@@ -943,7 +954,18 @@ __global__ void bn_bwd_finalize_kernel(long rows_total, int C, int nchunk, const
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double s = 0, q = 0;
-    for (int k = 0; k < nchunk; ++k) { s += partial[((long)k * C + c) * 2]; q += partial[((long)k * C + c) * 2 + 1]; }
+    {
+        const float2* pp = reinterpret_cast<const float2*>(partial) + c;
+        int k = 0;
+        for (; k + 8 <= nchunk; k += 8) {           // eight chunk records in flight; same order of additions
+            float2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = pp[(long)(k + u) * C];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s += v[u].x; q += v[u].y; }
+        }
+        for (; k < nchunk; ++k) { const float2 v = pp[(long)k * C]; s += v.x; q += v.y; }
+    }
     dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
     dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)q;
     sums[c * 2] = (float)(s / (double)rows_total);
