@@ -49,23 +49,32 @@ __device__ __forceinline__ float bf2f(unsigned short u) { return __builtin_bit_c
 // the next step's rows.
 
 // one 16-row x CPL-column piece of the epilogue: v[] += bias (LDS) + residual (already in registers), rounded to bf16, 16-byte stores
+// (CPL = 4: one 8-byte store, no residual form)
 template <int CPL, bool RES>
-__device__ __forceinline__ void r16_store(float (&v)[CPL], const float* __restrict__ bias_l, const u16x8 (&rv)[CPL / 8], unsigned short* __restrict__ cp) {
+__device__ __forceinline__ void r16_store(float (&v)[CPL], const float* __restrict__ bias_l, const u16x8 (&rv)[CPL / 8 > 0 ? CPL / 8 : 1], unsigned short* __restrict__ cp) {
 #pragma unroll
     for (int j = 0; j < CPL / 4; ++j) {
         const float4 bb = *reinterpret_cast<const float4*>(bias_l + 4 * j);
         v[4 * j] += bb.x; v[4 * j + 1] += bb.y; v[4 * j + 2] += bb.z; v[4 * j + 3] += bb.w;
     }
+    if constexpr (CPL == 4) {
+        typedef __bf16 bf4s __attribute__((ext_vector_type(4)));
+        bf4s o;
 #pragma unroll
-    for (int h = 0; h < CPL / 8; ++h) {
-        bf8 o;
+        for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+        *reinterpret_cast<bf4s*>(cp) = o;
+    } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float x = v[8 * h + e];
-            if (RES) x += bf2f(rv[h][e]);
-            o[e] = (__bf16)x;
+        for (int h = 0; h < CPL / 8; ++h) {
+            bf8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float x = v[8 * h + e];
+                if (RES) x += bf2f(rv[h][e]);
+                o[e] = (__bf16)x;
+            }
+            *reinterpret_cast<bf8*>(cp + 8 * h) = o;
         }
-        *reinterpret_cast<bf8*>(cp + 8 * h) = o;
     }
 }
 
@@ -161,15 +170,16 @@ __global__ __launch_bounds__(256, 2) void rows16_reg_kernel(const RowsParams p) 
 //   and D - 1 DMA groups, all counted statically (rows past the end are clamped like above, the ring keeps fetching the last step).
 template <int KB, int NSW, bool RES>
 __global__ __launch_bounds__(256, 2) void rows16_ring_kernel(const RowsParams p) {
-    // KB = K / 32 (a multiple of 4: the four waves fetch a quarter of a step each), NSW = 4 (64 channels per wave: K = 256) or 2 (32
-    // channels per wave: K = 384, 512 — the weight fragments stay at 96 / 128 VGPRs)
+    // KB = K / 32 (a multiple of 4: the four waves fetch a quarter of a step each), NSW = 4 (64 channels per wave: K = 256), 2 (32
+    // channels per wave: K = 384, 512 — the weight fragments stay at 96 / 128 VGPRs) or 1 (16 channels per wave, no residual: K = 768 —
+    // the qkv data gradient; a fragment read then feeds ONE MFMA, which makes this form LDS-read-bound near the HBM floor of those shapes)
     constexpr int ROW_B = KB * 64, STEP_B = 16 * ROW_B;                   // bytes of a row, of a step's rows
     constexpr int CW = NSW * 16, RROW_B = CW * 2, RES_B = 16 * RROW_B;    // a wave's channels; bytes of a residual row, of a wave's residual piece
     constexpr int NA = KB / 4, NR = RES ? RES_B / 1024 : 0;               // DMAs per wave and step: rows, residual
-    constexpr int STORES = CW / 32;                                       // (16 consecutive columns per lane = two stores; 8 = one)
+    constexpr int STORES = CW / 32 > 0 ? CW / 32 : 1;                     // (16 consecutive columns per lane = two stores; 8 or 4 = one)
     constexpr int D = (R16_RING_LDS / (STEP_B + (RES ? 4 * RES_B : 0))) - 1 > 5 ? 5 : (R16_RING_LDS / (STEP_B + (RES ? 4 * RES_B : 0))) - 1, R = D + 1;
     constexpr int WAITN = D * STORES + (D - 1) * (NA + NR);
-    static_assert(KB % 4 == 0 && (NSW == 4 || NSW == 2) && D >= 2, "rows16 ring: unsupported shape");
+    static_assert(KB % 4 == 0 && (NSW == 4 || NSW == 2 || (NSW == 1 && !RES)) && D >= 2, "rows16 ring: unsupported shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* a_ring = lds;
     unsigned char* r_ring = lds + R * STEP_B;                            // [slot][wave][RES_B]
@@ -249,8 +259,8 @@ __global__ __launch_bounds__(256, 2) void rows16_ring_kernel(const RowsParams p)
         for (int j = 0; j < NSW; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[4 * j + e] = acc[j][e];
-        u16x8 rv[CPL / 8];
-        if (RES) {
+        u16x8 rv[CPL / 8 > 0 ? CPL / 8 : 1];
+        if constexpr (RES) {
             constexpr int PPR = RROW_B / 16;
             const unsigned char* rl = r_ring + (slot * 4 + wave) * RES_B + i16 * RROW_B;
             const int sw = (i16 >> (PPR == 8 ? 1 : 2)) & (PPR - 1);
@@ -314,7 +324,7 @@ int cdae_rows16_ok(const void* a16, long lda, const void* b16, long ldb, const f
     auto al16 = [](const void* q) { return (reinterpret_cast<size_t>(q) & 15) == 0; };
     if (gn_part || accumulate || M < cdae_tune(TUNE_ROWS16_MIN_M)) return 0;
     if (!(io & 1) || (res && !(io & 2))) return 0;                              // bf16 result, bf16 residual
-    if (!(K == 64 || K == 128 || K == 192 || K == 256 || ((K == 384 || K == 512) && N % 128 == 0))) return 0;
+    if (!(K == 64 || K == 128 || K == 192 || K == 256 || ((K == 384 || K == 512) && N % 128 == 0) || (K == 768 && !res && N % 64 == 0))) return 0;
     if ((long)M * (lda > ldc ? lda : ldc) >= (1L << 31)) return 0;
     if (N % (K <= 128 ? 128 : 64) || N > 8192) return 0;
     if (lda % 8 || ldb % 8 || ldc % 8 || !al16(a16) || !al16(b16) || !al16(c) || !al16(res) || (reinterpret_cast<size_t>(bias) & 3)) return 0;
@@ -346,6 +356,7 @@ int cdae_rows16_gemm(const void* a16, long lda, const void* b16, long ldb, const
     if (K == 256 && N % 256 == 0 && ring) rc = p.res ? launch_rows16_ring<8, 4, true>(p, st) : launch_rows16_ring<8, 4, false>(p, st);
     else if (K == 384) rc = p.res ? launch_rows16_ring<12, 2, true>(p, st) : launch_rows16_ring<12, 2, false>(p, st);
     else if (K == 512) rc = p.res ? launch_rows16_ring<16, 2, true>(p, st) : launch_rows16_ring<16, 2, false>(p, st);
+    else if (K == 768) rc = launch_rows16_ring<24, 1, false>(p, st);
     else if (K == 256) rc = launch_rows16<8, 4>(p, st);
     else if (K == 192) rc = launch_rows16<6, 4>(p, st);
     else if (K == 128) rc = launch_rows16<4, 8>(p, st);

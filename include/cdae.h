@@ -462,7 +462,7 @@ int cdae_rep_loss_bwd(const float* mu, const float* var, const float* z_post, co
  *                                      block slots and 256 x 128 tiles do not, 1 = wherever they apply (tests), -1 = never
  *   CDAE_TUNE_HEAD_MFMA          (1)   the output head (cdae_head_conv_fwd) on v_mfma_f32_4x4x1 (exact fp32 products, like the scalar
  *                                      form it replaces: 0 = that form; the two differ in summation order only)
- *   CDAE_TUNE_ROWS16_MIN_M       (2048) cdae_gemm16_ps with at least this many rows (K in {64, 128, 192, 256, 384, 512}, bf16 result / residual, no
+ *   CDAE_TUNE_ROWS16_MIN_M       (2048) cdae_gemm16_ps with at least this many rows (K in {64, 128, 192, 256, 384, 512; 768 without residual}, bf16 result / residual, no
  *                                      GroupNorm sums / accumulation) runs on the streaming kernel of rows16.hip (weight fragments in
  *                                      registers, activation rows global -> registers); below it on the plane GEMM, whose split-K
  *                                      covers short row counts (cdae_linear_wgrad_io takes wg16.hip from twice this many rows).

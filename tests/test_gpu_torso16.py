@@ -301,7 +301,9 @@ def test_attn16_kernels_against_float64(T, ch, heads, B):
     (4100, 512, 512, 3, True, True),         # K = 512: two steps in flight beside the residual ring
     (2048, 1536, 512, 1, False, False),
     (5, 128, 128, 1, True, False),           # fewer rows than one step
-    (8192, 256, 768, 1, False, False),       # K > 256: stays on the plane GEMM (both calls identical)
+    (8192, 256, 768, 1, False, False),       # the qkv data gradient: 16 channels per wave, six DMAs per wave and step
+    (5000, 256, 768, 1, True, False),
+    (4100, 256, 1152, 1, False, False),      # K = 3 x 384: stays on the plane GEMM (both calls identical)
     (4100, 128, 128, 0, True, False),        # fp32 result: plane GEMM
 ])
 def test_rows16_streaming_gemm(M, N, K, io, bias, res):
@@ -344,7 +346,7 @@ def test_rows16_is_what_the_torso_launches():
     assert lib.cdae_tune_get(4) == 2048
     assert lib.cdae_rows16_supported(65536, 256, 256, 1, 0) == 1 and lib.cdae_rows16_supported(262144, 128, 128, 3, 1) == 1
     assert lib.cdae_rows16_supported(65536, 768, 256, 1, 0) == 1
-    assert lib.cdae_rows16_supported(1024, 256, 256, 1, 0) == 0 and lib.cdae_rows16_supported(65536, 256, 768, 1, 0) == 0
+    assert lib.cdae_rows16_supported(1024, 256, 256, 1, 0) == 0 and lib.cdae_rows16_supported(65536, 256, 768, 1, 0) == 1 and lib.cdae_rows16_supported(65536, 256, 768, 3, 1) == 0
     assert lib.cdae_rows16_supported(65536, 256, 256, 0, 0) == 0
 
 
