@@ -432,6 +432,18 @@ int cdae_conv3x3_fwd16(const void* x16, long sn, long sy, long sx, const void* w
     return cdae_gemm_dispatch(p, stream);
 }
 
+// out16 = conv3x3(x16, w, stride 2, pad 1) + bias (reference unet.py:92-105 Downsample with use_conv): bf16 rows in and out, the gather of
+// the plane GEMM (the window kernels are stride 1); out16 [N, (H - 1) / 2 + 1, (W - 1) / 2 + 1, Cout] rows of pitch ldo
+int cdae_conv3x3_s2_fwd16(const void* x16, long sn, long sy, long sx, const void* w16, const float* bias, void* out16, long ldo, int N, int H, int W, int Cin,
+                          int Cout, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    GemmParams p;
+    if (conv16_params(p, x16, sn, sy, sx, w16, nullptr, 9 * Cin, bias, nullptr, out16, ldo, nullptr, N, H, W, Cin, Cout, 1)) return -1;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    p.stride = 2; p.Ho = Ho; p.Wo = Wo; p.M = N * Ho * Wo; p.conv_M = p.M; p.out_hw = Ho * Wo;
+    set_splitk(p, splitk_ws, splitk_ws_bytes);
+    return cdae_gemm_dispatch(p, stream);
+}
+
 // dx16 = conv3x3(dy16, wt): dy16 bf16 [N, H, W, Cout] dense, wt16 / wtk16 the bf16 dgrad weights ([Cin][9][Cout] flipped; K-group-major)
 int cdae_conv3x3_dgrad16(const void* dy16, const void* wt16, const void* wtk16, void* dx16, long lddx, int N, int H, int W, int Cin, int Cout,
                          float* splitk_ws, size_t splitk_ws_bytes, void* stream) {

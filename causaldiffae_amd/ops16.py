@@ -437,6 +437,72 @@ def upconv_train(x, w, b=None):
     return _UpConv16.apply(x, w, b)
 
 
+# ----------------------------------------------------------------------------- Downsample conv
+class _Down16(Function):
+    """out = conv3x3(x, w, stride 2, padding 1) + b (reference unet.py:92-105) with bf16 rows in and out.  Forward: the plane GEMM's strided
+    gather on the bf16 tensor itself (one launch; it was the fp32-operand conv between two casts).  Backward: the kernels of the fp32-storage
+    node (ops._Conv3x3: sub-pixel-phase dgrad, implicit-GEMM wgrad) on fp32 casts of the two operands — three launches per model."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = rows16(x)
+        N, C, H, W = x.shape
+        Cout = w.shape[0]
+        w_in, w = w, ops.ohwi(w)
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        out = new_act16(N, Cout, Ho, Wo, x.device)
+        f, _, _, _ = _w16_conv(w)
+        ws, wsb = _sk(x.device)
+        check(lib.cdae_conv3x3_s2_fwd16(ptr(x), H * W * C, W * C, C, f, ptr(b), ptr(out), Cout, N, H, W, C, Cout, ws, wsb, stream()))
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (b is not None, (N, C, H, W))
+        ctx.sinks = (ops._sink(w_in), ops._sink(b))
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x16, w = ctx.saved_tensors
+        has_b, (N, C, H, W) = ctx.cfg
+        Cout = w.shape[0]
+        dev = dy.device
+        dy32, x32 = to32_raw(rows16(dy)), to32_raw(x16)
+        ws, wsb = _sk(dev)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx32 = ops.new_act(N, C, H, W, dev)
+            if not ops._s2_dgrad_ps(dy32, w, dx32, N, H, W, C, Cout, ws, wsb):
+                check(lib.cdae_conv3x3_dgrad(ptr(dy32), Cout, ptr(w), ptr(dx32), C, N, H, W, C, Cout, 2, 0, 0, ws, wsb, stream()))
+            dx = to16_raw(dx32)
+        if ctx.needs_input_grad[1]:
+            (gw, rw), (gb, rb) = ctx.sinks
+            direct = gw is not None and w.stride() == gw.stride() and (not has_b or gb is not None)
+            if direct:
+                dw, db = gw, gb
+            else:
+                dw = torch.empty_like(w)
+                db = torch.empty(Cout, dtype=torch.float32, device=dev) if has_b else None
+
+            def wg(st_, ws_, wsb_, dw=dw, db=db):
+                check(lib.cdae_conv3x3_wgrad(ptr(x32), x32.stride(0), x32.stride(2), x32.stride(3), x32.stride(1), ptr(dy32), Cout, ptr(dw), ptr(db),
+                                             N, H, W, C, Cout, 2, 0, 1 if direct else 0, ws_, wsb_, st_))
+            if direct:
+                ops.side_launch(dev, (x32, dy32), wg)
+                dw = db = None
+                ops._done(rw, rb)
+            else:
+                wg(stream(), ws, wsb)
+        return dx, dw, db
+
+
+def down_ok(x, Cout):
+    N, C, H, W = x.shape
+    return ops._DOWN16_ON and C % 32 == 0 and Cout % 32 == 0 and H % 2 == 0 and W % 2 == 0 and long_ok(N, H, W, max(C, Cout))
+
+
+def downsample_train(x, w, b=None):
+    return _Down16.apply(x, w, b)
+
+
 # ----------------------------------------------------------------------------- AttentionBlock
 class _AttnBlock16(Function):
     """The whole AttentionBlock (reference unet.py:223-253) as one node on a bf16 residual stream:

@@ -118,7 +118,9 @@ class Downsample(nn.Module):
 
     def forward(self, x):
         assert x.shape[1] == self.channels
-        if x.dtype == th.bfloat16:             # the 16-bit torso: the three stride-2 convs run the fp32-operand kernels between two casts
+        if x.dtype == th.bfloat16:             # the 16-bit torso: forward on the bf16 rows themselves, backward on the fp32-storage node's kernels
+            if ops16.down_ok(x, self.channels):
+                return ops16.downsample_train(x, self.op.weight, self.op.bias)
             return ops16.to16(self.op(ops16.to32(x)))
         xs = getattr(x, "_split", None)
         if xs is not None and ops.presplit_ok():

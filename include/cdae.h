@@ -479,6 +479,8 @@ int cdae_tune_get(int key);       /* -1: unknown key */
    residual is bf16, 4 / 8 the A / B operand of an fp32-operand entry point is bf16. */
 int cdae_conv3x3_fwd16(const void* x16, long sn, long sy, long sx, const void* w16, const void* wk16, const float* bias, const void* res16, void* out16,
                        long ldo, float* gn_part, int N, int H, int W, int Cin, int Cout, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
+int cdae_conv3x3_s2_fwd16(const void* x16, long sn, long sy, long sx, const void* w16, const float* bias, void* out16, long ldo, int N, int H, int W, int Cin,
+                          int Cout, float* splitk_ws, size_t splitk_ws_bytes, void* stream);      /* the Downsample conv (stride 2) on bf16 rows */
 int cdae_conv3x3_dgrad16(const void* dy16, const void* wt16, const void* wtk16, void* dx16, long lddx, int N, int H, int W, int Cin, int Cout,
                          float* splitk_ws, size_t splitk_ws_bytes, void* stream);
 int cdae_gemm16_ps(const void* a16, long lda, const void* b16, long ldb, const float* bias, const void* res, void* c, long ldc, float* gn_part, int M, int N,

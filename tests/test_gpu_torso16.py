@@ -386,3 +386,28 @@ def test_wg16_weight_gradient_from_bf16_rows(M, N, K, acc, wide, bias):
         assert (dW.double() - ref_w).abs().max().item() < 2e-5 * sw
         if bias:
             assert (db.double() - ref_b).abs().max().item() < 2e-5 * sb
+
+
+@pytest.mark.parametrize("N,C,S", [(8, 128, 32), (4, 256, 16), (3, 384, 8)])
+def test_downsample16_against_float64(mixed16, N, C, S):
+    """The Downsample conv (stride 2, reference unet.py:92-105) as a bf16-row node (ops16._Down16: forward on the plane GEMM's strided gather,
+    backward on the fp32-storage node's kernels) against float64 conv2d of the same bf16-rounded operands."""
+    from causaldiffae_amd import ops, ops16
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(N, C, S, S, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) / (9 * C) ** 0.5
+    b = torch.randn(C, generator=g) * 0.1
+    dout = torch.randn(N, C, S // 2, S // 2, generator=g)
+    xr, wr, br = _bf(x).requires_grad_(True), _bf(w).requires_grad_(True), b.double().requires_grad_(True)
+    ref = F.conv2d(xr, wr, br, stride=2, padding=1)
+    ref.backward(_bf(dout))
+    xd = ops16.to16_raw(ops.to_nhwc(x.to(DEV))).requires_grad_(True)
+    wd = w.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    bd = b.to(DEV).requires_grad_(True)
+    assert ops16.down_ok(xd, C)
+    o = ops16.downsample_train(xd, wd, bd)
+    assert o.dtype == torch.bfloat16 and o.shape == (N, C, S // 2, S // 2)
+    assert _rel(o, ref) < 1e-2
+    o.backward(dout.to(DEV).to(torch.bfloat16))
+    ops.side_join()
+    assert _rel(xd.grad, xr.grad) < 2e-2 and _rel(wd.grad, wr.grad) < 2e-2 and _rel(bd.grad, br.grad) < 2e-2

@@ -4,6 +4,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 dev = torch.device("cuda:0")
+if os.environ.get("OFF"):               # OFF=name,name: fused paths of causaldiffae_amd.ops.PATH_TOGGLES switched off (same-box A/B)
+    from causaldiffae_amd import ops as _ops
+    for _n in os.environ["OFF"].split(","):
+        setattr(_ops, _ops.PATH_TOGGLES[_n], False)
 if os.environ.get("ROWS16_MIN_M"):          # A/B of the streaming kernels' row threshold (include/cdae.h, CDAE_TUNE_ROWS16_MIN_M)
     from causaldiffae_amd._lib import lib as _l
     _l.cdae_tune_set(4, int(os.environ["ROWS16_MIN_M"]))
