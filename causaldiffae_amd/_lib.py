@@ -141,6 +141,7 @@ SIGNATURES = {
     "cdae_gn_apply16": [P, I, P, I, I, P, I, I, I, I, I, P, P, P, P, P, I, I, P],
     "cdae_gn_bwd16": [P, I, P, I, I, P, I, P, I, P, I, I, I, I, I, P, P, P, P, P, I, I, P, P, I, P, I, I, P, I, P, P],
     "cdae_conv3x3_s2_fwd16": [P, L, L, L, P, P, P, L, I, I, I, I, I, P, SZ, P],
+    "cdae_im2col3x3_16": [P, P, I, I, I, I, P],
     "cdae_attn16_supported": [I, I],
     "cdae_rows16_supported": [I, I, I, I, I],
     "cdae_attn16_fwd": [P, P, P, I, I, I, I, P],

@@ -425,6 +425,24 @@ __global__ void upsample2_16_kernel(const ew_bf4* __restrict__ x, ew_bf4* __rest
         y[o] = v; y[o + C4] = v; y[o + row] = v; y[o + row + C4] = v;
     }
 }
+// rows of the 3 x 3 patch matrix of a bf16 NHWC tensor: y[(n, yy, xx)][tap][c] = x[n][yy + ky - 1][xx + kx - 1][c] (zero outside), tap = 3 ky + kx —
+// the B operand of a conv's weight gradient as a plain [pixels][9 C] matrix (the 4 x 4 level of the 16-bit torso, where the window wgrad
+// kernel's rows are too short: 19 MB at batch 256 instead of two fp32 casts and the scalar-gather implicit GEMM)
+typedef unsigned short ew_u16x8 __attribute__((ext_vector_type(8)));
+__global__ void im2col3x3_16_kernel(const ew_u16x8* __restrict__ x, ew_u16x8* __restrict__ y, int H, int W, int C8, long total) {
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C8);
+        long r = i / C8;
+        const int tap = (int)(r % 9); r /= 9;
+        const int xx = (int)(r % W); r /= W;
+        const int yy = (int)(r % H);
+        const long n = r / H;
+        const int sy = yy + tap / 3 - 1, sx = xx + tap % 3 - 1;
+        ew_u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (sy >= 0 && sy < H && sx >= 0 && sx < W) v = x[((n * H + sy) * W + sx) * C8 + c];
+        y[i] = v;
+    }
+}
 __global__ void sumpool2_16_kernel(const ew_bf4* __restrict__ src, ew_bf4* __restrict__ dst, int N, int H, int W, int C4) {
     const long total = (long)N * H * W * C4;
     GRID_STRIDE(i, total) {
@@ -839,6 +857,11 @@ int cdae_upsample2_16(const void* x, void* y, int N, int H, int W, int C, void* 
     if (C % 4) return cdae_fail("upsample2_16: C % 4 == 0 required");
     const long total = (long)N * H * W * (C / 4);
     LAUNCH1D(upsample2_16_kernel, total, (const ew_bf4*)x, (ew_bf4*)y, H, W, C / 4, total);
+}
+int cdae_im2col3x3_16(const void* x, void* y, int N, int H, int W, int C, void* stream) {
+    if (C % 8 || (((size_t)x | (size_t)y) & 15)) return cdae_fail("im2col3x3_16: C % 8 == 0 and 16-byte aligned buffers required");
+    const long total = (long)N * H * W * 9 * (C / 8);
+    LAUNCH1D(im2col3x3_16_kernel, total, (const ew_u16x8*)x, (ew_u16x8*)y, H, W, C / 8, total);
 }
 int cdae_sumpool2_16(const void* src, void* dst, int N, int H, int W, int C, void* stream) {
     if (C % 4) return cdae_fail("sumpool2_16: C % 4 == 0 required");

@@ -1266,6 +1266,7 @@ class ConvWeightBank:
 
 _BANK_OF = {}
 _WEIGHT_BANK_ON = True
+_IM2COL16_ON = True     # path toggle: False = the torso's 4 x 4-level conv weight gradients on fp32 casts + the implicit GEMM (before round 5's last change)
 _DOWN16_ON = True       # path toggle: False = the torso's Downsample convs run the fp32-storage node between two casts (before round 5's last change)
 _TORSO16_ON = True      # path toggle: False = the mixed16 mode keeps fp32 activation storage (single-plane products only, the round-3 torso)
 
@@ -2256,7 +2257,7 @@ PATH_TOGGLES = {"skipgn_v2": "_SKIPGN_V2", "skip_gn": "_SKIPGN_ON", "stream_gemm
                 "linear_gn": "_LINEAR_GN", "fused_attn": "_FUSED_ATTN_ON", "fused_attn_train": "_FUSED_ATTN_TRAIN", "kpack": "_KPACK_ON",
                 "presplit": "_PRESPLIT_ON", "train_presplit": "_TRAIN_PS_ON", "train_rbnode": "_RBNODE_ON", "train_gnparts": "_RB_PARTS_ON",
                 "train_emball": "_EMBALL_ON", "train_cat": "_TRAIN_CAT_ON", "weight_bank": "_WEIGHT_BANK_ON", "wscale": "_WSCALE_ON",
-                "s2_dgrad_ps": "_S2DGRAD_ON", "dgrad_stream": "_DGRAD_STREAM_ON", "wgrad_stream": "_WGRAD_SIDE_ON", "torso16": "_TORSO16_ON", "wgrad_group": "_WG_GROUP_ON", "down16": "_DOWN16_ON"}
+                "s2_dgrad_ps": "_S2DGRAD_ON", "dgrad_stream": "_DGRAD_STREAM_ON", "wgrad_stream": "_WGRAD_SIDE_ON", "torso16": "_TORSO16_ON", "wgrad_group": "_WG_GROUP_ON", "down16": "_DOWN16_ON", "im2col16": "_IM2COL16_ON"}
 
 
 class path_scope:

@@ -245,8 +245,23 @@ def _conv_bwd(a16, dy16, w, sinks, has_b, N, H, W, Cin, Cout, need_w, st):
         def wg(st_, ws_, wsb_, dw=dw, db=db):
             check(lib.cdae_conv3x3_wgrad_win(ptr(a16), ptr(a16), ptr(dy16), ptr(dy16), ptr(dw), ptr(db), N, H, W, Cin, Cout,
                                              1 if direct else 0, ws_, wsb_, st_))
-        if not _win_ok(N, H, W, Cin, Cout):
-            # rows too short for the window kernel (4 x 4): the fp32-operand implicit GEMM on casts of the two small operands
+        if not _win_ok(N, H, W, Cin, Cout) and ops._IM2COL16_ON and Cin % 128 == 0 and Cout % 128 == 0 and N * H * W * 9 * Cin < (1 << 31):
+            # rows too short for the window kernel (4 x 4): the patch matrix [pixels][9 Cin] (bf16, a few MB) and the streaming weight-gradient
+            # kernel of the 1 x 1 convs (wg16.hip) — dW is [Cout][9 Cin] = the OHWI weight itself
+            cols = torch.empty((N * H * W, 9 * Cin), dtype=BF16, device=dev)
+            check(lib.cdae_im2col3x3_16(ptr(a16), ptr(cols), N, H, W, Cin, st))
+
+            def wgc(st_, ws_, wsb_, dw=dw, db=db):
+                check(lib.cdae_linear_wgrad_io(ptr(cols), 9 * Cin, ptr(dy16), Cout, ptr(dw), 9 * Cin, ptr(db), N * H * W, Cout, 9 * Cin, 12,
+                                               1 if direct else 0, ws_, wsb_, st_))
+            if direct:
+                ops.side_launch(dev, (cols, dy16), wgc)
+                dw = db = None
+                ops._done(rw, rb)
+            else:
+                wgc(st, ws, wsb)
+        elif not _win_ok(N, H, W, Cin, Cout):
+            # (other channel counts) the fp32-operand implicit GEMM on casts of the two small operands
             a32, d32 = to32_raw(a16.permute(0, 3, 1, 2)), to32_raw(dy16.permute(0, 3, 1, 2))
 
             def wg32(st_, ws_, wsb_, dw=dw, db=db):

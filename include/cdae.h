@@ -515,7 +515,10 @@ int cdae_rows16_supported(int M, int N, int K, int io, int has_res);
 int cdae_cast_f32_bf16(const float* x, void* y, long n, void* stream);
 int cdae_cast_bf16_f32(const void* x, float* y, long n, void* stream);
 int cdae_upsample2_16(const void* x, void* y, int N, int H, int W, int C, void* stream);       /* nearest 2x of bf16 NHWC rows (unet.py:76-78) */
-int cdae_sumpool2_16(const void* src, void* dst, int N, int H, int W, int C, void* stream);    /* its gradient: 2x2 sum pool */
+int cdae_sumpool2_16(const void* src, void* dst, int N, int H, int W, int C, void* stream);
+/* y[N H W][9][C] = the 3 x 3 patches (zero padded) of the bf16 NHWC tensor x: a conv's weight gradient then is cdae_linear_wgrad_io over
+   [pixels][9 C] rows — used where the rows are too short for the window wgrad kernel (the 4 x 4 level) */
+int cdae_im2col3x3_16(const void* x, void* y, int N, int H, int W, int C, void* stream);    /* its gradient: 2x2 sum pool */
 int cdae_wprep_all_m16(const float* flat, const void* desc, int nw, int total_tiles, long base, unsigned short* f_hi, unsigned short* f_lo,
                        unsigned short* b_hi, unsigned short* b_lo, unsigned short* kf_hi, unsigned short* kf_lo, unsigned short* kb_hi,
                        unsigned short* kb_lo, const float* w_scales, void* stream);
