@@ -83,7 +83,10 @@ __device__ __forceinline__ void cw_dma(const void* sbase, int soff, unsigned vof
 // the CUs run one block instead of two) and 128 x 4 n-tiles of 96 are exactly 512.  The weight stage keeps its 128-row geometry (rows beyond
 // the n-tile are loaded and never read).
 // IO16 (one-plane instantiations of the 16-bit torso): the result and the residual are bf16 rows (GemmParams::io16 bits 0 and 1 both set)
-template <bool BF, int NT, int NPL = 2, int NJ = 4, bool IO16 = false>
+// PAIR (NPL = 2, the 16-bit torso): the two plane slots carry the FIRST and the SECOND HALF of the input channels of a one-plane operand
+// (the launch points A_lo / Bk_lo half the channels further and halves Cin): two MFMAs per product pair — hi.hi + lo.lo — for the fragment
+// reads, barrier and DMAs of one K step, i.e. half the K steps of the NPL = 1 form, whose step is bound by exactly those fixed costs.
+template <bool BF, int NT, int NPL = 2, int NJ = 4, bool IO16 = false, bool PAIR = false>
 __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, const int ntiles) {
     typedef const unsigned short* hp;
     constexpr int BN = 32 * NJ, WNC = 16 * NJ;                         // n-tile width, columns per wave
@@ -321,7 +324,8 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                     if (i == 0) CW_WAIT("s_waitcnt lgkmcnt(%2)" : "+v"(ah[0]), "+v"(bh[0]) : "n"(NJ - 1));
                     else CW_WAIT("s_waitcnt lgkmcnt(0)" : "+v"(ah[cur]));
                 }
-                if constexpr (NPL == 2) {
+                if constexpr (NPL == 2 && PAIR) acc[i][0] = mma(al(cur), bl(0), acc[i][0]);
+                else if constexpr (NPL == 2) {
                     acc[i][0] = mma(al(cur), bh[0], acc[i][0]);
                     acc[i][0] = mma(ah[cur], bl(0), acc[i][0]);
                 }
@@ -342,7 +346,8 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
                     // tile 0: B(j) is the oldest of the reads in flight [B(j) .. B(NJ - 1), A(1)]
                     if constexpr (NPL == 2) { if (i == 0) CW_WAIT("s_waitcnt lgkmcnt(%2)" : "+v"(bh[j]), "+v"(bl(j)) : "n"(2 * (NJ - j))); }
                     else { if (i == 0) CW_WAIT("s_waitcnt lgkmcnt(%1)" : "+v"(bh[j]) : "n"(NJ - j)); }
-                    if constexpr (NPL == 2) {
+                    if constexpr (NPL == 2 && PAIR) acc[i][j] = mma(al(cur), bl(j), acc[i][j]);
+                    else if constexpr (NPL == 2) {
                         acc[i][j] = mma(al(cur), bh[j], acc[i][j]);
                         acc[i][j] = mma(ah[cur], bl(j), acc[i][j]);
                     }
@@ -544,18 +549,18 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
     }
 }
 
-template <bool BF, int NT, int NPL = 2, int NJ = 4, bool IO16 = false>
+template <bool BF, int NT, int NPL = 2, int NJ = 4, bool IO16 = false, bool PAIR = false>
 int launch_convwin(const GemmParams& p, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convwin_kernel<BF, NT, NPL, NJ, IO16>), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convwin_kernel<BF, NT, NPL, NJ, IO16, PAIR>), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS) != hipSuccess)
             return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
         attr_done = true;
     }
     const long ntiles = (long)((p.M + CW_BM - 1) / CW_BM) * ((p.N + 32 * NJ - 1) / (32 * NJ)) * p.ksplit * (p.nphase > 1 ? p.nphase : 1);
     static const int cfg_persist = CDAE_DEV_INT("CDAE_CONVWIN_GRID", 512);      // persistent blocks: two per CU
     dim3 grid((unsigned)(ntiles < cfg_persist ? ntiles : cfg_persist));
-    hipLaunchKernelGGL((convwin_kernel<BF, NT, NPL, NJ, IO16>), grid, dim3(256), CW_LDS, st, p, (int)ntiles);
+    hipLaunchKernelGGL((convwin_kernel<BF, NT, NPL, NJ, IO16, PAIR>), grid, dim3(256), CW_LDS, st, p, (int)ntiles);
     return hipGetLastError() == hipSuccess ? 0 : cdae_fail("convwin_kernel launch failed");
 }
 
@@ -671,6 +676,15 @@ int cdae_convwin_launch(const GemmParams& p, void* stream) {
     if (p.prec == 3) return launch_convwin<false, 9, 1>(p, st);          // mixed16: one f16 plane
     if (p.io16 & 3) {                                                     // the 16-bit torso: bf16 result (and residual) rows
         if (p.prec != 4 || (p.io16 & 3) != ((p.res ? 2 : 0) | 1)) return cdae_fail("convwin: 16-bit rows need one bf16 plane per operand, a bf16 result and (if any) a bf16 residual");
+        // channel halves in the two plane slots (see PAIR): K-group-major weights, Cin a multiple of 64
+        if (p.Bk_hi && p.Cin % 64 == 0 && !p.a_gm && cdae_tune(TUNE_CONVWIN_PAIR16)) {
+            GemmParams q = p;
+            q.A_lo = reinterpret_cast<const unsigned short*>(p.A) + p.Cin / 2;
+            q.Bk_lo = p.Bk_hi + (long)(p.Cin / 32) * 9 * p.N * 16;
+            q.Cin = p.Cin / 2;
+            // (a K split chosen over the 32-channel chunks of the whole Cin stays as it is: splits beyond the halved chunk count write zero slabs)
+            return launch_convwin<true, 9, 2, 4, true, true>(q, st);
+        }
         return launch_convwin<true, 9, 1, 4, true>(p, st);
     }
     if (p.prec == 4) return launch_convwin<true, 9, 1>(p, st);           // mixed16, gradient operand: one bf16 plane

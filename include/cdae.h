@@ -468,9 +468,12 @@ int cdae_rep_loss_bwd(const float* mu, const float* var, const float* z_post, co
  *                                      covers short row counts (cdae_linear_wgrad_io takes wg16.hip from twice this many rows).
  *                                      1: wherever they apply (tests)
  *   CDAE_TUNE_ROWS16_RING        (1)   K = 256, N % 256 == 0 of that kernel (K = 384 / 512 always): the rows of a step reach the four waves of a block through
- *                                      an LDS ring filled by LDS-DMA several steps ahead; 0: every wave loads them into registers itself */
+ *                                      an LDS ring filled by LDS-DMA several steps ahead; 0: every wave loads them into registers itself
+ *   CDAE_TUNE_CONVWIN_PAIR16     (1)   the window conv on bf16 rows (cdae_conv3x3_fwd16 / _dgrad16, Cin % 64 == 0, K-group-major weights):
+ *                                      the two plane slots of the kernel carry the two halves of the input channels (two MFMAs per K step);
+ *                                      0: the one-plane instantiation */
 enum { CDAE_TUNE_CONVWIN_MIN_TILES = 0, CDAE_TUNE_CONVWIN_SPLITK = 1, CDAE_TUNE_CONVWIN_NJ3 = 2, CDAE_TUNE_HEAD_MFMA = 3, CDAE_TUNE_ROWS16_MIN_M = 4,
-       CDAE_TUNE_ROWS16_RING = 5 };
+       CDAE_TUNE_ROWS16_RING = 5, CDAE_TUNE_CONVWIN_PAIR16 = 6 };
 int cdae_tune_set(int key, int value);
 int cdae_tune_get(int key);       /* -1: unknown key */
 

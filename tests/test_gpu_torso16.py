@@ -411,3 +411,39 @@ def test_downsample16_against_float64(mixed16, N, C, S):
     o.backward(dout.to(DEV).to(torch.bfloat16))
     ops.side_join()
     assert _rel(xd.grad, xr.grad) < 2e-2 and _rel(wd.grad, wr.grad) < 2e-2 and _rel(bd.grad, br.grad) < 2e-2
+
+
+@pytest.mark.parametrize("N,S,Cin,Cout,res", [(4, 32, 128, 128, True), (2, 64, 256, 128, False), (8, 16, 384, 256, True), (16, 8, 512, 512, False)])
+def test_window_conv_bf16_rows_channel_halves_in_the_two_plane_slots(mixed16, N, S, Cin, Cout, res, expect_kernels):
+    """convwin_kernel<bf16, 9, 2 slots, 4, bf16 rows, PAIR>: the window kernel's two plane slots carry the two halves of the input channels
+    (two MFMAs per K step instead of one).  Forward (with residual and GroupNorm sums) and data gradient against float64 of the same
+    bf16 operands, and against the one-plane instantiation (CDAE_TUNE_CONVWIN_PAIR16 = 0): same products, another order of additions."""
+    from causaldiffae_amd import ops, ops16
+    from causaldiffae_amd._lib import check, lib, ptr, stream, tune_scope
+    g = torch.Generator(device=DEV).manual_seed(43)
+    x = ops16.to16_raw(ops.to_nhwc(torch.randn(N, Cin, S, S, device=DEV, generator=g)))
+    w = (torch.randn(Cout, Cin, 3, 3, device=DEV, generator=g) / (9 * Cin) ** 0.5).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(Cout, device=DEV, generator=g) * 0.1
+    r = ops16.to16_raw(ops.to_nhwc(torch.randn(N, Cout, S, S, device=DEV, generator=g))) if res else None
+    dy = ops16.to16_raw(ops.to_nhwc(torch.randn(N, Cout, S, S, device=DEV, generator=g)))
+    f, fk, d, dk = ops.conv_planes16(w)
+    assert fk is not None and dk is not None
+    ws, wsb = ops16._sk(torch.device(DEV))
+    outs, parts, dxs = [], [], []
+    for pair in (1, 0):
+        with tune_scope(convwin_min_tiles=1, convwin_pair16=pair), expect_kernels(convwin_dgrad=2):          # (one-bf16-plane launches are counted with the gradient family)
+            out = ops16.new_act16(N, Cout, S, S, DEV)
+            pt = torch.zeros((N * S * S // 32, Cout, 2), device=DEV)
+            check(lib.cdae_conv3x3_fwd16(ptr(x), S * S * Cin, S * Cin, Cin, f, fk, ptr(b), ptr(r), ptr(out), Cout, ptr(pt), N, S, S, Cin, Cout, ws, wsb, stream()))
+            dx = torch.empty((N, S, S, Cin), dtype=torch.bfloat16, device=DEV)
+            check(lib.cdae_conv3x3_dgrad16(ptr(dy), d, dk, ptr(dx), Cin, N, S, S, Cin, Cout, ws, wsb, stream()))
+        outs.append(out); parts.append(pt); dxs.append(dx)
+    xr, wr = x.double(), w.to(torch.bfloat16).double()
+    ref = F.conv2d(xr, wr, b.double(), padding=1) + (r.double() if res else 0)
+    refdx = F.conv_transpose2d(dy.double(), wr, padding=1)
+    for out, pt, dx in zip(outs, parts, dxs):
+        assert _rel(out, ref) < 1e-2
+        assert _rel(dx.permute(0, 3, 1, 2), refdx) < 1e-2
+        o = out.double().permute(0, 2, 3, 1).reshape(-1, 32, Cout)              # the statistics are those of the ROUNDED values
+        assert (pt[:, :, 0].double() - o.sum(1)).abs().max().item() < 1e-3 * 32 and (pt[:, :, 1].double() - (o * o).sum(1)).abs().max().item() < 1e-2 * 32
+    assert _rel(outs[0], outs[1]) < 1e-2 and _rel(dxs[0], dxs[1]) < 1e-2

@@ -243,17 +243,17 @@ def test_window_conv_k_loop_has_no_compiler_drain():
     spec.loader.exec_module(mod)
     kernels = [r for r in mod.lint("convwin") if "convwin_kernel" in r["kernel"]]
     # <f16 | bf16, 9 taps> x <plane pairs | one plane>, <f16 | bf16, 4 taps, pairs>, the 96-column tile <f16, 9, pairs, 3>, and the 16-bit
-    # torso's <bf16, 9, one plane, bf16 rows out>
-    assert len(kernels) == 8
+    # torso's <bf16, 9, one plane, bf16 rows out> and <bf16, 9, channel halves in the two plane slots, bf16 rows out> (PAIR: two MFMAs per product pair)
+    assert len(kernels) == 9
     for r in kernels:
         assert r["loops"], r["kernel"]
-        args = [a.strip() for a in r["kernel"].split("convwin_kernel<")[1].split(">")[0].split(",")]      # BF, taps, planes, column tiles per wave
-        want = 8 * int(args[3]) * (3 if args[2] == "2" else 1)
+        args = [a.strip() for a in r["kernel"].split("convwin_kernel<")[1].split(">")[0].split(",")]      # BF, taps, planes, column tiles per wave, IO16, PAIR
+        want = 8 * int(args[3]) * ((2 if args[5] == "true" else 3) if args[2] == "2" else 1)
         for lp in r["loops"]:
             assert lp["mfmas"] == want and lp["barriers"] == 1, (r["kernel"], lp)
             assert not lp["vmcnt_waits"] and not lp["scratch"], (r["kernel"], lp)
         # (the bf16-row instantiation's epilogue exchanges values between lane pairs: a few more spilled values, all outside the K loop)
-        assert 0 <= r["vgpr_spills"] <= (24 if args[-1] == "true" else 16), (r["kernel"], r["vgpr_spills"])
+        assert 0 <= r["vgpr_spills"] <= (24 if args[4] == "true" else 16), (r["kernel"], r["vgpr_spills"])
 
 
 

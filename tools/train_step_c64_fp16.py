@@ -9,6 +9,9 @@ if os.environ.get("OFF"):               # OFF=name,name: fused paths of causaldi
     from causaldiffae_amd import ops as _ops
     for _n in os.environ["OFF"].split(","):
         setattr(_ops, _ops.PATH_TOGGLES[_n], False)
+if os.environ.get("PAIR16"):            # A/B of the window conv's channel-halves form on bf16 rows (CDAE_TUNE_CONVWIN_PAIR16)
+    from causaldiffae_amd._lib import lib as _l2
+    _l2.cdae_tune_set(6, int(os.environ["PAIR16"]))
 if os.environ.get("ROWS16_MIN_M"):          # A/B of the streaming kernels' row threshold (include/cdae.h, CDAE_TUNE_ROWS16_MIN_M)
     from causaldiffae_amd._lib import lib as _l
     _l.cdae_tune_set(4, int(os.environ["ROWS16_MIN_M"]))
