@@ -20,6 +20,20 @@
 namespace {
 
 __device__ __forceinline__ float silu_f(float v) { return cdae_silu(v); }
+// On bf16 rows (the 16-bit torso) the result is rounded to 8 significand bits: the short form of the logistic function, 1 / (1 + 2^(-x log2 e)) —
+// four instructions instead of cdae_sigmoid's eight (which carries the rounding error of the exponent into a 2-ulp result so that fp32
+// producers agree bit for bit).  2^t overflows to inf for x < -88 and the reciprocal of inf is 0: no clamp needed for finite x.
+// The bf16 GroupNorm kernels are VALU-bound (two transcendentals + ~30 fp32 operations per element against 2-byte loads).
+template <typename T>
+__device__ __forceinline__ float sigmoid_t(float x) {
+    if constexpr (sizeof(T) == 2) return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.44269502162933349609375f));
+    else return cdae_sigmoid(x);
+}
+template <typename T>
+__device__ __forceinline__ float silu_t(float v) {
+    if constexpr (sizeof(T) == 2) return v * sigmoid_t<T>(v);
+    else return cdae_silu(v);
+}
 
 // Storage type of an activation / gradient tensor: float (the parity modes) or __bf16 (the half-precision torso: the reference's
 // convert_to_fp16 placement, unet.py:501-507 — 16-bit activations between the layers, fp32 statistics inside GroupNorm32, nn.py:435-437).
@@ -374,7 +388,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     ldx = ldxe;
     T* yp = y + (long)n * HW * ldy + c;
     const int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
-    auto apply = [&](float v, int i) { float h = fmaf(v, A[i], B[i]); return do_silu ? silu_f(h) : h; };
+    auto apply = [&](float v, int i) { float h = fmaf(v, A[i], B[i]); return do_silu ? silu_t<T>(h) : h; };
     int p = p0 + r;
     if constexpr (VEC == 4) {
         const long hbase = (long)n * HW * ldy + c;
@@ -518,7 +532,7 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const T* __restrict
                 float u = xh * gm[i] + bt[i];
                 float h = u * a[i] + sh[i];
                 float dh = dv[i];
-                if (do_silu) { float s = cdae_sigmoid(h); dh *= s * (1.f + h * (1.f - s)); }
+                if (do_silu) { float s = sigmoid_t<T>(h); dh *= s * (1.f + h * (1.f - s)); }
                 float du = dh * a[i];
                 float dxh = du * gm[i];
                 A += dxh; B += dxh * xh;
@@ -728,7 +742,7 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const T* __restrict__ x,
             float xh = (xv[i] - mu) * rs;
             float h = (xh * gm + beta[c + i]) * a + sh;
             float dh = dv[i];
-            if (do_silu) { float s = cdae_sigmoid(h); dh *= s * (1.f + h * (1.f - s)); }
+            if (do_silu) { float s = sigmoid_t<T>(h); dh *= s * (1.f + h * (1.f - s)); }
             float dxh = dh * a * gm;
             o[i] = rs * (dxh - m1 - xh * m2);
         }
@@ -816,7 +830,7 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_stream_kernel(const T* __restri
             float xh = (xv[i] - mu) * rs;
             float h = (xh * gm[i] + bt[i]) * a[i] + sh[i];
             float dh = dv[i];
-            if (do_silu) { float s = cdae_sigmoid(h); dh *= s * (1.f + h * (1.f - s)); }
+            if (do_silu) { float s = sigmoid_t<T>(h); dh *= s * (1.f + h * (1.f - s)); }
             float dxh = dh * a[i] * gm[i];
             o[i] = rs * (dxh - m1 - xh * m2);
         }
