@@ -1,23 +1,25 @@
 // rows16.hip — the 1 x 1 convolutions / linears of the 16-bit torso on LARGE row counts (gfx950 only):
 //
-//     C[M][N] = A[M][K] . B[N][K]^T + bias (+ res),      A, B bf16 rows with K contiguous, C / res bf16 rows,  K <= 256
+//     C[M][N] = A[M][K] . B[N][K]^T + bias (+ res),      A, B bf16 rows with K contiguous, C / res bf16 rows,  K in {64 .. 768}
 //
 // (reference improved_diffusion/unet.py:165-171 skip_connection = conv_nd(dims, channels, out_channels, 1), :218-236 AttentionBlock qkv /
 // proj_out as conv_nd(1, ...), and their data gradients with B = W^T.)  With M = batch x pixels in the 10^4..10^5 and K, N of 128..768 these
 // are HBM streams — 2 (K + N) bytes per row against 2 K N flops — that the 128 x 128 plane GEMM tile (ps_kernel) runs at 0.3 of the
 // HBM rate: every block pays a global -> LDS prologue for both operands and a 2-byte-store epilogue around eight K-steps.  Here:
-//   * the weight does not go through LDS at all: a wave keeps the MFMA fragments of ITS 64 (K = 256) or 128 (K <= 128) output channels
-//     over the whole K in registers (128 VGPRs) and streams 16-row steps;
-//   * the activation rows never touch LDS either: a lane's fragment IS 16 contiguous bytes of its row, loaded global -> registers one
-//     step ahead of the products;
+//   * the weight does not go through LDS at all: a wave keeps the MFMA fragments of ITS output channels over the whole K in registers
+//     (96 - 128 VGPRs: 128 channels for K <= 128, 64 for K = 256, 32 for K = 384 / 512, 16 for K = 768) and streams 16-row steps;
+//   * the activation rows: a lane's fragment IS 16 contiguous bytes of its row.  rows16_reg_kernel loads them global -> registers one step
+//     ahead (K <= 256 with few channel groups); rows16_ring_kernel fetches a step once per block by LDS-DMA, two to five steps ahead
+//     (the four waves of a block hold four channel groups of the same rows: without the ring a CU has two 8 KB steps in flight);
 //   * v_mfma_f32_16x16x32_bf16 with the operands SWAPPED (weight fragment in the A slot): the accumulator registers of a lane are then
-//     four consecutive COLUMNS of one row, and with the weight columns permuted inside each 64-column group a lane owns 16 consecutive
+//     four consecutive COLUMNS of one row, and with the weight columns permuted inside each group a lane owns 16 (8, 4) consecutive
 //     columns — residual and result move as 16-byte pieces (the ps_kernel epilogue: 2-byte pieces);
-//   * the waves of a block take neighbouring channel groups of the same rows (their fragment loads hit L1 / L2) or, when the result has
-//     fewer than four groups, neighbouring row steps; the blocks of one row range run on one XCD (N = 768: three blocks read a row).
+//   * the waves of a block take neighbouring channel groups of the same rows or, when the result has fewer than four groups,
+//     neighbouring row steps; the blocks of one row range run on one XCD (N = 768: three blocks read a row).
 // Arithmetic: single-plane bf16 products, fp32 accumulation — the mixed16 mode's; K order differs from ps_kernel's, nothing else.
-// K > 256 (the qkv data gradient, K = 3 C) stays on the plane GEMM: its weight does not fit the registers, and an LDS-panel form of this
-// kernel (one 256-deep chunk resident, reloaded per row tile) measured 57 us against the plane GEMM's 56 on 65536 x 256 x 768.
+// K = 1152 / 1536 (the qkv data gradient of the 384 / 512-channel levels) stay on the plane GEMM: 192 VGPRs of weight at 16 channels per
+// wave, one ring step per slot.  (An LDS-PANEL form — weight chunk resident in LDS, rows global -> registers — was the first version:
+// 24 us on 65536 x 256 x 256 where the ring form takes 20.5, and 57 us at K = 768 with the panel reloaded per row tile.)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 
