@@ -24,5 +24,10 @@ for pid in "${pids[@]:-}"; do [ -z "$pid" ] || wait "$pid" || { echo "build.sh: 
 echo "$FLAGS" > build/.flags
 objs=""
 for u in $UNITS; do objs="$objs build/$u.o"; done
+# build/ holds exactly the current units' objects: anything else (retired objects, -save-temps dumps) would ride to every GPU lease
+for f in build/*; do
+    keep=0; for u in $UNITS; do [ "$f" = "build/$u.o" ] && keep=1; done
+    [ $keep = 1 ] || rm -rf "$f"
+done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $objs
 echo "built $(realpath $OUT)"

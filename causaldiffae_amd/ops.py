@@ -1274,10 +1274,12 @@ _TORSO16_ON = True      # path toggle: False = the mixed16 mode keeps fp32 activ
 _FLAT16 = []
 
 
-def register_flat16(flat):
-    """Called by train_util.FlatParams: weights that are views of `flat` get their bf16 copy from ONE cast of the buffer per weight version."""
+def register_flat16(flat, views=()):
+    """Called by train_util.FlatParams: weights that are views of `flat` get their bf16 copy from ONE cast of the buffer per weight version.
+    `views`: every parameter view of the buffer — their versions are recorded WHEN the image is cast, so an in-place write to a weight that
+    has not been asked for yet in this epoch is seen at its first ask."""
     _FLAT16[:] = [e for e in _FLAT16 if e["ref"]() is not None]
-    _FLAT16.append(dict(ref=weakref.ref(flat), img=None, epoch=None, versions={}))
+    _FLAT16.append(dict(ref=weakref.ref(flat), img=None, epoch=None, versions={}, views=[weakref.ref(v) for v in views]))
 
 
 def flat16_pointer(w):
@@ -1289,16 +1291,23 @@ def flat16_pointer(w):
         flat = e["ref"]()
         if flat is None or flat.untyped_storage().data_ptr() != sp or not w.is_contiguous():
             continue
-        if e["epoch"] != _WEIGHT_EPOCH[0] or e["versions"].get(id(w), w._version) != w._version:
+        off = (w.data_ptr() - flat.data_ptr()) // 4
+        if off % 8:
+            return None              # the streaming kernels read weights as 16-byte pieces: the caller takes its own (aligned) per-weight copy
+        # stale: a new weight epoch (the optimizer kernel rewrote the buffer), or THIS weight's version is not the one the image was cast
+        # from (recorded for every registered view at cast time; a tensor that is not a registered view is recast at its first ask)
+        rec = e["versions"].get(id(w))
+        if e["epoch"] != _WEIGHT_EPOCH[0] or rec is None or rec[0]() is not w or rec[1] != w._version:
             if e["img"] is None:
                 e["img"] = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device)
             n4 = flat.numel() // 4 * 4
             check(lib.cdae_cast_f32_bf16(ptr(flat), ptr(e["img"]), n4, stream()))
             if n4 < flat.numel():
                 e["img"][n4:].copy_(flat[n4:])
-            e["epoch"], e["versions"] = _WEIGHT_EPOCH[0], {}
-        e["versions"][id(w)] = w._version
-        return e["img"].data_ptr() + (w.data_ptr() - flat.data_ptr()) // 2
+            live = [v for v in (r() for r in e["views"]) if v is not None]
+            e["epoch"], e["versions"] = _WEIGHT_EPOCH[0], {id(v): (weakref.ref(v), v._version) for v in live}
+            e["versions"][id(w)] = (weakref.ref(w), w._version)
+        return e["img"].data_ptr() + 2 * off
     return None
 
 

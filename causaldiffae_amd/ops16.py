@@ -194,7 +194,7 @@ def _gn_bwd(x, x2, dy, dx, dx2, stats, gamma, beta, ss, silu, sinks, ss_sink, N,
 def _w16_conv(w):
     """(forward OHWI, forward K-group-major, dgrad [Cin][9][Cout], dgrad K-group-major) bf16 plane pointers of a conv3x3 weight"""
     bank = ops._bank(w)
-    if bank is not None:
+    if bank is not None and bank.kpack:          # (the bank's one-launch bf16 forward planes ride with its K-group-major planes: `kpack` path toggle)
         return bank.pointers16(w)
     return ops.conv_planes16(w)
 

@@ -21,6 +21,9 @@ from ._lib import check, lib, ptr, stream
 from .resample import LossAwareSampler, UniformSampler
 
 
+FLAT_ALIGN = 8         # elements: see FlatParams.__init__
+
+
 class FlatParams:
     """Re-homes a module's parameters (and their .grad) as views of two flat fp32 buffers, in registration order."""
 
@@ -39,12 +42,16 @@ class FlatParams:
         self.params = [p for _, p in named]
         self.names = [n for n, _ in named]
         dev = self.params[0].device
+        # every view starts on a 32-byte boundary (8 fp32 = 8 bf16 of the buffer's 16-bit image = one 16-byte piece of it): the streaming
+        # kernels read weights / write weight gradients as 16-byte pieces, and n_vars = 3 or 5 makes `causal_mask.*.bias` 170 / 102 elements,
+        # which would leave every 1x1 weight behind it 8 bytes off.  The padding elements are zero in weights, gradients and moments and stay zero.
         self.offsets, off = [], 0
         for p in self.params:
+            off = (off + FLAT_ALIGN - 1) // FLAT_ALIGN * FLAT_ALIGN
             self.offsets.append(off)
             off += p.numel()
         self.numel = off
-        self.flat = th.empty(off, dtype=th.float32, device=dev)
+        self.flat = th.zeros(off, dtype=th.float32, device=dev)
         self.grad = th.zeros(off, dtype=th.float32, device=dev)
         for p, o in zip(self.params, self.offsets):
             view = self.flat.as_strided(p.shape, p.stride(), o)
@@ -62,6 +69,8 @@ class FlatParams:
             for blk, w in zip(blocks, ws):
                 offs.append((id(blk), o, w.shape[0]))
                 o += w.shape[0]
+            assert self.offsets[len(ws)] == T * K and all(self.offsets[len(ws) + i + 1] - self.offsets[len(ws) + i] == w.shape[0] for i, w in enumerate(ws[:-1])), \
+                "emb_layers weights / biases must lie back to back (channel counts that are multiples of 8)"
             emb_w = self.flat[:T * K].view(T, K)
             model._emb_flat = dict(w=emb_w, b=self.flat[T * K:T * K + T], gw=self.grad[:T * K].view(T, K),
                                    gb=self.grad[T * K:T * K + T], params=lead, offs=offs)
@@ -71,7 +80,7 @@ class FlatParams:
         self.scale_table = ops.register_scale_table(self.flat, self.params + ([emb_w] if emb_w is not None else [])) if dev.type == "cuda" else None
         self.conv_bank = ops.register_conv_bank(self.flat, self.params) if dev.type == "cuda" else None
         if dev.type == "cuda":
-            ops.register_flat16(self.flat)          # the 16-bit torso's 1x1 / linear weights: one bf16 image of the buffer per weight version
+            ops.register_flat16(self.flat, self.params)          # the 16-bit torso's 1x1 / linear weights: one bf16 image of the buffer per weight version
 
     def zero_grad(self):
         self.grad.zero_()
@@ -396,7 +405,16 @@ class TrainLoop:
         self.buckets.reduce_all()
         return True
 
+    @property
+    def grad_scale(self):
+        """What to multiply `p.grad` / the flat gradient buffer by to get the data-parallel MEAN gradient (see forward_backward)."""
+        return getattr(self, "_grad_scale", 1.0)
+
     def forward_backward(self, batch, cond):
+        """Contract (differs from the reference's DDP, which averages before the optimizer): after this call the flat gradient buffer — and so
+        every `p.grad` — holds the cross-rank SUM; the 1 / world factor is `self.grad_scale`, which `optimize_normal` hands to the fused
+        AdamW / EMA kernel and `log_step` to the gradient norm.  Anything else that reads `p.grad` between the two calls (clipping, custom
+        logging, another optimizer) must multiply by `self.grad_scale`."""
         from ._lib import precision_scope
         with precision_scope(getattr(self.model, "_cdae_precision", None)):      # the backward kernels run in the model's own mode too
             self._forward_backward(batch, cond)

@@ -2,7 +2,8 @@
 import os, sys, json, io, contextlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from causaldiffae_amd._lib import lib, TUNE_KEYS
-for kv in sys.argv[1:]:
+KEYS = list(sys.argv[1:])
+for kv in KEYS:
     k, v = kv.split("=")
     assert lib.cdae_tune_set(TUNE_KEYS[k], int(v)) == 0
 sys.argv = ["bench.py", "--steps", "20", "--warmup", "5", "--regions", "3", "--no-train", "--no-fp32", "--no-extra", "--no-cpu-baseline", "--batch", "16"]
@@ -13,4 +14,4 @@ with contextlib.redirect_stdout(buf):
 for l in buf.getvalue().splitlines():
     if l.startswith("{"):
         d = json.loads(l)
-        print(" ".join(sys.argv[1:]) if False else "", "batch 16: %.3f ms per step" % d["ms_per_step"])
+        print(" ".join(KEYS) or "(defaults)", "| batch 16: %.3f ms per step" % d["ms_per_step"])

@@ -25,7 +25,8 @@ bench.randomize(model, 4321)
 model.to(dev).train()
 data = load_data(data_dir="synthetic", batch_size=B, image_size=64, in_channels=3, n_vars=4, seed=0, device=dev)
 loop = TrainLoop(model=model, diffusion=diff, data=data, batch_size=B, microbatch=-1, lr=1e-4, ema_rate="0.9999", log_interval=10 ** 9,
-                 save_interval=10 ** 9, resume_checkpoint="", rep_cond=True, n_vars=4, causal_modeling=True, in_channels=3)
+                 save_interval=10 ** 9, resume_checkpoint="", rep_cond=True, n_vars=4, causal_modeling=True, in_channels=3,
+                 use_graph=bool(int(os.environ.get("GRAPH", "0"))), use_fp16=bool(int(os.environ.get("FP16", "0"))))
 diff.kl_weight = 0.1
 
 
@@ -37,12 +38,15 @@ def step():
 
 for _ in range(8):
     step()
-out = []
+out, cpu = [], []
 for _ in range(REGIONS):
     torch.cuda.synchronize()
+    c0 = time.process_time()
     t0 = time.perf_counter()
     for _ in range(STEPS):
         step()
     torch.cuda.synchronize()
     out.append((time.perf_counter() - t0) / STEPS * 1e3)
-print("train ms/step:", " ".join(f"{v:.3f}" for v in out), "| env:", {k: v for k, v in os.environ.items() if k.startswith("CDAE_") or k == "OFF"})
+    cpu.append((time.process_time() - c0) / STEPS * 1e3)
+print("train ms/step:", " ".join(f"{v:.3f}" for v in out), "| host cpu ms/step:", " ".join(f"{v:.1f}" for v in cpu),
+      "| graphs:", len(loop._graphs), "failed:", loop._graph_failed, "| loss", float(loop.last_losses["loss"].mean()), "| env:", {k: v for k, v in os.environ.items() if k.startswith("CDAE_") or k == "OFF"})

@@ -10,10 +10,10 @@ if os.environ.get("OFF"):               # OFF=name,name: fused paths of causaldi
         setattr(_ops, _ops.PATH_TOGGLES[_n], False)
 if os.environ.get("PAIR16"):            # A/B of the window conv's channel-halves form on bf16 rows (CDAE_TUNE_CONVWIN_PAIR16)
     from causaldiffae_amd._lib import lib as _l2
-    _l2.cdae_tune_set(6, int(os.environ["PAIR16"]))
+    _l2.cdae_tune_set(__import__("causaldiffae_amd")._lib.TUNE_KEYS["convwin_pair16"], int(os.environ["PAIR16"]))
 if os.environ.get("ROWS16_MIN_M"):          # A/B of the streaming kernels' row threshold (include/cdae.h, CDAE_TUNE_ROWS16_MIN_M)
     from causaldiffae_amd._lib import lib as _l
-    _l.cdae_tune_set(4, int(os.environ["ROWS16_MIN_M"]))
+    _l.cdae_tune_set(__import__("causaldiffae_amd")._lib.TUNE_KEYS["rows16_min_m"], int(os.environ["ROWS16_MIN_M"]))
 fp16 = len(sys.argv) > 2 and sys.argv[2] == "1"
 r = bench.train_bench(dev, 1, 0, int(sys.argv[1]) if len(sys.argv) > 1 else 3, 2, 256, use_fp16=fp16, workload="M32", image_size=32, in_channels=1, n_vars=2, class_cond=True)
 print({k: r[k] for k in ("value", "ms_per_step", "precision_mode")})
