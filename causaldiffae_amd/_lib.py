@@ -158,6 +158,9 @@ SIGNATURES = {
     "cdae_prof_read": [P, P, P, P],
     "cdae_calib_mfma": [P, SZ, I, P, P, P],
     "cdae_calib_copy": [P, P, SZ, I, P, P],
+    "cdae_stream_link_create": [P],
+    "cdae_stream_link_order": [P, P, P],
+    "cdae_stream_link_destroy": [P],
 }
 _RESTYPES = {"cdae_last_error": ctypes.c_char_p, "cdae_gn_workspace_floats": SZ, "cdae_bn_workspace_floats": SZ, "cdae_workspace_bytes": SZ}
 

@@ -107,8 +107,35 @@ __global__ void __launch_bounds__(64) calib_mfma_kernel(const calib_half8* __res
     out[blockIdx.x * 64 + threadIdx.x] = s;
     if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) { atomicAdd(&clk[0], t1 - t0); atomicAdd(&clk[1], r1 - r0); }
 }
-__global__ void __launch_bounds__(256) calib_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long n4) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) dst[i] = src[i];
+// flat copy with U 16-byte loads in flight per lane before the first store (a block moves U x 4 KiB per trip; the tail trip is guarded).
+// NT: nontemporal loads and stores (no reuse: keeps the stream out of the MALL's way).
+template <int U, bool NT>
+__global__ void __launch_bounds__(256) calib_copy_kernel(const calib_f32x4* __restrict__ src, calib_f32x4* __restrict__ dst, long n4) {
+    const long chunk = 256L * U;
+    for (long base = (long)blockIdx.x * chunk; base < n4; base += (long)gridDim.x * chunk) {
+        calib_f32x4 v[U];
+        const long i0 = base + threadIdx.x;
+        if (base + chunk <= n4) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(src + i0 + 256L * u) : src[i0 + 256L * u];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { if (NT) __builtin_nontemporal_store(v[u], dst + i0 + 256L * u); else dst[i0 + 256L * u] = v[u]; }
+        } else {
+            for (int u = 0; u < U; ++u) if (i0 + 256L * u < n4) dst[i0 + 256L * u] = src[i0 + 256L * u];
+        }
+    }
+}
+template <int U, bool NT>
+static double calib_copy_run(const void* src, void* dst, long n4, int blocks, int reps, hipEvent_t e0, hipEvent_t e1, hipStream_t st) {
+    hipLaunchKernelGGL((calib_copy_kernel<U, NT>), dim3(blocks), dim3(256), 0, st, (const calib_f32x4*)src, (calib_f32x4*)dst, n4);
+    hipEventRecord(e0, st);
+    for (int r = 0; r < reps; ++r)
+        hipLaunchKernelGGL((calib_copy_kernel<U, NT>), dim3(blocks), dim3(256), 0, st, (const calib_f32x4*)src, (calib_f32x4*)dst, n4);
+    hipEventRecord(e1, st);
+    if (hipEventSynchronize(e1) != hipSuccess) return -1.0;
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    return 2.0 * 16.0 * (double)n4 * reps / (ms * 1e-3) / 1e12;
 }
 }  // namespace
 
@@ -147,22 +174,64 @@ int cdae_calib_mfma(void* scratch, size_t scratch_bytes, int iters, double* tflo
     return 0;
 }
 
-// HBM copy rate (read + write bytes per second) of a flat float4 copy src -> dst of `bytes` bytes (use >= 1 GiB: beyond the 256 MiB MALL)
+// HBM copy rate (read + write bytes per second) of a flat 16-byte-per-lane copy src -> dst of `bytes` bytes (use >= 1 GiB: beyond the
+// 256 MiB MALL): the best of a few forms (1 / 4 / 8 loads in flight per lane, plain or nontemporal, grid = 8 or 16 blocks per CU) — the
+// number stands for what the box's memory system delivers, not for one kernel shape (MI355X_MICROARCH.md measures 6.29 TB/s).
 int cdae_calib_copy(const void* src, void* dst, size_t bytes, int reps, double* tbps, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (!src || !dst || bytes < 4096 || bytes % 16 || reps <= 0 || !tbps) return cdae_fail("calib_copy: bad arguments");
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     const long n4 = (long)(bytes / 16);
-    hipLaunchKernelGGL(calib_copy_kernel, dim3(256 * 16), dim3(256), 0, st, (const float4*)src, (float4*)dst, n4);
-    hipEventRecord(e0, st);
-    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(calib_copy_kernel, dim3(256 * 16), dim3(256), 0, st, (const float4*)src, (float4*)dst, n4);
-    hipEventRecord(e1, st);
-    if (hipEventSynchronize(e1) != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); return cdae_fail("calib_copy: kernel failed"); }
-    float ms = 0.f;
-    hipEventElapsedTime(&ms, e0, e1);
+    double best = 0.0;
+    bool bad = false;
+    auto take = [&](double v) { if (v < 0) bad = true; else if (v > best) best = v; };
+    for (int blocks : {256 * 8, 256 * 16}) {
+        take(calib_copy_run<1, false>(src, dst, n4, blocks, reps, e0, e1, st));
+        take(calib_copy_run<4, false>(src, dst, n4, blocks, reps, e0, e1, st));
+        take(calib_copy_run<8, false>(src, dst, n4, blocks, reps, e0, e1, st));
+        take(calib_copy_run<4, true>(src, dst, n4, blocks, reps, e0, e1, st));
+        take(calib_copy_run<8, true>(src, dst, n4, blocks, reps, e0, e1, st));
+    }
     hipEventDestroy(e0); hipEventDestroy(e1);
-    *tbps = 2.0 * (double)bytes * reps / (ms * 1e-3) / 1e12;
+    if (bad) return cdae_fail("calib_copy: kernel failed");
+    *tbps = best;
+    return 0;
+}
+
+// ---- stream order links: see include/cdae.h
+struct CdaeStreamLink { void* word; unsigned seq; };
+
+int cdae_stream_link_create(void** link) {
+    if (!link) return cdae_fail("stream_link_create: null argument");
+    void* w = nullptr;
+    if (hipExtMallocWithFlags(&w, 8, hipMallocSignalMemory) != hipSuccess || !w) return cdae_fail("stream_link_create: hipExtMallocWithFlags(signal memory) failed");
+    if (hipMemset(w, 0, 8) != hipSuccess) { (void)hipFree(w); return cdae_fail("stream_link_create: hipMemset failed"); }
+    *link = new CdaeStreamLink{w, 0u};
+    return 0;
+}
+
+int cdae_stream_link_order(void* link, void* producer_stream, void* consumer_stream) {
+    CdaeStreamLink* l = static_cast<CdaeStreamLink*>(link);
+    if (!l || !l->word) return cdae_fail("stream_link_order: null link");
+    hipStream_t prod = (hipStream_t)producer_stream, cons = (hipStream_t)consumer_stream;
+    if (prod == cons) return 0;
+    if (l->seq >= 0x7ffffff0u) {               // the comparison is >= on 32 bits: start over behind both streams (once per 2^31 dependencies)
+        if (hipStreamSynchronize(prod) != hipSuccess || hipStreamSynchronize(cons) != hipSuccess || hipMemset(l->word, 0, 8) != hipSuccess)
+            return cdae_fail("stream_link_order: sequence reset failed");
+        l->seq = 0;
+    }
+    const unsigned v = ++l->seq;
+    if (hipStreamWriteValue32(prod, l->word, v, 0) != hipSuccess) return cdae_fail("stream_link_order: hipStreamWriteValue32 failed");
+    if (hipStreamWaitValue32(cons, l->word, v, hipStreamWaitValueGte, 0xffffffffu) != hipSuccess) return cdae_fail("stream_link_order: hipStreamWaitValue32 failed");
+    return 0;
+}
+
+int cdae_stream_link_destroy(void* link) {
+    CdaeStreamLink* l = static_cast<CdaeStreamLink*>(link);
+    if (!l) return 0;
+    if (l->word) (void)hipFree(l->word);
+    delete l;
     return 0;
 }
 

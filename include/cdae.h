@@ -537,6 +537,18 @@ int cdae_prof_read(double* ms, double* work, double* bytes, long long* launches)
 int cdae_calib_mfma(void* scratch, size_t scratch_bytes, int iters, double* tflops, double* sclk_ghz, void* stream);
 int cdae_calib_copy(const void* src, void* dst, size_t bytes, int reps, double* tbps, void* stream);
 
+/* ---- stream order links (prof.hip): "everything enqueued on `consumer` after this call runs behind everything enqueued on `producer`
+   before it", WITHOUT a hipEvent.  The trainer overlaps weight gradients (a second stream) with the data-gradient chain (reference
+   train_util.py:255-259 runs them on one stream); ordered by hipEventRecord / hipStreamWaitEvent, every pending dependency keeps a ROCm
+   runtime helper thread spinning on the host (one full core per rank for the whole step: 28 ms of CPU per 27 ms step on MI355X /
+   ROCm 7.2).  A link is one 8-byte word of signal memory: the producer stream WRITES the next sequence number when it gets there
+   (hipStreamWriteValue32), the consumer stream WAITS for it (hipStreamWaitValue32, >=) — both executed by the GPU's command processor.
+   One link per direction and stream pair; calls on one link must come from one host thread at a time.  Not capturable into a HIP graph
+   (the caller uses events there).  cdae_stream_link_create allocates (the one allocation of the library besides the profiler's events). */
+int cdae_stream_link_create(void** link);
+int cdae_stream_link_order(void* link, void* producer_stream, void* consumer_stream);
+int cdae_stream_link_destroy(void* link);
+
 #ifdef __cplusplus
 }
 #endif

@@ -765,6 +765,42 @@ def g15_m32_b256(out_dir):
     np.savez_compressed(os.path.join(out_dir, "g15_m32_b256.npz"), **out)
 
 
+# --------------------------------------------------------------------------- G21: a 24-step fp32 loss curve the 16-bit torso is trained against
+def g21_m32_curve(out_dir):
+    """24 optimizer steps of the reference (fp32, AdamW lr 1e-4, kl_weight 0.1) on the M32 model at batch 16, data cycling through a pool of
+    four closed-form batches: the loss / mse / kld_rep means per step.  tests/test_gpu_torso16.py trains the SAME run through TrainLoop in the
+    parity mode (tight) and on the 16-bit torso (use_fp16: 2e-2) and then carries both on to 120 steps (train_util.py:231-297)."""
+    from torch.optim import AdamW
+    out = {}
+    N, STEPS = 16, 24
+    model, diff, base = make("M32")
+    model.train()
+    params = list(model.parameters())
+    opt = AdamW(params, lr=1e-4, weight_decay=0.0)
+    diff.kl_weight = 0.1
+    for step in range(STEPS):
+        b = step % 4
+        x0 = synth(f"M32c.{b}.x0", (N, 1, 32, 32), -1.0, 1.0)
+        c = synth(f"M32c.{b}.c", (N, 2), 0.0, 1.0)
+        y = th.tensor([(b + 3 * i) % 10 for i in range(N)], dtype=th.int64)
+        t = th.tensor([(137 * (step + 1) + 251 * i) % 1000 for i in range(N)], dtype=th.int64)
+        noise = synth_noise(f"M32c.{step}.noise", (N, 1, 32, 32))
+        for p in params:
+            p.grad = None
+        th.manual_seed(300 + step)
+        terms = diff.training_losses(model, x0, t, model_kwargs=dict(c=c, y=y), noise=noise, rep_cond=True, causal_modeling=True)
+        th.manual_seed(300 + step)
+        eps = th.randn(N, 512)
+        out[f"step{step}/eps_draw_check"] = np.array([eps.double().sum().item(), (eps.double() ** 2).sum().item()] + eps.flatten()[:6].tolist())
+        terms["loss"].mean().backward()
+        for k in ("loss", "mse", "kld_rep"):
+            out[f"step{step}/{k}_mean"] = np.float64(terms[k].detach().double().mean().item())
+        opt.step()
+        print("  G21 step", step, float(terms["loss"].mean()), float(terms["mse"].mean()), flush=True)
+    out["steps"], out["batch"] = np.int64(STEPS), np.int64(N)
+    np.savez_compressed(os.path.join(out_dir, "g21_m32_curve.npz"), **out)
+
+
 # --------------------------------------------------------------------------- G16
 def g16_dropout(out_dir):
     """Training-mode ResBlock with dropout > 0 (unet.py:153): the keep mask the reference's nn.Dropout drew is recorded next to the
@@ -956,7 +992,7 @@ def g20_traversal(out_dir):
     np.savez_compressed(os.path.join(out_dir, "g20_traversal.npz"), **out)
 
 
-ALL = dict(G16=g16_dropout, G1=g1_schedules, G2=g2_temb, G3=g3_blocks, G4=g4_encoder, G5=g5_rep_loss, G6=g6_unet, G7=g7_train, G8=g8_ddim, G9=g9_vlb, G10=g10_flow, G11=g11_variants, G12=g12_full_train, G13=g13_guidance, G14=g14_p_sample_loop, G15=g15_m32_b256, G17=g17_ddim250, G18=g18_p_sample_t1000, G19=g19_trained_like, G20=g20_traversal)
+ALL = dict(G16=g16_dropout, G1=g1_schedules, G2=g2_temb, G3=g3_blocks, G4=g4_encoder, G5=g5_rep_loss, G6=g6_unet, G7=g7_train, G8=g8_ddim, G9=g9_vlb, G10=g10_flow, G11=g11_variants, G12=g12_full_train, G13=g13_guidance, G14=g14_p_sample_loop, G15=g15_m32_b256, G17=g17_ddim250, G18=g18_p_sample_t1000, G19=g19_trained_like, G20=g20_traversal, G21=g21_m32_curve)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
