@@ -3,6 +3,13 @@ without it raises, and calling any op on a non-GPU tensor raises — there is no
 import ctypes
 import os
 
+# ROCm runtime default, set before the HIP runtime reads its settings (its first API call): ROCclr releases a queue's completed commands in
+# batches, each batch end being a completion callback served by rocr's AsyncEventsLoop thread.  At the default batch size that thread is
+# busy for 23 of the 27.5 ms of a training step (~1000 launches, the host one step ahead): a second host core per rank that eight ranks
+# under a 16-core quota do not have.  With batches of 32768 commands it is 1-3 ms (measured, tools/host_env_sweep2.sh; docs/NOTES.md
+# round 6).  A user's own setting wins; a process that initialised HIP before importing this package keeps the runtime's default.
+os.environ.setdefault("DEBUG_CLR_MAX_BATCH_SIZE", "32768")
+
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -158,9 +165,6 @@ SIGNATURES = {
     "cdae_prof_read": [P, P, P, P],
     "cdae_calib_mfma": [P, SZ, I, P, P, P],
     "cdae_calib_copy": [P, P, SZ, I, P, P],
-    "cdae_stream_link_create": [P],
-    "cdae_stream_link_order": [P, P, P],
-    "cdae_stream_link_destroy": [P],
 }
 _RESTYPES = {"cdae_last_error": ctypes.c_char_p, "cdae_gn_workspace_floats": SZ, "cdae_bn_workspace_floats": SZ, "cdae_workspace_bytes": SZ}
 
@@ -365,7 +369,7 @@ class precision_scope:
         return False
 
 
-TUNE_KEYS = {"convwin_min_tiles": 0, "convwin_splitk": 1, "convwin_nj3": 2, "head_mfma": 3, "rows16_min_m": 4, "rows16_ring": 5, "convwin_pair16": 6}
+TUNE_KEYS = {"convwin_min_tiles": 0, "convwin_splitk": 1, "convwin_nj3": 2, "head_mfma": 3, "rows16_min_m": 4, "rows16_ring": 5, "convwin_pair16": 6, "gn_bwd_fold2": 7}
 
 
 class tune_scope:

@@ -790,8 +790,48 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_stream_kernel(const T* __restri
                                                                 const T* __restrict__ x2, int ld2, int C1,
                                                                 T* __restrict__ dx2, int lddx2,
                                                                 int N, const float* __restrict__ nc_part, float* __restrict__ dgamma,
-                                                                float* __restrict__ dbeta, int accumulate_params) {
-    if ((int)blockIdx.y == N) {       // (nc_part != nullptr) one extra row of blocks: pass 2b, dgamma / dbeta = the per-image sums folded over the batch
+                                                                float* __restrict__ dbeta, int accumulate_params,
+                                                                const float* __restrict__ gpart = nullptr, const float* __restrict__ cpart = nullptr,
+                                                                int nchunk_p = 0, float* __restrict__ dss = nullptr, int ld_dss = 0) {
+    if (cpart != nullptr && (int)blockIdx.y >= N) {
+        // FOLD form (gpart / cpart given: no separate fold launch): rows N.. of the grid fold pass 1's per-chunk channel sums — channel
+        // block cb = (y - N) * gridDim.x + x, 8 image lanes x 32 channels: d(scale, shift)[n][c] = the chunk sums of image n, and
+        // dgamma / dbeta = those of every image, all in a fixed order (chunks of an image in sequence, images of a lane in sequence, lanes 0..7)
+        __shared__ double sA[8][32], sB[8][32];
+        const int cb = ((int)blockIdx.y - N) * (int)gridDim.x + (int)blockIdx.x;
+        if (cb * 32 >= C) return;
+        const int cc = threadIdx.x & 31, nl = threadIdx.x >> 5, c = cb * 32 + cc;
+        double a = 0, b = 0;
+        if (c < C) {
+            for (int n = nl; n < N; n += 8) {
+                const float* src = cpart + ((long)n * nchunk_p * C + c) * 4;
+                double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+                int k = 0;
+                for (; k + 4 <= nchunk_p; k += 4) {      // four chunk records in flight; additions in chunk order
+                    const float4 p0 = *reinterpret_cast<const float4*>(src + (long)k * C * 4), p1 = *reinterpret_cast<const float4*>(src + (long)(k + 1) * C * 4),
+                                 p2 = *reinterpret_cast<const float4*>(src + (long)(k + 2) * C * 4), p3 = *reinterpret_cast<const float4*>(src + (long)(k + 3) * C * 4);
+                    v0 += p0.x; v1 += p0.y; v2 += p0.z; v3 += p0.w;
+                    v0 += p1.x; v1 += p1.y; v2 += p1.z; v3 += p1.w;
+                    v0 += p2.x; v1 += p2.y; v2 += p2.z; v3 += p2.w;
+                    v0 += p3.x; v1 += p3.y; v2 += p3.z; v3 += p3.w;
+                }
+                for (; k < nchunk_p; ++k) { const float4 pp = *reinterpret_cast<const float4*>(src + (long)k * C * 4); v0 += pp.x; v1 += pp.y; v2 += pp.z; v3 += pp.w; }
+                a += (double)(float)v0; b += (double)(float)v1;          // (rounded per image like the separate fold's [N][C][2] table)
+                if (dss) { dss[(long)n * ld_dss + c] = (float)v2; dss[(long)n * ld_dss + C + c] = (float)v3; }
+            }
+        }
+        sA[nl][cc] = a; sB[nl][cc] = b;
+        __syncthreads();
+        if (nl == 0 && c < C) {
+            a = 0; b = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { a += sA[k][cc]; b += sB[k][cc]; }
+            dgamma[c] = (accumulate_params ? dgamma[c] : 0.f) + (float)a;
+            dbeta[c] = (accumulate_params ? dbeta[c] : 0.f) + (float)b;
+        }
+        return;
+    }
+    if (cpart == nullptr && (int)blockIdx.y == N) {       // (nc_part != nullptr) one extra row of blocks: pass 2b, dgamma / dbeta = the per-image sums folded over the batch
         __shared__ double sA[8][32], sB[8][32];
         for (int cb = blockIdx.x; cb * 32 < C; cb += gridDim.x) {
             if (cb != (int)blockIdx.x) __syncthreads();
@@ -805,7 +845,22 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_stream_kernel(const T* __restri
     if (r >= rows) return;
     const int c = e * 4, g = c / cpg;
     const float mu = mean[n * G + g], rs = rstd[n * G + g];
-    const float m1 = gsum[(n * G + g) * 2], m2 = gsum[(n * G + g) * 2 + 1];
+    float m1, m2;
+    if (gpart != nullptr) {
+        // the group's two means from pass 1's chunk sums (at most 64 records of 8 bytes, L2-resident): every thread folds its own group's —
+        // the same few hundred bytes the separate fold launch read once and every dx block then re-read as a table
+        const float* src = gpart + ((long)n * nchunk_p * G + g) * 2;
+        double s0 = 0, s1 = 0;
+        int k = 0;
+        for (; k + 4 <= nchunk_p; k += 4) {
+            const float2 p0 = *reinterpret_cast<const float2*>(src + (long)k * G * 2), p1 = *reinterpret_cast<const float2*>(src + (long)(k + 1) * G * 2),
+                         p2 = *reinterpret_cast<const float2*>(src + (long)(k + 2) * G * 2), p3 = *reinterpret_cast<const float2*>(src + (long)(k + 3) * G * 2);
+            s0 += p0.x; s1 += p0.y; s0 += p1.x; s1 += p1.y; s0 += p2.x; s1 += p2.y; s0 += p3.x; s1 += p3.y;
+        }
+        for (; k < nchunk_p; ++k) { const float2 pp = *reinterpret_cast<const float2*>(src + (long)k * G * 2); s0 += pp.x; s1 += pp.y; }
+        const double cnt = (double)HW * cpg;
+        m1 = (float)(s0 / cnt); m2 = (float)(s1 / cnt);
+    } else { m1 = gsum[(n * G + g) * 2]; m2 = gsum[(n * G + g) * 2 + 1]; }
     float gm[4], bt[4], a[4], sh[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1093,9 +1148,23 @@ static int gn_bwd_impl(const T* x, const T* x2, int ld2, int C1, const T* dy, T*
     if (cdae_prof_on()) { char tag[96]; snprintf(tag, sizeof(tag), "gn_bwd_impl N=%d HW=%d C=%d B=%d", (int)N, (int)HW, (int)C, (int)sizeof(T)); cdae_prof_tag(tag); }
     if (VEC == 4) hipLaunchKernelGGL((gn_bwd_partial_kernel<4, T>), dim3(nchunk, N), dim3(256), 0, st, x, dy, HW, C, ldx, lddy, cpg, groups, ppb, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gpart, cpart, x2, ld2, C1);
     else hipLaunchKernelGGL((gn_bwd_partial_kernel<1, T>), dim3(nchunk, N), dim3(256), 0, st, x, dy, HW, C, ldx, lddy, cpg, groups, ppb, mean, rstd, gamma, beta, scale_shift, ld_ss, silu, gpart, cpart, x2, ld2, C1);
-    hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3((C + 63) / 64 + 1, N), dim3(256), 0, st, N, HW, C, cpg, groups, nchunk, gpart, cpart, gsum, d_scale_shift, ld_dss, ncp);
     static const int cfg_dxs = CDAE_DEV_INT("CDAE_GN_BWD_STREAM", 1);
     const bool dx_stream = VEC == 4 && cfg_dxs && E <= 256 && (!accumulate_dx || dx);
+    // TWO launches (round 6): the streaming dx kernel folds the group sums itself (each thread its own group's <= 64 chunk records) and
+    // carries the channel folds — d(scale, shift) per image, dgamma / dbeta over the batch — as extra rows of its grid, one block per 32
+    // channels: the separate fold launch (56 per C64 training step, 4.8 us each + a launch boundary) is gone.  CDAE_GN_BWD_FOLD2=0
+    // (dev build): the three-launch form
+    static const int cfg_fold2 = CDAE_DEV_INT("CDAE_GN_BWD_FOLD2", 1);
+    if (dx_stream && cfg_fold2 && cdae_tune(TUNE_GN_BWD_FOLD2)) {
+        const int cblocks = (C + 31) / 32, rows_extra = (cblocks + nchunk - 1) / nchunk;
+        hipLaunchKernelGGL((gn_bwd_dx_stream_kernel<T>), dim3(nchunk, N + rows_extra), dim3(256), 0, st, x, dy, dx, HW, C, ldx, lddy, lddx, cpg, groups, ppb, mean, rstd,
+                           gamma, beta, scale_shift, ld_ss, silu, (const float*)nullptr, accumulate_dx, dx_add, ld_add, dxb_hi, dxb_lo, x2, ld2, C1, dx2, lddx2,
+                           N, (const float*)nullptr, dgamma, dbeta, accumulate_params, (const float*)gpart, (const float*)cpart, nchunk, d_scale_shift, ld_dss);
+        cdae_prof_end(PROF_GN, st);
+        CHECK_LAUNCH("gn_bwd launch failed");
+        return 0;
+    }
+    hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3((C + 63) / 64 + 1, N), dim3(256), 0, st, N, HW, C, cpg, groups, nchunk, gpart, cpart, gsum, d_scale_shift, ld_dss, ncp);
     // pass 2b (dgamma / dbeta over the batch) rides along as one extra row of blocks of the streaming dx launch (it only needs pass 2a's
     // per-image sums, like dx): one launch less per GroupNorm, 56 per C64 training step; CDAE_GN_BWD_PARAM_ROW=0: its own launch
     static const int cfg_prow = CDAE_DEV_INT("CDAE_GN_BWD_PARAM_ROW", 1);

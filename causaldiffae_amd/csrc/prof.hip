@@ -43,7 +43,7 @@ int* cdae_range_flag_ptr() {
 
 namespace {
 // defaults = the measured optimum on MI355X (dispatch table)
-int g_tune[TUNE_N] = {256, 1, 0, 1, 2048, 1, 1};
+int g_tune[TUNE_N] = {256, 1, 0, 1, 2048, 1, 1, 1};
 }
 int cdae_tune(int key) { return key >= 0 && key < TUNE_N ? g_tune[key] : 0; }
 
@@ -196,42 +196,6 @@ int cdae_calib_copy(const void* src, void* dst, size_t bytes, int reps, double* 
     hipEventDestroy(e0); hipEventDestroy(e1);
     if (bad) return cdae_fail("calib_copy: kernel failed");
     *tbps = best;
-    return 0;
-}
-
-// ---- stream order links: see include/cdae.h
-struct CdaeStreamLink { void* word; unsigned seq; };
-
-int cdae_stream_link_create(void** link) {
-    if (!link) return cdae_fail("stream_link_create: null argument");
-    void* w = nullptr;
-    if (hipExtMallocWithFlags(&w, 8, hipMallocSignalMemory) != hipSuccess || !w) return cdae_fail("stream_link_create: hipExtMallocWithFlags(signal memory) failed");
-    if (hipMemset(w, 0, 8) != hipSuccess) { (void)hipFree(w); return cdae_fail("stream_link_create: hipMemset failed"); }
-    *link = new CdaeStreamLink{w, 0u};
-    return 0;
-}
-
-int cdae_stream_link_order(void* link, void* producer_stream, void* consumer_stream) {
-    CdaeStreamLink* l = static_cast<CdaeStreamLink*>(link);
-    if (!l || !l->word) return cdae_fail("stream_link_order: null link");
-    hipStream_t prod = (hipStream_t)producer_stream, cons = (hipStream_t)consumer_stream;
-    if (prod == cons) return 0;
-    if (l->seq >= 0x7ffffff0u) {               // the comparison is >= on 32 bits: start over behind both streams (once per 2^31 dependencies)
-        if (hipStreamSynchronize(prod) != hipSuccess || hipStreamSynchronize(cons) != hipSuccess || hipMemset(l->word, 0, 8) != hipSuccess)
-            return cdae_fail("stream_link_order: sequence reset failed");
-        l->seq = 0;
-    }
-    const unsigned v = ++l->seq;
-    if (hipStreamWriteValue32(prod, l->word, v, 0) != hipSuccess) return cdae_fail("stream_link_order: hipStreamWriteValue32 failed");
-    if (hipStreamWaitValue32(cons, l->word, v, hipStreamWaitValueGte, 0xffffffffu) != hipSuccess) return cdae_fail("stream_link_order: hipStreamWaitValue32 failed");
-    return 0;
-}
-
-int cdae_stream_link_destroy(void* link) {
-    CdaeStreamLink* l = static_cast<CdaeStreamLink*>(link);
-    if (!l) return 0;
-    if (l->word) (void)hipFree(l->word);
-    delete l;
     return 0;
 }
 

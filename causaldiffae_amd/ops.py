@@ -144,38 +144,18 @@ def wgrad_side_stream_on():
     return _WGRAD_SIDE_ON
 
 
-_LINKS_ON = True        # path toggle: False = hipEvent record / wait between the two streams (before round 6)
-
-
 def _side(dev):
     st = _SIDE.get(dev.index)
     if st is None:
-        st = _SIDE[dev.index] = dict(stream=torch.cuda.Stream(device=dev), dirty=False, pending=[], hooked=None, held=[], links=None)
+        st = _SIDE[dev.index] = dict(stream=torch.cuda.Stream(device=dev), dirty=False, pending=[], hooked=None, held=[])
     return st
-
-
-def stream_order(sd, producer, consumer, which):
-    """`consumer` (a torch stream) runs behind everything enqueued on `producer` so far.  Outside a graph capture the dependency is a
-    stream order link (cdae_stream_link_order: a value written by the producer stream and awaited by the consumer stream, both on the
-    GPU's command processor): with hipEventRecord / hipStreamWaitEvent every PENDING cross-stream dependency keeps a ROCm runtime helper
-    thread spinning — one host core per rank for the whole training step (tools/two_stream_probe*.py).  Events inside a capture."""
-    if not _LINKS_ON or torch.cuda.is_current_stream_capturing():
-        consumer.wait_stream(producer)
-        return
-    if sd["links"] is None:
-        a, b = ctypes.c_void_p(), ctypes.c_void_p()
-        with torch.cuda.device(sd["stream"].device):
-            check(lib.cdae_stream_link_create(ctypes.byref(a)))
-            check(lib.cdae_stream_link_create(ctypes.byref(b)))
-        sd["links"] = {"fork": a, "join": b}
-    check(lib.cdae_stream_link_order(sd["links"][which], producer.cuda_stream, consumer.cuda_stream))
 
 
 def _side_flush(sd, dev):
     if not sd["pending"]:
         return
     side = sd["stream"]
-    stream_order(sd, torch.cuda.current_stream(dev), side, "fork")
+    side.wait_stream(torch.cuda.current_stream(dev))
     ws, wsb = ptr(workspace(dev, "splitk_side", SPLITK_BYTES)), SPLITK_BYTES
     for tensors, fn in sd["pending"]:
         for t in tensors:
@@ -302,7 +282,7 @@ def side_join(dev=None):
         sdev = sd["stream"].device
         _side_flush(sd, sdev)
         if sd["dirty"]:
-            stream_order(sd, sd["stream"], torch.cuda.current_stream(sdev), "join")
+            torch.cuda.current_stream(sdev).wait_stream(sd["stream"])
             sd["dirty"] = False
         sd["held"] = []
 
@@ -2286,7 +2266,7 @@ PATH_TOGGLES = {"skipgn_v2": "_SKIPGN_V2", "skip_gn": "_SKIPGN_ON", "stream_gemm
                 "linear_gn": "_LINEAR_GN", "fused_attn": "_FUSED_ATTN_ON", "fused_attn_train": "_FUSED_ATTN_TRAIN", "kpack": "_KPACK_ON",
                 "presplit": "_PRESPLIT_ON", "train_presplit": "_TRAIN_PS_ON", "train_rbnode": "_RBNODE_ON", "train_gnparts": "_RB_PARTS_ON",
                 "train_emball": "_EMBALL_ON", "train_cat": "_TRAIN_CAT_ON", "weight_bank": "_WEIGHT_BANK_ON", "wscale": "_WSCALE_ON",
-                "s2_dgrad_ps": "_S2DGRAD_ON", "dgrad_stream": "_DGRAD_STREAM_ON", "wgrad_stream": "_WGRAD_SIDE_ON", "stream_links": "_LINKS_ON", "torso16": "_TORSO16_ON", "wgrad_group": "_WG_GROUP_ON", "down16": "_DOWN16_ON", "im2col16": "_IM2COL16_ON"}
+                "s2_dgrad_ps": "_S2DGRAD_ON", "dgrad_stream": "_DGRAD_STREAM_ON", "wgrad_stream": "_WGRAD_SIDE_ON", "torso16": "_TORSO16_ON", "wgrad_group": "_WG_GROUP_ON", "down16": "_DOWN16_ON", "im2col16": "_IM2COL16_ON"}
 
 
 class path_scope:

@@ -352,9 +352,12 @@ class TrainLoop:
         GPU, sets the step time.  With static shapes (one microbatch, uniform timestep sampling) the whole forward + backward is
         captured once into a hipGraph and replayed; inputs, timesteps, loss weights and the KL weight live in static buffers.
         The gradient all-reduce (world > 1) and the optimizer kernel stay outside the graph.
-        OPT-IN (use_graph=True): gradients match the eager step to its own run-to-run noise (6e-6), but on
-        ROCm 7.2 replaying the 1600-node graph measured 48.9 ms against 42.0 ms for eager launches on the same MI355X box — the
-        eager launch queue already overlaps with execution, graph nodes do not."""
+        OPT-IN (use_graph=True): gradients match the eager step to its own run-to-run noise (6e-6), but replay is no faster on ROCm 7.2.
+        Re-measured in round 6 on today's step (C64 batch 32, ~1080 nodes, same MI355X box, tools/exp_train.py GRAPH=1): parity mode
+        28.1 ms replayed against 26.9 ms eager, 16-bit torso 18.1 against 16.8 (round 1, 1600 nodes: 48.9 against 42.0).  The eager launch
+        queue already runs ahead of the GPU and overlaps the weight-gradient stream with the data-gradient chain; the captured graph keeps
+        the fork as a branch but its nodes do not overlap.  Nor is replay free for the host: hipGraphLaunch walks the nodes on the CPU
+        (33 ms of process CPU per replayed step against 46 eager)."""
         return (self.use_graph and not self._graph_failed and th.cuda.is_available() and isinstance(self.schedule_sampler, UniformSampler)
                 and self.microbatch >= batch.shape[0] and self._eager_steps >= 2)
 

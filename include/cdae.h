@@ -471,9 +471,11 @@ int cdae_rep_loss_bwd(const float* mu, const float* var, const float* z_post, co
  *                                      an LDS ring filled by LDS-DMA several steps ahead; 0: every wave loads them into registers itself
  *   CDAE_TUNE_CONVWIN_PAIR16     (1)   the window conv on bf16 rows (cdae_conv3x3_fwd16 / _dgrad16, Cin % 64 == 0, K-group-major weights):
  *                                      the two plane slots of the kernel carry the two halves of the input channels (two MFMAs per K step);
- *                                      0: the one-plane instantiation */
+ *                                      0: the one-plane instantiation
+ *   CDAE_TUNE_GN_BWD_FOLD2       (1)   GroupNorm backward as TWO launches (partial sums; dx with the group fold in its prologue and the
+ *                                      channel folds as extra rows of its grid); 0: the separate fold launch between them (A/B, tests) */
 enum { CDAE_TUNE_CONVWIN_MIN_TILES = 0, CDAE_TUNE_CONVWIN_SPLITK = 1, CDAE_TUNE_CONVWIN_NJ3 = 2, CDAE_TUNE_HEAD_MFMA = 3, CDAE_TUNE_ROWS16_MIN_M = 4,
-       CDAE_TUNE_ROWS16_RING = 5, CDAE_TUNE_CONVWIN_PAIR16 = 6 };
+       CDAE_TUNE_ROWS16_RING = 5, CDAE_TUNE_CONVWIN_PAIR16 = 6, CDAE_TUNE_GN_BWD_FOLD2 = 7 };
 int cdae_tune_set(int key, int value);
 int cdae_tune_get(int key);       /* -1: unknown key */
 
@@ -536,18 +538,6 @@ int cdae_prof_read(double* ms, double* work, double* bytes, long long* launches)
    Both synchronise the stream; scratch >= 4 MiB + 8 KiB of device memory. */
 int cdae_calib_mfma(void* scratch, size_t scratch_bytes, int iters, double* tflops, double* sclk_ghz, void* stream);
 int cdae_calib_copy(const void* src, void* dst, size_t bytes, int reps, double* tbps, void* stream);
-
-/* ---- stream order links (prof.hip): "everything enqueued on `consumer` after this call runs behind everything enqueued on `producer`
-   before it", WITHOUT a hipEvent.  The trainer overlaps weight gradients (a second stream) with the data-gradient chain (reference
-   train_util.py:255-259 runs them on one stream); ordered by hipEventRecord / hipStreamWaitEvent, every pending dependency keeps a ROCm
-   runtime helper thread spinning on the host (one full core per rank for the whole step: 28 ms of CPU per 27 ms step on MI355X /
-   ROCm 7.2).  A link is one 8-byte word of signal memory: the producer stream WRITES the next sequence number when it gets there
-   (hipStreamWriteValue32), the consumer stream WAITS for it (hipStreamWaitValue32, >=) — both executed by the GPU's command processor.
-   One link per direction and stream pair; calls on one link must come from one host thread at a time.  Not capturable into a HIP graph
-   (the caller uses events there).  cdae_stream_link_create allocates (the one allocation of the library besides the profiler's events). */
-int cdae_stream_link_create(void** link);
-int cdae_stream_link_order(void* link, void* producer_stream, void* consumer_stream);
-int cdae_stream_link_destroy(void* link);
 
 #ifdef __cplusplus
 }

@@ -191,10 +191,19 @@ def test_conv3x3_backward(N, Cin, Cout, H, stride, up, nchw_in):
 
 
 # ------------------------------------------------------------------ GroupNorm
-@pytest.mark.parametrize("N,C,H", [(2, 128, 16), (2, 384, 8), (3, 640, 4), (2, 896, 8), (2, 1024, 8), (2, 128, 64), (2, 32, 7), (2, 96, 6)])
+@pytest.mark.parametrize("N,C,H", [(2, 128, 16), (2, 384, 8), (3, 640, 4), (2, 896, 8), (2, 1024, 8), (2, 128, 64), (2, 32, 7), (2, 96, 6), (9, 256, 16), (17, 128, 32)])
 @pytest.mark.parametrize("ssn,silu", [(False, True), (True, True), (False, False)])
-def test_group_norm(N, C, H, ssn, silu):
+@pytest.mark.parametrize("fold2", [1, 0])
+def test_group_norm(N, C, H, ssn, silu, fold2):
+    """forward + backward against float64 autograd; fold2: the backward as two launches (group fold in the dx kernel's prologue, channel
+    folds as extra rows of its grid — the default since round 6) and with the separate fold launch (cdae_tune_set)"""
     from causaldiffae_amd import ops
+    from causaldiffae_amd._lib import tune_scope
+    with tune_scope(gn_bwd_fold2=fold2):
+        _group_norm_case(ops, N, C, H, ssn, silu)
+
+
+def _group_norm_case(ops, N, C, H, ssn, silu):
     x = rnd(N, C, H, H, lo=-2, hi=3)
     x = x + torch.linspace(-3, 3, C)[None, :, None, None]        # per-channel offsets: mean^2 >> var inside groups
     g, b = rnd(C, seed=1) + 1.5, rnd(C, seed=2)

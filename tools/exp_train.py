@@ -10,10 +10,16 @@ from improved_diffusion.image_datasets import load_data
 from improved_diffusion.train_util import TrainLoop
 
 dev = torch.device("cuda:0")
+if os.environ.get("PTRACE_ANY"):          # a debugger started beside the job may attach (tools/spin_bt.sh)
+    import ctypes
+    ctypes.CDLL(None).prctl(0x59616D61, ctypes.c_ulong(-1), 0, 0, 0)
 if os.environ.get("OFF"):               # OFF=name,name: fused paths of causaldiffae_amd.ops.PATH_TOGGLES switched off for this run (same-box A/B)
     from causaldiffae_amd import ops as _ops
     for _n in os.environ["OFF"].split(","):
         setattr(_ops, _ops.PATH_TOGGLES[_n], False)
+if os.environ.get("SIDE_GROUP"):           # weight-gradient launches handed to the side stream in groups of this many (one cross-stream dependency per group)
+    from causaldiffae_amd import ops as _ops2
+    _ops2._SIDE_GROUP = int(os.environ["SIDE_GROUP"])
 B = int(os.environ.get("BATCH", "32"))
 if os.environ.get("NJ3"):
     from causaldiffae_amd._lib import lib as _l
@@ -39,6 +45,7 @@ def step():
 for _ in range(8):
     step()
 out, cpu = [], []
+th0 = bench.thread_cpu()
 for _ in range(REGIONS):
     torch.cuda.synchronize()
     c0 = time.process_time()
@@ -48,5 +55,8 @@ for _ in range(REGIONS):
     torch.cuda.synchronize()
     out.append((time.perf_counter() - t0) / STEPS * 1e3)
     cpu.append((time.process_time() - c0) / STEPS * 1e3)
+th1 = bench.thread_cpu()
+per_thread = sorted(((name, round(1e3 * (c - th0.get(tid, ("", 0.0))[1]) / (STEPS * REGIONS), 1)) for tid, (name, c) in th1.items()), key=lambda kv: -kv[1])
+print("threads ms/step:", [kv for kv in per_thread if kv[1] >= 0.3])
 print("train ms/step:", " ".join(f"{v:.3f}" for v in out), "| host cpu ms/step:", " ".join(f"{v:.1f}" for v in cpu),
       "| graphs:", len(loop._graphs), "failed:", loop._graph_failed, "| loss", float(loop.last_losses["loss"].mean()), "| env:", {k: v for k, v in os.environ.items() if k.startswith("CDAE_") or k == "OFF"})
