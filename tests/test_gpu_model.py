@@ -856,13 +856,15 @@ def test_training_curve_reference_parity_and_torso(golden):
     e_par, e_tor = rel(par[:REF], ref).max(axis=0), rel(tor[:REF], ref).max(axis=0)
     print("G21 worst relative error over 24 steps (loss, mse, kld_rep): parity", e_par, "torso", e_tor)
     assert ref[0, 0] - ref[-1, 0] > 4.0 and par[0, 0] - par[-1, 0] > 4.0            # the run converges (the loss falls by a fifth in 24 steps)
-    assert (e_par < np.array([2e-4, 2e-3, 2e-4])).all(), e_par
-    assert (e_tor < 2e-2).all(), e_tor
+    # bars = 1.5 - 5 x what the kernels deliver (measured on MI355X: parity 3.6e-6 / 1.0e-5 / 3.6e-6; torso 2.3e-4 / 3.9e-3 / 6.4e-5; smoothed 120-step
+    # curves 1.1e-4 / 1.5e-3 / 1.2e-4), all far inside SURVEY 8d's 2e-2 for the reduced-precision configuration
+    assert (e_par < np.array([2e-5, 5e-5, 2e-5])).all(), e_par
+    assert (e_tor < np.array([6e-4, 8e-3, 2e-4])).all(), e_tor
     smooth = lambda v: np.convolve(v, np.ones(10) / 10.0, mode="valid")
     e_smooth = [rel(smooth(tor[:, i]), smooth(par[:, i])).max() for i in range(3)]
     e_last = rel(tor[-20:].mean(axis=0), par[-20:].mean(axis=0))
     print("G21 torso vs parity mode over 120 steps: smoothed curves", e_smooth, "last 20 steps", e_last, "final loss", par[-1, 0], tor[-1, 0])
-    assert max(e_smooth) < 2e-2, e_smooth
+    assert max(e_smooth) < 4e-3, e_smooth
     assert par[-20:, 0].mean() < par[:20, 0].mean() - 5.0
 
 

@@ -239,6 +239,7 @@ def test_full_model_step_on_the_16bit_torso_matches_fp32_storage(arch):
         f = loop.opt.flat
         return losses["loss"].mean().item(), {n: f.grad[o:o + p.numel()].clone() for n, p, o in zip(f.names, f.params, f.offsets)}
 
+    BAR = {"m32": (0.12, 0.985), "c64": (0.12, 0.985)}
     l32, g32 = run(False)
     for torso in (True, False):
         l16, g16 = run(True, torso)
@@ -251,7 +252,9 @@ def test_full_model_step_on_the_16bit_torso_matches_fp32_storage(arch):
             rel = (a - b).abs().max().item() / b.abs().max().item()
             cos = (a * b).sum().item() / (a.norm().item() * b.norm().item() + 1e-30)
             worst.append((rel, cos, n))
-        assert max(w[0] for w in worst) < 0.12 and min(w[1] for w in worst) > 0.985, (torso, sorted(worst)[-3:], sorted(worst, key=lambda w: w[1])[:3])
+        print(f"torso16 {arch} torso={torso}: loss rel {abs(l16 - l32) / abs(l32):.2e}; worst gradient max-error / scale {max(w[0] for w in worst):.4f} "
+              f"({sorted(worst)[-1][2]}), worst cosine {min(w[1] for w in worst):.5f} ({sorted(worst, key=lambda w: w[1])[0][2]})")
+        assert max(w[0] for w in worst) < BAR[arch][0] and min(w[1] for w in worst) > BAR[arch][1], (torso, sorted(worst)[-3:], sorted(worst, key=lambda w: w[1])[:3])
 
 
 @pytest.mark.parametrize("T,ch,heads,B", [(256, 64, 4, 3), (64, 128, 2, 5), (64, 96, 4, 2), (256, 96, 1, 2)])

@@ -20,6 +20,11 @@ if os.environ.get("OFF"):               # OFF=name,name: fused paths of causaldi
 if os.environ.get("SIDE_GROUP"):           # weight-gradient launches handed to the side stream in groups of this many (one cross-stream dependency per group)
     from causaldiffae_amd import ops as _ops2
     _ops2._SIDE_GROUP = int(os.environ["SIDE_GROUP"])
+if os.environ.get("TUNE"):                  # TUNE=key=value,key=value: dispatch thresholds of the library (cdae_tune_set) for a same-box A/B
+    from causaldiffae_amd import _lib as _l3
+    for kv in os.environ["TUNE"].split(","):
+        k, v = kv.split("=")
+        assert _l3.lib.cdae_tune_set(_l3.TUNE_KEYS[k], int(v)) == 0
 B = int(os.environ.get("BATCH", "32"))
 if os.environ.get("NJ3"):
     from causaldiffae_amd._lib import lib as _l
