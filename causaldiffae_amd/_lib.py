@@ -143,6 +143,7 @@ SIGNATURES = {
     "cdae_gemm16_ps": [P, L, P, L, P, P, P, L, P, I, I, I, I, I, P, SZ, P],
     "cdae_linear_fwd_io": [P, L, P, L, P, P, P, P, L, I, I, I, I, P, SZ, P],
     "cdae_linear_dgrad_io": [P, L, P, L, P, L, I, I, I, I, P, SZ, P],
+    "cdae_linear_wgrad_group": [P, I, P, SZ, P],
     "cdae_linear_wgrad_io": [P, L, P, L, P, L, P, I, I, I, I, I, P, SZ, P],
     "cdae_gn_stats16": [P, I, P, I, I, I, I, I, I, F, P, P, P, P, P, I, P, P, P],
     "cdae_gn_apply16": [P, I, P, I, I, P, I, I, I, I, I, P, P, P, P, P, I, I, P],
@@ -174,6 +175,11 @@ PROF_FAMILIES = ("igemm", "groupnorm", "softmax", "elementwise", "optimizer", "c
 
 class CdaeError(RuntimeError):
     pass
+
+
+class LwItem(ctypes.Structure):
+    """cdae_lw_item (include/cdae.h): one linear / 1x1 weight gradient of a group launch"""
+    _fields_ = [("x", P), ("dy", P), ("dw", P), ("dbias", P), ("ldx", L), ("lddy", L), ("lddw", L), ("M", I), ("N", I), ("K", I), ("accumulate", I)]
 
 
 class WgItem(ctypes.Structure):

@@ -399,6 +399,41 @@ int cdae_linear_wgrad(const float* x, long ldx, const float* dy, long lddy, floa
     return cdae_gemm_dispatch(p, stream);
 }
 
+// n linear / 1x1-conv weight gradients in ONE launch where together they fill the chip unsplit (igemm.hip cdae_gemm_group_dispatch);
+// else, and for members the grouped loaders do not take, one launch each exactly as cdae_linear_wgrad.  Members with a bias gradient
+// must accumulate (the fused column sums add into dbias; the trainer's flat gradient buffer is zeroed once per step).
+int cdae_linear_wgrad_group(const cdae_lw_item* items, int n, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    if (n <= 0) return 0;
+    if (!items) return cdae_fail("linear_wgrad_group: null items");
+    int i0 = 0;
+    while (i0 < n) {
+        const int cnt = n - i0 < GEMM_GROUP_MAX ? n - i0 : GEMM_GROUP_MAX;
+        int rc = 1;
+        if (cnt >= 2) {
+            GemmGroupArg g;
+            memset(&g, 0, sizeof(g));
+            g.common = base_params();
+            g.common.amode = A_PLAIN_MC; g.common.bmode = B_PLAIN_MC; g.common.grad_operand = 1;
+            g.n = cnt;
+            bool ok = true;
+            for (int i = 0; i < cnt; ++i) {
+                const cdae_lw_item& it = items[i0 + i];
+                ok = ok && (it.accumulate || !it.dbias) && it.dw && it.x && it.dy;
+                g.items[i] = GemmGroupItem{it.dy, it.x, it.dw, it.dbias, it.N, it.K, it.M, it.accumulate, it.lddy, it.ldx, it.lddw};
+            }
+            rc = ok ? cdae_gemm_group_dispatch(g, stream) : 1;
+            if (rc < 0) return rc;
+        }
+        if (rc == 1)
+            for (int i = 0; i < cnt; ++i) {
+                const cdae_lw_item& it = items[i0 + i];
+                if (cdae_linear_wgrad(it.x, it.ldx, it.dy, it.lddy, it.dw, it.lddw, it.dbias, it.M, it.N, it.K, it.accumulate, splitk_ws, splitk_ws_bytes, stream)) return -1;
+            }
+        i0 += cnt;
+    }
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------------------------------------
 // The 16-bit torso (reference unet.py:501-507 convert_to_fp16 + fp16_util.py:9-15: half activations between the layers; here bf16, the
 // dtype BASELINE config [1] names): activations and gradients are bf16 NHWC rows, which ARE the one-plane operands of the matrix-core

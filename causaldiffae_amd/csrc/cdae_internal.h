@@ -87,6 +87,24 @@ struct GemmParams {
 };
 
 int cdae_gemm_dispatch(GemmParams p, void* stream);
+
+// A GROUP of fp32-operand GEMMs in ONE launch (igemm.hip, the linear / 1x1 weight gradients of a resolution level): `common` carries
+// everything the members share (operand modes, precision, flags), an item what differs.  Block -> member by a scalar scan of first[].
+// The whole argument travels as kernel arguments (no device memory for descriptors).
+struct GemmGroupItem {
+    const float* A; const float* B; float* C; float* colsum_out;
+    int M, N, K, accumulate;
+    long lda, ldb, ldc;
+};
+constexpr int GEMM_GROUP_MAX = 24;
+struct GemmGroupArg {
+    GemmParams common;
+    int n;
+    int first[GEMM_GROUP_MAX + 1];          // first block of member i; first[n] = grid size
+    GemmGroupItem items[GEMM_GROUP_MAX];
+};
+// 0: launched; 1: not taken as a group (the caller launches the members one by one); -1: error
+int cdae_gemm_group_dispatch(GemmGroupArg& g, void* stream);
 #ifdef __HIPCC__
 int cdae_splitk_finish(const GemmParams& p, bool gn_finish_ok, hipStream_t st);      // igemm.hip
 #endif

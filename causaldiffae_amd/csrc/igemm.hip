@@ -47,8 +47,28 @@ namespace {
 // GroupNorm (+SiLU; folded per (image, channel) coefficients p.gn_coef, bit-identical to gn_apply_kernel) and write the result as
 // f16 hi/lo planes (p.S_hi / p.S_lo, dense [M][K]): the separate normalisation pass over the tensor disappears.  The GEMM is
 // HBM-bound, the extra VALU work is free.
-template <int BM, int BN, int AMODE, int BMODE, bool SCALAR, int WAVES_N = 2, int PREC = 0, bool GNS = false, bool DEEP = false>
-__global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_kernel(const GemmParams p) {     // GNS + DEEP: keep four waves per SIMD (128 VGPRs)
+// GROUP: the kernel argument is a GemmGroupArg — several GEMMs of one operand-mode family in one launch (the linear / 1x1 weight
+// gradients of a resolution level: each alone has 9 - 48 tiles and split K 8 - 26 ways into slabs + a finish launch; together they
+// fill the chip unsplit).  A block finds its member by a scalar scan and assembles that member's GemmParams in registers.
+__device__ __forceinline__ const GemmParams& igemm_pick(const GemmParams& a, const GemmParams&) { return a; }
+__device__ __forceinline__ const GemmParams& igemm_pick(const GemmGroupArg&, const GemmParams& l) { return l; }
+
+template <int BM, int BN, int AMODE, int BMODE, bool SCALAR, int WAVES_N = 2, int PREC = 0, bool GNS = false, bool DEEP = false, bool GROUP = false>
+__global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_kernel(const std::conditional_t<GROUP, GemmGroupArg, GemmParams> karg) {     // GNS + DEEP: keep four waves per SIMD (128 VGPRs)
+    GemmParams pl_;
+    unsigned grid_ = gridDim.x, blk_ = blockIdx.x;
+    if constexpr (GROUP) {
+        int g = 0;
+        for (int i = 1; i < karg.n; ++i) g = (int)blockIdx.x >= karg.first[i] ? i : g;
+        g = __builtin_amdgcn_readfirstlane(g);
+        pl_ = karg.common;
+        const GemmGroupItem& it = karg.items[g];
+        pl_.A = it.A; pl_.B = it.B; pl_.C = it.C; pl_.colsum_out = it.colsum_out;
+        pl_.M = it.M; pl_.N = it.N; pl_.K = it.K; pl_.accumulate = it.accumulate;
+        pl_.lda = it.lda; pl_.ldb = it.ldb; pl_.ldc = it.ldc;
+        grid_ = (unsigned)(karg.first[g + 1] - karg.first[g]); blk_ = blockIdx.x - (unsigned)karg.first[g];
+    }
+    const GemmParams& p = igemm_pick(karg, pl_);
     static_assert(PREC == 0 || !SCALAR, "split precision is only built for vectorised loaders");
     static_assert(!GNS || (AMODE == A_PLAIN_KC && PREC == 1 && !SCALAR), "the GroupNorm side output rides on the K-contiguous f16x3 loader");
     constexpr int NPL = (PREC == 1 || PREC == 2) ? 2 : 1;       // 16-bit planes per operand
@@ -89,7 +109,7 @@ __global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_ke
     const int nmt = (p.M + BM - 1) / BM, nnt = (p.N + BN - 1) / BN;
     int mt, nt, ks, bz;
     {
-        const unsigned G = gridDim.x, b = blockIdx.x;
+        const unsigned G = grid_, b = blk_;
         const unsigned q = G >> 3, r = G & 7, x = b & 7;
         unsigned v = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
         nt = v % nnt; v /= nnt;
@@ -874,6 +894,33 @@ int launch(const GemmParams& p, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : cdae_fail("igemm launch failed");
 }
 
+static_assert(sizeof(GemmGroupArg) <= 4096, "a group travels as kernel arguments");
+template <int BM, int BN, int AMODE, int BMODE, int WAVES_N, int PREC, bool DEEP>
+int launch_group(const GemmGroupArg& g, hipStream_t st) {
+    constexpr bool A_MC = (AMODE == A_PLAIN_MC);
+    constexpr bool B_MC = (BMODE != B_PLAIN_KC);
+    constexpr int NPL = (PREC == 1 || PREC == 2) ? 2 : 1;
+    constexpr int A_TILE = PREC ? NPL * (A_MC ? BK * (BM + 32) : BM * 32) / 2 : (A_MC ? BK * (BM + 4) : BM * LDK);
+    constexpr int B_TILE = PREC ? NPL * (B_MC ? BK * (BN + 32) : BN * 32) / 2 : (B_MC ? BK * (BN + 4) : BN * LDK);
+    constexpr size_t tiles = 2 * (A_TILE + B_TILE) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, AMODE, BMODE, false, WAVES_N, PREC, false, DEEP, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiles) != hipSuccess)
+            return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
+        attr_done = true;
+    }
+    GemmGroupArg q = g;
+    int blocks = 0;
+    for (int i = 0; i < q.n; ++i) {
+        q.first[i] = blocks;
+        blocks += ((q.items[i].M + BM - 1) / BM) * ((q.items[i].N + BN - 1) / BN);
+    }
+    q.first[q.n] = blocks;
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, AMODE, BMODE, false, WAVES_N, PREC, false, DEEP, true>), dim3((unsigned)blocks), dim3(128 * WAVES_N), tiles, st, q);
+    return hipGetLastError() == hipSuccess ? 0 : cdae_fail("igemm group launch failed");
+}
+
 template <int AMODE, int BMODE>
 int launch_tiles(const GemmParams& p, int big, bool scalar, hipStream_t st) {
     if (scalar) return launch<64, 64, AMODE, BMODE, true>(p, st);
@@ -937,6 +984,50 @@ int cdae_splitk_finish(const GemmParams& p, bool gn_finish_ok, hipStream_t st) {
     else if (vec4) hipLaunchKernelGGL(splitk_reduce4_kernel, dim3(blocks), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
     if (hipGetLastError() != hipSuccess) rc = cdae_fail("splitk reduce launch failed");
+    return rc;
+}
+
+// A group of k-major x k-major GEMMs (the weight gradients of linears / 1x1 convs: C[N_out][K_in] (+)= dy^T x over the rows) as one
+// unsplit launch.  Taken when the members together fill the chip (>= 1.5 blocks of 128 x 128 per CU, else >= 0.75 blocks of 64 x 64 per
+// CU); otherwise the caller launches them one by one, each with its own K split.
+int cdae_gemm_group_dispatch(GemmGroupArg& g, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    GemmParams& c = g.common;
+    if (g.n < 2 || g.n > GEMM_GROUP_MAX || c.amode != A_PLAIN_MC || c.bmode != B_PLAIN_MC || c.batch != 1 || c.presplit) return 1;
+    if (c.prec < 0) {
+        const int mode = cdae_get_default_precision();
+        c.prec = mode == CDAE_PREC_FP32 ? 0 : mode == CDAE_PREC_MIXED16 ? (c.grad_operand ? 4 : 3) : (c.grad_operand ? 2 : 1);
+    }
+    if (c.prec != 0 && c.prec != 2) return 1;
+    long tiles_big = 0, tiles_small = 0;
+    double flops = 0, bytes = 0;
+    for (int i = 0; i < g.n; ++i) {
+        const GemmGroupItem& it = g.items[i];
+        if (it.M <= 0 || it.N <= 0 || it.K <= 0 || it.M % 4 || it.N % 4 || it.lda % 4 || it.ldb % 4 ||
+            (reinterpret_cast<size_t>(it.A) & 15) || (reinterpret_cast<size_t>(it.B) & 15)) return 1;      // the vector k-major loaders
+        tiles_big += (long)((it.M + 127) / 128) * ((it.N + 127) / 128);
+        tiles_small += (long)((it.M + 63) / 64) * ((it.N + 63) / 64);
+        flops += 2.0 * it.M * it.N * (double)it.K;
+        bytes += 4.0 * ((double)it.M * it.K + (double)it.N * it.K + (double)it.M * it.N);
+    }
+    static const int cfg_big = CDAE_DEV_INT("CDAE_GROUP_BIG_TILES", 384), cfg_small = CDAE_DEV_INT("CDAE_GROUP_SMALL_TILES", 192);
+    const bool big = tiles_big >= cfg_big;
+    if (!big && tiles_small < cfg_small) return 1;
+    c.ksplit = 1; c.batch_inner = 1; c.a_scalar = c.b_scalar = 0; c.w_scale = nullptr; c.range_flag = cdae_range_flag_ptr();
+    static const int cfg_waves8 = CDAE_DEV_INT("CDAE_IGEMM_WAVES8", 1);
+    c.waves8 = cfg_waves8;
+    cdae_prof_begin(PROF_IGEMM, flops, st);
+    cdae_prof_note(PROF_IGEMM, bytes);
+    if (cdae_prof_on()) {
+        char tag[128];
+        snprintf(tag, sizeof(tag), "gemm group x%d a3 b1 %s tiles=%ld prec=%d (first: M=%d N=%d K=%d)", g.n, big ? "128" : "64", big ? tiles_big : tiles_small, c.prec,
+                 g.items[0].M, g.items[0].N, g.items[0].K);
+        cdae_prof_tag(tag);
+    }
+    int rc;
+    if (c.prec == 2) rc = big ? launch_group<128, 128, A_PLAIN_MC, B_PLAIN_MC, 4, 2, true>(g, st) : launch_group<64, 64, A_PLAIN_MC, B_PLAIN_MC, 2, 2, true>(g, st);
+    else rc = big ? launch_group<128, 128, A_PLAIN_MC, B_PLAIN_MC, 4, 0, false>(g, st) : launch_group<64, 64, A_PLAIN_MC, B_PLAIN_MC, 2, 0, false>(g, st);
+    cdae_prof_end(PROF_IGEMM, st);
     return rc;
 }
 

@@ -234,6 +234,59 @@ def wgrad_win(dev, a_planes, d_planes, dw, db, N, H, W, Cin, Cout):
 
 _WG_HOOK = {}
 
+# ---- the same for the linear / 1x1-conv weight gradients (skip_connection, qkv, proj_out): cdae_linear_wgrad_group.  A member alone has
+# 9 - 48 tiles and splits its rows 8 - 26 ways (slabs + a finish launch each); the members of a level together run unsplit in one launch.
+_LW_GROUP_ON = True        # path toggle: False = every linear weight gradient as its own launch (+ its K-split finish)
+_LW_PENDING = {}
+
+
+def linear_wgrad(dev, x, ldx, dy, lddy, dw_ptr, lddw, db_ptr, M, N, K, keep, hold=()):
+    """dw[N][K] += dy^T x over the M rows, dbias += column sums of dy — straight into flat-gradient views (accumulating), deferred into the
+    level's group launch on the weight-gradient stream.  `keep`: tensors the launch reads (alive until it is issued); `hold`: see side_launch."""
+    from ._lib import LwItem
+    if hold and wgrad_side_stream_on():
+        _side(dev)["held"].extend(t for t in hold if t is not None)
+    item = LwItem(ptr(x), ptr(dy), dw_ptr, db_ptr, ldx, lddy, lddw, M, N, K, 1)
+    if not _LW_GROUP_ON:
+        def one(st_, ws_, wsb_, item=item):
+            check(lib.cdae_linear_wgrad_group(ctypes.byref(item), 1, ws_, wsb_, st_))
+        side_launch(dev, keep, one)
+        return
+    pend = _LW_PENDING.setdefault(dev.index, dict(key=None, items=[], keep=[], prec=None))
+    if pend["items"] and (pend["key"] != M or len(pend["items"]) >= 24):
+        _lw_flush(dev)
+    pend["key"], pend["prec"] = M, lib.cdae_get_default_precision()
+    pend["items"].append(item)
+    pend["keep"].extend(keep)
+    _hook_backward_end(_side(dev) if wgrad_side_stream_on() else _WG_HOOK.setdefault(dev.index, dict(hooked=None)))
+
+
+def _lw_ok(x, dy, ldx, lddy, M, N, K):
+    """what the grouped launch's vector loaders take (else the member runs alone through cdae_linear_wgrad's own dispatch)"""
+    return (_LW_GROUP_ON and N % 4 == 0 and K % 4 == 0 and ldx % 4 == 0 and lddy % 4 == 0 and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0
+            and x.dtype == torch.float32 and dy.dtype == torch.float32)
+
+
+def _lw_flush(dev):
+    pend = _LW_PENDING.get(dev.index)
+    if not pend or not pend["items"]:
+        return
+    items, keep, prec = pend["items"], tuple(pend["keep"]), pend["prec"]
+    pend["items"], pend["keep"] = [], []
+    from ._lib import LwItem
+    arr = (LwItem * len(items))(*items)
+
+    def group(st_, ws_, wsb_, arr=arr, n=len(items), prec=prec):
+        cur = lib.cdae_get_default_precision()          # the group runs in the mode its members were issued in
+        if cur != prec:
+            lib.cdae_set_default_precision(prec)
+        try:
+            check(lib.cdae_linear_wgrad_group(arr, n, ws_, wsb_, st_))
+        finally:
+            if cur != prec:
+                lib.cdae_set_default_precision(cur)
+    side_launch(dev, keep, group)
+
 
 def _wg_flush(dev):
     pend = _WG_PENDING.get(dev.index)
@@ -273,6 +326,9 @@ def side_join(dev=None):
     for idx in list(_WG_PENDING):
         if dev is None or dev.index == idx:
             _wg_flush(torch.device("cuda", idx))
+    for idx in list(_LW_PENDING):
+        if dev is None or dev.index == idx:
+            _lw_flush(torch.device("cuda", idx))
     for h in _WG_HOOK.values():
         h["hooked"] = None
     for idx, sd in _SIDE.items():
@@ -514,7 +570,11 @@ class _Linear(Function):
                 check(lib.cdae_linear_wgrad(ptr(x), x.stride(0), ptr(dya), Nf, ptr(dw), K, ptr(db) if want_b else None, M, Nf, K,
                                             1 if direct else 0, ws_, wsb_, st_))
             if direct:
-                side_launch(dev, (x, dya), wg, hold=(dya,) if (has_res and dya is dy) else ())
+                if _lw_ok(x, dya, x.stride(0), Nf, M, Nf, K):
+                    linear_wgrad(dev, x, x.stride(0), dya, Nf, ptr(dw), K, ptr(db) if want_b else None, M, Nf, K, (x, dya),
+                                 hold=(dya,) if (has_res and dya is dy) else ())
+                else:
+                    side_launch(dev, (x, dya), wg, hold=(dya,) if (has_res and dya is dy) else ())
                 dw = db = None
                 _done(rw, rb if want_b else None)
             else:
@@ -2056,7 +2116,10 @@ class _ResBlockPS(Function):
                 dg1, db1, _ = gn_bwd(x, dyn1, stats1, g1, b1, None, (sg1, sb1), C, dx, True, None, None)
                 def wg(st_, ws_, wsb_, dsw=dsw, dsb=dsb):        # (bound now: the launch may run after these names were cleared)
                     check(lib.cdae_linear_wgrad(ptr(x), C, ptr(dout), Cout, ptr(dsw), C, ptr(dsb), M, Cout, C, acc, ws_, wsb_, st_))
-                side_launch(dev, (x, dout), wg) if direct else wg(st, ws, wsb)
+                if direct and _lw_ok(x, dout, C, Cout, M, Cout, C):
+                    linear_wgrad(dev, x, C, dout, Cout, ptr(dsw), C, ptr(dsb), M, Cout, C, (x, dout))
+                else:
+                    side_launch(dev, (x, dout), wg) if direct else wg(st, ws, wsb)
             else:
                 # two sources: the skip conv's dgrad / wgrad column ranges go to / come from the two tensors, then the first GroupNorm's
                 # backward accumulates onto both
@@ -2078,7 +2141,11 @@ class _ResBlockPS(Function):
                 def wg(st_, ws_, wsb_, dsw=dsw, dsb=dsb):
                     check(lib.cdae_linear_wgrad(ptr(x), C1, ptr(dout), Cout, ptr(dsw), C, ptr(dsb), M, Cout, C1, acc, ws_, wsb_, st_))
                     check(lib.cdae_linear_wgrad(ptr(x2), C2, ptr(dout), Cout, dsw.data_ptr() + 4 * C1, C, None, M, Cout, C2, acc, ws_, wsb_, st_))
-                side_launch(dev, (x, x2, dout), wg) if direct else wg(st, ws, wsb)
+                if direct and _lw_ok(x, dout, C1, Cout, M, Cout, C1) and _lw_ok(x2, dout, C2, Cout, M, Cout, C2) and (C1 * 4) % 16 == 0:
+                    linear_wgrad(dev, x, C1, dout, Cout, ptr(dsw), C, ptr(dsb), M, Cout, C1, (x, dout))
+                    linear_wgrad(dev, x2, C2, dout, Cout, dsw.data_ptr() + 4 * C1, C, None, M, Cout, C2, (x2, dout))
+                else:
+                    side_launch(dev, (x, x2, dout), wg) if direct else wg(st, ws, wsb)
             if direct:
                 dsw = dsb = None
                 _done(rsw, rsb if has_sb else None)
@@ -2266,7 +2333,7 @@ PATH_TOGGLES = {"skipgn_v2": "_SKIPGN_V2", "skip_gn": "_SKIPGN_ON", "stream_gemm
                 "linear_gn": "_LINEAR_GN", "fused_attn": "_FUSED_ATTN_ON", "fused_attn_train": "_FUSED_ATTN_TRAIN", "kpack": "_KPACK_ON",
                 "presplit": "_PRESPLIT_ON", "train_presplit": "_TRAIN_PS_ON", "train_rbnode": "_RBNODE_ON", "train_gnparts": "_RB_PARTS_ON",
                 "train_emball": "_EMBALL_ON", "train_cat": "_TRAIN_CAT_ON", "weight_bank": "_WEIGHT_BANK_ON", "wscale": "_WSCALE_ON",
-                "s2_dgrad_ps": "_S2DGRAD_ON", "dgrad_stream": "_DGRAD_STREAM_ON", "wgrad_stream": "_WGRAD_SIDE_ON", "torso16": "_TORSO16_ON", "wgrad_group": "_WG_GROUP_ON", "down16": "_DOWN16_ON", "im2col16": "_IM2COL16_ON"}
+                "s2_dgrad_ps": "_S2DGRAD_ON", "dgrad_stream": "_DGRAD_STREAM_ON", "wgrad_stream": "_WGRAD_SIDE_ON", "torso16": "_TORSO16_ON", "wgrad_group": "_WG_GROUP_ON", "lwgrad_group": "_LW_GROUP_ON", "down16": "_DOWN16_ON", "im2col16": "_IM2COL16_ON"}
 
 
 class path_scope:

@@ -332,6 +332,17 @@ int cdae_linear_dgrad(const float* dy, long lddy, const float* w, long ldw, floa
 /* dw[N][K] (+)= dy[M][N]^T @ x[M][K];  dbias[N] (+)= column sums of dy (may be NULL) */
 int cdae_linear_wgrad(const float* x, long ldx, const float* dy, long lddy, float* dw, long lddw, float* dbias, int M, int N, int K,
                       int accumulate, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
+/* one weight gradient of a GROUP launch: the arguments of cdae_linear_wgrad (x [M][K] rows of pitch ldx, dy [M][N] rows of pitch lddy,
+   dw [N][K] rows of pitch lddw, dbias [N] or NULL) */
+typedef struct cdae_lw_item {
+    const float* x; const float* dy; float* dw; float* dbias;
+    long ldx, lddy, lddw;
+    int M, N, K, accumulate;
+} cdae_lw_item;
+/* n such weight gradients (the 1x1 convs / linears of a resolution level: skip_connection, qkv, proj_out — unet.py:165-171, 216-236) in
+   ONE unsplit launch where together they fill the chip (each alone has 9 - 48 tiles and would split its rows 8 - 26 ways into slabs + a
+   finish launch); otherwise one launch each.  Members with dbias must have accumulate = 1. */
+int cdae_linear_wgrad_group(const cdae_lw_item* items, int n, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
 int cdae_colsum(const float* x, long ldx, float* out, long rows, int cols, int accumulate, void* stream);
 
 /* QKVAttention (unet.py:239-253) on the NHWC output of the qkv 1x1 conv: qkv[B][T][heads*3*ch] with the

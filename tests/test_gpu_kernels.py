@@ -126,6 +126,46 @@ def test_linear_backward():
     assert err(bd.grad, bc.grad) < 2e-4
 
 
+@pytest.mark.parametrize("shapes,rows,grouped", [
+    ([(384, 384)] * 5 + [(1152, 384)] * 3, 2048, True),          # the 16 x 16 level's mix: 64 x 64 tiles
+    ([(512, 512)] * 9 + [(1536, 512)] * 5 + [(512, 1024)], 512, True),    # the 8 x 8 level's: 128 x 128 tiles
+    ([(128, 128)] * 3, 4096, False),                               # too few tiles together: one launch each, K split
+    ([(384, 380), (384, 384)] * 6, 1024, True),                    # ragged tile edges
+])
+def test_linear_wgrad_group(shapes, rows, grouped, precision):
+    """cdae_linear_wgrad_group: the weight gradients of a level's 1 x 1 convs / linears (reference unet.py:165-171, 216-236 through
+    autograd) in ONE unsplit launch where together they fill the chip — dw += dy^T x and dbias += column sums of dy, accumulating into
+    buffers that already hold values — against float64; the launch log says whether the group form ran."""
+    import ctypes
+    from causaldiffae_amd import _lib
+    from causaldiffae_amd._lib import LwItem, check, lib, ptr, splitk_ws, stream, SPLITK_BYTES
+    dev = torch.device(DEV)
+    g = torch.Generator().manual_seed(len(shapes) + rows)
+    items, keep, want = [], [], []
+    for i, (N, K) in enumerate(shapes):
+        x = torch.randn(rows, K, generator=g)
+        dy = torch.randn(rows, N, generator=g) * (0.5 + i % 3)
+        dw0, db0 = torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+        has_b = i % 2 == 0
+        xd, dyd, dwd, dbd = x.to(dev), dy.to(dev), dw0.to(dev), db0.to(dev)
+        keep.append((xd, dyd, dwd, dbd))
+        items.append(LwItem(ptr(xd), ptr(dyd), ptr(dwd), ptr(dbd) if has_b else None, K, N, K, rows, N, K, 1))
+        want.append((dw0.double() + dy.double().t() @ x.double(), db0.double() + (dy.double().sum(0) if has_b else 0.0)))
+    arr = (LwItem * len(items))(*items)
+    ws = splitk_ws(dev)
+    torch.cuda.synchronize()
+    _lib.prof_enable(True)
+    _lib.prof_read()
+    check(lib.cdae_linear_wgrad_group(arr, len(items), ptr(ws), SPLITK_BYTES, stream()))
+    launches = _lib.prof_read()["igemm"]["launches"]
+    _lib.prof_enable(False)
+    assert (launches == 1) == grouped, launches          # (one by one: a launch per member)
+    tol = 2e-5 if precision == "fp32" else 2e-4
+    for (xd, dyd, dwd, dbd), (dw, db) in zip(keep, want):
+        assert err(dwd, dw) < tol * float(dw.abs().max()), (tuple(dwd.shape), err(dwd, dw), float(dw.abs().max()))
+        assert err(dbd, db) < tol * float(db.abs().max())
+
+
 # ------------------------------------------------------------------ conv3x3 forward
 CONVS = [
     # N, Cin, Cout, H, stride, up, nchw_in, out_nchw
