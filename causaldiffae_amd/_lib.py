@@ -120,6 +120,8 @@ SIGNATURES = {
     "cdae_nchw_to_nhwc": [P, P, I, I, I, P],
     "cdae_nhwc_to_nchw": [P, P, I, I, I, P],
     "cdae_sumpool2": [P, P, I, I, I, I, P],
+    "cdae_upsample2": [P, P, I, I, I, I, F, P],
+    "cdae_pool2": [P, P, I, I, I, I, F, P],
     "cdae_gather_u8": [P, P, P, I, L, F, F, P],
     "cdae_q_sample": [P, P, P, P, I, P, I, L, P],
     "cdae_ddim_update": [P, P, P, P, I, F, P, I, P, P, I, L, P],

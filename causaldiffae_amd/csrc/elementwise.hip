@@ -485,6 +485,46 @@ __global__ void sumpool2_v4_kernel(const float4* __restrict__ src, float4* __res
     }
 }
 
+// nearest-2x of an fp32 NHWC tensor [N,H,W,C] -> [N,2H,2W,C], times `scale` (1: Upsample without a conv, unet.py:76-78; 0.25: the
+// gradient of the 2 x 2 average pool), and the 2 x 2 pool [N,2H,2W,C] -> [N,H,W,C] times `scale` (0.25: Downsample without a conv,
+// unet.py:101-103 avg_pool_nd; 1: the gradient of the upsample).  C % 4 == 0 vector forms, scalar otherwise.
+__global__ void upsample2_f32_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C, int V, float scale, long total) {
+    GRID_STRIDE(i, total) {
+        const int cv = C / V, c = (int)(i % cv);
+        long pix = i / cv;
+        const int xx = (int)(pix % W); pix /= W;
+        const int yy = (int)(pix % H);
+        const long n = pix / H;
+        const long o = (((n * 2 * H + 2 * yy) * 2 * W + 2 * xx) * cv + c) * V, row = 2L * W * C;
+        if (V == 4) {
+            float4 v = *reinterpret_cast<const float4*>(x + i * 4);
+            v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+            *reinterpret_cast<float4*>(y + o) = v; *reinterpret_cast<float4*>(y + o + C) = v;
+            *reinterpret_cast<float4*>(y + o + row) = v; *reinterpret_cast<float4*>(y + o + row + C) = v;
+        } else {
+            const float v = x[i] * scale;
+            y[o] = v; y[o + C] = v; y[o + row] = v; y[o + row + C] = v;
+        }
+    }
+}
+__global__ void pool2_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int C, int V, float scale, long total) {
+    GRID_STRIDE(i, total) {
+        const int cv = C / V, c = (int)(i % cv);
+        long r = i / cv;
+        const int x = (int)(r % W); r /= W;
+        const int y = (int)(r % H);
+        const long n = r / H;
+        const float* s = src + (((n * 2 * H + 2 * y) * 2 * W + 2 * x) * cv + c) * V;
+        const long row = 2L * W * C;
+        if (V == 4) {
+            const float4 a = *reinterpret_cast<const float4*>(s), b = *reinterpret_cast<const float4*>(s + C), d = *reinterpret_cast<const float4*>(s + row),
+                         e = *reinterpret_cast<const float4*>(s + row + C);
+            *reinterpret_cast<float4*>(dst + i * 4) = make_float4(((a.x + b.x) + (d.x + e.x)) * scale, ((a.y + b.y) + (d.y + e.y)) * scale,
+                                                                  ((a.z + b.z) + (d.z + e.z)) * scale, ((a.w + b.w) + (d.w + e.w)) * scale);
+        } else dst[i] = ((s[0] + s[C]) + (s[row] + s[row + C])) * scale;
+    }
+}
+
 // ---- sampler math.  tab = fp32 copies of the f64 tables (rounded exactly like `.float()`), [NTAB][T]
 __global__ void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise, const long long* __restrict__ t,
                                 const float* __restrict__ tab, int T, float* __restrict__ out, long per_sample, long total) {
@@ -936,6 +976,15 @@ int cdae_sumpool2(const float* src, float* dst, int N, int H, int W, int C, void
     if (C % 4 == 0 && ((reinterpret_cast<size_t>(src) | reinterpret_cast<size_t>(dst)) & 15) == 0)
         LAUNCH1D(sumpool2_v4_kernel, (long)N * H * W * (C / 4), reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), N, H, W, C / 4);
     LAUNCH1D(sumpool2_kernel, (long)N * H * W * C, src, dst, N, H, W, C);
+}
+
+int cdae_upsample2(const float* x, float* y, int N, int H, int W, int C, float scale, void* stream) {
+    const int V = (C % 4 == 0 && ((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(y)) & 15) == 0) ? 4 : 1;
+    LAUNCH1D(upsample2_f32_kernel, (long)N * H * W * (C / V), x, y, H, W, C, V, scale, (long)N * H * W * (C / V));
+}
+int cdae_pool2(const float* src, float* dst, int N, int H, int W, int C, float scale, void* stream) {
+    const int V = (C % 4 == 0 && ((reinterpret_cast<size_t>(src) | reinterpret_cast<size_t>(dst)) & 15) == 0) ? 4 : 1;
+    LAUNCH1D(pool2_f32_kernel, (long)N * H * W * (C / V), src, dst, H, W, C, V, scale, (long)N * H * W * (C / V));
 }
 
 int cdae_q_sample(const float* x0, const float* noise, const long long* t, const float* tab, int T, float* out, int N, long per_sample, void* stream) {

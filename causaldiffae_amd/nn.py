@@ -171,8 +171,18 @@ def linear(*args, **kwargs):
     return Linear(*args, **kwargs)
 
 
-def avg_pool_nd(*args, **kwargs):
-    raise NotImplementedError("avg-pool downsampling (conv_resample=False) is not used by CausalDiffAE")
+class AvgPool2(nn.Module):
+    """nn.AvgPool2d(kernel_size=2, stride=2) on the library's kernels (even image sizes)"""
+
+    def forward(self, x):
+        return ops.avg_pool2(x)
+
+
+def avg_pool_nd(dims, *args, **kwargs):
+    """Create a 2D average pooling module (reference nn.py:483-493; the UNet asks for kernel_size = stride = 2, unet.py:101-103)."""
+    if dims != 2 or (args and args[0] != 2) or kwargs.get("kernel_size", 2) != 2 or kwargs.get("stride", 2) not in (2, None):
+        raise NotImplementedError("avg_pool_nd: 2-D pooling with kernel_size = stride = 2 (what the UNet builds) only")
+    return AvgPool2()
 
 
 class GroupNorm32(nn.Module):

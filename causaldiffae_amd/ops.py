@@ -343,6 +343,47 @@ def side_join(dev=None):
         sd["held"] = []
 
 
+# ----------------------------------------------------------------------------- resampling without a convolution (conv_resample=False)
+class _Resample2(Function):
+    """up=True: nearest 2x (reference unet.py:76-78 F.interpolate(scale_factor=2, mode="nearest")); up=False: 2 x 2 average pool
+    (unet.py:101-103 avg_pool_nd(2)).  fp32 NHWC in and out; each is the other's gradient up to the factor 1/4."""
+
+    @staticmethod
+    def forward(ctx, x, up):
+        x = to_nhwc(x)
+        N, C, H, W = x.shape
+        ctx.up = up
+        if up:
+            y = new_act(N, C, 2 * H, 2 * W, x.device)
+            check(lib.cdae_upsample2(ptr(x), ptr(y), N, H, W, C, 1.0, stream()))
+        else:
+            if H % 2 or W % 2:
+                raise NotImplementedError("2 x 2 average pool: even image sizes only")
+            y = new_act(N, C, H // 2, W // 2, x.device)
+            check(lib.cdae_pool2(ptr(x), ptr(y), N, H // 2, W // 2, C, 0.25, stream()))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = to_nhwc(dy)
+        N, C, H, W = dy.shape
+        if ctx.up:
+            dx = new_act(N, C, H // 2, W // 2, dy.device)
+            check(lib.cdae_pool2(ptr(dy), ptr(dx), N, H // 2, W // 2, C, 1.0, stream()))
+        else:
+            dx = new_act(N, C, 2 * H, 2 * W, dy.device)
+            check(lib.cdae_upsample2(ptr(dy), ptr(dx), N, H, W, C, 0.25, stream()))
+        return dx, None
+
+
+def upsample2(x):
+    return _Resample2.apply(x, True)
+
+
+def avg_pool2(x):
+    return _Resample2.apply(x, False)
+
+
 # ----------------------------------------------------------------------------- conv3x3
 class _Conv3x3(Function):
     @staticmethod

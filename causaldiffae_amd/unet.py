@@ -32,6 +32,7 @@ from .nn import (
     Identity,
     Linear,
     MultivariateCausalFlow,
+    avg_pool_nd,
     SiLU,
     _RNG_OVERRIDE,
     checkpoint,
@@ -89,13 +90,16 @@ class EmbAll:
 class Upsample(nn.Module):
     def __init__(self, channels, use_conv, dims=2):
         super().__init__()
-        if not use_conv or dims != 2:
-            raise NotImplementedError("CausalDiffAE always upsamples with conv_resample=True in 2-D")
+        if dims != 2:
+            raise NotImplementedError("Upsample: 2-D only (the reference's scripts never build another)")
         self.channels, self.use_conv, self.dims = channels, use_conv, dims
-        self.conv = conv_nd(dims, channels, channels, 3, padding=1)
+        if use_conv:
+            self.conv = conv_nd(dims, channels, channels, 3, padding=1)
 
     def forward(self, x):
         assert x.shape[1] == self.channels
+        if not self.use_conv:                  # conv_resample=False (unet.py:76-78 without the conv): nearest 2x, nothing else
+            return ops16.to16(ops.upsample2(ops16.to32(x))) if x.dtype == th.bfloat16 else ops.upsample2(x)
         if x.dtype == th.bfloat16:             # the 16-bit torso
             if ops16.upconv_ok(x, self.channels):
                 return ops16.upconv_train(x, self.conv.weight, self.conv.bias)
@@ -111,13 +115,15 @@ class Upsample(nn.Module):
 class Downsample(nn.Module):
     def __init__(self, channels, use_conv, dims=2):
         super().__init__()
-        if not use_conv or dims != 2:
-            raise NotImplementedError("CausalDiffAE always downsamples with conv_resample=True in 2-D")
+        if dims != 2:
+            raise NotImplementedError("Downsample: 2-D only (the reference's scripts never build another)")
         self.channels, self.use_conv, self.dims = channels, use_conv, dims
-        self.op = conv_nd(dims, channels, channels, 3, stride=2, padding=1)
+        self.op = conv_nd(dims, channels, channels, 3, stride=2, padding=1) if use_conv else avg_pool_nd(dims, 2)
 
     def forward(self, x):
         assert x.shape[1] == self.channels
+        if not self.use_conv:                  # conv_resample=False (unet.py:101-103): 2 x 2 average pool
+            return ops16.to16(self.op(ops16.to32(x))) if x.dtype == th.bfloat16 else self.op(x)
         if x.dtype == th.bfloat16:             # the 16-bit torso: forward on the bf16 rows themselves, backward on the fp32-storage node's kernels
             if ops16.down_ok(x, self.channels):
                 return ops16.downsample_train(x, self.op.weight, self.op.bias)
@@ -376,10 +382,12 @@ class UNetModel(nn.Module):
 
     # ------------------------------------------------------------------ precision
     def convert_to_fp16(self):
-        """Reduced-precision torso (reference unet.py:501-507 casts the conv weights to half).  Here storage stays
-        fp32 and the matrix-core contractions switch to single-plane f16 (bf16 where an operand is a gradient) with
-        fp32 accumulation; GroupNorm, softmax, embeddings and the optimizer stay fp32 like the reference's GroupNorm32 /
-        softmax.  The mode belongs to this model: other models / samplers of the process keep the parity mode."""
+        """Reduced-precision torso (reference unet.py:501-507 casts the conv weights to half, fp16_util.py:9-15).  In grad mode (training)
+        every activation and gradient from the input conv's result to the output head's input is then a bf16 NHWC tensor (ops16.py: the
+        one-plane operand of the matrix-core kernels, fp32 accumulation, results rounded once in the epilogue); master weights, weight
+        gradients, GroupNorm statistics (GroupNorm32, nn.py:435-437), the softmax, embeddings, the encoder and the optimizer stay fp32.  In
+        no-grad mode storage stays fp32 and the contractions use one f16 plane per operand.  The mode belongs to this model: other models /
+        samplers of the process keep the parity mode."""
         self._cdae_precision = "mixed16"       # applied around THIS model's forward (and by TrainLoop around its backward), not process-wide
 
     def convert_to_fp32(self):

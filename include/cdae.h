@@ -418,6 +418,11 @@ int cdae_nhwc_to_nchw(const float* src, float* dst, int N, int C, int HW, void* 
    reference's host DataLoader + ToTensor/`/255` per item (image_datasets.py:266-297, 352-372, 451-467); per_sample % 4 == 0 */
 int cdae_gather_u8(const unsigned char* pool, const long long* idx, float* out, int B, long per_sample, float div, float shift, void* stream);
 int cdae_sumpool2(const float* src, float* dst, int N, int H, int W, int C, void* stream);
+/* resampling WITHOUT a convolution (conv_resample=False; unet.py:76-78 F.interpolate(scale_factor=2, "nearest"), :101-103 avg_pool_nd(2)),
+   fp32 NHWC: y[N,2H,2W,C] = scale * nearest2x(x[N,H,W,C]);  dst[N,H,W,C] = scale * (sum of the 2 x 2 blocks of src[N,2H,2W,C]).
+   Upsample: (upsample2, 1) forward, (pool2, 1) backward; average pool: (pool2, 0.25) forward, (upsample2, 0.25) backward. */
+int cdae_upsample2(const float* x, float* y, int N, int H, int W, int C, float scale, void* stream);
+int cdae_pool2(const float* src, float* dst, int N, int H, int W, int C, float scale, void* stream);
 /* q_sample (gaussian_diffusion.py:201-222) */
 int cdae_q_sample(const float* x0, const float* noise, const long long* t, const float* tab, int T, float* out, int N, long per_sample, void* stream);
 /* one fused DDIM update (p_mean_variance eps branch + ddim_sample, gaussian_diffusion.py:336-338,533-558); noise may be NULL iff eta==0.

@@ -166,6 +166,38 @@ def test_linear_wgrad_group(shapes, rows, grouped, precision):
         assert err(dbd, db) < tol * float(db.abs().max())
 
 
+# ------------------------------------------------------------------ resampling without a conv (conv_resample=False)
+def test_plain_resample_golden(golden):
+    """Upsample(use_conv=False) (reference unet.py:51-78: nearest 2x alone) against the reference's own output and input gradient (G22);
+    Downsample(use_conv=False) against torch's avg_pool2d — the reference module cannot be built (its avg_pool_nd(stride) call lacks
+    `dims`: TypeError, recorded in the fixture), the docstring's meaning (2 x 2 average pool) is what is implemented; bf16 rows too."""
+    from causaldiffae_amd.unet import Downsample, Upsample
+    from oracle.closed_form import synth
+    g = golden("g22_plain_resample.npz")
+    assert int(g["down/reference_builds"]) == 0
+    x = synth("T28r.x", (2, 64, 7, 14))
+    gy = synth("T28r.gy", (2, 64, 14, 28))
+    xd = x.to(DEV).requires_grad_(True)
+    y = Upsample(64, False)(xd)
+    (y * gy.to(DEV)).sum().backward()
+    assert err(y, torch.from_numpy(g["up/y"])) == 0.0 and err(xd.grad, torch.from_numpy(g["up/dx"])) < 1e-6
+    # average pool (and its gradient) against torch, odd channel count included (scalar kernels)
+    for C, H, W in ((64, 14, 28), (6, 8, 8)):
+        a = rnd(3, C, H, W)
+        ga = rnd(3, C, H // 2, W // 2, seed=1)
+        ad = a.to(DEV).requires_grad_(True)
+        o = Downsample(C, False)(ad)
+        (o * ga.to(DEV)).sum().backward()
+        ac = a.double().requires_grad_(True)
+        oc = F.avg_pool2d(ac, 2)
+        (oc * ga.double()).sum().backward()
+        assert err(o, oc) < 1e-6 and err(ad.grad, ac.grad) < 1e-6
+        u = Upsample(C, False)(ad.detach())
+        assert err(u, F.interpolate(a, scale_factor=2, mode="nearest")) == 0.0
+    with pytest.raises(NotImplementedError):
+        Downsample(8, False)(torch.zeros(1, 8, 7, 7, device=DEV))
+
+
 # ------------------------------------------------------------------ conv3x3 forward
 CONVS = [
     # N, Cin, Cout, H, stride, up, nchw_in, out_nchw

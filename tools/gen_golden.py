@@ -801,6 +801,28 @@ def g21_m32_curve(out_dir):
     np.savez_compressed(os.path.join(out_dir, "g21_m32_curve.npz"), **out)
 
 
+# --------------------------------------------------------------------------- G22: resampling without a conv (conv_resample=False)
+def g22_plain_resample(out_dir):
+    """runet.Upsample(channels, use_conv=False) (unet.py:51-78: F.interpolate alone): output and input gradient on a closed-form tensor.
+    The matching Downsample(use_conv=False) cannot be run: the reference builds it as avg_pool_nd(stride) — `dims` is missing, so
+    nn.AvgPool2d() raises TypeError at construction (unet.py:101, nn.py:497) and UNetModel(conv_resample=False) never gets built; recorded
+    here so that the fixture says why the pool is pinned to torch's avg_pool2d only."""
+    out = {}
+    up = runet.Upsample(64, False)
+    x = synth("T28r.x", (2, 64, 7, 14)).requires_grad_(True)
+    y = up(x)
+    gy = synth("T28r.gy", tuple(y.shape))
+    (y * gy).sum().backward()
+    out["up/y"], out["up/dx"] = y.detach().numpy(), x.grad.numpy()
+    try:
+        runet.Downsample(64, False)
+        out["down/reference_builds"] = np.int64(1)
+    except TypeError as e:
+        out["down/reference_builds"] = np.int64(0)
+        out["down/error"] = np.array(str(e))
+    np.savez_compressed(os.path.join(out_dir, "g22_plain_resample.npz"), **out)
+
+
 # --------------------------------------------------------------------------- G16
 def g16_dropout(out_dir):
     """Training-mode ResBlock with dropout > 0 (unet.py:153): the keep mask the reference's nn.Dropout drew is recorded next to the
@@ -992,7 +1014,7 @@ def g20_traversal(out_dir):
     np.savez_compressed(os.path.join(out_dir, "g20_traversal.npz"), **out)
 
 
-ALL = dict(G16=g16_dropout, G1=g1_schedules, G2=g2_temb, G3=g3_blocks, G4=g4_encoder, G5=g5_rep_loss, G6=g6_unet, G7=g7_train, G8=g8_ddim, G9=g9_vlb, G10=g10_flow, G11=g11_variants, G12=g12_full_train, G13=g13_guidance, G14=g14_p_sample_loop, G15=g15_m32_b256, G17=g17_ddim250, G18=g18_p_sample_t1000, G19=g19_trained_like, G20=g20_traversal, G21=g21_m32_curve)
+ALL = dict(G16=g16_dropout, G1=g1_schedules, G2=g2_temb, G3=g3_blocks, G4=g4_encoder, G5=g5_rep_loss, G6=g6_unet, G7=g7_train, G8=g8_ddim, G9=g9_vlb, G10=g10_flow, G11=g11_variants, G12=g12_full_train, G13=g13_guidance, G14=g14_p_sample_loop, G15=g15_m32_b256, G17=g17_ddim250, G18=g18_p_sample_t1000, G19=g19_trained_like, G20=g20_traversal, G21=g21_m32_curve, G22=g22_plain_resample)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
