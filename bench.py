@@ -524,7 +524,7 @@ def main():
             traffic = traffic_src = None
             # (convwin: the 9-TAP instantiation's own summary — the 4-tap sub-pixel kernel is a separate kernel name and a separate file)
             stem = "convwin9" if dom is cw else "igemm"
-            cands = [f"r05_{stem}_pmc_summary_{prec}.json", f"r04_{stem}_pmc_summary_{prec}.json"] + ([f"r03_convwin_pmc_summary_{prec}.json"] if dom is cw else [f"r01_igemm_pmc_summary_{prec}.json"])
+            cands = [f"r06_{stem}_pmc_summary_{prec}.json", f"r05_{stem}_pmc_summary_{prec}.json", f"r04_{stem}_pmc_summary_{prec}.json"] + ([f"r03_convwin_pmc_summary_{prec}.json"] if dom is cw else [f"r01_igemm_pmc_summary_{prec}.json"])
             pmc_file = next((os.path.join(ROOT, "profiles", c) for c in cands if os.path.exists(os.path.join(ROOT, "profiles", c))), None)
             if pmc_file and N == 128:
                 pm = json.load(open(pmc_file))
@@ -537,7 +537,7 @@ def main():
             if up["launches"] > 0 and up["ms"] > 0:
                 ach4 = up["work"] / (up["ms"] * 1e-3) / 1e12
                 alg4 = up["bytes"] / up["launches"] if up["bytes"] > 0 else None
-                pm4 = next((os.path.join(ROOT, "profiles", c) for c in (f"r05_convwin4_pmc_summary_{prec}.json", f"r04_convwin4_pmc_summary_{prec}.json")
+                pm4 = next((os.path.join(ROOT, "profiles", c) for c in (f"r06_convwin4_pmc_summary_{prec}.json", f"r05_convwin4_pmc_summary_{prec}.json", f"r04_convwin4_pmc_summary_{prec}.json")
                             if os.path.exists(os.path.join(ROOT, "profiles", c))), None)
                 t4 = json.load(open(pm4))["hbm_traffic_bytes_per_launch"] if pm4 and N == 128 else None
                 r["upconv_4tap"] = {"kernel": "convwin_kernel<f16, 4 taps>", "bound": "mfma", "achieved": ach4, "peak": peak, "frac": ach4 / peak,

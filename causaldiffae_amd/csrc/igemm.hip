@@ -1010,8 +1010,8 @@ int cdae_gemm_group_dispatch(GemmGroupArg& g, void* stream) {
         flops += 2.0 * it.M * it.N * (double)it.K;
         bytes += 4.0 * ((double)it.M * it.K + (double)it.N * it.K + (double)it.M * it.N);
     }
-    static const int cfg_big = CDAE_DEV_INT("CDAE_GROUP_BIG_TILES", 384), cfg_small = CDAE_DEV_INT("CDAE_GROUP_SMALL_TILES", 192);
-    const bool big = tiles_big >= cfg_big;
+    static const int cfg_small = CDAE_DEV_INT("CDAE_GROUP_SMALL_TILES", 192);
+    const bool big = tiles_big >= cdae_tune(TUNE_GROUP_BIG_TILES);
     if (!big && tiles_small < cfg_small) return 1;
     c.ksplit = 1; c.batch_inner = 1; c.a_scalar = c.b_scalar = 0; c.w_scale = nullptr; c.range_flag = cdae_range_flag_ptr();
     static const int cfg_waves8 = CDAE_DEV_INT("CDAE_IGEMM_WAVES8", 1);

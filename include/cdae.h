@@ -489,9 +489,11 @@ int cdae_rep_loss_bwd(const float* mu, const float* var, const float* z_post, co
  *                                      the two plane slots of the kernel carry the two halves of the input channels (two MFMAs per K step);
  *                                      0: the one-plane instantiation
  *   CDAE_TUNE_GN_BWD_FOLD2       (1)   GroupNorm backward as TWO launches (partial sums; dx with the group fold in its prologue and the
- *                                      channel folds as extra rows of its grid); 0: the separate fold launch between them (A/B, tests) */
+ *                                      channel folds as extra rows of its grid); 0: the separate fold launch between them (A/B, tests)
+ *   CDAE_TUNE_GROUP_BIG_TILES    (384) cdae_linear_wgrad_group runs 128 x 128 tiles when the members together have at least this many of them,
+ *                                      else 64 x 64 tiles (at least 192 of those, or one launch per member) */
 enum { CDAE_TUNE_CONVWIN_MIN_TILES = 0, CDAE_TUNE_CONVWIN_SPLITK = 1, CDAE_TUNE_CONVWIN_NJ3 = 2, CDAE_TUNE_HEAD_MFMA = 3, CDAE_TUNE_ROWS16_MIN_M = 4,
-       CDAE_TUNE_ROWS16_RING = 5, CDAE_TUNE_CONVWIN_PAIR16 = 6, CDAE_TUNE_GN_BWD_FOLD2 = 7 };
+       CDAE_TUNE_ROWS16_RING = 5, CDAE_TUNE_CONVWIN_PAIR16 = 6, CDAE_TUNE_GN_BWD_FOLD2 = 7, CDAE_TUNE_GROUP_BIG_TILES = 8 };
 int cdae_tune_set(int key, int value);
 int cdae_tune_get(int key);       /* -1: unknown key */
 

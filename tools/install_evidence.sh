@@ -22,13 +22,14 @@ import json, sys
 d = json.load(open(f"profiles/{sys.argv[1]}_bench_line_{sys.argv[2]}.json"))
 r, t = d["roofline"], d["train"]
 print("ddim", round(d["value"], 1), round(d["ms_per_step"], 3), "convwin frac", round(r["frac"], 4), round(r["avg_launch_us"], 1), "whole-step TF", round(d["model_tflops"], 1))
-print("families", {k: round(v, 3) for k, v in r["family_ms_per_step"].items()})
 print("fp32 ddim", round(d["other_precision"]["ms_per_step"], 2), round(d["other_precision"]["roofline"]["frac"], 3))
 print("train", round(t["value"], 2), round(t["ms_per_step"], 3), round(t["frac_of_roof"], 4), "host ms", round(t["host_cpu_ms_per_step"], 1),
-      "| world-8 policy", round(t["world8_policy"]["ms_per_step"], 2), round(t["world8_policy"]["host_cpu_over_step"], 3))
+      "| world-8 policy", round(t["world8_policy"]["ms_per_step"], 2), round(t["world8_policy"]["host_cpu_over_step"], 3), "cores needed at world 8", round(t["host_cores_needed_at_world8"], 1))
 print("fp32 train", round(t["fp32_mode"]["ms_per_step"], 2), round(t["fp32_mode"]["frac_of_roof"], 3))
 c = t["config1_m32_b256"]
-print("m32 b256", round(c["f16x3"]["ms_per_step"], 2), round(c["mixed16"]["ms_per_step"], 2), round(c["mixed16"]["frac_of_roof"], 4))
+print("m32 b256", round(c["f16x3"]["ms_per_step"], 2), round(c["mixed16"]["ms_per_step"], 2), round(c["mixed16"]["frac_of_roof"], 4), "world-8 host", round(c["mixed16"]["world8_policy"]["host_cpu_over_step"], 3))
+print("c64 torso", round(t["mixed16_torso"]["ms_per_step"], 2), round(t["mixed16_torso"]["frac_of_roof"], 4), "world-8 host", round(t["mixed16_torso"]["world8_policy"]["host_cpu_over_step"], 3))
+print("box", d["box"], "bytes of the line", len(json.dumps(d)))
 print("guided", round(d["guided_w2"]["ms_per_step"], 2), "batch16", round(d["batch16"]["ms_per_step"], 3), "public loop", round(d["public_ddim_sample_loop"]["default_ms_per_step"], 2),
       round(d["public_ddim_sample_loop"]["eager_ms_per_step"], 2))
 print("cpu", round(d["cpu_baseline"]["value"], 2), round(d["cpu_baseline"]["train"]["value"], 3), "gpu/cpu", round(d["gpu_over_cpu"], 1))
