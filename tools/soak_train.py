@@ -25,7 +25,8 @@ for i in range(steps):
     if i % 25 == 0 or i == steps - 1:
         l = loop.last_losses
         hist.append((i, float(l["mse"].mean()), float(l["kld_rep"].mean())))
-        print(hist[-1], flush=True)
+        rss = int(open("/proc/self/statm").read().split()[1]) * os.sysconf("SC_PAGE_SIZE") >> 20      # host memory: the runtime's command batches must not pile up
+        print(hist[-1], "host RSS MiB", rss, "device MiB", torch.cuda.memory_allocated() >> 20, flush=True)
 torch.cuda.synchronize()
 print("steps/s", steps / (time.perf_counter() - t0))
 assert all(map(lambda h: h[1] == h[1] and h[1] < 10, hist)), "non-finite or exploding loss"
