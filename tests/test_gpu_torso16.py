@@ -202,8 +202,8 @@ def test_attention_block16_and_upconv16_against_float64(mixed16, C, heads):
 def test_full_model_step_on_the_16bit_torso_matches_fp32_storage(arch):
     """One training_losses + backward of the M32 model (BASELINE config [1]'s architecture) and of the C64 model (64 x 64, 93 M parameters:
     channel counts of 384 / 512 that the streaming 1 x 1 kernels do not take, attention heads of 96 and 128 channels) with convert_to_fp16(): the 16-bit torso
-    against the same model in the parity mode — loss within 2e-2, every large gradient tensor within 8e-2 of its own scale and well
-    correlated; and with the torso toggled off (fp32 storage, one-plane products: the round-3 behaviour) the same bar holds."""
+    against the same model in the parity mode — loss within 2e-2 (measured 2e-5 .. 4e-5), every large gradient tensor within the BAR below of
+    its own scale and of cosine 1; and with the torso toggled off (fp32 storage, one-plane products: the round-3 behaviour) the same bar holds."""
     import bench
     from causaldiffae_amd import ops
     from improved_diffusion import script_util as su
@@ -239,7 +239,9 @@ def test_full_model_step_on_the_16bit_torso_matches_fp32_storage(arch):
         f = loop.opt.flat
         return losses["loss"].mean().item(), {n: f.grad[o:o + p.numel()].clone() for n, p, o in zip(f.names, f.params, f.offsets)}
 
-    BAR = {"m32": (0.12, 0.985), "c64": (0.12, 0.985)}
+    # 1.5 x what the kernels deliver (MI355X, round 6: m32 0.0123 / 0.99992, c64 0.087 — an encoder conv upstream of the torso — / 0.99988); the cosine is
+    # the bar a systematic bias would hit first (round 5 accepted 0.12 / 0.985)
+    BAR = {"m32": (0.02, 0.9998), "c64": (0.13, 0.9997)}
     l32, g32 = run(False)
     for torso in (True, False):
         l16, g16 = run(True, torso)
@@ -255,6 +257,53 @@ def test_full_model_step_on_the_16bit_torso_matches_fp32_storage(arch):
         print(f"torso16 {arch} torso={torso}: loss rel {abs(l16 - l32) / abs(l32):.2e}; worst gradient max-error / scale {max(w[0] for w in worst):.4f} "
               f"({sorted(worst)[-1][2]}), worst cosine {min(w[1] for w in worst):.5f} ({sorted(worst, key=lambda w: w[1])[0][2]})")
         assert max(w[0] for w in worst) < BAR[arch][0] and min(w[1] for w in worst) > BAR[arch][1], (torso, sorted(worst)[-3:], sorted(worst, key=lambda w: w[1])[:3])
+
+
+@pytest.mark.parametrize("odd", [170, 102, 5])
+def test_torso_training_with_odd_sized_parameters(odd):
+    """A parameter whose element count is not a multiple of 8 in FRONT of the 1 x 1 weights (the round-5 advisor's case: n_vars = 3 / 5 would give
+    `causal_mask.*.net.2.bias` 170 / 102 elements — configurations the reference itself cannot run, its reshape to [N, n_vars, 512 // n_vars] fails,
+    so the odd size is planted directly): packed back to back, every weight behind it sat 8 bytes off a 16-byte boundary and the streaming
+    kernels' aligned-rows check refused the bf16 image of the flat parameter buffer.  FlatParams now starts every view on a 32-byte boundary: a
+    use_fp16 training step runs, every view and every bf16 image pointer is aligned, the loss matches the parity mode's within the torso's bar."""
+    import bench
+    from causaldiffae_amd import ops16
+    from causaldiffae_amd._lib import precision_scope
+    from improved_diffusion import script_util as su
+    from improved_diffusion.train_util import TrainLoop
+    dev = torch.device(DEV)
+    g = torch.Generator().manual_seed(5 + odd)
+    N = 8
+    x0 = torch.rand(N, 1, 32, 32, generator=g) * 2 - 1
+    cond = {"c": torch.rand(N, 2, generator=g), "y": torch.randint(0, 10, (N,), generator=g)}
+
+    def run(fp16):
+        cfg = {**su.model_and_diffusion_defaults(), "image_size": 32, "in_channels": 1, "n_vars": 2, "rep_cond": True, "causal_modeling": True, "class_cond": True}
+        model, diff = su.create_model_and_diffusion(**cfg)
+        bench.randomize(model, 4321)
+        model.register_parameter("odd_probe", torch.nn.Parameter(torch.zeros(odd)))
+        assert next(iter(model.named_parameters()))[0] == "odd_probe"      # (a root module's own parameters come first: everything else lies behind it)
+        model.to(dev).train()
+        loop = TrainLoop(model=model, diffusion=diff, data=iter(()), batch_size=N, microbatch=-1, lr=1e-4, ema_rate="0.9999", log_interval=10 ** 9,
+                         save_interval=10 ** 9, resume_checkpoint="", rep_cond=True, n_vars=2, causal_modeling=True, in_channels=1, use_fp16=fp16)
+        diff.kl_weight = 0.1
+        f = loop.opt.flat
+        assert "odd_probe" in f.names and all(o % 8 == 0 for o in f.offsets) and all(p.data_ptr() % 32 == 0 for p in f.params)
+        torch.manual_seed(9)
+        np.random.seed(3)                                     # (the timestep sampler draws from numpy)
+        loop.forward_backward(x0, cond)
+        loop.optimize_normal()
+        if fp16:
+            with precision_scope("mixed16"):
+                ptrs = [ops16.w16(m.skip_connection.weight) for m in model.modules()
+                        if getattr(getattr(m, "skip_connection", None), "weight", None) is not None]
+            assert ptrs and all(q % 16 == 0 for q in ptrs)
+        torch.cuda.synchronize()
+        return float(loop.last_losses["loss"].mean()), float(f.flat.abs().max())
+
+    l32, _ = run(False)
+    l16, wmax = run(True)
+    assert np.isfinite(l16) and np.isfinite(wmax) and abs(l16 - l32) < 2e-2 * abs(l32), (l16, l32)
 
 
 @pytest.mark.parametrize("T,ch,heads,B", [(256, 64, 4, 3), (64, 128, 2, 5), (64, 96, 4, 2), (256, 96, 1, 2)])
