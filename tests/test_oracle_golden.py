@@ -787,3 +787,62 @@ def test_traversal_p64(golden):
             value += 0.15
         final = D.sample_loop(sch, lambda xx, tm: U.unet_forward(sd, cfg, xx, tm, z=zs[7])[0], x_t, ddim=True)
     close(final.numpy(), g["sample7"], 1e-4)
+
+
+# ------------------------------------------------------------------ G21: the converging run the 16-bit torso is trained against
+def test_training_curve_m32(golden):
+    """The first 8 of G21's 24 reference steps (M32, batch 16, AdamW 1e-4, kl 0.1, four batches in rotation; reference train_util.py:231-297)
+    through the oracle's training_losses + adamw_ema_step: the loss curve the GPU test holds the parity mode and the 16-bit torso to."""
+    g = golden("g21_m32_curve.npz")
+    cfg = model_cfg("M32")
+    spec = U.param_spec(cfg)
+    sd = fill_state_dict(spec)
+    pkeys = [k for k, _ in spec if "running" not in k and "num_batches" not in k]
+    params = [sd[k].requires_grad_(True) for k in pkeys]
+    ema = [p.detach().clone() for p in params]
+    m = [torch.zeros_like(p) for p in params]
+    v = [torch.zeros_like(p) for p in params]
+    sch = D.Schedule(1000, "linear", "", True)
+    N = int(g["batch"])
+    for step in range(8):
+        b = step % 4
+        x0 = synth(f"M32c.{b}.x0", (N, 1, 32, 32), -1.0, 1.0)
+        c = synth(f"M32c.{b}.c", (N, 2), 0.0, 1.0)
+        y = torch.tensor([(b + 3 * i) % 10 for i in range(N)], dtype=torch.int64)
+        t = torch.tensor([(137 * (step + 1) + 251 * i) % 1000 for i in range(N)], dtype=torch.int64)
+        noise = synth_noise(f"M32c.{step}.noise", (N, 1, 32, 32))
+        torch.manual_seed(300 + step)
+        eps_z = torch.randn(N, 512)
+        chk = g[f"step{step}/eps_draw_check"]
+        assert abs(eps_z.double().sum().item() - chk[0]) < 1e-6 * max(1.0, abs(chk[0])) and np.allclose(eps_z.flatten()[:6].numpy(), chk[2:], atol=0)
+        new = {}
+
+        def model_full(x_t, tm, xs):
+            return U.unet_forward(sd, cfg, x_t, tm, y=y, c=c, x_start=xs, eps_z=eps_z, training=True, new_stats=new)
+
+        for p in params:
+            p.grad = None
+        terms = D.training_losses(sch, model_full, x0, t, noise, c=c, rep_cond=True, causal_modeling=True, kl_weight=0.1)
+        terms["loss"].mean().backward()
+        for k in ("loss", "mse", "kld_rep"):
+            ref = float(g[f"step{step}/{k}_mean"])
+            got = float(terms[k].detach().double().mean())
+            assert abs(got - ref) <= 2e-5 * abs(ref), (step, k, got, ref)
+        with torch.no_grad():
+            D.adamw_ema_step(params, [p.grad for p in params], m, v, ema, step + 1)
+            for k, val in new.items():
+                sd[k] = val
+    assert float(g["step0/loss_mean"]) - float(g["step23/loss_mean"]) > 4.0          # (the fixture's run converges)
+
+
+# ------------------------------------------------------------------ G22: resampling without a conv
+def test_plain_resample(golden):
+    """Upsample(use_conv=False) = nearest 2x alone (reference unet.py:76-78): the fixture's output and gradient are what nearest
+    interpolation and its 2 x 2 sum give; and the fixture records that the reference's Downsample(use_conv=False) cannot be built."""
+    g = golden("g22_plain_resample.npz")
+    x = synth("T28r.x", (2, 64, 7, 14))
+    gy = synth("T28r.gy", (2, 64, 14, 28))
+    close(x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3).numpy(), g["up/y"], 0.0)
+    close(gy.reshape(2, 64, 7, 2, 14, 2).sum(dim=(3, 5)).numpy(), g["up/dx"], 1e-6)
+    assert int(g["down/reference_builds"]) == 0 and "kernel_size" in str(g["down/error"])
+
