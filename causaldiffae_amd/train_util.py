@@ -100,6 +100,11 @@ class GradBuckets:
     def __init__(self, flat, bucket_bytes=64 << 20, group=None):
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # the bucketed all-reduce runs for world > 1 — and, CDAE_DDP_FORCE=1, in an initialised process group of ONE rank: the whole
+        # data-parallel path (hooks, ordered bucket launches, RCCL's stream, the waits) on a one-GPU box with the real backend, where the
+        # reduction is the identity (tests/test_gpu_model.py::test_rccl_data_parallel_path_with_one_rank)
+        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("CDAE_DDP_FORCE") == "1")
+        self.launched = 0           # collectives issued (diagnostics)
         self._gloo = dist.is_initialized() and dist.get_backend(group) == "gloo"
         self.buckets, self.bucket_of = [], {}
         hi, acc, members = flat.numel, 0, []
@@ -114,7 +119,7 @@ class GradBuckets:
                 hi, acc, members = lo, 0, []
         self.enabled = True
         self._hooks = []
-        if self.world > 1:
+        if self.active:
             for i, p in enumerate(flat.params):
                 if p.requires_grad:
                     hook = self._make_hook(i)
@@ -155,6 +160,7 @@ class GradBuckets:
             # AMD_SERIALIZE_KERNEL=3, or the side stream's own waits make it go away).  RCCL runs its kernels on the device and has no such
             # staging copy; for gloo the host simply waits for the launch stream first.
             th.cuda.current_stream(grad.device).synchronize()
+        self.launched += 1
         return dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _make_hook(self, i):
@@ -173,7 +179,7 @@ class GradBuckets:
 
     def reduce_all(self):
         """All buckets at once, after a backward that ran with the hooks disabled (hipGraph replay)."""
-        if self.world == 1:
+        if not self.active:
             return
         self.reset()
         self.finish()
@@ -182,7 +188,7 @@ class GradBuckets:
         """Wait for in-flight buckets, reduce any bucket whose hook never fired (unused params), average.  `average=False` leaves the
         all-reduced SUM in the flat buffer: TrainLoop hands 1 / world to the optimizer kernel's gradient scale instead of spending a
         pass of its own over the buffer (374 MB for the 93 M-parameter UNet)."""
-        if self.world == 1:
+        if not self.active:
             return
         for b in self.buckets:             # in index order, like the hooks
             if b["work"] is None:

@@ -1561,6 +1561,31 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+def test_rccl_data_parallel_path_with_one_rank():
+    """The data-parallel training path on the REAL backend (`nccl` = RCCL), which a one-GPU box otherwise never executes (the 2-GPU nccl test
+    skips, gloo stands in elsewhere): an initialised process group of one rank with CDAE_DDP_FORCE=1 runs the gradient-ready hooks, the ordered
+    64 MiB bucket all-reduces on RCCL's stream while backward is still running, the waits and the rank-0 broadcast.  Reducing over one rank is
+    the identity, so three optimizer steps must end in the weights of a run without a process group (reference train_util.py:107-118, 255-259:
+    DDP + broadcast there)."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "CDAE_DIST_BACKEND")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    recs = {}
+    for mode in ("plain", "rccl"):
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "rccl1_worker.py"), mode], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("RCCL1 ")]
+        assert len(line) == 1, r.stdout[-1500:]
+        recs[mode] = json.loads(line[0][6:])
+    a, b = recs["plain"], recs["rccl"]
+    assert b["backend"] == "nccl" and b["active"] and not a["active"]
+    assert b["collectives"] == 3 * b["buckets"] and b["buckets"] >= 5, b          # every bucket of every step went through RCCL
+    assert np.allclose(a["losses"], b["losses"], rtol=1e-5, atol=0), (a["losses"], b["losses"])
+    assert abs(a["sumsq"] - b["sumsq"]) <= 1e-9 * a["sumsq"] and np.allclose(a["probe"], b["probe"], rtol=1e-5, atol=1e-7 * a["absmax"])
+
+
+@pytest.mark.gpu
 def test_bench_gpus_flag_launches_its_own_ranks():
     """`python bench.py --gpus 2` started BARE (no launcher, WORLD_SIZE unset — the way the driver starts `--gpus 1`): the script starts
     two fresh rank processes itself before touching the GPU and relays rank 0's single line (n_gpus == ranks_in_group == 2).  On a
