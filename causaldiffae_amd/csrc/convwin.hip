@@ -689,5 +689,6 @@ int cdae_convwin_launch(const GemmParams& p, void* stream) {
     }
     if (p.prec == 4) return launch_convwin<true, 9, 1>(p, st);           // mixed16, gradient operand: one bf16 plane
     if (p.cw_nj == 3 && p.prec == 1) return launch_convwin<false, 9, 2, 3>(p, st);      // planes.hip chose the tile width
+    if (p.cw_nj == 2 && p.prec == 1) return launch_convwin<false, 9, 2, 2>(p, st);
     return p.prec == 2 ? launch_convwin<true, 9>(p, st) : launch_convwin<false, 9>(p, st);
 }

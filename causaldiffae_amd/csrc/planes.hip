@@ -576,6 +576,18 @@ int cdae_planes_dispatch(GemmParams& p, int big, int& ks, hipStream_t st) {
             auto fill = [](long t) { return (double)t / (double)(((t + 511) / 512) * 512); };
             if (tune_nj > 0 || (fill(mt * (p.N / 96)) >= 0.9 && fill(mt * (p.N / 96)) > fill(mt * ((p.N + 127) / 128)) + 0.1)) p.cw_nj = 3;
         }
+        // 256 x 64 tiles (round 6): small-batch sampling leaves half of the 512 block slots empty at the high-resolution levels (batch 16:
+        // 256 tiles of 256 x 128 at 64 x 64, 128 at 32 x 32 — ONE block per CU, so the kernel's two barrier domains per SIMD never overlap);
+        // 64-column tiles double the blocks for one more read of the window from L2.  Only where the wide tiles fill less than 0.6 of the
+        // slots and the narrow ones do better by 0.25; bit-identical results (same K order per output element).
+        // TUNE_CONVWIN_NJ2: 0 auto, 1 wherever 64 columns apply (parity tests), -1 never.
+        const int tune_nj2 = cdae_tune(TUNE_CONVWIN_NJ2);
+        if (cw && p.cw_nj == 4 && tune_nj2 >= 0 && p.ps_taps != 4 && p.prec == 1 && ks == 1 && p.N % 64 == 0) {
+            const long mt = (p.M + 255) / 256;
+            auto fill = [](long t) { return (double)t / (double)(((t + 511) / 512) * 512); };
+            const double f4 = fill(mt * ((p.N + 127) / 128)), f2 = fill(mt * (p.N / 64));
+            if (tune_nj2 > 0 || (f4 < 0.6 && f2 >= f4 + 0.25)) p.cw_nj = 2;
+        }
         const long cw_tiles = (long)((p.M + 255) / 256) * ((p.N + 32 * p.cw_nj - 1) / (32 * p.cw_nj)) * (p.nphase > 1 ? p.nphase : 1);
         if (cw) {
             int kbest = ks;

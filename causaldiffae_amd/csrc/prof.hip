@@ -43,7 +43,7 @@ int* cdae_range_flag_ptr() {
 
 namespace {
 // defaults = the measured optimum on MI355X (dispatch table)
-int g_tune[TUNE_N] = {256, 1, 0, 1, 2048, 1, 1, 1, 384};
+int g_tune[TUNE_N] = {256, 1, 0, 1, 2048, 1, 1, 1, 384, 0};
 }
 int cdae_tune(int key) { return key >= 0 && key < TUNE_N ? g_tune[key] : 0; }
 
@@ -216,7 +216,7 @@ int cdae_range_status(int* nonfinite) {
 
 int cdae_tune_set(int key, int value) {
     if (key < 0 || key >= TUNE_N) return cdae_fail("tune_set: unknown key");
-    if (value < 0 && key != TUNE_CONVWIN_NJ3) return cdae_fail("tune_set: value must be >= 0");
+    if (value < 0 && key != TUNE_CONVWIN_NJ3 && key != TUNE_CONVWIN_NJ2) return cdae_fail("tune_set: value must be >= 0");
     g_tune[key] = value;
     return 0;
 }

@@ -491,9 +491,12 @@ int cdae_rep_loss_bwd(const float* mu, const float* var, const float* z_post, co
  *   CDAE_TUNE_GN_BWD_FOLD2       (1)   GroupNorm backward as TWO launches (partial sums; dx with the group fold in its prologue and the
  *                                      channel folds as extra rows of its grid); 0: the separate fold launch between them (A/B, tests)
  *   CDAE_TUNE_GROUP_BIG_TILES    (384) cdae_linear_wgrad_group runs 128 x 128 tiles when the members together have at least this many of them,
- *                                      else 64 x 64 tiles (at least 192 of those, or one launch per member) */
+ *                                      else 64 x 64 tiles (at least 192 of those, or one launch per member)
+ *   CDAE_TUNE_CONVWIN_NJ2        (0)   256 x 64 tiles of the forward window kernel (Cout % 64 == 0, unsplit K): 0 = where 256 x 128 tiles fill less
+ *                                      than 0.6 of the block slots and the narrow ones clearly more (small-batch sampling at 64 x 64 / 32 x 32),
+ *                                      1 = wherever they apply (tests), -1 = never */
 enum { CDAE_TUNE_CONVWIN_MIN_TILES = 0, CDAE_TUNE_CONVWIN_SPLITK = 1, CDAE_TUNE_CONVWIN_NJ3 = 2, CDAE_TUNE_HEAD_MFMA = 3, CDAE_TUNE_ROWS16_MIN_M = 4,
-       CDAE_TUNE_ROWS16_RING = 5, CDAE_TUNE_CONVWIN_PAIR16 = 6, CDAE_TUNE_GN_BWD_FOLD2 = 7, CDAE_TUNE_GROUP_BIG_TILES = 8 };
+       CDAE_TUNE_ROWS16_RING = 5, CDAE_TUNE_CONVWIN_PAIR16 = 6, CDAE_TUNE_GN_BWD_FOLD2 = 7, CDAE_TUNE_GROUP_BIG_TILES = 8, CDAE_TUNE_CONVWIN_NJ2 = 9 };
 int cdae_tune_set(int key, int value);
 int cdae_tune_get(int key);       /* -1: unknown key */
 

@@ -757,6 +757,45 @@ def test_window_conv_96_column_tiles(seed, expect_kernels):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1])
+def test_window_conv_64_column_tiles(seed, expect_kernels):
+    """convwin_kernel<f16, 9, pairs, NJ = 2>: 256 x 64 tiles (round 6: the dispatcher picks them where 256 x 128 tiles leave more than 0.4 of the
+    block slots empty — small-batch sampling at 64 x 64 / 32 x 32).  Forced here (cdae_tune_set CONVWIN_NJ2 = 1) onto small cases with
+    Cout in {64 .. 384}: against F.conv2d in fp64, bit-identical to the 128-column instantiation, with residual, partial row tiles, Cout not a
+    multiple of 128, and the epilogue's GroupNorm partial sums equal to those of the 128-column kernel."""
+    import random
+    from causaldiffae_amd import ops
+    from causaldiffae_amd._lib import tune_scope, range_check
+    rng = random.Random(700 + seed)
+    g = torch.Generator(device="cuda:0").manual_seed(191 + seed)
+    for case in range(6):
+        S = rng.choice([8, 16, 32])
+        N = rng.randint(1, 6 if S >= 32 else 24)
+        ci, co = 32 * rng.randint(1, 8), 64 * rng.randint(1, 6)
+        res = rng.random() < 0.5
+        stats = case % 2 == 0 and (S * S) % 32 == 0
+        x = ops.to_nhwc(torch.randn(N, ci, S, S, device="cuda:0", generator=g))
+        w = (torch.randn(co, ci, 3, 3, device="cuda:0", generator=g) / (9 * ci) ** 0.5).contiguous(memory_format=torch.channels_last)
+        b = torch.randn(co, device="cuda:0", generator=g)
+        r = ops.to_nhwc(torch.randn(N, co, S, S, device="cuda:0", generator=g)) if res else None
+        xs = _split_nhwc(x)
+        with torch.no_grad(), tune_scope(convwin_min_tiles=1, convwin_splitk=0, convwin_nj3=-1):
+            with tune_scope(convwin_nj2=1), expect_kernels(convwin=1):
+                y2 = ops.conv3x3_ps(xs, w, b, res=r, gn_stats=stats)
+            with tune_scope(convwin_nj2=-1), expect_kernels(convwin=1):
+                y4 = ops.conv3x3_ps(xs, w, b, res=r, gn_stats=stats)
+        exact = F.conv2d(x.double().contiguous(), w.double(), b.double(), padding=1)
+        if res:
+            exact = exact + r.double()
+        e = (y2.double() - exact).abs().max().item() / max(1.0, exact.abs().max().item())
+        assert torch.isfinite(y2).all() and e < 2e-5, ((N, ci, co, S, res), e)
+        assert torch.equal(y2, y4), (N, ci, co, S, res)
+        if stats and hasattr(y4, "_gnparts"):
+            assert hasattr(y2, "_gnparts") and torch.equal(y2._gnparts, y4._gnparts)
+    range_check("64-column tiles")
+
+
+@pytest.mark.gpu
 def test_groupnorm_sums_with_a_partial_last_row_tile():
     """Epilogue GroupNorm sums when M % 256 != 0 (batch 130 at 8 x 8: 32.5 row tiles of 256; round-3 advisor finding: the last tile's
     chunks beyond M used to be written past the end of the [M / 32] buffer).  A canary row behind the buffer must stay untouched, and
