@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from causaldiffae_amd import ops
 from causaldiffae_amd._lib import check, lib, ptr, stream
-B = 128
+B = int(os.environ.get("BATCH", "128"))          # BATCH=16: the reference evaluation script's batch
 # (Cin, Cout, res, count per DDIM step) — reference unet.py:386-470 with channel_mult (1,2,3,4), 2 res blocks, P64
 SHAPES = [(128, 128, 64, 7), (256, 128, 64, 2), (384, 128, 64, 1),
           (128, 256, 32, 1), (256, 256, 32, 6), (384, 256, 32, 1), (512, 256, 32, 1), (640, 256, 32, 1),
