@@ -242,9 +242,9 @@ def test_window_conv_k_loop_has_no_compiler_drain():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     kernels = [r for r in mod.lint("convwin") if "convwin_kernel" in r["kernel"]]
-    # <f16 | bf16, 9 taps> x <plane pairs | one plane>, <f16 | bf16, 4 taps, pairs>, the 96-column tile <f16, 9, pairs, 3>, and the 16-bit
+    # <f16 | bf16, 9 taps> x <plane pairs | one plane>, <f16 | bf16, 4 taps, pairs>, the 96- and 64-column tiles <f16, 9, pairs, 3 | 2>, and the 16-bit
     # torso's <bf16, 9, one plane, bf16 rows out> and <bf16, 9, channel halves in the two plane slots, bf16 rows out> (PAIR: two MFMAs per product pair)
-    assert len(kernels) == 9
+    assert len(kernels) == 10
     for r in kernels:
         assert r["loops"], r["kernel"]
         args = [a.strip() for a in r["kernel"].split("convwin_kernel<")[1].split(">")[0].split(",")]      # BF, taps, planes, column tiles per wave, IO16, PAIR
