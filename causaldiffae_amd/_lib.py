@@ -146,6 +146,7 @@ SIGNATURES = {
     "cdae_linear_fwd_io": [P, L, P, L, P, P, P, P, L, I, I, I, I, P, SZ, P],
     "cdae_linear_dgrad_io": [P, L, P, L, P, L, I, I, I, I, P, SZ, P],
     "cdae_linear_wgrad_group": [P, I, P, SZ, P],
+    "cdae_linear_wgrad_group_io": [P, I, I, P, SZ, P],
     "cdae_linear_wgrad_io": [P, L, P, L, P, L, P, I, I, I, I, I, P, SZ, P],
     "cdae_gn_stats16": [P, I, P, I, I, I, I, I, I, F, P, P, P, P, P, I, P, P, P],
     "cdae_gn_apply16": [P, I, P, I, I, P, I, I, I, I, I, P, P, P, P, P, I, I, P],

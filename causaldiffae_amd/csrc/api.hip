@@ -402,22 +402,31 @@ int cdae_linear_wgrad(const float* x, long ldx, const float* dy, long lddy, floa
 // n linear / 1x1-conv weight gradients in ONE launch where together they fill the chip unsplit (igemm.hip cdae_gemm_group_dispatch);
 // else, and for members the grouped loaders do not take, one launch each exactly as cdae_linear_wgrad.  Members with a bias gradient
 // must accumulate (the fused column sums add into dbias; the trainer's flat gradient buffer is zeroed once per step).
-int cdae_linear_wgrad_group(const cdae_lw_item* items, int n, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+static int lw_one(const cdae_lw_item& it, int io, float* ws, size_t wsb, void* stream) {
+    return io ? cdae_linear_wgrad_io(it.x, it.ldx, it.dy, it.lddy, it.dw, it.lddw, it.dbias, it.M, it.N, it.K, io, it.accumulate, ws, wsb, stream)
+              : cdae_linear_wgrad(it.x, it.ldx, it.dy, it.lddy, it.dw, it.lddw, it.dbias, it.M, it.N, it.K, it.accumulate, ws, wsb, stream);
+}
+
+// io = 0: fp32 rows (cdae_linear_wgrad_group); io = 12: both operands bf16 rows (the 16-bit torso) — members the streaming kernel takes
+// (wg16.hip: >= 4096 rows, channel counts that are multiples of 128) keep their own launch, the others are grouped
+int cdae_linear_wgrad_group_io(const cdae_lw_item* items, int n, int io, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
     if (n <= 0) return 0;
     if (!items) return cdae_fail("linear_wgrad_group: null items");
-    int i0 = 0;
-    while (i0 < n) {
-        const int cnt = n - i0 < GEMM_GROUP_MAX ? n - i0 : GEMM_GROUP_MAX;
+    if (io != 0 && (io & 12) != 12) return cdae_fail("linear_wgrad_group_io: io = 0 (fp32 rows) or 12 (bf16 rows of both operands)");
+    cdae_lw_item rest[GEMM_GROUP_MAX];
+    int nr = 0;
+    auto flush = [&]() -> int {
         int rc = 1;
-        if (cnt >= 2) {
+        if (nr >= 2) {
             GemmGroupArg g;
             memset(&g, 0, sizeof(g));
             g.common = base_params();
             g.common.amode = A_PLAIN_MC; g.common.bmode = B_PLAIN_MC; g.common.grad_operand = 1;
-            g.n = cnt;
+            if (io) { g.common.prec = 4; g.common.io16 = io & 12; }
+            g.n = nr;
             bool ok = true;
-            for (int i = 0; i < cnt; ++i) {
-                const cdae_lw_item& it = items[i0 + i];
+            for (int i = 0; i < nr; ++i) {
+                const cdae_lw_item& it = rest[i];
                 ok = ok && (it.accumulate || !it.dbias) && it.dw && it.x && it.dy;
                 g.items[i] = GemmGroupItem{it.dy, it.x, it.dw, it.dbias, it.N, it.K, it.M, it.accumulate, it.lddy, it.ldx, it.lddw};
             }
@@ -425,13 +434,25 @@ int cdae_linear_wgrad_group(const cdae_lw_item* items, int n, float* splitk_ws, 
             if (rc < 0) return rc;
         }
         if (rc == 1)
-            for (int i = 0; i < cnt; ++i) {
-                const cdae_lw_item& it = items[i0 + i];
-                if (cdae_linear_wgrad(it.x, it.ldx, it.dy, it.lddy, it.dw, it.lddw, it.dbias, it.M, it.N, it.K, it.accumulate, splitk_ws, splitk_ws_bytes, stream)) return -1;
-            }
-        i0 += cnt;
+            for (int i = 0; i < nr; ++i)
+                if (lw_one(rest[i], io, splitk_ws, splitk_ws_bytes, stream)) return -1;
+        nr = 0;
+        return 0;
+    };
+    for (int i = 0; i < n; ++i) {
+        const cdae_lw_item& it = items[i];
+        if (io && splitk_ws && cdae_wg16_ok(it.x, it.ldx, it.dy, it.lddy, it.dw, it.lddw, it.M, it.N, it.K, io, splitk_ws_bytes)) {
+            if (lw_one(it, io, splitk_ws, splitk_ws_bytes, stream)) return -1;          // the HBM-stream kernel
+            continue;
+        }
+        rest[nr++] = it;
+        if (nr == GEMM_GROUP_MAX && flush()) return -1;
     }
-    return 0;
+    return flush();
+}
+
+int cdae_linear_wgrad_group(const cdae_lw_item* items, int n, float* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    return cdae_linear_wgrad_group_io(items, n, 0, splitk_ws, splitk_ws_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------

@@ -998,17 +998,18 @@ int cdae_gemm_group_dispatch(GemmGroupArg& g, void* stream) {
         const int mode = cdae_get_default_precision();
         c.prec = mode == CDAE_PREC_FP32 ? 0 : mode == CDAE_PREC_MIXED16 ? (c.grad_operand ? 4 : 3) : (c.grad_operand ? 2 : 1);
     }
-    if (c.prec != 0 && c.prec != 2) return 1;
+    const bool rows16 = c.prec == 4 && (c.io16 & 12) == 12;       // the 16-bit torso: both operands are bf16 rows (8-byte vector loads)
+    if (c.prec != 0 && c.prec != 2 && !rows16) return 1;
     long tiles_big = 0, tiles_small = 0;
     double flops = 0, bytes = 0;
     for (int i = 0; i < g.n; ++i) {
         const GemmGroupItem& it = g.items[i];
         if (it.M <= 0 || it.N <= 0 || it.K <= 0 || it.M % 4 || it.N % 4 || it.lda % 4 || it.ldb % 4 ||
-            (reinterpret_cast<size_t>(it.A) & 15) || (reinterpret_cast<size_t>(it.B) & 15)) return 1;      // the vector k-major loaders
+            (reinterpret_cast<size_t>(it.A) & (rows16 ? 7 : 15)) || (reinterpret_cast<size_t>(it.B) & (rows16 ? 7 : 15))) return 1;      // the vector k-major loaders
         tiles_big += (long)((it.M + 127) / 128) * ((it.N + 127) / 128);
         tiles_small += (long)((it.M + 63) / 64) * ((it.N + 63) / 64);
         flops += 2.0 * it.M * it.N * (double)it.K;
-        bytes += 4.0 * ((double)it.M * it.K + (double)it.N * it.K + (double)it.M * it.N);
+        bytes += (rows16 ? 2.0 : 4.0) * ((double)it.M * it.K + (double)it.N * it.K) + 4.0 * (double)it.M * it.N;
     }
     static const int cfg_small = CDAE_DEV_INT("CDAE_GROUP_SMALL_TILES", 192);
     const bool big = tiles_big >= cdae_tune(TUNE_GROUP_BIG_TILES);
@@ -1025,7 +1026,8 @@ int cdae_gemm_group_dispatch(GemmGroupArg& g, void* stream) {
         cdae_prof_tag(tag);
     }
     int rc;
-    if (c.prec == 2) rc = big ? launch_group<128, 128, A_PLAIN_MC, B_PLAIN_MC, 4, 2, true>(g, st) : launch_group<64, 64, A_PLAIN_MC, B_PLAIN_MC, 2, 2, true>(g, st);
+    if (c.prec == 4) rc = big ? launch_group<128, 128, A_PLAIN_MC, B_PLAIN_MC, 4, 4, false>(g, st) : launch_group<64, 64, A_PLAIN_MC, B_PLAIN_MC, 2, 4, false>(g, st);
+    else if (c.prec == 2) rc = big ? launch_group<128, 128, A_PLAIN_MC, B_PLAIN_MC, 4, 2, true>(g, st) : launch_group<64, 64, A_PLAIN_MC, B_PLAIN_MC, 2, 2, true>(g, st);
     else rc = big ? launch_group<128, 128, A_PLAIN_MC, B_PLAIN_MC, 4, 0, false>(g, st) : launch_group<64, 64, A_PLAIN_MC, B_PLAIN_MC, 2, 0, false>(g, st);
     cdae_prof_end(PROF_IGEMM, st);
     return rc;

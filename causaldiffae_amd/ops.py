@@ -240,22 +240,23 @@ _LW_GROUP_ON = True        # path toggle: False = every linear weight gradient a
 _LW_PENDING = {}
 
 
-def linear_wgrad(dev, x, ldx, dy, lddy, dw_ptr, lddw, db_ptr, M, N, K, keep, hold=()):
+def linear_wgrad(dev, x, ldx, dy, lddy, dw_ptr, lddw, db_ptr, M, N, K, keep, hold=(), io=0):
     """dw[N][K] += dy^T x over the M rows, dbias += column sums of dy — straight into flat-gradient views (accumulating), deferred into the
-    level's group launch on the weight-gradient stream.  `keep`: tensors the launch reads (alive until it is issued); `hold`: see side_launch."""
+    level's group launch on the weight-gradient stream.  `keep`: tensors the launch reads (alive until it is issued); `hold`: see side_launch;
+    io = 12: x and dy are bf16 rows (the 16-bit torso, cdae_linear_wgrad_group_io)."""
     from ._lib import LwItem
     if hold and wgrad_side_stream_on():
         _side(dev)["held"].extend(t for t in hold if t is not None)
     item = LwItem(ptr(x), ptr(dy), dw_ptr, db_ptr, ldx, lddy, lddw, M, N, K, 1)
     if not _LW_GROUP_ON:
         def one(st_, ws_, wsb_, item=item):
-            check(lib.cdae_linear_wgrad_group(ctypes.byref(item), 1, ws_, wsb_, st_))
+            check(lib.cdae_linear_wgrad_group_io(ctypes.byref(item), 1, io, ws_, wsb_, st_))
         side_launch(dev, keep, one)
         return
     pend = _LW_PENDING.setdefault(dev.index, dict(key=None, items=[], keep=[], prec=None))
-    if pend["items"] and (pend["key"] != M or len(pend["items"]) >= 24):
+    if pend["items"] and (pend["key"] != (M, io) or len(pend["items"]) >= 24):
         _lw_flush(dev)
-    pend["key"], pend["prec"] = M, lib.cdae_get_default_precision()
+    pend["key"], pend["prec"] = (M, io), lib.cdae_get_default_precision()
     pend["items"].append(item)
     pend["keep"].extend(keep)
     _hook_backward_end(_side(dev) if wgrad_side_stream_on() else _WG_HOOK.setdefault(dev.index, dict(hooked=None)))
@@ -271,17 +272,17 @@ def _lw_flush(dev):
     pend = _LW_PENDING.get(dev.index)
     if not pend or not pend["items"]:
         return
-    items, keep, prec = pend["items"], tuple(pend["keep"]), pend["prec"]
+    items, keep, prec, io = pend["items"], tuple(pend["keep"]), pend["prec"], pend["key"][1]
     pend["items"], pend["keep"] = [], []
     from ._lib import LwItem
     arr = (LwItem * len(items))(*items)
 
-    def group(st_, ws_, wsb_, arr=arr, n=len(items), prec=prec):
+    def group(st_, ws_, wsb_, arr=arr, n=len(items), prec=prec, io=io):
         cur = lib.cdae_get_default_precision()          # the group runs in the mode its members were issued in
         if cur != prec:
             lib.cdae_set_default_precision(prec)
         try:
-            check(lib.cdae_linear_wgrad_group(arr, n, ws_, wsb_, st_))
+            check(lib.cdae_linear_wgrad_group_io(arr, n, io, ws_, wsb_, st_))
         finally:
             if cur != prec:
                 lib.cdae_set_default_precision(cur)

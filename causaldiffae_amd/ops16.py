@@ -130,6 +130,11 @@ def w16(w):
     return c[2].data_ptr()
 
 
+def _lw16_ok(x, dy, ldx, lddy):
+    """operands the grouped weight-gradient launch takes on bf16 rows (else the member keeps its own launch)"""
+    return (ops._LW_GROUP_ON and x.dtype == BF16 and dy.dtype == BF16 and ldx % 4 == 0 and lddy % 4 == 0 and x.data_ptr() % 8 == 0 and dy.data_ptr() % 8 == 0)
+
+
 def wt16(w):
     """Device pointer of the bf16 W^T [K][N] of a dense weight [N][K] (the hi plane of ops.wt_planes)"""
     return ops.wt_planes(w).data_ptr()
@@ -370,7 +375,13 @@ class _ResBlock16(Function):
                 check(lib.cdae_linear_wgrad_io(ptr(x), C1, ptr(dout), Cout, ptr(dsw), C, ptr(dsb), M, Cout, C1, 12, acc, ws_, wsb_, st_))
                 if x2 is not None:
                     check(lib.cdae_linear_wgrad_io(ptr(x2), C - C1, ptr(dout), Cout, dsw.data_ptr() + 4 * C1, C, None, M, Cout, C - C1, 12, acc, ws_, wsb_, st_))
-            if direct:
+            if direct and _lw16_ok(x, dout, C1, Cout) and (x2 is None or (_lw16_ok(x2, dout, C - C1, Cout) and C1 % 4 == 0)):
+                ops.linear_wgrad(dev, x, C1, dout, Cout, ptr(dsw), C, ptr(dsb), M, Cout, C1, (x, dout), io=12)
+                if x2 is not None:
+                    ops.linear_wgrad(dev, x2, C - C1, dout, Cout, dsw.data_ptr() + 4 * C1, C, None, M, Cout, C - C1, (x2, dout), io=12)
+                dsw = dsb = None
+                ops._done(rsw, rsb if has_sb else None)
+            elif direct:
                 ops.side_launch(dev, (x, x2, dout), wg)
                 dsw = dsb = None
                 ops._done(rsw, rsb if has_sb else None)
@@ -583,6 +594,10 @@ class _AttnBlock16(Function):
 
             def wg(st_, ws_, wsb_, dw=dw, db=db):
                 check(lib.cdae_linear_wgrad_io(ptr(x_t), ldx, ptr(dy_t), lddy, ptr(dw), K, ptr(db), M, Nw, K, io, 1 if direct else 0, ws_, wsb_, st_))
+            if direct and io == 12 and _lw16_ok(x_t, dy_t, ldx, lddy) and K % 4 == 0 and Nw % 4 == 0:
+                ops.linear_wgrad(dev, x_t, ldx, dy_t, lddy, ptr(dw), K, ptr(db), M, Nw, K, (x_t, dy_t), io=12)
+                ops._done(rw, rb if has_b else None)
+                return None, None
             if direct:
                 ops.side_launch(dev, (x_t, dy_t), wg)
                 ops._done(rw, rb if has_b else None)

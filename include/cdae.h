@@ -343,6 +343,9 @@ typedef struct cdae_lw_item {
    ONE unsplit launch where together they fill the chip (each alone has 9 - 48 tiles and would split its rows 8 - 26 ways into slabs + a
    finish launch); otherwise one launch each.  Members with dbias must have accumulate = 1. */
 int cdae_linear_wgrad_group(const cdae_lw_item* items, int n, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
+/* the same for the 16-bit torso: io = 12 — x and dy of every member are bf16 rows (the pointers of cdae_lw_item are reinterpreted, pitches in
+   elements); members the streaming kernel takes (cdae_linear_wgrad_io's wg16 form) keep their own launch, the rest go out together.  io = 0: as above. */
+int cdae_linear_wgrad_group_io(const cdae_lw_item* items, int n, int io, float* splitk_ws, size_t splitk_ws_bytes, void* stream);
 int cdae_colsum(const float* x, long ldx, float* out, long rows, int cols, int accumulate, void* stream);
 
 /* QKVAttention (unet.py:239-253) on the NHWC output of the qkv 1x1 conv: qkv[B][T][heads*3*ch] with the

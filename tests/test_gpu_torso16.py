@@ -259,6 +259,43 @@ def test_full_model_step_on_the_16bit_torso_matches_fp32_storage(arch):
         assert max(w[0] for w in worst) < BAR[arch][0] and min(w[1] for w in worst) > BAR[arch][1], (torso, sorted(worst)[-3:], sorted(worst, key=lambda w: w[1])[:3])
 
 
+@pytest.mark.parametrize("shapes,rows,launches", [
+    ([(512, 512)] * 9 + [(1536, 512)] * 5, 512, 1),          # the 8 x 8 level of a C64 batch-32 step: short rows, one grouped launch
+    ([(384, 384)] * 3 + [(256, 128)] * 2, 8192, 5),          # long rows with 128-multiples: every member on the streaming kernel (wg16), one launch each
+    ([(384, 380), (380, 384)] * 4 + [(128, 128)], 1024, 1),   # ragged edges, grouped
+])
+def test_linear_wgrad_group_on_bf16_rows(mixed16, shapes, rows, launches):
+    """cdae_linear_wgrad_group_io(io = 12): the 16-bit torso's 1 x 1 / linear weight gradients of a level from bf16 rows — grouped into one
+    unsplit launch where the rows are too short for the streaming kernel, one wg16 launch each where it applies — accumulating into
+    buffers that hold values, against float64 of the same bf16-rounded operands."""
+    import ctypes
+    from causaldiffae_amd import _lib
+    from causaldiffae_amd._lib import LwItem, check, lib, ptr, splitk_ws, stream, SPLITK_BYTES
+    dev = torch.device(DEV)
+    g = torch.Generator().manual_seed(len(shapes) + rows)
+    items, keep, want = [], [], []
+    for i, (N, K) in enumerate(shapes):
+        x = torch.randn(rows, K, generator=g).to(torch.bfloat16)
+        dy = (torch.randn(rows, N, generator=g) * (0.5 + i % 3)).to(torch.bfloat16)
+        dw0, db0 = torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+        has_b = i % 2 == 0
+        xd, dyd, dwd, dbd = x.to(dev), dy.to(dev), dw0.to(dev), db0.to(dev)
+        keep.append((xd, dyd, dwd, dbd))
+        items.append(LwItem(ptr(xd), ptr(dyd), ptr(dwd), ptr(dbd) if has_b else None, K, N, K, rows, N, K, 1))
+        want.append((dw0.double() + dy.double().t() @ x.double(), db0.double() + (dy.double().sum(0) if has_b else 0.0)))
+    arr = (LwItem * len(items))(*items)
+    ws = splitk_ws(dev)
+    torch.cuda.synchronize()
+    _lib.prof_enable(True)
+    _lib.prof_read()
+    check(lib.cdae_linear_wgrad_group_io(arr, len(items), 12, ptr(ws), SPLITK_BYTES, stream()))
+    got = _lib.prof_read()["igemm"]["launches"]
+    _lib.prof_enable(False)
+    assert got == launches, got
+    for (xd, dyd, dwd, dbd), (dw, db) in zip(keep, want):
+        assert _rel(dwd, dw) < 2e-5 and _rel(dbd, db) < 2e-5, (tuple(dwd.shape), _rel(dwd, dw), _rel(dbd, db))
+
+
 @pytest.mark.parametrize("odd", [170, 102, 5])
 def test_torso_training_with_odd_sized_parameters(odd):
     """A parameter whose element count is not a multiple of 8 in FRONT of the 1 x 1 weights (the round-5 advisor's case: n_vars = 3 / 5 would give
