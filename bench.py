@@ -224,20 +224,23 @@ def train_bench(dev, world, rank, steps, warmup, batch, regions=1, image_size=64
         _ops.side_join()
         _ops._WGRAD_SIDE_ON = False
         try:
+            for _ in range(5):             # (the other policy's tensor lifetimes: let the caching allocator settle first)
+                b, c = next(data)
+                loop.forward_backward(b, c)
+                loop.optimize_normal()
+            k8, runs = max(10, min(steps, 20)), []
             for _ in range(3):
-                b, c = next(data)
-                loop.forward_backward(b, c)
-                loop.optimize_normal()
-            sync()
-            k8 = max(10, min(steps, 20))
-            t0, c0 = time.perf_counter(), time.process_time()
-            for _ in range(k8):
-                b, c = next(data)
-                loop.forward_backward(b, c)
-                loop.optimize_normal()
-            sync()
-            dt8, cpu8 = (time.perf_counter() - t0) / k8, (time.process_time() - c0) / k8
-            w8 = {"value": 1.0 / dt8, "ms_per_step": 1e3 * dt8, "host_cpu_ms_per_step": 1e3 * cpu8, "host_cpu_over_step": cpu8 / dt8, "wgrad_side_stream": False, "steps": k8}
+                sync()
+                t0, c0 = time.perf_counter(), time.process_time()
+                for _ in range(k8):
+                    b, c = next(data)
+                    loop.forward_backward(b, c)
+                    loop.optimize_normal()
+                sync()
+                runs.append(((time.perf_counter() - t0) / k8, (time.process_time() - c0) / k8))
+            dt8, cpu8 = sorted(runs)[1]        # the median region
+            w8 = {"value": 1.0 / dt8, "ms_per_step": 1e3 * dt8, "host_cpu_ms_per_step": 1e3 * cpu8, "host_cpu_over_step": cpu8 / dt8, "wgrad_side_stream": False,
+                  "steps": k8, "regions": 3}
         finally:
             _ops._WGRAD_SIDE_ON = True
     # kernel-family milliseconds of one step (HIP events around every launch of the library, outside the timed regions): where the step goes
