@@ -14,7 +14,8 @@ bench.randomize(model, 4321)
 model.to(dev).train()
 data = load_data(data_dir="synthetic", batch_size=32, image_size=64, in_channels=3, n_vars=4, seed=0, device=dev)
 loop = TrainLoop(model=model, diffusion=diff, data=data, batch_size=32, microbatch=-1, lr=1e-4, ema_rate="0.9999", log_interval=10 ** 9,
-                 save_interval=10 ** 9, resume_checkpoint="", rep_cond=True, n_vars=4, causal_modeling=True, in_channels=3)
+                 save_interval=10 ** 9, resume_checkpoint="", rep_cond=True, n_vars=4, causal_modeling=True, in_channels=3,
+                 use_fp16=os.environ.get("FP16") == "1")          # FP16=1: the 16-bit torso
 diff.kl_weight = 0.1
 def steps(n):
     for _ in range(n):
