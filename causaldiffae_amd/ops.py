@@ -85,8 +85,18 @@ def _f32c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+_SK_CACHE = {}
+
+
 def _sk(dev):
-    return ptr(splitk_ws(dev)), SPLITK_BYTES
+    """(pointer, bytes) of the device's split-K workspace for the current scratch lane — memoised: ~400 asks per training step, and the buffer
+    (sized once for every layer: `SPLITK_BYTES`) never moves"""
+    from ._lib import _WS_LANE
+    key = (dev.index, _WS_LANE[0])
+    hit = _SK_CACHE.get(key)
+    if hit is None:
+        hit = _SK_CACHE[key] = (ptr(splitk_ws(dev)), SPLITK_BYTES)
+    return hit
 
 
 def _sink(t):
