@@ -48,6 +48,8 @@ __device__ __forceinline__ void store_planes_cw(const GemmParams& p, long addr, 
     p.C_lo[addr] = __builtin_bit_cast(unsigned short, l);
 }
 
+__device__ __attribute__((aligned(64))) unsigned g_zero_cw[16] = {0u};      // a zero line: the bias / residual of launches that have none
+
 constexpr int CW_BM = 256, CW_BN = 128;
 constexpr int CW_A_PLANE = 12288, CW_A_HALF = 2 * CW_A_PLANE;               // 384 rows x 32 B
 constexpr int CW_B_BASE = 2 * CW_A_HALF, CW_B_KH = 4096, CW_B_PLANE = 2 * CW_B_KH, CW_B_STAGE = 2 * CW_B_PLANE;
@@ -74,6 +76,15 @@ __device__ __forceinline__ void cw_dma(const void* sbase, int soff, unsigned vof
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane((int)lds_dst)), "v"(voff), "s"(base) : "memory", "m0");
 }
 
+// sum of a value over the 16 lanes of its DPP row (lanes 16 k .. 16 k + 15), left in every lane: quad butterfly, then half-row and row mirrors
+__device__ __forceinline__ float cw_row16_sum(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true));      // quad_perm [1, 0, 3, 2]
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true));      // quad_perm [2, 3, 0, 1]
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, true));     // row_half_mirror
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, true));     // row_mirror
+    return x;
+}
+
 // NT = 9: the 3x3 window.  NT = 4: the 2x2 window of one sub-pixel phase (ph_y, ph_x) of nearest-2x-upsample + conv3x3 (tap t reads window
 // position (t / 2 + ph_y, t % 2 + ph_x) of the same 3x3 neighbourhood; weights [rows][4][K]; result scattered to (2y + ph_y, 2x + ph_x)).
 // NPL = 2: hi / lo plane pairs, three MFMAs per product (the fp32-parity modes).  NPL = 1: ONE plane per operand and one MFMA per product —
@@ -86,10 +97,19 @@ __device__ __forceinline__ void cw_dma(const void* sbase, int soff, unsigned vof
 // PAIR (NPL = 2, the 16-bit torso): the two plane slots carry the FIRST and the SECOND HALF of the input channels of a one-plane operand
 // (the launch points A_lo / Bk_lo half the channels further and halves Cin): two MFMAs per product pair — hi.hi + lo.lo — for the fragment
 // reads, barrier and DMAs of one K step, i.e. half the K steps of the NPL = 1 form, whose step is bound by exactly those fixed costs.
+// IO16 instantiations are CHANNEL-MAJOR (round 6): the weight fragment sits in the MFMA's first operand, so a lane's accumulator registers are
+// four consecutive output CHANNELS of one pixel, and with the weight rows permuted inside each 64-row group at DMA time (LDS row 16 j + l holds
+// channel 16 (l >> 2) + 4 j + (l & 3): the fragment reads keep their conflict-free addresses) a lane owns 16 consecutive channels of a pixel per
+// 16-row tile — the bf16 result and the residual move as two 16-byte pieces per lane and tile row instead of 16 two-byte ones (the row-major
+// epilogue was 17 us of a 101 us conv without and 47 of 131 us with a residual: 128 -> 128 at 32 x 32, batch 256).  The GroupNorm partial sums
+// then need the 16 lanes of a DPP row added up (cw_row16_sum).  (On fp32 rows this form lost in round 3 — the residual's tag look-ups; fp32
+// stores are dwords either way — and stays row-major.)
 template <bool BF, int NT, int NPL = 2, int NJ = 4, bool IO16 = false, bool PAIR = false>
 __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, const int ntiles) {
     typedef const unsigned short* hp;
     constexpr int BN = 32 * NJ, WNC = 16 * NJ;                         // n-tile width, columns per wave
+    constexpr bool SWAP = IO16;
+    static_assert(!IO16 || NJ == 4, "bf16-row instantiations: 64 channels per wave");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -143,7 +163,11 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
             const int pix = min(max(pix0 + (wave + 4 * q) * 32 + (lane_s >> 1), 0), p.M - 1);
             aoffb[q] = (p.a_gm ? (unsigned)pix * 32u : (unsigned)pix * (unsigned)p.sx * 2u) + (lane_s & 1) * 16u;
         }
-        const int wrow = min(n0 + wave * 32 + (lane_s >> 1), p.N - 1);
+        int wr_ = wave * 32 + (lane_s >> 1);                          // LDS row of the 128-row weight stage this lane fetches
+        // ... holds this channel.  (K-split launches keep the natural order: their fp32 slab pieces — register j = channels 16 j + 4 kg .. + 3 —
+        //  then lie 64 bytes contiguous per row and store instruction; permuted, the pieces of a row are 64 bytes apart: measured +17 % on those convs)
+        if constexpr (SWAP) { if (p.ksplit == 1) { const int l_ = wr_ & 15, j_ = (wr_ >> 4) & 3; wr_ = (wr_ & 64) + 16 * (l_ >> 2) + 4 * j_ + (l_ & 3); } }
+        const int wrow = min(n0 + wr_, p.N - 1);
         woffb = packed ? (unsigned)wrow * 32u + (lane_s & 1) * 16u : (unsigned)wrow * (unsigned)p.ldb * 2u + (lane_s & 1) * 16u;
         if (NT == 4 && p.nphase > 1) woffb += (unsigned)cph * (unsigned)p.phase_w * 2u;
 #pragma unroll
@@ -205,7 +229,9 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto mma = [&](const u32x4& x, const u32x4& y, const f32x4& c) -> f32x4 {
+    auto mma = [&](const u32x4& x_, const u32x4& y_, const f32x4& c) -> f32x4 {
+        const u32x4& x = SWAP ? y_ : x_;                               // (activation fragment, weight fragment): channel-major tiles take the weights first
+        const u32x4& y = SWAP ? x_ : y_;
         if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, x), __builtin_bit_cast(bf8, y), c, 0, 0, 0);
         else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, x), __builtin_bit_cast(half8, y), c, 0, 0, 0);
     };
@@ -388,6 +414,78 @@ __global__ __launch_bounds__(256, 2) void convwin_kernel(const GemmParams p, con
         asm volatile("" : "+v"(lr_), "+v"(kg_));
         const float alpha_ = p.w_scale ? p.alpha * p.w_scale[1] : p.alpha;      // the weight planes hold w * 2^k: the exact 2^-k rides on alpha
         if (dbg_ & 256) {}                                                // dev ablation: no epilogue
+        else if constexpr (SWAP) {
+            // channel-major tiles (bf16 rows; interior tiles only, cdae_convwin_ok): this lane holds pixel 16 i + lr of the wave's 128 rows and
+            // channels 16 kg .. 16 kg + 15 of its 64 (register j, element r <-> channel 4 j + r)
+            typedef __bf16 cw_bf8 __attribute__((ext_vector_type(8)));
+            const int colb = en0 + wn * WNC + 16 * kg_;
+            const long row_l = (long)(em0 + wm * 128 + lr_);
+            if (p.ksplit > 1) {
+                float* __restrict__ cb = p.splitk_ws + (long)eks * (long)p.M * p.N + row_l * p.N + en0 + wn * WNC + 4 * kg_;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x4*>(cb + (long)(16 * i) * p.N + 16 * j) = acc[i][j];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                // 32-bit byte offsets from the (scalar) base pointers: a tile's addresses cost one VALU add each instead of 64-bit pointer
+                // arithmetic per access (cdae_convwin_ok: M * ldc < 2^30 for these instantiations).  No branch around a memory operation: a missing
+                // bias / residual reads a zero line instead (an `if (p.res)` per row is a scalar branch per row with a full vmcnt drain at its join).
+                // Few values live beside the 128 accumulator registers: a row pair is finished eight channels at a time — its rounded results stay
+                // packed (8 registers) for the GroupNorm sums.
+                char* const cbase = reinterpret_cast<char*>(p.C);
+                const bool has_res = p.res != nullptr;
+                const char* const rbase = has_res ? reinterpret_cast<const char*>(p.res) : reinterpret_cast<const char*>(g_zero_cw);
+                const unsigned ldc2 = (unsigned)p.ldc * 2u;                                   // row pitch, bytes
+                const unsigned ob = ((unsigned)(em0 + wm * 128 + lr_) * (unsigned)p.ldc + (unsigned)colb) * 2u;
+                const unsigned rmask = has_res ? 0xffffffffu : 0u;                            // (no residual: every lane reads byte 0 of the zero line)
+                const float* __restrict__ bp = p.bias ? p.bias + colb : reinterpret_cast<const float*>(g_zero_cw);
+                const unsigned gb = (((unsigned)(em0 + wm * 128) >> 5) * (unsigned)p.N + (unsigned)colb) * 8u;      // byte offset of (chunk, channel) in gn_part
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) {
+                    float ssel = 0.f, qsel = 0.f;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {                        // channels 8 h .. 8 h + 7: accumulator registers j = 2 h, 2 h + 1
+                        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp + 8 * h), b1 = *reinterpret_cast<const f32x4*>(bp + 8 * h + 4);
+                        cw_bf8 ov[2];
+#pragma unroll
+                        for (int ii = 0; ii < 2; ++ii) {
+                            const unsigned ro = ob + (unsigned)(32 * i2 + 16 * ii) * ldc2 + 16u * h;
+                            const cw_bf8 rr = *reinterpret_cast<const cw_bf8*>(rbase + (ro & rmask));
+                            float fin = 0.f;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                float v = acc[2 * i2 + ii][2 * h + (e >> 2)][e & 3] * alpha_ + (e < 4 ? b0[e & 3] : b1[e & 3]) + (float)rr[e];
+                                const __bf16 h_ = (__bf16)v;
+                                ov[ii][e] = h_;
+                                fin += (float)h_;
+                            }
+                            *reinterpret_cast<cw_bf8*>(cbase + ro) = ov[ii];
+                            // (the branch per row also keeps hipcc's register allocation in check — see the row-major epilogue below; accumulated
+                            //  branch-free, the whole epilogue became one block with 299 spilled registers)
+                            if (!__builtin_isfinite(fin) && p.range_flag) *p.range_flag = 1;
+                        }
+                        if (p.gn_part) {
+                            // per (32-row chunk, channel): this lane's two rows, then the 16 lanes of the DPP row; every lane of the row ends with
+                            // every channel's sums and keeps those of channel lr
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float a0 = (float)ov[0][e], a1 = (float)ov[1][e];
+                                const float s_ = cw_row16_sum(a0 + a1), q_ = cw_row16_sum(a0 * a0 + a1 * a1);
+                                ssel = lr_ == 8 * h + e ? s_ : ssel;
+                                qsel = lr_ == 8 * h + e ? q_ : qsel;
+                            }
+                        }
+                    }
+                    if (p.gn_part) {                                     // ONE 8-byte store per lane and chunk (a row's 16 lanes: 128 contiguous bytes)
+                        typedef float cw_f2 __attribute__((ext_vector_type(2)));
+                        *reinterpret_cast<cw_f2*>(reinterpret_cast<char*>(p.gn_part) + (gb + (unsigned)i2 * (unsigned)p.N * 8u + (unsigned)lr_ * 8u)) = cw_f2{ssel, qsel};
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
         else if (interior && p.ksplit == 1 && !p.accumulate && !p.C_hi) {
             // the common case, kept lean (the general path below spends ~20 instructions per element on bounds and mode tests):
             // one row pointer per (tile, r), the four column tiles at immediate offsets
@@ -602,6 +700,9 @@ bool cdae_convwin_ok(const GemmParams& p) {
     // 16-bit rows (IO16 instantiation): interior tiles only — its edge path stores fp32 (a runtime choice of the element type there cost 350
     // spilled registers) — and both the result and the residual bf16
     if ((p.io16 & 3) && (p.M % CW_BM || p.N % CW_BN || p.prec != 4 || p.accumulate || p.C_hi || (p.io16 & 3) != ((p.res ? 2 : 0) | 1))) return false;
+    // (channel-major bf16 tiles: 16-byte pieces of the result / residual rows, float4 pieces of the GroupNorm sums and the split-K slabs)
+    if ((p.io16 & 3) && (p.ldc % 8 || (reinterpret_cast<size_t>(p.C) & 15) || (reinterpret_cast<size_t>(p.res) & 15) || (reinterpret_cast<size_t>(p.gn_part) & 15) ||
+                         (reinterpret_cast<size_t>(p.bias) & 15) || p.ps_taps == 4 || p.nphase > 1 || (long)p.M * p.ldc >= (1L << 30) || (long)p.M * p.N >= (1L << 31))) return false;
     if (p.ps_taps == 4 ? (p.out_mode != OUT_UP2 || (p.prec != 1 && p.prec != 2) || p.Bk_hi) : p.out_mode != OUT_ROWMAJOR) return false;      // (4 taps, bf16: the stride-2 conv's dgrad as sub-pixel phases)
     if (p.W != 8 && p.W != 16 && p.W != 32 && p.W != 64) return false;            // tight window: tiles start on image-row boundaries
     if (p.Cin % 32 || p.ldb % 8 || p.sx % 8) return false;

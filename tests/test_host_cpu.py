@@ -252,8 +252,8 @@ def test_window_conv_k_loop_has_no_compiler_drain():
         for lp in r["loops"]:
             assert lp["mfmas"] == want and lp["barriers"] == 1, (r["kernel"], lp)
             assert not lp["vmcnt_waits"] and not lp["scratch"], (r["kernel"], lp)
-        # (the bf16-row instantiation's epilogue exchanges values between lane pairs: a few more spilled values, all outside the K loop)
-        assert 0 <= r["vgpr_spills"] <= (24 if args[4] == "true" else 16), (r["kernel"], r["vgpr_spills"])
+        # (the bf16-row instantiations' channel-major epilogue was written against the allocator: 2 / 0 spilled values, outside the K loop)
+        assert 0 <= r["vgpr_spills"] <= (4 if args[4] == "true" else 16), (r["kernel"], r["vgpr_spills"])
 
 
 
