@@ -1569,8 +1569,12 @@ def test_rccl_data_parallel_path_with_one_rank():
     DDP + broadcast there)."""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "CDAE_DIST_BACKEND")}
+    import socket
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "CDAE_DIST_BACKEND")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        env["MASTER_PORT"] = str(sk.getsockname()[1])          # a free port, not a fixed one
     recs = {}
     for mode in ("plain", "rccl"):
         r = subprocess.run([sys.executable, os.path.join(root, "tests", "rccl1_worker.py"), mode], env=env, capture_output=True, text=True, timeout=600, cwd=root)
