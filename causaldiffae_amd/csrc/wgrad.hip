@@ -16,7 +16,7 @@
 // zero rows between them (served from a zero line), which makes the vertical padding and the image boundaries ordinary rows;
 // the horizontal padding (x-1 at x == 0, x+1 at x == W-1) is a mask on the activation fragments (element 0 / element 7 of a
 // lane's 8 pixels, because steps start on multiples of 64 and W divides 64).
-// Ring rows come in 16-row DMA blocks; a tap's 32 rows may start anywhere, so slots 0 and 1 are mirrored behind the last slot and
+// Ring rows come in 16-row DMA blocks; a tap's 32 rows may start anywhere, so slots 0, 1 and 2 are mirrored behind the last slot and
 // reads never wrap inside a fragment.  Split-K over the pixel range: each block writes its partial [Cout][9*Cin] slab, reduced in a
 // fixed order by wg_reduce_kernel (deterministic), or stores directly when one block covers all pixels.
 // The bias gradient (column sums of dy) rides along as extra MFMAs against a ones operand in one wave per K group of the blocks of
@@ -26,6 +26,12 @@
 #include <stdlib.h>
 #include "cdae_internal.h"
 #include "../../include/cdae.h"
+
+// WG_ABL (dev ablations, timing only — results are wrong): 1 no operand DMAs after the prologue, 2 no MFMAs, 4 no activation fragment reads
+// after tap 1, 8 no end-of-step wait / barrier, 32 ONE step per block (what a block costs outside its step loop)
+#ifndef WG_ABL
+#define WG_ABL 0
+#endif
 
 namespace {
 
@@ -44,6 +50,8 @@ struct WgParams {
     int steps, steps_per, ksplit, accumulate;
     int period, period_shift; unsigned period_magic;            // HW + G rows per image in the virtual stream
     int U0, RB;              // rows before image 0 (16 * halo blocks); ring size in 16-row blocks
+    int D;                   // prefetch distance in 64-pixel steps (1 or 2): dy has D + 1 stages, the ring holds D prefetch groups
+    int swz;                 // W >= 16: rows with bit 3 set keep their two 32-byte halves swapped in LDS (conflict-free transpose reads)
 };
 
 // A GROUP of weight gradients as one launch (round 5): at the 8 x 8 / 16 x 16 levels of a batch-32 step one conv has 36-128 (Cout, Cin) tiles for
@@ -59,7 +67,7 @@ __device__ __forceinline__ int fdiv(int n, unsigned magic, int shift) {
     return (int)((__umulhi((unsigned)n, magic) + (unsigned)n) >> shift);
 }
 
-// LDS image: activations [plane 2][channel half 2][(RB + 2) * 16 rows][64 B], dy [stage 2][plane 2][channel half 2][64 rows][64 B].
+// LDS image: activations [plane 2][channel half 2][(RB + 3) * 16 rows][64 B], dy [stage 2][plane 2][channel half 2][64 rows][64 B].
 // 8 waves = two K groups of 4 (pixels 0..31 / 32..63 of every 64-pixel step; two waves per SIMD that cover each other's LDS latency);
 // the second group's accumulators are added to the first's through LDS at the end.  A wave owns ALL 64 output channels x 16 input
 // channels, and its group's 32 pixels of a step are ONE 32-deep step of v_mfma_f32_16x16x32_bf16 (the shape that holds its clock under
@@ -67,23 +75,45 @@ __device__ __forceinline__ int fdiv(int n, unsigned magic, int shift) {
 // only its 16-channel activation fragment pair: 2.9 KB of LDS reads per tap and wave (a 32 x 32 wave tile on 32x32x16 MFMAs needs
 // 4.4 KB and kept the LDS pipe ~70 % busy beside the MFMAs: 5.02 -> 4.74 ms over the step's 47 wgrads).  The horizontal padding mask
 // sits on the tap's activation fragment (masked copies of the 8 dy fragments would not fit the registers).  A fragment spans 32 ring
-// rows, so slots 0 AND 1 are mirrored behind the ring.
-// NPL = 1 (the `mixed16` torso): one bf16 plane per operand, one MFMA per product; the lo sub-planes are neither staged nor read.
+// rows starting up to one row behind the ring's end, so slots 0, 1 AND 2 are mirrored behind the ring.
+// NPL = 1 (the `mixed16` torso): one bf16 plane per operand, one MFMA per product; the lo sub-planes do not exist in LDS (the image is
+// [NPL][half 2] sub-planes per operand), which is what pays for the deeper ring there.
+//
+// Round 6: (a) PREFETCH DISTANCE.  With one MFMA per product a step is ~0.5 us of matrix work per SIMD while a DMA issued at the top of the
+// step needs 1-2 us to land (L2 hit rate 0.52): the vmcnt(0) at the end of every step was the kernel (MFMA busy 0.35).  The operands of step
+// s + 2 are now requested at the top of step s (ring deeper by one prefetch group, dy in three stages) and the wait at the end of a step
+// is COUNTED: only the youngest group (>= 4 DMAs per issuing wave) may stay in flight.  D = 1 (the old schedule) where the LDS does not
+// hold the deeper ring (two planes at W = 64).
+// (b) BANK CONFLICTS.  ds_read_b64_tr_b16 is banked per 32-lane half over 256 bytes; a half reads rows r .. r + 3 and r + 8 .. r + 11 of a
+// 64-byte-pitch sub-plane, 32 bytes each: rows r and r + 8 are 512 bytes apart, i.e. on the same banks (2-way on every fragment read,
+// 1.65e9 conflict cycles per config [1] step).  Rows with bit 3 set now keep their two 32-byte halves SWAPPED — done by the DMA's
+// per-lane SOURCE pointer (the LDS side of an LDS-DMA is fixed at 16 bytes per lane), so a half-wave's eight 32-byte pieces cover all
+// 64 banks for every start row.  The read side pays no per-read arithmetic for it: bit 3 of a lane's row depends only on the tap's
+// horizontal shift (the vertical one is a multiple of 16 rows for W >= 16), so each lane keeps six offsets (3 kx x 2 reads).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int NPL = 2>
 __global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgGroup grp) {
     int di = 0;
     while (di + 1 < grp.nd && (int)blockIdx.x >= grp.start[di + 1]) ++di;           // (uniform: scalar compares on kernel arguments)
-    const WgParams& p = grp.d[di];
+    const WgParams& pd = grp.d[di];
+    // The descriptor is reached through a run-time index: left alone, hipcc re-loads its fields from the kernel-argument segment INSIDE the
+    // step loop (s_load_dword + s_waitcnt lgkmcnt(0) — which also drains the wave's LDS fragment reads; a dozen dependent round trips per
+    // step in the DMA-issuing waves: a third of the single-plane kernel's time, `WG_ABL=1`).  Every field a loop uses is copied once into
+    // a register the optimiser cannot re-derive.
+    struct { int N, HW, W, Cin, Cout, steps, period, U0, RB, D, swz; } p;
+#define WG_PIN(F) { int v_ = pd.F; asm volatile("" : "+s"(v_)); p.F = v_; }
+    WG_PIN(N) WG_PIN(HW) WG_PIN(W) WG_PIN(Cin) WG_PIN(Cout) WG_PIN(steps) WG_PIN(period) WG_PIN(U0) WG_PIN(RB) WG_PIN(D) WG_PIN(swz)
+#undef WG_PIN
     const unsigned gb0 = (unsigned)grp.start[di], gG = (unsigned)(grp.start[di + 1] - grp.start[di]);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* const lds = reinterpret_cast<char*>(smem);
-    const int RROWS = (p.RB + 2) * 16;                 // ring rows incl. the mirrors of slots 0 and 1
+    const int RROWS = (p.RB + 3) * 16;                 // ring rows incl. the mirrors of slots 0, 1 and 2
     const int A_SUB = RROWS * 64;                      // bytes per (plane, half) sub-plane
-    char* const dyb = lds + 4 * A_SUB;                 // dy stages
-    constexpr int D_SUB = 64 * 64, D_STAGE = 4 * D_SUB;
+    char* const dyb = lds + 2 * NPL * A_SUB;           // dy stages
+    constexpr int D_SUB = 64 * 64, D_STAGE = 2 * NPL * D_SUB;
+    const int NST = p.D + 1;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, k4 = lane >> 4;
     const int wn = wave & 3;                           // wave tile: input channels 16 wn .. + 15, all 64 output channels
     const int kg = wave >> 2;                          // K group: pixels 32 kg .. + 31 of every step
@@ -97,52 +127,81 @@ __global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgGroup grp) {
     const int cot = b % nco; b /= nco;
     const int ks = b;
     const int ci0 = cit * 64, co0 = cot * 64;
-    const int s_begin = ks * p.steps_per, s_end = min(p.steps, s_begin + p.steps_per);
+    const int s_begin = ks * pd.steps_per, s_end = min(p.steps, s_begin + pd.steps_per);
 
-    // ---- DMA roles: wave w stages sub-plane (P = w >> 1, half = w & 1); group 0 the activations, group 1 dy
-    const int dP = (wave >> 1) & 1, dH = wave & 1;
-    const bool dma_a = kg == 0 && (NPL == 2 || dP == 0), dma_d = kg == 1 && (NPL == 2 || dP == 0);
-    const unsigned short* const a_src = (dP ? p.a_lo : p.a_hi) + ci0 + dH * 32 + (lane & 3) * 8;
-    const unsigned short* const d_src = (dP ? p.d_lo : p.d_hi) + co0 + dH * 32 + (lane & 3) * 8;
-    char* const a_dst = lds + (dP * 2 + dH) * A_SUB;
-    auto dma = [&](const void* src, char* dst_wave_base) {
-        cdae_lds_dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst_wave_base - lds)));
+    // ---- DMA roles.  Two planes: wave w stages sub-plane (P = (w >> 1) & 1, half = w & 1), K group 0 the activations, group 1 dy.
+    // One plane: waves 0, 1 the activation halves, waves 6, 7 the dy halves — one issuing wave on every SIMD (waves w and w + 4 share one).
+    const int dH = wave & 1;
+    const int dP = NPL == 2 ? (wave >> 1) & 1 : 0;
+    const bool dma_a = kg == 0 && (NPL == 2 || (wave & 2) == 0), dma_d = kg == 1 && (NPL == 2 || (wave & 2) != 0);
+    // Addresses are formed on the SCALAR unit: a DMA reads from (64-bit scalar base) + (32-bit lane offset); the lane offset — row
+    // (lane >> 2) of the 16-row block, 16-byte chunk lane & 3 of the sub-plane's 64-byte row piece — never changes, the base walks.
+    // (lanes 32..63 fill rows 8..15 of the block: their chunk is the one of the other 32-byte half, see (b) above)
+    const int swz_a = (p.swz && (lane & 32)) ? 2 : 0, swz_d = (lane & 32) ? 2 : 0;
+    const unsigned a_voff = (unsigned)(((lane >> 2) * p.Cin + ci0 + dH * 32 + ((lane & 3) ^ swz_a) * 8) * 2);
+    const unsigned d_voff = (unsigned)(((lane >> 2) * p.Cout + co0 + dH * 32 + ((lane & 3) ^ swz_d) * 8) * 2);
+    unsigned v_zero = 0;
+    asm volatile("" : "+v"(v_zero));
+    const char* const a_base = reinterpret_cast<const char*>(dP ? pd.a_lo : pd.a_hi);
+    const char* const d_base = reinterpret_cast<const char*>(dP ? pd.d_lo : pd.d_hi);
+    const char* const zero_base = reinterpret_cast<const char*>(g_zero_wg);
+    const unsigned a_dst = (unsigned)((dP * 2 + dH) * A_SUB);
+    auto dma = [&](const char* sbase, unsigned voff, unsigned dst) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(sbase) : "memory", "m0");
     };
-    // U0, HW and the period are multiples of 16, so a 16-row block lies entirely inside one image or entirely in a gap: which one is
-    // decided on the scalar unit (the block index is uniform), and a lane only adds the block's offset to its own row pointer
-    const unsigned short* const a_lane = a_src + (long)(lane >> 2) * p.Cin;
-    const unsigned short* const d_lane = d_src + (long)(lane >> 2) * p.Cout;
-    auto issue_a = [&](int blk, int slot) {
-        const int v = __builtin_amdgcn_readfirstlane(blk * 16 - p.U0);
-        const int vv = v < 0 ? 0 : v;
-        const int img = fdiv(vv, p.period_magic, p.period_shift);
-        const int q = vv - img * p.period;
-        const bool ok = v >= 0 && q < p.HW && img < p.N;
-        const long off = ((long)img * p.HW + q) * p.Cin;
-        const void* src = ok ? (const void*)(a_lane + off) : (const void*)g_zero_wg;
-        dma(src, a_dst + slot * 1024);
-        if (slot < 2) dma(src, a_dst + (p.RB + slot) * 1024);
+    // The activation cursor: the next 16-row block of the virtual pixel stream is rows a_q .. a_q + 15 of image a_img's period (rows
+    // HW .. period - 1 are the zero gap; image -1 is the lead-in in front of image 0), a_off the element offset of the next REAL row
+    // (images are contiguous in memory, so it simply advances by 16 rows per real block).  U0, HW and the period are multiples of 16.
+    int a_img = 0, a_q = 0, a_off = 0;
+    auto issue_a = [&](int slot) {
+        const bool ok = (unsigned)a_img < (unsigned)p.N && a_q < p.HW;
+        const unsigned dst = a_dst + (unsigned)slot * 1024u;
+        if (ok) {
+            const char* const src = a_base + 2 * (long)a_off;
+            dma(src, a_voff, dst);
+            if (slot < 3) dma(src, a_voff, a_dst + (unsigned)(p.RB + slot) * 1024u);
+            a_off += 16 * p.Cin;
+        } else {
+            dma(zero_base, v_zero, dst);
+            if (slot < 3) dma(zero_base, v_zero, a_dst + (unsigned)(p.RB + slot) * 1024u);
+        }
+        a_q += 16;
+        if (a_q == p.period) { a_q = 0; ++a_img; }
     };
     auto issue_d = [&](int pix0, int stage) {
-        char* const dst = dyb + stage * D_STAGE + (dP * 2 + dH) * D_SUB;
+        const unsigned dst = (unsigned)((dyb - lds) + stage * D_STAGE + (dP * 2 + dH) * D_SUB);
+        const char* src = d_base + 2 * (long)pix0 * p.Cout;
+        const long pitch16 = 32L * p.Cout;
 #pragma unroll
-        for (int blk = 0; blk < 4; ++blk)
-            dma(d_lane + (long)(pix0 + blk * 16) * p.Cout, dst + blk * 1024);
+        for (int blk = 0; blk < 4; ++blk) { dma(src, d_voff, dst + blk * 1024u); src += pitch16; }
     };
 
     // ---- fragments: 16 channels x 32 pixels; lane (column l15, k block k4) gets pixels 8 k4 .. + 7 through two transpose reads 4 rows apart
     const int q4 = l15 >> 2, p4 = lane & 3;
     const int lane_off = (8 * k4 + q4) * 64 + 8 * p4;
+    // dy rows are 32 kg + 8 k4 + q4 (+ 4): bit 3 = k4 & 1 for both reads; the sub-tile's 32-byte half (c & 1) is the other one in those rows
+    const int dy_off[2] = {lane_off + (k4 & 1) * 32, lane_off + ((k4 & 1) ^ 1) * 32};
+    // activation rows are rt + 8 k4 + q4 (+ 4) with rt = 16 m + (kx - 1) (+ 8 (ky - 1) at W = 8: no swap there): per kx and read
+    int a_rd[3][2];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            const int L = 8 * k4 + q4 + 4 * rd;
+            const int sb = p.swz ? (((kx + 15 + L) & 15) >> 3) : 0;
+            a_rd[kx][rd] = (L + kx - 1) * 64 + 8 * p4 + (((wn & 1) ^ sb) * 32);      // (the tap's own +-1 row rides in the lane offset)
+        }
     auto trread = [&](const char* src) -> u32x2 {
         const fp16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(src));
         return __builtin_bit_cast(u32x2, v);
     };
-    auto frag = [&](const char* src) -> u32x4 {
-        const u32x2 a = trread(src), c = trread(src + 256);
+    auto frag2 = [&](const char* s0, const char* s1) -> u32x4 {
+        const u32x2 a = trread(s0), c = trread(s1);
         u32x4 r; r[0] = a[0]; r[1] = a[1]; r[2] = c[0]; r[3] = c[1];
         return r;
     };
     auto mma = [&](const u32x4& x, const u32x4& y, const f32x4& c) -> f32x4 {
+        if (WG_ABL & 2) { f32x4 r = c; r[0] += __builtin_bit_cast(float, x[0] ^ y[1]); return r; }
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, x), __builtin_bit_cast(bf8, y), c, 0, 0, 0);
     };
 
@@ -158,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgGroup grp) {
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int r = 0; r < 4; ++r) accb[c][r] = 0.f;
-    const bool do_colsum = p.colsum != nullptr && cit == 0 && wn == 0;
+    const bool do_colsum = pd.colsum != nullptr && cit == 0 && wn == 0;
     u32x4 ones; ones[0] = ones[1] = ones[2] = ones[3] = 0x3F803F80u;       // bf16 1.0 pairs
 
     // horizontal padding: this lane's 8 pixels start at x0 = (32 kg + 8 k4) mod W (steps start on multiples of 64 and W divides 64)
@@ -172,58 +231,87 @@ __global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgGroup grp) {
         int B0 = (img * p.period + q + p.U0) >> 4;
         int slot0 = 0;
         int next_blk = B0 - hb, next_slot = 0;
+        {   // the first block is virtual row img * period + q - U0: inside image img, or in the gap behind image img - 1 (q < U0)
+            const int qq = q - p.U0;
+            a_img = qq >= 0 ? img : img - 1;
+            a_q = qq >= 0 ? qq : qq + p.period;
+            a_off = (img * p.HW + (qq >= 0 ? qq : 0)) * p.Cin;
+        }
         auto load_upto = [&](int blk_end) {
-            for (; next_blk < blk_end; ++next_blk) {
-                if (dma_a) issue_a(next_blk, next_slot);
-                next_slot = next_slot + 1 == p.RB ? 0 : next_slot + 1;
+            if (dma_a) {
+                for (; next_blk < blk_end; ++next_blk) {
+                    issue_a(next_slot);
+                    next_slot = next_slot + 1 == p.RB ? 0 : next_slot + 1;
+                }
             }
         };
-        load_upto(B0 + 4 + hb);
-        if (dma_d) issue_d(s_begin * 64, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the prefetch cursor: step sP (image imgP, pixel qP) is the next one whose operands are requested, into dy stage stP
+        int sP = s_begin, imgP = img, qP = q, stP = 0;
+        auto prefetch_step = [&]() {
+            const int B0p = (imgP * p.period + qP + p.U0) >> 4;
+            load_upto(B0p + 4 + hb);
+            if (dma_d) issue_d(sP * 64, stP);
+            ++sP; qP += 64;
+            if (qP == p.HW) { qP = 0; ++imgP; }
+            stP = stP + 1 == NST ? 0 : stP + 1;
+        };
+        prefetch_step();
+        if (p.D == 2 && sP < s_end) {
+            prefetch_step();
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");           // (a group is >= 4 DMAs in every issuing wave: step s_begin has landed)
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();
 
         const int kg_s = __builtin_amdgcn_readfirstlane(kg);
-        for (int s = s_begin; s < s_end; ++s) {
-            const int st = (s - s_begin) & 1;
+        int st = 0;
+        for (int s = s_begin; s < ((WG_ABL & 32) ? s_begin + 1 : s_end); ++s) {
             int img_n = img, q_n = q + 64;
             if (q_n == p.HW) { q_n = 0; ++img_n; }
             const int B0n = (img_n * p.period + q_n + p.U0) >> 4;
-            if (s + 1 < s_end) {
-                load_upto(B0n + 4 + hb);
-                if (dma_d) issue_d((s + 1) * 64, st ^ 1);
-            }
+            const bool pre = sP < s_end && !(WG_ABL & 1);              // (uniform) a group younger than step s + 1's goes out now
+            if (pre) prefetch_step();
             // ---- compute: this K group's 32 pixels of step s
-            const char* const dy_hi = dyb + st * D_STAGE + kg_s * (32 * 64) + lane_off;
-            const char* const a_hi = lds + (wn >> 1) * A_SUB + (wn & 1) * 32 + lane_off;
+            const char* const dy_hi = dyb + st * D_STAGE + kg_s * (32 * 64);
+            const char* const a_hi = lds + (wn >> 1) * A_SUB;
             const int row_own = __builtin_amdgcn_readfirstlane(slot0 * 16 + p.U0 + 32 * kg_s);
             const int ring = p.RB * 16;
             u32x4 dh[4], dl[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                dh[c] = frag(dy_hi + (c >> 1) * D_SUB + (c & 1) * 32);
-                if constexpr (NPL == 2) dl[c] = frag(dy_hi + (2 + (c >> 1)) * D_SUB + (c & 1) * 32);
+                const char* const src = dy_hi + (c >> 1) * D_SUB + dy_off[c & 1];
+                dh[c] = frag2(src, src + 256);
+                if constexpr (NPL == 2) dl[c] = frag2(src + 2 * D_SUB, src + 2 * D_SUB + 256);
             }
             if (do_colsum) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) { accb[c] = mma(dh[c], ones, accb[c]); if constexpr (NPL == 2) accb[c] = mma(dl[c], ones, accb[c]); }
             }
-            auto tap_src = [&](int t) -> const char* {
-                int rt = row_own + (t / 3 - 1) * p.W + (t % 3 - 1);
-                rt = rt < 0 ? rt + ring : rt;
-                rt = rt >= ring ? rt - ring : rt;
-                return a_hi + __builtin_amdgcn_readfirstlane(rt * 64);
-            };
+            // the centre-column taps of the three kernel rows start at ring rows c_ky = row_own + (ky - 1) W, taken into (0, ring]: with the
+            // +-1 of kx a fragment then spans rows c - 1 .. c + 32 <= ring + 32, inside the ring or its three mirrored slots (row_own >= U0 > W,
+            // so c is positive before the wrap) — three scalar wraps per step instead of nine
+            const char* cky[3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                int c = row_own + (ky - 1) * p.W;
+                c = c > ring ? c - ring : c;
+                cky[ky] = a_hi + __builtin_amdgcn_readfirstlane(c * 64);
+            }
             u32x4 fh[3], fl[3];                        // fragment sets of taps t, t + 1, t + 2
-            fh[0] = frag(tap_src(0)); if constexpr (NPL == 2) fl[0] = frag(tap_src(0) + 2 * A_SUB);
-            fh[1] = frag(tap_src(1)); if constexpr (NPL == 2) fl[1] = frag(tap_src(1) + 2 * A_SUB);
+            auto load_tap = [&](int t) {
+                const char* const b = cky[t / 3];
+                const char* const s0 = b + a_rd[t % 3][0];
+                const char* const s1 = b + a_rd[t % 3][1];
+                fh[t % 3] = frag2(s0, s1);
+                if constexpr (NPL == 2) fl[t % 3] = frag2(s0 + 2 * A_SUB, s1 + 2 * A_SUB);
+            };
+            load_tap(0);
+            load_tap(1);
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int kx = t % 3, cur = t % 3;
-                if (t + 2 < 9) {
-                    const char* src = tap_src(t + 2);
-                    fh[(t + 2) % 3] = frag(src); if constexpr (NPL == 2) fl[(t + 2) % 3] = frag(src + 2 * A_SUB);
-                }
+                if (t + 2 < 9 && !(WG_ABL & 4)) load_tap(t + 2);
                 __builtin_amdgcn_sched_barrier(0);
                 if (kx == 0) { fh[cur][0] &= mL; if constexpr (NPL == 2) fl[cur][0] &= mL; }
                 if (kx == 2) { fh[cur][3] &= mR; if constexpr (NPL == 2) fl[cur][3] &= mR; }
@@ -240,8 +328,13 @@ __global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgGroup grp) {
             const int adv = B0n - B0;
             slot0 += adv; slot0 = slot0 >= p.RB ? slot0 - p.RB : slot0;
             B0 = B0n; img = img_n; q = q_n;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            st = st + 1 == NST ? 0 : st + 1;
+            // step s + 1 must have landed; with D = 2 the group issued at the top of THIS step (>= 4 DMAs per issuing wave) may stay in flight
+            if (!(WG_ABL & 8)) {
+            if (pre && p.D == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            }
         }
     }
 
@@ -286,8 +379,8 @@ __global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgGroup grp) {
 
     // ---- epilogue: D[row = co][col = ci] of (tap t, output sub-tile c): row 16 c + 4 k4 + r, column 16 wn + l15
     const long ldo = 9L * p.Cin;
-    float* const ob = p.out + (p.ksplit > 1 ? (long)ks * p.Cout * ldo : 0L) + (long)(co0 + 4 * k4) * ldo + ci0 + wn * 16 + l15;
-    const bool accum = p.ksplit == 1 && p.accumulate;
+    float* const ob = pd.out + (pd.ksplit > 1 ? (long)ks * p.Cout * ldo : 0L) + (long)(co0 + 4 * k4) * ldo + ci0 + wn * 16 + l15;
+    const bool accum = pd.ksplit == 1 && pd.accumulate;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -301,7 +394,7 @@ __global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgGroup grp) {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(p.colsum + co0 + 16 * c + 4 * k4 + r, accb[c][r]);
+            for (int r = 0; r < 4; ++r) atomicAdd(pd.colsum + co0 + 16 * c + 4 * k4 + r, accb[c][r]);
     }
 }
 
@@ -476,7 +569,12 @@ extern "C" int cdae_conv3x3_wgrad_win_group(const cdae_wg_item* items, int n, fl
             const int hb = it.W / 16 + 1;                      // 16 hb >= W + 1
             const int G = 16 * hb;                             // zero rows between images
             p.U0 = 16 * hb; p.period = p.HW + G;
-            p.RB = 8 + G / 16 + 2 * hb + 1;                    // live window (4 + 2 hb) + the largest prefetch (4 + G/16) + 1 spare
+            // ring = live window (4 + 2 hb) + D prefetch groups (the largest: 4 + G/16 blocks) + 1 spare; D = 2 where the image fits the 160 KB
+            const int npl = single ? 1 : 2;
+            auto lds_bytes = [&](int D) { return (size_t)2 * npl * ((4 + 2 * hb) + D * (4 + G / 16) + 1 + 3) * 1024 + (size_t)(D + 1) * 2 * npl * 4096; };
+            p.D = (cdae_tune(TUNE_WGWIN_DIST) >= 2 && lds_bytes(2) <= 160 * 1024) ? 2 : 1;
+            p.RB = (4 + 2 * hb) + p.D * (4 + G / 16) + 1;
+            p.swz = (cdae_tune(TUNE_WGWIN_SWZ) && it.W >= 16) ? 1 : 0;
             int sh = 0;
             while ((1u << sh) < (unsigned)p.period) ++sh;
             p.period_magic = (unsigned)(((unsigned long long)((1ull << sh) - (unsigned)p.period) << 32) / (unsigned)p.period) + 1u;
@@ -485,7 +583,8 @@ extern "C" int cdae_conv3x3_wgrad_win_group(const cdae_wg_item* items, int n, fl
             tiles[d] = (long)(it.Cin / 64) * (it.Cout / 64);
             slab[d] = (size_t)it.Cout * 9 * it.Cin * sizeof(float);
             tiles_all += tiles[d];
-            const size_t sm = (size_t)4 * (p.RB + 2) * 16 * 64 + 2 * 4 * 64 * 64;
+            size_t sm = lds_bytes(p.D);
+            if (sm < 65536) sm = 65536;                        // (the fold of the two K groups uses [4][64][64] floats of it)
             if (sm > smem) smem = sm;
             flops += 2.0 * it.Cout * 9.0 * it.Cin * (double)it.N * p.HW;
             if (it.dbias && !it.accumulate && hipMemsetAsync(it.dbias, 0, sizeof(float) * it.Cout, st) != hipSuccess) return cdae_fail("dbias memset failed");

@@ -497,9 +497,15 @@ int cdae_rep_loss_bwd(const float* mu, const float* var, const float* z_post, co
  *                                      else 64 x 64 tiles (at least 192 of those, or one launch per member)
  *   CDAE_TUNE_CONVWIN_NJ2        (0)   256 x 64 tiles of the forward window kernel (Cout % 64 == 0, unsplit K): 0 = where 256 x 128 tiles fill less
  *                                      than 0.6 of the block slots and the narrow ones clearly more (small-batch sampling at 64 x 64 / 32 x 32),
- *                                      1 = wherever they apply (tests), -1 = never */
+ *                                      1 = wherever they apply (tests), -1 = never
+ *   CDAE_TUNE_WGWIN_DIST         (2)   the window weight gradient (cdae_conv3x3_wgrad_win*) requests its operands this many 64-pixel steps ahead
+ *                                      (2 where the deeper ring fits the 160 KB of LDS — everything but two-plane operands at W = 64 — else 1);
+ *                                      1: one step ahead everywhere (the round-3..5 schedule; A/B, tests)
+ *   CDAE_TUNE_WGWIN_SWZ          (1)   its LDS image keeps the 32-byte halves of rows with bit 3 set swapped (W >= 16: conflict-free transpose
+ *                                      reads); 0: plain rows (A/B, tests).  Neither key changes a result bit. */
 enum { CDAE_TUNE_CONVWIN_MIN_TILES = 0, CDAE_TUNE_CONVWIN_SPLITK = 1, CDAE_TUNE_CONVWIN_NJ3 = 2, CDAE_TUNE_HEAD_MFMA = 3, CDAE_TUNE_ROWS16_MIN_M = 4,
-       CDAE_TUNE_ROWS16_RING = 5, CDAE_TUNE_CONVWIN_PAIR16 = 6, CDAE_TUNE_GN_BWD_FOLD2 = 7, CDAE_TUNE_GROUP_BIG_TILES = 8, CDAE_TUNE_CONVWIN_NJ2 = 9 };
+       CDAE_TUNE_ROWS16_RING = 5, CDAE_TUNE_CONVWIN_PAIR16 = 6, CDAE_TUNE_GN_BWD_FOLD2 = 7, CDAE_TUNE_GROUP_BIG_TILES = 8, CDAE_TUNE_CONVWIN_NJ2 = 9,
+       CDAE_TUNE_WGWIN_DIST = 10, CDAE_TUNE_WGWIN_SWZ = 11 };
 int cdae_tune_set(int key, int value);
 int cdae_tune_get(int key);       /* -1: unknown key */
 

@@ -1176,6 +1176,46 @@ def test_wgrad_window_group_launch(seed):
         assert (db.double() - ref_b).abs().max().item() < 3e-5 * ref_b.abs().max().item()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f16x3", "mixed16"])
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(5, 32, 32, 128, 64), (3, 64, 64, 64, 128), (9, 16, 16, 192, 128), (21, 8, 8, 128, 128), (4, 16, 32, 64, 64),
+                                            (2, 32, 16, 64, 64)])
+def test_wgrad_window_schedule_and_layout_are_bit_identical(N, H, W, Cin, Cout, mode):
+    """Round 6: the window weight gradient requests its operands two steps ahead (deeper ring, three dy stages, counted waits) and keeps the
+    32-byte halves of LDS rows with bit 3 set swapped (DMA-time permutation, conflict-free transpose reads).  Neither may change a bit:
+    every (distance, layout) combination against the round-5 form (distance 1, plain rows), on two operand planes and on one (`mixed16`),
+    shapes with image gaps inside a block's range, W = 8 (no swap), W = 64 (distance 1 on two planes: the LDS does not hold the ring),
+    non-square images both ways; and the default against fp64."""
+    from causaldiffae_amd._lib import check, lib, ptr, stream, splitk_ws, SPLITK_BYTES, precision_scope, tune_scope
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(77)
+    a = torch.randn(N, H, W, Cin, device=dev, generator=g)
+    dy = torch.randn(N, H, W, Cout, device=dev, generator=g) * 1e-3
+    ap = torch.empty((2, N, H, W, Cin), dtype=torch.bfloat16, device=dev)
+    dp = torch.empty((2, N, H, W, Cout), dtype=torch.bfloat16, device=dev)
+    check(lib.cdae_split_bf16(ptr(a), ptr(ap[0]), ptr(ap[1]), a.numel(), stream()))
+    check(lib.cdae_split_bf16(ptr(dy), ptr(dp[0]), ptr(dp[1]), dy.numel(), stream()))
+    out = {}
+    with precision_scope(mode):
+        for dist, swz in ((1, 0), (2, 1), (2, 0), (1, 1)):
+            dw = torch.full((Cout, 3, 3, Cin), float("nan"), device=dev)
+            db = torch.full((Cout,), float("nan"), device=dev)
+            with tune_scope(wgwin_dist=dist, wgwin_swz=swz):
+                check(lib.cdae_conv3x3_wgrad_win(ptr(ap[0]), ptr(ap[1]), ptr(dp[0]), ptr(dp[1]), ptr(dw), ptr(db), N, H, W, Cin, Cout, 0,
+                                                 ptr(splitk_ws(torch.device(dev))), SPLITK_BYTES, stream()))
+            torch.cuda.synchronize()
+            out[(dist, swz)] = (dw, db)
+    base = out[(1, 0)]
+    for k, (dw, db) in out.items():
+        assert torch.equal(dw, base[0]), k
+        assert (db - base[1]).abs().max().item() <= 1e-5 * base[1].abs().max().item(), k      # (column sums arrive by atomicAdd: order of the blocks)
+    planes = 1 if mode == "mixed16" else 2
+    a_q = sum(ap[i].float() for i in range(planes)).permute(0, 3, 1, 2)
+    dy_q = sum(dp[i].float() for i in range(planes)).permute(0, 3, 1, 2)
+    ref_w, _ = _wgrad_ref(a_q, dy_q)
+    assert (out[(2, 1)][0].double() - ref_w).abs().max().item() < 3e-5 * ref_w.abs().max().item()
+
+
 def _wgrad_window_case(N, H, W, Cin, Cout, accumulate):
     from causaldiffae_amd._lib import check, lib, ptr, stream, splitk_ws, SPLITK_BYTES
     dev = "cuda:0"
