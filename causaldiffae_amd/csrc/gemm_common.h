@@ -71,11 +71,12 @@ __device__ __forceinline__ bool tap_offset(const GemmParams& p, const PixRow& r,
 // keeps the loads unconditional, back-to-back and un-waited until the LDS store after the MFMAs.
 static __device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // non-const: stays in the global address space (a constant-space pointer turns the select into flat loads)
 
-__device__ __forceinline__ float4 ld4_if(const float* /*unused*/, const float* p, bool ok) {
-    return ld4(ok ? p : g_zero16);
+// (zero: the caller's register copy of g_zero16 — see igemm_kernel)
+__device__ __forceinline__ float4 ld4_if(const float* zero, const float* p, bool ok) {
+    return ld4(ok ? p : zero);
 }
-__device__ __forceinline__ float ld1_if(const float* /*unused*/, const float* p, bool ok) {
-    return *(ok ? p : g_zero16);
+__device__ __forceinline__ float ld1_if(const float* zero, const float* p, bool ok) {
+    return *(ok ? p : zero);
 }
 
 // second output of an epilogue: v as f16 hi/lo planes

@@ -120,6 +120,10 @@ __global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_ke
     const int bo = bz / p.batch_inner, bi = bz - bo * p.batch_inner;
     const float* __restrict__ Ag = p.A + bo * p.a_bs0 + bi * p.a_bs1;
     const float* __restrict__ Bg = p.B + bo * p.b_bs0 + bi * p.b_bs1;
+    // the zero line of the guarded loads, held in a scalar register pair: as a plain global its address was re-loaded from the GOT inside
+    // the K loop (s_load_dwordx2 + s_waitcnt lgkmcnt(0), twice per iteration — the wait also drains the LDS fragment reads in flight)
+    const float* zp = g_zero16;
+    asm volatile("" : "+s"(zp));
 
     const int nk_total = (p.K + BK - 1) / BK;
     const int nk_per = (nk_total + p.ksplit - 1) / p.ksplit;
@@ -193,11 +197,11 @@ __global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_ke
             const int k = k0 + (tid & 7) * 4;
 #pragma unroll
             for (int q = 0; q < A_V4; ++q) {
-                if constexpr (!SCALAR) ra[q] = ld4_if(Ag, arowp[q] + k0 + ((p.A2 && k0 >= p.K1) ? adelta[q] : 0L), arow_ok[q] && k < p.K);
+                if constexpr (!SCALAR) ra[q] = ld4_if(zp, arowp[q] + k0 + ((p.A2 && k0 >= p.K1) ? adelta[q] : 0L), arow_ok[q] && k < p.K);
                 else {
                     float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = ld1_if(Ag, arowp[q] + k0 + e, arow_ok[q] && k + e < p.K);
+                    for (int e = 0; e < 4; ++e) v[e] = ld1_if(zp, arowp[q] + k0 + e, arow_ok[q] && k + e < p.K);
                     ra[q] = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_ke
                 }
             }
 #pragma unroll
-            for (int q = 0; q < A_V4; ++q) ra[q] = ld4_if(Ag, Ag + atap_off[q] + c0, atap_ok[q]);
+            for (int q = 0; q < A_V4; ++q) ra[q] = ld4_if(zp, Ag + atap_off[q] + c0, atap_ok[q]);
         } else if constexpr (AMODE == A_CONV_GEN) {
 #pragma unroll
             for (int q = 0; q < A_V4; ++q) {
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_ke
                     const int ky = tap / 3, kx = tap - ky * 3;
                     long off = 0;
                     const bool ok = arow[q].ok && k < p.K && tap_offset(p, arow[q], ky, kx, off);
-                    v[e] = ld1_if(Ag, Ag + off + (long)c * p.sc, ok);
+                    v[e] = ld1_if(zp, Ag + off + (long)c * p.sc, ok);
                 }
                 ra[q] = make_float4(v[0], v[1], v[2], v[3]);
             }
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_ke
                         const int kk = idx / (BM / 4), i4 = idx - kk * (BM / 4);
                         const int k = k0 + kk, i = m0 + i4 * 4;
                         const bool ok = k < p.K && i < p.M;
-                        const float2 raw = *reinterpret_cast<const float2*>(ok ? reinterpret_cast<const float*>(A16 + (long)k * p.lda + i) : g_zero16);
+                        const float2 raw = *reinterpret_cast<const float2*>(ok ? reinterpret_cast<const float*>(A16 + (long)k * p.lda + i) : zp);
                         ra[q] = make_float4(raw.x, raw.y, 0.f, 0.f);
                     }
                     return;
@@ -253,11 +257,11 @@ __global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_ke
                 const int kk = idx / (BM / 4), i4 = idx - kk * (BM / 4);
                 const int k = k0 + kk, i = m0 + i4 * 4;
                 const float* src = Ag + (long)(k < p.K ? k : 0) * p.lda + i;
-                if constexpr (!SCALAR) ra[q] = ld4_if(Ag, src, k < p.K && i < p.M);      // host guarantees M % 4 == 0
+                if constexpr (!SCALAR) ra[q] = ld4_if(zp, src, k < p.K && i < p.M);      // host guarantees M % 4 == 0
                 else {
                     float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = ld1_if(Ag, src + e, k < p.K && i + e < p.M);
+                    for (int e = 0; e < 4; ++e) v[e] = ld1_if(zp, src + e, k < p.K && i + e < p.M);
                     ra[q] = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
@@ -270,11 +274,11 @@ __global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_ke
             const int k = k0 + (tid & 7) * 4;
 #pragma unroll
             for (int q = 0; q < B_V4; ++q) {
-                if constexpr (!SCALAR) rb[q] = ld4_if(Bg, browp[q] + k0, brow_ok[q] && k < p.K);
+                if constexpr (!SCALAR) rb[q] = ld4_if(zp, browp[q] + k0, brow_ok[q] && k < p.K);
                 else {
                     float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = ld1_if(Bg, browp[q] + k0 + e, brow_ok[q] && k + e < p.K);
+                    for (int e = 0; e < 4; ++e) v[e] = ld1_if(zp, browp[q] + k0 + e, brow_ok[q] && k + e < p.K);
                     rb[q] = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_ke
                         const int kk = idx / (BN / 4), j4 = idx - kk * (BN / 4);
                         const int k = k0 + kk, j = n0 + j4 * 4;
                         const bool ok = k < p.K && j < p.N;
-                        const float2 raw = *reinterpret_cast<const float2*>(ok ? reinterpret_cast<const float*>(B16 + (long)k * p.ldb + j) : g_zero16);
+                        const float2 raw = *reinterpret_cast<const float2*>(ok ? reinterpret_cast<const float*>(B16 + (long)k * p.ldb + j) : zp);
                         rb[q] = make_float4(raw.x, raw.y, 0.f, 0.f);
                     }
                     return;
@@ -310,7 +314,7 @@ __global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_ke
                         const int ky = tap / 3, kx = tap - ky * 3;
                         long off = 0;
                         const bool ok = r.ok && j + e < p.N && tap_offset(p, r, ky, kx, off);
-                        v[e] = ld1_if(Bg, Bg + off + (long)c * p.sc, ok);
+                        v[e] = ld1_if(zp, Bg + off + (long)c * p.sc, ok);
                     }
                     rb[q] = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
@@ -331,11 +335,11 @@ __global__ __launch_bounds__(128 * WAVES_N, (GNS && DEEP) ? 4 : 1) void igemm_ke
                         const int ft = p.wflip ? 8 - tap : tap;
                         src = Bg + ((long)co * 9 + ft) * p.wCin + j;
                     }
-                    if constexpr (!SCALAR) rb[q] = ld4_if(Bg, src, kok && j < p.N);      // host guarantees N % 4 == 0
+                    if constexpr (!SCALAR) rb[q] = ld4_if(zp, src, kok && j < p.N);      // host guarantees N % 4 == 0
                     else {
                         float v[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = ld1_if(Bg, src + e, kok && j + e < p.N);
+                        for (int e = 0; e < 4; ++e) v[e] = ld1_if(zp, src + e, kok && j + e < p.N);
                         rb[q] = make_float4(v[0], v[1], v[2], v[3]);
                     }
                 }

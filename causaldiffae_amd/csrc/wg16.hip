@@ -66,6 +66,10 @@ __global__ __launch_bounds__(256, 2) void wg16_kernel(const Wg16Params p) {
 
     // this wave's share of a step: rows 8 wave .. + 7 of both operands, two DMAs each (4 rows x 16 pieces); LDS piece j of row r <- global
     // piece j ^ f(r), f(r) = 2 ((r & 3) | ((r >> 3 & 1) << 2))
+    // (the zero line's address in a scalar register pair: as a plain global it was re-loaded from the GOT twice per step, each load with an
+    //  lgkmcnt(0) wait that also drains the fragment reads in flight)
+    const void* zero_line = (const void*)g_zero_wg16;
+    asm volatile("" : "+s"(zero_line));
     auto fetch = [&](int s, int slot) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -73,8 +77,8 @@ __global__ __launch_bounds__(256, 2) void wg16_kernel(const Wg16Params p) {
             const long row = row0 + (long)s * 32 + r;
             const bool live = s < nsteps && row < row1;
             const int pc = (lane & 15) ^ (2 * ((r & 3) | (((r >> 3) & 1) << 2)));
-            const void* sy = live ? (const void*)(p.DY + row * p.lddy + n0 + pc * 8) : (const void*)g_zero_wg16;
-            const void* sx = live ? (const void*)(p.X + row * p.ldx + k0 + pc * 8) : (const void*)g_zero_wg16;
+            const void* sy = live ? (const void*)(p.DY + row * p.lddy + n0 + pc * 8) : zero_line;
+            const void* sx = live ? (const void*)(p.X + row * p.ldx + k0 + pc * 8) : zero_line;
             cdae_lds_dma16(sy, base + slot * WG_SLOT_B + (8 * wave + 4 * e) * 256);
             cdae_lds_dma16(sx, base + slot * WG_SLOT_B + WG_OP_B + (8 * wave + 4 * e) * 256);
         }

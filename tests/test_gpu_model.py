@@ -1586,7 +1586,9 @@ def test_rccl_data_parallel_path_with_one_rank():
     assert b["backend"] == "nccl" and b["active"] and not a["active"]
     assert b["collectives"] == 3 * b["buckets"] and b["buckets"] >= 5, b          # every bucket of every step went through RCCL
     assert np.allclose(a["losses"], b["losses"], rtol=1e-5, atol=0), (a["losses"], b["losses"])
-    assert abs(a["sumsq"] - b["sumsq"]) <= 1e-9 * a["sumsq"] and np.allclose(a["probe"], b["probe"], rtol=1e-5, atol=1e-7 * a["absmax"])
+    # (two processes: the bias gradients' atomicAdd order across K-split blocks is not fixed from run to run — last-bit differences, seen as
+    #  3e-9 of the squared norm; a dropped or doubled bucket would be 1e-3 and more)
+    assert abs(a["sumsq"] - b["sumsq"]) <= 1e-7 * a["sumsq"] and np.allclose(a["probe"], b["probe"], rtol=1e-5, atol=1e-7 * a["absmax"])
 
 
 @pytest.mark.gpu
