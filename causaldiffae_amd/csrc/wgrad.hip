@@ -23,12 +23,14 @@
 // the first input-channel tile.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include "cdae_internal.h"
 #include "../../include/cdae.h"
 
 // WG_ABL (dev ablations, timing only — results are wrong): 1 no operand DMAs after the prologue, 2 no MFMAs, 4 no activation fragment reads
-// after tap 1, 8 no end-of-step wait / barrier, 32 ONE step per block (what a block costs outside its step loop)
+// after tap 1, 8 no end-of-step wait / barrier, 32 ONE step per block (what a block costs outside its step loop),
+// 512 cycle stamps (s_memtime) around the prefetch code, the compute part and the end-of-step wait + barrier, printed per wave by blocks 0 and 37
 #ifndef WG_ABL
 #define WG_ABL 0
 #endif
@@ -129,11 +131,15 @@ __global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgGroup grp) {
     const int ci0 = cit * 64, co0 = cot * 64;
     const int s_begin = ks * pd.steps_per, s_end = min(p.steps, s_begin + pd.steps_per);
 
-    // ---- DMA roles.  Two planes: wave w stages sub-plane (P = (w >> 1) & 1, half = w & 1), K group 0 the activations, group 1 dy.
-    // One plane: waves 0, 1 the activation halves, waves 6, 7 the dy halves — one issuing wave on every SIMD (waves w and w + 4 share one).
+    // ---- DMA roles: the waves of K group 0 issue everything.  Cycle stamps (`WG_ABL=512`) show the two waves of a SIMD far apart: the
+    // K group 0 wave gets the matrix cores first and is through its taps in 1 150 (one plane) / 2 700 (two planes) cycles, its partner needs
+    // 1 650 / 4 300 — group 0 waited 500 / 1 500 cycles per step at the barrier, and what the dy-issuing waves of group 1 spent on DMAs was
+    // pure critical path.  Two planes: wave w < 4 stages sub-plane (P = w >> 1, half = w & 1) of BOTH operands; one plane: waves 0, 1 the
+    // activation halves, waves 2, 3 the dy halves.
     const int dH = wave & 1;
     const int dP = NPL == 2 ? (wave >> 1) & 1 : 0;
-    const bool dma_a = kg == 0 && (NPL == 2 || (wave & 2) == 0), dma_d = kg == 1 && (NPL == 2 || (wave & 2) != 0);
+    const bool dma_a = kg == 0 && (NPL == 2 || (wave & 2) == 0), dma_d = kg == 0 && (NPL == 2 || (wave & 2) != 0);
+    constexpr int WG_NMIN = NPL == 2 ? 8 : 4;          // DMAs of a prefetch group in an issuing wave, at least
     // Addresses are formed on the SCALAR unit: a DMA reads from (64-bit scalar base) + (32-bit lane offset); the lane offset — row
     // (lane >> 2) of the 16-row block, 16-byte chunk lane & 3 of the sub-plane's 64-byte row piece — never changes, the base walks.
     // (lanes 32..63 fill rows 8..15 of the block: their chunk is the one of the other 32-byte half, see (b) above)
@@ -225,6 +231,7 @@ __global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgGroup grp) {
     const unsigned mL = x0 == 0 ? 0xFFFF0000u : 0xFFFFFFFFu;           // tap kx = 0 reads x - 1: the pixel at x == 0 (element 0) contributes nothing
     const unsigned mR = x0 == p.W - 8 ? 0x0000FFFFu : 0xFFFFFFFFu;     // tap kx = 2 reads x + 1: the pixel at x == W - 1 (element 7)
 
+    unsigned long long st_pre = 0, st_cmp = 0, st_syn = 0;
     if (s_begin < s_end) {
         const int hb = p.U0 >> 4;
         int img = (s_begin * 64) / p.HW, q = s_begin * 64 - img * p.HW;
@@ -239,9 +246,21 @@ __global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgGroup grp) {
         }
         auto load_upto = [&](int blk_end) {
             if (dma_a) {
-                for (; next_blk < blk_end; ++next_blk) {
-                    issue_a(next_slot);
-                    next_slot = next_slot + 1 == p.RB ? 0 : next_slot + 1;
+                if (blk_end - next_blk == 4 && a_q + 64 <= p.HW && (unsigned)a_img < (unsigned)p.N && next_slot >= 3 && next_slot + 4 <= p.RB) {
+                    // the common group — four real blocks inside one image, no ring wrap, no mirrored slot — straight-line: the cursor walk
+                    // below was 1 030 cycles per step in the issuing wave (stamps), this is the four DMAs and their scalar adds
+                    const char* src = a_base + ((WG_ABL & 64) ? 0L : 2 * (long)a_off);
+                    const unsigned dst = a_dst + (unsigned)next_slot * 1024u;
+                    const long pitch16 = 32L * p.Cin;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { dma(src, a_voff, dst + j * 1024u); src += pitch16; }
+                    a_off += 64 * p.Cin; a_q += 64; next_blk += 4;
+                    next_slot = next_slot + 4 == p.RB ? 0 : next_slot + 4;
+                } else {
+                    for (; next_blk < blk_end; ++next_blk) {
+                        issue_a(next_slot);
+                        next_slot = next_slot + 1 == p.RB ? 0 : next_slot + 1;
+                    }
                 }
             }
         };
@@ -258,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgGroup grp) {
         prefetch_step();
         if (p.D == 2 && sP < s_end) {
             prefetch_step();
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");           // (a group is >= 4 DMAs in every issuing wave: step s_begin has landed)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WG_NMIN) : "memory");      // (a group is >= WG_NMIN DMAs in every issuing wave: step s_begin has landed)
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -271,7 +290,10 @@ __global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgGroup grp) {
             if (q_n == p.HW) { q_n = 0; ++img_n; }
             const int B0n = (img_n * p.period + q_n + p.U0) >> 4;
             const bool pre = sP < s_end && !(WG_ABL & 1);              // (uniform) a group younger than step s + 1's goes out now
+            unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+            if (WG_ABL & 512) ts0 = __builtin_readcyclecounter();
             if (pre) prefetch_step();
+            if (WG_ABL & 512) ts1 = __builtin_readcyclecounter();
             // ---- compute: this K group's 32 pixels of step s
             const char* const dy_hi = dyb + st * D_STAGE + kg_s * (32 * 64);
             const char* const a_hi = lds + (wn >> 1) * A_SUB;
@@ -330,12 +352,17 @@ __global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgGroup grp) {
             B0 = B0n; img = img_n; q = q_n;
             st = st + 1 == NST ? 0 : st + 1;
             // step s + 1 must have landed; with D = 2 the group issued at the top of THIS step (>= 4 DMAs per issuing wave) may stay in flight
+            if (WG_ABL & 512) ts2 = __builtin_readcyclecounter();
             if (!(WG_ABL & 8)) {
-            if (pre && p.D == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (pre && p.D == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WG_NMIN) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             }
+            if (WG_ABL & 512) { const unsigned long long ts3 = __builtin_readcyclecounter(); st_pre += ts1 - ts0; st_cmp += ts2 - ts1; st_syn += ts3 - ts2; }
         }
+        if ((WG_ABL & 512) && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 37))
+            printf("wgwin stamps block %d wave %d steps %d: prefetch %llu compute %llu wait+barrier %llu cycles per step\n", (int)blockIdx.x, wave, s_end - s_begin,
+                   st_pre / (s_end - s_begin), st_cmp / (s_end - s_begin), st_syn / (s_end - s_begin));
     }
 
     // fold the second K group into the first through LDS (the ring is dead now), three taps at a time: [wave & 3][48 + 16][64] floats
