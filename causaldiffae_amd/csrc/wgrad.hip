@@ -34,6 +34,10 @@
 #ifndef WG_ABL
 #define WG_ABL 0
 #endif
+// WG_NF (compile-time experiment): activation fragment sets in flight (3 = two taps ahead)
+#ifndef WG_NF
+#define WG_NF 3
+#endif
 
 namespace {
 
@@ -320,20 +324,21 @@ __global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgGroup grp) {
                 c = c > ring ? c - ring : c;
                 cky[ky] = a_hi + __builtin_amdgcn_readfirstlane(c * 64);
             }
-            u32x4 fh[3], fl[3];                        // fragment sets of taps t, t + 1, t + 2
+            constexpr int NF = WG_NF;                  // fragment sets in flight: taps t .. t + NF - 1
+            u32x4 fh[NF], fl[NF];
             auto load_tap = [&](int t) {
                 const char* const b = cky[t / 3];
                 const char* const s0 = b + a_rd[t % 3][0];
                 const char* const s1 = b + a_rd[t % 3][1];
-                fh[t % 3] = frag2(s0, s1);
-                if constexpr (NPL == 2) fl[t % 3] = frag2(s0 + 2 * A_SUB, s1 + 2 * A_SUB);
+                fh[t % NF] = frag2(s0, s1);
+                if constexpr (NPL == 2) fl[t % NF] = frag2(s0 + 2 * A_SUB, s1 + 2 * A_SUB);
             };
-            load_tap(0);
-            load_tap(1);
+#pragma unroll
+            for (int t = 0; t < NF - 1; ++t) load_tap(t);
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const int kx = t % 3, cur = t % 3;
-                if (t + 2 < 9 && !(WG_ABL & 4)) load_tap(t + 2);
+                const int kx = t % 3, cur = t % NF;
+                if (t + NF - 1 < 9 && !(WG_ABL & 4)) load_tap(t + NF - 1);
                 __builtin_amdgcn_sched_barrier(0);
                 if (kx == 0) { fh[cur][0] &= mL; if constexpr (NPL == 2) fl[cur][0] &= mL; }
                 if (kx == 2) { fh[cur][3] &= mR; if constexpr (NPL == 2) fl[cur][3] &= mR; }
