@@ -178,7 +178,10 @@ int cdae_wg16(const void* x, long ldx, const void* dy, long lddy, float* dw, lon
     const int T = p.tn * p.tk;
     // row splits: fill the 512 block slots (two blocks per CU), but keep the slabs (written once, read once by the finish) below half of
     // the operand bytes, a split at least four steps long, and inside the workspace
-    long splits = 8 * (512 / (8 * T) > 0 ? 512 / (8 * T) : 1);
+    // (measured, tools/wg16_slots.py: with at most four tiles one block per CU is enough to stream at the rate two reach — the slabs halve: 256 x 256
+    //  over 65 536 rows 31.0 -> 28.5 us, over 16 384 rows 25.3 -> 19.4; 768 x 256 — twelve tiles — needs both slots: 43.5 -> 60.6 us with one)
+    const int slots = T <= 4 ? cdae_tune(TUNE_WG16_SLOTS) / 2 : cdae_tune(TUNE_WG16_SLOTS);
+    long splits = 8 * (slots / (8 * T) > 0 ? slots / (8 * T) : 1);
     if (splits > 256) splits = 256;            // (one tile: the finish walks every slab per result element — 512 slabs cost it more than the second block per CU gains)
     const double in_bytes = 2.0 * M * (N + K), slab_bytes = 4.0 * N * K;
     while (splits > 8 && (2.0 * splits * slab_bytes > in_bytes || (long)M / splits < 128 || (size_t)(splits * slab_bytes) > ws_bytes)) splits -= 8;
