@@ -624,6 +624,7 @@ extern "C" int cdae_conv3x3_wgrad_win_group(const cdae_wg_item* items, int n, fl
         // S = steps per block.  Candidates: every steps_d / k; cost = rounds of 256 blocks x (S + ~12 steps of prologue / epilogue / fold) + what
         // the splits cost (slab round trip + finish launch, about a dozen steps' worth, once per launch that has any)
         static const int cfg_blocks = CDAE_DEV_INT("CDAE_WG_BLOCKS", 256);      // one block per CU fits (84-134 KB of LDS)
+        const int fixed = cdae_tune(TUNE_WGWIN_FIXED);
         int bestS = 1 << 30; long best_cost = -1;
         for (int d = 0; d < nd; ++d)
             for (int k = 1; k <= 256; ++k) {
@@ -637,7 +638,7 @@ extern "C" int cdae_conv3x3_wgrad_win_group(const cdae_wg_item* items, int n, fl
                 }
                 if (need > splitk_ws_bytes || (need && !splitk_ws)) continue;
                 const long rounds = (blocks + cfg_blocks - 1) / cfg_blocks;
-                const long cost = rounds * (S + 12) + (any ? 12 : 0);
+                const long cost = rounds * (S + fixed) + (any ? fixed : 0);
                 if (best_cost < 0 || cost < best_cost || (cost == best_cost && S > bestS)) { best_cost = cost; bestS = S; }
                 if (blocks > 4 * cfg_blocks) break;
             }
