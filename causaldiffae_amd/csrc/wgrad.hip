@@ -73,7 +73,7 @@ __device__ __forceinline__ int fdiv(int n, unsigned magic, int shift) {
     return (int)((__umulhi((unsigned)n, magic) + (unsigned)n) >> shift);
 }
 
-// LDS image: activations [plane 2][channel half 2][(RB + 3) * 16 rows][64 B], dy [stage 2][plane 2][channel half 2][64 rows][64 B].
+// LDS image: activations [plane NPL][channel half 2][(RB + 3) * 16 rows][64 B], dy [stage D + 1][plane NPL][channel half 2][64 rows][64 B].
 // 8 waves = two K groups of 4 (pixels 0..31 / 32..63 of every 64-pixel step; two waves per SIMD that cover each other's LDS latency);
 // the second group's accumulators are added to the first's through LDS at the end.  A wave owns ALL 64 output channels x 16 input
 // channels, and its group's 32 pixels of a step are ONE 32-deep step of v_mfma_f32_16x16x32_bf16 (the shape that holds its clock under
@@ -85,11 +85,13 @@ __device__ __forceinline__ int fdiv(int n, unsigned magic, int shift) {
 // NPL = 1 (the `mixed16` torso): one bf16 plane per operand, one MFMA per product; the lo sub-planes do not exist in LDS (the image is
 // [NPL][half 2] sub-planes per operand), which is what pays for the deeper ring there.
 //
-// Round 6: (a) PREFETCH DISTANCE.  With one MFMA per product a step is ~0.5 us of matrix work per SIMD while a DMA issued at the top of the
-// step needs 1-2 us to land (L2 hit rate 0.52): the vmcnt(0) at the end of every step was the kernel (MFMA busy 0.35).  The operands of step
-// s + 2 are now requested at the top of step s (ring deeper by one prefetch group, dy in three stages) and the wait at the end of a step
-// is COUNTED: only the youngest group (>= 4 DMAs per issuing wave) may stay in flight.  D = 1 (the old schedule) where the LDS does not
-// hold the deeper ring (two planes at W = 64).
+// Round 6 (docs/NOTES.md has the ablation table and the cycle stamps behind each point):
+// (0) SCALAR SIDE.  The step loop re-loaded descriptor fields from the kernel-argument segment (s_load + lgkmcnt(0), which also drains the
+// wave's LDS reads) — a third of the one-plane kernel.  Fields are pinned in SGPRs at entry, DMA addresses are scalar base + constant lane
+// offset with an incremental cursor, the regular four-block group is issued straight-line, the nine tap bases are three scalar wraps.
+// (a) PREFETCH DISTANCE.  The operands of step s + 2 are requested at the top of step s (ring deeper by one prefetch group, dy in three
+// stages) and the wait at the end of a step is COUNTED: only the youngest group (>= WG_NMIN DMAs per issuing wave) may stay in flight.
+// D = 1 (the old schedule) where the LDS does not hold the deeper ring (two planes at W = 64).  Worth 1-3 %: latency was not the limiter.
 // (b) BANK CONFLICTS.  ds_read_b64_tr_b16 is banked per 32-lane half over 256 bytes; a half reads rows r .. r + 3 and r + 8 .. r + 11 of a
 // 64-byte-pitch sub-plane, 32 bytes each: rows r and r + 8 are 512 bytes apart, i.e. on the same banks (2-way on every fragment read,
 // 1.65e9 conflict cycles per config [1] step).  Rows with bit 3 set now keep their two 32-byte halves SWAPPED — done by the DMA's
