@@ -242,7 +242,6 @@ __global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgGroup grp) {
         const int hb = p.U0 >> 4;
         int img = (s_begin * 64) / p.HW, q = s_begin * 64 - img * p.HW;
         int B0 = (img * p.period + q + p.U0) >> 4;
-        int slot0 = 0;
         int next_blk = B0 - hb, next_slot = 0;
         {   // the first block is virtual row img * period + q - U0: inside image img, or in the gap behind image img - 1 (q < U0)
             const int qq = q - p.U0;
@@ -270,14 +269,14 @@ __global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgGroup grp) {
                 }
             }
         };
-        // the prefetch cursor: step sP (image imgP, pixel qP) is the next one whose operands are requested, into dy stage stP
-        int sP = s_begin, imgP = img, qP = q, stP = 0;
+        // the prefetch cursor: step sP (pixel qP of its image) is the next one whose operands are requested, into dy stage stP
+        int sP = s_begin, qP = q, stP = 0;
+        int endP = B0 + 4 + hb;                                            // one past the last block the step at the cursor needs
         auto prefetch_step = [&]() {
-            const int B0p = (imgP * p.period + qP + p.U0) >> 4;
-            load_upto(B0p + 4 + hb);
+            load_upto(endP);
             if (dma_d) issue_d(sP * 64, stP);
-            ++sP; qP += 64;
-            if (qP == p.HW) { qP = 0; ++imgP; }
+            ++sP; qP += 64; endP += 4;
+            if (qP == p.HW) { qP = 0; endP += (p.period - p.HW) >> 4; }
             stP = stP + 1 == NST ? 0 : stP + 1;
         };
         prefetch_step();
@@ -290,11 +289,14 @@ __global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgGroup grp) {
         __syncthreads();
 
         const int kg_s = __builtin_amdgcn_readfirstlane(kg);
+        const int ring_rows = p.RB * 16, row_base = p.U0 + 32 * kg_s;      // this K group's 32 pixel rows of the block's first step start at ring row row_base
+        int row_cur = row_base;
         int st = 0;
         for (int s = s_begin; s < ((WG_ABL & 32) ? s_begin + 1 : s_end); ++s) {
-            int img_n = img, q_n = q + 64;
-            if (q_n == p.HW) { q_n = 0; ++img_n; }
-            const int B0n = (img_n * p.period + q_n + p.U0) >> 4;
+            // (the consumer's position advances by 64 rows per step, + the G zero rows behind an image's last step: kept as a row count)
+            q += 64;
+            int adv_rows = 64;
+            if (q == p.HW) { q = 0; adv_rows += p.period - p.HW; }
             const bool pre = sP < s_end && !(WG_ABL & 1);              // (uniform) a group younger than step s + 1's goes out now
             unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
             if (WG_ABL & 512) ts0 = __builtin_readcyclecounter();
@@ -303,8 +305,8 @@ __global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgGroup grp) {
             // ---- compute: this K group's 32 pixels of step s
             const char* const dy_hi = dyb + st * D_STAGE + kg_s * (32 * 64);
             const char* const a_hi = lds + (wn >> 1) * A_SUB;
-            const int row_own = __builtin_amdgcn_readfirstlane(slot0 * 16 + p.U0 + 32 * kg_s);
-            const int ring = p.RB * 16;
+            const int row_own = row_cur;
+            const int ring = ring_rows;
             u32x4 dh[4], dl[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -354,9 +356,7 @@ __global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgGroup grp) {
                 for (int c = 0; c < 4; ++c) acc[t][c] = mma(dh[c], fh[cur], acc[t][c]);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const int adv = B0n - B0;
-            slot0 += adv; slot0 = slot0 >= p.RB ? slot0 - p.RB : slot0;
-            B0 = B0n; img = img_n; q = q_n;
+            row_cur += adv_rows; row_cur = row_cur >= ring_rows + row_base ? row_cur - ring_rows : row_cur;
             st = st + 1 == NST ? 0 : st + 1;
             // step s + 1 must have landed; with D = 2 the group issued at the top of THIS step (>= 4 DMAs per issuing wave) may stay in flight
             if (WG_ABL & 512) ts2 = __builtin_readcyclecounter();

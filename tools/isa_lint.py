@@ -24,7 +24,7 @@ def lint(unit, extra=()):
     res = []
     starts = [i for i, l in enumerate(lines) if re.match(r"^_Z\w+:\s", l)]
     for s in starts:
-        e = next(k for k in range(s, len(lines)) if "s_endpgm" in lines[k])
+        e = next(k for k in range(s, len(lines)) if lines[k].startswith(".Lfunc_end"))      # (not the first s_endpgm: an early exit may be laid out in front of the loops)
         body = lines[s:e + 1]
         sym = lines[s].split(":")[0]
         name = subprocess.run(["c++filt", sym], capture_output=True, text=True).stdout.strip()
