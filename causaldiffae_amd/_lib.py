@@ -378,7 +378,7 @@ class precision_scope:
         return False
 
 
-TUNE_KEYS = {"convwin_min_tiles": 0, "convwin_splitk": 1, "convwin_nj3": 2, "head_mfma": 3, "rows16_min_m": 4, "rows16_ring": 5, "convwin_pair16": 6, "gn_bwd_fold2": 7, "group_big_tiles": 8, "convwin_nj2": 9, "wgwin_dist": 10, "wgwin_swz": 11, "wg16_slots": 12, "wgwin_fixed": 13}
+TUNE_KEYS = {"convwin_min_tiles": 0, "convwin_splitk": 1, "convwin_nj3": 2, "head_mfma": 3, "rows16_min_m": 4, "rows16_ring": 5, "convwin_pair16": 6, "gn_bwd_fold2": 7, "group_big_tiles": 8, "convwin_nj2": 9, "wgwin_dist": 10, "wgwin_swz": 11, "wg16_slots": 12, "wgwin_fixed": 13, "wgwin_co2": 14}
 
 
 class tune_scope:

@@ -132,7 +132,7 @@ int cdae_planes_dispatch(GemmParams& p, int big, int& ks, hipStream_t st);
 #endif
 
 // run-time dispatch thresholds (cdae_tune_set / cdae_tune_get in include/cdae.h; prof.hip holds the values)
-enum { TUNE_CONVWIN_MIN_TILES = 0, TUNE_CONVWIN_SPLITK = 1, TUNE_CONVWIN_NJ3 = 2, TUNE_HEAD_MFMA = 3, TUNE_ROWS16_MIN_M = 4, TUNE_ROWS16_RING = 5, TUNE_CONVWIN_PAIR16 = 6, TUNE_GN_BWD_FOLD2 = 7, TUNE_GROUP_BIG_TILES = 8, TUNE_CONVWIN_NJ2 = 9, TUNE_WGWIN_DIST = 10, TUNE_WGWIN_SWZ = 11, TUNE_WG16_SLOTS = 12, TUNE_WGWIN_FIXED = 13, TUNE_N = 14 };
+enum { TUNE_CONVWIN_MIN_TILES = 0, TUNE_CONVWIN_SPLITK = 1, TUNE_CONVWIN_NJ3 = 2, TUNE_HEAD_MFMA = 3, TUNE_ROWS16_MIN_M = 4, TUNE_ROWS16_RING = 5, TUNE_CONVWIN_PAIR16 = 6, TUNE_GN_BWD_FOLD2 = 7, TUNE_GROUP_BIG_TILES = 8, TUNE_CONVWIN_NJ2 = 9, TUNE_WGWIN_DIST = 10, TUNE_WGWIN_SWZ = 11, TUNE_WG16_SLOTS = 12, TUNE_WGWIN_FIXED = 13, TUNE_WGWIN_CO2 = 14, TUNE_N = 15 };
 int cdae_tune(int key);
 
 // rows16.hip: the streaming GEMM of the 16-bit torso's 1 x 1 convs / linears (cdae_gemm16_ps dispatches)

@@ -43,7 +43,7 @@ int* cdae_range_flag_ptr() {
 
 namespace {
 // defaults = the measured optimum on MI355X (dispatch table)
-int g_tune[TUNE_N] = {256, 1, 0, 1, 2048, 1, 1, 1, 384, 0, 2, 1, 512, 12};
+int g_tune[TUNE_N] = {256, 1, 0, 1, 2048, 1, 1, 1, 384, 0, 2, 1, 512, 12, 1};
 }
 int cdae_tune(int key) { return key >= 0 && key < TUNE_N ? g_tune[key] : 0; }
 

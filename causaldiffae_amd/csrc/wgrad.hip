@@ -99,8 +99,14 @@ __device__ __forceinline__ int fdiv(int n, unsigned magic, int shift) {
 // 64 banks for every start row.  The read side pays no per-read arithmetic for it: bit 3 of a lane's row depends only on the tap's
 // horizontal shift (the vertical one is a multiple of 16 rows for W >= 16), so each lane keeps six offsets (3 kx x 2 reads).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-template <int NPL = 2>
+// CO2 (one plane only): the block owns 128 output channels — the two wave groups split the OUTPUT CHANNELS (64 each) instead of the step's
+// pixels, every wave walks both 32-pixel halves of a step.  Per MFMA: half the activation DMAs, half the barriers and cursor work, no fold
+// of the second group through LDS at the end; dy comes in four 32-channel sub-planes per stage.
+template <int NPL = 2, bool CO2 = false>
 __global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgGroup grp) {
+    static_assert(!CO2 || NPL == 1, "the 128-channel block tile exists for one operand plane");
+    constexpr int NDH = CO2 ? 4 : 2;                   // 32-channel dy sub-planes per plane
+    constexpr int NPH = CO2 ? 2 : 1;                   // 32-pixel halves of a step a wave walks
     int di = 0;
     while (di + 1 < grp.nd && (int)blockIdx.x >= grp.start[di + 1]) ++di;           // (uniform: scalar compares on kernel arguments)
     const WgParams& pd = grp.d[di];
@@ -118,14 +124,14 @@ __global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgGroup grp) {
     const int RROWS = (p.RB + 3) * 16;                 // ring rows incl. the mirrors of slots 0, 1 and 2
     const int A_SUB = RROWS * 64;                      // bytes per (plane, half) sub-plane
     char* const dyb = lds + 2 * NPL * A_SUB;           // dy stages
-    constexpr int D_SUB = 64 * 64, D_STAGE = 2 * NPL * D_SUB;
+    constexpr int D_SUB = 64 * 64, D_STAGE = NDH * NPL * D_SUB;
     const int NST = p.D + 1;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, k4 = lane >> 4;
     const int wn = wave & 3;                           // wave tile: input channels 16 wn .. + 15, all 64 output channels
-    const int kg = wave >> 2;                          // K group: pixels 32 kg .. + 31 of every step
-    const int nci = p.Cin >> 6, nco = p.Cout >> 6;
+    const int kg = wave >> 2;                          // wave group: pixels 32 kg .. + 31 of every step (CO2: output channels 64 kg .. + 63 of the block's 128)
+    const int nci = p.Cin >> 6, nco = CO2 ? p.Cout >> 7 : p.Cout >> 6;
     int b;
     {
         const unsigned G = gG, bb = blockIdx.x - gb0, q = G >> 3, r = G & 7, x = bb & 7;
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgGroup grp) {
     const int cit = b % nci; b /= nci;
     const int cot = b % nco; b /= nco;
     const int ks = b;
-    const int ci0 = cit * 64, co0 = cot * 64;
+    const int ci0 = cit * 64, co0 = cot * (CO2 ? 128 : 64);
     const int s_begin = ks * pd.steps_per, s_end = min(p.steps, s_begin + pd.steps_per);
 
     // ---- DMA roles: the waves of K group 0 issue everything.  Cycle stamps (`WG_ABL=512`) show the two waves of a SIMD far apart: the
@@ -144,14 +150,15 @@ __global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgGroup grp) {
     // activation halves, waves 2, 3 the dy halves.
     const int dH = wave & 1;
     const int dP = NPL == 2 ? (wave >> 1) & 1 : 0;
-    const bool dma_a = kg == 0 && (NPL == 2 || (wave & 2) == 0), dma_d = kg == 0 && (NPL == 2 || (wave & 2) != 0);
+    const bool dma_a = kg == 0 && (NPL == 2 || (wave & 2) == 0), dma_d = kg == 0 && (NPL == 2 || CO2 || (wave & 2) != 0);
+    const int dQ = CO2 ? (wave & 3) : dH;                // dy sub-plane this wave stages (CO2: the four 32-channel quarters of the block's 128, one per wave of group 0)
     constexpr int WG_NMIN = NPL == 2 ? 8 : 4;          // DMAs of a prefetch group in an issuing wave, at least
     // Addresses are formed on the SCALAR unit: a DMA reads from (64-bit scalar base) + (32-bit lane offset); the lane offset — row
     // (lane >> 2) of the 16-row block, 16-byte chunk lane & 3 of the sub-plane's 64-byte row piece — never changes, the base walks.
     // (lanes 32..63 fill rows 8..15 of the block: their chunk is the one of the other 32-byte half, see (b) above)
     const int swz_a = (p.swz && (lane & 32)) ? 2 : 0, swz_d = (lane & 32) ? 2 : 0;
     const unsigned a_voff = (unsigned)(((lane >> 2) * p.Cin + ci0 + dH * 32 + ((lane & 3) ^ swz_a) * 8) * 2);
-    const unsigned d_voff = (unsigned)(((lane >> 2) * p.Cout + co0 + dH * 32 + ((lane & 3) ^ swz_d) * 8) * 2);
+    const unsigned d_voff = (unsigned)(((lane >> 2) * p.Cout + co0 + dQ * 32 + ((lane & 3) ^ swz_d) * 8) * 2);
     unsigned v_zero = 0;
     asm volatile("" : "+v"(v_zero));
     const char* const a_base = reinterpret_cast<const char*>(dP ? pd.a_lo : pd.a_hi);
@@ -181,7 +188,7 @@ __global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgGroup grp) {
         if (a_q == p.period) { a_q = 0; ++a_img; }
     };
     auto issue_d = [&](int pix0, int stage) {
-        const unsigned dst = (unsigned)((dyb - lds) + stage * D_STAGE + (dP * 2 + dH) * D_SUB);
+        const unsigned dst = (unsigned)((dyb - lds) + stage * D_STAGE + (dP * NDH + dQ) * D_SUB);
         const char* src = d_base + 2 * (long)pix0 * p.Cout;
         const long pitch16 = 32L * p.Cout;
 #pragma unroll
@@ -233,9 +240,14 @@ __global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgGroup grp) {
     u32x4 ones; ones[0] = ones[1] = ones[2] = ones[3] = 0x3F803F80u;       // bf16 1.0 pairs
 
     // horizontal padding: this lane's 8 pixels start at x0 = (32 kg + 8 k4) mod W (steps start on multiples of 64 and W divides 64)
-    const int x0 = (32 * kg + 8 * k4) & (p.W - 1);
-    const unsigned mL = x0 == 0 ? 0xFFFF0000u : 0xFFFFFFFFu;           // tap kx = 0 reads x - 1: the pixel at x == 0 (element 0) contributes nothing
-    const unsigned mR = x0 == p.W - 8 ? 0x0000FFFFu : 0xFFFFFFFFu;     // tap kx = 2 reads x + 1: the pixel at x == W - 1 (element 7)
+    // (CO2: a wave walks both 32-pixel halves, one mask pair per half)
+    unsigned mLp[NPH], mRp[NPH];
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph) {
+        const int x0 = (32 * (CO2 ? ph : kg) + 8 * k4) & (p.W - 1);
+        mLp[ph] = x0 == 0 ? 0xFFFF0000u : 0xFFFFFFFFu;             // tap kx = 0 reads x - 1: the pixel at x == 0 (element 0) contributes nothing
+        mRp[ph] = x0 == p.W - 8 ? 0x0000FFFFu : 0xFFFFFFFFu;       // tap kx = 2 reads x + 1: the pixel at x == W - 1 (element 7)
+    }
 
     unsigned long long st_pre = 0, st_cmp = 0, st_syn = 0;
     if (s_begin < s_end) {
@@ -289,7 +301,7 @@ __global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgGroup grp) {
         __syncthreads();
 
         const int kg_s = __builtin_amdgcn_readfirstlane(kg);
-        const int ring_rows = p.RB * 16, row_base = p.U0 + 32 * kg_s;      // this K group's 32 pixel rows of the block's first step start at ring row row_base
+        const int ring_rows = p.RB * 16, row_base = p.U0 + (CO2 ? 0 : 32 * kg_s);      // this K group's 32 pixel rows of the block's first step start at ring row row_base
         int row_cur = row_base;
         int st = 0;
         for (int s = s_begin; s < ((WG_ABL & 32) ? s_begin + 1 : s_end); ++s) {
@@ -302,17 +314,20 @@ __global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgGroup grp) {
             if (WG_ABL & 512) ts0 = __builtin_readcyclecounter();
             if (pre) prefetch_step();
             if (WG_ABL & 512) ts1 = __builtin_readcyclecounter();
-            // ---- compute: this K group's 32 pixels of step s
-            const char* const dy_hi = dyb + st * D_STAGE + kg_s * (32 * 64);
+            // ---- compute: this wave group's 32 pixels of step s (CO2: both halves, one after the other, into the same accumulators)
+#pragma unroll
+            for (int ph = 0; ph < NPH; ++ph) {
+            const char* const dy_hi = dyb + st * D_STAGE + (CO2 ? ph : kg_s) * (32 * 64) + (CO2 ? 2 * kg_s : 0) * D_SUB;
             const char* const a_hi = lds + (wn >> 1) * A_SUB;
-            const int row_own = row_cur;
+            const int row_own = row_cur + 32 * ph;
+            const unsigned mL = mLp[ph], mR = mRp[ph];
             const int ring = ring_rows;
             u32x4 dh[4], dl[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const char* const src = dy_hi + (c >> 1) * D_SUB + dy_off[c & 1];
                 dh[c] = frag2(src, src + 256);
-                if constexpr (NPL == 2) dl[c] = frag2(src + 2 * D_SUB, src + 2 * D_SUB + 256);
+                if constexpr (NPL == 2) dl[c] = frag2(src + NDH * D_SUB, src + NDH * D_SUB + 256);
             }
             if (do_colsum) {
 #pragma unroll
@@ -356,6 +371,7 @@ __global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgGroup grp) {
                 for (int c = 0; c < 4; ++c) acc[t][c] = mma(dh[c], fh[cur], acc[t][c]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            }
             row_cur += adv_rows; row_cur = row_cur >= ring_rows + row_base ? row_cur - ring_rows : row_cur;
             st = st + 1 == NST ? 0 : st + 1;
             // step s + 1 must have landed; with D = 2 the group issued at the top of THIS step (>= 4 DMAs per issuing wave) may stay in flight
@@ -373,7 +389,8 @@ __global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgGroup grp) {
     }
 
     // fold the second K group into the first through LDS (the ring is dead now), three taps at a time: [wave & 3][48 + 16][64] floats
-    {
+    // (CO2: the groups own different output channels — nothing to fold, all eight waves store)
+    if constexpr (!CO2) {
         float* const xch = reinterpret_cast<float*>(lds) + (wave & 3) * (64 * 64) + lane;
 #pragma unroll
         for (int round = 0; round < 3; ++round) {
@@ -413,7 +430,8 @@ __global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgGroup grp) {
 
     // ---- epilogue: D[row = co][col = ci] of (tap t, output sub-tile c): row 16 c + 4 k4 + r, column 16 wn + l15
     const long ldo = 9L * p.Cin;
-    float* const ob = pd.out + (pd.ksplit > 1 ? (long)ks * p.Cout * ldo : 0L) + (long)(co0 + 4 * k4) * ldo + ci0 + wn * 16 + l15;
+    const int cow = co0 + (CO2 ? 64 * kg : 0);            // first output channel of this wave
+    float* const ob = pd.out + (pd.ksplit > 1 ? (long)ks * p.Cout * ldo : 0L) + (long)(cow + 4 * k4) * ldo + ci0 + wn * 16 + l15;
     const bool accum = pd.ksplit == 1 && pd.accumulate;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -428,7 +446,7 @@ __global__ __launch_bounds__(512, 2) void wgwin_kernel(const WgGroup grp) {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(pd.colsum + co0 + 16 * c + 4 * k4 + r, accb[c][r]);
+            for (int r = 0; r < 4; ++r) atomicAdd(pd.colsum + cow + 16 * c + 4 * k4 + r, accb[c][r]);
     }
 }
 
@@ -584,6 +602,12 @@ extern "C" int cdae_conv3x3_wgrad_win_group(const cdae_wg_item* items, int n, fl
     if (n <= 0) return 0;
     if (!items) return cdae_fail("conv3x3_wgrad_win_group: no items");
     const bool single = cdae_get_default_precision() == CDAE_PREC_MIXED16;      // one bf16 plane per operand in the reduced-precision mode
+    // 128-output-channel block tiles: every member of a launch must allow them.  Measured (tools/wgwin_co2.py): the grouped launches of a level
+    // gain 5-19 % (x7 128 -> 128 @ 32 x 32, batch 256: 574 -> 500 us; x7 256 -> 256 @ 16 x 16: 608 -> 493), a lone conv mostly loses (half the tiles:
+    // twice the splits) — tune key 1 = launches of two or more members, 2 = every launch (tests), 0 = never
+    const int co2_mode = cdae_tune(TUNE_WGWIN_CO2);
+    bool co2_all = single && (co2_mode >= 2 || (co2_mode == 1 && n >= 2));
+    for (int i = 0; i < n && co2_all; ++i) co2_all = items[i].Cout % 128 == 0;
     for (int i0 = 0; i0 < n; i0 += WG_MAXD) {
         const int nd = n - i0 < WG_MAXD ? n - i0 : WG_MAXD;
         WgGroup g;
@@ -605,7 +629,7 @@ extern "C" int cdae_conv3x3_wgrad_win_group(const cdae_wg_item* items, int n, fl
             p.U0 = 16 * hb; p.period = p.HW + G;
             // ring = live window (4 + 2 hb) + D prefetch groups (the largest: 4 + G/16 blocks) + 1 spare; D = 2 where the image fits the 160 KB
             const int npl = single ? 1 : 2;
-            auto lds_bytes = [&](int D) { return (size_t)2 * npl * ((4 + 2 * hb) + D * (4 + G / 16) + 1 + 3) * 1024 + (size_t)(D + 1) * 2 * npl * 4096; };
+            auto lds_bytes = [&](int D) { return (size_t)2 * npl * ((4 + 2 * hb) + D * (4 + G / 16) + 1 + 3) * 1024 + (size_t)(D + 1) * (co2_all ? 4 : 2) * npl * 4096; };
             p.D = (cdae_tune(TUNE_WGWIN_DIST) >= 2 && lds_bytes(2) <= 160 * 1024) ? 2 : 1;
             p.RB = (4 + 2 * hb) + p.D * (4 + G / 16) + 1;
             p.swz = (cdae_tune(TUNE_WGWIN_SWZ) && it.W >= 16) ? 1 : 0;
@@ -614,7 +638,7 @@ extern "C" int cdae_conv3x3_wgrad_win_group(const cdae_wg_item* items, int n, fl
             p.period_magic = (unsigned)(((unsigned long long)((1ull << sh) - (unsigned)p.period) << 32) / (unsigned)p.period) + 1u;
             p.period_shift = sh;
             p.accumulate = it.accumulate; p.colsum = it.dbias;
-            tiles[d] = (long)(it.Cin / 64) * (it.Cout / 64);
+            tiles[d] = (long)(it.Cin / 64) * (it.Cout / (co2_all ? 128 : 64));
             slab[d] = (size_t)it.Cout * 9 * it.Cin * sizeof(float);
             tiles_all += tiles[d];
             size_t sm = lds_bytes(p.D);
@@ -663,6 +687,7 @@ extern "C" int cdae_conv3x3_wgrad_win_group(const cdae_wg_item* items, int n, fl
         static size_t attr_bytes = 0;
         if (smem > attr_bytes) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgwin_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&wgwin_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(&wgwin_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
                 return cdae_fail("hipFuncSetAttribute(max dynamic LDS) failed");
             attr_bytes = smem;
@@ -672,10 +697,11 @@ extern "C" int cdae_conv3x3_wgrad_win_group(const cdae_wg_item* items, int n, fl
             char tag[128];
             const WgParams& p = g.d[0];
             snprintf(tag, sizeof(tag), "wgwin x%d %d->%d @%dx%d n=%d tiles=%ld blocks=%d S=%d ks0=%d planes=%d", nd, p.Cin, p.Cout, p.HW / p.W, p.W, p.N, tiles_all, nblk, bestS,
-                     p.ksplit, single ? 1 : 2);
+                     p.ksplit, co2_all ? 128 : single ? 1 : 2);
             cdae_prof_tag(tag);
         }
-        if (single) hipLaunchKernelGGL((wgwin_kernel<1>), dim3((unsigned)nblk), dim3(512), smem, st, g);
+        if (co2_all) hipLaunchKernelGGL((wgwin_kernel<1, true>), dim3((unsigned)nblk), dim3(512), smem, st, g);
+        else if (single) hipLaunchKernelGGL((wgwin_kernel<1>), dim3((unsigned)nblk), dim3(512), smem, st, g);
         else hipLaunchKernelGGL((wgwin_kernel<2>), dim3((unsigned)nblk), dim3(512), smem, st, g);
         int rc = hipGetLastError() == hipSuccess ? 0 : cdae_fail("wgwin_kernel launch failed");
         for (int d = 0; d < nd && rc == 0; ++d) {

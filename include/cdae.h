@@ -505,11 +505,14 @@ int cdae_rep_loss_bwd(const float* mu, const float* var, const float* z_post, co
  *                                      reads); 0: plain rows (A/B, tests).  Neither key changes a result bit.
  *   CDAE_TUNE_WGWIN_FIXED        (12)  what a block of the window weight gradient costs outside its step loop, in 64-pixel steps (prologue, fold, epilogue):
  *                                      the split search of a grouped launch minimises rounds x (steps per block + this)
+ *   CDAE_TUNE_WGWIN_CO2          (1)   one-plane window weight gradient on 128-output-channel block tiles (the wave groups split the output channels instead of
+ *                                      the step's pixels) where every member of a launch has Cout % 128 == 0: 1 = launches of two or more members,
+ *                                      2 = every launch (tests), 0 = never
  *   CDAE_TUNE_WG16_SLOTS         (512) cdae_linear_wgrad_io's streaming kernel (wg16.hip) splits its rows until tiles x splits reach this many blocks
  *                                      (two block slots per CU = 512; half of it when dW has at most four tiles); fewer blocks = fewer, larger slabs for the finish */
 enum { CDAE_TUNE_CONVWIN_MIN_TILES = 0, CDAE_TUNE_CONVWIN_SPLITK = 1, CDAE_TUNE_CONVWIN_NJ3 = 2, CDAE_TUNE_HEAD_MFMA = 3, CDAE_TUNE_ROWS16_MIN_M = 4,
        CDAE_TUNE_ROWS16_RING = 5, CDAE_TUNE_CONVWIN_PAIR16 = 6, CDAE_TUNE_GN_BWD_FOLD2 = 7, CDAE_TUNE_GROUP_BIG_TILES = 8, CDAE_TUNE_CONVWIN_NJ2 = 9,
-       CDAE_TUNE_WGWIN_DIST = 10, CDAE_TUNE_WGWIN_SWZ = 11, CDAE_TUNE_WG16_SLOTS = 12, CDAE_TUNE_WGWIN_FIXED = 13 };
+       CDAE_TUNE_WGWIN_DIST = 10, CDAE_TUNE_WGWIN_SWZ = 11, CDAE_TUNE_WG16_SLOTS = 12, CDAE_TUNE_WGWIN_FIXED = 13, CDAE_TUNE_WGWIN_CO2 = 14 };
 int cdae_tune_set(int key, int value);
 int cdae_tune_get(int key);       /* -1: unknown key */
 

@@ -1216,6 +1216,43 @@ def test_wgrad_window_schedule_and_layout_are_bit_identical(N, H, W, Cin, Cout, 
     assert (out[(2, 1)][0].double() - ref_w).abs().max().item() < 3e-5 * ref_w.abs().max().item()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,H,W,Cin,Cout,acc", [(5, 32, 32, 128, 128, 0), (3, 64, 64, 64, 256, 1), (9, 16, 16, 192, 384, 0), (21, 8, 8, 128, 128, 1), (4, 16, 32, 64, 128, 0),
+                                                (37, 8, 8, 64, 256, 0), (12, 16, 16, 256, 256, 0)])
+def test_wgrad_window_128_channel_block_tiles(N, H, W, Cin, Cout, acc):
+    """wgwin_kernel<1 plane, CO2> (tune key wgwin_co2): the block owns 128 output channels, its two wave groups split them instead of the step's
+    pixels (every wave walks both pixel halves; no fold through LDS; dy in four sub-planes per stage).  One bf16 plane per operand: against
+    autograd in fp64 on exactly those planes at the bar of the shipped kernel, against the shipped kernel itself (a different summation order:
+    1e-5), bias gradients included, with and without accumulation, split ranges that start inside images, W = 8 and W = 64."""
+    from causaldiffae_amd._lib import check, lib, ptr, stream, splitk_ws, SPLITK_BYTES, precision_scope, tune_scope
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(123)
+    a = torch.randn(N, H, W, Cin, device=dev, generator=g)
+    dy = torch.randn(N, H, W, Cout, device=dev, generator=g) * 1e-3
+    ap = torch.empty((2, N, H, W, Cin), dtype=torch.bfloat16, device=dev)
+    dp = torch.empty((2, N, H, W, Cout), dtype=torch.bfloat16, device=dev)
+    check(lib.cdae_split_bf16(ptr(a), ptr(ap[0]), ptr(ap[1]), a.numel(), stream()))
+    check(lib.cdae_split_bf16(ptr(dy), ptr(dp[0]), ptr(dp[1]), dy.numel(), stream()))
+    dw0 = torch.randn(Cout, 3, 3, Cin, device=dev, generator=g) * 1e-2
+    db0 = torch.randn(Cout, device=dev, generator=g) * 1e-2
+    out = {}
+    with precision_scope("mixed16"):
+        for co2 in (0, 1):
+            dw, db = dw0.clone(), db0.clone()
+            with tune_scope(wgwin_co2=2 * co2):
+                check(lib.cdae_conv3x3_wgrad_win(ptr(ap[0]), ptr(ap[1]), ptr(dp[0]), ptr(dp[1]), ptr(dw), ptr(db), N, H, W, Cin, Cout, acc,
+                                                 ptr(splitk_ws(torch.device(dev))), SPLITK_BYTES, stream()))
+            torch.cuda.synchronize()
+            out[co2] = (dw, db)
+    ref_w, ref_b = _wgrad_ref(ap[0].float().permute(0, 3, 1, 2), dp[0].float().permute(0, 3, 1, 2))
+    if acc:
+        ref_w, ref_b = ref_w + dw0.double(), ref_b + db0.double()
+    for co2 in (0, 1):
+        assert (out[co2][0].double() - ref_w).abs().max().item() < 3e-5 * ref_w.abs().max().item(), co2
+        assert (out[co2][1].double() - ref_b).abs().max().item() < 3e-5 * ref_b.abs().max().item(), co2
+    assert (out[1][0] - out[0][0]).abs().max().item() < 1e-5 * out[0][0].abs().max().item()
+
+
 def _wgrad_window_case(N, H, W, Cin, Cout, accumulate):
     from causaldiffae_amd._lib import check, lib, ptr, stream, splitk_ws, SPLITK_BYTES
     dev = "cuda:0"

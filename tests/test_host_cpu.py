@@ -268,14 +268,15 @@ def test_wgrad_window_kernel_step_loop_is_clean():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     kernels = [r for r in mod.lint("wgrad") if "wgwin_kernel" in r["kernel"]]
-    assert len(kernels) == 2          # hi / lo plane pairs, and the single-plane mixed16 form
+    assert len(kernels) == 3          # hi / lo plane pairs, the single-plane mixed16 form, and its 128-output-channel block tile
     for r in kernels:
-        single = "<1>" in r["kernel"]
+        single = "<1, " in r["kernel"]
+        co2 = "<1, true>" in r["kernel"]
         assert r["vgpr_spills"] == 0 and r["scratch_ops"] == 0, (r["kernel"], r["vgpr_spills"])
         steps = [lp for lp in r["loops"] if lp["barriers"] == 1]
         assert len(steps) == 1, (r["kernel"], r["loops"])
         lp = steps[0]
-        assert lp["mfmas"] == (36 + 4 if single else 108 + 8), (r["kernel"], lp)
+        assert lp["mfmas"] == (72 + 8 if co2 else 36 + 4 if single else 108 + 8), (r["kernel"], lp)
         assert not lp["vmcnt_waits"] and not lp["scratch"], (r["kernel"], lp)
 
 
